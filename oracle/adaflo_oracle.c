@@ -1,0 +1,1072 @@
+/* adaflo_oracle.c -- CPU restatement ("oracle") of adaflo's matrix-free operator path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (adaflo_amd/, the
+ * C-ABI library) may include, link or call this file.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+ *
+ * What it restates (reference = kronbichler/adaflo, paths relative to the
+ * reference root; deal.II itself is NOT available offline, so its FEEvaluation
+ * semantics are restated from the call sites -- see SURVEY.md Appendix A):
+ *   - NavierStokesMatrix::local_operation        source/navier_stokes_matrix.cc:601-916
+ *   - NavierStokesMatrix::vmult / residual / velocity_vmult / divergence_vmult_add /
+ *     pressure_poisson_vmult / pressure_mass_vmult / pressure_convdiff_vmult
+ *                                                source/navier_stokes_matrix.cc:221-483
+ *   - local_divergence / local_pressure_*        source/navier_stokes_matrix.cc:920-1140
+ *   - apply_pressure_average_projection          source/navier_stokes_matrix.cc:191-205
+ *   - level-set operators (advect/reinit/normal/curvature)
+ *                                                source/level_set_okz_*.cc (cited per function)
+ *
+ * Parity pin: the first nonlinear residual of tests/beltrami_3d (uniform 16^3,
+ * Q2/Q1) printed in tests/beltrami_3d.output:13 (2.590e+00, 6.423e-02) is
+ * reproduced by tests/test_oracle_golden.py through this file.  deal.II cannot
+ * be built here (needs cmake + Trilinos + p4est, none present): the reference
+ * build is "unbuildable", see DESIGN.md.
+ *
+ * Discretisation conventions:
+ *   mesh      : axis-aligned brick, ncell[d] cells of size h[d], origin[d].
+ *   FE_Q(k)   : nodal Lagrange basis on the k+1 Gauss-Lobatto points of [0,1].
+ *   FE_Q_iso_Q1(s): continuous piecewise linear hats on s sub-intervals.
+ *   numbering : nodes lexicographic (x fastest) over the whole brick,
+ *               dof = node*ncomp + comp (components interleaved per node).
+ *   cells     : lexicographic c = cx + ncx*(cy + ncy*cz); q-points in a cell
+ *               lexicographic q = qx + n*(qy + n*qz).
+ *   q-arrays  : [cell][q][...]  (canonical layout).
+ *
+ * The evaluation here is deliberately NAIVE (full tensor basis tables, no sum
+ * factorisation) so that it shares no structure with the HIP kernels.  A
+ * sum-factorised OpenMP version used as the timed CPU baseline lives in
+ * adaflo_oracle_fast.c and is itself checked against this file.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_MAX1D 12
+
+typedef struct
+{
+  int    dim;
+  int    ncell[3];
+  double h[3];
+  double origin[3];
+} orc_mesh;
+
+/* fields read at source/navier_stokes_matrix.cc:621-653 */
+typedef struct
+{
+  int    physical_type; /* 0 incompressible, 1 incompressible_stationary, 2 stokes */
+  int    linearization; /* 0 newton, 1 picard, 2 semi-implicit, 3 explicit, 4 projection */
+  double beta;          /* beta_convective_term_momentum_balance */
+  double tau_grad_div;
+  double density;
+  double viscosity;
+  double damping;       /* stored with flipped sign, source/parameters.cc:466-467 */
+  double density_diff;  /* only used by pressure_poisson: min(rho, rho+diff) */
+  double weight, weight_old, weight_old_old, tau1; /* TimeStepping scalars */
+  double extrap_old, extrap_old_old;               /* TimeStepping::extrapolate factors */
+} orc_ns_params;
+
+enum { ORC_OP_VMULT = 0, ORC_OP_RESIDUAL = 1, ORC_OP_VMULT_VELOCITY = 2 };
+enum { ORC_FE_Q = 0, ORC_FE_Q_ISO_Q1 = 1 };
+
+/* ------------------------------------------------------------------------- */
+/* 1D building blocks                                                         */
+/* ------------------------------------------------------------------------- */
+
+/* Legendre polynomial P_n and derivative on [-1,1] */
+static void legendre(int n, double x, double *p, double *dp)
+{
+  double p0 = 1., p1 = x;
+  if (n == 0) { *p = 1.; *dp = 0.; return; }
+  for (int j = 2; j <= n; ++j)
+    {
+      double pj = ((2. * j - 1.) * x * p1 - (j - 1.) * p0) / j;
+      p0 = p1; p1 = pj;
+    }
+  *p  = p1;
+  /* (1-x^2) P_n' = n (P_{n-1} - x P_n) */
+  if (fabs(fabs(x) - 1.) < 1e-14) /* P_n'(+-1) = (+-1)^(n-1) n(n+1)/2 */
+    *dp = 0.5 * n * (n + 1.) * ((x < 0 && (n % 2 == 0)) ? -1. : 1.);
+  else
+    *dp = n * (p0 - x * p1) / (1. - x * x);
+}
+
+/* n-point Gauss-Legendre on [0,1] (deal.II QGauss<1>(n)) */
+void orc_gauss_legendre(int n, double *x, double *w)
+{
+  for (int i = 0; i < n; ++i)
+    {
+      double z = -cos(M_PI * (i + 0.75) / (n + 0.5)), p, dp;
+      for (int it = 0; it < 100; ++it)
+        {
+          legendre(n, z, &p, &dp);
+          double dz = p / dp;
+          z -= dz;
+          if (fabs(dz) < 1e-16) break;
+        }
+      legendre(n, z, &p, &dp);
+      x[i] = 0.5 * (z + 1.);
+      w[i] = 1. / ((1. - z * z) * dp * dp); /* = (2/((1-z^2)dp^2))/2 */
+    }
+}
+
+/* n Gauss-Lobatto points on [0,1] (support points of FE_Q(QGaussLobatto<1>(n))) */
+void orc_gauss_lobatto(int n, double *x)
+{
+  const int k = n - 1;
+  x[0] = 0.; x[k] = 1.;
+  for (int i = 1; i < k; ++i)
+    {
+      double z = -cos(M_PI * i / k), p, dp;
+      for (int it = 0; it < 100; ++it)
+        {
+          legendre(k, z, &p, &dp);
+          /* f = P_k'(z); f' = P_k'' = (2 z P_k' - k(k+1) P_k)/(1-z^2) */
+          double ddp = (2. * z * dp - k * (k + 1.) * p) / (1. - z * z);
+          double dz  = dp / ddp;
+          z -= dz;
+          if (fabs(dz) < 1e-16) break;
+        }
+      x[i] = 0.5 * (z + 1.);
+    }
+  /* symmetrise */
+  for (int i = 0; i < n / 2; ++i)
+    {
+      double a = 0.5 * (x[i] + (1. - x[k - i]));
+      x[i] = a; x[k - i] = 1. - a;
+    }
+  if (n % 2) x[k / 2] = 0.5;
+}
+
+/* values S[q*ndof+i] = l_i(xq), D[q*ndof+i] = l_i'(xq) (d/dxhat on [0,1]) */
+void orc_shape_1d(int fe_type, int degree, int nq, const double *xq, double *S, double *D)
+{
+  const int nd = degree + 1;
+  if (fe_type == ORC_FE_Q)
+    {
+      double nodes[ORC_MAX1D];
+      if (degree == 0) nodes[0] = 0.5; else orc_gauss_lobatto(nd, nodes);
+      for (int q = 0; q < nq; ++q)
+        for (int i = 0; i < nd; ++i)
+          {
+            double v = 1., d = 0.;
+            for (int j = 0; j < nd; ++j)
+              if (j != i) v *= (xq[q] - nodes[j]) / (nodes[i] - nodes[j]);
+            for (int m = 0; m < nd; ++m)
+              if (m != i)
+                {
+                  double t = 1. / (nodes[i] - nodes[m]);
+                  for (int j = 0; j < nd; ++j)
+                    if (j != i && j != m) t *= (xq[q] - nodes[j]) / (nodes[i] - nodes[j]);
+                  d += t;
+                }
+            S[q * nd + i] = v;
+            D[q * nd + i] = d;
+          }
+    }
+  else
+    {
+      const int s = degree;
+      for (int q = 0; q < nq; ++q)
+        for (int i = 0; i < nd; ++i)
+          {
+            double t = xq[q] * s - i; /* hat centred at node i, width 1 in t */
+            double v = 0., d = 0.;
+            if (t > -1. && t <= 0.) { v = 1. + t; d = s; }
+            else if (t > 0. && t < 1.) { v = 1. - t; d = -s; }
+            S[q * nd + i] = v;
+            D[q * nd + i] = d;
+          }
+    }
+}
+
+/* quadrature used with a space: gauss(nq) or QIterated(QGauss<1>(2), s) */
+void orc_quadrature_1d(int iterated, int n, double *x, double *w)
+{
+  if (!iterated) { orc_gauss_legendre(n, x, w); return; }
+  double g[2], gw[2];
+  orc_gauss_legendre(2, g, gw);
+  for (int m = 0; m < n; ++m)
+    for (int j = 0; j < 2; ++j)
+      {
+        x[2 * m + j] = (m + g[j]) / n;
+        w[2 * m + j] = gw[j] / n;
+      }
+}
+
+/* ------------------------------------------------------------------------- */
+/* cell tables: N[q][i], dN[e][q][i] (reference derivatives), w[q]            */
+/* ------------------------------------------------------------------------- */
+typedef struct
+{
+  int     dim, nd1, nq1, ndc, nqc;
+  double *N, *dN[3], *w;
+} orc_table;
+
+static int ipow(int b, int e) { int r = 1; while (e-- > 0) r *= b; return r; }
+
+static void table_init(orc_table *t, int dim, int fe_type, int degree, int nq1, int iterated)
+{
+  double xq[2 * ORC_MAX1D], wq[2 * ORC_MAX1D], S[4 * ORC_MAX1D * ORC_MAX1D], D[4 * ORC_MAX1D * ORC_MAX1D];
+  const int nqpts = iterated ? 2 * nq1 : nq1; /* nq1 = subdivisions when iterated */
+  orc_quadrature_1d(iterated, nq1, xq, wq);
+  orc_shape_1d(fe_type, degree, nqpts, xq, S, D);
+  t->dim = dim; t->nd1 = degree + 1; t->nq1 = nqpts;
+  t->ndc = ipow(t->nd1, dim); t->nqc = ipow(nqpts, dim);
+  t->N = (double *)malloc(sizeof(double) * t->nqc * t->ndc);
+  for (int e = 0; e < 3; ++e)
+    t->dN[e] = e < dim ? (double *)malloc(sizeof(double) * t->nqc * t->ndc) : NULL;
+  t->w = (double *)malloc(sizeof(double) * t->nqc);
+  const int nd = t->nd1, nq = nqpts;
+  for (int q = 0; q < t->nqc; ++q)
+    {
+      int qq[3] = {q % nq, (q / nq) % nq, q / (nq * nq)};
+      double ww = 1.;
+      for (int e = 0; e < dim; ++e) ww *= wq[qq[e]];
+      t->w[q] = ww;
+      for (int i = 0; i < t->ndc; ++i)
+        {
+          int ii[3] = {i % nd, (i / nd) % nd, i / (nd * nd)};
+          double v = 1.;
+          for (int e = 0; e < dim; ++e) v *= S[qq[e] * nd + ii[e]];
+          t->N[q * t->ndc + i] = v;
+          for (int e = 0; e < dim; ++e)
+            {
+              double g = 1.;
+              for (int f = 0; f < dim; ++f)
+                g *= (f == e ? D : S)[qq[f] * nd + ii[f]];
+              t->dN[e][q * t->ndc + i] = g;
+            }
+        }
+    }
+}
+
+static void table_free(orc_table *t)
+{
+  free(t->N); free(t->w);
+  for (int e = 0; e < 3; ++e) if (t->dN[e]) free(t->dN[e]);
+}
+
+/* ------------------------------------------------------------------------- */
+/* mesh / numbering helpers                                                   */
+/* ------------------------------------------------------------------------- */
+static long n_cells(const orc_mesh *m)
+{
+  long n = 1;
+  for (int d = 0; d < m->dim; ++d) n *= m->ncell[d];
+  return n;
+}
+
+long orc_n_nodes(const orc_mesh *m, int degree)
+{
+  long n = 1;
+  for (int d = 0; d < m->dim; ++d) n *= (long)degree * m->ncell[d] + 1;
+  return n;
+}
+
+/* local node i (lexicographic in the cell) of cell c -> global node */
+static long cell_node(const orc_mesh *m, int degree, long c, int i)
+{
+  const int nd = degree + 1;
+  long cc[3] = {c % m->ncell[0], m->dim > 1 ? (c / m->ncell[0]) % m->ncell[1] : 0,
+                m->dim > 2 ? c / ((long)m->ncell[0] * m->ncell[1]) : 0};
+  int  ii[3] = {i % nd, (i / nd) % nd, i / (nd * nd)};
+  long g = 0, stride = 1;
+  for (int d = 0; d < m->dim; ++d)
+    {
+      g += (cc[d] * degree + ii[d]) * stride;
+      stride *= (long)degree * m->ncell[d] + 1;
+    }
+  return g;
+}
+
+static double cell_jxw(const orc_mesh *m)
+{
+  double v = 1.;
+  for (int d = 0; d < m->dim; ++d) v *= m->h[d];
+  return v;
+}
+
+/* read_dof_values (constraints resolved: constrained -> 0) or _plain (con == NULL) */
+static void gather(const orc_mesh *m, int degree, int ncomp, long c, int ndc,
+                   const double *vec, const uint8_t *con, double *loc /*[ncomp][ndc]*/)
+{
+  for (int i = 0; i < ndc; ++i)
+    {
+      long g = cell_node(m, degree, c, i);
+      for (int k = 0; k < ncomp; ++k)
+        {
+          long dof = g * ncomp + k;
+          loc[k * ndc + i] = (con && con[dof]) ? 0. : vec[dof];
+        }
+    }
+}
+
+/* distribute_local_to_global: scatter-add, constrained rows skipped */
+static void scatter_add(const orc_mesh *m, int degree, int ncomp, long c, int ndc,
+                        double *vec, const uint8_t *con, const double *loc)
+{
+  for (int i = 0; i < ndc; ++i)
+    {
+      long g = cell_node(m, degree, c, i);
+      for (int k = 0; k < ncomp; ++k)
+        {
+          long dof = g * ncomp + k;
+          if (!(con && con[dof])) vec[dof] += loc[k * ndc + i];
+        }
+    }
+}
+
+/* FEEvaluation::evaluate: values val[k][q], real-space gradients grad[k][e][q] */
+static void evaluate(const orc_table *t, const orc_mesh *m, int ncomp, const double *loc,
+                     double *val, double *grad)
+{
+  for (int k = 0; k < ncomp; ++k)
+    for (int q = 0; q < t->nqc; ++q)
+      {
+        double v = 0., g[3] = {0., 0., 0.};
+        for (int i = 0; i < t->ndc; ++i)
+          {
+            const double u = loc[k * t->ndc + i];
+            v += t->N[q * t->ndc + i] * u;
+            for (int e = 0; e < t->dim; ++e) g[e] += t->dN[e][q * t->ndc + i] * u;
+          }
+        if (val) val[k * t->nqc + q] = v;
+        if (grad)
+          for (int e = 0; e < t->dim; ++e)
+            grad[(k * 3 + e) * t->nqc + q] = g[e] / m->h[e]; /* J^{-T} for diag J */
+      }
+}
+
+/* FEEvaluation::integrate: loc[k][i] = sum_q (tv N_i + tg . grad N_i) JxW */
+static void integrate(const orc_table *t, const orc_mesh *m, int ncomp, const double *tv,
+                      const double *tg, double *loc)
+{
+  const double det = cell_jxw(m);
+  for (int k = 0; k < ncomp; ++k)
+    for (int i = 0; i < t->ndc; ++i)
+      {
+        double s = 0.;
+        for (int q = 0; q < t->nqc; ++q)
+          {
+            double a = 0.;
+            if (tv) a += tv[k * t->nqc + q] * t->N[q * t->ndc + i];
+            if (tg)
+              for (int e = 0; e < t->dim; ++e)
+                a += tg[(k * 3 + e) * t->nqc + q] * t->dN[e][q * t->ndc + i] / m->h[e];
+            s += a * t->w[q] * det;
+          }
+        loc[k * t->ndc + i] = s;
+      }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Navier-Stokes block operator: source/navier_stokes_matrix.cc:601-916       */
+/* ------------------------------------------------------------------------- */
+/* cell loop only (no zeroing of dst, no constrained-row fix-up), exactly what
+ * matrix_free->cell_loop(local_operation<...>) does.  lin: canonical layout
+ * [cell][q][d + d*d] = (u_lin[d], grad_lin[d][e] row-major).                  */
+int orc_ns_local_operation(const orc_mesh *m, int k, const orc_ns_params *P, int op,
+                           const double *src_u, const double *src_p, double *dst_u,
+                           double *dst_p, const uint8_t *con_u, const uint8_t *con_p,
+                           double *lin, const double *rho_q, const double *mu_q,
+                           const double *damp_q, const double *old_u, const double *oldold_u)
+{
+  const int dim = m->dim, p = k - 1, n = p + 2;
+  orc_table tu, tp;
+  table_init(&tu, dim, ORC_FE_Q, k, n, 0);
+  table_init(&tp, dim, ORC_FE_Q, p, n, 0);
+  const int nq = tu.nqc, nlin = dim + dim * dim;
+  double *lu = (double *)malloc(sizeof(double) * 3 * tu.ndc), *lp = (double *)malloc(sizeof(double) * tp.ndc);
+  double *lo = (double *)malloc(sizeof(double) * 3 * tu.ndc), *loo = (double *)malloc(sizeof(double) * 3 * tu.ndc);
+  double *vu = (double *)malloc(sizeof(double) * 3 * nq), *gu = (double *)malloc(sizeof(double) * 9 * nq);
+  double *vo = (double *)malloc(sizeof(double) * 3 * nq), *go = (double *)malloc(sizeof(double) * 9 * nq);
+  double *voo = (double *)malloc(sizeof(double) * 3 * nq), *goo = (double *)malloc(sizeof(double) * 9 * nq);
+  double *vp = (double *)malloc(sizeof(double) * nq), *tvp = (double *)malloc(sizeof(double) * nq);
+  double *tvu = (double *)malloc(sizeof(double) * 3 * nq), *tgu = (double *)malloc(sizeof(double) * 9 * nq);
+
+  /* :621-629 */
+  const double w0 = P->physical_type == 0 ? P->weight : 0.;
+  const double w1 = P->weight_old, w2 = P->weight_old_old, tau1 = P->tau1;
+  const int need_extrap = P->linearization == 4 || P->linearization == 2 || P->linearization == 3; /* :644-647 */
+  const double beta = P->beta;
+  const int stokes = P->physical_type == 2;
+  const int residual = op == ORC_OP_RESIDUAL;
+
+  const long nc = n_cells(m);
+  for (long c = 0; c < nc; ++c)
+    {
+      /* :662-671 */
+      gather(m, k, dim, c, tu.ndc, src_u, residual ? NULL : con_u, lu);
+      evaluate(&tu, m, dim, lu, vu, gu);
+      /* :673-686 */
+      if (residual && P->physical_type == 0)
+        {
+          gather(m, k, dim, c, tu.ndc, old_u, NULL, lo);
+          evaluate(&tu, m, dim, lo, vo, go);
+          gather(m, k, dim, c, tu.ndc, oldold_u, NULL, loo);
+          evaluate(&tu, m, dim, loo, voo, goo);
+        }
+      /* :688-697 */
+      if (op != ORC_OP_VMULT_VELOCITY)
+        {
+          gather(m, p, 1, c, tp.ndc, src_p, residual ? NULL : con_p, lp);
+          evaluate(&tp, m, 1, lp, vp, NULL);
+        }
+      for (int q = 0; q < nq; ++q)
+        {
+          double g[3][3] = {{0}}, val[3] = {0}, conv[3] = {0};
+          for (int d = 0; d < dim; ++d)
+            {
+              val[d] = vu[d * nq + q];
+              for (int e = 0; e < dim; ++e) g[d][e] = gu[(d * 3 + e) * nq + q];
+            }
+          double div = 0.;
+          for (int d = 0; d < dim; ++d) div += g[d][d]; /* :706 */
+          double *L = lin ? lin + ((size_t)c * nq + q) * nlin : NULL;
+          if (!stokes) /* :708 */
+            {
+              const double rho = rho_q ? rho_q[c * nq + q] : P->density; /* :711-713 */
+              for (int d = 0; d < dim; ++d) conv[d] = val[d] * w0;         /* :717 */
+              if (residual)
+                {
+                  if (P->physical_type != 1) /* :727-732 */
+                    for (int d = 0; d < dim; ++d)
+                      conv[d] += vo[d * nq + q] * w1 + voo[d * nq + q] * w2;
+                  if (need_extrap) /* :740-782 */
+                    {
+                      double og[3][3], ov[3], ediv = 0.;
+                      for (int d = 0; d < dim; ++d)
+                        {
+                          for (int e = 0; e < dim; ++e)
+                            og[d][e] = go[(d * 3 + e) * nq + q] * P->extrap_old +
+                                       goo[(d * 3 + e) * nq + q] * P->extrap_old_old;
+                          ov[d] = vo[d * nq + q] * P->extrap_old + voo[d * nq + q] * P->extrap_old_old;
+                        }
+                      for (int d = 0; d < dim; ++d) ediv += og[d][d];
+                      if (P->linearization == 3)
+                        for (int d = 0; d < dim; ++d)
+                          {
+                            double res = beta * ediv * ov[d];
+                            for (int e = 0; e < dim; ++e) res += ov[e] * og[d][e];
+                            conv[d] += tau1 * res;
+                          }
+                      else
+                        {
+                          for (int d = 0; d < dim; ++d)
+                            {
+                              double res = beta * ediv * val[d];
+                              for (int e = 0; e < dim; ++e) res += ov[e] * g[d][e];
+                              conv[d] += tau1 * res;
+                              L[d] = ov[d];
+                            }
+                          L[dim] = ediv; /* second[0][0] */
+                        }
+                    }
+                  else /* :783-799 */
+                    {
+                      for (int d = 0; d < dim; ++d)
+                        {
+                          double res = beta * div * val[d];
+                          for (int e = 0; e < dim; ++e) res += val[e] * g[d][e];
+                          conv[d] += tau1 * res;
+                          L[d] = val[d];
+                        }
+                      if (P->linearization == 0)
+                        for (int d = 0; d < dim; ++d)
+                          for (int e = 0; e < dim; ++e) L[dim + d * dim + e] = g[d][e];
+                      else
+                        L[dim] = div;
+                    }
+                }
+              else if (P->linearization == 0) /* :802-816 */
+                {
+                  double trl = 0.;
+                  for (int d = 0; d < dim; ++d) trl += L[dim + d * dim + d];
+                  const double f1 = beta * div, f2 = beta * trl;
+                  for (int d = 0; d < dim; ++d)
+                    {
+                      double res = f1 * L[d] + f2 * val[d];
+                      for (int e = 0; e < dim; ++e)
+                        res += L[e] * g[d][e] + val[e] * L[dim + d * dim + e];
+                      conv[d] += tau1 * res;
+                    }
+                }
+              else if (P->linearization != 3) /* :817-826 */
+                for (int d = 0; d < dim; ++d)
+                  {
+                    double res = beta * L[dim] * val[d];
+                    for (int e = 0; e < dim; ++e) res += L[e] * g[d][e];
+                    conv[d] += tau1 * res;
+                  }
+              const double damping = damp_q ? damp_q[c * nq + q] : P->damping; /* :831-835 */
+              for (int d = 0; d < dim; ++d)
+                {
+                  conv[d] *= rho;
+                  conv[d] -= damping * val[d];
+                  tvu[d * nq + q] = conv[d]; /* :837 */
+                }
+            }
+          /* :841-845 */
+          const double tmu = (mu_q ? mu_q[c * nq + q] : P->viscosity) * tau1;
+          double pres = 0.;
+          if (op != ORC_OP_VMULT_VELOCITY) /* :851-857 */
+            {
+              pres = vp[q];
+              tvp[q] = -div;
+            }
+          /* :859-881 symmetrise */
+          for (int d = 0; d < dim; ++d)
+            for (int e = d + 1; e < dim; ++e)
+              {
+                const double sym = tmu * (g[d][e] + g[e][d]);
+                g[d][e] = sym; g[e][d] = sym;
+              }
+          /* :883-890 */
+          for (int d = 0; d < dim; ++d)
+            {
+              g[d][d] = 2. * tmu * g[d][d] + P->tau_grad_div * div;
+              if (op != ORC_OP_VMULT_VELOCITY) g[d][d] -= pres;
+            }
+          for (int d = 0; d < dim; ++d)
+            for (int e = 0; e < dim; ++e) tgu[(d * 3 + e) * nq + q] = g[d][e]; /* :892 */
+        }
+      /* :897-907 */
+      integrate(&tu, m, dim, stokes ? NULL : tvu, tgu, lu);
+      scatter_add(m, k, dim, c, tu.ndc, dst_u, con_u, lu);
+      if (op != ORC_OP_VMULT_VELOCITY && P->linearization != 4)
+        {
+          integrate(&tp, m, 1, tvp, NULL, lp);
+          scatter_add(m, p, 1, c, tp.ndc, dst_p, con_p, lp);
+        }
+    }
+  free(lu); free(lp); free(lo); free(loo); free(vu); free(gu); free(vo); free(go);
+  free(voo); free(goo); free(vp); free(tvp); free(tvu); free(tgu);
+  table_free(&tu); table_free(&tp);
+  return 0;
+}
+
+/* local_pressure_mass_weight  source/navier_stokes_matrix.cc:1075-1095
+ * (quad_index_p: n = p+1 Gauss points) */
+int orc_ns_pressure_mass_weight(const orc_mesh *m, int k, double *dst_p, const uint8_t *con_p)
+{
+  const int p = k - 1;
+  orc_table tp;
+  table_init(&tp, m->dim, ORC_FE_Q, p, p + 1, 0);
+  double *one = (double *)malloc(sizeof(double) * tp.nqc), *lp = (double *)malloc(sizeof(double) * tp.ndc);
+  for (int q = 0; q < tp.nqc; ++q) one[q] = 1.;
+  const long nc = n_cells(m);
+  for (long c = 0; c < nc; ++c)
+    {
+      integrate(&tp, m, 1, one, NULL, lp);
+      scatter_add(m, p, 1, c, tp.ndc, dst_p, con_p, lp);
+    }
+  free(one); free(lp); table_free(&tp);
+  return 0;
+}
+
+/* apply_pressure_average_projection  source/navier_stokes_matrix.cc:191-205
+ * modes/weights as built in initialize() :117-168 (mode 0 only; mode 1 = DG0
+ * enrichment of augmented Taylor-Hood is out of scope).                       */
+void orc_ns_pressure_projection(long n_p, double *vec, const double *weights, const double *modes)
+{
+  double mw = 0., prod = 0.;
+  for (long i = 0; i < n_p; ++i) { mw += modes[i] * weights[i]; prod += weights[i] * vec[i]; }
+  const double f = prod / mw;
+  for (long i = 0; i < n_p; ++i) vec[i] -= f * modes[i];
+}
+
+static void constrained_rows(long n, double *dst, const double *src, const uint8_t *con, double sign)
+{
+  if (!con) return;
+  for (long i = 0; i < n; ++i) if (con[i]) dst[i] = sign * src[i];
+}
+
+/* NavierStokesMatrix::vmult  source/navier_stokes_matrix.cc:221-262
+ * weights/modes may be NULL (no pressure_average_fix).                        */
+int orc_ns_vmult(const orc_mesh *m, int k, const orc_ns_params *P, const double *src_u,
+                 const double *src_p, double *dst_u, double *dst_p, const uint8_t *con_u,
+                 const uint8_t *con_p, double *lin, const double *rho_q, const double *mu_q,
+                 const double *damp_q, const double *weights, const double *modes)
+{
+  const long nu = orc_n_nodes(m, k) * m->dim, np = orc_n_nodes(m, k - 1);
+  memset(dst_u, 0, sizeof(double) * nu);
+  memset(dst_p, 0, sizeof(double) * np);
+  orc_ns_local_operation(m, k, P, ORC_OP_VMULT, src_u, src_p, dst_u, dst_p, con_u, con_p, lin,
+                         rho_q, mu_q, damp_q, NULL, NULL);
+  constrained_rows(nu, dst_u, src_u, con_u, 1.);
+  constrained_rows(np, dst_p, src_p, con_p, -1.);
+  if (weights && P->linearization != 4 && P->physical_type != 1)
+    orc_ns_pressure_projection(np, dst_p, weights, modes);
+  return 0;
+}
+
+/* NavierStokesMatrix::residual  source/navier_stokes_matrix.cc:266-293
+ * system_rhs is NOT zeroed (the caller sets it to const_rhs,
+ * source/navier_stokes.cc:784); afterwards system_rhs = -system_rhs + user_rhs. */
+int orc_ns_residual(const orc_mesh *m, int k, const orc_ns_params *P, const double *src_u,
+                    const double *src_p, double *rhs_u, double *rhs_p, const double *user_u,
+                    const double *user_p, const uint8_t *con_u, const uint8_t *con_p,
+                    double *lin, const double *rho_q, const double *mu_q, const double *damp_q,
+                    const double *old_u, const double *oldold_u)
+{
+  const long nu = orc_n_nodes(m, k) * m->dim, np = orc_n_nodes(m, k - 1);
+  orc_ns_local_operation(m, k, P, ORC_OP_RESIDUAL, src_u, src_p, rhs_u, rhs_p, con_u, con_p, lin,
+                         rho_q, mu_q, damp_q, old_u, oldold_u);
+  for (long i = 0; i < nu; ++i) rhs_u[i] = -rhs_u[i] + (user_u ? user_u[i] : 0.);
+  for (long i = 0; i < np; ++i) rhs_p[i] = -rhs_p[i] + (user_p ? user_p[i] : 0.);
+  return 0;
+}
+
+/* velocity_vmult  source/navier_stokes_matrix.cc:337-382 */
+int orc_ns_velocity_vmult(const orc_mesh *m, int k, const orc_ns_params *P, const double *src_u,
+                          double *dst_u, const uint8_t *con_u, double *lin, const double *rho_q,
+                          const double *mu_q, const double *damp_q)
+{
+  const long nu = orc_n_nodes(m, k) * m->dim;
+  memset(dst_u, 0, sizeof(double) * nu);
+  orc_ns_local_operation(m, k, P, ORC_OP_VMULT_VELOCITY, src_u, NULL, dst_u, NULL, con_u, NULL,
+                         lin, rho_q, mu_q, damp_q, NULL, NULL);
+  constrained_rows(nu, dst_u, src_u, con_u, 1.);
+  return 0;
+}
+
+/* divergence_vmult_add + local_divergence  :300-332, :920-961 (dst NOT zeroed) */
+int orc_ns_divergence_vmult_add(const orc_mesh *m, int k, const orc_ns_params *P,
+                                const double *src_u, double *dst_p, const uint8_t *con_u,
+                                const uint8_t *con_p, const double *mu_q, int weight_by_viscosity)
+{
+  const int dim = m->dim, p = k - 1, n = p + 2;
+  orc_table tu, tp;
+  table_init(&tu, dim, ORC_FE_Q, k, n, 0);
+  table_init(&tp, dim, ORC_FE_Q, p, n, 0);
+  const int nq = tu.nqc;
+  double *lu = (double *)malloc(sizeof(double) * 3 * tu.ndc), *lp = (double *)malloc(sizeof(double) * tp.ndc);
+  double *gu = (double *)malloc(sizeof(double) * 9 * nq), *tvp = (double *)malloc(sizeof(double) * nq);
+  const long nc = n_cells(m);
+  for (long c = 0; c < nc; ++c)
+    {
+      gather(m, k, dim, c, tu.ndc, src_u, P->linearization == 4 ? NULL : con_u, lu);
+      evaluate(&tu, m, dim, lu, NULL, gu);
+      for (int q = 0; q < nq; ++q)
+        {
+          double div = 0.;
+          for (int d = 0; d < dim; ++d) div += gu[(d * 3 + d) * nq + q];
+          const double w = weight_by_viscosity ? (mu_q ? -mu_q[c * nq + q] : -P->viscosity) : -1.;
+          tvp[q] = w * div;
+        }
+      integrate(&tp, m, 1, tvp, NULL, lp);
+      scatter_add(m, p, 1, c, tp.ndc, dst_p, con_p, lp);
+    }
+  free(lu); free(lp); free(gu); free(tvp); table_free(&tu); table_free(&tp);
+  return 0;
+}
+
+/* pressure_poisson_vmult + local_pressure_poisson  :386-417, :965-1032 */
+int orc_ns_pressure_poisson_vmult(const orc_mesh *m, int k, const orc_ns_params *P,
+                                  const double *src_p, double *dst_p, const uint8_t *con_p,
+                                  const double *rho_q)
+{
+  const int dim = m->dim, p = k - 1;
+  const long np = orc_n_nodes(m, p);
+  memset(dst_p, 0, sizeof(double) * np);
+  const int var = rho_q && P->linearization != 4;
+  const int nq_u = ipow(p + 2, dim);
+  orc_table tp;
+  const int full = var && P->physical_type != 1;
+  table_init(&tp, dim, ORC_FE_Q, p, full ? p + 2 : p + 1, 0);
+  const int nq = tp.nqc;
+  double *lp = (double *)malloc(sizeof(double) * tp.ndc), *gp = (double *)malloc(sizeof(double) * 3 * nq);
+  const long nc = n_cells(m);
+  for (long c = 0; c < nc; ++c)
+    {
+      gather(m, p, 1, c, tp.ndc, src_p, con_p, lp);
+      evaluate(&tp, m, 1, lp, NULL, gp);
+      double coef_cell = 1.;
+      if (!full)
+        {
+          const double rho = var ? rho_q[c * nq_u + nq_u / 2] /* :1016 */
+                                 : fmin(P->density, P->density + P->density_diff);
+          coef_cell = P->physical_type == 1 ? 1. : 1. / (P->weight * rho);
+        }
+      for (int q = 0; q < nq; ++q)
+        {
+          const double cf = full ? 1. / (P->weight * rho_q[c * nq_u + q]) : coef_cell;
+          for (int e = 0; e < dim; ++e) gp[e * nq + q] *= cf;
+        }
+      integrate(&tp, m, 1, NULL, gp, lp);
+      scatter_add(m, p, 1, c, tp.ndc, dst_p, con_p, lp);
+    }
+  constrained_rows(np, dst_p, src_p, con_p, 1.);
+  free(lp); free(gp); table_free(&tp);
+  return 0;
+}
+
+/* pressure_mass_vmult + local_pressure_mass  :421-455, :1036-1071 (mode-1 projection n/a) */
+int orc_ns_pressure_mass_vmult(const orc_mesh *m, int k, const orc_ns_params *P,
+                               const double *src_p, double *dst_p, const uint8_t *con_p,
+                               const double *mu_q)
+{
+  const int dim = m->dim, p = k - 1;
+  const long np = orc_n_nodes(m, p);
+  memset(dst_p, 0, sizeof(double) * np);
+  const int nq_u = ipow(p + 2, dim);
+  orc_table tp;
+  table_init(&tp, dim, ORC_FE_Q, p, p + 1, 0);
+  const int nq = tp.nqc;
+  double *lp = (double *)malloc(sizeof(double) * tp.ndc), *vp = (double *)malloc(sizeof(double) * nq);
+  const long nc = n_cells(m);
+  for (long c = 0; c < nc; ++c)
+    {
+      gather(m, p, 1, c, tp.ndc, src_p, con_p, lp);
+      evaluate(&tp, m, 1, lp, vp, NULL);
+      const double mu = mu_q ? mu_q[c * nq_u + nq_u / 2] : P->viscosity; /* :1057 */
+      const double cf = (P->linearization == 4 || P->physical_type == 1) ? 1. : 1. / (mu + P->tau_grad_div);
+      for (int q = 0; q < nq; ++q) vp[q] *= cf;
+      integrate(&tp, m, 1, vp, NULL, lp);
+      scatter_add(m, p, 1, c, tp.ndc, dst_p, con_p, lp);
+    }
+  constrained_rows(np, dst_p, src_p, con_p, 1.);
+  free(lp); free(vp); table_free(&tp);
+  return 0;
+}
+
+/* pressure_convdiff_vmult + local_pressure_convdiff  :459-483, :1099-1140 */
+int orc_ns_pressure_convdiff_vmult(const orc_mesh *m, int k, const orc_ns_params *P,
+                                   const double *src_p, double *dst_p, const uint8_t *con_p,
+                                   const double *mu_q)
+{
+  const int dim = m->dim, p = k - 1;
+  const long np = orc_n_nodes(m, p);
+  memset(dst_p, 0, sizeof(double) * np);
+  orc_table tp;
+  table_init(&tp, dim, ORC_FE_Q, p, p + 2, 0);
+  const int nq = tp.nqc;
+  double *lp = (double *)malloc(sizeof(double) * tp.ndc), *gp = (double *)malloc(sizeof(double) * 3 * nq);
+  const long nc = n_cells(m);
+  for (long c = 0; c < nc; ++c)
+    {
+      gather(m, p, 1, c, tp.ndc, src_p, con_p, lp);
+      evaluate(&tp, m, 1, lp, NULL, gp);
+      const double mu = mu_q ? mu_q[c * nq + nq / 2] : P->viscosity; /* :1124 */
+      for (int q = 0; q < nq; ++q)
+        for (int e = 0; e < dim; ++e) gp[e * nq + q] *= mu;
+      integrate(&tp, m, 1, NULL, gp, lp);
+      scatter_add(m, p, 1, c, tp.ndc, dst_p, con_p, lp);
+    }
+  constrained_rows(np, dst_p, src_p, con_p, 1.);
+  free(lp); free(gp); table_free(&tp);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* helpers used by the tests: nodal interpolation points                      */
+/* ------------------------------------------------------------------------- */
+/* coordinates of all nodes of the FE_Q(degree) (or iso-Q1) space: xyz[node*dim+d] */
+void orc_node_coordinates(const orc_mesh *m, int fe_type, int degree, double *xyz)
+{
+  double nodes[ORC_MAX1D];
+  if (fe_type == ORC_FE_Q) orc_gauss_lobatto(degree + 1, nodes);
+  else for (int i = 0; i <= degree; ++i) nodes[i] = (double)i / degree;
+  long nn[3] = {1, 1, 1};
+  for (int d = 0; d < m->dim; ++d) nn[d] = (long)degree * m->ncell[d] + 1;
+  const long ntot = nn[0] * nn[1] * nn[2];
+  for (long g = 0; g < ntot; ++g)
+    {
+      long ii[3] = {g % nn[0], (g / nn[0]) % nn[1], g / (nn[0] * nn[1])};
+      for (int d = 0; d < m->dim; ++d)
+        {
+          long c = ii[d] / degree; int l = (int)(ii[d] % degree);
+          if (c == m->ncell[d]) { c -= 1; l = degree; }
+          xyz[g * m->dim + d] = m->origin[d] + (c + nodes[l]) * m->h[d];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Level-set operators (scalar FE_Q_iso_Q1(s), quadrature QIterated(QGauss(2),s)) */
+/* ------------------------------------------------------------------------- */
+typedef struct
+{
+  int    ls_degree;       /* s */
+  double epsilon_used;    /* two_phase_base.cc:290-291 */
+  double minimal_edge_length;
+  double time_step;       /* time_stepping.step_size() */
+  double weight;          /* time_stepping.weight() (advection) */
+  double cell_diameter;   /* uniform mesh: max_d h[d] (util.h:47-120) */
+  double epsilon;         /* parameters.epsilon (normal/curvature damping) */
+} orc_ls_params;
+
+/* reinitialization_vmult + local_reinitialize
+ * source/level_set_okz_reinitialization.cc:53-106, :193-231.
+ * normal_q: [cell][q][dim]; diag: preconditioner.get_vector() for constrained rows. */
+int orc_ls_reinit_vmult(const orc_mesh *m, const orc_ls_params *P, int diffuse_only,
+                        const double *src, double *dst, const uint8_t *con,
+                        const double *normal_q, const double *diag)
+{
+  const int dim = m->dim, s = P->ls_degree;
+  const long nn = orc_n_nodes(m, s);
+  memset(dst, 0, sizeof(double) * nn);
+  orc_table t;
+  table_init(&t, dim, ORC_FE_Q_ISO_Q1, s, s, 1);
+  const int nq = t.nqc;
+  /* :65-67 */
+  const double dtau_inv = fmax(0.95 / (1. / (dim * dim) * P->minimal_edge_length / s),
+                               1. / (5. * P->time_step));
+  const double diffusion = fmax(P->epsilon_used, P->cell_diameter / (double)s); /* :82-85 */
+  double *l = (double *)malloc(sizeof(double) * t.ndc), *v = (double *)malloc(sizeof(double) * nq);
+  double *g = (double *)malloc(sizeof(double) * 3 * nq);
+  const long nc = n_cells(m);
+  for (long c = 0; c < nc; ++c)
+    {
+      gather(m, s, 1, c, t.ndc, src, con, l);
+      evaluate(&t, m, 1, l, v, g);
+      for (int q = 0; q < nq; ++q)
+        {
+          v[q] *= dtau_inv;
+          if (!diffuse_only)
+            {
+              const double *nrm = normal_q + ((size_t)c * nq + q) * dim;
+              double ng = 0.;
+              for (int e = 0; e < dim; ++e) ng += nrm[e] * g[e * nq + q];
+              for (int e = 0; e < dim; ++e) g[e * nq + q] = (diffusion * ng) * nrm[e];
+            }
+          else
+            for (int e = 0; e < dim; ++e) g[e * nq + q] *= diffusion;
+        }
+      integrate(&t, m, 1, v, g, l);
+      scatter_add(m, s, 1, c, t.ndc, dst, con, l);
+    }
+  if (con) for (long i = 0; i < nn; ++i) if (con[i]) dst[i] = diag[i] * src[i]; /* :227-230 */
+  free(l); free(v); free(g); table_free(&t);
+  return 0;
+}
+
+/* local_reinitialize_rhs  source/level_set_okz_reinitialization.cc:128-189
+ * dst NOT zeroed here; when first_step != 0 normal_q is WRITTEN (normalised
+ * projection of normal_vec, d-block vector given as d separate scalar vectors
+ * concatenated: normal_vec[e*nn + node]).                                    */
+int orc_ls_reinit_rhs(const orc_mesh *m, const orc_ls_params *P, int diffuse_only, int first_step,
+                      const double *solution, const double *normal_vec, double *dst,
+                      const uint8_t *con, double *normal_q)
+{
+  const int dim = m->dim, s = P->ls_degree;
+  const long nn = orc_n_nodes(m, s);
+  orc_table t;
+  table_init(&t, dim, ORC_FE_Q_ISO_Q1, s, s, 1);
+  const int nq = t.nqc;
+  const double diffusion = fmax(P->epsilon_used, P->cell_diameter / (double)s);
+  double *l = (double *)malloc(sizeof(double) * t.ndc), *v = (double *)malloc(sizeof(double) * nq);
+  double *g = (double *)malloc(sizeof(double) * 3 * nq), *nv = (double *)malloc(sizeof(double) * 3 * nq);
+  const long nc = n_cells(m);
+  for (long c = 0; c < nc; ++c)
+    {
+      gather(m, s, 1, c, t.ndc, solution, NULL, l);
+      evaluate(&t, m, 1, l, v, g);
+      if (!diffuse_only && first_step)
+        for (int e = 0; e < dim; ++e)
+          {
+            gather(m, s, 1, c, t.ndc, normal_vec + (size_t)e * nn, NULL, l);
+            evaluate(&t, m, 1, l, nv + e * nq, NULL);
+          }
+      for (int q = 0; q < nq; ++q)
+        {
+          if (!diffuse_only)
+            {
+              double *nrm = normal_q + ((size_t)c * nq + q) * dim;
+              if (first_step) /* :167-172 */
+                {
+                  double nr = 0.;
+                  for (int e = 0; e < dim; ++e) nr += nv[e * nq + q] * nv[e * nq + q];
+                  nr = dim == 1 ? fabs(nv[q]) : sqrt(nr);
+                  const double sc = fmax(1e-4, nr);
+                  for (int e = 0; e < dim; ++e) nrm[e] = nv[e * nq + q] / sc;
+                }
+              double ng = 0.;
+              for (int e = 0; e < dim; ++e) ng += nrm[e] * g[e * nq + q];
+              const double f = 0.5 * (1. - v[q] * v[q]) - ng * diffusion; /* :176-178 */
+              for (int e = 0; e < dim; ++e) g[e * nq + q] = nrm[e] * f;
+            }
+          else
+            for (int e = 0; e < dim; ++e) g[e * nq + q] *= -diffusion;
+        }
+      integrate(&t, m, 1, NULL, g, l);
+      scatter_add(m, s, 1, c, t.ndc, dst, con, l);
+    }
+  free(l); free(v); free(g); free(nv); table_free(&t);
+  return 0;
+}
+
+/* advance_concentration_vmult + local_advance_concentration
+ * source/level_set_okz_advance_concentration.cc:217-258, :401-480
+ * (convection stabilization = 0: no artificial viscosity / face terms).
+ * vel_q: evaluated_convection [cell][q][dim].                                 */
+int orc_ls_advect_vmult(const orc_mesh *m, const orc_ls_params *P, const double *src, double *dst,
+                        const uint8_t *con, const double *vel_q, const double *diag)
+{
+  const int dim = m->dim, s = P->ls_degree;
+  const long nn = orc_n_nodes(m, s);
+  memset(dst, 0, sizeof(double) * nn);
+  orc_table t;
+  table_init(&t, dim, ORC_FE_Q_ISO_Q1, s, s, 1);
+  const int nq = t.nqc;
+  double *l = (double *)malloc(sizeof(double) * t.ndc), *v = (double *)malloc(sizeof(double) * nq);
+  double *g = (double *)malloc(sizeof(double) * 3 * nq);
+  const long nc = n_cells(m);
+  for (long c = 0; c < nc; ++c)
+    {
+      gather(m, s, 1, c, t.ndc, src, con, l);
+      evaluate(&t, m, 1, l, v, g);
+      for (int q = 0; q < nq; ++q)
+        {
+          const double *u = vel_q + ((size_t)c * nq + q) * dim;
+          double ug = 0.;
+          for (int e = 0; e < dim; ++e) ug += u[e] * g[e * nq + q];
+          v[q] = v[q] * P->weight + ug; /* :244-249 */
+        }
+      integrate(&t, m, 1, v, NULL, l);
+      scatter_add(m, s, 1, c, t.ndc, dst, con, l);
+    }
+  if (con) for (long i = 0; i < nn; ++i) if (con[i]) dst[i] = diag[i] * src[i]; /* :476-479 */
+  free(l); free(v); free(g); table_free(&t);
+  return 0;
+}
+
+/* compute_normal_vmult + local_compute_normal
+ * source/level_set_okz_compute_normal.cc:82-119, :160-183: per component
+ * (w,n) + (grad w, delta grad n), delta = 4 max(eps_used/eps, h/s)^2.
+ * src/dst: d blocks concatenated [e*nn + node].                               */
+int orc_ls_normal_vmult(const orc_mesh *m, const orc_ls_params *P, const double *src, double *dst,
+                        const uint8_t *con, const double *diag)
+{
+  const int dim = m->dim, s = P->ls_degree;
+  const long nn = orc_n_nodes(m, s);
+  memset(dst, 0, sizeof(double) * nn * dim);
+  orc_table t;
+  table_init(&t, dim, ORC_FE_Q_ISO_Q1, s, s, 1);
+  const int nq = t.nqc;
+  const double b = fmax(P->epsilon_used / P->epsilon, P->cell_diameter / (double)s);
+  const double damping = 4. * b * b;
+  double *l = (double *)malloc(sizeof(double) * t.ndc), *v = (double *)malloc(sizeof(double) * nq);
+  double *g = (double *)malloc(sizeof(double) * 3 * nq);
+  const long nc = n_cells(m);
+  for (int comp = 0; comp < dim; ++comp)
+    for (long c = 0; c < nc; ++c)
+      {
+        gather(m, s, 1, c, t.ndc, src + (size_t)comp * nn, con, l);
+        evaluate(&t, m, 1, l, v, g);
+        for (int q = 0; q < nq; ++q)
+          for (int e = 0; e < dim; ++e) g[e * nq + q] *= damping;
+        integrate(&t, m, 1, v, g, l);
+        scatter_add(m, s, 1, c, t.ndc, dst + (size_t)comp * nn, con, l);
+      }
+  if (con)
+    for (int comp = 0; comp < dim; ++comp)
+      for (long i = 0; i < nn; ++i)
+        if (con[i]) dst[comp * nn + i] = diag[i] * src[comp * nn + i];
+  free(l); free(v); free(g); table_free(&t);
+  return 0;
+}
+
+/* local_compute_normal_rhs  source/level_set_okz_compute_normal.cc:123-156: (w, grad phi) */
+int orc_ls_normal_rhs(const orc_mesh *m, const orc_ls_params *P, const double *solution,
+                      double *dst, const uint8_t *con)
+{
+  const int dim = m->dim, s = P->ls_degree;
+  const long nn = orc_n_nodes(m, s);
+  orc_table t;
+  table_init(&t, dim, ORC_FE_Q_ISO_Q1, s, s, 1);
+  const int nq = t.nqc;
+  double *l = (double *)malloc(sizeof(double) * t.ndc), *g = (double *)malloc(sizeof(double) * 3 * nq);
+  const long nc = n_cells(m);
+  for (long c = 0; c < nc; ++c)
+    {
+      gather(m, s, 1, c, t.ndc, solution, NULL, l);
+      evaluate(&t, m, 1, l, NULL, g);
+      for (int e = 0; e < dim; ++e)
+        {
+          integrate(&t, m, 1, g + e * nq, NULL, l);
+          scatter_add(m, s, 1, c, t.ndc, dst + (size_t)e * nn, con, l);
+        }
+    }
+  free(l); free(g); table_free(&t);
+  return 0;
+}
+
+/* compute_curvature_vmult + local_compute_curvature
+ * source/level_set_okz_compute_curvature.cc:86-133, :263-304:
+ * (w,k) + (grad w, delta grad k), delta = max(eps_used/eps, h/s)^2.           */
+int orc_ls_curvature_vmult(const orc_mesh *m, const orc_ls_params *P, int apply_diffusion,
+                           const double *src, double *dst, const uint8_t *con, const double *diag)
+{
+  const int dim = m->dim, s = P->ls_degree;
+  const long nn = orc_n_nodes(m, s);
+  memset(dst, 0, sizeof(double) * nn);
+  orc_table t;
+  table_init(&t, dim, ORC_FE_Q_ISO_Q1, s, s, 1);
+  const int nq = t.nqc;
+  const double b = fmax(P->epsilon_used / P->epsilon, P->cell_diameter / (double)s);
+  const double damping = apply_diffusion ? b * b : 0.; /* diffusion_setting 1 / 0 */
+  double *l = (double *)malloc(sizeof(double) * t.ndc), *v = (double *)malloc(sizeof(double) * nq);
+  double *g = (double *)malloc(sizeof(double) * 3 * nq);
+  const long nc = n_cells(m);
+  for (long c = 0; c < nc; ++c)
+    {
+      gather(m, s, 1, c, t.ndc, src, con, l);
+      evaluate(&t, m, 1, l, v, g);
+      for (int q = 0; q < nq; ++q)
+        for (int e = 0; e < dim; ++e) g[e * nq + q] *= damping;
+      integrate(&t, m, 1, v, g, l);
+      scatter_add(m, s, 1, c, t.ndc, dst, con, l);
+    }
+  if (con) for (long i = 0; i < nn; ++i) if (con[i]) dst[i] = diag[i] * src[i];
+  free(l); free(v); free(g); table_free(&t);
+  return 0;
+}
+
+/* local_compute_curvature_rhs  source/level_set_okz_compute_curvature.cc:212-259:
+ * rhs = (w, -div(n/|n|)); the normal is normalised at the DoFs (entries with
+ * |n| <= 1e-2 zeroed, :155-170), cells with all-zero normal skipped (:250).     */
+int orc_ls_curvature_rhs(const orc_mesh *m, const orc_ls_params *P, const double *normal_vec,
+                         double *dst, const uint8_t *con)
+{
+  const int dim = m->dim, s = P->ls_degree;
+  const long nn = orc_n_nodes(m, s);
+  orc_table t;
+  table_init(&t, dim, ORC_FE_Q_ISO_Q1, s, s, 1);
+  const int nq = t.nqc;
+  double *ln = (double *)malloc(sizeof(double) * 3 * t.ndc), *l = (double *)malloc(sizeof(double) * t.ndc);
+  double *v = (double *)malloc(sizeof(double) * nq), *g = (double *)malloc(sizeof(double) * 3 * nq);
+  const long nc = n_cells(m);
+  for (long c = 0; c < nc; ++c)
+    {
+      for (int e = 0; e < dim; ++e)
+        gather(m, s, 1, c, t.ndc, normal_vec + (size_t)e * nn, NULL, ln + e * t.ndc);
+      int all_zero = 1;
+      for (int i = 0; i < t.ndc; ++i)
+        {
+          double nr = 0.;
+          for (int e = 0; e < dim; ++e) nr += ln[e * t.ndc + i] * ln[e * t.ndc + i];
+          nr = sqrt(nr);
+          if (nr > 1e-2)
+            {
+              all_zero = 0;
+              for (int e = 0; e < dim; ++e) ln[e * t.ndc + i] /= nr;
+            }
+          else
+            for (int e = 0; e < dim; ++e) ln[e * t.ndc + i] = 0.;
+        }
+      if (all_zero) continue;
+      for (int q = 0; q < nq; ++q) v[q] = 0.;
+      for (int e = 0; e < dim; ++e)
+        {
+          evaluate(&t, m, 1, ln + e * t.ndc, NULL, g);
+          for (int q = 0; q < nq; ++q) v[q] -= g[e * nq + q];
+        }
+      integrate(&t, m, 1, v, NULL, l);
+      scatter_add(m, s, 1, c, t.ndc, dst, con, l);
+    }
+  free(ln); free(l); free(v); free(g); table_free(&t);
+  return 0;
+}
