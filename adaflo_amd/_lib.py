@@ -1,0 +1,89 @@
+"""ctypes binding of include/adaflo_hip.h (the C-ABI drop-in boundary)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libadaflo_hip.so")
+
+
+class BrickDesc(C.Structure):
+    _fields_ = [("dim", C.c_int), ("ncell", C.c_int * 3), ("h", C.c_double * 3),
+                ("origin", C.c_double * 3), ("velocity_degree", C.c_int), ("ls_degree", C.c_int),
+                ("velocity_constrained", C.c_uint32), ("pressure_constrained", C.c_uint32),
+                ("ls_constrained", C.c_uint32), ("pressure_average_fix", C.c_int),
+                ("device", C.c_int), ("stream", C.c_void_p)]
+
+
+class NSParams(C.Structure):
+    _fields_ = [("physical_type", C.c_int), ("linearization", C.c_int), ("beta", C.c_double),
+                ("tau_grad_div", C.c_double), ("density", C.c_double), ("viscosity", C.c_double),
+                ("damping", C.c_double), ("density_diff", C.c_double), ("weight", C.c_double),
+                ("weight_old", C.c_double), ("weight_old_old", C.c_double), ("tau1", C.c_double),
+                ("extrap_old", C.c_double), ("extrap_old_old", C.c_double)]
+
+
+_D = C.c_void_p  # device pointer
+_CTX = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/adaflo_hip.h one to one
+SIGNATURES = {
+    "adaflo_ctx_create": (C.c_int, [C.POINTER(BrickDesc), C.POINTER(_CTX)]),
+    "adaflo_ctx_destroy": (C.c_int, [_CTX]),
+    "adaflo_last_error": (C.c_char_p, [_CTX]),
+    "adaflo_synchronize": (C.c_int, [_CTX]),
+    "adaflo_stream": (C.c_void_p, [_CTX]),
+    "adaflo_n_cells": (C.c_int64, [_CTX]),
+    "adaflo_n_dofs_u": (C.c_int64, [_CTX]),
+    "adaflo_n_dofs_p": (C.c_int64, [_CTX]),
+    "adaflo_n_dofs_ls": (C.c_int64, [_CTX]),
+    "adaflo_n_q_points_u": (C.c_int, [_CTX]),
+    "adaflo_n_q_points_ls": (C.c_int, [_CTX]),
+    "adaflo_malloc": (C.c_int, [_CTX, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "adaflo_free": (C.c_int, [_CTX, _D]),
+    "adaflo_copy_h2d": (C.c_int, [_CTX, _D, C.c_void_p, C.c_size_t]),
+    "adaflo_copy_d2h": (C.c_int, [_CTX, C.c_void_p, _D, C.c_size_t]),
+    "adaflo_ns_set_params": (C.c_int, [_CTX, C.POINTER(NSParams)]),
+    "adaflo_ns_set_linearization": (C.c_int, [_CTX, C.c_void_p, C.c_int]),
+    "adaflo_ns_get_linearization": (C.c_int, [_CTX, C.c_void_p, C.c_int]),
+    "adaflo_ns_set_coefficients": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "adaflo_ns_fix_linearization_point": (C.c_int, [_CTX]),
+    "adaflo_ns_vmult": (C.c_int, [_CTX, _D, _D, _D, _D]),
+    "adaflo_ns_residual": (C.c_int, [_CTX, _D, _D, _D, _D, _D, _D, _D, _D]),
+    "adaflo_ns_velocity_vmult": (C.c_int, [_CTX, _D, _D]),
+    "adaflo_ns_divergence_vmult_add": (C.c_int, [_CTX, _D, _D, C.c_int]),
+    "adaflo_ns_pressure_poisson_vmult": (C.c_int, [_CTX, _D, _D]),
+    "adaflo_ns_pressure_mass_vmult": (C.c_int, [_CTX, _D, _D]),
+    "adaflo_ns_pressure_convdiff_vmult": (C.c_int, [_CTX, _D, _D]),
+    "adaflo_ns_apply_pressure_average_projection": (C.c_int, [_CTX, _D]),
+    "adaflo_ns_get_matvec_statistics": (C.c_int, [_CTX, C.POINTER(C.c_uint), C.POINTER(C.c_double)]),
+    "adaflo_set_kernel_variant": (C.c_int, [_CTX, C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP engine; raises (no fallback) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "HIP engine %s is missing: run `python -m adaflo_amd.build` (hipcc, gfx950). "
+                "There is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class AdafloError(RuntimeError):
+    pass
+
+
+def check(ctx, code):
+    if code != 0:
+        msg = load().adaflo_last_error(ctx)
+        raise AdafloError("adaflo_hip error %d: %s" % (code, msg.decode() if msg else "?"))

@@ -1,0 +1,620 @@
+// capi.hip -- implementation of the C ABI declared in include/adaflo_hip.h.
+//
+// Each adaflo_ns_* function reproduces the *wrapper* part of the corresponding
+// NavierStokesMatrix<dim> method (zeroing, dispatch on degree, constrained
+// rows, mean projection, timer) -- source/navier_stokes_matrix.cc:191-483 --
+// around the HIP cell kernels.
+#include <chrono>
+#include <cstring>
+
+#include "kernels.hpp"
+
+using namespace adaflo_hip;
+
+namespace
+{
+  thread_local std::string g_create_error;
+
+  int fail(adaflo_ctx *ctx, const int code, const std::string &msg)
+  {
+    if (ctx)
+      ctx->last_error = msg;
+    else
+      g_create_error = msg;
+    return code;
+  }
+
+#define HIP_TRY(ctx, expr)                                                          \
+  do                                                                                \
+    {                                                                               \
+      const hipError_t e_ = (expr);                                                 \
+      if (e_ != hipSuccess)                                                         \
+        return fail(ctx, ADAFLO_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    }                                                                               \
+  while (0)
+
+#define CHECK_CTX(ctx)                     \
+  if (!(ctx))                              \
+    return fail(nullptr, ADAFLO_ENOTINIT, "null context")
+
+#define TRY(ctx, expr, what)                 \
+  do                                         \
+    {                                        \
+      const int e_ = (expr);                 \
+      if (e_ != 0)                           \
+        return fail(ctx, e_, what);          \
+    }                                        \
+  while (0)
+
+  int alloc(adaflo_ctx *ctx, DeviceBuffer &b, const size_t count)
+  {
+    if (b.count == count && b.p)
+      return 0;
+    if (b.p)
+      (void)hipFree(b.p);
+    b.p     = nullptr;
+    b.count = 0;
+    if (count == 0)
+      return 0;
+    if (hipMalloc(&b.p, count * sizeof(double)) != hipSuccess)
+      return fail(ctx, ADAFLO_ENOMEM, "hipMalloc failed for quadrature-point state");
+    b.count = count;
+    return 0;
+  }
+
+  void release(DeviceBuffer &b)
+  {
+    if (b.p)
+      (void)hipFree(b.p);
+    b.p     = nullptr;
+    b.count = 0;
+  }
+
+  int upload(adaflo_ctx *ctx, double **dptr, const std::vector<double> &host)
+  {
+    HIP_TRY(ctx, hipMalloc(dptr, host.size() * sizeof(double)));
+    HIP_TRY(ctx, hipMemcpy(*dptr, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
+    return 0;
+  }
+
+  // time one operator application with a pair of events (get_matvec_statistics)
+  struct MatvecTimer
+  {
+    adaflo_ctx *ctx;
+    hipEvent_t  start = nullptr, stop = nullptr;
+    explicit MatvecTimer(adaflo_ctx *c)
+      : ctx(c)
+    {
+      if (!ctx->timing)
+        return;
+      if (ctx->ev_used + 2 > ctx->ev_pool.size())
+        {
+          if (ctx->ev_pool.size() >= 8192)
+            { // fold what has been recorded so far
+              (void)hipStreamSynchronize(ctx->stream);
+              for (size_t i = 0; i + 1 < ctx->ev_used; i += 2)
+                {
+                  float ms = 0.f;
+                  if (hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]) == hipSuccess)
+                    ctx->matvec_seconds += 1e-3 * ms;
+                }
+              ctx->ev_used = 0;
+            }
+          else
+            for (int i = 0; i < 2; ++i)
+              {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess)
+                  return;
+                ctx->ev_pool.push_back(e);
+              }
+        }
+      start = ctx->ev_pool[ctx->ev_used++];
+      stop  = ctx->ev_pool[ctx->ev_used++];
+      (void)hipEventRecord(start, ctx->stream);
+    }
+    ~MatvecTimer()
+    {
+      if (stop)
+        (void)hipEventRecord(stop, ctx->stream);
+      ctx->matvec_count++;
+    }
+  };
+
+  NSArgs make_ns_args(adaflo_ctx *ctx, const bool prec_state)
+  {
+    NSArgs a{};
+    a.brick   = ctx->brick;
+    a.ns      = ctx->ns;
+    a.lin     = prec_state && ctx->lin_prec.p ? ctx->lin_prec.p : ctx->lin.p;
+    a.rho     = prec_state && ctx->rho_prec.p ? ctx->rho_prec.p : ctx->rho.p;
+    a.mu      = prec_state && ctx->mu_prec.p ? ctx->mu_prec.p : ctx->mu.p;
+    a.damp    = prec_state && ctx->damp_prec.p ? ctx->damp_prec.p : ctx->damp.p;
+    a.tab     = ctx->d_tab_u;
+    a.n_cells = ctx->n_cells;
+    return a;
+  }
+
+  bool needs_lin(const adaflo_ctx *ctx)
+  {
+    return ctx->ns.linearization != ADAFLO_COUPLED_VELOCITY_EXPLICIT &&
+           ctx->ns.physical_type != ADAFLO_STOKES;
+  }
+
+  int nn(const adaflo_ctx *ctx, const int degree, const int d)
+  {
+    return degree * ctx->desc.ncell[d] + 1;
+  }
+} // namespace
+
+extern "C" {
+
+const char *adaflo_last_error(const adaflo_ctx *ctx)
+{
+  return ctx ? ctx->last_error.c_str() : g_create_error.c_str();
+}
+
+int adaflo_ctx_create(const adaflo_brick_desc *desc, adaflo_ctx **out)
+{
+  if (!desc || !out)
+    return fail(nullptr, ADAFLO_EINVAL, "null argument");
+  *out = nullptr;
+  if (desc->dim != 3)
+    return fail(nullptr, ADAFLO_EUNSUPPORTED, "only dim = 3 is implemented on the device");
+  if (desc->velocity_degree < 2 || desc->velocity_degree > 5)
+    return fail(nullptr, ADAFLO_EUNSUPPORTED, "velocity degree must be in [2,5] (reference: ExcNotImplemented)");
+  for (int d = 0; d < 3; ++d)
+    if (desc->ncell[d] < 1 || !(desc->h[d] > 0.))
+      return fail(nullptr, ADAFLO_EINVAL, "invalid brick extents");
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, ADAFLO_EHIP, "no HIP device available (the engine has no CPU fallback)");
+  if (desc->device < 0 || desc->device >= ndev)
+    return fail(nullptr, ADAFLO_EINVAL, "invalid device ordinal");
+
+  adaflo_ctx *ctx = new adaflo_ctx;
+  ctx->desc       = *desc;
+  HIP_TRY(nullptr, hipSetDevice(desc->device));
+  if (desc->stream)
+    ctx->stream = static_cast<hipStream_t>(desc->stream);
+  else
+    {
+      HIP_TRY(nullptr, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+      ctx->own_stream = true;
+    }
+  ctx->k = desc->velocity_degree;
+  ctx->s = desc->ls_degree;
+  const int k = ctx->k;
+  ctx->n_cells   = (int64_t)desc->ncell[0] * desc->ncell[1] * desc->ncell[2];
+  ctx->n_nodes_u = (int64_t)nn(ctx, k, 0) * nn(ctx, k, 1) * nn(ctx, k, 2);
+  ctx->n_nodes_p = (int64_t)nn(ctx, k - 1, 0) * nn(ctx, k - 1, 1) * nn(ctx, k - 1, 2);
+  ctx->n_nodes_ls = ctx->s > 0 ? (int64_t)nn(ctx, ctx->s, 0) * nn(ctx, ctx->s, 1) * nn(ctx, ctx->s, 2) : 0;
+  ctx->nq_u       = (k + 1) * (k + 1) * (k + 1);
+  for (int d = 0; d < 3; ++d)
+    {
+      ctx->brick.ncell[d] = desc->ncell[d];
+      ctx->brick.h[d]     = desc->h[d];
+    }
+  ctx->brick.con_u  = desc->velocity_constrained;
+  ctx->brick.con_p  = desc->pressure_constrained;
+  ctx->brick.con_ls = desc->ls_constrained;
+
+  // 1D tables: quad_index_u = QGauss(k+1), quad_index_p = QGauss(k)
+  {
+    const Quadrature1D  qu = gauss(k + 1), qp = gauss(k);
+    const Shape1D       su = shape_fe_q(k, qu), sp = shape_fe_q(k - 1, qu), spp = shape_fe_q(k - 1, qp);
+    std::vector<double> tab;
+    tab.insert(tab.end(), su.S.begin(), su.S.end());
+    tab.insert(tab.end(), su.D.begin(), su.D.end());
+    tab.insert(tab.end(), sp.S.begin(), sp.S.end());
+    tab.insert(tab.end(), sp.D.begin(), sp.D.end());
+    tab.insert(tab.end(), qu.w.begin(), qu.w.end());
+    TRY(nullptr, upload(nullptr, &ctx->d_tab_u, tab), g_create_error);
+    std::vector<double> tabp;
+    tabp.insert(tabp.end(), spp.S.begin(), spp.S.end());
+    tabp.insert(tabp.end(), spp.D.begin(), spp.D.end());
+    tabp.insert(tabp.end(), qp.w.begin(), qp.w.end());
+    TRY(nullptr, upload(nullptr, &ctx->d_tab_pp, tabp), g_create_error);
+  }
+
+  // default parameters = FlowParameters defaults relevant to the kernels
+  ctx->ns = NSDev{ADAFLO_INCOMPRESSIBLE, ADAFLO_COUPLED_IMPLICIT_NEWTON, 0.5, 0., 1., 1., 0., 0.,
+                  1., -1., 0., 1., 1., 0.};
+
+  // pressure constant mode 0, source/navier_stokes_matrix.cc:117-168
+  if (desc->pressure_average_fix)
+    {
+      const long np = ctx->n_nodes_p;
+      HIP_TRY(nullptr, hipMalloc(&ctx->d_p_weights, np * sizeof(double)));
+      HIP_TRY(nullptr, hipMalloc(&ctx->d_p_modes, np * sizeof(double)));
+      // pres_mass = cell_loop(local_pressure_mass_weight) on a zero vector
+      TRY(nullptr, launch_fill(ctx, ctx->d_p_weights, 0., np), "fill failed");
+      ScalarArgs sa{};
+      sa.brick   = ctx->brick; // distribute_local_to_global skips constrained rows (stay 0)
+      sa.ns      = ctx->ns;
+      sa.dst     = ctx->d_p_weights;
+      sa.tab     = ctx->d_tab_pp;
+      sa.n_cells = ctx->n_cells;
+      sa.mode    = SC_MASS_WEIGHT;
+      sa.nq_u3   = ctx->nq_u;
+      TRY(nullptr, launch_ns_scalar_generic(ctx, sa), "mass-weight kernel launch failed");
+      TRY(nullptr, launch_fill(ctx, ctx->d_p_modes, 1., np), "fill failed");
+      if (ctx->brick.con_p != 0u)
+        TRY(nullptr,
+            launch_prepare_dst(ctx, ctx->d_p_modes, ctx->d_p_modes, np, 1, nn(ctx, k - 1, 0),
+                               nn(ctx, k - 1, 1), nn(ctx, k - 1, 2), ctx->brick.con_p, 0., false),
+            "mask failed");
+      const double mw = host_dot(ctx, ctx->d_p_modes, ctx->d_p_weights, np);
+      ctx->inv_p_weight = 1. / mw;
+    }
+  HIP_TRY(nullptr, hipStreamSynchronize(ctx->stream));
+  *out = ctx;
+  return 0;
+}
+
+int adaflo_ctx_destroy(adaflo_ctx *ctx)
+{
+  CHECK_CTX(ctx);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (DeviceBuffer *b : {&ctx->lin, &ctx->rho, &ctx->mu, &ctx->damp, &ctx->lin_prec, &ctx->rho_prec,
+                          &ctx->mu_prec, &ctx->damp_prec, &ctx->lin_q2})
+    release(*b);
+  for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch})
+    if (p)
+      (void)hipFree(p);
+  for (hipEvent_t e : ctx->ev_pool)
+    (void)hipEventDestroy(e);
+  if (ctx->own_stream)
+    (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return 0;
+}
+
+int adaflo_synchronize(adaflo_ctx *ctx)
+{
+  CHECK_CTX(ctx);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+void *adaflo_stream(adaflo_ctx *ctx)
+{
+  return ctx ? ctx->stream : nullptr;
+}
+
+int64_t adaflo_n_cells(const adaflo_ctx *ctx) { return ctx ? ctx->n_cells : 0; }
+int64_t adaflo_n_dofs_u(const adaflo_ctx *ctx) { return ctx ? 3 * ctx->n_nodes_u : 0; }
+int64_t adaflo_n_dofs_p(const adaflo_ctx *ctx) { return ctx ? ctx->n_nodes_p : 0; }
+int64_t adaflo_n_dofs_ls(const adaflo_ctx *ctx) { return ctx ? ctx->n_nodes_ls : 0; }
+int     adaflo_n_q_points_u(const adaflo_ctx *ctx) { return ctx ? ctx->nq_u : 0; }
+int     adaflo_n_q_points_ls(const adaflo_ctx *ctx) { return ctx ? 8 * ctx->s * ctx->s * ctx->s : 0; }
+
+int adaflo_malloc(adaflo_ctx *ctx, size_t bytes, void **dptr)
+{
+  CHECK_CTX(ctx);
+  if (hipMalloc(dptr, bytes) != hipSuccess)
+    return fail(ctx, ADAFLO_ENOMEM, "hipMalloc failed");
+  return 0;
+}
+
+int adaflo_free(adaflo_ctx *ctx, void *dptr)
+{
+  CHECK_CTX(ctx);
+  HIP_TRY(ctx, hipFree(dptr));
+  return 0;
+}
+
+int adaflo_copy_h2d(adaflo_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+  CHECK_CTX(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int adaflo_copy_d2h(adaflo_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+  CHECK_CTX(ctx);
+  HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int adaflo_set_kernel_variant(adaflo_ctx *ctx, int variant)
+{
+  CHECK_CTX(ctx);
+  if (variant < 0 || variant > 1)
+    return fail(ctx, ADAFLO_EINVAL, "unknown kernel variant");
+  ctx->variant = variant;
+  return 0;
+}
+
+int adaflo_ns_set_params(adaflo_ctx *ctx, const adaflo_ns_params *p)
+{
+  CHECK_CTX(ctx);
+  if (!p)
+    return fail(ctx, ADAFLO_EINVAL, "null params");
+  if (p->physical_type < 0 || p->physical_type > 2 || p->linearization < 0 || p->linearization > 4)
+    return fail(ctx, ADAFLO_EINVAL, "invalid physical type / linearization");
+  if (p->physical_type == ADAFLO_INCOMPRESSIBLE_STATIONARY &&
+      p->linearization != ADAFLO_COUPLED_IMPLICIT_NEWTON)
+    return fail(ctx, ADAFLO_EINVAL,
+                "stationary equation requires coupled implicit Newton (parameters.cc:501-504)");
+  ctx->ns = NSDev{p->physical_type, p->linearization, p->beta, p->tau_grad_div, p->density,
+                  p->viscosity, p->damping, p->density_diff, p->weight, p->weight_old,
+                  p->weight_old_old, p->tau1, p->extrap_old, p->extrap_old_old};
+  ctx->ns_params_set = true;
+  return 0;
+}
+
+int adaflo_ns_set_linearization(adaflo_ctx *ctx, const double *lin, int src_on_device)
+{
+  CHECK_CTX(ctx);
+  const size_t count = (size_t)ctx->n_cells * ctx->nq_u * NLIN;
+  TRY(ctx, alloc(ctx, ctx->lin, count), ctx->last_error);
+  double *staging = nullptr;
+  const double *src = lin;
+  if (!src_on_device)
+    {
+      HIP_TRY(ctx, hipMalloc(&staging, count * sizeof(double)));
+      HIP_TRY(ctx, hipMemcpyAsync(staging, lin, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      src = staging;
+    }
+  TRY(ctx, launch_transpose_state(ctx, ctx->lin.p, src, ctx->n_cells, ctx->nq_u, NLIN, true),
+      "state re-layout failed");
+  ctx->lin_q2_valid = false;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (staging)
+    (void)hipFree(staging);
+  return 0;
+}
+
+int adaflo_ns_get_linearization(adaflo_ctx *ctx, double *lin, int dst_on_device)
+{
+  CHECK_CTX(ctx);
+  if (!ctx->lin.p)
+    return fail(ctx, ADAFLO_ENOTINIT, "no linearization data stored");
+  const size_t count = ctx->lin.count;
+  double      *dst   = lin;
+  double      *staging = nullptr;
+  if (!dst_on_device)
+    {
+      HIP_TRY(ctx, hipMalloc(&staging, count * sizeof(double)));
+      dst = staging;
+    }
+  TRY(ctx, launch_transpose_state(ctx, dst, ctx->lin.p, ctx->n_cells, ctx->nq_u, NLIN, false),
+      "state re-layout failed");
+  if (staging)
+    {
+      HIP_TRY(ctx, hipMemcpyAsync(lin, staging, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (staging)
+    (void)hipFree(staging);
+  return 0;
+}
+
+int adaflo_ns_set_coefficients(adaflo_ctx *ctx, const double *rho, const double *mu,
+                               const double *damping, int src_on_device)
+{
+  CHECK_CTX(ctx);
+  const size_t count = (size_t)ctx->n_cells * ctx->nq_u;
+  if (!rho && !mu && !damping)
+    {
+      release(ctx->rho);
+      release(ctx->mu);
+      release(ctx->damp);
+      return 0;
+    }
+  if (!rho || !mu || !damping)
+    return fail(ctx, ADAFLO_EINVAL, "density, viscosity and damping arrays must be given together "
+                                    "(navier_stokes_matrix.cc:100-108)");
+  // canonical [cell][q] == generic [cell][1][q]: plain copy
+  const hipMemcpyKind kind = src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  TRY(ctx, alloc(ctx, ctx->rho, count), ctx->last_error);
+  TRY(ctx, alloc(ctx, ctx->mu, count), ctx->last_error);
+  TRY(ctx, alloc(ctx, ctx->damp, count), ctx->last_error);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->rho.p, rho, count * sizeof(double), kind, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->mu.p, mu, count * sizeof(double), kind, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->damp.p, damping, count * sizeof(double), kind, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx)
+{
+  CHECK_CTX(ctx);
+  const DeviceBuffer *src[4] = {&ctx->lin, &ctx->rho, &ctx->mu, &ctx->damp};
+  DeviceBuffer       *dst[4] = {&ctx->lin_prec, &ctx->rho_prec, &ctx->mu_prec, &ctx->damp_prec};
+  for (int i = 0; i < 4; ++i)
+    {
+      TRY(ctx, alloc(ctx, *dst[i], src[i]->count), ctx->last_error);
+      if (src[i]->count)
+        HIP_TRY(ctx, hipMemcpyAsync(dst[i]->p, src[i]->p, src[i]->count * sizeof(double),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+    }
+  return 0;
+}
+
+int adaflo_ns_apply_pressure_average_projection(adaflo_ctx *ctx, double *vec_p)
+{
+  CHECK_CTX(ctx);
+  // :196-198
+  if (ctx->ns.linearization == ADAFLO_PROJECTION ||
+      ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE_STATIONARY || !ctx->d_p_weights)
+    return 0;
+  TRY(ctx,
+      launch_mean_projection(ctx, vec_p, ctx->d_p_weights, ctx->d_p_modes, ctx->n_nodes_p,
+                             ctx->inv_p_weight),
+      "projection launch failed");
+  return 0;
+}
+
+int adaflo_ns_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double *src_u,
+                    const double *src_p)
+{
+  CHECK_CTX(ctx);
+  if (!dst_u || !dst_p || !src_u || !src_p)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  if (needs_lin(ctx) && !ctx->lin.p)
+    return fail(ctx, ADAFLO_ENOTINIT, "linearization data not set (call residual or set_linearization)");
+  MatvecTimer timer(ctx);
+  const int   k = ctx->k;
+  if (ctx->variant == 1 && q2_supported(ctx))
+    {
+      TRY(ctx, launch_ns_vmult_q2(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p), "Q2 kernel launch failed");
+    }
+  else
+    {
+      // dst = 0 (:229) fused with the constrained rows (:247-256)
+      TRY(ctx,
+          launch_prepare_dst(ctx, dst_u, src_u, ctx->n_nodes_u, 3, nn(ctx, k, 0), nn(ctx, k, 1),
+                             nn(ctx, k, 2), ctx->brick.con_u, 1., true),
+          "prepare failed");
+      TRY(ctx,
+          launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, nn(ctx, k - 1, 0), nn(ctx, k - 1, 1),
+                             nn(ctx, k - 1, 2), ctx->brick.con_p, -1., true),
+          "prepare failed");
+      NSArgs a = make_ns_args(ctx, false);
+      a.src_u  = src_u;
+      a.src_p  = src_p;
+      a.dst_u  = dst_u;
+      a.dst_p  = dst_p;
+      TRY(ctx, launch_ns_cell_generic(ctx, OP_VMULT, a), "cell kernel launch failed");
+    }
+  return adaflo_ns_apply_pressure_average_projection(ctx, dst_p); // :258
+}
+
+int adaflo_ns_residual(adaflo_ctx *ctx, double *rhs_u, double *rhs_p, const double *src_u,
+                       const double *src_p, const double *user_u, const double *user_p,
+                       const double *old_u, const double *old_old_u)
+{
+  CHECK_CTX(ctx);
+  if (!rhs_u || !rhs_p || !src_u || !src_p)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  if (ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE && (!old_u || !old_old_u))
+    return fail(ctx, ADAFLO_EINVAL, "solution_old / solution_old_old required");
+  if (needs_lin(ctx))
+    TRY(ctx, alloc(ctx, ctx->lin, (size_t)ctx->n_cells * ctx->nq_u * NLIN), ctx->last_error);
+  NSArgs a   = make_ns_args(ctx, false);
+  a.src_u    = src_u;
+  a.src_p    = src_p;
+  a.dst_u    = rhs_u;
+  a.dst_p    = rhs_p;
+  a.old_u    = old_u;
+  a.oldold_u = old_old_u;
+  TRY(ctx, launch_ns_cell_generic(ctx, OP_RESIDUAL, a), "cell kernel launch failed");
+  ctx->lin_q2_valid = false;
+  // system_rhs.sadd(-1., 1., user_rhs)  :292
+  TRY(ctx, launch_sadd(ctx, rhs_u, -1., user_u, 3 * ctx->n_nodes_u), "sadd failed");
+  TRY(ctx, launch_sadd(ctx, rhs_p, -1., user_p, ctx->n_nodes_p), "sadd failed");
+  return 0;
+}
+
+int adaflo_ns_velocity_vmult(adaflo_ctx *ctx, double *dst_u, const double *src_u)
+{
+  CHECK_CTX(ctx);
+  if (!dst_u || !src_u)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  if (needs_lin(ctx) && !ctx->lin.p)
+    return fail(ctx, ADAFLO_ENOTINIT, "linearization data not set");
+  const int k = ctx->k;
+  TRY(ctx,
+      launch_prepare_dst(ctx, dst_u, src_u, ctx->n_nodes_u, 3, nn(ctx, k, 0), nn(ctx, k, 1),
+                         nn(ctx, k, 2), ctx->brick.con_u, 1., true),
+      "prepare failed");
+  // :349-356: operate on the state frozen by fix_linearization_point, if any
+  NSArgs a = make_ns_args(ctx, true);
+  a.src_u  = src_u;
+  a.dst_u  = dst_u;
+  TRY(ctx, launch_ns_cell_generic(ctx, OP_VMULT_VELOCITY, a), "cell kernel launch failed");
+  return 0;
+}
+
+static int scalar_op(adaflo_ctx *ctx, double *dst, const double *src, const int mode,
+                     const double *coef, const bool quad_u, const bool zero_dst)
+{
+  const int k = ctx->k;
+  if (zero_dst)
+    TRY(ctx,
+        launch_prepare_dst(ctx, dst, src, ctx->n_nodes_p, 1, nn(ctx, k - 1, 0), nn(ctx, k - 1, 1),
+                           nn(ctx, k - 1, 2), ctx->brick.con_p, 1., true),
+        "prepare failed");
+  ScalarArgs sa{};
+  sa.brick   = ctx->brick;
+  sa.ns      = ctx->ns;
+  sa.src     = src;
+  sa.dst     = dst;
+  sa.coef_q  = coef;
+  sa.tab     = quad_u ? ctx->d_tab_u : ctx->d_tab_pp;
+  sa.n_cells = ctx->n_cells;
+  sa.mode    = mode;
+  sa.nq_u3   = ctx->nq_u;
+  TRY(ctx, launch_ns_scalar_generic(ctx, sa), "scalar kernel launch failed");
+  return 0;
+}
+
+int adaflo_ns_divergence_vmult_add(adaflo_ctx *ctx, double *dst_p, const double *src_u,
+                                   int weight_by_viscosity)
+{
+  CHECK_CTX(ctx);
+  if (!dst_p || !src_u)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  return scalar_op(ctx, dst_p, src_u, weight_by_viscosity ? SC_DIVERGENCE_VISC : SC_DIVERGENCE,
+                   ctx->mu.p, true, false);
+}
+
+int adaflo_ns_pressure_poisson_vmult(adaflo_ctx *ctx, double *dst_p, const double *src_p)
+{
+  CHECK_CTX(ctx);
+  if (!dst_p || !src_p)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  // :395-396 preconditioner copy of the densities if fixed
+  const double *rho = ctx->rho_prec.p ? ctx->rho_prec.p : ctx->rho.p;
+  const bool    var = rho && ctx->ns.linearization != ADAFLO_PROJECTION; // :976-978
+  const bool    full = var && ctx->ns.physical_type != ADAFLO_INCOMPRESSIBLE_STATIONARY;
+  return scalar_op(ctx, dst_p, src_p, full ? SC_POISSON_VARIABLE : SC_POISSON_CELL, var ? rho : nullptr,
+                   full, true);
+}
+
+int adaflo_ns_pressure_mass_vmult(adaflo_ctx *ctx, double *dst_p, const double *src_p)
+{
+  CHECK_CTX(ctx);
+  if (!dst_p || !src_p)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  const double *mu = ctx->mu_prec.p ? ctx->mu_prec.p : ctx->mu.p;
+  return scalar_op(ctx, dst_p, src_p, SC_MASS, mu, false, true);
+}
+
+int adaflo_ns_pressure_convdiff_vmult(adaflo_ctx *ctx, double *dst_p, const double *src_p)
+{
+  CHECK_CTX(ctx);
+  if (!dst_p || !src_p)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  if (!ctx->lin.p) // Assert(linearized_velocities.size() > 0) :1110
+    return fail(ctx, ADAFLO_ENOTINIT, "linearization data not set");
+  return scalar_op(ctx, dst_p, src_p, SC_CONVDIFF, ctx->mu.p, true, true);
+}
+
+int adaflo_ns_get_matvec_statistics(adaflo_ctx *ctx, unsigned *count, double *seconds)
+{
+  CHECK_CTX(ctx);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i + 1 < ctx->ev_used; i += 2)
+    {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]) == hipSuccess)
+        ctx->matvec_seconds += 1e-3 * ms;
+    }
+  ctx->ev_used = 0;
+  if (count)
+    *count = ctx->matvec_count;
+  if (seconds)
+    *seconds = ctx->matvec_seconds;
+  ctx->matvec_count   = 0;
+  ctx->matvec_seconds = 0.;
+  return 0;
+}
+
+} // extern "C"

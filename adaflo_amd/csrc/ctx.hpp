@@ -1,0 +1,77 @@
+// ctx.hpp -- the engine context behind the C ABI (include/adaflo_hip.h).
+//
+// Plays the role of NavierStokesMatrix<dim>'s private state
+// (include/adaflo/navier_stokes_matrix.h:253-282): pointers to the mesh
+// description (here: a structured brick instead of MatrixFree<dim>), the
+// operator parameters, and the quadrature-point arrays it owns.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/adaflo_hip.h"
+#include "basis.hpp"
+#include "fe_kernels.hpp"
+
+namespace adaflo_hip
+{
+  // device mirror of adaflo_ns_params with the derived flags local_operation
+  // computes at source/navier_stokes_matrix.cc:621-653
+  struct NSDev
+  {
+    int    physical_type, linearization;
+    double beta, tau_grad_div, density, viscosity, damping, density_diff;
+    double weight, weight_old, weight_old_old, tau1, extrap_old, extrap_old_old;
+  };
+
+  struct DeviceBuffer
+  {
+    double *p     = nullptr;
+    size_t  count = 0;
+  };
+} // namespace adaflo_hip
+
+struct adaflo_ctx
+{
+  adaflo_brick_desc desc{};
+  hipStream_t       stream     = nullptr;
+  bool              own_stream = false;
+  int               variant    = 1;
+
+  int     k = 0, s = 0;
+  int64_t n_cells = 0, n_nodes_u = 0, n_nodes_p = 0, n_nodes_ls = 0;
+  int     nq_u = 0; // (k+1)^3
+
+  adaflo_hip::BrickDev brick{};
+  adaflo_hip::NSDev    ns{};
+  bool                 ns_params_set = false;
+
+  // 1D tables on the device, one packed buffer:
+  //   [S_u D_u S_p D_p w] for quad_index_u (n = k+1 points)
+  //   [S_pp D_pp w_pp]    for quad_index_p (n = k points), pressure only
+  double *d_tab_u = nullptr, *d_tab_pp = nullptr;
+
+  // quadrature-point state, generic layout [cell][comp][q]
+  adaflo_hip::DeviceBuffer lin, rho, mu, damp;
+  adaflo_hip::DeviceBuffer lin_prec, rho_prec, mu_prec, damp_prec; // fix_linearization_point
+
+  // specialised (Q2/Q1 sweep kernel) copy of the linearisation, see ns_q2.hip
+  adaflo_hip::DeviceBuffer lin_q2;
+  bool                     lin_q2_valid = false;
+
+  // pressure constant mode (mode 0) data, source/navier_stokes_matrix.cc:117-168
+  double *d_p_weights = nullptr, *d_p_modes = nullptr;
+  double  inv_p_weight = 0.;
+  double *d_scratch    = nullptr; // reduction scratch (partials + result)
+  size_t  scratch_count = 0;
+
+  // matvec statistics (get_matvec_statistics)
+  unsigned                 matvec_count = 0;
+  double                   matvec_seconds = 0.;
+  bool                     timing = true;
+  std::vector<hipEvent_t>  ev_pool;
+  size_t                   ev_used = 0;
+
+  std::string last_error;
+};

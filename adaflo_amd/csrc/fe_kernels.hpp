@@ -1,0 +1,245 @@
+// fe_kernels.hpp -- device building blocks of the generic (any degree) cell kernels.
+//
+// One workgroup evaluates one cell; every tensor lives in LDS and the 1D
+// contractions of the sum factorisation are distributed over the NT threads of
+// the workgroup.  This is the engine's restatement of what deal.II's
+// FEEvaluation::{read_dof_values, evaluate, integrate, distribute_local_to_global}
+// do at the call sites in source/navier_stokes_matrix.cc:662-671,897-906 and
+// source/level_set_okz_*.cc.
+//
+// General (non-collocation) scheme so that it also covers FE_Q_iso_Q1:
+//   values    S_z S_y S_x u,  d/dx: S_z S_y D_x u,  d/dy: S_z D_y S_x u,  d/dz: D_z S_y S_x u
+// Index convention: x fastest everywhere; S,D are [q][i] row-major in LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace adaflo_hip
+{
+  // structured brick description handed to every kernel by value
+  struct BrickDev
+  {
+    int      ncell[3];
+    double   h[3];
+    uint32_t con_u, con_p, con_ls;
+  };
+
+  // lexicographic cell index -> XCD-aware remap of blockIdx (workgroups are
+  // dealt round-robin to the 8 XCDs; give each XCD a contiguous range of cells
+  // so that neighbouring cells share one L2)
+  __device__ __forceinline__ long xcd_remap(const long b, const long n)
+  {
+    const long per = n / 8;
+    if (b >= per * 8)
+      return b; // tail
+    return (b % 8) * per + b / 8;
+  }
+
+  // is node (I,J,K) of a space with nn[d] nodes per direction on a constrained
+  // face?  mask bit = stride*f + comp with f = 2*d + side
+  __device__ __forceinline__ bool on_constrained_face(const int I, const int J, const int K,
+                                                      const int nnx, const int nny, const int nnz,
+                                                      const uint32_t mask, const int stride,
+                                                      const int comp)
+  {
+    uint32_t f = 0;
+    f |= (I == 0) ? (1u << (stride * 0 + comp)) : 0u;
+    f |= (I == nnx - 1) ? (1u << (stride * 1 + comp)) : 0u;
+    f |= (J == 0) ? (1u << (stride * 2 + comp)) : 0u;
+    f |= (J == nny - 1) ? (1u << (stride * 3 + comp)) : 0u;
+    f |= (K == 0) ? (1u << (stride * 4 + comp)) : 0u;
+    f |= (K == nnz - 1) ? (1u << (stride * 5 + comp)) : 0u;
+    return (f & mask) != 0u;
+  }
+
+  template <int ND, int NQ, int NT>
+  struct SumFac
+  {
+    static constexpr int ND3 = ND * ND * ND;
+    static constexpr int NQ2 = NQ * NQ;
+    static constexpr int NQ3 = NQ * NQ * NQ;
+    static constexpr int T1  = NQ * ND * ND;
+    static constexpr int T2  = NQ * NQ * ND;
+    static constexpr int TMP = 2 * T1 + 3 * T2;
+
+    // u[ND3] -> val[NQ3], gx/gy/gz[NQ3] (reference-cell derivatives)
+    template <bool VAL, bool GRAD>
+    static __device__ void evaluate(const double *S, const double *D, const double *u, double *val,
+                                    double *gx, double *gy, double *gz, double *tmp)
+    {
+      double *t1 = tmp, *t1d = tmp + T1, *t2 = tmp + 2 * T1, *t2dy = t2 + T2, *t2dx = t2 + 2 * T2;
+      const int tid = threadIdx.x;
+      for (int o = tid; o < T1; o += NT)
+        {
+          const int q = o % NQ, base = (o / NQ) * ND;
+          double    a = 0., b = 0.;
+#pragma unroll
+          for (int i = 0; i < ND; ++i)
+            {
+              const double v = u[base + i];
+              a += S[q * ND + i] * v;
+              if (GRAD)
+                b += D[q * ND + i] * v;
+            }
+          t1[o] = a;
+          if (GRAD)
+            t1d[o] = b;
+        }
+      __syncthreads();
+      for (int o = tid; o < T2; o += NT)
+        {
+          const int q = o % NQ, r = (o / NQ) % NQ, k = o / NQ2;
+          double    a = 0., dy = 0., dx = 0.;
+#pragma unroll
+          for (int j = 0; j < ND; ++j)
+            {
+              const double v = t1[(k * ND + j) * NQ + q];
+              a += S[r * ND + j] * v;
+              if (GRAD)
+                {
+                  dy += D[r * ND + j] * v;
+                  dx += S[r * ND + j] * t1d[(k * ND + j) * NQ + q];
+                }
+            }
+          t2[o] = a;
+          if (GRAD)
+            {
+              t2dy[o] = dy;
+              t2dx[o] = dx;
+            }
+        }
+      __syncthreads();
+      for (int o = tid; o < NQ3; o += NT)
+        {
+          const int rq = o % NQ2, s = o / NQ2;
+          double    a = 0., dz = 0., dy = 0., dx = 0.;
+#pragma unroll
+          for (int k = 0; k < ND; ++k)
+            {
+              const double v = t2[k * NQ2 + rq];
+              a += S[s * ND + k] * v;
+              if (GRAD)
+                {
+                  dz += D[s * ND + k] * v;
+                  dy += S[s * ND + k] * t2dy[k * NQ2 + rq];
+                  dx += S[s * ND + k] * t2dx[k * NQ2 + rq];
+                }
+            }
+          if (VAL)
+            val[o] = a;
+          if (GRAD)
+            {
+              gx[o] = dx;
+              gy[o] = dy;
+              gz[o] = dz;
+            }
+        }
+      __syncthreads();
+    }
+
+    // transpose of evaluate: out[ND3] = S^T tv + D_x^T tgx + D_y^T tgy + D_z^T tgz
+    template <bool VAL, bool GRAD>
+    static __device__ void integrate(const double *S, const double *D, const double *tv,
+                                     const double *tgx, const double *tgy, const double *tgz,
+                                     double *out, double *tmp)
+    {
+      double *t1 = tmp, *t1d = tmp + T1, *t2 = tmp + 2 * T1, *t2dy = t2 + T2, *t2dx = t2 + 2 * T2;
+      const int tid = threadIdx.x;
+      for (int o = tid; o < T2; o += NT)
+        {
+          const int rq = o % NQ2, k = o / NQ2;
+          double    a = 0., ay = 0., ax = 0.;
+#pragma unroll
+          for (int s = 0; s < NQ; ++s)
+            {
+              if (VAL)
+                a += S[s * ND + k] * tv[s * NQ2 + rq];
+              if (GRAD)
+                {
+                  a += D[s * ND + k] * tgz[s * NQ2 + rq];
+                  ay += S[s * ND + k] * tgy[s * NQ2 + rq];
+                  ax += S[s * ND + k] * tgx[s * NQ2 + rq];
+                }
+            }
+          t2[o] = a;
+          if (GRAD)
+            {
+              t2dy[o] = ay;
+              t2dx[o] = ax;
+            }
+        }
+      __syncthreads();
+      for (int o = tid; o < T1; o += NT)
+        {
+          const int q = o % NQ, j = (o / NQ) % ND, k = o / (NQ * ND);
+          double    b = 0., bx = 0.;
+#pragma unroll
+          for (int r = 0; r < NQ; ++r)
+            {
+              b += S[r * ND + j] * t2[(k * NQ + r) * NQ + q];
+              if (GRAD)
+                {
+                  b += D[r * ND + j] * t2dy[(k * NQ + r) * NQ + q];
+                  bx += S[r * ND + j] * t2dx[(k * NQ + r) * NQ + q];
+                }
+            }
+          t1[o] = b;
+          if (GRAD)
+            t1d[o] = bx;
+        }
+      __syncthreads();
+      for (int o = tid; o < ND3; o += NT)
+        {
+          const int i = o % ND, kj = o / ND;
+          double    c = 0.;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            {
+              c += S[q * ND + i] * t1[kj * NQ + q];
+              if (GRAD)
+                c += D[q * ND + i] * t1d[kj * NQ + q];
+            }
+          out[o] = c;
+        }
+      __syncthreads();
+    }
+  };
+
+  // gather the (DEG+1)^3 x NC local values of cell (cx,cy,cz); dof = node*NC+c.
+  // RESOLVE: constrained entries read as zero (read_dof_values), else plain.
+  template <int DEG, int NC, int NT, bool RESOLVE>
+  __device__ void gather_cell(const double *__restrict__ vec, double *loc, const int cx,
+                              const int cy, const int cz, const int nnx, const int nny,
+                              const int nnz, const uint32_t mask)
+  {
+    constexpr int ND = DEG + 1, ND3 = ND * ND * ND;
+    for (int o = threadIdx.x; o < ND3 * NC; o += NT)
+      {
+        const int  c = o % NC, l = o / NC;
+        const int  i = l % ND, j = (l / ND) % ND, k = l / (ND * ND);
+        const int  I = cx * DEG + i, J = cy * DEG + j, K = cz * DEG + k;
+        const long node = I + (long)nnx * (J + (long)nny * K);
+        double     v    = vec[node * NC + c];
+        if (RESOLVE && on_constrained_face(I, J, K, nnx, nny, nnz, mask, NC == 1 ? 1 : 3, c))
+          v = 0.;
+        loc[c * ND3 + l] = v;
+      }
+  }
+
+  // distribute_local_to_global: atomic scatter-add, constrained rows skipped
+  template <int DEG, int NC, int NT>
+  __device__ void scatter_cell(double *__restrict__ vec, const double *loc, const int cx,
+                               const int cy, const int cz, const int nnx, const int nny,
+                               const int nnz, const uint32_t mask)
+  {
+    constexpr int ND = DEG + 1, ND3 = ND * ND * ND;
+    for (int o = threadIdx.x; o < ND3 * NC; o += NT)
+      {
+        const int  c = o % NC, l = o / NC;
+        const int  i = l % ND, j = (l / ND) % ND, k = l / (ND * ND);
+        const int  I = cx * DEG + i, J = cy * DEG + j, K = cz * DEG + k;
+        const long node = I + (long)nnx * (J + (long)nny * K);
+        if (!on_constrained_face(I, J, K, nnx, nny, nnz, mask, NC == 1 ? 1 : 3, c))
+          unsafeAtomicAdd(&vec[node * NC + c], loc[c * ND3 + l]);
+      }
+  }
+} // namespace adaflo_hip

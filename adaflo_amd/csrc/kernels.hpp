@@ -1,0 +1,77 @@
+// kernels.hpp -- internal launch interface between the C ABI (capi.hip) and the
+// kernel translation units.  All functions enqueue on ctx->stream and return a
+// hipError_t-like int (0 = ok).
+#pragma once
+#include "ctx.hpp"
+
+namespace adaflo_hip
+{
+  enum NSOp
+  {
+    OP_VMULT          = 0, // NavierStokesOps::vmult        include/adaflo/navier_stokes_matrix.h:36-41
+    OP_RESIDUAL       = 1,
+    OP_VMULT_VELOCITY = 2
+  };
+
+  constexpr int NLIN = 12; // dim + dim*dim doubles of linearisation state per q-point
+
+  struct NSArgs
+  {
+    BrickDev      brick;
+    NSDev         ns;
+    const double *src_u, *src_p, *old_u, *oldold_u;
+    double       *dst_u, *dst_p;
+    double       *lin;
+    const double *rho, *mu, *damp;
+    const double *tab;
+    long          n_cells;
+  };
+
+  // generic cell kernels (ns_generic.hip)
+  int launch_ns_cell_generic(adaflo_ctx *ctx, int op, const NSArgs &args);
+
+  struct ScalarArgs
+  {
+    BrickDev      brick;
+    NSDev         ns;
+    const double *src;
+    double       *dst;
+    const double *coef_q; // per-q coefficient array in generic layout [cell][q] or nullptr
+    const double *tab;
+    long          n_cells;
+    int           mode;
+    int           nq_u3; // number of q-points of quad_index_u per cell ("mid-cell" sampling)
+  };
+  enum ScalarMode
+  {
+    SC_DIVERGENCE = 0,       // local_divergence              :920-961
+    SC_DIVERGENCE_VISC,      //   weight_by_viscosity
+    SC_POISSON_VARIABLE,     // local_pressure_poisson, variable rho at quad_u :984-1000
+    SC_POISSON_CELL,         // local_pressure_poisson, per-cell coefficient at quad_p :1002-1031
+    SC_MASS,                 // local_pressure_mass           :1036-1071
+    SC_MASS_WEIGHT,          // local_pressure_mass_weight    :1075-1095
+    SC_CONVDIFF              // local_pressure_convdiff       :1099-1140
+  };
+  int launch_ns_scalar_generic(adaflo_ctx *ctx, const ScalarArgs &args);
+
+  // vector helpers (vector_ops.hip)
+  // dst = constrained ? sign*src : 0  (fuses `dst = 0` with the constrained-row
+  // fix-up of source/navier_stokes_matrix.cc:229,247-256)
+  int launch_prepare_dst(adaflo_ctx *ctx, double *dst, const double *src, long n_nodes, int ncomp,
+                         int nnx, int nny, int nnz, uint32_t mask, double sign, bool zero_rest);
+  // v -= (w.v) * inv * modes   (apply_pressure_average_projection :191-205)
+  int launch_mean_projection(adaflo_ctx *ctx, double *v, const double *w, const double *modes,
+                             long n, double inv);
+  int launch_sadd(adaflo_ctx *ctx, double *x, double a, const double *y, long n); // x = a*x + y
+  int launch_fill(adaflo_ctx *ctx, double *x, double v, long n);
+  // canonical [cell][q][comp] <-> generic [cell][comp][q]
+  int launch_transpose_state(adaflo_ctx *ctx, double *dst, const double *src, long n_cells, int nq,
+                             int ncomp, bool to_generic);
+  double host_dot(adaflo_ctx *ctx, const double *a, const double *b, long n);
+
+  // specialised 3D Q2/Q1 sweep kernel (ns_q2.hip)
+  bool q2_supported(const adaflo_ctx *ctx);
+  int  q2_prepare_state(adaflo_ctx *ctx);
+  int  launch_ns_vmult_q2(adaflo_ctx *ctx, int op, double *dst_u, double *dst_p,
+                          const double *src_u, const double *src_p);
+} // namespace adaflo_hip

@@ -1,0 +1,481 @@
+// ns_generic.hip -- generic-degree Navier-Stokes cell kernels (one workgroup per cell).
+//
+// Restates adaflo::NavierStokesMatrix<dim>::local_operation
+// (source/navier_stokes_matrix.cc:601-916) and the scalar sub-block kernels
+// local_divergence / local_pressure_* (:920-1140) for a structured brick, any
+// Taylor-Hood degree k in {2..5}.  The specialised Q2/Q1 streaming kernel lives
+// in ns_q2.hip; this file is the reference-shaped fallback for every other
+// degree and for the operators that are not on the headline path.
+#include "kernels.hpp"
+
+namespace adaflo_hip
+{
+  template <int K>
+  struct NSLayout
+  {
+    static constexpr int NDU = K + 1, NDP = K, NQ = K + 1;
+    static constexpr int NDU3 = NDU * NDU * NDU, NDP3 = NDP * NDP * NDP, NQ3 = NQ * NQ * NQ;
+    static constexpr int TAB = 2 * NQ * NDU + 2 * NQ * NDP + NQ;
+    static constexpr int TABP = (TAB + 1) & ~1;
+  };
+
+  template <int K, int NT>
+  constexpr size_t ns_lds_doubles(const bool residual)
+  {
+    using L = NSLayout<K>;
+    size_t n = L::TABP + 3 * L::NDU3 + L::NDP3 + 3 * L::NQ3 + 9 * L::NQ3 + L::NQ3 +
+               SumFac<L::NDU, L::NQ, NT>::TMP;
+    if (residual)
+      n += 2 * (3 * L::NQ3 + 9 * L::NQ3);
+    return n;
+  }
+
+  template <int K, int OP, int NT>
+  __global__ __launch_bounds__(NT) void ns_cell_kernel(const NSArgs a)
+  {
+    using L   = NSLayout<K>;
+    using SFU = SumFac<L::NDU, L::NQ, NT>;
+    using SFP = SumFac<L::NDP, L::NQ, NT>;
+    constexpr int NQ = L::NQ, NQ3 = L::NQ3, NDU3 = L::NDU3, NDP3 = L::NDP3;
+    constexpr bool RES = OP == OP_RESIDUAL;
+
+    extern __shared__ double lds[];
+    double *S_u = lds, *D_u = S_u + NQ * L::NDU, *S_p = D_u + NQ * L::NDU, *D_p = S_p + NQ * L::NDP,
+           *wq = D_p + NQ * L::NDP;
+    double *ul = lds + L::TABP, *pl = ul + 3 * NDU3, *vu = pl + NDP3, *gu = vu + 3 * NQ3,
+           *vp = gu + 9 * NQ3, *tmp = vp + NQ3;
+    double *vo = tmp + SFU::TMP, *go = vo + 3 * NQ3, *voo = go + 9 * NQ3, *goo = voo + 3 * NQ3;
+
+    const int tid = threadIdx.x;
+    for (int o = tid; o < L::TAB; o += NT)
+      lds[o] = a.tab[o];
+
+    const long c   = xcd_remap(blockIdx.x, a.n_cells);
+    const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
+    const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
+    const int  nux = K * ncx + 1, nuy = K * ncy + 1, nuz = K * ncz + 1;
+    const int  npx = (K - 1) * ncx + 1, npy = (K - 1) * ncy + 1, npz = (K - 1) * ncz + 1;
+
+    const NSDev &P = a.ns;
+
+    // :662-667 velocity: plain read for the residual, constraints resolved otherwise
+    gather_cell<K, 3, NT, !RES>(a.src_u, ul, cx, cy, cz, nux, nuy, nuz, a.brick.con_u);
+    if (OP != OP_VMULT_VELOCITY)
+      gather_cell<K - 1, 1, NT, !RES>(a.src_p, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
+    __syncthreads();
+
+    // :668-671
+    for (int d = 0; d < 3; ++d)
+      SFU::template evaluate<true, true>(S_u, D_u, ul + d * NDU3, vu + d * NQ3, gu + (3 * d + 0) * NQ3,
+                                         gu + (3 * d + 1) * NQ3, gu + (3 * d + 2) * NQ3, tmp);
+    // :688-697
+    if (OP != OP_VMULT_VELOCITY)
+      SFP::template evaluate<true, false>(S_p, D_p, pl, vp, nullptr, nullptr, nullptr, tmp);
+
+    // :673-686 old solutions for the residual
+    if (RES && P.physical_type == ADAFLO_INCOMPRESSIBLE)
+      {
+        gather_cell<K, 3, NT, false>(a.old_u, ul, cx, cy, cz, nux, nuy, nuz, 0u);
+        __syncthreads();
+        for (int d = 0; d < 3; ++d)
+          SFU::template evaluate<true, true>(S_u, D_u, ul + d * NDU3, vo + d * NQ3,
+                                             go + (3 * d + 0) * NQ3, go + (3 * d + 1) * NQ3,
+                                             go + (3 * d + 2) * NQ3, tmp);
+        gather_cell<K, 3, NT, false>(a.oldold_u, ul, cx, cy, cz, nux, nuy, nuz, 0u);
+        __syncthreads();
+        for (int d = 0; d < 3; ++d)
+          SFU::template evaluate<true, true>(S_u, D_u, ul + d * NDU3, voo + d * NQ3,
+                                             goo + (3 * d + 0) * NQ3, goo + (3 * d + 1) * NQ3,
+                                             goo + (3 * d + 2) * NQ3, tmp);
+      }
+
+    // :621-653
+    const double w0   = P.physical_type == ADAFLO_INCOMPRESSIBLE ? P.weight : 0.;
+    const double tau1 = P.tau1, beta = P.beta;
+    const bool   stokes      = P.physical_type == ADAFLO_STOKES;
+    const bool   need_extrap = P.linearization == ADAFLO_PROJECTION ||
+                             P.linearization == ADAFLO_COUPLED_VELOCITY_SEMI_IMPLICIT ||
+                             P.linearization == ADAFLO_COUPLED_VELOCITY_EXPLICIT;
+    const double ih[3] = {1. / a.brick.h[0], 1. / a.brick.h[1], 1. / a.brick.h[2]};
+    const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
+    double      *lin   = a.lin ? a.lin + (size_t)c * NLIN * NQ3 : nullptr;
+
+    // :702-893 quadrature-point loop
+    for (int q = tid; q < NQ3; q += NT)
+      {
+        const int    qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
+        const double jxw = det * wq[qx] * wq[qy] * wq[qz];
+        double       g[3][3], val[3], conv[3] = {0., 0., 0.};
+        for (int d = 0; d < 3; ++d)
+          {
+            val[d] = vu[d * NQ3 + q];
+            for (int e = 0; e < 3; ++e)
+              g[d][e] = gu[(3 * d + e) * NQ3 + q] * ih[e];
+          }
+        const double div = g[0][0] + g[1][1] + g[2][2];
+        if (!stokes)
+          {
+            const double rho = a.rho ? a.rho[(size_t)c * NQ3 + q] : P.density;
+            for (int d = 0; d < 3; ++d)
+              conv[d] = val[d] * w0;
+            if (RES)
+              {
+                if (P.physical_type != ADAFLO_INCOMPRESSIBLE_STATIONARY)
+                  for (int d = 0; d < 3; ++d)
+                    conv[d] += vo[d * NQ3 + q] * P.weight_old + voo[d * NQ3 + q] * P.weight_old_old;
+                if (need_extrap)
+                  {
+                    double og[3][3], ov[3];
+                    for (int d = 0; d < 3; ++d)
+                      {
+                        for (int e = 0; e < 3; ++e)
+                          og[d][e] = (go[(3 * d + e) * NQ3 + q] * P.extrap_old +
+                                      goo[(3 * d + e) * NQ3 + q] * P.extrap_old_old) * ih[e];
+                        ov[d] = vo[d * NQ3 + q] * P.extrap_old + voo[d * NQ3 + q] * P.extrap_old_old;
+                      }
+                    const double ediv = og[0][0] + og[1][1] + og[2][2];
+                    if (P.linearization == ADAFLO_COUPLED_VELOCITY_EXPLICIT)
+                      for (int d = 0; d < 3; ++d)
+                        {
+                          double res = beta * ediv * ov[d];
+                          for (int e = 0; e < 3; ++e)
+                            res += ov[e] * og[d][e];
+                          conv[d] += tau1 * res;
+                        }
+                    else
+                      {
+                        for (int d = 0; d < 3; ++d)
+                          {
+                            double res = beta * ediv * val[d];
+                            for (int e = 0; e < 3; ++e)
+                              res += ov[e] * g[d][e];
+                            conv[d] += tau1 * res;
+                            lin[d * NQ3 + q] = ov[d];
+                          }
+                        lin[3 * NQ3 + q] = ediv;
+                      }
+                  }
+                else
+                  {
+                    for (int d = 0; d < 3; ++d)
+                      {
+                        double res = beta * div * val[d];
+                        for (int e = 0; e < 3; ++e)
+                          res += val[e] * g[d][e];
+                        conv[d] += tau1 * res;
+                        lin[d * NQ3 + q] = val[d];
+                      }
+                    if (P.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON)
+                      for (int d = 0; d < 3; ++d)
+                        for (int e = 0; e < 3; ++e)
+                          lin[(3 + 3 * d + e) * NQ3 + q] = g[d][e];
+                    else
+                      lin[3 * NQ3 + q] = div;
+                  }
+              }
+            else if (P.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON)
+              {
+                double lu[3], lg[3][3];
+                for (int d = 0; d < 3; ++d)
+                  {
+                    lu[d] = lin[d * NQ3 + q];
+                    for (int e = 0; e < 3; ++e)
+                      lg[d][e] = lin[(3 + 3 * d + e) * NQ3 + q];
+                  }
+                const double f1 = beta * div, f2 = beta * (lg[0][0] + lg[1][1] + lg[2][2]);
+                for (int d = 0; d < 3; ++d)
+                  {
+                    double res = f1 * lu[d] + f2 * val[d];
+                    for (int e = 0; e < 3; ++e)
+                      res += lu[e] * g[d][e] + val[e] * lg[d][e];
+                    conv[d] += tau1 * res;
+                  }
+              }
+            else if (P.linearization != ADAFLO_COUPLED_VELOCITY_EXPLICIT)
+              {
+                double lu[3];
+                for (int d = 0; d < 3; ++d)
+                  lu[d] = lin[d * NQ3 + q];
+                const double ldiv = lin[3 * NQ3 + q];
+                for (int d = 0; d < 3; ++d)
+                  {
+                    double res = beta * ldiv * val[d];
+                    for (int e = 0; e < 3; ++e)
+                      res += lu[e] * g[d][e];
+                    conv[d] += tau1 * res;
+                  }
+              }
+            const double damping = a.damp ? a.damp[(size_t)c * NQ3 + q] : P.damping;
+            for (int d = 0; d < 3; ++d)
+              conv[d] = conv[d] * rho - damping * val[d];
+          }
+        const double tmu = (a.mu ? a.mu[(size_t)c * NQ3 + q] : P.viscosity) * tau1;
+        double       pres = 0.;
+        if (OP != OP_VMULT_VELOCITY)
+          {
+            pres  = vp[q];
+            vp[q] = -div * jxw;
+          }
+        for (int d = 0; d < 3; ++d)
+          for (int e = d + 1; e < 3; ++e)
+            {
+              const double sym = tmu * (g[d][e] + g[e][d]);
+              g[d][e] = g[e][d] = sym;
+            }
+        for (int d = 0; d < 3; ++d)
+          {
+            g[d][d] = 2. * tmu * g[d][d] + P.tau_grad_div * div;
+            if (OP != OP_VMULT_VELOCITY)
+              g[d][d] -= pres;
+          }
+        for (int d = 0; d < 3; ++d)
+          {
+            vu[d * NQ3 + q] = conv[d] * jxw; // zero for Stokes: same result as skipping values
+            for (int e = 0; e < 3; ++e)
+              gu[(3 * d + e) * NQ3 + q] = g[d][e] * (jxw * ih[e]);
+          }
+      }
+    __syncthreads();
+
+    // :897-907
+    for (int d = 0; d < 3; ++d)
+      SFU::template integrate<true, true>(S_u, D_u, vu + d * NQ3, gu + (3 * d + 0) * NQ3,
+                                          gu + (3 * d + 1) * NQ3, gu + (3 * d + 2) * NQ3,
+                                          ul + d * NDU3, tmp);
+    scatter_cell<K, 3, NT>(a.dst_u, ul, cx, cy, cz, nux, nuy, nuz, a.brick.con_u);
+    if (OP != OP_VMULT_VELOCITY && P.linearization != ADAFLO_PROJECTION)
+      {
+        SFP::template integrate<true, false>(S_p, D_p, vp, nullptr, nullptr, nullptr, pl, tmp);
+        scatter_cell<K - 1, 1, NT>(a.dst_p, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
+      }
+  }
+
+  template <int K, int NT>
+  static int launch_k(adaflo_ctx *ctx, const int op, const NSArgs &args)
+  {
+    const dim3 grid((unsigned)args.n_cells), block(NT);
+    const size_t lds = sizeof(double) * ns_lds_doubles<K, NT>(op == OP_RESIDUAL);
+    hipError_t   err = hipSuccess;
+#define LAUNCH(OPV)                                                                              \
+  {                                                                                              \
+    if (lds > 64 * 1024)                                                                         \
+      err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_cell_kernel<K, OPV, NT>),     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+    if (err == hipSuccess)                                                                       \
+      hipLaunchKernelGGL((ns_cell_kernel<K, OPV, NT>), grid, block, lds, ctx->stream, args);     \
+  }
+    switch (op)
+      {
+        case OP_VMULT:
+          LAUNCH(OP_VMULT);
+          break;
+        case OP_RESIDUAL:
+          LAUNCH(OP_RESIDUAL);
+          break;
+        case OP_VMULT_VELOCITY:
+          LAUNCH(OP_VMULT_VELOCITY);
+          break;
+        default:
+          return ADAFLO_EINVAL;
+      }
+#undef LAUNCH
+    if (err == hipSuccess)
+      err = hipGetLastError();
+    return err == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+
+  int launch_ns_cell_generic(adaflo_ctx *ctx, const int op, const NSArgs &args)
+  {
+    // EXPAND_OPERATIONS, source/navier_stokes_matrix.cc:64-82 (degree_p = k-1)
+    switch (ctx->k)
+      {
+        case 2:
+          return launch_k<2, 64>(ctx, op, args);
+        case 3:
+          return launch_k<3, 64>(ctx, op, args);
+        case 4:
+          return launch_k<4, 128>(ctx, op, args);
+        case 5:
+          return launch_k<5, 256>(ctx, op, args);
+        default:
+          return ADAFLO_EUNSUPPORTED;
+      }
+  }
+
+  // ------------------------------------------------------------------------
+  // scalar sub-block kernels
+  // ------------------------------------------------------------------------
+  template <int K, bool QU>
+  struct ScLayout
+  {
+    static constexpr int NDU = K + 1, NDP = K, NQ = QU ? K + 1 : K;
+    static constexpr int NDU3 = NDU * NDU * NDU, NDP3 = NDP * NDP * NDP, NQ3 = NQ * NQ * NQ;
+  };
+
+  template <int K, bool QU, int NT>
+  constexpr size_t sc_lds_doubles()
+  {
+    using L = ScLayout<K, QU>;
+    return NSLayout<K>::TABP + 3 * L::NDU3 + L::NDP3 + 9 * L::NQ3 + 4 * L::NQ3 +
+           SumFac<L::NDU, L::NQ, NT>::TMP;
+  }
+
+  // QU: quadrature = quad_index_u (k+1 points, table layout of NSLayout) else
+  // quad_index_p (k points, table [S_pp D_pp w_pp])
+  template <int K, bool QU, int NT>
+  __global__ __launch_bounds__(NT) void ns_scalar_kernel(const ScalarArgs a)
+  {
+    using L   = ScLayout<K, QU>;
+    using SFU = SumFac<L::NDU, L::NQ, NT>;
+    using SFP = SumFac<L::NDP, L::NQ, NT>;
+    constexpr int NQ = L::NQ, NQ3 = L::NQ3, NDU3 = L::NDU3, NDP3 = L::NDP3;
+
+    extern __shared__ double lds[];
+    double *S_u = lds, *D_u = S_u + NQ * L::NDU;
+    double *S_p = QU ? D_u + NQ * L::NDU : lds, *D_p = S_p + NQ * L::NDP, *wq = D_p + NQ * L::NDP;
+    double *ul = lds + NSLayout<K>::TABP, *pl = ul + 3 * NDU3, *gu = pl + NDP3, *vp = gu + 9 * NQ3,
+           *gp = vp + NQ3, *tmp = gp + 3 * NQ3;
+
+    const int tid  = threadIdx.x;
+    const int ntab = QU ? NSLayout<K>::TAB : (2 * NQ * L::NDP + NQ);
+    for (int o = tid; o < ntab; o += NT)
+      lds[o] = a.tab[o];
+
+    const long c   = xcd_remap(blockIdx.x, a.n_cells);
+    const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
+    const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
+    const int  nux = K * ncx + 1, nuy = K * ncy + 1, nuz = K * ncz + 1;
+    const int  npx = (K - 1) * ncx + 1, npy = (K - 1) * ncy + 1, npz = (K - 1) * ncz + 1;
+    const NSDev &P = a.ns;
+    const double ih[3] = {1. / a.brick.h[0], 1. / a.brick.h[1], 1. / a.brick.h[2]};
+    const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
+    const int    mode  = a.mode;
+
+    if (mode == SC_DIVERGENCE || mode == SC_DIVERGENCE_VISC)
+      {
+        // :935-939: plain read for the projection scheme
+        if (P.linearization == ADAFLO_PROJECTION)
+          gather_cell<K, 3, NT, false>(a.src, ul, cx, cy, cz, nux, nuy, nuz, 0u);
+        else
+          gather_cell<K, 3, NT, true>(a.src, ul, cx, cy, cz, nux, nuy, nuz, a.brick.con_u);
+        __syncthreads();
+        if (QU)
+          for (int d = 0; d < 3; ++d)
+            SFU::template evaluate<false, true>(S_u, D_u, ul + d * NDU3, nullptr,
+                                                gu + (3 * d + 0) * NQ3, gu + (3 * d + 1) * NQ3,
+                                                gu + (3 * d + 2) * NQ3, tmp);
+        for (int q = tid; q < NQ3; q += NT)
+          {
+            const int    qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
+            const double jxw = det * wq[qx] * wq[qy] * wq[qz];
+            const double div = gu[0 * NQ3 + q] * ih[0] + gu[4 * NQ3 + q] * ih[1] + gu[8 * NQ3 + q] * ih[2];
+            const double w   = mode == SC_DIVERGENCE_VISC ?
+                                 (a.coef_q ? -a.coef_q[(size_t)c * NQ3 + q] : -P.viscosity) :
+                                 -1.;
+            vp[q] = w * div * jxw;
+          }
+        __syncthreads();
+        SFP::template integrate<true, false>(S_p, D_p, vp, nullptr, nullptr, nullptr, pl, tmp);
+        scatter_cell<K - 1, 1, NT>(a.dst, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
+        return;
+      }
+
+    // pressure -> pressure operators
+    const bool need_val  = mode == SC_MASS;
+    const bool need_grad = mode == SC_POISSON_VARIABLE || mode == SC_POISSON_CELL || mode == SC_CONVDIFF;
+    if (mode != SC_MASS_WEIGHT)
+      {
+        gather_cell<K - 1, 1, NT, true>(a.src, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
+        __syncthreads();
+        if (need_grad)
+          SFP::template evaluate<false, true>(S_p, D_p, pl, nullptr, gp, gp + NQ3, gp + 2 * NQ3, tmp);
+        else
+          SFP::template evaluate<true, false>(S_p, D_p, pl, vp, nullptr, nullptr, nullptr, tmp);
+      }
+    // per-cell coefficient ("mid-cell" sampling at q-index n_q/2 of quad_index_u,
+    // source/navier_stokes_matrix.cc:1016,1057,1124)
+    double cell_coef = 1.;
+    const size_t mid = (size_t)c * a.nq_u3 + a.nq_u3 / 2;
+    if (mode == SC_POISSON_CELL)
+      {
+        const double rho = a.coef_q ? a.coef_q[mid] : fmin(P.density, P.density + P.density_diff);
+        cell_coef = P.physical_type == ADAFLO_INCOMPRESSIBLE_STATIONARY ? 1. : 1. / (P.weight * rho);
+      }
+    else if (mode == SC_MASS)
+      {
+        const double mu = a.coef_q ? a.coef_q[mid] : P.viscosity;
+        cell_coef = (P.linearization == ADAFLO_PROJECTION ||
+                     P.physical_type == ADAFLO_INCOMPRESSIBLE_STATIONARY) ?
+                      1. :
+                      1. / (mu + P.tau_grad_div);
+      }
+    else if (mode == SC_CONVDIFF)
+      cell_coef = a.coef_q ? a.coef_q[mid] : P.viscosity;
+
+    for (int q = tid; q < NQ3; q += NT)
+      {
+        const int    qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
+        const double jxw = det * wq[qx] * wq[qy] * wq[qz];
+        if (mode == SC_MASS_WEIGHT)
+          vp[q] = jxw;
+        else if (need_val)
+          vp[q] *= cell_coef * jxw;
+        else
+          {
+            double cf = cell_coef;
+            if (mode == SC_POISSON_VARIABLE)
+              cf = 1. / (P.weight * a.coef_q[(size_t)c * NQ3 + q]);
+            for (int e = 0; e < 3; ++e)
+              gp[e * NQ3 + q] *= cf * jxw * ih[e] * ih[e];
+          }
+      }
+    __syncthreads();
+    if (need_grad)
+      SFP::template integrate<false, true>(S_p, D_p, nullptr, gp, gp + NQ3, gp + 2 * NQ3, pl, tmp);
+    else
+      SFP::template integrate<true, false>(S_p, D_p, vp, nullptr, nullptr, nullptr, pl, tmp);
+    scatter_cell<K - 1, 1, NT>(a.dst, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
+  }
+
+  template <int K, int NT>
+  static int launch_sc(adaflo_ctx *ctx, const ScalarArgs &args)
+  {
+    const dim3 grid((unsigned)args.n_cells), block(NT);
+    const bool qu = args.mode == SC_DIVERGENCE || args.mode == SC_DIVERGENCE_VISC ||
+                    args.mode == SC_POISSON_VARIABLE || args.mode == SC_CONVDIFF;
+    hipError_t err = hipSuccess;
+    if (qu)
+      {
+        const size_t lds = sizeof(double) * sc_lds_doubles<K, true, NT>();
+        if (lds > 64 * 1024)
+          err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_scalar_kernel<K, true, NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ns_scalar_kernel<K, true, NT>), grid, block, lds, ctx->stream, args);
+      }
+    else
+      {
+        const size_t lds = sizeof(double) * sc_lds_doubles<K, false, NT>();
+        hipLaunchKernelGGL((ns_scalar_kernel<K, false, NT>), grid, block, lds, ctx->stream, args);
+      }
+    if (err == hipSuccess)
+      err = hipGetLastError();
+    return err == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+
+  int launch_ns_scalar_generic(adaflo_ctx *ctx, const ScalarArgs &args)
+  {
+    switch (ctx->k)
+      {
+        case 2:
+          return launch_sc<2, 64>(ctx, args);
+        case 3:
+          return launch_sc<3, 64>(ctx, args);
+        case 4:
+          return launch_sc<4, 128>(ctx, args);
+        case 5:
+          return launch_sc<5, 256>(ctx, args);
+        default:
+          return ADAFLO_EUNSUPPORTED;
+      }
+  }
+} // namespace adaflo_hip

@@ -1,0 +1,215 @@
+// vector_ops.hip -- whole-vector helper kernels around the cell loops:
+// zero + constrained-row fix-up, pressure-mean projection, state re-layout.
+#include "kernels.hpp"
+
+namespace adaflo_hip
+{
+  namespace
+  {
+    constexpr int VT = 256;
+
+    inline unsigned grid_for(const long n, const int per_thread = 1)
+    {
+      long b = (n + (long)VT * per_thread - 1) / ((long)VT * per_thread);
+      if (b < 1)
+        b = 1;
+      if (b > 256 * 16)
+        b = 256 * 16; // grid-stride beyond that
+      return (unsigned)b;
+    }
+
+    // dst = constrained ? sign*src : (zero_rest ? 0 : dst)
+    // source/navier_stokes_matrix.cc:229 (dst = 0) + :247-256 (constrained rows)
+    __global__ __launch_bounds__(VT) void prepare_dst_kernel(double *__restrict__ dst,
+                                                             const double *__restrict__ src,
+                                                             const long n_nodes, const int ncomp,
+                                                             const int nnx, const int nny,
+                                                             const int nnz, const uint32_t mask,
+                                                             const double sign, const bool zero_rest)
+    {
+      const long n = n_nodes * ncomp;
+      for (long i = blockIdx.x * (long)VT + threadIdx.x; i < n; i += (long)gridDim.x * VT)
+        {
+          const long node = i / ncomp;
+          const int  c    = (int)(i - node * ncomp);
+          const int  I = node % nnx, J = (node / nnx) % nny, K = node / ((long)nnx * nny);
+          if (mask != 0u && on_constrained_face(I, J, K, nnx, nny, nnz, mask, ncomp == 1 ? 1 : 3, c))
+            dst[i] = sign * src[i];
+          else if (zero_rest)
+            dst[i] = 0.;
+        }
+    }
+
+    __global__ __launch_bounds__(VT) void dot_partial_kernel(const double *__restrict__ a,
+                                                             const double *__restrict__ b,
+                                                             const long n, double *__restrict__ part)
+    {
+      __shared__ double red[VT / 64];
+      double            s = 0.;
+      for (long i = blockIdx.x * (long)VT + threadIdx.x; i < n; i += (long)gridDim.x * VT)
+        s += a[i] * b[i];
+      for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_down(s, off, 64);
+      if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = s;
+      __syncthreads();
+      if (threadIdx.x == 0)
+        {
+          double t = 0.;
+          for (int w = 0; w < VT / 64; ++w)
+            t += red[w];
+          part[blockIdx.x] = t;
+        }
+    }
+
+    // single block: result[0] = sum(part[0..np))  (fixed order -> deterministic)
+    __global__ __launch_bounds__(VT) void dot_final_kernel(const double *__restrict__ part,
+                                                           const int np, double *__restrict__ result)
+    {
+      __shared__ double red[VT / 64];
+      double            s = 0.;
+      for (int i = threadIdx.x; i < np; i += VT)
+        s += part[i];
+      for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_down(s, off, 64);
+      if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = s;
+      __syncthreads();
+      if (threadIdx.x == 0)
+        {
+          double t = 0.;
+          for (int w = 0; w < VT / 64; ++w)
+            t += red[w];
+          result[0] = t;
+        }
+    }
+
+    // v -= (*prod) * inv * modes
+    __global__ __launch_bounds__(VT) void project_kernel(double *__restrict__ v,
+                                                         const double *__restrict__ modes,
+                                                         const double *__restrict__ prod,
+                                                         const double inv, const long n)
+    {
+      const double f = prod[0] * inv;
+      for (long i = blockIdx.x * (long)VT + threadIdx.x; i < n; i += (long)gridDim.x * VT)
+        v[i] -= f * modes[i];
+    }
+
+    __global__ __launch_bounds__(VT) void sadd_kernel(double *__restrict__ x, const double a,
+                                                      const double *__restrict__ y, const long n)
+    {
+      for (long i = blockIdx.x * (long)VT + threadIdx.x; i < n; i += (long)gridDim.x * VT)
+        x[i] = a * x[i] + (y ? y[i] : 0.);
+    }
+
+    __global__ __launch_bounds__(VT) void fill_kernel(double *__restrict__ x, const double v,
+                                                      const long n)
+    {
+      for (long i = blockIdx.x * (long)VT + threadIdx.x; i < n; i += (long)gridDim.x * VT)
+        x[i] = v;
+    }
+
+    // to_generic: dst[cell][comp][q] = src[cell][q][comp]; else the inverse
+    __global__ __launch_bounds__(VT) void transpose_state_kernel(double *__restrict__ dst,
+                                                                 const double *__restrict__ src,
+                                                                 const long n_cells, const int nq,
+                                                                 const int ncomp,
+                                                                 const bool to_generic)
+    {
+      const long per = (long)nq * ncomp, n = n_cells * per;
+      for (long i = blockIdx.x * (long)VT + threadIdx.x; i < n; i += (long)gridDim.x * VT)
+        {
+          const long cell = i / per;
+          const int  r    = (int)(i - cell * per);
+          if (to_generic)
+            {
+              const int comp = r / nq, q = r % nq; // i indexes dst
+              dst[i]         = src[cell * per + (long)q * ncomp + comp];
+            }
+          else
+            {
+              const int q = r / ncomp, comp = r % ncomp; // i indexes dst
+              dst[i]      = src[cell * per + (long)comp * nq + q];
+            }
+        }
+    }
+
+    int check()
+    {
+      return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+    }
+  } // namespace
+
+  int launch_prepare_dst(adaflo_ctx *ctx, double *dst, const double *src, const long n_nodes,
+                         const int ncomp, const int nnx, const int nny, const int nnz,
+                         const uint32_t mask, const double sign, const bool zero_rest)
+  {
+    hipLaunchKernelGGL(prepare_dst_kernel, dim3(grid_for(n_nodes * ncomp)), dim3(VT), 0, ctx->stream,
+                       dst, src, n_nodes, ncomp, nnx, nny, nnz, mask, sign, zero_rest);
+    return check();
+  }
+
+  static int ensure_scratch(adaflo_ctx *ctx, const size_t count)
+  {
+    if (ctx->scratch_count >= count)
+      return 0;
+    if (ctx->d_scratch)
+      (void)hipFree(ctx->d_scratch);
+    if (hipMalloc(&ctx->d_scratch, count * sizeof(double)) != hipSuccess)
+      return ADAFLO_ENOMEM;
+    ctx->scratch_count = count;
+    return 0;
+  }
+
+  static int launch_dot(adaflo_ctx *ctx, const double *a, const double *b, const long n)
+  {
+    const unsigned nb = grid_for(n, 4);
+    if (int e = ensure_scratch(ctx, 256 * 16 + 8))
+      return e;
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(VT), 0, ctx->stream, a, b, n,
+                       ctx->d_scratch + 8);
+    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(VT), 0, ctx->stream, ctx->d_scratch + 8,
+                       (int)nb, ctx->d_scratch);
+    return check();
+  }
+
+  int launch_mean_projection(adaflo_ctx *ctx, double *v, const double *w, const double *modes,
+                             const long n, const double inv)
+  {
+    if (int e = launch_dot(ctx, w, v, n))
+      return e;
+    hipLaunchKernelGGL(project_kernel, dim3(grid_for(n)), dim3(VT), 0, ctx->stream, v, modes,
+                       ctx->d_scratch, inv, n);
+    return check();
+  }
+
+  double host_dot(adaflo_ctx *ctx, const double *a, const double *b, const long n)
+  {
+    double r = 0.;
+    if (launch_dot(ctx, a, b, n) != 0)
+      return 0.;
+    (void)hipMemcpyAsync(&r, ctx->d_scratch, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    return r;
+  }
+
+  int launch_sadd(adaflo_ctx *ctx, double *x, const double a, const double *y, const long n)
+  {
+    hipLaunchKernelGGL(sadd_kernel, dim3(grid_for(n)), dim3(VT), 0, ctx->stream, x, a, y, n);
+    return check();
+  }
+
+  int launch_fill(adaflo_ctx *ctx, double *x, const double v, const long n)
+  {
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(VT), 0, ctx->stream, x, v, n);
+    return check();
+  }
+
+  int launch_transpose_state(adaflo_ctx *ctx, double *dst, const double *src, const long n_cells,
+                             const int nq, const int ncomp, const bool to_generic)
+  {
+    hipLaunchKernelGGL(transpose_state_kernel, dim3(grid_for(n_cells * nq * ncomp)), dim3(VT), 0,
+                       ctx->stream, dst, src, n_cells, nq, ncomp, to_generic);
+    return check();
+  }
+} // namespace adaflo_hip

@@ -1,0 +1,227 @@
+"""Host-side mirror of adaflo::NavierStokesMatrix<dim>
+(include/adaflo/navier_stokes_matrix.h:44-282): same method names, argument
+meaning and error behaviour, forwarding to the C ABI (include/adaflo_hip.h).
+
+deal.II's MatrixFree<dim> is replaced by a structured-brick description
+(BrickMesh + boundary-face constraint sets)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .parameters import LINEARIZATIONS, PHYSICAL_TYPES
+from .vectors import BlockVector, DeviceVector
+
+
+class BrickMesh:
+    """ncell[d] hexahedra on [lower, upper]; faces numbered 2*d+side as deal.II's
+    GridGenerator::subdivided_hyper_rectangle(colorize=true) boundary ids."""
+
+    def __init__(self, ncell, lower, upper):
+        assert len(ncell) == 3, "the device engine is dim = 3"
+        self.ncell = [int(n) for n in ncell]
+        self.lower = [float(x) for x in lower]
+        self.upper = [float(x) for x in upper]
+        self.h = [(u - l) / n for u, l, n in zip(self.upper, self.lower, self.ncell)]
+
+    @property
+    def n_cells(self):
+        return int(np.prod(self.ncell))
+
+    def n_nodes(self, degree):
+        return int(np.prod([degree * n + 1 for n in self.ncell]))
+
+
+def face_mask(faces, ncomp=1, comps=None):
+    m = 0
+    for f in faces:
+        for c in range(ncomp):
+            if comps is None or c in comps:
+                m |= 1 << (ncomp * f + c) if ncomp > 1 else 1 << f
+    return m
+
+
+class NavierStokesMatrix:
+    """Operator object usable by any Krylov solver that needs `vmult(dst, src)`."""
+
+    def __init__(self, parameters, mesh, dirichlet_faces_u=range(6), constrained_faces_p=(),
+                 device=0, stream=None, ls_degree=0):
+        self.parameters = parameters
+        self.mesh = mesh
+        self._lib = _lib.load()
+        self._ctx = None
+        self._desc = _lib.BrickDesc()
+        d = self._desc
+        d.dim = 3
+        for i in range(3):
+            d.ncell[i] = mesh.ncell[i]
+            d.h[i] = mesh.h[i]
+            d.origin[i] = mesh.lower[i]
+        d.velocity_degree = parameters.velocity_degree
+        d.ls_degree = ls_degree
+        d.velocity_constrained = face_mask(dirichlet_faces_u, 3)
+        d.pressure_constrained = face_mask(constrained_faces_p, 1)
+        d.ls_constrained = 0
+        d.device = device
+        d.stream = stream
+        self.time_stepping = None
+
+    # -- lifetime -----------------------------------------------------------------------------
+    def initialize(self, time_stepping, pressure_average_fix):
+        """NavierStokesMatrix::initialize, source/navier_stokes_matrix.cc:85-168"""
+        self.clear()
+        self._desc.pressure_average_fix = int(bool(pressure_average_fix))
+        ctx = C.c_void_p()
+        code = self._lib.adaflo_ctx_create(C.byref(self._desc), C.byref(ctx))
+        if code != 0:
+            raise _lib.AdafloError("adaflo_ctx_create failed (%d): %s" % (
+                code, self._lib.adaflo_last_error(None).decode()))
+        self._ctx = ctx
+        self.time_stepping = time_stepping
+        self.update_parameters()
+
+    def clear(self):
+        if self._ctx is not None:
+            self._lib.adaflo_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.clear()
+        except Exception:
+            pass
+
+    def _require(self):
+        if self._ctx is None:
+            raise _lib.AdafloError("ExcNotInitialized: call initialize() first")
+        return self._ctx
+
+    def update_parameters(self):
+        """push FlowParameters + TimeStepping scalars (read at navier_stokes_matrix.cc:621-653)"""
+        ctx = self._require()
+        p, ts = self.parameters, self.time_stepping
+        if ts.tau2() != 0.0:
+            raise NotImplementedError("tau2 != 0 (navier_stokes_matrix.cc:629)")
+        q = _lib.NSParams()
+        q.physical_type = PHYSICAL_TYPES[p.physical_type]
+        q.linearization = LINEARIZATIONS[p.linearization]
+        q.beta = p.beta
+        q.tau_grad_div = p.tau_grad_div
+        q.density = p.density
+        q.viscosity = p.viscosity
+        q.damping = p.stored_damping
+        q.density_diff = p.density_diff
+        q.weight, q.weight_old, q.weight_old_old = ts.weight(), ts.weight_old(), ts.weight_old_old()
+        q.tau1 = ts.tau1()
+        q.extrap_old, q.extrap_old_old = ts.factor_extrapol_old, ts.factor_extrapol_old_old
+        _lib.check(ctx, self._lib.adaflo_ns_set_params(ctx, C.byref(q)))
+
+    # -- sizes / vectors ----------------------------------------------------------------------
+    def n_dofs_u(self):
+        return self._lib.adaflo_n_dofs_u(self._require())
+
+    def n_dofs_p(self):
+        return self._lib.adaflo_n_dofs_p(self._require())
+
+    def n_cells(self):
+        return self._lib.adaflo_n_cells(self._require())
+
+    def n_q_points(self):
+        return self._lib.adaflo_n_q_points_u(self._require())
+
+    def pressure_degree(self):
+        return self.parameters.velocity_degree - 1
+
+    def initialize_u_vector(self, values=None):
+        v = DeviceVector(self._require(), self.n_dofs_u())
+        v.set(np.zeros(v.n) if values is None else values)
+        return v
+
+    def initialize_p_vector(self, values=None):
+        v = DeviceVector(self._require(), self.n_dofs_p())
+        v.set(np.zeros(v.n) if values is None else values)
+        return v
+
+    def block_vector(self, u=None, p=None):
+        return BlockVector([self.initialize_u_vector(u), self.initialize_p_vector(p)])
+
+    def synchronize(self):
+        _lib.check(self._ctx, self._lib.adaflo_synchronize(self._require()))
+
+    def set_kernel_variant(self, variant):
+        _lib.check(self._ctx, self._lib.adaflo_set_kernel_variant(self._require(), variant))
+
+    # -- quadrature-point state ---------------------------------------------------------------
+    def set_linearization(self, lin):
+        """canonical [cell][q][dim+dim*dim] (navier_stokes_matrix.h:54-56)"""
+        ctx = self._require()
+        lin = np.ascontiguousarray(lin, dtype=np.float64)
+        assert lin.size == self.n_cells() * self.n_q_points() * 12
+        _lib.check(ctx, self._lib.adaflo_ns_set_linearization(ctx, lin.ctypes.data, 0))
+
+    def get_linearization(self):
+        ctx = self._require()
+        out = np.empty(self.n_cells() * self.n_q_points() * 12)
+        _lib.check(ctx, self._lib.adaflo_ns_get_linearization(ctx, out.ctypes.data, 0))
+        return out
+
+    def set_coefficients(self, rho=None, mu=None, damping=None):
+        ctx = self._require()
+        if rho is None:
+            _lib.check(ctx, self._lib.adaflo_ns_set_coefficients(ctx, None, None, None, 0))
+            return
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (rho, mu, damping)]
+        _lib.check(ctx, self._lib.adaflo_ns_set_coefficients(
+            ctx, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, 0))
+
+    def fix_linearization_point(self):
+        _lib.check(self._ctx, self._lib.adaflo_ns_fix_linearization_point(self._require()))
+
+    # -- the operator methods (navier_stokes_matrix.h:125-153) --------------------------------
+    def vmult(self, dst, src):
+        ctx = self._require()
+        _lib.check(ctx, self._lib.adaflo_ns_vmult(ctx, dst.block(0).ptr, dst.block(1).ptr,
+                                                  src.block(0).ptr, src.block(1).ptr))
+
+    def residual(self, residual_vector, src, user_rhs, solution_old, solution_old_old):
+        """solution_old / solution_old_old are constructor references in the reference
+        (navier_stokes_matrix.h:57-64); passed per call here."""
+        ctx = self._require()
+        ur = user_rhs.block(0).ptr if user_rhs is not None else None
+        pr = user_rhs.block(1).ptr if user_rhs is not None else None
+        _lib.check(ctx, self._lib.adaflo_ns_residual(
+            ctx, residual_vector.block(0).ptr, residual_vector.block(1).ptr, src.block(0).ptr,
+            src.block(1).ptr, ur, pr,
+            solution_old.block(0).ptr if solution_old is not None else None,
+            solution_old_old.block(0).ptr if solution_old_old is not None else None))
+
+    def velocity_vmult(self, dst, src):
+        ctx = self._require()
+        _lib.check(ctx, self._lib.adaflo_ns_velocity_vmult(ctx, dst.ptr, src.ptr))
+
+    def divergence_vmult_add(self, dst, src, weight_by_viscosity=False):
+        ctx = self._require()
+        _lib.check(ctx, self._lib.adaflo_ns_divergence_vmult_add(ctx, dst.ptr, src.ptr,
+                                                                 int(weight_by_viscosity)))
+
+    def pressure_poisson_vmult(self, dst, src):
+        ctx = self._require()
+        _lib.check(ctx, self._lib.adaflo_ns_pressure_poisson_vmult(ctx, dst.ptr, src.ptr))
+
+    def pressure_mass_vmult(self, dst, src):
+        ctx = self._require()
+        _lib.check(ctx, self._lib.adaflo_ns_pressure_mass_vmult(ctx, dst.ptr, src.ptr))
+
+    def pressure_convdiff_vmult(self, dst, src):
+        ctx = self._require()
+        _lib.check(ctx, self._lib.adaflo_ns_pressure_convdiff_vmult(ctx, dst.ptr, src.ptr))
+
+    def apply_pressure_average_projection(self, vector):
+        ctx = self._require()
+        _lib.check(ctx, self._lib.adaflo_ns_apply_pressure_average_projection(ctx, vector.ptr))
+
+    def get_matvec_statistics(self):
+        ctx = self._require()
+        n, s = C.c_uint(), C.c_double()
+        _lib.check(ctx, self._lib.adaflo_ns_get_matvec_statistics(ctx, C.byref(n), C.byref(s)))
+        return s.value, n.value

@@ -1,0 +1,178 @@
+/* adaflo_hip.h -- C ABI of the MI355X-native matrix-free operator engine.
+ *
+ * This is the drop-in boundary for adaflo's operator hot path.  The reference
+ * (kronbichler/adaflo) has no FFI layer; its seam is the C++ duck-typed
+ * operator interface required by deal.II's Krylov solvers
+ * (`void vmult(VectorType &dst, const VectorType &src) const`).  Every entry
+ * point below names the reference method it replaces (paths relative to the
+ * reference root).  INTEGRATION.md shows the deal.II-side adapter that forwards
+ * `NavierStokesMatrix<dim>::vmult` & friends to these functions.
+ *
+ * Conventions
+ *  - All functions return 0 on success, a negative ADAFLO_E* code on failure;
+ *    adaflo_last_error() returns a human-readable message.  No exceptions cross
+ *    the boundary (the reference throws deal.II exceptions instead).
+ *  - One context = one GPU + one HIP stream; like the reference operators
+ *    (mutable timers / array swaps, source/navier_stokes_matrix.cc:227,349-375)
+ *    a context is NOT re-entrant.
+ *  - All `double *` vector arguments are DEVICE pointers (hipMalloc / a
+ *    torch.cuda tensor's data_ptr) holding one deal.II
+ *    LinearAlgebra::distributed::Vector<double> block: a contiguous
+ *    double[n_dofs].  adaflo_malloc/adaflo_copy_* are provided so a host-only
+ *    caller (ctypes, the deal.II adapter) can stage vectors.
+ *  - Mesh: structured axis-aligned brick of ncell[0] x ncell[1] x ncell[2]
+ *    hexahedra of size h[d].  DoF numbering (documented, "not part of the
+ *    reference contract"):
+ *        nodes lexicographic over the brick (x fastest),
+ *        FE_Q(k) nodes per direction: k*ncell[d]+1 (Gauss-Lobatto support points),
+ *        velocity dof = node*dim + component (components interleaved per
+ *        node, as in deal.II's FESystem vectors), pressure dof = node,
+ *        level-set dof = node of FE_Q_iso_Q1(s): s*ncell[d]+1 per direction.
+ *    Cells are lexicographic c = cx + ncx*(cy + ncy*cz); quadrature points in
+ *    a cell lexicographic q = qx + n*(qy + n*qz).
+ *  - Quadrature-point operator state (the reference's public begin_*
+ *    accessors, include/adaflo/navier_stokes_matrix.h:162-180) crosses the
+ *    boundary in CANONICAL layout [cell][q][component]; the engine converts to
+ *    its internal streaming layout.
+ */
+#ifndef ADAFLO_HIP_H
+#define ADAFLO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct adaflo_ctx adaflo_ctx;
+
+enum
+{
+  ADAFLO_OK            = 0,
+  ADAFLO_EINVAL        = -1, /* bad argument / unsupported degree (reference: ExcNotImplemented) */
+  ADAFLO_ENOTINIT      = -2, /* reference: ExcNotInitialized */
+  ADAFLO_EHIP          = -3, /* HIP runtime error */
+  ADAFLO_ENOMEM        = -4,
+  ADAFLO_EUNSUPPORTED  = -5
+};
+
+/* FlowParameters::PhysicalType, include/adaflo/parameters.h:57-62 */
+enum { ADAFLO_INCOMPRESSIBLE = 0, ADAFLO_INCOMPRESSIBLE_STATIONARY = 1, ADAFLO_STOKES = 2 };
+/* FlowParameters::Linearization, include/adaflo/parameters.h:77-84 */
+enum
+{
+  ADAFLO_COUPLED_IMPLICIT_NEWTON        = 0,
+  ADAFLO_COUPLED_IMPLICIT_PICARD        = 1,
+  ADAFLO_COUPLED_VELOCITY_SEMI_IMPLICIT = 2,
+  ADAFLO_COUPLED_VELOCITY_EXPLICIT      = 3,
+  ADAFLO_PROJECTION                     = 4
+};
+
+/* Structured-brick descriptor: replaces what NavierStokesMatrix::initialize()
+ * pulls out of MatrixFree<dim> (dof indices, constrained dofs, mapping info),
+ * source/navier_stokes_matrix.cc:85-168 and source/navier_stokes.cc:396-502. */
+typedef struct
+{
+  int      dim;             /* 3 */
+  int      ncell[3];
+  double   h[3];
+  double   origin[3];
+  int      velocity_degree; /* k >= 2; pressure degree k-1 (Taylor-Hood) */
+  int      ls_degree;       /* s: FE_Q_iso_Q1(s) subdivisions; 0 = no level-set spaces */
+  /* homogeneous Dirichlet constraints by boundary face f = 2*d + side
+   * (deal.II hyper_rectangle boundary ids): bit (3*f + comp) for velocity,
+   * bit f for pressure / level set.                                          */
+  uint32_t velocity_constrained;
+  uint32_t pressure_constrained;
+  uint32_t ls_constrained;
+  int      pressure_average_fix; /* initialize(..., pressure_average_fix), :117-168 */
+  int      device;               /* HIP device ordinal */
+  void    *stream;               /* hipStream_t to run on, NULL = create one */
+} adaflo_brick_desc;
+
+/* The scalars local_operation reads, source/navier_stokes_matrix.cc:621-653,
+ * plus TimeStepping::{weight,weight_old,weight_old_old,tau1,extrapolate}
+ * (source/time_stepping.cc:123-200).                                         */
+typedef struct
+{
+  int    physical_type;
+  int    linearization;
+  double beta;           /* beta_convective_term_momentum_balance */
+  double tau_grad_div;
+  double density;
+  double viscosity;
+  double damping;        /* sign as stored by FlowParameters (flipped), parameters.cc:466-467 */
+  double density_diff;
+  double weight, weight_old, weight_old_old, tau1;
+  double extrap_old, extrap_old_old;
+} adaflo_ns_params;
+
+/* ---- context ------------------------------------------------------------ */
+int         adaflo_ctx_create(const adaflo_brick_desc *desc, adaflo_ctx **out);
+int         adaflo_ctx_destroy(adaflo_ctx *ctx);              /* NavierStokesMatrix::clear */
+const char *adaflo_last_error(const adaflo_ctx *ctx);         /* ctx may be NULL: last create error */
+int         adaflo_synchronize(adaflo_ctx *ctx);
+void       *adaflo_stream(adaflo_ctx *ctx);
+
+int64_t adaflo_n_cells(const adaflo_ctx *ctx);
+int64_t adaflo_n_dofs_u(const adaflo_ctx *ctx);               /* NavierStokesMatrix::n_dofs_u */
+int64_t adaflo_n_dofs_p(const adaflo_ctx *ctx);               /* NavierStokesMatrix::n_dofs_p */
+int64_t adaflo_n_dofs_ls(const adaflo_ctx *ctx);
+int     adaflo_n_q_points_u(const adaflo_ctx *ctx);           /* (k+1)^dim, quad_index_u */
+int     adaflo_n_q_points_ls(const adaflo_ctx *ctx);          /* (2s)^dim */
+
+/* ---- device memory helpers (for host-only callers) ---------------------- */
+int adaflo_malloc(adaflo_ctx *ctx, size_t bytes, void **dptr);
+int adaflo_free(adaflo_ctx *ctx, void *dptr);
+int adaflo_copy_h2d(adaflo_ctx *ctx, void *dst, const void *src, size_t bytes);
+int adaflo_copy_d2h(adaflo_ctx *ctx, void *dst, const void *src, size_t bytes);
+
+/* ---- Navier-Stokes operator state --------------------------------------- */
+int adaflo_ns_set_params(adaflo_ctx *ctx, const adaflo_ns_params *p);
+/* linearized_velocities (navier_stokes_matrix.h:54-56,178): canonical
+ * [cell][q][dim + dim*dim] = (u_lin[d], grad_lin[d][e]); host or device source. */
+int adaflo_ns_set_linearization(adaflo_ctx *ctx, const double *lin, int src_on_device);
+int adaflo_ns_get_linearization(adaflo_ctx *ctx, double *lin, int dst_on_device);
+/* begin_densities / begin_viscosities / begin_damping_coeff: canonical [cell][q];
+ * all NULL = constant coefficients (use_variable_coefficients() == false).      */
+int adaflo_ns_set_coefficients(adaflo_ctx *ctx, const double *rho, const double *mu,
+                               const double *damping, int src_on_device);
+int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx);       /* :1144-1152 */
+
+/* ---- Navier-Stokes operators (source/navier_stokes_matrix.cc) ----------- */
+/* vmult :221-262 */
+int adaflo_ns_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double *src_u,
+                    const double *src_p);
+/* residual :266-293; system_rhs is read-modify-written exactly like the
+ * reference (cell loop adds into it, then rhs = -rhs + user_rhs); user_* may be
+ * NULL (= 0); solution_old / solution_old_old velocity blocks are the
+ * references the reference's constructor takes (navier_stokes_matrix.h:57-64). */
+int adaflo_ns_residual(adaflo_ctx *ctx, double *rhs_u, double *rhs_p, const double *src_u,
+                       const double *src_p, const double *user_u, const double *user_p,
+                       const double *old_u, const double *old_old_u);
+/* velocity_vmult :337-382 */
+int adaflo_ns_velocity_vmult(adaflo_ctx *ctx, double *dst_u, const double *src_u);
+/* divergence_vmult_add :300-332 (dst NOT zeroed) */
+int adaflo_ns_divergence_vmult_add(adaflo_ctx *ctx, double *dst_p, const double *src_u,
+                                   int weight_by_viscosity);
+/* pressure_poisson_vmult :386-417 */
+int adaflo_ns_pressure_poisson_vmult(adaflo_ctx *ctx, double *dst_p, const double *src_p);
+/* pressure_mass_vmult :421-455 */
+int adaflo_ns_pressure_mass_vmult(adaflo_ctx *ctx, double *dst_p, const double *src_p);
+/* pressure_convdiff_vmult :459-483 */
+int adaflo_ns_pressure_convdiff_vmult(adaflo_ctx *ctx, double *dst_p, const double *src_p);
+/* apply_pressure_average_projection :191-205 */
+int adaflo_ns_apply_pressure_average_projection(adaflo_ctx *ctx, double *vec_p);
+/* get_matvec_statistics :1194-1206: number of vmult calls and accumulated wall
+ * seconds since the last query (resets the counters like the reference).      */
+int adaflo_ns_get_matvec_statistics(adaflo_ctx *ctx, unsigned *count, double *seconds);
+
+/* select the implementation of adaflo_ns_vmult: 0 = generic (any degree),
+ * 1 = auto (specialised kernels where available; default).                    */
+int adaflo_set_kernel_variant(adaflo_ctx *ctx, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,164 @@
+"""GPU parity tests: HIP engine (through the C ABI) vs the CPU oracle on identical
+seeded inputs.  Tolerance from BASELINE.json north_star: 1e-12 relative L2."""
+import numpy as np
+import pytest
+
+from common import Case, rel_l2
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def run_vmult(case, variant=0, coefficients=False):
+    src_u, src_p = case.random_u(), case.random_p()
+    lin = case.random_lin()
+    coef = case.random_coefficients() if coefficients else (None, None, None)
+    w, modes = case.weights_modes()
+    ref_u, ref_p = orc.ns_vmult(case.mesh, case.k, case.prm, src_u, src_p, case.con_u, case.con_p,
+                                lin=lin, rho=coef[0], mu=coef[1], damp=coef[2], weights=w, modes=modes)
+    op = case.engine()
+    op.set_kernel_variant(variant)
+    op.set_linearization(lin)
+    if coefficients:
+        op.set_coefficients(*coef)
+    src = op.block_vector(src_u, src_p)
+    dst = op.block_vector(np.full(case.n_u, 7.0), np.full(case.n_p, -3.0))  # must be overwritten
+    op.vmult(dst, src)
+    got_u, got_p = dst.numpy()
+    return rel_l2(got_u, ref_u), rel_l2(got_p, ref_p)
+
+
+@pytest.mark.parametrize("k,ncell", [(2, (4, 3, 5)), (3, (3, 2, 2)), (4, (2, 2, 3))])
+def test_vmult_newton_generic(k, ncell):
+    case = Case(ncell, k=k, upper=(1.0, 0.5, 2.0))
+    eu, ep = run_vmult(case, variant=0)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+@pytest.mark.parametrize("lin", [1, 2, 3, 4])
+def test_vmult_linearizations_generic(lin):
+    case = Case((3, 4, 2), k=2, linearization=lin, beta=1.0, tau_grad_div=0.3)
+    eu, ep = run_vmult(case, variant=0)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+@pytest.mark.parametrize("phys", [1, 2])
+def test_vmult_physical_types_generic(phys):
+    case = Case((3, 3, 3), k=2, physical_type=phys, viscosity=0.1)
+    eu, ep = run_vmult(case, variant=0)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+def test_vmult_variable_coefficients_generic():
+    case = Case((4, 4, 3), k=2, density_diff=0.5, damping=0.2)
+    eu, ep = run_vmult(case, variant=0, coefficients=True)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+def test_vmult_partial_constraints_generic():
+    # Dirichlet only on x-faces, pressure constrained on one face, no mean fix
+    case = Case((4, 3, 3), k=2, faces_u=[0, 1], faces_p=[3], pressure_average_fix=False)
+    eu, ep = run_vmult(case, variant=0)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+@pytest.mark.parametrize("lin", [0, 1, 2, 3])
+def test_residual_and_linearization_state(lin):
+    case = Case((3, 3, 4), k=2, linearization=lin, steps=3)
+    src_u, src_p = case.smooth_u(0.1) + 0.01 * case.random_u(), case.smooth_p(0.1)
+    old_u, oldold_u = case.smooth_u(0.05), case.smooth_u(0.0)
+    lin_ref = np.zeros(case.n_cells * case.nq * 12)
+    ref_u, ref_p = orc.ns_residual(case.mesh, case.k, case.prm, src_u, src_p, old_u, oldold_u,
+                                   con_u=case.con_u, con_p=case.con_p, lin=lin_ref)
+    op = case.engine()
+    src = op.block_vector(src_u, src_p)
+    rhs = op.block_vector()
+    old = op.block_vector(old_u)
+    oldold = op.block_vector(oldold_u)
+    op.residual(rhs, src, None, old, oldold)
+    got_u, got_p = rhs.numpy()
+    assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL
+    if lin != 3:
+        got_lin = op.get_linearization().reshape(-1, 12)
+        ref = lin_ref.reshape(-1, 12)
+        ncomp = 12 if lin == 0 else 4  # Picard/semi-implicit store (u, div) only
+        assert rel_l2(got_lin[:, :ncomp], ref[:, :ncomp]) < TOL
+
+
+def test_velocity_vmult_and_fixed_point():
+    case = Case((3, 4, 3), k=2)
+    src_u = case.random_u()
+    lin = case.random_lin()
+    ref = orc.ns_velocity_vmult(case.mesh, case.k, case.prm, src_u, case.con_u, lin=lin)
+    op = case.engine()
+    op.set_linearization(lin)
+    op.fix_linearization_point()
+    op.set_linearization(case.random_lin())  # later state must not affect velocity_vmult
+    src, dst = op.initialize_u_vector(src_u), op.initialize_u_vector()
+    op.velocity_vmult(dst, src)
+    assert rel_l2(dst.numpy(), ref) < TOL
+
+
+@pytest.mark.parametrize("k", [2, 3])
+def test_scalar_sub_blocks(k):
+    case = Case((3, 2, 4), k=k, faces_p=[0], density_diff=0.3, upper=(1.0, 0.7, 1.5))
+    op = case.engine()
+    src_u, src_p = case.random_u(), case.random_p()
+    rho, mu, damp = case.random_coefficients()
+    su, sp = op.initialize_u_vector(src_u), op.initialize_p_vector(src_p)
+    for variable in (False, True):
+        if variable:
+            op.set_coefficients(rho, mu, damp)
+        c = dict(rho=rho, mu=mu) if variable else dict(rho=None, mu=None)
+        # divergence_vmult_add keeps the previous content of dst
+        base = case.random_p()
+        for wv in (False, True):
+            dp = op.initialize_p_vector(base)
+            op.divergence_vmult_add(dp, su, wv)
+            ref = orc.ns_divergence_vmult_add(case.mesh, k, case.prm, src_u, base, case.con_u,
+                                              case.con_p, mu=c["mu"], weight_by_viscosity=wv)
+            assert rel_l2(dp.numpy(), ref) < TOL
+        dp = op.initialize_p_vector(base)
+        op.pressure_poisson_vmult(dp, sp)
+        assert rel_l2(dp.numpy(), orc.ns_pressure_poisson_vmult(case.mesh, k, case.prm, src_p,
+                                                                 case.con_p, rho=c["rho"])) < TOL
+        op.pressure_mass_vmult(dp, sp)
+        assert rel_l2(dp.numpy(), orc.ns_pressure_mass_vmult(case.mesh, k, case.prm, src_p,
+                                                              case.con_p, mu=c["mu"])) < TOL
+        op.set_linearization(case.random_lin())
+        op.pressure_convdiff_vmult(dp, sp)
+        assert rel_l2(dp.numpy(), orc.ns_pressure_convdiff_vmult(case.mesh, k, case.prm, src_p,
+                                                                  case.con_p, mu=c["mu"])) < TOL
+
+
+def test_beltrami_golden_residual_on_device(oracle):
+    """tests/beltrami_3d.output:13 reproduced by the HIP residual kernel."""
+    case = Case((16, 16, 16), k=2, steps=1)
+    xu = orc.node_coordinates(case.mesh, 2)
+    u0, p0 = case.smooth_u(0.0), case.smooth_p(0.0)
+    sol_u = u0.copy()
+    ub = orc.beltrami_u(xu, 0.05)
+    sol_u[case.con_u == 1] = ub[case.con_u == 1]
+    op = case.engine()
+    rhs = op.block_vector()
+    op.residual(rhs, op.block_vector(sol_u, p0), None, op.block_vector(u0), op.block_vector())
+    op.apply_pressure_average_projection(rhs.block(1))
+    ru, rp = rhs.numpy()
+    assert abs(np.linalg.norm(ru) - 2.590) < 5e-4
+    assert abs(np.linalg.norm(rp) - 6.423e-2) < 5e-6
+
+
+def test_matvec_statistics_and_errors():
+    case = Case((2, 2, 2), k=2)
+    op = case.engine()
+    src, dst = op.block_vector(case.random_u(), case.random_p()), op.block_vector()
+    with pytest.raises(Exception):
+        op.vmult(dst, src)  # linearization not set -> ExcNotInitialized-like error
+    op.set_linearization(case.random_lin())
+    op.get_matvec_statistics()
+    for _ in range(3):
+        op.vmult(dst, src)
+    seconds, count = op.get_matvec_statistics()
+    assert count == 3 and seconds > 0
+    assert op.get_matvec_statistics()[1] == 0
