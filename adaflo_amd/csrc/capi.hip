@@ -258,7 +258,7 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
   CHECK_CTX(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   for (DeviceBuffer *b : {&ctx->lin, &ctx->rho, &ctx->mu, &ctx->damp, &ctx->lin_prec, &ctx->rho_prec,
-                          &ctx->mu_prec, &ctx->damp_prec, &ctx->lin_q2})
+                          &ctx->mu_prec, &ctx->damp_prec, &ctx->lin_q2, &ctx->lin_q2_prec})
     release(*b);
   for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch})
     if (p)
@@ -434,6 +434,16 @@ int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx)
         HIP_TRY(ctx, hipMemcpyAsync(dst[i]->p, src[i]->p, src[i]->count * sizeof(double),
                                     hipMemcpyDeviceToDevice, ctx->stream));
     }
+  // keep a frozen copy in the streaming layout of the Q2/Q1 kernel as well
+  if (q2_supported(ctx) && ctx->lin.p && needs_lin(ctx))
+    {
+      TRY(ctx, q2_prepare_state(ctx), "state conversion failed");
+      TRY(ctx, alloc(ctx, ctx->lin_q2_prec, ctx->lin_q2.count), ctx->last_error);
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->lin_q2_prec.p, ctx->lin_q2.p, ctx->lin_q2.count * sizeof(double),
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+    }
+  else
+    release(ctx->lin_q2_prec);
   return 0;
 }
 
@@ -520,6 +530,12 @@ int adaflo_ns_velocity_vmult(adaflo_ctx *ctx, double *dst_u, const double *src_u
   if (needs_lin(ctx) && !ctx->lin.p)
     return fail(ctx, ADAFLO_ENOTINIT, "linearization data not set");
   const int k = ctx->k;
+  if (ctx->variant == 1 && q2_supported(ctx) && !ctx->rho_prec.p)
+    {
+      TRY(ctx, launch_ns_vmult_q2(ctx, OP_VMULT_VELOCITY, dst_u, nullptr, src_u, nullptr),
+          "Q2 kernel launch failed");
+      return 0;
+    }
   TRY(ctx,
       launch_prepare_dst(ctx, dst_u, src_u, ctx->n_nodes_u, 3, nn(ctx, k, 0), nn(ctx, k, 1),
                          nn(ctx, k, 2), ctx->brick.con_u, 1., true),

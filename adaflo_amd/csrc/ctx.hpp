@@ -57,8 +57,10 @@ struct adaflo_ctx
   adaflo_hip::DeviceBuffer lin_prec, rho_prec, mu_prec, damp_prec; // fix_linearization_point
 
   // specialised (Q2/Q1 sweep kernel) copy of the linearisation, see ns_q2.hip
-  adaflo_hip::DeviceBuffer lin_q2;
+  adaflo_hip::DeviceBuffer lin_q2, lin_q2_prec;
   bool                     lin_q2_valid = false;
+  int                      lin_q2_mode  = -1;
+  int                      q2_lz        = 0; // z-chunk length override (0 = heuristic)
 
   // pressure constant mode (mode 0) data, source/navier_stokes_matrix.cc:117-168
   double *d_p_weights = nullptr, *d_p_modes = nullptr;

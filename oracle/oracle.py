@@ -314,3 +314,19 @@ def beltrami_p(xyz, t, nu=1.0):
         x, y = xyz[:, 0], xyz[:, 1]
         v = -a * a * 0.25 * (np.cos(2 * a * x) + np.cos(2 * a * y)) * np.exp(-4.0 * nu * a * a * t)
     return np.ascontiguousarray(v)
+
+
+# ----------------------------------------------------------------------------- fast CPU baseline
+def fast_n_threads():
+    return int(lib().orc_fast_n_threads())
+
+
+def fast_ns_vmult(mesh, k, prm, src_u, src_p, con_u=None, con_p=None, lin=None, rho=None, mu=None,
+                  damp=None, weights=None, modes=None, out=None):
+    """sum-factorised OpenMP restatement (adaflo_oracle_fast.c); the timed CPU baseline."""
+    dst_u, dst_p = out if out is not None else (np.empty_like(src_u), np.empty_like(src_p))
+    rc = lib().orc_fast_ns_vmult(C.byref(mesh), k, C.byref(prm), _p(src_u), _p(src_p), _p(dst_u),
+                                 _p(dst_p), _u8(con_u), _u8(con_p), _p(lin), _p(rho), _p(mu),
+                                 _p(damp), _p(weights), _p(modes))
+    assert rc == 0
+    return dst_u, dst_p

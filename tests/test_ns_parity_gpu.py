@@ -162,3 +162,46 @@ def test_matvec_statistics_and_errors():
     seconds, count = op.get_matvec_statistics()
     assert count == 3 and seconds > 0
     assert op.get_matvec_statistics()[1] == 0
+
+
+# ----------------------------------------------------------------------------- Q2/Q1 sweep kernel
+@pytest.mark.parametrize("ncell", [(8, 8, 4), (5, 3, 2), (16, 8, 9), (9, 17, 5), (24, 16, 20)])
+def test_vmult_q2_kernel_newton(ncell):
+    case = Case(ncell, k=2, upper=(1.0, 0.5, 2.0))
+    eu, ep = run_vmult(case, variant=1)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+@pytest.mark.parametrize("lin", [1, 2, 3, 4])
+def test_vmult_q2_kernel_linearizations(lin):
+    case = Case((9, 8, 5), k=2, linearization=lin, beta=1.0, tau_grad_div=0.3, damping=0.1)
+    eu, ep = run_vmult(case, variant=1)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+@pytest.mark.parametrize("phys", [1, 2])
+def test_vmult_q2_kernel_physical_types(phys):
+    case = Case((8, 9, 3), k=2, physical_type=phys, viscosity=0.1)
+    eu, ep = run_vmult(case, variant=1)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+def test_vmult_q2_kernel_partial_constraints():
+    case = Case((10, 8, 6), k=2, faces_u=[0, 3, 4], faces_p=[1, 5], pressure_average_fix=False)
+    eu, ep = run_vmult(case, variant=1)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+def test_velocity_vmult_q2_kernel():
+    case = Case((9, 8, 7), k=2)
+    src_u = case.random_u()
+    lin = case.random_lin()
+    ref = orc.ns_velocity_vmult(case.mesh, case.k, case.prm, src_u, case.con_u, lin=lin)
+    op = case.engine()
+    op.set_kernel_variant(1)
+    op.set_linearization(lin)
+    op.fix_linearization_point()
+    op.set_linearization(case.random_lin())
+    src, dst = op.initialize_u_vector(src_u), op.initialize_u_vector(np.full(case.n_u, 3.0))
+    op.velocity_vmult(dst, src)
+    assert rel_l2(dst.numpy(), ref) < TOL
