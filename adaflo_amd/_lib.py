@@ -55,8 +55,13 @@ SIGNATURES = {
     "adaflo_ns_pressure_mass_vmult": (C.c_int, [_CTX, _D, _D]),
     "adaflo_ns_pressure_convdiff_vmult": (C.c_int, [_CTX, _D, _D]),
     "adaflo_ns_apply_pressure_average_projection": (C.c_int, [_CTX, _D]),
+    "adaflo_ns_pressure_mass_weight_add": (C.c_int, [_CTX, _D]),
+    "adaflo_ns_apply_constrained_rows": (C.c_int, [_CTX, _D, _D, _D, _D]),
     "adaflo_ns_get_matvec_statistics": (C.c_int, [_CTX, C.POINTER(C.c_uint), C.POINTER(C.c_double)]),
     "adaflo_set_kernel_variant": (C.c_int, [_CTX, C.c_int]),
+    "adaflo_get_kernel_statistics": (C.c_int, [_CTX, C.POINTER(C.c_uint), C.POINTER(C.c_double)]),
+    "adaflo_set_timing": (C.c_int, [_CTX, C.c_int]),
+    "adaflo_set_q2_chunk": (C.c_int, [_CTX, C.c_int]),
 }
 
 _lib = None

@@ -78,46 +78,23 @@ namespace
   }
 
   // time one operator application with a pair of events (get_matvec_statistics)
-  struct MatvecTimer
+  struct ScopedTimer
   {
     adaflo_ctx *ctx;
-    hipEvent_t  start = nullptr, stop = nullptr;
-    explicit MatvecTimer(adaflo_ctx *c)
+    EventTimer &t;
+    hipEvent_t  stop = nullptr;
+    ScopedTimer(adaflo_ctx *c, EventTimer &timer)
       : ctx(c)
+      , t(timer)
     {
-      if (!ctx->timing)
-        return;
-      if (ctx->ev_used + 2 > ctx->ev_pool.size())
-        {
-          if (ctx->ev_pool.size() >= 8192)
-            { // fold what has been recorded so far
-              (void)hipStreamSynchronize(ctx->stream);
-              for (size_t i = 0; i + 1 < ctx->ev_used; i += 2)
-                {
-                  float ms = 0.f;
-                  if (hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]) == hipSuccess)
-                    ctx->matvec_seconds += 1e-3 * ms;
-                }
-              ctx->ev_used = 0;
-            }
-          else
-            for (int i = 0; i < 2; ++i)
-              {
-                hipEvent_t e;
-                if (hipEventCreate(&e) != hipSuccess)
-                  return;
-                ctx->ev_pool.push_back(e);
-              }
-        }
-      start = ctx->ev_pool[ctx->ev_used++];
-      stop  = ctx->ev_pool[ctx->ev_used++];
-      (void)hipEventRecord(start, ctx->stream);
+      if (ctx->timing)
+        stop = t.start(ctx->stream);
     }
-    ~MatvecTimer()
+    ~ScopedTimer()
     {
       if (stop)
         (void)hipEventRecord(stop, ctx->stream);
-      ctx->matvec_count++;
+      t.count++;
     }
   };
 
@@ -263,8 +240,8 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
   for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch})
     if (p)
       (void)hipFree(p);
-  for (hipEvent_t e : ctx->ev_pool)
-    (void)hipEventDestroy(e);
+  ctx->matvec_timer.destroy();
+  ctx->kernel_timer.destroy();
   if (ctx->own_stream)
     (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -469,7 +446,7 @@ int adaflo_ns_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double 
     return fail(ctx, ADAFLO_EINVAL, "null vector");
   if (needs_lin(ctx) && !ctx->lin.p)
     return fail(ctx, ADAFLO_ENOTINIT, "linearization data not set (call residual or set_linearization)");
-  MatvecTimer timer(ctx);
+  ScopedTimer timer(ctx, ctx->matvec_timer);
   const int   k = ctx->k;
   if (ctx->variant == 1 && q2_supported(ctx))
     {
@@ -594,6 +571,32 @@ int adaflo_ns_pressure_poisson_vmult(adaflo_ctx *ctx, double *dst_p, const doubl
                    full, true);
 }
 
+int adaflo_ns_pressure_mass_weight_add(adaflo_ctx *ctx, double *dst_p)
+{
+  CHECK_CTX(ctx);
+  if (!dst_p)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  return scalar_op(ctx, dst_p, nullptr, SC_MASS_WEIGHT, nullptr, false, false);
+}
+
+int adaflo_ns_apply_constrained_rows(adaflo_ctx *ctx, double *dst_u, double *dst_p,
+                                     const double *src_u, const double *src_p)
+{
+  CHECK_CTX(ctx);
+  const int k = ctx->k;
+  if (dst_u && ctx->brick.con_u)
+    TRY(ctx,
+        launch_prepare_dst(ctx, dst_u, src_u, ctx->n_nodes_u, 3, nn(ctx, k, 0), nn(ctx, k, 1),
+                           nn(ctx, k, 2), ctx->brick.con_u, 1., false),
+        "constrained rows failed");
+  if (dst_p && ctx->brick.con_p)
+    TRY(ctx,
+        launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, nn(ctx, k - 1, 0), nn(ctx, k - 1, 1),
+                           nn(ctx, k - 1, 2), ctx->brick.con_p, -1., false),
+        "constrained rows failed");
+  return 0;
+}
+
 int adaflo_ns_pressure_mass_vmult(adaflo_ctx *ctx, double *dst_p, const double *src_p)
 {
   CHECK_CTX(ctx);
@@ -613,23 +616,44 @@ int adaflo_ns_pressure_convdiff_vmult(adaflo_ctx *ctx, double *dst_p, const doub
   return scalar_op(ctx, dst_p, src_p, SC_CONVDIFF, ctx->mu.p, true, true);
 }
 
+static int read_timer(adaflo_ctx *ctx, EventTimer &t, unsigned *count, double *seconds)
+{
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  t.fold();
+  if (count)
+    *count = t.count;
+  if (seconds)
+    *seconds = t.seconds;
+  t.count   = 0;
+  t.seconds = 0.;
+  return 0;
+}
+
 int adaflo_ns_get_matvec_statistics(adaflo_ctx *ctx, unsigned *count, double *seconds)
 {
   CHECK_CTX(ctx);
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  for (size_t i = 0; i + 1 < ctx->ev_used; i += 2)
-    {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]) == hipSuccess)
-        ctx->matvec_seconds += 1e-3 * ms;
-    }
-  ctx->ev_used = 0;
-  if (count)
-    *count = ctx->matvec_count;
-  if (seconds)
-    *seconds = ctx->matvec_seconds;
-  ctx->matvec_count   = 0;
-  ctx->matvec_seconds = 0.;
+  return read_timer(ctx, ctx->matvec_timer, count, seconds);
+}
+
+int adaflo_get_kernel_statistics(adaflo_ctx *ctx, unsigned *count, double *seconds)
+{
+  CHECK_CTX(ctx);
+  return read_timer(ctx, ctx->kernel_timer, count, seconds);
+}
+
+int adaflo_set_timing(adaflo_ctx *ctx, int enabled)
+{
+  CHECK_CTX(ctx);
+  ctx->timing = enabled != 0;
+  return 0;
+}
+
+int adaflo_set_q2_chunk(adaflo_ctx *ctx, int layers)
+{
+  CHECK_CTX(ctx);
+  if (layers < 0)
+    return fail(ctx, ADAFLO_EINVAL, "negative chunk length");
+  ctx->q2_lz = layers;
   return 0;
 }
 

@@ -30,6 +30,55 @@ namespace adaflo_hip
     double *p     = nullptr;
     size_t  count = 0;
   };
+
+  // accumulates the device time between pairs of events recorded on a stream
+  struct EventTimer
+  {
+    std::vector<hipEvent_t> pool;
+    size_t                  used    = 0;
+    unsigned                count   = 0;
+    double                  seconds = 0.;
+
+    void fold()
+    {
+      for (size_t i = 0; i + 1 < used; i += 2)
+        {
+          float ms = 0.f;
+          if (hipEventElapsedTime(&ms, pool[i], pool[i + 1]) == hipSuccess)
+            seconds += 1e-3 * ms;
+        }
+      used = 0;
+    }
+    // returns the stop event to record after the work (nullptr on failure)
+    hipEvent_t start(hipStream_t stream)
+    {
+      if (used + 2 > pool.size())
+        {
+          if (pool.size() >= 8192)
+            {
+              (void)hipStreamSynchronize(stream);
+              fold();
+            }
+          else
+            for (int i = 0; i < 2; ++i)
+              {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess)
+                  return nullptr;
+                pool.push_back(e);
+              }
+        }
+      hipEvent_t a = pool[used++], b = pool[used++];
+      (void)hipEventRecord(a, stream);
+      return b;
+    }
+    void destroy()
+    {
+      for (hipEvent_t e : pool)
+        (void)hipEventDestroy(e);
+      pool.clear();
+    }
+  };
 } // namespace adaflo_hip
 
 struct adaflo_ctx
@@ -68,12 +117,9 @@ struct adaflo_ctx
   double *d_scratch    = nullptr; // reduction scratch (partials + result)
   size_t  scratch_count = 0;
 
-  // matvec statistics (get_matvec_statistics)
-  unsigned                 matvec_count = 0;
-  double                   matvec_seconds = 0.;
+  // matvec statistics (get_matvec_statistics) and dominant-kernel statistics
   bool                     timing = true;
-  std::vector<hipEvent_t>  ev_pool;
-  size_t                   ev_used = 0;
+  adaflo_hip::EventTimer   matvec_timer, kernel_timer;
 
   std::string last_error;
 };

@@ -286,20 +286,30 @@ namespace adaflo_hip
 
   int launch_ns_cell_generic(adaflo_ctx *ctx, const int op, const NSArgs &args)
   {
+    hipEvent_t stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
+    int        rc;
     // EXPAND_OPERATIONS, source/navier_stokes_matrix.cc:64-82 (degree_p = k-1)
     switch (ctx->k)
       {
         case 2:
-          return launch_k<2, 64>(ctx, op, args);
+          rc = launch_k<2, 64>(ctx, op, args);
+          break;
         case 3:
-          return launch_k<3, 64>(ctx, op, args);
+          rc = launch_k<3, 64>(ctx, op, args);
+          break;
         case 4:
-          return launch_k<4, 128>(ctx, op, args);
+          rc = launch_k<4, 128>(ctx, op, args);
+          break;
         case 5:
-          return launch_k<5, 256>(ctx, op, args);
+          rc = launch_k<5, 256>(ctx, op, args);
+          break;
         default:
-          return ADAFLO_EUNSUPPORTED;
+          rc = ADAFLO_EUNSUPPORTED;
       }
+    if (stop)
+      (void)hipEventRecord(stop, ctx->stream);
+    ctx->kernel_timer.count++;
+    return rc;
   }
 
   // ------------------------------------------------------------------------

@@ -41,13 +41,14 @@ namespace adaflo_hip
     {
       int    ncx, ncy, ncz, nnx, nny, nnz, npx, npy, npz;
       int    tiles_x, tiles_y, LZ, n_chunks;
-      double ih[3], det;
+      double ih[3];
       double s0, s1, s2;   // first row of the 3x3 interpolation matrix (rows: [s0 s1 s2], [0 1 0], [s2 s1 s0])
-      double dc[9];        // collocation derivative at the Gauss points
-      double w[3];
-      double gamma, tau1, beta, tau_gd, rho, mu, damping;
-      int    lin_mode;     // 0 Newton, 1 Picard-type (u_lin, div), 2 none
-      int    stokes, with_pressure, integrate_p;
+      // collocation derivative at the 3 Gauss points: rows (a0 a1 a2), (-b 0 b), (-a2 -a1 -a0)
+      double a0, a1, a2, b;
+      double wj[4];        // JxW by number of "middle" indices of the q-point: det * w0^(3-m) * w1^m
+      double cA, cB;       // conv = cA * u + cB * res, cA = gamma*rho - damping, cB = tau1*rho
+      double beta, tau_gd, tmu;
+      int    integrate_p;
       uint32_t con_u, con_p;
       const double *src_u, *src_p;
       double       *dst_u, *dst_p;
@@ -89,6 +90,41 @@ namespace adaflo_hip
       x0 = t0;
       x1 = t1;
       x2 = t2;
+    }
+
+    // derivative at point p of the quadratic through (v0,v1,v2) at the 3 Gauss points
+    __device__ __forceinline__ double dline(const int p, const double v0, const double v1,
+                                            const double v2, const double a0, const double a1,
+                                            const double a2, const double b)
+    {
+      if (p == 0)
+        return a0 * v0 + a1 * v1 + a2 * v2;
+      if (p == 1)
+        return b * (v2 - v0);
+      return -(a2 * v0 + a1 * v1 + a0 * v2);
+    }
+    // transpose: (r0,r1,r2) += row p of the derivative matrix times t
+    __device__ __forceinline__ void dline_t(const int p, const double t, double &r0, double &r1,
+                                            double &r2, const double a0, const double a1,
+                                            const double a2, const double b)
+    {
+      if (p == 0)
+        {
+          r0 += a0 * t;
+          r1 += a1 * t;
+          r2 += a2 * t;
+        }
+      else if (p == 1)
+        {
+          r0 -= b * t;
+          r2 += b * t;
+        }
+      else
+        {
+          r0 -= a2 * t;
+          r1 -= a1 * t;
+          r2 -= a0 * t;
+        }
     }
 
     // load one velocity node plane K of the tile into LDS, constraints resolved
@@ -240,6 +276,9 @@ namespace adaflo_hip
         }
     }
 
+    // LIN_MODE: 0 Newton (state = u_lin, grad u_lin), 1 Picard-type (state = u_lin, div u_lin),
+    //           2 no convective linearisation (explicit convection, Stokes)
+    template <int LIN_MODE, bool WITH_P>
     __global__ __launch_bounds__(NT, 2) void ns_q2_kernel(const Q2Args A)
     {
       __shared__ double u_pl[3 * UPLANE];
@@ -265,8 +304,8 @@ namespace adaflo_hip
       const int  tcx = min(TX, A.ncx - TX * bx), tcy = min(TY, A.ncy - TY * by);
 
       const double s0 = A.s0, s1 = A.s1, s2 = A.s2;
-      const bool   is_p   = d == 3;
-      const double vmask  = is_p ? 0. : 1.;
+      const bool   is_p  = d == 3;
+      const double tmu_l = is_p ? 0. : A.tmu; // the pressure lane integrates no gradient terms
       const double d0 = d == 0 ? 1. : 0., d1 = d == 1 ? 1. : 0., d2 = d == 2 ? 1. : 0.;
 
       double carry_u[4] = {0., 0., 0., 0.}, carry_p = 0.;
@@ -275,7 +314,7 @@ namespace adaflo_hip
       load_u_plane(A, u_pl + ((2 * cz0) % 3) * UPLANE, 2 * cz0, I0, J0);
       load_u_plane(A, u_pl + ((2 * cz0 + 1) % 3) * UPLANE, 2 * cz0 + 1, I0, J0);
       load_u_plane(A, u_pl + ((2 * cz0 + 2) % 3) * UPLANE, 2 * cz0 + 2, I0, J0);
-      if (A.with_pressure)
+      if (WITH_P)
         {
           load_p_plane(A, p_pl + (cz0 % 2) * PPLANE, cz0, Ip0, Jp0);
           load_p_plane(A, p_pl + ((cz0 + 1) % 2) * PPLANE, cz0 + 1, Ip0, Jp0);
@@ -314,7 +353,7 @@ namespace adaflo_hip
                   for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
-                      V[2 * a + 6 * b + 18 * c] = A.with_pressure ? pl[b * QNX + a] : 0.;
+                      V[2 * a + 6 * b + 18 * c] = WITH_P ? pl[b * QNX + a] : 0.;
                 }
 #pragma unroll
               for (int c = 0; c < 3; c += 2)
@@ -352,16 +391,17 @@ namespace adaflo_hip
           for (int n = 0; n < 27; ++n)
             R[n] = 0.;
 
-          const size_t sbase = ((size_t)bt * A.ncz + cz) * (27 * 2 * NCELL * 3) + cell * 3 + (is_p ? 0 : d);
-          double2      sbuf[PF][2];
-          const bool   use_state = A.lin_mode != 2 && !A.stokes;
-          if (use_state)
+          // uniform (scalar) base of this (tile, layer) block + per-lane offset, in double2 units
+          const double2 *sp   = state + ((size_t)bt * A.ncz + cz) * (27 * 2 * NCELL * 3);
+          const unsigned slan = cell * 3 + (is_p ? 0 : d);
+          double2        sbuf[PF][2];
+          if (LIN_MODE != 2)
             {
 #pragma unroll
               for (int q = 0; q < PF; ++q)
                 {
-                  sbuf[q][0] = state[sbase + (size_t)(2 * q) * (NCELL * 3)];
-                  sbuf[q][1] = state[sbase + (size_t)(2 * q + 1) * (NCELL * 3)];
+                  sbuf[q][0] = sp[(2 * q) * (NCELL * 3) + slan];
+                  sbuf[q][1] = sp[(2 * q + 1) * (NCELL * 3) + slan];
                 }
             }
 
@@ -370,82 +410,74 @@ namespace adaflo_hip
             {
               const int qx = q % 3, qy = (q / 3) % 3, qz = q / 9;
               double2   st0 = make_double2(0., 0.), st1 = make_double2(0., 0.);
-              if (use_state)
+              if (LIN_MODE != 2)
                 {
                   st0 = sbuf[q % PF][0];
                   st1 = sbuf[q % PF][1];
                   if (q + PF < 27)
                     {
-                      sbuf[q % PF][0] = state[sbase + (size_t)(2 * (q + PF)) * (NCELL * 3)];
-                      sbuf[q % PF][1] = state[sbase + (size_t)(2 * (q + PF) + 1) * (NCELL * 3)];
+                      sbuf[q % PF][0] = sp[(2 * (q + PF)) * (NCELL * 3) + slan];
+                      sbuf[q % PF][1] = sp[(2 * (q + PF) + 1) * (NCELL * 3) + slan];
                     }
                   asm volatile("" ::: "memory");
                 }
               const double Vq = V[q];
               // reference-cell derivatives by the collocation derivative, then J^{-T}
-              const double g0 = (A.dc[3 * qx] * V[0 + 3 * qy + 9 * qz] + A.dc[3 * qx + 1] * V[1 + 3 * qy + 9 * qz] +
-                                 A.dc[3 * qx + 2] * V[2 + 3 * qy + 9 * qz]) * A.ih[0];
-              const double g1 = (A.dc[3 * qy] * V[qx + 9 * qz] + A.dc[3 * qy + 1] * V[qx + 3 + 9 * qz] +
-                                 A.dc[3 * qy + 2] * V[qx + 6 + 9 * qz]) * A.ih[1];
-              const double g2 = (A.dc[3 * qz] * V[qx + 3 * qy] + A.dc[3 * qz + 1] * V[qx + 3 * qy + 9] +
-                                 A.dc[3 * qz + 2] * V[qx + 3 * qy + 18]) * A.ih[2];
+              const double g0 = dline(qx, V[0 + 3 * qy + 9 * qz], V[1 + 3 * qy + 9 * qz], V[2 + 3 * qy + 9 * qz],
+                                      A.a0, A.a1, A.a2, A.b) * A.ih[0];
+              const double g1 = dline(qy, V[qx + 9 * qz], V[qx + 3 + 9 * qz], V[qx + 6 + 9 * qz],
+                                      A.a0, A.a1, A.a2, A.b) * A.ih[1];
+              const double g2 = dline(qz, V[qx + 3 * qy], V[qx + 3 * qy + 9], V[qx + 3 * qy + 18],
+                                      A.a0, A.a1, A.a2, A.b) * A.ih[2];
 
               // gradient rows of the three velocity components, visible to all four lanes
               const double G00 = quad_bcast<0>(g0), G01 = quad_bcast<0>(g1), G02 = quad_bcast<0>(g2);
               const double G10 = quad_bcast<1>(g0), G11 = quad_bcast<1>(g1), G12 = quad_bcast<1>(g2);
               const double G20 = quad_bcast<2>(g0), G21 = quad_bcast<2>(g1), G22 = quad_bcast<2>(g2);
-              const double div  = G00 + G11 + G22; // :706
-              const double u0 = quad_bcast<0>(Vq), u1 = quad_bcast<1>(Vq), u2 = quad_bcast<2>(Vq);
-              const double pres = quad_bcast<3>(Vq);
+              const double div = G00 + G11 + G22; // :706
 
-              double conv = 0.;
-              if (!A.stokes) // :708-838
+              double conv = A.cA * Vq; // :717, :827-835
+              if (LIN_MODE == 0)       // Newton :802-816
                 {
-                  conv = A.gamma * Vq;
-                  if (A.lin_mode == 0) // Newton :802-816
-                    {
-                      const double ub0 = quad_bcast<0>(st0.x), ub1 = quad_bcast<1>(st0.x), ub2 = quad_bcast<2>(st0.x);
-                      const double trl = quad_bcast<0>(st0.y) + quad_bcast<1>(st1.x) + quad_bcast<2>(st1.y);
-                      double       res = (A.beta * div) * st0.x + (A.beta * trl) * Vq;
-                      res += ub0 * g0 + u0 * st0.y;
-                      res += ub1 * g1 + u1 * st1.x;
-                      res += ub2 * g2 + u2 * st1.y;
-                      conv += A.tau1 * res;
-                    }
-                  else if (A.lin_mode == 1) // Picard-type :817-826, state = (u_lin, div_lin)
-                    {
-                      const double ub0 = quad_bcast<0>(st0.x), ub1 = quad_bcast<1>(st0.x), ub2 = quad_bcast<2>(st0.x);
-                      double       res = (A.beta * st0.y) * Vq;
-                      res += ub0 * g0;
-                      res += ub1 * g1;
-                      res += ub2 * g2;
-                      conv += A.tau1 * res;
-                    }
-                  conv = conv * A.rho - A.damping * Vq; // :827-835
+                  const double u0 = quad_bcast<0>(Vq), u1 = quad_bcast<1>(Vq), u2 = quad_bcast<2>(Vq);
+                  const double ub0 = quad_bcast<0>(st0.x), ub1 = quad_bcast<1>(st0.x), ub2 = quad_bcast<2>(st0.x);
+                  const double trl = quad_bcast<0>(st0.y) + quad_bcast<1>(st1.x) + quad_bcast<2>(st1.y);
+                  double       res = A.beta * (div * st0.x + trl * Vq);
+                  res += ub0 * g0 + u0 * st0.y;
+                  res += ub1 * g1 + u1 * st1.x;
+                  res += ub2 * g2 + u2 * st1.y;
+                  conv += A.cB * res;
+                }
+              else if (LIN_MODE == 1) // Picard-type :817-826, state = (u_lin, div_lin)
+                {
+                  const double ub0 = quad_bcast<0>(st0.x), ub1 = quad_bcast<1>(st0.x), ub2 = quad_bcast<2>(st0.x);
+                  double       res = (A.beta * st0.y) * Vq;
+                  res += ub0 * g0;
+                  res += ub1 * g1;
+                  res += ub2 * g2;
+                  conv += A.cB * res;
                 }
 
-              const double jxw = A.det * A.w[qx] * A.w[qy] * A.w[qz];
+              const double jxw = A.wj[(qx == 1) + (qy == 1) + (qz == 1)];
               // column d of the velocity gradient (transpose part of the symmetric gradient)
               const double c0 = sel3(d, G00, G01, G02), c1 = sel3(d, G10, G11, G12), c2 = sel3(d, G20, G21, G22);
-              const double tmu  = A.mu * A.tau1; // :841-845
-              const double diag = A.tau_gd * div - (A.with_pressure ? pres : 0.);
-              // :859-892: row d of tmu (grad u + grad u^T) + (tau_gd div - p) I, already times JxW J^{-1}
-              const double jw  = jxw * vmask;
-              const double tg0 = (tmu * (g0 + c0) + d0 * diag) * (jw * A.ih[0]);
-              const double tg1 = (tmu * (g1 + c1) + d1 * diag) * (jw * A.ih[1]);
-              const double tg2 = (tmu * (g2 + c2) + d2 * diag) * (jw * A.ih[2]);
+              double       diag = A.tau_gd * div;
+              if (WITH_P)
+                diag -= quad_bcast<3>(Vq);
+              diag *= jxw;
+              // :859-892: row d of tmu (grad u + grad u^T) + (tau_gd div - p) I, times JxW J^{-1}
+              const double tmj = tmu_l * jxw;
+              const double tg0 = (tmj * (g0 + c0) + d0 * diag) * A.ih[0];
+              const double tg1 = (tmj * (g1 + c1) + d1 * diag) * A.ih[1];
+              const double tg2 = (tmj * (g2 + c2) + d2 * diag) * A.ih[2];
               // test value: momentum rows (:837) or the pressure row (q, -div u) (:853-856)
               const double tv = (is_p ? -div : conv) * jxw;
 
               // integrate (collocation derivative transposed), accumulate at the Gauss points
               R[q] += tv;
-#pragma unroll
-              for (int r = 0; r < 3; ++r)
-                {
-                  R[r + 3 * qy + 9 * qz] += A.dc[3 * qx + r] * tg0;
-                  R[qx + 3 * r + 9 * qz] += A.dc[3 * qy + r] * tg1;
-                  R[qx + 3 * qy + 9 * r] += A.dc[3 * qz + r] * tg2;
-                }
+              dline_t(qx, tg0, R[0 + 3 * qy + 9 * qz], R[1 + 3 * qy + 9 * qz], R[2 + 3 * qy + 9 * qz], A.a0, A.a1, A.a2, A.b);
+              dline_t(qy, tg1, R[qx + 9 * qz], R[qx + 3 + 9 * qz], R[qx + 6 + 9 * qz], A.a0, A.a1, A.a2, A.b);
+              dline_t(qz, tg2, R[qx + 3 * qy], R[qx + 3 * qy + 9], R[qx + 3 * qy + 18], A.a0, A.a1, A.a2, A.b);
             }
 
           // ---- transposed interpolation back to the nodes --------------------------------
@@ -520,7 +552,7 @@ namespace adaflo_hip
                     carry_u[r]     = node_sum_u(scr_u, n % PNX, n / PNX, 2, comp, tcx, tcy);
                   }
               }
-            if (A.with_pressure && A.integrate_p)
+            if (WITH_P && A.integrate_p)
               {
                 emit_p_plane<false>(A, scr_p, carry_p, cz, Ip0, Jp0, zseam0, tcx, tcy);
                 if (tid < PPLANE)
@@ -530,7 +562,7 @@ namespace adaflo_hip
               {
                 load_u_plane(A, u_pl + ((2 * cz + 3) % 3) * UPLANE, 2 * cz + 3, I0, J0);
                 load_u_plane(A, u_pl + ((2 * cz + 4) % 3) * UPLANE, 2 * cz + 4, I0, J0);
-                if (A.with_pressure)
+                if (WITH_P)
                   load_p_plane(A, p_pl + ((cz + 2) % 2) * PPLANE, cz + 2, Ip0, Jp0);
               }
           }
@@ -542,7 +574,7 @@ namespace adaflo_hip
         const int  cze   = cz0 + nl;
         const bool zseam = cze < A.ncz;
         emit_u_plane<true>(A, scr_u, 0, carry_u, 2 * cze, I0, J0, zseam, tcx, tcy);
-        if (A.with_pressure && A.integrate_p)
+        if (WITH_P && A.integrate_p)
           emit_p_plane<true>(A, scr_p, carry_p, cze, Ip0, Jp0, zseam, tcx, tcy);
       }
     }
@@ -660,43 +692,45 @@ namespace adaflo_hip
     }
     for (int d = 0; d < 3; ++d)
       A.ih[d] = 1. / ctx->desc.h[d];
-    A.det = ctx->desc.h[0] * ctx->desc.h[1] * ctx->desc.h[2];
     {
-      const Quadrature1D qu = gauss(3);
-      const Shape1D      su = shape_fe_q(2, qu);
+      const double       det = ctx->desc.h[0] * ctx->desc.h[1] * ctx->desc.h[2];
+      const Quadrature1D qu  = gauss(3);
+      const Shape1D      su  = shape_fe_q(2, qu);
       A.s0 = su.S[0];
       A.s1 = su.S[1];
       A.s2 = su.S[2];
       const std::vector<double> dc = collocation_derivative(qu);
-      for (int i = 0; i < 9; ++i)
-        A.dc[i] = dc[i];
-      for (int i = 0; i < 3; ++i)
-        A.w[i] = qu.w[i];
+      A.a0 = dc[0];
+      A.a1 = dc[1];
+      A.a2 = dc[2];
+      A.b  = dc[5];
+      for (int m = 0; m < 4; ++m)
+        A.wj[m] = det * std::pow(qu.w[0], 3 - m) * std::pow(qu.w[1], m);
     }
-    const NSDev &P  = ctx->ns;
-    A.gamma         = P.physical_type == ADAFLO_INCOMPRESSIBLE ? P.weight : 0.;
-    A.tau1          = P.tau1;
-    A.beta          = P.beta;
-    A.tau_gd        = P.tau_grad_div;
-    A.rho           = P.density;
-    A.mu            = P.viscosity;
-    A.damping       = P.damping;
-    A.lin_mode      = q2_lin_mode(ctx);
-    A.stokes        = P.physical_type == ADAFLO_STOKES;
-    A.with_pressure = op == OP_VMULT;
-    A.integrate_p   = P.linearization != ADAFLO_PROJECTION;
-    A.con_u         = ctx->brick.con_u;
-    A.con_p         = ctx->brick.con_p;
-    A.src_u         = src_u;
-    A.src_p         = src_p;
-    A.dst_u         = dst_u;
-    A.dst_p         = dst_p;
-    A.state         = (op == OP_VMULT_VELOCITY && ctx->lin_q2_prec.p) ? ctx->lin_q2_prec.p : ctx->lin_q2.p;
+    const NSDev &P      = ctx->ns;
+    const bool   stokes = P.physical_type == ADAFLO_STOKES;
+    const double gamma  = P.physical_type == ADAFLO_INCOMPRESSIBLE ? P.weight : 0.;
+    // conv = (gamma u + tau1 res) rho - damping u   (:717,:827-835); Stokes: no value terms (:708)
+    A.cA          = stokes ? 0. : gamma * P.density - P.damping;
+    A.cB          = stokes ? 0. : P.tau1 * P.density;
+    A.beta        = P.beta;
+    A.tau_gd      = P.tau_grad_div;
+    A.tmu         = P.viscosity * P.tau1; // :841-845
+    A.integrate_p = P.linearization != ADAFLO_PROJECTION;
+    A.con_u       = ctx->brick.con_u;
+    A.con_p       = ctx->brick.con_p;
+    A.src_u       = src_u;
+    A.src_p       = src_p;
+    A.dst_u       = dst_u;
+    A.dst_p       = dst_p;
+    A.state       = (op == OP_VMULT_VELOCITY && ctx->lin_q2_prec.p) ? ctx->lin_q2_prec.p : ctx->lin_q2.p;
+    const int  lin_mode = q2_lin_mode(ctx);
+    const bool with_p   = op == OP_VMULT;
 
     // seam nodes are accumulated with atomics -> dst must start from zero (:229)
     if (hipMemsetAsync(dst_u, 0, sizeof(double) * 3 * ctx->n_nodes_u, ctx->stream) != hipSuccess)
       return ADAFLO_EHIP;
-    if (op == OP_VMULT)
+    if (with_p)
       {
         if (A.integrate_p)
           {
@@ -707,8 +741,36 @@ namespace adaflo_hip
                                             A.con_p, -1., true))
           return e;
       }
-    const long nwg = (long)A.tiles_x * A.tiles_y * A.n_chunks;
-    hipLaunchKernelGGL(ns_q2_kernel, dim3((unsigned)nwg), dim3(NT), 0, ctx->stream, A);
+    const long nwg  = (long)A.tiles_x * A.tiles_y * A.n_chunks;
+    hipEvent_t stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
+    const dim3 grid((unsigned)nwg), block(NT);
+    if (with_p)
+      switch (lin_mode)
+        {
+          case 0:
+            hipLaunchKernelGGL((ns_q2_kernel<0, true>), grid, block, 0, ctx->stream, A);
+            break;
+          case 1:
+            hipLaunchKernelGGL((ns_q2_kernel<1, true>), grid, block, 0, ctx->stream, A);
+            break;
+          default:
+            hipLaunchKernelGGL((ns_q2_kernel<2, true>), grid, block, 0, ctx->stream, A);
+        }
+    else
+      switch (lin_mode)
+        {
+          case 0:
+            hipLaunchKernelGGL((ns_q2_kernel<0, false>), grid, block, 0, ctx->stream, A);
+            break;
+          case 1:
+            hipLaunchKernelGGL((ns_q2_kernel<1, false>), grid, block, 0, ctx->stream, A);
+            break;
+          default:
+            hipLaunchKernelGGL((ns_q2_kernel<2, false>), grid, block, 0, ctx->stream, A);
+        }
+    if (stop)
+      (void)hipEventRecord(stop, ctx->stream);
+    ctx->kernel_timer.count++;
     return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
   }
 } // namespace adaflo_hip

@@ -225,3 +225,32 @@ class NavierStokesMatrix:
         n, s = C.c_uint(), C.c_double()
         _lib.check(ctx, self._lib.adaflo_ns_get_matvec_statistics(ctx, C.byref(n), C.byref(s)))
         return s.value, n.value
+
+    def get_kernel_statistics(self):
+        """(seconds, launches) of the dominant cell kernel since the last query"""
+        ctx = self._require()
+        n, s = C.c_uint(), C.c_double()
+        _lib.check(ctx, self._lib.adaflo_get_kernel_statistics(ctx, C.byref(n), C.byref(s)))
+        return s.value, n.value
+
+    def set_timing(self, enabled):
+        _lib.check(self._ctx, self._lib.adaflo_set_timing(self._require(), int(enabled)))
+
+    def set_q2_chunk(self, layers):
+        _lib.check(self._ctx, self._lib.adaflo_set_q2_chunk(self._require(), int(layers)))
+
+    def pressure_mass_weight(self, dst):
+        """dst += integral of the pressure shape functions (local_pressure_mass_weight)"""
+        ctx = self._require()
+        _lib.check(ctx, self._lib.adaflo_ns_pressure_mass_weight_add(ctx, dst.ptr))
+
+    def apply_constrained_rows(self, dst, src):
+        ctx = self._require()
+        _lib.check(ctx, self._lib.adaflo_ns_apply_constrained_rows(
+            ctx, dst.block(0).ptr, dst.block(1).ptr, src.block(0).ptr, src.block(1).ptr))
+
+    def projection_active(self):
+        """apply_pressure_average_projection is skipped for the projection scheme and the
+        stationary equation (navier_stokes_matrix.cc:196-197)"""
+        p = self.parameters
+        return p.linearization != "projection" and p.physical_type != "incompressible stationary"

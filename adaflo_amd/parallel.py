@@ -1,0 +1,248 @@
+"""Multi-GPU layer: brick partition of the mesh, ghost-DoF exchange over RCCL (xGMI),
+and the distributed NavierStokesMatrix.
+
+Replaces what deal.II does inside `MatrixFree::cell_loop` for a
+LinearAlgebra::distributed::Vector (SURVEY.md section 2 "collective call sites",
+8e): `src.update_ghost_values()` before the cell loop and `dst.compress(add)`
+after it, plus the one-double all-reduce of the pressure-mean projection
+(source/navier_stokes_matrix.cc:201).
+
+Layout: one process per GPU; the uniform mesh is cut into px x py x pz bricks
+(1, 2x1x1, 2x2x1, 2x2x2 for 1/2/4/8 GPUs).  Every rank stores the DoFs of its
+whole local brick, i.e. nodes on an inter-rank interface are REPLICATED on the
+(up to 8) ranks that share them; the sharer with the lowest grid coordinates
+owns the node (deal.II: "owned" vs "ghost").  A vector is *consistent* when all
+replicas agree.  Both exchanges are ONE round of point-to-point messages to the
+<= 26 (here <= 7) neighbours -- one message per xGMI link in the 2x2x2 layout,
+no ring collective.
+"""
+import itertools
+
+import numpy as np
+
+
+def brick_grid(world):
+    """process grid for `world` GPUs of one node"""
+    grids = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
+    if world in grids:
+        return grids[world]
+    g = [1, 1, 1]  # generic: factor into near-cubic grid
+    n, d = world, 0
+    f = 2
+    while n > 1:
+        while n % f == 0:
+            g[d % 3] *= f
+            n //= f
+            d += 1
+        f += 1
+    return tuple(g)
+
+
+class BrickPartition:
+    """rank -> local brick of `cells_per_rank` cells inside the global box."""
+
+    def __init__(self, grid, rank, cells_per_rank, lower, upper):
+        self.grid = tuple(grid)
+        self.world = int(np.prod(grid))
+        self.rank = rank
+        self.cells = [int(c) for c in cells_per_rank]
+        self.coords = (rank % grid[0], (rank // grid[0]) % grid[1], rank // (grid[0] * grid[1]))
+        self.global_lower = [float(x) for x in lower]
+        self.global_upper = [float(x) for x in upper]
+        self.h = [(u - l) / (g * c) for u, l, g, c in zip(upper, lower, grid, self.cells)]
+        self.lower = [l + co * c * h for l, co, c, h in zip(lower, self.coords, self.cells, self.h)]
+        self.upper = [l + c * h for l, c, h in zip(self.lower, self.cells, self.h)]
+
+    def rank_of(self, coords):
+        return coords[0] + self.grid[0] * (coords[1] + self.grid[1] * coords[2])
+
+    def physical_faces(self):
+        """faces (2*d+side) of the local brick that lie on the domain boundary"""
+        out = []
+        for d in range(3):
+            if self.coords[d] == 0:
+                out.append(2 * d)
+            if self.coords[d] == self.grid[d] - 1:
+                out.append(2 * d + 1)
+        return out
+
+    def neighbours(self):
+        """[(offset, rank)] of all existing neighbours (faces, edges, corners)"""
+        out = []
+        for o in itertools.product((-1, 0, 1), repeat=3):
+            if o == (0, 0, 0):
+                continue
+            c = [self.coords[d] + o[d] for d in range(3)]
+            if all(0 <= c[d] < self.grid[d] for d in range(3)):
+                out.append((o, self.rank_of(c)))
+        return out
+
+    def n_global_dofs(self, k):
+        """velocity + pressure unknowns of the global Taylor-Hood Q_k/Q_{k-1} problem"""
+        nu = int(np.prod([k * g * c + 1 for g, c in zip(self.grid, self.cells)]))
+        npr = int(np.prod([(k - 1) * g * c + 1 for g, c in zip(self.grid, self.cells)]))
+        return 3 * nu + npr
+
+    def nodes(self, degree):
+        return [degree * c + 1 for c in self.cells]
+
+
+def _region(offset, nn):
+    """slices (z, y, x) of the local node box shared with the neighbour at `offset`"""
+    sl = []
+    for d in (2, 1, 0):
+        o = offset[d]
+        sl.append(slice(None) if o == 0 else (slice(0, 1) if o < 0 else slice(nn[d] - 1, nn[d])))
+    return tuple(sl)
+
+
+class HaloExchange:
+    """ghost update / compress(add) for a set of fields living on the same brick.
+
+    fields: list of (degree, ncomp); a field vector is a flat torch tensor of
+    nn_z*nn_y*nn_x*ncomp doubles (node-major, components interleaved)."""
+
+    def __init__(self, part, fields, group=None):
+        self.part = part
+        self.fields = fields
+        self.group = group
+        self.nbrs = part.neighbours()
+        # order messages by dimensionality: faces first, corners last (authoritative owner last)
+        self.nbrs.sort(key=lambda t: sum(abs(x) for x in t[0]))
+        self._bufs = {}
+
+    def _views(self, vecs):
+        out = []
+        for v, (deg, nc) in zip(vecs, self.fields):
+            nn = self.part.nodes(deg)
+            out.append(v.view(nn[2], nn[1], nn[0], nc))
+        return out
+
+    def _exchange(self, vecs, mode):
+        import torch
+        import torch.distributed as dist
+        if self.part.world == 1 or not self.nbrs:
+            return
+        views = self._views(vecs)
+        sends, recvs, ops = [], [], []
+        for o, nb in self.nbrs:
+            regs = [_region(o, self.part.nodes(deg)) for deg, _ in self.fields]
+            positive = all(x >= 0 for x in o)   # I am on the low side of every cut direction
+            negative = all(x <= 0 for x in o)
+            do_send = mode == "add" or positive
+            do_recv = mode == "add" or negative
+            if do_send:
+                buf = torch.cat([w[r].reshape(-1) for w, r in zip(views, regs)])
+                sends.append(buf)
+                ops.append(dist.P2POp(dist.isend, buf, nb, group=self.group))
+            if do_recv:
+                n = sum(w[r].numel() for w, r in zip(views, regs))
+                key = (o, mode)
+                if key not in self._bufs or self._bufs[key].numel() != n or \
+                        self._bufs[key].device != vecs[0].device:
+                    self._bufs[key] = torch.empty(n, dtype=vecs[0].dtype, device=vecs[0].device)
+                rb = self._bufs[key]
+                recvs.append((o, regs, rb))
+                ops.append(dist.P2POp(dist.irecv, rb, nb, group=self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for o, regs, rb in recvs:
+            off = 0
+            for w, r in zip(views, regs):
+                n = w[r].numel()
+                piece = rb[off:off + n].view(w[r].shape)
+                if mode == "add":
+                    w[r] += piece
+                else:
+                    w[r] = piece
+                off += n
+
+    def compress_add(self, vecs):
+        """dst.compress(VectorOperation::add): afterwards every replica holds the total"""
+        self._exchange(vecs, "add")
+
+    def update_ghost_values(self, vecs):
+        """owner -> replicas"""
+        self._exchange(vecs, "copy")
+
+    def owned_mask(self, field, device=None):
+        """1.0 where this rank owns the node (lowest sharer), else 0.0; flat per DoF"""
+        import torch
+        deg, nc = self.fields[field]
+        nn = self.part.nodes(deg)
+        m = torch.ones(nn[2], nn[1], nn[0], nc, dtype=torch.float64, device=device)
+        for d, axis in ((0, 2), (1, 1), (2, 0)):
+            if self.part.coords[d] > 0:            # a lower neighbour exists: it owns my low face
+                idx = [slice(None)] * 4
+                idx[axis] = 0
+                m[tuple(idx)] = 0.0
+        return m.reshape(-1)
+
+
+class DistributedNavierStokesMatrix:
+    """NavierStokesMatrix over a brick partition: local HIP engine + RCCL halo exchange."""
+
+    def __init__(self, parameters, part, device=0, stream=None, group=None):
+        from .navier_stokes_matrix import BrickMesh, NavierStokesMatrix
+        self.part = part
+        self.group = group
+        self.parameters = parameters
+        k = parameters.velocity_degree
+        mesh = BrickMesh(part.cells, part.lower, part.upper)
+        self.local = NavierStokesMatrix(parameters, mesh, dirichlet_faces_u=part.physical_faces(),
+                                        constrained_faces_p=(), device=device, stream=stream)
+        self.halo = HaloExchange(part, [(k, 3), (k - 1, 1)], group=group)
+        self._w_owned = None
+        self._inv = None
+
+    def initialize(self, time_stepping, pressure_average_fix):
+        single = self.part.world == 1
+        self.local.initialize(time_stepping, pressure_average_fix and single)
+        self.pressure_average_fix = pressure_average_fix
+        if pressure_average_fix and not single:
+            self._setup_projection()
+
+    def set_kernel_variant(self, v):
+        self.local.set_kernel_variant(v)
+
+    def _setup_projection(self):
+        """global version of source/navier_stokes_matrix.cc:117-168 (mode 0)"""
+        import torch
+        import torch.distributed as dist
+        from .vectors import DeviceVector
+        ctx = self.local._ctx
+        n_p = self.local.n_dofs_p()
+        dev = torch.device("cuda", self.local._desc.device)
+        w = torch.zeros(n_p, dtype=torch.float64, device=dev)
+        self.local.pressure_mass_weight(DeviceVector.from_torch(ctx, w))
+        self.local.synchronize()
+        torch.cuda.synchronize(dev)
+        u_dummy = torch.zeros(self.local.n_dofs_u(), dtype=torch.float64, device=dev)
+        self.halo.compress_add([u_dummy, w])
+        self._w_owned = w * self.halo.owned_mask(1, device=dev)
+        s = self._w_owned.sum()
+        dist.all_reduce(s, group=self.group)
+        self._inv = 1.0 / s                       # device scalar, modes == 1 everywhere
+
+    def make_consistent(self, vec):
+        if self.part.world > 1:
+            self.halo.update_ghost_values([b._keepalive for b in vec.blocks])
+
+    def vmult(self, dst, src, src_consistent=False):
+        """NavierStokesMatrix::vmult on the global problem; block vectors wrap torch tensors"""
+        if self.part.world == 1:
+            self.local.vmult(dst, src)
+            return
+        import torch.distributed as dist
+        tsrc = [b._keepalive for b in src.blocks]
+        tdst = [b._keepalive for b in dst.blocks]
+        if not src_consistent:
+            self.halo.update_ghost_values(tsrc)            # src.update_ghost_values()
+        self.local.vmult(dst, src)                          # local cells (no projection)
+        self.halo.compress_add(tdst)                        # dst.compress(add)
+        self.local.apply_constrained_rows(dst, src)         # rows on boundary x interface
+        if self.pressure_average_fix and self.local.projection_active():
+            s = (self._w_owned * tdst[1]).sum()
+            dist.all_reduce(s, group=self.group)
+            tdst[1].sub_(s * self._inv)

@@ -162,11 +162,27 @@ int adaflo_ns_pressure_poisson_vmult(adaflo_ctx *ctx, double *dst_p, const doubl
 int adaflo_ns_pressure_mass_vmult(adaflo_ctx *ctx, double *dst_p, const double *src_p);
 /* pressure_convdiff_vmult :459-483 */
 int adaflo_ns_pressure_convdiff_vmult(adaflo_ctx *ctx, double *dst_p, const double *src_p);
+/* cell loop of local_pressure_mass_weight :1075-1095 (dst += int phi_i); building
+ * block of initialize() :123-131, exposed for the distributed set-up            */
+int adaflo_ns_pressure_mass_weight_add(adaflo_ctx *ctx, double *dst_p);
+/* the constrained-row fix-up of vmult :247-256 alone (dst_u[c] = src_u[c],
+ * dst_p[c] = -src_p[c]); needed again after an inter-GPU compress(add)          */
+int adaflo_ns_apply_constrained_rows(adaflo_ctx *ctx, double *dst_u, double *dst_p,
+                                     const double *src_u, const double *src_p);
 /* apply_pressure_average_projection :191-205 */
 int adaflo_ns_apply_pressure_average_projection(adaflo_ctx *ctx, double *vec_p);
 /* get_matvec_statistics :1194-1206: number of vmult calls and accumulated wall
  * seconds since the last query (resets the counters like the reference).      */
 int adaflo_ns_get_matvec_statistics(adaflo_ctx *ctx, unsigned *count, double *seconds);
+
+/* dominant cell-kernel statistics (device time between HIP events recorded on
+ * the context's stream around the cell kernel only); used by bench.py for the
+ * roofline figure.  Resets like adaflo_ns_get_matvec_statistics.                */
+int adaflo_get_kernel_statistics(adaflo_ctx *ctx, unsigned *count, double *seconds);
+/* switch the event timers off/on (default on) */
+int adaflo_set_timing(adaflo_ctx *ctx, int enabled);
+/* tuning: number of cell layers one workgroup of the Q2/Q1 kernel sweeps (0 = heuristic) */
+int adaflo_set_q2_chunk(adaflo_ctx *ctx, int layers);
 
 /* select the implementation of adaflo_ns_vmult: 0 = generic (any degree),
  * 1 = auto (specialised kernels where available; default).                    */
