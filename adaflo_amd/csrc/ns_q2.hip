@@ -127,152 +127,132 @@ namespace adaflo_hip
         }
     }
 
-    // load one velocity node plane K of the tile into LDS, constraints resolved
-    __device__ __forceinline__ void load_u_plane(const Q2Args &A, double *pl, const int K,
-                                                 const int I0, const int J0)
+    // ---------------------------------------------------------------------------------
+    // LDS carve-up (dynamic shared memory, doubles)
+    // ---------------------------------------------------------------------------------
+    constexpr int RING      = 9;              // state pieces per wave in the LDS ring (54 % RING == 0)
+    constexpr int AHEAD     = 8;              // pieces issued ahead of the consumer
+    constexpr int PIECE     = 96;             // doubles per piece: 48 lanes x 16 B
+    constexpr int L_RING    = 0;
+    constexpr int L_UPL     = L_RING + 4 * RING * PIECE;  // 3 velocity node planes
+    constexpr int L_PPL     = L_UPL + 3 * UPLANE + 1;     // 2 pressure node planes
+    constexpr int L_SCRU    = L_PPL + 2 * PPLANE;         // [3 planes][5 slots][192]
+    constexpr int L_SCRP    = L_SCRU + 15 * NCELL * 3;    // [2 planes][3 slots][64]
+    constexpr int L_CEX     = L_SCRP + 6 * NCELL;         // carry of the far x column  [17][3]
+    constexpr int L_CEY     = L_CEX + PNY * 3;            // carry of the far y row     [17][3]
+    constexpr int L_CPX     = L_CEY + PNX * 3;            // pressure far column [9], far row [9]
+    constexpr int L_CPY     = L_CPX + QNY;
+    constexpr int L_TOTAL   = L_CPY + QNX;
+    constexpr int NPL_U     = 18;             // plane-DMA instructions per wave and layer (fixed count)
+    constexpr int NPL_P     = 3;
+
+    __device__ __forceinline__ void lds_barrier()
     {
-      for (int e = threadIdx.x; e < UPLANE; e += NT)
+      // LDS-only workgroup barrier: unlike __syncthreads() it does not drain vmcnt, so the
+      // asynchronous global->LDS copies stay in flight across it
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    template <int N>
+    __device__ __forceinline__ void wait_vmcnt()
+    {
+      // (asm + memory clobber: LDS reads of DMA'd data must not be hoisted above the wait)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    }
+
+    // Asynchronous global -> LDS copy (LDS-DMA), hand-issued so that (i) no exec-mask branch
+    // splits the quadrature loop into basic blocks, (ii) the address is scalar base + 32-bit
+    // lane offset, (iii) hipcc does not pessimise following LDS reads with vmcnt(0).  The copies
+    // are invisible to the compiler's waitcnt bookkeeping: every consumer is guarded by an
+    // explicit wait_vmcnt<> below.  EXEC is all ones wherever these are called.
+    __device__ __forceinline__ unsigned uniform32(const unsigned x)
+    {
+      return (unsigned)__builtin_amdgcn_readfirstlane((int)x);
+    }
+    __device__ __forceinline__ unsigned long long uniform64(const unsigned long long x)
+    {
+      return ((unsigned long long)uniform32((unsigned)(x >> 32)) << 32) | uniform32((unsigned)x);
+    }
+
+    //   lds_byte : wave-uniform LDS byte address (goes to M0); lane l writes lds_byte + 16*l
+    __device__ __forceinline__ void dma_b128(const void *sbase, const unsigned voff,
+                                             const unsigned lds_byte, const unsigned long long mask)
+    {
+      asm volatile("s_mov_b32 m0, %0\n\t"
+                   "s_mov_b64 exec, %3\n\t"
+                   "global_load_lds_dwordx4 %1, %2\n\t"
+                   "s_mov_b64 exec, -1" ::"s"(uniform32(lds_byte)),
+                   "v"(voff), "s"(uniform64((unsigned long long)sbase)), "s"(uniform64(mask))
+                   : "memory");
+    }
+    //   lane l writes lds_byte + 4*l
+    __device__ __forceinline__ void dma_b32(const void *sbase, const unsigned voff,
+                                            const unsigned lds_byte, const unsigned long long mask)
+    {
+      asm volatile("s_mov_b32 m0, %0\n\t"
+                   "s_mov_b64 exec, %3\n\t"
+                   "global_load_lds_dword %1, %2\n\t"
+                   "s_mov_b64 exec, -1" ::"s"(uniform32(lds_byte)),
+                   "v"(voff), "s"(uniform64((unsigned long long)sbase)), "s"(uniform64(mask))
+                   : "memory");
+    }
+
+    __device__ __forceinline__ unsigned lds_addr(const void *p)
+    {
+      return (unsigned)(size_t)p; // LDS aperture: the low 32 bits are the LDS byte address
+    }
+
+    // asynchronous copy of (part of) one row of doubles into LDS, 4 B per lane and instruction.
+    // The instruction is ALWAYS issued with at least one active lane and in-bounds addresses
+    // (the vmcnt bookkeeping of the kernel relies on a fixed number of VMEM operations); lanes
+    // beyond the valid part of the row are switched off except lane 0, whose (harmless) write
+    // lands in an LDS entry that belongs to a node outside the domain.
+    __device__ __forceinline__ void dma_row_dwords(const double *grow, double *lrow, const int lane,
+                                                   const int n_dwords, const int first)
+    {
+      const int                dw   = first + lane;
+      const unsigned long long mask = __ballot(dw < n_dwords) | 1ull;
+      dma_b32(grow, 4u * (unsigned)min(dw, n_dwords - 1), lds_addr(lrow) + 4u * first, mask);
+    }
+
+    // the fixed number (NPL_U) of row copies one wave contributes to velocity planes K0, K0+1
+    // (rows / planes beyond the domain re-read the last valid row: their LDS copy is never used)
+    __device__ __forceinline__ void dma_u_planes(const Q2Args &A, double *lds, const int K0,
+                                                 const int I0, const int J0, const int wave,
+                                                 const int lane)
+    {
+      const int nrow_dw = 6 * min(PNX, A.nnx - I0); // valid dwords of a tile row
+#pragma unroll
+      for (int t = 0; t < NPL_U / 2; ++t)
         {
-          const int comp = e % 3, n = e / 3, i = n % PNX, j = n / PNX;
-          const int I = I0 + i, J = J0 + j;
-          double    v = 0.;
-          if (I < A.nnx && J < A.nny && K < A.nnz)
-            {
-              v = A.src_u[((long)(K * (long)A.nny + J) * A.nnx + I) * 3 + comp];
-              if (on_constrained_face(I, J, K, A.nnx, A.nny, A.nnz, A.con_u, 3, comp))
-                v = 0.;
-            }
-          pl[e] = v;
+          // 34 rows (2 planes x 17) dealt round-robin to 4 waves; surplus slots repeat a row
+          int r = wave + 4 * t;
+          if (r >= 2 * PNY)
+            r -= 4;
+          const int     pl = r / PNY, j = r - pl * PNY, K = K0 + pl;
+          const int     Jg = min(J0 + j, A.nny - 1), Kg = min(K, A.nnz - 1);
+          const double *g  = A.src_u + ((long)(Kg * (long)A.nny + Jg) * A.nnx + I0) * 3;
+          double       *l  = lds + L_UPL + (K % 3) * UPLANE + j * PNX * 3;
+          dma_row_dwords(g, l, lane, nrow_dw, 0);
+          dma_row_dwords(g, l, lane, nrow_dw, 64);
         }
     }
 
-    __device__ __forceinline__ void load_p_plane(const Q2Args &A, double *pl, const int K,
-                                                 const int I0, const int J0)
+    __device__ __forceinline__ void dma_p_plane(const Q2Args &A, double *lds, const int K,
+                                                const int I0, const int J0, const int wave,
+                                                const int lane)
     {
-      for (int e = threadIdx.x; e < PPLANE; e += NT)
+      const int nrow_dw = 2 * min(QNX, A.npx - I0);
+#pragma unroll
+      for (int t = 0; t < NPL_P; ++t)
         {
-          const int i = e % QNX, j = e / QNX;
-          const int I = I0 + i, J = J0 + j;
-          double    v = 0.;
-          if (I < A.npx && J < A.npy && K < A.npz)
-            {
-              v = A.src_p[(long)(K * (long)A.npy + J) * A.npx + I];
-              if (on_constrained_face(I, J, K, A.npx, A.npy, A.npz, A.con_p, 1, 0))
-                v = 0.;
-            }
-          pl[e] = v;
-        }
-    }
-
-    // sum of the cell-local contributions to tile node (i,j) of local plane lk
-    // (cells beyond the domain inside a partial tile, tcx/tcy = valid extents, are skipped)
-    __device__ __forceinline__ double node_sum_u(const double *scr, const int i, const int j,
-                                                 const int lk, const int comp, const int tcx,
-                                                 const int tcy)
-    {
-      double    s   = 0.;
-      const int cx0 = i >> 1, cy0 = j >> 1;
-#pragma unroll
-      for (int sy = 0; sy < 2; ++sy)
-#pragma unroll
-        for (int sx = 0; sx < 2; ++sx)
-          {
-            // candidate cell (cx0 - sx, cy0 - sy) sees the node at local index li = i - 2*cx
-            const int cx = cx0 - sx, cy = cy0 - sy;
-            const int li = i - 2 * cx, lj = j - 2 * cy;
-            if (cx >= 0 && cx < tcx && cy >= 0 && cy < tcy && li <= 2 && lj <= 2)
-              s += scr[((li + 3 * lj + 9 * lk) * NCELL + cy * TX + cx) * 3 + comp];
-          }
-      return s;
-    }
-
-    __device__ __forceinline__ double node_sum_p(const double *scr, const int i, const int j,
-                                                 const int lk, const int tcx, const int tcy)
-    {
-      double s = 0.;
-#pragma unroll
-      for (int sy = 0; sy < 2; ++sy)
-#pragma unroll
-        for (int sx = 0; sx < 2; ++sx)
-          {
-            const int cx = i - sx, cy = j - sy; // local node index li = sx
-            if (cx >= 0 && cx < tcx && cy >= 0 && cy < tcy)
-              s += scr[((sx + 2 * sy + 4 * lk)) * NCELL + cy * TX + cx];
-          }
-      return s;
-    }
-
-    // write one finished velocity node plane (tile-local entries e = tid + r*NT)
-    template <bool FROM_CARRY>
-    __device__ __forceinline__ void emit_u_plane(const Q2Args &A, const double *scr, const int lk,
-                                                 double (&carry)[4], const int K, const int I0,
-                                                 const int J0, const bool zseam, const int tcx,
-                                                 const int tcy)
-    {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        {
-          const int e = threadIdx.x + r * NT;
-          if (e < UPLANE)
-            {
-              const int comp = e % 3, n = e / 3, i = n % PNX, j = n / PNX;
-              const int I = I0 + i, J = J0 + j;
-              double    v;
-              if (FROM_CARRY)
-                v = carry[r];
-              else
-                {
-                  v = node_sum_u(scr, i, j, lk, comp, tcx, tcy);
-                  if (lk == 0)
-                    v += carry[r];
-                }
-              if (I < A.nnx && J < A.nny)
-                {
-                  const long idx = ((long)(K * (long)A.nny + J) * A.nnx + I) * 3 + comp;
-                  if (on_constrained_face(I, J, K, A.nnx, A.nny, A.nnz, A.con_u, 3, comp))
-                    A.dst_u[idx] = A.src_u[idx]; // :247-256 (+1 on the velocity block)
-                  else
-                    {
-                      const bool seam = zseam || (i == 0 && I > 0) || (i == PNX - 1 && I < A.nnx - 1) ||
-                                        (j == 0 && J > 0) || (j == PNY - 1 && J < A.nny - 1);
-                      if (seam)
-                        unsafeAtomicAdd(&A.dst_u[idx], v);
-                      else
-                        A.dst_u[idx] = v;
-                    }
-                }
-            }
-        }
-    }
-
-    template <bool FROM_CARRY>
-    __device__ __forceinline__ void emit_p_plane(const Q2Args &A, const double *scr, double &carry,
-                                                 const int K, const int I0, const int J0,
-                                                 const bool zseam, const int tcx, const int tcy)
-    {
-      const int e = threadIdx.x;
-      if (e < PPLANE)
-        {
-          const int i = e % QNX, j = e / QNX;
-          const int I = I0 + i, J = J0 + j;
-          double    v = carry;
-          if (!FROM_CARRY)
-            v += node_sum_p(scr, i, j, 0, tcx, tcy);
-          if (I < A.npx && J < A.npy)
-            {
-              const long idx = (long)(K * (long)A.npy + J) * A.npx + I;
-              if (on_constrained_face(I, J, K, A.npx, A.npy, A.npz, A.con_p, 1, 0))
-                A.dst_p[idx] = -A.src_p[idx]; // -1 on the pressure block of vmult
-              else
-                {
-                  const bool seam = zseam || (i == 0 && I > 0) || (i == QNX - 1 && I < A.npx - 1) ||
-                                    (j == 0 && J > 0) || (j == QNY - 1 && J < A.npy - 1);
-                  if (seam)
-                    unsafeAtomicAdd(&A.dst_p[idx], v);
-                  else
-                    A.dst_p[idx] = v;
-                }
-            }
+          int j = wave + 4 * t;
+          if (j >= QNY)
+            j -= 4;
+          const int     Jg = min(J0 + j, A.npy - 1), Kg = min(K, A.npz - 1);
+          const double *g  = A.src_p + (long)(Kg * (long)A.npy + Jg) * A.npx + I0;
+          double       *l  = lds + L_PPL + (K % 2) * PPLANE + j * QNX;
+          dma_row_dwords(g, l, lane, nrow_dw, 0);
         }
     }
 
@@ -281,10 +261,7 @@ namespace adaflo_hip
     template <int LIN_MODE, bool WITH_P>
     __global__ __launch_bounds__(NT, 2) void ns_q2_kernel(const Q2Args A)
     {
-      __shared__ double u_pl[3 * UPLANE];
-      __shared__ double p_pl[2 * PPLANE];
-      __shared__ double scr_u[SCR_U];
-      __shared__ double scr_p[SCR_P];
+      extern __shared__ double lds[];
 
       const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
       const int d = lane & 3, cq = lane >> 2;
@@ -299,8 +276,8 @@ namespace adaflo_hip
       const int  bx = bt % A.tiles_x, by = bt / A.tiles_x;
       const int  cz0 = bz * A.LZ;
       const int  nl  = min(A.LZ, A.ncz - cz0);
-      const int  I0 = 2 * TX * bx, J0 = 2 * TY * by;   // velocity node origin of the tile
-      const int  Ip0 = TX * bx, Jp0 = TY * by;        // pressure node origin
+      const int  I0 = 2 * TX * bx, J0 = 2 * TY * by; // velocity node origin of the tile
+      const int  Ip0 = TX * bx, Jp0 = TY * by;       // pressure node origin
       const int  tcx = min(TX, A.ncx - TX * bx), tcy = min(TY, A.ncy - TY * by);
 
       const double s0 = A.s0, s1 = A.s1, s2 = A.s2;
@@ -308,24 +285,102 @@ namespace adaflo_hip
       const double tmu_l = is_p ? 0. : A.tmu; // the pressure lane integrates no gradient terms
       const double d0 = d == 0 ? 1. : 0., d1 = d == 1 ? 1. : 0., d2 = d == 2 ? 1. : 0.;
 
-      double carry_u[4] = {0., 0., 0., 0.}, carry_p = 0.;
+      // ---- per-lane flags of the nodes this lane combines and writes ("owned" nodes) ---------
+      // velocity lanes: local (li,lj) in {0,1}^2, plus li = 2 / lj = 2 for the last valid cell of
+      // the tile in x / y; pressure lane: (0,0) plus li = 1 / lj = 1 likewise.  Bit li + 3*lj.
+      const bool valid = cxl < tcx && cyl < tcy;
+      const bool lastx = cxl == tcx - 1, lasty = cyl == tcy - 1;
+      const bool hasW = cxl > 0, hasS = cyl > 0;
+      unsigned   m_own = 0, m_con = 0, m_seam = 0, m_zero = 0;
+      {
+        const int  nn_x = is_p ? A.npx : A.nnx, nn_y = is_p ? A.npy : A.nny;
+        const int  deg  = is_p ? 1 : 2;
+        const int  ib = (is_p ? Ip0 : I0) + deg * cxl, jb = (is_p ? Jp0 : J0) + deg * cyl;
+        const uint32_t con = is_p ? A.con_p : A.con_u;
+        const int  st = is_p ? 1 : 3, cc = is_p ? 0 : d;
+        for (int lj = 0; lj <= 2; ++lj)
+          for (int li = 0; li <= 2; ++li)
+            {
+              const int  bit = li + 3 * lj;
+              const int  I = ib + li, J = jb + lj;
+              const bool cx_ = (I == 0 && (con >> (st * 0 + cc) & 1)) || (I == nn_x - 1 && (con >> (st * 1 + cc) & 1));
+              const bool cy_ = (J == 0 && (con >> (st * 2 + cc) & 1)) || (J == nn_y - 1 && (con >> (st * 3 + cc) & 1));
+              if (cx_ || cy_)
+                m_zero |= 1u << bit; // read-as-zero in the gather (all 9 in-plane positions)
+              if (li > deg || lj > deg)
+                continue;
+              const bool own = valid && (li < deg || lastx) && (lj < deg || lasty);
+              if (!own)
+                continue;
+              m_own |= 1u << bit;
+              if (cx_ || cy_)
+                m_con |= 1u << bit;
+              // node on the lateral rim of the tile but not of the domain: shared with another workgroup
+              const int  ti = deg * cxl + li, tj = deg * cyl + lj; // tile-local node index
+              const int  tnx = deg * TX, tny = deg * TY;
+              const bool seam = (ti == 0 && I > 0) || (ti == tnx && I < nn_x - 1) ||
+                                (tj == 0 && J > 0) || (tj == tny && J < nn_y - 1);
+              if (seam)
+                m_seam |= 1u << bit;
+            }
+      }
+      const bool     conz_lo = is_p ? (A.con_p >> 4 & 1) : (A.con_u >> (12 + d) & 1);
+      const bool     conz_hi = is_p ? (A.con_p >> 5 & 1) : (A.con_u >> (15 + d) & 1);
+      const unsigned lane_g  = is_p ? (unsigned)((Jp0 + cyl) * A.npx + Ip0 + cxl) :
+                                      (unsigned)(((J0 + 2 * cyl) * A.nnx + I0 + 2 * cxl) * 3 + d);
 
-      // prologue: bottom planes of the first layer
-      load_u_plane(A, u_pl + ((2 * cz0) % 3) * UPLANE, 2 * cz0, I0, J0);
-      load_u_plane(A, u_pl + ((2 * cz0 + 1) % 3) * UPLANE, 2 * cz0 + 1, I0, J0);
-      load_u_plane(A, u_pl + ((2 * cz0 + 2) % 3) * UPLANE, 2 * cz0 + 2, I0, J0);
-      if (WITH_P)
-        {
-          load_p_plane(A, p_pl + (cz0 % 2) * PPLANE, cz0, Ip0, Jp0);
-          load_p_plane(A, p_pl + ((cz0 + 1) % 2) * PPLANE, cz0 + 1, Ip0, Jp0);
-        }
-      __syncthreads();
+      double cu[4] = {0., 0., 0., 0.}; // carried top-plane sums of the regular owned nodes
+      // zero the LDS carries of the far column / row
+      for (int e = tid; e < L_TOTAL - L_CEX; e += NT)
+        lds[L_CEX + e] = 0.;
 
+      // ---- prologue: first node planes and first state pieces ---------------------------------
       const double2 *state = reinterpret_cast<const double2 *>(A.state);
+      double        *ringw = lds + L_RING + wave * RING * PIECE;
+      const unsigned slan  = cell * 3 + (is_p ? 0 : d); // my element of a piece
+      {
+        // plane 2*cz0 by one wave-split pass (rows 0..16 -> waves), then the regular pair
+        const int nrow_dw = 6 * min(PNX, A.nnx - I0);
+        for (int j = wave; j < PNY; j += 4)
+          {
+            const int     Jg = min(J0 + j, A.nny - 1), K = 2 * cz0;
+            const double *g  = A.src_u + ((long)(K * (long)A.nny + Jg) * A.nnx + I0) * 3;
+            double       *l  = lds + L_UPL + (K % 3) * UPLANE + j * PNX * 3;
+            dma_row_dwords(g, l, lane, nrow_dw, 0);
+            dma_row_dwords(g, l, lane, nrow_dw, 64);
+          }
+        dma_u_planes(A, lds, 2 * cz0 + 1, I0, J0, wave, lane);
+        if (WITH_P)
+          {
+            dma_p_plane(A, lds, cz0, Ip0, Jp0, wave, lane);
+            dma_p_plane(A, lds, cz0 + 1, Ip0, Jp0, wave, lane);
+          }
+      }
+      const unsigned ring_byte = lds_addr(ringw);
+      const unsigned piece_voff = 16u * (unsigned)min(lane, 47);
+      auto issue_piece = [&](const int layer_cz, const int p) {
+        // piece p (= 2q + half) of cell layer layer_cz: 48 consecutive double2 of this wave
+        const double2 *g = state + ((size_t)bt * A.ncz + layer_cz) * (27 * 2 * NCELL * 3) +
+                           (size_t)p * (NCELL * 3) + wave * 48;
+        dma_b128(g, piece_voff, ring_byte + (p % RING) * (PIECE * 8), 0x0000ffffffffffffull);
+      };
+      if (LIN_MODE != 2)
+        {
+#pragma unroll
+          for (int p = 0; p < AHEAD; ++p)
+            issue_piece(cz0, p);
+        }
+      // planes must have landed before anybody gathers from them
+      if (LIN_MODE != 2)
+        wait_vmcnt<AHEAD>();
+      else
+        wait_vmcnt<0>();
+      lds_barrier();
 
       for (int layer = 0; layer < nl; ++layer)
         {
-          const int cz = cz0 + layer;
+          const int cz      = cz0 + layer;
+          const int cz_next = layer + 1 < nl ? cz + 1 : cz;
 
           // ---- B: gather my 27 (8) values from the LDS node planes ---------------------
           double V[27];
@@ -334,7 +389,7 @@ namespace adaflo_hip
 #pragma unroll
               for (int c = 0; c < 3; ++c)
                 {
-                  const double *pl = u_pl + ((2 * cz + c) % 3) * UPLANE + (2 * cyl * PNX + 2 * cxl) * 3 + d;
+                  const double *pl = lds + L_UPL + ((2 * cz + c) % 3) * UPLANE + (2 * cyl * PNX + 2 * cxl) * 3 + d;
 #pragma unroll
                   for (int b = 0; b < 3; ++b)
 #pragma unroll
@@ -348,13 +403,38 @@ namespace adaflo_hip
 #pragma unroll
               for (int c = 0; c < 2; ++c)
                 {
-                  const double *pl = p_pl + ((cz + c) % 2) * PPLANE + cyl * QNX + cxl;
+                  const double *pl = lds + L_PPL + ((cz + c) % 2) * PPLANE + cyl * QNX + cxl;
 #pragma unroll
                   for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
                       V[2 * a + 6 * b + 18 * c] = WITH_P ? pl[b * QNX + a] : 0.;
                 }
+            }
+          // read_dof_values: constrained entries read as zero (boundary tiles / layers only)
+          {
+            const bool zlo = conz_lo && cz == 0, zhi = conz_hi && cz == A.ncz - 1;
+            if (__builtin_amdgcn_readfirstlane(__any(m_zero != 0u || zlo || zhi)))
+              {
+                const int deg = is_p ? 1 : 2;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                  for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                      {
+                        // pressure lane: only the corner positions hold values at this point
+                        const int  li = is_p ? a / 2 : a, lj = is_p ? b / 2 : b;
+                        const bool z  = (m_zero >> (li + 3 * lj) & 1u) || (zlo && c == 0) || (zhi && c == 2);
+                        (void)deg;
+                        if (z)
+                          V[a + 3 * b + 9 * c] = 0.;
+                      }
+              }
+          }
+          if (is_p)
+            {
 #pragma unroll
               for (int c = 0; c < 3; c += 2)
 #pragma unroll
@@ -369,6 +449,12 @@ namespace adaflo_hip
               for (int n = 0; n < 9; ++n)
                 V[n + 9] = 0.5 * (V[n] + V[n + 18]);
             }
+          // every wave has finished reading planes 2cz, 2cz+1: refill their slots for the next layer
+          lds_barrier();
+          // (issued for the last layer of the chunk too: fixed VMEM op count, see wait_vmcnt uses)
+          dma_u_planes(A, lds, 2 * cz + 3, I0, J0, wave, lane);
+          if (WITH_P)
+            dma_p_plane(A, lds, cz + 2, Ip0, Jp0, wave, lane);
 
           // ---- C: interpolate to the Gauss points (in place) ----------------------------
 #pragma unroll
@@ -391,20 +477,6 @@ namespace adaflo_hip
           for (int n = 0; n < 27; ++n)
             R[n] = 0.;
 
-          // uniform (scalar) base of this (tile, layer) block + per-lane offset, in double2 units
-          const double2 *sp   = state + ((size_t)bt * A.ncz + cz) * (27 * 2 * NCELL * 3);
-          const unsigned slan = cell * 3 + (is_p ? 0 : d);
-          double2        sbuf[PF][2];
-          if (LIN_MODE != 2)
-            {
-#pragma unroll
-              for (int q = 0; q < PF; ++q)
-                {
-                  sbuf[q][0] = sp[(2 * q) * (NCELL * 3) + slan];
-                  sbuf[q][1] = sp[(2 * q + 1) * (NCELL * 3) + slan];
-                }
-            }
-
 #pragma unroll
           for (int q = 0; q < 27; ++q)
             {
@@ -412,14 +484,34 @@ namespace adaflo_hip
               double2   st0 = make_double2(0., 0.), st1 = make_double2(0., 0.);
               if (LIN_MODE != 2)
                 {
-                  st0 = sbuf[q % PF][0];
-                  st1 = sbuf[q % PF][1];
-                  if (q + PF < 27)
+                  // outstanding after the pieces of q: AHEAD - 2 younger pieces, plus, right
+                  // after the plane refill was issued (q < 4), the plane copies of this wave
+                  constexpr int younger = AHEAD - 2;
+                  if (q < AHEAD / 2)
                     {
-                      sbuf[q % PF][0] = sp[(2 * (q + PF)) * (NCELL * 3) + slan];
-                      sbuf[q % PF][1] = sp[(2 * (q + PF) + 1) * (NCELL * 3) + slan];
+                      if (WITH_P)
+                        wait_vmcnt<younger + NPL_U + NPL_P>();
+                      else
+                        wait_vmcnt<younger + NPL_U>();
                     }
-                  asm volatile("" ::: "memory");
+                  else
+                    wait_vmcnt<younger>();
+                  const double2 *rs = reinterpret_cast<const double2 *>(ringw);
+                  st0 = rs[((2 * q) % RING) * (PIECE / 2) + slan - wave * 48];
+                  st1 = rs[((2 * q + 1) % RING) * (PIECE / 2) + slan - wave * 48];
+                  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                  // refill the two slots that became free (after the last layer of the chunk
+                  // the same pieces are harmlessly fetched again: fixed VMEM op count)
+                  if (2 * q + AHEAD < 54)
+                    {
+                      issue_piece(cz, 2 * q + AHEAD);
+                      issue_piece(cz, 2 * q + AHEAD + 1);
+                    }
+                  else
+                    {
+                      issue_piece(cz_next, 2 * q + AHEAD - 54);
+                      issue_piece(cz_next, 2 * q + AHEAD + 1 - 54);
+                    }
                 }
               const double Vq = V[q];
               // reference-cell derivatives by the collocation derivative, then J^{-T}
@@ -495,12 +587,26 @@ namespace adaflo_hip
             for (int b = 0; b < 3; ++b)
               interp3_t(R[3 * b + 9 * c], R[1 + 3 * b + 9 * c], R[2 + 3 * b + 9 * c], s0, s1, s2);
 
-          // ---- D: cell results -> LDS scratch ---------------------------------------------
+          // my plane copies for the next layer are older than the AHEAD pieces issued last
+          if (LIN_MODE != 2)
+            wait_vmcnt<AHEAD>();
+          else
+            wait_vmcnt<0>();
+
+          // ---- D: publish what the east / north neighbour cells need ----------------------
+          // velocity: local (2,0) (2,1) (2,2) (0,2) (1,2) of every plane -> slots 0..4
           if (!is_p)
             {
+              double *sc = lds + L_SCRU + cell * 3 + d;
 #pragma unroll
-              for (int l = 0; l < 27; ++l)
-                scr_u[(l * NCELL + cell) * 3 + d] = R[l];
+              for (int lk = 0; lk < 3; ++lk)
+                {
+                  sc[(lk * 5 + 0) * (NCELL * 3)] = R[2 + 0 + 9 * lk];
+                  sc[(lk * 5 + 1) * (NCELL * 3)] = R[2 + 3 + 9 * lk];
+                  sc[(lk * 5 + 2) * (NCELL * 3)] = R[2 + 6 + 9 * lk];
+                  sc[(lk * 5 + 3) * (NCELL * 3)] = R[0 + 6 + 9 * lk];
+                  sc[(lk * 5 + 4) * (NCELL * 3)] = R[1 + 6 + 9 * lk];
+                }
             }
           else
             {
@@ -527,55 +633,228 @@ namespace adaflo_hip
                     R[3 * b + 9 * c] += 0.5 * R[1 + 3 * b + 9 * c];
                     R[2 + 3 * b + 9 * c] += 0.5 * R[1 + 3 * b + 9 * c];
                   }
+              // pressure: local (1,0) (0,1) (1,1) of both planes -> slots 0..2
+              double *sc = lds + L_SCRP + cell;
 #pragma unroll
-              for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                  for (int a = 0; a < 2; ++a)
-                    scr_p[(a + 2 * b + 4 * c) * NCELL + cell] = R[2 * a + 6 * b + 18 * c];
+              for (int lk = 0; lk < 2; ++lk)
+                {
+                  sc[(lk * 3 + 0) * NCELL] = R[2 + 0 + 18 * lk];
+                  sc[(lk * 3 + 1) * NCELL] = R[0 + 6 + 18 * lk];
+                  sc[(lk * 3 + 2) * NCELL] = R[2 + 6 + 18 * lk];
+                }
             }
-          __syncthreads();
+          lds_barrier();
 
-          // ---- E: combine per node, write the two finished planes, stage next planes -----
-          {
-            const bool zseam0 = layer == 0 && cz0 > 0;
-            emit_u_plane<false>(A, scr_u, 0, carry_u, 2 * cz, I0, J0, zseam0, tcx, tcy);
-            emit_u_plane<false>(A, scr_u, 1, carry_u, 2 * cz + 1, I0, J0, false, tcx, tcy);
+          // ---- E: combine per owned node and write the two finished planes -----------------
+          if (!is_p)
+            {
+              const double *sc = lds + L_SCRU + cell * 3 + d;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              {
-                const int e = tid + r * NT;
-                if (e < UPLANE)
-                  {
-                    const int comp = e % 3, n = e / 3;
-                    carry_u[r]     = node_sum_u(scr_u, n % PNX, n / PNX, 2, comp, tcx, tcy);
-                  }
-              }
-            if (WITH_P && A.integrate_p)
-              {
-                emit_p_plane<false>(A, scr_p, carry_p, cz, Ip0, Jp0, zseam0, tcx, tcy);
-                if (tid < PPLANE)
-                  carry_p = node_sum_p(scr_p, tid % QNX, tid / QNX, 1, tcx, tcy);
-              }
-            if (layer + 1 < nl)
-              {
-                load_u_plane(A, u_pl + ((2 * cz + 3) % 3) * UPLANE, 2 * cz + 3, I0, J0);
-                load_u_plane(A, u_pl + ((2 * cz + 4) % 3) * UPLANE, 2 * cz + 4, I0, J0);
-                if (WITH_P)
-                  load_p_plane(A, p_pl + ((cz + 2) % 2) * PPLANE, cz + 2, Ip0, Jp0);
-              }
-          }
-          __syncthreads();
+              for (int lk = 0; lk < 3; ++lk)
+                {
+                  // contributions of the west / south / south-west cells
+                  const double w0 = hasW ? sc[(lk * 5 + 0) * (NCELL * 3) - 3] : 0.;
+                  const double w1 = hasW ? sc[(lk * 5 + 1) * (NCELL * 3) - 3] : 0.;
+                  const double w2 = hasW ? sc[(lk * 5 + 2) * (NCELL * 3) - 3] : 0.;
+                  const double t0 = hasS ? sc[(lk * 5 + 3) * (NCELL * 3) - 24] : 0.;
+                  const double t1 = hasS ? sc[(lk * 5 + 4) * (NCELL * 3) - 24] : 0.;
+                  const double t2 = hasS ? sc[(lk * 5 + 2) * (NCELL * 3) - 24] : 0.;
+                  const double sw = (hasW && hasS) ? sc[(lk * 5 + 2) * (NCELL * 3) - 27] : 0.;
+                  double       nv[9];
+                  nv[0] = R[0 + 9 * lk] + w0 + t0 + sw;
+                  nv[1] = R[1 + 9 * lk] + t1;
+                  nv[2] = R[2 + 9 * lk] + t2;
+                  nv[3] = R[3 + 9 * lk] + w1;
+                  nv[4] = R[4 + 9 * lk];
+                  nv[5] = R[5 + 9 * lk];
+                  nv[6] = R[6 + 9 * lk] + w2;
+                  nv[7] = R[7 + 9 * lk];
+                  nv[8] = R[8 + 9 * lk];
+                  double *cex = lds + L_CEX + (2 * cyl) * 3 + d, *cey = lds + L_CEY + (2 * cxl) * 3 + d;
+                  if (lk == 2)
+                    {
+                      // top plane: finished only after the next layer -> carry
+                      cu[0] = nv[0];
+                      cu[1] = nv[1];
+                      cu[2] = nv[3];
+                      cu[3] = nv[4];
+                      if (lastx)
+                        {
+                          cex[0] = nv[2];
+                          cex[3] = nv[5];
+                        }
+                      if (lasty)
+                        {
+                          cey[0] = nv[6];
+                          cey[3] = nv[7];
+                        }
+                      if (lastx && lasty)
+                        cex[6] = nv[8];
+                    }
+                  else
+                    {
+                      const int K = 2 * cz + lk;
+                      if (lk == 0)
+                        {
+                          nv[0] += cu[0];
+                          nv[1] += cu[1];
+                          nv[3] += cu[2];
+                          nv[4] += cu[3];
+                          if (lastx)
+                            {
+                              nv[2] += cex[0];
+                              nv[5] += cex[3];
+                            }
+                          if (lasty)
+                            {
+                              nv[6] += cey[0];
+                              nv[7] += cey[3];
+                            }
+                          if (lastx && lasty)
+                            nv[8] += cex[6];
+                        }
+                      const bool   zseam = lk == 0 && layer == 0 && cz0 > 0;
+                      const bool   zcon  = (K == 0 && conz_lo);
+                      const size_t pbase = (size_t)K * A.nny * A.nnx * 3;
+#pragma unroll
+                      for (int n = 0; n < 9; ++n)
+                        if (m_own >> n & 1u)
+                          {
+                            const int      li = n % 3, lj = n / 3;
+                            const size_t   idx = pbase + lane_g + (unsigned)((lj * A.nnx + li) * 3);
+                            if ((m_con >> n & 1u) || zcon)
+                              A.dst_u[idx] = A.src_u[idx]; // :247-256 (+1 on the velocity block)
+                            else if ((m_seam >> n & 1u) || zseam)
+                              unsafeAtomicAdd(&A.dst_u[idx], nv[n]);
+                            else
+                              A.dst_u[idx] = nv[n];
+                          }
+                    }
+                }
+            }
+          else if (WITH_P && A.integrate_p)
+            {
+              const double *sc = lds + L_SCRP + cell;
+#pragma unroll
+              for (int lk = 0; lk < 2; ++lk)
+                {
+                  const double w0 = hasW ? sc[(lk * 3 + 0) * NCELL - 1] : 0.;            // W (1,0)
+                  const double w1 = hasW ? sc[(lk * 3 + 2) * NCELL - 1] : 0.;            // W (1,1)
+                  const double t0 = hasS ? sc[(lk * 3 + 1) * NCELL - 8] : 0.;            // S (0,1)
+                  const double t1 = hasS ? sc[(lk * 3 + 2) * NCELL - 8] : 0.;            // S (1,1)
+                  const double sw = (hasW && hasS) ? sc[(lk * 3 + 2) * NCELL - 9] : 0.;  // SW (1,1)
+                  double       nv[4];
+                  nv[0] = R[0 + 18 * lk] + w0 + t0 + sw;
+                  nv[1] = R[2 + 18 * lk] + t1; // local (1,0)
+                  nv[2] = R[6 + 18 * lk] + w1; // local (0,1)
+                  nv[3] = R[8 + 18 * lk];      // local (1,1)
+                  double *cpx = lds + L_CPX + cyl, *cpy = lds + L_CPY + cxl;
+                  if (lk == 1)
+                    {
+                      cu[0] = nv[0];
+                      if (lastx)
+                        cpx[0] = nv[1];
+                      if (lasty)
+                        cpy[0] = nv[2];
+                      if (lastx && lasty)
+                        cpx[1] = nv[3];
+                    }
+                  else
+                    {
+                      nv[0] += cu[0];
+                      if (lastx)
+                        nv[1] += cpx[0];
+                      if (lasty)
+                        nv[2] += cpy[0];
+                      if (lastx && lasty)
+                        nv[3] += cpx[1];
+                      const int    K     = cz;
+                      const bool   zseam = layer == 0 && cz0 > 0;
+                      const bool   zcon  = (K == 0 && conz_lo);
+                      const size_t pbase = (size_t)K * A.npy * A.npx;
+#pragma unroll
+                      for (int n = 0; n < 4; ++n)
+                        {
+                          const int li = n % 2, lj = n / 2, bit = li + 3 * lj;
+                          if (m_own >> bit & 1u)
+                            {
+                              const size_t idx = pbase + lane_g + (unsigned)(lj * A.npx + li);
+                              if ((m_con >> bit & 1u) || zcon)
+                                A.dst_p[idx] = -A.src_p[idx]; // -1 on the pressure block of vmult
+                              else if ((m_seam >> bit & 1u) || zseam)
+                                unsafeAtomicAdd(&A.dst_p[idx], nv[n]);
+                              else
+                                A.dst_p[idx] = nv[n];
+                            }
+                        }
+                    }
+                }
+            }
+          // scratch may be overwritten / carries read by the next layer only after everybody is done
+          lds_barrier();
         }
 
-      // top plane of the chunk
+      // ---- top plane of the chunk --------------------------------------------------------------
       {
         const int  cze   = cz0 + nl;
         const bool zseam = cze < A.ncz;
-        emit_u_plane<true>(A, scr_u, 0, carry_u, 2 * cze, I0, J0, zseam, tcx, tcy);
-        if (WITH_P && A.integrate_p)
-          emit_p_plane<true>(A, scr_p, carry_p, cze, Ip0, Jp0, zseam, tcx, tcy);
+        if (!is_p)
+          {
+            const int     K     = 2 * cze;
+            const bool    zcon  = (K == A.nnz - 1 && conz_hi);
+            const size_t  pbase = (size_t)K * A.nny * A.nnx * 3;
+            const double *cex = lds + L_CEX + (2 * cyl) * 3 + d, *cey = lds + L_CEY + (2 * cxl) * 3 + d;
+            double        nv[9];
+            nv[0] = cu[0];
+            nv[1] = cu[1];
+            nv[3] = cu[2];
+            nv[4] = cu[3];
+            nv[2] = lastx ? cex[0] : 0.;
+            nv[5] = lastx ? cex[3] : 0.;
+            nv[6] = lasty ? cey[0] : 0.;
+            nv[7] = lasty ? cey[3] : 0.;
+            nv[8] = (lastx && lasty) ? cex[6] : 0.;
+#pragma unroll
+            for (int n = 0; n < 9; ++n)
+              if (m_own >> n & 1u)
+                {
+                  const int    li = n % 3, lj = n / 3;
+                  const size_t idx = pbase + lane_g + (unsigned)((lj * A.nnx + li) * 3);
+                  if ((m_con >> n & 1u) || zcon)
+                    A.dst_u[idx] = A.src_u[idx];
+                  else if ((m_seam >> n & 1u) || zseam)
+                    unsafeAtomicAdd(&A.dst_u[idx], nv[n]);
+                  else
+                    A.dst_u[idx] = nv[n];
+                }
+          }
+        else if (WITH_P && A.integrate_p)
+          {
+            const int     K     = cze;
+            const bool    zcon  = (K == A.npz - 1 && conz_hi);
+            const size_t  pbase = (size_t)K * A.npy * A.npx;
+            const double *cpx = lds + L_CPX + cyl, *cpy = lds + L_CPY + cxl;
+            double        nv[4];
+            nv[0] = cu[0];
+            nv[1] = lastx ? cpx[0] : 0.;
+            nv[2] = lasty ? cpy[0] : 0.;
+            nv[3] = (lastx && lasty) ? cpx[1] : 0.;
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+              {
+                const int li = n % 2, lj = n / 2, bit = li + 3 * lj;
+                if (m_own >> bit & 1u)
+                  {
+                    const size_t idx = pbase + lane_g + (unsigned)(lj * A.npx + li);
+                    if ((m_con >> bit & 1u) || zcon)
+                      A.dst_p[idx] = -A.src_p[idx];
+                    else if ((m_seam >> bit & 1u) || zseam)
+                      unsafeAtomicAdd(&A.dst_p[idx], nv[n]);
+                    else
+                      A.dst_p[idx] = nv[n];
+                  }
+              }
+          }
       }
     }
 
@@ -743,31 +1022,48 @@ namespace adaflo_hip
       }
     const long nwg  = (long)A.tiles_x * A.tiles_y * A.n_chunks;
     hipEvent_t stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
-    const dim3 grid((unsigned)nwg), block(NT);
+    const dim3   grid((unsigned)nwg), block(NT);
+    const size_t lds_bytes = sizeof(double) * L_TOTAL;
+    hipError_t   err       = hipSuccess;
+#define Q2_LAUNCH(LM, WP)                                                                       \
+  {                                                                                             \
+    static bool attr_set = false;                                                               \
+    if (!attr_set)                                                                              \
+      {                                                                                         \
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_q2_kernel<LM, WP>),        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
+        attr_set = err == hipSuccess;                                                           \
+      }                                                                                         \
+    if (err == hipSuccess)                                                                      \
+      hipLaunchKernelGGL((ns_q2_kernel<LM, WP>), grid, block, lds_bytes, ctx->stream, A);       \
+  }
     if (with_p)
       switch (lin_mode)
         {
           case 0:
-            hipLaunchKernelGGL((ns_q2_kernel<0, true>), grid, block, 0, ctx->stream, A);
+            Q2_LAUNCH(0, true);
             break;
           case 1:
-            hipLaunchKernelGGL((ns_q2_kernel<1, true>), grid, block, 0, ctx->stream, A);
+            Q2_LAUNCH(1, true);
             break;
           default:
-            hipLaunchKernelGGL((ns_q2_kernel<2, true>), grid, block, 0, ctx->stream, A);
+            Q2_LAUNCH(2, true);
         }
     else
       switch (lin_mode)
         {
           case 0:
-            hipLaunchKernelGGL((ns_q2_kernel<0, false>), grid, block, 0, ctx->stream, A);
+            Q2_LAUNCH(0, false);
             break;
           case 1:
-            hipLaunchKernelGGL((ns_q2_kernel<1, false>), grid, block, 0, ctx->stream, A);
+            Q2_LAUNCH(1, false);
             break;
           default:
-            hipLaunchKernelGGL((ns_q2_kernel<2, false>), grid, block, 0, ctx->stream, A);
+            Q2_LAUNCH(2, false);
         }
+#undef Q2_LAUNCH
+    if (err != hipSuccess)
+      return ADAFLO_EHIP;
     if (stop)
       (void)hipEventRecord(stop, ctx->stream);
     ctx->kernel_timer.count++;

@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--degree", type=int, default=2)
     ap.add_argument("--variant", type=int, default=1, help="0 generic kernels, 1 specialised")
     ap.add_argument("--chunk", type=int, default=0, help="Q2 kernel z-chunk (0 = heuristic)")
+    ap.add_argument("--linearization", default="coupled implicit Newton",
+                    help="diagnostic only: e.g. 'coupled velocity explicit' times the kernel without q-state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=48)
     return ap.parse_args()
@@ -125,7 +127,8 @@ def main():
         _build.build()
 
     nc, k = args.cells, args.degree
-    fp = adaflo_amd.FlowParameters(velocity_degree=k, time_step_size_start=0.05, end_time=1.0)
+    fp = adaflo_amd.FlowParameters(velocity_degree=k, time_step_size_start=0.05, end_time=1.0,
+                                   linearization=args.linearization)
     ts = adaflo_amd.TimeStepping(fp)
     for _ in range(3):
         ts.next()                                   # steady BDF-2 weights: gamma = 1.5/dt
