@@ -235,7 +235,8 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
   CHECK_CTX(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   for (DeviceBuffer *b : {&ctx->lin, &ctx->rho, &ctx->mu, &ctx->damp, &ctx->lin_prec, &ctx->rho_prec,
-                          &ctx->mu_prec, &ctx->damp_prec, &ctx->lin_q2, &ctx->lin_q2_prec})
+                          &ctx->mu_prec, &ctx->damp_prec, &ctx->lin_q2, &ctx->lin_q2_prec,
+                          &ctx->q2_slab_u, &ctx->q2_zslab_u, &ctx->q2_slab_p, &ctx->q2_zslab_p})
     release(*b);
   for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch})
     if (p)
@@ -645,6 +646,16 @@ int adaflo_set_timing(adaflo_ctx *ctx, int enabled)
 {
   CHECK_CTX(ctx);
   ctx->timing = enabled != 0;
+  return 0;
+}
+
+int adaflo_set_q2_state_pad(adaflo_ctx *ctx, int pad_16B)
+{
+  CHECK_CTX(ctx);
+  if (pad_16B < 0)
+    return fail(ctx, ADAFLO_EINVAL, "negative padding");
+  ctx->q2_state_pad = pad_16B;
+  ctx->lin_q2_valid = false;
   return 0;
 }
 

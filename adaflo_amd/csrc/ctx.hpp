@@ -107,9 +107,11 @@ struct adaflo_ctx
 
   // specialised (Q2/Q1 sweep kernel) copy of the linearisation, see ns_q2.hip
   adaflo_hip::DeviceBuffer lin_q2, lin_q2_prec;
+  adaflo_hip::DeviceBuffer q2_slab_u, q2_zslab_u, q2_slab_p, q2_zslab_p; // seam partial sums
   bool                     lin_q2_valid = false;
   int                      lin_q2_mode  = -1;
   int                      q2_lz        = 0; // z-chunk length override (0 = heuristic)
+  int                      q2_state_pad = 0; // skew padding (double2) per (tile, layer) state block
 
   // pressure constant mode (mode 0) data, source/navier_stokes_matrix.cc:117-168
   double *d_p_weights = nullptr, *d_p_modes = nullptr;

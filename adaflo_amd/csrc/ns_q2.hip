@@ -49,6 +49,8 @@ namespace adaflo_hip
       double cA, cB;       // conv = cA * u + cB * res, cA = gamma*rho - damping, cB = tau1*rho
       double beta, tau_gd, tmu;
       int    integrate_p;
+      long   state_stride; // double2 elements per (tile, layer) block (payload + skew padding)
+      double *slab_u, *zslab_u, *slab_p, *zslab_p; // seam partial sums, see q2_seam_fixup_kernel
       uint32_t con_u, con_p;
       const double *src_u, *src_p;
       double       *dst_u, *dst_p;
@@ -145,6 +147,30 @@ namespace adaflo_hip
     constexpr int L_TOTAL   = L_CPY + QNX;
     constexpr int NPL_U     = 18;             // plane-DMA instructions per wave and layer (fixed count)
     constexpr int NPL_P     = 3;
+
+    // ---------------------------------------------------------------------------------
+    // Seams between workgroups.  A node on the lateral rim of a tile is shared by up to four
+    // tiles, a node on the top/bottom plane of a z-chunk by two chunks.  Instead of f64 atomics
+    // (measured: the scattered atomic requests cost 0.85 ms of a 2.5 ms kernel) every workgroup
+    // stores its PARTIAL sums of such nodes in a private slab with plain stores and a small
+    // second kernel (q2_seam_fixup_kernel) adds the partials per node in a fixed order, which
+    // also makes the result bitwise reproducible.
+    //   slab [wg][plane lp of the chunk][rim r][comp]   rim nodes of the tile, every plane
+    //   zslab[wg][tile node][comp]                      top plane of a chunk that has a chunk above
+    // ---------------------------------------------------------------------------------
+    template <int TN>
+    __device__ __forceinline__ int rim_index(const int i, const int j)
+    {
+      // j == 0: i | j == TN-1: TN + i | i == 0: 2TN-1 + j (1 <= j <= TN-2) | i == TN-1: 3TN-3 + j
+      if (j == 0)
+        return i;
+      if (j == TN - 1)
+        return TN + i;
+      if (i == 0)
+        return 2 * TN - 1 + j;
+      return 3 * TN - 3 + j;
+    }
+    constexpr int RIM_U = 4 * (PNX - 1), RIM_P = 4 * (QNX - 1); // 64, 32
 
     __device__ __forceinline__ void lds_barrier()
     {
@@ -279,6 +305,7 @@ namespace adaflo_hip
       const int  I0 = 2 * TX * bx, J0 = 2 * TY * by; // velocity node origin of the tile
       const int  Ip0 = TX * bx, Jp0 = TY * by;       // pressure node origin
       const int  tcx = min(TX, A.ncx - TX * bx), tcy = min(TY, A.ncy - TY * by);
+      const size_t wgs = (size_t)bt * A.n_chunks + bz; // slab index of this workgroup
 
       const double s0 = A.s0, s1 = A.s1, s2 = A.s2;
       const bool   is_p  = d == 3;
@@ -360,7 +387,7 @@ namespace adaflo_hip
       const unsigned piece_voff = 16u * (unsigned)min(lane, 47);
       auto issue_piece = [&](const int layer_cz, const int p) {
         // piece p (= 2q + half) of cell layer layer_cz: 48 consecutive double2 of this wave
-        const double2 *g = state + ((size_t)bt * A.ncz + layer_cz) * (27 * 2 * NCELL * 3) +
+        const double2 *g = state + ((size_t)bt * A.ncz + layer_cz) * A.state_stride +
                            (size_t)p * (NCELL * 3) + wave * 48;
         dma_b128(g, piece_voff, ring_byte + (p % RING) * (PIECE * 8), 0x0000ffffffffffffull);
       };
@@ -487,27 +514,44 @@ namespace adaflo_hip
                   // outstanding after the pieces of q: AHEAD - 2 younger pieces, plus, right
                   // after the plane refill was issued (q < 4), the plane copies of this wave
                   constexpr int younger = AHEAD - 2;
+#if defined(Q2_EXP) && (Q2_EXP == 1 || Q2_EXP == 2)
+                  if (false)
+#else
                   if (q < AHEAD / 2)
+#endif
                     {
                       if (WITH_P)
                         wait_vmcnt<younger + NPL_U + NPL_P>();
                       else
                         wait_vmcnt<younger + NPL_U>();
                     }
+#if !defined(Q2_EXP) || (Q2_EXP != 1 && Q2_EXP != 2)
                   else
                     wait_vmcnt<younger>();
+#endif
                   const double2 *rs = reinterpret_cast<const double2 *>(ringw);
                   st0 = rs[((2 * q) % RING) * (PIECE / 2) + slan - wave * 48];
                   st1 = rs[((2 * q + 1) % RING) * (PIECE / 2) + slan - wave * 48];
                   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                   // refill the two slots that became free (after the last layer of the chunk
                   // the same pieces are harmlessly fetched again: fixed VMEM op count)
+#if defined(Q2_EXP) && Q2_EXP == 2
+                  if (false)
+                    {
+                    }
+                  else if (false)
+#else
                   if (2 * q + AHEAD < 54)
+#endif
                     {
                       issue_piece(cz, 2 * q + AHEAD);
                       issue_piece(cz, 2 * q + AHEAD + 1);
                     }
+#if !defined(Q2_EXP) || Q2_EXP != 2
                   else
+#else
+                  else if (false)
+#endif
                     {
                       issue_piece(cz_next, 2 * q + AHEAD - 54);
                       issue_piece(cz_next, 2 * q + AHEAD + 1 - 54);
@@ -713,7 +757,6 @@ namespace adaflo_hip
                           if (lastx && lasty)
                             nv[8] += cex[6];
                         }
-                      const bool   zseam = lk == 0 && layer == 0 && cz0 > 0;
                       const bool   zcon  = (K == 0 && conz_lo);
                       const size_t pbase = (size_t)K * A.nny * A.nnx * 3;
 #pragma unroll
@@ -724,8 +767,9 @@ namespace adaflo_hip
                             const size_t   idx = pbase + lane_g + (unsigned)((lj * A.nnx + li) * 3);
                             if ((m_con >> n & 1u) || zcon)
                               A.dst_u[idx] = A.src_u[idx]; // :247-256 (+1 on the velocity block)
-                            else if ((m_seam >> n & 1u) || zseam)
-                              unsafeAtomicAdd(&A.dst_u[idx], nv[n]);
+                            else if (m_seam >> n & 1u)
+                              A.slab_u[((wgs * (2 * A.LZ + 1) + 2 * layer + lk) * RIM_U +
+                                        rim_index<PNX>(2 * cxl + li, 2 * cyl + lj)) * 3 + d] = nv[n];
                             else
                               A.dst_u[idx] = nv[n];
                           }
@@ -769,7 +813,6 @@ namespace adaflo_hip
                       if (lastx && lasty)
                         nv[3] += cpx[1];
                       const int    K     = cz;
-                      const bool   zseam = layer == 0 && cz0 > 0;
                       const bool   zcon  = (K == 0 && conz_lo);
                       const size_t pbase = (size_t)K * A.npy * A.npx;
 #pragma unroll
@@ -781,8 +824,9 @@ namespace adaflo_hip
                               const size_t idx = pbase + lane_g + (unsigned)(lj * A.npx + li);
                               if ((m_con >> bit & 1u) || zcon)
                                 A.dst_p[idx] = -A.src_p[idx]; // -1 on the pressure block of vmult
-                              else if ((m_seam >> bit & 1u) || zseam)
-                                unsafeAtomicAdd(&A.dst_p[idx], nv[n]);
+                              else if (m_seam >> bit & 1u)
+                                A.slab_p[(wgs * (A.LZ + 1) + layer) * RIM_P +
+                                         rim_index<QNX>(cxl + li, cyl + lj)] = nv[n];
                               else
                                 A.dst_p[idx] = nv[n];
                             }
@@ -822,8 +866,11 @@ namespace adaflo_hip
                   const size_t idx = pbase + lane_g + (unsigned)((lj * A.nnx + li) * 3);
                   if ((m_con >> n & 1u) || zcon)
                     A.dst_u[idx] = A.src_u[idx];
-                  else if ((m_seam >> n & 1u) || zseam)
-                    unsafeAtomicAdd(&A.dst_u[idx], nv[n]);
+                  else if (m_seam >> n & 1u)
+                    A.slab_u[((wgs * (2 * A.LZ + 1) + 2 * nl) * RIM_U +
+                              rim_index<PNX>(2 * cxl + li, 2 * cyl + lj)) * 3 + d] = nv[n];
+                  else if (zseam)
+                    A.zslab_u[(wgs * (PNX * PNY) + (2 * cyl + lj) * PNX + 2 * cxl + li) * 3 + d] = nv[n];
                   else
                     A.dst_u[idx] = nv[n];
                 }
@@ -848,8 +895,10 @@ namespace adaflo_hip
                     const size_t idx = pbase + lane_g + (unsigned)(lj * A.npx + li);
                     if ((m_con >> bit & 1u) || zcon)
                       A.dst_p[idx] = -A.src_p[idx];
-                    else if ((m_seam >> bit & 1u) || zseam)
-                      unsafeAtomicAdd(&A.dst_p[idx], nv[n]);
+                    else if (m_seam >> bit & 1u)
+                      A.slab_p[(wgs * (A.LZ + 1) + nl) * RIM_P + rim_index<QNX>(cxl + li, cyl + lj)] = nv[n];
+                    else if (zseam)
+                      A.zslab_p[wgs * PPLANE + (cyl + lj) * QNX + cxl + li] = nv[n];
                     else
                       A.dst_p[idx] = nv[n];
                   }
@@ -858,13 +907,96 @@ namespace adaflo_hip
       }
     }
 
+    // second pass: add the seam partials per node (fixed order -> reproducible) and write dst
+    template <int DEG, int NC>
+    __device__ __forceinline__ void fixup_rim(const Q2Args &A, long t, double *dst,
+                                              const double *slab, const int nn_x, const int nn_y,
+                                              const int nn_z, const uint32_t con)
+    {
+      constexpr int TN = DEG * TX + 1, RIM = 4 * (TN - 1), HI = 2 * TN - 1;
+      const int     comp = (int)(t % NC);
+      t /= NC;
+      const int s = (int)(t % HI);
+      t /= HI;
+      const int  K  = (int)(t % nn_z);
+      const long bt = t / nn_z;
+      const int  bx = (int)(bt % A.tiles_x), by = (int)(bt / A.tiles_x);
+      const int  i = s < TN ? s : TN - 1, j = s < TN ? TN - 1 : s - TN;
+      const int  I = DEG * TX * bx + i, J = DEG * TY * by + j;
+      if (I >= nn_x || J >= nn_y)
+        return;
+      const bool seam_x = i == TN - 1 && I < nn_x - 1, seam_y = j == TN - 1 && J < nn_y - 1;
+      if (!(seam_x || seam_y))
+        return;
+      if ((i == 0 && I > 0) || (j == 0 && J > 0))
+        return; // owned by the tile to the west / south
+      if (on_constrained_face(I, J, K, nn_x, nn_y, nn_z, con, NC == 1 ? 1 : 3, comp))
+        return; // dst = +-src already written by every sharer
+      const int ppc  = DEG * A.LZ + 1;
+      const int c_hi = min(K / (DEG * A.LZ), A.n_chunks - 1);
+      const int lp   = K - DEG * A.LZ * c_hi;
+      double    sum  = 0.;
+      for (int dy = 0; dy <= (seam_y ? 1 : 0); ++dy)
+        for (int dx = 0; dx <= (seam_x ? 1 : 0); ++dx)
+          {
+            const long tb = (long)(by + dy) * A.tiles_x + bx + dx;
+            const int  r  = rim_index<TN>(i - (TN - 1) * dx, j - (TN - 1) * dy);
+            sum += slab[(((tb * A.n_chunks + c_hi) * ppc + lp) * RIM + r) * NC + comp];
+            if (lp == 0 && c_hi > 0) // top plane of the chunk below
+              sum += slab[(((tb * A.n_chunks + c_hi - 1) * ppc + DEG * A.LZ) * RIM + r) * NC + comp];
+          }
+      dst[((long)(K * (long)nn_y + J) * nn_x + I) * NC + comp] = sum;
+    }
+
+    template <int DEG, int NC>
+    __device__ __forceinline__ void fixup_zplane(const Q2Args &A, long t, double *dst,
+                                                 const double *zslab, const int nn_x, const int nn_y,
+                                                 const int nn_z, const uint32_t con)
+    {
+      constexpr int TN = DEG * TX + 1;
+      const int     e  = (int)(t % (TN * TN * NC));
+      t /= TN * TN * NC;
+      const int  m  = (int)(t % (A.n_chunks - 1)) + 1;
+      const long bt = t / (A.n_chunks - 1);
+      const int  bx = (int)(bt % A.tiles_x), by = (int)(bt / A.tiles_x);
+      const int  comp = e % NC, n = e / NC, i = n % TN, j = n / TN;
+      const int  I = DEG * TX * bx + i, J = DEG * TY * by + j, K = DEG * A.LZ * m;
+      if (I >= nn_x || J >= nn_y)
+        return;
+      const bool seam = (i == 0 && I > 0) || (i == TN - 1 && I < nn_x - 1) || (j == 0 && J > 0) ||
+                        (j == TN - 1 && J < nn_y - 1);
+      if (seam || on_constrained_face(I, J, K, nn_x, nn_y, nn_z, con, NC == 1 ? 1 : 3, comp))
+        return;
+      dst[((long)(K * (long)nn_y + J) * nn_x + I) * NC + comp] += zslab[(bt * A.n_chunks + m - 1) * (TN * TN * NC) + e];
+    }
+
+    __global__ __launch_bounds__(256) void q2_seam_fixup_kernel(const Q2Args A, const long n1,
+                                                                const long n2, const long n3,
+                                                                const long n4)
+    {
+      for (long t = blockIdx.x * 256L + threadIdx.x; t < n1 + n2 + n3 + n4; t += (long)gridDim.x * 256)
+        {
+          if (t < n1)
+            fixup_rim<2, 3>(A, t, A.dst_u, A.slab_u, A.nnx, A.nny, A.nnz, A.con_u);
+          else if (t < n1 + n2)
+            fixup_zplane<2, 3>(A, t - n1, A.dst_u, A.zslab_u, A.nnx, A.nny, A.nnz, A.con_u);
+          else if (t < n1 + n2 + n3)
+            fixup_rim<1, 1>(A, t - n1 - n2, A.dst_p, A.slab_p, A.npx, A.npy, A.npz, A.con_p);
+          else
+            fixup_zplane<1, 1>(A, t - n1 - n2 - n3, A.dst_p, A.zslab_p, A.npx, A.npy, A.npz, A.con_p);
+        }
+    }
+
     // generic [cell][12][27] -> streaming layout [tile][layer][q][half][cell-in-tile*3+d][2]
     __global__ __launch_bounds__(256) void q2_convert_state_kernel(double *__restrict__ out,
                                                                    const double *__restrict__ gen,
                                                                    const int ncx, const int ncy,
                                                                    const int ncz, const int tiles_x,
-                                                                   const long total, const int lin_mode)
+                                                                   const long total, const int lin_mode,
+                                                                   const long stride2)
     {
+      // `total` counts payload doubles; blocks of STATE_PER_LAYER doubles are stored stride2
+      // double2 apart (skew padding against HBM channel camping of the lock-step streams)
       for (long o = blockIdx.x * 256L + threadIdx.x; o < total; o += (long)gridDim.x * 256)
         {
           const int  j    = (int)(o & 1);
@@ -893,7 +1025,7 @@ namespace adaflo_hip
                 comp = 3 + 3 * d + (2 * half + j - 1); // grad_lin[d][e]
               v = gen[(cell * NLIN + comp) * 27 + q];
             }
-          out[o] = v;
+          out[(o / STATE_PER_LAYER) * (2 * stride2) + (o % STATE_PER_LAYER)] = v;
         }
     }
   } // namespace
@@ -915,7 +1047,9 @@ namespace adaflo_hip
     if (ctx->lin_q2_valid || q2_lin_mode(ctx) == 2)
       return 0;
     const int    tiles_x = (ctx->desc.ncell[0] + TX - 1) / TX, tiles_y = (ctx->desc.ncell[1] + TY - 1) / TY;
-    const size_t count   = (size_t)tiles_x * tiles_y * ctx->desc.ncell[2] * STATE_PER_LAYER;
+    const size_t payload = (size_t)tiles_x * tiles_y * ctx->desc.ncell[2] * STATE_PER_LAYER;
+    const long   stride2 = STATE_PER_LAYER / 2 + ctx->q2_state_pad;
+    const size_t count   = (size_t)tiles_x * tiles_y * ctx->desc.ncell[2] * 2 * stride2;
     if (ctx->lin_q2.count != count)
       {
         if (ctx->lin_q2.p)
@@ -926,12 +1060,14 @@ namespace adaflo_hip
           return ADAFLO_ENOMEM;
         ctx->lin_q2.count = count;
       }
-    long nb = (long)((count + 255) / 256);
+    if (hipMemsetAsync(ctx->lin_q2.p, 0, count * sizeof(double), ctx->stream) != hipSuccess)
+      return ADAFLO_EHIP;
+    long nb = (long)((payload + 255) / 256);
     if (nb > 256 * 32)
       nb = 256 * 32;
     hipLaunchKernelGGL(q2_convert_state_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream,
                        ctx->lin_q2.p, ctx->lin.p, ctx->desc.ncell[0], ctx->desc.ncell[1],
-                       ctx->desc.ncell[2], tiles_x, (long)count, q2_lin_mode(ctx));
+                       ctx->desc.ncell[2], tiles_x, (long)payload, q2_lin_mode(ctx), stride2);
     if (hipGetLastError() != hipSuccess)
       return ADAFLO_EHIP;
     ctx->lin_q2_valid = true;
@@ -996,6 +1132,7 @@ namespace adaflo_hip
     A.tau_gd      = P.tau_grad_div;
     A.tmu         = P.viscosity * P.tau1; // :841-845
     A.integrate_p = P.linearization != ADAFLO_PROJECTION;
+    A.state_stride = STATE_PER_LAYER / 2 + ctx->q2_state_pad;
     A.con_u       = ctx->brick.con_u;
     A.con_p       = ctx->brick.con_p;
     A.src_u       = src_u;
@@ -1006,20 +1143,33 @@ namespace adaflo_hip
     const int  lin_mode = q2_lin_mode(ctx);
     const bool with_p   = op == OP_VMULT;
 
-    // seam nodes are accumulated with atomics -> dst must start from zero (:229)
-    if (hipMemsetAsync(dst_u, 0, sizeof(double) * 3 * ctx->n_nodes_u, ctx->stream) != hipSuccess)
-      return ADAFLO_EHIP;
-    if (with_p)
-      {
-        if (A.integrate_p)
+    // seam partial sums go to slabs (no atomics, no zero-initialisation of dst needed: every
+    // entry of dst is written exactly once by the main kernel or by the fix-up kernel)
+    {
+      const size_t n_wg = (size_t)A.tiles_x * A.tiles_y * A.n_chunks;
+      const size_t need[4] = {n_wg * (2 * A.LZ + 1) * RIM_U * 3, n_wg * UPLANE,
+                              n_wg * (A.LZ + 1) * RIM_P, n_wg * PPLANE};
+      DeviceBuffer *buf[4] = {&ctx->q2_slab_u, &ctx->q2_zslab_u, &ctx->q2_slab_p, &ctx->q2_zslab_p};
+      for (int i = 0; i < 4; ++i)
+        if (buf[i]->count < need[i])
           {
-            if (hipMemsetAsync(dst_p, 0, sizeof(double) * ctx->n_nodes_p, ctx->stream) != hipSuccess)
-              return ADAFLO_EHIP;
+            if (buf[i]->p)
+              (void)hipFree(buf[i]->p);
+            buf[i]->p     = nullptr;
+            buf[i]->count = 0;
+            if (hipMalloc(&buf[i]->p, need[i] * sizeof(double)) != hipSuccess)
+              return ADAFLO_ENOMEM;
+            buf[i]->count = need[i];
           }
-        else if (int e = launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, A.npx, A.npy, A.npz,
-                                            A.con_p, -1., true))
-          return e;
-      }
+      A.slab_u  = ctx->q2_slab_u.p;
+      A.zslab_u = ctx->q2_zslab_u.p;
+      A.slab_p  = ctx->q2_slab_p.p;
+      A.zslab_p = ctx->q2_zslab_p.p;
+    }
+    if (with_p && !A.integrate_p)
+      if (int e = launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, A.npx, A.npy, A.npz,
+                                     A.con_p, -1., true))
+        return e;
     const long nwg  = (long)A.tiles_x * A.tiles_y * A.n_chunks;
     hipEvent_t stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
     const dim3   grid((unsigned)nwg), block(NT);
@@ -1067,6 +1217,17 @@ namespace adaflo_hip
     if (stop)
       (void)hipEventRecord(stop, ctx->stream);
     ctx->kernel_timer.count++;
+    {
+      const long tiles = (long)A.tiles_x * A.tiles_y;
+      const bool fix_p = with_p && A.integrate_p;
+      const long n1 = tiles * A.nnz * (2 * PNX - 1) * 3, n2 = tiles * (A.n_chunks - 1) * UPLANE;
+      const long n3 = fix_p ? tiles * A.npz * (2 * QNX - 1) : 0, n4 = fix_p ? tiles * (A.n_chunks - 1) * PPLANE : 0;
+      long       nb = (n1 + n2 + n3 + n4 + 255) / 256;
+      if (nb > 256 * 64)
+        nb = 256 * 64;
+      hipLaunchKernelGGL(q2_seam_fixup_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, A, n1,
+                         n2, n3, n4);
+    }
     return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
   }
 } // namespace adaflo_hip

@@ -254,3 +254,6 @@ class NavierStokesMatrix:
         stationary equation (navier_stokes_matrix.cc:196-197)"""
         p = self.parameters
         return p.linearization != "projection" and p.physical_type != "incompressible stationary"
+
+    def set_q2_state_pad(self, pad_16b):
+        _lib.check(self._ctx, self._lib.adaflo_set_q2_state_pad(self._require(), int(pad_16b)))

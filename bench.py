@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--degree", type=int, default=2)
     ap.add_argument("--variant", type=int, default=1, help="0 generic kernels, 1 specialised")
     ap.add_argument("--chunk", type=int, default=0, help="Q2 kernel z-chunk (0 = heuristic)")
+    ap.add_argument("--state-pad", type=int, default=-1, help="Q2 state skew padding in 16 B units")
     ap.add_argument("--linearization", default="coupled implicit Newton",
                     help="diagnostic only: e.g. 'coupled velocity explicit' times the kernel without q-state")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,6 +143,8 @@ def main():
     op.set_kernel_variant(args.variant)
     if args.chunk:
         op.local.set_q2_chunk(args.chunk)
+    if args.state_pad >= 0:
+        op.local.set_q2_state_pad(args.state_pad)
 
     mesh = op.local.mesh
     n_u, n_p = op.local.n_dofs_u(), op.local.n_dofs_p()

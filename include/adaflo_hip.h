@@ -183,6 +183,8 @@ int adaflo_get_kernel_statistics(adaflo_ctx *ctx, unsigned *count, double *secon
 int adaflo_set_timing(adaflo_ctx *ctx, int enabled);
 /* tuning: number of cell layers one workgroup of the Q2/Q1 kernel sweeps (0 = heuristic) */
 int adaflo_set_q2_chunk(adaflo_ctx *ctx, int layers);
+/* tuning: skew padding (units of 16 B) between the per-(tile,layer) blocks of the streamed state */
+int adaflo_set_q2_state_pad(adaflo_ctx *ctx, int pad_16B);
 
 /* select the implementation of adaflo_ns_vmult: 0 = generic (any degree),
  * 1 = auto (specialised kernels where available; default).                    */
