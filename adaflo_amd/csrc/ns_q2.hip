@@ -41,10 +41,9 @@ namespace adaflo_hip
     {
       int    ncx, ncy, ncz, nnx, nny, nnz, npx, npy, npz;
       int    tiles_x, tiles_y, LZ, n_chunks;
-      double ih[3];
       double s0, s1, s2;   // first row of the 3x3 interpolation matrix (rows: [s0 s1 s2], [0 1 0], [s2 s1 s0])
       // collocation derivative at the 3 Gauss points: rows (a0 a1 a2), (-b 0 b), (-a2 -a1 -a0)
-      double a0, a1, a2, b;
+      double ah[3][4];     // (a0, a1, a2, b) / h[e] per direction (ISO: only ah[0] is read)
       double wj[4];        // JxW by number of "middle" indices of the q-point: det * w0^(3-m) * w1^m
       double cA, cB;       // conv = cA * u + cB * res, cA = gamma*rho - damping, cB = tau1*rho
       double beta, tau_gd, tmu;
@@ -207,8 +206,7 @@ namespace adaflo_hip
       asm volatile("s_mov_b32 m0, %0\n\t"
                    "s_mov_b64 exec, %3\n\t"
                    "global_load_lds_dwordx4 %1, %2\n\t"
-                   "s_mov_b64 exec, -1" ::"s"(uniform32(lds_byte)),
-                   "v"(voff), "s"(uniform64((unsigned long long)sbase)), "s"(uniform64(mask))
+                   "s_mov_b64 exec, -1" ::"s"(lds_byte), "v"(voff), "s"(sbase), "s"(mask)
                    : "memory");
     }
     //   lane l writes lds_byte + 4*l
@@ -218,8 +216,7 @@ namespace adaflo_hip
       asm volatile("s_mov_b32 m0, %0\n\t"
                    "s_mov_b64 exec, %3\n\t"
                    "global_load_lds_dword %1, %2\n\t"
-                   "s_mov_b64 exec, -1" ::"s"(uniform32(lds_byte)),
-                   "v"(voff), "s"(uniform64((unsigned long long)sbase)), "s"(uniform64(mask))
+                   "s_mov_b64 exec, -1" ::"s"(lds_byte), "v"(voff), "s"(sbase), "s"(mask)
                    : "memory");
     }
 
@@ -284,12 +281,14 @@ namespace adaflo_hip
 
     // LIN_MODE: 0 Newton (state = u_lin, grad u_lin), 1 Picard-type (state = u_lin, div u_lin),
     //           2 no convective linearisation (explicit convection, Stokes)
-    template <int LIN_MODE, bool WITH_P>
+    // ISO: cubic cells, one set of derivative coefficients for all directions
+    template <int LIN_MODE, bool WITH_P, bool ISO>
     __global__ __launch_bounds__(NT, 2) void ns_q2_kernel(const Q2Args A)
     {
       extern __shared__ double lds[];
 
-      const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+      const int tid = threadIdx.x, lane = tid & 63;
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform by construction
       const int d = lane & 3, cq = lane >> 2;
       const int cxl = cq & 7, cyl = 2 * wave + (cq >> 3), cell = cyl * TX + cxl;
 
@@ -509,6 +508,7 @@ namespace adaflo_hip
             {
               const int qx = q % 3, qy = (q / 3) % 3, qz = q / 9;
               double2   st0 = make_double2(0., 0.), st1 = make_double2(0., 0.);
+              double    r_ub0 = 0., r_ub1 = 0., r_ub2 = 0., r_trl = 0.;
               if (LIN_MODE != 2)
                 {
                   // outstanding after the pieces of q: AHEAD - 2 younger pieces, plus, right
@@ -532,6 +532,16 @@ namespace adaflo_hip
                   const double2 *rs = reinterpret_cast<const double2 *>(ringw);
                   st0 = rs[((2 * q) % RING) * (PIECE / 2) + slan - wave * 48];
                   st1 = rs[((2 * q + 1) % RING) * (PIECE / 2) + slan - wave * 48];
+                  // the quad's three (u_lin_e, grad_e0) and (grad_e1, grad_e2) entries
+                  const double *rq0 = ringw + ((2 * q) % RING) * PIECE + 6 * cq;
+                  const double *rq1 = ringw + ((2 * q + 1) % RING) * PIECE + 6 * cq;
+                  if (LIN_MODE == 0)
+                    {
+                      r_ub0 = rq0[0], r_ub1 = rq0[2], r_ub2 = rq0[4];
+                      r_trl = rq0[1] + rq1[2] + rq1[5];
+                    }
+                  else
+                    r_ub0 = rq0[0], r_ub1 = rq0[2], r_ub2 = rq0[4];
                   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                   // refill the two slots that became free (after the last layer of the chunk
                   // the same pieces are harmlessly fetched again: fixed VMEM op count)
@@ -559,12 +569,13 @@ namespace adaflo_hip
                 }
               const double Vq = V[q];
               // reference-cell derivatives by the collocation derivative, then J^{-T}
-              const double g0 = dline(qx, V[0 + 3 * qy + 9 * qz], V[1 + 3 * qy + 9 * qz], V[2 + 3 * qy + 9 * qz],
-                                      A.a0, A.a1, A.a2, A.b) * A.ih[0];
-              const double g1 = dline(qy, V[qx + 9 * qz], V[qx + 3 + 9 * qz], V[qx + 6 + 9 * qz],
-                                      A.a0, A.a1, A.a2, A.b) * A.ih[1];
-              const double g2 = dline(qz, V[qx + 3 * qy], V[qx + 3 * qy + 9], V[qx + 3 * qy + 18],
-                                      A.a0, A.a1, A.a2, A.b) * A.ih[2];
+              constexpr int e1 = ISO ? 0 : 1, e2 = ISO ? 0 : 2;
+              const double  g0 = dline(qx, V[0 + 3 * qy + 9 * qz], V[1 + 3 * qy + 9 * qz], V[2 + 3 * qy + 9 * qz],
+                                       A.ah[0][0], A.ah[0][1], A.ah[0][2], A.ah[0][3]);
+              const double  g1 = dline(qy, V[qx + 9 * qz], V[qx + 3 + 9 * qz], V[qx + 6 + 9 * qz],
+                                       A.ah[e1][0], A.ah[e1][1], A.ah[e1][2], A.ah[e1][3]);
+              const double  g2 = dline(qz, V[qx + 3 * qy], V[qx + 3 * qy + 9], V[qx + 3 * qy + 18],
+                                       A.ah[e2][0], A.ah[e2][1], A.ah[e2][2], A.ah[e2][3]);
 
               // gradient rows of the three velocity components, visible to all four lanes
               const double G00 = quad_bcast<0>(g0), G01 = quad_bcast<0>(g1), G02 = quad_bcast<0>(g2);
@@ -576,8 +587,8 @@ namespace adaflo_hip
               if (LIN_MODE == 0)       // Newton :802-816
                 {
                   const double u0 = quad_bcast<0>(Vq), u1 = quad_bcast<1>(Vq), u2 = quad_bcast<2>(Vq);
-                  const double ub0 = quad_bcast<0>(st0.x), ub1 = quad_bcast<1>(st0.x), ub2 = quad_bcast<2>(st0.x);
-                  const double trl = quad_bcast<0>(st0.y) + quad_bcast<1>(st1.x) + quad_bcast<2>(st1.y);
+                  // u_lin of all components and tr(grad u_lin): quad-uniform LDS reads of the ring
+                  const double ub0 = r_ub0, ub1 = r_ub1, ub2 = r_ub2, trl = r_trl;
                   double       res = A.beta * (div * st0.x + trl * Vq);
                   res += ub0 * g0 + u0 * st0.y;
                   res += ub1 * g1 + u1 * st1.x;
@@ -586,7 +597,7 @@ namespace adaflo_hip
                 }
               else if (LIN_MODE == 1) // Picard-type :817-826, state = (u_lin, div_lin)
                 {
-                  const double ub0 = quad_bcast<0>(st0.x), ub1 = quad_bcast<1>(st0.x), ub2 = quad_bcast<2>(st0.x);
+                  const double ub0 = r_ub0, ub1 = r_ub1, ub2 = r_ub2;
                   double       res = (A.beta * st0.y) * Vq;
                   res += ub0 * g0;
                   res += ub1 * g1;
@@ -603,17 +614,20 @@ namespace adaflo_hip
               diag *= jxw;
               // :859-892: row d of tmu (grad u + grad u^T) + (tau_gd div - p) I, times JxW J^{-1}
               const double tmj = tmu_l * jxw;
-              const double tg0 = (tmj * (g0 + c0) + d0 * diag) * A.ih[0];
-              const double tg1 = (tmj * (g1 + c1) + d1 * diag) * A.ih[1];
-              const double tg2 = (tmj * (g2 + c2) + d2 * diag) * A.ih[2];
+              const double tg0 = tmj * (g0 + c0) + d0 * diag;
+              const double tg1 = tmj * (g1 + c1) + d1 * diag;
+              const double tg2 = tmj * (g2 + c2) + d2 * diag;
               // test value: momentum rows (:837) or the pressure row (q, -div u) (:853-856)
               const double tv = (is_p ? -div : conv) * jxw;
 
               // integrate (collocation derivative transposed), accumulate at the Gauss points
               R[q] += tv;
-              dline_t(qx, tg0, R[0 + 3 * qy + 9 * qz], R[1 + 3 * qy + 9 * qz], R[2 + 3 * qy + 9 * qz], A.a0, A.a1, A.a2, A.b);
-              dline_t(qy, tg1, R[qx + 9 * qz], R[qx + 3 + 9 * qz], R[qx + 6 + 9 * qz], A.a0, A.a1, A.a2, A.b);
-              dline_t(qz, tg2, R[qx + 3 * qy], R[qx + 3 * qy + 9], R[qx + 3 * qy + 18], A.a0, A.a1, A.a2, A.b);
+              dline_t(qx, tg0, R[0 + 3 * qy + 9 * qz], R[1 + 3 * qy + 9 * qz], R[2 + 3 * qy + 9 * qz],
+                      A.ah[0][0], A.ah[0][1], A.ah[0][2], A.ah[0][3]);
+              dline_t(qy, tg1, R[qx + 9 * qz], R[qx + 3 + 9 * qz], R[qx + 6 + 9 * qz],
+                      A.ah[e1][0], A.ah[e1][1], A.ah[e1][2], A.ah[e1][3]);
+              dline_t(qz, tg2, R[qx + 3 * qy], R[qx + 3 * qy + 9], R[qx + 3 * qy + 18],
+                      A.ah[e2][0], A.ah[e2][1], A.ah[e2][2], A.ah[e2][3]);
             }
 
           // ---- transposed interpolation back to the nodes --------------------------------
@@ -1105,8 +1119,6 @@ namespace adaflo_hip
       A.LZ       = lz;
       A.n_chunks = (A.ncz + lz - 1) / lz;
     }
-    for (int d = 0; d < 3; ++d)
-      A.ih[d] = 1. / ctx->desc.h[d];
     {
       const double       det = ctx->desc.h[0] * ctx->desc.h[1] * ctx->desc.h[2];
       const Quadrature1D qu  = gauss(3);
@@ -1115,10 +1127,14 @@ namespace adaflo_hip
       A.s1 = su.S[1];
       A.s2 = su.S[2];
       const std::vector<double> dc = collocation_derivative(qu);
-      A.a0 = dc[0];
-      A.a1 = dc[1];
-      A.a2 = dc[2];
-      A.b  = dc[5];
+      for (int e = 0; e < 3; ++e)
+        {
+          const double ih = 1. / ctx->desc.h[e];
+          A.ah[e][0]      = dc[0] * ih;
+          A.ah[e][1]      = dc[1] * ih;
+          A.ah[e][2]      = dc[2] * ih;
+          A.ah[e][3]      = dc[5] * ih;
+        }
       for (int m = 0; m < 4; ++m)
         A.wj[m] = det * std::pow(qu.w[0], 3 - m) * std::pow(qu.w[1], m);
     }
@@ -1172,20 +1188,28 @@ namespace adaflo_hip
         return e;
     const long nwg  = (long)A.tiles_x * A.tiles_y * A.n_chunks;
     hipEvent_t stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
+    const bool   iso = ctx->desc.h[0] == ctx->desc.h[1] && ctx->desc.h[1] == ctx->desc.h[2];
     const dim3   grid((unsigned)nwg), block(NT);
     const size_t lds_bytes = sizeof(double) * L_TOTAL;
     hipError_t   err       = hipSuccess;
-#define Q2_LAUNCH(LM, WP)                                                                       \
+#define Q2_LAUNCH_I(LM, WP, IS)                                                                       \
   {                                                                                             \
     static bool attr_set = false;                                                               \
     if (!attr_set)                                                                              \
       {                                                                                         \
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_q2_kernel<LM, WP>),        \
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_q2_kernel<LM, WP, IS>),        \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
         attr_set = err == hipSuccess;                                                           \
       }                                                                                         \
     if (err == hipSuccess)                                                                      \
-      hipLaunchKernelGGL((ns_q2_kernel<LM, WP>), grid, block, lds_bytes, ctx->stream, A);       \
+      hipLaunchKernelGGL((ns_q2_kernel<LM, WP, IS>), grid, block, lds_bytes, ctx->stream, A);   \
+  }
+#define Q2_LAUNCH(LM, WP)      \
+  {                            \
+    if (iso)                   \
+      Q2_LAUNCH_I(LM, WP, true) \
+    else                       \
+      Q2_LAUNCH_I(LM, WP, false) \
   }
     if (with_p)
       switch (lin_mode)
@@ -1212,6 +1236,7 @@ namespace adaflo_hip
             Q2_LAUNCH(2, false);
         }
 #undef Q2_LAUNCH
+#undef Q2_LAUNCH_I
     if (err != hipSuccess)
       return ADAFLO_EHIP;
     if (stop)
