@@ -257,3 +257,23 @@ class NavierStokesMatrix:
 
     def set_q2_state_pad(self, pad_16b):
         _lib.check(self._ctx, self._lib.adaflo_set_q2_state_pad(self._require(), int(pad_16b)))
+
+    # -- torch plumbing used by the multi-GPU layer ------------------------------------------
+    def _torch_device(self):
+        import torch
+        return torch.device("cuda", self._desc.device)
+
+    def new_u_tensor(self):
+        import torch
+        return torch.zeros(self.n_dofs_u(), dtype=torch.float64, device=self._torch_device())
+
+    def new_p_tensor(self):
+        import torch
+        return torch.zeros(self.n_dofs_p(), dtype=torch.float64, device=self._torch_device())
+
+    def wrap(self, tensor):
+        return DeviceVector.from_torch(self._require(), tensor)
+
+    def synchronize_torch(self):
+        import torch
+        torch.cuda.synchronize(self._torch_device())

@@ -183,15 +183,19 @@ class HaloExchange:
 class DistributedNavierStokesMatrix:
     """NavierStokesMatrix over a brick partition: local HIP engine + RCCL halo exchange."""
 
-    def __init__(self, parameters, part, device=0, stream=None, group=None):
+    def __init__(self, parameters, part, device=0, stream=None, group=None, local=None):
+        """`local`: the per-rank operator; default = the HIP engine on the local brick.  (The
+        gloo/CPU tests inject an oracle-backed stand-in to check the exchange logic.)"""
         from .navier_stokes_matrix import BrickMesh, NavierStokesMatrix
         self.part = part
         self.group = group
         self.parameters = parameters
         k = parameters.velocity_degree
-        mesh = BrickMesh(part.cells, part.lower, part.upper)
-        self.local = NavierStokesMatrix(parameters, mesh, dirichlet_faces_u=part.physical_faces(),
-                                        constrained_faces_p=(), device=device, stream=stream)
+        if local is None:
+            mesh = BrickMesh(part.cells, part.lower, part.upper)
+            local = NavierStokesMatrix(parameters, mesh, dirichlet_faces_u=part.physical_faces(),
+                                       constrained_faces_p=(), device=device, stream=stream)
+        self.local = local
         self.halo = HaloExchange(part, [(k, 3), (k - 1, 1)], group=group)
         self._w_owned = None
         self._inv = None
@@ -210,17 +214,12 @@ class DistributedNavierStokesMatrix:
         """global version of source/navier_stokes_matrix.cc:117-168 (mode 0)"""
         import torch
         import torch.distributed as dist
-        from .vectors import DeviceVector
-        ctx = self.local._ctx
-        n_p = self.local.n_dofs_p()
-        dev = torch.device("cuda", self.local._desc.device)
-        w = torch.zeros(n_p, dtype=torch.float64, device=dev)
-        self.local.pressure_mass_weight(DeviceVector.from_torch(ctx, w))
+        w = self.local.new_p_tensor()
+        self.local.pressure_mass_weight(self.local.wrap(w))
         self.local.synchronize()
-        torch.cuda.synchronize(dev)
-        u_dummy = torch.zeros(self.local.n_dofs_u(), dtype=torch.float64, device=dev)
+        u_dummy = self.local.new_u_tensor()
         self.halo.compress_add([u_dummy, w])
-        self._w_owned = w * self.halo.owned_mask(1, device=dev)
+        self._w_owned = w * self.halo.owned_mask(1, device=w.device)
         s = self._w_owned.sum()
         dist.all_reduce(s, group=self.group)
         self._inv = 1.0 / s                       # device scalar, modes == 1 everywhere

@@ -1,0 +1,42 @@
+"""Pin the oracle to the reference's own golden output:
+tests/beltrami_3d.output:1-3,13 -- uniform 16^3 Q2/Q1 Beltrami problem, first
+nonlinear residual printed by NavierStokes::compute_residual."""
+import numpy as np
+
+from oracle import oracle as orc
+
+
+def beltrami_first_residual(n=16, k=2, dt=0.05, beta=0.5):
+    mesh = orc.Mesh.make([n] * 3, [-1.0] * 3, [1.0] * 3)
+    xu, xp = orc.node_coordinates(mesh, k), orc.node_coordinates(mesh, k - 1)
+    u0, p0 = orc.beltrami_u(xu, 0.0), orc.beltrami_p(xp, 0.0)        # tests/beltrami.cc:436-440
+    con_u = orc.boundary_mask(mesh, k, 3)
+    sol_u = u0.copy()
+    sol_u[con_u == 1] = orc.beltrami_u(xu, dt)[con_u == 1]           # navier_stokes.cc:1216-1257
+    # time_stepping.cc:123-200, first step: weight 1/dt, weight_old -1/dt, no extrapolation
+    prm = orc.NSParams.make(beta=beta, weight=1 / dt, weight_old=-1 / dt, weight_old_old=0.0)
+    lin = np.zeros(mesh.n_cells * (k + 1) ** 3 * 12)
+    ru, rp = orc.ns_residual(mesh, k, prm, sol_u, p0, u0, np.zeros_like(u0), con_u=con_u, lin=lin)
+    w = orc.ns_pressure_mass_weight(mesh, k)
+    rp = orc.ns_pressure_projection(rp, w, np.ones_like(w))          # navier_stokes.cc:786
+    return mesh, ru, rp
+
+
+def test_dof_counts_match_reference_output():
+    mesh = orc.Mesh.make([16] * 3, [-1.0] * 3, [1.0] * 3)
+    assert mesh.n_cells == 4096
+    assert 3 * mesh.n_nodes(2) == 107811 and mesh.n_nodes(1) == 4913    # beltrami_3d.output:3
+
+
+def test_first_nonlinear_residual_matches_reference_output():
+    _, ru, rp = beltrami_first_residual()
+    # beltrami_3d.output:13  "2.590e+00   6.423e-02" (printf %-11.3e)
+    assert "%.3e" % np.linalg.norm(ru) == "2.590e+00"
+    assert "%.3e" % np.linalg.norm(rp) == "6.423e-02"
+
+
+def test_residual_distinguishes_the_convective_formulations():
+    # the golden pins beta = 0.5 (skew-symmetric default): the other two forms print differently
+    for beta in (0.0, 1.0):
+        _, ru, _ = beltrami_first_residual(beta=beta)
+        assert "%.3e" % np.linalg.norm(ru) != "2.590e+00"

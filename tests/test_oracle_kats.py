@@ -1,0 +1,109 @@
+"""Analytic known-answer tests of the oracle and consistency of its two
+implementations (naive tables vs sum-factorised OpenMP)."""
+import numpy as np
+import pytest
+
+from common import Case, rel_l2
+from oracle import oracle as orc
+
+
+def test_1d_data_against_numpy():
+    for n in range(1, 7):
+        x, w = orc.gauss_legendre(n)
+        xr, wr = np.polynomial.legendre.leggauss(n)
+        assert np.allclose(x, 0.5 * (xr + 1), atol=1e-15) and np.allclose(w, 0.5 * wr, atol=1e-15)
+    assert np.allclose(orc.gauss_lobatto(3), [0, 0.5, 1])
+    assert np.allclose(orc.gauss_lobatto(4), [0, 0.5 - 0.5 / np.sqrt(5), 0.5 + 0.5 / np.sqrt(5), 1])
+    assert np.allclose(orc.gauss_lobatto(5), [0, 0.5 - 0.5 * np.sqrt(3 / 7), 0.5, 0.5 + 0.5 * np.sqrt(3 / 7), 1])
+    for k in (1, 2, 3, 4):
+        xq, _ = orc.gauss_legendre(k + 1)
+        S, D = orc.shape_1d(0, k, xq)
+        assert np.allclose(S.sum(axis=1), 1.0) and np.allclose(D.sum(axis=1), 0.0, atol=1e-13)
+        assert np.allclose(S @ orc.gauss_lobatto(k + 1), xq)  # linear reproduction
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_poiseuille_is_in_the_kernel_of_the_stokes_operator(dim):
+    """u = (1/(2 nu))(1-y^2) e_x, p = 2 - x (tests/poiseuille.cc:73-113) is in the Q2/Q1 space:
+    interior rows of the Stokes residual vanish to round-off."""
+    nu = 0.1
+    ncell = [4, 6] if dim == 2 else [3, 4, 2]
+    mesh = orc.Mesh.make(ncell, [-1.0] * dim, [1.0] * dim)
+    xu, xp = orc.node_coordinates(mesh, 2), orc.node_coordinates(mesh, 1)
+    u = np.zeros((xu.shape[0], dim))
+    u[:, 0] = 0.5 / nu * (1 - xu[:, 1] ** 2)
+    p = 2 - xp[:, 0]
+    prm = orc.NSParams.make(physical_type=2, density=0.0, viscosity=nu)
+    con_u = orc.boundary_mask(mesh, 2, dim)
+    du, dp = orc.ns_vmult(mesh, 2, prm, u.reshape(-1).copy(), p.copy(), None, None)
+    assert np.abs(du[con_u == 0]).max() < 1e-12      # momentum rows of interior test functions
+    assert np.abs(dp).max() < 1e-12                  # continuity rows: div u = 0 exactly
+
+
+def test_constant_pressure_and_rigid_translation():
+    case = Case((3, 2, 4), k=2, upper=(1.0, 0.8, 1.7), pressure_average_fix=False, faces_u=[])
+    ones_p = np.ones(case.n_p)
+    du, dp = orc.ns_vmult(case.mesh, 2, case.prm, np.zeros(case.n_u), ones_p, None, None,
+                          lin=np.zeros(case.n_cells * 27 * 12))
+    interior = orc.boundary_mask(case.mesh, 2, 3) == 0
+    assert np.abs(du[interior]).max() < 1e-13        # B^T 1 = 0 on interior rows
+    # rigid translation: viscous part 0, mass part gamma * rho * M 1 -> total = gamma * rho * volume
+    u = np.tile([1.0, 0.0, 0.0], case.n_u // 3)
+    du, dp = orc.ns_vmult(case.mesh, 2, case.prm, u, np.zeros(case.n_p), None, None,
+                          lin=np.zeros(case.n_cells * 27 * 12))
+    vol = 2.0 * 1.8 * 2.7
+    assert abs(du.reshape(-1, 3)[:, 0].sum() - case.prm.weight * vol) < 1e-10
+    assert np.abs(dp).max() < 1e-12
+
+
+def test_stokes_operator_is_symmetric():
+    case = Case((3, 3, 2), k=2, physical_type=2, pressure_average_fix=False)
+    x = (case.random_u(), case.random_p())
+    y = (case.random_u(), case.random_p())
+    for v in (x, y):  # symmetric on the space with homogeneous constraints
+        v[0][case.con_u == 1] = 0
+    ax = orc.ns_vmult(case.mesh, 2, case.prm, *x, case.con_u, None)
+    ay = orc.ns_vmult(case.mesh, 2, case.prm, *y, case.con_u, None)
+    lhs = x[0] @ ay[0] + x[1] @ ay[1]
+    rhs = y[0] @ ax[0] + y[1] @ ax[1]
+    assert abs(lhs - rhs) < 1e-11 * abs(lhs)
+
+
+def test_operator_is_linear_and_matches_unit_vector_probing():
+    case = Case((2, 2, 2), k=2, pressure_average_fix=False)
+    lin = case.random_lin()
+    x, y = (case.random_u(), case.random_p()), (case.random_u(), case.random_p())
+    f = lambda v: np.concatenate(orc.ns_vmult(case.mesh, 2, case.prm, v[0], v[1], case.con_u, None, lin=lin))
+    z = (2.5 * x[0] - y[0], 2.5 * x[1] - y[1])
+    assert rel_l2(f(z), 2.5 * f(x) - f(y)) < 1e-13
+
+
+@pytest.mark.parametrize("k,ncell", [(2, (5, 4, 3)), (3, (3, 2, 2)), (4, (2, 2, 2))])
+@pytest.mark.parametrize("lin", [0, 1, 3])
+def test_fast_oracle_matches_naive_oracle(k, ncell, lin):
+    case = Case(ncell, k=k, linearization=lin, faces_p=[2])
+    su, sp, l = case.random_u(), case.random_p(), case.random_lin()
+    rho, mu, dmp = case.random_coefficients()
+    w, modes = case.weights_modes()
+    kw = dict(lin=l, rho=rho, mu=mu, damp=dmp, weights=w, modes=modes)
+    a = orc.ns_vmult(case.mesh, k, case.prm, su, sp, case.con_u, case.con_p, **kw)
+    b = orc.fast_ns_vmult(case.mesh, k, case.prm, su, sp, case.con_u, case.con_p, **kw)
+    assert rel_l2(b[0], a[0]) < 1e-13 and rel_l2(b[1], a[1]) < 1e-13
+
+
+def test_beltrami_residual_converges_with_mesh_refinement():
+    """manufactured solution (tests/beltrami.cc:82-172): the discrete momentum residual of the
+    exact fields (incl. time derivative via BDF weights of the exact history) decays under refinement"""
+    errs = []
+    for n in (4, 8):
+        mesh = orc.Mesh.make([n] * 3, [-1.0] * 3, [1.0] * 3)
+        xu, xp = orc.node_coordinates(mesh, 2), orc.node_coordinates(mesh, 1)
+        dt, t = 1e-3, 0.1
+        prm = orc.NSParams.make(weight=1.5 / dt, weight_old=-2 / dt, weight_old_old=0.5 / dt, beta=0.0)
+        ru, rp = orc.ns_residual(mesh, 2, prm, orc.beltrami_u(xu, t), orc.beltrami_p(xp, t),
+                                 orc.beltrami_u(xu, t - dt), orc.beltrami_u(xu, t - 2 * dt),
+                                 con_u=orc.boundary_mask(mesh, 2, 3),
+                                 lin=np.zeros(mesh.n_cells * 27 * 12))
+        # dual norm proxy: residual functional scaled by the lumped mass (h^3)
+        errs.append(np.linalg.norm(ru) / (2.0 / n) ** 1.5)
+    assert errs[1] < errs[0] / 3.0
