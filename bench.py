@@ -200,6 +200,14 @@ def main():
     if not torch.isfinite(dst_u).all():
         raise SystemExit("non-finite result")
 
+    traffic = None
+    try:  # PMC-measured HBM bytes per launch of the dominant kernel (profiles/, collected with rocprofv3)
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("workload") == "%dx%dx%d k=%d variant=%d" % (nc, nc, nc, k, args.variant):
+            traffic = pmc["ns_q2_kernel"]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
     out = {
         "metric": "MDoF/s for NavierStokesMatrix::vmult (3D Q2/Q1)",
         "value": round(value, 1), "unit": "MDoF/s", "n_gpus": world, "steps": args.steps,
@@ -216,7 +224,7 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                      "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBS, 4) if achieved else None,
-                     "traffic": None, "kernel": "ns_q2_kernel" if (k == 2 and args.variant == 1)
+                     "traffic": traffic, "kernel": "ns_q2_kernel" if (k == 2 and args.variant == 1)
                      else "ns_cell_kernel", "kernel_ms": round(1e3 * kernel_avg, 4),
                      "alg_bytes_per_launch": b_alg_launch, "vmult_ms_device": round(1e3 * msec / max(mcount, 1), 4)},
     }
