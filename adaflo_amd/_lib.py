@@ -14,6 +14,12 @@ class BrickDesc(C.Structure):
                 ("device", C.c_int), ("stream", C.c_void_p)]
 
 
+class LSParams(C.Structure):
+    _fields_ = [("epsilon_used", C.c_double), ("minimal_edge_length", C.c_double),
+                ("time_step", C.c_double), ("weight", C.c_double), ("weight_old", C.c_double),
+                ("weight_old_old", C.c_double), ("epsilon", C.c_double)]
+
+
 class NSParams(C.Structure):
     _fields_ = [("physical_type", C.c_int), ("linearization", C.c_int), ("beta", C.c_double),
                 ("tau_grad_div", C.c_double), ("density", C.c_double), ("viscosity", C.c_double),
@@ -58,6 +64,20 @@ SIGNATURES = {
     "adaflo_ns_pressure_mass_weight_add": (C.c_int, [_CTX, _D]),
     "adaflo_ns_apply_constrained_rows": (C.c_int, [_CTX, _D, _D, _D, _D]),
     "adaflo_ns_get_matvec_statistics": (C.c_int, [_CTX, C.POINTER(C.c_uint), C.POINTER(C.c_double)]),
+    "adaflo_ls_set_params": (C.c_int, [_CTX, C.POINTER(LSParams)]),
+    "adaflo_ls_set_diagonal": (C.c_int, [_CTX, _D]),
+    "adaflo_ls_set_evaluated_convection": (C.c_int, [_CTX, C.c_void_p, C.c_int]),
+    "adaflo_ls_get_evaluated_convection": (C.c_int, [_CTX, C.c_void_p, C.c_int]),
+    "adaflo_ls_set_evaluated_normal": (C.c_int, [_CTX, C.c_void_p, C.c_int]),
+    "adaflo_ls_get_evaluated_normal": (C.c_int, [_CTX, C.c_void_p, C.c_int]),
+    "adaflo_ls_advance_concentration_vmult": (C.c_int, [_CTX, _D, _D]),
+    "adaflo_ls_advance_concentration_rhs": (C.c_int, [_CTX, _D, _D, _D, _D, _D, C.c_int]),
+    "adaflo_ls_reinitialization_vmult": (C.c_int, [_CTX, _D, _D, C.c_int]),
+    "adaflo_ls_reinitialization_rhs": (C.c_int, [_CTX, _D, _D, _D, C.c_int, C.c_int]),
+    "adaflo_ls_compute_normal_vmult": (C.c_int, [_CTX, _D, _D]),
+    "adaflo_ls_compute_normal_rhs": (C.c_int, [_CTX, _D, _D]),
+    "adaflo_ls_compute_curvature_vmult": (C.c_int, [_CTX, _D, _D, C.c_int]),
+    "adaflo_ls_compute_curvature_rhs": (C.c_int, [_CTX, _D, _D]),
     "adaflo_set_kernel_variant": (C.c_int, [_CTX, C.c_int]),
     "adaflo_get_kernel_statistics": (C.c_int, [_CTX, C.POINTER(C.c_uint), C.POINTER(C.c_double)]),
     "adaflo_set_timing": (C.c_int, [_CTX, C.c_int]),

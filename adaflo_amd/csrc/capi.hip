@@ -195,6 +195,21 @@ int adaflo_ctx_create(const adaflo_brick_desc *desc, adaflo_ctx **out)
     TRY(nullptr, upload(nullptr, &ctx->d_tab_pp, tabp), g_create_error);
   }
 
+  if (ctx->s > 0)
+    {
+      if (ctx->s > 4)
+        return fail(nullptr, ADAFLO_EUNSUPPORTED, "level-set subdivisions must be in [1,4]");
+      const Quadrature1D  ql = gauss2_iterated(ctx->s);
+      const Shape1D       sl = shape_fe_q_iso_q1(ctx->s, ql), sv = shape_fe_q(k, ql);
+      std::vector<double> tab;
+      tab.insert(tab.end(), sl.S.begin(), sl.S.end());
+      tab.insert(tab.end(), sl.D.begin(), sl.D.end());
+      tab.insert(tab.end(), ql.w.begin(), ql.w.end());
+      tab.insert(tab.end(), sv.S.begin(), sv.S.end());
+      TRY(nullptr, upload(nullptr, &ctx->d_tab_ls, tab), g_create_error);
+      ctx->ls = LSDev{0., 0., 1., 1., -1., 0., 1.};
+    }
+
   // default parameters = FlowParameters defaults relevant to the kernels
   ctx->ns = NSDev{ADAFLO_INCOMPRESSIBLE, ADAFLO_COUPLED_IMPLICIT_NEWTON, 0.5, 0., 1., 1., 0., 0.,
                   1., -1., 0., 1., 1., 0.};
@@ -236,9 +251,11 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
   (void)hipStreamSynchronize(ctx->stream);
   for (DeviceBuffer *b : {&ctx->lin, &ctx->rho, &ctx->mu, &ctx->damp, &ctx->lin_prec, &ctx->rho_prec,
                           &ctx->mu_prec, &ctx->damp_prec, &ctx->lin_q2, &ctx->lin_q2_prec,
-                          &ctx->q2_slab_u, &ctx->q2_zslab_u, &ctx->q2_slab_p, &ctx->q2_zslab_p})
+                          &ctx->q2_slab_u, &ctx->q2_zslab_u, &ctx->q2_slab_p, &ctx->q2_zslab_p,
+                          &ctx->ls_convection, &ctx->ls_normal})
     release(*b);
-  for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch})
+  for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch,
+                    ctx->d_tab_ls, ctx->d_ls_diag})
     if (p)
       (void)hipFree(p);
   ctx->matvec_timer.destroy();
@@ -665,6 +682,221 @@ int adaflo_set_q2_chunk(adaflo_ctx *ctx, int layers)
   if (layers < 0)
     return fail(ctx, ADAFLO_EINVAL, "negative chunk length");
   ctx->q2_lz = layers;
+  return 0;
+}
+
+
+/* ------------------------------------------------------------------------- */
+/* level-set operators                                                        */
+/* ------------------------------------------------------------------------- */
+namespace
+{
+  int ls_ready(adaflo_ctx *ctx)
+  {
+    if (ctx->s <= 0 || !ctx->d_tab_ls)
+      return fail(ctx, ADAFLO_ENOTINIT, "context was created without level-set spaces (ls_degree = 0)");
+    return 0;
+  }
+
+  size_t ls_q_count(const adaflo_ctx *ctx)
+  {
+    return (size_t)ctx->n_cells * 3 * 8 * ctx->s * ctx->s * ctx->s;
+  }
+
+  int set_q_array(adaflo_ctx *ctx, DeviceBuffer &buf, const double *canonical, const int on_device)
+  {
+    const size_t count = ls_q_count(ctx);
+    TRY(ctx, alloc(ctx, buf, count), ctx->last_error);
+    double       *staging = nullptr;
+    const double *src     = canonical;
+    if (!on_device)
+      {
+        HIP_TRY(ctx, hipMalloc(&staging, count * sizeof(double)));
+        HIP_TRY(ctx, hipMemcpyAsync(staging, canonical, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        src = staging;
+      }
+    TRY(ctx, launch_transpose_state(ctx, buf.p, src, ctx->n_cells, 8 * ctx->s * ctx->s * ctx->s, 3, true),
+        "state re-layout failed");
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (staging)
+      (void)hipFree(staging);
+    return 0;
+  }
+
+  int get_q_array(adaflo_ctx *ctx, const DeviceBuffer &buf, double *canonical, const int on_device)
+  {
+    if (!buf.p)
+      return fail(ctx, ADAFLO_ENOTINIT, "quadrature-point array not set");
+    const size_t count   = buf.count;
+    double      *staging = nullptr, *dst = canonical;
+    if (!on_device)
+      {
+        HIP_TRY(ctx, hipMalloc(&staging, count * sizeof(double)));
+        dst = staging;
+      }
+    TRY(ctx, launch_transpose_state(ctx, dst, buf.p, ctx->n_cells, 8 * ctx->s * ctx->s * ctx->s, 3, false),
+        "state re-layout failed");
+    if (staging)
+      HIP_TRY(ctx, hipMemcpyAsync(canonical, staging, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (staging)
+      (void)hipFree(staging);
+    return 0;
+  }
+} // namespace
+
+int adaflo_ls_set_params(adaflo_ctx *ctx, const adaflo_ls_params *p)
+{
+  CHECK_CTX(ctx);
+  if (!p)
+    return fail(ctx, ADAFLO_EINVAL, "null params");
+  ctx->ls = LSDev{p->epsilon_used, p->minimal_edge_length, p->time_step, p->weight, p->weight_old,
+                  p->weight_old_old, p->epsilon};
+  return 0;
+}
+
+int adaflo_ls_set_diagonal(adaflo_ctx *ctx, const double *diag)
+{
+  CHECK_CTX(ctx);
+  if (int e = ls_ready(ctx))
+    return e;
+  if (!ctx->d_ls_diag)
+    HIP_TRY(ctx, hipMalloc(&ctx->d_ls_diag, ctx->n_nodes_ls * sizeof(double)));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ls_diag, diag, ctx->n_nodes_ls * sizeof(double),
+                              hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
+}
+
+int adaflo_ls_set_evaluated_convection(adaflo_ctx *ctx, const double *u_q, int src_on_device)
+{
+  CHECK_CTX(ctx);
+  if (int e = ls_ready(ctx))
+    return e;
+  return set_q_array(ctx, ctx->ls_convection, u_q, src_on_device);
+}
+
+int adaflo_ls_get_evaluated_convection(adaflo_ctx *ctx, double *u_q, int dst_on_device)
+{
+  CHECK_CTX(ctx);
+  return get_q_array(ctx, ctx->ls_convection, u_q, dst_on_device);
+}
+
+int adaflo_ls_set_evaluated_normal(adaflo_ctx *ctx, const double *n_q, int src_on_device)
+{
+  CHECK_CTX(ctx);
+  if (int e = ls_ready(ctx))
+    return e;
+  return set_q_array(ctx, ctx->ls_normal, n_q, src_on_device);
+}
+
+int adaflo_ls_get_evaluated_normal(adaflo_ctx *ctx, double *n_q, int dst_on_device)
+{
+  CHECK_CTX(ctx);
+  return get_q_array(ctx, ctx->ls_normal, n_q, dst_on_device);
+}
+
+static int ls_vmult(adaflo_ctx *ctx, double *dst, const double *src, const int mode, const int flag,
+                    double *qstate, const int nblocks)
+{
+  if (int e = ls_ready(ctx))
+    return e;
+  if (!dst || !src)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  HIP_TRY(ctx, hipMemsetAsync(dst, 0, sizeof(double) * nblocks * ctx->n_nodes_ls, ctx->stream)); // dst = 0.
+  TRY(ctx, launch_ls(ctx, 0, mode, flag, dst, src, nullptr, nullptr, nullptr, qstate, nblocks),
+      "level-set kernel launch failed");
+  TRY(ctx, launch_ls_constrained_rows(ctx, dst, src, nblocks), "constrained rows need adaflo_ls_set_diagonal");
+  return 0;
+}
+
+int adaflo_ls_advance_concentration_vmult(adaflo_ctx *ctx, double *dst, const double *src)
+{
+  CHECK_CTX(ctx);
+  if (!ctx->ls_convection.p)
+    return fail(ctx, ADAFLO_ENOTINIT, "evaluated_convection not set (run the rhs kernel first)");
+  return ls_vmult(ctx, dst, src, 0 /*LS_ADVECT*/, 0, ctx->ls_convection.p, 1);
+}
+
+int adaflo_ls_advance_concentration_rhs(adaflo_ctx *ctx, double *dst, const double *solution,
+                                        const double *solution_old, const double *solution_old_old,
+                                        const double *vel_solution, int use_old_old)
+{
+  CHECK_CTX(ctx);
+  if (int e = ls_ready(ctx))
+    return e;
+  if (!dst || !solution || !solution_old || !solution_old_old || !vel_solution)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  TRY(ctx, alloc(ctx, ctx->ls_convection, ls_q_count(ctx)), ctx->last_error);
+  TRY(ctx,
+      launch_ls(ctx, 2, 0, use_old_old, dst, solution, solution_old, solution_old_old, vel_solution,
+                ctx->ls_convection.p, 1),
+      "level-set kernel launch failed");
+  return 0;
+}
+
+int adaflo_ls_reinitialization_vmult(adaflo_ctx *ctx, double *dst, const double *src, int diffuse_only)
+{
+  CHECK_CTX(ctx);
+  if (!diffuse_only && !ctx->ls_normal.p)
+    return fail(ctx, ADAFLO_ENOTINIT, "evaluated_normal not set (run the rhs kernel with first_reinit_step)");
+  return ls_vmult(ctx, dst, src, diffuse_only ? 2 : 1, 0, ctx->ls_normal.p, 1);
+}
+
+int adaflo_ls_reinitialization_rhs(adaflo_ctx *ctx, double *dst, const double *solution,
+                                   const double *normal_vector_field, int diffuse_only,
+                                   int first_reinit_step)
+{
+  CHECK_CTX(ctx);
+  if (int e = ls_ready(ctx))
+    return e;
+  if (!dst || !solution || (!diffuse_only && first_reinit_step && !normal_vector_field))
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  if (!diffuse_only)
+    {
+      if (!first_reinit_step && !ctx->ls_normal.p)
+        return fail(ctx, ADAFLO_ENOTINIT, "evaluated_normal not set");
+      TRY(ctx, alloc(ctx, ctx->ls_normal, ls_q_count(ctx)), ctx->last_error);
+    }
+  TRY(ctx,
+      launch_ls(ctx, 1, 0 /*RHS_REINIT*/, (diffuse_only ? 1 : 0) | (first_reinit_step ? 2 : 0), dst,
+                solution, normal_vector_field, nullptr, nullptr, ctx->ls_normal.p, 1),
+      "level-set kernel launch failed");
+  return 0;
+}
+
+int adaflo_ls_compute_normal_vmult(adaflo_ctx *ctx, double *dst, const double *src)
+{
+  CHECK_CTX(ctx);
+  return ls_vmult(ctx, dst, src, 3 /*LS_NORMAL*/, 1, nullptr, 3);
+}
+
+int adaflo_ls_compute_normal_rhs(adaflo_ctx *ctx, double *dst, const double *level_set_solution)
+{
+  CHECK_CTX(ctx);
+  if (int e = ls_ready(ctx))
+    return e;
+  if (!dst || !level_set_solution)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  TRY(ctx, launch_ls(ctx, 1, 1 /*RHS_NORMAL*/, 0, dst, level_set_solution, nullptr, nullptr, nullptr, nullptr, 1),
+      "level-set kernel launch failed");
+  return 0;
+}
+
+int adaflo_ls_compute_curvature_vmult(adaflo_ctx *ctx, double *dst, const double *src, int apply_diffusion)
+{
+  CHECK_CTX(ctx);
+  return ls_vmult(ctx, dst, src, 4 /*LS_CURVATURE*/, apply_diffusion, nullptr, 1);
+}
+
+int adaflo_ls_compute_curvature_rhs(adaflo_ctx *ctx, double *dst, const double *normal_vector_field)
+{
+  CHECK_CTX(ctx);
+  if (int e = ls_ready(ctx))
+    return e;
+  if (!dst || !normal_vector_field)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  TRY(ctx, launch_ls(ctx, 1, 2 /*RHS_CURVATURE*/, 0, dst, normal_vector_field, nullptr, nullptr, nullptr, nullptr, 1),
+      "level-set kernel launch failed");
   return 0;
 }
 

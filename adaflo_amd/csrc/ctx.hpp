@@ -25,6 +25,13 @@ namespace adaflo_hip
     double weight, weight_old, weight_old_old, tau1, extrap_old, extrap_old_old;
   };
 
+  // scalars of the level-set operators (LevelSetOKZSolver*Parameter structs and the
+  // TimeStepping weights they read)
+  struct LSDev
+  {
+    double epsilon_used, minimal_edge_length, time_step, weight, weight_old, weight_old_old, epsilon;
+  };
+
   struct DeviceBuffer
   {
     double *p     = nullptr;
@@ -112,6 +119,12 @@ struct adaflo_ctx
   int                      lin_q2_mode  = -1;
   int                      q2_lz        = 0; // z-chunk length override (0 = heuristic)
   int                      q2_state_pad = 0; // skew padding (double2) per (tile, layer) state block
+
+  // level-set operators
+  adaflo_hip::LSDev        ls{};
+  double                  *d_tab_ls = nullptr;  // [S D w] of FE_Q_iso_Q1(s) at QIterated(QGauss(2),s), then S of FE_Q(k)
+  double                  *d_ls_diag = nullptr; // preconditioner.get_vector() for constrained rows
+  adaflo_hip::DeviceBuffer ls_convection, ls_normal; // evaluated_convection / evaluated_normal [cell][3][q]
 
   // pressure constant mode (mode 0) data, source/navier_stokes_matrix.cc:117-168
   double *d_p_weights = nullptr, *d_p_modes = nullptr;

@@ -69,6 +69,12 @@ namespace adaflo_hip
                              int ncomp, bool to_generic);
   double host_dot(adaflo_ctx *ctx, const double *a, const double *b, long n);
 
+  // level-set operators (ls_kernels.hip); kind: 0 operator application, 1 rhs, 2 advection rhs
+  int launch_ls(adaflo_ctx *ctx, int kind, int mode, int flag, double *dst, const double *src,
+                const double *src2, const double *src3, const double *vel, double *qstate,
+                int ncomp_blocks);
+  int launch_ls_constrained_rows(adaflo_ctx *ctx, double *dst, const double *src, int nblocks);
+
   // specialised 3D Q2/Q1 sweep kernel (ns_q2.hip)
   bool q2_supported(const adaflo_ctx *ctx);
   int  q2_prepare_state(adaflo_ctx *ctx);

@@ -1,0 +1,476 @@
+// ls_kernels.hip -- level-set (Olsson-Kreiss-Zahedi) operator cell kernels.
+//
+// Restates the local_* kernels of adaflo's four level-set operators for a
+// structured brick (FE_Q_iso_Q1(s), quadrature QIterated(QGauss<1>(2), s),
+// source/two_phase_base.cc:267-268, source/level_set_base.cc:58-59):
+//   advection       source/level_set_okz_advance_concentration.cc:217-258 (vmult), :288-397 (rhs)
+//   reinitialization source/level_set_okz_reinitialization.cc:53-106 (vmult), :128-189 (rhs)
+//   normal           source/level_set_okz_compute_normal.cc:82-119 (vmult), :123-156 (rhs)
+//   curvature        source/level_set_okz_compute_curvature.cc:86-133 (vmult), :212-259 (rhs)
+// One workgroup per cell, tensors in LDS (SumFac of fe_kernels.hpp); convection
+// stabilization = 0 (the FEFaceValues branch is out of scope).
+#include "kernels.hpp"
+
+namespace adaflo_hip
+{
+  enum LSMode
+  {
+    LS_ADVECT = 0,
+    LS_REINIT,
+    LS_REINIT_DIFFUSE,
+    LS_NORMAL,
+    LS_CURVATURE
+  };
+
+  struct LSArgs
+  {
+    BrickDev      brick;
+    LSDev         ls;
+    const double *src, *src2, *src3, *vel; // src2/src3: old solutions (advect rhs)
+    double       *dst;
+    double       *qstate;                  // [cell][3][q] evaluated_convection / evaluated_normal
+    const double *diag;
+    const double *tab;                     // [S D w] of the LS space, then [S_vel] for advect rhs
+    long          n_cells, n_nodes;
+    int           mode, flag;
+  };
+
+  template <int S, int NT>
+  constexpr size_t ls_lds_doubles(const int extra)
+  {
+    constexpr int ND = S + 1, NQ = 2 * S;
+    return ((2 * NQ * ND + NQ + 1) & ~1) + ND * ND * ND + 4 * NQ * NQ * NQ + SumFac<ND, NQ, NT>::TMP + extra;
+  }
+
+  template <int S>
+  struct LSCell
+  {
+    static constexpr int ND = S + 1, NQ = 2 * S, ND3 = ND * ND * ND, NQ3 = NQ * NQ * NQ;
+    static constexpr int TAB = 2 * NQ * ND + NQ, TABP = (TAB + 1) & ~1;
+  };
+
+  // ------------------------------------------------------------------ operator applications
+  template <int S, int NT>
+  __global__ __launch_bounds__(NT) void ls_vmult_kernel(const LSArgs a)
+  {
+    using C  = LSCell<S>;
+    using SF = SumFac<C::ND, C::NQ, NT>;
+    constexpr int NQ = C::NQ, NQ3 = C::NQ3;
+    extern __shared__ double lds[];
+    double *Sm = lds, *Dm = Sm + NQ * C::ND, *wq = Dm + NQ * C::ND;
+    double *ul = lds + C::TABP, *val = ul + C::ND3, *grad = val + NQ3, *tmp = grad + 3 * NQ3;
+
+    const int tid = threadIdx.x;
+    for (int o = tid; o < C::TAB; o += NT)
+      lds[o] = a.tab[o];
+    const long c   = xcd_remap(blockIdx.x, a.n_cells);
+    const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
+    const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
+    const int  nx = S * ncx + 1, ny = S * ncy + 1, nz = S * ncz + 1;
+    const int  comp = blockIdx.y; // LS_NORMAL: one scalar block per component
+    const double *src = a.src + (size_t)comp * a.n_nodes;
+    double       *dst = a.dst + (size_t)comp * a.n_nodes;
+
+    gather_cell<S, 1, NT, true>(src, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+    __syncthreads();
+    SF::template evaluate<true, true>(Sm, Dm, ul, val, grad, grad + NQ3, grad + 2 * NQ3, tmp);
+
+    const LSDev &P     = a.ls;
+    const double ih[3] = {1. / a.brick.h[0], 1. / a.brick.h[1], 1. / a.brick.h[2]};
+    const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
+    const double hcell = fmax(a.brick.h[0], fmax(a.brick.h[1], a.brick.h[2])); // util.h:47-120
+    // level_set_okz_reinitialization.cc:65-67,:82-85
+    const double dtau_inv  = fmax(0.95 / (1. / 9. * P.minimal_edge_length / S), 1. / (5. * P.time_step));
+    const double diffusion = fmax(P.epsilon_used, hcell / (double)S);
+    const double b         = fmax(P.epsilon_used / P.epsilon, hcell / (double)S);
+    // compute_normal.cc:107-110 (damping_scale_factor = 4), compute_curvature.cc:112-118
+    const double damping = a.mode == LS_NORMAL ? 4. * b * b : (a.flag ? b * b : 0.);
+    const double *qs = a.qstate ? a.qstate + (size_t)c * 3 * NQ3 : nullptr;
+
+    for (int q = tid; q < NQ3; q += NT)
+      {
+        const int    qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
+        const double jxw = det * wq[qx] * wq[qy] * wq[qz];
+        const double v   = val[q];
+        double       g[3];
+        for (int e = 0; e < 3; ++e)
+          g[e] = grad[e * NQ3 + q] * ih[e];
+        double tv = 0., tg[3] = {0., 0., 0.};
+        switch (a.mode)
+          {
+            case LS_ADVECT: // :244-249
+              tv = v * P.weight + qs[q] * g[0] + qs[NQ3 + q] * g[1] + qs[2 * NQ3 + q] * g[2];
+              break;
+            case LS_REINIT: // :88-95
+              {
+                const double n0 = qs[q], n1 = qs[NQ3 + q], n2 = qs[2 * NQ3 + q];
+                const double ng = diffusion * (n0 * g[0] + n1 * g[1] + n2 * g[2]);
+                tv    = dtau_inv * v;
+                tg[0] = ng * n0;
+                tg[1] = ng * n1;
+                tg[2] = ng * n2;
+              }
+              break;
+            case LS_REINIT_DIFFUSE: // :96-100
+              tv = dtau_inv * v;
+              for (int e = 0; e < 3; ++e)
+                tg[e] = diffusion * g[e];
+              break;
+            default: // LS_NORMAL / LS_CURVATURE: (w, n) + (grad w, damping grad n)
+              tv = v;
+              for (int e = 0; e < 3; ++e)
+                tg[e] = damping * g[e];
+          }
+        val[q] = tv * jxw;
+        for (int e = 0; e < 3; ++e)
+          grad[e * NQ3 + q] = tg[e] * (jxw * ih[e]);
+      }
+    __syncthreads();
+    SF::template integrate<true, true>(Sm, Dm, val, grad, grad + NQ3, grad + 2 * NQ3, ul, tmp);
+    scatter_cell<S, 1, NT>(dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+  }
+
+  // ------------------------------------------------------------------ right-hand sides
+  enum LSRhs
+  {
+    RHS_REINIT = 0,
+    RHS_NORMAL,
+    RHS_CURVATURE
+  };
+
+  template <int S, int NT>
+  __global__ __launch_bounds__(NT) void ls_rhs_kernel(const LSArgs a)
+  {
+    using C  = LSCell<S>;
+    using SF = SumFac<C::ND, C::NQ, NT>;
+    constexpr int NQ = C::NQ, NQ3 = C::NQ3, ND3 = C::ND3;
+    extern __shared__ double lds[];
+    double *Sm = lds, *Dm = Sm + NQ * C::ND, *wq = Dm + NQ * C::ND;
+    double *ul = lds + C::TABP, *val = ul + ND3, *grad = val + NQ3, *tmp = grad + 3 * NQ3;
+    double *nl = tmp + SF::TMP; // [3][ND3] normal dofs (curvature) / [3][NQ3] normal values (reinit)
+
+    const int tid = threadIdx.x;
+    for (int o = tid; o < C::TAB; o += NT)
+      lds[o] = a.tab[o];
+    const long c   = xcd_remap(blockIdx.x, a.n_cells);
+    const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
+    const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
+    const int  nx = S * ncx + 1, ny = S * ncy + 1, nz = S * ncz + 1;
+    const LSDev &P     = a.ls;
+    const double ih[3] = {1. / a.brick.h[0], 1. / a.brick.h[1], 1. / a.brick.h[2]};
+    const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
+    const double hcell = fmax(a.brick.h[0], fmax(a.brick.h[1], a.brick.h[2]));
+    const double diffusion = fmax(P.epsilon_used, hcell / (double)S);
+
+    if (a.mode == RHS_CURVATURE)
+      {
+        // :229-259: normalise the normal at the DoFs, rhs = (w, -div(n/|n|))
+        int nonzero = 0;
+        for (int d = 0; d < 3; ++d)
+          gather_cell<S, 1, NT, false>(a.src + (size_t)d * a.n_nodes, nl + d * ND3, cx, cy, cz, nx, ny, nz, 0u);
+        __syncthreads();
+        for (int i = tid; i < ND3; i += NT)
+          {
+            const double n0 = nl[i], n1 = nl[ND3 + i], n2 = nl[2 * ND3 + i];
+            const double nr = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+            if (nr > 1e-2)
+              {
+                nonzero       = 1;
+                nl[i]         = n0 / nr;
+                nl[ND3 + i]   = n1 / nr;
+                nl[2 * ND3 + i] = n2 / nr;
+              }
+            else
+              nl[i] = nl[ND3 + i] = nl[2 * ND3 + i] = 0.;
+          }
+        if (!__syncthreads_or(nonzero)) // :250
+          return;
+        for (int q = tid; q < NQ3; q += NT)
+          val[q] = 0.;
+        for (int d = 0; d < 3; ++d)
+          {
+            SF::template evaluate<false, true>(Sm, Dm, nl + d * ND3, nullptr, grad, grad + NQ3, grad + 2 * NQ3, tmp);
+            for (int q = tid; q < NQ3; q += NT)
+              val[q] -= grad[d * NQ3 + q] * ih[d];
+            __syncthreads();
+          }
+        for (int q = tid; q < NQ3; q += NT)
+          {
+            const int qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
+            val[q] *= det * wq[qx] * wq[qy] * wq[qz];
+          }
+        __syncthreads();
+        SF::template integrate<true, false>(Sm, Dm, val, nullptr, nullptr, nullptr, ul, tmp);
+        scatter_cell<S, 1, NT>(a.dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+        return;
+      }
+
+    // level-set value and gradient (plain read)
+    gather_cell<S, 1, NT, false>(a.src, ul, cx, cy, cz, nx, ny, nz, 0u);
+    __syncthreads();
+    SF::template evaluate<true, true>(Sm, Dm, ul, val, grad, grad + NQ3, grad + 2 * NQ3, tmp);
+
+    if (a.mode == RHS_NORMAL)
+      {
+        // :141-153: (w, grad phi), one block per component
+        for (int d = 0; d < 3; ++d)
+          {
+            for (int q = tid; q < NQ3; q += NT)
+              {
+                const int qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
+                grad[d * NQ3 + q] *= ih[d] * det * wq[qx] * wq[qy] * wq[qz];
+              }
+            __syncthreads();
+            SF::template integrate<true, false>(Sm, Dm, grad + d * NQ3, nullptr, nullptr, nullptr, ul, tmp);
+            scatter_cell<S, 1, NT>(a.dst + (size_t)d * a.n_nodes, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+            __syncthreads();
+          }
+        return;
+      }
+
+    // RHS_REINIT :128-189; a.flag bit 0 = diffuse_only, bit 1 = first_reinit_step
+    const bool diffuse_only = a.flag & 1, first = a.flag & 2;
+    double    *nq = a.qstate + (size_t)c * 3 * NQ3;
+    if (!diffuse_only && first)
+      {
+        for (int d = 0; d < 3; ++d)
+          {
+            gather_cell<S, 1, NT, false>(a.src2 + (size_t)d * a.n_nodes, ul, cx, cy, cz, nx, ny, nz, 0u);
+            __syncthreads();
+            SF::template evaluate<true, false>(Sm, Dm, ul, nl + d * NQ3, nullptr, nullptr, nullptr, tmp);
+          }
+      }
+    for (int q = tid; q < NQ3; q += NT)
+      {
+        const int    qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
+        const double jxw = det * wq[qx] * wq[qy] * wq[qz];
+        double       g[3];
+        for (int e = 0; e < 3; ++e)
+          g[e] = grad[e * NQ3 + q] * ih[e];
+        double tg[3];
+        if (!diffuse_only)
+          {
+            double n[3];
+            if (first) // :167-172
+              {
+                n[0] = nl[q];
+                n[1] = nl[NQ3 + q];
+                n[2] = nl[2 * NQ3 + q];
+                const double sc = fmax(1e-4, sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]));
+                for (int e = 0; e < 3; ++e)
+                  {
+                    n[e] /= sc;
+                    nq[e * NQ3 + q] = n[e];
+                  }
+              }
+            else
+              for (int e = 0; e < 3; ++e)
+                n[e] = nq[e * NQ3 + q];
+            const double v = val[q];
+            const double f = 0.5 * (1. - v * v) - (n[0] * g[0] + n[1] * g[1] + n[2] * g[2]) * diffusion; // :176-178
+            for (int e = 0; e < 3; ++e)
+              tg[e] = n[e] * f;
+          }
+        else
+          for (int e = 0; e < 3; ++e)
+            tg[e] = -diffusion * g[e];
+        for (int e = 0; e < 3; ++e)
+          grad[e * NQ3 + q] = tg[e] * (jxw * ih[e]);
+      }
+    __syncthreads();
+    SF::template integrate<false, true>(Sm, Dm, nullptr, grad, grad + NQ3, grad + 2 * NQ3, ul, tmp);
+    scatter_cell<S, 1, NT>(a.dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+  }
+
+  // advection right-hand side :288-397 (velocity of degree KU evaluated at the LS quadrature)
+  template <int S, int KU, int NT>
+  __global__ __launch_bounds__(NT) void ls_advect_rhs_kernel(const LSArgs a)
+  {
+    using C   = LSCell<S>;
+    using SF  = SumFac<C::ND, C::NQ, NT>;
+    using SFV = SumFac<KU + 1, C::NQ, NT>;
+    constexpr int NQ = C::NQ, NQ3 = C::NQ3, ND3 = C::ND3, NDV3 = (KU + 1) * (KU + 1) * (KU + 1);
+    constexpr int TMPX = SF::TMP > SFV::TMP ? SF::TMP : SFV::TMP;
+    extern __shared__ double lds[];
+    double *Sm = lds, *Dm = Sm + NQ * C::ND, *wq = Dm + NQ * C::ND;
+    double *ul = lds + C::TABP, *val = ul + ND3, *grad = val + NQ3, *tmp = grad + 3 * NQ3;
+    double *Sv = tmp + TMPX, *vl = Sv + NQ * (KU + 1), *vq = vl + 3 * NDV3, *vo = vq + 3 * NQ3, *voo = vo + NQ3;
+
+    const int tid = threadIdx.x;
+    for (int o = tid; o < C::TAB; o += NT)
+      lds[o] = a.tab[o];
+    for (int o = tid; o < NQ * (KU + 1); o += NT)
+      Sv[o] = a.tab[C::TAB + o];
+    const long c   = xcd_remap(blockIdx.x, a.n_cells);
+    const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
+    const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
+    const int  nx = S * ncx + 1, ny = S * ncy + 1, nz = S * ncz + 1;
+    const int  vx = KU * ncx + 1, vy = KU * ncy + 1, vz = KU * ncz + 1;
+    const LSDev &P     = a.ls;
+    const double ih[3] = {1. / a.brick.h[0], 1. / a.brick.h[1], 1. / a.brick.h[2]};
+    const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
+
+    // velocity values at the LS quadrature points
+    gather_cell<KU, 3, NT, false>(a.vel, vl, cx, cy, cz, vx, vy, vz, 0u);
+    __syncthreads();
+    for (int d = 0; d < 3; ++d)
+      SFV::template evaluate<true, false>(Sv, Sv, vl + d * NDV3, vq + d * NQ3, nullptr, nullptr, nullptr, tmp);
+    // old level-set values
+    gather_cell<S, 1, NT, false>(a.src2, ul, cx, cy, cz, nx, ny, nz, 0u);
+    __syncthreads();
+    SF::template evaluate<true, false>(Sm, Dm, ul, vo, nullptr, nullptr, nullptr, tmp);
+    gather_cell<S, 1, NT, false>(a.src3, ul, cx, cy, cz, nx, ny, nz, 0u);
+    __syncthreads();
+    SF::template evaluate<true, false>(Sm, Dm, ul, voo, nullptr, nullptr, nullptr, tmp);
+    // current level set
+    gather_cell<S, 1, NT, false>(a.src, ul, cx, cy, cz, nx, ny, nz, 0u);
+    __syncthreads();
+    SF::template evaluate<true, true>(Sm, Dm, ul, val, grad, grad + NQ3, grad + 2 * NQ3, tmp);
+
+    double *uq = a.qstate + (size_t)c * 3 * NQ3;
+    for (int q = tid; q < NQ3; q += NT)
+      {
+        const int    qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
+        const double jxw = det * wq[qx] * wq[qy] * wq[qz];
+        double old_value = P.weight_old * vo[q];
+        if (a.flag) // bdf_2 && step_no > 1  :375-378
+          old_value += P.weight_old_old * voo[q];
+        double ug = 0.;
+        for (int e = 0; e < 3; ++e)
+          {
+            const double u = vq[e * NQ3 + q];
+            ug += u * grad[e * NQ3 + q] * ih[e];
+            uq[e * NQ3 + q] = u; // :389 evaluated_convection
+          }
+        val[q] = -(val[q] * P.weight + ug + old_value) * jxw;
+      }
+    __syncthreads();
+    SF::template integrate<true, false>(Sm, Dm, val, nullptr, nullptr, nullptr, ul, tmp);
+    scatter_cell<S, 1, NT>(a.dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+  }
+
+  // dst[c] = diag[c] * src[c] on constrained rows (e.g. reinitialization.cc:227-230)
+  __global__ __launch_bounds__(256) void ls_constrained_rows_kernel(double *dst, const double *src,
+                                                                    const double *diag, const long n,
+                                                                    const int nx, const int ny,
+                                                                    const int nz, const uint32_t mask)
+  {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+      {
+        const int I = i % nx, J = (i / nx) % ny, K = i / ((long)nx * ny);
+        if (on_constrained_face(I, J, K, nx, ny, nz, mask, 1, 0))
+          dst[i] = diag[i] * src[i];
+      }
+  }
+
+  // ------------------------------------------------------------------ launchers
+  template <int S>
+  static int launch_ls_s(adaflo_ctx *ctx, const int kind, LSArgs &a, const int ncomp_blocks)
+  {
+    constexpr int NT = S >= 3 ? 256 : 64;
+    constexpr int NQ3 = 8 * S * S * S, ND3 = (S + 1) * (S + 1) * (S + 1);
+    const dim3    grid((unsigned)a.n_cells, (unsigned)ncomp_blocks), block(NT);
+    hipError_t    err = hipSuccess;
+    if (kind == 0)
+      {
+        const size_t lds = sizeof(double) * ls_lds_doubles<S, NT>(0);
+        if (lds > 64 * 1024)
+          err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_vmult_kernel<S, NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ls_vmult_kernel<S, NT>), grid, block, lds, ctx->stream, a);
+      }
+    else if (kind == 1)
+      {
+        const size_t lds = sizeof(double) * ls_lds_doubles<S, NT>(3 * (NQ3 > ND3 ? NQ3 : ND3));
+        if (lds > 64 * 1024)
+          err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_rhs_kernel<S, NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((ls_rhs_kernel<S, NT>), grid, block, lds, ctx->stream, a);
+      }
+    else
+      {
+#define ADV(KU)                                                                                      \
+  {                                                                                                  \
+    constexpr int    NDV3 = (KU + 1) * (KU + 1) * (KU + 1);                                          \
+    constexpr size_t tmpv = SumFac<KU + 1, 2 * S, NT>::TMP, tmps = SumFac<S + 1, 2 * S, NT>::TMP;    \
+    const size_t     lds  = sizeof(double) * (ls_lds_doubles<S, NT>(0) + (tmpv > tmps ? tmpv - tmps : 0) + \
+                                         2 * S * (KU + 1) + 3 * NDV3 + 5 * NQ3);                      \
+    if (lds > 64 * 1024)                                                                             \
+      err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_advect_rhs_kernel<S, KU, NT>),    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+    hipLaunchKernelGGL((ls_advect_rhs_kernel<S, KU, NT>), grid, block, lds, ctx->stream, a);         \
+  }
+        switch (ctx->k)
+          {
+            case 2:
+              ADV(2);
+              break;
+            case 3:
+              ADV(3);
+              break;
+            case 4:
+              ADV(4);
+              break;
+            default:
+              return ADAFLO_EUNSUPPORTED;
+          }
+#undef ADV
+      }
+    if (err == hipSuccess)
+      err = hipGetLastError();
+    return err == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+
+  // kind: 0 operator application, 1 rhs (reinit / normal / curvature), 2 advection rhs
+  int launch_ls(adaflo_ctx *ctx, const int kind, const int mode, const int flag, double *dst,
+                const double *src, const double *src2, const double *src3, const double *vel,
+                double *qstate, const int ncomp_blocks)
+  {
+    LSArgs a{};
+    a.brick   = ctx->brick;
+    a.ls      = ctx->ls;
+    a.src     = src;
+    a.src2    = src2;
+    a.src3    = src3;
+    a.vel     = vel;
+    a.dst     = dst;
+    a.qstate  = qstate;
+    a.diag    = ctx->d_ls_diag;
+    a.tab     = ctx->d_tab_ls;
+    a.n_cells = ctx->n_cells;
+    a.n_nodes = ctx->n_nodes_ls;
+    a.mode    = mode;
+    a.flag    = flag;
+    switch (ctx->s)
+      {
+        case 1:
+          return launch_ls_s<1>(ctx, kind, a, ncomp_blocks);
+        case 2:
+          return launch_ls_s<2>(ctx, kind, a, ncomp_blocks);
+        case 3:
+          return launch_ls_s<3>(ctx, kind, a, ncomp_blocks);
+        case 4:
+          return launch_ls_s<4>(ctx, kind, a, ncomp_blocks);
+        default:
+          return ADAFLO_EUNSUPPORTED;
+      }
+  }
+
+  int launch_ls_constrained_rows(adaflo_ctx *ctx, double *dst, const double *src, const int nblocks)
+  {
+    if (!ctx->brick.con_ls)
+      return 0;
+    if (!ctx->d_ls_diag)
+      return ADAFLO_ENOTINIT;
+    const int nx = ctx->s * ctx->desc.ncell[0] + 1, ny = ctx->s * ctx->desc.ncell[1] + 1,
+              nz = ctx->s * ctx->desc.ncell[2] + 1;
+    long nb = (ctx->n_nodes_ls + 255) / 256;
+    if (nb > 4096)
+      nb = 4096;
+    for (int b = 0; b < nblocks; ++b)
+      hipLaunchKernelGGL(ls_constrained_rows_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream,
+                         dst + (size_t)b * ctx->n_nodes_ls, src + (size_t)b * ctx->n_nodes_ls,
+                         ctx->d_ls_diag, (long)ctx->n_nodes_ls, nx, ny, nz, ctx->brick.con_ls);
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+} // namespace adaflo_hip

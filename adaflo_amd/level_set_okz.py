@@ -1,0 +1,144 @@
+"""Host-side mirrors of adaflo's four level-set operator classes
+(include/adaflo/level_set_okz_{advance_concentration,reinitialization,compute_normal,
+compute_curvature}.h): same method names and argument meaning, forwarding to the C ABI.
+
+In the reference the operators hold references to the vectors they work on
+(constructor arguments, e.g. level_set_okz_reinitialization.h:74-104); here the vectors
+are passed per call.  All four share one engine context (one MatrixFree in the reference,
+source/two_phase_base.cc:239-275) created by `LevelSetOperators`."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .vectors import DeviceVector
+
+
+class LevelSetOperators:
+    """owns the engine context for the level-set spaces on a brick (FE_Q_iso_Q1(ls_degree))"""
+
+    def __init__(self, mesh, ls_degree, velocity_degree=2, constrained_faces=(), device=0, stream=None):
+        self._lib = _lib.load()
+        self.mesh, self.s, self.k = mesh, ls_degree, velocity_degree
+        d = _lib.BrickDesc()
+        d.dim = 3
+        for i in range(3):
+            d.ncell[i], d.h[i], d.origin[i] = mesh.ncell[i], mesh.h[i], mesh.lower[i]
+        d.velocity_degree, d.ls_degree = velocity_degree, ls_degree
+        d.ls_constrained = sum(1 << f for f in constrained_faces)
+        d.device, d.stream = device, stream
+        ctx = C.c_void_p()
+        code = self._lib.adaflo_ctx_create(C.byref(d), C.byref(ctx))
+        if code != 0:
+            raise _lib.AdafloError("adaflo_ctx_create failed (%d): %s" % (
+                code, self._lib.adaflo_last_error(None).decode()))
+        self._ctx = ctx
+        self.n_dofs = self._lib.adaflo_n_dofs_ls(ctx)
+        self.n_q = self._lib.adaflo_n_q_points_ls(ctx)
+        self.n_cells = self._lib.adaflo_n_cells(ctx)
+        # compute_cell_diameters on a Cartesian mesh, include/adaflo/util.h:47-120
+        self.cell_diameter = max(mesh.h)
+        self.minimal_edge_length = min(mesh.h)
+
+    def __del__(self):
+        try:
+            if self._ctx is not None:
+                self._lib.adaflo_ctx_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    def vector(self, values=None, blocks=1):
+        v = DeviceVector(self._ctx, self.n_dofs * blocks)
+        v.set(np.zeros(v.n) if values is None else values)
+        return v
+
+    def velocity_vector(self, values):
+        return DeviceVector.from_numpy(self._ctx, values)
+
+    def set_parameters(self, epsilon_used, time_step, weight=1.0, weight_old=-1.0, weight_old_old=0.0,
+                       epsilon=1.0):
+        p = _lib.LSParams(epsilon_used, self.minimal_edge_length, time_step, weight, weight_old,
+                          weight_old_old, epsilon)
+        _lib.check(self._ctx, self._lib.adaflo_ls_set_params(self._ctx, C.byref(p)))
+
+    def set_diagonal(self, diag):
+        """DiagonalPreconditioner::get_vector() used on constrained rows"""
+        _lib.check(self._ctx, self._lib.adaflo_ls_set_diagonal(self._ctx, diag.ptr))
+
+    def _q(self, getter):
+        out = np.empty(self.n_cells * self.n_q * 3)
+        _lib.check(self._ctx, getter(self._ctx, out.ctypes.data, 0))
+        return out
+
+    def _set_q(self, setter, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.size == self.n_cells * self.n_q * 3
+        _lib.check(self._ctx, setter(self._ctx, a.ctypes.data, 0))
+
+
+class LevelSetOKZSolverAdvanceConcentration:
+    def __init__(self, ops):
+        self.ops, self._lib, self._ctx = ops, ops._lib, ops._ctx
+
+    def advance_concentration_vmult(self, dst, src):
+        _lib.check(self._ctx, self._lib.adaflo_ls_advance_concentration_vmult(self._ctx, dst.ptr, src.ptr))
+
+    def local_advance_concentration_rhs(self, dst, solution, solution_old, solution_old_old,
+                                        vel_solution, use_old_old):
+        _lib.check(self._ctx, self._lib.adaflo_ls_advance_concentration_rhs(
+            self._ctx, dst.ptr, solution.ptr, solution_old.ptr, solution_old_old.ptr,
+            vel_solution.ptr, int(use_old_old)))
+
+    @property
+    def evaluated_convection(self):
+        return self.ops._q(self._lib.adaflo_ls_get_evaluated_convection)
+
+    @evaluated_convection.setter
+    def evaluated_convection(self, a):
+        self.ops._set_q(self._lib.adaflo_ls_set_evaluated_convection, a)
+
+
+class LevelSetOKZSolverReinitialization:
+    def __init__(self, ops):
+        self.ops, self._lib, self._ctx = ops, ops._lib, ops._ctx
+
+    def reinitialization_vmult(self, dst, src, diffuse_only):
+        _lib.check(self._ctx, self._lib.adaflo_ls_reinitialization_vmult(self._ctx, dst.ptr, src.ptr,
+                                                                        int(diffuse_only)))
+
+    def local_reinitialize_rhs(self, dst, solution, normal_vector_field, diffuse_only, first_reinit_step):
+        nptr = normal_vector_field.ptr if normal_vector_field is not None else None
+        _lib.check(self._ctx, self._lib.adaflo_ls_reinitialization_rhs(
+            self._ctx, dst.ptr, solution.ptr, nptr, int(diffuse_only), int(first_reinit_step)))
+
+    @property
+    def evaluated_normal(self):
+        return self.ops._q(self._lib.adaflo_ls_get_evaluated_normal)
+
+    @evaluated_normal.setter
+    def evaluated_normal(self, a):
+        self.ops._set_q(self._lib.adaflo_ls_set_evaluated_normal, a)
+
+
+class LevelSetOKZSolverComputeNormal:
+    def __init__(self, ops):
+        self.ops, self._lib, self._ctx = ops, ops._lib, ops._ctx
+
+    def compute_normal_vmult(self, dst, src):
+        _lib.check(self._ctx, self._lib.adaflo_ls_compute_normal_vmult(self._ctx, dst.ptr, src.ptr))
+
+    def local_compute_normal_rhs(self, dst, level_set_solution):
+        _lib.check(self._ctx, self._lib.adaflo_ls_compute_normal_rhs(self._ctx, dst.ptr, level_set_solution.ptr))
+
+
+class LevelSetOKZSolverComputeCurvature:
+    def __init__(self, ops):
+        self.ops, self._lib, self._ctx = ops, ops._lib, ops._ctx
+
+    def compute_curvature_vmult(self, dst, src, apply_diffusion):
+        _lib.check(self._ctx, self._lib.adaflo_ls_compute_curvature_vmult(self._ctx, dst.ptr, src.ptr,
+                                                                         int(apply_diffusion)))
+
+    def local_compute_curvature_rhs(self, dst, normal_vector_field):
+        _lib.check(self._ctx, self._lib.adaflo_ls_compute_curvature_rhs(self._ctx, dst.ptr, normal_vector_field.ptr))

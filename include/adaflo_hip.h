@@ -175,6 +175,47 @@ int adaflo_ns_apply_pressure_average_projection(adaflo_ctx *ctx, double *vec_p);
  * seconds since the last query (resets the counters like the reference).      */
 int adaflo_ns_get_matvec_statistics(adaflo_ctx *ctx, unsigned *count, double *seconds);
 
+/* ---- level-set operators (LevelSetOKZSolver*, source/level_set_okz_*.cc) ---- */
+/* FE_Q_iso_Q1(ls_degree) on the same brick; block vectors with dim blocks (normal
+ * vector field) are passed as ONE pointer to dim consecutive double[n_dofs_ls].
+ * Quadrature-point arrays cross the boundary in canonical layout [cell][q][dim].  */
+typedef struct
+{
+  double epsilon_used;        /* two_phase_base.cc:282-291 */
+  double minimal_edge_length; /* util.h:97-119 */
+  double time_step;           /* time_stepping.step_size() */
+  double weight, weight_old, weight_old_old; /* TimeStepping weights (advection) */
+  double epsilon;             /* parameters.epsilon (normal / curvature damping) */
+} adaflo_ls_params;
+int adaflo_ls_set_params(adaflo_ctx *ctx, const adaflo_ls_params *p);
+/* preconditioner.get_vector(): diagonal used for constrained rows (device pointer),
+ * e.g. level_set_okz_reinitialization.cc:227-230 */
+int adaflo_ls_set_diagonal(adaflo_ctx *ctx, const double *diag);
+/* evaluated_convection / evaluated_normal (written by the rhs kernels, readable for tests) */
+int adaflo_ls_set_evaluated_convection(adaflo_ctx *ctx, const double *u_q, int src_on_device);
+int adaflo_ls_get_evaluated_convection(adaflo_ctx *ctx, double *u_q, int dst_on_device);
+int adaflo_ls_set_evaluated_normal(adaflo_ctx *ctx, const double *n_q, int src_on_device);
+int adaflo_ls_get_evaluated_normal(adaflo_ctx *ctx, double *n_q, int dst_on_device);
+/* advance_concentration_vmult  level_set_okz_advance_concentration.cc:401-480 */
+int adaflo_ls_advance_concentration_vmult(adaflo_ctx *ctx, double *dst, const double *src);
+/* local_advance_concentration_rhs :288-397 (cell loop: adds into dst, stores the velocity at
+ * the quadrature points); use_old_old = (scheme == bdf_2 && step_no > 1), :375-378 */
+int adaflo_ls_advance_concentration_rhs(adaflo_ctx *ctx, double *dst, const double *solution,
+                                        const double *solution_old, const double *solution_old_old,
+                                        const double *vel_solution, int use_old_old);
+/* reinitialization_vmult  level_set_okz_reinitialization.cc:193-231 */
+int adaflo_ls_reinitialization_vmult(adaflo_ctx *ctx, double *dst, const double *src, int diffuse_only);
+/* local_reinitialize_rhs :128-189 (adds into dst; writes evaluated_normal on the first step) */
+int adaflo_ls_reinitialization_rhs(adaflo_ctx *ctx, double *dst, const double *solution,
+                                   const double *normal_vector_field, int diffuse_only,
+                                   int first_reinit_step);
+/* compute_normal_vmult / local_compute_normal_rhs  level_set_okz_compute_normal.cc:160-183, :123-156 */
+int adaflo_ls_compute_normal_vmult(adaflo_ctx *ctx, double *dst, const double *src);
+int adaflo_ls_compute_normal_rhs(adaflo_ctx *ctx, double *dst, const double *level_set_solution);
+/* compute_curvature_vmult / local_compute_curvature_rhs  level_set_okz_compute_curvature.cc:263-304, :212-259 */
+int adaflo_ls_compute_curvature_vmult(adaflo_ctx *ctx, double *dst, const double *src, int apply_diffusion);
+int adaflo_ls_compute_curvature_rhs(adaflo_ctx *ctx, double *dst, const double *normal_vector_field);
+
 /* dominant cell-kernel statistics (device time between HIP events recorded on
  * the context's stream around the cell kernel only); used by bench.py for the
  * roofline figure.  Resets like adaflo_ns_get_matvec_statistics.                */

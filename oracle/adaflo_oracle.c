@@ -1070,3 +1070,51 @@ int orc_ls_curvature_rhs(const orc_mesh *m, const orc_ls_params *P, const double
   free(ln); free(l); free(v); free(g); table_free(&t);
   return 0;
 }
+
+/* local_advance_concentration_rhs  source/level_set_okz_advance_concentration.cc:288-397
+ * (convection stabilization = 0).  dst NOT zeroed.  vel: FE_Q(ku) vector, dof = node*dim+comp;
+ * vel_q [cell][q][dim] is WRITTEN (:389).  use_old_old = (bdf_2 && step_no > 1), :375-378.     */
+int orc_ls_advect_rhs(const orc_mesh *m, const orc_ls_params *P, int ku, int use_old_old,
+                      double weight_old, double weight_old_old, const double *solution,
+                      const double *solution_old, const double *solution_old_old,
+                      const double *vel, double *dst, const uint8_t *con, double *vel_q)
+{
+  const int dim = m->dim, s = P->ls_degree;
+  orc_table t, tv;
+  table_init(&t, dim, ORC_FE_Q_ISO_Q1, s, s, 1);
+  table_init(&tv, dim, ORC_FE_Q, ku, s, 1);
+  const int nq = t.nqc;
+  double *l = (double *)malloc(sizeof(double) * t.ndc), *lv = (double *)malloc(sizeof(double) * 3 * tv.ndc);
+  double *v = (double *)malloc(sizeof(double) * nq), *g = (double *)malloc(sizeof(double) * 3 * nq);
+  double *vo = (double *)malloc(sizeof(double) * nq), *voo = (double *)malloc(sizeof(double) * nq);
+  double *uq = (double *)malloc(sizeof(double) * 3 * nq);
+  const long nc = n_cells(m);
+  for (long c = 0; c < nc; ++c)
+    {
+      gather(m, ku, dim, c, tv.ndc, vel, NULL, lv);
+      evaluate(&tv, m, dim, lv, uq, NULL);
+      gather(m, s, 1, c, t.ndc, solution_old, NULL, l);
+      evaluate(&t, m, 1, l, vo, NULL);
+      gather(m, s, 1, c, t.ndc, solution_old_old, NULL, l);
+      evaluate(&t, m, 1, l, voo, NULL);
+      gather(m, s, 1, c, t.ndc, solution, NULL, l);
+      evaluate(&t, m, 1, l, v, g);
+      for (int q = 0; q < nq; ++q)
+        {
+          double old_value = weight_old * vo[q];
+          if (use_old_old) old_value += weight_old_old * voo[q];
+          double ug = 0.;
+          for (int e = 0; e < dim; ++e)
+            {
+              ug += uq[e * nq + q] * g[e * nq + q];
+              vel_q[((size_t)c * nq + q) * dim + e] = uq[e * nq + q];
+            }
+          v[q] = -(v[q] * P->weight + ug + old_value);
+        }
+      integrate(&t, m, 1, v, NULL, l);
+      scatter_add(m, s, 1, c, t.ndc, dst, con, l);
+    }
+  free(l); free(lv); free(v); free(g); free(vo); free(voo); free(uq);
+  table_free(&t); table_free(&tv);
+  return 0;
+}

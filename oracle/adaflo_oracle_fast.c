@@ -85,7 +85,7 @@ int orc_fast_ns_vmult(const orc_mesh *m, int k, const orc_ns_params *P, const do
 {
   if (m->dim != 3 || k + 1 > MAXN) return -1;
   const int p = k - 1, n = k + 1, ndu = k + 1, ndp = k;
-  const int nq3 = n * n * n, ndu3 = ndu * ndu * ndu, ndp3 = ndp * ndp * ndp;
+  const int nq3 = n * n * n, ndu3 = ndu * ndu * ndu;
   double xq[MAXN], wq[MAXN], Su[MAXN * MAXN], Du[MAXN * MAXN], Sp[MAXN * MAXN], Dp[MAXN * MAXN];
   double Dc[MAXN * MAXN]; /* collocation derivative at the q-points */
   orc_gauss_legendre(n, xq, wq);

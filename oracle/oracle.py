@@ -330,3 +330,19 @@ def fast_ns_vmult(mesh, k, prm, src_u, src_p, con_u=None, con_p=None, lin=None, 
                                  _p(damp), _p(weights), _p(modes))
     assert rc == 0
     return dst_u, dst_p
+
+
+def ls_advect_rhs(mesh, prm, ku, solution, solution_old, solution_old_old, vel, vel_q,
+                  weight_old, weight_old_old, use_old_old=True, con=None):
+    dst = np.zeros_like(solution)
+    lib().orc_ls_advect_rhs(C.byref(mesh), C.byref(prm), ku, int(use_old_old), C.c_double(weight_old),
+                            C.c_double(weight_old_old), _p(solution), _p(solution_old),
+                            _p(solution_old_old), _p(vel), _p(dst), _u8(con), _p(vel_q))
+    return dst
+
+
+def make_ls_params(s, epsilon_used, minimal_edge_length, time_step, weight, cell_diameter, epsilon):
+    p = LSParams()
+    p.ls_degree, p.epsilon_used, p.minimal_edge_length = s, epsilon_used, minimal_edge_length
+    p.time_step, p.weight, p.cell_diameter, p.epsilon = time_step, weight, cell_diameter, epsilon
+    return p
