@@ -64,6 +64,8 @@ SIGNATURES = {
     "adaflo_ns_pressure_mass_weight_add": (C.c_int, [_CTX, _D]),
     "adaflo_ns_apply_constrained_rows": (C.c_int, [_CTX, _D, _D, _D, _D]),
     "adaflo_ns_get_matvec_statistics": (C.c_int, [_CTX, C.POINTER(C.c_uint), C.POINTER(C.c_double)]),
+    "adaflo_halo_transfer": (C.c_int, [_CTX, _D, _D, C.POINTER(C.c_int), C.c_int, C.c_int,
+                                      C.POINTER(C.c_int), C.c_int]),
     "adaflo_ls_set_params": (C.c_int, [_CTX, C.POINTER(LSParams)]),
     "adaflo_ls_set_diagonal": (C.c_int, [_CTX, _D]),
     "adaflo_ls_set_evaluated_convection": (C.c_int, [_CTX, C.c_void_p, C.c_int]),

@@ -687,6 +687,38 @@ int adaflo_set_q2_chunk(adaflo_ctx *ctx, int layers)
 
 
 /* ------------------------------------------------------------------------- */
+/* inter-GPU exchange helpers                                                 */
+/* ------------------------------------------------------------------------- */
+int adaflo_halo_transfer(adaflo_ctx *ctx, double *vec, double *buf, const int *nn, int ncomp,
+                         int n_regions, const int *regions, int mode)
+{
+  CHECK_CTX(ctx);
+  if (!vec || !buf || !nn || !regions || n_regions < 0 || n_regions > 26 || mode < 0 || mode > 2)
+    return fail(ctx, ADAFLO_EINVAL, "invalid halo transfer arguments");
+  HaloPlan plan{};
+  plan.n_regions = n_regions;
+  plan.ncomp     = ncomp;
+  for (int d = 0; d < 3; ++d)
+    plan.nn[d] = nn[d];
+  plan.offset[0] = 0;
+  for (int r = 0; r < n_regions; ++r)
+    {
+      long n = ncomp;
+      for (int d = 0; d < 3; ++d)
+        {
+          plan.lo[r][d] = regions[6 * r + 2 * d];
+          plan.hi[r][d] = regions[6 * r + 2 * d + 1];
+          if (plan.lo[r][d] < 0 || plan.hi[r][d] > nn[d] || plan.hi[r][d] <= plan.lo[r][d])
+            return fail(ctx, ADAFLO_EINVAL, "halo region out of range");
+          n *= plan.hi[r][d] - plan.lo[r][d];
+        }
+      plan.offset[r + 1] = plan.offset[r] + n;
+    }
+  TRY(ctx, launch_halo(ctx, vec, buf, plan, mode), "halo kernel launch failed");
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* level-set operators                                                        */
 /* ------------------------------------------------------------------------- */
 namespace

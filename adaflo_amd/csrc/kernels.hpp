@@ -54,6 +54,16 @@ namespace adaflo_hip
   };
   int launch_ns_scalar_generic(adaflo_ctx *ctx, const ScalarArgs &args);
 
+  // interface regions of a brick vector for the inter-GPU exchange (faces, edges, corners)
+  struct HaloPlan
+  {
+    int  n_regions, ncomp;
+    int  nn[3];
+    int  lo[26][3], hi[26][3]; // half-open node index ranges
+    long offset[27];           // prefix sums of the region sizes (doubles) in the packed buffer
+  };
+  int launch_halo(adaflo_ctx *ctx, double *vec, double *buf, const HaloPlan &plan, int mode);
+
   // vector helpers (vector_ops.hip)
   // dst = constrained ? sign*src : 0  (fuses `dst = 0` with the constrained-row
   // fix-up of source/navier_stokes_matrix.cc:229,247-256)

@@ -134,6 +134,35 @@ namespace adaflo_hip
         }
     }
 
+    // interface-region copy between a brick vector and a packed message buffer
+    // mode 0: buf <- vec (pack), 1: vec <- buf (unpack, copy), 2: vec += buf (unpack, add)
+    __global__ __launch_bounds__(VT) void halo_kernel(double *__restrict__ vec, double *__restrict__ buf,
+                                                      const HaloPlan plan, const int mode)
+    {
+      const long total = plan.offset[plan.n_regions];
+      for (long t = blockIdx.x * (long)VT + threadIdx.x; t < total; t += (long)gridDim.x * VT)
+        {
+          int r = 0;
+          while (t >= plan.offset[r + 1])
+            ++r;
+          long      e  = t - plan.offset[r];
+          const int nc = plan.ncomp, ni = plan.hi[r][0] - plan.lo[r][0], nj = plan.hi[r][1] - plan.lo[r][1];
+          const int c  = (int)(e % nc);
+          e /= nc;
+          const int i = (int)(e % ni) + plan.lo[r][0];
+          e /= ni;
+          const int  j   = (int)(e % nj) + plan.lo[r][1];
+          const int  k   = (int)(e / nj) + plan.lo[r][2];
+          const long idx = ((long)(k * (long)plan.nn[1] + j) * plan.nn[0] + i) * nc + c;
+          if (mode == 0)
+            buf[t] = vec[idx];
+          else if (mode == 1)
+            vec[idx] = buf[t];
+          else // regions of different neighbours overlap on edges / corners
+            unsafeAtomicAdd(&vec[idx], buf[t]);
+        }
+    }
+
     int check()
     {
       return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
@@ -191,6 +220,15 @@ namespace adaflo_hip
     (void)hipMemcpyAsync(&r, ctx->d_scratch, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     (void)hipStreamSynchronize(ctx->stream);
     return r;
+  }
+
+  int launch_halo(adaflo_ctx *ctx, double *vec, double *buf, const HaloPlan &plan, const int mode)
+  {
+    const long total = plan.offset[plan.n_regions];
+    if (total == 0)
+      return 0;
+    hipLaunchKernelGGL(halo_kernel, dim3(grid_for(total)), dim3(VT), 0, ctx->stream, vec, buf, plan, mode);
+    return check();
   }
 
   int launch_sadd(adaflo_ctx *ctx, double *x, const double a, const double *y, const long n)

@@ -102,10 +102,11 @@ class HaloExchange:
     fields: list of (degree, ncomp); a field vector is a flat torch tensor of
     nn_z*nn_y*nn_x*ncomp doubles (node-major, components interleaved)."""
 
-    def __init__(self, part, fields, group=None):
+    def __init__(self, part, fields, group=None, native=None):
         self.part = part
         self.fields = fields
         self.group = group
+        self.native = native      # engine context whose halo kernel packs / unpacks GPU tensors
         self.nbrs = part.neighbours()
         # order messages by dimensionality: faces first, corners last (authoritative owner last)
         self.nbrs.sort(key=lambda t: sum(abs(x) for x in t[0]))
@@ -119,44 +120,111 @@ class HaloExchange:
         return out
 
     def _exchange(self, vecs, mode):
+        """one round of point-to-point messages with all neighbours.  On GPU tensors the
+        interface regions are packed / unpacked by the engine's halo kernel (native=ctx),
+        otherwise by torch slicing (CPU tests)."""
         import torch
         import torch.distributed as dist
         if self.part.world == 1 or not self.nbrs:
             return
         views = self._views(vecs)
-        sends, recvs, ops = [], [], []
+        dev, dtype = vecs[0].device, vecs[0].dtype
+        send_list, recv_list = [], []
         for o, nb in self.nbrs:
-            regs = [_region(o, self.part.nodes(deg)) for deg, _ in self.fields]
             positive = all(x >= 0 for x in o)   # I am on the low side of every cut direction
             negative = all(x <= 0 for x in o)
-            do_send = mode == "add" or positive
-            do_recv = mode == "add" or negative
-            if do_send:
-                buf = torch.cat([w[r].reshape(-1) for w, r in zip(views, regs)])
-                sends.append(buf)
-                ops.append(dist.P2POp(dist.isend, buf, nb, group=self.group))
-            if do_recv:
-                n = sum(w[r].numel() for w, r in zip(views, regs))
-                key = (o, mode)
-                if key not in self._bufs or self._bufs[key].numel() != n or \
-                        self._bufs[key].device != vecs[0].device:
-                    self._bufs[key] = torch.empty(n, dtype=vecs[0].dtype, device=vecs[0].device)
-                rb = self._bufs[key]
-                recvs.append((o, regs, rb))
-                ops.append(dist.P2POp(dist.irecv, rb, nb, group=self.group))
+            if mode == "add" or positive:
+                send_list.append((o, nb))
+            if mode == "add" or negative:
+                recv_list.append((o, nb))
+        sizes = lambda o: [int(np.prod([len(range(*sl.indices(n))) for sl, n in
+                                        zip(_region(o, self.part.nodes(deg)), self.part.nodes(deg)[::-1])])) * nc
+                           for deg, nc in self.fields]
+        key = (mode, dev)
+        if key not in self._bufs:
+            ns = sum(sum(sizes(o)) for o, _ in send_list)
+            nr = sum(sum(sizes(o)) for o, _ in recv_list)
+            self._bufs[key] = (torch.empty(max(ns, 1), dtype=dtype, device=dev),
+                               torch.empty(max(nr, 1), dtype=dtype, device=dev))
+        sbuf, rbuf = self._bufs[key]
+        # --- pack: buffer layout [field][neighbour] so that one kernel per field packs everything
+        seg_send, seg_recv = {}, {}
+        off = 0
+        for f in range(len(self.fields)):
+            for o, nb in send_list:
+                n = sizes(o)[f]
+                seg_send[(f, o)] = (off, n)
+                off += n
+        off = 0
+        for f in range(len(self.fields)):
+            for o, nb in recv_list:
+                n = sizes(o)[f]
+                seg_recv[(f, o)] = (off, n)
+                off += n
+        if self.native is not None and vecs[0].is_cuda:
+            for f, v in enumerate(vecs):
+                if send_list:
+                    base = seg_send[(f, send_list[0][0])][0]
+                    self._native_transfer(v, sbuf[base:], f, [o for o, _ in send_list], 0)
+        else:
+            for f, w in enumerate(views):
+                for o, nb in send_list:
+                    a, n = seg_send[(f, o)]
+                    sbuf[a:a + n] = w[_region(o, self.part.nodes(self.fields[f][0]))].reshape(-1)
+        # --- messages: one per (neighbour, field)
+        ops = []
+        for o, nb in send_list:
+            for f in range(len(self.fields)):
+                a, n = seg_send[(f, o)]
+                ops.append(dist.P2POp(dist.isend, sbuf[a:a + n], nb, group=self.group, tag=f))
+        for o, nb in recv_list:
+            for f in range(len(self.fields)):
+                a, n = seg_recv[(f, o)]
+                ops.append(dist.P2POp(dist.irecv, rbuf[a:a + n], nb, group=self.group, tag=f))
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        for o, regs, rb in recvs:
-            off = 0
-            for w, r in zip(views, regs):
-                n = w[r].numel()
-                piece = rb[off:off + n].view(w[r].shape)
+        # --- unpack: faces first, corners last (in copy mode the lowest sharer wins)
+        if self.native is not None and vecs[0].is_cuda:
+            for f, v in enumerate(vecs):
+                if not recv_list:
+                    continue
                 if mode == "add":
-                    w[r] += piece
+                    base = seg_recv[(f, recv_list[0][0])][0]
+                    self._native_transfer(v, rbuf[base:], f, [o for o, _ in recv_list], 2)
                 else:
-                    w[r] = piece
-                off += n
+                    for cls in (1, 2, 3):
+                        group = [o for o, _ in recv_list if sum(abs(x) for x in o) == cls]
+                        if group:
+                            base = seg_recv[(f, group[0])][0]
+                            self._native_transfer(v, rbuf[base:], f, group, 1)
+        else:
+            for f, w in enumerate(views):
+                for o, nb in recv_list:
+                    a, n = seg_recv[(f, o)]
+                    r = _region(o, self.part.nodes(self.fields[f][0]))
+                    piece = rbuf[a:a + n].view(w[r].shape)
+                    if mode == "add":
+                        w[r] += piece
+                    else:
+                        w[r] = piece
+
+    def _native_transfer(self, vec, buf, field, offsets, mode):
+        """engine halo kernel over the regions of `offsets` (contiguous in buf, in this order)"""
+        import ctypes as C
+        from . import _lib
+        deg, nc = self.fields[field]
+        nn = self.part.nodes(deg)
+        regs = []
+        for o in offsets:
+            for d in range(3):
+                lo = 0 if o[d] <= 0 else nn[d] - 1
+                hi = nn[d] if o[d] == 0 else lo + 1
+                regs += [lo, hi]
+        arr = (C.c_int * len(regs))(*regs)
+        nn_c = (C.c_int * 3)(*nn)
+        _lib.check(self.native, _lib.load().adaflo_halo_transfer(
+            self.native, vec.data_ptr(), buf.data_ptr(), nn_c, nc, len(offsets), arr, mode))
 
     def compress_add(self, vecs):
         """dst.compress(VectorOperation::add): afterwards every replica holds the total"""
@@ -203,6 +271,7 @@ class DistributedNavierStokesMatrix:
     def initialize(self, time_stepping, pressure_average_fix):
         single = self.part.world == 1
         self.local.initialize(time_stepping, pressure_average_fix and single)
+        self.halo.native = getattr(self.local, "_ctx", None)
         self.pressure_average_fix = pressure_average_fix
         if pressure_average_fix and not single:
             self._setup_projection()

@@ -175,6 +175,16 @@ int adaflo_ns_apply_pressure_average_projection(adaflo_ctx *ctx, double *vec_p);
  * seconds since the last query (resets the counters like the reference).      */
 int adaflo_ns_get_matvec_statistics(adaflo_ctx *ctx, unsigned *count, double *seconds);
 
+/* ---- multi-GPU: packing of interface DoFs ---------------------------------- */
+/* What deal.II's Utilities::MPI::Partitioner does with its import/export index lists
+ * inside update_ghost_values() / compress(add): copy the n_regions node boxes
+ * regions[r] = {i0,i1, j0,j1, k0,k1} (half-open) of the brick vector `vec` (nn[3] nodes,
+ * ncomp interleaved components) to / from the packed message buffer `buf` (regions back to
+ * back).  mode 0: buf <- vec, 1: vec <- buf, 2: vec += buf.  The messages themselves are
+ * sent by the caller over RCCL (adaflo_amd/parallel.py).                              */
+int adaflo_halo_transfer(adaflo_ctx *ctx, double *vec, double *buf, const int *nn, int ncomp,
+                         int n_regions, const int *regions, int mode);
+
 /* ---- level-set operators (LevelSetOKZSolver*, source/level_set_okz_*.cc) ---- */
 /* FE_Q_iso_Q1(ls_degree) on the same brick; block vectors with dim blocks (normal
  * vector field) are passed as ONE pointer to dim consecutive double[n_dofs_ls].

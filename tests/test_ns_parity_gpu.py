@@ -205,3 +205,49 @@ def test_velocity_vmult_q2_kernel():
     src, dst = op.initialize_u_vector(src_u), op.initialize_u_vector(np.full(case.n_u, 3.0))
     op.velocity_vmult(dst, src)
     assert rel_l2(dst.numpy(), ref) < TOL
+
+
+def test_halo_pack_unpack_kernel_matches_slicing():
+    """adaflo_halo_transfer (pack / unpack-copy / unpack-add of interface node boxes) vs numpy slicing"""
+    import ctypes as C
+    from adaflo_amd import _lib, parallel
+    case = Case((3, 2, 4), k=2)
+    op = case.engine()
+    part = parallel.BrickPartition((3, 3, 3), 13, [3, 2, 4], [-1] * 3, [1] * 3)   # interior rank: 26 neighbours
+    nn = part.nodes(2)
+    v = case.random_u()
+    offs = [o for o, _ in part.neighbours()]
+    assert len(offs) == 26
+    regs, ref = [], []
+    v4 = v.reshape(nn[2], nn[1], nn[0], 3)
+    for o in offs:
+        sl = parallel._region(o, nn)
+        ref.append(v4[sl].reshape(-1))
+        for d in range(3):
+            lo = 0 if o[d] <= 0 else nn[d] - 1
+            regs += [lo, nn[d] if o[d] == 0 else lo + 1]
+    ref = np.concatenate(ref)
+    dv = op.initialize_u_vector(v)
+    from adaflo_amd.vectors import DeviceVector
+    buf = DeviceVector(op._ctx, ref.size)
+    arr, nn_c = (C.c_int * len(regs))(*regs), (C.c_int * 3)(*nn)
+    lib = _lib.load()
+    _lib.check(op._ctx, lib.adaflo_halo_transfer(op._ctx, dv.ptr, buf.ptr, nn_c, 3, 26, arr, 0))
+    assert np.array_equal(buf.numpy(), ref)
+    # unpack-add into zeros: every interface node receives the sum over the regions containing it
+    dz = op.initialize_u_vector()
+    _lib.check(op._ctx, lib.adaflo_halo_transfer(op._ctx, dz.ptr, buf.ptr, nn_c, 3, 26, arr, 2))
+    expect = np.zeros_like(v4)
+    for o in offs:
+        expect[parallel._region(o, nn)] += v4[parallel._region(o, nn)]
+    assert rel_l2(dz.numpy(), expect.reshape(-1)) < 1e-15
+    # unpack-copy of the six faces only
+    faces = [i for i, o in enumerate(offs) if sum(abs(x) for x in o) == 1]
+    farr = (C.c_int * (6 * len(faces)))(*[regs[6 * i + j] for i in faces for j in range(6)])
+    fbuf = DeviceVector.from_numpy(op._ctx, np.concatenate([v4[parallel._region(offs[i], nn)].reshape(-1) for i in faces]))
+    dz = op.initialize_u_vector()
+    _lib.check(op._ctx, lib.adaflo_halo_transfer(op._ctx, dz.ptr, fbuf.ptr, nn_c, 3, len(faces), farr, 1))
+    expect = np.zeros_like(v4)
+    for i in faces:
+        expect[parallel._region(offs[i], nn)] = v4[parallel._region(offs[i], nn)]
+    assert np.array_equal(dz.numpy(), expect.reshape(-1))
