@@ -131,21 +131,32 @@ namespace adaflo_hip
     // ---------------------------------------------------------------------------------
     // LDS carve-up (dynamic shared memory, doubles)
     // ---------------------------------------------------------------------------------
-    constexpr int RING      = 9;              // state pieces per wave in the LDS ring (54 % RING == 0)
-    constexpr int AHEAD     = 8;              // pieces issued ahead of the consumer
+#ifndef Q2_RING
+#define Q2_RING 9
+#endif
+    constexpr int RING      = Q2_RING;        // state pieces per wave in the LDS ring (54 % RING == 0)
+    constexpr int AHEAD     = (RING - 1) & ~1; // pieces issued ahead of the consumer (even)
     constexpr int PIECE     = 96;             // doubles per piece: 48 lanes x 16 B
     constexpr int L_RING    = 0;
+    // node planes in LDS: rows padded to a multiple of 16 B so that one 16-B-per-lane LDS-DMA
+    // instruction copies whole rows (26 / 5 lanes per row); the row's last double sits one slot
+    // later when the row length is odd (the last chunk is read shifted back by 8 B so that the
+    // copy never reads beyond the row), see dma_rows_b128
+    constexpr int UROW      = 52;                         // 17 nodes x 3 comps = 51 doubles (+1)
+    constexpr int PROW      = 10;                         // 9 doubles (+1)
+    constexpr int UPLANE_L  = PNY * UROW;                 // 884
+    constexpr int PPLANE_L  = QNY * PROW;                 // 90
     constexpr int L_UPL     = L_RING + 4 * RING * PIECE;  // 3 velocity node planes
-    constexpr int L_PPL     = L_UPL + 3 * UPLANE + 1;     // 2 pressure node planes
-    constexpr int L_SCRU    = L_PPL + 2 * PPLANE;         // [3 planes][5 slots][192]
+    constexpr int L_PPL     = L_UPL + 3 * UPLANE_L;       // 2 pressure node planes
+    constexpr int L_SCRU    = L_PPL + 2 * PPLANE_L;       // [3 planes][5 slots][192]
     constexpr int L_SCRP    = L_SCRU + 15 * NCELL * 3;    // [2 planes][3 slots][64]
     constexpr int L_CEX     = L_SCRP + 6 * NCELL;         // carry of the far x column  [17][3]
     constexpr int L_CEY     = L_CEX + PNY * 3;            // carry of the far y row     [17][3]
     constexpr int L_CPX     = L_CEY + PNX * 3;            // pressure far column [9], far row [9]
     constexpr int L_CPY     = L_CPX + QNY;
     constexpr int L_TOTAL   = L_CPY + QNX;
-    constexpr int NPL_U     = 18;             // plane-DMA instructions per wave and layer (fixed count)
-    constexpr int NPL_P     = 3;
+    constexpr int NPL_U     = 5;              // plane-DMA instructions per wave and layer (fixed count)
+    constexpr int NPL_P     = 1;
 
     // ---------------------------------------------------------------------------------
     // Seams between workgroups.  A node on the lateral rim of a tile is shared by up to four
@@ -170,6 +181,12 @@ namespace adaflo_hip
       return 3 * TN - 3 + j;
     }
     constexpr int RIM_U = 4 * (PNX - 1), RIM_P = 4 * (QNX - 1); // 64, 32
+
+#if defined(Q2_NOSTORE)
+#define Q2_STORE(lhs, rhs) do { if ((rhs) == 1.2345e300) lhs = (rhs); } while (0)
+#else
+#define Q2_STORE(lhs, rhs) lhs = (rhs)
+#endif
 
     __device__ __forceinline__ void lds_barrier()
     {
@@ -205,7 +222,11 @@ namespace adaflo_hip
     {
       asm volatile("s_mov_b32 m0, %0\n\t"
                    "s_mov_b64 exec, %3\n\t"
+#if defined(Q2_EXP) && Q2_EXP == 5
                    "global_load_lds_dwordx4 %1, %2\n\t"
+#else
+                   "global_load_lds_dwordx4 %1, %2 nt\n\t"
+#endif
                    "s_mov_b64 exec, -1" ::"s"(lds_byte), "v"(voff), "s"(sbase), "s"(mask)
                    : "memory");
     }
@@ -220,67 +241,101 @@ namespace adaflo_hip
                    : "memory");
     }
 
+    // one 16-byte global store (the address is only 8-byte aligned in general)
+    typedef double double2v __attribute__((ext_vector_type(2)));
+    __device__ __forceinline__ void store_b128(double *p, const double a, const double b)
+    {
+#if defined(Q2_NOSTORE)
+      if (a != 1.2345e300)
+        return;
+#endif
+      double2v v;
+      v.x = a;
+      v.y = b;
+      asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    }
+
     __device__ __forceinline__ unsigned lds_addr(const void *p)
     {
       return (unsigned)(size_t)p; // LDS aperture: the low 32 bits are the LDS byte address
     }
 
-    // asynchronous copy of (part of) one row of doubles into LDS, 4 B per lane and instruction.
-    // The instruction is ALWAYS issued with at least one active lane and in-bounds addresses
-    // (the vmcnt bookkeeping of the kernel relies on a fixed number of VMEM operations); lanes
-    // beyond the valid part of the row are switched off except lane 0, whose (harmless) write
-    // lands in an LDS entry that belongs to a node outside the domain.
-    __device__ __forceinline__ void dma_row_dwords(const double *grow, double *lrow, const int lane,
-                                                   const int n_dwords, const int first)
+    // One LDS-DMA instruction (16 B per lane) copying up to ROWS_PER = 64 / LPR consecutive rows
+    // of a node plane: lanes [r*LPR, (r+1)*LPR) serve row j0 + r.  A row holds nv valid doubles
+    // (nv <= 2*LPR - 1); lane c of a row copies doubles [2c, 2c+1], except that for odd nv the
+    // last lane copies [nv-2, nv-1] (=> the last double lands in LDS slot nv, slot nv-1 holds a
+    // duplicate).  Nothing beyond the row is ever read.  The instruction is always issued (lane
+    // 0 is always active; rows beyond the domain re-read the last valid row): the vmcnt
+    // bookkeeping of the kernel relies on a fixed number of VMEM operations per wave.
+    //   plane : scalar pointer to the first double of the global plane
+    //   row_off(j) = doubles from `plane` to the first entry of tile row j (clamped inside)
+    template <int LPR, int NROWS>
+    __device__ __forceinline__ void dma_rows_b128(const double *plane, const int lane, const int j0,
+                                                  const int nv, const int row_stride_dbl,
+                                                  const int row0_dbl, const int last_row,
+                                                  double *lds_row0)
     {
-      const int                dw   = first + lane;
-      const unsigned long long mask = __ballot(dw < n_dwords) | 1ull;
-      dma_b32(grow, 4u * (unsigned)min(dw, n_dwords - 1), lds_addr(lrow) + 4u * first, mask);
+      const int  r  = lane / LPR, c = lane - r * LPR;
+      const int  j  = j0 + r;
+      const int  nchunk = (nv + 1) >> 1;
+      const bool act = r < 64 / LPR && j < NROWS && c < nchunk;
+      const int  dbl = (c == nchunk - 1 && (nv & 1)) ? nv - 2 : 2 * c;
+      const int  jg  = min(j, last_row); // rows beyond the domain: harmless duplicate
+      const unsigned voff = 8u * (unsigned)(row0_dbl + jg * row_stride_dbl + dbl);
+      const unsigned long long mask = __ballot(act) | 1ull;
+      dma_b128(plane, act ? voff : 8u * (unsigned)(row0_dbl), lds_addr(lds_row0), mask);
     }
 
-    // the fixed number (NPL_U) of row copies one wave contributes to velocity planes K0, K0+1
-    // (rows / planes beyond the domain re-read the last valid row: their LDS copy is never used)
+    // the NPL_U row-pair copies one wave contributes to velocity planes K0 and K0+1
     __device__ __forceinline__ void dma_u_planes(const Q2Args &A, double *lds, const int K0,
                                                  const int I0, const int J0, const int wave,
                                                  const int lane)
     {
-      const int nrow_dw = 6 * min(PNX, A.nnx - I0); // valid dwords of a tile row
+      const int nv = 3 * min(PNX, A.nnx - I0); // valid doubles of a tile row
 #pragma unroll
-      for (int t = 0; t < NPL_U / 2; ++t)
+      for (int t = 0; t < NPL_U; ++t)
         {
-          // 34 rows (2 planes x 17) dealt round-robin to 4 waves; surplus slots repeat a row
-          int r = wave + 4 * t;
-          if (r >= 2 * PNY)
-            r -= 4;
-          const int     pl = r / PNY, j = r - pl * PNY, K = K0 + pl;
-          const int     Jg = min(J0 + j, A.nny - 1), Kg = min(K, A.nnz - 1);
-          const double *g  = A.src_u + ((long)(Kg * (long)A.nny + Jg) * A.nnx + I0) * 3;
-          double       *l  = lds + L_UPL + (K % 3) * UPLANE + j * PNX * 3;
-          dma_row_dwords(g, l, lane, nrow_dw, 0);
-          dma_row_dwords(g, l, lane, nrow_dw, 64);
+          // 2 planes x 9 row pairs (the 9th pair is a single row) dealt round-robin to the 4 waves
+          int n = wave + 4 * t;
+          if (n >= 18)
+            n -= 4;
+          const int     pl = n / 9, m = n - 9 * pl, K = K0 + pl, Kg = min(K, A.nnz - 1);
+          const double *plane = A.src_u + (size_t)Kg * A.nny * A.nnx * 3;
+          dma_rows_b128<26, PNY>(plane, lane, 2 * m, nv, A.nnx * 3, (J0 * A.nnx + I0) * 3,
+                                 A.nny - 1 - J0, lds + L_UPL + (K % 3) * UPLANE_L + 2 * m * UROW);
         }
     }
 
-    __device__ __forceinline__ void dma_p_plane(const Q2Args &A, double *lds, const int K,
-                                                const int I0, const int J0, const int wave,
-                                                const int lane)
+    // one plane (prologue): 9 row pairs over the 4 waves, 3 instructions per wave
+    __device__ __forceinline__ void dma_u_plane_single(const Q2Args &A, double *lds, const int K,
+                                                       const int I0, const int J0, const int wave,
+                                                       const int lane)
     {
-      const int nrow_dw = 2 * min(QNX, A.npx - I0);
+      const int     nv    = 3 * min(PNX, A.nnx - I0);
+      const double *plane = A.src_u + (size_t)K * A.nny * A.nnx * 3;
 #pragma unroll
-      for (int t = 0; t < NPL_P; ++t)
+      for (int t = 0; t < 3; ++t)
         {
-          int j = wave + 4 * t;
-          if (j >= QNY)
-            j -= 4;
-          const int     Jg = min(J0 + j, A.npy - 1), Kg = min(K, A.npz - 1);
-          const double *g  = A.src_p + (long)(Kg * (long)A.npy + Jg) * A.npx + I0;
-          double       *l  = lds + L_PPL + (K % 2) * PPLANE + j * QNX;
-          dma_row_dwords(g, l, lane, nrow_dw, 0);
+          int m = wave + 4 * t;
+          if (m >= 9)
+            m -= 4;
+          dma_rows_b128<26, PNY>(plane, lane, 2 * m, nv, A.nnx * 3, (J0 * A.nnx + I0) * 3,
+                                 A.nny - 1 - J0, lds + L_UPL + (K % 3) * UPLANE_L + 2 * m * UROW);
         }
     }
 
-    // LIN_MODE: 0 Newton (state = u_lin, grad u_lin), 1 Picard-type (state = u_lin, div u_lin),
-    //           2 no convective linearisation (explicit convection, Stokes)
+    // a pressure plane is a single instruction (9 rows x 5 lanes); every wave issues it (the
+    // copies are identical) to keep the per-wave VMEM op count fixed
+    __device__ __forceinline__ void dma_p_plane(const Q2Args &A, double *lds, const int K,
+                                                const int I0, const int J0, const int lane)
+    {
+      const int     nv    = min(QNX, A.npx - I0);
+      const int     Kg    = min(K, A.npz - 1);
+      const double *plane = A.src_p + (size_t)Kg * A.npy * A.npx;
+      dma_rows_b128<5, QNY>(plane, lane, 0, nv, A.npx, J0 * A.npx + I0, A.npy - 1 - J0,
+                            lds + L_PPL + (K % 2) * PPLANE_L);
+    }
+
     // ISO: cubic cells, one set of derivative coefficients for all directions
     template <int LIN_MODE, bool WITH_P, bool ISO>
     __global__ __launch_bounds__(NT, 2) void ns_q2_kernel(const Q2Args A)
@@ -355,6 +410,10 @@ namespace adaflo_hip
       const unsigned lane_g  = is_p ? (unsigned)((Jp0 + cyl) * A.npx + Ip0 + cxl) :
                                       (unsigned)(((J0 + 2 * cyl) * A.nnx + I0 + 2 * cxl) * 3 + d);
 
+      // the last double of an odd-length LDS plane row sits one slot later (dma_rows_b128)
+      const int nv_row   = is_p ? min(QNX, A.npx - Ip0) : 3 * min(PNX, A.nnx - I0);
+      const int fix_last = (lastx && (nv_row & 1) && (is_p || d == 2)) ? 1 : 0;
+
       double cu[4] = {0., 0., 0., 0.}; // carried top-plane sums of the regular owned nodes
       // zero the LDS carries of the far column / row
       for (int e = tid; e < L_TOTAL - L_CEX; e += NT)
@@ -365,21 +424,12 @@ namespace adaflo_hip
       double        *ringw = lds + L_RING + wave * RING * PIECE;
       const unsigned slan  = cell * 3 + (is_p ? 0 : d); // my element of a piece
       {
-        // plane 2*cz0 by one wave-split pass (rows 0..16 -> waves), then the regular pair
-        const int nrow_dw = 6 * min(PNX, A.nnx - I0);
-        for (int j = wave; j < PNY; j += 4)
-          {
-            const int     Jg = min(J0 + j, A.nny - 1), K = 2 * cz0;
-            const double *g  = A.src_u + ((long)(K * (long)A.nny + Jg) * A.nnx + I0) * 3;
-            double       *l  = lds + L_UPL + (K % 3) * UPLANE + j * PNX * 3;
-            dma_row_dwords(g, l, lane, nrow_dw, 0);
-            dma_row_dwords(g, l, lane, nrow_dw, 64);
-          }
+        dma_u_plane_single(A, lds, 2 * cz0, I0, J0, wave, lane);
         dma_u_planes(A, lds, 2 * cz0 + 1, I0, J0, wave, lane);
         if (WITH_P)
           {
-            dma_p_plane(A, lds, cz0, Ip0, Jp0, wave, lane);
-            dma_p_plane(A, lds, cz0 + 1, Ip0, Jp0, wave, lane);
+            dma_p_plane(A, lds, cz0, Ip0, Jp0, lane);
+            dma_p_plane(A, lds, cz0 + 1, Ip0, Jp0, lane);
           }
       }
       const unsigned ring_byte = lds_addr(ringw);
@@ -415,12 +465,12 @@ namespace adaflo_hip
 #pragma unroll
               for (int c = 0; c < 3; ++c)
                 {
-                  const double *pl = lds + L_UPL + ((2 * cz + c) % 3) * UPLANE + (2 * cyl * PNX + 2 * cxl) * 3 + d;
+                  const double *pl = lds + L_UPL + ((2 * cz + c) % 3) * UPLANE_L + 2 * cyl * UROW + 2 * cxl * 3 + d;
 #pragma unroll
                   for (int b = 0; b < 3; ++b)
 #pragma unroll
                     for (int a = 0; a < 3; ++a)
-                      V[a + 3 * b + 9 * c] = pl[(b * PNX + a) * 3];
+                      V[a + 3 * b + 9 * c] = pl[b * UROW + a * 3 + (a == 2 ? fix_last : 0)];
                 }
             }
           else
@@ -429,12 +479,12 @@ namespace adaflo_hip
 #pragma unroll
               for (int c = 0; c < 2; ++c)
                 {
-                  const double *pl = lds + L_PPL + ((cz + c) % 2) * PPLANE + cyl * QNX + cxl;
+                  const double *pl = lds + L_PPL + ((cz + c) % 2) * PPLANE_L + cyl * PROW + cxl;
 #pragma unroll
                   for (int b = 0; b < 2; ++b)
 #pragma unroll
                     for (int a = 0; a < 2; ++a)
-                      V[2 * a + 6 * b + 18 * c] = WITH_P ? pl[b * QNX + a] : 0.;
+                      V[2 * a + 6 * b + 18 * c] = WITH_P ? pl[b * PROW + a + (a == 1 ? fix_last : 0)] : 0.;
                 }
             }
           // read_dof_values: constrained entries read as zero (boundary tiles / layers only)
@@ -480,7 +530,7 @@ namespace adaflo_hip
           // (issued for the last layer of the chunk too: fixed VMEM op count, see wait_vmcnt uses)
           dma_u_planes(A, lds, 2 * cz + 3, I0, J0, wave, lane);
           if (WITH_P)
-            dma_p_plane(A, lds, cz + 2, Ip0, Jp0, wave, lane);
+            dma_p_plane(A, lds, cz + 2, Ip0, Jp0, lane);
 
           // ---- C: interpolate to the Gauss points (in place) ----------------------------
 #pragma unroll
@@ -567,6 +617,11 @@ namespace adaflo_hip
                       issue_piece(cz_next, 2 * q + AHEAD + 1 - 54);
                     }
                 }
+#if defined(Q2_EXP) && Q2_EXP == 4
+              // diagnostic: stream only -- consume the state minimally, skip the arithmetic
+              R[q] += st0.x + st1.y + r_trl + r_ub0 + r_ub1 + r_ub2;
+              continue;
+#endif
               const double Vq = V[q];
               // reference-cell derivatives by the collocation derivative, then J^{-T}
               constexpr int e1 = ISO ? 0 : 1, e2 = ISO ? 0 : 2;
@@ -773,20 +828,45 @@ namespace adaflo_hip
                         }
                       const bool   zcon  = (K == 0 && conz_lo);
                       const size_t pbase = (size_t)K * A.nny * A.nnx * 3;
+                      // constrained rows carry +src (:247-256); boundary tiles only
+                      if (m_con != 0u || zcon)
+                        {
 #pragma unroll
-                      for (int n = 0; n < 9; ++n)
-                        if (m_own >> n & 1u)
-                          {
-                            const int      li = n % 3, lj = n / 3;
-                            const size_t   idx = pbase + lane_g + (unsigned)((lj * A.nnx + li) * 3);
-                            if ((m_con >> n & 1u) || zcon)
-                              A.dst_u[idx] = A.src_u[idx]; // :247-256 (+1 on the velocity block)
-                            else if (m_seam >> n & 1u)
-                              A.slab_u[((wgs * (2 * A.LZ + 1) + 2 * layer + lk) * RIM_U +
-                                        rim_index<PNX>(2 * cxl + li, 2 * cyl + lj)) * 3 + d] = nv[n];
-                            else
-                              A.dst_u[idx] = nv[n];
-                          }
+                          for (int n = 0; n < 9; ++n)
+                            if ((m_own >> n & 1u) && ((m_con >> n & 1u) || zcon))
+                              nv[n] = A.src_u[pbase + lane_g + (unsigned)(((n / 3) * A.nnx + n % 3) * 3)];
+                        }
+                      // partial sums of nodes shared with other workgroups -> slab (q2_seam_fixup_kernel
+                      // writes their final dst value, so whatever lands in dst below is overwritten)
+                      if (m_seam != 0u)
+                        {
+#pragma unroll
+                          for (int n = 0; n < 9; ++n)
+                            if ((m_own & m_seam & ~m_con) >> n & 1u)
+                              Q2_STORE(A.slab_u[((wgs * (2 * A.LZ + 1) + 2 * layer + lk) * RIM_U +
+                                                 rim_index<PNX>(2 * cxl + n % 3, 2 * cyl + n / 3)) * 3 + d], nv[n]);
+                        }
+                      // regular nodes (li, lj in {0,1}): the quad's 2 nodes x 3 components of a row are 48
+                      // contiguous bytes; regroup them inside the quad so that every lane stores 16 B
+#pragma unroll
+                      for (int lj = 0; lj < 2; ++lj)
+                        {
+                          const double x0 = nv[3 * lj], x1 = nv[3 * lj + 1];
+                          const double b00 = quad_bcast<0>(x0), b01 = quad_bcast<1>(x0), b02 = quad_bcast<2>(x0);
+                          const double b10 = quad_bcast<0>(x1), b11 = quad_bcast<1>(x1), b12 = quad_bcast<2>(x1);
+                          const double first = sel3(d, b00, b02, b11), second = sel3(d, b01, b10, b12);
+                          if (valid)
+                            store_b128(A.dst_u + pbase + (lane_g - d) + (unsigned)(lj * A.nnx * 3 + 2 * d), first, second);
+                        }
+                      // far rim of the tile (li = 2 / lj = 2): last cells only
+                      if (lastx || lasty)
+                        {
+#pragma unroll
+                          for (int n = 0; n < 9; ++n)
+                            if ((n % 3 == 2 || n / 3 == 2) && (m_own >> n & 1u) &&
+                                (((m_con | ~m_seam) >> n & 1u) || zcon))
+                              Q2_STORE(A.dst_u[pbase + lane_g + (unsigned)(((n / 3) * A.nnx + n % 3) * 3)], nv[n]);
+                        }
                     }
                 }
             }
@@ -837,12 +917,12 @@ namespace adaflo_hip
                             {
                               const size_t idx = pbase + lane_g + (unsigned)(lj * A.npx + li);
                               if ((m_con >> bit & 1u) || zcon)
-                                A.dst_p[idx] = -A.src_p[idx]; // -1 on the pressure block of vmult
+                                Q2_STORE(A.dst_p[idx], -A.src_p[idx]); // -1 on the pressure block of vmult
                               else if (m_seam >> bit & 1u)
-                                A.slab_p[(wgs * (A.LZ + 1) + layer) * RIM_P +
-                                         rim_index<QNX>(cxl + li, cyl + lj)] = nv[n];
+                                Q2_STORE(A.slab_p[(wgs * (A.LZ + 1) + layer) * RIM_P +
+                                         rim_index<QNX>(cxl + li, cyl + lj)], nv[n]);
                               else
-                                A.dst_p[idx] = nv[n];
+                                Q2_STORE(A.dst_p[idx], nv[n]);
                             }
                         }
                     }
@@ -879,14 +959,14 @@ namespace adaflo_hip
                   const int    li = n % 3, lj = n / 3;
                   const size_t idx = pbase + lane_g + (unsigned)((lj * A.nnx + li) * 3);
                   if ((m_con >> n & 1u) || zcon)
-                    A.dst_u[idx] = A.src_u[idx];
+                    Q2_STORE(A.dst_u[idx], A.src_u[idx]);
                   else if (m_seam >> n & 1u)
-                    A.slab_u[((wgs * (2 * A.LZ + 1) + 2 * nl) * RIM_U +
-                              rim_index<PNX>(2 * cxl + li, 2 * cyl + lj)) * 3 + d] = nv[n];
+                    Q2_STORE(A.slab_u[((wgs * (2 * A.LZ + 1) + 2 * nl) * RIM_U +
+                              rim_index<PNX>(2 * cxl + li, 2 * cyl + lj)) * 3 + d], nv[n]);
                   else if (zseam)
-                    A.zslab_u[(wgs * (PNX * PNY) + (2 * cyl + lj) * PNX + 2 * cxl + li) * 3 + d] = nv[n];
+                    Q2_STORE(A.zslab_u[(wgs * (PNX * PNY) + (2 * cyl + lj) * PNX + 2 * cxl + li) * 3 + d], nv[n]);
                   else
-                    A.dst_u[idx] = nv[n];
+                    Q2_STORE(A.dst_u[idx], nv[n]);
                 }
           }
         else if (WITH_P && A.integrate_p)
@@ -908,13 +988,13 @@ namespace adaflo_hip
                   {
                     const size_t idx = pbase + lane_g + (unsigned)(lj * A.npx + li);
                     if ((m_con >> bit & 1u) || zcon)
-                      A.dst_p[idx] = -A.src_p[idx];
+                      Q2_STORE(A.dst_p[idx], -A.src_p[idx]);
                     else if (m_seam >> bit & 1u)
-                      A.slab_p[(wgs * (A.LZ + 1) + nl) * RIM_P + rim_index<QNX>(cxl + li, cyl + lj)] = nv[n];
+                      Q2_STORE(A.slab_p[(wgs * (A.LZ + 1) + nl) * RIM_P + rim_index<QNX>(cxl + li, cyl + lj)], nv[n]);
                     else if (zseam)
-                      A.zslab_p[wgs * PPLANE + (cyl + lj) * QNX + cxl + li] = nv[n];
+                      Q2_STORE(A.zslab_p[wgs * PPLANE + (cyl + lj) * QNX + cxl + li], nv[n]);
                     else
-                      A.dst_p[idx] = nv[n];
+                      Q2_STORE(A.dst_p[idx], nv[n]);
                   }
               }
           }
