@@ -155,6 +155,7 @@ namespace adaflo_hip
     constexpr int L_CPX     = L_CEY + PNX * 3;            // pressure far column [9], far row [9]
     constexpr int L_CPY     = L_CPX + QNY;
     constexpr int L_TOTAL   = L_CPY + QNX;
+    constexpr int XQ        = 18;             // doubles per quad record: 4 lanes x 4 + pad (bank spread, 16-B aligned)
     constexpr int NPL_U     = 5;              // plane-DMA instructions per wave and layer (fixed count)
     constexpr int NPL_P     = 1;
 
@@ -184,8 +185,16 @@ namespace adaflo_hip
 
 #if defined(Q2_NOSTORE)
 #define Q2_STORE(lhs, rhs) do { if ((rhs) == 1.2345e300) lhs = (rhs); } while (0)
+#define Q2_STORE_SLAB(lhs, rhs) Q2_STORE(lhs, rhs)
+#elif defined(Q2_NOSLAB)
+#define Q2_STORE(lhs, rhs) lhs = (rhs)
+#define Q2_STORE_SLAB(lhs, rhs) do { if ((rhs) == 1.2345e300) lhs = (rhs); } while (0)
+#elif defined(Q2_NODST)
+#define Q2_STORE(lhs, rhs) do { if ((rhs) == 1.2345e300) lhs = (rhs); } while (0)
+#define Q2_STORE_SLAB(lhs, rhs) lhs = (rhs)
 #else
 #define Q2_STORE(lhs, rhs) lhs = (rhs)
+#define Q2_STORE_SLAB(lhs, rhs) lhs = (rhs)
 #endif
 
     __device__ __forceinline__ void lds_barrier()
@@ -245,7 +254,7 @@ namespace adaflo_hip
     typedef double double2v __attribute__((ext_vector_type(2)));
     __device__ __forceinline__ void store_b128(double *p, const double a, const double b)
     {
-#if defined(Q2_NOSTORE)
+#if defined(Q2_NOSTORE) || defined(Q2_NODST)
       if (a != 1.2345e300)
         return;
 #endif
@@ -372,8 +381,10 @@ namespace adaflo_hip
       const bool valid = cxl < tcx && cyl < tcy;
       const bool lastx = cxl == tcx - 1, lasty = cyl == tcy - 1;
       const bool hasW = cxl > 0, hasS = cyl > 0;
-      unsigned   m_own = 0, m_con = 0, m_seam = 0, m_zero = 0;
+      unsigned flags; // bits 0-8 owned, 9-17 constrained, 18-26 seam; m_zero separately (gather)
+      unsigned m_zero = 0;
       {
+        unsigned m_own = 0, m_con = 0, m_seam = 0;
         const int  nn_x = is_p ? A.npx : A.nnx, nn_y = is_p ? A.npy : A.nny;
         const int  deg  = is_p ? 1 : 2;
         const int  ib = (is_p ? Ip0 : I0) + deg * cxl, jb = (is_p ? Jp0 : J0) + deg * cyl;
@@ -404,7 +415,12 @@ namespace adaflo_hip
               if (seam)
                 m_seam |= 1u << bit;
             }
+        flags = m_own | (m_con << 9) | (m_seam << 18);
       }
+      // keep ONE packed register alive across the quadrature loop (register pressure)
+#define m_own (flags & 0x1ffu)
+#define m_con ((flags >> 9) & 0x1ffu)
+#define m_seam ((flags >> 18) & 0x1ffu)
       const bool     conz_lo = is_p ? (A.con_p >> 4 & 1) : (A.con_u >> (12 + d) & 1);
       const bool     conz_hi = is_p ? (A.con_p >> 5 & 1) : (A.con_u >> (15 + d) & 1);
       const unsigned lane_g  = is_p ? (unsigned)((Jp0 + cyl) * A.npx + Ip0 + cxl) :
@@ -432,6 +448,11 @@ namespace adaflo_hip
             dma_p_plane(A, lds, cz0 + 1, Ip0, Jp0, lane);
           }
       }
+      // wave-private exchange records (alias of the publish scratch, which is only live in D/E)
+#if defined(Q2_LDS_EXCHANGE)
+      double        *xb = lds + L_SCRU + wave * (16 * XQ);
+      const int      xq = cq * XQ;
+#endif
       const unsigned ring_byte = lds_addr(ringw);
       const unsigned piece_voff = 16u * (unsigned)min(lane, 47);
       auto issue_piece = [&](const int layer_cz, const int p) {
@@ -632,16 +653,36 @@ namespace adaflo_hip
               const double  g2 = dline(qz, V[qx + 3 * qy], V[qx + 3 * qy + 9], V[qx + 3 * qy + 18],
                                        A.ah[e2][0], A.ah[e2][1], A.ah[e2][2], A.ah[e2][3]);
 
-              // gradient rows of the three velocity components, visible to all four lanes
+#if !defined(Q2_LDS_EXCHANGE)
+              // gradient rows of the three velocity components, visible to all four lanes (DPP)
               const double G00 = quad_bcast<0>(g0), G01 = quad_bcast<0>(g1), G02 = quad_bcast<0>(g2);
               const double G10 = quad_bcast<1>(g0), G11 = quad_bcast<1>(g1), G12 = quad_bcast<1>(g2);
               const double G20 = quad_bcast<2>(g0), G21 = quad_bcast<2>(g1), G22 = quad_bcast<2>(g2);
+              const double c0 = sel3(d, G00, G01, G02), c1 = sel3(d, G10, G11, G12), c2 = sel3(d, G20, G21, G22);
+              const double u0 = quad_bcast<0>(Vq), u1 = quad_bcast<1>(Vq), u2 = quad_bcast<2>(Vq);
+              const double pres = quad_bcast<3>(Vq);
+#else
+              // (measured alternative, 17 % slower: exposed LDS latency per point + one more barrier)
+              // Exchange inside the quad through a wave-private LDS record [lane d][g0 g1 g2 v]:
+              // one wave's LDS operations execute in order, so the reads below see this
+              // iteration's writes of all four lanes without any barrier.  Lane d picks column d
+              // of the velocity gradient with a lane-dependent ADDRESS instead of register selects.
+              {
+                double2 *w2 = reinterpret_cast<double2 *>(xb + xq + 4 * d);
+                w2[0] = make_double2(g0, g1);
+                w2[1] = make_double2(g2, Vq);
+              }
+              const double c0 = xb[xq + d], c1 = xb[xq + 4 + d], c2 = xb[xq + 8 + d];
+              const double G00 = xb[xq], G11 = xb[xq + 5], G22 = xb[xq + 10];
+              const double u0 = xb[xq + 3], u1 = xb[xq + 7], u2 = xb[xq + 11];
+              const double pres = xb[xq + 15];
+#endif
               const double div = G00 + G11 + G22; // :706
+              (void)u0, (void)u1, (void)u2, (void)pres;
 
               double conv = A.cA * Vq; // :717, :827-835
               if (LIN_MODE == 0)       // Newton :802-816
                 {
-                  const double u0 = quad_bcast<0>(Vq), u1 = quad_bcast<1>(Vq), u2 = quad_bcast<2>(Vq);
                   // u_lin of all components and tr(grad u_lin): quad-uniform LDS reads of the ring
                   const double ub0 = r_ub0, ub1 = r_ub1, ub2 = r_ub2, trl = r_trl;
                   double       res = A.beta * (div * st0.x + trl * Vq);
@@ -661,11 +702,10 @@ namespace adaflo_hip
                 }
 
               const double jxw = A.wj[(qx == 1) + (qy == 1) + (qz == 1)];
-              // column d of the velocity gradient (transpose part of the symmetric gradient)
-              const double c0 = sel3(d, G00, G01, G02), c1 = sel3(d, G10, G11, G12), c2 = sel3(d, G20, G21, G22);
-              double       diag = A.tau_gd * div;
+              // c_e = column d of the velocity gradient (transpose part of the symmetric gradient)
+              double diag = A.tau_gd * div;
               if (WITH_P)
-                diag -= quad_bcast<3>(Vq);
+                diag -= pres;
               diag *= jxw;
               // :859-892: row d of tmu (grad u + grad u^T) + (tau_gd div - p) I, times JxW J^{-1}
               const double tmj = tmu_l * jxw;
@@ -706,6 +746,11 @@ namespace adaflo_hip
           else
             wait_vmcnt<0>();
 
+#if defined(Q2_LDS_EXCHANGE)
+          // the exchange records alias the publish scratch: every wave must have left its
+          // quadrature loop before anybody publishes
+          lds_barrier();
+#endif
           // ---- D: publish what the east / north neighbour cells need ----------------------
           // velocity: local (2,0) (2,1) (2,2) (0,2) (1,2) of every plane -> slots 0..4
           if (!is_p)
@@ -759,6 +804,19 @@ namespace adaflo_hip
           lds_barrier();
 
           // ---- E: combine per owned node and write the two finished planes -----------------
+          // Re-derive the lane coordinates from an opaque copy of the thread id: otherwise the
+          // compiler hoists all per-lane address arithmetic of this phase out of the layer loop
+          // and spills it around the quadrature loop (scratch reloads = s_waitcnt vmcnt(0) = a
+          // drained DMA queue every layer).
+          int tid_e = threadIdx.x;
+          asm volatile("" : "+v"(tid_e));
+          const int  lane_e = tid_e & 63;
+          const int  d = lane_e & 3, cq_e = lane_e >> 2;
+          const int  cxl = cq_e & 7, cyl = 2 * wave + (cq_e >> 3), cell = cyl * TX + cxl;
+          const bool is_p = d == 3;
+          const bool valid = cxl < tcx && cyl < tcy;
+          const bool lastx = cxl == tcx - 1, lasty = cyl == tcy - 1;
+          const bool hasW = cxl > 0, hasS = cyl > 0;
           if (!is_p)
             {
               const double *sc = lds + L_SCRU + cell * 3 + d;
@@ -843,7 +901,7 @@ namespace adaflo_hip
 #pragma unroll
                           for (int n = 0; n < 9; ++n)
                             if ((m_own & m_seam & ~m_con) >> n & 1u)
-                              Q2_STORE(A.slab_u[((wgs * (2 * A.LZ + 1) + 2 * layer + lk) * RIM_U +
+                              Q2_STORE_SLAB(A.slab_u[((wgs * (2 * A.LZ + 1) + 2 * layer + lk) * RIM_U +
                                                  rim_index<PNX>(2 * cxl + n % 3, 2 * cyl + n / 3)) * 3 + d], nv[n]);
                         }
                       // regular nodes (li, lj in {0,1}): the quad's 2 nodes x 3 components of a row are 48
@@ -919,7 +977,7 @@ namespace adaflo_hip
                               if ((m_con >> bit & 1u) || zcon)
                                 Q2_STORE(A.dst_p[idx], -A.src_p[idx]); // -1 on the pressure block of vmult
                               else if (m_seam >> bit & 1u)
-                                Q2_STORE(A.slab_p[(wgs * (A.LZ + 1) + layer) * RIM_P +
+                                Q2_STORE_SLAB(A.slab_p[(wgs * (A.LZ + 1) + layer) * RIM_P +
                                          rim_index<QNX>(cxl + li, cyl + lj)], nv[n]);
                               else
                                 Q2_STORE(A.dst_p[idx], nv[n]);
@@ -961,10 +1019,10 @@ namespace adaflo_hip
                   if ((m_con >> n & 1u) || zcon)
                     Q2_STORE(A.dst_u[idx], A.src_u[idx]);
                   else if (m_seam >> n & 1u)
-                    Q2_STORE(A.slab_u[((wgs * (2 * A.LZ + 1) + 2 * nl) * RIM_U +
+                    Q2_STORE_SLAB(A.slab_u[((wgs * (2 * A.LZ + 1) + 2 * nl) * RIM_U +
                               rim_index<PNX>(2 * cxl + li, 2 * cyl + lj)) * 3 + d], nv[n]);
                   else if (zseam)
-                    Q2_STORE(A.zslab_u[(wgs * (PNX * PNY) + (2 * cyl + lj) * PNX + 2 * cxl + li) * 3 + d], nv[n]);
+                    Q2_STORE_SLAB(A.zslab_u[(wgs * (PNX * PNY) + (2 * cyl + lj) * PNX + 2 * cxl + li) * 3 + d], nv[n]);
                   else
                     Q2_STORE(A.dst_u[idx], nv[n]);
                 }
@@ -990,9 +1048,9 @@ namespace adaflo_hip
                     if ((m_con >> bit & 1u) || zcon)
                       Q2_STORE(A.dst_p[idx], -A.src_p[idx]);
                     else if (m_seam >> bit & 1u)
-                      Q2_STORE(A.slab_p[(wgs * (A.LZ + 1) + nl) * RIM_P + rim_index<QNX>(cxl + li, cyl + lj)], nv[n]);
+                      Q2_STORE_SLAB(A.slab_p[(wgs * (A.LZ + 1) + nl) * RIM_P + rim_index<QNX>(cxl + li, cyl + lj)], nv[n]);
                     else if (zseam)
-                      Q2_STORE(A.zslab_p[wgs * PPLANE + (cyl + lj) * QNX + cxl + li], nv[n]);
+                      Q2_STORE_SLAB(A.zslab_p[wgs * PPLANE + (cyl + lj) * QNX + cxl + li], nv[n]);
                     else
                       Q2_STORE(A.dst_p[idx], nv[n]);
                   }
@@ -1000,6 +1058,10 @@ namespace adaflo_hip
           }
       }
     }
+
+#undef m_own
+#undef m_con
+#undef m_seam
 
     // second pass: add the seam partials per node (fixed order -> reproducible) and write dst
     template <int DEG, int NC>

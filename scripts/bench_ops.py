@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the driver's bench contract): generic-degree NS vmult and the
+level-set operators on one MI355X; prints one JSON line per operator with MDoF/s and the
+algorithmic HBM rate (SURVEY.md 8d byte counts)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import adaflo_amd  # noqa: E402
+from adaflo_amd import level_set_okz as lso  # noqa: E402
+
+
+def timeit(fn, sync, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps
+
+
+def ns_case(k, n, variant):
+    fp = adaflo_amd.FlowParameters(velocity_degree=k)
+    ts = adaflo_amd.TimeStepping(fp)
+    for _ in range(3):
+        ts.next()
+    op = adaflo_amd.NavierStokesMatrix(fp, adaflo_amd.BrickMesh([n] * 3, [-1] * 3, [1] * 3))
+    op.initialize(ts, True)
+    op.set_kernel_variant(variant)
+    rng = np.random.default_rng(1)
+    nq = (k + 1) ** 3
+    op.set_linearization(rng.uniform(-1, 1, op.n_cells() * nq * 12))
+    src = op.block_vector(rng.uniform(-1, 1, op.n_dofs_u()), rng.uniform(-1, 1, op.n_dofs_p()))
+    dst = op.block_vector()
+    t = timeit(lambda: op.vmult(dst, src), op.synchronize)
+    ndof = op.n_dofs_u() + op.n_dofs_p()
+    b_alg = op.n_cells() * (16 * (3 * k ** 3 + (k - 1) ** 3) + 8 * 12 * nq)
+    print(json.dumps({"op": "ns_vmult", "k": k, "cells": n, "variant": variant, "ms": round(t * 1e3, 4),
+                      "MDoF/s": round(ndof / t / 1e6, 1), "alg_GB/s": round(b_alg / t / 1e9, 1),
+                      "frac_of_8TB/s": round(b_alg / t / 8e12, 4)}), flush=True)
+
+
+def ls_case(s, ncell):
+    mesh = adaflo_amd.BrickMesh(list(ncell), [0, 0, 0], [1, 1, 2])
+    ops = lso.LevelSetOperators(mesh, s)
+    ops.set_parameters(1.5 * max(mesh.h) / s, 0.02, 75.0, -100.0, 25.0, 1.5)
+    rng = np.random.default_rng(2)
+    nq = (2 * s) ** 3
+    ncells = int(np.prod(ncell))
+    src = ops.vector(rng.uniform(-1, 1, ops.n_dofs))
+    dst = ops.vector()
+    sync = lambda: adaflo_amd._lib.load().adaflo_synchronize(ops._ctx)
+    adv = lso.LevelSetOKZSolverAdvanceConcentration(ops)
+    adv.evaluated_convection = rng.uniform(-1, 1, ncells * nq * 3)
+    rei = lso.LevelSetOKZSolverReinitialization(ops)
+    rei.evaluated_normal = rng.uniform(-1, 1, ncells * nq * 3)
+    nor = lso.LevelSetOKZSolverComputeNormal(ops)
+    cur = lso.LevelSetOKZSolverComputeCurvature(ops)
+    src3, dst3 = ops.vector(rng.uniform(-1, 1, 3 * ops.n_dofs), blocks=3), ops.vector(blocks=3)
+    cases = [("ls_advect_vmult", lambda: adv.advance_concentration_vmult(dst, src), 1, 16 * s ** 3 + 24 * nq),
+             ("ls_reinit_vmult", lambda: rei.reinitialization_vmult(dst, src, False), 1, 16 * s ** 3 + 24 * nq),
+             ("ls_normal_vmult", lambda: nor.compute_normal_vmult(dst3, src3), 3, 3 * 16 * s ** 3),
+             ("ls_curvature_vmult", lambda: cur.compute_curvature_vmult(dst, src, True), 1, 16 * s ** 3)]
+    for name, fn, blocks, bytes_per_cell in cases:
+        t = timeit(fn, sync)
+        print(json.dumps({"op": name, "s": s, "cells": list(ncell), "ms": round(t * 1e3, 4),
+                          "MDoF/s": round(blocks * ops.n_dofs / t / 1e6, 1),
+                          "alg_GB/s": round(bytes_per_cell * ncells / t / 1e9, 1),
+                          "frac_of_8TB/s": round(bytes_per_cell * ncells / t / 8e12, 4)}), flush=True)
+
+
+if __name__ == "__main__":
+    ns_case(2, 128, 1)
+    ns_case(2, 128, 0)
+    ns_case(3, 64, 0)
+    ns_case(4, 64, 0)
+    ls_case(4, (40, 40, 80))
