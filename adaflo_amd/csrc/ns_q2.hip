@@ -194,7 +194,11 @@ namespace adaflo_hip
 #define Q2_STORE_SLAB(lhs, rhs) lhs = (rhs)
 #else
 #define Q2_STORE(lhs, rhs) lhs = (rhs)
+#if defined(Q2_SLAB_NT)
+#define Q2_STORE_SLAB(lhs, rhs) __builtin_nontemporal_store((rhs), &(lhs))
+#else
 #define Q2_STORE_SLAB(lhs, rhs) lhs = (rhs)
+#endif
 #endif
 
     __device__ __forceinline__ void lds_barrier()
@@ -261,7 +265,8 @@ namespace adaflo_hip
       double2v v;
       v.x = a;
       v.y = b;
-      asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+      // nt: dst is written once and not re-read by this kernel (measured -2 %)
+      asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
     }
 
     __device__ __forceinline__ unsigned lds_addr(const void *p)
@@ -407,11 +412,12 @@ namespace adaflo_hip
               m_own |= 1u << bit;
               if (cx_ || cy_)
                 m_con |= 1u << bit;
-              // node on the lateral rim of the tile but not of the domain: shared with another workgroup
+              // node on the HIGH lateral rim of the tile (and not of the domain): its final value is
+              // assembled by the tile that has it on its low rim (the owner, which stores its own
+              // partial sum straight to dst); this tile's partial sum goes to the slab
               const int  ti = deg * cxl + li, tj = deg * cyl + lj; // tile-local node index
               const int  tnx = deg * TX, tny = deg * TY;
-              const bool seam = (ti == 0 && I > 0) || (ti == tnx && I < nn_x - 1) ||
-                                (tj == 0 && J > 0) || (tj == tny && J < nn_y - 1);
+              const bool seam = (ti == tnx && I < nn_x - 1) || (tj == tny && J < nn_y - 1);
               if (seam)
                 m_seam |= 1u << bit;
             }
@@ -894,8 +900,8 @@ namespace adaflo_hip
                             if ((m_own >> n & 1u) && ((m_con >> n & 1u) || zcon))
                               nv[n] = A.src_u[pbase + lane_g + (unsigned)(((n / 3) * A.nnx + n % 3) * 3)];
                         }
-                      // partial sums of nodes shared with other workgroups -> slab (q2_seam_fixup_kernel
-                      // writes their final dst value, so whatever lands in dst below is overwritten)
+                      // partial sums of high-rim nodes shared with other workgroups -> slab
+                      // (q2_seam_fixup_kernel adds them to the owner tile's partial sum in dst)
                       if (m_seam != 0u)
                         {
 #pragma unroll
@@ -1066,42 +1072,52 @@ namespace adaflo_hip
     // second pass: add the seam partials per node (fixed order -> reproducible) and write dst
     template <int DEG, int NC>
     __device__ __forceinline__ void fixup_rim(const Q2Args &A, long t, double *dst,
-                                              const double *slab, const int nn_x, const int nn_y,
-                                              const int nn_z, const uint32_t con)
+                                              const double *slab, const double *zslab,
+                                              const int nn_x, const int nn_y, const int nn_z,
+                                              const uint32_t con)
     {
-      constexpr int TN = DEG * TX + 1, RIM = 4 * (TN - 1), HI = 2 * TN - 1;
+      // one thread per (tile, plane K, LOW-rim node, component): the tile owns the node, its own
+      // partial sum is already in dst; add the partial sums of the west / south / south-west
+      // tiles (their high rim) and, on a chunk boundary plane, of the chunk below
+      constexpr int TN = DEG * TX + 1, RIM = 4 * (TN - 1), LO = 2 * TN - 1;
       const int     comp = (int)(t % NC);
       t /= NC;
-      const int s = (int)(t % HI);
-      t /= HI;
+      const int s = (int)(t % LO);
+      t /= LO;
       const int  K  = (int)(t % nn_z);
       const long bt = t / nn_z;
       const int  bx = (int)(bt % A.tiles_x), by = (int)(bt / A.tiles_x);
-      const int  i = s < TN ? s : TN - 1, j = s < TN ? TN - 1 : s - TN;
+      const int  i = s < TN ? s : 0, j = s < TN ? 0 : s - TN + 1; // south row, then west column
       const int  I = DEG * TX * bx + i, J = DEG * TY * by + j;
       if (I >= nn_x || J >= nn_y)
         return;
-      const bool seam_x = i == TN - 1 && I < nn_x - 1, seam_y = j == TN - 1 && J < nn_y - 1;
+      const bool seam_x = i == 0 && I > 0, seam_y = j == 0 && J > 0;
       if (!(seam_x || seam_y))
         return;
-      if ((i == 0 && I > 0) || (j == 0 && J > 0))
-        return; // owned by the tile to the west / south
+      // a node that is on this tile's HIGH rim in the other direction belongs to another owner
+      if ((i == TN - 1 && I < nn_x - 1) || (j == TN - 1 && J < nn_y - 1))
+        return;
       if (on_constrained_face(I, J, K, nn_x, nn_y, nn_z, con, NC == 1 ? 1 : 3, comp))
         return; // dst = +-src already written by every sharer
-      const int ppc  = DEG * A.LZ + 1;
-      const int c_hi = min(K / (DEG * A.LZ), A.n_chunks - 1);
-      const int lp   = K - DEG * A.LZ * c_hi;
-      double    sum  = 0.;
+      const int  ppc  = DEG * A.LZ + 1;
+      const int  c_hi = min(K / (DEG * A.LZ), A.n_chunks - 1);
+      const int  lp   = K - DEG * A.LZ * c_hi;
+      const bool zb   = lp == 0 && c_hi > 0; // K is the top plane of the chunk below as well
+      double     sum  = 0.;
       for (int dy = 0; dy <= (seam_y ? 1 : 0); ++dy)
         for (int dx = 0; dx <= (seam_x ? 1 : 0); ++dx)
           {
-            const long tb = (long)(by + dy) * A.tiles_x + bx + dx;
-            const int  r  = rim_index<TN>(i - (TN - 1) * dx, j - (TN - 1) * dy);
+            if (dx == 0 && dy == 0)
+              continue;
+            const long tb = (long)(by - dy) * A.tiles_x + bx - dx;
+            const int  r  = rim_index<TN>(i + (TN - 1) * dx, j + (TN - 1) * dy);
             sum += slab[(((tb * A.n_chunks + c_hi) * ppc + lp) * RIM + r) * NC + comp];
-            if (lp == 0 && c_hi > 0) // top plane of the chunk below
+            if (zb)
               sum += slab[(((tb * A.n_chunks + c_hi - 1) * ppc + DEG * A.LZ) * RIM + r) * NC + comp];
           }
-      dst[((long)(K * (long)nn_y + J) * nn_x + I) * NC + comp] = sum;
+      if (zb) // this tile's own partial of the chunk below
+        sum += zslab[((bt * A.n_chunks + c_hi - 1) * (TN * TN) + j * TN + i) * NC + comp];
+      dst[((long)(K * (long)nn_y + J) * nn_x + I) * NC + comp] += sum;
     }
 
     template <int DEG, int NC>
@@ -1133,11 +1149,11 @@ namespace adaflo_hip
       for (long t = blockIdx.x * 256L + threadIdx.x; t < n1 + n2 + n3 + n4; t += (long)gridDim.x * 256)
         {
           if (t < n1)
-            fixup_rim<2, 3>(A, t, A.dst_u, A.slab_u, A.nnx, A.nny, A.nnz, A.con_u);
+            fixup_rim<2, 3>(A, t, A.dst_u, A.slab_u, A.zslab_u, A.nnx, A.nny, A.nnz, A.con_u);
           else if (t < n1 + n2)
             fixup_zplane<2, 3>(A, t - n1, A.dst_u, A.zslab_u, A.nnx, A.nny, A.nnz, A.con_u);
           else if (t < n1 + n2 + n3)
-            fixup_rim<1, 1>(A, t - n1 - n2, A.dst_p, A.slab_p, A.npx, A.npy, A.npz, A.con_p);
+            fixup_rim<1, 1>(A, t - n1 - n2, A.dst_p, A.slab_p, A.zslab_p, A.npx, A.npy, A.npz, A.con_p);
           else
             fixup_zplane<1, 1>(A, t - n1 - n2 - n3, A.dst_p, A.zslab_p, A.npx, A.npy, A.npz, A.con_p);
         }
