@@ -1069,93 +1069,99 @@ namespace adaflo_hip
 #undef m_con
 #undef m_seam
 
-    // second pass: add the seam partials per node (fixed order -> reproducible) and write dst
+    // second pass: add the seam partials per node (fixed order -> reproducible).
+    // One wave per (tile, plane): lane = low-rim entry, so the south row (contiguous in dst and
+    // in the slabs) is accessed coalesced and all index arithmetic but the lane part is scalar.
     template <int DEG, int NC>
-    __device__ __forceinline__ void fixup_rim(const Q2Args &A, long t, double *dst,
+    __device__ __forceinline__ void fixup_rim(const Q2Args &A, const long bt, const int K, double *dst,
                                               const double *slab, const double *zslab,
                                               const int nn_x, const int nn_y, const int nn_z,
                                               const uint32_t con)
     {
-      // one thread per (tile, plane K, LOW-rim node, component): the tile owns the node, its own
-      // partial sum is already in dst; add the partial sums of the west / south / south-west
-      // tiles (their high rim) and, on a chunk boundary plane, of the chunk below
-      constexpr int TN = DEG * TX + 1, RIM = 4 * (TN - 1), LO = 2 * TN - 1;
-      const int     comp = (int)(t % NC);
-      t /= NC;
-      const int s = (int)(t % LO);
-      t /= LO;
-      const int  K  = (int)(t % nn_z);
-      const long bt = t / nn_z;
-      const int  bx = (int)(bt % A.tiles_x), by = (int)(bt / A.tiles_x);
-      const int  i = s < TN ? s : 0, j = s < TN ? 0 : s - TN + 1; // south row, then west column
-      const int  I = DEG * TX * bx + i, J = DEG * TY * by + j;
-      if (I >= nn_x || J >= nn_y)
-        return;
-      const bool seam_x = i == 0 && I > 0, seam_y = j == 0 && J > 0;
-      if (!(seam_x || seam_y))
-        return;
-      // a node that is on this tile's HIGH rim in the other direction belongs to another owner
-      if ((i == TN - 1 && I < nn_x - 1) || (j == TN - 1 && J < nn_y - 1))
-        return;
-      if (on_constrained_face(I, J, K, nn_x, nn_y, nn_z, con, NC == 1 ? 1 : 3, comp))
-        return; // dst = +-src already written by every sharer
-      const int  ppc  = DEG * A.LZ + 1;
-      const int  c_hi = min(K / (DEG * A.LZ), A.n_chunks - 1);
-      const int  lp   = K - DEG * A.LZ * c_hi;
-      const bool zb   = lp == 0 && c_hi > 0; // K is the top plane of the chunk below as well
-      double     sum  = 0.;
-      for (int dy = 0; dy <= (seam_y ? 1 : 0); ++dy)
-        for (int dx = 0; dx <= (seam_x ? 1 : 0); ++dx)
-          {
-            if (dx == 0 && dy == 0)
-              continue;
-            const long tb = (long)(by - dy) * A.tiles_x + bx - dx;
-            const int  r  = rim_index<TN>(i + (TN - 1) * dx, j + (TN - 1) * dy);
-            sum += slab[(((tb * A.n_chunks + c_hi) * ppc + lp) * RIM + r) * NC + comp];
-            if (zb)
-              sum += slab[(((tb * A.n_chunks + c_hi - 1) * ppc + DEG * A.LZ) * RIM + r) * NC + comp];
-          }
-      if (zb) // this tile's own partial of the chunk below
-        sum += zslab[((bt * A.n_chunks + c_hi - 1) * (TN * TN) + j * TN + i) * NC + comp];
-      dst[((long)(K * (long)nn_y + J) * nn_x + I) * NC + comp] += sum;
+      // the tile owns its LOW-rim nodes; its own partial sum is already in dst; add the partial
+      // sums of the west / south / south-west tiles (their high rim) and, on a chunk boundary
+      // plane, of the chunk below
+      constexpr int TN = DEG * TX + 1, RIM = 4 * (TN - 1), NE = (2 * TN - 1) * NC;
+      const int     bx = (int)(bt % A.tiles_x), by = (int)(bt / A.tiles_x);
+      const int     ppc  = DEG * A.LZ + 1;
+      const int     c_hi = min(K / (DEG * A.LZ), A.n_chunks - 1);
+      const int     lp   = K - DEG * A.LZ * c_hi;
+      const bool    zb   = lp == 0 && c_hi > 0; // K is the top plane of the chunk below as well
+      for (int e = threadIdx.x; e < NE; e += 64)
+        {
+          const int comp = e % NC, s = e / NC;
+          const int i = s < TN ? s : 0, j = s < TN ? 0 : s - TN + 1; // south row, then west column
+          const int I = DEG * TX * bx + i, J = DEG * TY * by + j;
+          if (I >= nn_x || J >= nn_y)
+            continue;
+          const bool seam_x = i == 0 && I > 0, seam_y = j == 0 && J > 0;
+          if (!(seam_x || seam_y))
+            continue;
+          // a node that is on this tile's HIGH rim in the other direction belongs to another owner
+          if ((i == TN - 1 && I < nn_x - 1) || (j == TN - 1 && J < nn_y - 1))
+            continue;
+          if (on_constrained_face(I, J, K, nn_x, nn_y, nn_z, con, NC == 1 ? 1 : 3, comp))
+            continue; // dst = +-src already written by every sharer
+          double sum = 0.;
+          for (int dy = 0; dy <= (seam_y ? 1 : 0); ++dy)
+            for (int dx = 0; dx <= (seam_x ? 1 : 0); ++dx)
+              {
+                if (dx == 0 && dy == 0)
+                  continue;
+                const long tb = (long)(by - dy) * A.tiles_x + bx - dx;
+                const int  r  = rim_index<TN>(i + (TN - 1) * dx, j + (TN - 1) * dy);
+                sum += slab[(((tb * A.n_chunks + c_hi) * ppc + lp) * RIM + r) * NC + comp];
+                if (zb)
+                  sum += slab[(((tb * A.n_chunks + c_hi - 1) * ppc + DEG * A.LZ) * RIM + r) * NC + comp];
+              }
+          if (zb) // this tile's own partial of the chunk below
+            sum += zslab[((bt * A.n_chunks + c_hi - 1) * (TN * TN) + j * TN + i) * NC + comp];
+          dst[((long)(K * (long)nn_y + J) * nn_x + I) * NC + comp] += sum;
+        }
     }
 
+    // interior (non-seam) nodes of a chunk-boundary plane: dst (bottom partial of the upper chunk)
+    // += top partial of the lower chunk
     template <int DEG, int NC>
-    __device__ __forceinline__ void fixup_zplane(const Q2Args &A, long t, double *dst,
+    __device__ __forceinline__ void fixup_zplane(const Q2Args &A, const long bt, const int m, double *dst,
                                                  const double *zslab, const int nn_x, const int nn_y,
                                                  const int nn_z, const uint32_t con)
     {
       constexpr int TN = DEG * TX + 1;
-      const int     e  = (int)(t % (TN * TN * NC));
-      t /= TN * TN * NC;
-      const int  m  = (int)(t % (A.n_chunks - 1)) + 1;
-      const long bt = t / (A.n_chunks - 1);
-      const int  bx = (int)(bt % A.tiles_x), by = (int)(bt / A.tiles_x);
-      const int  comp = e % NC, n = e / NC, i = n % TN, j = n / TN;
-      const int  I = DEG * TX * bx + i, J = DEG * TY * by + j, K = DEG * A.LZ * m;
-      if (I >= nn_x || J >= nn_y)
-        return;
-      const bool seam = (i == 0 && I > 0) || (i == TN - 1 && I < nn_x - 1) || (j == 0 && J > 0) ||
-                        (j == TN - 1 && J < nn_y - 1);
-      if (seam || on_constrained_face(I, J, K, nn_x, nn_y, nn_z, con, NC == 1 ? 1 : 3, comp))
-        return;
-      dst[((long)(K * (long)nn_y + J) * nn_x + I) * NC + comp] += zslab[(bt * A.n_chunks + m - 1) * (TN * TN * NC) + e];
+      const int     bx = (int)(bt % A.tiles_x), by = (int)(bt / A.tiles_x);
+      const int     K  = DEG * A.LZ * m;
+      for (int e = threadIdx.x; e < TN * TN * NC; e += 64)
+        {
+          const int comp = e % NC, n = e / NC, i = n % TN, j = n / TN;
+          const int I = DEG * TX * bx + i, J = DEG * TY * by + j;
+          if (I >= nn_x || J >= nn_y)
+            continue;
+          const bool seam = (i == 0 && I > 0) || (i == TN - 1 && I < nn_x - 1) || (j == 0 && J > 0) ||
+                            (j == TN - 1 && J < nn_y - 1);
+          if (seam || on_constrained_face(I, J, K, nn_x, nn_y, nn_z, con, NC == 1 ? 1 : 3, comp))
+            continue;
+          dst[((long)(K * (long)nn_y + J) * nn_x + I) * NC + comp] += zslab[(bt * A.n_chunks + m - 1) * (TN * TN * NC) + e];
+        }
     }
 
-    __global__ __launch_bounds__(256) void q2_seam_fixup_kernel(const Q2Args A, const long n1,
-                                                                const long n2, const long n3,
-                                                                const long n4)
+    // blocks [0,n1): velocity rim (tile, K); [n1,n1+n2): velocity z-planes (tile, m);
+    // then the same two ranges for the pressure
+    __global__ __launch_bounds__(64) void q2_seam_fixup_kernel(const Q2Args A, const long n1, const long n2,
+                                                               const long n3, const long n4)
     {
-      for (long t = blockIdx.x * 256L + threadIdx.x; t < n1 + n2 + n3 + n4; t += (long)gridDim.x * 256)
+      for (long b = blockIdx.x; b < n1 + n2 + n3 + n4; b += gridDim.x)
         {
-          if (t < n1)
-            fixup_rim<2, 3>(A, t, A.dst_u, A.slab_u, A.zslab_u, A.nnx, A.nny, A.nnz, A.con_u);
-          else if (t < n1 + n2)
-            fixup_zplane<2, 3>(A, t - n1, A.dst_u, A.zslab_u, A.nnx, A.nny, A.nnz, A.con_u);
-          else if (t < n1 + n2 + n3)
-            fixup_rim<1, 1>(A, t - n1 - n2, A.dst_p, A.slab_p, A.zslab_p, A.npx, A.npy, A.npz, A.con_p);
+          if (b < n1)
+            fixup_rim<2, 3>(A, b / A.nnz, (int)(b % A.nnz), A.dst_u, A.slab_u, A.zslab_u, A.nnx, A.nny, A.nnz, A.con_u);
+          else if (b < n1 + n2)
+            fixup_zplane<2, 3>(A, (b - n1) / (A.n_chunks - 1), (int)((b - n1) % (A.n_chunks - 1)) + 1, A.dst_u,
+                               A.zslab_u, A.nnx, A.nny, A.nnz, A.con_u);
+          else if (b < n1 + n2 + n3)
+            fixup_rim<1, 1>(A, (b - n1 - n2) / A.npz, (int)((b - n1 - n2) % A.npz), A.dst_p, A.slab_p, A.zslab_p,
+                            A.npx, A.npy, A.npz, A.con_p);
           else
-            fixup_zplane<1, 1>(A, t - n1 - n2 - n3, A.dst_p, A.zslab_p, A.npx, A.npy, A.npz, A.con_p);
+            fixup_zplane<1, 1>(A, (b - n1 - n2 - n3) / (A.n_chunks - 1), (int)((b - n1 - n2 - n3) % (A.n_chunks - 1)) + 1,
+                               A.dst_p, A.zslab_p, A.npx, A.npy, A.npz, A.con_p);
         }
     }
 
@@ -1403,13 +1409,12 @@ namespace adaflo_hip
     {
       const long tiles = (long)A.tiles_x * A.tiles_y;
       const bool fix_p = with_p && A.integrate_p;
-      const long n1 = tiles * A.nnz * (2 * PNX - 1) * 3, n2 = tiles * (A.n_chunks - 1) * UPLANE;
-      const long n3 = fix_p ? tiles * A.npz * (2 * QNX - 1) : 0, n4 = fix_p ? tiles * (A.n_chunks - 1) * PPLANE : 0;
-      long       nb = (n1 + n2 + n3 + n4 + 255) / 256;
-      if (nb > 256 * 64)
-        nb = 256 * 64;
-      hipLaunchKernelGGL(q2_seam_fixup_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, A, n1,
-                         n2, n3, n4);
+      const long n1 = tiles * A.nnz, n2 = tiles * (A.n_chunks - 1);
+      const long n3 = fix_p ? tiles * A.npz : 0, n4 = fix_p ? tiles * (A.n_chunks - 1) : 0;
+      long       nb = n1 + n2 + n3 + n4;
+      if (nb > 256 * 512)
+        nb = 256 * 512;
+      hipLaunchKernelGGL(q2_seam_fixup_kernel, dim3((unsigned)nb), dim3(64), 0, ctx->stream, A, n1, n2, n3, n4);
     }
     return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
   }
