@@ -38,6 +38,7 @@ SIGNATURES = {
     "adaflo_last_error": (C.c_char_p, [_CTX]),
     "adaflo_synchronize": (C.c_int, [_CTX]),
     "adaflo_stream": (C.c_void_p, [_CTX]),
+    "adaflo_set_stream": (C.c_int, [_CTX, C.c_void_p]),
     "adaflo_n_cells": (C.c_int64, [_CTX]),
     "adaflo_n_dofs_u": (C.c_int64, [_CTX]),
     "adaflo_n_dofs_p": (C.c_int64, [_CTX]),

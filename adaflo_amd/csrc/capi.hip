@@ -273,6 +273,17 @@ int adaflo_synchronize(adaflo_ctx *ctx)
   return 0;
 }
 
+int adaflo_set_stream(adaflo_ctx *ctx, void *stream)
+{
+  CHECK_CTX(ctx);
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->own_stream)
+    (void)hipStreamDestroy(ctx->stream);
+  ctx->own_stream = false;
+  ctx->stream     = static_cast<hipStream_t>(stream); // NULL = the legacy default stream
+  return 0;
+}
+
 void *adaflo_stream(adaflo_ctx *ctx)
 {
   return ctx ? ctx->stream : nullptr;

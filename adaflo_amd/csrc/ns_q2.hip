@@ -384,7 +384,7 @@ namespace adaflo_hip
       // velocity lanes: local (li,lj) in {0,1}^2, plus li = 2 / lj = 2 for the last valid cell of
       // the tile in x / y; pressure lane: (0,0) plus li = 1 / lj = 1 likewise.  Bit li + 3*lj.
       const bool valid = cxl < tcx && cyl < tcy;
-      const bool lastx = cxl == tcx - 1, lasty = cyl == tcy - 1;
+      const bool lastx = valid && cxl == tcx - 1, lasty = valid && cyl == tcy - 1; // valid cells only
       const bool hasW = cxl > 0, hasS = cyl > 0;
       unsigned flags; // bits 0-8 owned, 9-17 constrained, 18-26 seam; m_zero separately (gather)
       unsigned m_zero = 0;
@@ -821,7 +821,7 @@ namespace adaflo_hip
           const int  cxl = cq_e & 7, cyl = 2 * wave + (cq_e >> 3), cell = cyl * TX + cxl;
           const bool is_p = d == 3;
           const bool valid = cxl < tcx && cyl < tcy;
-          const bool lastx = cxl == tcx - 1, lasty = cyl == tcy - 1;
+          const bool lastx = valid && cxl == tcx - 1, lasty = valid && cyl == tcy - 1; // valid cells only
           const bool hasW = cxl > 0, hasS = cyl > 0;
           if (!is_p)
             {

@@ -26,13 +26,15 @@ class LevelSetOperators:
             d.ncell[i], d.h[i], d.origin[i] = mesh.ncell[i], mesh.h[i], mesh.lower[i]
         d.velocity_degree, d.ls_degree = velocity_degree, ls_degree
         d.ls_constrained = sum(1 << f for f in constrained_faces)
-        d.device, d.stream = device, stream
+        d.device, d.stream = device, None
         ctx = C.c_void_p()
         code = self._lib.adaflo_ctx_create(C.byref(d), C.byref(ctx))
         if code != 0:
             raise _lib.AdafloError("adaflo_ctx_create failed (%d): %s" % (
                 code, self._lib.adaflo_last_error(None).decode()))
         self._ctx = ctx
+        if stream is not None:
+            _lib.check(ctx, self._lib.adaflo_set_stream(ctx, stream or None))
         self.n_dofs = self._lib.adaflo_n_dofs_ls(ctx)
         self.n_q = self._lib.adaflo_n_q_points_ls(ctx)
         self.n_cells = self._lib.adaflo_n_cells(ctx)

@@ -63,7 +63,8 @@ class NavierStokesMatrix:
         d.pressure_constrained = face_mask(constrained_faces_p, 1)
         d.ls_constrained = 0
         d.device = device
-        d.stream = stream
+        d.stream = None
+        self._stream = stream       # None: engine-owned stream; int (0 = default stream): caller's
         self.time_stepping = None
 
     # -- lifetime -----------------------------------------------------------------------------
@@ -77,6 +78,8 @@ class NavierStokesMatrix:
             raise _lib.AdafloError("adaflo_ctx_create failed (%d): %s" % (
                 code, self._lib.adaflo_last_error(None).decode()))
         self._ctx = ctx
+        if self._stream is not None:
+            _lib.check(ctx, self._lib.adaflo_set_stream(ctx, self._stream or None))
         self.time_stepping = time_stepping
         self.update_parameters()
 

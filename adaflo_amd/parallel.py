@@ -171,7 +171,12 @@ class HaloExchange:
                 for o, nb in send_list:
                     a, n = seg_send[(f, o)]
                     sbuf[a:a + n] = w[_region(o, self.part.nodes(self.fields[f][0]))].reshape(-1)
-        # --- messages: one per (neighbour, field)
+        # --- messages: one per (neighbour, field).  With a gloo group (functional tests of the
+        # multi-GPU path on a single GPU) the packed buffers are staged through host memory.
+        stage = vecs[0].is_cuda and dist.get_backend(self.group) == "gloo"
+        if stage:
+            sbuf_d, rbuf_d = sbuf, rbuf
+            sbuf, rbuf = sbuf_d.cpu(), torch.empty(rbuf_d.shape, dtype=dtype)
         ops = []
         for o, nb in send_list:
             for f in range(len(self.fields)):
@@ -184,6 +189,9 @@ class HaloExchange:
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+        if stage:
+            rbuf_d.copy_(rbuf)
+            sbuf, rbuf = sbuf_d, rbuf_d
         # --- unpack: faces first, corners last (in copy mode the lowest sharer wins)
         if self.native is not None and vecs[0].is_cuda:
             for f, v in enumerate(vecs):
@@ -248,6 +256,17 @@ class HaloExchange:
         return m.reshape(-1)
 
 
+def _all_reduce_sum(t, group):
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        c = t.cpu()
+        dist.all_reduce(c, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
 class DistributedNavierStokesMatrix:
     """NavierStokesMatrix over a brick partition: local HIP engine + RCCL halo exchange."""
 
@@ -260,6 +279,11 @@ class DistributedNavierStokesMatrix:
         self.parameters = parameters
         k = parameters.velocity_degree
         if local is None:
+            if stream is None:
+                # the exchange mixes engine kernels with torch ops on the same tensors: run the
+                # engine on torch's current stream so that everything is ordered
+                import torch
+                stream = torch.cuda.current_stream(torch.device("cuda", device)).cuda_stream
             mesh = BrickMesh(part.cells, part.lower, part.upper)
             local = NavierStokesMatrix(parameters, mesh, dirichlet_faces_u=part.physical_faces(),
                                        constrained_faces_p=(), device=device, stream=stream)
@@ -289,8 +313,7 @@ class DistributedNavierStokesMatrix:
         u_dummy = self.local.new_u_tensor()
         self.halo.compress_add([u_dummy, w])
         self._w_owned = w * self.halo.owned_mask(1, device=w.device)
-        s = self._w_owned.sum()
-        dist.all_reduce(s, group=self.group)
+        s = _all_reduce_sum(self._w_owned.sum().reshape(1), self.group)
         self._inv = 1.0 / s                       # device scalar, modes == 1 everywhere
 
     def make_consistent(self, vec):
@@ -311,6 +334,5 @@ class DistributedNavierStokesMatrix:
         self.halo.compress_add(tdst)                        # dst.compress(add)
         self.local.apply_constrained_rows(dst, src)         # rows on boundary x interface
         if self.pressure_average_fix and self.local.projection_active():
-            s = (self._w_owned * tdst[1]).sum()
-            dist.all_reduce(s, group=self.group)
+            s = _all_reduce_sum((self._w_owned * tdst[1]).sum().reshape(1), self.group)
             tdst[1].sub_(s * self._inv)

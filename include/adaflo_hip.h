@@ -114,6 +114,9 @@ int         adaflo_ctx_destroy(adaflo_ctx *ctx);              /* NavierStokesMat
 const char *adaflo_last_error(const adaflo_ctx *ctx);         /* ctx may be NULL: last create error */
 int         adaflo_synchronize(adaflo_ctx *ctx);
 void       *adaflo_stream(adaflo_ctx *ctx);
+/* run all further work of the context on the caller's stream; NULL selects the legacy default
+ * stream (which is what torch uses as its current stream unless told otherwise)           */
+int         adaflo_set_stream(adaflo_ctx *ctx, void *stream);
 
 int64_t adaflo_n_cells(const adaflo_ctx *ctx);
 int64_t adaflo_n_dofs_u(const adaflo_ctx *ctx);               /* NavierStokesMatrix::n_dofs_u */

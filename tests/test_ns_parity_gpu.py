@@ -165,7 +165,7 @@ def test_matvec_statistics_and_errors():
 
 
 # ----------------------------------------------------------------------------- Q2/Q1 sweep kernel
-@pytest.mark.parametrize("ncell", [(8, 8, 4), (5, 3, 2), (16, 8, 9), (9, 17, 5), (24, 16, 20)])
+@pytest.mark.parametrize("ncell", [(8, 8, 4), (5, 3, 2), (16, 8, 9), (9, 17, 5), (24, 16, 20), (16, 10, 6), (10, 16, 7), (17, 9, 33)])
 def test_vmult_q2_kernel_newton(ncell):
     case = Case(ncell, k=2, upper=(1.0, 0.5, 2.0))
     eu, ep = run_vmult(case, variant=1)
@@ -251,3 +251,16 @@ def test_halo_pack_unpack_kernel_matches_slicing():
     for i in faces:
         expect[parallel._region(offs[i], nn)] = v4[parallel._region(offs[i], nn)]
     assert np.array_equal(dz.numpy(), expect.reshape(-1))
+
+
+def test_vmult_q2_kernel_random_bricks():
+    """many brick shapes (partial tiles in x / y, short and ragged z-chunks, random Dirichlet faces)"""
+    rng = np.random.default_rng(2026)
+    for trial in range(14):
+        ncell = tuple(int(x) for x in rng.integers(1, 21, 3))
+        faces_u = [f for f in range(6) if rng.random() < 0.6]
+        faces_p = [f for f in range(6) if rng.random() < 0.2]
+        case = Case(ncell, k=2, upper=(1.0, 0.7, 1.3), faces_u=faces_u, faces_p=faces_p,
+                    pressure_average_fix=bool(trial % 2), seed=trial)
+        eu, ep = run_vmult(case, variant=1)
+        assert eu < TOL and ep < TOL, (ncell, faces_u, faces_p, eu, ep)
