@@ -114,12 +114,19 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP engine)")
+    # functional dry run of the N > 1 path on a single GPU (not a measurement):
+    #   ADAFLO_BENCH_BACKEND=gloo ADAFLO_BENCH_SINGLE_DEVICE=1 torchrun --nproc-per-node 2 bench.py --gpus 2 --cells 32
+    backend = os.environ.get("ADAFLO_BENCH_BACKEND", "nccl")
+    if os.environ.get("ADAFLO_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import adaflo_amd
     from adaflo_amd import build as _build
@@ -136,7 +143,7 @@ def main():
     grid = parallel.brick_grid(world)
     part = parallel.BrickPartition(grid, rank, [nc] * 3, lower=[-1.0] * 3,
                                    upper=[-1.0 + 2.0 * g for g in grid] if world > 1 else [1.0] * 3)
-    stream = torch.cuda.current_stream(device).cuda_stream
+    stream = torch.cuda.current_stream(device).cuda_stream   # 0 = the legacy default stream
     op = parallel.DistributedNavierStokesMatrix(fp, part, device=local_rank, stream=stream,
                                                 group=dist.group.WORLD if world > 1 else None)
     op.initialize(ts, True)
@@ -185,7 +192,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ksec, kcount = op.local.get_kernel_statistics()
