@@ -252,7 +252,8 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
   for (DeviceBuffer *b : {&ctx->lin, &ctx->rho, &ctx->mu, &ctx->damp, &ctx->lin_prec, &ctx->rho_prec,
                           &ctx->mu_prec, &ctx->damp_prec, &ctx->lin_q2, &ctx->lin_q2_prec,
                           &ctx->q2_slab_u, &ctx->q2_zslab_u, &ctx->q2_slab_p, &ctx->q2_zslab_p,
-                          &ctx->ls_convection, &ctx->ls_normal})
+                          &ctx->ls_convection, &ctx->ls_normal, &ctx->q1_convection, &ctx->q1_normal,
+                          &ctx->q1_slab, &ctx->q1_zslab})
     release(*b);
   for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch,
                     ctx->d_tab_ls, ctx->d_ls_diag})
@@ -596,6 +597,18 @@ int adaflo_ns_pressure_poisson_vmult(adaflo_ctx *ctx, double *dst_p, const doubl
   const double *rho = ctx->rho_prec.p ? ctx->rho_prec.p : ctx->rho.p;
   const bool    var = rho && ctx->ns.linearization != ADAFLO_PROJECTION; // :976-978
   const bool    full = var && ctx->ns.physical_type != ADAFLO_INCOMPRESSIBLE_STATIONARY;
+  if (ctx->variant == 1 && ctx->k == 2 && !var)
+    {
+      // constant coefficient on Q1: structured sweep kernel (:1002-1031)
+      const NSDev &P = ctx->ns;
+      const double c = P.physical_type == ADAFLO_INCOMPRESSIBLE_STATIONARY ?
+                         1. :
+                         1. / (P.weight * std::min(P.density, P.density + P.density_diff));
+      TRY(ctx,
+          launch_q1_sweep(ctx, 1, Q1_MASS_LAPLACE, 0., c, 0., ctx->brick.con_p, 1., nullptr, dst_p, src_p, nullptr),
+          "pressure kernel launch failed");
+      return 0;
+    }
   return scalar_op(ctx, dst_p, src_p, full ? SC_POISSON_VARIABLE : SC_POISSON_CELL, var ? rho : nullptr,
                    full, true);
 }
@@ -632,6 +645,18 @@ int adaflo_ns_pressure_mass_vmult(adaflo_ctx *ctx, double *dst_p, const double *
   if (!dst_p || !src_p)
     return fail(ctx, ADAFLO_EINVAL, "null vector");
   const double *mu = ctx->mu_prec.p ? ctx->mu_prec.p : ctx->mu.p;
+  if (ctx->variant == 1 && ctx->k == 2 && !mu)
+    {
+      // constant coefficient on Q1: structured sweep kernel (:1036-1071)
+      const NSDev &P = ctx->ns;
+      const double c = (P.linearization == ADAFLO_PROJECTION || P.physical_type == ADAFLO_INCOMPRESSIBLE_STATIONARY) ?
+                         1. :
+                         1. / (P.viscosity + P.tau_grad_div);
+      TRY(ctx,
+          launch_q1_sweep(ctx, 1, Q1_MASS_LAPLACE, c, 0., 0., ctx->brick.con_p, 1., nullptr, dst_p, src_p, nullptr),
+          "pressure kernel launch failed");
+      return 0;
+    }
   return scalar_op(ctx, dst_p, src_p, SC_MASS, mu, false, true);
 }
 
@@ -815,6 +840,7 @@ int adaflo_ls_set_evaluated_convection(adaflo_ctx *ctx, const double *u_q, int s
   CHECK_CTX(ctx);
   if (int e = ls_ready(ctx))
     return e;
+  ctx->q1_convection_valid = false;
   return set_q_array(ctx, ctx->ls_convection, u_q, src_on_device);
 }
 
@@ -829,6 +855,7 @@ int adaflo_ls_set_evaluated_normal(adaflo_ctx *ctx, const double *n_q, int src_o
   CHECK_CTX(ctx);
   if (int e = ls_ready(ctx))
     return e;
+  ctx->q1_normal_valid = false;
   return set_q_array(ctx, ctx->ls_normal, n_q, src_on_device);
 }
 
@@ -845,6 +872,57 @@ static int ls_vmult(adaflo_ctx *ctx, double *dst, const double *src, const int m
     return e;
   if (!dst || !src)
     return fail(ctx, ADAFLO_EINVAL, "null vector");
+  if (ctx->variant == 1)
+    {
+      // structured Q1 sweep kernel: FE_Q_iso_Q1(s) = trilinear elements on the refined grid
+      if (ctx->brick.con_ls && !ctx->d_ls_diag)
+        return fail(ctx, ADAFLO_ENOTINIT, "constrained rows need adaflo_ls_set_diagonal");
+      const LSDev &P     = ctx->ls;
+      const double hcell = std::max(ctx->desc.h[0], std::max(ctx->desc.h[1], ctx->desc.h[2]));
+      // level_set_okz_reinitialization.cc:65-67,:82-85; compute_normal.cc:107-110;
+      // compute_curvature.cc:112-118
+      const double dtau_inv  = std::max(0.95 / (1. / 9. * P.minimal_edge_length / ctx->s), 1. / (5. * P.time_step));
+      const double diffusion = std::max(P.epsilon_used, hcell / ctx->s);
+      const double b         = std::max(P.epsilon_used / P.epsilon, hcell / ctx->s);
+      int          q1mode = Q1_MASS_LAPLACE;
+      double       c_mass = 1., c_lap = 0.;
+      const double *state = nullptr;
+      switch (mode)
+        {
+          case 0:
+            q1mode = Q1_ADVECT;
+            if (!ctx->q1_convection_valid)
+              TRY(ctx, q1_convert_state(ctx, ctx->q1_convection, qstate), "state re-layout failed");
+            ctx->q1_convection_valid = true;
+            state                    = ctx->q1_convection.p;
+            break;
+          case 1:
+            q1mode = Q1_REINIT;
+            c_mass = dtau_inv;
+            c_lap  = diffusion;
+            if (!ctx->q1_normal_valid)
+              TRY(ctx, q1_convert_state(ctx, ctx->q1_normal, qstate), "state re-layout failed");
+            ctx->q1_normal_valid = true;
+            state                = ctx->q1_normal.p;
+            break;
+          case 2:
+            c_mass = dtau_inv;
+            c_lap  = diffusion;
+            break;
+          case 3:
+            c_lap = 4. * b * b;
+            break;
+          default:
+            c_lap = flag ? b * b : 0.;
+        }
+      for (int blk = 0; blk < nblocks; ++blk)
+        TRY(ctx,
+            launch_q1_sweep(ctx, ctx->s, q1mode, c_mass, c_lap, P.weight, ctx->brick.con_ls, 1.,
+                            ctx->d_ls_diag, dst + (size_t)blk * ctx->n_nodes_ls,
+                            src + (size_t)blk * ctx->n_nodes_ls, state),
+            "level-set kernel launch failed");
+      return 0;
+    }
   HIP_TRY(ctx, hipMemsetAsync(dst, 0, sizeof(double) * nblocks * ctx->n_nodes_ls, ctx->stream)); // dst = 0.
   TRY(ctx, launch_ls(ctx, 0, mode, flag, dst, src, nullptr, nullptr, nullptr, qstate, nblocks),
       "level-set kernel launch failed");
@@ -870,6 +948,7 @@ int adaflo_ls_advance_concentration_rhs(adaflo_ctx *ctx, double *dst, const doub
   if (!dst || !solution || !solution_old || !solution_old_old || !vel_solution)
     return fail(ctx, ADAFLO_EINVAL, "null vector");
   TRY(ctx, alloc(ctx, ctx->ls_convection, ls_q_count(ctx)), ctx->last_error);
+  ctx->q1_convection_valid = false;
   TRY(ctx,
       launch_ls(ctx, 2, 0, use_old_old, dst, solution, solution_old, solution_old_old, vel_solution,
                 ctx->ls_convection.p, 1),
@@ -899,6 +978,8 @@ int adaflo_ls_reinitialization_rhs(adaflo_ctx *ctx, double *dst, const double *s
       if (!first_reinit_step && !ctx->ls_normal.p)
         return fail(ctx, ADAFLO_ENOTINIT, "evaluated_normal not set");
       TRY(ctx, alloc(ctx, ctx->ls_normal, ls_q_count(ctx)), ctx->last_error);
+      if (first_reinit_step)
+        ctx->q1_normal_valid = false;
     }
   TRY(ctx,
       launch_ls(ctx, 1, 0 /*RHS_REINIT*/, (diffuse_only ? 1 : 0) | (first_reinit_step ? 2 : 0), dst,

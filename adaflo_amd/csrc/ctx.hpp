@@ -125,6 +125,9 @@ struct adaflo_ctx
   double                  *d_tab_ls = nullptr;  // [S D w] of FE_Q_iso_Q1(s) at QIterated(QGauss(2),s), then S of FE_Q(k)
   double                  *d_ls_diag = nullptr; // preconditioner.get_vector() for constrained rows
   adaflo_hip::DeviceBuffer ls_convection, ls_normal; // evaluated_convection / evaluated_normal [cell][3][q]
+  // structured Q1 sweep kernel (q1_sweep.hip): streaming copies of the two arrays, seam partial sums
+  adaflo_hip::DeviceBuffer q1_convection, q1_normal, q1_slab, q1_zslab;
+  bool                     q1_convection_valid = false, q1_normal_valid = false;
 
   // pressure constant mode (mode 0) data, source/navier_stokes_matrix.cc:117-168
   double *d_p_weights = nullptr, *d_p_modes = nullptr;

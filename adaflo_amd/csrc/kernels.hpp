@@ -85,6 +85,19 @@ namespace adaflo_hip
                 int ncomp_blocks);
   int launch_ls_constrained_rows(adaflo_ctx *ctx, double *dst, const double *src, int nblocks);
 
+  // structured Q1 sweep kernel (q1_sweep.hip): level-set operators on the s-times refined grid
+  // (sub = s) and the Q1 pressure mass / Poisson operators of the Q2/Q1 pair (sub = 1)
+  enum Q1Mode
+  {
+    Q1_MASS_LAPLACE = 0, // (w, c_mass v) + (grad w, c_lap grad v)
+    Q1_ADVECT       = 1, // (w, weight v + u . grad v)
+    Q1_REINIT       = 2  // (w, c_mass v) + (grad w, c_lap (n . grad v) n)
+  };
+  int q1_convert_state(adaflo_ctx *ctx, DeviceBuffer &out, const double *generic_dev);
+  int launch_q1_sweep(adaflo_ctx *ctx, int sub, int mode, double c_mass, double c_lap, double weight,
+                      uint32_t con, double con_sign, const double *diag, double *dst, const double *src,
+                      const double *state);
+
   // specialised 3D Q2/Q1 sweep kernel (ns_q2.hip)
   bool q2_supported(const adaflo_ctx *ctx);
   int  q2_prepare_state(adaflo_ctx *ctx);

@@ -1,0 +1,542 @@
+// q1_sweep.hip -- structured trilinear (Q1) operator kernel with 2x2x2 Gauss points.
+//
+// FE_Q_iso_Q1(s) with QIterated(QGauss<1>(2), s) IS a Q1 element with 2-point Gauss quadrature
+// on the s-times refined grid (source/level_set_base.cc:58-59, source/two_phase_base.cc:267-268),
+// and the Q1 pressure of the Q2/Q1 Taylor-Hood pair with quad_index_p = QGauss(2) is the same
+// thing on the cell grid (source/navier_stokes.cc:447-448).  One kernel therefore serves
+//   level set : advance_concentration_vmult, reinitialization_vmult, compute_normal_vmult,
+//               compute_curvature_vmult           (source/level_set_okz_*.cc)
+//   pressure  : pressure_mass_vmult, pressure_poisson_vmult with a cell-wise constant
+//               coefficient                       (source/navier_stokes_matrix.cc:1002-1071)
+//
+// MI355X mapping: a workgroup (256 lanes) owns a column of 16x16 sub-cells and sweeps LZ layers;
+// a LANE owns one sub-cell per layer and keeps everything (8 nodal values, 8 Gauss points) in
+// registers -- no LDS for the contractions.  Node planes are staged in LDS (each src entry is
+// fetched once per workgroup), the 8 local results are combined per owned node (lower-left node
+// of the sub-cell) through LDS with compile-time offsets, finished planes leave as row-contiguous
+// stores.  Nodes shared between workgroups: the low-rim tile owns the node, the others store
+// partial sums in slabs that a small second kernel adds (no atomics, bitwise reproducible).
+// The kernel is register-light, so occupancy (not a DMA ring) hides the latency of the
+// quadrature-point state stream, which is laid out [tile][layer][12][256 lanes][2 doubles].
+#include "kernels.hpp"
+
+namespace adaflo_hip
+{
+  namespace
+  {
+    constexpr int TS  = 16;           // sub-cells per tile edge
+    constexpr int TNQ = TS + 1;       // nodes per tile edge
+    constexpr int NTQ = TS * TS;      // threads
+    constexpr int RIMQ = 4 * TS;      // rim nodes of a tile plane
+    constexpr int QSTATE = 12 * NTQ * 2; // doubles of q-state per (tile, layer): 8 points x 3 comps per lane
+
+    struct Q1Args
+    {
+      int      nsx, nsy, nsz, nnx, nny, nnz, tiles_x, tiles_y, LZ, n_chunks, mode;
+      double   ih[3], jxw, ga, gb; // 1/h_sub, h0 h1 h2 / 8, N_0(g_0) = ga, N_1(g_0) = gb
+      double   c_mass, c_lap, weight;
+      uint32_t con;
+      double   con_sign;           // constrained rows: dst = (diag ? diag : con_sign) * src
+      const double *diag, *src;
+      double       *dst;
+      const double *state;
+      double       *slab, *zslab;
+    };
+
+    template <int TN>
+    __device__ __forceinline__ int rim_index_q(const int i, const int j)
+    {
+      if (j == 0)
+        return i;
+      if (j == TN - 1)
+        return TN + i;
+      if (i == 0)
+        return 2 * TN - 1 + j;
+      return 3 * TN - 3 + j;
+    }
+
+    template <int MODE>
+    __global__ __launch_bounds__(NTQ) void q1_sweep_kernel(const Q1Args A)
+    {
+      __shared__ double pl[2][TNQ * TNQ]; // node planes K, K+1 (ring)
+      __shared__ double pub[2][3][NTQ];   // published high faces: [plane lk][(1,0),(0,1),(1,1)][lane]
+
+      const int  tid = threadIdx.x;
+      const int  sx = tid % TS, sy = tid / TS;
+      const long nwg = (long)A.tiles_x * A.tiles_y * A.n_chunks;
+      const long wg  = xcd_remap(blockIdx.x, nwg);
+      const int  bz = (int)(wg % A.n_chunks), bt = (int)(wg / A.n_chunks);
+      const int  bx = bt % A.tiles_x, by = bt / A.tiles_x;
+      const int  cz0 = bz * A.LZ, nl = min(A.LZ, A.nsz - cz0);
+      const int  I0 = TS * bx, J0 = TS * by;
+      const int  tcx = min(TS, A.nsx - I0), tcy = min(TS, A.nsy - J0);
+      const bool valid = sx < tcx && sy < tcy;
+      const bool lastx = valid && sx == tcx - 1, lasty = valid && sy == tcy - 1;
+      const bool hasW = sx > 0, hasS = sy > 0;
+      const size_t wgs = (size_t)bt * A.n_chunks + bz;
+
+      // per-lane flags of the up to 4 owned nodes (li,lj) in {0,1}^2, bit li + 2*lj
+      unsigned own = 0, con = 0, seam = 0, zero = 0;
+      for (int lj = 0; lj < 2; ++lj)
+        for (int li = 0; li < 2; ++li)
+          {
+            const int  bit = li + 2 * lj, I = I0 + sx + li, J = J0 + sy + lj;
+            const bool c   = (I == 0 && (A.con >> 0 & 1)) || (I == A.nnx - 1 && (A.con >> 1 & 1)) ||
+                           (J == 0 && (A.con >> 2 & 1)) || (J == A.nny - 1 && (A.con >> 3 & 1));
+            if (c)
+              zero |= 1u << bit;
+            if (!(valid && (li == 0 || lastx) && (lj == 0 || lasty)))
+              continue;
+            own |= 1u << bit;
+            if (c)
+              con |= 1u << bit;
+            // high-rim node shared with another workgroup -> slab (the low-rim tile owns it)
+            if ((sx + li == TS && I < A.nnx - 1) || (sy + lj == TS && J < A.nny - 1))
+              seam |= 1u << bit;
+          }
+      const bool     conz_lo = A.con >> 4 & 1, conz_hi = A.con >> 5 & 1;
+      const unsigned lane_g  = (unsigned)((J0 + sy) * A.nnx + I0 + sx);
+
+      auto load_plane = [&](const int K, double *p) {
+        for (int e = tid; e < TNQ * TNQ; e += NTQ)
+          {
+            const int i = e % TNQ, j = e / TNQ, I = I0 + i, J = J0 + j;
+            p[e] = (I < A.nnx && J < A.nny && K < A.nnz) ? A.src[((size_t)K * A.nny + J) * A.nnx + I] : 0.;
+          }
+      };
+      // store of one owned node value (constrained rows, slabs, plain stores)
+      auto emit = [&](const int bit, const int li, const int lj, const int K, const int lp, double v,
+                      const bool zcon, const bool ztop) {
+        if (!(own >> bit & 1u))
+          return;
+        const size_t idx = (size_t)K * A.nny * A.nnx + lane_g + (unsigned)(lj * A.nnx + li);
+        if ((con >> bit & 1u) || zcon)
+          A.dst[idx] = (A.diag ? A.diag[idx] : A.con_sign) * A.src[idx];
+        else if (seam >> bit & 1u)
+          A.slab[(wgs * (A.LZ + 1) + lp) * RIMQ + rim_index_q<TNQ>(sx + li, sy + lj)] = v;
+        else if (ztop)
+          A.zslab[wgs * (TNQ * TNQ) + (sy + lj) * TNQ + sx + li] = v;
+        else
+          A.dst[idx] = v;
+      };
+
+      double carry[4] = {0., 0., 0., 0.}; // top-plane sums of the owned nodes, kept for the next layer
+      load_plane(cz0, pl[cz0 & 1]);
+      const double2 *state = reinterpret_cast<const double2 *>(A.state);
+
+      for (int layer = 0; layer < nl; ++layer)
+        {
+          const int cz = cz0 + layer;
+          load_plane(cz + 1, pl[(cz + 1) & 1]);
+          // quadrature-point state of this sub-cell: issued before the barrier, used after it
+          double2 st[12];
+          if (MODE != Q1_MASS_LAPLACE)
+            {
+              const double2 *sp = state + ((size_t)bt * A.nsz + cz) * (12 * NTQ) + tid;
+#pragma unroll
+              for (int c = 0; c < 12; ++c)
+                st[c] = sp[c * NTQ];
+            }
+          __syncthreads();
+
+          // ---- gather + read_dof_values (constrained -> 0) -----------------------------------
+          double u[2][2][2];
+#pragma unroll
+          for (int lk = 0; lk < 2; ++lk)
+#pragma unroll
+            for (int lj = 0; lj < 2; ++lj)
+#pragma unroll
+              for (int li = 0; li < 2; ++li)
+                {
+                  double v = pl[(cz + lk) & 1][(sy + lj) * TNQ + sx + li];
+                  const int K = cz + lk;
+                  if ((zero >> (li + 2 * lj) & 1u) || (K == 0 && conz_lo) || (K == A.nnz - 1 && conz_hi))
+                    v = 0.;
+                  u[lk][lj][li] = v;
+                }
+          // ---- evaluate at the 2x2x2 Gauss points (trilinear, sum factorised) -----------------
+          const double ga = A.ga, gb = A.gb;
+          double X[2][2][2], DX[2][2];
+#pragma unroll
+          for (int lk = 0; lk < 2; ++lk)
+#pragma unroll
+            for (int lj = 0; lj < 2; ++lj)
+              {
+                X[lk][lj][0] = ga * u[lk][lj][0] + gb * u[lk][lj][1];
+                X[lk][lj][1] = gb * u[lk][lj][0] + ga * u[lk][lj][1];
+                DX[lk][lj]   = (u[lk][lj][1] - u[lk][lj][0]) * A.ih[0];
+              }
+          double XY[2][2][2], DY[2][2], DXY[2][2];
+#pragma unroll
+          for (int lk = 0; lk < 2; ++lk)
+            {
+#pragma unroll
+              for (int qx = 0; qx < 2; ++qx)
+                {
+                  XY[lk][0][qx] = ga * X[lk][0][qx] + gb * X[lk][1][qx];
+                  XY[lk][1][qx] = gb * X[lk][0][qx] + ga * X[lk][1][qx];
+                  DY[lk][qx]    = (X[lk][1][qx] - X[lk][0][qx]) * A.ih[1];
+                }
+              DXY[lk][0] = ga * DX[lk][0] + gb * DX[lk][1];
+              DXY[lk][1] = gb * DX[lk][0] + ga * DX[lk][1];
+            }
+          // values val[qz][qy][qx]; gradients are constant along their own direction:
+          // gx[qz][qy], gy[qz][qx], gz[qy][qx]
+          double val[2][2][2], gx[2][2], gy[2][2], gz[2][2];
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              {
+                val[0][a][b] = ga * XY[0][a][b] + gb * XY[1][a][b];
+                val[1][a][b] = gb * XY[0][a][b] + ga * XY[1][a][b];
+                gz[a][b]     = (XY[1][a][b] - XY[0][a][b]) * A.ih[2];
+              }
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+            {
+              gx[0][a] = ga * DXY[0][a] + gb * DXY[1][a];
+              gx[1][a] = gb * DXY[0][a] + ga * DXY[1][a];
+              gy[0][a] = ga * DY[0][a] + gb * DY[1][a];
+              gy[1][a] = gb * DY[0][a] + ga * DY[1][a];
+            }
+          // ---- quadrature-point operation -------------------------------------------------------
+          double tv[2][2][2], t0[2][2][2], t1[2][2][2], t2[2][2][2];
+#pragma unroll
+          for (int qz = 0; qz < 2; ++qz)
+#pragma unroll
+            for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+              for (int qx = 0; qx < 2; ++qx)
+                {
+                  const double v = val[qz][qy][qx], g0 = gx[qz][qy], g1 = gy[qz][qx], g2 = gz[qy][qx];
+                  const int    q = qx + 2 * qy + 4 * qz;
+                  double       a = 0., b0 = 0., b1 = 0., b2 = 0.;
+                  if (MODE == Q1_MASS_LAPLACE)
+                    {
+                      a  = A.c_mass * v;
+                      b0 = A.c_lap * g0;
+                      b1 = A.c_lap * g1;
+                      b2 = A.c_lap * g2;
+                    }
+                  else
+                    {
+                      // state element 3q+e of this lane: double2 index (3q+e)/2, component (3q+e)&1
+                      const double s0 = (3 * q) & 1 ? st[(3 * q) / 2].y : st[(3 * q) / 2].x;
+                      const double s1 = (3 * q + 1) & 1 ? st[(3 * q + 1) / 2].y : st[(3 * q + 1) / 2].x;
+                      const double s2 = (3 * q + 2) & 1 ? st[(3 * q + 2) / 2].y : st[(3 * q + 2) / 2].x;
+                      if (MODE == Q1_ADVECT) // level_set_okz_advance_concentration.cc:244-249
+                        a = A.weight * v + s0 * g0 + s1 * g1 + s2 * g2;
+                      else // Q1_REINIT: level_set_okz_reinitialization.cc:88-95
+                        {
+                          const double ng = A.c_lap * (s0 * g0 + s1 * g1 + s2 * g2);
+                          a  = A.c_mass * v;
+                          b0 = ng * s0;
+                          b1 = ng * s1;
+                          b2 = ng * s2;
+                        }
+                    }
+                  tv[qz][qy][qx] = a * A.jxw;
+                  t0[qz][qy][qx] = b0 * (A.jxw * A.ih[0]);
+                  t1[qz][qy][qx] = b1 * (A.jxw * A.ih[1]);
+                  t2[qz][qy][qx] = b2 * (A.jxw * A.ih[2]);
+                }
+          // ---- integrate (transpose of the evaluation) -----------------------------------------
+          // z: Z[lk][qy][qx] = sum_qz N_lk(qz) tv + dN_lk t2
+          double r[2][2][2];
+          {
+            double Zv[2][2][2], Zx[2][2][2], Zy[2][2][2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int b = 0; b < 2; ++b)
+                {
+                  const double d2 = t2[0][a][b] + t2[1][a][b];
+                  Zv[0][a][b] = ga * tv[0][a][b] + gb * tv[1][a][b] - d2;
+                  Zv[1][a][b] = gb * tv[0][a][b] + ga * tv[1][a][b] + d2;
+                  Zx[0][a][b] = ga * t0[0][a][b] + gb * t0[1][a][b];
+                  Zx[1][a][b] = gb * t0[0][a][b] + ga * t0[1][a][b];
+                  Zy[0][a][b] = ga * t1[0][a][b] + gb * t1[1][a][b];
+                  Zy[1][a][b] = gb * t1[0][a][b] + ga * t1[1][a][b];
+                }
+            // y
+            double Yv[2][2][2], Yx[2][2][2];
+#pragma unroll
+            for (int lk = 0; lk < 2; ++lk)
+#pragma unroll
+              for (int b = 0; b < 2; ++b)
+                {
+                  const double d1 = Zy[lk][0][b] + Zy[lk][1][b];
+                  Yv[lk][0][b] = ga * Zv[lk][0][b] + gb * Zv[lk][1][b] - d1;
+                  Yv[lk][1][b] = gb * Zv[lk][0][b] + ga * Zv[lk][1][b] + d1;
+                  Yx[lk][0][b] = ga * Zx[lk][0][b] + gb * Zx[lk][1][b];
+                  Yx[lk][1][b] = gb * Zx[lk][0][b] + ga * Zx[lk][1][b];
+                }
+            // x
+#pragma unroll
+            for (int lk = 0; lk < 2; ++lk)
+#pragma unroll
+              for (int lj = 0; lj < 2; ++lj)
+                {
+                  const double d0 = Yx[lk][lj][0] + Yx[lk][lj][1];
+                  r[lk][lj][0] = ga * Yv[lk][lj][0] + gb * Yv[lk][lj][1] - d0;
+                  r[lk][lj][1] = gb * Yv[lk][lj][0] + ga * Yv[lk][lj][1] + d0;
+                }
+          }
+          // ---- publish the high faces, combine per owned node ---------------------------------
+#pragma unroll
+          for (int lk = 0; lk < 2; ++lk)
+            {
+              pub[lk][0][tid] = r[lk][0][1];
+              pub[lk][1][tid] = r[lk][1][0];
+              pub[lk][2][tid] = r[lk][1][1];
+            }
+          __syncthreads();
+#pragma unroll
+          for (int lk = 0; lk < 2; ++lk)
+            {
+              const double w0 = hasW ? pub[lk][0][tid - 1] : 0., w1 = hasW ? pub[lk][2][tid - 1] : 0.;
+              const double s0 = hasS ? pub[lk][1][tid - TS] : 0., s1 = hasS ? pub[lk][2][tid - TS] : 0.;
+              const double sw = (hasW && hasS) ? pub[lk][2][tid - TS - 1] : 0.;
+              double       nv[4];
+              nv[0] = r[lk][0][0] + w0 + s0 + sw;
+              nv[1] = r[lk][0][1] + s1; // (1,0): far column, last cells in x only
+              nv[2] = r[lk][1][0] + w1; // (0,1)
+              nv[3] = r[lk][1][1];
+              if (lk == 1)
+                {
+#pragma unroll
+                  for (int n = 0; n < 4; ++n)
+                    carry[n] = nv[n];
+                }
+              else
+                {
+                  const bool zcon = cz == 0 && conz_lo;
+#pragma unroll
+                  for (int n = 0; n < 4; ++n)
+                    emit(n, n & 1, n >> 1, cz, layer, nv[n] + carry[n], zcon, false);
+                }
+            }
+          __syncthreads();
+        }
+      // ---- top plane of the chunk ---------------------------------------------------------------
+      {
+        const int  cze  = cz0 + nl;
+        const bool ztop = cze < A.nsz, zcon = cze == A.nnz - 1 && conz_hi;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          emit(n, n & 1, n >> 1, cze, nl, carry[n], zcon, ztop);
+      }
+    }
+
+    // second pass: dst[low-rim node] += partial sums of the other sharers (and of the chunk below)
+    __global__ __launch_bounds__(64) void q1_fixup_kernel(const Q1Args A, const long n1, const long n2)
+    {
+      for (long b = blockIdx.x; b < n1 + n2; b += gridDim.x)
+        {
+          if (b < n1)
+            {
+              const long bt = b / A.nnz;
+              const int  K = (int)(b % A.nnz), bx = (int)(bt % A.tiles_x), by = (int)(bt / A.tiles_x);
+              const int  ppc = A.LZ + 1, c_hi = min(K / A.LZ, A.n_chunks - 1), lp = K - A.LZ * c_hi;
+              const bool zb = lp == 0 && c_hi > 0;
+              const bool zc = (K == 0 && (A.con >> 4 & 1)) || (K == A.nnz - 1 && (A.con >> 5 & 1));
+              for (int e = threadIdx.x; e < 2 * TNQ - 1; e += 64)
+                {
+                  const int i = e < TNQ ? e : 0, j = e < TNQ ? 0 : e - TNQ + 1;
+                  const int I = TS * bx + i, J = TS * by + j;
+                  if (I >= A.nnx || J >= A.nny)
+                    continue;
+                  const bool seam_x = i == 0 && I > 0, seam_y = j == 0 && J > 0;
+                  if (!(seam_x || seam_y) || (i == TS && I < A.nnx - 1) || (j == TS && J < A.nny - 1))
+                    continue;
+                  const bool c = zc || (I == 0 && (A.con >> 0 & 1)) || (I == A.nnx - 1 && (A.con >> 1 & 1)) ||
+                                 (J == 0 && (A.con >> 2 & 1)) || (J == A.nny - 1 && (A.con >> 3 & 1));
+                  if (c)
+                    continue;
+                  double sum = 0.;
+                  for (int dy = 0; dy <= (seam_y ? 1 : 0); ++dy)
+                    for (int dx = 0; dx <= (seam_x ? 1 : 0); ++dx)
+                      {
+                        if (dx == 0 && dy == 0)
+                          continue;
+                        const long tb = (long)(by - dy) * A.tiles_x + bx - dx;
+                        const int  r  = rim_index_q<TNQ>(i + TS * dx, j + TS * dy);
+                        sum += A.slab[((tb * A.n_chunks + c_hi) * ppc + lp) * RIMQ + r];
+                        if (zb)
+                          sum += A.slab[((tb * A.n_chunks + c_hi - 1) * ppc + A.LZ) * RIMQ + r];
+                      }
+                  if (zb)
+                    sum += A.zslab[(bt * A.n_chunks + c_hi - 1) * (TNQ * TNQ) + j * TNQ + i];
+                  A.dst[((size_t)K * A.nny + J) * A.nnx + I] += sum;
+                }
+            }
+          else
+            {
+              const long bb = b - n1, bt = bb / (A.n_chunks - 1);
+              const int  m = (int)(bb % (A.n_chunks - 1)) + 1, K = A.LZ * m;
+              const int  bx = (int)(bt % A.tiles_x), by = (int)(bt / A.tiles_x);
+              for (int e = threadIdx.x; e < TNQ * TNQ; e += 64)
+                {
+                  const int i = e % TNQ, j = e / TNQ, I = TS * bx + i, J = TS * by + j;
+                  if (I >= A.nnx || J >= A.nny)
+                    continue;
+                  const bool seam = (i == 0 && I > 0) || (i == TS && I < A.nnx - 1) || (j == 0 && J > 0) ||
+                                    (j == TS && J < A.nny - 1);
+                  const bool c = (I == 0 && (A.con >> 0 & 1)) || (I == A.nnx - 1 && (A.con >> 1 & 1)) ||
+                                 (J == 0 && (A.con >> 2 & 1)) || (J == A.nny - 1 && (A.con >> 3 & 1));
+                  if (seam || c)
+                    continue;
+                  A.dst[((size_t)K * A.nny + J) * A.nnx + I] += A.zslab[(bt * A.n_chunks + m - 1) * (TNQ * TNQ) + e];
+                }
+            }
+        }
+    }
+
+    // generic [cell][3][q (2s)^3] -> [tile][layer][12][256][2]: lane = sub-cell, 24 doubles
+    // (8 Gauss points x 3 components, index 3*q_local + e)
+    __global__ __launch_bounds__(256) void q1_convert_state_kernel(double *__restrict__ out,
+                                                                   const double *__restrict__ canon,
+                                                                   const int s, const int ncx,
+                                                                   const int ncy, const int nsx,
+                                                                   const int nsy, const int nsz,
+                                                                   const int tiles_x, const long total)
+    {
+      const int nq1 = 2 * s, nqc = nq1 * nq1 * nq1;
+      for (long o = blockIdx.x * 256L + threadIdx.x; o < total; o += (long)gridDim.x * 256)
+        {
+          const int j = (int)(o & 1);
+          long      r = o >> 1;
+          const int lane = (int)(r % NTQ);
+          r /= NTQ;
+          const int c2 = (int)(r % 12);
+          r /= 12;
+          const int  z  = (int)(r % nsz);
+          const long bt = r / nsz;
+          const int  bx = (int)(bt % tiles_x), by = (int)(bt / tiles_x);
+          const int  x = bx * TS + lane % TS, y = by * TS + lane / TS;
+          const int  k = 2 * c2 + j, ql = k / 3, e = k % 3; // local Gauss point, component
+          double     v = 0.;
+          if (x < nsx && y < nsy)
+            {
+              const int  cx = x / s, cy = y / s, cz = z / s;
+              const int  qx = 2 * (x % s) + (ql & 1), qy = 2 * (y % s) + (ql >> 1 & 1), qz = 2 * (z % s) + (ql >> 2);
+              const long cell = cx + (long)ncx * (cy + (long)ncy * cz);
+              v = canon[(cell * 3 + e) * nqc + qx + nq1 * (qy + nq1 * qz)];
+            }
+          out[o] = v;
+        }
+    }
+  } // namespace
+
+  // ---------------------------------------------------------------------------------------------
+  // host side
+  // ---------------------------------------------------------------------------------------------
+  int q1_convert_state(adaflo_ctx *ctx, DeviceBuffer &out, const double *canonical_dev)
+  {
+    const int    s = ctx->s, nsx = s * ctx->desc.ncell[0], nsy = s * ctx->desc.ncell[1], nsz = s * ctx->desc.ncell[2];
+    const int    tiles_x = (nsx + TS - 1) / TS, tiles_y = (nsy + TS - 1) / TS;
+    const size_t count   = (size_t)tiles_x * tiles_y * nsz * QSTATE;
+    if (out.count != count)
+      {
+        if (out.p)
+          (void)hipFree(out.p);
+        out.p     = nullptr;
+        out.count = 0;
+        if (hipMalloc(&out.p, count * sizeof(double)) != hipSuccess)
+          return ADAFLO_ENOMEM;
+        out.count = count;
+      }
+    long nb = (long)((count + 255) / 256);
+    if (nb > 256 * 64)
+      nb = 256 * 64;
+    hipLaunchKernelGGL(q1_convert_state_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, out.p,
+                       canonical_dev, s, ctx->desc.ncell[0], ctx->desc.ncell[1], nsx, nsy, nsz, tiles_x,
+                       (long)count);
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+
+  // sub = subdivisions of a cell (level set: s, pressure: 1); mode/coefficients as Q1Args
+  int launch_q1_sweep(adaflo_ctx *ctx, const int sub, const int mode, const double c_mass,
+                      const double c_lap, const double weight, const uint32_t con, const double con_sign,
+                      const double *diag, double *dst, const double *src, const double *state)
+  {
+    Q1Args A{};
+    A.nsx = sub * ctx->desc.ncell[0];
+    A.nsy = sub * ctx->desc.ncell[1];
+    A.nsz = sub * ctx->desc.ncell[2];
+    A.nnx = A.nsx + 1;
+    A.nny = A.nsy + 1;
+    A.nnz = A.nsz + 1;
+    A.tiles_x = (A.nsx + TS - 1) / TS;
+    A.tiles_y = (A.nsy + TS - 1) / TS;
+    {
+      const long tiles = (long)A.tiles_x * A.tiles_y;
+      int        lz    = 32;
+      while (lz > 4 && tiles * ((A.nsz + lz - 1) / lz) < 2048)
+        lz /= 2;
+      if (lz > A.nsz)
+        lz = A.nsz;
+      A.LZ       = lz;
+      A.n_chunks = (A.nsz + lz - 1) / lz;
+    }
+    A.mode = mode;
+    double det = 1.;
+    for (int d = 0; d < 3; ++d)
+      {
+        const double hs = ctx->desc.h[d] / sub;
+        A.ih[d]         = 1. / hs;
+        det *= hs;
+      }
+    A.jxw      = det / 8.;
+    A.gb       = 0.5 * (1. - 1. / std::sqrt(3.)); // first Gauss point of QGauss<1>(2) on [0,1]
+    A.ga       = 1. - A.gb;
+    A.c_mass   = c_mass;
+    A.c_lap    = c_lap;
+    A.weight   = weight;
+    A.con      = con;
+    A.con_sign = con_sign;
+    A.diag     = diag;
+    A.src      = src;
+    A.dst      = dst;
+    A.state    = state;
+    const size_t n_wg    = (size_t)A.tiles_x * A.tiles_y * A.n_chunks;
+    const size_t need[2] = {n_wg * (A.LZ + 1) * RIMQ, n_wg * TNQ * TNQ};
+    DeviceBuffer *buf[2] = {&ctx->q1_slab, &ctx->q1_zslab};
+    for (int i = 0; i < 2; ++i)
+      if (buf[i]->count < need[i])
+        {
+          if (buf[i]->p)
+            (void)hipFree(buf[i]->p);
+          buf[i]->p     = nullptr;
+          buf[i]->count = 0;
+          if (hipMalloc(&buf[i]->p, need[i] * sizeof(double)) != hipSuccess)
+            return ADAFLO_ENOMEM;
+          buf[i]->count = need[i];
+        }
+    A.slab  = ctx->q1_slab.p;
+    A.zslab = ctx->q1_zslab.p;
+    const dim3 grid((unsigned)n_wg), block(NTQ);
+    hipEvent_t stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
+    switch (mode)
+      {
+        case Q1_MASS_LAPLACE:
+          hipLaunchKernelGGL((q1_sweep_kernel<Q1_MASS_LAPLACE>), grid, block, 0, ctx->stream, A);
+          break;
+        case Q1_ADVECT:
+          hipLaunchKernelGGL((q1_sweep_kernel<Q1_ADVECT>), grid, block, 0, ctx->stream, A);
+          break;
+        default:
+          hipLaunchKernelGGL((q1_sweep_kernel<Q1_REINIT>), grid, block, 0, ctx->stream, A);
+      }
+    if (stop)
+      (void)hipEventRecord(stop, ctx->stream);
+    ctx->kernel_timer.count++;
+    const long tiles = (long)A.tiles_x * A.tiles_y, n1 = tiles * A.nnz, n2 = tiles * (A.n_chunks - 1);
+    long       nb    = n1 + n2;
+    if (nb > 256 * 512)
+      nb = 256 * 512;
+    hipLaunchKernelGGL(q1_fixup_kernel, dim3((unsigned)nb), dim3(64), 0, ctx->stream, A, n1, n2);
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+} // namespace adaflo_hip

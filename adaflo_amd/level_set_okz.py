@@ -64,6 +64,11 @@ class LevelSetOperators:
                           weight_old_old, epsilon)
         _lib.check(self._ctx, self._lib.adaflo_ls_set_params(self._ctx, C.byref(p)))
 
+    def set_kernel_variant(self, variant):
+        """0: generic per-cell kernels, 1 (default): structured Q1 sweep kernel for the operator
+        applications (FE_Q_iso_Q1(s) = trilinear elements on the s-times refined grid)"""
+        _lib.check(self._ctx, self._lib.adaflo_set_kernel_variant(self._ctx, variant))
+
     def set_diagonal(self, diag):
         """DiagonalPreconditioner::get_vector() used on constrained rows"""
         _lib.check(self._ctx, self._lib.adaflo_ls_set_diagonal(self._ctx, diag.ptr))

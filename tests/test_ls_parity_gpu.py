@@ -38,9 +38,15 @@ class LSCase:
         return self.rng.uniform(-1, 1, self.mesh.n_cells * self.nq * 3)
 
 
-@pytest.mark.parametrize("s,ncell,faces", [(4, (2, 3, 2), ()), (2, (3, 3, 4), (0, 5)), (1, (4, 4, 4), ()), (3, (2, 2, 2), (2,))])
-def test_ls_operator_applications(s, ncell, faces):
+@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("s,ncell,faces", [(4, (2, 3, 2), ()), (2, (3, 3, 4), (0, 5)), (1, (4, 4, 4), ()),
+                                           (3, (2, 2, 2), (2,)), (4, (5, 9, 3), (1, 2, 4)),
+                                           (2, (9, 8, 20), (0, 1, 2, 3, 4, 5)), (1, (33, 17, 40), (3,))])
+def test_ls_operator_applications(s, ncell, faces, variant):
+    """variant 1: structured Q1 sweep kernel (multi-tile, partial tiles, z-chunks in the larger
+    cases); variant 0: generic per-cell kernels"""
     c = LSCase(ncell, s, faces=faces)
+    c.ops.set_kernel_variant(variant)
     src = c.rand()
     d = c.ops.vector(np.full(c.nn, 9.0))
     # advection

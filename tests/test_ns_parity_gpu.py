@@ -100,10 +100,14 @@ def test_velocity_vmult_and_fixed_point():
     assert rel_l2(dst.numpy(), ref) < TOL
 
 
-@pytest.mark.parametrize("k", [2, 3])
-def test_scalar_sub_blocks(k):
-    case = Case((3, 2, 4), k=k, faces_p=[0], density_diff=0.3, upper=(1.0, 0.7, 1.5))
+@pytest.mark.parametrize("k,ncell,variant", [(2, (3, 2, 4), 0), (3, (3, 2, 4), 0), (2, (3, 2, 4), 1),
+                                             (2, (18, 17, 35), 1)])
+def test_scalar_sub_blocks(k, ncell, variant):
+    """variant 1 with k = 2: constant-coefficient pressure mass / Poisson run on the structured
+    Q1 sweep kernel, everything else on the generic kernels"""
+    case = Case(ncell, k=k, faces_p=[0], density_diff=0.3, upper=(1.0, 0.7, 1.5))
     op = case.engine()
+    op.set_kernel_variant(variant)
     src_u, src_p = case.random_u(), case.random_p()
     rho, mu, damp = case.random_coefficients()
     su, sp = op.initialize_u_vector(src_u), op.initialize_p_vector(src_p)
