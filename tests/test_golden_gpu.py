@@ -1,0 +1,111 @@
+"""GPU tier: the HIP engine (through the C ABI) against the committed fixtures in tests/golden/
+(inputs + expected outputs; no oracle call in this file).  Tolerance: 1e-12 relative L2."""
+import numpy as np
+import pytest
+
+import adaflo_amd
+from adaflo_amd import level_set_okz as lso
+from common import BETA, LIN, PHYS, rel_l2
+from golden_util import LS_FIXTURES, NS_FIXTURES, FixedTimeStepping, load, prm_dict
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+NS_3D = [n for n in NS_FIXTURES if "_3d_" in n]
+
+
+@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("name", NS_3D)
+def test_ns_operators_match_fixture(name, variant):
+    d = load(name)
+    p = prm_dict(d)
+    k = int(d["k"])
+    fp = adaflo_amd.FlowParameters(
+        velocity_degree=k, physical_type=PHYS[p["physical_type"]], linearization=LIN[p["linearization"]],
+        formulation_convective_term=BETA[p["beta"]], viscosity=p["viscosity"], density=p["density"],
+        damping=-p["damping"], tau_grad_div=p["tau_grad_div"], density_diff=p["density_diff"])
+    mesh = adaflo_amd.BrickMesh([int(n) for n in d["ncell"]], tuple(d["lower"]), tuple(d["upper"]))
+    op = adaflo_amd.NavierStokesMatrix(fp, mesh, dirichlet_faces_u=range(6), constrained_faces_p=[0])
+    op.initialize(FixedTimeStepping(p), False)
+    op.set_kernel_variant(variant)
+    if "rho" in d:
+        op.set_coefficients(d["rho"], d["mu"], d["damp"])
+    if p["physical_type"] != 2:
+        op.set_linearization(d["lin"])
+    src, dst = op.block_vector(d["src_u"], d["src_p"]), op.block_vector()
+    op.vmult(dst, src)
+    du, dp = dst.numpy()
+    assert rel_l2(du, d["vmult_u"]) < TOL and rel_l2(dp, d["vmult_p"]) < TOL
+    du = op.initialize_u_vector()
+    op.velocity_vmult(du, src.block(0))
+    assert rel_l2(du.numpy(), d["velocity_vmult"]) < TOL
+    dp = op.initialize_p_vector(d["src_p"])
+    op.divergence_vmult_add(dp, src.block(0), False)
+    assert rel_l2(dp.numpy(), d["divergence_add"]) < TOL
+    if "pressure_poisson" in d:  # not for Stokes (density = 0, parameters.cc:477-478)
+        op.pressure_poisson_vmult(dp, src.block(1))
+        assert rel_l2(dp.numpy(), d["pressure_poisson"]) < TOL
+    op.pressure_mass_vmult(dp, src.block(1))
+    assert rel_l2(dp.numpy(), d["pressure_mass"]) < TOL
+    # residual last: it overwrites the stored linearisation
+    res = op.block_vector()
+    op.residual(res, src, None, op.block_vector(d["old_u"]), op.block_vector(d["oldold_u"]))
+    ru, rp = res.numpy()
+    # system_rhs = -F (navier_stokes_matrix.cc:292); the fixture stores the oracle's residual output
+    assert rel_l2(ru, d["residual_u"]) < TOL and rel_l2(rp, d["residual_p"]) < TOL
+    if d["residual_lin"].any():
+        ncomp = 12 if p["linearization"] == 0 else 4  # Picard / semi-implicit store (u, div u) only
+        got, ref = op.get_linearization().reshape(-1, 12), d["residual_lin"].reshape(-1, 12)
+        assert rel_l2(got[:, :ncomp], ref[:, :ncomp]) < TOL
+
+
+@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("name", LS_FIXTURES)
+def test_ls_operators_match_fixture(name, variant):
+    d = load(name)
+    s, k = int(d["s"]), int(d["k"])
+    eps_used, dt, weight, w_old, w_oo, epsilon = d["scalars"]
+    mesh = adaflo_amd.BrickMesh([int(n) for n in d["ncell"]], tuple(d["lower"]), tuple(d["upper"]))
+    ops = lso.LevelSetOperators(mesh, s, velocity_degree=k, constrained_faces=(0, 5))
+    ops.set_parameters(eps_used, dt, weight, w_old, w_oo, epsilon)
+    ops.set_diagonal(ops.vector(d["diag"]))
+    ops.set_kernel_variant(variant)
+    out = ops.vector()
+    adv = lso.LevelSetOKZSolverAdvanceConcentration(ops)
+    adv.evaluated_convection = d["vel_q"]
+    adv.advance_concentration_vmult(out, ops.vector(d["src"]))
+    assert rel_l2(out.numpy(), d["advect_vmult"]) < TOL
+    rei = lso.LevelSetOKZSolverReinitialization(ops)
+    rei.evaluated_normal = d["normal_q"]
+    rei.reinitialization_vmult(out, ops.vector(d["src"]), False)
+    assert rel_l2(out.numpy(), d["reinit_vmult"]) < TOL
+    rei.reinitialization_vmult(out, ops.vector(d["src"]), True)
+    assert rel_l2(out.numpy(), d["reinit_diffuse_vmult"]) < TOL
+    out3 = ops.vector(blocks=3)
+    lso.LevelSetOKZSolverComputeNormal(ops).compute_normal_vmult(out3, ops.vector(d["src3"], blocks=3))
+    assert rel_l2(out3.numpy(), d["normal_vmult"]) < TOL
+    lso.LevelSetOKZSolverComputeCurvature(ops).compute_curvature_vmult(out, ops.vector(d["src"]), True)
+    assert rel_l2(out.numpy(), d["curvature_vmult"]) < TOL
+    # right-hand sides (formed without constraints in the fixture)
+    ops_u = lso.LevelSetOperators(mesh, s, velocity_degree=k)
+    ops_u.set_parameters(eps_used, dt, weight, w_old, w_oo, epsilon)
+    out = ops_u.vector()
+    rei = lso.LevelSetOKZSolverReinitialization(ops_u)
+    rei.local_reinitialize_rhs(out, ops_u.vector(d["src"]), ops_u.vector(d["src3"], blocks=3), False, True)
+    assert rel_l2(out.numpy(), d["reinit_rhs_first"]) < TOL
+    assert rel_l2(rei.evaluated_normal, d["reinit_rhs_normal_q"]) < TOL
+    # ... and the operator application right after uses the array the rhs kernel just wrote
+    rei.reinitialization_vmult(out, ops_u.vector(d["src"]), False)
+    out3 = ops_u.vector(blocks=3)
+    lso.LevelSetOKZSolverComputeNormal(ops_u).local_compute_normal_rhs(out3, ops_u.vector(d["src"]))
+    assert rel_l2(out3.numpy(), d["normal_rhs"]) < TOL
+    # the local_*_rhs cell loops accumulate (the reference's callers zero the vector first,
+    # e.g. level_set_okz_compute_curvature.cc:333)
+    out = ops_u.vector()
+    lso.LevelSetOKZSolverComputeCurvature(ops_u).local_compute_curvature_rhs(out, ops_u.vector(d["src3"], blocks=3))
+    assert rel_l2(out.numpy(), d["curvature_rhs"]) < TOL
+    adv = lso.LevelSetOKZSolverAdvanceConcentration(ops_u)
+    out = ops_u.vector()
+    adv.local_advance_concentration_rhs(out, ops_u.vector(d["src"]), ops_u.vector(d["old"]), ops_u.vector(d["oldold"]),
+                                        ops_u.velocity_vector(d["vel"]), True)
+    assert rel_l2(out.numpy(), d["advect_rhs"]) < TOL
+    assert rel_l2(adv.evaluated_convection, d["advect_rhs_vel_q"]) < TOL

@@ -268,3 +268,58 @@ def test_vmult_q2_kernel_random_bricks():
                     pressure_average_fix=bool(trial % 2), seed=trial)
         eu, ep = run_vmult(case, variant=1)
         assert eu < TOL and ep < TOL, (ncell, faces_u, faces_p, eu, ep)
+
+
+# ----------------------------------------------------------------------------- BASELINE size
+def test_full_size_properties_128cubed():
+    """Config 2 (128^3 Q2/Q1, 53 M DoF) is far beyond what the naive oracle finishes in seconds,
+    so parity at that size is checked through size-independent properties:
+      * the Q2/Q1 sweep kernel and the generic per-cell kernel (independent code) agree,
+      * linearity  A(a x + b y) = a A x + b A y,
+      * constant pressure: B^T 1 vanishes on unconstrained velocity rows,
+      * the Stokes operator (no projection) is symmetric: x^T A y = y^T A x.
+    Tolerance 1e-12 relative L2 as everywhere."""
+    n = 128
+    case = Case((n, n, n), k=2)
+    op = case.engine()
+    rng = np.random.default_rng(7)
+    # linearisation state = Beltrami interpolant seen through the residual kernel (as bench.py)
+    u0 = case.smooth_u(0.0)
+    tmp = op.block_vector()
+    op.residual(tmp, op.block_vector(u0, case.smooth_p(0.0)), None, op.block_vector(u0), op.block_vector())
+    x_u, x_p = rng.uniform(-1, 1, case.n_u), rng.uniform(-1, 1, case.n_p)
+    y_u, y_p = rng.uniform(-1, 1, case.n_u), rng.uniform(-1, 1, case.n_p)
+    x, y = op.block_vector(x_u, x_p), op.block_vector(y_u, y_p)
+    dst = op.block_vector()
+    res = {}
+    for variant in (1, 0):
+        op.set_kernel_variant(variant)
+        op.vmult(dst, x)
+        res[variant] = dst.numpy()
+    assert rel_l2(res[1][0], res[0][0]) < TOL and rel_l2(res[1][1], res[0][1]) < TOL
+    op.set_kernel_variant(1)
+    ax_u, ax_p = res[1]
+    op.vmult(dst, y)
+    ay_u, ay_p = dst.numpy()
+    a, b = 0.75, -1.25
+    op.vmult(dst, op.block_vector(a * x_u + b * y_u, a * x_p + b * y_p))
+    z_u, z_p = dst.numpy()
+    assert rel_l2(z_u, a * ax_u + b * ay_u) < TOL and rel_l2(z_p, a * ax_p + b * ay_p) < TOL
+    # constant pressure, zero velocity: only constrained rows (identity on a zero vector) and
+    # round-off remain in the velocity block
+    op.vmult(dst, op.block_vector(np.zeros(case.n_u), np.ones(case.n_p)))
+    bt_u, _ = dst.numpy()
+    h = 2.0 / n
+    assert np.abs(bt_u).max() < 1e-12 * h * h
+    del op
+    # Stokes, no mean projection: symmetric operator (constrained rows are +-identity)
+    sc = Case((n, n, n), k=2, physical_type=2, pressure_average_fix=False)
+    sop = sc.engine()
+    d1, d2 = sop.block_vector(), sop.block_vector()
+    sop.vmult(d1, sop.block_vector(x_u, x_p))
+    sop.vmult(d2, sop.block_vector(y_u, y_p))
+    a1u, a1p = d1.numpy()
+    a2u, a2p = d2.numpy()
+    xay = y_u @ a1u + y_p @ a1p
+    yax = x_u @ a2u + x_p @ a2p
+    assert abs(xay - yax) < 1e-12 * max(abs(xay), np.linalg.norm(a1u) * np.linalg.norm(y_u))
