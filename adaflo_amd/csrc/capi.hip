@@ -259,6 +259,8 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
                     ctx->d_tab_ls, ctx->d_ls_diag})
     if (p)
       (void)hipFree(p);
+  if (ctx->q2_wg_list)
+    (void)hipFree(ctx->q2_wg_list);
   ctx->matvec_timer.destroy();
   ctx->kernel_timer.destroy();
   if (ctx->own_stream)
@@ -501,6 +503,25 @@ int adaflo_ns_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double 
       TRY(ctx, launch_ns_cell_generic(ctx, OP_VMULT, a), "cell kernel launch failed");
     }
   return adaflo_ns_apply_pressure_average_projection(ctx, dst_p); // :258
+}
+
+int adaflo_ns_vmult_phase(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double *src_u,
+                          const double *src_p, int phase, unsigned interface_faces)
+{
+  CHECK_CTX(ctx);
+  if (!dst_u || !dst_p || !src_u || !src_p)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  if (phase < 0 || phase > 2)
+    return fail(ctx, ADAFLO_EINVAL, "phase must be 0, 1 or 2");
+  if (!(ctx->variant == 1 && q2_supported(ctx)))
+    return fail(ctx, ADAFLO_EUNSUPPORTED, "phased vmult needs the Q2/Q1 sweep kernel");
+  if (needs_lin(ctx) && !ctx->lin.p)
+    return fail(ctx, ADAFLO_ENOTINIT, "linearization data not set (call residual or set_linearization)");
+  TRY(ctx, launch_ns_vmult_q2(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p, phase, interface_faces),
+      "Q2 kernel launch failed");
+  if (phase == 1)
+    ctx->matvec_timer.count++;
+  return 0;
 }
 
 int adaflo_ns_residual(adaflo_ctx *ctx, double *rhs_u, double *rhs_p, const double *src_u,

@@ -115,6 +115,9 @@ struct adaflo_ctx
   // specialised (Q2/Q1 sweep kernel) copy of the linearisation, see ns_q2.hip
   adaflo_hip::DeviceBuffer lin_q2, lin_q2_prec;
   adaflo_hip::DeviceBuffer q2_slab_u, q2_zslab_u, q2_slab_p, q2_zslab_p; // seam partial sums
+  int                     *q2_wg_list = nullptr;     // [interface | interior A | interior B] workgroups
+  long                     q2_wg_key[4] = {0, 0, 0, 0};
+  int                      q2_wg_counts[3] = {0, 0, 0};
   bool                     lin_q2_valid = false;
   int                      lin_q2_mode  = -1;
   int                      q2_lz        = 0; // z-chunk length override (0 = heuristic)

@@ -102,5 +102,5 @@ namespace adaflo_hip
   bool q2_supported(const adaflo_ctx *ctx);
   int  q2_prepare_state(adaflo_ctx *ctx);
   int  launch_ns_vmult_q2(adaflo_ctx *ctx, int op, double *dst_u, double *dst_p,
-                          const double *src_u, const double *src_p);
+                          const double *src_u, const double *src_p, int phase = -1, uint32_t iface = 0);
 } // namespace adaflo_hip

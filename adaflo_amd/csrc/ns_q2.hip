@@ -19,6 +19,8 @@
 //  * The Q1 pressure is expanded to the Q2 nodal basis at gather time, so all
 //    four lanes of a quad run the identical Q2 interpolation code.
 #include "kernels.hpp"
+#include <cstring>
+#include <vector>
 
 namespace adaflo_hip
 {
@@ -54,7 +56,24 @@ namespace adaflo_hip
       const double *src_u, *src_p;
       double       *dst_u, *dst_p;
       const double *state;
+      // phased execution for the multi-GPU overlap (launch_ns_vmult_q2): explicit workgroup list
+      // for the main kernel, node filter for the fix-up (1: only nodes on the inter-GPU interface
+      // faces `iface`, 2: all other nodes, 0: everything)
+      const int *wg_list;
+      int        wg_offset, wg_count, fix_mode;
+      uint32_t   iface;
     };
+
+    __device__ __forceinline__ bool fix_skip(const Q2Args &A, const int I, const int J, const int K,
+                                             const int nn_x, const int nn_y, const int nn_z)
+    {
+      if (A.fix_mode == 0)
+        return false;
+      const bool on = (I == 0 && (A.iface & 1u)) || (I == nn_x - 1 && (A.iface & 2u)) ||
+                      (J == 0 && (A.iface & 4u)) || (J == nn_y - 1 && (A.iface & 8u)) ||
+                      (K == 0 && (A.iface & 16u)) || (K == nn_z - 1 && (A.iface & 32u));
+      return A.fix_mode == 1 ? !on : on;
+    }
 
     template <int SEL>
     __device__ __forceinline__ double quad_bcast(const double x)
@@ -363,8 +382,10 @@ namespace adaflo_hip
 
       // workgroup -> (tile, z-chunk); chunks of one tile column are consecutive
       // in the remapped index so that an XCD's L2 sees neighbouring work
-      const long nwg = (long)A.tiles_x * A.tiles_y * A.n_chunks;
-      const long wg  = xcd_remap(blockIdx.x, nwg);
+      const long nwg = A.wg_list ? (long)A.wg_count : (long)A.tiles_x * A.tiles_y * A.n_chunks;
+      long       wg  = xcd_remap(blockIdx.x, nwg);
+      if (A.wg_list)
+        wg = A.wg_list[A.wg_offset + wg];
       const int  bz  = (int)(wg % A.n_chunks);
       const int  bt  = (int)(wg / A.n_chunks);
       const int  bx = bt % A.tiles_x, by = bt / A.tiles_x;
@@ -1102,6 +1123,8 @@ namespace adaflo_hip
             continue;
           if (on_constrained_face(I, J, K, nn_x, nn_y, nn_z, con, NC == 1 ? 1 : 3, comp))
             continue; // dst = +-src already written by every sharer
+          if (fix_skip(A, I, J, K, nn_x, nn_y, nn_z))
+            continue;
           double sum = 0.;
           for (int dy = 0; dy <= (seam_y ? 1 : 0); ++dy)
             for (int dx = 0; dx <= (seam_x ? 1 : 0); ++dx)
@@ -1138,7 +1161,8 @@ namespace adaflo_hip
             continue;
           const bool seam = (i == 0 && I > 0) || (i == TN - 1 && I < nn_x - 1) || (j == 0 && J > 0) ||
                             (j == TN - 1 && J < nn_y - 1);
-          if (seam || on_constrained_face(I, J, K, nn_x, nn_y, nn_z, con, NC == 1 ? 1 : 3, comp))
+          if (seam || on_constrained_face(I, J, K, nn_x, nn_y, nn_z, con, NC == 1 ? 1 : 3, comp) ||
+              fix_skip(A, I, J, K, nn_x, nn_y, nn_z))
             continue;
           dst[((long)(K * (long)nn_y + J) * nn_x + I) * NC + comp] += zslab[(bt * A.n_chunks + m - 1) * (TN * TN * NC) + e];
         }
@@ -1253,8 +1277,12 @@ namespace adaflo_hip
     return 0;
   }
 
+  // phase -1: the whole operator.  Phases 0/1/2 (multi-GPU overlap): 0 = first half of the
+  // workgroups that touch no node of the inter-GPU interface faces `iface` (bit = face 2*dim+side),
+  // 1 = the workgroups that do + seam fix-up of the interface nodes (dst is then final there and
+  // can be packed), 2 = the remaining interior workgroups + the rest of the fix-up.
   int launch_ns_vmult_q2(adaflo_ctx *ctx, const int op, double *dst_u, double *dst_p,
-                         const double *src_u, const double *src_p)
+                         const double *src_u, const double *src_p, const int phase, const uint32_t iface)
   {
     if (ctx->lin_q2_valid && ctx->lin_q2_mode != q2_lin_mode(ctx))
       ctx->lin_q2_valid = false;
@@ -1346,14 +1374,51 @@ namespace adaflo_hip
       A.slab_p  = ctx->q2_slab_p.p;
       A.zslab_p = ctx->q2_zslab_p.p;
     }
-    if (with_p && !A.integrate_p)
+    if (with_p && !A.integrate_p && phase <= 0)
       if (int e = launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, A.npx, A.npy, A.npz,
                                      A.con_p, -1., true))
         return e;
-    const long nwg  = (long)A.tiles_x * A.tiles_y * A.n_chunks;
-    hipEvent_t stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
+    long nwg = (long)A.tiles_x * A.tiles_y * A.n_chunks;
+    if (phase >= 0)
+      {
+        // workgroup list [interface | interior A | interior B], cached per (grid, iface)
+        const long key[4] = {A.tiles_x, A.tiles_y, A.n_chunks, (long)iface};
+        if (!ctx->q2_wg_list || std::memcmp(key, ctx->q2_wg_key, sizeof(key)) != 0)
+          {
+            std::vector<int> bnd, inner;
+            for (int by = 0; by < A.tiles_y; ++by)
+              for (int bx = 0; bx < A.tiles_x; ++bx)
+                for (int bz = 0; bz < A.n_chunks; ++bz)
+                  {
+                    const bool b = (bx == 0 && (iface & 1u)) || (bx == A.tiles_x - 1 && (iface & 2u)) ||
+                                   (by == 0 && (iface & 4u)) || (by == A.tiles_y - 1 && (iface & 8u)) ||
+                                   (bz == 0 && (iface & 16u)) || (bz == A.n_chunks - 1 && (iface & 32u));
+                    (b ? bnd : inner).push_back((by * A.tiles_x + bx) * A.n_chunks + bz);
+                  }
+            ctx->q2_wg_counts[0] = (int)bnd.size();
+            ctx->q2_wg_counts[1] = (int)(inner.size() / 2);
+            ctx->q2_wg_counts[2] = (int)(inner.size() - inner.size() / 2);
+            bnd.insert(bnd.end(), inner.begin(), inner.end());
+            if (ctx->q2_wg_list)
+              (void)hipFree(ctx->q2_wg_list);
+            ctx->q2_wg_list = nullptr;
+            if (hipMalloc(&ctx->q2_wg_list, sizeof(int) * (bnd.size() + 1)) != hipSuccess)
+              return ADAFLO_ENOMEM;
+            if (hipMemcpy(ctx->q2_wg_list, bnd.data(), sizeof(int) * bnd.size(), hipMemcpyHostToDevice) != hipSuccess)
+              return ADAFLO_EHIP;
+            std::memcpy(ctx->q2_wg_key, key, sizeof(key));
+          }
+        const int nb = ctx->q2_wg_counts[0], na = ctx->q2_wg_counts[1], nc = ctx->q2_wg_counts[2];
+        A.wg_list   = ctx->q2_wg_list;
+        A.wg_offset = phase == 1 ? 0 : (phase == 0 ? nb : nb + na);
+        A.wg_count  = phase == 1 ? nb : (phase == 0 ? na : nc);
+        A.fix_mode  = phase; // 1: interface nodes, 2: the others (phase 0 runs no fix-up)
+        A.iface     = iface;
+        nwg         = A.wg_count;
+      }
+    hipEvent_t stop = (ctx->timing && nwg > 0) ? ctx->kernel_timer.start(ctx->stream) : nullptr;
     const bool   iso = ctx->desc.h[0] == ctx->desc.h[1] && ctx->desc.h[1] == ctx->desc.h[2];
-    const dim3   grid((unsigned)nwg), block(NT);
+    const dim3   grid((unsigned)(nwg > 0 ? nwg : 1)), block(NT);
     const size_t lds_bytes = sizeof(double) * L_TOTAL;
     hipError_t   err       = hipSuccess;
 #define Q2_LAUNCH_I(LM, WP, IS)                                                                       \
@@ -1365,7 +1430,7 @@ namespace adaflo_hip
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
         attr_set = err == hipSuccess;                                                           \
       }                                                                                         \
-    if (err == hipSuccess)                                                                      \
+    if (err == hipSuccess && nwg > 0)                                                           \
       hipLaunchKernelGGL((ns_q2_kernel<LM, WP, IS>), grid, block, lds_bytes, ctx->stream, A);   \
   }
 #define Q2_LAUNCH(LM, WP)      \
@@ -1405,7 +1470,9 @@ namespace adaflo_hip
       return ADAFLO_EHIP;
     if (stop)
       (void)hipEventRecord(stop, ctx->stream);
-    ctx->kernel_timer.count++;
+    if (phase == -1 || phase == 1)
+      ctx->kernel_timer.count++;
+    if (phase != 0)
     {
       const long tiles = (long)A.tiles_x * A.tiles_y;
       const bool fix_p = with_p && A.integrate_p;

@@ -66,6 +66,8 @@ class NavierStokesMatrix:
         d.stream = None
         self._stream = stream       # None: engine-owned stream; int (0 = default stream): caller's
         self.time_stepping = None
+        self._variant = 1
+        self._has_variable_coefficients = False
 
     # -- lifetime -----------------------------------------------------------------------------
     def initialize(self, time_stepping, pressure_average_fix):
@@ -153,6 +155,7 @@ class NavierStokesMatrix:
 
     def set_kernel_variant(self, variant):
         _lib.check(self._ctx, self._lib.adaflo_set_kernel_variant(self._require(), variant))
+        self._variant = variant
 
     # -- quadrature-point state ---------------------------------------------------------------
     def set_linearization(self, lin):
@@ -170,6 +173,7 @@ class NavierStokesMatrix:
 
     def set_coefficients(self, rho=None, mu=None, damping=None):
         ctx = self._require()
+        self._has_variable_coefficients = rho is not None
         if rho is None:
             _lib.check(ctx, self._lib.adaflo_ns_set_coefficients(ctx, None, None, None, 0))
             return
@@ -185,6 +189,20 @@ class NavierStokesMatrix:
         ctx = self._require()
         _lib.check(ctx, self._lib.adaflo_ns_vmult(ctx, dst.block(0).ptr, dst.block(1).ptr,
                                                   src.block(0).ptr, src.block(1).ptr))
+
+    def vmult_phase(self, dst, src, phase, interface_faces):
+        """one of the three parts of vmult used to overlap the inter-GPU exchange with interior
+        cells (adaflo_ns_vmult_phase); interface_faces: bit mask of the brick faces shared with
+        other GPUs.  No mean-value projection."""
+        ctx = self._require()
+        _lib.check(ctx, self._lib.adaflo_ns_vmult_phase(ctx, dst.block(0).ptr, dst.block(1).ptr,
+                                                        src.block(0).ptr, src.block(1).ptr, phase,
+                                                        interface_faces))
+
+    def supports_phases(self):
+        """phased execution exists for the Q2/Q1 sweep kernel only"""
+        return (self.parameters.velocity_degree == 2 and getattr(self, "_variant", 1) == 1
+                and not self._has_variable_coefficients)
 
     def residual(self, residual_vector, src, user_rhs, solution_old, solution_old_old):
         """solution_old / solution_old_old are constructor references in the reference

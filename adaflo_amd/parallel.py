@@ -66,6 +66,11 @@ class BrickPartition:
                 out.append(2 * d + 1)
         return out
 
+    def interface_mask(self):
+        """bit 2*d+side for the faces of the local brick shared with another rank"""
+        phys = self.physical_faces()
+        return sum(1 << f for f in range(6) if f not in phys)
+
     def neighbours(self):
         """[(offset, rank)] of all existing neighbours (faces, edges, corners)"""
         out = []
@@ -119,16 +124,12 @@ class HaloExchange:
             out.append(v.view(nn[2], nn[1], nn[0], nc))
         return out
 
-    def _exchange(self, vecs, mode):
-        """one round of point-to-point messages with all neighbours.  On GPU tensors the
-        interface regions are packed / unpacked by the engine's halo kernel (native=ctx),
-        otherwise by torch slicing (CPU tests)."""
+    def _plan(self, mode, dev, dtype):
+        """static description of one exchange round (who sends what where), built once"""
         import torch
-        import torch.distributed as dist
-        if self.part.world == 1 or not self.nbrs:
-            return
-        views = self._views(vecs)
-        dev, dtype = vecs[0].device, vecs[0].dtype
+        key = (mode, str(dev))
+        if key in self._bufs:
+            return self._bufs[key]
         send_list, recv_list = [], []
         for o, nb in self.nbrs:
             positive = all(x >= 0 for x in o)   # I am on the low side of every cut direction
@@ -137,17 +138,12 @@ class HaloExchange:
                 send_list.append((o, nb))
             if mode == "add" or negative:
                 recv_list.append((o, nb))
-        sizes = lambda o: [int(np.prod([len(range(*sl.indices(n))) for sl, n in
-                                        zip(_region(o, self.part.nodes(deg)), self.part.nodes(deg)[::-1])])) * nc
-                           for deg, nc in self.fields]
-        key = (mode, dev)
-        if key not in self._bufs:
-            ns = sum(sum(sizes(o)) for o, _ in send_list)
-            nr = sum(sum(sizes(o)) for o, _ in recv_list)
-            self._bufs[key] = (torch.empty(max(ns, 1), dtype=dtype, device=dev),
-                               torch.empty(max(nr, 1), dtype=dtype, device=dev))
-        sbuf, rbuf = self._bufs[key]
-        # --- pack: buffer layout [field][neighbour] so that one kernel per field packs everything
+
+        def sizes(o):
+            return [int(np.prod([len(range(*sl.indices(n))) for sl, n in
+                                 zip(_region(o, self.part.nodes(deg)), self.part.nodes(deg)[::-1])])) * nc
+                    for deg, nc in self.fields]
+        # buffer layout [field][neighbour] so that one kernel per field packs everything
         seg_send, seg_recv = {}, {}
         off = 0
         for f in range(len(self.fields)):
@@ -155,45 +151,74 @@ class HaloExchange:
                 n = sizes(o)[f]
                 seg_send[(f, o)] = (off, n)
                 off += n
+        ns = off
         off = 0
         for f in range(len(self.fields)):
             for o, nb in recv_list:
                 n = sizes(o)[f]
                 seg_recv[(f, o)] = (off, n)
                 off += n
-        if self.native is not None and vecs[0].is_cuda:
+        nr = off
+        plan = dict(send_list=send_list, recv_list=recv_list, seg_send=seg_send, seg_recv=seg_recv,
+                    sbuf=torch.empty(max(ns, 1), dtype=dtype, device=dev),
+                    rbuf=torch.empty(max(nr, 1), dtype=dtype, device=dev))
+        self._bufs[key] = plan
+        return plan
+
+    def start(self, vecs, mode):
+        """pack the interface regions and post the point-to-point messages with all neighbours.
+        With the nccl (RCCL) backend the transfers run asynchronously to kernels launched on the
+        current stream afterwards; finish() makes the current stream wait for them and unpacks.
+        On GPU tensors packing / unpacking is done by the engine's halo kernel (native=ctx),
+        otherwise by torch slicing (CPU tests)."""
+        import torch
+        import torch.distributed as dist
+        if self.part.world == 1 or not self.nbrs:
+            return None
+        plan = self._plan(mode, vecs[0].device, vecs[0].dtype)
+        send_list, recv_list = plan["send_list"], plan["recv_list"]
+        seg_send, seg_recv = plan["seg_send"], plan["seg_recv"]
+        sbuf, rbuf = plan["sbuf"], plan["rbuf"]
+        native = self.native is not None and vecs[0].is_cuda
+        if native:
             for f, v in enumerate(vecs):
                 if send_list:
                     base = seg_send[(f, send_list[0][0])][0]
                     self._native_transfer(v, sbuf[base:], f, [o for o, _ in send_list], 0)
         else:
+            views = self._views(vecs)
             for f, w in enumerate(views):
                 for o, nb in send_list:
                     a, n = seg_send[(f, o)]
                     sbuf[a:a + n] = w[_region(o, self.part.nodes(self.fields[f][0]))].reshape(-1)
-        # --- messages: one per (neighbour, field).  With a gloo group (functional tests of the
+        # one message per (neighbour, field).  With a gloo group (functional tests of the
         # multi-GPU path on a single GPU) the packed buffers are staged through host memory.
         stage = vecs[0].is_cuda and dist.get_backend(self.group) == "gloo"
-        if stage:
-            sbuf_d, rbuf_d = sbuf, rbuf
-            sbuf, rbuf = sbuf_d.cpu(), torch.empty(rbuf_d.shape, dtype=dtype)
+        hs, hr = (sbuf.cpu(), torch.empty(rbuf.shape, dtype=rbuf.dtype)) if stage else (sbuf, rbuf)
         ops = []
         for o, nb in send_list:
             for f in range(len(self.fields)):
                 a, n = seg_send[(f, o)]
-                ops.append(dist.P2POp(dist.isend, sbuf[a:a + n], nb, group=self.group, tag=f))
+                ops.append(dist.P2POp(dist.isend, hs[a:a + n], nb, group=self.group, tag=f))
         for o, nb in recv_list:
             for f in range(len(self.fields)):
                 a, n = seg_recv[(f, o)]
-                ops.append(dist.P2POp(dist.irecv, rbuf[a:a + n], nb, group=self.group, tag=f))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        if stage:
-            rbuf_d.copy_(rbuf)
-            sbuf, rbuf = sbuf_d, rbuf_d
-        # --- unpack: faces first, corners last (in copy mode the lowest sharer wins)
-        if self.native is not None and vecs[0].is_cuda:
+                ops.append(dist.P2POp(dist.irecv, hr[a:a + n], nb, group=self.group, tag=f))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return dict(plan=plan, mode=mode, vecs=vecs, works=works, stage=stage, hr=hr, native=native)
+
+    def finish(self, handle):
+        """wait for the messages of start() and unpack (copy: faces first, corners last so that
+        the lowest sharer wins; add: every replica ends up with the total)"""
+        if handle is None:
+            return
+        plan, mode, vecs = handle["plan"], handle["mode"], handle["vecs"]
+        recv_list, seg_recv, rbuf = plan["recv_list"], plan["seg_recv"], plan["rbuf"]
+        for w in handle["works"]:
+            w.wait()
+        if handle["stage"]:
+            rbuf.copy_(handle["hr"])
+        if handle["native"]:
             for f, v in enumerate(vecs):
                 if not recv_list:
                     continue
@@ -207,6 +232,7 @@ class HaloExchange:
                             base = seg_recv[(f, group[0])][0]
                             self._native_transfer(v, rbuf[base:], f, group, 1)
         else:
+            views = self._views(vecs)
             for f, w in enumerate(views):
                 for o, nb in recv_list:
                     a, n = seg_recv[(f, o)]
@@ -216,6 +242,10 @@ class HaloExchange:
                         w[r] += piece
                     else:
                         w[r] = piece
+
+    def _exchange(self, vecs, mode):
+        """one blocking round: start + finish"""
+        self.finish(self.start(vecs, mode))
 
     def _native_transfer(self, vec, buf, field, offsets, mode):
         """engine halo kernel over the regions of `offsets` (contiguous in buf, in this order)"""
@@ -288,6 +318,7 @@ class DistributedNavierStokesMatrix:
             local = NavierStokesMatrix(parameters, mesh, dirichlet_faces_u=part.physical_faces(),
                                        constrained_faces_p=(), device=device, stream=stream)
         self.local = local
+        self.overlap = True       # overlap the exchanges with interior cells where supported
         self.halo = HaloExchange(part, [(k, 3), (k - 1, 1)], group=group)
         self._w_owned = None
         self._inv = None
@@ -321,17 +352,32 @@ class DistributedNavierStokesMatrix:
             self.halo.update_ghost_values([b._keepalive for b in vec.blocks])
 
     def vmult(self, dst, src, src_consistent=False):
-        """NavierStokesMatrix::vmult on the global problem; block vectors wrap torch tensors"""
+        """NavierStokesMatrix::vmult on the global problem; block vectors wrap torch tensors.
+
+        With the Q2/Q1 sweep kernel the two exchanges are overlapped with interior cells, the way
+        MatrixFree::cell_loop overlaps update_ghost_values / compress with its cell partitions:
+          ghost update of src   ||  interior cells, first half
+          cells at the interface, seam sums of the interface nodes
+          compress(add) of dst  ||  interior cells, second half"""
         if self.part.world == 1:
             self.local.vmult(dst, src)
             return
-        import torch.distributed as dist
         tsrc = [b._keepalive for b in src.blocks]
         tdst = [b._keepalive for b in dst.blocks]
-        if not src_consistent:
-            self.halo.update_ghost_values(tsrc)            # src.update_ghost_values()
-        self.local.vmult(dst, src)                          # local cells (no projection)
-        self.halo.compress_add(tdst)                        # dst.compress(add)
+        if self.overlap and getattr(self.local, "supports_phases", lambda: False)():
+            mask = self.part.interface_mask()
+            h = None if src_consistent else self.halo.start(tsrc, "copy")
+            self.local.vmult_phase(dst, src, 0, mask)
+            self.halo.finish(h)
+            self.local.vmult_phase(dst, src, 1, mask)
+            h = self.halo.start(tdst, "add")
+            self.local.vmult_phase(dst, src, 2, mask)
+            self.halo.finish(h)
+        else:
+            if not src_consistent:
+                self.halo.update_ghost_values(tsrc)        # src.update_ghost_values()
+            self.local.vmult(dst, src)                      # local cells (no projection)
+            self.halo.compress_add(tdst)                    # dst.compress(add)
         self.local.apply_constrained_rows(dst, src)         # rows on boundary x interface
         if self.pressure_average_fix and self.local.projection_active():
             s = _all_reduce_sum((self._w_owned * tdst[1]).sum().reshape(1), self.group)

@@ -143,6 +143,20 @@ int adaflo_ns_set_coefficients(adaflo_ctx *ctx, const double *rho, const double 
                                const double *damping, int src_on_device);
 int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx);       /* :1144-1152 */
 
+/* The same operator in three parts, for overlapping the inter-GPU ghost exchange with the
+ * evaluation of interior cells (the reference overlaps inside MatrixFree::cell_loop's
+ * update_ghost_values_start/finish and compress_start/finish around
+ * source/navier_stokes_matrix.cc:232-245).  interface_faces: bit 2*dim+side set for the faces of
+ * the brick that are shared with another GPU.
+ *   phase 0: cells that touch no interface node (first half)  -- needs no ghost values of src
+ *   phase 1: cells that touch the interface; afterwards dst is final on the interface nodes
+ *            (ready for compress(add)); requires the ghost values of src
+ *   phase 2: the remaining interior cells and seam sums
+ * After phase 2 dst equals the result of adaflo_ns_vmult without the mean-value projection.
+ * Only with the Q2/Q1 sweep kernel (ADAFLO_EUNSUPPORTED otherwise). */
+int adaflo_ns_vmult_phase(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double *src_u,
+                          const double *src_p, int phase, unsigned interface_faces);
+
 /* ---- Navier-Stokes operators (source/navier_stokes_matrix.cc) ----------- */
 /* vmult :221-262 */
 int adaflo_ns_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double *src_u,

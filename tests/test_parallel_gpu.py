@@ -67,20 +67,28 @@ def _worker(rank, world, port, grid, cells, gu, gp, glin, ref_u, ref_p, results)
         du, dp = torch.full_like(su, 3.0), torch.full_like(sp, 3.0)
         src = adaflo_amd.BlockVector([V(ctx, su), V(ctx, sp)])
         dst = adaflo_amd.BlockVector([V(ctx, du), V(ctx, dp)])
-        for variant in (1, 0):
+        # Q2/Q1 sweep kernel with and without the overlapped (phased) schedule, generic kernel
+        for variant, overlap in ((1, True), (1, False), (0, False)):
             op.set_kernel_variant(variant)
+            op.overlap = overlap
+            du.fill_(3.0)
+            dp.fill_(3.0)
+            su.copy_(torch.from_numpy(np.where(ou > 0, lu, -5.0)))
+            sp.copy_(torch.from_numpy(np.where(opm > 0, lp, -5.0)))
             op.vmult(dst, src)
             torch.cuda.synchronize()
             nu = [k * g * c + 1 for g, c in zip(grid, cells)]
             npn = [(k - 1) * g * c + 1 for g, c in zip(grid, cells)]
             ru = _view(ref_u.reshape(nu[2], nu[1], nu[0], 3), part, k).reshape(-1)
             rp = _view(ref_p.reshape(npn[2], npn[1], npn[0], 1), part, k - 1).reshape(-1)
-            results[(rank, variant)] = (rel_l2(du.cpu().numpy(), ru), rel_l2(dp.cpu().numpy(), rp))
+            results[(rank, variant, overlap)] = (rel_l2(du.cpu().numpy(), ru), rel_l2(dp.cpu().numpy(), rp))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,cells", [(2, (9, 8, 5)), (4, (8, 5, 6)), (8, (4, 5, 3))])
+# the larger bricks have workgroups in all three phases (interface / interior A / interior B)
+@pytest.mark.parametrize("world,cells", [(2, (9, 8, 5)), (4, (8, 5, 6)), (8, (4, 5, 3)), (2, (40, 24, 12)),
+                                         (8, (24, 17, 12))])
 def test_distributed_vmult_on_one_gpu(world, cells):
     grid = parallel.brick_grid(world)
     k = 2
@@ -104,6 +112,6 @@ def test_distributed_vmult_on_one_gpu(world, cells):
     results = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), grid, list(cells), gu, gp, glin, ref_u, ref_p, results),
              nprocs=world, join=True)
-    assert len(results) == 2 * world
+    assert len(results) == 3 * world
     for key, (eu, ep) in results.items():
         assert eu < 1e-12 and ep < 1e-12, (key, eu, ep)
