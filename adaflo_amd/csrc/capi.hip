@@ -409,6 +409,7 @@ int adaflo_ns_set_coefficients(adaflo_ctx *ctx, const double *rho, const double 
 {
   CHECK_CTX(ctx);
   const size_t count = (size_t)ctx->n_cells * ctx->nq_u;
+  ctx->lin_q2_valid = false; // the streaming copy of the Q2/Q1 kernel carries the coefficients
   if (!rho && !mu && !damping)
     {
       release(ctx->rho);
@@ -450,6 +451,7 @@ int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx)
       TRY(ctx, alloc(ctx, ctx->lin_q2_prec, ctx->lin_q2.count), ctx->last_error);
       HIP_TRY(ctx, hipMemcpyAsync(ctx->lin_q2_prec.p, ctx->lin_q2.p, ctx->lin_q2.count * sizeof(double),
                                   hipMemcpyDeviceToDevice, ctx->stream));
+      ctx->lin_q2_prec_varco = ctx->lin_q2_varco;
     }
   else
     release(ctx->lin_q2_prec);
@@ -558,7 +560,8 @@ int adaflo_ns_velocity_vmult(adaflo_ctx *ctx, double *dst_u, const double *src_u
   if (needs_lin(ctx) && !ctx->lin.p)
     return fail(ctx, ADAFLO_ENOTINIT, "linearization data not set");
   const int k = ctx->k;
-  if (ctx->variant == 1 && q2_supported(ctx) && !ctx->rho_prec.p)
+  // (frozen coefficient copies without a frozen streaming copy: generic kernel)
+  if (ctx->variant == 1 && q2_supported(ctx) && (!ctx->rho_prec.p || ctx->lin_q2_prec.p))
     {
       TRY(ctx, launch_ns_vmult_q2(ctx, OP_VMULT_VELOCITY, dst_u, nullptr, src_u, nullptr),
           "Q2 kernel launch failed");

@@ -118,7 +118,7 @@ struct adaflo_ctx
   int                     *q2_wg_list = nullptr;     // [interface | interior A | interior B] workgroups
   long                     q2_wg_key[4] = {0, 0, 0, 0};
   int                      q2_wg_counts[3] = {0, 0, 0};
-  bool                     lin_q2_valid = false;
+  bool                     lin_q2_valid = false, lin_q2_varco = false, lin_q2_prec_varco = false;
   int                      lin_q2_mode  = -1;
   int                      q2_lz        = 0; // z-chunk length override (0 = heuristic)
   int                      q2_state_pad = 0; // skew padding (double2) per (tile, layer) state block

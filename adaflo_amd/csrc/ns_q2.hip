@@ -49,6 +49,7 @@ namespace adaflo_hip
       double wj[4];        // JxW by number of "middle" indices of the q-point: det * w0^(3-m) * w1^m
       double cA, cB;       // conv = cA * u + cB * res, cA = gamma*rho - damping, cB = tau1*rho
       double beta, tau_gd, tmu;
+      double gamma, tau1; // variable coefficients: cA = gamma rho_q - damping_q, cB = tau1 rho_q, tmu = tau1 mu_q
       int    integrate_p;
       long   state_stride; // double2 elements per (tile, layer) block (payload + skew padding)
       double *slab_u, *zslab_u, *slab_p, *zslab_p; // seam partial sums, see q2_seam_fixup_kernel
@@ -370,10 +371,17 @@ namespace adaflo_hip
     }
 
     // ISO: cubic cells, one set of derivative coefficients for all directions
-    template <int LIN_MODE, bool WITH_P, bool ISO>
+    template <int LIN_MODE, bool WITH_P, bool ISO, bool VARCO>
     __global__ __launch_bounds__(NT, 2) void ns_q2_kernel(const Q2Args A)
     {
       extern __shared__ double lds[];
+      // state ring geometry.  Constant coefficients: pieces of 48 lanes x 16 B, 9 slots.
+      // Variable rho/mu/damping (two-phase flow): lanes 48..63 of every piece carry the
+      // coefficients of the wave's 16 cells -- (rho, mu) in half 0, (damping, -) in half 1 --
+      // so the DMA instruction count per point stays at two; 6 slots of 64 lanes x 16 B.
+      constexpr int PIECE_ = VARCO ? 128 : PIECE, RING_ = VARCO ? 6 : RING, AHEAD_ = VARCO ? 4 : AHEAD;
+      constexpr int PLANES_ = VARCO ? 64 : 48; // double2 per wave and piece
+      static_assert(54 % RING_ == 0 && 4 * RING_ * PIECE_ <= 4 * RING * PIECE, "ring geometry");
 
       const int tid = threadIdx.x, lane = tid & 63;
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform by construction
@@ -464,7 +472,7 @@ namespace adaflo_hip
 
       // ---- prologue: first node planes and first state pieces ---------------------------------
       const double2 *state = reinterpret_cast<const double2 *>(A.state);
-      double        *ringw = lds + L_RING + wave * RING * PIECE;
+      double        *ringw = lds + L_RING + wave * RING_ * PIECE_;
       const unsigned slan  = cell * 3 + (is_p ? 0 : d); // my element of a piece
       {
         dma_u_plane_single(A, lds, 2 * cz0, I0, J0, wave, lane);
@@ -481,22 +489,23 @@ namespace adaflo_hip
       const int      xq = cq * XQ;
 #endif
       const unsigned ring_byte = lds_addr(ringw);
-      const unsigned piece_voff = 16u * (unsigned)min(lane, 47);
+      const unsigned piece_voff = 16u * (unsigned)(VARCO ? lane : min(lane, 47));
       auto issue_piece = [&](const int layer_cz, const int p) {
         // piece p (= 2q + half) of cell layer layer_cz: 48 consecutive double2 of this wave
         const double2 *g = state + ((size_t)bt * A.ncz + layer_cz) * A.state_stride +
-                           (size_t)p * (NCELL * 3) + wave * 48;
-        dma_b128(g, piece_voff, ring_byte + (p % RING) * (PIECE * 8), 0x0000ffffffffffffull);
+                           (size_t)p * (4 * PLANES_) + wave * PLANES_;
+        dma_b128(g, piece_voff, ring_byte + (p % RING_) * (PIECE_ * 8),
+                 VARCO ? 0xffffffffffffffffull : 0x0000ffffffffffffull);
       };
       if (LIN_MODE != 2)
         {
 #pragma unroll
-          for (int p = 0; p < AHEAD; ++p)
+          for (int p = 0; p < AHEAD_; ++p)
             issue_piece(cz0, p);
         }
       // planes must have landed before anybody gathers from them
       if (LIN_MODE != 2)
-        wait_vmcnt<AHEAD>();
+        wait_vmcnt<AHEAD_>();
       else
         wait_vmcnt<0>();
       lds_barrier();
@@ -607,15 +616,16 @@ namespace adaflo_hip
               const int qx = q % 3, qy = (q / 3) % 3, qz = q / 9;
               double2   st0 = make_double2(0., 0.), st1 = make_double2(0., 0.);
               double    r_ub0 = 0., r_ub1 = 0., r_ub2 = 0., r_trl = 0.;
+              double    r_rho = 0., r_mu = 0., r_damp = 0.;
               if (LIN_MODE != 2)
                 {
                   // outstanding after the pieces of q: AHEAD - 2 younger pieces, plus, right
                   // after the plane refill was issued (q < 4), the plane copies of this wave
-                  constexpr int younger = AHEAD - 2;
+                  constexpr int younger = AHEAD_ - 2;
 #if defined(Q2_EXP) && (Q2_EXP == 1 || Q2_EXP == 2)
                   if (false)
 #else
-                  if (q < AHEAD / 2)
+                  if (q < AHEAD_ / 2)
 #endif
                     {
                       if (WITH_P)
@@ -628,11 +638,17 @@ namespace adaflo_hip
                     wait_vmcnt<younger>();
 #endif
                   const double2 *rs = reinterpret_cast<const double2 *>(ringw);
-                  st0 = rs[((2 * q) % RING) * (PIECE / 2) + slan - wave * 48];
-                  st1 = rs[((2 * q + 1) % RING) * (PIECE / 2) + slan - wave * 48];
+                  st0 = rs[((2 * q) % RING_) * (PIECE_ / 2) + slan - wave * 48];
+                  st1 = rs[((2 * q + 1) % RING_) * (PIECE_ / 2) + slan - wave * 48];
                   // the quad's three (u_lin_e, grad_e0) and (grad_e1, grad_e2) entries
-                  const double *rq0 = ringw + ((2 * q) % RING) * PIECE + 6 * cq;
-                  const double *rq1 = ringw + ((2 * q + 1) % RING) * PIECE + 6 * cq;
+                  const double *rq0 = ringw + ((2 * q) % RING_) * PIECE_ + 6 * cq;
+                  const double *rq1 = ringw + ((2 * q + 1) % RING_) * PIECE_ + 6 * cq;
+                  if (VARCO) // quad-uniform reads of the cell's (rho, mu) and damping
+                    {
+                      const double *rc0 = ringw + ((2 * q) % RING_) * PIECE_ + 96 + 2 * cq;
+                      const double *rc1 = ringw + ((2 * q + 1) % RING_) * PIECE_ + 96 + 2 * cq;
+                      r_rho = rc0[0], r_mu = rc0[1], r_damp = rc1[0];
+                    }
                   if (LIN_MODE == 0)
                     {
                       r_ub0 = rq0[0], r_ub1 = rq0[2], r_ub2 = rq0[4];
@@ -649,11 +665,11 @@ namespace adaflo_hip
                     }
                   else if (false)
 #else
-                  if (2 * q + AHEAD < 54)
+                  if (2 * q + AHEAD_ < 54)
 #endif
                     {
-                      issue_piece(cz, 2 * q + AHEAD);
-                      issue_piece(cz, 2 * q + AHEAD + 1);
+                      issue_piece(cz, 2 * q + AHEAD_);
+                      issue_piece(cz, 2 * q + AHEAD_ + 1);
                     }
 #if !defined(Q2_EXP) || Q2_EXP != 2
                   else
@@ -661,8 +677,8 @@ namespace adaflo_hip
                   else if (false)
 #endif
                     {
-                      issue_piece(cz_next, 2 * q + AHEAD - 54);
-                      issue_piece(cz_next, 2 * q + AHEAD + 1 - 54);
+                      issue_piece(cz_next, 2 * q + AHEAD_ - 54);
+                      issue_piece(cz_next, 2 * q + AHEAD_ + 1 - 54);
                     }
                 }
 #if defined(Q2_EXP) && Q2_EXP == 4
@@ -707,7 +723,11 @@ namespace adaflo_hip
               const double div = G00 + G11 + G22; // :706
               (void)u0, (void)u1, (void)u2, (void)pres;
 
-              double conv = A.cA * Vq; // :717, :827-835
+              // :717, :827-835, :841-845 with the coefficients of this point
+              const double cA_q = VARCO ? A.gamma * r_rho - r_damp : A.cA;
+              const double cB_q = VARCO ? A.tau1 * r_rho : A.cB;
+              const double tmu_q = VARCO ? (is_p ? 0. : A.tau1 * r_mu) : tmu_l;
+              double conv = cA_q * Vq;
               if (LIN_MODE == 0)       // Newton :802-816
                 {
                   // u_lin of all components and tr(grad u_lin): quad-uniform LDS reads of the ring
@@ -716,7 +736,7 @@ namespace adaflo_hip
                   res += ub0 * g0 + u0 * st0.y;
                   res += ub1 * g1 + u1 * st1.x;
                   res += ub2 * g2 + u2 * st1.y;
-                  conv += A.cB * res;
+                  conv += cB_q * res;
                 }
               else if (LIN_MODE == 1) // Picard-type :817-826, state = (u_lin, div_lin)
                 {
@@ -725,7 +745,7 @@ namespace adaflo_hip
                   res += ub0 * g0;
                   res += ub1 * g1;
                   res += ub2 * g2;
-                  conv += A.cB * res;
+                  conv += cB_q * res;
                 }
 
               const double jxw = A.wj[(qx == 1) + (qy == 1) + (qz == 1)];
@@ -735,7 +755,7 @@ namespace adaflo_hip
                 diag -= pres;
               diag *= jxw;
               // :859-892: row d of tmu (grad u + grad u^T) + (tau_gd div - p) I, times JxW J^{-1}
-              const double tmj = tmu_l * jxw;
+              const double tmj = tmu_q * jxw;
               const double tg0 = tmj * (g0 + c0) + d0 * diag;
               const double tg1 = tmj * (g1 + c1) + d1 * diag;
               const double tg2 = tmj * (g2 + c2) + d2 * diag;
@@ -769,7 +789,7 @@ namespace adaflo_hip
 
           // my plane copies for the next layer are older than the AHEAD pieces issued last
           if (LIN_MODE != 2)
-            wait_vmcnt<AHEAD>();
+            wait_vmcnt<AHEAD_>();
           else
             wait_vmcnt<0>();
 
@@ -1189,22 +1209,32 @@ namespace adaflo_hip
         }
     }
 
-    // generic [cell][12][27] -> streaming layout [tile][layer][q][half][cell-in-tile*3+d][2]
+    // generic [cell][12][27] (+ [cell][27] coefficient arrays) -> streaming layout
+    // [tile][layer][q][half][wave][lane][2]: lanes 0..47 of a wave = (cell-in-wave*3+d) state
+    // entries; with variable coefficients 16 more lanes per wave = (rho, mu) / (damping, 0) of
+    // the wave's 16 cells
     __global__ __launch_bounds__(256) void q2_convert_state_kernel(double *__restrict__ out,
                                                                    const double *__restrict__ gen,
+                                                                   const double *__restrict__ rho,
+                                                                   const double *__restrict__ mu,
+                                                                   const double *__restrict__ damp,
                                                                    const int ncx, const int ncy,
                                                                    const int ncz, const int tiles_x,
                                                                    const long total, const int lin_mode,
                                                                    const long stride2)
     {
-      // `total` counts payload doubles; blocks of STATE_PER_LAYER doubles are stored stride2
-      // double2 apart (skew padding against HBM channel camping of the lock-step streams)
+      // `total` counts payload doubles; blocks of per_layer doubles are stored stride2
+      // double2 apart (optional skew padding)
+      const int  lanes     = rho ? 64 : 48;
+      const long per_layer = 27L * 2 * 4 * lanes * 2;
       for (long o = blockIdx.x * 256L + threadIdx.x; o < total; o += (long)gridDim.x * 256)
         {
-          const int  j    = (int)(o & 1);
-          long       r    = o >> 1;
-          const int  cd   = (int)(r % (NCELL * 3));
-          r /= NCELL * 3;
+          const int j    = (int)(o & 1);
+          long      r    = o >> 1;
+          const int lane = (int)(r % lanes);
+          r /= lanes;
+          const int wave = (int)(r & 3);
+          r >>= 2;
           const int half = (int)(r & 1);
           r >>= 1;
           const int q = (int)(r % 27);
@@ -1212,22 +1242,29 @@ namespace adaflo_hip
           const int  cz = (int)(r % ncz);
           const long bt = r / ncz;
           const int  bx = (int)(bt % tiles_x), by = (int)(bt / tiles_x);
-          const int  cl = cd / 3, d = cd % 3;
+          const int  cl = wave * 16 + (lane < 48 ? lane / 3 : lane - 48), d = lane % 3;
           const int  cx = bx * TX + (cl % TX), cy = by * TY + (cl / TX);
           double     v  = 0.;
           if (cx < ncx && cy < ncy)
             {
               const long cell = cx + (long)ncx * (cy + (long)ncy * cz);
-              int        comp;
-              if (half == 0 && j == 0)
-                comp = d; // u_lin[d]
-              else if (lin_mode == 1)
-                comp = 3; // div_lin (second[0][0])
-              else
-                comp = 3 + 3 * d + (2 * half + j - 1); // grad_lin[d][e]
-              v = gen[(cell * NLIN + comp) * 27 + q];
+              if (lane < 48)
+                {
+                  int comp;
+                  if (half == 0 && j == 0)
+                    comp = d; // u_lin[d]
+                  else if (lin_mode == 1)
+                    comp = 3; // div_lin (second[0][0])
+                  else
+                    comp = 3 + 3 * d + (2 * half + j - 1); // grad_lin[d][e]
+                  v = gen[(cell * NLIN + comp) * 27 + q];
+                }
+              else if (half == 0)
+                v = (j == 0 ? rho : mu)[cell * 27 + q];
+              else if (j == 0)
+                v = damp[cell * 27 + q];
             }
-          out[(o / STATE_PER_LAYER) * (2 * stride2) + (o % STATE_PER_LAYER)] = v;
+          out[(o / per_layer) * (2 * stride2) + (o % per_layer)] = v;
         }
     }
   } // namespace
@@ -1239,9 +1276,21 @@ namespace adaflo_hip
     return ctx->ns.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON ? 0 : 1;
   }
 
+  // variable coefficients (two-phase flow) ride along with the linearisation state, so they
+  // need a linearisation that has one (Newton / Picard-type); Stokes or explicit convection
+  // with variable coefficients stays on the generic kernel
+  static bool q2_varco(const adaflo_ctx *ctx)
+  {
+    return ctx->rho.p && ctx->mu.p && ctx->damp.p;
+  }
+
   bool q2_supported(const adaflo_ctx *ctx)
   {
-    return ctx->k == 2 && ctx->rho.p == nullptr && ctx->mu.p == nullptr && ctx->damp.p == nullptr;
+    if (ctx->k != 2)
+      return false;
+    if (!ctx->rho.p && !ctx->mu.p && !ctx->damp.p)
+      return true;
+    return q2_varco(ctx) && q2_lin_mode(ctx) != 2;
   }
 
   int q2_prepare_state(adaflo_ctx *ctx)
@@ -1249,8 +1298,10 @@ namespace adaflo_hip
     if (ctx->lin_q2_valid || q2_lin_mode(ctx) == 2)
       return 0;
     const int    tiles_x = (ctx->desc.ncell[0] + TX - 1) / TX, tiles_y = (ctx->desc.ncell[1] + TY - 1) / TY;
-    const size_t payload = (size_t)tiles_x * tiles_y * ctx->desc.ncell[2] * STATE_PER_LAYER;
-    const long   stride2 = STATE_PER_LAYER / 2 + ctx->q2_state_pad;
+    const bool   varco     = q2_varco(ctx);
+    const long   per_layer = 27L * 2 * 4 * (varco ? 64 : 48) * 2;
+    const size_t payload = (size_t)tiles_x * tiles_y * ctx->desc.ncell[2] * per_layer;
+    const long   stride2 = per_layer / 2 + ctx->q2_state_pad;
     const size_t count   = (size_t)tiles_x * tiles_y * ctx->desc.ncell[2] * 2 * stride2;
     if (ctx->lin_q2.count != count)
       {
@@ -1268,12 +1319,14 @@ namespace adaflo_hip
     if (nb > 256 * 32)
       nb = 256 * 32;
     hipLaunchKernelGGL(q2_convert_state_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream,
-                       ctx->lin_q2.p, ctx->lin.p, ctx->desc.ncell[0], ctx->desc.ncell[1],
+                       ctx->lin_q2.p, ctx->lin.p, varco ? ctx->rho.p : nullptr, ctx->mu.p, ctx->damp.p,
+                       ctx->desc.ncell[0], ctx->desc.ncell[1],
                        ctx->desc.ncell[2], tiles_x, (long)payload, q2_lin_mode(ctx), stride2);
     if (hipGetLastError() != hipSuccess)
       return ADAFLO_EHIP;
     ctx->lin_q2_valid = true;
     ctx->lin_q2_mode  = q2_lin_mode(ctx);
+    ctx->lin_q2_varco = varco;
     return 0;
   }
 
@@ -1284,7 +1337,7 @@ namespace adaflo_hip
   int launch_ns_vmult_q2(adaflo_ctx *ctx, const int op, double *dst_u, double *dst_p,
                          const double *src_u, const double *src_p, const int phase, const uint32_t iface)
   {
-    if (ctx->lin_q2_valid && ctx->lin_q2_mode != q2_lin_mode(ctx))
+    if (ctx->lin_q2_valid && (ctx->lin_q2_mode != q2_lin_mode(ctx) || ctx->lin_q2_varco != q2_varco(ctx)))
       ctx->lin_q2_valid = false;
     if (int e = q2_prepare_state(ctx))
       return e;
@@ -1340,14 +1393,19 @@ namespace adaflo_hip
     A.tau_gd      = P.tau_grad_div;
     A.tmu         = P.viscosity * P.tau1; // :841-845
     A.integrate_p = P.linearization != ADAFLO_PROJECTION;
-    A.state_stride = STATE_PER_LAYER / 2 + ctx->q2_state_pad;
+    A.gamma       = gamma;
+    A.tau1        = P.tau1;
+    // the frozen copy of velocity_vmult carries the coefficients it was built with
+    const bool use_prec = op == OP_VMULT_VELOCITY && ctx->lin_q2_prec.p;
+    const bool varco    = use_prec ? ctx->lin_q2_prec_varco : q2_varco(ctx);
+    A.state_stride = 27L * 2 * 4 * (varco ? 64 : 48) + ctx->q2_state_pad;
     A.con_u       = ctx->brick.con_u;
     A.con_p       = ctx->brick.con_p;
     A.src_u       = src_u;
     A.src_p       = src_p;
     A.dst_u       = dst_u;
     A.dst_p       = dst_p;
-    A.state       = (op == OP_VMULT_VELOCITY && ctx->lin_q2_prec.p) ? ctx->lin_q2_prec.p : ctx->lin_q2.p;
+    A.state       = use_prec ? ctx->lin_q2_prec.p : ctx->lin_q2.p;
     const int  lin_mode = q2_lin_mode(ctx);
     const bool with_p   = op == OP_VMULT;
 
@@ -1421,17 +1479,24 @@ namespace adaflo_hip
     const dim3   grid((unsigned)(nwg > 0 ? nwg : 1)), block(NT);
     const size_t lds_bytes = sizeof(double) * L_TOTAL;
     hipError_t   err       = hipSuccess;
-#define Q2_LAUNCH_I(LM, WP, IS)                                                                       \
+#define Q2_LAUNCH_V(LM, WP, IS, VC)                                                                   \
   {                                                                                             \
     static bool attr_set = false;                                                               \
     if (!attr_set)                                                                              \
       {                                                                                         \
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_q2_kernel<LM, WP, IS>),        \
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_q2_kernel<LM, WP, IS, VC>),    \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
         attr_set = err == hipSuccess;                                                           \
       }                                                                                         \
     if (err == hipSuccess && nwg > 0)                                                           \
-      hipLaunchKernelGGL((ns_q2_kernel<LM, WP, IS>), grid, block, lds_bytes, ctx->stream, A);   \
+      hipLaunchKernelGGL((ns_q2_kernel<LM, WP, IS, VC>), grid, block, lds_bytes, ctx->stream, A); \
+  }
+#define Q2_LAUNCH_I(LM, WP, IS)       \
+  {                                   \
+    if (varco)                        \
+      Q2_LAUNCH_V(LM, WP, IS, true)   \
+    else                              \
+      Q2_LAUNCH_V(LM, WP, IS, false)  \
   }
 #define Q2_LAUNCH(LM, WP)      \
   {                            \
@@ -1466,6 +1531,7 @@ namespace adaflo_hip
         }
 #undef Q2_LAUNCH
 #undef Q2_LAUNCH_I
+#undef Q2_LAUNCH_V
     if (err != hipSuccess)
       return ADAFLO_EHIP;
     if (stop)

@@ -27,8 +27,8 @@ def timeit(fn, sync, reps=20, warm=3):
     return (time.perf_counter() - t0) / reps
 
 
-def ns_case(k, n, variant):
-    fp = adaflo_amd.FlowParameters(velocity_degree=k)
+def ns_case(k, n, variant, two_phase=False):
+    fp = adaflo_amd.FlowParameters(velocity_degree=k, density_diff=0.5 if two_phase else 0.0)
     ts = adaflo_amd.TimeStepping(fp)
     for _ in range(3):
         ts.next()
@@ -38,12 +38,16 @@ def ns_case(k, n, variant):
     rng = np.random.default_rng(1)
     nq = (k + 1) ** 3
     op.set_linearization(rng.uniform(-1, 1, op.n_cells() * nq * 12))
+    if two_phase:  # variable rho, mu, damping at the quadrature points
+        nc = op.n_cells() * nq
+        op.set_coefficients(rng.uniform(.5, 2, nc), rng.uniform(.5, 2, nc), rng.uniform(-.5, .5, nc))
     src = op.block_vector(rng.uniform(-1, 1, op.n_dofs_u()), rng.uniform(-1, 1, op.n_dofs_p()))
     dst = op.block_vector()
     t = timeit(lambda: op.vmult(dst, src), op.synchronize)
     ndof = op.n_dofs_u() + op.n_dofs_p()
-    b_alg = op.n_cells() * (16 * (3 * k ** 3 + (k - 1) ** 3) + 8 * 12 * nq)
-    print(json.dumps({"op": "ns_vmult", "k": k, "cells": n, "variant": variant, "ms": round(t * 1e3, 4),
+    b_alg = op.n_cells() * (16 * (3 * k ** 3 + (k - 1) ** 3) + 8 * (15 if two_phase else 12) * nq)
+    print(json.dumps({"op": "ns_vmult" + ("_two_phase" if two_phase else ""), "k": k, "cells": n,
+                      "variant": variant, "ms": round(t * 1e3, 4),
                       "MDoF/s": round(ndof / t / 1e6, 1), "alg_GB/s": round(b_alg / t / 1e9, 1),
                       "frac_of_8TB/s": round(b_alg / t / 8e12, 4)}), flush=True)
 
@@ -80,6 +84,8 @@ def ls_case(s, ncell):
 if __name__ == "__main__":
     ns_case(2, 128, 1)
     ns_case(2, 128, 0)
+    ns_case(2, 128, 1, two_phase=True)
+    ns_case(2, 128, 0, two_phase=True)
     ns_case(3, 64, 0)
     ns_case(4, 64, 0)
     ls_case(4, (40, 40, 80))

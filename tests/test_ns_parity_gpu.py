@@ -323,3 +323,35 @@ def test_full_size_properties_128cubed():
     xay = y_u @ a1u + y_p @ a1p
     yax = x_u @ a2u + x_p @ a2p
     assert abs(xay - yax) < 1e-12 * max(abs(xay), np.linalg.norm(a1u) * np.linalg.norm(y_u))
+
+
+# ----------------------------------------------------------------------------- two-phase flow
+@pytest.mark.parametrize("lin,ncell", [(0, (4, 4, 3)), (0, (17, 9, 20)), (1, (9, 16, 5)), (2, (10, 8, 6))])
+def test_vmult_variable_coefficients_q2_kernel(lin, ncell):
+    """variable rho / mu / damping at the quadrature points ride in the spare lanes of the state
+    pieces of the Q2/Q1 sweep kernel (navier_stokes_matrix.cc:636-642,:827-845)"""
+    case = Case(ncell, k=2, linearization=lin, density_diff=0.5, damping=0.2, tau_grad_div=0.1,
+                upper=(1.0, 0.5, 2.0))
+    eu, ep = run_vmult(case, variant=1, coefficients=True)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+def test_velocity_vmult_variable_coefficients_uses_the_frozen_state():
+    case = Case((9, 8, 7), k=2, density_diff=0.5)
+    src_u, lin, coef = case.random_u(), case.random_lin(), case.random_coefficients()
+    ref = orc.ns_velocity_vmult(case.mesh, case.k, case.prm, src_u, case.con_u, lin=lin,
+                                rho=coef[0], mu=coef[1], damp=coef[2])
+    for variant in (1, 0):
+        op = case.engine()
+        op.set_kernel_variant(variant)
+        op.set_linearization(lin)
+        op.set_coefficients(*coef)
+        op.fix_linearization_point()
+        # later changes of the state and the coefficients must not affect velocity_vmult (:349-375)
+        op.set_linearization(case.random_lin())
+        op.set_coefficients(*case.random_coefficients())
+        src, dst = op.initialize_u_vector(src_u), op.initialize_u_vector(np.full(case.n_u, 3.0))
+        op.velocity_vmult(dst, src)
+        assert rel_l2(dst.numpy(), ref) < TOL
+        # ... while vmult sees the new ones: switching back to constant coefficients works too
+        op.set_coefficients(None, None, None)
