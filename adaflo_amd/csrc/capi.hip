@@ -939,12 +939,10 @@ static int ls_vmult(adaflo_ctx *ctx, double *dst, const double *src, const int m
           default:
             c_lap = flag ? b * b : 0.;
         }
-      for (int blk = 0; blk < nblocks; ++blk)
-        TRY(ctx,
-            launch_q1_sweep(ctx, ctx->s, q1mode, c_mass, c_lap, P.weight, ctx->brick.con_ls, 1.,
-                            ctx->d_ls_diag, dst + (size_t)blk * ctx->n_nodes_ls,
-                            src + (size_t)blk * ctx->n_nodes_ls, state),
-            "level-set kernel launch failed");
+      TRY(ctx,
+          launch_q1_sweep(ctx, ctx->s, q1mode, c_mass, c_lap, P.weight, ctx->brick.con_ls, 1., ctx->d_ls_diag,
+                          dst, src, state, nblocks),
+          "level-set kernel launch failed");
       return 0;
     }
   HIP_TRY(ctx, hipMemsetAsync(dst, 0, sizeof(double) * nblocks * ctx->n_nodes_ls, ctx->stream)); // dst = 0.

@@ -96,7 +96,7 @@ namespace adaflo_hip
   int q1_convert_state(adaflo_ctx *ctx, DeviceBuffer &out, const double *generic_dev);
   int launch_q1_sweep(adaflo_ctx *ctx, int sub, int mode, double c_mass, double c_lap, double weight,
                       uint32_t con, double con_sign, const double *diag, double *dst, const double *src,
-                      const double *state);
+                      const double *state, int n_blocks = 1);
 
   // specialised 3D Q2/Q1 sweep kernel (ns_q2.hip)
   bool q2_supported(const adaflo_ctx *ctx);

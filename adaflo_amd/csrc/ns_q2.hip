@@ -34,10 +34,6 @@ namespace adaflo_hip
     constexpr int QNX = TX + 1, QNY = TY + 1;
     constexpr int PPLANE = QNX * QNY;      // doubles per pressure node plane (81)
     constexpr int NCELL = TX * TY;         // 64
-    constexpr int SCR_U = 27 * NCELL * 3;  // scratch: [local node][cell][comp]
-    constexpr int SCR_P = 8 * NCELL;
-    constexpr int STATE_PER_LAYER = 27 * 2 * NCELL * 3 * 2; // doubles per (tile, layer)
-    constexpr int PF = 3;                  // q-points of state prefetched ahead
 
     struct Q2Args
     {
@@ -175,7 +171,7 @@ namespace adaflo_hip
     constexpr int L_CPX     = L_CEY + PNX * 3;            // pressure far column [9], far row [9]
     constexpr int L_CPY     = L_CPX + QNY;
     constexpr int L_TOTAL   = L_CPY + QNX;
-    constexpr int XQ        = 18;             // doubles per quad record: 4 lanes x 4 + pad (bank spread, 16-B aligned)
+    [[maybe_unused]] constexpr int XQ = 18;             // doubles per quad record: 4 lanes x 4 + pad (bank spread, 16-B aligned)
     constexpr int NPL_U     = 5;              // plane-DMA instructions per wave and layer (fixed count)
     constexpr int NPL_P     = 1;
 
@@ -414,7 +410,6 @@ namespace adaflo_hip
       // the tile in x / y; pressure lane: (0,0) plus li = 1 / lj = 1 likewise.  Bit li + 3*lj.
       const bool valid = cxl < tcx && cyl < tcy;
       const bool lastx = valid && cxl == tcx - 1, lasty = valid && cyl == tcy - 1; // valid cells only
-      const bool hasW = cxl > 0, hasS = cyl > 0;
       unsigned flags; // bits 0-8 owned, 9-17 constrained, 18-26 seam; m_zero separately (gather)
       unsigned m_zero = 0;
       {

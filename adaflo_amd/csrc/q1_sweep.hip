@@ -41,6 +41,7 @@ namespace adaflo_hip
       double       *dst;
       const double *state;
       double       *slab, *zslab;
+      long          comp_stride, slab_stride, zslab_stride; // blockIdx.y = scalar block (normal vector: 3)
     };
 
     template <int TN>
@@ -74,6 +75,9 @@ namespace adaflo_hip
       const bool lastx = valid && sx == tcx - 1, lasty = valid && sy == tcy - 1;
       const bool hasW = sx > 0, hasS = sy > 0;
       const size_t wgs = (size_t)bt * A.n_chunks + bz;
+      const double *src_c = A.src + blockIdx.y * A.comp_stride;
+      double       *dst_c = A.dst + blockIdx.y * A.comp_stride;
+      double       *slab_c = A.slab + blockIdx.y * A.slab_stride, *zslab_c = A.zslab + blockIdx.y * A.zslab_stride;
 
       // per-lane flags of the up to 4 owned nodes (li,lj) in {0,1}^2, bit li + 2*lj
       unsigned own = 0, con = 0, seam = 0, zero = 0;
@@ -101,7 +105,7 @@ namespace adaflo_hip
         for (int e = tid; e < TNQ * TNQ; e += NTQ)
           {
             const int i = e % TNQ, j = e / TNQ, I = I0 + i, J = J0 + j;
-            p[e] = (I < A.nnx && J < A.nny && K < A.nnz) ? A.src[((size_t)K * A.nny + J) * A.nnx + I] : 0.;
+            p[e] = (I < A.nnx && J < A.nny && K < A.nnz) ? src_c[((size_t)K * A.nny + J) * A.nnx + I] : 0.;
           }
       };
       // store of one owned node value (constrained rows, slabs, plain stores)
@@ -111,13 +115,13 @@ namespace adaflo_hip
           return;
         const size_t idx = (size_t)K * A.nny * A.nnx + lane_g + (unsigned)(lj * A.nnx + li);
         if ((con >> bit & 1u) || zcon)
-          A.dst[idx] = (A.diag ? A.diag[idx] : A.con_sign) * A.src[idx];
+          dst_c[idx] = (A.diag ? A.diag[idx] : A.con_sign) * src_c[idx];
         else if (seam >> bit & 1u)
-          A.slab[(wgs * (A.LZ + 1) + lp) * RIMQ + rim_index_q<TNQ>(sx + li, sy + lj)] = v;
+          slab_c[(wgs * (A.LZ + 1) + lp) * RIMQ + rim_index_q<TNQ>(sx + li, sy + lj)] = v;
         else if (ztop)
-          A.zslab[wgs * (TNQ * TNQ) + (sy + lj) * TNQ + sx + li] = v;
+          zslab_c[wgs * (TNQ * TNQ) + (sy + lj) * TNQ + sx + li] = v;
         else
-          A.dst[idx] = v;
+          dst_c[idx] = v;
       };
 
       double carry[4] = {0., 0., 0., 0.}; // top-plane sums of the owned nodes, kept for the next layer
@@ -330,8 +334,12 @@ namespace adaflo_hip
     }
 
     // second pass: dst[low-rim node] += partial sums of the other sharers (and of the chunk below)
-    __global__ __launch_bounds__(64) void q1_fixup_kernel(const Q1Args A, const long n1, const long n2)
+    __global__ __launch_bounds__(64) void q1_fixup_kernel(const Q1Args A0, const long n1, const long n2)
     {
+      Q1Args A = A0;
+      A.dst += blockIdx.y * A.comp_stride;
+      A.slab += blockIdx.y * A.slab_stride;
+      A.zslab += blockIdx.y * A.zslab_stride;
       for (long b = blockIdx.x; b < n1 + n2; b += gridDim.x)
         {
           if (b < n1)
@@ -459,7 +467,8 @@ namespace adaflo_hip
   // sub = subdivisions of a cell (level set: s, pressure: 1); mode/coefficients as Q1Args
   int launch_q1_sweep(adaflo_ctx *ctx, const int sub, const int mode, const double c_mass,
                       const double c_lap, const double weight, const uint32_t con, const double con_sign,
-                      const double *diag, double *dst, const double *src, const double *state)
+                      const double *diag, double *dst, const double *src, const double *state,
+                      const int n_blocks)
   {
     Q1Args A{};
     A.nsx = sub * ctx->desc.ncell[0];
@@ -491,6 +500,7 @@ namespace adaflo_hip
     A.jxw      = det / 8.;
     A.gb       = 0.5 * (1. - 1. / std::sqrt(3.)); // first Gauss point of QGauss<1>(2) on [0,1]
     A.ga       = 1. - A.gb;
+    const size_t n_wg = (size_t)A.tiles_x * A.tiles_y * A.n_chunks;
     A.c_mass   = c_mass;
     A.c_lap    = c_lap;
     A.weight   = weight;
@@ -500,8 +510,10 @@ namespace adaflo_hip
     A.src      = src;
     A.dst      = dst;
     A.state    = state;
-    const size_t n_wg    = (size_t)A.tiles_x * A.tiles_y * A.n_chunks;
-    const size_t need[2] = {n_wg * (A.LZ + 1) * RIMQ, n_wg * TNQ * TNQ};
+    A.comp_stride  = (long)A.nnx * A.nny * A.nnz;
+    A.slab_stride  = (long)(n_wg * (A.LZ + 1) * RIMQ);
+    A.zslab_stride = (long)(n_wg * TNQ * TNQ);
+    const size_t need[2] = {(size_t)A.slab_stride * n_blocks, (size_t)A.zslab_stride * n_blocks};
     DeviceBuffer *buf[2] = {&ctx->q1_slab, &ctx->q1_zslab};
     for (int i = 0; i < 2; ++i)
       if (buf[i]->count < need[i])
@@ -516,7 +528,7 @@ namespace adaflo_hip
         }
     A.slab  = ctx->q1_slab.p;
     A.zslab = ctx->q1_zslab.p;
-    const dim3 grid((unsigned)n_wg), block(NTQ);
+    const dim3 grid((unsigned)n_wg, (unsigned)n_blocks), block(NTQ);
     hipEvent_t stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
     switch (mode)
       {
@@ -536,7 +548,7 @@ namespace adaflo_hip
     long       nb    = n1 + n2;
     if (nb > 256 * 512)
       nb = 256 * 512;
-    hipLaunchKernelGGL(q1_fixup_kernel, dim3((unsigned)nb), dim3(64), 0, ctx->stream, A, n1, n2);
+    hipLaunchKernelGGL(q1_fixup_kernel, dim3((unsigned)nb, (unsigned)n_blocks), dim3(64), 0, ctx->stream, A, n1, n2);
     return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
   }
 } // namespace adaflo_hip
