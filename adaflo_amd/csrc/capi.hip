@@ -333,7 +333,7 @@ int adaflo_copy_d2h(adaflo_ctx *ctx, void *dst, const void *src, size_t bytes)
 int adaflo_set_kernel_variant(adaflo_ctx *ctx, int variant)
 {
   CHECK_CTX(ctx);
-  if (variant < 0 || variant > 1)
+  if (variant < 0 || variant > 2)
     return fail(ctx, ADAFLO_EINVAL, "unknown kernel variant");
   ctx->variant = variant;
   return 0;
@@ -482,9 +482,13 @@ int adaflo_ns_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double 
     return fail(ctx, ADAFLO_ENOTINIT, "linearization data not set (call residual or set_linearization)");
   ScopedTimer timer(ctx, ctx->matvec_timer);
   const int   k = ctx->k;
-  if (ctx->variant == 1 && q2_supported(ctx))
+  if (ctx->variant >= 1 && q2_supported(ctx))
     {
       TRY(ctx, launch_ns_vmult_q2(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p), "Q2 kernel launch failed");
+    }
+  else if (ctx->variant == 2 && ho_supported(ctx)) // opt-in, see ns_ho.hip
+    {
+      TRY(ctx, launch_ns_vmult_ho(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p), "sweep kernel launch failed");
     }
   else
     {
@@ -515,7 +519,7 @@ int adaflo_ns_vmult_phase(adaflo_ctx *ctx, double *dst_u, double *dst_p, const d
     return fail(ctx, ADAFLO_EINVAL, "null vector");
   if (phase < 0 || phase > 2)
     return fail(ctx, ADAFLO_EINVAL, "phase must be 0, 1 or 2");
-  if (!(ctx->variant == 1 && q2_supported(ctx)))
+  if (!(ctx->variant >= 1 && q2_supported(ctx)))
     return fail(ctx, ADAFLO_EUNSUPPORTED, "phased vmult needs the Q2/Q1 sweep kernel");
   if (needs_lin(ctx) && !ctx->lin.p)
     return fail(ctx, ADAFLO_ENOTINIT, "linearization data not set (call residual or set_linearization)");
@@ -561,10 +565,16 @@ int adaflo_ns_velocity_vmult(adaflo_ctx *ctx, double *dst_u, const double *src_u
     return fail(ctx, ADAFLO_ENOTINIT, "linearization data not set");
   const int k = ctx->k;
   // (frozen coefficient copies without a frozen streaming copy: generic kernel)
-  if (ctx->variant == 1 && q2_supported(ctx) && (!ctx->rho_prec.p || ctx->lin_q2_prec.p))
+  if (ctx->variant >= 1 && q2_supported(ctx) && (!ctx->rho_prec.p || ctx->lin_q2_prec.p))
     {
       TRY(ctx, launch_ns_vmult_q2(ctx, OP_VMULT_VELOCITY, dst_u, nullptr, src_u, nullptr),
           "Q2 kernel launch failed");
+      return 0;
+    }
+  if (ctx->variant == 2 && ho_supported(ctx) && !ctx->rho_prec.p)
+    {
+      TRY(ctx, launch_ns_vmult_ho(ctx, OP_VMULT_VELOCITY, dst_u, nullptr, src_u, nullptr),
+          "sweep kernel launch failed");
       return 0;
     }
   TRY(ctx,
@@ -621,7 +631,7 @@ int adaflo_ns_pressure_poisson_vmult(adaflo_ctx *ctx, double *dst_p, const doubl
   const double *rho = ctx->rho_prec.p ? ctx->rho_prec.p : ctx->rho.p;
   const bool    var = rho && ctx->ns.linearization != ADAFLO_PROJECTION; // :976-978
   const bool    full = var && ctx->ns.physical_type != ADAFLO_INCOMPRESSIBLE_STATIONARY;
-  if (ctx->variant == 1 && ctx->k == 2 && !var)
+  if (ctx->variant >= 1 && ctx->k == 2 && !var)
     {
       // constant coefficient on Q1: structured sweep kernel (:1002-1031)
       const NSDev &P = ctx->ns;
@@ -669,7 +679,7 @@ int adaflo_ns_pressure_mass_vmult(adaflo_ctx *ctx, double *dst_p, const double *
   if (!dst_p || !src_p)
     return fail(ctx, ADAFLO_EINVAL, "null vector");
   const double *mu = ctx->mu_prec.p ? ctx->mu_prec.p : ctx->mu.p;
-  if (ctx->variant == 1 && ctx->k == 2 && !mu)
+  if (ctx->variant >= 1 && ctx->k == 2 && !mu)
     {
       // constant coefficient on Q1: structured sweep kernel (:1036-1071)
       const NSDev &P = ctx->ns;
@@ -896,7 +906,7 @@ static int ls_vmult(adaflo_ctx *ctx, double *dst, const double *src, const int m
     return e;
   if (!dst || !src)
     return fail(ctx, ADAFLO_EINVAL, "null vector");
-  if (ctx->variant == 1)
+  if (ctx->variant >= 1)
     {
       // structured Q1 sweep kernel: FE_Q_iso_Q1(s) = trilinear elements on the refined grid
       if (ctx->brick.con_ls && !ctx->d_ls_diag)

@@ -201,7 +201,7 @@ class NavierStokesMatrix:
 
     def supports_phases(self):
         """phased execution exists for the Q2/Q1 sweep kernel only"""
-        return (self.parameters.velocity_degree == 2 and getattr(self, "_variant", 1) == 1
+        return (self.parameters.velocity_degree == 2 and getattr(self, "_variant", 1) >= 1
                 and not self._has_variable_coefficients)
 
     def residual(self, residual_vector, src, user_rhs, solution_old, solution_old_old):

@@ -254,8 +254,10 @@ int adaflo_set_q2_chunk(adaflo_ctx *ctx, int layers);
 /* tuning: skew padding (units of 16 B) between the per-(tile,layer) blocks of the streamed state */
 int adaflo_set_q2_state_pad(adaflo_ctx *ctx, int pad_16B);
 
-/* select the implementation of adaflo_ns_vmult: 0 = generic (any degree),
- * 1 = auto (specialised kernels where available; default).                    */
+/* select the implementation of the operator applications: 0 = generic per-cell kernels (any
+ * degree), 1 = auto (default: Q2/Q1 sweep kernel, structured Q1 sweep kernel for the level set and
+ * the Q1 pressure operators, generic elsewhere), 2 = as 1 plus the experimental Q3..Q5 sweep
+ * kernel (ns_ho.hip; bitwise reproducible, currently not faster than the generic kernel). */
 int adaflo_set_kernel_variant(adaflo_ctx *ctx, int variant);
 
 #ifdef __cplusplus

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Timing of the Q3..Q5 sweep kernel against the generic kernel (development aid)."""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import adaflo_amd
+
+
+def run(k, n, variant, phys="incompressible"):
+    fp = adaflo_amd.FlowParameters(velocity_degree=k, physical_type=phys)
+    ts = adaflo_amd.TimeStepping(fp)
+    for _ in range(3):
+        ts.next()
+    op = adaflo_amd.NavierStokesMatrix(fp, adaflo_amd.BrickMesh([n] * 3, [-1] * 3, [1] * 3))
+    op.initialize(ts, True)
+    op.set_kernel_variant(variant)
+    rng = np.random.default_rng(1)
+    nq = (k + 1) ** 3
+    if phys != "stokes":
+        op.set_linearization(rng.uniform(-1, 1, op.n_cells() * nq * 12))
+    src = op.block_vector(rng.uniform(-1, 1, op.n_dofs_u()), rng.uniform(-1, 1, op.n_dofs_p()))
+    dst = op.block_vector()
+    for _ in range(3):
+        op.vmult(dst, src)
+    op.synchronize()
+    op.get_kernel_statistics()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        op.vmult(dst, src)
+    op.synchronize()
+    t = (time.perf_counter() - t0) / 20
+    ks, kc = op.get_kernel_statistics()
+    print(json.dumps({"k": k, "cells": n, "variant": variant, "phys": phys, "ms": round(t * 1e3, 4),
+                      "kernel_ms": round(1e3 * ks / max(kc, 1), 4), "GDoF/s": round((op.n_dofs_u() + op.n_dofs_p()) / t / 1e9, 2)}), flush=True)
+
+
+if __name__ == "__main__":
+    ks = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [4]
+    for k in ks:
+        n = {3: 64, 4: 64, 5: 48}[k]
+        run(k, n, 2)
+        run(k, n, 2, "stokes")
+        run(k, n, 0)

@@ -86,6 +86,10 @@ if __name__ == "__main__":
     ns_case(2, 128, 0)
     ns_case(2, 128, 1, two_phase=True)
     ns_case(2, 128, 0, two_phase=True)
+    ns_case(3, 64, 2)
     ns_case(3, 64, 0)
+    ns_case(4, 64, 2)
     ns_case(4, 64, 0)
+    ns_case(5, 48, 2)
+    ns_case(5, 48, 0)
     ls_case(4, (40, 40, 80))

@@ -13,7 +13,7 @@ TOL = 1e-12
 NS_3D = [n for n in NS_FIXTURES if "_3d_" in n]
 
 
-@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("variant", [1, 0, 2])
 @pytest.mark.parametrize("name", NS_3D)
 def test_ns_operators_match_fixture(name, variant):
     d = load(name)

@@ -355,3 +355,40 @@ def test_velocity_vmult_variable_coefficients_uses_the_frozen_state():
         assert rel_l2(dst.numpy(), ref) < TOL
         # ... while vmult sees the new ones: switching back to constant coefficients works too
         op.set_coefficients(None, None, None)
+
+
+# ----------------------------------------------------------------------------- Q3..Q5 sweep kernel
+@pytest.mark.parametrize("k,ncell", [(3, (4, 4, 3)), (3, (9, 5, 6)), (3, (8, 8, 20)), (4, (4, 2, 3)), (4, (5, 3, 4)),
+                                     (4, (9, 6, 10)), (5, (3, 2, 2)), (5, (4, 3, 3))])
+def test_vmult_high_order_sweep_kernel(k, ncell):
+    """tiles, partial tiles, several z-chunks; Newton with pressure"""
+    case = Case(ncell, k=k, upper=(1.0, 0.5, 2.0), tau_grad_div=0.2)
+    eu, ep = run_vmult(case, variant=2)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+@pytest.mark.parametrize("lin,phys", [(1, 0), (2, 0), (3, 0), (4, 0), (0, 1), (0, 2)])
+def test_vmult_high_order_sweep_kernel_modes(lin, phys):
+    case = Case((5, 4, 3), k=3, linearization=lin, physical_type=phys, beta=1.0, tau_grad_div=0.3, viscosity=0.2)
+    eu, ep = run_vmult(case, variant=2)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+def test_vmult_high_order_sweep_kernel_partial_constraints():
+    case = Case((5, 5, 3), k=4, faces_u=[0, 3, 4], faces_p=[1, 5], pressure_average_fix=False)
+    eu, ep = run_vmult(case, variant=2)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+def test_velocity_vmult_high_order_sweep_kernel():
+    case = Case((5, 3, 4), k=4)
+    src_u, lin = case.random_u(), case.random_lin()
+    ref = orc.ns_velocity_vmult(case.mesh, case.k, case.prm, src_u, case.con_u, lin=lin)
+    op = case.engine()
+    op.set_kernel_variant(2)
+    op.set_linearization(lin)
+    op.fix_linearization_point()
+    op.set_linearization(case.random_lin())
+    src, dst = op.initialize_u_vector(src_u), op.initialize_u_vector(np.full(case.n_u, 3.0))
+    op.velocity_vmult(dst, src)
+    assert rel_l2(dst.numpy(), ref) < TOL
