@@ -1207,7 +1207,12 @@ namespace adaflo_hip
     // generic [cell][12][27] (+ [cell][27] coefficient arrays) -> streaming layout
     // [tile][layer][q][half][wave][lane][2]: lanes 0..47 of a wave = (cell-in-wave*3+d) state
     // entries; with variable coefficients 16 more lanes per wave = (rho, mu) / (damping, 0) of
-    // the wave's 16 cells
+    // the wave's 16 cells.
+    // One workgroup per (tile, layer, half, wave = 16 cells): the 6 (+2) components a half needs
+    // are read as whole 216-B runs (27 points of one cell and component are contiguous in the
+    // generic layout), transposed through LDS (28 KB: several workgroups per CU) and written as
+    // 27 contiguous runs of 768 (1024) B.
+    constexpr int CV_STRIDE = 8 * 27 + 1; // doubles per cell in LDS: 6 state + 2 coefficient comps (+1: bank skew)
     __global__ __launch_bounds__(256) void q2_convert_state_kernel(double *__restrict__ out,
                                                                    const double *__restrict__ gen,
                                                                    const double *__restrict__ rho,
@@ -1215,37 +1220,28 @@ namespace adaflo_hip
                                                                    const double *__restrict__ damp,
                                                                    const int ncx, const int ncy,
                                                                    const int ncz, const int tiles_x,
-                                                                   const long total, const int lin_mode,
-                                                                   const long stride2)
+                                                                   const int lin_mode, const long stride2)
     {
-      // `total` counts payload doubles; blocks of per_layer doubles are stored stride2
-      // double2 apart (optional skew padding)
-      const int  lanes     = rho ? 64 : 48;
-      const long per_layer = 27L * 2 * 4 * lanes * 2;
-      for (long o = blockIdx.x * 256L + threadIdx.x; o < total; o += (long)gridDim.x * 256)
+      extern __shared__ double cv[]; // [cell 16][slot 8][27]
+      const int  lanes = rho ? 64 : 48;
+      const long blk   = blockIdx.x;
+      const int  half = (int)(blk & 1), wave = (int)(blk >> 1 & 3);
+      const int  cz   = (int)((blk >> 3) % ncz);
+      const long bt   = (blk >> 3) / ncz;
+      const int  bx = (int)(bt % tiles_x), by = (int)(bt / tiles_x);
+      // slot s < 6: state entry (d = s / 2, j = s % 2) of this half; slots 6, 7: coefficients j = 0, 1
+      for (int e = threadIdx.x; e < 16 * 8 * 27; e += 256)
         {
-          const int j    = (int)(o & 1);
-          long      r    = o >> 1;
-          const int lane = (int)(r % lanes);
-          r /= lanes;
-          const int wave = (int)(r & 3);
-          r >>= 2;
-          const int half = (int)(r & 1);
-          r >>= 1;
-          const int q = (int)(r % 27);
-          r /= 27;
-          const int  cz = (int)(r % ncz);
-          const long bt = r / ncz;
-          const int  bx = (int)(bt % tiles_x), by = (int)(bt / tiles_x);
-          const int  cl = wave * 16 + (lane < 48 ? lane / 3 : lane - 48), d = lane % 3;
-          const int  cx = bx * TX + (cl % TX), cy = by * TY + (cl / TX);
-          double     v  = 0.;
-          if (cx < ncx && cy < ncy)
+          const int q = e % 27, s = (e / 27) % 8, cw = e / (27 * 8), cl = wave * 16 + cw;
+          const int cx = bx * TX + (cl % TX), cy = by * TY + (cl / TX);
+          double    v  = 0.;
+          if (cx < ncx && cy < ncy && (s < 6 || rho))
             {
               const long cell = cx + (long)ncx * (cy + (long)ncy * cz);
-              if (lane < 48)
+              if (s < 6)
                 {
-                  int comp;
+                  const int d = s / 2, j = s % 2;
+                  int       comp;
                   if (half == 0 && j == 0)
                     comp = d; // u_lin[d]
                   else if (lin_mode == 1)
@@ -1255,11 +1251,21 @@ namespace adaflo_hip
                   v = gen[(cell * NLIN + comp) * 27 + q];
                 }
               else if (half == 0)
-                v = (j == 0 ? rho : mu)[cell * 27 + q];
-              else if (j == 0)
+                v = (s == 6 ? rho : mu)[cell * 27 + q];
+              else if (s == 6)
                 v = damp[cell * 27 + q];
             }
-          out[(o / per_layer) * (2 * stride2) + (o % per_layer)] = v;
+          cv[cw * CV_STRIDE + s * 27 + q] = v;
+        }
+      __syncthreads();
+      double *o = out + ((bt * ncz + cz) * (2 * stride2)) + (long)(half * 4 + wave) * (lanes * 2);
+      const int per_q = 2 * 4 * lanes * 2; // doubles per point: both halves, four waves
+      for (int e = threadIdx.x; e < 27 * lanes * 2; e += 256)
+        {
+          const int j = e & 1, lane = (e >> 1) % lanes, q = (e >> 1) / lanes;
+          const int cw = lane < 48 ? lane / 3 : lane - 48;
+          const int s  = lane < 48 ? 2 * (lane % 3) + j : 6 + j;
+          o[(long)q * per_q + lane * 2 + j] = cv[cw * CV_STRIDE + s * 27 + q];
         }
     }
   } // namespace
@@ -1295,7 +1301,6 @@ namespace adaflo_hip
     const int    tiles_x = (ctx->desc.ncell[0] + TX - 1) / TX, tiles_y = (ctx->desc.ncell[1] + TY - 1) / TY;
     const bool   varco     = q2_varco(ctx);
     const long   per_layer = 27L * 2 * 4 * (varco ? 64 : 48) * 2;
-    const size_t payload = (size_t)tiles_x * tiles_y * ctx->desc.ncell[2] * per_layer;
     const long   stride2 = per_layer / 2 + ctx->q2_state_pad;
     const size_t count   = (size_t)tiles_x * tiles_y * ctx->desc.ncell[2] * 2 * stride2;
     if (ctx->lin_q2.count != count)
@@ -1308,15 +1313,23 @@ namespace adaflo_hip
           return ADAFLO_ENOMEM;
         ctx->lin_q2.count = count;
       }
-    if (hipMemsetAsync(ctx->lin_q2.p, 0, count * sizeof(double), ctx->stream) != hipSuccess)
+    if (ctx->q2_state_pad > 0 && hipMemsetAsync(ctx->lin_q2.p, 0, count * sizeof(double), ctx->stream) != hipSuccess)
       return ADAFLO_EHIP;
-    long nb = (long)((payload + 255) / 256);
-    if (nb > 256 * 32)
-      nb = 256 * 32;
-    hipLaunchKernelGGL(q2_convert_state_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream,
-                       ctx->lin_q2.p, ctx->lin.p, varco ? ctx->rho.p : nullptr, ctx->mu.p, ctx->damp.p,
-                       ctx->desc.ncell[0], ctx->desc.ncell[1],
-                       ctx->desc.ncell[2], tiles_x, (long)payload, q2_lin_mode(ctx), stride2);
+    {
+      const size_t lds = sizeof(double) * 16 * CV_STRIDE;
+      static bool  attr_set = false;
+      if (!attr_set)
+        {
+          if (hipFuncSetAttribute(reinterpret_cast<const void *>(&q2_convert_state_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ADAFLO_EHIP;
+          attr_set = true;
+        }
+      const long nb = (long)tiles_x * tiles_y * ctx->desc.ncell[2] * 8;
+      hipLaunchKernelGGL(q2_convert_state_kernel, dim3((unsigned)nb), dim3(256), lds, ctx->stream, ctx->lin_q2.p,
+                         ctx->lin.p, varco ? ctx->rho.p : nullptr, ctx->mu.p, ctx->damp.p, ctx->desc.ncell[0],
+                         ctx->desc.ncell[1], ctx->desc.ncell[2], tiles_x, q2_lin_mode(ctx), stride2);
+    }
     if (hipGetLastError() != hipSuccess)
       return ADAFLO_EHIP;
     ctx->lin_q2_valid = true;
