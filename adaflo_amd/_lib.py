@@ -20,6 +20,15 @@ class LSParams(C.Structure):
                 ("weight_old_old", C.c_double), ("epsilon", C.c_double)]
 
 
+class SolverControl(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("abs_tol", C.c_double), ("rel_tol", C.c_double)]
+
+
+class SolverResult(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("converged", C.c_int), ("initial_residual", C.c_double),
+                ("final_residual", C.c_double)]
+
+
 class NSParams(C.Structure):
     _fields_ = [("physical_type", C.c_int), ("linearization", C.c_int), ("beta", C.c_double),
                 ("tau_grad_div", C.c_double), ("density", C.c_double), ("viscosity", C.c_double),
@@ -83,6 +92,9 @@ SIGNATURES = {
     "adaflo_ls_compute_curvature_vmult": (C.c_int, [_CTX, _D, _D, C.c_int]),
     "adaflo_ls_compute_curvature_rhs": (C.c_int, [_CTX, _D, _D]),
     "adaflo_set_kernel_variant": (C.c_int, [_CTX, C.c_int]),
+    "adaflo_invert_diagonal": (C.c_int, [_CTX, _D, _D, C.c_int64]),
+    "adaflo_solve": (C.c_int, [_CTX, C.c_int, C.c_int, _D, _D, _D, C.POINTER(SolverControl),
+                               C.POINTER(SolverResult)]),
     "adaflo_get_kernel_statistics": (C.c_int, [_CTX, C.POINTER(C.c_uint), C.POINTER(C.c_double)]),
     "adaflo_set_timing": (C.c_int, [_CTX, C.c_int]),
     "adaflo_set_q2_chunk": (C.c_int, [_CTX, C.c_int]),

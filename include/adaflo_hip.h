@@ -243,6 +243,59 @@ int adaflo_ls_compute_normal_rhs(adaflo_ctx *ctx, double *dst, const double *lev
 int adaflo_ls_compute_curvature_vmult(adaflo_ctx *ctx, double *dst, const double *src, int apply_diffusion);
 int adaflo_ls_compute_curvature_rhs(adaflo_ctx *ctx, double *dst, const double *normal_vector_field);
 
+/* --------------------------------------------------------------------------------------------
+ * Krylov drivers with device-resident vectors (callers of the operators above)
+ *   SolverCG / SolverBicgstab with ReductionControl and DiagonalPreconditioner as used at
+ *   source/level_set_okz_reinitialization.cc:325-345      CG, ReductionControl(2000, 1e-50, 1e-6)
+ *   source/level_set_okz_advance_concentration.cc:623-644 BiCGStab, ReductionControl(30, ., 1e-8)
+ *   source/level_set_okz_compute_normal.cc:252-267        CG on the 3-block normal system
+ *   source/level_set_okz_compute_curvature.cc:345-355     CG, rel. 1e-8
+ *   source/navier_stokes_preconditioner.cc:743-773        CG on the pressure mass matrix
+ * -------------------------------------------------------------------------------------------- */
+typedef enum adaflo_operator
+{
+  ADAFLO_OP_LS_ADVANCE_CONCENTRATION   = 0, /* AdvanceConcentrationMatrix   advance_concentration.cc:484-499 */
+  ADAFLO_OP_LS_REINITIALIZATION        = 1, /* ReinitializationMatrix(diffuse = false) reinitialization.cc:235-252 */
+  ADAFLO_OP_LS_REINITIALIZATION_DIFFUSE = 2,
+  ADAFLO_OP_LS_NORMAL                  = 3, /* ComputeNormalMatrix (3 scalar blocks) compute_normal.cc:187-203 */
+  ADAFLO_OP_LS_CURVATURE               = 4, /* ComputeCurvatureMatrix        compute_curvature.cc:308-323 */
+  ADAFLO_OP_NS_PRESSURE_MASS           = 5,
+  ADAFLO_OP_NS_PRESSURE_POISSON        = 6,
+  ADAFLO_OP_NS_VELOCITY                = 7  /* velocity_vmult (A block) */
+} adaflo_operator;
+
+typedef enum adaflo_solver
+{
+  ADAFLO_SOLVER_CG       = 0,
+  ADAFLO_SOLVER_BICGSTAB = 1
+} adaflo_solver;
+
+/* ReductionControl(max_iterations, abs_tol, rel_tol): success when the l2 norm of the residual is
+ * below abs_tol or below rel_tol times its initial value */
+typedef struct adaflo_solver_control
+{
+  int    max_iterations;
+  double abs_tol, rel_tol;
+} adaflo_solver_control;
+
+typedef struct adaflo_solver_result
+{
+  int    iterations; /* SolverControl::last_step() */
+  int    converged;  /* 0: max_iterations reached or breakdown (deal.II throws NoConvergence) */
+  double initial_residual, final_residual;
+} adaflo_solver_result;
+
+/* DiagonalPreconditioner::reinit (source/diagonal_preconditioner.cc:27-47):
+ * inv[i] = |d[i]| > 1e-10 max|d| ? 1/d[i] : 1 ; device pointers */
+int adaflo_invert_diagonal(adaflo_ctx *ctx, double *inverse_diagonal, const double *diagonal, int64_t n);
+
+/* x <- approximate solution of op(x) = b, starting from the x passed in; all pointers are device
+ * pointers of the operator's vector size (3 blocks for ADAFLO_OP_LS_NORMAL).  inverse_diagonal:
+ * one block long (applied to every block) or NULL for no preconditioning. */
+int adaflo_solve(adaflo_ctx *ctx, int op, int method, double *x, const double *b,
+                 const double *inverse_diagonal, const adaflo_solver_control *control,
+                 adaflo_solver_result *result);
+
 /* dominant cell-kernel statistics (device time between HIP events recorded on
  * the context's stream around the cell kernel only); used by bench.py for the
  * roofline figure.  Resets like adaflo_ns_get_matvec_statistics.                */

@@ -81,6 +81,35 @@ def ls_case(s, ncell):
                           "frac_of_8TB/s": round(bytes_per_cell * ncells / t / 8e12, 4)}), flush=True)
 
 
+def krylov_case(s, ncell):
+    """device-resident CG on the curvature projection system (compute_curvature.cc:345-355) with a
+    mass-type diagonal preconditioner: iterations and time per iteration"""
+    from adaflo_amd import solvers
+    mesh = adaflo_amd.BrickMesh(list(ncell), [0, 0, 0], [1, 1, 2])
+    ops = lso.LevelSetOperators(mesh, s)
+    ops.set_parameters(1.5 * max(mesh.h) / s, 0.02, 75.0, -100.0, 25.0, 1.5)
+    rng = np.random.default_rng(3)
+    b = ops.vector(rng.uniform(-1, 1, ops.n_dofs))
+    # diagonal of the operator ~ row sums of the mass part: A * 1 (no constraints)
+    ones, diag = ops.vector(np.ones(ops.n_dofs)), ops.vector()
+    cur = lso.LevelSetOKZSolverComputeCurvature(ops)
+    cur.compute_curvature_vmult(diag, ones, False)
+    pre = solvers.DiagonalPreconditioner(diag)
+    sync = lambda: adaflo_amd._lib.load().adaflo_synchronize(ops._ctx)
+    for _ in range(2):
+        control = solvers.ReductionControl(2000, 1e-50, 1e-8)
+        x = ops.vector()
+        sync()
+        t0 = time.perf_counter()
+        solvers.SolverCG(control).solve(solvers.ComputeCurvatureMatrix(ops), x, b, pre)
+        sync()
+        t = time.perf_counter() - t0
+    print(json.dumps({"op": "ls_curvature_cg_solve", "s": s, "cells": list(ncell), "dofs": ops.n_dofs,
+                      "iterations": control.last_step(), "ms": round(t * 1e3, 3),
+                      "ms_per_iteration": round(t * 1e3 / max(control.last_step(), 1), 4),
+                      "reduction": control.last_value() / control.initial_value()}), flush=True)
+
+
 if __name__ == "__main__":
     ns_case(2, 128, 1)
     ns_case(2, 128, 0)
@@ -93,3 +122,4 @@ if __name__ == "__main__":
     ns_case(5, 48, 2)
     ns_case(5, 48, 0)
     ls_case(4, (40, 40, 80))
+    krylov_case(4, (40, 40, 80))
