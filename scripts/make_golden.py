@@ -28,7 +28,9 @@ def reference_outputs():
         "_source": "transcribed from /root/reference/tests/*.output (data only)",
         "beltrami_3d": {  # tests/beltrami_3d.output:1-3,13-15 ; tests/beltrami_3d.prm
             "cells": 4096, "dofs_u": 107811, "dofs_p": 4913, "dt": 0.05, "viscosity": 1.0,
-            "first_step_residuals_u": ["2.590e+00"], "first_step_residuals_p": ["6.423e-02"]},
+            "first_step_residuals_u": ["2.590e+00"], "first_step_residuals_p": ["6.423e-02"],
+            # :31 first residual of time step #2 (after step #1 converged to 1e-9)
+            "second_step_residuals_u": ["2.348e+00"], "second_step_residuals_p": ["5.678e-02"]},
         "rising_bubble_ls": {  # tests/rising_bubble_ls.output (2D): DoF counts of the three spaces
             "cells": 3200, "dofs_u": 26082, "dofs_p": 3321, "dofs_ls": 51681},
     }

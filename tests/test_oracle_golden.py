@@ -40,3 +40,27 @@ def test_residual_distinguishes_the_convective_formulations():
     for beta in (0.0, 1.0):
         _, ru, _ = beltrami_first_residual(beta=beta)
         assert "%.3e" % np.linalg.norm(ru) != "2.590e+00"
+
+
+def test_second_time_step_first_residual_matches_reference_output():
+    """tests/beltrami_3d.output:31 -- time step #2 starts from the CONVERGED solution of step #1
+    (NL tolerance 1e-9 in the reference), which no longer depends on the reference's ILU-preconditioned
+    linear solver: the oracle's residual, its Jacobian (vmult with the state the residual stored),
+    BDF-2 start-up weights, the shift of the old solutions and the boundary values must all be right
+    to reproduce `2.348e+00   5.678e-02`.  Newton converging quadratically on the way pins
+    vmult = d(residual)/du."""
+    from threadpoolctl import threadpool_limits
+
+    import adaflo_amd
+    from oracle import newton_oracle as no
+    fp = adaflo_amd.FlowParameters(velocity_degree=2, viscosity=1.0, time_step_size_start=0.05, end_time=1.0)
+    stepper = no.BeltramiStepper(16, adaflo_amd.TimeStepping(fp))
+    with threadpool_limits(limits=1, user_api="blas"):     # the oracle's OpenMP threads own the cores
+        history = stepper.advance_time_step(tol_nl=1e-6)
+        stepper.init_time_advance()
+        ru, rp = stepper.residual()
+    assert "%.3e" % history[0][0] == "2.590e+00" and "%.3e" % history[0][1] == "6.423e-02"
+    # quadratic convergence of the exact Newton method: 2.6 -> 9e-3 -> 2e-8
+    assert len(history) == 3 and history[1][0] < 1e-2 and history[2][0] < 1e-7
+    assert "%.3e" % np.linalg.norm(ru) == "2.348e+00"
+    assert "%.3e" % np.linalg.norm(rp) == "5.678e-02"
