@@ -93,6 +93,10 @@ SIGNATURES = {
     "adaflo_ls_compute_curvature_rhs": (C.c_int, [_CTX, _D, _D]),
     "adaflo_set_kernel_variant": (C.c_int, [_CTX, C.c_int]),
     "adaflo_invert_diagonal": (C.c_int, [_CTX, _D, _D, C.c_int64]),
+    "adaflo_ns_preconditioner_setup": (C.c_int, [_CTX]),
+    "adaflo_ns_preconditioner_vmult": (C.c_int, [_CTX, _D, _D, _D, _D]),
+    "adaflo_ns_solve_system": (C.c_int, [_CTX, _D, _D, _D, _D, C.POINTER(SolverControl), C.c_int,
+                                         C.POINTER(SolverResult)]),
     "adaflo_solve": (C.c_int, [_CTX, C.c_int, C.c_int, _D, _D, _D, C.POINTER(SolverControl),
                                C.POINTER(SolverResult)]),
     "adaflo_get_kernel_statistics": (C.c_int, [_CTX, C.POINTER(C.c_uint), C.POINTER(C.c_double)]),

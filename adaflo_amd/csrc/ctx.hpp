@@ -132,6 +132,11 @@ struct adaflo_ctx
   adaflo_hip::DeviceBuffer q1_convection, q1_normal, q1_slab, q1_zslab;
   bool                     q1_convection_valid = false, q1_normal_valid = false;
 
+  // block preconditioner of the coupled system (krylov.hip): inverse diagonals of the velocity
+  // block, the pressure mass and the pressure Poisson operator, work vectors
+  adaflo_hip::DeviceBuffer pc_inv_u, pc_inv_pm, pc_inv_pl, pc_ones_p, pc_tmp_u, pc_tmp_p, pc_tmp_p2, pc_work;
+  bool                     pc_ready = false;
+
   // pressure constant mode (mode 0) data, source/navier_stokes_matrix.cc:117-168
   double *d_p_weights = nullptr, *d_p_modes = nullptr;
   double  inv_p_weight = 0.;

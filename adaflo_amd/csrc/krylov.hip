@@ -37,12 +37,12 @@ namespace adaflo_hip
       return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
     }
 
-    // y = a*x + b*y
-    __global__ __launch_bounds__(KT) void axpby_kernel(double *__restrict__ y, const double a,
-                                                       const double *__restrict__ x, const double b, const long n)
+    // y = a*x + b*y   (b == 0: y is not read -- it may be uninitialised memory; x may alias y)
+    __global__ __launch_bounds__(KT) void axpby_kernel(double *y, const double a, const double *x, const double b,
+                                                       const long n)
     {
       for (long i = blockIdx.x * (long)KT + threadIdx.x; i < n; i += (long)gridDim.x * KT)
-        y[i] = a * x[i] + b * y[i];
+        y[i] = b == 0. ? a * x[i] : a * x[i] + b * y[i];
     }
     // z = x + a*(y + b*w)         (BiCGStab: p = r + beta (p - omega v))
     __global__ __launch_bounds__(KT) void xpaybw_kernel(double *__restrict__ z, const double *__restrict__ x,
@@ -86,6 +86,45 @@ namespace adaflo_hip
     {
       for (long i = blockIdx.x * (long)KT + threadIdx.x; i < n; i += (long)gridDim.x * KT)
         inv[i] = fabs(diag[i]) > threshold ? 1. / diag[i] : 1.;
+    }
+
+    // diagonal probing: nodes that are `period` apart never share a cell of degree period-1, so
+    // A * (sum of unit vectors of one colour) shows the diagonal entries of that colour
+    // (the reference assembles these matrices with deal.II/Trilinos:
+    // source/navier_stokes_preconditioner.cc:135-300; here the operator itself is probed)
+    __global__ __launch_bounds__(KT) void probe_fill_kernel(double *__restrict__ e, const int nnx, const int nny,
+                                                            const long n_nodes, const int ncomp, const int period,
+                                                            const int colour, const int comp)
+    {
+      for (long t = blockIdx.x * (long)KT + threadIdx.x; t < n_nodes * ncomp; t += (long)gridDim.x * KT)
+        {
+          const long node = t / ncomp;
+          const int  c    = (int)(t - node * ncomp);
+          const int  I = (int)(node % nnx), J = (int)((node / nnx) % nny), K = (int)(node / ((long)nnx * nny));
+          const int  col = (I % period) + period * ((J % period) + period * (K % period));
+          e[t]           = (col == colour && c == comp) ? 1. : 0.;
+        }
+    }
+    __global__ __launch_bounds__(KT) void probe_take_kernel(double *__restrict__ diag, const double *__restrict__ y,
+                                                            const int nnx, const int nny, const long n_nodes,
+                                                            const int ncomp, const int period, const int colour,
+                                                            const int comp)
+    {
+      for (long t = blockIdx.x * (long)KT + threadIdx.x; t < n_nodes * ncomp; t += (long)gridDim.x * KT)
+        {
+          const long node = t / ncomp;
+          const int  c    = (int)(t - node * ncomp);
+          const int  I = (int)(node % nnx), J = (int)((node / nnx) % nny), K = (int)(node / ((long)nnx * nny));
+          const int  col = (I % period) + period * ((J % period) + period * (K % period));
+          if (col == colour && c == comp)
+            diag[t] = y[t];
+        }
+    }
+    // x -= m   (mean-free rhs / solution of the pure Neumann pressure Poisson problem)
+    __global__ __launch_bounds__(KT) void shift_kernel(double *__restrict__ x, const double m, const long n)
+    {
+      for (long i = blockIdx.x * (long)KT + threadIdx.x; i < n; i += (long)gridDim.x * KT)
+        x[i] -= m;
     }
 
     struct Workspace
@@ -342,6 +381,291 @@ int adaflo_solve(adaflo_ctx *ctx, int op, int method, double *x, const double *b
     return rc; // the operator recorded its message
   if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
     return kfail(ctx, ADAFLO_EHIP, "Krylov kernels failed");
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Linear solver of the coupled Navier-Stokes system: NavierStokes::solve_system
+// (source/navier_stokes.cc:561-653) = FGMRES(50) on NavierStokesMatrix::vmult, right-preconditioned
+// by NavierStokesPreconditioner::vmult with do_inner_solves = true
+// (source/navier_stokes_preconditioner.cc:595-737):
+//   1. velocity block   BiCGStab, SolverControl(100, 3e-2 |r_u|), on velocity_vmult        :636-666
+//   2. t = -r_p + B du  divergence_vmult_add                                                :671-672
+//   3. dp  = M_p^-1 t   CG, ReductionControl(100, 1e-50, 1e-2), diagonal preconditioner     :712,:743-773
+//   4. dp += L_p^-1 t   CG, SolverControl(30, 3e-2 |t|)  (Cahouet-Chabard)                  :715-733
+// The reference preconditions the inner solves 1 and 4 with ILU / AMG of assembled matrices
+// (Trilinos, out of scope here); this engine uses the pointwise Jacobi preconditioner built from
+// the probed operator diagonals instead.  Everything else -- structure, tolerances, the frozen
+// linearisation point of the velocity block (fix_linearization_point) -- follows the reference.
+// ------------------------------------------------------------------------------------------------
+namespace
+{
+  int pc_alloc(adaflo_ctx *ctx, DeviceBuffer &b, const size_t count)
+  {
+    if (b.count == count && b.p)
+      return 0;
+    if (b.p)
+      (void)hipFree(b.p);
+    b.p     = nullptr;
+    b.count = 0;
+    if (hipMalloc(&b.p, count * sizeof(double)) != hipSuccess)
+      return kfail(ctx, ADAFLO_ENOMEM, "out of device memory");
+    b.count = count;
+    return 0;
+  }
+
+  // diag(op) by coloured probing; e, y: work vectors of the operator's size
+  int probe_diagonal(adaflo_ctx *ctx, const Operator &A, double *diag, double *e, double *y, const int degree,
+                     const int ncomp)
+  {
+    const int  nnx = degree * ctx->desc.ncell[0] + 1, nny = degree * ctx->desc.ncell[1] + 1;
+    const long n_nodes = (long)nnx * nny * (degree * ctx->desc.ncell[2] + 1);
+    const int  period = degree + 1;
+    const long n = n_nodes * ncomp;
+    for (int colour = 0; colour < period * period * period; ++colour)
+      for (int comp = 0; comp < ncomp; ++comp)
+        {
+          hipLaunchKernelGGL(probe_fill_kernel, dim3(kgrid(n)), dim3(KT), 0, ctx->stream, e, nnx, nny, n_nodes, ncomp,
+                             period, colour, comp);
+          if (int rc = A(y, e))
+            return rc;
+          hipLaunchKernelGGL(probe_take_kernel, dim3(kgrid(n)), dim3(KT), 0, ctx->stream, diag, y, nnx, nny, n_nodes,
+                             ncomp, period, colour, comp);
+        }
+    return hipGetLastError() == hipSuccess ? 0 : kfail(ctx, ADAFLO_EHIP, "probing kernels failed");
+  }
+
+  int invert_in_place(adaflo_ctx *ctx, double *d, const long n)
+  {
+    return adaflo_invert_diagonal(ctx, d, d, n);
+  }
+} // namespace
+
+int adaflo_ns_preconditioner_setup(adaflo_ctx *ctx)
+{
+  if (!ctx)
+    return ADAFLO_ENOTINIT;
+  const long nu = 3 * ctx->n_nodes_u, np = ctx->n_nodes_p;
+  // NavierStokes::build_preconditioner freezes the linearisation point first (:747-779)
+  if (int rc = adaflo_ns_fix_linearization_point(ctx))
+    return rc;
+  for (DeviceBuffer *b : {&ctx->pc_inv_u, &ctx->pc_tmp_u})
+    if (int rc = pc_alloc(ctx, *b, nu))
+      return rc;
+  for (DeviceBuffer *b : {&ctx->pc_inv_pm, &ctx->pc_inv_pl, &ctx->pc_ones_p, &ctx->pc_tmp_p, &ctx->pc_tmp_p2})
+    if (int rc = pc_alloc(ctx, *b, np))
+      return rc;
+  Workspace w;
+  if (hipMalloc(&w.p, (size_t)nu * sizeof(double)) != hipSuccess)
+    return kfail(ctx, ADAFLO_ENOMEM, "out of device memory");
+  if (int rc = probe_diagonal(ctx, [ctx](double *d, const double *s) { return adaflo_ns_velocity_vmult(ctx, d, s); },
+                              ctx->pc_inv_u.p, ctx->pc_tmp_u.p, w.p, ctx->k, 3))
+    return rc;
+  if (int rc = probe_diagonal(ctx, [ctx](double *d, const double *s) { return adaflo_ns_pressure_mass_vmult(ctx, d, s); },
+                              ctx->pc_inv_pm.p, ctx->pc_tmp_p.p, w.p, ctx->k - 1, 1))
+    return rc;
+  const bool poisson = ctx->ns.density > 0.; // :715
+  if (poisson)
+    if (int rc = probe_diagonal(ctx,
+                                [ctx](double *d, const double *s) { return adaflo_ns_pressure_poisson_vmult(ctx, d, s); },
+                                ctx->pc_inv_pl.p, ctx->pc_tmp_p.p, w.p, ctx->k - 1, 1))
+      return rc;
+  if (int rc = invert_in_place(ctx, ctx->pc_inv_u.p, nu))
+    return rc;
+  if (int rc = invert_in_place(ctx, ctx->pc_inv_pm.p, np))
+    return rc;
+  if (poisson)
+    if (int rc = invert_in_place(ctx, ctx->pc_inv_pl.p, np))
+      return rc;
+  if (launch_fill(ctx, ctx->pc_ones_p.p, 1., np))
+    return kfail(ctx, ADAFLO_EHIP, "fill failed");
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+    return kfail(ctx, ADAFLO_EHIP, "preconditioner setup failed");
+  ctx->pc_ready = true;
+  return 0;
+}
+
+int adaflo_ns_preconditioner_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double *src_u,
+                                   const double *src_p)
+{
+  if (!ctx)
+    return ADAFLO_ENOTINIT;
+  if (!ctx->pc_ready)
+    return kfail(ctx, ADAFLO_ENOTINIT, "call adaflo_ns_preconditioner_setup first");
+  if (!dst_u || !dst_p || !src_u || !src_p)
+    return kfail(ctx, ADAFLO_EINVAL, "null vector");
+  const long nu = 3 * ctx->n_nodes_u, np = ctx->n_nodes_p;
+  adaflo_solver_result res{};
+  if (int rc = pc_alloc(ctx, ctx->pc_work, (size_t)7 * nu)) // Krylov vectors of the inner solves
+    return rc;
+  struct
+  {
+    double *p;
+  } w{ctx->pc_work.p};
+  // 1. velocity block (:636-666)
+  {
+    Krylov K{};
+    K.ctx = ctx;
+    K.n = K.n_block = nu;
+    K.inv_diag      = ctx->pc_inv_u.p;
+    K.A             = [ctx](double *d, const double *s) { return adaflo_ns_velocity_vmult(ctx, d, s); };
+    const double norm = std::sqrt(host_dot(ctx, src_u, src_u, nu));
+    const adaflo_solver_control c{100, 3e-2 * norm, 0.};
+    if (launch_fill(ctx, dst_u, 0., nu))
+      return kfail(ctx, ADAFLO_EHIP, "fill failed");
+    if (int rc = solve_bicgstab(K, dst_u, src_u, c, res, w.p))
+      return rc;
+  }
+  // 2. t = -r_p + B du (:671-672)
+  double *t = ctx->pc_tmp_p.p, *t2 = ctx->pc_tmp_p2.p;
+  hipLaunchKernelGGL(axpby_kernel, dim3(kgrid(np)), dim3(KT), 0, ctx->stream, t, -1., src_p, 0., np);
+  if (int rc = adaflo_ns_divergence_vmult_add(ctx, t, dst_u, 0))
+    return rc;
+  Krylov K{};
+  K.ctx = ctx;
+  K.n = K.n_block = np;
+  // 3. pressure mass (:712, :743-773)
+  {
+    K.inv_diag = ctx->pc_inv_pm.p;
+    K.A        = [ctx](double *d, const double *s) { return adaflo_ns_pressure_mass_vmult(ctx, d, s); };
+    const adaflo_solver_control c{100, 1e-50, 1e-2};
+    if (launch_fill(ctx, dst_p, 0., np))
+      return kfail(ctx, ADAFLO_EHIP, "fill failed");
+    if (int rc = solve_cg(K, dst_p, t, c, res, w.p))
+      return rc;
+  }
+  // 4. pressure Poisson (:715-733); without a constrained pressure face the operator has the
+  // constant in its kernel (the reference pins one entry, constraints_schur_complement_only):
+  // make the right-hand side and the solution mean-free instead
+  if (ctx->ns.density > 0.)
+    {
+      const bool singular = ctx->brick.con_p == 0u;
+      if (singular)
+        {
+          const double m = host_dot(ctx, t, ctx->pc_ones_p.p, np) / (double)np;
+          hipLaunchKernelGGL(shift_kernel, dim3(kgrid(np)), dim3(KT), 0, ctx->stream, t, m, np);
+        }
+      K.inv_diag = ctx->pc_inv_pl.p;
+      K.A        = [ctx](double *d, const double *s) { return adaflo_ns_pressure_poisson_vmult(ctx, d, s); };
+      const double norm = std::sqrt(host_dot(ctx, t, t, np));
+      const adaflo_solver_control c{30, 3e-2 * norm, 0.};
+      if (launch_fill(ctx, t2, 0., np))
+        return kfail(ctx, ADAFLO_EHIP, "fill failed");
+      if (int rc = solve_cg(K, t2, t, c, res, w.p))
+        return rc;
+      if (singular)
+        {
+          const double m = host_dot(ctx, t2, ctx->pc_ones_p.p, np) / (double)np;
+          hipLaunchKernelGGL(shift_kernel, dim3(kgrid(np)), dim3(KT), 0, ctx->stream, t2, m, np);
+        }
+      hipLaunchKernelGGL(axpby_kernel, dim3(kgrid(np)), dim3(KT), 0, ctx->stream, dst_p, 1., t2, 1., np);
+    }
+  return hipGetLastError() == hipSuccess ? 0 : kfail(ctx, ADAFLO_EHIP, "preconditioner kernels failed");
+}
+
+int adaflo_ns_solve_system(adaflo_ctx *ctx, double *update_u, double *update_p, const double *rhs_u,
+                           const double *rhs_p, const adaflo_solver_control *control, int restart,
+                           adaflo_solver_result *result)
+{
+  if (!ctx)
+    return ADAFLO_ENOTINIT;
+  if (!update_u || !update_p || !rhs_u || !rhs_p || !control || !result || restart < 1)
+    return kfail(ctx, ADAFLO_EINVAL, "bad argument");
+  if (!ctx->pc_ready)
+    return kfail(ctx, ADAFLO_ENOTINIT, "call adaflo_ns_preconditioner_setup first");
+  const long nu = 3 * ctx->n_nodes_u, np = ctx->n_nodes_p, n = nu + np;
+  const int  m  = restart;
+  // Krylov basis V_0..V_m and the preconditioned vectors Z_0..Z_{m-1}; block vectors stored [u | p]
+  Workspace w;
+  if (hipMalloc(&w.p, (size_t)(2 * m + 2) * n * sizeof(double)) != hipSuccess)
+    return kfail(ctx, ADAFLO_ENOMEM, "out of device memory for the FGMRES basis");
+  double *V = w.p, *Z = w.p + (size_t)(m + 1) * n, *wv = Z + (size_t)m * n;
+  auto vec = [&](double *base, const int j) { return base + (size_t)j * n; };
+  auto dotn = [&](const double *a, const double *b) { return host_dot(ctx, a, b, n); };
+  auto axpy = [&](double *y, const double a, const double *x, const double bsc) {
+    hipLaunchKernelGGL(axpby_kernel, dim3(kgrid(n)), dim3(KT), 0, ctx->stream, y, a, x, bsc, n);
+  };
+  auto A = [&](double *d, const double *s) { return adaflo_ns_vmult(ctx, d, d + nu, s, s + nu); };
+  auto M = [&](double *d, const double *s) { return adaflo_ns_preconditioner_vmult(ctx, d, d + nu, s, s + nu); };
+
+  // solution_update = 0 (:567); r = rhs
+  (void)launch_fill(ctx, update_u, 0., nu);
+  (void)launch_fill(ctx, update_p, 0., np);
+  double *r = vec(V, 0);
+  (void)hipMemcpyAsync(r, rhs_u, nu * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
+  (void)hipMemcpyAsync(r + nu, rhs_p, np * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
+  double beta = std::sqrt(dotn(r, r));
+  result->initial_residual = beta;
+  result->iterations       = 0;
+  result->converged        = beta <= control->abs_tol;
+  std::vector<double> H((size_t)(m + 1) * m), g(m + 1), cs(m), sn(m), y(m);
+  while (!result->converged && result->iterations < control->max_iterations)
+    {
+      const int mm = std::min(m, control->max_iterations - result->iterations);
+      axpy(vec(V, 0), 1. / beta, vec(V, 0), 0.); // v_0 = r / |r|
+      std::fill(g.begin(), g.end(), 0.);
+      g[0]   = beta;
+      int kk = 0;
+      for (int j = 0; j < mm; ++j)
+        {
+          if (int rc = M(vec(Z, j), vec(V, j)))
+            return rc;
+          if (int rc = A(wv, vec(Z, j)))
+            return rc;
+          for (int i = 0; i <= j; ++i) // modified Gram-Schmidt
+            {
+              const double h = dotn(wv, vec(V, i));
+              H[(size_t)i * m + j] = h;
+              axpy(wv, -h, vec(V, i), 1.);
+            }
+          const double hn          = std::sqrt(dotn(wv, wv));
+          H[(size_t)(j + 1) * m + j] = hn;
+          hipLaunchKernelGGL(axpby_kernel, dim3(kgrid(n)), dim3(KT), 0, ctx->stream, vec(V, j + 1), hn > 0. ? 1. / hn : 1.,
+                             wv, 0., n);
+          for (int i = 0; i < j; ++i) // previous Givens rotations
+            {
+              const double a = H[(size_t)i * m + j], b = H[(size_t)(i + 1) * m + j];
+              H[(size_t)i * m + j]       = cs[i] * a + sn[i] * b;
+              H[(size_t)(i + 1) * m + j] = -sn[i] * a + cs[i] * b;
+            }
+          const double a = H[(size_t)j * m + j], b = H[(size_t)(j + 1) * m + j], d = std::hypot(a, b);
+          cs[j]                      = a / d;
+          sn[j]                      = b / d;
+          H[(size_t)j * m + j]       = d;
+          H[(size_t)(j + 1) * m + j] = 0.;
+          g[j + 1]                   = -sn[j] * g[j];
+          g[j]                       = cs[j] * g[j];
+          kk                         = j + 1;
+          result->iterations++;
+          if (std::fabs(g[j + 1]) <= control->abs_tol)
+            break;
+        }
+      for (int i = kk - 1; i >= 0; --i) // back substitution
+        {
+          double sum = g[i];
+          for (int l = i + 1; l < kk; ++l)
+            sum -= H[(size_t)i * m + l] * y[l];
+          y[i] = sum / H[(size_t)i * m + i];
+        }
+      for (int i = 0; i < kk; ++i)
+        {
+          hipLaunchKernelGGL(axpby_kernel, dim3(kgrid(nu)), dim3(KT), 0, ctx->stream, update_u, y[i], vec(Z, i), 1., nu);
+          hipLaunchKernelGGL(axpby_kernel, dim3(kgrid(np)), dim3(KT), 0, ctx->stream, update_p, y[i], vec(Z, i) + nu, 1.,
+                             np);
+        }
+      // true residual for the restart / the reported value
+      if (int rc = adaflo_ns_vmult(ctx, wv, wv + nu, update_u, update_p))
+        return rc;
+      (void)hipMemcpyAsync(r, rhs_u, nu * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
+      (void)hipMemcpyAsync(r + nu, rhs_p, np * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
+      axpy(r, -1., wv, 1.);
+      beta              = std::sqrt(dotn(r, r));
+      result->converged = beta <= control->abs_tol;
+    }
+  result->final_residual = beta;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+    return kfail(ctx, ADAFLO_EHIP, "FGMRES kernels failed");
   return 0;
 }
 

@@ -1,0 +1,156 @@
+"""Host-side mirror of adaflo::NavierStokes<dim> (source/navier_stokes.cc) for a uniform brick:
+the time loop and the Newton iteration around the operators, with every vector resident in HBM.
+
+    init_time_advance        :659-745   TimeStepping::next, shift of the old solutions, extrapolated
+                                        initial guess, Dirichlet values of the new time level
+    compute_residual         :781-800   residual + mean-value projection of the pressure rows
+    solve_nonlinear_system   :832-960   Newton with the linear tolerance rule of :862-876
+    solve_system             :561-653   FGMRES(50) + NavierStokesPreconditioner with inner solves
+                                        (native: csrc/krylov.hip, adaflo_ns_solve_system)
+    advance_time_step        :964-990
+
+Vectors are torch CUDA tensors (device memory + the small vector algebra of the driver) wrapped
+as DeviceVectors for the engine; the engine runs on torch's current stream."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .navier_stokes_matrix import NavierStokesMatrix
+from .vectors import BlockVector, DeviceVector
+
+
+def gauss_lobatto_points(n):
+    """n Gauss-Lobatto points on [0, 1] (support points of FE_Q(QGaussLobatto(n)), navier_stokes.cc:95)"""
+    if n == 2:
+        return np.array([0.0, 1.0])
+    c = np.zeros(n)
+    c[-1] = 1.0                                   # P_{n-1}
+    inner = np.polynomial.legendre.Legendre(c).deriv().roots()
+    return 0.5 * (np.concatenate([[-1.0], np.sort(inner.real), [1.0]]) + 1.0)
+
+
+def node_coordinates(mesh, degree):
+    """coordinates [n_nodes][3] of the lexicographic nodes of FE_Q(degree) on the brick"""
+    axes = []
+    gl = gauss_lobatto_points(degree + 1)
+    for d in range(3):
+        h = mesh.h[d]
+        x = np.concatenate([[mesh.lower[d]]] + [mesh.lower[d] + h * (c + gl[1:]) for c in range(mesh.ncell[d])])
+        axes.append(x)
+    z, y, x = np.meshgrid(axes[2], axes[1], axes[0], indexing="ij")
+    return np.stack([x.reshape(-1), y.reshape(-1), z.reshape(-1)], axis=1)
+
+
+class NavierStokes:
+    def __init__(self, parameters, mesh, time_stepping, dirichlet_function, device=0):
+        """dirichlet_function(xyz[n][3], t) -> velocity[n][3] on the (all-Dirichlet) boundary"""
+        import torch
+        self.parameters, self.mesh, self.time_stepping = parameters, mesh, time_stepping
+        self.dirichlet_function = dirichlet_function
+        self.device = torch.device("cuda", device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.navier_stokes_matrix = NavierStokesMatrix(parameters, mesh, device=device, stream=stream)
+        self.navier_stokes_matrix.initialize(time_stepping, True)
+        m = self.navier_stokes_matrix
+        k = parameters.velocity_degree
+        self._lib, self._ctx = _lib.load(), m._require()
+        # boundary nodes and their coordinates (apply_boundary_conditions :1216-1257)
+        nn = [k * n + 1 for n in mesh.ncell]
+        idx = np.indices((nn[2], nn[1], nn[0]))
+        on_b = ((idx[0] == 0) | (idx[0] == nn[2] - 1) | (idx[1] == 0) | (idx[1] == nn[1] - 1) |
+                (idx[2] == 0) | (idx[2] == nn[0] - 1)).reshape(-1)
+        self._bnodes = np.nonzero(on_b)[0]
+        self._bxyz = node_coordinates(mesh, k)[self._bnodes]
+        dof = (3 * self._bnodes[:, None] + np.arange(3)[None, :]).reshape(-1)
+        self._bdofs = torch.from_numpy(dof).to(self.device)
+        mk = lambda n: torch.zeros(n, dtype=torch.float64, device=self.device)
+        nu, npp = m.n_dofs_u(), m.n_dofs_p()
+        self.solution = [mk(nu), mk(npp)]
+        self.solution_old = [mk(nu), mk(npp)]
+        self.solution_old_old = [mk(nu), mk(npp)]
+        self.solution_update = [mk(nu), mk(npp)]
+        self.system_rhs = [mk(nu), mk(npp)]
+        self.update_preconditioner = True
+        self.history = []           # (res_u, res_p) per compute_residual, like the reference's table
+        self.linear_iterations = []
+
+    def _bv(self, pair):
+        m = self.navier_stokes_matrix
+        return BlockVector([m.wrap(pair[0]), m.wrap(pair[1])])
+
+    def set_initial_condition(self, u, p):
+        import torch
+        self.solution[0].copy_(torch.from_numpy(np.ascontiguousarray(u, dtype=np.float64)))
+        self.solution[1].copy_(torch.from_numpy(np.ascontiguousarray(p, dtype=np.float64)))
+
+    # ------------------------------------------------------------------------------------------
+    def init_time_advance(self):
+        import torch
+        ts = self.time_stepping
+        ts.next()
+        self.navier_stokes_matrix.update_parameters()
+        for b in range(2):      # :672-686
+            cur, old, oo = self.solution[b], self.solution_old[b], self.solution_old_old[b]
+            tmp = ts.extrapolate(cur, old)
+            oo.copy_(old)
+            old.copy_(cur)
+            cur.copy_(tmp)
+        vals = np.ascontiguousarray(self.dirichlet_function(self._bxyz, ts.now()), dtype=np.float64).reshape(-1)
+        self.solution[0][self._bdofs] = torch.from_numpy(vals).to(self.device)
+        self.update_preconditioner = True
+
+    def compute_residual(self):
+        m = self.navier_stokes_matrix
+        # system_rhs.equ(1., const_rhs) with const_rhs = 0 (:784): the residual cell loop accumulates
+        self.system_rhs[0].zero_()
+        self.system_rhs[1].zero_()
+        m.residual(self._bv(self.system_rhs), self._bv(self.solution), None, self._bv(self.solution_old),
+                   self._bv(self.solution_old_old))
+        m.apply_pressure_average_projection(m.wrap(self.system_rhs[1]))
+        res_u, res_p = float(self.system_rhs[0].norm()), float(self.system_rhs[1].norm())
+        self.history.append((res_u, res_p))
+        return float(np.hypot(res_u, res_p))
+
+    def build_preconditioner(self):
+        _lib.check(self._ctx, self._lib.adaflo_ns_preconditioner_setup(self._ctx))
+        self.update_preconditioner = False
+
+    def solve_system(self, linear_tolerance):
+        p = self.parameters
+        ctl = _lib.SolverControl(p.max_lin_iteration, linear_tolerance, 0.0)
+        res = _lib.SolverResult()
+        upd, rhs = self.solution_update, self.system_rhs
+        _lib.check(self._ctx, self._lib.adaflo_ns_solve_system(
+            self._ctx, upd[0].data_ptr(), upd[1].data_ptr(), rhs[0].data_ptr(), rhs[1].data_ptr(),
+            C.byref(ctl), 50, C.byref(res)))
+        return res.iterations, res.final_residual
+
+    def solve_nonlinear_system(self, initial_residual):
+        p = self.parameters
+        res = initial_residual
+        n_tot = 0
+        for step in range(p.max_nl_iteration):
+            linear_tolerance = p.tol_lin_iteration
+            if p.rel_lin_iteration:     # :862-876
+                newton = p.linearization in ("coupled implicit Newton", "coupled implicit Picard")
+                if res * p.tol_lin_iteration < 0.5 * p.tol_nl_iteration or not newton:
+                    linear_tolerance = 0.5 * p.tol_nl_iteration
+                else:
+                    linear_tolerance = min(p.tol_lin_iteration * res, p.tol_lin_iteration)
+            if step == 0 and self.update_preconditioner:
+                self.build_preconditioner()
+            its, lin_res = self.solve_system(linear_tolerance)
+            self.linear_iterations.append((its, lin_res))
+            n_tot += its
+            self.solution[0] += self.solution_update[0]
+            self.solution[1] += self.solution_update[1]
+            res = self.compute_residual()
+            if res < p.tol_nl_iteration:
+                break
+        return step + 1, n_tot
+
+    def advance_time_step(self):
+        self.init_time_advance()
+        res = self.compute_residual()
+        return self.solve_nonlinear_system(res)

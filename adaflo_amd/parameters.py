@@ -32,6 +32,12 @@ class FlowParameters:
     time_step_size_start: float = 0.05
     time_step_size_max: float = 1e10
     time_step_size_min: float = 0.0
+    # solver section (parameters.cc "Solver": defaults of the reference)
+    max_nl_iteration: int = 10
+    tol_nl_iteration: float = 1e-6
+    max_lin_iteration: int = 500
+    tol_lin_iteration: float = 1e-3
+    rel_lin_iteration: bool = True
 
     def __post_init__(self):
         if self.velocity_degree <= 1:

@@ -296,6 +296,21 @@ int adaflo_solve(adaflo_ctx *ctx, int op, int method, double *x, const double *b
                  const double *inverse_diagonal, const adaflo_solver_control *control,
                  adaflo_solver_result *result);
 
+/* NavierStokes::solve_system (source/navier_stokes.cc:561-653): FGMRES(restart) on adaflo_ns_vmult,
+ * right-preconditioned by NavierStokesPreconditioner::vmult with inner solves
+ * (source/navier_stokes_preconditioner.cc:595-737: velocity block BiCGStab, divergence, pressure
+ * mass CG + pressure Poisson CG).  The reference's ILU / AMG inner preconditioners (Trilinos) are
+ * replaced by Jacobi preconditioners built from the probed operator diagonals.
+ *   adaflo_ns_preconditioner_setup  build_preconditioner (:747-779): fix_linearization_point + diagonals
+ *   control: SolverControl(max_iterations, abs_tol) -- rel_tol is ignored; restart = 50 in the reference
+ *   update_* are overwritten (solution_update = 0 first, :567). */
+int adaflo_ns_preconditioner_setup(adaflo_ctx *ctx);
+int adaflo_ns_preconditioner_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double *src_u,
+                                   const double *src_p);
+int adaflo_ns_solve_system(adaflo_ctx *ctx, double *update_u, double *update_p, const double *rhs_u,
+                           const double *rhs_p, const adaflo_solver_control *control, int restart,
+                           adaflo_solver_result *result);
+
 /* dominant cell-kernel statistics (device time between HIP events recorded on
  * the context's stream around the cell kernel only); used by bench.py for the
  * roofline figure.  Resets like adaflo_ns_get_matvec_statistics.                */

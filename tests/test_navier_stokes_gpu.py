@@ -1,0 +1,52 @@
+"""GPU tier: the reference's own test problem end to end on the device.
+
+tests/beltrami_3d.prm / tests/beltrami.cc: 16^3 Q2/Q1 cells on [-1,1]^3, nu = 1, BDF-2, dt = 0.05,
+Dirichlet values of the exact Beltrami flow, coupled implicit Newton.  Residual, Jacobian
+(vmult on the state the residual stored), FGMRES + block preconditioner with inner CG / BiCGStab
+solves all run in HIP kernels behind the C ABI (adaflo_amd.NavierStokes mirrors
+source/navier_stokes.cc).  Pinned numbers from tests/beltrami_3d.output:
+  line 13: first residual of time step #1   2.590e+00   6.423e-02
+  line 31: first residual of time step #2   2.348e+00   5.678e-02   (after step #1 CONVERGED:
+           independent of the linear solver, unlike the intermediate Newton residuals, which the
+           reference reaches with 30 ILU-preconditioned iterations and an unconverged linear solve)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import adaflo_amd
+from adaflo_amd.navier_stokes import NavierStokes, node_coordinates
+from oracle import oracle as orc     # only the closed-form Beltrami field (test input)
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_outputs.json")
+
+
+def test_beltrami_two_time_steps_reproduce_the_reference_output():
+    with open(GOLDEN) as f:
+        ref = json.load(f)["beltrami_3d"]
+    fp = adaflo_amd.FlowParameters(velocity_degree=2, viscosity=ref["viscosity"], time_step_size_start=ref["dt"],
+                                   end_time=1.0, max_nl_iteration=10, tol_nl_iteration=1e-9,
+                                   max_lin_iteration=100, tol_lin_iteration=1e-5)
+    mesh = adaflo_amd.BrickMesh([16] * 3, [-1.0] * 3, [1.0] * 3)
+    ns = NavierStokes(fp, mesh, adaflo_amd.TimeStepping(fp),
+                      dirichlet_function=lambda x, t: orc.beltrami_u(x, t, ref["viscosity"]).reshape(-1, 3))
+    assert ns.navier_stokes_matrix.n_dofs_u() == ref["dofs_u"] and ns.navier_stokes_matrix.n_dofs_p() == ref["dofs_p"]
+    xu, xp = node_coordinates(mesh, 2), node_coordinates(mesh, 1)
+    ns.set_initial_condition(orc.beltrami_u(xu, 0.0, ref["viscosity"]), orc.beltrami_p(xp, 0.0, ref["viscosity"]))
+    # ---- time step #1
+    n_newton, n_linear = ns.advance_time_step()
+    h = ns.history
+    assert "%.3e" % h[0][0] == ref["first_step_residuals_u"][0] and "%.3e" % h[0][1] == ref["first_step_residuals_p"][0]
+    assert np.hypot(*h[-1]) < 1e-9 and n_newton <= 5           # the reference needs 4 Newton steps
+    # Newton with J = vmult on the stored state: super-linear decrease of the residual
+    assert h[1][0] < 2e-2 and h[2][0] < 1e-4 * h[1][0] * 10
+    assert all(its <= 100 for its, _ in ns.linear_iterations)
+    # ---- time step #2: first residual
+    ns.history.clear()
+    ns.init_time_advance()
+    ns.compute_residual()
+    assert "%.3e" % ns.history[0][0] == ref["second_step_residuals_u"][0]
+    assert "%.3e" % ns.history[0][1] == ref["second_step_residuals_p"][0]
