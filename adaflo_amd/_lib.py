@@ -20,6 +20,12 @@ class LSParams(C.Structure):
                 ("weight_old_old", C.c_double), ("epsilon", C.c_double)]
 
 
+class ForceParams(C.Structure):
+    _fields_ = [("surface_tension", C.c_double), ("gravity", C.c_double), ("density", C.c_double),
+                ("density_diff", C.c_double), ("viscosity", C.c_double), ("viscosity_diff", C.c_double),
+                ("interpolate_grad_onto_pressure", C.c_int)]
+
+
 class SolverControl(C.Structure):
     _fields_ = [("max_iterations", C.c_int), ("abs_tol", C.c_double), ("rel_tol", C.c_double)]
 
@@ -62,6 +68,7 @@ SIGNATURES = {
     "adaflo_ns_set_linearization": (C.c_int, [_CTX, C.c_void_p, C.c_int]),
     "adaflo_ns_get_linearization": (C.c_int, [_CTX, C.c_void_p, C.c_int]),
     "adaflo_ns_set_coefficients": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "adaflo_ns_get_coefficients": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "adaflo_ns_fix_linearization_point": (C.c_int, [_CTX]),
     "adaflo_ns_vmult": (C.c_int, [_CTX, _D, _D, _D, _D]),
     "adaflo_ns_vmult_phase": (C.c_int, [_CTX, _D, _D, _D, _D, C.c_int, C.c_uint]),
@@ -92,6 +99,8 @@ SIGNATURES = {
     "adaflo_ls_compute_curvature_vmult": (C.c_int, [_CTX, _D, _D, C.c_int]),
     "adaflo_ls_compute_curvature_rhs": (C.c_int, [_CTX, _D, _D]),
     "adaflo_set_kernel_variant": (C.c_int, [_CTX, C.c_int]),
+    "adaflo_ls_compute_heaviside": (C.c_int, [_CTX, _D, _D, C.c_double]),
+    "adaflo_ls_compute_force": (C.c_int, [_CTX, _D, _D, _D, C.POINTER(ForceParams)]),
     "adaflo_invert_diagonal": (C.c_int, [_CTX, _D, _D, C.c_int64]),
     "adaflo_ns_preconditioner_setup": (C.c_int, [_CTX]),
     "adaflo_ns_preconditioner_vmult": (C.c_int, [_CTX, _D, _D, _D, _D]),

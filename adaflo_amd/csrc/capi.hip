@@ -257,7 +257,7 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
                           &ctx->pc_ones_p, &ctx->pc_tmp_u, &ctx->pc_tmp_p, &ctx->pc_tmp_p2, &ctx->pc_work})
     release(*b);
   for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch,
-                    ctx->d_tab_ls, ctx->d_ls_diag})
+                    ctx->d_tab_ls, ctx->d_ls_diag, ctx->d_tab_force})
     if (p)
       (void)hipFree(p);
   if (ctx->q2_wg_list)
@@ -429,6 +429,22 @@ int adaflo_ns_set_coefficients(adaflo_ctx *ctx, const double *rho, const double 
   HIP_TRY(ctx, hipMemcpyAsync(ctx->rho.p, rho, count * sizeof(double), kind, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->mu.p, mu, count * sizeof(double), kind, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->damp.p, damping, count * sizeof(double), kind, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int adaflo_ns_get_coefficients(adaflo_ctx *ctx, double *rho, double *mu, double *damping, int dst_on_device)
+{
+  CHECK_CTX(ctx);
+  if (!ctx->rho.p || !ctx->mu.p || !ctx->damp.p)
+    return fail(ctx, ADAFLO_ENOTINIT, "variable coefficients not set");
+  const size_t        count = (size_t)ctx->n_cells * ctx->nq_u;
+  const hipMemcpyKind kind  = dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  double             *dst[3] = {rho, mu, damping};
+  const double       *src[3] = {ctx->rho.p, ctx->mu.p, ctx->damp.p};
+  for (int i = 0; i < 3; ++i)
+    if (dst[i])
+      HIP_TRY(ctx, hipMemcpyAsync(dst[i], src[i], count * sizeof(double), kind, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }
@@ -1043,6 +1059,52 @@ int adaflo_ls_compute_curvature_vmult(adaflo_ctx *ctx, double *dst, const double
 {
   CHECK_CTX(ctx);
   return ls_vmult(ctx, dst, src, 4 /*LS_CURVATURE*/, apply_diffusion, nullptr, 1);
+}
+
+int adaflo_ls_compute_heaviside(adaflo_ctx *ctx, double *heaviside, const double *level_set, double epsilon)
+{
+  CHECK_CTX(ctx);
+  if (int e = ls_ready(ctx))
+    return e;
+  if (!heaviside || !level_set)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  TRY(ctx, launch_ls_heaviside(ctx, heaviside, level_set, epsilon), "heaviside kernels failed");
+  return 0;
+}
+
+int adaflo_ls_compute_force(adaflo_ctx *ctx, double *user_rhs_u, const double *heaviside,
+                            const double *curvature, const adaflo_force_params *p)
+{
+  CHECK_CTX(ctx);
+  if (int e = ls_ready(ctx))
+    return e;
+  if (!user_rhs_u || !heaviside || !curvature || !p)
+    return fail(ctx, ADAFLO_EINVAL, "null argument");
+  if (ctx->k > 4)
+    return fail(ctx, ADAFLO_EUNSUPPORTED, "compute_force: velocity degree <= 4");
+  if (!ctx->d_tab_force)
+    {
+      const std::vector<double> tab = force_tables(ctx->s, ctx->k);
+      TRY(ctx, upload(ctx, &ctx->d_tab_force, tab), ctx->last_error);
+    }
+  const bool variable = p->density_diff != 0. || p->viscosity_diff != 0.; // :333-334
+  if (variable)
+    {
+      const size_t count = (size_t)ctx->n_cells * ctx->nq_u;
+      const bool   had_damping = ctx->damp.p != nullptr;
+      TRY(ctx, alloc(ctx, ctx->rho, count), ctx->last_error);
+      TRY(ctx, alloc(ctx, ctx->mu, count), ctx->last_error);
+      TRY(ctx, alloc(ctx, ctx->damp, count), ctx->last_error);
+      if (!had_damping) // variable_damping_coefficients default to parameters.damping
+        TRY(ctx, launch_fill(ctx, ctx->damp.p, ctx->ns.damping, (long)count), "fill failed");
+      ctx->lin_q2_valid = false; // the streaming copy of the Q2/Q1 kernel carries the coefficients
+    }
+  TRY(ctx,
+      launch_ls_force(ctx, user_rhs_u, heaviside, curvature, ctx->d_tab_force, variable ? ctx->rho.p : nullptr,
+                      variable ? ctx->mu.p : nullptr, p->surface_tension, p->gravity, p->density, p->density_diff,
+                      p->viscosity, p->viscosity_diff, p->interpolate_grad_onto_pressure),
+      "force kernel launch failed");
+  return 0;
 }
 
 int adaflo_ls_compute_curvature_rhs(adaflo_ctx *ctx, double *dst, const double *normal_vector_field)

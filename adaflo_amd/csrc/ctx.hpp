@@ -127,6 +127,7 @@ struct adaflo_ctx
   adaflo_hip::LSDev        ls{};
   double                  *d_tab_ls = nullptr;  // [S D w] of FE_Q_iso_Q1(s) at QIterated(QGauss(2),s), then S of FE_Q(k)
   double                  *d_ls_diag = nullptr; // preconditioner.get_vector() for constrained rows
+  double                  *d_tab_force = nullptr; // 1D tables of local_compute_force (ls_force.hip)
   adaflo_hip::DeviceBuffer ls_convection, ls_normal; // evaluated_convection / evaluated_normal [cell][3][q]
   // structured Q1 sweep kernel (q1_sweep.hip): streaming copies of the two arrays, seam partial sums
   adaflo_hip::DeviceBuffer q1_convection, q1_normal, q1_slab, q1_zslab;

@@ -4,6 +4,8 @@
 #pragma once
 #include "ctx.hpp"
 
+#include <vector>
+
 namespace adaflo_hip
 {
   enum NSOp
@@ -103,6 +105,14 @@ namespace adaflo_hip
   int  q2_prepare_state(adaflo_ctx *ctx);
   int  launch_ns_vmult_q2(adaflo_ctx *ctx, int op, double *dst_u, double *dst_p,
                           const double *src_u, const double *src_p, int phase = -1, uint32_t iface = 0);
+
+  // compute_heaviside / local_compute_force (ls_force.hip)
+  int                 launch_ls_heaviside(adaflo_ctx *ctx, double *heaviside, const double *phi, double epsilon);
+  std::vector<double> force_tables(int s, int k);
+  int launch_ls_force(adaflo_ctx *ctx, double *dst_u, const double *heaviside, const double *curvature,
+                      const double *tab, double *rho, double *mu, double surface_tension, double gravity,
+                      double density, double density_diff, double viscosity, double viscosity_diff,
+                      int on_pressure);
 
   // Q_k/Q_{k-1} sweep kernel for k = 3, 4, 5 (ns_ho.hip), constant coefficients
   bool ho_supported(const adaflo_ctx *ctx);

@@ -17,15 +17,29 @@ from .vectors import DeviceVector
 class LevelSetOperators:
     """owns the engine context for the level-set spaces on a brick (FE_Q_iso_Q1(ls_degree))"""
 
-    def __init__(self, mesh, ls_degree, velocity_degree=2, constrained_faces=(), device=0, stream=None):
+    def __init__(self, mesh, ls_degree, velocity_degree=2, constrained_faces=(), device=0, stream=None,
+                 dirichlet_faces_u=(), navier_stokes_matrix=None):
+        """navier_stokes_matrix: share the engine context of an initialised NavierStokesMatrix that
+        was constructed with ls_degree = this degree, so that compute_force writes the density /
+        viscosity arrays of THAT operator (LevelSetOKZSolver holds a reference to navier_stokes)"""
         self._lib = _lib.load()
         self.mesh, self.s, self.k = mesh, ls_degree, velocity_degree
+        self._owns_ctx = navier_stokes_matrix is None
+        if navier_stokes_matrix is not None:
+            self._ctx = navier_stokes_matrix._require()
+            assert self._lib.adaflo_n_dofs_ls(self._ctx) > 0, "NavierStokesMatrix was built without ls_degree"
+            self.n_dofs = self._lib.adaflo_n_dofs_ls(self._ctx)
+            self.n_q = self._lib.adaflo_n_q_points_ls(self._ctx)
+            self.n_cells = self._lib.adaflo_n_cells(self._ctx)
+            self.cell_diameter, self.minimal_edge_length = max(mesh.h), min(mesh.h)
+            return
         d = _lib.BrickDesc()
         d.dim = 3
         for i in range(3):
             d.ncell[i], d.h[i], d.origin[i] = mesh.ncell[i], mesh.h[i], mesh.lower[i]
         d.velocity_degree, d.ls_degree = velocity_degree, ls_degree
         d.ls_constrained = sum(1 << f for f in constrained_faces)
+        d.velocity_constrained = sum(1 << (3 * f + c) for f in dirichlet_faces_u for c in range(3))
         d.device, d.stream = device, None
         ctx = C.c_void_p()
         code = self._lib.adaflo_ctx_create(C.byref(d), C.byref(ctx))
@@ -44,9 +58,9 @@ class LevelSetOperators:
 
     def __del__(self):
         try:
-            if self._ctx is not None:
+            if self._ctx is not None and self._owns_ctx:
                 self._lib.adaflo_ctx_destroy(self._ctx)
-                self._ctx = None
+            self._ctx = None
         except Exception:
             pass
 
@@ -63,6 +77,20 @@ class LevelSetOperators:
         p = _lib.LSParams(epsilon_used, self.minimal_edge_length, time_step, weight, weight_old,
                           weight_old_old, epsilon)
         _lib.check(self._ctx, self._lib.adaflo_ls_set_params(self._ctx, C.byref(p)))
+
+    def compute_heaviside(self, heaviside, level_set, epsilon):
+        """LevelSetOKZSolver::compute_heaviside, level_set_okz.cc:479-540 (epsilon = parameters.epsilon)"""
+        _lib.check(self._ctx, self._lib.adaflo_ls_compute_heaviside(self._ctx, heaviside.ptr, level_set.ptr, epsilon))
+
+    def compute_force(self, user_rhs_u, heaviside, curvature, parameters):
+        """the cell loop of LevelSetOKZSolver::compute_force, level_set_okz.cc:317-432: adds the
+        surface-tension + gravity force to user_rhs_u (zero it first, :420) and refreshes the
+        variable density / viscosity arrays of the engine context"""
+        p = _lib.ForceParams(parameters.surface_tension, parameters.gravity, parameters.density,
+                             parameters.density_diff, parameters.viscosity, parameters.viscosity_diff,
+                             int(parameters.interpolate_grad_onto_pressure))
+        _lib.check(self._ctx, self._lib.adaflo_ls_compute_force(self._ctx, user_rhs_u.ptr, heaviside.ptr,
+                                                                curvature.ptr, C.byref(p)))
 
     def set_kernel_variant(self, variant):
         """0: generic per-cell kernels, 1 (default): structured Q1 sweep kernel for the operator

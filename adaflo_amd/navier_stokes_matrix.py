@@ -181,6 +181,15 @@ class NavierStokesMatrix:
         _lib.check(ctx, self._lib.adaflo_ns_set_coefficients(
             ctx, arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, 0))
 
+    def get_coefficients(self):
+        """(rho, mu, damping) at the quadrature points, canonical [cell][q]"""
+        ctx = self._require()
+        n = self.n_cells() * self.n_q_points()
+        out = [np.empty(n) for _ in range(3)]
+        _lib.check(ctx, self._lib.adaflo_ns_get_coefficients(ctx, out[0].ctypes.data, out[1].ctypes.data,
+                                                             out[2].ctypes.data, 0))
+        return out
+
     def fix_linearization_point(self):
         _lib.check(self._ctx, self._lib.adaflo_ns_fix_linearization_point(self._require()))
 

@@ -32,6 +32,12 @@ class FlowParameters:
     time_step_size_start: float = 0.05
     time_step_size_max: float = 1e10
     time_step_size_min: float = 0.0
+    # two-phase section (parameters.cc:285-330, defaults of the reference)
+    surface_tension: float = 1.0
+    gravity: float = 0.0
+    epsilon: float = 1.0
+    concentration_subdivisions: int = 2
+    interpolate_grad_onto_pressure: bool = False   # "grad pressure compatible"
     # solver section (parameters.cc "Solver": defaults of the reference)
     max_nl_iteration: int = 10
     tol_nl_iteration: float = 1e-6

@@ -141,6 +141,8 @@ int adaflo_ns_get_linearization(adaflo_ctx *ctx, double *lin, int dst_on_device)
  * all NULL = constant coefficients (use_variable_coefficients() == false).      */
 int adaflo_ns_set_coefficients(adaflo_ctx *ctx, const double *rho, const double *mu,
                                const double *damping, int src_on_device);
+/* read access to the same stores (begin_densities etc.); any pointer may be NULL */
+int adaflo_ns_get_coefficients(adaflo_ctx *ctx, double *rho, double *mu, double *damping, int dst_on_device);
 int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx);       /* :1144-1152 */
 
 /* The same operator in three parts, for overlapping the inter-GPU ghost exchange with the
@@ -242,6 +244,25 @@ int adaflo_ls_compute_normal_rhs(adaflo_ctx *ctx, double *dst, const double *lev
 /* compute_curvature_vmult / local_compute_curvature_rhs  level_set_okz_compute_curvature.cc:263-304, :212-259 */
 int adaflo_ls_compute_curvature_vmult(adaflo_ctx *ctx, double *dst, const double *src, int apply_diffusion);
 int adaflo_ls_compute_curvature_rhs(adaflo_ctx *ctx, double *dst, const double *normal_vector_field);
+
+/* LevelSetOKZSolver::compute_heaviside (source/level_set_okz.cc:479-540) and local_compute_force
+ * (:317-413) -- SURVEY 8f rank 2, the producer of the Navier-Stokes operator's variable density /
+ * viscosity arrays and of the surface-tension + gravity right-hand side.
+ *   heaviside[node] = discrete_heaviside(2 epsilon / s * atanh-distance(level_set[node])) in the cells
+ *     around the interface, 0 / 1 away from it (epsilon = parameters.epsilon, relative width)
+ *   compute_force ADDS (v, surface_tension * kappa * grad H - gravity * rho * e_z) into the
+ *     velocity block user_rhs_u (the reference zeroes navier_stokes.user_rhs before the cell loop)
+ *     and, if density_diff or viscosity_diff is non-zero, overwrites the engine's density /
+ *     viscosity stores (what adaflo_ns_set_coefficients would set) with
+ *     density + density_diff * H(x_q), viscosity + viscosity_diff * H(x_q). */
+typedef struct adaflo_force_params
+{
+  double surface_tension, gravity, density, density_diff, viscosity, viscosity_diff;
+  int    interpolate_grad_onto_pressure; /* "grad pressure compatible" */
+} adaflo_force_params;
+int adaflo_ls_compute_heaviside(adaflo_ctx *ctx, double *heaviside, const double *level_set, double epsilon);
+int adaflo_ls_compute_force(adaflo_ctx *ctx, double *user_rhs_u, const double *heaviside,
+                            const double *curvature, const adaflo_force_params *params);
 
 /* --------------------------------------------------------------------------------------------
  * Krylov drivers with device-resident vectors (callers of the operators above)

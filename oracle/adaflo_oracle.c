@@ -167,17 +167,23 @@ void orc_shape_1d(int fe_type, int degree, int nq, const double *xq, double *S, 
     }
   else
     {
+      /* continuous piecewise-linear hats on s equal sub-intervals.  A point that falls exactly on
+       * a breakpoint (possible only when the space is evaluated at a foreign quadrature, e.g. the
+       * middle Gauss point of QGauss(3) with an even s in local_compute_force) takes the derivative
+       * of the sub-interval to its right -- what deal.II returns there is an implementation detail
+       * of Polynomials::PiecewisePolynomial; the reference's two-phase tests avoid the situation
+       * with "grad pressure compatible = 1". */
       const int s = degree;
       for (int q = 0; q < nq; ++q)
-        for (int i = 0; i < nd; ++i)
-          {
-            double t = xq[q] * s - i; /* hat centred at node i, width 1 in t */
-            double v = 0., d = 0.;
-            if (t > -1. && t <= 0.) { v = 1. + t; d = s; }
-            else if (t > 0. && t < 1.) { v = 1. - t; d = -s; }
-            S[q * nd + i] = v;
-            D[q * nd + i] = d;
-          }
+        {
+          int m = (int)floor(xq[q] * s);
+          if (m >= s) m = s - 1;
+          if (m < 0) m = 0;
+          const double xi = xq[q] * s - m;
+          for (int i = 0; i < nd; ++i) { S[q * nd + i] = 0.; D[q * nd + i] = 0.; }
+          S[q * nd + m] = 1. - xi; S[q * nd + m + 1] = xi;
+          D[q * nd + m] = -(double)s; D[q * nd + m + 1] = (double)s;
+        }
     }
 }
 
@@ -1116,5 +1122,136 @@ int orc_ls_advect_rhs(const orc_mesh *m, const orc_ls_params *P, int ku, int use
     }
   free(l); free(lv); free(v); free(g); free(vo); free(voo); free(uq);
   table_free(&t); table_free(&tv);
+  return 0;
+}
+
+/* ========================================================================= */
+/* LevelSetOKZSolver::compute_heaviside / local_compute_force                 */
+/* (the producer of the variable density / viscosity     */
+/* arrays of the Navier-Stokes operator and of the surface-tension + gravity  */
+/* right-hand side)                                                           */
+/* ========================================================================= */
+
+/* include/adaflo/level_set_base.h:122-144 (integral of Peskin's discrete delta) */
+double orc_discrete_heaviside(double x)
+{
+  if (x > 0) return 1. - orc_discrete_heaviside(-x);
+  else if (x < -2.) return 0.;
+  else if (x < -1.)
+    return (1. / 8. * (5. * x + x * x) + 1. / 32. * (-3. - 2. * x) * sqrt(-7. - 12. * x - 4. * x * x) -
+            1. / 16 * asin(sqrt(2.) * (x + 3. / 2.)) + 23. / 32. - M_PI / 64.);
+  else
+    return (1. / 8. * (3. * x + x * x) - 1. / 32. * (-1. - 2. * x) * sqrt(1. - 4. * x - 4. * x * x) +
+            1. / 16 * asin(sqrt(2.) * (x + 1. / 2.)) + 15. / 32. - M_PI / 64.);
+}
+
+/* source/level_set_okz.cc:479-540.  The reference loops over the cells and lets later cells
+ * overwrite the values of shared nodes; a node that belongs both to a cell near the interface
+ * ("considered": some |phi| < tanh(2)) and to a cell away from it gets the same number from both
+ * whenever 6 epsilon / subdivisions >= 2 (the default epsilon = 1.5 with 4 subdivisions); in
+ * general the result depends on the cell order.  Here the considered cells win. */
+int orc_ls_compute_heaviside(const orc_mesh *m, int s, double epsilon, const double *phi, double *heaviside)
+{
+  const double cutoff = tanh(2.);
+  const int ndc = ipow(s + 1, m->dim);
+  const long nc = n_cells(m);
+  for (int pass = 0; pass < 2; ++pass) /* pass 0: cells away from the interface, pass 1: considered cells */
+    for (long c = 0; c < nc; ++c)
+      {
+        int consider = 0;
+        for (int i = 0; i < ndc; ++i)
+          if (fabs(phi[cell_node(m, s, c, i)]) < cutoff) { consider = 1; break; }
+        if (consider != pass) continue;
+        if (consider)
+          for (int i = 0; i < ndc; ++i)
+            {
+              const long g = cell_node(m, s, c, i);
+              const double cv = phi[g];
+              double distance;
+              if (cv < -cutoff) distance = -3;
+              else if (cv > cutoff) distance = 3;
+              else distance = log((1 + cv) / (1 - cv));
+              distance *= epsilon * 2. / s;
+              heaviside[g] = orc_discrete_heaviside(distance);
+            }
+        else
+          {
+            const double v = phi[cell_node(m, s, c, 0)] < 0 ? 0. : 1.;
+            for (int i = 0; i < ndc; ++i) heaviside[cell_node(m, s, c, i)] = v;
+          }
+      }
+  return 0;
+}
+
+typedef struct
+{
+  double surface_tension, gravity, density, density_diff, viscosity, viscosity_diff;
+  int    interpolate_grad_onto_pressure;
+} orc_force_params;
+
+/* source/level_set_okz.cc:317-413: dst_u += (v, sigma kappa grad H - g rho e_z) at the
+ * quad_index 0 points (ku+1 Gauss points), rho/mu written per quadrature point [cell][q] */
+int orc_ls_compute_force(const orc_mesh *m, int s, int ku, const orc_force_params *P, const double *heaviside,
+                         const double *curvature, double *dst_u, const uint8_t *con_u, double *rho_q,
+                         double *mu_q)
+{
+  const int dim = m->dim, n = ku + 1, kp = ku - 1;
+  orc_table tl, tv, tp;
+  table_init(&tl, dim, ORC_FE_Q_ISO_Q1, s, n, 0);
+  table_init(&tv, dim, ORC_FE_Q, ku, n, 0);
+  table_init(&tp, dim, ORC_FE_Q, kp, n, 0);
+  const int nq = tl.nqc;
+  /* interpolation_concentration_pressure (level_set_base.cc:106-122): level-set shape functions
+   * at the support points of the pressure element, tensor product of a 1D matrix */
+  double xp[ORC_MAX1D], I1[ORC_MAX1D * ORC_MAX1D], dummy[ORC_MAX1D * ORC_MAX1D];
+  if (kp == 0) xp[0] = 0.5; else orc_gauss_lobatto(kp + 1, xp);
+  orc_shape_1d(ORC_FE_Q_ISO_Q1, s, kp + 1, xp, I1, dummy); /* I1[i][j], i pressure node, j ls node */
+  const int variable = P->density_diff != 0. || P->viscosity_diff != 0.;
+  double *l = (double *)malloc(sizeof(double) * tl.ndc), *lc = (double *)malloc(sizeof(double) * tl.ndc);
+  double *lp = (double *)malloc(sizeof(double) * tp.ndc), *lv = (double *)malloc(sizeof(double) * 3 * tv.ndc);
+  double *hv = (double *)malloc(sizeof(double) * nq), *hg = (double *)malloc(sizeof(double) * 3 * nq);
+  double *cv = (double *)malloc(sizeof(double) * nq), *f = (double *)malloc(sizeof(double) * 3 * nq);
+  const long nc = n_cells(m);
+  for (long c = 0; c < nc; ++c)
+    {
+      gather(m, s, 1, c, tl.ndc, heaviside, NULL, l); /* read_dof_values_plain */
+      evaluate(&tl, m, 1, l, hv, hg);
+      if (variable)
+        for (int q = 0; q < nq; ++q)
+          {
+            rho_q[c * nq + q] = P->density + P->density_diff * hv[q];
+            mu_q[c * nq + q]  = P->viscosity + P->viscosity_diff * hv[q];
+          }
+      if (P->interpolate_grad_onto_pressure)
+        {
+          const int np1 = kp + 1, nl1 = s + 1;
+          for (int i = 0; i < tp.ndc; ++i)
+            {
+              const int ii[3] = {i % np1, (i / np1) % np1, i / (np1 * np1)};
+              double v = 0.;
+              for (int j = 0; j < tl.ndc; ++j)
+                {
+                  const int jj[3] = {j % nl1, (j / nl1) % nl1, j / (nl1 * nl1)};
+                  double w = 1.;
+                  for (int e = 0; e < dim; ++e) w *= I1[ii[e] * nl1 + jj[e]];
+                  v += w * l[j];
+                }
+              lp[i] = v;
+            }
+          evaluate(&tp, m, 1, lp, NULL, hg);
+        }
+      gather(m, s, 1, c, tl.ndc, curvature, NULL, lc);
+      evaluate(&tl, m, 1, lc, cv, NULL);
+      for (int q = 0; q < nq; ++q)
+        {
+          const double rho = variable ? rho_q[c * nq + q] : P->density;
+          for (int e = 0; e < dim; ++e) f[e * nq + q] = P->surface_tension * cv[q] * hg[e * nq + q];
+          f[(dim - 1) * nq + q] -= P->gravity * rho;
+        }
+      integrate(&tv, m, dim, f, NULL, lv);
+      scatter_add(m, ku, dim, c, tv.ndc, dst_u, con_u, lv);
+    }
+  free(l); free(lc); free(lp); free(lv); free(hv); free(hg); free(cv); free(f);
+  table_free(&tl); table_free(&tv); table_free(&tp);
   return 0;
 }

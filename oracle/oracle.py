@@ -346,3 +346,40 @@ def make_ls_params(s, epsilon_used, minimal_edge_length, time_step, weight, cell
     p.ls_degree, p.epsilon_used, p.minimal_edge_length = s, epsilon_used, minimal_edge_length
     p.time_step, p.weight, p.cell_diameter, p.epsilon = time_step, weight, cell_diameter, epsilon
     return p
+
+
+# --------------------------------------------------------------------------- compute_force
+class ForceParams(C.Structure):
+    _fields_ = [("surface_tension", C.c_double), ("gravity", C.c_double), ("density", C.c_double),
+                ("density_diff", C.c_double), ("viscosity", C.c_double), ("viscosity_diff", C.c_double),
+                ("interpolate_grad_onto_pressure", C.c_int)]
+
+
+def discrete_heaviside(x):
+    f = lib().orc_discrete_heaviside
+    f.restype = C.c_double
+    return np.array([f(C.c_double(v)) for v in np.atleast_1d(x)])
+
+
+def ls_compute_heaviside(mesh, s, epsilon, phi):
+    out = np.zeros_like(phi)
+    lib().orc_ls_compute_heaviside(C.byref(mesh), s, C.c_double(epsilon), _p(phi), _p(out))
+    return out
+
+
+def ls_compute_force(mesh, s, ku, heaviside, curvature, surface_tension=1.0, gravity=0.0, density=1.0,
+                     density_diff=0.0, viscosity=1.0, viscosity_diff=0.0, interpolate_grad_onto_pressure=False,
+                     con_u=None, dst_u=None):
+    """returns (user_rhs velocity block, rho_q, mu_q); rho_q / mu_q are None for constant parameters"""
+    p = ForceParams(surface_tension, gravity, density, density_diff, viscosity, viscosity_diff,
+                    int(interpolate_grad_onto_pressure))
+    dim = mesh.dim
+    dst = np.zeros(mesh.n_nodes(ku) * dim) if dst_u is None else dst_u.copy()
+    nq = (ku + 1) ** dim
+    variable = density_diff != 0.0 or viscosity_diff != 0.0
+    rho = np.zeros(mesh.n_cells * nq) if variable else None
+    mu = np.zeros(mesh.n_cells * nq) if variable else None
+    rc = lib().orc_ls_compute_force(C.byref(mesh), s, ku, C.byref(p), _p(heaviside), _p(curvature), _p(dst),
+                                    _u8(con_u), _p(rho), _p(mu))
+    assert rc == 0
+    return dst, rho, mu

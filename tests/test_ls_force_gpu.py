@@ -1,0 +1,85 @@
+"""GPU tier: compute_heaviside / local_compute_force (HIP through the C ABI) against the oracle, and
+the hand-off of the density / viscosity arrays they write to the two-phase Navier-Stokes vmult."""
+import numpy as np
+import pytest
+
+import adaflo_amd
+from adaflo_amd import level_set_okz as lso
+from common import rel_l2
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def setup(ncell, s, k, upper=(1., 1., 2.), **fp_kw):
+    lower = (0., 0., 0.)
+    mesh = orc.Mesh.make(list(ncell), lower, upper)
+    bmesh = adaflo_amd.BrickMesh(list(ncell), lower, upper)
+    fp = adaflo_amd.FlowParameters(velocity_degree=k, concentration_subdivisions=s, **fp_kw)
+    return mesh, bmesh, fp
+
+
+@pytest.mark.parametrize("s,k,ncell,eps", [(4, 2, (3, 3, 4), 1.5), (2, 2, (5, 4, 3), 1.0), (3, 3, (2, 3, 2), 1.5), (1, 2, (6, 6, 6), 1.0)])
+def test_compute_heaviside(s, k, ncell, eps):
+    mesh, bmesh, fp = setup(ncell, s, k, upper=(1., 1., 1.))
+    x = orc.node_coordinates(mesh, s, fe_type=1)
+    h = max(mesh.h[d] for d in range(3))
+    dist = np.linalg.norm(x - np.array([0.45, 0.5, 0.55]), axis=1) - 0.27       # sphere (rising_bubble.cc:59-77)
+    phi = np.tanh(dist / (2 * eps * h / s))
+    ops = lso.LevelSetOperators(bmesh, s, velocity_degree=k)
+    H = ops.vector(np.full(phi.size, -7.0))
+    ops.compute_heaviside(H, ops.vector(phi), eps)
+    ref = orc.ls_compute_heaviside(mesh, s, eps, phi)
+    assert np.abs(H.numpy() - ref).max() < 1e-14
+    assert 0.0 < ref.min() + 1e-300 or ref.min() == 0.0
+
+
+@pytest.mark.parametrize("on_pressure", [True, False])
+@pytest.mark.parametrize("s,k,ncell", [(4, 2, (3, 2, 3)), (2, 2, (4, 4, 3)), (2, 3, (3, 2, 2)), (1, 4, (2, 2, 2))])
+def test_compute_force_and_variable_parameters(s, k, ncell, on_pressure):
+    mesh, bmesh, fp = setup(ncell, s, k, surface_tension=0.7, gravity=9.81, density=1.2, density_diff=-0.7,
+                            viscosity=0.05, viscosity_diff=0.2, interpolate_grad_onto_pressure=on_pressure)
+    rng = np.random.default_rng(4)
+    nn = mesh.n_nodes(s)
+    H, kappa = rng.uniform(0, 1, nn), rng.uniform(-3, 3, nn)
+    base = rng.uniform(-1, 1, mesh.n_nodes(k) * 3)
+    con_u = orc.boundary_mask(mesh, k, 3, faces=[0, 1, 4])
+    ref, rho, mu = orc.ls_compute_force(mesh, s, k, H, kappa, surface_tension=0.7, gravity=9.81, density=1.2,
+                                        density_diff=-0.7, viscosity=0.05, viscosity_diff=0.2,
+                                        interpolate_grad_onto_pressure=on_pressure, con_u=con_u, dst_u=base)
+    # one engine context for both operators (LevelSetOKZSolver holds a reference to navier_stokes)
+    ns = adaflo_amd.NavierStokesMatrix(fp, bmesh, dirichlet_faces_u=[0, 1, 4], ls_degree=s)
+    ts = adaflo_amd.TimeStepping(fp)
+    ts.next()
+    ns.initialize(ts, False)
+    ops = lso.LevelSetOperators(bmesh, s, velocity_degree=k, navier_stokes_matrix=ns)
+    rhs = ns.initialize_u_vector(base)
+    ops.compute_force(rhs, ops.vector(H), ops.vector(kappa), fp)
+    assert rel_l2(rhs.numpy(), ref) < TOL
+    got_rho, got_mu, got_damp = ns.get_coefficients()
+    assert rel_l2(got_rho, rho) < TOL and rel_l2(got_mu, mu) < TOL and np.all(got_damp == 0.0)
+    # ... and the Navier-Stokes operator now works with these arrays (two-phase vmult)
+    if k == 2:
+        lin = rng.uniform(-1, 1, mesh.n_cells * 27 * 12)
+        src_u, src_p = rng.uniform(-1, 1, mesh.n_nodes(2) * 3), rng.uniform(-1, 1, mesh.n_nodes(1))
+        ns.set_linearization(lin)
+        dst = ns.block_vector()
+        ns.vmult(dst, ns.block_vector(src_u, src_p))
+        prm = orc.NSParams.make(beta=0.5, density=1.2, viscosity=0.05, density_diff=-0.7, weight=ts.weight(),
+                                weight_old=ts.weight_old(), weight_old_old=ts.weight_old_old())
+        ru, rp = orc.ns_vmult(mesh, 2, prm, src_u, src_p, con_u, None, lin=lin, rho=rho, mu=mu, damp=np.zeros_like(rho))
+        du, dp = dst.numpy()
+        assert rel_l2(du, ru) < TOL and rel_l2(dp, rp) < TOL
+
+
+def test_constant_parameters_leave_the_coefficient_stores_alone():
+    mesh, bmesh, fp = setup((2, 2, 2), 2, 2, surface_tension=1.0, gravity=0.5)
+    rng = np.random.default_rng(5)
+    H, kappa = rng.uniform(0, 1, mesh.n_nodes(2)), rng.uniform(-1, 1, mesh.n_nodes(2))
+    ref, rho, mu = orc.ls_compute_force(mesh, 2, 2, H, kappa, surface_tension=1.0, gravity=0.5)
+    assert rho is None
+    ops = lso.LevelSetOperators(bmesh, 2, velocity_degree=2)
+    rhs = ops.velocity_vector(np.zeros(mesh.n_nodes(2) * 3))
+    ops.compute_force(rhs, ops.vector(H), ops.vector(kappa), fp)
+    assert rel_l2(rhs.numpy(), ref) < TOL
