@@ -125,6 +125,16 @@ def load():
             raise RuntimeError(
                 "HIP engine %s is missing: run `python -m adaflo_amd.build` (hipcc, gfx950). "
                 "There is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: the PyTorch-ROCm wheel ships its own libamdhip64 and the
+        # engine links the one under /opt/rocm.  If the engine's copy initialises the GPU first,
+        # torch later loads a second runtime that sees no device ("No HIP GPUs are available").
+        # Importing torch first makes the dynamic linker resolve the engine's libamdhip64.so.7 to
+        # the copy that is already loaded.  (ADAFLO_NO_TORCH=1: engine-only processes.)
+        if os.environ.get("ADAFLO_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
