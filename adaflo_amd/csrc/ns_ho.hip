@@ -24,6 +24,11 @@
 // (register spills: 65 doubles of values + gradients per thread are live in the quadrature loop)
 // and 2.5 ms at one workgroup per CU, against 2.3 ms of the generic LDS kernel; PMC counters show
 // 72 % of the wave cycles parked in waits (serial stage chain at 1-2 waves per SIMD), not issue.
+// A second design was tried and discarded (not in the tree): four lanes per z-line (three velocity
+// components + pressure, DPP quad broadcasts for the physics as in ns_q2.hip) and [component]
+// [cell][line] regrouping for the LDS sweeps in 1024-thread workgroups.  A lane then holds one
+// component, but still ~150 live registers at k = 4 against the 128-VGPR budget of four waves per
+// SIMD: the spills went to scratch memory and the kernel ran at 14 ms (64^3 Q4/Q3 Newton).
 // The linearisation state is read in the generic layout [cell][12][(k+1)^3] the residual kernel
 // writes: for a fixed component the (k+1)^2 threads of a cell read consecutive doubles.
 #include "basis.hpp"
