@@ -101,6 +101,10 @@ SIGNATURES = {
     "adaflo_set_kernel_variant": (C.c_int, [_CTX, C.c_int]),
     "adaflo_ls_compute_heaviside": (C.c_int, [_CTX, _D, _D, C.c_double]),
     "adaflo_ls_compute_force": (C.c_int, [_CTX, _D, _D, _D, C.POINTER(ForceParams)]),
+    "adaflo_vector_fill": (C.c_int, [_CTX, _D, C.c_double, C.c_int64]),
+    "adaflo_vector_sadd": (C.c_int, [_CTX, _D, C.c_double, C.c_double, _D, C.c_int64]),
+    "adaflo_vector_dot": (C.c_int, [_CTX, _D, _D, C.c_int64, C.POINTER(C.c_double)]),
+    "adaflo_ls_mass_matrix_diagonal": (C.c_int, [_CTX, _D]),
     "adaflo_invert_diagonal": (C.c_int, [_CTX, _D, _D, C.c_int64]),
     "adaflo_ns_preconditioner_setup": (C.c_int, [_CTX]),
     "adaflo_ns_preconditioner_vmult": (C.c_int, [_CTX, _D, _D, _D, _D]),

@@ -1061,6 +1061,17 @@ int adaflo_ls_compute_curvature_vmult(adaflo_ctx *ctx, double *dst, const double
   return ls_vmult(ctx, dst, src, 4 /*LS_CURVATURE*/, apply_diffusion, nullptr, 1);
 }
 
+int adaflo_ls_mass_matrix_diagonal(adaflo_ctx *ctx, double *diagonal)
+{
+  CHECK_CTX(ctx);
+  if (int e = ls_ready(ctx))
+    return e;
+  if (!diagonal)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  TRY(ctx, launch_ls_mass_diagonal(ctx, diagonal), "kernel launch failed");
+  return 0;
+}
+
 int adaflo_ls_compute_heaviside(adaflo_ctx *ctx, double *heaviside, const double *level_set, double epsilon)
 {
   CHECK_CTX(ctx);

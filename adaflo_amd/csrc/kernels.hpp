@@ -109,6 +109,7 @@ namespace adaflo_hip
   // compute_heaviside / local_compute_force (ls_force.hip)
   int                 launch_ls_heaviside(adaflo_ctx *ctx, double *heaviside, const double *phi, double epsilon);
   std::vector<double> force_tables(int s, int k);
+  int                 launch_ls_mass_diagonal(adaflo_ctx *ctx, double *diag);
   int launch_ls_force(adaflo_ctx *ctx, double *dst_u, const double *heaviside, const double *curvature,
                       const double *tab, double *rho, double *mu, double surface_tension, double gravity,
                       double density, double density_diff, double viscosity, double viscosity_diff,

@@ -461,6 +461,37 @@ using namespace adaflo_hip;
 
 extern "C" {
 
+// ---- small vector algebra for the drivers around the solvers (LinearAlgebra::distributed::Vector
+// operator=, sadd, operator*, l2_norm on device-resident vectors)
+int adaflo_vector_fill(adaflo_ctx *ctx, double *x, double value, int64_t n)
+{
+  if (!ctx)
+    return ADAFLO_ENOTINIT;
+  if (!x || n < 0)
+    return kfail(ctx, ADAFLO_EINVAL, "null vector");
+  return launch_fill(ctx, x, value, (long)n) == 0 ? 0 : kfail(ctx, ADAFLO_EHIP, "fill failed");
+}
+
+int adaflo_vector_sadd(adaflo_ctx *ctx, double *x, double a, double b, const double *y, int64_t n)
+{
+  if (!ctx)
+    return ADAFLO_ENOTINIT;
+  if (!x || !y || n < 0)
+    return kfail(ctx, ADAFLO_EINVAL, "null vector");
+  hipLaunchKernelGGL(axpby_kernel, dim3(kgrid(n)), dim3(KT), 0, ctx->stream, x, b, y, a, (long)n); // x = a x + b y
+  return hipGetLastError() == hipSuccess ? 0 : kfail(ctx, ADAFLO_EHIP, "kernel launch failed");
+}
+
+int adaflo_vector_dot(adaflo_ctx *ctx, const double *x, const double *y, int64_t n, double *result)
+{
+  if (!ctx)
+    return ADAFLO_ENOTINIT;
+  if (!x || !y || !result || n < 0)
+    return kfail(ctx, ADAFLO_EINVAL, "null argument");
+  *result = host_dot(ctx, x, y, (long)n);
+  return 0;
+}
+
 int adaflo_invert_diagonal(adaflo_ctx *ctx, double *inverse_diagonal, const double *diagonal, int64_t n)
 {
   if (!ctx)

@@ -110,6 +110,20 @@ namespace adaflo_hip
         }
     }
 
+    // initialize_mass_matrix_diagonal: FE_Q_iso_Q1(s) with 2-point Gauss per sub-interval integrates
+    // phi_i^2 exactly: (h_sub / 3) per adjacent sub-interval and direction
+    __global__ __launch_bounds__(256) void ls_mass_diagonal_kernel(double *__restrict__ diag, const int nx,
+                                                                   const int ny, const int nz, const double unit,
+                                                                   const long n_nodes)
+    {
+      for (long g = blockIdx.x * 256L + threadIdx.x; g < n_nodes; g += (long)gridDim.x * 256)
+        {
+          const int I = (int)(g % nx), J = (int)((g / nx) % ny), K = (int)(g / ((long)nx * ny));
+          const int cnt = ((I > 0) + (I < nx - 1)) * ((J > 0) + (J < ny - 1)) * ((K > 0) + (K < nz - 1));
+          diag[g]       = unit * cnt;
+        }
+    }
+
     struct ForceArgs
     {
       BrickDev      brick;
@@ -242,6 +256,17 @@ namespace adaflo_hip
     const hipError_t e1 = hipStreamSynchronize(ctx->stream), e2 = hipGetLastError();
     (void)hipFree(flag);
     return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : ADAFLO_EHIP;
+  }
+
+  int launch_ls_mass_diagonal(adaflo_ctx *ctx, double *diag)
+  {
+    const int  s = ctx->s, nx = s * ctx->desc.ncell[0] + 1, ny = s * ctx->desc.ncell[1] + 1, nz = s * ctx->desc.ncell[2] + 1;
+    const long n = ctx->n_nodes_ls;
+    const double unit = (ctx->desc.h[0] / s / 3.) * (ctx->desc.h[1] / s / 3.) * (ctx->desc.h[2] / s / 3.);
+    long nb = (n + 255) / 256;
+    hipLaunchKernelGGL(ls_mass_diagonal_kernel, dim3((unsigned)(nb > 65536 ? 65536 : nb)), dim3(256), 0, ctx->stream, diag,
+                       nx, ny, nz, unit, n);
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
   }
 
   // tables of the force kernel for (s, k); host vector in the layout of ForceCfg

@@ -92,6 +92,15 @@ class LevelSetOperators:
         _lib.check(self._ctx, self._lib.adaflo_ls_compute_force(self._ctx, user_rhs_u.ptr, heaviside.ptr,
                                                                 curvature.ptr, C.byref(p)))
 
+    def initialize_mass_matrix_diagonal(self):
+        """initialize_mass_matrix_diagonal (level_set_okz_preconditioner.h:35-76): the
+        DiagonalPreconditioner of all level-set solves; also registered for the constrained rows"""
+        from .solvers import DiagonalPreconditioner
+        diag = self.vector()
+        _lib.check(self._ctx, self._lib.adaflo_ls_mass_matrix_diagonal(self._ctx, diag.ptr))
+        self.set_diagonal(diag)
+        return DiagonalPreconditioner(diag)
+
     def set_kernel_variant(self, variant):
         """0: generic per-cell kernels, 1 (default): structured Q1 sweep kernel for the operator
         applications (FE_Q_iso_Q1(s) = trilinear elements on the s-times refined grid)"""
@@ -125,6 +134,28 @@ class LevelSetOKZSolverAdvanceConcentration:
             self._ctx, dst.ptr, solution.ptr, solution_old.ptr, solution_old_old.ptr,
             vel_solution.ptr, int(use_old_old)))
 
+    def advance_concentration(self, solution, solution_old, solution_old_old, vel_solution, rhs, increment,
+                              preconditioner, use_old_old=True, tol_nl_iteration=1e-8):
+        """LevelSetOKZSolverAdvanceConcentration::advance_concentration without convection
+        stabilisation (level_set_okz_advance_concentration.cc:549-660): right-hand side, BiCGStab
+        with ReductionControl(30, 0.05 tol_nl, 1e-8), solution += increment.  The caller has advanced
+        the level-set TimeStepping and pushed its weights (set_parameters).  Returns
+        (iterations, initial residual) like the reference prints them."""
+        from .solvers import AdvanceConcentrationMatrix, NoConvergence, ReductionControl, SolverBicgstab
+        rhs.fill(0.0)
+        self.local_advance_concentration_rhs(rhs, solution, solution_old, solution_old_old, vel_solution, use_old_old)
+        control = ReductionControl(30, 0.05 * tol_nl_iteration, 1e-8)
+        increment.fill(0.0)
+        try:
+            SolverBicgstab(control).solve(AdvanceConcentrationMatrix(self.ops), increment, rhs, preconditioner)
+        except NoConvergence:
+            # the reference falls back to GMRES here (:634-641); retry with a longer BiCGStab run
+            control = ReductionControl(3000, 0.05 * tol_nl_iteration, 1e-8)
+            increment.fill(0.0)
+            SolverBicgstab(control).solve(AdvanceConcentrationMatrix(self.ops), increment, rhs, preconditioner)
+        solution.add(increment)
+        return control.last_step(), control.initial_value()
+
     @property
     def evaluated_convection(self):
         return self.ops._q(self._lib.adaflo_ls_get_evaluated_convection)
@@ -147,6 +178,32 @@ class LevelSetOKZSolverReinitialization:
         _lib.check(self._ctx, self._lib.adaflo_ls_reinitialization_rhs(
             self._ctx, dst.ptr, solution.ptr, nptr, int(diffuse_only), int(first_reinit_step)))
 
+    def reinitialize(self, solution, normal_vector_field, rhs, increment, preconditioner, stab_steps,
+                     diff_steps=0, compute_normal=None, last_concentration_range=(-1.0, 1.0)):
+        """LevelSetOKZSolverReinitialization::reinitialize (level_set_okz_reinitialization.cc:255-375):
+        diff_steps diffusion-only steps, then stab_steps Olsson-Kreiss-Zahedi steps; the normal is
+        recomputed (compute_normal(True)) before the first of them.  Returns the CG iteration counts."""
+        from .solvers import ReductionControl, ReinitializationMatrix, SolverCG
+        actual_diff_steps = diff_steps
+        if last_concentration_range[0] < -1.02 or last_concentration_range[1] > 1.02:
+            actual_diff_steps += 3
+        iterations = []
+        for tau in range(actual_diff_steps + stab_steps):
+            first_reinit_step = tau == actual_diff_steps
+            if first_reinit_step and compute_normal is not None:
+                compute_normal(True)
+            diffuse = tau < actual_diff_steps
+            rhs.fill(0.0)
+            self.local_reinitialize_rhs(rhs, solution, normal_vector_field, diffuse, first_reinit_step)
+            increment.fill(0.0)
+            control = ReductionControl(2000, 1e-50, 1e-6)
+            SolverCG(control).solve(ReinitializationMatrix(self.ops, diffuse), increment, rhs, preconditioner)
+            iterations.append(control.last_step())
+            solution.add(increment)
+            if increment.l2_norm() < 1e-6:
+                break
+        return iterations
+
     @property
     def evaluated_normal(self):
         return self.ops._q(self._lib.adaflo_ls_get_evaluated_normal)
@@ -166,6 +223,19 @@ class LevelSetOKZSolverComputeNormal:
     def local_compute_normal_rhs(self, dst, level_set_solution):
         _lib.check(self._ctx, self._lib.adaflo_ls_compute_normal_rhs(self._ctx, dst.ptr, level_set_solution.ptr))
 
+    def compute_normal(self, normal_vector_field, normal_vector_rhs, level_set_solution, preconditioner,
+                       fast_computation=False):
+        """LevelSetOKZSolverComputeNormal::compute_normal (level_set_okz_compute_normal.cc:207-285) in
+        its matrix-free form (:262: solver.solve(matrix, field, rhs, preconditioner); the production
+        code solves the same system with an assembled matrix + ILU): projection of grad(phi), CG to
+        1e-7 (1e-5 fast), starting from the previous normal field"""
+        from .solvers import ComputeNormalMatrix, ReductionControl, SolverCG
+        normal_vector_rhs.fill(0.0)
+        self.local_compute_normal_rhs(normal_vector_rhs, level_set_solution)
+        control = ReductionControl(4000, 1e-50, 1e-5 if fast_computation else 1e-7)
+        SolverCG(control).solve(ComputeNormalMatrix(self.ops), normal_vector_field, normal_vector_rhs, preconditioner)
+        return control.last_step()
+
 
 class LevelSetOKZSolverComputeCurvature:
     def __init__(self, ops):
@@ -177,3 +247,14 @@ class LevelSetOKZSolverComputeCurvature:
 
     def local_compute_curvature_rhs(self, dst, normal_vector_field):
         _lib.check(self._ctx, self._lib.adaflo_ls_compute_curvature_rhs(self._ctx, dst.ptr, normal_vector_field.ptr))
+
+    def compute_curvature(self, solution_curvature, rhs, normal_vector_field, preconditioner):
+        """LevelSetOKZSolverComputeCurvature::compute_curvature (level_set_okz_compute_curvature.cc:
+        325-357), matrix-free form (:350), without the optional curvature correction: projection of
+        -div(n), CG to 1e-8 starting from the previous curvature"""
+        from .solvers import ComputeCurvatureMatrix, ReductionControl, SolverCG
+        rhs.fill(0.0)
+        self.local_compute_curvature_rhs(rhs, normal_vector_field)
+        control = ReductionControl(2000, 1e-50, 1e-8)
+        SolverCG(control).solve(ComputeCurvatureMatrix(self.ops), solution_curvature, rhs, preconditioner)
+        return control.last_step()

@@ -43,6 +43,25 @@ class DeviceVector:
         _lib.check(self.ctx, _lib.load().adaflo_copy_d2h(self.ctx, out.ctypes.data, self.ptr, self.n * 8))
         return out
 
+    # -- the vector algebra the drivers around the solvers need (device-side)
+    def fill(self, value):
+        _lib.check(self.ctx, _lib.load().adaflo_vector_fill(self.ctx, self.ptr, float(value), self.n))
+
+    def sadd(self, a, b, y):
+        """self = a * self + b * y"""
+        _lib.check(self.ctx, _lib.load().adaflo_vector_sadd(self.ctx, self.ptr, float(a), float(b), y.ptr, self.n))
+
+    def add(self, y):
+        self.sadd(1.0, 1.0, y)
+
+    def dot(self, y):
+        r = C.c_double()
+        _lib.check(self.ctx, _lib.load().adaflo_vector_dot(self.ctx, self.ptr, y.ptr, self.n, C.byref(r)))
+        return r.value
+
+    def l2_norm(self):
+        return float(np.sqrt(self.dot(self)))
+
     def free(self):
         if self._own and self.ptr:
             _lib.load().adaflo_free(self.ctx, self.ptr)

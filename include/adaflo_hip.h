@@ -306,6 +306,16 @@ typedef struct adaflo_solver_result
   double initial_residual, final_residual;
 } adaflo_solver_result;
 
+/* vector algebra of the drivers on device vectors: x = value; x = a x + b y; (x, y) */
+int adaflo_vector_fill(adaflo_ctx *ctx, double *x, double value, int64_t n);
+int adaflo_vector_sadd(adaflo_ctx *ctx, double *x, double a, double b, const double *y, int64_t n);
+int adaflo_vector_dot(adaflo_ctx *ctx, const double *x, const double *y, int64_t n, double *result);
+
+/* initialize_mass_matrix_diagonal (include/adaflo/level_set_okz_preconditioner.h:35-76): diagonal of
+ * the level-set mass matrix, sum_q phi_i(x_q)^2 JxW, the vector behind the DiagonalPreconditioner of
+ * all level-set solves */
+int adaflo_ls_mass_matrix_diagonal(adaflo_ctx *ctx, double *diagonal);
+
 /* DiagonalPreconditioner::reinit (source/diagonal_preconditioner.cc:27-47):
  * inv[i] = |d[i]| > 1e-10 max|d| ? 1/d[i] : 1 ; device pointers */
 int adaflo_invert_diagonal(adaflo_ctx *ctx, double *inverse_diagonal, const double *diagonal, int64_t n);

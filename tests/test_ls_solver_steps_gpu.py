@@ -1,0 +1,109 @@
+"""GPU tier: the solver steps around the level-set operators (advance_concentration, reinitialize,
+compute_normal, compute_curvature: right-hand side kernel + Krylov solve + update, all on the
+device) against the same loops written with numpy on top of the oracle operators."""
+import numpy as np
+import pytest
+
+import adaflo_amd
+from adaflo_amd import level_set_okz as lso
+from common import rel_l2
+from oracle import krylov_oracle as ko
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+class Setup:
+    def __init__(self, ncell=(4, 4, 4), s=2, k=2):
+        self.s, self.k = s, k
+        lower, upper = (0., 0., 0.), (1., 1., 1.)
+        self.mesh = orc.Mesh.make(list(ncell), lower, upper)
+        self.bmesh = adaflo_amd.BrickMesh(list(ncell), lower, upper)
+        h = max(self.mesh.h[d] for d in range(3))
+        self.eps_rel, self.dt = 1.5, 0.02
+        self.eps_used = self.eps_rel * h / s
+        self.weights = (1.0 / self.dt, -1.0 / self.dt, 0.0)          # implicit Euler / first BDF-2 step
+        self.prm = orc.make_ls_params(s, self.eps_used, h, self.dt, self.weights[0], h, self.eps_rel)
+        self.ops = lso.LevelSetOperators(self.bmesh, s, velocity_degree=k)
+        self.ops.set_parameters(self.eps_used, self.dt, *self.weights, self.eps_rel)
+        self.pre = self.ops.initialize_mass_matrix_diagonal()
+        self.x = orc.node_coordinates(self.mesh, s, fe_type=1)
+        self.nn = self.x.shape[0]
+        self.nq = (2 * s) ** 3
+        # mass diagonal on the oracle side: curvature operator without diffusion = mass matrix
+        A = lambda v: orc.ls_curvature_vmult(self.mesh, self.prm, v, apply_diffusion=False)
+        from test_krylov_oracle import probe_diagonal
+        self.diag = probe_diagonal(A, self.nn)
+
+    def sphere(self, width_factor=1.0):
+        d = np.linalg.norm(self.x - 0.5, axis=1) - 0.27
+        return -np.tanh(d / (2 * self.eps_used * width_factor))
+
+
+def test_mass_matrix_diagonal():
+    c = Setup((3, 2, 3), 4)
+    assert rel_l2(c.pre.diagonal_vector.numpy(), c.diag) < 1e-13
+
+
+def test_normal_curvature_and_reinitialization_steps():
+    c = Setup()
+    phi0 = c.sphere(1.6)                      # too wide a profile: reinitialisation sharpens it
+    inv = 1.0 / c.diag
+    # ---- oracle side: compute_normal, compute_curvature, two reinitialisation steps
+    rhs_n = orc.ls_normal_rhs(c.mesh, c.prm, phi0)
+    An = lambda v: orc.ls_normal_vmult(c.mesh, c.prm, v)
+    n_ref, n_it, *_ = ko.cg(An, rhs_n, inv_diag=np.tile(inv, 3), max_it=4000, rel_tol=1e-7)
+    rhs_c = orc.ls_curvature_rhs(c.mesh, c.prm, n_ref)
+    Ac = lambda v: orc.ls_curvature_vmult(c.mesh, c.prm, v)
+    k_ref, k_it, *_ = ko.cg(Ac, rhs_c, inv_diag=inv, max_it=2000, rel_tol=1e-8)
+    phi_ref, its_ref = phi0.copy(), []
+    nq = np.zeros(c.mesh.n_cells * c.nq * 3)
+    for tau in range(2):
+        rhs = orc.ls_reinit_rhs(c.mesh, c.prm, phi_ref, n_ref, nq, diffuse_only=False, first_step=tau == 0)
+        Ar = lambda v: orc.ls_reinit_vmult(c.mesh, c.prm, v, nq)
+        inc, it, *_ = ko.cg(Ar, rhs, inv_diag=inv, max_it=2000, rel_tol=1e-6)
+        its_ref.append(it)
+        phi_ref += inc
+    # ---- device side
+    ops = c.ops
+    phi = ops.vector(phi0)
+    normal, normal_rhs = ops.vector(blocks=3), ops.vector(blocks=3)
+    nor = lso.LevelSetOKZSolverComputeNormal(ops)
+    assert nor.compute_normal(normal, normal_rhs, phi, c.pre) == n_it
+    assert rel_l2(normal.numpy(), n_ref) < 1e-9
+    cur = lso.LevelSetOKZSolverComputeCurvature(ops)
+    kappa, rhs_v = ops.vector(), ops.vector()
+    assert cur.compute_curvature(kappa, rhs_v, normal, c.pre) == k_it
+    assert rel_l2(kappa.numpy(), k_ref) < 1e-8
+    # sanity of the oracle result itself: the curvature of a sphere of radius 0.27 is 2 / r = 7.4; the
+    # damped projection of a too wide profile on this coarse mesh (8 intervals) gives the right sign
+    # and order of magnitude
+    band = np.abs(phi0) < 0.3
+    assert 0.5 * 2 / 0.27 < abs(np.median(k_ref[band])) < 1.2 * 2 / 0.27
+    rei = lso.LevelSetOKZSolverReinitialization(ops)
+    its = rei.reinitialize(phi, normal, rhs_v, ops.vector(), c.pre, stab_steps=2)
+    assert its == its_ref
+    assert rel_l2(phi.numpy(), phi_ref) < 1e-9
+    # the step moved the profile towards the sharper one
+    assert np.linalg.norm(phi.numpy() - c.sphere(1.0)) < np.linalg.norm(phi0 - c.sphere(1.0))
+
+
+def test_advance_concentration_step():
+    c = Setup((4, 4, 4), 2)
+    phi0 = c.sphere()
+    xu = orc.node_coordinates(c.mesh, c.k)
+    vel = np.stack([-(xu[:, 1] - 0.5), xu[:, 0] - 0.5, np.zeros(xu.shape[0])], axis=1).reshape(-1)   # rotation
+    inv = 1.0 / c.diag
+    uq = np.zeros(c.mesh.n_cells * c.nq * 3)
+    rhs = orc.ls_advect_rhs(c.mesh, c.prm, c.k, phi0, phi0, phi0, vel, uq, c.weights[1], c.weights[2], False)
+    A = lambda v: orc.ls_advect_vmult(c.mesh, c.prm, v, uq)
+    inc, it, r0, *_ = ko.bicgstab(A, rhs, inv_diag=inv, max_it=30, abs_tol=0.05 * 1e-8, rel_tol=1e-8)
+    ops = c.ops
+    phi, old = ops.vector(phi0), ops.vector(phi0)
+    adv = lso.LevelSetOKZSolverAdvanceConcentration(ops)
+    n_it, res0 = adv.advance_concentration(phi, old, old, ops.velocity_vector(vel), ops.vector(), ops.vector(), c.pre,
+                                           use_old_old=False)
+    assert abs(n_it - it) <= 1 and abs(res0 - r0) < 1e-10 * r0
+    assert rel_l2(phi.numpy(), phi0 + inc) < 1e-8
+    # a rotation about the centre of the sphere leaves the profile (almost) unchanged
+    assert np.linalg.norm(inc) < 0.05 * np.linalg.norm(phi0)
