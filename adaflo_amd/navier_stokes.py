@@ -43,14 +43,16 @@ def node_coordinates(mesh, degree):
 
 
 class NavierStokes:
-    def __init__(self, parameters, mesh, time_stepping, dirichlet_function, device=0):
-        """dirichlet_function(xyz[n][3], t) -> velocity[n][3] on the (all-Dirichlet) boundary"""
+    def __init__(self, parameters, mesh, time_stepping, dirichlet_function, device=0, ls_degree=0):
+        """dirichlet_function(xyz[n][3], t) -> velocity[n][3] on the (all-Dirichlet) boundary;
+        ls_degree > 0 adds the level-set spaces to the engine context (two-phase flow)"""
         import torch
         self.parameters, self.mesh, self.time_stepping = parameters, mesh, time_stepping
         self.dirichlet_function = dirichlet_function
         self.device = torch.device("cuda", device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        self.navier_stokes_matrix = NavierStokesMatrix(parameters, mesh, device=device, stream=stream)
+        self.navier_stokes_matrix = NavierStokesMatrix(parameters, mesh, device=device, stream=stream,
+                                                       ls_degree=ls_degree)
         self.navier_stokes_matrix.initialize(time_stepping, True)
         m = self.navier_stokes_matrix
         k = parameters.velocity_degree
@@ -71,6 +73,7 @@ class NavierStokes:
         self.solution_old_old = [mk(nu), mk(npp)]
         self.solution_update = [mk(nu), mk(npp)]
         self.system_rhs = [mk(nu), mk(npp)]
+        self.user_rhs = [mk(nu), mk(npp)]     # surface tension + gravity (LevelSetOKZSolver::compute_force)
         self.update_preconditioner = True
         self.history = []           # (res_u, res_p) per compute_residual, like the reference's table
         self.linear_iterations = []
@@ -105,8 +108,8 @@ class NavierStokes:
         # system_rhs.equ(1., const_rhs) with const_rhs = 0 (:784): the residual cell loop accumulates
         self.system_rhs[0].zero_()
         self.system_rhs[1].zero_()
-        m.residual(self._bv(self.system_rhs), self._bv(self.solution), None, self._bv(self.solution_old),
-                   self._bv(self.solution_old_old))
+        m.residual(self._bv(self.system_rhs), self._bv(self.solution), self._bv(self.user_rhs),
+                   self._bv(self.solution_old), self._bv(self.solution_old_old))
         m.apply_pressure_average_projection(m.wrap(self.system_rhs[1]))
         res_u, res_p = float(self.system_rhs[0].norm()), float(self.system_rhs[1].norm())
         self.history.append((res_u, res_p))

