@@ -254,7 +254,8 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
                           &ctx->q2_slab_u, &ctx->q2_zslab_u, &ctx->q2_slab_p, &ctx->q2_zslab_p,
                           &ctx->ls_convection, &ctx->ls_normal, &ctx->q1_convection, &ctx->q1_normal,
                           &ctx->q1_slab, &ctx->q1_zslab, &ctx->pc_inv_u, &ctx->pc_inv_pm, &ctx->pc_inv_pl,
-                          &ctx->pc_ones_p, &ctx->pc_tmp_u, &ctx->pc_tmp_p, &ctx->pc_tmp_p2, &ctx->pc_work})
+                          &ctx->pc_ones_p, &ctx->pc_tmp_u, &ctx->pc_tmp_p, &ctx->pc_tmp_p2, &ctx->pc_work,
+                          &ctx->q1_poisson_coef})
     release(*b);
   for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch,
                     ctx->d_tab_ls, ctx->d_ls_diag, ctx->d_tab_force})
@@ -410,7 +411,8 @@ int adaflo_ns_set_coefficients(adaflo_ctx *ctx, const double *rho, const double 
 {
   CHECK_CTX(ctx);
   const size_t count = (size_t)ctx->n_cells * ctx->nq_u;
-  ctx->lin_q2_valid = false; // the streaming copy of the Q2/Q1 kernel carries the coefficients
+  ctx->lin_q2_valid   = false; // the streaming copy of the Q2/Q1 kernel carries the coefficients
+  ctx->q1_poisson_src = nullptr;
   if (!rho && !mu && !damping)
     {
       release(ctx->rho);
@@ -461,6 +463,7 @@ int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx)
         HIP_TRY(ctx, hipMemcpyAsync(dst[i]->p, src[i]->p, src[i]->count * sizeof(double),
                                     hipMemcpyDeviceToDevice, ctx->stream));
     }
+  ctx->q1_poisson_src = nullptr; // the frozen density copy may have changed content
   // keep a frozen copy in the streaming layout of the Q2/Q1 kernel as well
   if (q2_supported(ctx) && ctx->lin.p && needs_lin(ctx))
     {
@@ -660,6 +663,22 @@ int adaflo_ns_pressure_poisson_vmult(adaflo_ctx *ctx, double *dst_p, const doubl
           "pressure kernel launch failed");
       return 0;
     }
+  if (ctx->variant >= 1 && ctx->k == 2 && full)
+    {
+      // variable density at the 27 points of quad_index_u (:984-1000): structured sweep kernel on the
+      // coefficient 1 / (weight rho) re-laid out once per density field / time-step weight
+      if (ctx->q1_poisson_src != rho || ctx->q1_poisson_weight != ctx->ns.weight || !ctx->q1_poisson_coef.p)
+        {
+          TRY(ctx, q1_convert_poisson_coef(ctx, ctx->q1_poisson_coef, rho, ctx->ns.weight), "coefficient re-layout failed");
+          ctx->q1_poisson_src    = rho;
+          ctx->q1_poisson_weight = ctx->ns.weight;
+        }
+      TRY(ctx,
+          launch_q1_sweep(ctx, 1, Q1_LAPLACE_Q3, 0., 0., 0., ctx->brick.con_p, 1., nullptr, dst_p, src_p,
+                          ctx->q1_poisson_coef.p),
+          "pressure kernel launch failed");
+      return 0;
+    }
   return scalar_op(ctx, dst_p, src_p, full ? SC_POISSON_VARIABLE : SC_POISSON_CELL, var ? rho : nullptr,
                    full, true);
 }
@@ -705,6 +724,16 @@ int adaflo_ns_pressure_mass_vmult(adaflo_ctx *ctx, double *dst_p, const double *
                          1. / (P.viscosity + P.tau_grad_div);
       TRY(ctx,
           launch_q1_sweep(ctx, 1, Q1_MASS_LAPLACE, c, 0., 0., ctx->brick.con_p, 1., nullptr, dst_p, src_p, nullptr),
+          "pressure kernel launch failed");
+      return 0;
+    }
+  if (ctx->variant >= 1 && ctx->k == 2 && mu &&
+      !(ctx->ns.linearization == ADAFLO_PROJECTION || ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE_STATIONARY))
+    {
+      // per-cell viscosity sample (:1057-1066): c = 1 / (mu(mid point) + tau_grad_div)
+      TRY(ctx,
+          launch_q1_sweep(ctx, 1, Q1_MASS_LAPLACE, 1., 0., 0., ctx->brick.con_p, 1., nullptr, dst_p, src_p, nullptr, 1,
+                          mu, ctx->nq_u, ctx->nq_u / 2, ctx->ns.tau_grad_div),
           "pressure kernel launch failed");
       return 0;
     }
@@ -1108,7 +1137,8 @@ int adaflo_ls_compute_force(adaflo_ctx *ctx, double *user_rhs_u, const double *h
       TRY(ctx, alloc(ctx, ctx->damp, count), ctx->last_error);
       if (!had_damping) // variable_damping_coefficients default to parameters.damping
         TRY(ctx, launch_fill(ctx, ctx->damp.p, ctx->ns.damping, (long)count), "fill failed");
-      ctx->lin_q2_valid = false; // the streaming copy of the Q2/Q1 kernel carries the coefficients
+      ctx->lin_q2_valid   = false; // the streaming copy of the Q2/Q1 kernel carries the coefficients
+      ctx->q1_poisson_src = nullptr;
     }
   TRY(ctx,
       launch_ls_force(ctx, user_rhs_u, heaviside, curvature, ctx->d_tab_force, variable ? ctx->rho.p : nullptr,

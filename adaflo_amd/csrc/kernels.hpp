@@ -93,12 +93,15 @@ namespace adaflo_hip
   {
     Q1_MASS_LAPLACE = 0, // (w, c_mass v) + (grad w, c_lap grad v)
     Q1_ADVECT       = 1, // (w, weight v + u . grad v)
-    Q1_REINIT       = 2  // (w, c_mass v) + (grad w, c_lap (n . grad v) n)
+    Q1_REINIT       = 2, // (w, c_mass v) + (grad w, c_lap (n . grad v) n)
+    Q1_LAPLACE_Q3   = 3  // (grad w, c(x_q) grad v) with the 3x3x3 Gauss rule, c per point (pressure Poisson)
   };
   int q1_convert_state(adaflo_ctx *ctx, DeviceBuffer &out, const double *generic_dev);
   int launch_q1_sweep(adaflo_ctx *ctx, int sub, int mode, double c_mass, double c_lap, double weight,
                       uint32_t con, double con_sign, const double *diag, double *dst, const double *src,
-                      const double *state, int n_blocks = 1);
+                      const double *state, int n_blocks = 1, const double *coef_cell = nullptr, int coef_stride = 0,
+                      int coef_mid = 0, double coef_shift = 0.);
+  int q1_convert_poisson_coef(adaflo_ctx *ctx, DeviceBuffer &out, const double *rho_generic, double weight);
 
   // specialised 3D Q2/Q1 sweep kernel (ns_q2.hip)
   bool q2_supported(const adaflo_ctx *ctx);

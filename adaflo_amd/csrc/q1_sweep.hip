@@ -18,6 +18,7 @@
 // partial sums in slabs that a small second kernel adds (no atomics, bitwise reproducible).
 // The kernel is register-light, so occupancy (not a DMA ring) hides the latency of the
 // quadrature-point state stream, which is laid out [tile][layer][12][256 lanes][2 doubles].
+#include "basis.hpp"
 #include "kernels.hpp"
 
 namespace adaflo_hip
@@ -35,6 +36,14 @@ namespace adaflo_hip
       int      nsx, nsy, nsz, nnx, nny, nnz, tiles_x, tiles_y, LZ, n_chunks, mode;
       double   ih[3], jxw, ga, gb; // 1/h_sub, h0 h1 h2 / 8, N_0(g_0) = ga, N_1(g_0) = gb
       double   c_mass, c_lap, weight;
+      // variable coefficients of the pressure operators (two-phase flow):
+      //   coef_cell: per-cell sample of the viscosity, c_mass = 1 / (coef[cell*stride + mid] + shift)
+      //              (local_pressure_mass, navier_stokes_matrix.cc:1057-1066)
+      //   Q1_LAPLACE_Q3: `state` holds 1 / (weight * rho) per point of the 3x3x3 Gauss rule,
+      //              [tile][layer][27][256 lanes] (local_pressure_poisson, :984-1000)
+      const double *coef_cell;
+      int           coef_stride, coef_mid;
+      double        coef_shift, g3x[3], g3w[3];
       uint32_t con;
       double   con_sign;           // constrained rows: dst = (diag ? diag : con_sign) * src
       const double *diag, *src;
@@ -134,7 +143,15 @@ namespace adaflo_hip
           load_plane(cz + 1, pl[(cz + 1) & 1]);
           // quadrature-point state of this sub-cell: issued before the barrier, used after it
           double2 st[12];
-          if (MODE != Q1_MASS_LAPLACE)
+          double  cf[27];
+          if (MODE == Q1_LAPLACE_Q3)
+            {
+              const double *cp = A.state + ((size_t)bt * A.nsz + cz) * (27 * NTQ) + tid;
+#pragma unroll
+              for (int q = 0; q < 27; ++q)
+                cf[q] = cp[q * NTQ];
+            }
+          else if (MODE != Q1_MASS_LAPLACE)
             {
               const double2 *sp = state + ((size_t)bt * A.nsz + cz) * (12 * NTQ) + tid;
 #pragma unroll
@@ -157,6 +174,91 @@ namespace adaflo_hip
                   if ((zero >> (li + 2 * lj) & 1u) || (K == 0 && conz_lo) || (K == A.nnz - 1 && conz_hi))
                     v = 0.;
                   u[lk][lj][li] = v;
+                }
+          double r[2][2][2];
+          if (MODE == Q1_LAPLACE_Q3)
+            {
+              // (grad q, c grad p) with the 3x3x3 Gauss rule and one coefficient per point.  The
+              // gradient of a trilinear function is constant along its own direction.
+              double DX[2][2], DY[2][2], DZ[2][2]; // [lk][lj], [lk][li], [lj][li]
+#pragma unroll
+              for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                  {
+                    DX[a][b] = (u[a][b][1] - u[a][b][0]) * A.ih[0];
+                    DY[a][b] = (u[a][1][b] - u[a][0][b]) * A.ih[1];
+                    DZ[a][b] = (u[1][a][b] - u[0][a][b]) * A.ih[2];
+                  }
+              double RX[2][2] = {{0., 0.}, {0., 0.}}, RY[2][2] = {{0., 0.}, {0., 0.}}, RZ[2][2] = {{0., 0.}, {0., 0.}};
+#pragma unroll
+              for (int qz = 0; qz < 3; ++qz)
+#pragma unroll
+                for (int qy = 0; qy < 3; ++qy)
+                  {
+                    const double z1 = A.g3x[qz], z0 = 1. - z1, y1 = A.g3x[qy], y0 = 1. - y1;
+                    // d/dx at (qy, qz); the sum over qx of the coefficient times weight
+                    const double gxq = z0 * (y0 * DX[0][0] + y1 * DX[0][1]) + z1 * (y0 * DX[1][0] + y1 * DX[1][1]);
+                    double       cx = 0.;
+#pragma unroll
+                    for (int qx = 0; qx < 3; ++qx)
+                      cx += cf[qx + 3 * qy + 9 * qz] * A.g3w[qx];
+                    const double tx = gxq * cx * (A.g3w[qy] * A.g3w[qz] * A.jxw * A.ih[0]);
+                    RX[0][0] += z0 * y0 * tx;
+                    RX[0][1] += z0 * y1 * tx;
+                    RX[1][0] += z1 * y0 * tx;
+                    RX[1][1] += z1 * y1 * tx;
+                  }
+#pragma unroll
+              for (int qz = 0; qz < 3; ++qz)
+#pragma unroll
+                for (int qx = 0; qx < 3; ++qx)
+                  {
+                    const double z1 = A.g3x[qz], z0 = 1. - z1, x1 = A.g3x[qx], x0 = 1. - x1;
+                    const double gyq = z0 * (x0 * DY[0][0] + x1 * DY[0][1]) + z1 * (x0 * DY[1][0] + x1 * DY[1][1]);
+                    double       cy = 0.;
+#pragma unroll
+                    for (int qy = 0; qy < 3; ++qy)
+                      cy += cf[qx + 3 * qy + 9 * qz] * A.g3w[qy];
+                    const double ty = gyq * cy * (A.g3w[qx] * A.g3w[qz] * A.jxw * A.ih[1]);
+                    RY[0][0] += z0 * x0 * ty;
+                    RY[0][1] += z0 * x1 * ty;
+                    RY[1][0] += z1 * x0 * ty;
+                    RY[1][1] += z1 * x1 * ty;
+                  }
+#pragma unroll
+              for (int qy = 0; qy < 3; ++qy)
+#pragma unroll
+                for (int qx = 0; qx < 3; ++qx)
+                  {
+                    const double y1 = A.g3x[qy], y0 = 1. - y1, x1 = A.g3x[qx], x0 = 1. - x1;
+                    const double gzq = y0 * (x0 * DZ[0][0] + x1 * DZ[0][1]) + y1 * (x0 * DZ[1][0] + x1 * DZ[1][1]);
+                    double       cz_ = 0.;
+#pragma unroll
+                    for (int qz = 0; qz < 3; ++qz)
+                      cz_ += cf[qx + 3 * qy + 9 * qz] * A.g3w[qz];
+                    const double tz = gzq * cz_ * (A.g3w[qx] * A.g3w[qy] * A.jxw * A.ih[2]);
+                    RZ[0][0] += y0 * x0 * tz;
+                    RZ[0][1] += y0 * x1 * tz;
+                    RZ[1][0] += y1 * x0 * tz;
+                    RZ[1][1] += y1 * x1 * tz;
+                  }
+#pragma unroll
+              for (int lk = 0; lk < 2; ++lk)
+#pragma unroll
+                for (int lj = 0; lj < 2; ++lj)
+#pragma unroll
+                  for (int li = 0; li < 2; ++li)
+                    r[lk][lj][li] = (li ? RX[lk][lj] : -RX[lk][lj]) + (lj ? RY[lk][li] : -RY[lk][li]) +
+                                    (lk ? RZ[lj][li] : -RZ[lj][li]);
+            }
+          else
+            {
+              double c_mass_l = A.c_mass;
+              if (MODE == Q1_MASS_LAPLACE && A.coef_cell) // per-cell sample (sub = 1: lane = cell)
+                {
+                  const long cell = min(I0 + sx, A.nsx - 1) + (long)A.nsx * (min(J0 + sy, A.nsy - 1) + (long)A.nsy * cz);
+                  c_mass_l        = 1. / (A.coef_cell[cell * A.coef_stride + A.coef_mid] + A.coef_shift);
                 }
           // ---- evaluate at the 2x2x2 Gauss points (trilinear, sum factorised) -----------------
           const double ga = A.ga, gb = A.gb;
@@ -218,7 +320,7 @@ namespace adaflo_hip
                   double       a = 0., b0 = 0., b1 = 0., b2 = 0.;
                   if (MODE == Q1_MASS_LAPLACE)
                     {
-                      a  = A.c_mass * v;
+                      a  = c_mass_l * v;
                       b0 = A.c_lap * g0;
                       b1 = A.c_lap * g1;
                       b2 = A.c_lap * g2;
@@ -247,7 +349,6 @@ namespace adaflo_hip
                 }
           // ---- integrate (transpose of the evaluation) -----------------------------------------
           // z: Z[lk][qy][qx] = sum_qz N_lk(qz) tv + dN_lk t2
-          double r[2][2][2];
           {
             double Zv[2][2][2], Zx[2][2][2], Zy[2][2][2];
 #pragma unroll
@@ -287,6 +388,7 @@ namespace adaflo_hip
                   r[lk][lj][1] = gb * Yv[lk][lj][0] + ga * Yv[lk][lj][1] + d0;
                 }
           }
+            }
           // ---- publish the high faces, combine per owned node ---------------------------------
 #pragma unroll
           for (int lk = 0; lk < 2; ++lk)
@@ -437,9 +539,58 @@ namespace adaflo_hip
     }
   } // namespace
 
+  namespace
+  {
+    // generic [cell][27] density -> 1 / (weight rho) in the lane layout [tile][layer][27][256]
+    __global__ __launch_bounds__(256) void q1_convert_poisson_coef_kernel(double *__restrict__ out,
+                                                                          const double *__restrict__ rho,
+                                                                          const double weight, const int ncx,
+                                                                          const int ncy, const int ncz,
+                                                                          const int tiles_x, const long total)
+    {
+      for (long o = blockIdx.x * 256L + threadIdx.x; o < total; o += (long)gridDim.x * 256)
+        {
+          const int lane = (int)(o % NTQ);
+          long      r    = o / NTQ;
+          const int q    = (int)(r % 27);
+          r /= 27;
+          const int  z  = (int)(r % ncz);
+          const long bt = r / ncz;
+          const int  x = (int)(bt % tiles_x) * TS + lane % TS, y = (int)(bt / tiles_x) * TS + lane / TS;
+          double     v = 0.;
+          if (x < ncx && y < ncy)
+            v = 1. / (weight * rho[(x + (long)ncx * (y + (long)ncy * z)) * 27 + q]);
+          out[o] = v;
+        }
+    }
+  } // namespace
+
   // ---------------------------------------------------------------------------------------------
   // host side
   // ---------------------------------------------------------------------------------------------
+  int q1_convert_poisson_coef(adaflo_ctx *ctx, DeviceBuffer &out, const double *rho_generic, const double weight)
+  {
+    const int    ncx = ctx->desc.ncell[0], ncy = ctx->desc.ncell[1], ncz = ctx->desc.ncell[2];
+    const int    tiles_x = (ncx + TS - 1) / TS, tiles_y = (ncy + TS - 1) / TS;
+    const size_t count   = (size_t)tiles_x * tiles_y * ncz * 27 * NTQ;
+    if (out.count != count)
+      {
+        if (out.p)
+          (void)hipFree(out.p);
+        out.p     = nullptr;
+        out.count = 0;
+        if (hipMalloc(&out.p, count * sizeof(double)) != hipSuccess)
+          return ADAFLO_ENOMEM;
+        out.count = count;
+      }
+    long nb = (long)((count + 255) / 256);
+    if (nb > 256 * 64)
+      nb = 256 * 64;
+    hipLaunchKernelGGL(q1_convert_poisson_coef_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, out.p,
+                       rho_generic, weight, ncx, ncy, ncz, tiles_x, (long)count);
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+
   int q1_convert_state(adaflo_ctx *ctx, DeviceBuffer &out, const double *canonical_dev)
   {
     const int    s = ctx->s, nsx = s * ctx->desc.ncell[0], nsy = s * ctx->desc.ncell[1], nsz = s * ctx->desc.ncell[2];
@@ -468,9 +619,22 @@ namespace adaflo_hip
   int launch_q1_sweep(adaflo_ctx *ctx, const int sub, const int mode, const double c_mass,
                       const double c_lap, const double weight, const uint32_t con, const double con_sign,
                       const double *diag, double *dst, const double *src, const double *state,
-                      const int n_blocks)
+                      const int n_blocks, const double *coef_cell, const int coef_stride, const int coef_mid,
+                      const double coef_shift)
   {
     Q1Args A{};
+    A.coef_cell   = coef_cell;
+    A.coef_stride = coef_stride;
+    A.coef_mid    = coef_mid;
+    A.coef_shift  = coef_shift;
+    {
+      const Quadrature1D g3 = gauss(3);
+      for (int q = 0; q < 3; ++q)
+        {
+          A.g3x[q] = g3.x[q];
+          A.g3w[q] = g3.w[q];
+        }
+    }
     A.nsx = sub * ctx->desc.ncell[0];
     A.nsy = sub * ctx->desc.ncell[1];
     A.nsz = sub * ctx->desc.ncell[2];
@@ -497,7 +661,7 @@ namespace adaflo_hip
         A.ih[d]         = 1. / hs;
         det *= hs;
       }
-    A.jxw      = det / 8.;
+    A.jxw      = mode == Q1_LAPLACE_Q3 ? det : det / 8.; // (2-point rule: weights 1/2 per direction)
     A.gb       = 0.5 * (1. - 1. / std::sqrt(3.)); // first Gauss point of QGauss<1>(2) on [0,1]
     A.ga       = 1. - A.gb;
     const size_t n_wg = (size_t)A.tiles_x * A.tiles_y * A.n_chunks;
@@ -534,6 +698,9 @@ namespace adaflo_hip
       {
         case Q1_MASS_LAPLACE:
           hipLaunchKernelGGL((q1_sweep_kernel<Q1_MASS_LAPLACE>), grid, block, 0, ctx->stream, A);
+          break;
+        case Q1_LAPLACE_Q3:
+          hipLaunchKernelGGL((q1_sweep_kernel<Q1_LAPLACE_Q3>), grid, block, 0, ctx->stream, A);
           break;
         case Q1_ADVECT:
           hipLaunchKernelGGL((q1_sweep_kernel<Q1_ADVECT>), grid, block, 0, ctx->stream, A);
