@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""The reference's 3D Beltrami test (tests/beltrami.cc, tests/beltrami_3d.prm: [-1,1]^3, nu = 1,
+BDF-2, dt = 0.05, Q2/Q1, coupled implicit Newton) on one MI355X; prints the nonlinear residual
+table of tests/beltrami_3d.output.      python examples/beltrami_3d.py [cells per direction] [steps]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,7 +16,7 @@ ns = NavierStokes(fp, mesh, adaflo_amd.TimeStepping(fp), dirichlet_function=lamb
 xu, xp = node_coordinates(mesh, 2), node_coordinates(mesh, 1)
 ns.set_initial_condition(orc.beltrami_u(xu, 0.0, 1.0), orc.beltrami_p(xp, 0.0, 1.0))
 import time, torch
-for step in range(2):
+for step in range(int(sys.argv[2]) if len(sys.argv) > 2 else 2):
     torch.cuda.synchronize(); t0 = time.time()
     print(ns.advance_time_step())
     torch.cuda.synchronize(); print("time step wall", time.time() - t0)
