@@ -32,7 +32,10 @@ def reference_outputs():
             # :31 first residual of time step #2 (after step #1 converged to 1e-9)
             "second_step_residuals_u": ["2.348e+00"], "second_step_residuals_p": ["5.678e-02"]},
         "rising_bubble_ls": {  # tests/rising_bubble_ls.output (2D): DoF counts of the three spaces
-            "cells": 3200, "dofs_u": 26082, "dofs_p": 3321, "dofs_ls": 51681},
+            "cells": 3200, "dofs_u": 26082, "dofs_p": 3321, "dofs_ls": 51681,
+            # :5 "reinitialize (8 + 8)", :12 "reinitialize (7 + 7)", :13 "Residual/iterations: [0.0198/"
+            "initial_reinitialize_iterations": [8, 8], "step1_reinitialize_iterations": [7, 7],
+            "step1_first_residual": "0.0198"},
     }
 
 

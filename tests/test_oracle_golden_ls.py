@@ -1,0 +1,96 @@
+"""Pin the level-set part of the oracle to the reference's own golden output
+tests/rising_bubble_ls.output (2D rising bubble, tests/rising_bubble.cc + rising_bubble_ls.prm:
+40 x 80 cells on [0,1] x [0,2], Q2/Q1 + FE_Q_iso_Q1(4), epsilon = 1.5, bubble of radius 0.25):
+
+  line  5  `reinitialize (8 + 8)`            CG iterations of the two initial reinitialisation steps
+  line 12  `reinitialize (7 + 7)`            ... and of time step #1
+  line 13  `Residual/iterations: [0.0198/`   first Navier-Stokes residual of time step #1: with u = 0,
+                                             p = 0 it is the norm of the surface-tension + gravity
+                                             right-hand side on the unconstrained rows
+
+These numbers go through (in 2D) the tanh initial profile, epsilon_used, the mass-matrix
+DiagonalPreconditioner, compute_normal (operator + rhs), the reinitialisation operator + rhs
+with the stored normalised normal, compute_heaviside, compute_curvature (operator + rhs +
+curvature correction) and local_compute_force with the gradient interpolated onto the
+pressure space and the variable density.  The solvers are oracle/krylov_oracle.py (the
+reference solves the normal / curvature projections with an assembled matrix + ILU; the
+solutions agree to the solver tolerance, which is what the iteration counts and three
+printed digits need)."""
+import json
+import os
+
+import numpy as np
+from threadpoolctl import threadpool_limits
+
+from oracle import krylov_oracle as ko
+from oracle import oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_outputs.json")
+
+
+def test_rising_bubble_initial_reinitialisation_and_first_force():
+    with open(GOLDEN) as f:
+        ref = json.load(f)["rising_bubble_ls"]
+    s, k, h, eps_rel, dt = 4, 2, 0.025, 1.5, 0.02
+    mesh = orc.Mesh.make([40, 80], (0., 0.), (1., 2.))
+    assert (mesh.n_cells, mesh.n_nodes(s)) == (ref["cells"], ref["dofs_ls"])
+    eps_used = eps_rel / s * h                                         # two_phase_base.cc:290-291
+    prm = orc.make_ls_params(s, eps_used, h, dt, 1.0 / dt, h, eps_rel)
+    x = orc.node_coordinates(mesh, s, fe_type=1)
+    nn = mesh.n_nodes(s)
+    phi = -np.tanh((np.linalg.norm(x - 0.5, axis=1) - 0.25) / (2 * eps_used))   # rising_bubble.cc:59-77
+    # initialize_mass_matrix_diagonal: the curvature operator without diffusion is the mass matrix;
+    # probe its diagonal (nodes two apart never share a sub-cell)
+    idx = np.indices((4 * 80 + 1, 4 * 40 + 1))
+    col = ((idx[1] % 2) + 2 * (idx[0] % 2)).reshape(-1)
+    diag = np.zeros(nn)
+    for c in range(4):
+        y = orc.ls_curvature_vmult(mesh, prm, (col == c).astype(float), apply_diffusion=False)
+        diag[col == c] = y[col == c]
+    inv = 1.0 / diag
+    nq = np.zeros(mesh.n_cells * (2 * s) ** 2 * 2)
+    An = lambda v: orc.ls_normal_vmult(mesh, prm, v)
+    Ar = lambda v: orc.ls_reinit_vmult(mesh, prm, v, nq)
+    Ac = lambda v: orc.ls_curvature_vmult(mesh, prm, v)
+
+    def compute_normal(phi, normal, fast):
+        rhs = orc.ls_normal_rhs(mesh, prm, phi)
+        return ko.cg(An, rhs, x0=normal, inv_diag=np.tile(inv, 2), max_it=4000, rel_tol=1e-5 if fast else 1e-7)[0]
+
+    def reinitialize(phi, normal, steps):                               # reinitialization.cc:255-375
+        its = []
+        for tau in range(steps):
+            if tau == 0:
+                normal = compute_normal(phi, normal, True)
+            rhs = orc.ls_reinit_rhs(mesh, prm, phi, normal, nq, diffuse_only=False, first_step=tau == 0)
+            inc, it, *_ = ko.cg(Ar, rhs, inv_diag=inv, max_it=2000, abs_tol=1e-50, rel_tol=1e-6)
+            its.append(it)
+            phi = phi + inc
+        return phi, normal, its
+
+    with threadpool_limits(limits=1, user_api="blas"):
+        normal = np.zeros(2 * nn)
+        phi, normal, its0 = reinitialize(phi, normal, 2)                # number initial reinit steps = 2
+        assert its0 == ref["initial_reinitialize_iterations"]
+        # time step #1: the velocity is zero, the advection right-hand side vanishes ("advect [0/0]")
+        vel = np.zeros(mesh.n_nodes(k) * 2)
+        uq = np.zeros(mesh.n_cells * (2 * s) ** 2 * 2)
+        rhs_adv = orc.ls_advect_rhs(mesh, prm, k, phi, phi, phi, vel, uq, -1.0 / dt, 0.0, False)
+        assert np.linalg.norm(rhs_adv) < 1e-12
+        phi, normal, its1 = reinitialize(phi, normal, 2)                # number reinit steps = 2
+        assert its1 == ref["step1_reinitialize_iterations"]
+        # compute_force: Heaviside, normal (1e-7), curvature (1e-8) with the curvature correction
+        H = orc.ls_compute_heaviside(mesh, s, eps_rel, phi)
+        normal = compute_normal(phi, normal, False)
+        kappa = ko.cg(Ac, orc.ls_curvature_rhs(mesh, prm, normal), inv_diag=inv, max_it=2000, rel_tol=1e-8)[0]
+        with np.errstate(divide="ignore"):
+            dist = np.where(1 - phi * phi > 1e-2, eps_used * np.log((1 + phi) / (1 - phi)), 0.0)
+        sel = kappa > 1e-4                                              # compute_curvature.cc:360-376, dim - 1 = 1
+        kappa[sel] = 1.0 / (1.0 / kappa[sel] + dist[sel])
+        # no-slip on the bottom / top, symmetry (normal component) on the left / right (rising_bubble.cc:133-150)
+        con_u = orc.boundary_mask(mesh, k, 2, faces=[2, 3]) | orc.boundary_mask(mesh, k, 2, faces=[0, 1], comps=[0])
+        force, rho, mu = orc.ls_compute_force(mesh, s, k, H, kappa, surface_tension=0.0245, gravity=0.98, density=1.0,
+                                              density_diff=-0.9, viscosity=0.01, viscosity_diff=-0.009,
+                                              interpolate_grad_onto_pressure=True, con_u=con_u)
+    assert "%.3g" % np.linalg.norm(force) == ref["step1_first_residual"]
+    assert abs(rho.min() - 0.1) < 1e-12 and abs(rho.max() - 1.0) < 1e-12
