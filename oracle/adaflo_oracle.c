@@ -16,10 +16,13 @@
  *   - level-set operators (advect/reinit/normal/curvature)
  *                                                source/level_set_okz_*.cc (cited per function)
  *
- * Parity pin: the first nonlinear residual of tests/beltrami_3d (uniform 16^3,
- * Q2/Q1) printed in tests/beltrami_3d.output:13 (2.590e+00, 6.423e-02) is
- * reproduced by tests/test_oracle_golden.py through this file.  deal.II cannot
- * be built here (needs cmake + Trilinos + p4est, none present): the reference
+ * Parity pins (the reference's own golden outputs, reproduced through this file):
+ *   tests/beltrami_3d.output:13   first nonlinear residual of time step #1, 2.590e+00 / 6.423e-02
+ *   tests/beltrami_3d.output:31   first residual of time step #2 after a converged Newton
+ *                                 iteration, 2.348e+00 / 5.678e-02   (tests/test_oracle_golden.py)
+ *   tests/rising_bubble_ls.output:5,12,13   `reinitialize (8 + 8)`, `reinitialize (7 + 7)`, first
+ *                                 two-phase residual 0.0198 (2D; tests/test_oracle_golden_ls.py)
+ * deal.II cannot be built here (needs cmake + Trilinos + p4est, none present): the reference
  * build is "unbuildable", see DESIGN.md.
  *
  * Discretisation conventions:
