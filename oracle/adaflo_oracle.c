@@ -20,8 +20,10 @@
  *   tests/beltrami_3d.output:13   first nonlinear residual of time step #1, 2.590e+00 / 6.423e-02
  *   tests/beltrami_3d.output:31   first residual of time step #2 after a converged Newton
  *                                 iteration, 2.348e+00 / 5.678e-02   (tests/test_oracle_golden.py)
- *   tests/rising_bubble_ls.output:5,12,13   `reinitialize (8 + 8)`, `reinitialize (7 + 7)`, first
- *                                 two-phase residual 0.0198 (2D; tests/test_oracle_golden_ls.py)
+ *   tests/rising_bubble_ls.output:5-29   initial state and time steps #1-#3 of the 2D rising bubble:
+ *                                 advection residual / iterations, reinitialisation iterations,
+ *                                 first two-phase residual of every step
+ *                                 (oracle/two_phase_oracle.py, tests/test_oracle_golden_ls.py)
  * deal.II cannot be built here (needs cmake + Trilinos + p4est, none present): the reference
  * build is "unbuildable", see DESIGN.md.
  *

@@ -1,0 +1,190 @@
+"""CPU restatement of the two-phase time step of LevelSetOKZSolver in 2D (TEST INFRASTRUCTURE ONLY):
+tests/rising_bubble.cc + tests/rising_bubble_ls.prm of the reference on its own 40 x 80 mesh.
+
+    LevelSetBaseAlgorithm::advance_time_step        source/level_set_base.cc:190-291
+    TwoPhaseBaseAlgorithm::init_time_advance        source/two_phase_base.cc:441-460
+    advance_concentration / reinitialize / compute_normal / compute_curvature (+ correction) /
+    compute_heaviside / compute_force               source/level_set_okz*.cc
+    NavierStokes::compute_residual, Newton          source/navier_stokes.cc:781-960
+
+All operators are the oracle's (oracle/adaflo_oracle.c); the Krylov recurrences are
+oracle/krylov_oracle.py.  The Navier-Stokes Newton systems are solved EXACTLY: the Jacobian (the
+oracle's vmult on the state its residual stored, with the variable density / viscosity arrays of
+compute_force) is assembled by coloured probing and factorised by SciPy's sparse LU -- cheap in 2D.
+A converged Newton iteration is independent of the linear solver, so the numbers the reference
+prints at the START of the following steps (advection residual and iterations, reinitialisation
+iterations, first Navier-Stokes residual) are reproducible; see tests/test_oracle_golden_ls.py."""
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from . import krylov_oracle as ko
+from . import oracle as orc
+
+
+class RisingBubble2D:
+    def __init__(self, time_stepping_factory, ncell=(40, 80), s=4, k=2, eps_rel=1.5, dt=0.02):
+        self.s, self.k, self.eps_rel, self.dt = s, k, eps_rel, dt
+        self.ncell = list(ncell)
+        self.mesh = orc.Mesh.make(self.ncell, (0., 0.), (1., 2.))
+        self.h = 1.0 / ncell[0]
+        self.eps_used = eps_rel / s * self.h                               # two_phase_base.cc:290-291
+        mesh = self.mesh
+        self.nn, self.nu, self.np_ = mesh.n_nodes(s), mesh.n_nodes(k) * 2, mesh.n_nodes(k - 1)
+        self.nq_ls = (2 * s) ** 2
+        # NavierStokes, advection and reinitialisation advance their own TimeStepping objects
+        self.ts_ns, self.ts_adv, self.ts_rei = (time_stepping_factory() for _ in range(3))
+        self.prm = self._ls_prm(self.ts_ns)
+        # initialize_mass_matrix_diagonal: the curvature operator without diffusion is the mass matrix
+        idx = np.indices((s * ncell[1] + 1, s * ncell[0] + 1))
+        col = ((idx[1] % 2) + 2 * (idx[0] % 2)).reshape(-1)
+        diag = np.zeros(self.nn)
+        for c in range(4):
+            y = orc.ls_curvature_vmult(mesh, self.prm, (col == c).astype(float), apply_diffusion=False)
+            diag[col == c] = y[col == c]
+        self.inv_diag = 1.0 / diag
+        # no-slip at the bottom / top, symmetry (normal component) left / right (rising_bubble.cc:133-150)
+        self.con_u = orc.boundary_mask(mesh, k, 2, faces=[2, 3]) | orc.boundary_mask(mesh, k, 2, faces=[0, 1], comps=[0])
+        x = orc.node_coordinates(mesh, s, fe_type=1)
+        self.phi = -np.tanh((np.linalg.norm(x - 0.5, axis=1) - 0.25) / (2 * self.eps_used))   # rising_bubble.cc:59-77
+        self.normal, self.kappa, self.kappa_old = np.zeros(2 * self.nn), np.zeros(self.nn), np.zeros(self.nn)
+        self.normal_q = np.zeros(mesh.n_cells * self.nq_ls * 2)
+        self.log = {}
+        self.phi, its = self.reinitialize(self.phi, 2)                      # number initial reinit steps
+        self.ts_rei.next()
+        self.log["initial_reinitialize"] = its
+        self.phi_old, self.phi_oo = self.phi.copy(), self.phi.copy()
+        self.u, self.p = np.zeros(self.nu), np.zeros(self.np_)
+        self.u_old, self.u_oo, self.p_old = np.zeros(self.nu), np.zeros(self.nu), np.zeros(self.np_)
+
+    def _ls_prm(self, ts):
+        return orc.make_ls_params(self.s, self.eps_used, self.h, self.dt, ts.weight(), self.h, self.eps_rel)
+
+    # ---- level-set steps
+    def compute_normal(self, phi, fast):
+        A = lambda v: orc.ls_normal_vmult(self.mesh, self.prm, v)
+        rhs = orc.ls_normal_rhs(self.mesh, self.prm, phi)
+        self.normal = ko.cg(A, rhs, x0=self.normal, inv_diag=np.tile(self.inv_diag, 2), max_it=4000,
+                            rel_tol=1e-5 if fast else 1e-7)[0]
+
+    def reinitialize(self, phi, steps):                                      # reinitialization.cc:255-375
+        A = lambda v: orc.ls_reinit_vmult(self.mesh, self.prm, v, self.normal_q)
+        its = []
+        for tau in range(steps):
+            if tau == 0:
+                self.compute_normal(phi, True)
+            rhs = orc.ls_reinit_rhs(self.mesh, self.prm, phi, self.normal, self.normal_q, diffuse_only=False,
+                                    first_step=tau == 0)
+            inc, it, *_ = ko.cg(A, rhs, inv_diag=self.inv_diag, max_it=2000, abs_tol=1e-50, rel_tol=1e-6)
+            its.append(it)
+            phi = phi + inc
+        return phi, its
+
+    def compute_force(self):                                                 # level_set_okz.cc:415-432
+        mesh, prm = self.mesh, self.prm
+        H = orc.ls_compute_heaviside(mesh, self.s, self.eps_rel, self.phi)
+        self.compute_normal(self.phi, False)
+        A = lambda v: orc.ls_curvature_vmult(mesh, prm, v)
+        kappa = ko.cg(A, orc.ls_curvature_rhs(mesh, prm, self.normal), x0=self.kappa, inv_diag=self.inv_diag,
+                      max_it=2000, rel_tol=1e-8)[0]
+        with np.errstate(divide="ignore", invalid="ignore"):                 # compute_curvature.cc:360-376
+            dist = np.where(1 - self.phi ** 2 > 1e-2, self.eps_used * np.log((1 + self.phi) / (1 - self.phi)), 0.0)
+        sel = kappa > 1e-4
+        kappa[sel] = 1.0 / (1.0 / kappa[sel] + dist[sel])                     # dim - 1 = 1
+        self.kappa = kappa
+        return orc.ls_compute_force(mesh, self.s, self.k, H, kappa, surface_tension=0.0245, gravity=0.98, density=1.0,
+                                    density_diff=-0.9, viscosity=0.01, viscosity_diff=-0.009,
+                                    interpolate_grad_onto_pressure=True, con_u=self.con_u)
+
+    # ---- exact Newton step: Jacobian by coloured probing, sparse LU
+    def _assemble(self, vm):
+        mesh, k, nu, npp = self.mesh, self.k, self.nu, self.np_
+        nnu, nnp = mesh.nodes_per_dim(k), mesh.nodes_per_dim(k - 1)
+        iu, ip = np.indices((nnu[1], nnu[0])), np.indices((nnp[1], nnp[0]))
+        Iu, Ju, Ip, Jp = iu[1].reshape(-1), iu[0].reshape(-1), ip[1].reshape(-1), ip[0].reshape(-1)
+        P, Pp = 6, 3                                        # probe columns 3 cells apart never share a row
+        colu, colp = (Iu % P) + P * (Ju % P), (Ip % Pp) + Pp * (Jp % Pp)
+        rows, cols, vals = [], [], []
+        near = lambda a, c, per: c + per * np.round((a - c) / per).astype(int)
+        for c in range(P * P):
+            ci, cj = c % P, c // P
+            for comp in range(2):
+                e = np.zeros(nu)
+                e[2 * np.nonzero(colu == c)[0] + comp] = 1.0
+                yu, yp = vm(e, np.zeros(npp))
+                nz = np.nonzero(yu)[0]
+                rows.append(nz)
+                cols.append(2 * (near(Ju[nz // 2], cj, P) * nnu[0] + near(Iu[nz // 2], ci, P)) + comp)
+                vals.append(yu[nz])
+                nz = np.nonzero(yp)[0]                      # pressure node (I,J) sits at velocity node (2I, 2J)
+                rows.append(nu + nz)
+                cols.append(2 * (near(2 * Jp[nz], cj, P) * nnu[0] + near(2 * Ip[nz], ci, P)) + comp)
+                vals.append(yp[nz])
+        for c in range(Pp * Pp):
+            ci, cj = c % Pp, c // Pp
+            yu, yp = vm(np.zeros(nu), (colp == c).astype(float))
+            nz = np.nonzero(yu)[0]
+            rows.append(nz)
+            cols.append(nu + near(Ju[nz // 2] / 2, cj, Pp) * nnp[0] + near(Iu[nz // 2] / 2, ci, Pp))
+            vals.append(yu[nz])
+            nz = np.nonzero(yp)[0]
+            rows.append(nu + nz)
+            cols.append(nu + near(Jp[nz], cj, Pp) * nnp[0] + near(Ip[nz], ci, Pp))
+            vals.append(yp[nz])
+        n = nu + npp
+        return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+
+    def advance_time_step(self, tol_nl=1e-9):
+        """returns what the reference prints for the step: advection (initial residual, iterations),
+        reinitialisation iterations, Navier-Stokes residual history"""
+        mesh, k, nu = self.mesh, self.k, self.nu
+        ts = self.ts_ns
+        ts.next()                                                           # init_time_advance
+        u_new, p_new = ts.extrapolate(self.u, self.u_old), ts.extrapolate(self.p, self.p_old)
+        self.u_oo, self.u_old, self.u = self.u_old, self.u, u_new.copy()
+        self.p_old, self.p = self.p, p_new.copy()
+        so, st = ts.old_step_size(), ts.step_size()
+        new_phi, new_kappa = self.phi.copy(), self.kappa.copy()
+        if so > 0:                                                          # two_phase_base.cc:449-452
+            new_phi = (st + so) / so * self.phi - st / so * self.phi_old
+            new_kappa = (st + so) / so * self.kappa - st / so * self.kappa_old
+        self.phi_oo, self.phi_old, self.phi = self.phi_old, self.phi, new_phi
+        self.kappa_old, self.kappa = self.kappa, new_kappa
+        # advance_concentration (advance_concentration.cc:503-660)
+        ta = self.ts_adv
+        ta.next()
+        self.prm = self._ls_prm(ta)
+        uq = np.zeros(mesh.n_cells * self.nq_ls * 2)
+        rhs = orc.ls_advect_rhs(mesh, self.prm, k, self.phi, self.phi_old, self.phi_oo, self.u, uq, ta.weight_old(),
+                                ta.weight_old_old(), ta.scheme == "bdf_2" and ta.step_no() > 1)
+        A = lambda v: orc.ls_advect_vmult(mesh, self.prm, v, uq)
+        inc, adv_it, adv_r0, *_ = ko.bicgstab(A, rhs, inv_diag=self.inv_diag, max_it=30, abs_tol=0.05 * tol_nl, rel_tol=1e-8)
+        self.phi = self.phi + inc
+        # reinitialize (number reinit steps = 2)
+        self.prm = self._ls_prm(self.ts_rei)
+        self.phi, rei_its = self.reinitialize(self.phi, 2)
+        self.ts_rei.next()
+        # compute_force, Navier-Stokes
+        self.prm = self._ls_prm(ts)
+        force, rho, mu = self.compute_force()
+        nsp = orc.NSParams.make(beta=0.5, density=1.0, viscosity=0.01, density_diff=-0.9, weight=ts.weight(),
+                                weight_old=ts.weight_old(), weight_old_old=ts.weight_old_old(), tau1=ts.tau1(),
+                                extrap_old=ts.factor_extrapol_old, extrap_old_old=ts.factor_extrapol_old_old)
+        lin, damp, history = np.zeros(mesh.n_cells * 9 * 6), np.zeros_like(rho), []
+        for _ in range(10):
+            ru, rp = orc.ns_residual(mesh, k, nsp, self.u, self.p, self.u_old, self.u_oo, con_u=self.con_u, lin=lin,
+                                     rho=rho, mu=mu, damp=damp, user_u=force)
+            rp = rp - rp.mean()          # mean-value projection of the pressure rows (uniform mesh: weights ~ 1 inside)
+            history.append(float(np.hypot(np.linalg.norm(ru), np.linalg.norm(rp))))
+            if history[-1] < tol_nl:
+                break
+            vm = lambda a, b: orc.ns_vmult(mesh, k, nsp, a, b, self.con_u, None, lin=lin, rho=rho, mu=mu, damp=damp)
+            J = self._assemble(vm).tolil()
+            J[nu, :] = 0
+            J[nu, nu] = 1.0                                                   # pin one pressure value
+            rhs_all = np.concatenate([ru, rp])
+            rhs_all[nu] = 0.0
+            d = spla.spsolve(J.tocsc(), rhs_all)
+            self.u += d[:nu]
+            self.p += d[nu:]
+        return (adv_r0, adv_it), rei_its, history

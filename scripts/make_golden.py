@@ -35,7 +35,12 @@ def reference_outputs():
             "cells": 3200, "dofs_u": 26082, "dofs_p": 3321, "dofs_ls": 51681,
             # :5 "reinitialize (8 + 8)", :12 "reinitialize (7 + 7)", :13 "Residual/iterations: [0.0198/"
             "initial_reinitialize_iterations": [8, 8], "step1_reinitialize_iterations": [7, 7],
-            "step1_first_residual": "0.0198"},
+            "step1_first_residual": "0.0198",
+            # :11-29 per time step: "advect [res/its] and reinitialize (a + b)", "Residual/iterations: [res/"
+            "time_steps": [
+                {"advect_residual": "0", "advect_iterations": 0, "reinitialize_iterations": [7, 7], "first_residual": "0.0198"},
+                {"advect_residual": "0.000471", "advect_iterations": 9, "reinitialize_iterations": [11, 10], "first_residual": "0.00581"},
+                {"advect_residual": "0.00108", "advect_iterations": 10, "reinitialize_iterations": [11, 11], "first_residual": "0.000246"}]},
     }
 
 
