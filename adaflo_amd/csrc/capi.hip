@@ -1112,6 +1112,17 @@ int adaflo_ls_compute_heaviside(adaflo_ctx *ctx, double *heaviside, const double
   return 0;
 }
 
+int adaflo_ls_curvature_correction(adaflo_ctx *ctx, double *curvature, const double *level_set)
+{
+  CHECK_CTX(ctx);
+  if (int e = ls_ready(ctx))
+    return e;
+  if (!curvature || !level_set)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  TRY(ctx, launch_ls_curvature_correction(ctx, curvature, level_set), "curvature correction kernel failed");
+  return 0;
+}
+
 int adaflo_ls_compute_force(adaflo_ctx *ctx, double *user_rhs_u, const double *heaviside,
                             const double *curvature, const adaflo_force_params *p)
 {

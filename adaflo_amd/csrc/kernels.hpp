@@ -113,6 +113,7 @@ namespace adaflo_hip
   int                 launch_ls_heaviside(adaflo_ctx *ctx, double *heaviside, const double *phi, double epsilon);
   std::vector<double> force_tables(int s, int k);
   int                 launch_ls_mass_diagonal(adaflo_ctx *ctx, double *diag);
+  int                 launch_ls_curvature_correction(adaflo_ctx *ctx, double *curvature, const double *phi);
   int launch_ls_force(adaflo_ctx *ctx, double *dst_u, const double *heaviside, const double *curvature,
                       const double *tab, double *rho, double *mu, double surface_tension, double gravity,
                       double density, double density_diff, double viscosity, double viscosity_diff,

@@ -258,6 +258,32 @@ namespace adaflo_hip
     return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : ADAFLO_EHIP;
   }
 
+  // level_set_okz_compute_curvature.cc:360-376: extend the curvature along the normal direction to
+  // the value at the interface, 1 / (1 / kappa + distance / (dim - 1)) with dim = 3
+  __global__ void curvature_correction_kernel(double *__restrict__ kappa, const double *__restrict__ phi,
+                                              const double epsilon_used, const long n)
+  {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+      {
+        const double kv = kappa[i];
+        if (kv > 1e-4)
+          {
+            const double c        = phi[i];
+            const double distance = (1 - c * c) > 1e-2 ? epsilon_used * log((1. + c) / (1. - c)) : 0.;
+            kappa[i]              = 1. / (1. / kv + distance / 2.);
+          }
+      }
+  }
+
+  int launch_ls_curvature_correction(adaflo_ctx *ctx, double *curvature, const double *phi)
+  {
+    const long n  = ctx->n_nodes_ls;
+    const long nb = (n + 255) / 256;
+    hipLaunchKernelGGL(curvature_correction_kernel, dim3((unsigned)(nb > 65536 ? 65536 : nb)), dim3(256), 0, ctx->stream,
+                       curvature, phi, ctx->ls.epsilon_used, n);
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+
   int launch_ls_mass_diagonal(adaflo_ctx *ctx, double *diag)
   {
     const int  s = ctx->s, nx = s * ctx->desc.ncell[0] + 1, ny = s * ctx->desc.ncell[1] + 1, nz = s * ctx->desc.ncell[2] + 1;

@@ -248,13 +248,17 @@ class LevelSetOKZSolverComputeCurvature:
     def local_compute_curvature_rhs(self, dst, normal_vector_field):
         _lib.check(self._ctx, self._lib.adaflo_ls_compute_curvature_rhs(self._ctx, dst.ptr, normal_vector_field.ptr))
 
-    def compute_curvature(self, solution_curvature, rhs, normal_vector_field, preconditioner):
+    def compute_curvature(self, solution_curvature, rhs, normal_vector_field, preconditioner, solution_ls=None):
         """LevelSetOKZSolverComputeCurvature::compute_curvature (level_set_okz_compute_curvature.cc:
-        325-357), matrix-free form (:350), without the optional curvature correction: projection of
-        -div(n), CG to 1e-8 starting from the previous curvature"""
+        325-376), matrix-free form (:350): projection of -div(n), CG to 1e-8 starting from the
+        previous curvature; with solution_ls given, followed by the curvature correction (:360-376,
+        parameters.curvature_correction)"""
         from .solvers import ComputeCurvatureMatrix, ReductionControl, SolverCG
         rhs.fill(0.0)
         self.local_compute_curvature_rhs(rhs, normal_vector_field)
         control = ReductionControl(2000, 1e-50, 1e-8)
         SolverCG(control).solve(ComputeCurvatureMatrix(self.ops), solution_curvature, rhs, preconditioner)
+        if solution_ls is not None:
+            ops = self.ops
+            _lib.check(ops._ctx, ops._lib.adaflo_ls_curvature_correction(ops._ctx, solution_curvature.ptr, solution_ls.ptr))
         return control.last_step()

@@ -9,7 +9,7 @@ method of Olsson, Kreiss and Zahedi) on a uniform brick, every vector and every 
 
 One engine context carries the Navier-Stokes operator and the level-set operators, so that
 compute_force writes the density / viscosity arrays the two-phase Jacobian reads.  Not mirrored:
-adaptive mesh refinement, the curvature correction, convection stabilisation, output."""
+adaptive mesh refinement, convection stabilisation, output."""
 import numpy as np
 
 from . import level_set_okz as lso
@@ -51,11 +51,13 @@ class LevelSetOKZSolver:
         # initial profile (level_set_okz.cc:203-210) and initial reinitialisation steps
         dist = np.asarray(distance_function(self._x_ls), dtype=np.float64)
         self.solution.set(-np.tanh(dist / (2.0 * self.epsilon_used)))
+        self.reinit_iterations = []
         if n_initial_reinit_steps > 0:
             self.reinitialize(n_initial_reinit_steps)
+        self.initial_reinit_iterations = self.reinit_iterations.pop() if self.reinit_iterations else []
         self.solution_old.sadd(0.0, 1.0, self.solution)
         self.solution_old_old.sadd(0.0, 1.0, self.solution)
-        self.concentration_iterations, self.reinit_iterations = [], []
+        self.concentration_iterations = []
 
     # ------------------------------------------------------------------------------------------
     def _ls_node_coordinates(self):
@@ -105,13 +107,13 @@ class LevelSetOKZSolver:
                                                 self.solution_update, self.preconditioner, stab_steps, diff_steps,
                                                 compute_normal=self.compute_normal)
         ts.next()
-        if hasattr(self, "reinit_iterations"):
-            self.reinit_iterations.append(its)
+        self.reinit_iterations.append(its)
 
     def compute_curvature(self):
         self.compute_normal(False)
-        return self.curvature_operator.compute_curvature(self.curvature, self.system_rhs, self.normal_vector_field,
-                                                         self.preconditioner)
+        return self.curvature_operator.compute_curvature(
+            self.curvature, self.system_rhs, self.normal_vector_field, self.preconditioner,
+            solution_ls=self.solution if self.parameters.curvature_correction else None)
 
     def compute_force(self):
         """level_set_okz.cc:415-432"""

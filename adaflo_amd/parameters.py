@@ -38,6 +38,7 @@ class FlowParameters:
     epsilon: float = 1.0
     concentration_subdivisions: int = 2
     interpolate_grad_onto_pressure: bool = False   # "grad pressure compatible"
+    curvature_correction: bool = False             # "curvature correction" (parameters.cc:314)
     # solver section (parameters.cc "Solver": defaults of the reference)
     max_nl_iteration: int = 10
     tol_nl_iteration: float = 1e-6

@@ -263,6 +263,11 @@ typedef struct adaflo_force_params
 int adaflo_ls_compute_heaviside(adaflo_ctx *ctx, double *heaviside, const double *level_set, double epsilon);
 int adaflo_ls_compute_force(adaflo_ctx *ctx, double *user_rhs_u, const double *heaviside,
                             const double *curvature, const adaflo_force_params *params);
+/* "curvature correction = 1" (source/level_set_okz_compute_curvature.cc:360-376): where
+ * curvature[node] > 1e-4, replace it by 1 / (1 / curvature + distance / (dim - 1)), distance =
+ * epsilon_used * log((1 + phi) / (1 - phi)) if 1 - phi^2 > 1e-2, else 0 (epsilon_used from
+ * adaflo_ls_set_parameters). */
+int adaflo_ls_curvature_correction(adaflo_ctx *ctx, double *curvature, const double *level_set);
 
 /* --------------------------------------------------------------------------------------------
  * Krylov drivers with device-resident vectors (callers of the operators above)

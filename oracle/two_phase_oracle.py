@@ -1,5 +1,6 @@
-"""CPU restatement of the two-phase time step of LevelSetOKZSolver in 2D (TEST INFRASTRUCTURE ONLY):
-tests/rising_bubble.cc + tests/rising_bubble_ls.prm of the reference on its own 40 x 80 mesh.
+"""CPU restatement of the two-phase time step of LevelSetOKZSolver (TEST INFRASTRUCTURE ONLY):
+tests/rising_bubble.cc + tests/rising_bubble_ls.prm of the reference -- in 2D on its own 40 x 80
+mesh (golden output), and the same algorithm in 3D as the checker of the device drivers.
 
     LevelSetBaseAlgorithm::advance_time_step        source/level_set_base.cc:190-291
     TwoPhaseBaseAlgorithm::init_time_advance        source/two_phase_base.cc:441-460
@@ -22,33 +23,40 @@ from . import krylov_oracle as ko
 from . import oracle as orc
 
 
-class RisingBubble2D:
-    def __init__(self, time_stepping_factory, ncell=(40, 80), s=4, k=2, eps_rel=1.5, dt=0.02):
+class RisingBubble:
+    def __init__(self, time_stepping_factory, ncell=(40, 80), s=4, k=2, eps_rel=1.5, dt=0.02, no_slip_everywhere=False):
+        """dim = len(ncell); the domain is [0,1]^(dim-1) x [0,2] with gravity along the last axis"""
         self.s, self.k, self.eps_rel, self.dt = s, k, eps_rel, dt
         self.ncell = list(ncell)
-        self.mesh = orc.Mesh.make(self.ncell, (0., 0.), (1., 2.))
+        dim = self.dim = len(ncell)
+        self.mesh = orc.Mesh.make(self.ncell, (0.,) * dim, (1.,) * (dim - 1) + (2.,))
         self.h = 1.0 / ncell[0]
         self.eps_used = eps_rel / s * self.h                               # two_phase_base.cc:290-291
         mesh = self.mesh
-        self.nn, self.nu, self.np_ = mesh.n_nodes(s), mesh.n_nodes(k) * 2, mesh.n_nodes(k - 1)
-        self.nq_ls = (2 * s) ** 2
+        self.nn, self.nu, self.np_ = mesh.n_nodes(s), mesh.n_nodes(k) * dim, mesh.n_nodes(k - 1)
+        self.nq_ls = (2 * s) ** dim
         # NavierStokes, advection and reinitialisation advance their own TimeStepping objects
         self.ts_ns, self.ts_adv, self.ts_rei = (time_stepping_factory() for _ in range(3))
         self.prm = self._ls_prm(self.ts_ns)
         # initialize_mass_matrix_diagonal: the curvature operator without diffusion is the mass matrix
-        idx = np.indices((s * ncell[1] + 1, s * ncell[0] + 1))
-        col = ((idx[1] % 2) + 2 * (idx[0] % 2)).reshape(-1)
+        idx = np.indices(tuple(s * n + 1 for n in reversed(ncell)))      # (z,) y, x
+        col = sum((idx[dim - 1 - d] % 2) * 2 ** d for d in range(dim)).reshape(-1)
         diag = np.zeros(self.nn)
-        for c in range(4):
+        for c in range(2 ** dim):
             y = orc.ls_curvature_vmult(mesh, self.prm, (col == c).astype(float), apply_diffusion=False)
             diag[col == c] = y[col == c]
         self.inv_diag = 1.0 / diag
-        # no-slip at the bottom / top, symmetry (normal component) left / right (rising_bubble.cc:133-150)
-        self.con_u = orc.boundary_mask(mesh, k, 2, faces=[2, 3]) | orc.boundary_mask(mesh, k, 2, faces=[0, 1], comps=[0])
+        # no-slip at the bottom / top, symmetry (normal component) on the side walls (rising_bubble.cc:133-150)
+        if no_slip_everywhere:
+            self.con_u = orc.boundary_mask(mesh, k, dim)
+        else:
+            self.con_u = orc.boundary_mask(mesh, k, dim, faces=[2 * (dim - 1), 2 * (dim - 1) + 1])
+            for d in range(dim - 1):
+                self.con_u = self.con_u | orc.boundary_mask(mesh, k, dim, faces=[2 * d, 2 * d + 1], comps=[d])
         x = orc.node_coordinates(mesh, s, fe_type=1)
         self.phi = -np.tanh((np.linalg.norm(x - 0.5, axis=1) - 0.25) / (2 * self.eps_used))   # rising_bubble.cc:59-77
-        self.normal, self.kappa, self.kappa_old = np.zeros(2 * self.nn), np.zeros(self.nn), np.zeros(self.nn)
-        self.normal_q = np.zeros(mesh.n_cells * self.nq_ls * 2)
+        self.normal, self.kappa, self.kappa_old = np.zeros(dim * self.nn), np.zeros(self.nn), np.zeros(self.nn)
+        self.normal_q = np.zeros(mesh.n_cells * self.nq_ls * dim)
         self.log = {}
         self.phi, its = self.reinitialize(self.phi, 2)                      # number initial reinit steps
         self.ts_rei.next()
@@ -64,7 +72,7 @@ class RisingBubble2D:
     def compute_normal(self, phi, fast):
         A = lambda v: orc.ls_normal_vmult(self.mesh, self.prm, v)
         rhs = orc.ls_normal_rhs(self.mesh, self.prm, phi)
-        self.normal = ko.cg(A, rhs, x0=self.normal, inv_diag=np.tile(self.inv_diag, 2), max_it=4000,
+        self.normal = ko.cg(A, rhs, x0=self.normal, inv_diag=np.tile(self.inv_diag, self.dim), max_it=4000,
                             rel_tol=1e-5 if fast else 1e-7)[0]
 
     def reinitialize(self, phi, steps):                                      # reinitialization.cc:255-375
@@ -90,7 +98,7 @@ class RisingBubble2D:
         with np.errstate(divide="ignore", invalid="ignore"):                 # compute_curvature.cc:360-376
             dist = np.where(1 - self.phi ** 2 > 1e-2, self.eps_used * np.log((1 + self.phi) / (1 - self.phi)), 0.0)
         sel = kappa > 1e-4
-        kappa[sel] = 1.0 / (1.0 / kappa[sel] + dist[sel])                     # dim - 1 = 1
+        kappa[sel] = 1.0 / (1.0 / kappa[sel] + dist[sel] / (self.dim - 1))
         self.kappa = kappa
         return orc.ls_compute_force(mesh, self.s, self.k, H, kappa, surface_tension=0.0245, gravity=0.98, density=1.0,
                                     density_diff=-0.9, viscosity=0.01, viscosity_diff=-0.009,
@@ -98,38 +106,51 @@ class RisingBubble2D:
 
     # ---- exact Newton step: Jacobian by coloured probing, sparse LU
     def _assemble(self, vm):
-        mesh, k, nu, npp = self.mesh, self.k, self.nu, self.np_
+        mesh, k, nu, npp, dim = self.mesh, self.k, self.nu, self.np_, self.dim
         nnu, nnp = mesh.nodes_per_dim(k), mesh.nodes_per_dim(k - 1)
-        iu, ip = np.indices((nnu[1], nnu[0])), np.indices((nnp[1], nnp[0]))
-        Iu, Ju, Ip, Jp = iu[1].reshape(-1), iu[0].reshape(-1), ip[1].reshape(-1), ip[0].reshape(-1)
+        iu, ip = np.indices(tuple(reversed(nnu))), np.indices(tuple(reversed(nnp)))
+        Xu = [iu[dim - 1 - d].reshape(-1) for d in range(dim)]       # node coordinates (index units), x first
+        Xp = [ip[dim - 1 - d].reshape(-1) for d in range(dim)]
         P, Pp = 6, 3                                        # probe columns 3 cells apart never share a row
-        colu, colp = (Iu % P) + P * (Ju % P), (Ip % Pp) + Pp * (Jp % Pp)
-        rows, cols, vals = [], [], []
+        colu = sum((Xu[d] % P) * P ** d for d in range(dim))
+        colp = sum((Xp[d] % Pp) * Pp ** d for d in range(dim))
         near = lambda a, c, per: c + per * np.round((a - c) / per).astype(int)
-        for c in range(P * P):
-            ci, cj = c % P, c // P
-            for comp in range(2):
+
+        def flat(coords, nn):
+            out = coords[dim - 1]
+            for d in range(dim - 2, -1, -1):
+                out = out * nn[d] + coords[d]
+            return out
+        rows, cols, vals = [], [], []
+        for c in range(P ** dim):
+            cc = [(c // P ** d) % P for d in range(dim)]
+            sel = np.nonzero(colu == c)[0]
+            if sel.size == 0:
+                continue
+            for comp in range(dim):
                 e = np.zeros(nu)
-                e[2 * np.nonzero(colu == c)[0] + comp] = 1.0
+                e[dim * sel + comp] = 1.0
                 yu, yp = vm(e, np.zeros(npp))
                 nz = np.nonzero(yu)[0]
                 rows.append(nz)
-                cols.append(2 * (near(Ju[nz // 2], cj, P) * nnu[0] + near(Iu[nz // 2], ci, P)) + comp)
+                cols.append(dim * flat([near(Xu[d][nz // dim], cc[d], P) for d in range(dim)], nnu) + comp)
                 vals.append(yu[nz])
-                nz = np.nonzero(yp)[0]                      # pressure node (I,J) sits at velocity node (2I, 2J)
+                nz = np.nonzero(yp)[0]                      # pressure node I sits at velocity node 2 I
                 rows.append(nu + nz)
-                cols.append(2 * (near(2 * Jp[nz], cj, P) * nnu[0] + near(2 * Ip[nz], ci, P)) + comp)
+                cols.append(dim * flat([near(2 * Xp[d][nz], cc[d], P) for d in range(dim)], nnu) + comp)
                 vals.append(yp[nz])
-        for c in range(Pp * Pp):
-            ci, cj = c % Pp, c // Pp
+        for c in range(Pp ** dim):
+            cc = [(c // Pp ** d) % Pp for d in range(dim)]
+            if not np.any(colp == c):
+                continue
             yu, yp = vm(np.zeros(nu), (colp == c).astype(float))
             nz = np.nonzero(yu)[0]
             rows.append(nz)
-            cols.append(nu + near(Ju[nz // 2] / 2, cj, Pp) * nnp[0] + near(Iu[nz // 2] / 2, ci, Pp))
+            cols.append(nu + flat([near(Xu[d][nz // dim] / 2, cc[d], Pp) for d in range(dim)], nnp))
             vals.append(yu[nz])
             nz = np.nonzero(yp)[0]
             rows.append(nu + nz)
-            cols.append(nu + near(Jp[nz], cj, Pp) * nnp[0] + near(Ip[nz], ci, Pp))
+            cols.append(nu + flat([near(Xp[d][nz], cc[d], Pp) for d in range(dim)], nnp))
             vals.append(yp[nz])
         n = nu + npp
         return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
@@ -154,7 +175,7 @@ class RisingBubble2D:
         ta = self.ts_adv
         ta.next()
         self.prm = self._ls_prm(ta)
-        uq = np.zeros(mesh.n_cells * self.nq_ls * 2)
+        uq = np.zeros(mesh.n_cells * self.nq_ls * self.dim)
         rhs = orc.ls_advect_rhs(mesh, self.prm, k, self.phi, self.phi_old, self.phi_oo, self.u, uq, ta.weight_old(),
                                 ta.weight_old_old(), ta.scheme == "bdf_2" and ta.step_no() > 1)
         A = lambda v: orc.ls_advect_vmult(mesh, self.prm, v, uq)
@@ -170,7 +191,7 @@ class RisingBubble2D:
         nsp = orc.NSParams.make(beta=0.5, density=1.0, viscosity=0.01, density_diff=-0.9, weight=ts.weight(),
                                 weight_old=ts.weight_old(), weight_old_old=ts.weight_old_old(), tau1=ts.tau1(),
                                 extrap_old=ts.factor_extrapol_old, extrap_old_old=ts.factor_extrapol_old_old)
-        lin, damp, history = np.zeros(mesh.n_cells * 9 * 6), np.zeros_like(rho), []
+        lin, damp, history = np.zeros(mesh.n_cells * (k + 1) ** self.dim * orc.n_lin(self.dim)), np.zeros_like(rho), []
         for _ in range(10):
             ru, rp = orc.ns_residual(mesh, k, nsp, self.u, self.p, self.u_old, self.u_oo, con_u=self.con_u, lin=lin,
                                      rho=rho, mu=mu, damp=damp, user_u=force)
@@ -178,7 +199,11 @@ class RisingBubble2D:
             history.append(float(np.hypot(np.linalg.norm(ru), np.linalg.norm(rp))))
             if history[-1] < tol_nl:
                 break
-            vm = lambda a, b: orc.ns_vmult(mesh, k, nsp, a, b, self.con_u, None, lin=lin, rho=rho, mu=mu, damp=damp)
+            if self.dim == 3:      # OpenMP sum-factorised restatement (checked against the naive one)
+                vm = lambda a, b: tuple(v.copy() for v in orc.fast_ns_vmult(mesh, k, nsp, a, b, self.con_u, None, lin=lin,
+                                                                            rho=rho, mu=mu, damp=damp))
+            else:
+                vm = lambda a, b: orc.ns_vmult(mesh, k, nsp, a, b, self.con_u, None, lin=lin, rho=rho, mu=mu, damp=damp)
             J = self._assemble(vm).tolil()
             J[nu, :] = 0
             J[nu, nu] = 1.0                                                   # pin one pressure value

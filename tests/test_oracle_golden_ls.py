@@ -112,7 +112,7 @@ def test_rising_bubble_three_time_steps_match_the_reference_output():
         ref = json.load(f)["rising_bubble_ls"]
     fp = adaflo_amd.FlowParameters(velocity_degree=2, time_step_size_start=0.02, end_time=1.0)
     with threadpool_limits(limits=1, user_api="blas"):
-        sim = tpo.RisingBubble2D(lambda: adaflo_amd.TimeStepping(fp))
+        sim = tpo.RisingBubble(lambda: adaflo_amd.TimeStepping(fp))
         assert sim.log["initial_reinitialize"] == ref["initial_reinitialize_iterations"]
         for expected in ref["time_steps"]:
             (adv_r0, adv_it), rei_its, history = sim.advance_time_step()

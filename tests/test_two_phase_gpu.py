@@ -3,7 +3,8 @@
 device: level-set advection / reinitialisation / normal / curvature solves, Heaviside + force with
 the variable density / viscosity arrays, two-phase residual, Newton with FGMRES + block
 preconditioner on the two-phase Jacobian.  The reference has no 3D golden output for this case
-(its rising_bubble outputs are 2D), so the checks are physical invariants."""
+(its rising_bubble outputs are 2D), so the checks are physical invariants, plus a comparison of the
+printed per-step quantities with the oracle's time step, which is pinned to the 2D golden output."""
 import numpy as np
 import pytest
 
@@ -17,7 +18,7 @@ def test_rising_bubble_three_time_steps():
     fp = adaflo_amd.FlowParameters(
         velocity_degree=2, density=1.0, density_diff=-0.9, viscosity=0.01, viscosity_diff=-0.009,
         surface_tension=0.0245, gravity=0.98, epsilon=1.5, concentration_subdivisions=2,
-        interpolate_grad_onto_pressure=True, time_step_size_start=0.02, end_time=1.0,
+        interpolate_grad_onto_pressure=True, curvature_correction=True, time_step_size_start=0.02, end_time=1.0,
         max_nl_iteration=10, tol_nl_iteration=1e-8, max_lin_iteration=200, tol_lin_iteration=1e-4)
     mesh = adaflo_amd.BrickMesh([8, 8, 16], [0., 0., 0.], [1., 1., 2.])
     centre = np.array([0.5, 0.5, 0.5])
@@ -47,3 +48,40 @@ def test_rising_bubble_three_time_steps():
     _, c = solver.bubble_volume_and_centre()
     assert abs(c[0] - 0.5) < 1e-8 and abs(c[1] - 0.5) < 1e-8
     assert abs(vols[-1] - vols[0]) < 0.02 * vols[0]
+
+
+def test_device_time_steps_equal_the_oracle_time_steps_in_3d():
+    """The oracle's two-phase time step (oracle/two_phase_oracle.py) reproduces the reference's 2D
+    golden output (tests/test_oracle_golden_ls.py).  The same oracle algorithm in 3D is the checker
+    here: on an 8 x 8 x 16 mesh the device drivers (adaflo_amd.LevelSetOKZSolver) must print the same
+    advection residual / iterations, reinitialisation iterations and first Navier-Stokes residual for
+    the first two time steps.  (Start-of-step quantities only: the device solves its Newton systems
+    with FGMRES to 1e-9, the oracle exactly.)"""
+    from threadpoolctl import threadpool_limits
+
+    from oracle import two_phase_oracle as tpo
+    kw = dict(velocity_degree=2, density=1.0, density_diff=-0.9, viscosity=0.01, viscosity_diff=-0.009,
+              surface_tension=0.0245, gravity=0.98, epsilon=1.5, concentration_subdivisions=2,
+              interpolate_grad_onto_pressure=True, curvature_correction=True, time_step_size_start=0.02, end_time=1.0,
+              max_nl_iteration=10, tol_nl_iteration=1e-9, max_lin_iteration=200, tol_lin_iteration=1e-4)
+    fp = adaflo_amd.FlowParameters(**kw)
+    mesh = adaflo_amd.BrickMesh([8, 8, 16], [0., 0., 0.], [1., 1., 2.])
+    dev = LevelSetOKZSolver(fp, mesh, lambda x: np.linalg.norm(x - 0.5, axis=1) - 0.25)
+    with threadpool_limits(limits=1, user_api="blas"):
+        ref = tpo.RisingBubble(lambda: adaflo_amd.TimeStepping(adaflo_amd.FlowParameters(**kw)), ncell=(8, 8, 16), s=2,
+                               no_slip_everywhere=True)
+        assert dev.initial_reinit_iterations == ref.log["initial_reinitialize"]
+        for step in range(2):
+            (adv_r0, adv_it), rei_its, history = ref.advance_time_step()
+            dev.navier_stokes.history.clear()
+            dev.advance_time_step()
+            d_it, d_r0 = dev.concentration_iterations[-1]
+            assert abs(d_it - adv_it) <= 1 and abs(d_r0 - adv_r0) <= 1e-6 * max(adv_r0, 1e-10), (step, d_it, adv_it, d_r0, adv_r0)
+            assert dev.reinit_iterations[-1] == rei_its, (step, dev.reinit_iterations[-1], rei_its)
+            first = float(np.hypot(*dev.navier_stokes.history[0]))
+            assert abs(first - history[0]) < 1e-6 * history[0], (step, first, history[0])
+    assert rel(dev.solution.numpy(), ref.phi) < 1e-6
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
