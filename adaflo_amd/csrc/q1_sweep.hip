@@ -563,6 +563,118 @@ namespace adaflo_hip
           out[o] = v;
         }
     }
+
+    // -------------------------------------------------------------------------------------------
+    // Constant-coefficient  c_mass (v, u) + c_lap (grad v, grad u)  for trilinear elements on the
+    // uniform refined grid is the tensor-product 27-point stencil
+    //   c_mass Mx My Mz + c_lap (Kx My Mz + Mx Ky Mz + Mx My Kz),
+    // M = h/6 [1 4 1], K = 1/h [-1 2 -1] (half rows at the domain boundary): the 2-point Gauss rule
+    // of the cell loop integrates these products exactly.  Pure gather: no seams, no fix-up pass.
+    // A thread owns one (i, j) node column of a z-chunk and marches in z with the in-plane sums
+    //   A_k = Mx My u_k,  B_k = (Kx My + Mx Ky) u_k  of three planes in registers:
+    //   dst_k = sum_dz (c_mass Mz + c_lap Kz)[dz] A_{k+dz} + c_lap Mz[dz] B_{k+dz}.
+    // HBM traffic: src once (+2/LZ halo planes) + dst once = 16 B per node.
+    struct StencilArgs
+    {
+      int           nnx, nny, nnz, LZ, n_chunks, blocks_per_plane;
+      long          plane, comp_stride;
+      double        m_off[3], m_ctr[3], k_off[3], k_ctr[3]; // h/6, h/3, -1/h, 1/h per direction
+      double        c_mass, c_lap, con_sign;
+      uint32_t      con;
+      const double *diag, *src;
+      double       *dst;
+    };
+
+    __global__ __launch_bounds__(256) void q1_stencil_kernel(const StencilArgs A)
+    {
+      const long nwg   = (long)A.blocks_per_plane * A.n_chunks;
+      const long wg    = xcd_remap(blockIdx.x, nwg);
+      const int  chunk = (int)(wg / A.blocks_per_plane);
+      const long p_raw = (wg % A.blocks_per_plane) * 256 + threadIdx.x;
+      const bool active = p_raw < A.plane;
+      const long p      = active ? p_raw : A.plane - 1;
+      const int  i = (int)(p % A.nnx), j = (int)(p / A.nnx);
+      const double *src_c = A.src + blockIdx.y * A.comp_stride;
+      double       *dst_c = A.dst + blockIdx.y * A.comp_stride;
+
+      // 1D rows of M and K at this node; a neighbour outside the mesh or on a constrained face
+      // contributes nothing
+      auto rows = [&](const int d, const int idx, const int n, double *m, double *k, long *off, const long stride) {
+        const bool lo = idx > 0, hi = idx < n - 1;
+        const bool clo = lo && !(idx - 1 == 0 && (A.con >> (2 * d) & 1));
+        const bool chi = hi && !(idx + 1 == n - 1 && (A.con >> (2 * d + 1) & 1));
+        m[0] = clo ? A.m_off[d] : 0.;
+        m[2] = chi ? A.m_off[d] : 0.;
+        m[1] = ((lo ? 1. : 0.) + (hi ? 1. : 0.)) * A.m_ctr[d];
+        k[0] = clo ? A.k_off[d] : 0.;
+        k[2] = chi ? A.k_off[d] : 0.;
+        k[1] = ((lo ? 1. : 0.) + (hi ? 1. : 0.)) * A.k_ctr[d];
+        off[0] = lo ? -stride : 0;
+        off[1] = 0;
+        off[2] = hi ? stride : 0;
+      };
+      double mx[3], kx[3], my[3], ky[3];
+      long   ox[3], oy[3];
+      rows(0, i, A.nnx, mx, kx, ox, 1);
+      rows(1, j, A.nny, my, ky, oy, A.nnx);
+      const bool con_xy = (i == 0 && (A.con >> 0 & 1)) || (i == A.nnx - 1 && (A.con >> 1 & 1)) ||
+                          (j == 0 && (A.con >> 2 & 1)) || (j == A.nny - 1 && (A.con >> 3 & 1));
+      // (rows of constrained nodes are overwritten below, so their own weights do not matter)
+
+      auto plane_sums = [&](const int k, double &Ap, double &Bp, double &centre) {
+        const double *s = src_c + (long)k * A.plane + p;
+        double        a[3], b[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+          {
+            const double *r  = s + oy[dy];
+            const double  v0 = r[ox[0]], v1 = r[0], v2 = r[ox[2]];
+            a[dy] = mx[0] * v0 + mx[1] * v1 + mx[2] * v2;
+            b[dy] = kx[0] * v0 + kx[1] * v1 + kx[2] * v2;
+            if (dy == 1)
+              centre = v1;
+          }
+        Ap = my[0] * a[0] + my[1] * a[1] + my[2] * a[2];
+        Bp = my[0] * b[0] + my[1] * b[1] + my[2] * b[2] + ky[0] * a[0] + ky[1] * a[1] + ky[2] * a[2];
+      };
+
+      const int  k0 = chunk * A.LZ, k1 = min(k0 + A.LZ, A.nnz);
+      const bool conz_lo = A.con >> 4 & 1, conz_hi = A.con >> 5 & 1;
+      double     Am = 0., Bm = 0., A0, B0, Ap = 0., Bp = 0., c0, cp = 0., cm = 0.;
+      if (k0 > 0 && !(k0 - 1 == 0 && conz_lo))
+        plane_sums(k0 - 1, Am, Bm, cm);
+      plane_sums(k0, A0, B0, c0);
+      if (k0 == 0 && conz_lo)
+        A0 = B0 = 0.;
+      for (int k = k0; k < k1; ++k)
+        {
+          const bool hi = k < A.nnz - 1, lo = k > 0;
+          if (hi)
+            {
+              plane_sums(k + 1, Ap, Bp, cp);
+              if (k + 1 == A.nnz - 1 && conz_hi)
+                Ap = Bp = 0.;
+            }
+          else
+            Ap = Bp = 0.;
+          const double nz  = (lo ? 1. : 0.) + (hi ? 1. : 0.);
+          const double mzc = nz * A.m_ctr[2], kzc = nz * A.k_ctr[2];
+          const double mzl = lo ? A.m_off[2] : 0., mzh = hi ? A.m_off[2] : 0.;
+          const double kzl = lo ? A.k_off[2] : 0., kzh = hi ? A.k_off[2] : 0.;
+          double       r   = (A.c_mass * mzl + A.c_lap * kzl) * Am + A.c_lap * mzl * Bm;
+          r += (A.c_mass * mzc + A.c_lap * kzc) * A0 + A.c_lap * mzc * B0;
+          r += (A.c_mass * mzh + A.c_lap * kzh) * Ap + A.c_lap * mzh * Bp;
+          const bool conz = (k == 0 && conz_lo) || (k == A.nnz - 1 && conz_hi);
+          if (active)
+            {
+              const long idx = (long)k * A.plane + p;
+              if (con_xy || conz)
+                r = (A.diag ? A.diag[idx] : A.con_sign) * c0;
+              __builtin_nontemporal_store(r, dst_c + idx);
+            }
+          Am = A0, Bm = B0, A0 = Ap, B0 = Bp, c0 = cp;
+        }
+    }
   } // namespace
 
   // ---------------------------------------------------------------------------------------------
@@ -622,6 +734,43 @@ namespace adaflo_hip
                       const int n_blocks, const double *coef_cell, const int coef_stride, const int coef_mid,
                       const double coef_shift)
   {
+    if (mode == Q1_MASS_LAPLACE && coef_cell == nullptr)
+      {
+        StencilArgs S{};
+        S.nnx = sub * ctx->desc.ncell[0] + 1;
+        S.nny = sub * ctx->desc.ncell[1] + 1;
+        S.nnz = sub * ctx->desc.ncell[2] + 1;
+        S.plane            = (long)S.nnx * S.nny;
+        S.comp_stride      = S.plane * S.nnz;
+        S.blocks_per_plane = (int)((S.plane + 255) / 256);
+        int lz = 32;
+        while (lz > 4 && (long)S.blocks_per_plane * ((S.nnz + lz - 1) / lz) < 2048)
+          lz /= 2;
+        S.LZ       = lz;
+        S.n_chunks = (S.nnz + lz - 1) / lz;
+        for (int d = 0; d < 3; ++d)
+          {
+            const double hs = ctx->desc.h[d] / sub;
+            S.m_off[d] = hs / 6.;
+            S.m_ctr[d] = hs / 3.;
+            S.k_off[d] = -1. / hs;
+            S.k_ctr[d] = 1. / hs;
+          }
+        S.c_mass   = c_mass;
+        S.c_lap    = c_lap;
+        S.con      = con;
+        S.con_sign = con_sign;
+        S.diag     = diag;
+        S.src      = src;
+        S.dst      = dst;
+        hipEvent_t stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
+        hipLaunchKernelGGL(q1_stencil_kernel, dim3((unsigned)(S.blocks_per_plane * S.n_chunks), (unsigned)n_blocks),
+                           dim3(256), 0, ctx->stream, S);
+        if (stop)
+          (void)hipEventRecord(stop, ctx->stream);
+        ctx->kernel_timer.count++;
+        return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+      }
     Q1Args A{};
     A.coef_cell   = coef_cell;
     A.coef_stride = coef_stride;
