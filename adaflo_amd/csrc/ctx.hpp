@@ -138,13 +138,14 @@ struct adaflo_ctx
 
   // block preconditioner of the coupled system (krylov.hip): inverse diagonals of the velocity
   // block, the pressure mass and the pressure Poisson operator, work vectors
-  adaflo_hip::DeviceBuffer pc_inv_u, pc_inv_pm, pc_inv_pl, pc_ones_p, pc_tmp_u, pc_tmp_p, pc_tmp_p2, pc_work;
+  adaflo_hip::DeviceBuffer pc_inv_u, pc_inv_pm, pc_inv_pl, pc_ones_p, pc_tmp_u, pc_tmp_p, pc_tmp_p2, pc_work, kr_work, kr_basis;
   bool                     pc_ready = false;
 
   // pressure constant mode (mode 0) data, source/navier_stokes_matrix.cc:117-168
   double *d_p_weights = nullptr, *d_p_modes = nullptr;
   double  inv_p_weight = 0.;
   double *d_scratch    = nullptr; // reduction scratch (partials + result)
+  double *h_result = nullptr, *h_result_dev = nullptr; // pinned host copy of reduction results + its device address
   size_t  scratch_count = 0;
 
   // matvec statistics (get_matvec_statistics) and dominant-kernel statistics

@@ -137,6 +137,22 @@ namespace adaflo_hip
       }
     };
 
+    // grow-only workspace kept in the context: hipMalloc / hipFree of multi-GB Krylov bases per solve
+    // costs more than the solve itself
+    double *persistent(DeviceBuffer &b, const size_t count)
+    {
+      if (b.count >= count && b.p)
+        return b.p;
+      if (b.p)
+        (void)hipFree(b.p);
+      b.p     = nullptr;
+      b.count = 0;
+      if (hipMalloc(&b.p, count * sizeof(double)) != hipSuccess)
+        return nullptr;
+      b.count = count;
+      return b.p;
+    }
+
     using Operator = std::function<int(double *, const double *)>;
 
     struct Krylov
@@ -198,7 +214,8 @@ namespace adaflo_hip
     }
     // single block, fixed order: out[0..1] = sums of the interleaved partials
     __global__ __launch_bounds__(KT) void reduce2_final_kernel(const double *__restrict__ partial, const int nb,
-                                                               double *__restrict__ out)
+                                                               double *__restrict__ out,
+                                                               double *__restrict__ host_out)
     {
       double s0 = 0., s1 = 0.;
       for (int i = threadIdx.x; i < nb; i += KT)
@@ -228,6 +245,8 @@ namespace adaflo_hip
             }
           out[0] = t0;
           out[1] = t1;
+          host_out[0] = t0; // pinned, device-mapped (ctx->h_result)
+          host_out[1] = t1;
         }
     }
     // (a.b, c.d)
@@ -316,13 +335,12 @@ namespace adaflo_hip
     int read2(Krylov &K, const unsigned nb, double &a, double &b)
     {
       double *scr = K.ctx->d_scratch; // [0..1] results, [8..) partials (allocated by host_dot)
-      hipLaunchKernelGGL(reduce2_final_kernel, dim3(1), dim3(KT), 0, K.ctx->stream, scr + 8, (int)nb, scr);
-      double h[2];
-      if (hipMemcpyAsync(h, scr, sizeof(h), hipMemcpyDeviceToHost, K.ctx->stream) != hipSuccess ||
-          hipStreamSynchronize(K.ctx->stream) != hipSuccess)
+      hipLaunchKernelGGL(reduce2_final_kernel, dim3(1), dim3(KT), 0, K.ctx->stream, scr + 8, (int)nb, scr,
+                         K.ctx->h_result_dev);
+      if (hipStreamSynchronize(K.ctx->stream) != hipSuccess)
         return ADAFLO_EHIP;
-      a = h[0];
-      b = h[1];
+      a = K.ctx->h_result[0];
+      b = K.ctx->h_result[1];
       return 0;
     }
 
@@ -568,14 +586,14 @@ int adaflo_solve(adaflo_ctx *ctx, int op, int method, double *x, const double *b
     return kfail(ctx, ADAFLO_ENOTINIT, "operator space not initialised (level-set degree 0?)");
   K.n = K.n_block * blocks;
   const int nvec = method == ADAFLO_SOLVER_CG ? 4 : 7;
-  Workspace w;
-  if (hipMalloc(&w.p, (size_t)nvec * K.n * sizeof(double)) != hipSuccess)
+  double *work = persistent(ctx->kr_work, (size_t)nvec * K.n);
+  if (!work)
     return kfail(ctx, ADAFLO_ENOMEM, "out of device memory for the Krylov vectors");
   int rc;
   if (method == ADAFLO_SOLVER_CG)
-    rc = solve_cg(K, x, b, *control, *result, w.p);
+    rc = solve_cg(K, x, b, *control, *result, work);
   else if (method == ADAFLO_SOLVER_BICGSTAB)
-    rc = solve_bicgstab(K, x, b, *control, *result, w.p);
+    rc = solve_bicgstab(K, x, b, *control, *result, work);
   else
     return kfail(ctx, ADAFLO_EINVAL, "unknown solver");
   if (rc != 0)
@@ -657,20 +675,20 @@ int adaflo_ns_preconditioner_setup(adaflo_ctx *ctx)
   for (DeviceBuffer *b : {&ctx->pc_inv_pm, &ctx->pc_inv_pl, &ctx->pc_ones_p, &ctx->pc_tmp_p, &ctx->pc_tmp_p2})
     if (int rc = pc_alloc(ctx, *b, np))
       return rc;
-  Workspace w;
-  if (hipMalloc(&w.p, (size_t)nu * sizeof(double)) != hipSuccess)
+  double *probe_work = persistent(ctx->kr_work, (size_t)nu);
+  if (!probe_work)
     return kfail(ctx, ADAFLO_ENOMEM, "out of device memory");
   if (int rc = probe_diagonal(ctx, [ctx](double *d, const double *s) { return adaflo_ns_velocity_vmult(ctx, d, s); },
-                              ctx->pc_inv_u.p, ctx->pc_tmp_u.p, w.p, ctx->k, 3))
+                              ctx->pc_inv_u.p, ctx->pc_tmp_u.p, probe_work, ctx->k, 3))
     return rc;
   if (int rc = probe_diagonal(ctx, [ctx](double *d, const double *s) { return adaflo_ns_pressure_mass_vmult(ctx, d, s); },
-                              ctx->pc_inv_pm.p, ctx->pc_tmp_p.p, w.p, ctx->k - 1, 1))
+                              ctx->pc_inv_pm.p, ctx->pc_tmp_p.p, probe_work, ctx->k - 1, 1))
     return rc;
   const bool poisson = ctx->ns.density > 0.; // :715
   if (poisson)
     if (int rc = probe_diagonal(ctx,
                                 [ctx](double *d, const double *s) { return adaflo_ns_pressure_poisson_vmult(ctx, d, s); },
-                                ctx->pc_inv_pl.p, ctx->pc_tmp_p.p, w.p, ctx->k - 1, 1))
+                                ctx->pc_inv_pl.p, ctx->pc_tmp_p.p, probe_work, ctx->k - 1, 1))
       return rc;
   if (int rc = invert_in_place(ctx, ctx->pc_inv_u.p, nu))
     return rc;
@@ -778,10 +796,10 @@ int adaflo_ns_solve_system(adaflo_ctx *ctx, double *update_u, double *update_p, 
   const long nu = 3 * ctx->n_nodes_u, np = ctx->n_nodes_p, n = nu + np;
   const int  m  = restart;
   // Krylov basis V_0..V_m and the preconditioned vectors Z_0..Z_{m-1}; block vectors stored [u | p]
-  Workspace w;
-  if (hipMalloc(&w.p, (size_t)(2 * m + 2) * n * sizeof(double)) != hipSuccess)
+  double *basis = persistent(ctx->kr_basis, (size_t)(2 * m + 2) * n);
+  if (!basis)
     return kfail(ctx, ADAFLO_ENOMEM, "out of device memory for the FGMRES basis");
-  double *V = w.p, *Z = w.p + (size_t)(m + 1) * n, *wv = Z + (size_t)m * n;
+  double *V = basis, *Z = basis + (size_t)(m + 1) * n, *wv = Z + (size_t)m * n;
   auto vec = [&](double *base, const int j) { return base + (size_t)j * n; };
   auto dotn = [&](const double *a, const double *b) { return host_dot(ctx, a, b, n); };
   auto axpy = [&](double *y, const double a, const double *x, const double bsc) {

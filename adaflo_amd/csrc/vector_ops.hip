@@ -64,7 +64,8 @@ namespace adaflo_hip
 
     // single block: result[0] = sum(part[0..np))  (fixed order -> deterministic)
     __global__ __launch_bounds__(VT) void dot_final_kernel(const double *__restrict__ part,
-                                                           const int np, double *__restrict__ result)
+                                                           const int np, double *__restrict__ result,
+                                                           double *__restrict__ host_result)
     {
       __shared__ double red[VT / 64];
       double            s = 0.;
@@ -81,6 +82,8 @@ namespace adaflo_hip
           for (int w = 0; w < VT / 64; ++w)
             t += red[w];
           result[0] = t;
+          if (host_result) // pinned, device-mapped: visible to the host after the stream synchronises
+            host_result[0] = t;
         }
     }
 
@@ -180,6 +183,14 @@ namespace adaflo_hip
 
   static int ensure_scratch(adaflo_ctx *ctx, const size_t count)
   {
+    if (!ctx->h_result)
+      {
+        // results of reductions travel through pinned, device-mapped host memory: a pageable
+        // hipMemcpy D2H costs ~200 us per Krylov scalar on this platform
+        if (hipHostMalloc((void **)&ctx->h_result, 8 * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&ctx->h_result_dev, ctx->h_result, 0) != hipSuccess)
+          return ADAFLO_ENOMEM;
+      }
     if (ctx->scratch_count >= count)
       return 0;
     if (ctx->d_scratch)
@@ -190,7 +201,7 @@ namespace adaflo_hip
     return 0;
   }
 
-  static int launch_dot(adaflo_ctx *ctx, const double *a, const double *b, const long n)
+  static int launch_dot(adaflo_ctx *ctx, const double *a, const double *b, const long n, const bool to_host = false)
   {
     const unsigned nb = grid_for(n, 4);
     if (int e = ensure_scratch(ctx, 2 * 256 * 16 + 8)) // (the fused Krylov kernels leave two partials per block)
@@ -198,7 +209,7 @@ namespace adaflo_hip
     hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(VT), 0, ctx->stream, a, b, n,
                        ctx->d_scratch + 8);
     hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(VT), 0, ctx->stream, ctx->d_scratch + 8,
-                       (int)nb, ctx->d_scratch);
+                       (int)nb, ctx->d_scratch, to_host ? ctx->h_result_dev : nullptr);
     return check();
   }
 
@@ -214,12 +225,10 @@ namespace adaflo_hip
 
   double host_dot(adaflo_ctx *ctx, const double *a, const double *b, const long n)
   {
-    double r = 0.;
-    if (launch_dot(ctx, a, b, n) != 0)
+    if (launch_dot(ctx, a, b, n, true) != 0)
       return 0.;
-    (void)hipMemcpyAsync(&r, ctx->d_scratch, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     (void)hipStreamSynchronize(ctx->stream);
-    return r;
+    return ctx->h_result[0];
   }
 
   int launch_halo(adaflo_ctx *ctx, double *vec, double *buf, const HaloPlan &plan, const int mode)
