@@ -138,7 +138,7 @@ struct adaflo_ctx
 
   // block preconditioner of the coupled system (krylov.hip): inverse diagonals of the velocity
   // block, the pressure mass and the pressure Poisson operator, work vectors
-  adaflo_hip::DeviceBuffer pc_inv_u, pc_inv_pm, pc_inv_pl, pc_ones_p, pc_tmp_u, pc_tmp_p, pc_tmp_p2, pc_work, kr_work, kr_basis;
+  adaflo_hip::DeviceBuffer pc_inv_u, pc_inv_pm, pc_inv_pl, pc_ones_p, pc_tmp_u, pc_tmp_p, pc_tmp_p2, pc_work, kr_work, kr_basis, kr_scalars;
   bool                     pc_ready = false;
 
   // pressure constant mode (mode 0) data, source/navier_stokes_matrix.cc:117-168

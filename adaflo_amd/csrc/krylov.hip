@@ -17,7 +17,8 @@
 // Vorst's right-preconditioned BiCGStab with the convergence check after the first half step, as
 // deal.II's SolverBicgstab does).  oracle/krylov_oracle.py restates the same recurrences in numpy.
 // Scalars of the recurrences are reduced on the device (two-stage deterministic dot product) and
-// read back once per use: the stopping test needs them on the host every iteration anyway.
+// STAY there: the kernels read alpha / beta / omega from device memory and the host inspects the
+// stopping flag one iteration late (see "Device-resident recurrences" below).
 #include "kernels.hpp"
 
 #include <cmath>
@@ -43,14 +44,6 @@ namespace adaflo_hip
     {
       for (long i = blockIdx.x * (long)KT + threadIdx.x; i < n; i += (long)gridDim.x * KT)
         y[i] = b == 0. ? a * x[i] : a * x[i] + b * y[i];
-    }
-    // z = x + a*(y + b*w)         (BiCGStab: p = r + beta (p - omega v))
-    __global__ __launch_bounds__(KT) void xpaybw_kernel(double *__restrict__ z, const double *__restrict__ x,
-                                                        const double a, const double *__restrict__ y, const double b,
-                                                        const double *__restrict__ w, const long n)
-    {
-      for (long i = blockIdx.x * (long)KT + threadIdx.x; i < n; i += (long)gridDim.x * KT)
-        z[i] = x[i] + a * (y[i] + b * w[i]);
     }
     // dst[blk][i] = src[blk][i] * inv_diag[i]   (DiagonalPreconditioner::vmult, :82-124; identity if null)
     __global__ __launch_bounds__(KT) void precond_kernel(double *__restrict__ dst, const double *__restrict__ src,
@@ -182,10 +175,9 @@ namespace adaflo_hip
     }
 
     // ---- fused vector kernels: every pass over the vectors does all the updates that are ready
-    // and leaves up to two partial dot products per block; one tiny kernel finishes them and ONE
-    // 16-byte read-back per fused step brings them to the host (profile of a Navier-Stokes time
-    // step before the fusion: 47 % of the kernel time in separate axpy / dot / preconditioner
-    // passes and their launches)
+    // and leaves up to two partial dot products per block, finished by one tiny kernel (profile of
+    // a Navier-Stokes time step before the fusion: 47 % of the kernel time in separate axpy / dot /
+    // preconditioner passes and their launches)
     __device__ __forceinline__ void block_reduce2(double s0, double s1, double *__restrict__ partial)
     {
       __shared__ double red[2][KT / 64];
@@ -212,11 +204,64 @@ namespace adaflo_hip
           partial[2 * blockIdx.x + 1] = t1;
         }
     }
-    // single block, fixed order: out[0..1] = sums of the interleaved partials
-    __global__ __launch_bounds__(KT) void reduce2_final_kernel(const double *__restrict__ partial, const int nb,
-                                                               double *__restrict__ out,
-                                                               double *__restrict__ host_out)
+    // -------------------------------------------------------------------------------------------
+    // Device-resident recurrences.  The scalars (rho, alpha, omega, beta, residual, stopping flag)
+    // live in a small device array S; the one-block kernel that finishes a two-value reduction
+    // also advances the recurrence (kr_final_kernel), and the fused vector kernels read their
+    // coefficients from S and return at once when the `done` flag is up.  The host therefore
+    // never waits for a scalar: it enqueues iteration i+1 and only then looks at the stopping flag
+    // of iteration i (pinned, device-mapped mirror H, guarded by an event), so the GPU queue never
+    // drains; the price is one speculative operator application after convergence.
+    // (Measured alternative, discarded: finishing the reduction in the last block of the vector
+    // kernel itself -- arrival ticket + agent-scope fences, no extra kernel.  The fences write back
+    // the XCD's L2 per block: bicg_x 71 -> 278 us, dot 12 -> 76 us at 6.9 M unknowns.)
+    enum
     {
+      S_RHO = 0, // BiCGStab: rho = rbar.r;  CG: r.z
+      S_ALPHA,
+      S_OMEGA,
+      S_BETA,
+      S_RES,
+      S_THRESHOLD, // max(abs_tol, rel_tol * ||r_0||)
+      S_DONE,
+      S_CONVERGED,
+      S_ITERATIONS,
+      S_HALF, // BiCGStab: converged after the first half step
+      S_COUNT
+    };
+    enum
+    {
+      ST_CG_ALPHA = 0,
+      ST_CG_UPDATE,
+      ST_BICG_ALPHA,
+      ST_BICG_S,
+      ST_BICG_OMEGA,
+      ST_BICG_X
+    };
+
+    __global__ void kr_init_kernel(double *S, double *H, const double rho, const double threshold, const double res)
+    {
+      if (threadIdx.x == 0)
+        {
+          for (int i = 0; i < S_COUNT; ++i)
+            S[i] = 0.;
+          S[S_RHO]       = rho;
+          S[S_ALPHA]     = 1.;
+          S[S_OMEGA]     = 1.;
+          S[S_RES]       = res;
+          S[S_THRESHOLD] = threshold;
+          H[0] = H[1] = H[2] = 0.;
+          H[3] = res;
+        }
+    }
+
+    // single block: sums the interleaved partials in a fixed order, then advances the recurrence
+    __global__ __launch_bounds__(KT) void kr_final_kernel(const double *__restrict__ partial, const int nb,
+                                                          double *__restrict__ S, double *__restrict__ H,
+                                                          const int stage, const int it)
+    {
+      if (S[S_DONE] != 0.)
+        return;
       double s0 = 0., s1 = 0.;
       for (int i = threadIdx.x; i < nb; i += KT)
         {
@@ -235,41 +280,105 @@ namespace adaflo_hip
           red[1][threadIdx.x >> 6] = s1;
         }
       __syncthreads();
-      if (threadIdx.x == 0)
+      if (threadIdx.x != 0)
+        return;
+      double t0 = 0., t1 = 0.;
+      for (int w = 0; w < KT / 64; ++w)
         {
-          double t0 = 0., t1 = 0.;
-          for (int w = 0; w < KT / 64; ++w)
-            {
-              t0 += red[0][w];
-              t1 += red[1][w];
-            }
-          out[0] = t0;
-          out[1] = t1;
-          host_out[0] = t0; // pinned, device-mapped (ctx->h_result)
-          host_out[1] = t1;
+          t0 += red[0][w];
+          t1 += red[1][w];
+        }
+      bool report = false;
+      switch (stage)
+        {
+          case ST_CG_ALPHA: // t0 = p.Ap
+          case ST_BICG_ALPHA: // t0 = rbar.v
+            S[S_ALPHA] = S[S_RHO] / t0;
+            break;
+          case ST_CG_UPDATE: // t0 = r.r, t1 = r.z
+            S[S_RES]        = sqrt(t0);
+            S[S_ITERATIONS] = it;
+            if (S[S_RES] <= S[S_THRESHOLD])
+              S[S_DONE] = S[S_CONVERGED] = 1.;
+            else
+              {
+                S[S_BETA] = t1 / S[S_RHO];
+                S[S_RHO]  = t1;
+              }
+            report = true;
+            break;
+          case ST_BICG_S: // t0 = s.s
+            S[S_RES]        = sqrt(t0);
+            S[S_ITERATIONS] = it;
+            if (S[S_RES] <= S[S_THRESHOLD])
+              S[S_HALF] = 1.; // x += alpha y is applied by the x kernel with omega = 0
+            break;
+          case ST_BICG_OMEGA: // t0 = t.s, t1 = t.t
+            S[S_OMEGA] = S[S_HALF] != 0. ? 0. : t0 / t1;
+            break;
+          case ST_BICG_X: // t0 = r.r, t1 = rbar.r
+            S[S_RES] = sqrt(t0);
+            if (S[S_HALF] != 0. || S[S_RES] <= S[S_THRESHOLD])
+              S[S_DONE] = S[S_CONVERGED] = 1.;
+            else if (t1 == 0. || S[S_OMEGA] == 0.)
+              S[S_DONE] = 1.; // breakdown (deal.II restarts; the callers fall back to GMRES)
+            else
+              {
+                S[S_BETA] = (t1 / S[S_RHO]) * (S[S_ALPHA] / S[S_OMEGA]);
+                S[S_RHO]  = t1;
+              }
+            report = true;
+            break;
+        }
+      if (report)
+        {
+          H[1] = S[S_CONVERGED];
+          H[2] = S[S_ITERATIONS];
+          H[3] = S[S_RES];
+          H[0] = S[S_DONE];
         }
     }
-    // (a.b, c.d)
-    __global__ __launch_bounds__(KT) void dot2_kernel(const double *a, const double *b, const double *c,
-                                                      const double *d, const long n, double *__restrict__ partial)
+
+    // (a.b, 0)
+    __global__ __launch_bounds__(KT) void dot1_dev_kernel(const double *__restrict__ a, const double *__restrict__ b,
+                                                          const long n, double *__restrict__ partial,
+                                                          const double *__restrict__ S)
     {
+      if (S[S_DONE] != 0.)
+        return;
+      double s0 = 0.;
+      for (long i = blockIdx.x * (long)KT + threadIdx.x; i < n; i += (long)gridDim.x * KT)
+        s0 += a[i] * b[i];
+      block_reduce2(s0, 0., partial);
+    }
+    // (t.s, t.t)
+    __global__ __launch_bounds__(KT) void dot_ts_dev_kernel(const double *__restrict__ t, const double *__restrict__ sv,
+                                                            const long n, double *__restrict__ partial,
+                                                            const double *__restrict__ S)
+    {
+      if (S[S_DONE] != 0.)
+        return;
       double s0 = 0., s1 = 0.;
       for (long i = blockIdx.x * (long)KT + threadIdx.x; i < n; i += (long)gridDim.x * KT)
         {
-          s0 += a[i] * b[i];
-          s1 += c[i] * d[i];
+          const double ti = t[i];
+          s0 += ti * sv[i];
+          s1 += ti * ti;
         }
       block_reduce2(s0, s1, partial);
     }
     // CG: x += alpha p, r -= alpha Ap, z = P r;  (r.r, r.z)
-    __global__ __launch_bounds__(KT) void cg_update_kernel(double *__restrict__ x, double *__restrict__ r,
-                                                           double *__restrict__ z, const double *__restrict__ p,
-                                                           const double *__restrict__ Ap,
-                                                           const double *__restrict__ inv, const long n_block,
-                                                           const double alpha, const long n,
-                                                           double *__restrict__ partial)
+    __global__ __launch_bounds__(KT) void cg_update_dev_kernel(double *__restrict__ x, double *__restrict__ r,
+                                                               double *__restrict__ z, const double *__restrict__ p,
+                                                               const double *__restrict__ Ap,
+                                                               const double *__restrict__ inv, const long n_block,
+                                                               const long n, double *__restrict__ partial,
+                                                               const double *__restrict__ S)
     {
-      double s0 = 0., s1 = 0.;
+      if (S[S_DONE] != 0.)
+        return;
+      const double alpha = S[S_ALPHA];
+      double       s0 = 0., s1 = 0.;
       for (long i = blockIdx.x * (long)KT + threadIdx.x; i < n; i += (long)gridDim.x * KT)
         {
           x[i] += alpha * p[i];
@@ -282,13 +391,25 @@ namespace adaflo_hip
         }
       block_reduce2(s0, s1, partial);
     }
-    // BiCGStab: p = first ? r : r + beta (p - omega v);  y = P p
-    __global__ __launch_bounds__(KT) void bicg_p_kernel(double *__restrict__ p, double *__restrict__ y,
-                                                        const double *__restrict__ r, const double *__restrict__ v,
-                                                        const double *__restrict__ inv, const long n_block,
-                                                        const double beta, const double omega, const int first,
-                                                        const long n)
+    // CG: p = z + beta p
+    __global__ __launch_bounds__(KT) void cg_p_dev_kernel(double *__restrict__ p, const double *__restrict__ z,
+                                                          const long n, const double *__restrict__ S)
     {
+      if (S[S_DONE] != 0.)
+        return;
+      const double beta = S[S_BETA];
+      for (long i = blockIdx.x * (long)KT + threadIdx.x; i < n; i += (long)gridDim.x * KT)
+        p[i] = z[i] + beta * p[i];
+    }
+    // BiCGStab: p = first ? r : r + beta (p - omega v);  y = P p
+    __global__ __launch_bounds__(KT) void bicg_p_dev_kernel(double *__restrict__ p, double *__restrict__ y,
+                                                            const double *__restrict__ r, const double *__restrict__ v,
+                                                            const double *__restrict__ inv, const long n_block,
+                                                            const int first, const long n, const double *__restrict__ S)
+    {
+      if (S[S_DONE] != 0.)
+        return;
+      const double beta = S[S_BETA], omega = S[S_OMEGA];
       for (long i = blockIdx.x * (long)KT + threadIdx.x; i < n; i += (long)gridDim.x * KT)
         {
           const double pi = first ? r[i] : r[i] + beta * (p[i] - omega * v[i]);
@@ -297,12 +418,15 @@ namespace adaflo_hip
         }
     }
     // BiCGStab: s = r - alpha v (in r), z = P s;  (s.s, -)
-    __global__ __launch_bounds__(KT) void bicg_s_kernel(double *__restrict__ r, double *__restrict__ z,
-                                                        const double *__restrict__ v, const double *__restrict__ inv,
-                                                        const long n_block, const double alpha, const long n,
-                                                        double *__restrict__ partial)
+    __global__ __launch_bounds__(KT) void bicg_s_dev_kernel(double *__restrict__ r, double *__restrict__ z,
+                                                            const double *__restrict__ v, const double *__restrict__ inv,
+                                                            const long n_block, const long n, double *__restrict__ partial,
+                                                            const double *__restrict__ S)
     {
-      double s0 = 0.;
+      if (S[S_DONE] != 0.)
+        return;
+      const double alpha = S[S_ALPHA];
+      double       s0    = 0.;
       for (long i = blockIdx.x * (long)KT + threadIdx.x; i < n; i += (long)gridDim.x * KT)
         {
           const double si = r[i] - alpha * v[i];
@@ -313,35 +437,79 @@ namespace adaflo_hip
       block_reduce2(s0, 0., partial);
     }
     // BiCGStab: x += alpha y + omega z, r -= omega t;  (r.r, rbar.r)
-    __global__ __launch_bounds__(KT) void bicg_x_kernel(double *__restrict__ x, double *__restrict__ r,
-                                                        const double *__restrict__ y, const double *__restrict__ z,
-                                                        const double *__restrict__ t, const double *__restrict__ rbar,
-                                                        const double alpha, const double omega, const long n,
-                                                        double *__restrict__ partial)
+    __global__ __launch_bounds__(KT) void bicg_x_dev_kernel(double *__restrict__ x, double *__restrict__ r,
+                                                            const double *__restrict__ y, const double *__restrict__ z,
+                                                            const double *__restrict__ t, const double *__restrict__ rbar,
+                                                            const long n, double *__restrict__ partial,
+                                                            const double *__restrict__ S)
     {
-      double s0 = 0., s1 = 0.;
-      for (long i = blockIdx.x * (long)KT + threadIdx.x; i < n; i += (long)gridDim.x * KT)
-        {
-          x[i] += alpha * y[i] + omega * z[i];
-          const double ri = r[i] - omega * t[i];
-          r[i]            = ri;
-          s0 += ri * ri;
-          s1 += rbar[i] * ri;
-        }
+      if (S[S_DONE] != 0.)
+        return;
+      const double alpha = S[S_ALPHA], omega = S[S_OMEGA];
+      double       s0 = 0., s1 = 0.;
+      if (omega == 0.) // half-step exit: t was computed speculatively and may hold anything
+        for (long i = blockIdx.x * (long)KT + threadIdx.x; i < n; i += (long)gridDim.x * KT)
+          {
+            x[i] += alpha * y[i];
+            const double ri = r[i];
+            s0 += ri * ri;
+            s1 += rbar[i] * ri;
+          }
+      else
+        for (long i = blockIdx.x * (long)KT + threadIdx.x; i < n; i += (long)gridDim.x * KT)
+          {
+            x[i] += alpha * y[i] + omega * z[i];
+            const double ri = r[i] - omega * t[i];
+            r[i]            = ri;
+            s0 += ri * ri;
+            s1 += rbar[i] * ri;
+          }
       block_reduce2(s0, s1, partial);
     }
 
-    // finish the two partial sums left by the previous fused kernel and read them
-    int read2(Krylov &K, const unsigned nb, double &a, double &b)
+    // host side of the pipelined loop: `enqueue(it)` launches iteration it; the stopping flag of
+    // iteration it-1 is inspected after iteration it has been queued
+    struct Pipeline
     {
-      double *scr = K.ctx->d_scratch; // [0..1] results, [8..) partials (allocated by host_dot)
-      hipLaunchKernelGGL(reduce2_final_kernel, dim3(1), dim3(KT), 0, K.ctx->stream, scr + 8, (int)nb, scr,
-                         K.ctx->h_result_dev);
-      if (hipStreamSynchronize(K.ctx->stream) != hipSuccess)
-        return ADAFLO_EHIP;
-      a = K.ctx->h_result[0];
-      b = K.ctx->h_result[1];
-      return 0;
+      adaflo_ctx *ctx;
+      hipEvent_t  ev[2] = {nullptr, nullptr};
+      ~Pipeline()
+      {
+        for (hipEvent_t e : ev)
+          if (e)
+            (void)hipEventDestroy(e);
+      }
+      int run(const int max_iterations, const std::function<int(int)> &enqueue, adaflo_solver_result &out)
+      {
+        for (hipEvent_t &e : ev)
+          if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+            return ADAFLO_EHIP;
+        volatile double *H = ctx->h_result;
+        for (int it = 1; it <= max_iterations; ++it)
+          {
+            if (int e = enqueue(it))
+              return e;
+            (void)hipEventRecord(ev[it & 1], ctx->stream);
+            if (it > 1)
+              {
+                if (hipEventSynchronize(ev[(it - 1) & 1]) != hipSuccess)
+                  return ADAFLO_EHIP;
+                if (H[0] != 0.)
+                  break;
+              }
+          }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+          return ADAFLO_EHIP;
+        out.converged      = H[1] != 0. ? 1 : 0;
+        out.iterations     = (int)H[2];
+        out.final_residual = H[3];
+        return 0;
+      }
+    };
+
+    double *krylov_scalars(adaflo_ctx *ctx)
+    {
+      return persistent(ctx->kr_scalars, 64);
     }
 
     // returns 0, fills result; the iteration count follows SolverControl::last_step()
@@ -366,32 +534,28 @@ namespace adaflo_hip
         }
       K.precondition(z, r);
       (void)hipMemcpyAsync(p, z, n * sizeof(double), hipMemcpyDeviceToDevice, K.ctx->stream);
-      double rz = K.dot(r, z);
-      double *partial = K.ctx->d_scratch + 8;
-      for (int it = 1; it <= c.max_iterations; ++it)
-        {
+      const double rz = K.dot(r, z);
+      double      *S = krylov_scalars(K.ctx), *H = K.ctx->h_result_dev, *partial = K.ctx->d_scratch + 8;
+      if (!S)
+        return ADAFLO_ENOMEM;
+      hipStream_t st = K.ctx->stream;
+      hipLaunchKernelGGL(kr_init_kernel, dim3(1), dim3(64), 0, st, S, H, rz, std::fmax(c.abs_tol, c.rel_tol * res), res);
+      Pipeline pipe{K.ctx};
+      return pipe.run(
+        c.max_iterations,
+        [&](const int it) {
+          if (it > 1)
+            hipLaunchKernelGGL(cg_p_dev_kernel, dim3(nb), dim3(KT), 0, st, p, z, n, S); // p = z + beta p
           if (int e = K.A(Ap, p))
             return e;
-          const double alpha = rz / K.dot(p, Ap);
-          hipLaunchKernelGGL(cg_update_kernel, dim3(nb), dim3(KT), 0, K.ctx->stream, x, r, z, p, Ap, K.inv_diag,
-                             K.n_block, alpha, n, partial);
-          double rr, rz_new;
-          if (int e = read2(K, nb, rr, rz_new))
-            return e;
-          res            = std::sqrt(rr);
-          out.iterations = it;
-          if (converged(res, out.initial_residual, c))
-            {
-              out.final_residual = res;
-              out.converged      = 1;
-              return 0;
-            }
-          K.axpby(p, 1., z, rz_new / rz); // p = z + beta p
-          rz = rz_new;
-        }
-      out.final_residual = res;
-      out.converged      = 0;
-      return 0;
+          hipLaunchKernelGGL(dot1_dev_kernel, dim3(nb), dim3(KT), 0, st, p, Ap, n, partial, S);
+          hipLaunchKernelGGL(kr_final_kernel, dim3(1), dim3(KT), 0, st, partial, (int)nb, S, H, (int)ST_CG_ALPHA, it);
+          hipLaunchKernelGGL(cg_update_dev_kernel, dim3(nb), dim3(KT), 0, st, x, r, z, p, Ap, K.inv_diag, K.n_block, n,
+                             partial, S);
+          hipLaunchKernelGGL(kr_final_kernel, dim3(1), dim3(KT), 0, st, partial, (int)nb, S, H, (int)ST_CG_UPDATE, it);
+          return 0;
+        },
+        out);
     }
 
     int solve_bicgstab(Krylov &K, double *x, const double *b, const adaflo_solver_control &c,
@@ -407,63 +571,45 @@ namespace adaflo_hip
       K.axpby(r, -1., v, 1.);
       (void)hipMemcpyAsync(rbar, r, n * sizeof(double), hipMemcpyDeviceToDevice, K.ctx->stream);
       const double rr0 = K.dot(r, r);
-      double       res = std::sqrt(rr0);
+      const double res = std::sqrt(rr0);
       out.initial_residual = res;
+      out.final_residual   = res;
       out.iterations       = 0;
       out.converged        = 0;
       if (converged(res, res, c))
         {
-          out.final_residual = res;
-          out.converged      = 1;
+          out.converged = 1;
           return 0;
         }
-      double *partial = K.ctx->d_scratch + 8;
-      double  rho = 1., alpha = 1., omega = 1., rho_new = rr0; // rbar.r of the first step
-      for (int it = 1; it <= c.max_iterations; ++it)
-        {
-          if (rho_new == 0. || omega == 0.)
-            break; // breakdown (deal.II restarts; the callers fall back to GMRES)
-          const double beta = (rho_new / rho) * (alpha / omega);
-          hipLaunchKernelGGL(bicg_p_kernel, dim3(nb), dim3(KT), 0, K.ctx->stream, p, y, r, v, K.inv_diag, K.n_block, beta,
-                             omega, it == 1 ? 1 : 0, n);
-          rho = rho_new;
+      if (rr0 == 0.)
+        return 0;
+      double *S = krylov_scalars(K.ctx), *H = K.ctx->h_result_dev, *partial = K.ctx->d_scratch + 8;
+      if (!S)
+        return ADAFLO_ENOMEM;
+      hipStream_t st = K.ctx->stream;
+      // rho = rbar.r of the first step; beta is not used by the first p kernel
+      hipLaunchKernelGGL(kr_init_kernel, dim3(1), dim3(64), 0, st, S, H, rr0, std::fmax(c.abs_tol, c.rel_tol * res), res);
+      Pipeline pipe{K.ctx};
+      return pipe.run(
+        c.max_iterations,
+        [&](const int it) {
+          hipLaunchKernelGGL(bicg_p_dev_kernel, dim3(nb), dim3(KT), 0, st, p, y, r, v, K.inv_diag, K.n_block,
+                             it == 1 ? 1 : 0, n, S);
           if (int e = K.A(v, y))
             return e;
-          alpha = rho / K.dot(rbar, v);
-          hipLaunchKernelGGL(bicg_s_kernel, dim3(nb), dim3(KT), 0, K.ctx->stream, r, z, v, K.inv_diag, K.n_block, alpha, n,
-                             partial);
-          double ss, unused;
-          if (int e = read2(K, nb, ss, unused))
-            return e;
-          res            = std::sqrt(ss);
-          out.iterations = it;
-          if (converged(res, out.initial_residual, c))
-            {
-              K.axpby(x, alpha, y, 1.);
-              out.converged = 1;
-              break;
-            }
+          hipLaunchKernelGGL(dot1_dev_kernel, dim3(nb), dim3(KT), 0, st, rbar, v, n, partial, S);
+          hipLaunchKernelGGL(kr_final_kernel, dim3(1), dim3(KT), 0, st, partial, (int)nb, S, H, (int)ST_BICG_ALPHA, it);
+          hipLaunchKernelGGL(bicg_s_dev_kernel, dim3(nb), dim3(KT), 0, st, r, z, v, K.inv_diag, K.n_block, n, partial, S);
+          hipLaunchKernelGGL(kr_final_kernel, dim3(1), dim3(KT), 0, st, partial, (int)nb, S, H, (int)ST_BICG_S, it);
           if (int e = K.A(t, z))
             return e;
-          hipLaunchKernelGGL(dot2_kernel, dim3(nb), dim3(KT), 0, K.ctx->stream, t, r, t, t, n, partial);
-          double ts, tt;
-          if (int e = read2(K, nb, ts, tt))
-            return e;
-          omega = ts / tt;
-          hipLaunchKernelGGL(bicg_x_kernel, dim3(nb), dim3(KT), 0, K.ctx->stream, x, r, y, z, t, rbar, alpha, omega, n,
-                             partial);
-          double rr;
-          if (int e = read2(K, nb, rr, rho_new))
-            return e;
-          res = std::sqrt(rr);
-          if (converged(res, out.initial_residual, c))
-            {
-              out.converged = 1;
-              break;
-            }
-        }
-      out.final_residual = res;
-      return 0;
+          hipLaunchKernelGGL(dot_ts_dev_kernel, dim3(nb), dim3(KT), 0, st, t, r, n, partial, S);
+          hipLaunchKernelGGL(kr_final_kernel, dim3(1), dim3(KT), 0, st, partial, (int)nb, S, H, (int)ST_BICG_OMEGA, it);
+          hipLaunchKernelGGL(bicg_x_dev_kernel, dim3(nb), dim3(KT), 0, st, x, r, y, z, t, rbar, n, partial, S);
+          hipLaunchKernelGGL(kr_final_kernel, dim3(1), dim3(KT), 0, st, partial, (int)nb, S, H, (int)ST_BICG_X, it);
+          return 0;
+        },
+        out);
     }
 
     int kfail(adaflo_ctx *ctx, const int code, const std::string &msg)
