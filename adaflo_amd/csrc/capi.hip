@@ -1081,6 +1081,11 @@ int adaflo_ls_compute_normal_rhs(adaflo_ctx *ctx, double *dst, const double *lev
     return e;
   if (!dst || !level_set_solution)
     return fail(ctx, ADAFLO_EINVAL, "null vector");
+  if (ctx->variant >= 1)
+    {
+      TRY(ctx, launch_q1_stencil_rhs(ctx, 0, dst, level_set_solution), "level-set kernel launch failed");
+      return 0;
+    }
   TRY(ctx, launch_ls(ctx, 1, 1 /*RHS_NORMAL*/, 0, dst, level_set_solution, nullptr, nullptr, nullptr, nullptr, 1),
       "level-set kernel launch failed");
   return 0;
@@ -1168,6 +1173,11 @@ int adaflo_ls_compute_curvature_rhs(adaflo_ctx *ctx, double *dst, const double *
     return e;
   if (!dst || !normal_vector_field)
     return fail(ctx, ADAFLO_EINVAL, "null vector");
+  if (ctx->variant >= 1)
+    {
+      TRY(ctx, launch_q1_stencil_rhs(ctx, 1, dst, normal_vector_field), "level-set kernel launch failed");
+      return 0;
+    }
   TRY(ctx, launch_ls(ctx, 1, 2 /*RHS_CURVATURE*/, 0, dst, normal_vector_field, nullptr, nullptr, nullptr, nullptr, 1),
       "level-set kernel launch failed");
   return 0;

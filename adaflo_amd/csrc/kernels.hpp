@@ -97,6 +97,7 @@ namespace adaflo_hip
     Q1_LAPLACE_Q3   = 3  // (grad w, c(x_q) grad v) with the 3x3x3 Gauss rule, c per point (pressure Poisson)
   };
   int q1_convert_state(adaflo_ctx *ctx, DeviceBuffer &out, const double *generic_dev);
+  int launch_q1_stencil_rhs(adaflo_ctx *ctx, int mode, double *dst, const double *src);
   int launch_q1_sweep(adaflo_ctx *ctx, int sub, int mode, double c_mass, double c_lap, double weight,
                       uint32_t con, double con_sign, const double *diag, double *dst, const double *src,
                       const double *state, int n_blocks = 1, const double *coef_cell = nullptr, int coef_stride = 0,

@@ -675,6 +675,131 @@ namespace adaflo_hip
           Am = A0, Bm = B0, A0 = Ap, B0 = Bp, c0 = cp;
         }
     }
+
+    // -------------------------------------------------------------------------------------------
+    // Right-hand sides of the normal and curvature projections as tensor-product stencils (same
+    // marching scheme as q1_stencil_kernel), with C = int N_i N_j' = 1/2 [-1 0 1] (half rows at the
+    // boundary):
+    //   MODE 0  LevelSetOKZSolverComputeNormal::local_compute_normal_rhs (compute_normal.cc:141-153)
+    //           dst_d += (w, d_d phi):       dst_0 = Cx My Mz phi, dst_1 = Mx Cy Mz phi, dst_2 = Mx My Cz phi
+    //   MODE 1  LevelSetOKZSolverComputeCurvature::local_compute_curvature_rhs (:229-259)
+    //           dst  += -(w, div n~),  n~ = n / |n| at the nodes (0 where |n| <= 1e-2)
+    // Like the cell loops they replace, the kernels ADD into dst and skip constrained rows.
+    struct StencilRhsArgs
+    {
+      int           nnx, nny, nnz, LZ, n_chunks, blocks_per_plane;
+      long          plane, comp_stride;
+      double        m_off[3], m_ctr[3];
+      uint32_t      con;
+      const double *src;
+      double       *dst;
+    };
+
+    template <int MODE>
+    __global__ __launch_bounds__(256) void q1_stencil_rhs_kernel(const StencilRhsArgs A)
+    {
+      const long nwg   = (long)A.blocks_per_plane * A.n_chunks;
+      const long wg    = xcd_remap(blockIdx.x, nwg);
+      const int  chunk = (int)(wg / A.blocks_per_plane);
+      const long p_raw = (wg % A.blocks_per_plane) * 256 + threadIdx.x;
+      const bool active = p_raw < A.plane;
+      const long p      = active ? p_raw : A.plane - 1;
+      const int  i = (int)(p % A.nnx), j = (int)(p / A.nnx);
+
+      auto rows = [&](const int d, const int idx, const int n, double *m, double *c, long *off, const long stride) {
+        const bool lo = idx > 0, hi = idx < n - 1;
+        m[0] = lo ? A.m_off[d] : 0.;
+        m[2] = hi ? A.m_off[d] : 0.;
+        m[1] = ((lo ? 1. : 0.) + (hi ? 1. : 0.)) * A.m_ctr[d];
+        c[0] = lo ? -0.5 : 0.;
+        c[2] = hi ? 0.5 : 0.;
+        c[1] = (lo ? 0.5 : 0.) + (hi ? -0.5 : 0.);
+        off[0] = lo ? -stride : 0;
+        off[1] = 0;
+        off[2] = hi ? stride : 0;
+      };
+      double mx[3], cx[3], my[3], cy[3];
+      long   ox[3], oy[3];
+      rows(0, i, A.nnx, mx, cx, ox, 1);
+      rows(1, j, A.nny, my, cy, oy, A.nnx);
+      const bool con_xy = (i == 0 && (A.con >> 0 & 1)) || (i == A.nnx - 1 && (A.con >> 1 & 1)) ||
+                          (j == 0 && (A.con >> 2 & 1)) || (j == A.nny - 1 && (A.con >> 3 & 1));
+
+      // in-plane sums of plane k:  P = Mx My f,  Qx = Cx My f,  Qy = Mx Cy f
+      //   MODE 0: f = phi for all three;  MODE 1: P of n~_2, Qx of n~_0, Qy of n~_1
+      auto plane_sums = [&](const int k, double &P, double &Qx, double &Qy) {
+        const double *s = A.src + (long)k * A.plane + p;
+        double        a[3], bx[3], ay[3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+          {
+            const double *r = s + oy[dy];
+            if (MODE == 0)
+              {
+                const double v0 = r[ox[0]], v1 = r[0], v2 = r[ox[2]];
+                a[dy]  = mx[0] * v0 + mx[1] * v1 + mx[2] * v2;
+                bx[dy] = cx[0] * v0 + cx[1] * v1 + cx[2] * v2;
+                ay[dy] = a[dy];
+              }
+            else
+              {
+                double f0[3], f1[3], f2[3];
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+                  {
+                    const long   o  = dx == 1 ? 0 : ox[dx];
+                    const double n0 = r[o], n1 = r[o + A.comp_stride], n2 = r[o + 2 * A.comp_stride];
+                    const double nr = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+                    const double sc = nr > 1e-2 ? 1. / nr : 0.;
+                    f0[dx] = n0 * sc;
+                    f1[dx] = n1 * sc;
+                    f2[dx] = n2 * sc;
+                  }
+                a[dy]  = mx[0] * f2[0] + mx[1] * f2[1] + mx[2] * f2[2];
+                bx[dy] = cx[0] * f0[0] + cx[1] * f0[1] + cx[2] * f0[2];
+                ay[dy] = mx[0] * f1[0] + mx[1] * f1[1] + mx[2] * f1[2];
+              }
+          }
+        P  = my[0] * a[0] + my[1] * a[1] + my[2] * a[2];
+        Qx = my[0] * bx[0] + my[1] * bx[1] + my[2] * bx[2];
+        Qy = cy[0] * ay[0] + cy[1] * ay[1] + cy[2] * ay[2];
+      };
+
+      const int  k0 = chunk * A.LZ, k1 = min(k0 + A.LZ, A.nnz);
+      const bool conz_lo = A.con >> 4 & 1, conz_hi = A.con >> 5 & 1;
+      double     Pm = 0., Qxm = 0., Qym = 0., P0, Qx0, Qy0, Pp = 0., Qxp = 0., Qyp = 0.;
+      if (k0 > 0)
+        plane_sums(k0 - 1, Pm, Qxm, Qym);
+      plane_sums(k0, P0, Qx0, Qy0);
+      for (int k = k0; k < k1; ++k)
+        {
+          const bool hi = k < A.nnz - 1, lo = k > 0;
+          if (hi)
+            plane_sums(k + 1, Pp, Qxp, Qyp);
+          else
+            Pp = Qxp = Qyp = 0.;
+          const double nz  = (lo ? 1. : 0.) + (hi ? 1. : 0.);
+          const double mzl = lo ? A.m_off[2] : 0., mzc = nz * A.m_ctr[2], mzh = hi ? A.m_off[2] : 0.;
+          const double czl = lo ? -0.5 : 0., czc = (lo ? 0.5 : 0.) + (hi ? -0.5 : 0.), czh = hi ? 0.5 : 0.;
+          const double rx = mzl * Qxm + mzc * Qx0 + mzh * Qxp;
+          const double ry = mzl * Qym + mzc * Qy0 + mzh * Qyp;
+          const double rz = czl * Pm + czc * P0 + czh * Pp;
+          const bool   conz = (k == 0 && conz_lo) || (k == A.nnz - 1 && conz_hi);
+          if (active && !(con_xy || conz))
+            {
+              const long idx = (long)k * A.plane + p;
+              if (MODE == 0)
+                {
+                  A.dst[idx] += rx;
+                  A.dst[idx + A.comp_stride] += ry;
+                  A.dst[idx + 2 * A.comp_stride] += rz;
+                }
+              else
+                A.dst[idx] -= rx + ry + rz;
+            }
+          Pm = P0, Qxm = Qx0, Qym = Qy0, P0 = Pp, Qx0 = Qxp, Qy0 = Qyp;
+        }
+    }
   } // namespace
 
   // ---------------------------------------------------------------------------------------------
@@ -865,6 +990,39 @@ namespace adaflo_hip
     if (nb > 256 * 512)
       nb = 256 * 512;
     hipLaunchKernelGGL(q1_fixup_kernel, dim3((unsigned)nb, (unsigned)n_blocks), dim3(64), 0, ctx->stream, A, n1, n2);
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+
+  // mode 0: normal rhs (src = level set, dst = 3 blocks), 1: curvature rhs (src = normal, 3 blocks)
+  int launch_q1_stencil_rhs(adaflo_ctx *ctx, const int mode, double *dst, const double *src)
+  {
+    StencilRhsArgs S{};
+    const int sub = ctx->s;
+    S.nnx = sub * ctx->desc.ncell[0] + 1;
+    S.nny = sub * ctx->desc.ncell[1] + 1;
+    S.nnz = sub * ctx->desc.ncell[2] + 1;
+    S.plane            = (long)S.nnx * S.nny;
+    S.comp_stride      = S.plane * S.nnz;
+    S.blocks_per_plane = (int)((S.plane + 255) / 256);
+    int lz = 32;
+    while (lz > 4 && (long)S.blocks_per_plane * ((S.nnz + lz - 1) / lz) < 2048)
+      lz /= 2;
+    S.LZ       = lz;
+    S.n_chunks = (S.nnz + lz - 1) / lz;
+    for (int d = 0; d < 3; ++d)
+      {
+        const double hs = ctx->desc.h[d] / sub;
+        S.m_off[d] = hs / 6.;
+        S.m_ctr[d] = hs / 3.;
+      }
+    S.con = ctx->brick.con_ls;
+    S.src = src;
+    S.dst = dst;
+    const dim3 grid((unsigned)(S.blocks_per_plane * S.n_chunks));
+    if (mode == 0)
+      hipLaunchKernelGGL(q1_stencil_rhs_kernel<0>, grid, dim3(256), 0, ctx->stream, S);
+    else
+      hipLaunchKernelGGL(q1_stencil_rhs_kernel<1>, grid, dim3(256), 0, ctx->stream, S);
     return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
   }
 } // namespace adaflo_hip

@@ -76,47 +76,52 @@ def test_ls_operator_applications(s, ncell, faces, variant):
         assert rel_l2(d.numpy(), ref) < TOL
 
 
-@pytest.mark.parametrize("s,ncell", [(4, (2, 2, 3)), (2, (3, 4, 3))])
-def test_ls_right_hand_sides(s, ncell):
-    c = LSCase(ncell, s)
+@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("s,ncell,faces", [(4, (2, 2, 3), ()), (2, (3, 4, 3), ()), (2, (9, 5, 20), (0, 3, 4, 5)),
+                                           (1, (20, 17, 35), (1,))])
+def test_ls_right_hand_sides(s, ncell, faces, variant):
+    """variant 1: normal / curvature right-hand sides as tensor-product stencils (multi-block planes,
+    several z-chunks in the larger cases); variant 0: generic per-cell kernels"""
+    c = LSCase(ncell, s, faces=faces)
+    c.ops.set_kernel_variant(variant)
     phi = c.rand()
     normal = c.rand(3)
     normal[::7] *= 1e-3   # some nearly vanishing normals (thresholds 1e-4 / 1e-2)
     rei = lso.LevelSetOKZSolverReinitialization(c.ops)
     # reinit rhs, first step (writes evaluated_normal), then later step (reads it)
     nq_ref = np.zeros(c.mesh.n_cells * c.nq * 3)
-    ref = orc.ls_reinit_rhs(c.mesh, c.prm, phi, normal, nq_ref, diffuse_only=False, first_step=True)
+    ref = orc.ls_reinit_rhs(c.mesh, c.prm, phi, normal, nq_ref, diffuse_only=False, first_step=True, con=c.con)
     d = c.ops.vector()
     rei.local_reinitialize_rhs(d, c.ops.vector(phi), c.ops.vector(normal, blocks=3), False, True)
     assert rel_l2(d.numpy(), ref) < TOL
     assert rel_l2(rei.evaluated_normal, nq_ref) < TOL
     phi2 = c.rand()
-    ref = orc.ls_reinit_rhs(c.mesh, c.prm, phi2, normal, nq_ref, diffuse_only=False, first_step=False)
+    ref = orc.ls_reinit_rhs(c.mesh, c.prm, phi2, normal, nq_ref, diffuse_only=False, first_step=False, con=c.con)
     d = c.ops.vector()
     rei.local_reinitialize_rhs(d, c.ops.vector(phi2), None, False, False)
     assert rel_l2(d.numpy(), ref) < TOL
-    ref = orc.ls_reinit_rhs(c.mesh, c.prm, phi2, normal, nq_ref, diffuse_only=True, first_step=False)
+    ref = orc.ls_reinit_rhs(c.mesh, c.prm, phi2, normal, nq_ref, diffuse_only=True, first_step=False, con=c.con)
     d = c.ops.vector()
     rei.local_reinitialize_rhs(d, c.ops.vector(phi2), None, True, False)
     assert rel_l2(d.numpy(), ref) < TOL
     # normal rhs
     d3 = c.ops.vector(blocks=3)
     lso.LevelSetOKZSolverComputeNormal(c.ops).local_compute_normal_rhs(d3, c.ops.vector(phi))
-    assert rel_l2(d3.numpy(), orc.ls_normal_rhs(c.mesh, c.prm, phi)) < TOL
+    assert rel_l2(d3.numpy(), orc.ls_normal_rhs(c.mesh, c.prm, phi, con=c.con)) < TOL
     # curvature rhs (with a region of zero normal: early-out cells)
     normal_z = normal.reshape(3, -1).copy()
     normal_z[:, : c.nn // 3] = 0.0
     normal_z = normal_z.reshape(-1)
     d = c.ops.vector()
     lso.LevelSetOKZSolverComputeCurvature(c.ops).local_compute_curvature_rhs(d, c.ops.vector(normal_z, blocks=3))
-    assert rel_l2(d.numpy(), orc.ls_curvature_rhs(c.mesh, c.prm, normal_z)) < TOL
+    assert rel_l2(d.numpy(), orc.ls_curvature_rhs(c.mesh, c.prm, normal_z, con=c.con)) < TOL
     # advection rhs
     adv = lso.LevelSetOKZSolverAdvanceConcentration(c.ops)
     vel = c.rng.uniform(-1, 1, c.mesh.n_nodes(c.k) * 3)
     old, oldold = c.rand(), c.rand()
     for use_oo in (True, False):
         uq_ref = np.zeros(c.mesh.n_cells * c.nq * 3)
-        ref = orc.ls_advect_rhs(c.mesh, c.prm, c.k, phi, old, oldold, vel, uq_ref, c.w_old, c.w_oo, use_oo)
+        ref = orc.ls_advect_rhs(c.mesh, c.prm, c.k, phi, old, oldold, vel, uq_ref, c.w_old, c.w_oo, use_oo, con=c.con)
         d = c.ops.vector()
         adv.local_advance_concentration_rhs(d, c.ops.vector(phi), c.ops.vector(old), c.ops.vector(oldold),
                                             c.ops.velocity_vector(vel), use_oo)
