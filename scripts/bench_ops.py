@@ -52,6 +52,39 @@ def ns_case(k, n, variant, two_phase=False):
                       "frac_of_8TB/s": round(b_alg / t / 8e12, 4)}), flush=True)
 
 
+def ns_host_vector_case(n):
+    """adapter case of SURVEY 8d: src / dst live in (pinned) host memory, so every vmult pays
+    H2D of src and D2H of dst over PCIe -- reported beside, never instead of, the resident rate"""
+    import torch
+    fp = adaflo_amd.FlowParameters(velocity_degree=2)
+    ts = adaflo_amd.TimeStepping(fp)
+    for _ in range(3):
+        ts.next()
+    stream = torch.cuda.current_stream().cuda_stream
+    op = adaflo_amd.NavierStokesMatrix(fp, adaflo_amd.BrickMesh([n] * 3, [-1] * 3, [1] * 3), stream=stream)
+    op.initialize(ts, True)
+    rng = np.random.default_rng(1)
+    op.set_linearization(rng.uniform(-1, 1, op.n_cells() * 27 * 12))
+    nu, npp = op.n_dofs_u(), op.n_dofs_p()
+    h_src = [torch.from_numpy(rng.uniform(-1, 1, m)).pin_memory() for m in (nu, npp)]
+    h_dst = [torch.empty(m, dtype=torch.float64).pin_memory() for m in (nu, npp)]
+    d_src = [torch.empty(m, dtype=torch.float64, device="cuda") for m in (nu, npp)]
+    d_dst = [torch.empty(m, dtype=torch.float64, device="cuda") for m in (nu, npp)]
+    src = adaflo_amd.BlockVector([op.wrap(t) for t in d_src])
+    dst = adaflo_amd.BlockVector([op.wrap(t) for t in d_dst])
+
+    def step():
+        for d, h in zip(d_src, h_src):
+            d.copy_(h, non_blocking=True)
+        op.vmult(dst, src)
+        for d, h in zip(d_dst, h_dst):
+            h.copy_(d, non_blocking=True)
+    t = timeit(step, torch.cuda.synchronize, reps=10)
+    print(json.dumps({"op": "ns_vmult_host_vectors (pinned, PCIe-inclusive)", "k": 2, "cells": n,
+                      "ms": round(t * 1e3, 3), "MDoF/s": round((nu + npp) / t / 1e6, 1),
+                      "pcie_GB/s": round(16 * (nu + npp) / t / 1e9, 1)}), flush=True)
+
+
 def ls_case(s, ncell):
     mesh = adaflo_amd.BrickMesh(list(ncell), [0, 0, 0], [1, 1, 2])
     ops = lso.LevelSetOperators(mesh, s)
@@ -113,6 +146,7 @@ def krylov_case(s, ncell):
 if __name__ == "__main__":
     ns_case(2, 128, 1)
     ns_case(2, 128, 0)
+    ns_host_vector_case(128)
     ns_case(2, 128, 1, two_phase=True)
     ns_case(2, 128, 0, two_phase=True)
     ns_case(3, 64, 2)
