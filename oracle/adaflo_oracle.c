@@ -18,8 +18,10 @@
  *
  * Parity pins (the reference's own golden outputs, reproduced through this file):
  *   tests/beltrami_3d.output:13   first nonlinear residual of time step #1, 2.590e+00 / 6.423e-02
+ *   tests/beltrami_3d.output:5-6  L2 errors of the initial interpolant, 0.02383 / 0.0001993 (shape functions)
  *   tests/beltrami_3d.output:31   first residual of time step #2 after a converged Newton
  *                                 iteration, 2.348e+00 / 5.678e-02   (tests/test_oracle_golden.py)
+ *   tests/beltrami_3d.output:49   first residual of time step #3, 2.793e-01 / 6.590e-03
  *   tests/rising_bubble_ls.output:5-29   initial state and time steps #1-#3 of the 2D rising bubble:
  *                                 advection residual / iterations, reinitialisation iterations,
  *                                 first two-phase residual of every step

@@ -9,6 +9,8 @@ source/navier_stokes.cc).  Pinned numbers from tests/beltrami_3d.output:
   line 31: first residual of time step #2   2.348e+00   5.678e-02   (after step #1 CONVERGED:
            independent of the linear solver, unlike the intermediate Newton residuals, which the
            reference reaches with 30 ILU-preconditioned iterations and an unconverged linear solve)
+  line 49: first residual of time step #3   2.793e-01   6.590e-03   (full BDF-2 weights, extrapolated
+           start value)
 """
 import json
 import os
@@ -18,13 +20,13 @@ import pytest
 
 import adaflo_amd
 from adaflo_amd.navier_stokes import NavierStokes, node_coordinates
-from oracle import oracle as orc     # only the closed-form Beltrami field (test input)
+from adaflo_amd import beltrami
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_outputs.json")
 
 
-def test_beltrami_two_time_steps_reproduce_the_reference_output():
+def test_beltrami_three_time_steps_reproduce_the_reference_output():
     with open(GOLDEN) as f:
         ref = json.load(f)["beltrami_3d"]
     fp = adaflo_amd.FlowParameters(velocity_degree=2, viscosity=ref["viscosity"], time_step_size_start=ref["dt"],
@@ -32,10 +34,10 @@ def test_beltrami_two_time_steps_reproduce_the_reference_output():
                                    max_lin_iteration=100, tol_lin_iteration=1e-5)
     mesh = adaflo_amd.BrickMesh([16] * 3, [-1.0] * 3, [1.0] * 3)
     ns = NavierStokes(fp, mesh, adaflo_amd.TimeStepping(fp),
-                      dirichlet_function=lambda x, t: orc.beltrami_u(x, t, ref["viscosity"]).reshape(-1, 3))
+                      dirichlet_function=lambda x, t: beltrami.velocity(x, t, ref["viscosity"]))
     assert ns.navier_stokes_matrix.n_dofs_u() == ref["dofs_u"] and ns.navier_stokes_matrix.n_dofs_p() == ref["dofs_p"]
     xu, xp = node_coordinates(mesh, 2), node_coordinates(mesh, 1)
-    ns.set_initial_condition(orc.beltrami_u(xu, 0.0, ref["viscosity"]), orc.beltrami_p(xp, 0.0, ref["viscosity"]))
+    ns.set_initial_condition(beltrami.velocity(xu, 0.0, ref["viscosity"]).reshape(-1), beltrami.pressure(xp, 0.0, ref["viscosity"]))
     # ---- time step #1
     n_newton, n_linear = ns.advance_time_step()
     h = ns.history
@@ -44,9 +46,15 @@ def test_beltrami_two_time_steps_reproduce_the_reference_output():
     # Newton with J = vmult on the stored state: super-linear decrease of the residual
     assert h[1][0] < 2e-2 and h[2][0] < 1e-4 * h[1][0] * 10
     assert all(its <= 100 for its, _ in ns.linear_iterations)
-    # ---- time step #2: first residual
+    # ---- time step #2: first residual, then solve
+    ns.history.clear()
+    ns.advance_time_step()
+    assert "%.3e" % ns.history[0][0] == ref["second_step_residuals_u"][0]
+    assert "%.3e" % ns.history[0][1] == ref["second_step_residuals_p"][0]
+    assert np.hypot(*ns.history[-1]) < 1e-9
+    # ---- time step #3: first residual
     ns.history.clear()
     ns.init_time_advance()
     ns.compute_residual()
-    assert "%.3e" % ns.history[0][0] == ref["second_step_residuals_u"][0]
-    assert "%.3e" % ns.history[0][1] == ref["second_step_residuals_p"][0]
+    assert "%.3e" % ns.history[0][0] == ref["third_step_residuals_u"][0]
+    assert "%.3e" % ns.history[0][1] == ref["third_step_residuals_p"][0]

@@ -42,7 +42,7 @@ def test_residual_distinguishes_the_convective_formulations():
         assert "%.3e" % np.linalg.norm(ru) != "2.590e+00"
 
 
-def test_second_time_step_first_residual_matches_reference_output():
+def test_second_and_third_time_step_first_residuals_match_reference_output():
     """tests/beltrami_3d.output:31 -- time step #2 starts from the CONVERGED solution of step #1
     (NL tolerance 1e-9 in the reference), which no longer depends on the reference's ILU-preconditioned
     linear solver: the oracle's residual, its Jacobian (vmult with the state the residual stored),
@@ -57,10 +57,50 @@ def test_second_time_step_first_residual_matches_reference_output():
     stepper = no.BeltramiStepper(16, adaflo_amd.TimeStepping(fp))
     with threadpool_limits(limits=1, user_api="blas"):     # the oracle's OpenMP threads own the cores
         history = stepper.advance_time_step(tol_nl=1e-6)
+        history2 = stepper.advance_time_step(tol_nl=1e-6)
         stepper.init_time_advance()
         ru, rp = stepper.residual()
     assert "%.3e" % history[0][0] == "2.590e+00" and "%.3e" % history[0][1] == "6.423e-02"
     # quadratic convergence of the exact Newton method: 2.6 -> 9e-3 -> 2e-8
     assert len(history) == 3 and history[1][0] < 1e-2 and history[2][0] < 1e-7
-    assert "%.3e" % np.linalg.norm(ru) == "2.348e+00"
-    assert "%.3e" % np.linalg.norm(rp) == "5.678e-02"
+    assert "%.3e" % history2[0][0] == "2.348e+00" and "%.3e" % history2[0][1] == "5.678e-02"
+    # tests/beltrami_3d.output:49 -- time step #3 (full BDF-2 weights and extrapolated start value:
+    # TimeStepping with step_no > 1) from the converged step #2
+    assert "%.3e" % np.linalg.norm(ru) == "2.793e-01"
+    assert "%.3e" % np.linalg.norm(rp) == "6.590e-03"
+
+
+def _l2_norm_of_difference(mesh, k, dofs, ncomp, exact, n_gauss):
+    """VectorTools::integrate_difference(..., QGauss(n_gauss), L2_norm) for a nodal FE_Q(k) field on the
+    brick: sqrt(sum_cells sum_q |u_h(x_q) - exact(x_q)|^2 JxW)"""
+    xg, wg = orc.gauss_legendre(n_gauss)
+    S, _ = orc.shape_1d(0, k, xg)                      # [q][i]
+    nn = mesh.nodes_per_dim(k)
+    u = dofs.reshape(nn[2], nn[1], nn[0], ncomp)
+    n = [mesh.ncell[d] for d in range(3)]
+    h = [mesh.h[d] for d in range(3)]
+    # values at all Gauss points, cell by cell along each axis: [cz][qz][cy][qy][cx][qx][c]
+    idx = [np.arange(n[d])[:, None] * k + np.arange(k + 1)[None, :] for d in range(3)]
+    loc = u[idx[2][:, :, None, None, None, None], idx[1][None, None, :, :, None, None], idx[0][None, None, None, None, :, :]]
+    val = np.einsum("azbycxm,qz,ry,sx->aqbrcsm", loc, S, S, S)
+    axes = [mesh.origin[d] + h[d] * (np.arange(n[d])[:, None] + xg[None, :]) for d in range(3)]   # [cell][q]
+    Z, Y, X = np.meshgrid(axes[2].reshape(-1), axes[1].reshape(-1), axes[0].reshape(-1), indexing="ij")
+    ex = exact(np.stack([X.reshape(-1), Y.reshape(-1), Z.reshape(-1)], axis=1)).reshape(val.shape)
+    w = np.einsum("q,r,s->qrs", wg, wg, wg) * h[0] * h[1] * h[2]
+    return np.sqrt(np.einsum("aqbrcsm,qrs->", (val - ex) ** 2, w))
+
+
+def test_initial_interpolation_errors_match_reference_output():
+    """tests/beltrami_3d.output:5-6 -- L2 errors of the nodal interpolant of the exact solution at t = 0
+    (tests/beltrami.cc:255-296: error with QGauss(k+2), norm of the discrete solution with QGauss(k)):
+    pins the node placement, the FE_Q shape functions and the analytic fields of the oracle."""
+    mesh = orc.Mesh.make([16] * 3, [-1.0] * 3, [1.0] * 3)
+    k = 2
+    u0 = orc.beltrami_u(orc.node_coordinates(mesh, k), 0.0)
+    p0 = orc.beltrami_p(orc.node_coordinates(mesh, k - 1), 0.0)
+    eu = _l2_norm_of_difference(mesh, k, u0, 3, lambda x: orc.beltrami_u(x, 0.0), k + 2)
+    ep = _l2_norm_of_difference(mesh, k - 1, p0, 1, lambda x: orc.beltrami_p(x, 0.0), k + 2)
+    nu_ = _l2_norm_of_difference(mesh, k, u0, 3, lambda x: np.zeros(3 * len(x)), k)
+    np_ = _l2_norm_of_difference(mesh, k - 1, p0, 1, lambda x: np.zeros(len(x)), k)
+    assert "%.4g" % ep == "0.02383" and "%.4g" % eu == "0.0001993"          # :5 absolute
+    assert "%.3g" % (ep / np_) == "0.00394" and "%.3g" % (eu / nu_) == "3.88e-05"   # :6 relative
