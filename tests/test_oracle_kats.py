@@ -107,3 +107,39 @@ def test_beltrami_residual_converges_with_mesh_refinement():
         # dual norm proxy: residual functional scaled by the lumped mass (h^3)
         errs.append(np.linalg.norm(ru) / (2.0 / n) ** 1.5)
     assert errs[1] < errs[0] / 3.0
+
+
+def test_config1_2d_beltrami_64x64_vmult_is_the_jacobian_of_the_residual():
+    """BASELINE configs[0]: 2D Q2/Q1 on a uniform 64 x 64 mesh (CPU plumbing case, SURVEY 8 table: 4 096 cells,
+    33 282 + 4 225 DoF).  The Newton vmult on the state stored by the residual is the derivative of the
+    residual: (r(u - eps d) - r(u + eps d)) / (2 eps) = J d to O(eps^2) (the residual returns -F)."""
+    mesh = orc.Mesh.make([64, 64], [-1.0, -1.0], [1.0, 1.0])
+    k, dt = 2, 0.01
+    assert mesh.n_cells == 4096 and 2 * mesh.n_nodes(k) == 33282 and mesh.n_nodes(k - 1) == 4225
+    xu, xp = orc.node_coordinates(mesh, k), orc.node_coordinates(mesh, k - 1)
+    u, p = orc.beltrami_u(xu, 0.0), orc.beltrami_p(xp, 0.0)
+    u_old = orc.beltrami_u(xu, -dt)
+    con_u = orc.boundary_mask(mesh, k, 2)
+    prm = orc.NSParams.make(beta=0.5, weight=1.5 / dt, weight_old=-2.0 / dt, weight_old_old=0.5 / dt)
+    nlin = mesh.n_cells * (k + 1) ** 2 * orc.n_lin(2)
+    lin = np.zeros(nlin)
+    orc.ns_residual(mesh, k, prm, u, p, u_old, u_old, con_u=con_u, lin=lin)
+    rng = np.random.default_rng(7)
+    du, dp = rng.uniform(-1, 1, u.size), rng.uniform(-1, 1, p.size)
+    du[con_u == 1] = 0.0
+    ju, jp = orc.ns_vmult(mesh, k, prm, du, dp, con_u, None, lin=lin)
+    eps = 1e-5
+    scratch = np.zeros(nlin)
+    rpu, rpp = orc.ns_residual(mesh, k, prm, u + eps * du, p + eps * dp, u_old, u_old, con_u=con_u, lin=scratch)
+    rmu, rmp = orc.ns_residual(mesh, k, prm, u - eps * du, p - eps * dp, u_old, u_old, con_u=con_u, lin=scratch)
+    fd_u, fd_p = (rmu - rpu) / (2 * eps), (rmp - rpp) / (2 * eps)
+    free = con_u == 0
+    assert np.linalg.norm(fd_u[free] - ju[free]) < 1e-7 * np.linalg.norm(ju[free])
+    assert np.linalg.norm(fd_p - jp) < 1e-7 * np.linalg.norm(jp)
+    # linearity of the operator at this size
+    a, b = 0.7, -1.3
+    du2, dp2 = rng.uniform(-1, 1, u.size), rng.uniform(-1, 1, p.size)
+    ju2, jp2 = orc.ns_vmult(mesh, k, prm, du2, dp2, con_u, None, lin=lin)
+    ju3, jp3 = orc.ns_vmult(mesh, k, prm, a * du + b * du2, a * dp + b * dp2, con_u, None, lin=lin)
+    assert np.linalg.norm(ju3 - (a * ju + b * ju2)) < 1e-12 * np.linalg.norm(ju3)
+    assert np.linalg.norm(jp3 - (a * jp + b * jp2)) < 1e-12 * np.linalg.norm(jp3)
