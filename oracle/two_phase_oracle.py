@@ -24,9 +24,13 @@ from . import oracle as orc
 
 
 class RisingBubble:
-    def __init__(self, time_stepping_factory, ncell=(40, 80), s=4, k=2, eps_rel=1.5, dt=0.02, no_slip_everywhere=False):
+    def __init__(self, time_stepping_factory, ncell=(40, 80), s=4, k=2, eps_rel=1.5, dt=0.02, no_slip_everywhere=False,
+                 linearization=0, max_nl=10):
         """dim = len(ncell); the domain is [0,1]^(dim-1) x [0,2] with gravity along the last axis"""
         self.s, self.k, self.eps_rel, self.dt = s, k, eps_rel, dt
+        # linearization: 0 Newton, 1 Picard, 2 semi-implicit, 3 explicit convection (NSParams); max_nl = "NL max
+        # iterations" (1 for the linear schemes of rising_bubble_ls_imex.prm / _expl.prm)
+        self.linearization, self.max_nl = linearization, max_nl
         self.ncell = list(ncell)
         dim = self.dim = len(ncell)
         self.mesh = orc.Mesh.make(self.ncell, (0.,) * dim, (1.,) * (dim - 1) + (2.,))
@@ -188,16 +192,17 @@ class RisingBubble:
         # compute_force, Navier-Stokes
         self.prm = self._ls_prm(ts)
         force, rho, mu = self.compute_force()
-        nsp = orc.NSParams.make(beta=0.5, density=1.0, viscosity=0.01, density_diff=-0.9, weight=ts.weight(),
+        nsp = orc.NSParams.make(linearization=self.linearization, beta=0.5, density=1.0, viscosity=0.01,
+                                density_diff=-0.9, weight=ts.weight(),
                                 weight_old=ts.weight_old(), weight_old_old=ts.weight_old_old(), tau1=ts.tau1(),
                                 extrap_old=ts.factor_extrapol_old, extrap_old_old=ts.factor_extrapol_old_old)
         lin, damp, history = np.zeros(mesh.n_cells * (k + 1) ** self.dim * orc.n_lin(self.dim)), np.zeros_like(rho), []
-        for _ in range(10):
+        for it in range(self.max_nl + 1):
             ru, rp = orc.ns_residual(mesh, k, nsp, self.u, self.p, self.u_old, self.u_oo, con_u=self.con_u, lin=lin,
                                      rho=rho, mu=mu, damp=damp, user_u=force)
             rp = rp - rp.mean()          # mean-value projection of the pressure rows (uniform mesh: weights ~ 1 inside)
             history.append(float(np.hypot(np.linalg.norm(ru), np.linalg.norm(rp))))
-            if history[-1] < tol_nl:
+            if history[-1] < tol_nl or it == self.max_nl:
                 break
             if self.dim == 3:      # OpenMP sum-factorised restatement (checked against the naive one)
                 vm = lambda a, b: tuple(v.copy() for v in orc.fast_ns_vmult(mesh, k, nsp, a, b, self.con_u, None, lin=lin,
