@@ -101,6 +101,7 @@ SIGNATURES = {
     "adaflo_set_kernel_variant": (C.c_int, [_CTX, C.c_int]),
     "adaflo_ls_compute_heaviside": (C.c_int, [_CTX, _D, _D, C.c_double]),
     "adaflo_ls_curvature_correction": (C.c_int, [_CTX, _D, _D]),
+    "adaflo_ls_projection_vmult": (C.c_int, [_CTX, _D, _D]),
     "adaflo_ls_compute_force": (C.c_int, [_CTX, _D, _D, _D, C.POINTER(ForceParams)]),
     "adaflo_vector_fill": (C.c_int, [_CTX, _D, C.c_double, C.c_int64]),
     "adaflo_vector_sadd": (C.c_int, [_CTX, _D, C.c_double, C.c_double, _D, C.c_int64]),

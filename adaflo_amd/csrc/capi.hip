@@ -1074,6 +1074,12 @@ int adaflo_ls_compute_normal_vmult(adaflo_ctx *ctx, double *dst, const double *s
   return ls_vmult(ctx, dst, src, 3 /*LS_NORMAL*/, 1, nullptr, 3);
 }
 
+int adaflo_ls_projection_vmult(adaflo_ctx *ctx, double *dst, const double *src)
+{
+  CHECK_CTX(ctx);
+  return ls_vmult(ctx, dst, src, 3 /*LS_NORMAL*/, 1, nullptr, 1); // one scalar block of the normal operator
+}
+
 int adaflo_ls_compute_normal_rhs(adaflo_ctx *ctx, double *dst, const double *level_set_solution)
 {
   CHECK_CTX(ctx);

@@ -713,6 +713,10 @@ int adaflo_solve(adaflo_ctx *ctx, int op, int method, double *x, const double *b
         K.n_block = ctx->n_nodes_ls;
         K.A       = [ctx](double *d, const double *s) { return adaflo_ls_compute_curvature_vmult(ctx, d, s, 1); };
         break;
+      case ADAFLO_OP_LS_PROJECTION:
+        K.n_block = ctx->n_nodes_ls;
+        K.A       = [ctx](double *d, const double *s) { return adaflo_ls_projection_vmult(ctx, d, s); };
+        break;
       case ADAFLO_OP_NS_PRESSURE_MASS:
         K.n_block = ctx->n_nodes_p;
         K.A       = [ctx](double *d, const double *s) { return adaflo_ns_pressure_mass_vmult(ctx, d, s); };

@@ -248,16 +248,21 @@ class LevelSetOKZSolverComputeCurvature:
     def local_compute_curvature_rhs(self, dst, normal_vector_field):
         _lib.check(self._ctx, self._lib.adaflo_ls_compute_curvature_rhs(self._ctx, dst.ptr, normal_vector_field.ptr))
 
-    def compute_curvature(self, solution_curvature, rhs, normal_vector_field, preconditioner, solution_ls=None):
+    def compute_curvature(self, solution_curvature, rhs, normal_vector_field, preconditioner, solution_ls=None,
+                          use_projection_matrix=True):
         """LevelSetOKZSolverComputeCurvature::compute_curvature (level_set_okz_compute_curvature.cc:
-        325-376), matrix-free form (:350): projection of -div(n), CG to 1e-8 starting from the
-        previous curvature; with solution_ls given, followed by the curvature correction (:360-376,
+        325-376): projection of -div(n), CG to 1e-8 starting from the previous curvature.  Like the
+        reference (:355) the system matrix is the projection matrix shared with the normal solve
+        (mass + 4 delta Laplace, adaflo_ls_projection_vmult); use_projection_matrix=False solves with
+        ComputeCurvatureMatrix instead (the call the reference keeps commented out at :354).  With
+        solution_ls given, followed by the curvature correction (:360-376,
         parameters.curvature_correction)"""
-        from .solvers import ComputeCurvatureMatrix, ReductionControl, SolverCG
+        from .solvers import ComputeCurvatureMatrix, ProjectionMatrix, ReductionControl, SolverCG
         rhs.fill(0.0)
         self.local_compute_curvature_rhs(rhs, normal_vector_field)
         control = ReductionControl(2000, 1e-50, 1e-8)
-        SolverCG(control).solve(ComputeCurvatureMatrix(self.ops), solution_curvature, rhs, preconditioner)
+        matrix = ProjectionMatrix(self.ops) if use_projection_matrix else ComputeCurvatureMatrix(self.ops)
+        SolverCG(control).solve(matrix, solution_curvature, rhs, preconditioner)
         if solution_ls is not None:
             ops = self.ops
             _lib.check(ops._ctx, ops._lib.adaflo_ls_curvature_correction(ops._ctx, solution_curvature.ptr, solution_ls.ptr))

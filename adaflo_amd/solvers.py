@@ -12,7 +12,8 @@ import ctypes as C
 from . import _lib
 
 OPERATORS = {"advance_concentration": 0, "reinitialization": 1, "reinitialization_diffuse": 2,
-             "normal": 3, "curvature": 4, "pressure_mass": 5, "pressure_poisson": 6, "velocity": 7}
+             "normal": 3, "curvature": 4, "pressure_mass": 5, "pressure_poisson": 6, "velocity": 7,
+             "projection": 8}
 
 
 class NoConvergence(RuntimeError):
@@ -82,6 +83,14 @@ class ComputeNormalMatrix(_Matrix):
 class ComputeCurvatureMatrix(_Matrix):
     def __init__(self, ops):
         super().__init__(ops._ctx, "curvature")
+
+
+class ProjectionMatrix(_Matrix):
+    """the scalar projection matrix of LevelSetOKZSolver (level_set_okz.cc:262-312) the production
+    curvature solve uses (compute_curvature.cc:355), applied matrix-free"""
+
+    def __init__(self, ops):
+        super().__init__(ops._ctx, "projection")
 
 
 class PressureMassMatrix(_Matrix):

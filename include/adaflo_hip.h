@@ -241,6 +241,12 @@ int adaflo_ls_reinitialization_rhs(adaflo_ctx *ctx, double *dst, const double *s
 /* compute_normal_vmult / local_compute_normal_rhs  level_set_okz_compute_normal.cc:160-183, :123-156 */
 int adaflo_ls_compute_normal_vmult(adaflo_ctx *ctx, double *dst, const double *src);
 int adaflo_ls_compute_normal_rhs(adaflo_ctx *ctx, double *dst, const double *level_set_solution);
+/* The scalar "projection matrix" the production solves of the normal AND of the curvature use
+ * (LevelSetOKZSolver::local_projection_matrix, source/level_set_okz.cc:262-312: mass + 4 max(eps_used /
+ * eps, h / ls)^2 Laplace, assembled by the reference and applied per block; compute_curvature.cc:355
+ * solves with it, the call with ComputeCurvatureMatrix above it is commented out).  Matrix-free here:
+ * one scalar block of compute_normal_vmult. */
+int adaflo_ls_projection_vmult(adaflo_ctx *ctx, double *dst, const double *src);
 /* compute_curvature_vmult / local_compute_curvature_rhs  level_set_okz_compute_curvature.cc:263-304, :212-259 */
 int adaflo_ls_compute_curvature_vmult(adaflo_ctx *ctx, double *dst, const double *src, int apply_diffusion);
 int adaflo_ls_compute_curvature_rhs(adaflo_ctx *ctx, double *dst, const double *normal_vector_field);
@@ -287,7 +293,8 @@ typedef enum adaflo_operator
   ADAFLO_OP_LS_CURVATURE               = 4, /* ComputeCurvatureMatrix        compute_curvature.cc:308-323 */
   ADAFLO_OP_NS_PRESSURE_MASS           = 5,
   ADAFLO_OP_NS_PRESSURE_POISSON        = 6,
-  ADAFLO_OP_NS_VELOCITY                = 7  /* velocity_vmult (A block) */
+  ADAFLO_OP_NS_VELOCITY                = 7, /* velocity_vmult (A block) */
+  ADAFLO_OP_LS_PROJECTION              = 8  /* scalar projection matrix, adaflo_ls_projection_vmult */
 } adaflo_operator;
 
 typedef enum adaflo_solver

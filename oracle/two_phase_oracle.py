@@ -96,7 +96,16 @@ class RisingBubble:
         mesh, prm = self.mesh, self.prm
         H = orc.ls_compute_heaviside(mesh, self.s, self.eps_rel, self.phi)
         self.compute_normal(self.phi, False)
-        A = lambda v: orc.ls_curvature_vmult(mesh, prm, v)
+        # compute_curvature.cc:350-355: the production solve does NOT use ComputeCurvatureMatrix (that call is
+        # commented out) but the assembled projection matrix shared with the normal projection
+        # (level_set_okz.cc:262-300: mass + 4 max(eps_used / eps, h / ls)^2 Laplace) = one scalar block of the
+        # normal operator
+        nn = self.nn
+
+        def A(v):
+            blocks = np.zeros(self.dim * nn)
+            blocks[:nn] = v
+            return orc.ls_normal_vmult(mesh, prm, blocks)[:nn].copy()
         kappa = ko.cg(A, orc.ls_curvature_rhs(mesh, prm, self.normal), x0=self.kappa, inv_diag=self.inv_diag,
                       max_it=2000, rel_tol=1e-8)[0]
         with np.errstate(divide="ignore", invalid="ignore"):                 # compute_curvature.cc:360-376
@@ -115,7 +124,8 @@ class RisingBubble:
         iu, ip = np.indices(tuple(reversed(nnu))), np.indices(tuple(reversed(nnp)))
         Xu = [iu[dim - 1 - d].reshape(-1) for d in range(dim)]       # node coordinates (index units), x first
         Xp = [ip[dim - 1 - d].reshape(-1) for d in range(dim)]
-        P, Pp = 6, 3                                        # probe columns 3 cells apart never share a row
+        P, Pp = 3 * k, 3 * (k - 1)                          # probe columns 3 cells apart never share a row
+        up, pu = (k - 1) / k, k / (k - 1)                   # velocity <-> pressure node index units
         colu = sum((Xu[d] % P) * P ** d for d in range(dim))
         colp = sum((Xp[d] % Pp) * Pp ** d for d in range(dim))
         near = lambda a, c, per: c + per * np.round((a - c) / per).astype(int)
@@ -139,9 +149,9 @@ class RisingBubble:
                 rows.append(nz)
                 cols.append(dim * flat([near(Xu[d][nz // dim], cc[d], P) for d in range(dim)], nnu) + comp)
                 vals.append(yu[nz])
-                nz = np.nonzero(yp)[0]                      # pressure node I sits at velocity node 2 I
+                nz = np.nonzero(yp)[0]                      # pressure node I sits near velocity node I k / (k - 1)
                 rows.append(nu + nz)
-                cols.append(dim * flat([near(2 * Xp[d][nz], cc[d], P) for d in range(dim)], nnu) + comp)
+                cols.append(dim * flat([near(pu * Xp[d][nz], cc[d], P) for d in range(dim)], nnu) + comp)
                 vals.append(yp[nz])
         for c in range(Pp ** dim):
             cc = [(c // Pp ** d) % Pp for d in range(dim)]
@@ -150,7 +160,7 @@ class RisingBubble:
             yu, yp = vm(np.zeros(nu), (colp == c).astype(float))
             nz = np.nonzero(yu)[0]
             rows.append(nz)
-            cols.append(nu + flat([near(Xu[d][nz // dim] / 2, cc[d], Pp) for d in range(dim)], nnp))
+            cols.append(nu + flat([near(up * Xu[d][nz // dim], cc[d], Pp) for d in range(dim)], nnp))
             vals.append(yu[nz])
             nz = np.nonzero(yp)[0]
             rows.append(nu + nz)

@@ -56,6 +56,10 @@ def test_normal_curvature_and_reinitialization_steps():
     rhs_c = orc.ls_curvature_rhs(c.mesh, c.prm, n_ref)
     Ac = lambda v: orc.ls_curvature_vmult(c.mesh, c.prm, v)
     k_ref, k_it, *_ = ko.cg(Ac, rhs_c, inv_diag=inv, max_it=2000, rel_tol=1e-8)
+    nn = c.mesh.n_nodes(c.s)
+    # the projection matrix of the production solve = one scalar block of the normal operator
+    Ap = lambda v: orc.ls_normal_vmult(c.mesh, c.prm, np.concatenate([v, np.zeros(2 * nn)]))[:nn].copy()
+    kp_ref, kp_it, *_ = ko.cg(Ap, rhs_c, inv_diag=inv, max_it=2000, rel_tol=1e-8)
     phi_ref, its_ref = phi0.copy(), []
     nq = np.zeros(c.mesh.n_cells * c.nq * 3)
     for tau in range(2):
@@ -73,8 +77,11 @@ def test_normal_curvature_and_reinitialization_steps():
     assert rel_l2(normal.numpy(), n_ref) < 1e-9
     cur = lso.LevelSetOKZSolverComputeCurvature(ops)
     kappa, rhs_v = ops.vector(), ops.vector()
-    assert cur.compute_curvature(kappa, rhs_v, normal, c.pre) == k_it
+    assert cur.compute_curvature(kappa, rhs_v, normal, c.pre, use_projection_matrix=False) == k_it
     assert rel_l2(kappa.numpy(), k_ref) < 1e-8
+    kappa_p = ops.vector()
+    assert cur.compute_curvature(kappa_p, rhs_v, normal, c.pre) == kp_it
+    assert rel_l2(kappa_p.numpy(), kp_ref) < 1e-8
     # sanity of the oracle result itself: the curvature of a sphere of radius 0.27 is 2 / r = 7.4; the
     # damped projection of a too wide profile on this coarse mesh (8 intervals) gives the right sign
     # and order of magnitude

@@ -157,3 +157,30 @@ def test_rising_bubble_other_linearisations_match_their_reference_outputs(case, 
             assert history[-1] < 1e-9
     if "step3_second_residual" in ref:        # Picard: even the second residual of step #3 agrees to two digits
         assert abs(history[1] - float(ref["step3_second_residual"])) < 0.05 * history[1]
+
+
+def test_rising_bubble_q3_q2_matches_its_reference_output():
+    """tests/rising_bubble_ls_q3.output:2-30 -- Taylor-Hood Q3/Q2 on 20 x 40 cells (14 762 + 3 321 Navier-Stokes
+    DoF, 13 041 level-set DoF): pins the cubic velocity / quadratic pressure elements on Gauss-Lobatto nodes with
+    the 4-point Gauss rule in the residual, the Jacobian, the velocity evaluation of the advection right-hand
+    side and the force integration."""
+    import adaflo_amd
+    from oracle import two_phase_oracle as tpo
+    with open(GOLDEN) as f:
+        ref = json.load(f)["rising_bubble_ls_q3"]
+    fp = adaflo_amd.FlowParameters(velocity_degree=3, time_step_size_start=0.02, end_time=1.0)
+    with threadpool_limits(limits=1, user_api="blas"):
+        sim = tpo.RisingBubble(lambda: adaflo_amd.TimeStepping(fp), ncell=(20, 40), s=ref["concentration_subdivisions"],
+                               k=ref["velocity_degree"])
+        assert (sim.mesh.n_cells, sim.nu, sim.np_, sim.nn) == (ref["cells"], ref["dofs_u"], ref["dofs_p"], ref["dofs_ls"])
+        assert sim.log["initial_reinitialize"] == ref["initial_reinitialize_iterations"]
+        for expected in ref["time_steps"]:
+            (adv_r0, adv_it), rei_its, history = sim.advance_time_step()
+            assert adv_it == expected["advect_iterations"]
+            if expected["advect_residual"] == "0":
+                assert adv_r0 < 1e-12
+            else:
+                assert "%.3g" % adv_r0 == expected["advect_residual"]
+            assert rei_its == expected["reinitialize_iterations"]
+            assert "%.3g" % history[0] == expected["first_residual"]
+            assert history[-1] < 1e-9 and len(history) <= 4
