@@ -29,6 +29,7 @@
  *   tests/rising_bubble_ls_{picard,imex,expl}.output:6-30   the same with FE_Q_iso_Q1(3) and the Picard /
  *                                 semi-implicit / explicit linearisations (0.000244 / 0.000245 / 0.000246)
  *   tests/rising_bubble_ls_q3.output:2-30   Q3/Q2 elements (0.0261, 0.00764, 0.000257)
+ *   tests/spurious_currents_ls.output:2-25  static bubble, constant coefficients (0.365, 0.00024, 0.00014)
  * deal.II cannot be built here (needs cmake + Trilinos + p4est, none present): the reference
  * build is "unbuildable", see DESIGN.md.
  *

@@ -25,7 +25,7 @@ from . import oracle as orc
 
 class RisingBubble:
     def __init__(self, time_stepping_factory, ncell=(40, 80), s=4, k=2, eps_rel=1.5, dt=0.02, no_slip_everywhere=False,
-                 linearization=0, max_nl=10):
+                 linearization=0, max_nl=10, domain=None, centre=None, radius=0.25, physics=None, n_initial_reinit=2):
         """dim = len(ncell); the domain is [0,1]^(dim-1) x [0,2] with gravity along the last axis"""
         self.s, self.k, self.eps_rel, self.dt = s, k, eps_rel, dt
         # linearization: 0 Newton, 1 Picard, 2 semi-implicit, 3 explicit convection (NSParams); max_nl = "NL max
@@ -33,8 +33,14 @@ class RisingBubble:
         self.linearization, self.max_nl = linearization, max_nl
         self.ncell = list(ncell)
         dim = self.dim = len(ncell)
-        self.mesh = orc.Mesh.make(self.ncell, (0.,) * dim, (1.,) * (dim - 1) + (2.,))
-        self.h = 1.0 / ncell[0]
+        lower, upper = domain if domain is not None else ((0.,) * dim, (1.,) * (dim - 1) + (2.,))
+        self.mesh = orc.Mesh.make(self.ncell, lower, upper)
+        self.h = (upper[0] - lower[0]) / ncell[0]
+        # tests/rising_bubble_ls.prm; other cases (tests/spurious_currents_ls.prm) pass their own
+        self.physics = dict(surface_tension=0.0245, gravity=0.98, density=1.0, density_diff=-0.9, viscosity=0.01,
+                            viscosity_diff=-0.009)
+        self.physics.update(physics or {})
+        centre = np.full(dim, 0.5) if centre is None else np.asarray(centre, dtype=float)
         self.eps_used = eps_rel / s * self.h                               # two_phase_base.cc:290-291
         mesh = self.mesh
         self.nn, self.nu, self.np_ = mesh.n_nodes(s), mesh.n_nodes(k) * dim, mesh.n_nodes(k - 1)
@@ -58,12 +64,14 @@ class RisingBubble:
             for d in range(dim - 1):
                 self.con_u = self.con_u | orc.boundary_mask(mesh, k, dim, faces=[2 * d, 2 * d + 1], comps=[d])
         x = orc.node_coordinates(mesh, s, fe_type=1)
-        self.phi = -np.tanh((np.linalg.norm(x - 0.5, axis=1) - 0.25) / (2 * self.eps_used))   # rising_bubble.cc:59-77
+        self.phi = -np.tanh((np.linalg.norm(x - centre, axis=1) - radius) / (2 * self.eps_used))   # rising_bubble.cc:59-77
         self.normal, self.kappa, self.kappa_old = np.zeros(dim * self.nn), np.zeros(self.nn), np.zeros(self.nn)
         self.normal_q = np.zeros(mesh.n_cells * self.nq_ls * dim)
         self.log = {}
-        self.phi, its = self.reinitialize(self.phi, 2)                      # number initial reinit steps
-        self.ts_rei.next()
+        its = []
+        if n_initial_reinit > 0:                                            # number initial reinit steps
+            self.phi, its = self.reinitialize(self.phi, n_initial_reinit)
+            self.ts_rei.next()
         self.log["initial_reinitialize"] = its
         self.phi_old, self.phi_oo = self.phi.copy(), self.phi.copy()
         self.u, self.p = np.zeros(self.nu), np.zeros(self.np_)
@@ -113,8 +121,7 @@ class RisingBubble:
         sel = kappa > 1e-4
         kappa[sel] = 1.0 / (1.0 / kappa[sel] + dist[sel] / (self.dim - 1))
         self.kappa = kappa
-        return orc.ls_compute_force(mesh, self.s, self.k, H, kappa, surface_tension=0.0245, gravity=0.98, density=1.0,
-                                    density_diff=-0.9, viscosity=0.01, viscosity_diff=-0.009,
+        return orc.ls_compute_force(mesh, self.s, self.k, H, kappa, **self.physics,
                                     interpolate_grad_onto_pressure=True, con_u=self.con_u)
 
     # ---- exact Newton step: Jacobian by coloured probing, sparse LU
@@ -202,11 +209,13 @@ class RisingBubble:
         # compute_force, Navier-Stokes
         self.prm = self._ls_prm(ts)
         force, rho, mu = self.compute_force()
-        nsp = orc.NSParams.make(linearization=self.linearization, beta=0.5, density=1.0, viscosity=0.01,
-                                density_diff=-0.9, weight=ts.weight(),
+        ph = self.physics
+        nsp = orc.NSParams.make(linearization=self.linearization, beta=0.5, density=ph["density"], viscosity=ph["viscosity"],
+                                density_diff=ph["density_diff"], weight=ts.weight(),
                                 weight_old=ts.weight_old(), weight_old_old=ts.weight_old_old(), tau1=ts.tau1(),
                                 extrap_old=ts.factor_extrapol_old, extrap_old_old=ts.factor_extrapol_old_old)
-        lin, damp, history = np.zeros(mesh.n_cells * (k + 1) ** self.dim * orc.n_lin(self.dim)), np.zeros_like(rho), []
+        lin, history = np.zeros(mesh.n_cells * (k + 1) ** self.dim * orc.n_lin(self.dim)), []
+        damp = None if rho is None else np.zeros_like(rho)       # constant parameters: no coefficient arrays
         for it in range(self.max_nl + 1):
             ru, rp = orc.ns_residual(mesh, k, nsp, self.u, self.p, self.u_old, self.u_oo, con_u=self.con_u, lin=lin,
                                      rho=rho, mu=mu, damp=damp, user_u=force)

@@ -184,3 +184,30 @@ def test_rising_bubble_q3_q2_matches_its_reference_output():
             assert rei_its == expected["reinitialize_iterations"]
             assert "%.3g" % history[0] == expected["first_residual"]
             assert history[-1] < 1e-9 and len(history) <= 4
+
+
+def test_spurious_currents_matches_its_reference_output():
+    """tests/spurious_currents_ls.output:2-25 (tests/spurious_currents.cc:57-72,239-245, spurious_currents_ls.prm):
+    static bubble of radius 0.5 at (0.02, 0.03) in [-2.5, 2.5]^2, 80 x 80 cells, no-slip walls, equal densities and
+    viscosities (constant-coefficient Navier-Stokes operator driven by the surface tension alone), sigma = 1,
+    FE_Q_iso_Q1(3), no initial reinitialisation, dt = 0.01."""
+    import adaflo_amd
+    from oracle import two_phase_oracle as tpo
+    with open(GOLDEN) as f:
+        ref = json.load(f)["spurious_currents_ls"]
+    fp = adaflo_amd.FlowParameters(velocity_degree=2, time_step_size_start=ref["dt"], end_time=0.3)
+    with threadpool_limits(limits=1, user_api="blas"):
+        sim = tpo.RisingBubble(lambda: adaflo_amd.TimeStepping(fp), ncell=(80, 80), s=ref["concentration_subdivisions"],
+                               dt=ref["dt"], no_slip_everywhere=True, domain=ref["domain"], centre=ref["centre"],
+                               radius=ref["radius"], physics=ref["physics"], n_initial_reinit=0)
+        assert (sim.mesh.n_cells, sim.nu, sim.np_, sim.nn) == (ref["cells"], ref["dofs_u"], ref["dofs_p"], ref["dofs_ls"])
+        for expected in ref["time_steps"]:
+            (adv_r0, adv_it), rei_its, history = sim.advance_time_step()
+            assert adv_it == expected["advect_iterations"]
+            if expected["advect_residual"] == "0":
+                assert adv_r0 < 1e-12
+            else:
+                assert "%.3g" % adv_r0 == expected["advect_residual"]
+            assert rei_its == expected["reinitialize_iterations"]
+            assert "%.3g" % history[0] == expected["first_residual"]
+            assert history[-1] < 1e-9
