@@ -136,6 +136,129 @@ namespace adaflo_hip
       __syncthreads();
     }
 
+    // NB components at once (u + b ND3 -> val + b NQ3, g + (3 b + e) NQ3; tmp: NB * TMP doubles):
+    // the same three stages with NB times the work between two barriers -- the cell kernels are
+    // bound by barrier + LDS latency, not by LDS bandwidth
+    template <int NB>
+    static __device__ void evaluate_batch(const double *S, const double *D, const double *u, double *val, double *g,
+                                          double *tmp)
+    {
+      const int tid = threadIdx.x;
+      for (int ob = tid; ob < NB * T1; ob += NT)
+        {
+          const int b = ob / T1, o = ob - b * T1;
+          const int q = o % NQ, base = (o / NQ) * ND;
+          const double *ub = u + b * ND3;
+          double        a = 0., bb = 0.;
+#pragma unroll
+          for (int i = 0; i < ND; ++i)
+            {
+              const double v = ub[base + i];
+              a += S[q * ND + i] * v;
+              bb += D[q * ND + i] * v;
+            }
+          tmp[b * TMP + o]      = a;
+          tmp[b * TMP + T1 + o] = bb;
+        }
+      __syncthreads();
+      for (int ob = tid; ob < NB * T2; ob += NT)
+        {
+          const int b = ob / T2, o = ob - b * T2;
+          const int q = o % NQ, r = (o / NQ) % NQ, k = o / NQ2;
+          const double *t1 = tmp + b * TMP, *t1d = t1 + T1;
+          double        a = 0., dy = 0., dx = 0.;
+#pragma unroll
+          for (int j = 0; j < ND; ++j)
+            {
+              const double v = t1[(k * ND + j) * NQ + q];
+              a += S[r * ND + j] * v;
+              dy += D[r * ND + j] * v;
+              dx += S[r * ND + j] * t1d[(k * ND + j) * NQ + q];
+            }
+          double *t2 = tmp + b * TMP + 2 * T1;
+          t2[o]          = a;
+          t2[T2 + o]     = dy;
+          t2[2 * T2 + o] = dx;
+        }
+      __syncthreads();
+      for (int ob = tid; ob < NB * NQ3; ob += NT)
+        {
+          const int b = ob / NQ3, o = ob - b * NQ3;
+          const int rq = o % NQ2, s = o / NQ2;
+          const double *t2 = tmp + b * TMP + 2 * T1, *t2dy = t2 + T2, *t2dx = t2 + 2 * T2;
+          double        a = 0., dz = 0., dy = 0., dx = 0.;
+#pragma unroll
+          for (int k = 0; k < ND; ++k)
+            {
+              const double v = t2[k * NQ2 + rq];
+              a += S[s * ND + k] * v;
+              dz += D[s * ND + k] * v;
+              dy += S[s * ND + k] * t2dy[k * NQ2 + rq];
+              dx += S[s * ND + k] * t2dx[k * NQ2 + rq];
+            }
+          val[b * NQ3 + o]           = a;
+          g[(3 * b + 0) * NQ3 + o] = dx;
+          g[(3 * b + 1) * NQ3 + o] = dy;
+          g[(3 * b + 2) * NQ3 + o] = dz;
+        }
+      __syncthreads();
+    }
+
+    // transpose of evaluate_batch
+    template <int NB>
+    static __device__ void integrate_batch(const double *S, const double *D, const double *tv, const double *tg,
+                                           double *out, double *tmp)
+    {
+      const int tid = threadIdx.x;
+      for (int ob = tid; ob < NB * T2; ob += NT)
+        {
+          const int b = ob / T2, o = ob - b * T2;
+          const int rq = o % NQ2, k = o / NQ2;
+          const double *v = tv + b * NQ3, *gx = tg + (3 * b) * NQ3, *gy = gx + NQ3, *gz = gy + NQ3;
+          double        a = 0., ay = 0., ax = 0.;
+#pragma unroll
+          for (int s = 0; s < NQ; ++s)
+            {
+              a += S[s * ND + k] * v[s * NQ2 + rq] + D[s * ND + k] * gz[s * NQ2 + rq];
+              ay += S[s * ND + k] * gy[s * NQ2 + rq];
+              ax += S[s * ND + k] * gx[s * NQ2 + rq];
+            }
+          double *t2 = tmp + b * TMP + 2 * T1;
+          t2[o]          = a;
+          t2[T2 + o]     = ay;
+          t2[2 * T2 + o] = ax;
+        }
+      __syncthreads();
+      for (int ob = tid; ob < NB * T1; ob += NT)
+        {
+          const int b = ob / T1, o = ob - b * T1;
+          const int q = o % NQ, j = (o / NQ) % ND, k = o / (NQ * ND);
+          const double *t2 = tmp + b * TMP + 2 * T1, *t2dy = t2 + T2, *t2dx = t2 + 2 * T2;
+          double        bb = 0., bx = 0.;
+#pragma unroll
+          for (int r = 0; r < NQ; ++r)
+            {
+              bb += S[r * ND + j] * t2[(k * NQ + r) * NQ + q] + D[r * ND + j] * t2dy[(k * NQ + r) * NQ + q];
+              bx += S[r * ND + j] * t2dx[(k * NQ + r) * NQ + q];
+            }
+          tmp[b * TMP + o]      = bb;
+          tmp[b * TMP + T1 + o] = bx;
+        }
+      __syncthreads();
+      for (int ob = tid; ob < NB * ND3; ob += NT)
+        {
+          const int b = ob / ND3, o = ob - b * ND3;
+          const int i = o % ND, kj = o / ND;
+          const double *t1 = tmp + b * TMP, *t1d = t1 + T1;
+          double        c = 0.;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            c += S[q * ND + i] * t1[kj * NQ + q] + D[q * ND + i] * t1d[kj * NQ + q];
+          out[b * ND3 + o] = c;
+        }
+      __syncthreads();
+    }
+
     // transpose of evaluate: out[ND3] = S^T tv + D_x^T tgx + D_y^T tgy + D_z^T tgz
     template <bool VAL, bool GRAD>
     static __device__ void integrate(const double *S, const double *D, const double *tv,

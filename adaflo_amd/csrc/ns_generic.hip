@@ -17,6 +17,10 @@ namespace adaflo_hip
     static constexpr int NDU3 = NDU * NDU * NDU, NDP3 = NDP * NDP * NDP, NQ3 = NQ * NQ * NQ;
     static constexpr int TAB = 2 * NQ * NDU + 2 * NQ * NDP + NQ;
     static constexpr int TABP = (TAB + 1) & ~1;
+    // Q2: the three velocity components go through the sum factorisation together (a third of the
+    // barriers; 128^3 vmult 5.5 -> 4.6 ms).  For k >= 3 the three-fold scratch space costs more
+    // occupancy than the barriers cost time (measured 64^3 Q4: 2.5 -> 3.4 ms), so one component at a time.
+    static constexpr int NBATCH = K == 2 ? 3 : 1;
   };
 
   template <int K, int NT>
@@ -24,7 +28,7 @@ namespace adaflo_hip
   {
     using L = NSLayout<K>;
     size_t n = L::TABP + 3 * L::NDU3 + L::NDP3 + 3 * L::NQ3 + 9 * L::NQ3 + L::NQ3 +
-               SumFac<L::NDU, L::NQ, NT>::TMP;
+               NSLayout<K>::NBATCH * SumFac<L::NDU, L::NQ, NT>::TMP;
     if (residual)
       n += 2 * (3 * L::NQ3 + 9 * L::NQ3);
     return n;
@@ -44,7 +48,15 @@ namespace adaflo_hip
            *wq = D_p + NQ * L::NDP;
     double *ul = lds + L::TABP, *pl = ul + 3 * NDU3, *vu = pl + NDP3, *gu = vu + 3 * NQ3,
            *vp = gu + 9 * NQ3, *tmp = vp + NQ3;
-    double *vo = tmp + SFU::TMP, *go = vo + 3 * NQ3, *voo = go + 9 * NQ3, *goo = voo + 3 * NQ3;
+    double *vo = tmp + L::NBATCH * SFU::TMP, *go = vo + 3 * NQ3, *voo = go + 9 * NQ3, *goo = voo + 3 * NQ3;
+    auto evaluate_u = [&](const double *u, double *val, double *grad) {
+      if constexpr (L::NBATCH == 3)
+        SFU::template evaluate_batch<3>(S_u, D_u, u, val, grad, tmp);
+      else
+        for (int d = 0; d < 3; ++d)
+          SFU::template evaluate<true, true>(S_u, D_u, u + d * NDU3, val + d * NQ3, grad + (3 * d + 0) * NQ3,
+                                             grad + (3 * d + 1) * NQ3, grad + (3 * d + 2) * NQ3, tmp);
+    };
 
     const int tid = threadIdx.x;
     for (int o = tid; o < L::TAB; o += NT)
@@ -65,9 +77,7 @@ namespace adaflo_hip
     __syncthreads();
 
     // :668-671
-    for (int d = 0; d < 3; ++d)
-      SFU::template evaluate<true, true>(S_u, D_u, ul + d * NDU3, vu + d * NQ3, gu + (3 * d + 0) * NQ3,
-                                         gu + (3 * d + 1) * NQ3, gu + (3 * d + 2) * NQ3, tmp);
+    evaluate_u(ul, vu, gu);
     // :688-697
     if (OP != OP_VMULT_VELOCITY)
       SFP::template evaluate<true, false>(S_p, D_p, pl, vp, nullptr, nullptr, nullptr, tmp);
@@ -77,16 +87,10 @@ namespace adaflo_hip
       {
         gather_cell<K, 3, NT, false>(a.old_u, ul, cx, cy, cz, nux, nuy, nuz, 0u);
         __syncthreads();
-        for (int d = 0; d < 3; ++d)
-          SFU::template evaluate<true, true>(S_u, D_u, ul + d * NDU3, vo + d * NQ3,
-                                             go + (3 * d + 0) * NQ3, go + (3 * d + 1) * NQ3,
-                                             go + (3 * d + 2) * NQ3, tmp);
+        evaluate_u(ul, vo, go);
         gather_cell<K, 3, NT, false>(a.oldold_u, ul, cx, cy, cz, nux, nuy, nuz, 0u);
         __syncthreads();
-        for (int d = 0; d < 3; ++d)
-          SFU::template evaluate<true, true>(S_u, D_u, ul + d * NDU3, voo + d * NQ3,
-                                             goo + (3 * d + 0) * NQ3, goo + (3 * d + 1) * NQ3,
-                                             goo + (3 * d + 2) * NQ3, tmp);
+        evaluate_u(ul, voo, goo);
       }
 
     // :621-653
@@ -238,10 +242,12 @@ namespace adaflo_hip
     __syncthreads();
 
     // :897-907
-    for (int d = 0; d < 3; ++d)
-      SFU::template integrate<true, true>(S_u, D_u, vu + d * NQ3, gu + (3 * d + 0) * NQ3,
-                                          gu + (3 * d + 1) * NQ3, gu + (3 * d + 2) * NQ3,
-                                          ul + d * NDU3, tmp);
+    if constexpr (L::NBATCH == 3)
+      SFU::template integrate_batch<3>(S_u, D_u, vu, gu, ul, tmp);
+    else
+      for (int d = 0; d < 3; ++d)
+        SFU::template integrate<true, true>(S_u, D_u, vu + d * NQ3, gu + (3 * d + 0) * NQ3, gu + (3 * d + 1) * NQ3,
+                                            gu + (3 * d + 2) * NQ3, ul + d * NDU3, tmp);
     scatter_cell<K, 3, NT>(a.dst_u, ul, cx, cy, cz, nux, nuy, nuz, a.brick.con_u);
     if (OP != OP_VMULT_VELOCITY && P.linearization != ADAFLO_PROJECTION)
       {
