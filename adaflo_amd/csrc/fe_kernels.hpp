@@ -136,6 +136,75 @@ namespace adaflo_hip
       __syncthreads();
     }
 
+    // evaluate with the LAST stage kept in registers: thread tid < NQ3 returns value and reference
+    // gradient at quadrature point tid (needs NT >= NQ3); nothing but `tmp` is written
+    template <bool GRAD>
+    static __device__ void evaluate_to_registers(const double *S, const double *D, const double *u, double *tmp,
+                                                 double &val, double &gx, double &gy, double &gz)
+    {
+      static_assert(NT >= NQ3, "one thread per quadrature point");
+      double *t1 = tmp, *t1d = tmp + T1, *t2 = tmp + 2 * T1, *t2dy = t2 + T2, *t2dx = t2 + 2 * T2;
+      const int tid = threadIdx.x;
+      for (int o = tid; o < T1; o += NT)
+        {
+          const int q = o % NQ, base = (o / NQ) * ND;
+          double    a = 0., b = 0.;
+#pragma unroll
+          for (int i = 0; i < ND; ++i)
+            {
+              const double v = u[base + i];
+              a += S[q * ND + i] * v;
+              if (GRAD)
+                b += D[q * ND + i] * v;
+            }
+          t1[o] = a;
+          if (GRAD)
+            t1d[o] = b;
+        }
+      __syncthreads();
+      for (int o = tid; o < T2; o += NT)
+        {
+          const int q = o % NQ, r = (o / NQ) % NQ, k = o / NQ2;
+          double    a = 0., dy = 0., dx = 0.;
+#pragma unroll
+          for (int j = 0; j < ND; ++j)
+            {
+              const double v = t1[(k * ND + j) * NQ + q];
+              a += S[r * ND + j] * v;
+              if (GRAD)
+                {
+                  dy += D[r * ND + j] * v;
+                  dx += S[r * ND + j] * t1d[(k * ND + j) * NQ + q];
+                }
+            }
+          t2[o] = a;
+          if (GRAD)
+            {
+              t2dy[o] = dy;
+              t2dx[o] = dx;
+            }
+        }
+      __syncthreads();
+      val = gx = gy = gz = 0.;
+      if (tid < NQ3)
+        {
+          const int rq = tid % NQ2, s = tid / NQ2;
+#pragma unroll
+          for (int k = 0; k < ND; ++k)
+            {
+              const double v = t2[k * NQ2 + rq];
+              val += S[s * ND + k] * v;
+              if (GRAD)
+                {
+                  gz += D[s * ND + k] * v;
+                  gy += S[s * ND + k] * t2dy[k * NQ2 + rq];
+                  gx += S[s * ND + k] * t2dx[k * NQ2 + rq];
+                }
+            }
+        }
+      __syncthreads();
+    }
+
     // NB components at once (u + b ND3 -> val + b NQ3, g + (3 b + e) NQ3; tmp: NB * TMP doubles):
     // the same three stages with NB times the work between two barriers -- the cell kernels are
     // bound by barrier + LDS latency, not by LDS bandwidth

@@ -21,12 +21,19 @@ namespace adaflo_hip
     // barriers; 128^3 vmult 5.5 -> 4.6 ms).  For k >= 3 the three-fold scratch space costs more
     // occupancy than the barriers cost time (measured 64^3 Q4: 2.5 -> 3.4 ms), so one component at a time.
     static constexpr int NBATCH = K == 2 ? 3 : 1;
+    // k >= 3: the kernel is bound by the number of cells a CU can hold in LDS (Q4: 22 KB per cell).
+    // One thread per quadrature point keeps values and gradients of all components (and of the
+    // old solutions in the residual) in REGISTERS between evaluate and integrate; only the 1D
+    // sweeps go through LDS, one component at a time: Q4 14 KB per cell.
+    static constexpr bool REGQ = K >= 3;
   };
 
   template <int K, int NT>
   constexpr size_t ns_lds_doubles(const bool residual)
   {
     using L = NSLayout<K>;
+    if (L::REGQ)
+      return L::TABP + 3 * L::NDU3 + L::NDP3 + 4 * L::NQ3 + SumFac<L::NDU, L::NQ, NT>::TMP;
     size_t n = L::TABP + 3 * L::NDU3 + L::NDP3 + 3 * L::NQ3 + 9 * L::NQ3 + L::NQ3 +
                NSLayout<K>::NBATCH * SumFac<L::NDU, L::NQ, NT>::TMP;
     if (residual)
@@ -46,9 +53,22 @@ namespace adaflo_hip
     extern __shared__ double lds[];
     double *S_u = lds, *D_u = S_u + NQ * L::NDU, *S_p = D_u + NQ * L::NDU, *D_p = S_p + NQ * L::NDP,
            *wq = D_p + NQ * L::NDP;
-    double *ul = lds + L::TABP, *pl = ul + 3 * NDU3, *vu = pl + NDP3, *gu = vu + 3 * NQ3,
-           *vp = gu + 9 * NQ3, *tmp = vp + NQ3;
+    constexpr bool REGQ = L::REGQ;
+    // REGQ: [ul | pl | qb (4 NQ3: one component's tested value + gradient) | tmp]; vu / gu / vp unused
+    double *ul = lds + L::TABP, *pl = ul + 3 * NDU3, *vu = pl + NDP3, *gu = vu + (REGQ ? 1 : 3) * NQ3,
+           *vp = gu + (REGQ ? 3 : 9) * NQ3, *tmp = REGQ ? vp : vp + NQ3;
+    double *qb = vu;
+    double  rv[3] = {0., 0., 0.}, rg[9], rp = 0.;                  // REGQ: this thread's quadrature point
+    double  rvo[3] = {0., 0., 0.}, rgo[9], rvoo[3] = {0., 0., 0.}, rgoo[9];
+    for (int i = 0; i < 9; ++i)
+      rg[i] = rgo[i] = rgoo[i] = 0.;
     double *vo = tmp + L::NBATCH * SFU::TMP, *go = vo + 3 * NQ3, *voo = go + 9 * NQ3, *goo = voo + 3 * NQ3;
+    auto evaluate_u_reg = [&](const double *u, double *val, double *grad) {
+      if constexpr (REGQ)
+        for (int d = 0; d < 3; ++d)
+          SFU::template evaluate_to_registers<true>(S_u, D_u, u + d * NDU3, tmp, val[d], grad[3 * d], grad[3 * d + 1],
+                                                    grad[3 * d + 2]);
+    };
     auto evaluate_u = [&](const double *u, double *val, double *grad) {
       if constexpr (L::NBATCH == 3)
         SFU::template evaluate_batch<3>(S_u, D_u, u, val, grad, tmp);
@@ -77,20 +97,37 @@ namespace adaflo_hip
     __syncthreads();
 
     // :668-671
-    evaluate_u(ul, vu, gu);
+    if constexpr (REGQ)
+      evaluate_u_reg(ul, rv, rg);
+    else
+      evaluate_u(ul, vu, gu);
     // :688-697
     if (OP != OP_VMULT_VELOCITY)
-      SFP::template evaluate<true, false>(S_p, D_p, pl, vp, nullptr, nullptr, nullptr, tmp);
+      {
+        if constexpr (REGQ)
+          {
+            double d0, d1, d2;
+            SFP::template evaluate_to_registers<false>(S_p, D_p, pl, tmp, rp, d0, d1, d2);
+          }
+        else
+          SFP::template evaluate<true, false>(S_p, D_p, pl, vp, nullptr, nullptr, nullptr, tmp);
+      }
 
     // :673-686 old solutions for the residual
     if (RES && P.physical_type == ADAFLO_INCOMPRESSIBLE)
       {
         gather_cell<K, 3, NT, false>(a.old_u, ul, cx, cy, cz, nux, nuy, nuz, 0u);
         __syncthreads();
-        evaluate_u(ul, vo, go);
+        if constexpr (REGQ)
+          evaluate_u_reg(ul, rvo, rgo);
+        else
+          evaluate_u(ul, vo, go);
         gather_cell<K, 3, NT, false>(a.oldold_u, ul, cx, cy, cz, nux, nuy, nuz, 0u);
         __syncthreads();
-        evaluate_u(ul, voo, goo);
+        if constexpr (REGQ)
+          evaluate_u_reg(ul, rvoo, rgoo);
+        else
+          evaluate_u(ul, voo, goo);
       }
 
     // :621-653
@@ -112,9 +149,9 @@ namespace adaflo_hip
         double       g[3][3], val[3], conv[3] = {0., 0., 0.};
         for (int d = 0; d < 3; ++d)
           {
-            val[d] = vu[d * NQ3 + q];
+            val[d] = REGQ ? rv[d] : vu[d * NQ3 + q];
             for (int e = 0; e < 3; ++e)
-              g[d][e] = gu[(3 * d + e) * NQ3 + q] * ih[e];
+              g[d][e] = (REGQ ? rg[3 * d + e] : gu[(3 * d + e) * NQ3 + q]) * ih[e];
           }
         const double div = g[0][0] + g[1][1] + g[2][2];
         if (!stokes)
@@ -126,16 +163,18 @@ namespace adaflo_hip
               {
                 if (P.physical_type != ADAFLO_INCOMPRESSIBLE_STATIONARY)
                   for (int d = 0; d < 3; ++d)
-                    conv[d] += vo[d * NQ3 + q] * P.weight_old + voo[d * NQ3 + q] * P.weight_old_old;
+                    conv[d] += (REGQ ? rvo[d] : vo[d * NQ3 + q]) * P.weight_old +
+                               (REGQ ? rvoo[d] : voo[d * NQ3 + q]) * P.weight_old_old;
                 if (need_extrap)
                   {
                     double og[3][3], ov[3];
                     for (int d = 0; d < 3; ++d)
                       {
                         for (int e = 0; e < 3; ++e)
-                          og[d][e] = (go[(3 * d + e) * NQ3 + q] * P.extrap_old +
-                                      goo[(3 * d + e) * NQ3 + q] * P.extrap_old_old) * ih[e];
-                        ov[d] = vo[d * NQ3 + q] * P.extrap_old + voo[d * NQ3 + q] * P.extrap_old_old;
+                          og[d][e] = ((REGQ ? rgo[3 * d + e] : go[(3 * d + e) * NQ3 + q]) * P.extrap_old +
+                                      (REGQ ? rgoo[3 * d + e] : goo[(3 * d + e) * NQ3 + q]) * P.extrap_old_old) * ih[e];
+                        ov[d] = (REGQ ? rvo[d] : vo[d * NQ3 + q]) * P.extrap_old +
+                                (REGQ ? rvoo[d] : voo[d * NQ3 + q]) * P.extrap_old_old;
                       }
                     const double ediv = og[0][0] + og[1][1] + og[2][2];
                     if (P.linearization == ADAFLO_COUPLED_VELOCITY_EXPLICIT)
@@ -217,8 +256,11 @@ namespace adaflo_hip
         double       pres = 0.;
         if (OP != OP_VMULT_VELOCITY)
           {
-            pres  = vp[q];
-            vp[q] = -div * jxw;
+            pres = REGQ ? rp : vp[q];
+            if (REGQ)
+              rp = -div * jxw;
+            else
+              vp[q] = -div * jxw;
           }
         for (int d = 0; d < 3; ++d)
           for (int e = d + 1; e < 3; ++e)
@@ -234,15 +276,36 @@ namespace adaflo_hip
           }
         for (int d = 0; d < 3; ++d)
           {
-            vu[d * NQ3 + q] = conv[d] * jxw; // zero for Stokes: same result as skipping values
-            for (int e = 0; e < 3; ++e)
-              gu[(3 * d + e) * NQ3 + q] = g[d][e] * (jxw * ih[e]);
+            if (REGQ)
+              {
+                rv[d] = conv[d] * jxw;
+                for (int e = 0; e < 3; ++e)
+                  rg[3 * d + e] = g[d][e] * (jxw * ih[e]);
+              }
+            else
+              {
+                vu[d * NQ3 + q] = conv[d] * jxw; // zero for Stokes: same result as skipping values
+                for (int e = 0; e < 3; ++e)
+                  gu[(3 * d + e) * NQ3 + q] = g[d][e] * (jxw * ih[e]);
+              }
           }
       }
     __syncthreads();
 
     // :897-907
-    if constexpr (L::NBATCH == 3)
+    if constexpr (REGQ)
+      for (int d = 0; d < 3; ++d)
+        {
+          if (tid < NQ3)
+            {
+              qb[tid] = rv[d];
+              for (int e = 0; e < 3; ++e)
+                qb[(1 + e) * NQ3 + tid] = rg[3 * d + e];
+            }
+          __syncthreads();
+          SFU::template integrate<true, true>(S_u, D_u, qb, qb + NQ3, qb + 2 * NQ3, qb + 3 * NQ3, ul + d * NDU3, tmp);
+        }
+    else if constexpr (L::NBATCH == 3)
       SFU::template integrate_batch<3>(S_u, D_u, vu, gu, ul, tmp);
     else
       for (int d = 0; d < 3; ++d)
@@ -251,7 +314,15 @@ namespace adaflo_hip
     scatter_cell<K, 3, NT>(a.dst_u, ul, cx, cy, cz, nux, nuy, nuz, a.brick.con_u);
     if (OP != OP_VMULT_VELOCITY && P.linearization != ADAFLO_PROJECTION)
       {
-        SFP::template integrate<true, false>(S_p, D_p, vp, nullptr, nullptr, nullptr, pl, tmp);
+        if constexpr (REGQ)
+          {
+            if (tid < NQ3)
+              qb[tid] = rp;
+            __syncthreads();
+            SFP::template integrate<true, false>(S_p, D_p, qb, nullptr, nullptr, nullptr, pl, tmp);
+          }
+        else
+          SFP::template integrate<true, false>(S_p, D_p, vp, nullptr, nullptr, nullptr, pl, tmp);
         scatter_cell<K - 1, 1, NT>(a.dst_p, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
       }
   }
