@@ -25,6 +25,10 @@ namespace adaflo_hip
     // One thread per quadrature point keeps values and gradients of all components (and of the
     // old solutions in the residual) in REGISTERS between evaluate and integrate; only the 1D
     // sweeps go through LDS, one component at a time: Q4 14 KB per cell.
+    // PMC profile of the Q4 kernel after this change: the LDS pipeline is busy 82 % of the time and
+    // half of the LDS reads are 1D matrix entries.  Keeping the rows / columns a thread needs in
+    // registers (one pass per stage) halves the LDS instructions but costs 120 VGPRs = half the
+    // occupancy: measured Q3 1.04 -> 1.21 ms, Q4 2.38 -> 2.43 ms, Q5 2.26 -> 2.98 ms; not kept.
     static constexpr bool REGQ = K >= 3;
   };
 
