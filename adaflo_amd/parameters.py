@@ -45,6 +45,11 @@ class FlowParameters:
     max_lin_iteration: int = 500
     tol_lin_iteration: float = 1e-3
     rel_lin_iteration: bool = True
+    # level-set driver (parameters.cc:351-357) and mesh keys a driver needs
+    n_reinit_steps: int = 2
+    n_initial_reinit_steps: int = 0
+    global_refinements: int = 1
+    adaptive_refinements: int = 0
 
     def __post_init__(self):
         if self.velocity_degree <= 1:
@@ -69,3 +74,94 @@ class FlowParameters:
     @property
     def stored_damping(self):
         return -self.damping  # parameters.cc:466-467
+
+
+# ---------------------------------------------------------------------------------------------
+# deal.II ParameterHandler input files (the reference's tests/*.prm): `subsection X` ... `end`
+# blocks, `set key = value` entries, `#` comments.  FlowParameters::parse_parameters
+# (source/parameters.cc:449-614) reads the sections Navier-Stokes (+ its sub-section Solver),
+# Two phase, Time stepping and Output options; the mapping below follows it line by line for the
+# entries this engine uses.  Keys the engine has no use for (output, preconditioner names, AMR)
+# are accepted and kept in `FlowParameters.unused`.
+_PRM_KEYS = {
+    ("Navier-Stokes", "dimension"): ("dimension", int),
+    ("Navier-Stokes", "global refinements"): ("global_refinements", int),
+    ("Navier-Stokes", "adaptive refinements"): ("adaptive_refinements", int),
+    ("Navier-Stokes", "velocity degree"): ("velocity_degree", int),
+    ("Navier-Stokes", "augmented Taylor-Hood elements"): ("augmented_taylor_hood", lambda v: int(v) > 0),
+    ("Navier-Stokes", "viscosity"): ("viscosity", float),
+    ("Navier-Stokes", "density"): ("density", float),
+    ("Navier-Stokes", "damping"): ("damping", float),
+    ("Navier-Stokes", "physical type"): ("physical_type", str),
+    ("Navier-Stokes", "formulation convective term momentum balance"): ("formulation_convective_term", str),
+    ("Navier-Stokes/Solver", "NL max iterations"): ("max_nl_iteration", int),
+    ("Navier-Stokes/Solver", "NL tolerance"): ("tol_nl_iteration", float),
+    ("Navier-Stokes/Solver", "linearization scheme"): ("linearization", str),
+    ("Navier-Stokes/Solver", "tau grad div"): ("tau_grad_div", float),
+    ("Navier-Stokes/Solver", "lin max iterations"): ("max_lin_iteration", int),
+    ("Navier-Stokes/Solver", "lin tolerance"): ("tol_lin_iteration", float),
+    ("Navier-Stokes/Solver", "lin relative tolerance"): ("rel_lin_iteration", lambda v: int(v) > 0),
+    ("Two phase", "density difference"): ("density_diff", float),
+    ("Two phase", "viscosity difference"): ("viscosity_diff", float),
+    ("Two phase", "surface tension"): ("surface_tension", float),
+    ("Two phase", "gravity"): ("gravity", float),
+    ("Two phase", "epsilon"): ("epsilon", float),
+    ("Two phase", "concentration subdivisions"): ("concentration_subdivisions", int),
+    ("Two phase", "curvature correction"): ("curvature_correction", lambda v: int(v) > 0),
+    ("Two phase", "grad pressure compatible"): ("interpolate_grad_onto_pressure", lambda v: int(v) > 0),
+    ("Two phase", "number reinit steps"): ("n_reinit_steps", int),
+    ("Two phase", "number initial reinit steps"): ("n_initial_reinit_steps", int),
+    ("Time stepping", "start time"): ("start_time", float),
+    ("Time stepping", "end time"): ("end_time", float),
+    ("Time stepping", "step size"): ("time_step_size_start", float),
+    ("Time stepping", "max step size"): ("time_step_size_max", float),
+    ("Time stepping", "min step size"): ("time_step_size_min", float),
+    ("Time stepping", "scheme"): ("time_step_scheme", str),
+}
+
+
+def parse_prm(text):
+    """{(section path, key): value string} of a ParameterHandler input text"""
+    entries, path = {}, []
+    for number, raw in enumerate(text.splitlines(), 1):
+        line = raw.split("#", 1)[0].strip()
+        if not line:
+            continue
+        if line.startswith("subsection"):
+            path.append(line[len("subsection"):].strip())
+        elif line == "end":
+            if not path:
+                raise ValueError("line %d: 'end' without subsection" % number)
+            path.pop()
+        elif line.startswith("set"):
+            if "=" not in line:
+                raise ValueError("line %d: expected 'set key = value'" % number)
+            key, value = line[3:].split("=", 1)
+            entries[("/".join(path), " ".join(key.split()))] = value.strip()
+        else:
+            raise ValueError("line %d: cannot parse %r" % (number, raw))
+    if path:
+        raise ValueError("unclosed subsection %s" % path[-1])
+    return entries
+
+
+def flow_parameters_from_prm(text):
+    """FlowParameters from the text of a .prm file (FlowParameters::parse_parameters)"""
+    entries = parse_prm(text)
+    kw, unused = {}, {}
+    for (section, key), value in entries.items():
+        target = _PRM_KEYS.get((section, key))
+        if target is None:
+            unused[(section, key)] = value
+        else:
+            kw[target[0]] = target[1](value)
+    # parameters.cc:548-557: the Two phase section overrides density / viscosity when positive
+    for name in ("density", "viscosity"):
+        v = entries.get(("Two phase", name))
+        if v is not None and float(v) > 0.0:
+            kw[name] = float(v)
+    p = FlowParameters(**kw)
+    if p.time_step_size_min > p.time_step_size_start:          # :593-595
+        p.time_step_size_max = p.time_step_size_min = p.time_step_size_start
+    p.unused = unused
+    return p

@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
-"""3D rising bubble (tests/rising_bubble_ls.prm of the reference, extruded: [0,1]^2 x [0,2], bubble of
-radius 0.25 at (0.5, 0.5, 0.5)) with every kernel and every vector on one MI355X.
+"""3D rising bubble (tests/rising_bubble.cc + rising_bubble_ls.prm of the reference, extruded:
+[0,1]^2 x [0,2], bubble of radius 0.25 at (0.5, 0.5, 0.5), no-slip box) with every kernel and every
+vector on one MI355X.  Prints the lines of the reference's output (verbosity 1):
+    Concentration advance: advect [<initial residual>/<BiCGStab its>] and reinitialize (<CG its> + ...)
+    Residual/iterations: [<residual>/<FGMRES its>] ... [<residual>/conv.]
 
-    python examples/rising_bubble_3d.py [cells_x] [subdivisions] [time steps]"""
+    python examples/rising_bubble_3d.py [cells_x] [subdivisions] [time steps]
+    python examples/rising_bubble_3d.py --prm case.prm [time steps]     # 5 * 2^"global refinements" cells in x"""
 import os
 import sys
 import time
@@ -15,36 +19,55 @@ from adaflo_amd.level_set_okz_solver import LevelSetOKZSolver  # noqa: E402
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-    s = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-    fp = adaflo_amd.FlowParameters(
-        velocity_degree=2, density=1.0, density_diff=-0.9, viscosity=0.01, viscosity_diff=-0.009,
-        surface_tension=0.0245, gravity=0.98, epsilon=1.5, concentration_subdivisions=s,
-        interpolate_grad_onto_pressure=True, curvature_correction=True, time_step_size_start=0.02, end_time=3.0,
-        max_nl_iteration=10, tol_nl_iteration=1e-9, max_lin_iteration=200, tol_lin_iteration=1e-4)
+    args = sys.argv[1:]
+    if args and args[0] == "--prm":
+        with open(args[1]) as f:
+            fp = adaflo_amd.flow_parameters_from_prm(f.read())
+        fp.dimension = 3                                       # this engine is 3D: the case is extruded
+        n = 5 * 2 ** fp.global_refinements                    # rising_bubble.cc:125-133
+        steps = int(args[2]) if len(args) > 2 else 5
+    else:
+        n = int(args[0]) if len(args) > 0 else 16
+        s = int(args[1]) if len(args) > 1 else 4
+        steps = int(args[2]) if len(args) > 2 else 5
+        fp = adaflo_amd.FlowParameters(
+            velocity_degree=2, density=1.0, density_diff=-0.9, viscosity=0.01, viscosity_diff=-0.009,
+            surface_tension=0.0245, gravity=0.98, epsilon=1.5, concentration_subdivisions=s,
+            interpolate_grad_onto_pressure=True, curvature_correction=True, time_step_size_start=0.02, end_time=3.0,
+            max_nl_iteration=10, tol_nl_iteration=1e-9, max_lin_iteration=200, tol_lin_iteration=1e-4,
+            n_reinit_steps=2, n_initial_reinit_steps=2)
     mesh = adaflo_amd.BrickMesh([n, n, 2 * n], [0., 0., 0.], [1., 1., 2.])
     centre = np.array([0.5, 0.5, 0.5])
-    solver = LevelSetOKZSolver(fp, mesh, lambda x: np.linalg.norm(x - centre, axis=1) - 0.25)
+    solver = LevelSetOKZSolver(fp, mesh, lambda x: np.linalg.norm(x - centre, axis=1) - 0.25,
+                               n_reinit_steps=fp.n_reinit_steps, n_initial_reinit_steps=fp.n_initial_reinit_steps)
     m = solver.navier_stokes.navier_stokes_matrix
-    print("cells %d, dofs velocity/pressure/level set: %d / %d / %d" % (mesh.n_cells, m.n_dofs_u(), m.n_dofs_p(), solver.ops.n_dofs))
+    print("Number of active cells: %d." % mesh.n_cells)
+    print("Number of Navier-Stokes degrees of freedom: %d (%d + %d)." % (m.n_dofs_u() + m.n_dofs_p(), m.n_dofs_u(), m.n_dofs_p()))
+    print("Number of level set degrees of freedom: %d." % solver.ops.n_dofs)
+    print("  reinitialize (%s)" % " + ".join(str(i) for i in solver.initial_reinit_iterations))
     solver.ops.compute_heaviside(solver.heaviside, solver.solution, fp.epsilon)
     vol0, c0 = solver.bubble_volume_and_centre()
+    ts = solver.time_stepping
     for step in range(steps):
         import torch
         torch.cuda.synchronize()
         t0 = time.time()
-        solver.navier_stokes.history.clear()
-        solver.navier_stokes.linear_iterations.clear()
-        n_newton, n_linear = solver.advance_time_step()
-        torch.cuda.synchronize()
-        vol, c = solver.bubble_volume_and_centre()
         ns = solver.navier_stokes
-        umax = float(ns.solution[0].abs().max())
-        print("step %2d t=%.3f  advect %s  reinit %s  newton %d (lin %d)  res %.2e -> %.2e  z_c %.6f  vol %.6f (%+.2e)  |u|max %.3e  %.2f s"
-              % (step + 1, solver.time_stepping.now(), solver.concentration_iterations[-1][0], solver.reinit_iterations[-1],
-                 n_newton, n_linear, np.hypot(*ns.history[0]), np.hypot(*ns.history[-1]), c[2], vol, vol / vol0 - 1, umax,
-                 time.time() - t0), flush=True)
+        ns.history.clear()
+        ns.linear_iterations.clear()
+        solver.advance_time_step()
+        torch.cuda.synchronize()
+        wall = time.time() - t0
+        vol, c = solver.bubble_volume_and_centre()
+        print("\nTime step #%d, advancing from t_n-1 = %g to t = %g (dt = %g)." % (ts.step_no(), ts.previous(), ts.now(), ts.step_size()))
+        it, r0 = solver.concentration_iterations[-1]
+        print("  Concentration advance: advect [%.3g/%d] and reinitialize (%s)"
+              % (r0, it, " + ".join(str(i) for i in solver.reinit_iterations[-1])))
+        res = [float(np.hypot(*h)) for h in ns.history]
+        its = [i for i, _ in ns.linear_iterations]
+        print("  Residual/iterations: " + " ".join("[%.3g/%d]" % (r, i) for r, i in zip(res, its)) + " [%.3g/conv.]" % res[-1])
+        print("  Position of the center of mass:  %.8g  %.8g  %.8g" % tuple(c))
+        print("  (bubble volume drift %+.2e, |u|max %.3e, %.2f s wall)" % (vol / vol0 - 1, float(ns.solution[0].abs().max()), wall), flush=True)
 
 
 if __name__ == "__main__":
