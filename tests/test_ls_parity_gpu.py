@@ -166,3 +166,30 @@ def test_full_size_properties_config4():
     ay = d.numpy()
     ax = out[1][4]
     assert abs(y @ ax - x @ ay) < 1e-12 * np.linalg.norm(ax) * np.linalg.norm(y)
+
+
+@pytest.mark.parametrize("s,ncell,faces", [(4, (3, 2, 3), ()), (2, (5, 4, 9), (0, 3, 5))])
+def test_projection_matrix_and_curvature_correction(s, ncell, faces):
+    """adaflo_ls_projection_vmult = one scalar block of the normal operator (the assembled projection
+    matrix of level_set_okz.cc:262-312); adaflo_ls_curvature_correction = compute_curvature.cc:360-376"""
+    from adaflo_amd import _lib
+    c = LSCase(ncell, s, faces=faces)
+    lib, ctx = _lib.load(), c.ops._ctx
+    src = c.rand()
+    d = c.ops.vector(np.full(c.nn, 7.0))
+    _lib.check(ctx, lib.adaflo_ls_projection_vmult(ctx, d.ptr, c.ops.vector(src).ptr))
+    blocks = np.concatenate([src, np.zeros(2 * c.nn)])
+    ref = orc.ls_normal_vmult(c.mesh, c.prm, blocks, con=c.con, diag=c.diag)[:c.nn]
+    assert rel_l2(d.numpy(), ref) < TOL
+    # curvature correction: kappa > 1e-4 -> 1 / (1 / kappa + distance / 2), distance from the level set
+    kappa = c.rng.uniform(-3.0, 8.0, c.nn)
+    kappa[::5] = 5e-5
+    phi = np.tanh(c.rng.uniform(-4.0, 4.0, c.nn))
+    kv = c.ops.vector(kappa)
+    _lib.check(ctx, lib.adaflo_ls_curvature_correction(ctx, kv.ptr, c.ops.vector(phi).ptr))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dist = np.where(1 - phi * phi > 1e-2, c.eps_used * np.log((1 + phi) / (1 - phi)), 0.0)
+    expect = kappa.copy()
+    sel = kappa > 1e-4
+    expect[sel] = 1.0 / (1.0 / kappa[sel] + dist[sel] / 2.0)
+    assert np.abs(kv.numpy() - expect).max() < 1e-13 * max(1.0, np.abs(expect).max())
