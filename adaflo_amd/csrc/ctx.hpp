@@ -146,6 +146,11 @@ struct adaflo_ctx
   double  inv_p_weight = 0.;
   double *d_scratch    = nullptr; // reduction scratch (partials + result)
   double *h_result = nullptr, *h_result_dev = nullptr; // pinned host copy of reduction results + its device address
+  // operator kernels that can leave the partial sums of src . dst on the way (the stencil kernels):
+  // request (pointer + capacity in pairs) set by the CG driver, answer (pairs written, 0 = not done)
+  double *fused_dot_partial = nullptr;
+  long    fused_dot_capacity = 0;
+  int     fused_dot_count    = 0;
   size_t  scratch_count = 0;
 
   // matvec statistics (get_matvec_statistics) and dominant-kernel statistics

@@ -154,6 +154,7 @@ namespace adaflo_hip
       long        n, n_block;
       const double *inv_diag;
       Operator      A;
+      bool          fuse_dot = false; // A is ONE stencil launch that can leave the partials of src . dst
 
       double dot(const double *a, const double *b)
       {
@@ -546,10 +547,22 @@ namespace adaflo_hip
         [&](const int it) {
           if (it > 1)
             hipLaunchKernelGGL(cg_p_dev_kernel, dim3(nb), dim3(KT), 0, st, p, z, n, S); // p = z + beta p
-          if (int e = K.A(Ap, p))
-            return e;
-          hipLaunchKernelGGL(dot1_dev_kernel, dim3(nb), dim3(KT), 0, st, p, Ap, n, partial, S);
-          hipLaunchKernelGGL(kr_final_kernel, dim3(1), dim3(KT), 0, st, partial, (int)nb, S, H, (int)ST_CG_ALPHA, it);
+          // operators that compute p . A p on the way (stencil kernels) save the dot-product pass
+          K.ctx->fused_dot_partial  = K.fuse_dot ? partial : nullptr;
+          K.ctx->fused_dot_capacity = 32768;
+          K.ctx->fused_dot_count    = 0;
+          const int e_A             = K.A(Ap, p);
+          K.ctx->fused_dot_partial  = nullptr;
+          if (e_A)
+            return e_A;
+          int n_partial = K.ctx->fused_dot_count;
+          if (n_partial == 0)
+            {
+              hipLaunchKernelGGL(dot1_dev_kernel, dim3(nb), dim3(KT), 0, st, p, Ap, n, partial, S);
+              n_partial = (int)nb;
+            }
+          K.ctx->fused_dot_count = 0;
+          hipLaunchKernelGGL(kr_final_kernel, dim3(1), dim3(KT), 0, st, partial, n_partial, S, H, (int)ST_CG_ALPHA, it);
           hipLaunchKernelGGL(cg_update_dev_kernel, dim3(nb), dim3(KT), 0, st, x, r, z, p, Ap, K.inv_diag, K.n_block, n,
                              partial, S);
           hipLaunchKernelGGL(kr_final_kernel, dim3(1), dim3(KT), 0, st, partial, (int)nb, S, H, (int)ST_CG_UPDATE, it);
@@ -707,14 +720,17 @@ int adaflo_solve(adaflo_ctx *ctx, int op, int method, double *x, const double *b
       case ADAFLO_OP_LS_NORMAL:
         K.n_block = ctx->n_nodes_ls;
         blocks    = 3;
+        K.fuse_dot = true;
         K.A       = [ctx](double *d, const double *s) { return adaflo_ls_compute_normal_vmult(ctx, d, s); };
         break;
       case ADAFLO_OP_LS_CURVATURE:
         K.n_block = ctx->n_nodes_ls;
+        K.fuse_dot = true;
         K.A       = [ctx](double *d, const double *s) { return adaflo_ls_compute_curvature_vmult(ctx, d, s, 1); };
         break;
       case ADAFLO_OP_LS_PROJECTION:
         K.n_block = ctx->n_nodes_ls;
+        K.fuse_dot = true;
         K.A       = [ctx](double *d, const double *s) { return adaflo_ls_projection_vmult(ctx, d, s); };
         break;
       case ADAFLO_OP_NS_PRESSURE_MASS:

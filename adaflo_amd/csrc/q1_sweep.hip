@@ -583,6 +583,7 @@ namespace adaflo_hip
       uint32_t      con;
       const double *diag, *src;
       double       *dst;
+      double       *dot_partial; // optional: per block (sum of src_i dst_i, 0) for the CG driver (krylov.hip)
     };
 
     __global__ __launch_bounds__(256) void q1_stencil_kernel(const StencilArgs A)
@@ -640,7 +641,7 @@ namespace adaflo_hip
 
       const int  k0 = chunk * A.LZ, k1 = min(k0 + A.LZ, A.nnz);
       const bool conz_lo = A.con >> 4 & 1, conz_hi = A.con >> 5 & 1;
-      double     Am = 0., Bm = 0., A0, B0, Ap = 0., Bp = 0., c0, cp = 0., cm = 0.;
+      double     Am = 0., Bm = 0., A0, B0, Ap = 0., Bp = 0., c0, cp = 0., cm = 0., src_dot_dst = 0.;
       if (k0 > 0 && !(k0 - 1 == 0 && conz_lo))
         plane_sums(k0 - 1, Am, Bm, cm);
       plane_sums(k0, A0, B0, c0);
@@ -671,8 +672,25 @@ namespace adaflo_hip
               if (con_xy || conz)
                 r = (A.diag ? A.diag[idx] : A.con_sign) * c0;
               __builtin_nontemporal_store(r, dst_c + idx);
+              src_dot_dst += c0 * r;
             }
           Am = A0, Bm = B0, A0 = Ap, B0 = Bp, c0 = cp;
+        }
+      if (A.dot_partial) // p . A p of the CG iteration for free: the centre value is in a register anyway
+        {
+          __shared__ double red[4];
+          double            v = src_dot_dst;
+          for (int off = 32; off > 0; off >>= 1)
+            v += __shfl_down(v, off, 64);
+          if ((threadIdx.x & 63) == 0)
+            red[threadIdx.x >> 6] = v;
+          __syncthreads();
+          if (threadIdx.x == 0)
+            {
+              const long b = (long)blockIdx.y * gridDim.x + blockIdx.x;
+              A.dot_partial[2 * b]     = (red[0] + red[1]) + (red[2] + red[3]);
+              A.dot_partial[2 * b + 1] = 0.;
+            }
         }
     }
 
@@ -888,6 +906,14 @@ namespace adaflo_hip
         S.diag     = diag;
         S.src      = src;
         S.dst      = dst;
+        // a CG driver asks for src . dst through the context (krylov.hip): granted if the partials fit
+        const long n_partial = (long)S.blocks_per_plane * S.n_chunks * n_blocks;
+        ctx->fused_dot_count = 0;
+        if (ctx->fused_dot_partial && n_partial <= ctx->fused_dot_capacity)
+          {
+            S.dot_partial        = ctx->fused_dot_partial;
+            ctx->fused_dot_count = (int)n_partial;
+          }
         hipEvent_t stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
         hipLaunchKernelGGL(q1_stencil_kernel, dim3((unsigned)(S.blocks_per_plane * S.n_chunks), (unsigned)n_blocks),
                            dim3(256), 0, ctx->stream, S);

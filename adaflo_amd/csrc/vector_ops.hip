@@ -204,7 +204,7 @@ namespace adaflo_hip
   static int launch_dot(adaflo_ctx *ctx, const double *a, const double *b, const long n, const bool to_host = false)
   {
     const unsigned nb = grid_for(n, 4);
-    if (int e = ensure_scratch(ctx, 2 * 256 * 16 + 8)) // (the fused Krylov kernels leave two partials per block)
+    if (int e = ensure_scratch(ctx, 2 * 32768 + 8)) // (fused Krylov / stencil kernels leave two partials per block)
       return e;
     hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(VT), 0, ctx->stream, a, b, n,
                        ctx->d_scratch + 8);
