@@ -1,47 +1,27 @@
 """Generate the committed golden fixtures under tests/golden/.
 
-Two kinds of data:
-  * reference_outputs.json -- numbers transcribed from the reference's own test outputs
-    (tests/beltrami_3d.output, tests/rising_bubble_ls.output): DoF counts and nonlinear
-    residual norms.  These pin the oracle (tests/test_oracle_golden.py).
+Two kinds of data live there:
+  * reference_outputs.json -- numbers TRANSCRIBED BY HAND from the reference's own test outputs
+    (tests/beltrami_3d.output, tests/rising_bubble_ls{,_picard,_imex,_expl,_q3}.output,
+    tests/spurious_currents_ls.output): DoF counts, iteration counts and residual norms as printed.
+    They pin the oracle (tests/test_oracle_golden*.py).  Not written by this script.
   * *.npz -- seeded inputs and the outputs of the CPU oracle (oracle/adaflo_oracle.c) for small
-    meshes, every operator on the path.  They freeze the oracle against drift and let the HIP
-    engine be checked against data that does not depend on building the oracle at test time.
+    meshes, every operator on the path: written by this script.  They freeze the oracle against
+    drift and let the HIP engine be checked against data that does not depend on building the
+    oracle at test time.
 
-Run from the repo root:  python scripts/make_golden.py
+Run from the repo root:  python tests/golden/make_golden.py
 """
-import json
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import oracle as orc  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
-
-
-def reference_outputs():
-    return {
-        "_source": "transcribed from /root/reference/tests/*.output (data only)",
-        "beltrami_3d": {  # tests/beltrami_3d.output:1-3,13-15 ; tests/beltrami_3d.prm
-            "cells": 4096, "dofs_u": 107811, "dofs_p": 4913, "dt": 0.05, "viscosity": 1.0,
-            "first_step_residuals_u": ["2.590e+00"], "first_step_residuals_p": ["6.423e-02"],
-            # :31 first residual of time step #2 (after step #1 converged to 1e-9)
-            "second_step_residuals_u": ["2.348e+00"], "second_step_residuals_p": ["5.678e-02"]},
-        "rising_bubble_ls": {  # tests/rising_bubble_ls.output (2D): DoF counts of the three spaces
-            "cells": 3200, "dofs_u": 26082, "dofs_p": 3321, "dofs_ls": 51681,
-            # :5 "reinitialize (8 + 8)", :12 "reinitialize (7 + 7)", :13 "Residual/iterations: [0.0198/"
-            "initial_reinitialize_iterations": [8, 8], "step1_reinitialize_iterations": [7, 7],
-            "step1_first_residual": "0.0198",
-            # :11-29 per time step: "advect [res/its] and reinitialize (a + b)", "Residual/iterations: [res/"
-            "time_steps": [
-                {"advect_residual": "0", "advect_iterations": 0, "reinitialize_iterations": [7, 7], "first_residual": "0.0198"},
-                {"advect_residual": "0.000471", "advect_iterations": 9, "reinitialize_iterations": [11, 10], "first_residual": "0.00581"},
-                {"advect_residual": "0.00108", "advect_iterations": 10, "reinitialize_iterations": [11, 11], "first_residual": "0.000246"}]},
-    }
 
 
 def ns_case(name, ncell, k, lower, upper, linearization=0, physical_type=0, variable=False, seed=1):
@@ -121,8 +101,6 @@ def ls_case(name, ncell, s, k=2, seed=2):
 def main():
     orc.build()
     os.makedirs(OUT, exist_ok=True)
-    with open(os.path.join(OUT, "reference_outputs.json"), "w") as f:
-        json.dump(reference_outputs(), f, indent=1)
     names = [
         ns_case("ns_2d_q2_8x8_newton", (8, 8), 2, (-1., -1.), (1., 1.)),
         ns_case("ns_3d_q2_4x4x4_newton", (4, 4, 4), 2, (-1., -1., -1.), (1., 1., 1.)),

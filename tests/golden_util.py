@@ -1,4 +1,4 @@
-"""Loading of the committed fixtures under tests/golden/ (made by scripts/make_golden.py)."""
+"""Loading of the committed fixtures under tests/golden/ (made by tests/golden/make_golden.py)."""
 import glob
 import os
 
