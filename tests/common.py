@@ -87,3 +87,23 @@ class Case:
                                            constrained_faces_p=self.faces_p, device=device)
         op.initialize(self.ts, self.pressure_average_fix)
         return op
+
+
+def l2_norm_of_difference(mesh, k, dofs, ncomp, exact, n_gauss):
+    """VectorTools::integrate_difference(..., QGauss(n_gauss), L2_norm) for a nodal FE_Q(k) field on the
+    brick: sqrt(sum_cells sum_q |u_h(x_q) - exact(x_q)|^2 JxW)"""
+    xg, wg = orc.gauss_legendre(n_gauss)
+    S, _ = orc.shape_1d(0, k, xg)                      # [q][i]
+    nn = mesh.nodes_per_dim(k)
+    u = dofs.reshape(nn[2], nn[1], nn[0], ncomp)
+    n = [mesh.ncell[d] for d in range(3)]
+    h = [mesh.h[d] for d in range(3)]
+    # values at all Gauss points, cell by cell along each axis: [cz][qz][cy][qy][cx][qx][c]
+    idx = [np.arange(n[d])[:, None] * k + np.arange(k + 1)[None, :] for d in range(3)]
+    loc = u[idx[2][:, :, None, None, None, None], idx[1][None, None, :, :, None, None], idx[0][None, None, None, None, :, :]]
+    val = np.einsum("azbycxm,qz,ry,sx->aqbrcsm", loc, S, S, S)
+    axes = [mesh.origin[d] + h[d] * (np.arange(n[d])[:, None] + xg[None, :]) for d in range(3)]   # [cell][q]
+    Z, Y, X = np.meshgrid(axes[2].reshape(-1), axes[1].reshape(-1), axes[0].reshape(-1), indexing="ij")
+    ex = exact(np.stack([X.reshape(-1), Y.reshape(-1), Z.reshape(-1)], axis=1)).reshape(val.shape)
+    w = np.einsum("q,r,s->qrs", wg, wg, wg) * h[0] * h[1] * h[2]
+    return np.sqrt(np.einsum("aqbrcsm,qrs->", (val - ex) ** 2, w))

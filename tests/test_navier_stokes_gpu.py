@@ -58,3 +58,34 @@ def test_beltrami_three_time_steps_reproduce_the_reference_output():
     ns.compute_residual()
     assert "%.3e" % ns.history[0][0] == ref["third_step_residuals_u"][0]
     assert "%.3e" % ns.history[0][1] == ref["third_step_residuals_p"][0]
+
+
+def test_beltrami_velocity_errors_at_the_output_times_of_the_reference():
+    """tests/beltrami_3d.output:94-95,181-182,308-309,395-396,482-483 -- the whole run of the reference's test
+    (20 time steps to t = 1) on the device; the L2 error of the velocity against the exact solution, integrated as
+    tests/beltrami.cc:255-296 does, must print the reference's numbers at t = 0.2, 0.4, ..., 1.0.  (The pressure
+    errors of the reference contain the constant its Krylov solver happens to leave and are not comparable.)"""
+    from common import l2_norm_of_difference
+    from oracle import oracle as orc
+    with open(GOLDEN) as f:
+        ref = json.load(f)["beltrami_3d"]
+    nu = ref["viscosity"]
+    fp = adaflo_amd.FlowParameters(velocity_degree=2, viscosity=nu, time_step_size_start=ref["dt"], end_time=1.0,
+                                   max_nl_iteration=10, tol_nl_iteration=1e-9, max_lin_iteration=100, tol_lin_iteration=1e-5)
+    mesh = adaflo_amd.BrickMesh([16] * 3, [-1.0] * 3, [1.0] * 3)
+    omesh = orc.Mesh.make([16] * 3, [-1.0] * 3, [1.0] * 3)
+    ns = NavierStokes(fp, mesh, adaflo_amd.TimeStepping(fp), dirichlet_function=lambda x, t: beltrami.velocity(x, t, nu))
+    xu, xp = node_coordinates(mesh, 2), node_coordinates(mesh, 1)
+    ns.set_initial_condition(beltrami.velocity(xu, 0.0, nu).reshape(-1), beltrami.pressure(xp, 0.0, nu))
+    expected = ref["velocity_l2_errors_at_output_times"]
+    for step in range(1, 21):
+        ns.advance_time_step()
+        assert np.hypot(*ns.history[-1]) < 1e-9
+        key = "%.1f" % (0.05 * step)
+        if step % 4 == 0:
+            t = ns.time_stepping.now()
+            u = ns.solution[0].cpu().numpy()
+            err = l2_norm_of_difference(omesh, 2, u, 3, lambda x: beltrami.velocity(x, t, nu).reshape(-1), 4)
+            norm = l2_norm_of_difference(omesh, 2, u, 3, lambda x: np.zeros(3 * len(x)), 2)
+            assert "%.4g" % err == expected[key]["absolute"], (key, err)
+            assert "%.4g" % (err / norm) == expected[key]["relative"], (key, err / norm)
