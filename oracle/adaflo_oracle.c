@@ -30,6 +30,8 @@
  *                                 semi-implicit / explicit linearisations (0.000244 / 0.000245 / 0.000246)
  *   tests/rising_bubble_ls_q3.output:2-30   Q3/Q2 elements (0.0261, 0.00764, 0.000257)
  *   tests/spurious_currents_ls.output:2-25  static bubble, constant coefficients (0.365, 0.00024, 0.00014)
+ *   ... and, for the five rising-bubble outputs, the 8-digit bubble statistics of the CONVERGED solutions
+ *   (circularity, mean bubble velocity, centre of mass; oracle/two_phase_oracle.py::bubble_statistics_2d)
  * deal.II cannot be built here (needs cmake + Trilinos + p4est, none present): the reference
  * build is "unbuildable", see DESIGN.md.
  *

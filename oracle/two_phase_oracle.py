@@ -237,3 +237,92 @@ class RisingBubble:
             self.u += d[:nu]
             self.p += d[nu:]
         return (adv_r0, adv_it), rei_its, history
+
+
+def bubble_statistics_2d(sim):
+    """TwoPhaseBaseAlgorithm<2>::compute_bubble_statistics (source/two_phase_base.cc:621-905): area, perimeter,
+    circularity, mean velocity and centre of mass of the region phi > 0, with the interface located by linear
+    interpolation on a (k+3) x (k+3) trapezoidal sub-grid of every cut cell -- the numbers the reference prints
+    after every time step ("Degree of circularity", "Mean bubble velocity", "Position of the center of mass").
+    Returns (circularity, mean velocity[2], centre[2], area)."""
+    assert sim.dim == 2
+    mesh, s, k = sim.mesh, sim.s, sim.k
+    ncx, ncy = sim.ncell
+    hx, hy = mesh.h[0], mesh.h[1]
+    sub = k + 3
+    pts = np.linspace(0.0, 1.0, sub + 1)                               # QIterated(QTrapezoid, k + 3)
+    Sl, _ = orc.shape_1d(1, s, pts)                                     # [point][dof], FE_Q_iso_Q1(s)
+    Sv, _ = orc.shape_1d(0, k, pts)
+    xg, wg = orc.gauss_legendre(k)                                      # interior_quadrature = QGauss(k)
+    Sg, _ = orc.shape_1d(0, k, xg)
+    nls = [s * ncx + 1, s * ncy + 1]
+    nvs = [k * ncx + 1, k * ncy + 1]
+    phi = sim.phi.reshape(nls[1], nls[0])
+    vel = sim.u.reshape(nvs[1], nvs[0], 2)
+    area = perimeter = 0.0
+    com, velocity = np.zeros(2), np.zeros(2)
+    for cy in range(ncy):
+        for cx in range(ncx):
+            loc = phi[s * cy:s * cy + s + 1, s * cx:s * cx + s + 1]
+            lv = vel[k * cy:k * cy + k + 1, k * cx:k * cx + k + 1]
+            x0, y0 = mesh.origin[0] + hx * cx, mesh.origin[1] + hy * cy
+            flat = loc.reshape(-1)
+            if not np.any(flat[1:] * flat[0] <= 0):                     # :668-690 the interface does not cross the cell
+                if flat[0] > 0:
+                    ug = np.einsum("qj,pi,jic->qpc", Sg, Sg, lv)        # [qy][qx][c]
+                    w = np.outer(wg, wg) * hx * hy
+                    area += w.sum()
+                    com += [np.sum(w * (x0 + hx * xg)[None, :]), np.sum(w * (y0 + hy * xg)[:, None])]
+                    velocity += np.einsum("qp,qpc->c", w, ug)
+                continue
+            cval = Sl @ loc @ Sl.T                                      # [py][px]
+            uval = np.einsum("qj,pi,jic->qpc", Sv, Sv, lv)
+            wsub = hx * hy / (sub * sub) / 4.0                          # JxW * weight_correction of a patch corner
+            for dy in range(sub):
+                for dx in range(sub):
+                    idx = [(dy, dx), (dy, dx + 1), (dy + 1, dx), (dy + 1, dx + 1)]
+                    c = np.array([cval[i] for i in idx]) + 1e-22
+                    quad = np.array([[x0 + hx * pts[i[1]], y0 + hy * pts[i[0]]] for i in idx])
+                    local_area = 1.0
+                    rx0 = rx1 = ry0 = ry1 = -1.0
+                    px0 = px1 = py0 = py1 = None
+                    if c[0] * c[1] <= 0:
+                        rx0 = c[0] / (c[0] - c[1])
+                        px0 = quad[0] + (quad[1] - quad[0]) * rx0
+                    if c[2] * c[3] <= 0:
+                        rx1 = c[2] / (c[2] - c[3])
+                        px1 = quad[2] + (quad[3] - quad[2]) * rx1
+                    if c[0] * c[2] <= 0:
+                        ry0 = c[0] / (c[0] - c[2])
+                        py0 = quad[0] + (quad[2] - quad[0]) * ry0
+                    if c[1] * c[3] <= 0:
+                        ry1 = c[1] / (c[1] - c[3])
+                        py1 = quad[1] + (quad[3] - quad[1]) * ry1
+
+                    def cut(my_area, corner, a, b):
+                        nonlocal local_area, perimeter
+                        local_area -= my_area if corner < 0 else 1 - my_area
+                        perimeter += np.linalg.norm(a - b)
+                    if rx0 > 0:
+                        if ry0 > 0:
+                            cut(0.5 * rx0 * ry0, c[0], px0, py0)
+                        if ry1 > 0:
+                            cut(0.5 * (1 - rx0) * ry1, c[1], px0, py1)
+                        if rx1 > 0 and ry0 < 0 and ry1 < 0:
+                            cut(0.5 * (rx0 + rx1), c[0], px0, px1)
+                    if rx1 > 0:
+                        if ry0 > 0:
+                            cut(0.5 * rx1 * (1 - ry0), c[2], px1, py0)
+                        if ry1 > 0:
+                            cut(0.5 * (1 - rx1) * (1 - ry1), c[3], px1, py1)
+                    if ry0 > 0 and ry1 > 0 and rx0 < 0 and rx1 < 0:
+                        cut(0.5 * (ry0 + ry1), c[0], py0, py1)
+                    if rx0 <= 0 and rx1 <= 0 and ry0 <= 0 and ry1 <= 0 and c[0] <= 0:
+                        local_area = 0.0
+                    my_area = local_area * wsub
+                    for n, i in enumerate(idx):
+                        area += my_area
+                        com += quad[n] * my_area
+                        velocity += uval[i] * my_area
+    circularity = 2.0 * np.sqrt(area * np.pi) / perimeter
+    return circularity, velocity / area, com / area, area

@@ -29,6 +29,21 @@ from oracle import oracle as orc
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_outputs.json")
 
 
+def check_bubble_statistics(sim, expected, initial=None):
+    """"Degree of circularity", "Mean bubble velocity", "Position of the center of mass" (8 digits) of the
+    reference output against oracle/two_phase_oracle.py::bubble_statistics_2d on the oracle's CONVERGED solution
+    of the step: pins the two-phase Navier-Stokes solution itself, not only the start-of-step residuals.
+    One unit of the last printed digit is allowed (the reference stops its nonlinear iteration at ~4e-10)."""
+    from oracle import two_phase_oracle as tpo
+    circ, vel, centre, _ = tpo.bubble_statistics_2d(sim)
+    if initial is not None:
+        assert "%.8f" % circ == initial
+        return
+    assert abs(circ - float(expected["circularity"])) < 1.5e-8
+    assert abs(vel[0]) < 1e-7 * abs(vel[1]) and abs(vel[1] - float(expected["mean_bubble_velocity_y"])) < 1.5e-9
+    assert abs(centre[0] - 0.5) < 1e-9 and abs(centre[1] - float(expected["centre_of_mass_y"])) < 1.5e-8
+
+
 def test_rising_bubble_initial_reinitialisation_and_first_force():
     with open(GOLDEN) as f:
         ref = json.load(f)["rising_bubble_ls"]
@@ -115,6 +130,7 @@ def test_rising_bubble_three_time_steps_match_the_reference_output():
     with threadpool_limits(limits=1, user_api="blas"):
         sim = tpo.RisingBubble(lambda: adaflo_amd.TimeStepping(fp))
         assert sim.log["initial_reinitialize"] == ref["initial_reinitialize_iterations"]
+        check_bubble_statistics(sim, None, initial=ref["initial_circularity"])
         for expected in ref["time_steps"]:
             (adv_r0, adv_it), rei_its, history = sim.advance_time_step()
             assert adv_it == expected["advect_iterations"]
@@ -125,6 +141,7 @@ def test_rising_bubble_three_time_steps_match_the_reference_output():
             assert rei_its == expected["reinitialize_iterations"]
             assert "%.3g" % history[0] == expected["first_residual"]
             assert history[-1] < 1e-9 and len(history) <= 4         # Newton on the exact Jacobian
+            check_bubble_statistics(sim, expected)
 
 
 @pytest.mark.parametrize("case,lin", [("rising_bubble_ls_picard", 1), ("rising_bubble_ls_imex", 2), ("rising_bubble_ls_expl", 3)])
@@ -155,6 +172,7 @@ def test_rising_bubble_other_linearisations_match_their_reference_outputs(case, 
             assert rei_its == expected["reinitialize_iterations"]
             assert "%.3g" % history[0] == expected["first_residual"]
             assert history[-1] < 1e-9
+            check_bubble_statistics(sim, expected)
     if "step3_second_residual" in ref:        # Picard: even the second residual of step #3 agrees to two digits
         assert abs(history[1] - float(ref["step3_second_residual"])) < 0.05 * history[1]
 
@@ -184,6 +202,7 @@ def test_rising_bubble_q3_q2_matches_its_reference_output():
             assert rei_its == expected["reinitialize_iterations"]
             assert "%.3g" % history[0] == expected["first_residual"]
             assert history[-1] < 1e-9 and len(history) <= 4
+            check_bubble_statistics(sim, expected)
 
 
 def test_spurious_currents_matches_its_reference_output():
