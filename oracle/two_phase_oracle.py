@@ -326,3 +326,52 @@ def bubble_statistics_2d(sim):
                         velocity += uval[i] * my_area
     circularity = 2.0 * np.sqrt(area * np.pi) / perimeter
     return circularity, velocity / area, com / area, area
+
+
+def spurious_current_statistics_2d(sim):
+    """tests/spurious_currents.cc:121-222 -- what the reference prints after every step of the static-bubble test:
+    the relative error of the pressure jump in per cent, ((mean p over the cells whose centre is closer than 0.1 to the
+    origin) - (mean p over the boundary) - 2 (dim - 1) sigma) / (2 (dim - 1) sigma) * 100 with QGauss(k+1), and the
+    largest velocity magnitude over the QIterated(QTrapezoid, k+2) points of all cells."""
+    assert sim.dim == 2
+    mesh, k = sim.mesh, sim.k
+    ncx, ncy = sim.ncell
+    hx, hy = mesh.h[0], mesh.h[1]
+    sigma = sim.physics["surface_tension"]
+    # largest velocity
+    pts = np.linspace(0.0, 1.0, k + 3)
+    Sv, _ = orc.shape_1d(0, k, pts)
+    nvx, nvy = k * ncx + 1, k * ncy + 1
+    vel = sim.u.reshape(nvy, nvx, 2)
+    ix = (np.arange(ncx)[:, None] * k + np.arange(k + 1)[None, :])
+    iy = (np.arange(ncy)[:, None] * k + np.arange(k + 1)[None, :])
+    loc = vel[iy[:, :, None, None], ix[None, None, :, :]]                  # [cy][j][cx][i][c]
+    uq = np.einsum("ajbic,qj,pi->aqbpc", loc, Sv, Sv)
+    size = float(np.sqrt((uq ** 2).sum(axis=-1)).max())
+    # pressure jump
+    xg, wg = orc.gauss_legendre(k + 1)
+    Sp, _ = orc.shape_1d(0, k - 1, xg)
+    npx, npy = (k - 1) * ncx + 1, (k - 1) * ncy + 1
+    pr = sim.p.reshape(npy, npx)
+    kp = k - 1
+    p_avg = one_avg = p_b = one_b = 0.0
+    ends = {0: orc.shape_1d(0, kp, np.array([0.0]))[0][0], 1: orc.shape_1d(0, kp, np.array([1.0]))[0][0]}
+    for cy in range(ncy):
+        for cx in range(ncx):
+            cxm, cym = mesh.origin[0] + hx * (cx + 0.5), mesh.origin[1] + hy * (cy + 0.5)
+            lp = pr[kp * cy:kp * cy + kp + 1, kp * cx:kp * cx + kp + 1]        # [j][i]
+            if np.hypot(cxm, cym) < 0.1:
+                pq = Sp @ lp @ Sp.T
+                w = np.outer(wg, wg) * hx * hy
+                p_avg += float((pq * w).sum())
+                one_avg += float(w.sum())
+            for side, on_boundary, along, length in ((0, cx == 0, "y", hy), (1, cx == ncx - 1, "y", hy),
+                                                     (0, cy == 0, "x", hx), (1, cy == ncy - 1, "x", hx)):
+                if not on_boundary:
+                    continue
+                face = (lp @ ends[side]) if along == "y" else (ends[side] @ lp)    # dofs along the face
+                pf = Sp @ face
+                p_b += float((pf * wg).sum() * length)
+                one_b += length
+    jump = ((p_avg / one_avg - p_b / one_b) - 2.0 * (sim.dim - 1) * sigma) / (2.0 * (sim.dim - 1) * sigma) * 100.0
+    return jump, size

@@ -230,3 +230,9 @@ def test_spurious_currents_matches_its_reference_output():
             assert rei_its == expected["reinitialize_iterations"]
             assert "%.3g" % history[0] == expected["first_residual"]
             assert history[-1] < 1e-9
+            # converged pressure and velocity (tests/spurious_currents.cc:121-222): the error of the pressure jump across
+            # the interface and the largest parasitic velocity.  Both are tiny differences of the solution and the
+            # reference stops its Newton iteration at ~4e-10, so 6-7 of the printed 8 digits agree
+            jump, size = tpo.spurious_current_statistics_2d(sim)
+            assert abs(jump - float(expected["pressure_jump_error_percent"])) < 1e-6
+            assert abs(size - float(expected["size_spurious_currents"])) < 1e-6 * size
