@@ -85,6 +85,12 @@ def test_device_time_steps_equal_the_oracle_time_steps_in_3d(linearization, lin,
             assert dev.reinit_iterations[-1] == rei_its, (step, dev.reinit_iterations[-1], rei_its)
             first = float(np.hypot(*dev.navier_stokes.history[0]))
             assert abs(first - history[0]) < 1e-6 * history[0], (step, first, history[0])
+            # the converged flow of the step (the oracle's solutions are pinned to the reference's printed bubble
+            # statistics in 2D): velocity, and pressure up to its constant
+            u_dev = dev.navier_stokes.solution[0].cpu().numpy()
+            p_dev = dev.navier_stokes.solution[1].cpu().numpy()
+            assert rel(u_dev, ref.u) < 1e-5, (step, rel(u_dev, ref.u))
+            assert rel(p_dev - p_dev.mean(), ref.p - ref.p.mean()) < 1e-5, (step,)
     assert rel(dev.solution.numpy(), ref.phi) < 1e-6
 
 
