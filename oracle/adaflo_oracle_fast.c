@@ -67,6 +67,17 @@ static void apply_dir(const double *M, int nq, int nd, int transpose, int dir, c
       }
 }
 
+/* number of OpenMP threads of the following calls (the caller knows the CPU quota of its container) */
+void orc_fast_set_threads(int n)
+{
+#ifdef _OPENMP
+  if (n > 0)
+    omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int orc_fast_n_threads(void)
 {
 #ifdef _OPENMP

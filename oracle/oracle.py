@@ -88,6 +88,7 @@ def lib():
     if _lib is None:
         _lib = C.CDLL(build())
         _lib.orc_n_nodes.restype = C.c_long
+        _lib.orc_fast_set_threads(usable_cores())      # OpenMP threads = CPU quota of the container
     return _lib
 
 
@@ -319,6 +320,30 @@ def beltrami_p(xyz, t, nu=1.0):
 # ----------------------------------------------------------------------------- fast CPU baseline
 def fast_n_threads():
     return int(lib().orc_fast_n_threads())
+
+
+def usable_cores():
+    """cores this process may really use: scheduler affinity capped by the cgroup CPU quota (a container
+    that sees 256 cores may be allowed 16; 128 OpenMP threads then run three times slower than 16)"""
+    import os
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def fast_set_threads(n):
+    lib().orc_fast_set_threads(int(n))
 
 
 def fast_ns_vmult(mesh, k, prm, src_u, src_p, con_u=None, con_p=None, lin=None, rho=None, mu=None,
