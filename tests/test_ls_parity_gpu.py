@@ -41,7 +41,8 @@ class LSCase:
 @pytest.mark.parametrize("variant", [1, 0])
 @pytest.mark.parametrize("s,ncell,faces", [(4, (2, 3, 2), ()), (2, (3, 3, 4), (0, 5)), (1, (4, 4, 4), ()),
                                            (3, (2, 2, 2), (2,)), (4, (5, 9, 3), (1, 2, 4)),
-                                           (2, (9, 8, 20), (0, 1, 2, 3, 4, 5)), (1, (33, 17, 40), (3,))])
+                                           (2, (9, 8, 20), (0, 1, 2, 3, 4, 5)), (1, (33, 17, 40), (3,)),
+                                           (1, (1, 1, 1), ()), (2, (1, 2, 1), (0, 5)), (4, (1, 1, 2), ())])
 def test_ls_operator_applications(s, ncell, faces, variant):
     """variant 1: structured Q1 sweep kernel (multi-tile, partial tiles, z-chunks in the larger
     cases); variant 0: generic per-cell kernels"""
@@ -78,7 +79,7 @@ def test_ls_operator_applications(s, ncell, faces, variant):
 
 @pytest.mark.parametrize("variant", [1, 0])
 @pytest.mark.parametrize("s,ncell,faces", [(4, (2, 2, 3), ()), (2, (3, 4, 3), ()), (2, (9, 5, 20), (0, 3, 4, 5)),
-                                           (1, (20, 17, 35), (1,))])
+                                           (1, (20, 17, 35), (1,)), (1, (1, 1, 1), ()), (2, (1, 2, 1), (2,))])
 def test_ls_right_hand_sides(s, ncell, faces, variant):
     """variant 1: normal / curvature right-hand sides as tensor-product stencils (multi-block planes,
     several z-chunks in the larger cases); variant 0: generic per-cell kernels"""
