@@ -169,7 +169,8 @@ def test_matvec_statistics_and_errors():
 
 
 # ----------------------------------------------------------------------------- Q2/Q1 sweep kernel
-@pytest.mark.parametrize("ncell", [(8, 8, 4), (5, 3, 2), (16, 8, 9), (9, 17, 5), (24, 16, 20), (16, 10, 6), (10, 16, 7), (17, 9, 33)])
+@pytest.mark.parametrize("ncell", [(8, 8, 4), (5, 3, 2), (16, 8, 9), (9, 17, 5), (24, 16, 20), (16, 10, 6), (10, 16, 7), (17, 9, 33),
+                                   (1, 1, 1), (1, 2, 1), (2, 1, 3), (1, 1, 40)])
 def test_vmult_q2_kernel_newton(ncell):
     case = Case(ncell, k=2, upper=(1.0, 0.5, 2.0))
     eu, ep = run_vmult(case, variant=1)
