@@ -586,21 +586,33 @@ namespace adaflo_hip
       double       *dot_partial; // optional: per block (sum of src_i dst_i, 0) for the CG driver (krylov.hip)
     };
 
+    // Workgroup = 64 x 8 nodes of a plane (4 waves, two rows per thread), marching LZ planes in z.  A
+    // plane of src is staged through LDS with its one-node halo (66 x 10 values, 1.29 global loads per
+    // node) and the nine in-plane neighbours come from LDS: a probe kernel with the same marching
+    // pattern moves 7.5 / 5.8 / 2.9 TB/s with 1 / 3 / 9 global loads per node
+    // (scripts/dev/march_copy.hip) -- the texture path, not HBM, bounded the first version, which
+    // loaded all nine neighbours from global memory (33.9 M nodes: 0.215 ms; one row per thread
+    // 0.182 ms; two rows 0.158 ms; four rows 0.188 ms).
+    constexpr int STX = 64, STW = 4, STR = 2, STY = STW * STR; // 4 waves x STR rows per thread
+    constexpr int SHX = STX + 2, SHY = STY + 2, SHN = SHX * SHY, SLD = (SHN + 255) / 256;
     __global__ __launch_bounds__(256) void q1_stencil_kernel(const StencilArgs A)
     {
+      __shared__ double tile[2][SHN];
       const long nwg   = (long)A.blocks_per_plane * A.n_chunks;
       const long wg    = xcd_remap(blockIdx.x, nwg);
       const int  chunk = (int)(wg / A.blocks_per_plane);
-      const long p_raw = (wg % A.blocks_per_plane) * 256 + threadIdx.x;
-      const bool active = p_raw < A.plane;
-      const long p      = active ? p_raw : A.plane - 1;
-      const int  i = (int)(p % A.nnx), j = (int)(p / A.nnx);
-      const double *src_c = A.src + blockIdx.y * A.comp_stride;
-      double       *dst_c = A.dst + blockIdx.y * A.comp_stride;
+      const int  tiles_x = (A.nnx + STX - 1) / STX;
+      const int  bt = (int)(wg % A.blocks_per_plane), bx = bt % tiles_x, by = bt / tiles_x;
+      const int  tx = threadIdx.x % STX, ty = threadIdx.x / STX;
+      const int  i0 = bx * STX, j0 = by * STY;
+      const int  i_raw = i0 + tx;
+      const int  i     = min(i_raw, A.nnx - 1);
+      const double *__restrict__ src_c = A.src + blockIdx.y * A.comp_stride;
+      double *__restrict__       dst_c = A.dst + blockIdx.y * A.comp_stride;
 
       // 1D rows of M and K at this node; a neighbour outside the mesh or on a constrained face
       // contributes nothing
-      auto rows = [&](const int d, const int idx, const int n, double *m, double *k, long *off, const long stride) {
+      auto rows = [&](const int d, const int idx, const int n, double *m, double *k) {
         const bool lo = idx > 0, hi = idx < n - 1;
         const bool clo = lo && !(idx - 1 == 0 && (A.con >> (2 * d) & 1));
         const bool chi = hi && !(idx + 1 == n - 1 && (A.con >> (2 * d + 1) & 1));
@@ -610,71 +622,133 @@ namespace adaflo_hip
         k[0] = clo ? A.k_off[d] : 0.;
         k[2] = chi ? A.k_off[d] : 0.;
         k[1] = ((lo ? 1. : 0.) + (hi ? 1. : 0.)) * A.k_ctr[d];
-        off[0] = lo ? -stride : 0;
-        off[1] = 0;
-        off[2] = hi ? stride : 0;
       };
-      double mx[3], kx[3], my[3], ky[3];
-      long   ox[3], oy[3];
-      rows(0, i, A.nnx, mx, kx, ox, 1);
-      rows(1, j, A.nny, my, ky, oy, A.nnx);
-      const bool con_xy = (i == 0 && (A.con >> 0 & 1)) || (i == A.nnx - 1 && (A.con >> 1 & 1)) ||
-                          (j == 0 && (A.con >> 2 & 1)) || (j == A.nny - 1 && (A.con >> 3 & 1));
+      double mx[3], kx[3], my[STR][3], ky[STR][3];
+      bool   active[STR], con_xy[STR];
+      long   p[STR];
+      int    lc[STR]; // this thread's nodes in the halo tile
+      rows(0, i, A.nnx, mx, kx);
+#pragma unroll
+      for (int r = 0; r < STR; ++r)
+        {
+          const int j_raw = j0 + ty + STW * r, j = min(j_raw, A.nny - 1);
+          rows(1, j, A.nny, my[r], ky[r]);
+          active[r] = i_raw < A.nnx && j_raw < A.nny;
+          p[r]      = (long)j * A.nnx + i;
+          lc[r]     = (ty + STW * r + 1) * SHX + tx + 1;
+          con_xy[r] = (i == 0 && (A.con >> 0 & 1)) || (i == A.nnx - 1 && (A.con >> 1 & 1)) ||
+                      (j == 0 && (A.con >> 2 & 1)) || (j == A.nny - 1 && (A.con >> 3 & 1));
+        }
       // (rows of constrained nodes are overwritten below, so their own weights do not matter)
 
-      auto plane_sums = [&](const int k, double &Ap, double &Bp, double &centre) {
-        const double *s = src_c + (long)k * A.plane + p;
-        double        a[3], b[3];
+      // the halo-tile entries this thread stages per plane; out-of-mesh entries are zero
+      long g_off[SLD];
+      int  l_off[SLD];
+      bool g_ok[SLD];
+#pragma unroll
+      for (int r = 0; r < SLD; ++r)
+        {
+          const int e = threadIdx.x + 256 * r;
+          const int hx = e % SHX, hy = e / SHX, gi = i0 - 1 + hx, gj = j0 - 1 + hy;
+          l_off[r] = e < SHN ? e : -1;
+          g_ok[r]  = e < SHN && gi >= 0 && gi < A.nnx && gj >= 0 && gj < A.nny;
+          g_off[r] = g_ok[r] ? (long)gj * A.nnx + gi : 0;
+        }
+      auto stage = [&](const int k, double *buf) {
+        const double *s = src_c + (long)k * A.plane;
+        double        v[SLD];
+#pragma unroll
+        for (int r = 0; r < SLD; ++r)
+          v[r] = g_ok[r] ? s[g_off[r]] : 0.;
+#pragma unroll
+        for (int r = 0; r < SLD; ++r)
+          if (l_off[r] >= 0)
+            buf[l_off[r]] = v[r];
+      };
+      auto plane_sums = [&](const double *buf, const int r, double &Ap, double &Bp, double &centre) {
+        double a[3], b[3];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
           {
-            const double *r  = s + oy[dy];
-            const double  v0 = r[ox[0]], v1 = r[0], v2 = r[ox[2]];
+            const double *q  = buf + lc[r] + (dy - 1) * SHX;
+            const double  v0 = q[-1], v1 = q[0], v2 = q[1];
             a[dy] = mx[0] * v0 + mx[1] * v1 + mx[2] * v2;
             b[dy] = kx[0] * v0 + kx[1] * v1 + kx[2] * v2;
             if (dy == 1)
               centre = v1;
           }
-        Ap = my[0] * a[0] + my[1] * a[1] + my[2] * a[2];
-        Bp = my[0] * b[0] + my[1] * b[1] + my[2] * b[2] + ky[0] * a[0] + ky[1] * a[1] + ky[2] * a[2];
+        Ap = my[r][0] * a[0] + my[r][1] * a[1] + my[r][2] * a[2];
+        Bp = my[r][0] * b[0] + my[r][1] * b[1] + my[r][2] * b[2] + ky[r][0] * a[0] + ky[r][1] * a[1] + ky[r][2] * a[2];
       };
 
       const int  k0 = chunk * A.LZ, k1 = min(k0 + A.LZ, A.nnz);
       const bool conz_lo = A.con >> 4 & 1, conz_hi = A.con >> 5 & 1;
-      double     Am = 0., Bm = 0., A0, B0, Ap = 0., Bp = 0., c0, cp = 0., cm = 0., src_dot_dst = 0.;
-      if (k0 > 0 && !(k0 - 1 == 0 && conz_lo))
-        plane_sums(k0 - 1, Am, Bm, cm);
-      plane_sums(k0, A0, B0, c0);
-      if (k0 == 0 && conz_lo)
-        A0 = B0 = 0.;
+      double     Am[STR], Bm[STR], A0[STR], B0[STR], Ap[STR], Bp[STR], c0[STR], cp[STR], cm, src_dot_dst = 0.;
+#pragma unroll
+      for (int r = 0; r < STR; ++r)
+        Am[r] = Bm[r] = Ap[r] = Bp[r] = cp[r] = 0.;
+      int cur = 0;
+      if (k0 > 0) // (block-uniform)
+        {
+          stage(k0 - 1, tile[cur]);
+          __syncthreads();
+          if (!(k0 - 1 == 0 && conz_lo))
+#pragma unroll
+            for (int r = 0; r < STR; ++r)
+              plane_sums(tile[cur], r, Am[r], Bm[r], cm);
+          cur ^= 1;
+        }
+      stage(k0, tile[cur]);
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < STR; ++r)
+        {
+          plane_sums(tile[cur], r, A0[r], B0[r], c0[r]);
+          if (k0 == 0 && conz_lo)
+            A0[r] = B0[r] = 0.;
+        }
+      cur ^= 1;
       for (int k = k0; k < k1; ++k)
         {
           const bool hi = k < A.nnz - 1, lo = k > 0;
           if (hi)
             {
-              plane_sums(k + 1, Ap, Bp, cp);
-              if (k + 1 == A.nnz - 1 && conz_hi)
-                Ap = Bp = 0.;
+              stage(k + 1, tile[cur]);
+              __syncthreads();
+#pragma unroll
+              for (int r = 0; r < STR; ++r)
+                {
+                  plane_sums(tile[cur], r, Ap[r], Bp[r], cp[r]);
+                  if (k + 1 == A.nnz - 1 && conz_hi)
+                    Ap[r] = Bp[r] = 0.;
+                }
+              cur ^= 1;
             }
           else
-            Ap = Bp = 0.;
+#pragma unroll
+            for (int r = 0; r < STR; ++r)
+              Ap[r] = Bp[r] = 0.;
           const double nz  = (lo ? 1. : 0.) + (hi ? 1. : 0.);
           const double mzc = nz * A.m_ctr[2], kzc = nz * A.k_ctr[2];
           const double mzl = lo ? A.m_off[2] : 0., mzh = hi ? A.m_off[2] : 0.;
           const double kzl = lo ? A.k_off[2] : 0., kzh = hi ? A.k_off[2] : 0.;
-          double       r   = (A.c_mass * mzl + A.c_lap * kzl) * Am + A.c_lap * mzl * Bm;
-          r += (A.c_mass * mzc + A.c_lap * kzc) * A0 + A.c_lap * mzc * B0;
-          r += (A.c_mass * mzh + A.c_lap * kzh) * Ap + A.c_lap * mzh * Bp;
-          const bool conz = (k == 0 && conz_lo) || (k == A.nnz - 1 && conz_hi);
-          if (active)
+          const bool   conz = (k == 0 && conz_lo) || (k == A.nnz - 1 && conz_hi);
+#pragma unroll
+          for (int r = 0; r < STR; ++r)
             {
-              const long idx = (long)k * A.plane + p;
-              if (con_xy || conz)
-                r = (A.diag ? A.diag[idx] : A.con_sign) * c0;
-              __builtin_nontemporal_store(r, dst_c + idx);
-              src_dot_dst += c0 * r;
+              double v = (A.c_mass * mzl + A.c_lap * kzl) * Am[r] + A.c_lap * mzl * Bm[r];
+              v += (A.c_mass * mzc + A.c_lap * kzc) * A0[r] + A.c_lap * mzc * B0[r];
+              v += (A.c_mass * mzh + A.c_lap * kzh) * Ap[r] + A.c_lap * mzh * Bp[r];
+              if (active[r])
+                {
+                  const long idx = (long)k * A.plane + p[r];
+                  if (con_xy[r] || conz)
+                    v = (A.diag ? A.diag[idx] : A.con_sign) * c0[r];
+                  __builtin_nontemporal_store(v, dst_c + idx);
+                  src_dot_dst += c0[r] * v;
+                }
+              Am[r] = A0[r], Bm[r] = B0[r], A0[r] = Ap[r], B0[r] = Bp[r], c0[r] = cp[r];
             }
-          Am = A0, Bm = B0, A0 = Ap, B0 = Bp, c0 = cp;
         }
       if (A.dot_partial) // p . A p of the CG iteration for free: the centre value is in a register anyway
         {
@@ -885,7 +959,7 @@ namespace adaflo_hip
         S.nnz = sub * ctx->desc.ncell[2] + 1;
         S.plane            = (long)S.nnx * S.nny;
         S.comp_stride      = S.plane * S.nnz;
-        S.blocks_per_plane = (int)((S.plane + 255) / 256);
+        S.blocks_per_plane = ((S.nnx + STX - 1) / STX) * ((S.nny + STY - 1) / STY); // 64 x 4 node tiles
         int lz = 32;
         while (lz > 4 && (long)S.blocks_per_plane * ((S.nnz + lz - 1) / lz) < 2048)
           lz /= 2;
