@@ -8,6 +8,7 @@ class TimeStepping:
         self.start_val = p.start_time
         self.final_val = p.end_time
         self.scheme = p.time_step_scheme
+        self.start_step_val = p.time_step_size_start
         self.max_step_val = p.time_step_size_max
         self.min_step_val = p.time_step_size_min
         self.current_step_val = p.time_step_size_start
@@ -45,6 +46,34 @@ class TimeStepping:
     def set_time_step(self, value):
         self.current_step_val = value
         self.step_val = value
+
+    def set_desired_time_step(self, desired_value):
+        """source/time_stepping.cc:247-268: at most a factor 2 away from the previous step size and within
+        [min step size, max step size]"""
+        prev = desired_value if self.now_val == 0 else self.current_step_val
+        step = min(2 * prev, max(desired_value, 0.5 * prev))
+        self.current_step_val = min(self.max_step_val, max(self.min_step_val, step))
+        self.step_val = self.current_step_val
+
+    def restart(self):
+        """source/time_stepping.cc:104-119"""
+        self.step_no_val = 0
+        self.now_val = self.start_val
+        self.step_val = self.start_step_val
+        self.current_step_val = self.step_val
+        self.last_step_val = 0.0
+        self.at_end_val = (self.final_val - self.start_val) / self.start_step_val < 1e-14
+        self.weight_changed = True
+
+    def name(self):
+        return {"implicit_euler": "ImplEuler", "explicit_euler": "ExplEuler", "crank_nicolson": "CrankNicolson",
+                "bdf_2": "BDF-2"}[self.scheme]
+
+    def at_tick(self, tick):
+        """source/time_stepping.cc:225-235"""
+        time = self.now_val
+        slot = int(time * 1.0000000001 / tick) * tick
+        return not ((time - slot) > self.current_step_val * 0.95 and not self.at_end_val)
 
     def next(self):
         """source/time_stepping.cc:123-200"""

@@ -94,3 +94,30 @@ def test_errors():
             "subsection Navier-Stokes\n subsection Solver\n  set linearization scheme = something\n end\nend\n")
     with pytest.raises(NotImplementedError):                     # velocity degree > 1
         adaflo_amd.flow_parameters_from_prm("subsection Navier-Stokes\n set velocity degree = 1\nend\n")
+
+
+def test_time_stepping_helpers():
+    """TimeStepping::set_desired_time_step / restart / at_tick / name (source/time_stepping.cc:104-119,206-268)"""
+    p = adaflo_amd.FlowParameters(time_step_size_start=0.1, time_step_size_min=0.02, time_step_size_max=0.3, end_time=2.0)
+    ts = adaflo_amd.TimeStepping(p)
+    assert ts.name() == "BDF-2"
+    ts.set_desired_time_step(1.0)                # at t = 0 the desired value counts as the previous one: only the bounds act
+    assert ts.step_size() == 0.3
+    ts.next()
+    ts.set_desired_time_step(1.0)                # now limited to twice the previous step ... and to the maximum
+    assert ts.step_size() == 0.3
+    ts.set_desired_time_step(0.01)               # not below half the previous step
+    assert abs(ts.step_size() - 0.15) < 1e-15
+    ts.set_desired_time_step(0.001)
+    ts.set_desired_time_step(0.001)
+    ts.set_desired_time_step(0.001)
+    assert ts.step_size() == 0.02                # ... and not below the minimum
+    ts.restart()
+    assert (ts.now(), ts.step_no(), ts.step_size(), ts.old_step_size(), ts.at_end()) == (0.0, 0, 0.1, 0.0, False)
+    q = adaflo_amd.FlowParameters(time_step_size_start=0.05, end_time=1.0)
+    t2 = adaflo_amd.TimeStepping(q)
+    ticks = []
+    for _ in range(8):
+        t2.next()
+        ticks.append(t2.at_tick(0.2))
+    assert ticks == [False, False, False, True, False, False, False, True]     # output every 0.2: steps 4, 8 (beltrami_3d.prm)
