@@ -36,7 +36,7 @@ namespace adaflo_hip
   constexpr size_t ns_lds_doubles(const bool residual)
   {
     using L = NSLayout<K>;
-    if (L::REGQ)
+    if (L::REGQ || residual)
       return L::TABP + 3 * L::NDU3 + L::NDP3 + 4 * L::NQ3 + SumFac<L::NDU, L::NQ, NT>::TMP;
     size_t n = L::TABP + 3 * L::NDU3 + L::NDP3 + 3 * L::NQ3 + 9 * L::NQ3 + L::NQ3 +
                NSLayout<K>::NBATCH * SumFac<L::NDU, L::NQ, NT>::TMP;
@@ -57,7 +57,7 @@ namespace adaflo_hip
     extern __shared__ double lds[];
     double *S_u = lds, *D_u = S_u + NQ * L::NDU, *S_p = D_u + NQ * L::NDU, *D_p = S_p + NQ * L::NDP,
            *wq = D_p + NQ * L::NDP;
-    constexpr bool REGQ = L::REGQ;
+    constexpr bool REGQ = L::REGQ || RES; // (Q2 residual: three solutions at the q-points -> registers as well)
     // REGQ: [ul | pl | qb (4 NQ3: one component's tested value + gradient) | tmp]; vu / gu / vp unused
     double *ul = lds + L::TABP, *pl = ul + 3 * NDU3, *vu = pl + NDP3, *gu = vu + (REGQ ? 1 : 3) * NQ3,
            *vp = gu + (REGQ ? 3 : 9) * NQ3, *tmp = REGQ ? vp : vp + NQ3;
