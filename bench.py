@@ -2,16 +2,29 @@
 """bench.py -- MDoF/s of NavierStokesMatrix::vmult (3D Q2/Q1) + HBM roofline on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N = 1 : BASELINE.json configs[1] -- 3D Beltrami Q2/Q1, uniform 128^3 hex mesh,
-          one `vmult` (= one "step") of the Newton-linearised NS operator.
-  N > 1 : launched by torch.distributed.run, one rank per GPU; weak scaling: every
-          rank owns a 128^3-cell brick of a (px*128, py*128, pz*128) mesh (N = 8 is
-          configs[2], the 256^3 mesh), ghost-DoF exchange over RCCL.
+  --config beltrami (default)
+      N = 1 : BASELINE.json configs[1] -- 3D Beltrami Q2/Q1, uniform 128^3 hex mesh,
+              one `vmult` (= one "step") of the Newton-linearised NS operator.
+      N > 1 : one rank per GPU; weak scaling: every rank owns a 128^3-cell brick of a
+              (px*128, py*128, pz*128) mesh (N = 8 is configs[2], the 256^3 mesh),
+              ghost-DoF exchange over RCCL.
+  --config cavity
+      BASELINE.json configs[4] -- Q4/Q3 driven-cavity operator, 64^3 cells on
+      [0,1]x[0,1]x[0,3] (applications/drivencavity.cc:356-370), `incompressible stationary`,
+      mu = 0.01 (drivencavity.prm:9-14); the 64^3 mesh is FIXED and cut into bricks
+      (strong scaling: 32^3 cells per rank at N = 8).
 One JSON line on stdout (rank 0).  Inputs are resident in HBM before the timed region.
+
+With N > 1 and no torch.distributed environment the script launches its own N ranks
+(`python -m torch.distributed.run`) BEFORE anything touches the GPU, forwards the JSON line
+and exits with the child's return code.  If the box has fewer than N GPUs the ranks share
+device 0 and talk gloo: a functional dry run ("dry_run": true), not a measurement.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,7 +35,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_COPY_GBS = 6290.0       # measured float4 copy ceiling (same guide)
-B_ALG_PER_CELL_Q2 = 16 * (3 * 2 ** 3 + 1 ** 3) + 8 * 12 * 27   # 400 + 2592 B
+SEED = 20260515
+
+
+def b_alg_per_cell(k):
+    """vectors 16 (3 k^3 + (k-1)^3) + Newton state 8 * 12 * (k+1)^3 bytes per cell"""
+    return 16 * (3 * k ** 3 + (k - 1) ** 3) + 8 * 12 * (k + 1) ** 3
 
 
 def parse():
@@ -30,36 +48,83 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--cells", type=int, default=128, help="cells per direction per GPU")
-    ap.add_argument("--degree", type=int, default=2)
+    ap.add_argument("--config", default="beltrami", choices=["beltrami", "cavity"])
+    ap.add_argument("--cells", type=int, default=0,
+                    help="beltrami: cells per direction per GPU (128); cavity: GLOBAL cells per direction (64)")
+    ap.add_argument("--degree", type=int, default=0, help="velocity degree (beltrami 2, cavity 4)")
     ap.add_argument("--variant", type=int, default=1, help="0 generic kernels, 1 specialised")
     ap.add_argument("--chunk", type=int, default=0, help="Q2 kernel z-chunk (0 = heuristic)")
     ap.add_argument("--state-pad", type=int, default=-1, help="Q2 state skew padding in 16 B units")
     ap.add_argument("--linearization", default="coupled implicit Newton",
                     help="diagnostic only: e.g. 'coupled velocity explicit' times the kernel without q-state")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: blocking exchange schedule")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=48)
     return ap.parse_args()
 
 
-def beltrami_nodal(torch, mesh_lower, h, ncell, degree, t, device):
-    """nodal interpolant of the Beltrami field (tests/beltrami.cc:82-172) on the device"""
+def self_launch(args):
+    """N > 1 without a torch.distributed environment: start the ranks as a child job.  Nothing in
+    this process has touched the GPU (device_count() does not initialise it)."""
+    import torch
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.device_count() < args.gpus:
+        env["ADAFLO_BENCH_BACKEND"] = "gloo"
+        env["ADAFLO_BENCH_SINGLE_DEVICE"] = "1"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def _s64(x):
+    """two's-complement int64 value of x mod 2^64"""
+    x &= (1 << 64) - 1
+    return x - (1 << 64) if x >> 63 else x
+
+
+def hashed_uniform(torch, index, salt):
+    """deterministic doubles in [-1, 1) from GLOBAL DoF indices (splitmix64 finaliser): every
+    partitioning of the mesh sees the same global source vector without materialising it
+    (SURVEY 8d asks for one std::mt19937_64 stream in global order: same purpose)"""
+    def lsr(z, n):                                   # logical shift right on int64
+        return (z >> n) & ((1 << (64 - n)) - 1)
+    z = index + _s64(salt * 0x9E3779B97F4A7C15 + SEED)
+    z = (z ^ lsr(z, 30)) * _s64(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * _s64(0x94D049BB133111EB)
+    z = z ^ lsr(z, 31)
+    return lsr(z, 11).to(torch.float64) * (2.0 / (1 << 53)) - 1.0
+
+
+def global_dof_index(torch, part, degree, ncomp, device):
+    """global lexicographic index (node * ncomp + comp) of the local DoFs of a brick"""
+    nn_g = [degree * g * c + 1 for g, c in zip(part.grid, part.cells)]
+    ax = [torch.arange(degree * part.cells[d] + 1, device=device, dtype=torch.int64)
+          + degree * part.coords[d] * part.cells[d] for d in range(3)]
+    node = (ax[2][:, None, None] * nn_g[1] + ax[1][None, :, None]) * nn_g[0] + ax[0][None, None, :]
+    idx = node.reshape(-1, 1) * ncomp + torch.arange(ncomp, device=device, dtype=torch.int64)[None, :]
+    return idx.reshape(-1)
+
+
+def beltrami_nodal(torch, lower, h, ncell, degree, t, device, pressure=False):
+    """nodal interpolant of the Beltrami field (tests/beltrami.cc:82-172) on the device; FE_Q
+    support points = Gauss-Lobatto points (navier_stokes.cc:95-106)"""
+    from adaflo_amd.navier_stokes import gauss_lobatto_points
     a = 0.25 * np.pi
     d = 2.0 * a
+    gl = torch.tensor(gauss_lobatto_points(degree + 1), device=device, dtype=torch.float64)
     ax = []
     for dim in range(3):
-        n = degree * ncell[dim] + 1
-        idx = torch.arange(n, device=device, dtype=torch.float64)
-        if degree == 2:
-            x = mesh_lower[dim] + 0.5 * h[dim] * idx            # GLL nodes 0, 1/2, 1
-        elif degree == 1:
-            x = mesh_lower[dim] + h[dim] * idx
-        else:
-            from adaflo_amd import _lib  # noqa: F401  (higher degrees: host GLL nodes)
-            raise NotImplementedError
-        ax.append(x)
+        c = torch.arange(ncell[dim], device=device, dtype=torch.float64)
+        x = (c[:, None] + gl[None, :degree]).reshape(-1)
+        x = torch.cat([x, torch.tensor([float(ncell[dim])], device=device, dtype=torch.float64)])
+        ax.append(lower[dim] + h[dim] * x)
     z, y, x = torch.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
-    if degree == 1:
+    if pressure:
         p = -a * a * 0.5 * (torch.exp(2 * a * x) + torch.exp(2 * a * y) + torch.exp(2 * a * z)
                             + 2 * torch.sin(a * x + d * y) * torch.cos(a * z + d * x) * torch.exp(a * (y + z))
                             + 2 * torch.sin(a * y + d * z) * torch.cos(a * x + d * y) * torch.exp(a * (z + x))
@@ -80,7 +145,7 @@ def cpu_baseline(sample_cells, budget_s=12.0):
     n = sample_cells
     mesh = orc.Mesh.make([n] * 3, [-1.0] * 3, [1.0] * 3)
     prm = orc.NSParams.make(weight=1.5 / 0.05, weight_old=-2 / 0.05, weight_old_old=0.5 / 0.05)
-    rng = np.random.default_rng(20260515)
+    rng = np.random.default_rng(SEED)
     nu, npr = mesh.n_nodes(2) * 3, mesh.n_nodes(1)
     su, sp = rng.uniform(-1, 1, nu), rng.uniform(-1, 1, npr)
     lin = rng.uniform(-1, 1, mesh.n_cells * 27 * 12)
@@ -107,18 +172,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
-                             "(one rank per GPU)" % args.gpus)
+        raise SystemExit("bench.py --gpus %d inside a torch.distributed job of %d ranks" % (args.gpus, world))
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP engine)")
-    # functional dry run of the N > 1 path on a single GPU (not a measurement):
-    #   ADAFLO_BENCH_BACKEND=gloo ADAFLO_BENCH_SINGLE_DEVICE=1 torchrun --nproc-per-node 2 bench.py --gpus 2 --cells 32
+    # functional dry run of the N > 1 path on a single GPU (not a measurement): gloo messages
+    # staged through host memory, all ranks on device 0 (set by self_launch when GPUs are missing)
     backend = os.environ.get("ADAFLO_BENCH_BACKEND", "nccl")
-    if os.environ.get("ADAFLO_BENCH_SINGLE_DEVICE") == "1":
+    dry_run = os.environ.get("ADAFLO_BENCH_SINGLE_DEVICE") == "1"
+    if dry_run:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -135,20 +201,37 @@ def main():
     if not os.path.exists(_build.LIB):
         _build.build()
 
-    nc, k = args.cells, args.degree
-    fp = adaflo_amd.FlowParameters(velocity_degree=k, time_step_size_start=0.05, end_time=1.0,
-                                   linearization=args.linearization)
+    grid = parallel.brick_grid(world)
+    cavity = args.config == "cavity"
+    if cavity:
+        k = args.degree or 4
+        n_global = args.cells or 64
+        if any(n_global % g for g in grid):
+            raise SystemExit("cavity: %d cells are not divisible by the process grid %s" % (n_global, grid))
+        cells = [n_global // g for g in grid]
+        lower, upper = [0.0, 0.0, 0.0], [1.0, 1.0, 3.0]          # drivencavity.cc:357-370
+        fp = adaflo_amd.FlowParameters(velocity_degree=k, physical_type="incompressible stationary",
+                                       viscosity=0.01, time_step_size_start=0.05, end_time=1.0,
+                                       linearization=args.linearization)
+        scaling = "strong"
+    else:
+        k = args.degree or 2
+        nc = args.cells or 128
+        cells = [nc] * 3
+        lower, upper = [-1.0] * 3, ([-1.0 + 2.0 * g for g in grid] if world > 1 else [1.0] * 3)
+        fp = adaflo_amd.FlowParameters(velocity_degree=k, time_step_size_start=0.05, end_time=1.0,
+                                       linearization=args.linearization)
+        scaling = "weak"
     ts = adaflo_amd.TimeStepping(fp)
     for _ in range(3):
         ts.next()                                   # steady BDF-2 weights: gamma = 1.5/dt
-    grid = parallel.brick_grid(world)
-    part = parallel.BrickPartition(grid, rank, [nc] * 3, lower=[-1.0] * 3,
-                                   upper=[-1.0 + 2.0 * g for g in grid] if world > 1 else [1.0] * 3)
+    part = parallel.BrickPartition(grid, rank, cells, lower=lower, upper=upper)
     stream = torch.cuda.current_stream(device).cuda_stream   # 0 = the legacy default stream
     op = parallel.DistributedNavierStokesMatrix(fp, part, device=local_rank, stream=stream,
                                                 group=dist.group.WORLD if world > 1 else None)
     op.initialize(ts, True)
     op.set_kernel_variant(args.variant)
+    op.overlap = not args.no_overlap
     if args.chunk:
         op.local.set_q2_chunk(args.chunk)
     if args.state_pad >= 0:
@@ -156,8 +239,9 @@ def main():
 
     mesh = op.local.mesh
     n_u, n_p = op.local.n_dofs_u(), op.local.n_dofs_p()
-    # linearisation point = nodal interpolant of the Beltrami field at t = 0, pushed through
-    # the residual kernel, which is the only producer of the q-point state in the reference
+    # linearisation point = nodal interpolant of the Beltrami field at t = 0 (on the cavity box as
+    # well), pushed through the residual kernel, which is the only producer of the
+    # q-point state in the reference
     u_lin = beltrami_nodal(torch, mesh.lower, mesh.h, mesh.ncell, k, 0.0, device)
     p_lin = torch.zeros(n_p, device=device, dtype=torch.float64)
     zeros_u = torch.zeros(n_u, device=device, dtype=torch.float64)
@@ -166,16 +250,14 @@ def main():
     rhs = adaflo_amd.BlockVector([V(ctx, torch.zeros_like(u_lin)), V(ctx, torch.zeros_like(p_lin))])
     op.local.residual(rhs, adaflo_amd.BlockVector([V(ctx, u_lin), V(ctx, p_lin)]), None,
                       adaflo_amd.BlockVector([V(ctx, u_lin)]), adaflo_amd.BlockVector([V(ctx, zeros_u)]))
-    del rhs
-    # deterministic pseudo-random source in [-1,1], identical global vector for any partitioning
-    gen = torch.Generator(device=device)
-    gen.manual_seed(20260515 + rank)
-    src_u = torch.rand(n_u, device=device, dtype=torch.float64, generator=gen) * 2 - 1
-    src_p = torch.rand(n_p, device=device, dtype=torch.float64, generator=gen) * 2 - 1
+    del rhs, u_lin, zeros_u
+    # deterministic pseudo-random source in [-1,1): a hash of the GLOBAL DoF index, so any
+    # partitioning sees the same global vector (replicas of interface DoFs agree by construction)
+    src_u = hashed_uniform(torch, global_dof_index(torch, part, k, 3, device), 0)
+    src_p = hashed_uniform(torch, global_dof_index(torch, part, k - 1, 1, device), 1)
     dst_u, dst_p = torch.empty_like(src_u), torch.empty_like(src_p)
     src = adaflo_amd.BlockVector([V(ctx, src_u), V(ctx, src_p)])
     dst = adaflo_amd.BlockVector([V(ctx, dst_u), V(ctx, dst_p)])
-    op.make_consistent(src)
 
     def barrier():
         if world > 1:
@@ -183,19 +265,24 @@ def main():
         torch.cuda.synchronize(device)
 
     for _ in range(args.warmup):
-        op.vmult(dst, src)
+        op.vmult(dst, src, src_consistent=True)
     op.local.get_kernel_statistics()
     op.local.get_matvec_statistics()
+    # per-step device time: events on the stream the engine launches on (= torch's current stream)
+    events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        op.vmult(dst, src)
+    for i in range(args.steps):
+        events[i].record()
+        op.vmult(dst, src, src_consistent=True)
+    events[args.steps].record()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    step_ms = np.array([events[i].elapsed_time(events[i + 1]) for i in range(args.steps)])
     ksec, kcount = op.local.get_kernel_statistics()
     msec, mcount = op.local.get_matvec_statistics()
 
@@ -203,39 +290,53 @@ def main():
     n_cells_local = op.local.n_cells()
     value = n_dofs_global * args.steps / elapsed / 1e6
     kernel_avg = ksec / max(kcount, 1)
-    b_alg_launch = B_ALG_PER_CELL_Q2 * n_cells_local if k == 2 else None
-    achieved = b_alg_launch / kernel_avg / 1e9 if b_alg_launch else None
+    b_alg_launch = b_alg_per_cell(k) * n_cells_local
+    achieved = b_alg_launch / kernel_avg / 1e9 if kernel_avg > 0 else None
+    ms_per_step = 1e3 * elapsed / args.steps
+    frac_vmult = b_alg_launch / (1e-3 * ms_per_step) / 1e9 / HBM_PEAK_GBS
     if not torch.isfinite(dst_u).all():
         raise SystemExit("non-finite result")
 
+    kernel_name = "ns_q2_kernel" if (k == 2 and args.variant >= 1) else (
+        "ns_ho_kernel" if (k > 2 and args.variant == 2) else "ns_cell_kernel")
     traffic = None
     try:  # PMC-measured HBM bytes per launch of the dominant kernel (profiles/, collected with rocprofv3)
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
-        if pmc.get("workload") == "%dx%dx%d k=%d variant=%d" % (nc, nc, nc, k, args.variant):
-            traffic = pmc["ns_q2_kernel"]["hbm_bytes"]
-    except (OSError, KeyError, ValueError):
+        key = "%s k=%d variant=%d" % ("x".join(str(c) for c in cells), k, args.variant)
+        traffic = pmc[key][kernel_name]["hbm_bytes"]
+    except (OSError, KeyError, ValueError, TypeError):
         pass
+    mesh_str = "x".join(str(g * c) for g, c in zip(grid, cells))
+    if cavity:
+        workload = ("3D driven-cavity box [0,1]x[0,1]x[0,3] Q%d/Q%d NavierStokes vmult, incompressible stationary, "
+                    "mu = 0.01, Newton linearisation about the Beltrami formula, uniform hex mesh %s cells "
+                    "(%s per GPU), Dirichlet on all faces" % (k, k - 1, mesh_str, "x".join(map(str, cells))))
+    else:
+        workload = ("3D Beltrami Q%d/Q%d NavierStokes vmult, Newton linearisation, uniform hex mesh %s cells "
+                    "(%d^3 per GPU), Dirichlet on all faces, pressure mean projection" % (k, k - 1, mesh_str, cells[0]))
     out = {
-        "metric": "MDoF/s for NavierStokesMatrix::vmult (3D Q2/Q1)",
+        "metric": "MDoF/s for NavierStokesMatrix::vmult (3D Q%d/Q%d)" % (k, k - 1),
         "value": round(value, 1), "unit": "MDoF/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "ms_per_step_min": round(float(step_ms.min()), 4), "ms_per_step_median": round(float(np.median(step_ms)), 4),
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "3D Beltrami Q%d/Q%d NavierStokes vmult, Newton linearisation, "
-                               "uniform hex mesh %s cells (%d^3 per GPU), Dirichlet on all faces, "
-                               "pressure mean projection" % (k, k - 1, "x".join(
-                                   str(g * nc) for g in grid), nc),
-                   "dofs": n_dofs_global, "cells_per_gpu": n_cells_local,
-                   "partition": "x".join(str(g) for g in grid), "kernel_variant": args.variant},
+        "config": {"workload": workload, "dofs": n_dofs_global, "cells_per_gpu": n_cells_local,
+                   "partition": "x".join(str(g) for g in grid), "kernel_variant": args.variant,
+                   "overlap": bool(op.overlap) if world > 1 else None},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                     "frac_vmult": round(frac_vmult, 4),
                      "frac_of_copy_ceiling": round(achieved / HBM_COPY_GBS, 4) if achieved else None,
-                     "traffic": traffic, "kernel": "ns_q2_kernel" if (k == 2 and args.variant == 1)
-                     else "ns_cell_kernel", "kernel_ms": round(1e3 * kernel_avg, 4),
-                     "alg_bytes_per_launch": b_alg_launch, "vmult_ms_device": round(1e3 * msec / max(mcount, 1), 4)},
+                     "traffic": traffic, "kernel": kernel_name, "kernel_ms": round(1e3 * kernel_avg, 4),
+                     "alg_bytes_per_launch": b_alg_launch, "alg_bytes_per_dof": round(
+                         b_alg_per_cell(k) / (3 * k ** 3 + (k - 1) ** 3), 1),
+                     "vmult_ms_device": round(1e3 * msec / max(mcount, 1), 4)},
     }
+    if dry_run:
+        out["dry_run"] = True       # ranks share one GPU, gloo messages: functional check only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_cells)
     elif rank == 0:
