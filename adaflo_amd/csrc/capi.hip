@@ -255,7 +255,7 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
                           &ctx->ls_convection, &ctx->ls_normal, &ctx->q1_convection, &ctx->q1_normal,
                           &ctx->q1_slab, &ctx->q1_zslab, &ctx->pc_inv_u, &ctx->pc_inv_pm, &ctx->pc_inv_pl,
                           &ctx->pc_ones_p, &ctx->pc_tmp_u, &ctx->pc_tmp_p, &ctx->pc_tmp_p2, &ctx->pc_work, &ctx->kr_work, &ctx->kr_basis, &ctx->kr_scalars,
-                          &ctx->q1_poisson_coef})
+                          &ctx->q1_poisson_coef, &ctx->ho_tab})
     release(*b);
   for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch,
                     ctx->d_tab_ls, ctx->d_ls_diag, ctx->d_tab_force})
@@ -508,7 +508,7 @@ int adaflo_ns_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double 
     {
       TRY(ctx, launch_ns_vmult_q2(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p), "Q2 kernel launch failed");
     }
-  else if (ctx->variant == 2 && ho_supported(ctx)) // opt-in, see ns_ho.hip
+  else if (ho_supported(ctx) && (ctx->variant == 2 || (ctx->variant == 1 && ctx->k <= 4))) // ns_ho.hip
     {
       TRY(ctx, launch_ns_vmult_ho(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p), "sweep kernel launch failed");
     }
@@ -593,7 +593,7 @@ int adaflo_ns_velocity_vmult(adaflo_ctx *ctx, double *dst_u, const double *src_u
           "Q2 kernel launch failed");
       return 0;
     }
-  if (ctx->variant == 2 && ho_supported(ctx) && !ctx->rho_prec.p)
+  if (ho_supported(ctx) && (ctx->variant == 2 || (ctx->variant == 1 && ctx->k <= 4)) && !ctx->rho_prec.p)
     {
       TRY(ctx, launch_ns_vmult_ho(ctx, OP_VMULT_VELOCITY, dst_u, nullptr, src_u, nullptr),
           "sweep kernel launch failed");

@@ -115,6 +115,7 @@ struct adaflo_ctx
   // specialised (Q2/Q1 sweep kernel) copy of the linearisation, see ns_q2.hip
   adaflo_hip::DeviceBuffer lin_q2, lin_q2_prec;
   adaflo_hip::DeviceBuffer q2_slab_u, q2_zslab_u, q2_slab_p, q2_zslab_p; // seam partial sums
+  adaflo_hip::DeviceBuffer ho_tab;                                        // 1D tables of the Q3..Q5 sweep kernel
   int                     *q2_wg_list = nullptr;     // [interface | interior A | interior B] workgroups
   long                     q2_wg_key[4] = {0, 0, 0, 0};
   int                      q2_wg_counts[3] = {0, 0, 0};

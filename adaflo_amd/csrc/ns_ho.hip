@@ -2,71 +2,80 @@
 // NavierStokesMatrix::vmult / velocity_vmult with constant coefficients
 // (source/navier_stokes_matrix.cc:601-916, vmult and vmult_velocity branches).
 //
-// Same structure as the Q2/Q1 kernel (ns_q2.hip) -- a workgroup owns a column of TCX x TCY
-// cells and sweeps z, nodes shared between cells of the tile are combined through LDS, nodes
-// shared between workgroups go through slabs + a fix-up kernel (no atomics, no memset) -- but
-// with the work split the way sum factorisation wants it at higher degree:
-//   * (k+1)^2 threads per cell; thread (i,j) owns the z-LINE of nodes / quadrature points
-//     (i,j,0..k) in registers, so the z contractions, the quadrature-point physics and the
-//     carry of the top node plane into the next cell layer need no LDS at all;
-//   * for the x and y contractions the same (k+1)^2 threads re-distribute over the (k+1)^2
-//     lines of that direction: a thread reads ONE line from LDS, applies the 1D matrix with
-//     wave-uniform coefficients (scalar registers) and writes the line back;
-//   * collocation: interpolate to the Gauss points once, then differentiate there with the
-//     (k+1)x(k+1) collocation derivative (x: fused into the x sweep, z: registers,
-//     y: 1D stencil read with the thread's own matrix row).
-// FP64 MFMA was considered for the 1D contractions and rejected: on CDNA4 the f64 matrix rate
-// equals the f64 vector rate (78.6 TF both), the matrices are only (k+1)x(k+1) <= 6x6 and would
-// have to be padded to the 16x16x4 tile, and the kernel is bound by the HBM stream of the
-// quadrature-point state (12 doubles per point) anyway.
-// STATUS: parity-green (tests/test_ns_parity_gpu.py, tests/test_golden_gpu.py) but opt-in
-// (adaflo_set_kernel_variant(ctx, 2)): measured 64^3 Q4/Q3 Newton 3.1 ms at two workgroups per CU
-// (register spills: 65 doubles of values + gradients per thread are live in the quadrature loop)
-// and 2.5 ms at one workgroup per CU, against 2.3 ms of the generic LDS kernel; PMC counters show
-// 72 % of the wave cycles parked in waits (serial stage chain at 1-2 waves per SIMD), not issue.
-// A second design was tried and discarded (not in the tree): four lanes per z-line (three velocity
-// components + pressure, DPP quad broadcasts for the physics as in ns_q2.hip) and [component]
-// [cell][line] regrouping for the LDS sweeps in 1024-thread workgroups.  A lane then holds one
-// component, but still ~150 live registers at k = 4 against the 128-VGPR budget of four waves per
-// SIMD: the spills went to scratch memory and the kernel ran at 14 ms (64^3 Q4/Q3 Newton).
+// Design (round 2).  The generic cell kernel is bound by the LDS
+// instruction rate (every 1D contraction reads data AND matrix entries from LDS) and by ~30
+// workgroup barriers per cell.  Here:
+//   * (k+1)^2 lanes per cell, lane (i,j) owns the z-LINE of nodes / quadrature points (i,j,0..k)
+//     in registers: z contractions, the quadrature-point physics and the carry of the top node
+//     plane into the next cell layer need no LDS;
+//   * a CELL LIVES INSIDE ONE WAVE (k = 3: 4 cells of 16 lanes, k = 4: 2 cells of 25 lanes in
+//     32-lane halves, k = 5: 1 cell of 36 lanes).  The x / y contractions go through a
+//     wave-private LDS region: lanes write their values, then lane (a,b) reads the x-line
+//     (., b) or the y-line (a, .) it needs and contracts it with ITS row of the 1D matrix held
+//     in registers.  One wave's LDS operations execute in order, so these exchanges need no
+//     s_barrier at all -- only the data dependency (lgkmcnt);
+//   * collocation: interpolate to the Gauss points once (z in registers, x, y through LDS), then
+//     per quadrature plane c: d/dz from the register line, d/dx, d/dy from x- / y-line reads,
+//     physics, transposed derivatives the same way back; values and gradients of ONE plane are
+//     live at a time (12 + 12 doubles instead of 65 for the whole line);
+//   * z matrices are wave-uniform (scalar registers, symmetric halves), x / y rows per lane;
+//   * the workgroup (4 waves) owns a column of TCX x TCY cells and sweeps z; nodes shared
+//     between cells of the tile are combined through a double-buffered LDS publish area with ONE
+//     workgroup barrier per cell layer; nodes shared between workgroups go through slabs + a
+//     fix-up kernel (no atomics, no memset, bitwise reproducible), as in ns_q2.hip.
 // The linearisation state is read in the generic layout [cell][12][(k+1)^3] the residual kernel
-// writes: for a fixed component the (k+1)^2 threads of a cell read consecutive doubles.
+// writes: for a fixed component and plane the (k+1)^2 lanes of a cell read consecutive doubles.
+// FP64 MFMA for the 1D contractions: measured (scripts/dev/mfma_f64_probe.hip) and
+// rejected -- v_mfma_f64_16x16x4_f64 issues at the f64 vector rate and a 5x5 matrix fills at most
+// 29 % of the tile even with three cells packed on the block diagonal.
 #include "basis.hpp"
 #include "kernels.hpp"
+
+#include <utility>
 
 namespace adaflo_hip
 {
   namespace
   {
+    // K -> cells per wave (CPW), waves of the workgroup arranged WX x WY over the tile
     template <int K>
     struct HOCfg;
     template <>
     struct HOCfg<3>
     {
-      static constexpr int TCX = 4, TCY = 4; // 16 cells x 16 threads = 256
+      static constexpr int CPW = 4, WX = 1, WY = 4, PLS = 16; // 16 lanes per cell
     };
     template <>
     struct HOCfg<4>
     {
-      static constexpr int TCX = 4, TCY = 2; // 8 cells x 25 threads = 200
+      static constexpr int CPW = 2, WX = 2, WY = 2, PLS = 32; // 25 lanes per cell in a 32-lane half
     };
     template <>
     struct HOCfg<5>
     {
-      static constexpr int TCX = 3, TCY = 2; // 6 cells x 36 threads = 216
+      static constexpr int CPW = 1, WX = 2, WY = 2, PLS = 40; // 36 lanes per cell
     };
-    // keep the machine scheduler from interleaving independent components / points (it would hoist
-    // every load to the top and triple the live registers)
-#ifdef HO_FENCES
-#define HO_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define HO_FENCE()
-#endif
+    template <int K>
+    struct HOTile
+    {
+      using C                  = HOCfg<K>;
+      static constexpr int TCX = C::CPW * C::WX, TCY = C::WY; // cells of the workgroup tile
+    };
 #ifndef HO_LB
 #define HO_LB 2
 #endif
-    constexpr int NTH = 256;
+    constexpr int NTH  = 256;
     constexpr int NMAX = 6;
+    constexpr int L_TAB_D = NMAX * NMAX, L_TAB_SP = 2 * NMAX * NMAX, L_WAVE = 3 * NMAX * NMAX;
+
+    template <int K>
+    constexpr int ho_lds_doubles()
+    {
+      using C           = HOCfg<K>;
+      constexpr int N   = K + 1;
+      constexpr int per = C::CPW * (4 * N + 6) * C::PLS; // values [4][N] planes + exchange [6] planes
+      return L_WAVE + 4 * per + 4 * (HOTile<K>::TCX * HOTile<K>::TCY) * N * 4 * N;
+    }
 
     struct HOArgs
     {
@@ -81,6 +90,7 @@ namespace adaflo_hip
       const double *src_u, *src_p, *lin;
       double       *dst_u, *dst_p;
       double       *slab_u, *zslab_u, *slab_p, *zslab_p;
+      const double *tab; // [S N*N | D N*N | Sp N*NP | w N] for the scalar loads of the z contractions
     };
 
     template <int TNX, int TNY>
@@ -95,44 +105,153 @@ namespace adaflo_hip
       return 2 * TNX + TNY - 2 + j - 1;
     }
 
+    // compiler-only fence between a wave's LDS write and read phases (the hardware executes one
+    // wave's LDS operations in order; this keeps the compiler from moving them across)
+    __device__ __forceinline__ void wave_sync()
+    {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    // LDS reads of the contraction lines are hand-issued ds_read_b64: the compiler would merge them
+    // into ds_read2_b64, which runs at half the LDS rate of two ds_read_b64 (MI355X_MICROARCH.md, LDS
+    // table).  The results are tied to an explicit counted s_waitcnt (the compiler does not track
+    // the completion of asm outputs); LDS returns a wave's operations in order.
+    __device__ __forceinline__ unsigned lds_byte_addr(const void *p)
+    {
+      return (unsigned)(size_t)p; // LDS aperture: the low 32 bits are the LDS byte address
+    }
+    template <int OFF>
+    __device__ __forceinline__ double ds_rd(const unsigned a)
+    {
+      double v;
+      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+      return v;
+    }
+    // wait until at most CNT LDS operations are outstanding; the values listed become usable
+    template <int CNT, int NM>
+    __device__ __forceinline__ void ds_wait(double (&x)[NM])
+    {
+      constexpr int C = CNT > 15 ? 15 : CNT;
+      static_assert(NM >= 3 && NM <= 6, "line length");
+      if constexpr (NM == 3)
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]) : "n"(C));
+      else if constexpr (NM == 4)
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "n"(C));
+      else if constexpr (NM == 5)
+        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]) : "n"(C));
+      else
+        asm volatile("s_waitcnt lgkmcnt(%6)"
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5])
+                     : "n"(C));
+    }
+    template <int CNT>
+    __device__ __forceinline__ void ds_wait1(double &x)
+    {
+      constexpr int C = CNT > 15 ? 15 : CNT;
+      asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(C));
+    }
+    // x[m] = lds[base + OFF0 + 8 m STRIDE], m = 0 .. NM-1
+    template <int OFF0, int STRIDE, int NM, int... M>
+    __device__ __forceinline__ void rd_line_impl(const unsigned b, double (&x)[NM], std::integer_sequence<int, M...>)
+    {
+      ((x[M] = ds_rd<OFF0 + 8 * M * STRIDE>(b)), ...);
+    }
+    template <int OFF0, int STRIDE, int NM>
+    __device__ __forceinline__ void rd_line(const unsigned b, double (&x)[NM])
+    {
+      rd_line_impl<OFF0, STRIDE>(b, x, std::make_integer_sequence<int, NM>{});
+    }
+    template <int C0, int NPL, int NM, int STRIDE, int PLS>
+    struct LineReader
+    {
+      // issue the reads of line element M of plane C (recursion unrolls the compile-time offsets)
+      template <int C = 0, int M = 0>
+      static __device__ __forceinline__ void issue(const unsigned base, double (&ln)[NPL][NM])
+      {
+        if constexpr (C < NPL)
+          {
+            ln[C][M] = ds_rd<8 * ((C0 + C) * PLS + M * STRIDE)>(base);
+            if constexpr (M + 1 < NM)
+              issue<C, M + 1>(base, ln);
+            else
+              issue<C + 1, 0>(base, ln);
+          }
+      }
+      template <int C = 0>
+      static __device__ __forceinline__ void reduce(const double *coef, double (&ln)[NPL][NM], double *out)
+      {
+        if constexpr (C < NPL)
+          {
+            ds_wait<(NPL - 1 - C) * NM>(ln[C]);
+            double s = 0.;
+#pragma unroll
+            for (int m = 0; m < NM; ++m)
+              s += coef[m] * ln[C][m];
+            out[C] = s;
+            reduce<C + 1>(coef, ln, out);
+          }
+      }
+    };
+    // out[c] = sum_m coef[m] * lds[base + 8 (c * PLS + m * STRIDE)] for the NPL planes c, with the
+    // lane's coefficient vector coef[m] = lds[coef_addr + 8 m CSTRIDE] (row / column of a 1D matrix)
+    template <int NPL, int NM, int STRIDE, int PLS, int CSTRIDE>
+    __device__ __forceinline__ void ho_contract(const unsigned base, const unsigned coef_addr, double *out)
+    {
+      double coef[NM], ln[NPL][NM];
+      rd_line<0, CSTRIDE>(coef_addr, coef);
+      LineReader<0, NPL, NM, STRIDE, PLS>::issue(base, ln);
+      ds_wait<(NPL - 1) * NM>(ln[0]);
+      ds_wait<(NPL - 1) * NM>(coef);
+      LineReader<0, NPL, NM, STRIDE, PLS>::reduce(coef, ln, out);
+    }
+#define HO_FENCE() __builtin_amdgcn_sched_barrier(0)
+
     template <int K, int LIN_MODE, bool WITH_P>
     __global__ __launch_bounds__(NTH, HO_LB) void ns_ho_kernel(const HOArgs A)
     {
       using C = HOCfg<K>;
       constexpr int N = K + 1, NP = K, KP = K - 1, NL = N * N, N3 = N * N * N;
-      constexpr int TCX = C::TCX, TCY = C::TCY, NCELL = TCX * TCY;
+      constexpr int CPW = C::CPW, LPC = 64 / CPW, PLS = C::PLS;
+      constexpr int TCX = HOTile<K>::TCX, TCY = HOTile<K>::TCY, NCELL = TCX * TCY;
       constexpr int TNX = K * TCX + 1, TNY = K * TCY + 1, TPX = KP * TCX + 1, TPY = KP * TCY + 1;
       constexpr int RIMU = 2 * TNX + 2 * (TNY - 2), RIMP = 2 * TPX + 2 * (TPY - 2);
-      static_assert(NCELL * NL <= NTH, "tile does not fit the workgroup");
+      constexpr int VALW = CPW * 4 * N * PLS, TGW = CPW * 6 * PLS, PUBSZ = NCELL * N * 4 * N;
+      constexpr bool ALL_SLOTS = PLS >= LPC; // every lane has an LDS slot of its own
+      static_assert(NL <= LPC && NL <= PLS, "cell does not fit its lane group");
       extern __shared__ double lds[];
-      // (the lanes of the last wave beyond NCELL*NL threads work on a dummy cell slot NCELL of the
-      // LDS arrays: no divergent branches around the LDS traffic)
-      constexpr int NCS = NCELL * NL == NTH ? NCELL : NCELL + 1;
-      double *ARR0 = lds, *ARR1 = ARR0 + NCS * 3 * N3, *PARR = ARR1 + NCS * 3 * N3;
-      double *PUB_E = ARR1, *PUB_N = ARR1 + NCS * N * 4 * N; // [cell][j or i][4][k], alias of ARR1
-      static_assert(2 * NCS * N * 4 * N <= NCS * 3 * N3, "publish area must fit into ARR1");
 
-      // The 1D matrices live in scalar registers.  Gauss and Gauss-Lobatto points are symmetric
-      // about 1/2, so M[q][i] = +-M[n-1-q][m-1-i]: only the first half of each (flattened) matrix
-      // is ever read, which lets all three stay resident in SGPRs instead of being spilled.
-      auto Sv = [&](const int q, const int m) {
+      // wave-uniform 1D matrices (z direction): A.tab = [S | D | Sp | w] in global memory, read with
+      // scalar loads through a per-phase opaque copy of the pointer.  Gauss and Gauss-Lobatto points
+      // are symmetric about 1/2, so M[q][i] = +-M[n-1-q][m-1-i]: only the first half of S / Sp is read
+      typedef const double __attribute__((address_space(4))) *ctab_t; // constant address space: scalar loads
+      auto symS = [](const ctab_t t, const int q, const int m) {
         const int f = q * N + m;
-        return 2 * f < N * N ? A.S[f] : A.S[N * N - 1 - f];
+        return 2 * f < N * N ? t[f] : t[N * N - 1 - f];
       };
-      auto Dv = [&](const int q, const int m) {
-        const int f = q * N + m;
-        return 2 * f < N * N ? A.D[f] : -A.D[N * N - 1 - f];
-      };
-      auto Spv = [&](const int q, const int m) {
+      auto symSp = [](const ctab_t t, const int q, const int m) {
         const int f = q * NP + m;
-        return 2 * f < N * NP ? A.Sp[f] : A.Sp[N * NP - 1 - f];
+        return 2 * f < N * NP ? t[2 * N * N + f] : t[2 * N * N + N * NP - 1 - f];
       };
 
-      const int  tid    = threadIdx.x;
-      const bool active = tid < NCELL * NL;
-      const int  cell = active ? tid / NL : NCELL, l = active ? tid % NL : 0;
-      const int  i = l % N, j = l / N; // also: (a,b) of the owned quadrature line, line ids of the sweeps
-      const int  cxl = cell % TCX, cyl = cell / TCX;
+      const int tid  = threadIdx.x, lane = tid & 63;
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+      const int cw = lane / LPC, l = lane % LPC;
+      const bool active = l < NL;
+      const int  lc = active ? l : NL - 1;       // lanes beyond the cell shadow its last lane
+      const int  i = lc % N, j = lc / N;          // node column / quadrature column (a, b) of this lane
+      const int  cxl = (wave % C::WX) * CPW + cw, cyl = wave / C::WX, cell = cyl * TCX + cxl;
+      const bool slot_ok = ALL_SLOTS || l < PLS;
+
+      // the per-lane rows of the 1D matrices come from a small LDS table
+      for (int e = tid; e < NMAX * NMAX; e += NTH)
+        {
+          lds[e]            = A.S[e];
+          lds[L_TAB_D + e]  = A.D[e];
+          lds[L_TAB_SP + e] = A.Sp[e];
+        }
+      __syncthreads();
 
       const long nwg = (long)A.tiles_x * A.tiles_y * A.n_chunks;
       const long wg  = xcd_remap(blockIdx.x, nwg);
@@ -141,14 +260,14 @@ namespace adaflo_hip
       const int  cz0 = bz * A.LZ, nl = min(A.LZ, A.ncz - cz0);
       const int  tcx = min(TCX, A.ncx - bx * TCX), tcy = min(TCY, A.ncy - by * TCY);
       const bool valid = active && cxl < tcx && cyl < tcy;
-      // cells outside the mesh / dummy lanes compute on cell (0,0) of the tile: their results are
-      // never used (nothing is emitted, no valid cell collects from them), addresses stay legal
-      const int  cx = bx * TCX + (valid ? cxl : 0), cy = by * TCY + (valid ? cyl : 0);
+      // cells outside the mesh compute on cell (0,0) of the tile: their results are never used
+      // (nothing is emitted, no valid cell collects from them), addresses stay legal
+      const int  cx = bx * TCX + (cxl < tcx && cyl < tcy ? cxl : 0), cy = by * TCY + (cxl < tcx && cyl < tcy ? cyl : 0);
       const bool lastx = valid && cxl == tcx - 1, lasty = valid && cyl == tcy - 1;
       const bool hasW = cxl > 0, hasS = cyl > 0;
       const size_t wgs = (size_t)bt * A.n_chunks + bz;
 
-      // velocity node column of this thread
+      // velocity node column of this lane
       const int  I = K * cx + i, J = K * cy + j;
       const bool own_u  = valid && (i < K || lastx) && (j < K || lasty);
       const bool seam_u = (K * cxl + i == TNX - 1 && I < A.nnx - 1) || (K * cyl + j == TNY - 1 && J < A.nny - 1);
@@ -157,7 +276,7 @@ namespace adaflo_hip
         if ((I == 0 && (A.con_u >> (0 + d) & 1)) || (I == A.nnx - 1 && (A.con_u >> (3 + d) & 1)) ||
             (J == 0 && (A.con_u >> (6 + d) & 1)) || (J == A.nny - 1 && (A.con_u >> (9 + d) & 1)))
           cmask |= 1u << d;
-      // pressure node column (threads with i, j < NP)
+      // pressure node column (lanes with i, j < NP)
       const bool pth = valid && i < NP && j < NP;
       const int  Ip = KP * cx + min(i, KP), Jp = KP * cy + min(j, KP);
       const bool own_p  = pth && (i < KP || lastx) && (j < KP || lasty);
@@ -166,36 +285,29 @@ namespace adaflo_hip
                         (Jp == 0 && (A.con_p >> 2 & 1)) || (Jp == A.npy - 1 && (A.con_p >> 3 & 1));
 
       // all per-lane predicates in ONE register; the loop re-derives them from an opaque copy
-      // (kept as separate booleans the compiler parks ~20 loop-invariant lane masks in SGPR pairs,
-      // which pushes the 1D matrices out of the scalar register file)
       enum
       {
         F_OWN_U = 1, F_SEAM_U = 2, F_CON0 = 4, F_OWN_P = 32, F_SEAM_P = 64, F_PCON = 128, F_W = 256, F_S = 512,
         F_IK = 1024, F_JK = 2048, F_PTH = 4096, F_IKP = 8192, F_JKP = 16384
       };
       const unsigned flags = (own_u ? F_OWN_U : 0) | (seam_u ? F_SEAM_U : 0) | (cmask * F_CON0) | (own_p ? F_OWN_P : 0) |
-                             (seam_p ? F_SEAM_P : 0) | (pcon ? F_PCON : 0) | ((i == 0 && hasW) ? F_W : 0) |
-                             ((j == 0 && hasS) ? F_S : 0) | (i == K ? F_IK : 0) | (j == K ? F_JK : 0) |
-                             ((i < NP && j < NP) ? F_PTH : 0) | (i == KP ? F_IKP : 0) | (j == KP ? F_JKP : 0);
+                             (seam_p ? F_SEAM_P : 0) | (pcon ? F_PCON : 0) | ((active && i == 0 && hasW) ? F_W : 0) |
+                             ((active && j == 0 && hasS) ? F_S : 0) | ((active && i == K) ? F_IK : 0) |
+                             ((active && j == K) ? F_JK : 0) | ((active && i < NP && j < NP) ? F_PTH : 0) |
+                             (i == KP ? F_IKP : 0) | (j == KP ? F_JKP : 0);
 
-      // this thread's row / column of the collocation derivative (y direction)
-      double Drow[N], Dcol[N];
-#pragma unroll
-      for (int m = 0; m < N; ++m)
-        {
-          Drow[m] = A.D[j * N + m]; // (runtime row: full matrix in memory)
-          Dcol[m] = A.D[m * N + j];
-        }
       const double wab = A.det * A.w[i] * A.w[j];
 
-      // addresses = wave-uniform base pointer (scalar registers) + 32-bit per-thread element offset
+      // addresses = wave-uniform base pointer (scalar registers) + 32-bit per-lane element offset
       const unsigned ubase = (unsigned)((J * A.nnx + I) * 3), pbase = (unsigned)(Jp * A.npx + Ip);
       const size_t   plane_u = (size_t)A.nny * A.nnx * 3, plane_p = (size_t)A.npy * A.npx;
-      const unsigned loff = (unsigned)((cy * A.ncx + cx) * (NLIN * N3) + j * N + i); // + uniform layer / comp / point part
-      auto lidx = [&](const int d, const int c, const int jj, const int ii) {
-        return ((cell * 3 + d) * N + c) * NL + jj * N + ii;
-      };
-      auto pidx = [&](const int c, const int jj, const int ii) { return (cell * N + c) * NL + jj * N + ii; };
+      const unsigned loff = (unsigned)((cy * A.ncx + cx) * (NLIN * N3) + lc); // + uniform layer / comp / plane part
+
+      // wave-private LDS: values [4][N] planes of PLS slots, exchange [6] planes; slot of this lane = l
+      double *const VAL = lds + L_WAVE + wave * (VALW + TGW) + cw * (4 * N * PLS);
+      double *const TG  = lds + L_WAVE + wave * (VALW + TGW) + VALW + cw * (6 * PLS);
+      double *const PUB = lds + L_WAVE + 4 * (VALW + TGW); // [buffer 2][E | N][cell][j or i][4][k]
+      const int     xl = j * N, yl = i;                    // first element of my x-line / y-line in a plane
 
       // store of one owned velocity node (3 components) / pressure node
       auto emit_u = [&](const unsigned fl, const int Kz, const int lp, const double *v, const bool ztop) {
@@ -245,483 +357,499 @@ namespace adaflo_hip
           srcp_top = (A.src_p + (size_t)(KP * cz0) * plane_p)[pbase];
       }
 
+      constexpr int NST = LIN_MODE == 0 ? 12 : (LIN_MODE == 1 ? 4 : 0); // state doubles per point
+      double        st[NST > 0 ? NST : 1];                               // state of the plane to come
+      // nodal z-lines of the layer to come (planes 1..K; plane 0 is the previous layer's top plane)
+      double Un[3][N], Pn[N];
+      auto   load_nodes = [&](const int czn, const unsigned ubase, const unsigned pbase) {
+#pragma unroll
+        for (int k = 1; k < N; ++k)
+          {
+            const double *pl = A.src_u + (size_t)min(K * czn + k, A.nnz - 1) * plane_u;
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+              Un[d][k] = pl[ubase + d];
+          }
+        if (WITH_P)
+          {
+#pragma unroll
+            for (int k = 1; k < NP; ++k)
+              Pn[k] = (A.src_p + (size_t)min(KP * czn + k, A.npz - 1) * plane_p)[pbase];
+          }
+      };
+      auto load_state = [&](const double *ln, const unsigned loff) {
+#pragma unroll
+        for (int e = 0; e < NST; ++e)
+          st[e] = (ln + e * N3)[loff];
+      };
+      load_nodes(cz0, ubase, pbase);
+
+      const unsigned a_tab = lds_byte_addr(lds), a_val = lds_byte_addr(VAL), a_tg = lds_byte_addr(TG);
+      const unsigned a_x = a_val + 8 * xl, a_y = a_val + 8 * yl, a_own = a_val + 8 * l;
+
       for (int layer = 0; layer < nl; ++layer)
         {
           const int cz = cz0 + layer;
-          // ---- nodal values of my z-line (read_dof_values: constrained entries read as zero) ----
-          double U[3][N], P[N];
-#pragma unroll
-          for (int d = 0; d < 3; ++d)
-            U[d][0] = src_top[d];
-          P[0] = srcp_top;
-#pragma unroll
-          for (int k = 1; k < N; ++k)
-            {
-              const double *pl = A.src_u + (size_t)(K * cz + k) * plane_u;
-#pragma unroll
-              for (int d = 0; d < 3; ++d)
-                U[d][k] = pl[ubase + d];
-            }
-          P[KP] = 0.;
-          if (WITH_P)
-            {
-#pragma unroll
-              for (int k = 1; k < NP; ++k)
-                P[k] = (A.src_p + (size_t)(KP * cz + k) * plane_p)[pbase];
-            }
+          // opaque copies: keeps the per-lane rows / predicates from being hoisted out of the layer
+          // loop (they would stay live across the quadrature loop)
+          int ro_i = i, ro_j = j;
+          asm volatile("" : "+v"(ro_i), "+v"(ro_j));
           unsigned fl = flags;
           asm volatile("" : "+v"(fl));
+          // (same for the per-lane address parts: everything derived from them is recomputed where it
+          // is used instead of being kept in -- and spilled from -- registers across the whole loop)
+          unsigned ub_ = ubase, pb_ = pbase, lo_ = loff, ax_ = a_x, ay_ = a_y, ao_ = a_own, atg_ = a_tg, atab_ = a_tab;
+          asm volatile("" : "+v"(ub_), "+v"(pb_), "+v"(lo_), "+v"(ax_), "+v"(ay_), "+v"(ao_), "+v"(atg_), "+v"(atab_));
+          const unsigned a_ri = atab_ + 8 * N * ro_i, a_rj = atab_ + 8 * N * ro_j;    // row i / j of S (D: + 8 L_TAB_D)
+          const unsigned a_ci = atab_ + 8 * ro_i, a_cj = atab_ + 8 * ro_j;            // column i / j
+          const unsigned a_pri = atab_ + 8 * (L_TAB_SP + NP * ro_i), a_prj = atab_ + 8 * (L_TAB_SP + NP * ro_j);
+          const unsigned a_pci = atab_ + 8 * (L_TAB_SP + min(ro_i, KP)), a_pcj = atab_ + 8 * (L_TAB_SP + min(ro_j, KP));
+
+          // ---- nodal values of my z-line (read_dof_values: constrained entries read as zero) ----
+          {
+            double U[3][N], P[N];
 #pragma unroll
+            for (int d = 0; d < 3; ++d)
+              {
+                U[d][0] = src_top[d];
+#pragma unroll
+                for (int k = 1; k < N; ++k)
+                  U[d][k] = Un[d][k];
+              }
+            P[0]  = srcp_top;
+            P[KP] = 0.;
+            if (WITH_P)
+              {
+#pragma unroll
+                for (int k = 1; k < NP; ++k)
+                  P[k] = Pn[k];
+              }
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+              {
+                src_top[d] = U[d][K];
+                const bool zlo = cz == 0 && (A.con_u >> (12 + d) & 1), zhi = cz == A.ncz - 1 && (A.con_u >> (15 + d) & 1);
+                if (fl & (F_CON0 << d))
+                  {
+#pragma unroll
+                    for (int k = 0; k < N; ++k)
+                      U[d][k] = 0.;
+                  }
+                if (zlo)
+                  U[d][0] = 0.;
+                if (zhi)
+                  U[d][K] = 0.;
+              }
+            srcp_top = P[KP];
+            if (WITH_P)
+              {
+                if (fl & F_PCON)
+                  {
+#pragma unroll
+                    for (int k = 0; k < NP; ++k)
+                      P[k] = 0.;
+                  }
+                if (cz == 0 && (A.con_p >> 4 & 1))
+                  P[0] = 0.;
+                if (cz == A.ncz - 1 && (A.con_p >> 5 & 1))
+                  P[KP] = 0.;
+              }
+
+            // ---- Z: nodal z-line -> Gauss points (registers), hand over to the x contraction ----
+            {
+              ctab_t tz = (ctab_t)A.tab; // (opaque copy: the coefficients are re-loaded per phase, not spilled)
+              asm volatile("" : "+s"(tz));
+              if (slot_ok)
+                {
+#pragma unroll
+                  for (int d = 0; d < 3; ++d)
+                    {
+#pragma unroll
+                      for (int c = 0; c < N; ++c)
+                        {
+                          double s = 0.;
+#pragma unroll
+                          for (int k = 0; k < N; ++k)
+                            s += symS(tz, c, k) * U[d][k];
+                          VAL[(d * N + c) * PLS + l] = s;
+                        }
+                      HO_FENCE();
+                    }
+                  if (WITH_P)
+                    {
+#pragma unroll
+                      for (int c = 0; c < N; ++c)
+                        {
+                          double s = 0.;
+#pragma unroll
+                          for (int k = 0; k < NP; ++k)
+                            s += symSp(tz, c, k) * P[k];
+                          VAL[(3 * N + c) * PLS + l] = s;
+                        }
+                    }
+                }
+            }
+          }
+          // the state of the first quadrature plane arrives during the x / y contractions
+          const double *lin = A.lin + (size_t)cz * A.ncy * A.ncx * (NLIN * N3);
+          load_state(lin, lo_);
+          wave_sync();
+          // ---- X: lane (a,b) contracts the x-line (., b) of every plane with row a of S ---------
+#pragma unroll 1
           for (int d = 0; d < 3; ++d)
             {
-              src_top[d] = U[d][K];
-              const bool zlo = cz == 0 && (A.con_u >> (12 + d) & 1), zhi = cz == A.ncz - 1 && (A.con_u >> (15 + d) & 1);
-              if (fl & (F_CON0 << d))
+              double T[N];
+              ho_contract<N, N, 1, PLS, 1>(ax_ + d * (8 * N * PLS), a_ri, T);
+              wave_sync();
+              if (slot_ok)
                 {
 #pragma unroll
-                  for (int k = 0; k < N; ++k)
-                    U[d][k] = 0.;
+                  for (int c = 0; c < N; ++c)
+                    VAL[(d * N + c) * PLS + l] = T[c];
                 }
-              if (zlo)
-                U[d][0] = 0.;
-              if (zhi)
-                U[d][K] = 0.;
             }
-          srcp_top = P[KP];
           if (WITH_P)
             {
-              if (fl & F_PCON)
+              double T[N];
+              ho_contract<N, NP, 1, PLS, 1>(ax_ + 3 * (8 * N * PLS), a_pri, T);
+              wave_sync();
+              if (slot_ok)
                 {
 #pragma unroll
-                  for (int k = 0; k < NP; ++k)
-                    P[k] = 0.;
+                  for (int c = 0; c < N; ++c)
+                    VAL[(3 * N + c) * PLS + l] = T[c];
                 }
-              if (cz == 0 && (A.con_p >> 4 & 1))
-                P[0] = 0.;
-              if (cz == A.ncz - 1 && (A.con_p >> 5 & 1))
-                P[KP] = 0.;
             }
+          wave_sync();
+          // ---- Y: the y-line (a, .) with row b of S: values at my quadrature line ---------------
+          // (a component's planes are only read by its own contraction: write back per component)
+#pragma unroll 1
+          for (int d = 0; d < 3; ++d)
+            {
+              double T[N];
+              ho_contract<N, N, N, PLS, 1>(ay_ + d * (8 * N * PLS), a_rj, T);
+              wave_sync();
+              if (slot_ok)
+                {
+#pragma unroll
+                  for (int c = 0; c < N; ++c)
+                    VAL[(d * N + c) * PLS + l] = T[c];
+                }
+            }
+          if (WITH_P)
+            {
+              double T[N];
+              ho_contract<N, NP, N, PLS, 1>(ay_ + 3 * (8 * N * PLS), a_prj, T);
+              wave_sync();
+              if (slot_ok)
+                {
+#pragma unroll
+                  for (int c = 0; c < N; ++c)
+                    VAL[(3 * N + c) * PLS + l] = T[c];
+                }
+            }
+          wave_sync();
 
-          // ---- Z: nodal z-line -> Gauss points (registers), hand over to the y sweep ----------
+          // ---- quadrature planes: gradients, physics (navier_stokes_matrix.cc:702-893), -------
+          // ---- transposed collocation derivatives                                        -------
+          double R[3][N];
+#pragma unroll
+          for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int c = 0; c < N; ++c)
+              R[d][c] = 0.;
           {
+            ctab_t tz = (ctab_t)A.tab;
+            asm volatile("" : "+s"(tz));
+#pragma unroll 1
+            for (int c = 0; c < N; ++c)
+              {
+                double Dz[N], ec[N]; // row c of D, row c of the identity (wave-uniform)
 #pragma unroll
-              for (int d = 0; d < 3; ++d)
+                for (int m = 0; m < N; ++m)
+                  {
+                    Dz[m] = tz[N * N + c * N + m];
+                    ec[m] = c == m ? 1. : 0.;
+                  }
+                const double jxw = wab * tz[2 * N * N + N * NP + c];
+                double       g[3][3], u[3], pq = 0.;
+                {
+                  // rows a / b of D, then x-line, y-line and own value of plane c, software-pipelined
+                  // over the components
+                  const unsigned off = (unsigned)c * (PLS * 8);
+                  const unsigned xb = ax_ + off, yb = ay_ + off, ob = ao_ + off;
+                  double         Dx[N], Dy[N], lx[3][N], ly[3][N], lz[3][N];
+                  rd_line<8 * L_TAB_D, 1>(a_ri, Dx);
+                  rd_line<8 * L_TAB_D, 1>(a_rj, Dy);
+                  auto issue = [&](auto dt) {
+                    constexpr int d = decltype(dt)::value;
+                    rd_line<8 * d * N * PLS, 1>(xb, lx[d]);
+                    rd_line<8 * d * N * PLS, N>(yb, ly[d]);
+                    rd_line<8 * d * N * PLS, PLS>(ao_, lz[d]); // my z-line (all planes)
+                    u[d] = ds_rd<8 * d * N * PLS>(ob);
+                  };
+                  auto grad = [&](auto dt, auto cnt) {
+                    constexpr int d = decltype(dt)::value, CNT = decltype(cnt)::value;
+                    ds_wait<CNT>(lx[d]);
+                    ds_wait<CNT>(ly[d]);
+                    ds_wait<CNT>(lz[d]);
+                    ds_wait1<CNT>(u[d]);
+                    if (d == 0)
+                      {
+                        ds_wait<CNT>(Dx);
+                        ds_wait<CNT>(Dy);
+                      }
+                    double sx = 0., sy = 0., sz = 0.;
 #pragma unroll
-                for (int c = 0; c < N; ++c)
+                    for (int m = 0; m < N; ++m)
+                      {
+                        sx += Dx[m] * lx[d][m];
+                        sy += Dy[m] * ly[d][m];
+                        sz += Dz[m] * lz[d][m];
+                      }
+                    g[d][0] = sx * A.ih[0];
+                    g[d][1] = sy * A.ih[1];
+                    g[d][2] = sz * A.ih[2];
+                  };
+                  using I0 = std::integral_constant<int, 0>;
+                  using I1 = std::integral_constant<int, 1>;
+                  using I2 = std::integral_constant<int, 2>;
+                  constexpr int PER = 3 * N + 1, NPQ = WITH_P ? 1 : 0;
+                  issue(I0{});
+                  issue(I1{});
+                  grad(I0{}, std::integral_constant<int, PER>{});
+                  issue(I2{});
+                  if (WITH_P)
+                    pq = ds_rd<8 * 3 * N * PLS>(ob);
+                  grad(I1{}, std::integral_constant<int, PER + NPQ>{});
+                  grad(I2{}, std::integral_constant<int, NPQ>{});
+                  if (WITH_P)
+                    ds_wait1<0>(pq);
+                }
+                const double div = g[0][0] + g[1][1] + g[2][2];
+                double       conv[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                  {
+                    double res = 0.;
+                    if (LIN_MODE == 0) // Newton :802-816; st = (u_lin[3], grad u_lin[3][3])
+                      {
+                        res = A.beta * (div * st[d] + (st[3] + st[7] + st[11]) * u[d]);
+#pragma unroll
+                        for (int e = 0; e < 3; ++e)
+                          res += st[e] * g[d][e] + u[e] * st[3 + 3 * d + e];
+                      }
+                    else if (LIN_MODE == 1) // Picard-type :817-826; st = (u_lin[3], div u_lin)
+                      {
+                        res = A.beta * st[3] * u[d];
+#pragma unroll
+                        for (int e = 0; e < 3; ++e)
+                          res += st[e] * g[d][e];
+                      }
+                    conv[d] = (A.cA * u[d] + A.cB * res) * jxw; // :717,:827-835
+                  }
+                // the state registers are free: fetch the next plane's state; it arrives while this
+                // plane's transposed derivatives and the next plane's gradients are computed
+                HO_FENCE();
+                if (c + 1 < N)
+                  load_state(lin + (c + 1) * NL, lo_);
+                const double diag = A.tau_gd * div - pq;
+                double       tgx[3], tgy[3];
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+                  {
+                    // :859-892 row d of tmu (grad u + grad u^T) + (tau_gd div - p) I, times JxW J^{-1}
+                    tgx[d]           = (A.tmu * (g[d][0] + g[0][d]) + (d == 0 ? diag : 0.)) * (jxw * A.ih[0]);
+                    tgy[d]           = (A.tmu * (g[d][1] + g[1][d]) + (d == 1 ? diag : 0.)) * (jxw * A.ih[1]);
+                    const double tgz = (A.tmu * (g[d][2] + g[2][d]) + (d == 2 ? diag : 0.)) * (jxw * A.ih[2]);
+#pragma unroll
+                    for (int m = 0; m < N; ++m)
+                      R[d][m] += Dz[m] * tgz; // D^T in z: registers
+                  }
+                wave_sync();
+                if (slot_ok)
+                  {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+                      {
+                        TG[(2 * d) * PLS + l]     = tgx[d];
+                        TG[(2 * d + 1) * PLS + l] = tgy[d];
+                      }
+                    if (WITH_P)
+                      VAL[(3 * N + c) * PLS + l] = -div * jxw; // :853-856 (the slot's p value is consumed)
+                  }
+                wave_sync();
+                {
+                  const unsigned xb = atg_ + 8 * xl, yb = atg_ + 8 * yl;
+                  double         DTx[N], DTy[N], lx[3][N], ly[3][N];
+                  rd_line<8 * L_TAB_D, N>(a_ci, DTx); // columns a / b of D
+                  rd_line<8 * L_TAB_D, N>(a_cj, DTy);
+                  auto issue = [&](auto dt) {
+                    constexpr int d = decltype(dt)::value;
+                    rd_line<8 * (2 * d) * PLS, 1>(xb, lx[d]);
+                    rd_line<8 * (2 * d + 1) * PLS, N>(yb, ly[d]);
+                  };
+                  auto accumulate = [&](auto dt, auto cnt) {
+                    constexpr int d = decltype(dt)::value, CNT = decltype(cnt)::value;
+                    ds_wait<CNT>(lx[d]);
+                    ds_wait<CNT>(ly[d]);
+                    if (d == 0)
+                      {
+                        ds_wait<CNT>(DTx);
+                        ds_wait<CNT>(DTy);
+                      }
+                    double s = conv[d];
+#pragma unroll
+                    for (int m = 0; m < N; ++m)
+                      s += DTx[m] * lx[d][m] + DTy[m] * ly[d][m];
+#pragma unroll
+                    for (int m = 0; m < N; ++m)
+                      R[d][m] += ec[m] * s; // (R[d][c] += s with a run-time c)
+                  };
+                  using I0 = std::integral_constant<int, 0>;
+                  using I1 = std::integral_constant<int, 1>;
+                  using I2 = std::integral_constant<int, 2>;
+                  issue(I0{});
+                  issue(I1{});
+                  accumulate(I0{}, std::integral_constant<int, 2 * N>{});
+                  issue(I2{});
+                  accumulate(I1{}, std::integral_constant<int, 2 * N>{});
+                  accumulate(I2{}, std::integral_constant<int, 0>{});
+                }
+              }
+          }
+          // the nodal z-lines of the next layer arrive during the transposed interpolation
+          load_nodes(cz + 1, ub_, pb_);
+
+          // ---- transposed interpolation: x and y through LDS, z in registers ---------------------
+          double Rn[3][N], Rpn[N];
+          {
+            wave_sync();
+            if (slot_ok)
+              {
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+#pragma unroll
+                  for (int c = 0; c < N; ++c)
+                    VAL[(d * N + c) * PLS + l] = R[d][c];
+              }
+            wave_sync();
+#pragma unroll 1
+            for (int d = 0; d < 3; ++d)
+              {
+                double T[N];
+                ho_contract<N, N, 1, PLS, N>(ax_ + d * (8 * N * PLS), a_ci, T);
+                wave_sync();
+                if (slot_ok)
+                  {
+#pragma unroll
+                    for (int c = 0; c < N; ++c)
+                      VAL[(d * N + c) * PLS + l] = T[c];
+                  }
+              }
+            if (WITH_P)
+              {
+                double T[N];
+                ho_contract<N, N, 1, PLS, NP>(ax_ + 3 * (8 * N * PLS), a_pci, T);
+                wave_sync();
+                if (slot_ok)
+                  {
+#pragma unroll
+                    for (int c = 0; c < N; ++c)
+                      VAL[(3 * N + c) * PLS + l] = T[c];
+                  }
+              }
+            wave_sync();
+            ctab_t tz = (ctab_t)A.tab;
+            asm volatile("" : "+s"(tz));
+            // (rolled over the components: the results go back to the lane's own LDS slots and are
+            // picked up again for the combine / emit step; everything unrolled kept ~120 more VGPRs live)
+#pragma unroll 1
+            for (int d = 0; d < 3; ++d)
+              {
+                double T[N], Z[N];
+                ho_contract<N, N, N, PLS, N>(ay_ + d * (8 * N * PLS), a_cj, T);
+#pragma unroll
+                for (int k = 0; k < N; ++k)
                   {
                     double s = 0.;
 #pragma unroll
-                    for (int k = 0; k < N; ++k)
-                      s += Sv(c, k) * U[d][k];
-                    ARR0[lidx(d, c, j, i)] = s;
-                    HO_FENCE();
+                    for (int c = 0; c < N; ++c)
+                      s += symS(tz, c, k) * T[c];
+                    Z[k] = s;
                   }
-              if (WITH_P)
-                {
-#pragma unroll
-                  for (int c = 0; c < N; ++c)
-                    {
-                      double s = 0.;
-#pragma unroll
-                      for (int k = 0; k < NP; ++k)
-                        s += Spv(c, k) * P[k];
-                      PARR[pidx(c, j, i)] = s;
-                    }
-                }
-            }
-          __syncthreads();
-          // ---- Y: line (x = i, level c = j) along y ------------------------------------------
-          {
-              const int ii = i, c = j;
-#pragma unroll
-              for (int d = 0; d < 3; ++d)
-                {
-                  double in[N];
-#pragma unroll
-                  for (int m = 0; m < N; ++m)
-                    in[m] = ARR0[lidx(d, c, m, ii)];
-#pragma unroll
-                  for (int b = 0; b < N; ++b)
-                    {
-                      double s = 0.;
-#pragma unroll
-                      for (int m = 0; m < N; ++m)
-                        s += Sv(b, m) * in[m];
-                      ARR0[lidx(d, c, b, ii)] = s;
-                    }
-                  HO_FENCE();
-                }
-              if (WITH_P && ii < NP)
-                {
-                  double in[NP];
-#pragma unroll
-                  for (int m = 0; m < NP; ++m)
-                    in[m] = PARR[pidx(c, m, ii)];
-#pragma unroll
-                  for (int b = 0; b < N; ++b)
-                    {
-                      double s = 0.;
-#pragma unroll
-                      for (int m = 0; m < NP; ++m)
-                        s += Spv(b, m) * in[m];
-                      PARR[pidx(c, b, ii)] = s;
-                    }
-                }
-            }
-          __syncthreads();
-          // ---- X: line (y = i, level c = j) along x; values and d/dx at the Gauss points -------
-          {
-              const int b = i, c = j;
-#pragma unroll
-              for (int d = 0; d < 3; ++d)
-                {
-                  double in[N], v[N];
-#pragma unroll
-                  for (int m = 0; m < N; ++m)
-                    in[m] = ARR0[lidx(d, c, b, m)];
-#pragma unroll
-                  for (int a = 0; a < N; ++a)
-                    {
-                      double s = 0.;
-#pragma unroll
-                      for (int m = 0; m < N; ++m)
-                        s += Sv(a, m) * in[m];
-                      v[a] = s;
-                    }
-#pragma unroll
-                  for (int a = 0; a < N; ++a)
-                    {
-                      double s = 0.;
-#pragma unroll
-                      for (int m = 0; m < N; ++m)
-                        s += Dv(a, m) * v[m];
-                      ARR0[lidx(d, c, b, a)] = v[a];
-                      ARR1[lidx(d, c, b, a)] = s;
-                    }
-                  HO_FENCE();
-                }
-              if (WITH_P)
-                {
-                  double in[NP];
-#pragma unroll
-                  for (int m = 0; m < NP; ++m)
-                    in[m] = PARR[pidx(c, b, m)];
-#pragma unroll
-                  for (int a = 0; a < N; ++a)
-                    {
-                      double s = 0.;
-#pragma unroll
-                      for (int m = 0; m < NP; ++m)
-                        s += Spv(a, m) * in[m];
-                      PARR[pidx(c, b, a)] = s;
-                    }
-                }
-            }
-          __syncthreads();
-          // ---- G: my quadrature line (a = i, b = j, c = 0..k): values and real-space gradients --
-          double val[3][N], gx[3][N], gy[3][N], gz[3][N], pv[N];
-#pragma unroll
-          for (int d = 0; d < 3; ++d)
-            {
-#pragma unroll
-              for (int c = 0; c < N; ++c)
-                {
-                  double s = 0.;
-#pragma unroll
-                  for (int m = 0; m < N; ++m)
-                    s += Drow[m] * ARR0[lidx(d, c, m, i)];
-                  gy[d][c]  = s * A.ih[1];
-                  gx[d][c]  = ARR1[lidx(d, c, j, i)] * A.ih[0];
-                  val[d][c] = ARR0[lidx(d, c, j, i)];
-                  HO_FENCE();
-                }
-#pragma unroll
-              for (int c = 0; c < N; ++c)
-                {
-                  double s = 0.;
-#pragma unroll
-                  for (int m = 0; m < N; ++m)
-                    s += Dv(c, m) * val[d][m];
-                  gz[d][c] = s * A.ih[2];
-                }
-            }
-#pragma unroll
-          for (int c = 0; c < N; ++c)
-            pv[c] = WITH_P ? PARR[pidx(c, j, i)] : 0.;
-          __syncthreads(); // everybody has read ARR0 / ARR1 / PARR
-
-          // ---- quadrature-point operation (navier_stokes_matrix.cc:702-893) -------------------
-          const double *lin = A.lin + (size_t)cz * A.ncy * A.ncx * (NLIN * N3);
-#pragma unroll
-          for (int c = 0; c < N; ++c)
-            {
-              double lu[3] = {0., 0., 0.}, lg[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
-              if (LIN_MODE != 2)
-                {
-#pragma unroll
-                  for (int d = 0; d < 3; ++d)
-                    lu[d] = (lin + d * N3 + c * NL)[loff];
-                  if (LIN_MODE == 0)
-                    {
-#pragma unroll
-                      for (int d = 0; d < 3; ++d)
-#pragma unroll
-                        for (int e = 0; e < 3; ++e)
-                          lg[d][e] = (lin + (3 + 3 * d + e) * N3 + c * NL)[loff];
-                    }
-                  else
-                    lg[0][0] = (lin + 3 * N3 + c * NL)[loff]; // div of the linearisation point
-                }
-              const double jxw = wab * A.w[c];
-              const double u[3]    = {val[0][c], val[1][c], val[2][c]};
-              const double g[3][3] = {{gx[0][c], gy[0][c], gz[0][c]}, {gx[1][c], gy[1][c], gz[1][c]}, {gx[2][c], gy[2][c], gz[2][c]}};
-              const double div = g[0][0] + g[1][1] + g[2][2];
-              double       conv[3];
-#pragma unroll
-              for (int d = 0; d < 3; ++d)
-                {
-                  double res = 0.;
-                  if (LIN_MODE == 0) // Newton :802-816
-                    {
-                      res = A.beta * (div * lu[d] + (lg[0][0] + lg[1][1] + lg[2][2]) * u[d]);
-#pragma unroll
-                      for (int e = 0; e < 3; ++e)
-                        res += lu[e] * g[d][e] + u[e] * lg[d][e];
-                    }
-                  else if (LIN_MODE == 1) // Picard-type :817-826
-                    {
-                      res = A.beta * lg[0][0] * u[d];
-#pragma unroll
-                      for (int e = 0; e < 3; ++e)
-                        res += lu[e] * g[d][e];
-                    }
-                  conv[d] = A.cA * u[d] + A.cB * res; // :717,:827-835
-                }
-              const double diag = A.tau_gd * div - (WITH_P ? pv[c] : 0.);
-              pv[c]             = -div * jxw; // :853-856
-#pragma unroll
-              for (int d = 0; d < 3; ++d)
-                {
-                  val[d][c] = conv[d] * jxw;
-                  // :859-892 row d of tmu (grad u + grad u^T) + (tau_gd div - p) I, times JxW J^{-1}
-                  gx[d][c] = (A.tmu * (g[d][0] + g[0][d]) + (d == 0 ? diag : 0.)) * (jxw * A.ih[0]);
-                  gy[d][c] = (A.tmu * (g[d][1] + g[1][d]) + (d == 1 ? diag : 0.)) * (jxw * A.ih[1]);
-                  gz[d][c] = (A.tmu * (g[d][2] + g[2][d]) + (d == 2 ? diag : 0.)) * (jxw * A.ih[2]);
-                }
-              HO_FENCE();
-            }
-
-          // ---- integrate: transposed derivative in z (registers) and y (LDS), then the sweeps ---
-          {
-#pragma unroll
-              for (int d = 0; d < 3; ++d)
-#pragma unroll
-                for (int c = 0; c < N; ++c)
-                  ARR1[lidx(d, c, j, i)] = gy[d][c];
-            }
-          __syncthreads();
-#pragma unroll
-          for (int d = 0; d < 3; ++d)
-            {
-              double acc[N];
-#pragma unroll
-              for (int c = 0; c < N; ++c)
-                {
-                  double s = val[d][c];
-#pragma unroll
-                  for (int m = 0; m < N; ++m)
-                    s += Dcol[m] * ARR1[lidx(d, c, m, i)] + Dv(m, c) * gz[d][m];
-                  acc[c] = s;
-                  HO_FENCE();
-                }
-#pragma unroll
-              for (int c = 0; c < N; ++c)
-                val[d][c] = acc[c];
-            }
-          __syncthreads(); // ARR1 is read, it now takes the x-derivative test values
-          {
-#pragma unroll
-              for (int d = 0; d < 3; ++d)
-#pragma unroll
-                for (int c = 0; c < N; ++c)
+                wave_sync();
+                if (slot_ok)
                   {
-                    ARR0[lidx(d, c, j, i)] = val[d][c];
-                    ARR1[lidx(d, c, j, i)] = gx[d][c];
+#pragma unroll
+                    for (int k = 0; k < N; ++k)
+                      VAL[(d * N + k) * PLS + l] = Z[k];
                   }
-              if (WITH_P)
-                {
+              }
 #pragma unroll
-                  for (int c = 0; c < N; ++c)
-                    PARR[pidx(c, j, i)] = pv[c];
-                }
-            }
-          __syncthreads();
-          // ---- XT: line (y = i, level c = j): + D^T (x part), then S^T along x ------------------
-          {
-              const int b = i, c = j;
+            for (int k = 0; k < N; ++k)
+              Rpn[k] = 0.;
+            if (WITH_P)
+              {
+                double T[N];
+                ho_contract<N, N, N, PLS, NP>(ay_ + 3 * (8 * N * PLS), a_pcj, T);
+                if (fl & F_PTH)
+                  {
 #pragma unroll
-              for (int d = 0; d < 3; ++d)
-                {
-                  double t[N], gl[N];
+                    for (int k = 0; k < NP; ++k)
+                      {
+                        double s = 0.;
 #pragma unroll
-                  for (int m = 0; m < N; ++m)
-                    {
-                      t[m]  = ARR0[lidx(d, c, b, m)];
-                      gl[m] = ARR1[lidx(d, c, b, m)];
-                    }
-#pragma unroll
-                  for (int a = 0; a < N; ++a)
-                    {
-                      double s = t[a];
-#pragma unroll
-                      for (int m = 0; m < N; ++m)
-                        s += Dv(m, a) * gl[m];
-                      t[a] = s;
-                    }
-#pragma unroll
-                  for (int ii = 0; ii < N; ++ii)
-                    {
-                      double s = 0.;
-#pragma unroll
-                      for (int m = 0; m < N; ++m)
-                        s += Sv(m, ii) * t[m];
-                      ARR0[lidx(d, c, b, ii)] = s;
-                    }
-                  HO_FENCE();
-                }
-              if (WITH_P)
-                {
-                  double t[N];
-#pragma unroll
-                  for (int m = 0; m < N; ++m)
-                    t[m] = PARR[pidx(c, b, m)];
-#pragma unroll
-                  for (int ii = 0; ii < NP; ++ii)
-                    {
-                      double s = 0.;
-#pragma unroll
-                      for (int m = 0; m < N; ++m)
-                        s += Spv(m, ii) * t[m];
-                      PARR[pidx(c, b, ii)] = s;
-                    }
-                }
-            }
-          __syncthreads();
-          // ---- YT: line (x = i, level c = j): S^T along y ---------------------------------------
-          {
-              const int ii = i, c = j;
-#pragma unroll
-              for (int d = 0; d < 3; ++d)
-                {
-                  double t[N];
-#pragma unroll
-                  for (int m = 0; m < N; ++m)
-                    t[m] = ARR0[lidx(d, c, m, ii)];
-#pragma unroll
-                  for (int jj = 0; jj < N; ++jj)
-                    {
-                      double s = 0.;
-#pragma unroll
-                      for (int m = 0; m < N; ++m)
-                        s += Sv(m, jj) * t[m];
-                      ARR0[lidx(d, c, jj, ii)] = s;
-                    }
-                  HO_FENCE();
-                }
-              if (WITH_P && ii < NP)
-                {
-                  double t[N];
-#pragma unroll
-                  for (int m = 0; m < N; ++m)
-                    t[m] = PARR[pidx(c, m, ii)];
-#pragma unroll
-                  for (int jj = 0; jj < NP; ++jj)
-                    {
-                      double s = 0.;
-#pragma unroll
-                      for (int m = 0; m < N; ++m)
-                        s += Spv(m, jj) * t[m];
-                      PARR[pidx(c, jj, ii)] = s;
-                    }
-                }
-            }
-          __syncthreads();
-          // ---- ZT: my nodal z-line: S^T along z (registers) -------------------------------------
-          double R[3][N], Rp[N];
+                        for (int c = 0; c < N; ++c)
+                          s += symSp(tz, c, k) * T[c];
+                        Rpn[k] = s;
+                      }
+                  }
+              }
+          }
+
+          wave_sync();
 #pragma unroll
           for (int d = 0; d < 3; ++d)
-            {
-              double t[N];
 #pragma unroll
-              for (int c = 0; c < N; ++c)
-                t[c] = ARR0[lidx(d, c, j, i)];
-#pragma unroll
-              for (int k = 0; k < N; ++k)
-                {
-                  double s = 0.;
-#pragma unroll
-                  for (int c = 0; c < N; ++c)
-                    s += Sv(c, k) * t[c];
-                  R[d][k] = s;
-                }
-              HO_FENCE();
-            }
-#pragma unroll
-          for (int k = 0; k < N; ++k)
-            Rp[k] = 0.;
-          fl = flags;
-          asm volatile("" : "+v"(fl));
-          if (WITH_P && (fl & F_PTH))
-            {
-              double t[N];
-#pragma unroll
-              for (int c = 0; c < N; ++c)
-                t[c] = PARR[pidx(c, j, i)];
-#pragma unroll
-              for (int k = 0; k < NP; ++k)
-                {
-                  double s = 0.;
-#pragma unroll
-                  for (int c = 0; c < N; ++c)
-                    s += Spv(c, k) * t[c];
-                  Rp[k] = s;
-                }
-            }
-          // ---- combine the cells of the tile per owned node -------------------------------------
-          // (ARR1 was last read in XT, two barriers ago: its space now holds the published faces)
+            for (int k = 0; k < N; ++k)
+              Rn[d][k] = VAL[(d * N + k) * PLS + l];
+
+          // ---- combine the cells of the tile per owned node (one workgroup barrier per layer) ----
+          double *const PUB_E = PUB + (layer & 1) * (2 * PUBSZ), *const PUB_N = PUB_E + PUBSZ;
           {
-              if (fl & F_IK)
-                {
+            if (fl & F_IK)
+              {
 #pragma unroll
-                  for (int d = 0; d < 3; ++d)
+                for (int d = 0; d < 3; ++d)
 #pragma unroll
-                    for (int k = 0; k < N; ++k)
-                      PUB_E[((cell * N + j) * 4 + d) * N + k] = R[d][k];
-                }
-              if (fl & F_JK)
-                {
+                  for (int k = 0; k < N; ++k)
+                    PUB_E[((cell * N + j) * 4 + d) * N + k] = Rn[d][k];
+              }
+            if (fl & F_JK)
+              {
 #pragma unroll
-                  for (int d = 0; d < 3; ++d)
+                for (int d = 0; d < 3; ++d)
 #pragma unroll
-                    for (int k = 0; k < N; ++k)
-                      PUB_N[((cell * N + i) * 4 + d) * N + k] = R[d][k];
-                }
-              if (WITH_P && (fl & F_PTH))
-                {
-                  if (fl & F_IKP)
-                    {
+                  for (int k = 0; k < N; ++k)
+                    PUB_N[((cell * N + i) * 4 + d) * N + k] = Rn[d][k];
+              }
+            if (WITH_P && (fl & F_PTH))
+              {
+                if (fl & F_IKP)
+                  {
 #pragma unroll
-                      for (int k = 0; k < NP; ++k)
-                        PUB_E[((cell * N + j) * 4 + 3) * N + k] = Rp[k];
-                    }
-                  if (fl & F_JKP)
-                    {
+                    for (int k = 0; k < NP; ++k)
+                      PUB_E[((cell * N + j) * 4 + 3) * N + k] = Rpn[k];
+                  }
+                if (fl & F_JKP)
+                  {
 #pragma unroll
-                      for (int k = 0; k < NP; ++k)
-                        PUB_N[((cell * N + i) * 4 + 3) * N + k] = Rp[k];
-                    }
-                }
-            }
+                    for (int k = 0; k < NP; ++k)
+                      PUB_N[((cell * N + i) * 4 + 3) * N + k] = Rpn[k];
+                  }
+              }
+          }
           __syncthreads();
           // W neighbour's east face row j, S neighbour's north face column i, SW corner
           if (fl & F_W)
@@ -730,12 +858,12 @@ namespace adaflo_hip
               for (int d = 0; d < 3; ++d)
 #pragma unroll
                 for (int k = 0; k < N; ++k)
-                  R[d][k] += PUB_E[(((cell - 1) * N + j) * 4 + d) * N + k];
+                  Rn[d][k] += PUB_E[(((cell - 1) * N + j) * 4 + d) * N + k];
               if (WITH_P)
                 {
 #pragma unroll
                   for (int k = 0; k < NP; ++k)
-                    Rp[k] += PUB_E[(((cell - 1) * N + j) * 4 + 3) * N + k];
+                    Rpn[k] += PUB_E[(((cell - 1) * N + j) * 4 + 3) * N + k];
                 }
             }
           if (fl & F_S)
@@ -744,12 +872,12 @@ namespace adaflo_hip
               for (int d = 0; d < 3; ++d)
 #pragma unroll
                 for (int k = 0; k < N; ++k)
-                  R[d][k] += PUB_N[(((cell - TCX) * N + i) * 4 + d) * N + k];
+                  Rn[d][k] += PUB_N[(((cell - TCX) * N + i) * 4 + d) * N + k];
               if (WITH_P)
                 {
 #pragma unroll
                   for (int k = 0; k < NP; ++k)
-                    Rp[k] += PUB_N[(((cell - TCX) * N + i) * 4 + 3) * N + k];
+                    Rpn[k] += PUB_N[(((cell - TCX) * N + i) * 4 + 3) * N + k];
                 }
             }
           if ((fl & (F_W | F_S)) == (F_W | F_S))
@@ -758,88 +886,77 @@ namespace adaflo_hip
               for (int d = 0; d < 3; ++d)
 #pragma unroll
                 for (int k = 0; k < N; ++k)
-                  R[d][k] += PUB_E[(((cell - TCX - 1) * N + K) * 4 + d) * N + k];
+                  Rn[d][k] += PUB_E[(((cell - TCX - 1) * N + K) * 4 + d) * N + k];
               if (WITH_P)
                 {
 #pragma unroll
                   for (int k = 0; k < NP; ++k)
-                    Rp[k] += PUB_E[(((cell - TCX - 1) * N + KP) * 4 + 3) * N + k];
+                    Rpn[k] += PUB_E[(((cell - TCX - 1) * N + KP) * 4 + 3) * N + k];
                 }
             }
           // ---- emit the finished planes, carry the top plane -----------------------------------
-          R[0][0] += carry[0];
-          R[1][0] += carry[1];
-          R[2][0] += carry[2];
-          Rp[0] += carry_p;
-          // constrained rows only exist in tiles / layers at the domain boundary: everybody else takes
-          // the branch-light path (one exec region per store target instead of one per value)
-          const bool slow = __builtin_amdgcn_readfirstlane(__any((fl & (7 * F_CON0 | F_PCON)) != 0u)) ||
-                            (cz == 0 && ((A.con_u >> 12 & 7u) || (A.con_p >> 4 & 1u)));
-          if (slow)
+          Rn[0][0] += carry[0];
+          Rn[1][0] += carry[1];
+          Rn[2][0] += carry[2];
+          Rpn[0] += carry_p;
+          // every owned entry goes to dst or, on the high rim of the tile, to the slab ...
+          if (fl & F_OWN_U)
             {
+              const bool     seam   = (fl & F_SEAM_U) != 0u;
+              const unsigned r3     = rim_index_ho<TNX, TNY>(K * cxl + i, K * cyl + j) * 3;
+              double        *tp     = seam ? A.slab_u + (wgs * (K * A.LZ + 1) + K * layer) * (RIMU * 3) + r3 :
+                                             A.dst_u + (size_t)(K * cz) * plane_u + ub_;
+              const size_t   stride = seam ? (size_t)(RIMU * 3) : plane_u;
 #pragma unroll
               for (int k = 0; k < K; ++k)
-                {
-                  const double v[3] = {R[0][k], R[1][k], R[2][k]};
-                  emit_u(fl, K * cz + k, K * layer + k, v, false);
-                }
-              if (WITH_P)
-                {
 #pragma unroll
-                  for (int k = 0; k < KP; ++k)
-                    emit_p(fl, KP * cz + k, KP * layer + k, Rp[k], false);
-                }
+                for (int d = 0; d < 3; ++d)
+                  tp[k * stride + d] = Rn[d][k];
             }
-          else
+          if (WITH_P && A.integrate_p && (fl & F_OWN_P))
+            {
+              const bool     seam   = (fl & F_SEAM_P) != 0u;
+              const unsigned r      = rim_index_ho<TPX, TPY>(KP * cxl + i, KP * cyl + j);
+              double        *tp     = seam ? A.slab_p + (wgs * (KP * A.LZ + 1) + KP * layer) * RIMP + r :
+                                             A.dst_p + (size_t)(KP * cz) * plane_p + pb_;
+              const size_t   stride = seam ? (size_t)RIMP : plane_p;
+#pragma unroll
+              for (int k = 0; k < KP; ++k)
+                tp[k * stride] = Rpn[k];
+            }
+          // ... and constrained rows (tiles / layers at the domain boundary only) are then set to
+          // +-src (:250-255): a later store of the same lane to the same address, or an entry the
+          // fix-up kernel skips
+          if (__builtin_amdgcn_readfirstlane(__any((fl & (7 * F_CON0 | F_PCON)) != 0u)) ||
+              (cz == 0 && ((A.con_u >> 12 & 7u) || (A.con_p >> 4 & 1u))))
             {
               if (fl & F_OWN_U)
                 {
-                  if (fl & F_SEAM_U)
+#pragma unroll 1
+                  for (int k = 0; k < K; ++k)
                     {
-                      double *sl = A.slab_u + (wgs * (K * A.LZ + 1) + K * layer) * (RIMU * 3);
-                      const unsigned r3 = rim_index_ho<TNX, TNY>(K * cxl + i, K * cyl + j) * 3;
+                      const size_t po = (size_t)(K * cz + k) * plane_u + ub_;
 #pragma unroll
-                      for (int k = 0; k < K; ++k)
-#pragma unroll
-                        for (int d = 0; d < 3; ++d)
-                          sl[k * (RIMU * 3) + r3 + d] = R[d][k];
-                    }
-                  else
-                    {
-#pragma unroll
-                      for (int k = 0; k < K; ++k)
-                        {
-                          double *dp = A.dst_u + (size_t)(K * cz + k) * plane_u;
-#pragma unroll
-                          for (int d = 0; d < 3; ++d)
-                            dp[ubase + d] = R[d][k];
-                        }
+                      for (int d = 0; d < 3; ++d)
+                        if ((fl & (F_CON0 << d)) || (K * cz + k == 0 && (A.con_u >> (12 + d) & 1)))
+                          A.dst_u[po + d] = A.src_u[po + d];
                     }
                 }
               if (WITH_P && A.integrate_p && (fl & F_OWN_P))
                 {
-                  if (fl & F_SEAM_P)
+#pragma unroll 1
+                  for (int k = 0; k < KP; ++k)
                     {
-                      double *sl = A.slab_p + (wgs * (KP * A.LZ + 1) + KP * layer) * RIMP;
-                      const unsigned r = rim_index_ho<TPX, TPY>(KP * cxl + i, KP * cyl + j);
-#pragma unroll
-                      for (int k = 0; k < KP; ++k)
-                        sl[k * RIMP + r] = Rp[k];
-                    }
-                  else
-                    {
-#pragma unroll
-                      for (int k = 0; k < KP; ++k)
-                        (A.dst_p + (size_t)(KP * cz + k) * plane_p)[pbase] = Rp[k];
+                      const size_t po = (size_t)(KP * cz + k) * plane_p + pb_;
+                      if ((fl & F_PCON) || (KP * cz + k == 0 && (A.con_p >> 4 & 1)))
+                        A.dst_p[po] = -A.src_p[po];
                     }
                 }
             }
 #pragma unroll
           for (int d = 0; d < 3; ++d)
-            carry[d] = R[d][K];
-          carry_p = Rp[KP];
-          // (the next layer's Z stage writes ARR0 / PARR only; the publish area is rewritten
-          // after several barriers)
+            carry[d] = Rn[d][K];
+          carry_p = Rpn[KP];
         }
       // ---- top plane of the chunk -------------------------------------------------------------
       {
@@ -920,7 +1037,7 @@ namespace adaflo_hip
     __global__ __launch_bounds__(64) void ns_ho_fixup_kernel(const HOArgs A, const long n1, const long n2,
                                                              const long n3, const long n4)
     {
-      using C = HOCfg<K>;
+      using C = HOTile<K>;
       constexpr int TNX = K * C::TCX + 1, TNY = K * C::TCY + 1, TPX = (K - 1) * C::TCX + 1, TPY = (K - 1) * C::TCY + 1;
       for (long b = blockIdx.x; b < n1 + n2 + n3 + n4; b += gridDim.x)
         {
@@ -958,8 +1075,8 @@ namespace adaflo_hip
     int launch_ho(adaflo_ctx *ctx, const int op, double *dst_u, double *dst_p, const double *src_u,
                   const double *src_p)
     {
-      using C = HOCfg<K>;
-      constexpr int N = K + 1, NP = K, N3 = N * N * N, NCELL = C::TCX * C::TCY;
+      using C = HOTile<K>;
+      constexpr int N = K + 1, NP = K;
       constexpr int TNX = K * C::TCX + 1, TNY = K * C::TCY + 1, TPX = (K - 1) * C::TCX + 1, TPY = (K - 1) * C::TCY + 1;
       constexpr int RIMU = 2 * TNX + 2 * (TNY - 2), RIMP = 2 * TPX + 2 * (TPY - 2);
       HOArgs A{};
@@ -1019,6 +1136,23 @@ namespace adaflo_hip
       A.dst_u       = dst_u;
       A.dst_p       = dst_p;
       A.lin         = (op == OP_VMULT_VELOCITY && ctx->lin_prec.p) ? ctx->lin_prec.p : ctx->lin.p;
+      if (!ctx->ho_tab.p)
+        {
+          std::vector<double> tab;
+          for (int q = 0; q < N * N; ++q)
+            tab.push_back(A.S[(q / N) * N + q % N]);
+          for (int q = 0; q < N * N; ++q)
+            tab.push_back(A.D[q]);
+          for (int q = 0; q < N * NP; ++q)
+            tab.push_back(A.Sp[q]);
+          for (int q = 0; q < N; ++q)
+            tab.push_back(A.w[q]);
+          if (int e = ensure(ctx->ho_tab, tab.size()))
+            return e;
+          if (hipMemcpy(ctx->ho_tab.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+            return ADAFLO_EHIP;
+        }
+      A.tab = ctx->ho_tab.p;
       const bool with_p   = op == OP_VMULT;
       const int  lin_mode = (stokes || P.linearization == ADAFLO_COUPLED_VELOCITY_EXPLICIT) ?
                               2 :
@@ -1039,7 +1173,7 @@ namespace adaflo_hip
       if (with_p && !A.integrate_p)
         if (int e = launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, A.npx, A.npy, A.npz, A.con_p, -1., true))
           return e;
-      const size_t lds_bytes = sizeof(double) * (size_t)((NCELL * N * N == NTH ? NCELL : NCELL + 1) * 7 * N3);
+      const size_t lds_bytes = sizeof(double) * (size_t)ho_lds_doubles<K>();
       const dim3   grid((unsigned)n_wg), block(NTH);
       hipError_t   err  = hipSuccess;
       hipEvent_t   stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
