@@ -103,7 +103,7 @@ namespace
     NSArgs a{};
     a.brick   = ctx->brick;
     a.ns      = ctx->ns;
-    a.lin     = prec_state && ctx->lin_prec.p ? ctx->lin_prec.p : ctx->lin.p;
+    a.lin     = prec_state && ctx->lin_prec.p && ctx->lin_prec_generic_valid ? ctx->lin_prec.p : ctx->lin.p;
     a.rho     = prec_state && ctx->rho_prec.p ? ctx->rho_prec.p : ctx->rho.p;
     a.mu      = prec_state && ctx->mu_prec.p ? ctx->mu_prec.p : ctx->mu.p;
     a.damp    = prec_state && ctx->damp_prec.p ? ctx->damp_prec.p : ctx->damp.p;
@@ -116,6 +116,49 @@ namespace
   {
     return ctx->ns.linearization != ADAFLO_COUPLED_VELOCITY_EXPLICIT &&
            ctx->ns.physical_type != ADAFLO_STOKES;
+  }
+
+  // is a linearisation point stored (in either layout)?
+  bool has_lin(const adaflo_ctx *ctx)
+  {
+    return (ctx->lin.p && ctx->lin_generic_valid) || (ctx->lin_q2.p && ctx->lin_q2_valid);
+  }
+
+  // the generic copy [cell][12][q] of the state, rebuilt from the streaming copy the sweep-kernel
+  // residual wrote if it is stale
+  int ensure_lin_generic(adaflo_ctx *ctx)
+  {
+    if (ctx->lin_generic_valid || !(ctx->lin_q2.p && ctx->lin_q2_valid) || ctx->lin_q2_varco)
+      return 0;
+    const size_t count = (size_t)ctx->n_cells * ctx->nq_u * NLIN;
+    if (ctx->lin.count != count)
+      {
+        if (int e = alloc(ctx, ctx->lin, count))
+          return e;
+        if (hipMemsetAsync(ctx->lin.p, 0, count * sizeof(double), ctx->stream) != hipSuccess)
+          return ADAFLO_EHIP;
+      }
+    if (int e = q2_unconvert_state(ctx, ctx->lin.p, ctx->lin_q2.p, ctx->lin_q2_mode))
+      return e;
+    ctx->lin_generic_valid = true;
+    return 0;
+  }
+  int ensure_lin_prec_generic(adaflo_ctx *ctx)
+  {
+    if (ctx->lin_prec_generic_valid || !ctx->lin_q2_prec.p || ctx->lin_q2_prec_varco)
+      return 0;
+    const size_t count = (size_t)ctx->n_cells * ctx->nq_u * NLIN;
+    if (ctx->lin_prec.count != count)
+      {
+        if (int e = alloc(ctx, ctx->lin_prec, count))
+          return e;
+        if (hipMemsetAsync(ctx->lin_prec.p, 0, count * sizeof(double), ctx->stream) != hipSuccess)
+          return ADAFLO_EHIP;
+      }
+    if (int e = q2_unconvert_state(ctx, ctx->lin_prec.p, ctx->lin_q2_prec.p, ctx->lin_q2_prec_mode))
+      return e;
+    ctx->lin_prec_generic_valid = true;
+    return 0;
   }
 
   int nn(const adaflo_ctx *ctx, const int degree, const int d)
@@ -255,7 +298,7 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
                           &ctx->ls_convection, &ctx->ls_normal, &ctx->q1_convection, &ctx->q1_normal,
                           &ctx->q1_slab, &ctx->q1_zslab, &ctx->pc_inv_u, &ctx->pc_inv_pm, &ctx->pc_inv_pl,
                           &ctx->pc_ones_p, &ctx->pc_tmp_u, &ctx->pc_tmp_p, &ctx->pc_tmp_p2, &ctx->pc_work, &ctx->kr_work, &ctx->kr_basis, &ctx->kr_scalars,
-                          &ctx->q1_poisson_coef, &ctx->ho_tab})
+                          &ctx->q1_poisson_coef, &ctx->ho_tab, &ctx->res_sum_u, &ctx->res_sum_p, &ctx->res_old})
     release(*b);
   for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch,
                     ctx->d_tab_ls, ctx->d_ls_diag, ctx->d_tab_force})
@@ -376,7 +419,8 @@ int adaflo_ns_set_linearization(adaflo_ctx *ctx, const double *lin, int src_on_d
     }
   TRY(ctx, launch_transpose_state(ctx, ctx->lin.p, src, ctx->n_cells, ctx->nq_u, NLIN, true),
       "state re-layout failed");
-  ctx->lin_q2_valid = false;
+  ctx->lin_q2_valid      = false;
+  ctx->lin_generic_valid = true;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (staging)
     (void)hipFree(staging);
@@ -386,8 +430,9 @@ int adaflo_ns_set_linearization(adaflo_ctx *ctx, const double *lin, int src_on_d
 int adaflo_ns_get_linearization(adaflo_ctx *ctx, double *lin, int dst_on_device)
 {
   CHECK_CTX(ctx);
-  if (!ctx->lin.p)
+  if (!has_lin(ctx))
     return fail(ctx, ADAFLO_ENOTINIT, "no linearization data stored");
+  TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
   const size_t count = ctx->lin.count;
   double      *dst   = lin;
   double      *staging = nullptr;
@@ -413,6 +458,7 @@ int adaflo_ns_set_coefficients(adaflo_ctx *ctx, const double *rho, const double 
 {
   CHECK_CTX(ctx);
   const size_t count = (size_t)ctx->n_cells * ctx->nq_u;
+  TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
   ctx->lin_q2_valid   = false; // the streaming copy of the Q2/Q1 kernel carries the coefficients
   ctx->q1_poisson_src = nullptr;
   if (!rho && !mu && !damping)
@@ -456,9 +502,16 @@ int adaflo_ns_get_coefficients(adaflo_ctx *ctx, double *rho, double *mu, double 
 int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx)
 {
   CHECK_CTX(ctx);
+  // with the sweep kernels only the streaming copy is frozen; the generic frozen copy is rebuilt
+  // from it on demand (ensure_lin_prec_generic)
+  const bool streaming_only = ctx->variant >= 1 && q2_supported(ctx) && needs_lin(ctx) && ctx->lin_q2.p &&
+                              ctx->lin_q2_valid && !ctx->lin_q2_varco;
   const DeviceBuffer *src[4] = {&ctx->lin, &ctx->rho, &ctx->mu, &ctx->damp};
   DeviceBuffer       *dst[4] = {&ctx->lin_prec, &ctx->rho_prec, &ctx->mu_prec, &ctx->damp_prec};
-  for (int i = 0; i < 4; ++i)
+  if (!streaming_only)
+    TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
+  ctx->lin_prec_generic_valid = !streaming_only;
+  for (int i = streaming_only ? 1 : 0; i < 4; ++i)
     {
       TRY(ctx, alloc(ctx, *dst[i], src[i]->count), ctx->last_error);
       if (src[i]->count)
@@ -467,13 +520,14 @@ int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx)
     }
   ctx->q1_poisson_src = nullptr; // the frozen density copy may have changed content
   // keep a frozen copy in the streaming layout of the Q2/Q1 kernel as well
-  if (q2_supported(ctx) && ctx->lin.p && needs_lin(ctx))
+  if (q2_supported(ctx) && has_lin(ctx) && needs_lin(ctx))
     {
       TRY(ctx, q2_prepare_state(ctx), "state conversion failed");
       TRY(ctx, alloc(ctx, ctx->lin_q2_prec, ctx->lin_q2.count), ctx->last_error);
       HIP_TRY(ctx, hipMemcpyAsync(ctx->lin_q2_prec.p, ctx->lin_q2.p, ctx->lin_q2.count * sizeof(double),
                                   hipMemcpyDeviceToDevice, ctx->stream));
       ctx->lin_q2_prec_varco = ctx->lin_q2_varco;
+      ctx->lin_q2_prec_mode  = ctx->lin_q2_mode;
     }
   else
     release(ctx->lin_q2_prec);
@@ -500,7 +554,7 @@ int adaflo_ns_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double 
   CHECK_CTX(ctx);
   if (!dst_u || !dst_p || !src_u || !src_p)
     return fail(ctx, ADAFLO_EINVAL, "null vector");
-  if (needs_lin(ctx) && !ctx->lin.p)
+  if (needs_lin(ctx) && !has_lin(ctx))
     return fail(ctx, ADAFLO_ENOTINIT, "linearization data not set (call residual or set_linearization)");
   ScopedTimer timer(ctx, ctx->matvec_timer);
   const int   k = ctx->k;
@@ -523,6 +577,7 @@ int adaflo_ns_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double 
           launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, nn(ctx, k - 1, 0), nn(ctx, k - 1, 1),
                              nn(ctx, k - 1, 2), ctx->brick.con_p, -1., true),
           "prepare failed");
+      TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
       NSArgs a = make_ns_args(ctx, false);
       a.src_u  = src_u;
       a.src_p  = src_p;
@@ -543,7 +598,7 @@ int adaflo_ns_vmult_phase(adaflo_ctx *ctx, double *dst_u, double *dst_p, const d
     return fail(ctx, ADAFLO_EINVAL, "phase must be 0, 1 or 2");
   if (!(ctx->variant >= 1 && q2_supported(ctx)))
     return fail(ctx, ADAFLO_EUNSUPPORTED, "phased vmult needs the Q2/Q1 sweep kernel");
-  if (needs_lin(ctx) && !ctx->lin.p)
+  if (needs_lin(ctx) && !has_lin(ctx))
     return fail(ctx, ADAFLO_ENOTINIT, "linearization data not set (call residual or set_linearization)");
   TRY(ctx, launch_ns_vmult_q2(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p, phase, interface_faces),
       "Q2 kernel launch failed");
@@ -561,8 +616,34 @@ int adaflo_ns_residual(adaflo_ctx *ctx, double *rhs_u, double *rhs_p, const doub
     return fail(ctx, ADAFLO_EINVAL, "null vector");
   if (ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE && (!old_u || !old_old_u))
     return fail(ctx, ADAFLO_EINVAL, "solution_old / solution_old_old required");
+  if (ctx->variant >= 1 && q2_residual_supported(ctx))
+    {
+      // sweep kernel in residual mode: cell-loop sums into work vectors, then
+      // rhs = user - rhs - sum (the reference's cell loop adds into system_rhs, :279-292)
+      const long nu = 3 * ctx->n_nodes_u, np = ctx->n_nodes_p;
+      TRY(ctx, alloc(ctx, ctx->res_sum_u, nu), ctx->last_error);
+      TRY(ctx, alloc(ctx, ctx->res_sum_p, np), ctx->last_error);
+      const double *old_comb = nullptr;
+      if (ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE)
+        {
+          TRY(ctx, alloc(ctx, ctx->res_old, nu), ctx->last_error);
+          TRY(ctx, launch_lincomb(ctx, ctx->res_old.p, ctx->ns.weight_old, old_u, ctx->ns.weight_old_old, old_old_u, nu),
+              "old-solution combination failed");
+          old_comb = ctx->res_old.p;
+        }
+      TRY(ctx, launch_ns_residual_q2(ctx, ctx->res_sum_u.p, ctx->res_sum_p.p, src_u, src_p, old_comb),
+          "Q2 residual kernel launch failed");
+      if (needs_lin(ctx))
+        ctx->lin_generic_valid = false;
+      TRY(ctx, launch_residual_finish(ctx, rhs_u, ctx->res_sum_u.p, user_u, nu), "residual update failed");
+      TRY(ctx, launch_residual_finish(ctx, rhs_p, ctx->res_sum_p.p, user_p, np), "residual update failed");
+      return 0;
+    }
   if (needs_lin(ctx))
-    TRY(ctx, alloc(ctx, ctx->lin, (size_t)ctx->n_cells * ctx->nq_u * NLIN), ctx->last_error);
+    {
+      TRY(ctx, alloc(ctx, ctx->lin, (size_t)ctx->n_cells * ctx->nq_u * NLIN), ctx->last_error);
+      ctx->lin_generic_valid = true;
+    }
   NSArgs a   = make_ns_args(ctx, false);
   a.src_u    = src_u;
   a.src_p    = src_p;
@@ -583,7 +664,7 @@ int adaflo_ns_velocity_vmult(adaflo_ctx *ctx, double *dst_u, const double *src_u
   CHECK_CTX(ctx);
   if (!dst_u || !src_u)
     return fail(ctx, ADAFLO_EINVAL, "null vector");
-  if (needs_lin(ctx) && !ctx->lin.p)
+  if (needs_lin(ctx) && !has_lin(ctx))
     return fail(ctx, ADAFLO_ENOTINIT, "linearization data not set");
   const int k = ctx->k;
   // (frozen coefficient copies without a frozen streaming copy: generic kernel)
@@ -604,6 +685,8 @@ int adaflo_ns_velocity_vmult(adaflo_ctx *ctx, double *dst_u, const double *src_u
                          nn(ctx, k, 2), ctx->brick.con_u, 1., true),
       "prepare failed");
   // :349-356: operate on the state frozen by fix_linearization_point, if any
+  TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
+  TRY(ctx, ensure_lin_prec_generic(ctx), "state re-layout failed");
   NSArgs a = make_ns_args(ctx, true);
   a.src_u  = src_u;
   a.dst_u  = dst_u;
@@ -747,7 +830,7 @@ int adaflo_ns_pressure_convdiff_vmult(adaflo_ctx *ctx, double *dst_p, const doub
   CHECK_CTX(ctx);
   if (!dst_p || !src_p)
     return fail(ctx, ADAFLO_EINVAL, "null vector");
-  if (!ctx->lin.p) // Assert(linearized_velocities.size() > 0) :1110
+  if (!has_lin(ctx)) // Assert(linearized_velocities.size() > 0) :1110
     return fail(ctx, ADAFLO_ENOTINIT, "linearization data not set");
   return scalar_op(ctx, dst_p, src_p, SC_CONVDIFF, ctx->mu.p, true, true);
 }
@@ -789,6 +872,7 @@ int adaflo_set_q2_state_pad(adaflo_ctx *ctx, int pad_16B)
   CHECK_CTX(ctx);
   if (pad_16B < 0)
     return fail(ctx, ADAFLO_EINVAL, "negative padding");
+  TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
   ctx->q2_state_pad = pad_16B;
   ctx->lin_q2_valid = false;
   return 0;
@@ -1156,6 +1240,7 @@ int adaflo_ls_compute_force(adaflo_ctx *ctx, double *user_rhs_u, const double *h
     {
       const size_t count = (size_t)ctx->n_cells * ctx->nq_u;
       const bool   had_damping = ctx->damp.p != nullptr;
+      TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
       TRY(ctx, alloc(ctx, ctx->rho, count), ctx->last_error);
       TRY(ctx, alloc(ctx, ctx->mu, count), ctx->last_error);
       TRY(ctx, alloc(ctx, ctx->damp, count), ctx->last_error);

@@ -120,6 +120,11 @@ struct adaflo_ctx
   long                     q2_wg_key[4] = {0, 0, 0, 0};
   int                      q2_wg_counts[3] = {0, 0, 0};
   bool                     lin_q2_valid = false, lin_q2_varco = false, lin_q2_prec_varco = false;
+  // the sweep-kernel residual writes the state in the streaming layout only; the generic copies
+  // (lin, lin_prec) are then stale until somebody asks for them (ensure_lin_generic, capi.hip)
+  bool                     lin_generic_valid = true, lin_prec_generic_valid = true;
+  int                      lin_q2_prec_mode = -1;
+  adaflo_hip::DeviceBuffer res_sum_u, res_sum_p, res_old; // work vectors of the sweep-kernel residual
   int                      lin_q2_mode  = -1;
   int                      q2_lz        = 0; // z-chunk length override (0 = heuristic)
   int                      q2_state_pad = 0; // skew padding (double2) per (tile, layer) state block

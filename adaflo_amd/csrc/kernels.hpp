@@ -75,6 +75,8 @@ namespace adaflo_hip
   int launch_mean_projection(adaflo_ctx *ctx, double *v, const double *w, const double *modes,
                              long n, double inv);
   int launch_sadd(adaflo_ctx *ctx, double *x, double a, const double *y, long n); // x = a*x + y
+  int launch_lincomb(adaflo_ctx *ctx, double *z, double a, const double *x, double b, const double *y, long n); // z = a x + b y
+  int launch_residual_finish(adaflo_ctx *ctx, double *rhs, const double *sum, const double *user, long n); // rhs = user - rhs - sum
   int launch_fill(adaflo_ctx *ctx, double *x, double v, long n);
   // canonical [cell][q][comp] <-> generic [cell][comp][q]
   int launch_transpose_state(adaflo_ctx *ctx, double *dst, const double *src, long n_cells, int nq,
@@ -109,6 +111,11 @@ namespace adaflo_hip
   int  q2_prepare_state(adaflo_ctx *ctx);
   int  launch_ns_vmult_q2(adaflo_ctx *ctx, int op, double *dst_u, double *dst_p,
                           const double *src_u, const double *src_p, int phase = -1, uint32_t iface = 0);
+  // residual mode of the sweep kernel (writes the quadrature-point state in the streaming layout)
+  bool q2_residual_supported(const adaflo_ctx *ctx);
+  int  launch_ns_residual_q2(adaflo_ctx *ctx, double *sum_u, double *sum_p, const double *src_u,
+                             const double *src_p, const double *old_comb);
+  int  q2_unconvert_state(adaflo_ctx *ctx, double *generic, const double *streaming, int lin_mode);
 
   // compute_heaviside / local_compute_force (ls_force.hip)
   int                 launch_ls_heaviside(adaflo_ctx *ctx, double *heaviside, const double *phi, double epsilon);

@@ -53,6 +53,12 @@ namespace adaflo_hip
       const double *src_u, *src_p;
       double       *dst_u, *dst_p;
       const double *state;
+      // residual mode (template RES): combination of the old solutions at the nodes
+      // (weight_old u_old + weight_old_old u_old_old), its factor rho_old in the momentum row,
+      // and the streaming state array the kernel WRITES (linearisation point = src)
+      const double *old_u;
+      double        c_old;
+      double       *state_out;
       // phased execution for the multi-GPU overlap (launch_ns_vmult_q2): explicit workgroup list
       // for the main kernel, node filter for the fix-up (1: only nodes on the inter-GPU interface
       // faces `iface`, 2: all other nodes, 0: everything)
@@ -163,6 +169,8 @@ namespace adaflo_hip
     constexpr int UPLANE_L  = PNY * UROW;                 // 884
     constexpr int PPLANE_L  = QNY * PROW;                 // 90
     constexpr int L_UPL     = L_RING + 4 * RING * PIECE;  // 3 velocity node planes
+    constexpr int L_UPL_    = L_UPL;
+    static_assert(3 * (PNY * 52) <= 4 * RING * PIECE, "the residual mode keeps the old-solution planes in the ring area");
     constexpr int L_PPL     = L_UPL + 3 * UPLANE_L;       // 2 pressure node planes
     constexpr int L_SCRU    = L_PPL + 2 * PPLANE_L;       // [3 planes][5 slots][192]
     constexpr int L_SCRP    = L_SCRU + 15 * NCELL * 3;    // [2 planes][3 slots][64]
@@ -285,6 +293,19 @@ namespace adaflo_hip
       asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
     }
 
+    // 16-byte store to sbase + voff for the lanes in `mask` (no exec branch in the caller's code)
+    __device__ __forceinline__ void store_b128_masked(const void *sbase, const unsigned voff, const double a,
+                                                      const double b, const unsigned long long mask)
+    {
+      double2v v;
+      v.x = a;
+      v.y = b;
+      asm volatile("s_mov_b64 exec, %3\n\t"
+                   "global_store_dwordx4 %0, %1, %2 nt\n\t"
+                   "s_mov_b64 exec, -1" ::"v"(voff), "v"(v), "s"(sbase), "s"(mask)
+                   : "memory");
+    }
+
     __device__ __forceinline__ unsigned lds_addr(const void *p)
     {
       return (unsigned)(size_t)p; // LDS aperture: the low 32 bits are the LDS byte address
@@ -319,8 +340,11 @@ namespace adaflo_hip
     // the NPL_U row-pair copies one wave contributes to velocity planes K0 and K0+1
     __device__ __forceinline__ void dma_u_planes(const Q2Args &A, double *lds, const int K0,
                                                  const int I0, const int J0, const int wave,
-                                                 const int lane)
+                                                 const int lane, const double *src = nullptr,
+                                                 const int lds_base = -1)
     {
+      const double *vec = src ? src : A.src_u;
+      const int     lb  = lds_base >= 0 ? lds_base : -1;
       const int nv = 3 * min(PNX, A.nnx - I0); // valid doubles of a tile row
 #pragma unroll
       for (int t = 0; t < NPL_U; ++t)
@@ -330,19 +354,21 @@ namespace adaflo_hip
           if (n >= 18)
             n -= 4;
           const int     pl = n / 9, m = n - 9 * pl, K = K0 + pl, Kg = min(K, A.nnz - 1);
-          const double *plane = A.src_u + (size_t)Kg * A.nny * A.nnx * 3;
+          const double *plane = vec + (size_t)Kg * A.nny * A.nnx * 3;
           dma_rows_b128<26, PNY>(plane, lane, 2 * m, nv, A.nnx * 3, (J0 * A.nnx + I0) * 3,
-                                 A.nny - 1 - J0, lds + L_UPL + (K % 3) * UPLANE_L + 2 * m * UROW);
+                                 A.nny - 1 - J0, lds + (lb >= 0 ? lb : L_UPL_) + (K % 3) * UPLANE_L + 2 * m * UROW);
         }
     }
 
     // one plane (prologue): 9 row pairs over the 4 waves, 3 instructions per wave
     __device__ __forceinline__ void dma_u_plane_single(const Q2Args &A, double *lds, const int K,
                                                        const int I0, const int J0, const int wave,
-                                                       const int lane)
+                                                       const int lane, const double *src = nullptr,
+                                                       const int lds_base = -1)
     {
       const int     nv    = 3 * min(PNX, A.nnx - I0);
-      const double *plane = A.src_u + (size_t)K * A.nny * A.nnx * 3;
+      const double *plane = (src ? src : A.src_u) + (size_t)K * A.nny * A.nnx * 3;
+      const int     lb    = lds_base;
 #pragma unroll
       for (int t = 0; t < 3; ++t)
         {
@@ -350,7 +376,7 @@ namespace adaflo_hip
           if (m >= 9)
             m -= 4;
           dma_rows_b128<26, PNY>(plane, lane, 2 * m, nv, A.nnx * 3, (J0 * A.nnx + I0) * 3,
-                                 A.nny - 1 - J0, lds + L_UPL + (K % 3) * UPLANE_L + 2 * m * UROW);
+                                 A.nny - 1 - J0, lds + (lb >= 0 ? lb : L_UPL_) + (K % 3) * UPLANE_L + 2 * m * UROW);
         }
     }
 
@@ -367,9 +393,15 @@ namespace adaflo_hip
     }
 
     // ISO: cubic cells, one set of derivative coefficients for all directions
-    template <int LIN_MODE, bool WITH_P, bool ISO, bool VARCO>
+    // RES: residual mode (source/navier_stokes_matrix.cc:266-293 with NavierStokesOps::residual):
+    // src is the solution itself (plain read incl. boundary values), the combination of the old
+    // solutions enters the momentum row, the nonlinear term is evaluated with src, and the
+    // quadrature-point state (:725-800) is WRITTEN in the streaming layout instead of being read
+    template <int LIN_MODE, bool WITH_P, bool ISO, bool VARCO, bool RES = false>
     __global__ __launch_bounds__(NT, 2) void ns_q2_kernel(const Q2Args A)
     {
+      constexpr bool RING_ON = LIN_MODE != 2 && !RES; // state stream through the LDS ring
+      static_assert(!(RES && VARCO), "residual mode: constant coefficients only");
       extern __shared__ double lds[];
       // state ring geometry.  Constant coefficients: pieces of 48 lanes x 16 B, 9 slots.
       // Variable rho/mu/damping (two-phase flow): lanes 48..63 of every piece carry the
@@ -426,7 +458,7 @@ namespace adaflo_hip
               const int  I = ib + li, J = jb + lj;
               const bool cx_ = (I == 0 && (con >> (st * 0 + cc) & 1)) || (I == nn_x - 1 && (con >> (st * 1 + cc) & 1));
               const bool cy_ = (J == 0 && (con >> (st * 2 + cc) & 1)) || (J == nn_y - 1 && (con >> (st * 3 + cc) & 1));
-              if (cx_ || cy_)
+              if (!RES && (cx_ || cy_))
                 m_zero |= 1u << bit; // read-as-zero in the gather (all 9 in-plane positions)
               if (li > deg || lj > deg)
                 continue;
@@ -477,6 +509,11 @@ namespace adaflo_hip
             dma_p_plane(A, lds, cz0, Ip0, Jp0, lane);
             dma_p_plane(A, lds, cz0 + 1, Ip0, Jp0, lane);
           }
+        if (RES) // node planes of the old-solution combination live in the (unused) ring area
+          {
+            dma_u_plane_single(A, lds, 2 * cz0, I0, J0, wave, lane, A.old_u, L_RING);
+            dma_u_planes(A, lds, 2 * cz0 + 1, I0, J0, wave, lane, A.old_u, L_RING);
+          }
       }
       // wave-private exchange records (alias of the publish scratch, which is only live in D/E)
 #if defined(Q2_LDS_EXCHANGE)
@@ -492,24 +529,70 @@ namespace adaflo_hip
         dma_b128(g, piece_voff, ring_byte + (p % RING_) * (PIECE_ * 8),
                  VARCO ? 0xffffffffffffffffull : 0x0000ffffffffffffull);
       };
-      if (LIN_MODE != 2)
+      if (RING_ON)
         {
 #pragma unroll
           for (int p = 0; p < AHEAD_; ++p)
             issue_piece(cz0, p);
         }
       // planes must have landed before anybody gathers from them
-      if (LIN_MODE != 2)
+      if (RING_ON)
         wait_vmcnt<AHEAD_>();
       else
         wait_vmcnt<0>();
       lds_barrier();
+      // residual mode: the state of a point leaves as two 16-byte stores per velocity lane
+      const unsigned           sout_voff = 16u * (unsigned)(wave * 48 + cq * 3 + (is_p ? 0 : d));
+      const unsigned long long sout_mask = 0x7777777777777777ull; // lanes d < 3
+      auto interp_all = [&](double *X) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int b = 0; b < 3; ++b)
+            interp3(X[3 * b + 9 * c], X[1 + 3 * b + 9 * c], X[2 + 3 * b + 9 * c], s0, s1, s2);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+            interp3(X[a + 9 * c], X[a + 3 + 9 * c], X[a + 6 + 9 * c], s0, s1, s2);
+#pragma unroll
+        for (int n = 0; n < 9; ++n)
+          interp3(X[n], X[n + 9], X[n + 18], s0, s1, s2);
+      };
 
       for (int layer = 0; layer < nl; ++layer)
         {
           const int cz      = cz0 + layer;
           const int cz_next = layer + 1 < nl ? cz + 1 : cz;
 
+          double R[27];
+          if (RES)
+            {
+              // (w, rho (weight_old u_old + weight_old_old u_old_old)) of the momentum row (:675-686,
+              // :730-733): interpolate the nodal combination, it only enters through its values
+              double V2[27];
+#pragma unroll
+              for (int c = 0; c < 3; ++c)
+                {
+                  const double *pl = lds + L_RING + ((2 * cz + c) % 3) * UPLANE_L + 2 * cyl * UROW + 2 * cxl * 3 + (is_p ? 0 : d);
+#pragma unroll
+                  for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                      V2[a + 3 * b + 9 * c] = pl[b * UROW + a * 3 + (a == 2 ? fix_last : 0)];
+                }
+              interp_all(V2);
+              const double co = is_p ? 0. : A.c_old;
+#pragma unroll
+              for (int n = 0; n < 27; ++n)
+                R[n] = (co * A.wj[(n % 3 == 1) + ((n / 3) % 3 == 1) + (n / 9 == 1)]) * V2[n];
+            }
+          else
+            {
+#pragma unroll
+              for (int n = 0; n < 27; ++n)
+                R[n] = 0.;
+            }
           // ---- B: gather my 27 (8) values from the LDS node planes ---------------------
           double V[27];
           if (!is_p)
@@ -541,7 +624,7 @@ namespace adaflo_hip
             }
           // read_dof_values: constrained entries read as zero (boundary tiles / layers only)
           {
-            const bool zlo = conz_lo && cz == 0, zhi = conz_hi && cz == A.ncz - 1;
+            const bool zlo = !RES && conz_lo && cz == 0, zhi = !RES && conz_hi && cz == A.ncz - 1;
             if (__builtin_amdgcn_readfirstlane(__any(m_zero != 0u || zlo || zhi)))
               {
                 const int deg = is_p ? 1 : 2;
@@ -583,27 +666,15 @@ namespace adaflo_hip
           dma_u_planes(A, lds, 2 * cz + 3, I0, J0, wave, lane);
           if (WITH_P)
             dma_p_plane(A, lds, cz + 2, Ip0, Jp0, lane);
+          if (RES)
+            dma_u_planes(A, lds, 2 * cz + 3, I0, J0, wave, lane, A.old_u, L_RING);
 
           // ---- C: interpolate to the Gauss points (in place) ----------------------------
-#pragma unroll
-          for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int b = 0; b < 3; ++b)
-              interp3(V[3 * b + 9 * c], V[1 + 3 * b + 9 * c], V[2 + 3 * b + 9 * c], s0, s1, s2);
-#pragma unroll
-          for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-              interp3(V[a + 9 * c], V[a + 3 + 9 * c], V[a + 6 + 9 * c], s0, s1, s2);
-#pragma unroll
-          for (int n = 0; n < 9; ++n)
-            interp3(V[n], V[n + 9], V[n + 18], s0, s1, s2);
+          interp_all(V);
 
           // ---- quadrature-point loop (source/navier_stokes_matrix.cc:702-893) ------------
-          double R[27];
-#pragma unroll
-          for (int n = 0; n < 27; ++n)
-            R[n] = 0.;
+          const double2 *sout_layer = reinterpret_cast<const double2 *>(A.state_out) +
+                                      ((size_t)bt * A.ncz + cz) * A.state_stride;
 
 #pragma unroll
           for (int q = 0; q < 27; ++q)
@@ -612,7 +683,7 @@ namespace adaflo_hip
               double2   st0 = make_double2(0., 0.), st1 = make_double2(0., 0.);
               double    r_ub0 = 0., r_ub1 = 0., r_ub2 = 0., r_trl = 0.;
               double    r_rho = 0., r_mu = 0., r_damp = 0.;
-              if (LIN_MODE != 2)
+              if (RING_ON)
                 {
                   // outstanding after the pieces of q: AHEAD - 2 younger pieces, plus, right
                   // after the plane refill was issued (q < 4), the plane copies of this wave
@@ -723,7 +794,20 @@ namespace adaflo_hip
               const double cB_q = VARCO ? A.tau1 * r_rho : A.cB;
               const double tmu_q = VARCO ? (is_p ? 0. : A.tau1 * r_mu) : tmu_l;
               double conv = cA_q * Vq;
-              if (LIN_MODE == 0)       // Newton :802-816
+              if (RES)
+                {
+                  if (LIN_MODE != 2)
+                    {
+                      // :725-760 nonlinear term of the solution itself; the point's state goes out in
+                      // the streaming layout: (u_d, d_0 u_d | d_1 u_d, d_2 u_d) or (u_d, div u | ...)
+                      conv += cB_q * (A.beta * div * Vq + u0 * g0 + u1 * g1 + u2 * g2);
+                      const double2 *sp = sout_layer + (size_t)(2 * q) * (4 * 48);
+                      store_b128_masked(sp, sout_voff, Vq, LIN_MODE == 0 ? g0 : div, sout_mask);
+                      store_b128_masked(sp + 4 * 48, sout_voff, LIN_MODE == 0 ? g1 : div, LIN_MODE == 0 ? g2 : div,
+                                        sout_mask);
+                    }
+                }
+              else if (LIN_MODE == 0)       // Newton :802-816
                 {
                   // u_lin of all components and tr(grad u_lin): quad-uniform LDS reads of the ring
                   const double ub0 = r_ub0, ub1 = r_ub1, ub2 = r_ub2, trl = r_trl;
@@ -782,9 +866,12 @@ namespace adaflo_hip
             for (int b = 0; b < 3; ++b)
               interp3_t(R[3 * b + 9 * c], R[1 + 3 * b + 9 * c], R[2 + 3 * b + 9 * c], s0, s1, s2);
 
-          // my plane copies for the next layer are older than the AHEAD pieces issued last
-          if (LIN_MODE != 2)
+          // my plane copies for the next layer are older than the AHEAD pieces issued last (residual
+          // mode: than the 54 state stores of this layer)
+          if (RING_ON)
             wait_vmcnt<AHEAD_>();
+          else if (RES && LIN_MODE != 2)
+            wait_vmcnt<54>();
           else
             wait_vmcnt<0>();
 
@@ -934,7 +1021,7 @@ namespace adaflo_hip
 #pragma unroll
                           for (int n = 0; n < 9; ++n)
                             if ((m_own >> n & 1u) && ((m_con >> n & 1u) || zcon))
-                              nv[n] = A.src_u[pbase + lane_g + (unsigned)(((n / 3) * A.nnx + n % 3) * 3)];
+                              nv[n] = RES ? 0. : A.src_u[pbase + lane_g + (unsigned)(((n / 3) * A.nnx + n % 3) * 3)];
                         }
                       // partial sums of high-rim nodes shared with other workgroups -> slab
                       // (q2_seam_fixup_kernel adds them to the owner tile's partial sum in dst)
@@ -1017,7 +1104,7 @@ namespace adaflo_hip
                             {
                               const size_t idx = pbase + lane_g + (unsigned)(lj * A.npx + li);
                               if ((m_con >> bit & 1u) || zcon)
-                                Q2_STORE(A.dst_p[idx], -A.src_p[idx]); // -1 on the pressure block of vmult
+                                Q2_STORE(A.dst_p[idx], RES ? 0. : -A.src_p[idx]); // -1 on the pressure block of vmult
                               else if (m_seam >> bit & 1u)
                                 Q2_STORE_SLAB(A.slab_p[(wgs * (A.LZ + 1) + layer) * RIM_P +
                                          rim_index<QNX>(cxl + li, cyl + lj)], nv[n]);
@@ -1059,7 +1146,7 @@ namespace adaflo_hip
                   const int    li = n % 3, lj = n / 3;
                   const size_t idx = pbase + lane_g + (unsigned)((lj * A.nnx + li) * 3);
                   if ((m_con >> n & 1u) || zcon)
-                    Q2_STORE(A.dst_u[idx], A.src_u[idx]);
+                    Q2_STORE(A.dst_u[idx], RES ? 0. : A.src_u[idx]);
                   else if (m_seam >> n & 1u)
                     Q2_STORE_SLAB(A.slab_u[((wgs * (2 * A.LZ + 1) + 2 * nl) * RIM_U +
                               rim_index<PNX>(2 * cxl + li, 2 * cyl + lj)) * 3 + d], nv[n]);
@@ -1088,7 +1175,7 @@ namespace adaflo_hip
                   {
                     const size_t idx = pbase + lane_g + (unsigned)(lj * A.npx + li);
                     if ((m_con >> bit & 1u) || zcon)
-                      Q2_STORE(A.dst_p[idx], -A.src_p[idx]);
+                      Q2_STORE(A.dst_p[idx], RES ? 0. : -A.src_p[idx]);
                     else if (m_seam >> bit & 1u)
                       Q2_STORE_SLAB(A.slab_p[(wgs * (A.LZ + 1) + nl) * RIM_P + rim_index<QNX>(cxl + li, cyl + lj)], nv[n]);
                     else if (zseam)
@@ -1268,7 +1355,66 @@ namespace adaflo_hip
           o[(long)q * per_q + lane * 2 + j] = cv[cw * CV_STRIDE + s * 27 + q];
         }
     }
+    // inverse of q2_convert_state_kernel (constant-coefficient layout): streaming -> generic
+    // [cell][12][27].  Newton: all 12 entries; Picard-type: u_lin and div_lin (entry 3).
+    __global__ __launch_bounds__(256) void q2_unconvert_state_kernel(double *__restrict__ gen,
+                                                                     const double *__restrict__ str,
+                                                                     const int ncx, const int ncy,
+                                                                     const int ncz, const int tiles_x,
+                                                                     const int lin_mode, const long stride2)
+    {
+      extern __shared__ double cv[]; // [cell 16][slot 6][27]
+      const long blk   = blockIdx.x;
+      const int  half = (int)(blk & 1), wave = (int)(blk >> 1 & 3);
+      const int  cz   = (int)((blk >> 3) % ncz);
+      const long bt   = (blk >> 3) / ncz;
+      const int  bx = (int)(bt % tiles_x), by = (int)(bt / tiles_x);
+      const double *o     = str + ((bt * ncz + cz) * (2 * stride2)) + (long)(half * 4 + wave) * (48 * 2);
+      const int     per_q = 2 * 4 * 48 * 2;
+      for (int e = threadIdx.x; e < 27 * 48 * 2; e += 256)
+        {
+          const int j = e & 1, lane = (e >> 1) % 48, q = (e >> 1) / 48;
+          cv[(lane / 3) * CV_STRIDE + (2 * (lane % 3) + j) * 27 + q] = o[(long)q * per_q + lane * 2 + j];
+        }
+      __syncthreads();
+      for (int e = threadIdx.x; e < 16 * 6 * 27; e += 256)
+        {
+          const int q = e % 27, s = (e / 27) % 6, cw = e / (27 * 6), cl = wave * 16 + cw;
+          const int cx = bx * TX + (cl % TX), cy = by * TY + (cl / TX);
+          if (cx >= ncx || cy >= ncy)
+            continue;
+          const int d = s / 2, j = s % 2;
+          int       comp;
+          if (half == 0 && j == 0)
+            comp = d;
+          else if (lin_mode == 1)
+            comp = (half == 0 && d == 0) ? 3 : -1;
+          else
+            comp = 3 + 3 * d + (2 * half + j - 1);
+          if (comp >= 0)
+            gen[((cx + (long)ncx * (cy + (long)ncy * cz)) * NLIN + comp) * 27 + q] = cv[cw * CV_STRIDE + s * 27 + q];
+        }
+    }
   } // namespace
+
+  int q2_unconvert_state(adaflo_ctx *ctx, double *generic, const double *streaming, const int lin_mode)
+  {
+    const int    tiles_x = (ctx->desc.ncell[0] + TX - 1) / TX, tiles_y = (ctx->desc.ncell[1] + TY - 1) / TY;
+    const long   stride2 = 27L * 2 * 4 * 48 + ctx->q2_state_pad;
+    const size_t lds     = sizeof(double) * 16 * CV_STRIDE;
+    static bool  attr_set = false;
+    if (!attr_set)
+      {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&q2_unconvert_state_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+          return ADAFLO_EHIP;
+        attr_set = true;
+      }
+    const long nb = (long)tiles_x * tiles_y * ctx->desc.ncell[2] * 8;
+    hipLaunchKernelGGL(q2_unconvert_state_kernel, dim3((unsigned)nb), dim3(256), lds, ctx->stream, generic, streaming,
+                       ctx->desc.ncell[0], ctx->desc.ncell[1], ctx->desc.ncell[2], tiles_x, lin_mode, stride2);
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
 
   static int q2_lin_mode(const adaflo_ctx *ctx)
   {
@@ -1342,14 +1488,21 @@ namespace adaflo_hip
   // workgroups that touch no node of the inter-GPU interface faces `iface` (bit = face 2*dim+side),
   // 1 = the workgroups that do + seam fix-up of the interface nodes (dst is then final there and
   // can be packed), 2 = the remaining interior workgroups + the rest of the fix-up.
-  int launch_ns_vmult_q2(adaflo_ctx *ctx, const int op, double *dst_u, double *dst_p,
-                         const double *src_u, const double *src_p, const int phase, const uint32_t iface)
+  static int q2_launch(adaflo_ctx *ctx, const int op, double *dst_u, double *dst_p, const double *src_u,
+                       const double *src_p, const int phase, const uint32_t iface, const bool residual,
+                       const double *res_old, const double res_c_old)
   {
-    if (ctx->lin_q2_valid && (ctx->lin_q2_mode != q2_lin_mode(ctx) || ctx->lin_q2_varco != q2_varco(ctx)))
-      ctx->lin_q2_valid = false;
-    if (int e = q2_prepare_state(ctx))
-      return e;
+    if (!residual)
+      {
+        if (ctx->lin_q2_valid && (ctx->lin_q2_mode != q2_lin_mode(ctx) || ctx->lin_q2_varco != q2_varco(ctx)))
+          ctx->lin_q2_valid = false;
+        if (int e = q2_prepare_state(ctx))
+          return e;
+      }
     Q2Args A{};
+    A.old_u     = res_old;
+    A.c_old     = res_c_old;
+    A.state_out = residual ? ctx->lin_q2.p : nullptr;
     A.ncx = ctx->desc.ncell[0];
     A.ncy = ctx->desc.ncell[1];
     A.ncz = ctx->desc.ncell[2];
@@ -1405,7 +1558,7 @@ namespace adaflo_hip
     A.tau1        = P.tau1;
     // the frozen copy of velocity_vmult carries the coefficients it was built with
     const bool use_prec = op == OP_VMULT_VELOCITY && ctx->lin_q2_prec.p;
-    const bool varco    = use_prec ? ctx->lin_q2_prec_varco : q2_varco(ctx);
+    const bool varco    = residual ? false : (use_prec ? ctx->lin_q2_prec_varco : q2_varco(ctx));
     A.state_stride = 27L * 2 * 4 * (varco ? 64 : 48) + ctx->q2_state_pad;
     A.con_u       = ctx->brick.con_u;
     A.con_p       = ctx->brick.con_p;
@@ -1487,24 +1640,24 @@ namespace adaflo_hip
     const dim3   grid((unsigned)(nwg > 0 ? nwg : 1)), block(NT);
     const size_t lds_bytes = sizeof(double) * L_TOTAL;
     hipError_t   err       = hipSuccess;
-#define Q2_LAUNCH_V(LM, WP, IS, VC)                                                                   \
+#define Q2_LAUNCH_V(LM, WP, IS, VC, RS)                                                               \
   {                                                                                             \
     static bool attr_set = false;                                                               \
     if (!attr_set)                                                                              \
       {                                                                                         \
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_q2_kernel<LM, WP, IS, VC>),    \
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_q2_kernel<LM, WP, IS, VC, RS>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
         attr_set = err == hipSuccess;                                                           \
       }                                                                                         \
     if (err == hipSuccess && nwg > 0)                                                           \
-      hipLaunchKernelGGL((ns_q2_kernel<LM, WP, IS, VC>), grid, block, lds_bytes, ctx->stream, A); \
+      hipLaunchKernelGGL((ns_q2_kernel<LM, WP, IS, VC, RS>), grid, block, lds_bytes, ctx->stream, A); \
   }
-#define Q2_LAUNCH_I(LM, WP, IS)       \
-  {                                   \
-    if (varco)                        \
-      Q2_LAUNCH_V(LM, WP, IS, true)   \
-    else                              \
-      Q2_LAUNCH_V(LM, WP, IS, false)  \
+#define Q2_LAUNCH_I(LM, WP, IS)              \
+  {                                          \
+    if (varco)                               \
+      Q2_LAUNCH_V(LM, WP, IS, true, false)   \
+    else                                     \
+      Q2_LAUNCH_V(LM, WP, IS, false, false)  \
   }
 #define Q2_LAUNCH(LM, WP)      \
   {                            \
@@ -1513,7 +1666,35 @@ namespace adaflo_hip
     else                       \
       Q2_LAUNCH_I(LM, WP, false) \
   }
-    if (with_p)
+    if (residual)
+      {
+        // (constant coefficients, src = the solution: launch_ns_residual_q2)
+        if (iso)
+          switch (lin_mode)
+            {
+              case 0:
+                Q2_LAUNCH_V(0, true, true, false, true);
+                break;
+              case 1:
+                Q2_LAUNCH_V(1, true, true, false, true);
+                break;
+              default:
+                Q2_LAUNCH_V(2, true, true, false, true);
+            }
+        else
+          switch (lin_mode)
+            {
+              case 0:
+                Q2_LAUNCH_V(0, true, false, false, true);
+                break;
+              case 1:
+                Q2_LAUNCH_V(1, true, false, false, true);
+                break;
+              default:
+                Q2_LAUNCH_V(2, true, false, false, true);
+            }
+      }
+    else if (with_p)
       switch (lin_mode)
         {
           case 0:
@@ -1558,5 +1739,60 @@ namespace adaflo_hip
       hipLaunchKernelGGL(q2_seam_fixup_kernel, dim3((unsigned)nb), dim3(64), 0, ctx->stream, A, n1, n2, n3, n4);
     }
     return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+
+  int launch_ns_vmult_q2(adaflo_ctx *ctx, const int op, double *dst_u, double *dst_p, const double *src_u,
+                         const double *src_p, const int phase, const uint32_t iface)
+  {
+    return q2_launch(ctx, op, dst_u, dst_p, src_u, src_p, phase, iface, false, nullptr, 0.);
+  }
+
+  // residual on the sweep structure: Newton / Picard-type linearisations (the state they store is
+  // that of the solution itself) and Stokes, constant coefficients
+  bool q2_residual_supported(const adaflo_ctx *ctx)
+  {
+    if (ctx->k != 2 || ctx->rho.p || ctx->mu.p || ctx->damp.p)
+      return false;
+    const NSDev &P = ctx->ns;
+    return P.physical_type == ADAFLO_STOKES || P.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON ||
+           P.linearization == ADAFLO_COUPLED_IMPLICIT_PICARD;
+  }
+
+  // sum_u / sum_p = cell-loop result of NavierStokesOps::residual (zero on constrained rows);
+  // old_comb = weight_old u_old + weight_old_old u_old_old at the nodes (or nullptr).  Leaves the
+  // quadrature-point state of `src` in the streaming layout (ctx->lin_q2).
+  int launch_ns_residual_q2(adaflo_ctx *ctx, double *sum_u, double *sum_p, const double *src_u,
+                            const double *src_p, const double *old_comb)
+  {
+    const int lin_mode = q2_lin_mode(ctx);
+    if (lin_mode != 2)
+      {
+        const int    tiles_x = (ctx->desc.ncell[0] + TX - 1) / TX, tiles_y = (ctx->desc.ncell[1] + TY - 1) / TY;
+        const long   stride2 = 27L * 2 * 4 * 48 + ctx->q2_state_pad;
+        const size_t count   = (size_t)tiles_x * tiles_y * ctx->desc.ncell[2] * 2 * stride2;
+        if (ctx->lin_q2.count != count)
+          {
+            if (ctx->lin_q2.p)
+              (void)hipFree(ctx->lin_q2.p);
+            ctx->lin_q2.p     = nullptr;
+            ctx->lin_q2.count = 0;
+            if (hipMalloc(&ctx->lin_q2.p, count * sizeof(double)) != hipSuccess)
+              return ADAFLO_ENOMEM;
+            ctx->lin_q2.count = count;
+            // cells beyond the mesh in partial tiles are never written: define them once
+            if (hipMemsetAsync(ctx->lin_q2.p, 0, count * sizeof(double), ctx->stream) != hipSuccess)
+              return ADAFLO_EHIP;
+          }
+      }
+    const double c_old = (old_comb && ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE) ? ctx->ns.density : 0.;
+    if (int e = q2_launch(ctx, OP_VMULT, sum_u, sum_p, src_u, src_p, -1, 0u, true, old_comb ? old_comb : src_u, c_old))
+      return e;
+    if (lin_mode != 2)
+      {
+        ctx->lin_q2_valid = true;
+        ctx->lin_q2_mode  = lin_mode;
+        ctx->lin_q2_varco = false;
+      }
+    return 0;
   }
 } // namespace adaflo_hip

@@ -246,6 +246,36 @@ namespace adaflo_hip
     return check();
   }
 
+  namespace
+  {
+    __global__ __launch_bounds__(VT) void lincomb_kernel(double *__restrict__ z, const double a, const double *__restrict__ x,
+                                                         const double b, const double *__restrict__ y, const long n)
+    {
+      for (long i = blockIdx.x * (long)VT + threadIdx.x; i < n; i += (long)gridDim.x * VT)
+        z[i] = a * x[i] + b * y[i];
+    }
+    // system_rhs.sadd(-1., 1., user_rhs) after the cell loop added `sum` to it (:266-293)
+    __global__ __launch_bounds__(VT) void residual_finish_kernel(double *__restrict__ rhs, const double *__restrict__ sum,
+                                                                 const double *__restrict__ user, const long n)
+    {
+      for (long i = blockIdx.x * (long)VT + threadIdx.x; i < n; i += (long)gridDim.x * VT)
+        rhs[i] = (user ? user[i] : 0.) - rhs[i] - sum[i];
+    }
+  } // namespace
+
+  int launch_lincomb(adaflo_ctx *ctx, double *z, const double a, const double *x, const double b, const double *y,
+                     const long n)
+  {
+    hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(n, 4)), dim3(VT), 0, ctx->stream, z, a, x, b, y, n);
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+
+  int launch_residual_finish(adaflo_ctx *ctx, double *rhs, const double *sum, const double *user, const long n)
+  {
+    hipLaunchKernelGGL(residual_finish_kernel, dim3(grid_for(n, 4)), dim3(VT), 0, ctx->stream, rhs, sum, user, n);
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+
   int launch_fill(adaflo_ctx *ctx, double *x, const double v, const long n)
   {
     hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(VT), 0, ctx->stream, x, v, n);

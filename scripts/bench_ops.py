@@ -52,6 +52,28 @@ def ns_case(k, n, variant, two_phase=False):
                       "frac_of_8TB/s": round(b_alg / t / 8e12, 4)}), flush=True)
 
 
+def ns_residual_case(k, n, variant):
+    """NavierStokesMatrix::residual (a3: the producer of the q-point state, once per Newton step);
+    algorithmic bytes: 3 velocity vectors + p read, 2 vectors written, state written once"""
+    fp = adaflo_amd.FlowParameters(velocity_degree=k)
+    ts = adaflo_amd.TimeStepping(fp)
+    for _ in range(3):
+        ts.next()
+    op = adaflo_amd.NavierStokesMatrix(fp, adaflo_amd.BrickMesh([n] * 3, [-1] * 3, [1] * 3))
+    op.initialize(ts, True)
+    op.set_kernel_variant(variant)
+    rng = np.random.default_rng(1)
+    sol = op.block_vector(rng.uniform(-1, 1, op.n_dofs_u()), rng.uniform(-1, 1, op.n_dofs_p()))
+    old = adaflo_amd.BlockVector([op.initialize_u_vector(rng.uniform(-1, 1, op.n_dofs_u()))])
+    oldold = adaflo_amd.BlockVector([op.initialize_u_vector(rng.uniform(-1, 1, op.n_dofs_u()))])
+    rhs = op.block_vector()
+    t = timeit(lambda: op.residual(rhs, sol, None, old, oldold), op.synchronize, reps=10, warm=2)
+    nq = (k + 1) ** 3
+    b_alg = op.n_cells() * (8 * (5 * 3 * k ** 3 + 2 * (k - 1) ** 3) + 8 * 12 * nq)
+    print(json.dumps({"op": "ns_residual", "k": k, "cells": n, "variant": variant, "ms": round(t * 1e3, 4),
+                      "alg_GB/s": round(b_alg / t / 1e9, 1), "frac_of_8TB/s": round(b_alg / t / 8e12, 4)}), flush=True)
+
+
 def ns_host_vector_case(n):
     """adapter case of SURVEY 8d: src / dst live in (pinned) host memory, so every vmult pays
     H2D of src and D2H of dst over PCIe -- reported beside, never instead of, the resident rate"""
@@ -144,8 +166,14 @@ def krylov_case(s, ncell):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "residual":
+        ns_residual_case(2, 128, 1)
+        ns_residual_case(2, 128, 0)
+        sys.exit(0)
     ns_case(2, 128, 1)
     ns_case(2, 128, 0)
+    ns_residual_case(2, 128, 1)
+    ns_residual_case(2, 128, 0)
     ns_host_vector_case(128)
     ns_case(2, 128, 1, two_phase=True)
     ns_case(2, 128, 0, two_phase=True)

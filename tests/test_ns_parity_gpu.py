@@ -393,3 +393,51 @@ def test_velocity_vmult_high_order_sweep_kernel():
     src, dst = op.initialize_u_vector(src_u), op.initialize_u_vector(np.full(case.n_u, 3.0))
     op.velocity_vmult(dst, src)
     assert rel_l2(dst.numpy(), ref) < TOL
+
+
+@pytest.mark.parametrize("ncell,upper,lin,phys", [((9, 8, 5), (1., 1., 1.), 0, 0), ((17, 9, 6), (1., 1., 3.), 0, 0),
+                                                  ((8, 16, 3), (1., 1., 1.), 1, 0), ((5, 4, 9), (1., 2., 1.), 0, 1),
+                                                  ((4, 5, 3), (1., 1., 1.), 0, 2), ((1, 1, 1), (1., 1., 1.), 0, 0)])
+def test_residual_sweep_kernel(ncell, upper, lin, phys):
+    """residual mode of the Q2/Q1 sweep kernel (partial and multiple tiles, several z-chunks, non-cubic
+    cells, Picard state, stationary and Stokes equations): right-hand side with the read-modify-write
+    semantics of the reference (rhs = user - rhs - cell loop), the state it leaves (both layouts) and the
+    operator applied on that state, against the oracle; generic kernel on the same inputs"""
+    case = Case(ncell, k=2, lower=(0., 0., 0.), upper=upper, linearization=lin, physical_type=phys, steps=3)
+    src_u, src_p = case.smooth_u(0.1) + 0.01 * case.random_u(), case.smooth_p(0.1)
+    old_u, oldold_u = case.smooth_u(0.05), case.smooth_u(0.0)
+    rhs0_u, rhs0_p, usr_u, usr_p = case.random_u(), case.random_p(), case.random_u(), case.random_p()
+    lin_ref = np.zeros(case.n_cells * case.nq * 12)
+    ref_u, ref_p = orc.ns_residual(case.mesh, case.k, case.prm, src_u, src_p, old_u, oldold_u,
+                                   con_u=case.con_u, con_p=case.con_p, lin=lin_ref, rhs_u=rhs0_u, rhs_p=rhs0_p,
+                                   user_u=usr_u, user_p=usr_p)
+    vm_u, vm_p = case.random_u(), case.random_p()
+    w, modes = case.weights_modes()
+    ref_vu, ref_vp = orc.ns_vmult(case.mesh, 2, case.prm, vm_u, vm_p, case.con_u, case.con_p, lin=lin_ref,
+                                  weights=w, modes=modes)
+    for variant in (1, 0):
+        op = case.engine()
+        op.set_kernel_variant(variant)
+        rhs = op.block_vector(rhs0_u, rhs0_p)
+        op.residual(rhs, op.block_vector(src_u, src_p), op.block_vector(usr_u, usr_p), op.block_vector(old_u),
+                    op.block_vector(oldold_u))
+        got_u, got_p = rhs.numpy()
+        assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL, (variant, rel_l2(got_u, ref_u))
+        dst = op.block_vector()
+        op.vmult(dst, op.block_vector(vm_u, vm_p))      # streaming state written by the residual
+        gu, gp = dst.numpy()
+        assert rel_l2(gu, ref_vu) < TOL and rel_l2(gp, ref_vp) < TOL, (variant, rel_l2(gu, ref_vu))
+        if phys != 2:
+            ncomp = 12 if lin == 0 else 4
+            got_lin = op.get_linearization().reshape(-1, 12)
+            assert rel_l2(got_lin[:, :ncomp], lin_ref.reshape(-1, 12)[:, :ncomp]) < TOL
+            # frozen state of the preconditioner: velocity_vmult keeps using it after a new residual
+            op.fix_linearization_point()
+            ref_vel = orc.ns_velocity_vmult(case.mesh, 2, case.prm, vm_u, case.con_u, lin=lin_ref)
+            op.residual(rhs, op.block_vector(0.5 * src_u, src_p), None, op.block_vector(old_u), op.block_vector(oldold_u))
+            vsrc, vdst = op.initialize_u_vector(vm_u), op.initialize_u_vector()
+            op.velocity_vmult(vdst, vsrc)
+            assert rel_l2(vdst.numpy(), ref_vel) < TOL, variant
+            op.set_kernel_variant(0)                      # generic kernel on the frozen streaming copy
+            op.velocity_vmult(vdst, vsrc)
+            assert rel_l2(vdst.numpy(), ref_vel) < TOL, variant
