@@ -723,6 +723,21 @@ int adaflo_ns_divergence_vmult_add(adaflo_ctx *ctx, double *dst_p, const double 
   CHECK_CTX(ctx);
   if (!dst_p || !src_u)
     return fail(ctx, ADAFLO_EINVAL, "null vector");
+  // Q2/Q1, constant viscosity, constraints of src resolved (:935-939: plain read only for the
+  // projection scheme): divergence mode of the sweep kernel, then dst += sums on the free rows
+  if (ctx->variant >= 1 && ctx->k == 2 && !(weight_by_viscosity && ctx->mu.p) &&
+      ctx->ns.linearization != ADAFLO_PROJECTION)
+    {
+      TRY(ctx, alloc(ctx, ctx->res_sum_p, ctx->n_nodes_p), ctx->last_error);
+      TRY(ctx,
+          launch_ns_divergence_q2(ctx, ctx->res_sum_p.p, src_u, dst_p, weight_by_viscosity ? -ctx->ns.viscosity : -1.),
+          "Q2 divergence kernel launch failed");
+      TRY(ctx,
+          launch_add_unconstrained(ctx, dst_p, ctx->res_sum_p.p, ctx->n_nodes_p, 1, nn(ctx, 1, 0), nn(ctx, 1, 1),
+                                   nn(ctx, 1, 2), ctx->brick.con_p),
+          "add failed");
+      return 0;
+    }
   return scalar_op(ctx, dst_p, src_u, weight_by_viscosity ? SC_DIVERGENCE_VISC : SC_DIVERGENCE,
                    ctx->mu.p, true, false);
 }

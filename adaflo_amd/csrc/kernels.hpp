@@ -12,7 +12,8 @@ namespace adaflo_hip
   {
     OP_VMULT          = 0, // NavierStokesOps::vmult        include/adaflo/navier_stokes_matrix.h:36-41
     OP_RESIDUAL       = 1,
-    OP_VMULT_VELOCITY = 2
+    OP_VMULT_VELOCITY = 2,
+    OP_DIVERGENCE     = 3 // Q2/Q1 sweep kernel only: the divergence block
   };
 
   constexpr int NLIN = 12; // dim + dim*dim doubles of linearisation state per q-point
@@ -116,6 +117,10 @@ namespace adaflo_hip
   int  launch_ns_residual_q2(adaflo_ctx *ctx, double *sum_u, double *sum_p, const double *src_u,
                              const double *src_p, const double *old_comb);
   int  q2_unconvert_state(adaflo_ctx *ctx, double *generic, const double *streaming, int lin_mode);
+  int  launch_ns_divergence_q2(adaflo_ctx *ctx, double *sum_p, const double *src_u, const double *any_p, double weight);
+  // dst[i] += src[i] for the entries that are not on a constrained face
+  int launch_add_unconstrained(adaflo_ctx *ctx, double *dst, const double *src, long n_nodes, int ncomp, int nnx,
+                               int nny, int nnz, uint32_t mask);
 
   // compute_heaviside / local_compute_force (ls_force.hip)
   int                 launch_ls_heaviside(adaflo_ctx *ctx, double *heaviside, const double *phi, double epsilon);

@@ -59,6 +59,7 @@ namespace adaflo_hip
       const double *old_u;
       double        c_old;
       double       *state_out;
+      double        c_div; // divergence mode: -1 or -viscosity (weight_by_viscosity)
       // phased execution for the multi-GPU overlap (launch_ns_vmult_q2): explicit workgroup list
       // for the main kernel, node filter for the fix-up (1: only nodes on the inter-GPU interface
       // faces `iface`, 2: all other nodes, 0: everything)
@@ -397,10 +398,13 @@ namespace adaflo_hip
     // src is the solution itself (plain read incl. boundary values), the combination of the old
     // solutions enters the momentum row, the nonlinear term is evaluated with src, and the
     // quadrature-point state (:725-800) is WRITTEN in the streaming layout instead of being read
-    template <int LIN_MODE, bool WITH_P, bool ISO, bool VARCO, bool RES = false>
+    // DIV: divergence block only (local_divergence, :920-961): the pressure lane integrates
+    // (q, c_div div u), the velocity lanes evaluate but integrate and emit nothing
+    template <int LIN_MODE, bool WITH_P, bool ISO, bool VARCO, bool RES = false, bool DIV = false>
     __global__ __launch_bounds__(NT, 2) void ns_q2_kernel(const Q2Args A)
     {
       constexpr bool RING_ON = LIN_MODE != 2 && !RES; // state stream through the LDS ring
+      static_assert(!DIV || (LIN_MODE == 2 && WITH_P && !RES && !VARCO), "divergence mode");
       static_assert(!(RES && VARCO), "residual mode: constant coefficients only");
       extern __shared__ double lds[];
       // state ring geometry.  Constant coefficients: pieces of 48 lanes x 16 B, 9 slots.
@@ -828,6 +832,11 @@ namespace adaflo_hip
                 }
 
               const double jxw = A.wj[(qx == 1) + (qy == 1) + (qz == 1)];
+              if (DIV)
+                {
+                  R[q] += (is_p ? A.c_div * div : 0.) * jxw;
+                  continue;
+                }
               // c_e = column d of the velocity gradient (transpose part of the symmetric gradient)
               double diag = A.tau_gd * div;
               if (WITH_P)
@@ -882,7 +891,10 @@ namespace adaflo_hip
 #endif
           // ---- D: publish what the east / north neighbour cells need ----------------------
           // velocity: local (2,0) (2,1) (2,2) (0,2) (1,2) of every plane -> slots 0..4
-          if (!is_p)
+          if (DIV && !is_p)
+            {
+            }
+          else if (!is_p)
             {
               double *sc = lds + L_SCRU + cell * 3 + d;
 #pragma unroll
@@ -946,7 +958,10 @@ namespace adaflo_hip
           const bool valid = cxl < tcx && cyl < tcy;
           const bool lastx = valid && cxl == tcx - 1, lasty = valid && cyl == tcy - 1; // valid cells only
           const bool hasW = cxl > 0, hasS = cyl > 0;
-          if (!is_p)
+          if (DIV && !is_p)
+            {
+            }
+          else if (!is_p)
             {
               const double *sc = lds + L_SCRU + cell * 3 + d;
 #pragma unroll
@@ -1123,7 +1138,10 @@ namespace adaflo_hip
       {
         const int  cze   = cz0 + nl;
         const bool zseam = cze < A.ncz;
-        if (!is_p)
+        if (DIV && !is_p)
+          {
+          }
+        else if (!is_p)
           {
             const int     K     = 2 * cze;
             const bool    zcon  = (K == A.nnz - 1 && conz_hi);
@@ -1492,7 +1510,7 @@ namespace adaflo_hip
                        const double *src_p, const int phase, const uint32_t iface, const bool residual,
                        const double *res_old, const double res_c_old)
   {
-    if (!residual)
+    if (!residual && op != OP_DIVERGENCE)
       {
         if (ctx->lin_q2_valid && (ctx->lin_q2_mode != q2_lin_mode(ctx) || ctx->lin_q2_varco != q2_varco(ctx)))
           ctx->lin_q2_valid = false;
@@ -1500,9 +1518,11 @@ namespace adaflo_hip
           return e;
       }
     Q2Args A{};
+    const bool divergence = op == OP_DIVERGENCE;
     A.old_u     = res_old;
     A.c_old     = res_c_old;
     A.state_out = residual ? ctx->lin_q2.p : nullptr;
+    A.c_div     = res_c_old; // (divergence mode passes its weight here)
     A.ncx = ctx->desc.ncell[0];
     A.ncy = ctx->desc.ncell[1];
     A.ncz = ctx->desc.ncell[2];
@@ -1567,8 +1587,8 @@ namespace adaflo_hip
     A.dst_u       = dst_u;
     A.dst_p       = dst_p;
     A.state       = use_prec ? ctx->lin_q2_prec.p : ctx->lin_q2.p;
-    const int  lin_mode = q2_lin_mode(ctx);
-    const bool with_p   = op == OP_VMULT;
+    const int  lin_mode = divergence ? 2 : q2_lin_mode(ctx);
+    const bool with_p   = op == OP_VMULT || divergence;
 
     // seam partial sums go to slabs (no atomics, no zero-initialisation of dst needed: every
     // entry of dst is written exactly once by the main kernel or by the fix-up kernel)
@@ -1652,6 +1672,18 @@ namespace adaflo_hip
     if (err == hipSuccess && nwg > 0)                                                           \
       hipLaunchKernelGGL((ns_q2_kernel<LM, WP, IS, VC, RS>), grid, block, lds_bytes, ctx->stream, A); \
   }
+#define Q2_LAUNCH_V6(LM, WP, IS, VC, RS, DV)                                                          \
+  {                                                                                             \
+    static bool attr_set = false;                                                               \
+    if (!attr_set)                                                                              \
+      {                                                                                         \
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_q2_kernel<LM, WP, IS, VC, RS, DV>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
+        attr_set = err == hipSuccess;                                                           \
+      }                                                                                         \
+    if (err == hipSuccess && nwg > 0)                                                           \
+      hipLaunchKernelGGL((ns_q2_kernel<LM, WP, IS, VC, RS, DV>), grid, block, lds_bytes, ctx->stream, A); \
+  }
 #define Q2_LAUNCH_I(LM, WP, IS)              \
   {                                          \
     if (varco)                               \
@@ -1666,7 +1698,14 @@ namespace adaflo_hip
     else                       \
       Q2_LAUNCH_I(LM, WP, false) \
   }
-    if (residual)
+    if (divergence)
+      {
+        if (iso)
+          Q2_LAUNCH_V6(2, true, true, false, false, true)
+        else
+          Q2_LAUNCH_V6(2, true, false, false, false, true)
+      }
+    else if (residual)
       {
         // (constant coefficients, src = the solution: launch_ns_residual_q2)
         if (iso)
@@ -1721,6 +1760,7 @@ namespace adaflo_hip
 #undef Q2_LAUNCH
 #undef Q2_LAUNCH_I
 #undef Q2_LAUNCH_V
+#undef Q2_LAUNCH_V6
     if (err != hipSuccess)
       return ADAFLO_EHIP;
     if (stop)
@@ -1731,7 +1771,7 @@ namespace adaflo_hip
     {
       const long tiles = (long)A.tiles_x * A.tiles_y;
       const bool fix_p = with_p && A.integrate_p;
-      const long n1 = tiles * A.nnz, n2 = tiles * (A.n_chunks - 1);
+      const long n1 = divergence ? 0 : tiles * A.nnz, n2 = divergence ? 0 : tiles * (A.n_chunks - 1);
       const long n3 = fix_p ? tiles * A.npz : 0, n4 = fix_p ? tiles * (A.n_chunks - 1) : 0;
       long       nb = n1 + n2 + n3 + n4;
       if (nb > 256 * 512)
@@ -1745,6 +1785,13 @@ namespace adaflo_hip
                          const double *src_p, const int phase, const uint32_t iface)
   {
     return q2_launch(ctx, op, dst_u, dst_p, src_u, src_p, phase, iface, false, nullptr, 0.);
+  }
+
+  // sum_p = cell loop of local_divergence (q, weight div u) with the constraints of src_u resolved;
+  // entries on constrained pressure rows are undefined (the caller skips them)
+  int launch_ns_divergence_q2(adaflo_ctx *ctx, double *sum_p, const double *src_u, const double *any_p, const double weight)
+  {
+    return q2_launch(ctx, OP_DIVERGENCE, nullptr, sum_p, src_u, any_p, -1, 0u, false, nullptr, weight);
   }
 
   // residual on the sweep structure: Newton / Picard-type linearisations (the state they store is

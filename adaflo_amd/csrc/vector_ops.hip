@@ -263,6 +263,32 @@ namespace adaflo_hip
     }
   } // namespace
 
+  namespace
+  {
+    __global__ __launch_bounds__(VT) void add_unconstrained_kernel(double *__restrict__ dst, const double *__restrict__ src,
+                                                                   const long n_nodes, const int ncomp, const int nnx,
+                                                                   const int nny, const int nnz, const uint32_t mask)
+    {
+      const long n = n_nodes * ncomp;
+      for (long i = blockIdx.x * (long)VT + threadIdx.x; i < n; i += (long)gridDim.x * VT)
+        {
+          const long node = i / ncomp;
+          const int  c    = (int)(i - node * ncomp);
+          const int  I = node % nnx, J = (node / nnx) % nny, K = node / ((long)nnx * nny);
+          if (mask == 0u || !on_constrained_face(I, J, K, nnx, nny, nnz, mask, ncomp == 1 ? 1 : 3, c))
+            dst[i] += src[i];
+        }
+    }
+  } // namespace
+
+  int launch_add_unconstrained(adaflo_ctx *ctx, double *dst, const double *src, const long n_nodes, const int ncomp,
+                               const int nnx, const int nny, const int nnz, const uint32_t mask)
+  {
+    hipLaunchKernelGGL(add_unconstrained_kernel, dim3(grid_for(n_nodes * ncomp)), dim3(VT), 0, ctx->stream, dst, src,
+                       n_nodes, ncomp, nnx, nny, nnz, mask);
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+
   int launch_lincomb(adaflo_ctx *ctx, double *z, const double a, const double *x, const double b, const double *y,
                      const long n)
   {

@@ -74,6 +74,25 @@ def ns_residual_case(k, n, variant):
                       "alg_GB/s": round(b_alg / t / 1e9, 1), "frac_of_8TB/s": round(b_alg / t / 8e12, 4)}), flush=True)
 
 
+def ns_divergence_case(ncell, variant):
+    """divergence_vmult_add (a5), once per application of the block preconditioner: reads the
+    velocity vector, read-modify-writes the pressure vector"""
+    fp = adaflo_amd.FlowParameters(velocity_degree=2)
+    ts = adaflo_amd.TimeStepping(fp)
+    for _ in range(3):
+        ts.next()
+    op = adaflo_amd.NavierStokesMatrix(fp, adaflo_amd.BrickMesh(list(ncell), [0, 0, 0], [1, 1, 2]))
+    op.initialize(ts, True)
+    op.set_kernel_variant(variant)
+    rng = np.random.default_rng(1)
+    su = op.initialize_u_vector(rng.uniform(-1, 1, op.n_dofs_u()))
+    dp = op.initialize_p_vector()
+    t = timeit(lambda: op.divergence_vmult_add(dp, su, False), op.synchronize)
+    b_alg = 8 * op.n_dofs_u() + 16 * op.n_dofs_p()
+    print(json.dumps({"op": "ns_divergence_vmult_add", "cells": list(ncell), "variant": variant, "ms": round(t * 1e3, 4),
+                      "alg_GB/s": round(b_alg / t / 1e9, 1), "frac_of_8TB/s": round(b_alg / t / 8e12, 4)}), flush=True)
+
+
 def ns_host_vector_case(n):
     """adapter case of SURVEY 8d: src / dst live in (pinned) host memory, so every vmult pays
     H2D of src and D2H of dst over PCIe -- reported beside, never instead of, the resident rate"""
@@ -169,11 +188,17 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "residual":
         ns_residual_case(2, 128, 1)
         ns_residual_case(2, 128, 0)
+        for v in (1, 0):
+            ns_divergence_case((64, 64, 128), v)
+            ns_divergence_case((128, 128, 128), v)
         sys.exit(0)
     ns_case(2, 128, 1)
     ns_case(2, 128, 0)
     ns_residual_case(2, 128, 1)
     ns_residual_case(2, 128, 0)
+    for v in (1, 0):
+        ns_divergence_case((64, 64, 128), v)
+        ns_divergence_case((128, 128, 128), v)
     ns_host_vector_case(128)
     ns_case(2, 128, 1, two_phase=True)
     ns_case(2, 128, 0, two_phase=True)
