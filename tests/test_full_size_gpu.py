@@ -1,0 +1,80 @@
+"""Full-size parity of the BASELINE configurations on one MI355X:
+  config 2  128^3 Q2/Q1 Newton vmult against the oracle's OpenMP restatement (oracle/adaflo_oracle_fast.c,
+            itself checked against the naive oracle in tests/test_oracle_kats.py) on the same seeded inputs;
+  config 5  64^3 Q4/Q3 stationary driven-cavity operator: wave-private sweep kernel against the generic
+            per-cell kernel (independent code) + linearity;
+  config 3  the whole 256^3 Q2/Q1 problem (422 M DoF) on ONE GPU: sweep kernel against the generic kernel +
+            linearity (marked slow)."""
+import numpy as np
+import pytest
+
+from common import Case, rel_l2
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def test_config2_128cubed_against_openmp_oracle():
+    n = 128
+    case = Case((n, n, n), k=2)
+    rng = np.random.default_rng(20260515)
+    src_u, src_p = rng.uniform(-1, 1, case.n_u), rng.uniform(-1, 1, case.n_p)
+    lin = rng.uniform(-1, 1, case.n_cells * 27 * 12)
+    w, modes = case.weights_modes()
+    orc.fast_set_threads(orc.usable_cores())
+    ref_u, ref_p = orc.fast_ns_vmult(case.mesh, 2, case.prm, src_u, src_p, case.con_u, None, lin=lin,
+                                     weights=w, modes=modes)
+    op = case.engine()
+    op.set_linearization(lin)
+    del lin
+    dst = op.block_vector()
+    op.vmult(dst, op.block_vector(src_u, src_p))
+    got_u, got_p = dst.numpy()
+    assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL, (rel_l2(got_u, ref_u), rel_l2(got_p, ref_p))
+
+
+def _sweep_vs_generic_and_linearity(case, nq):
+    op = case.engine()
+    rng = np.random.default_rng(11)
+    # linearisation point = Beltrami interpolant seen through the residual kernel (as bench.py)
+    u0 = case.smooth_u(0.0)
+    tmp = op.block_vector()
+    op.residual(tmp, op.block_vector(u0, case.smooth_p(0.0)), None, op.block_vector(u0), op.block_vector())
+    del tmp
+    x_u, x_p = rng.uniform(-1, 1, case.n_u), rng.uniform(-1, 1, case.n_p)
+    y_u, y_p = rng.uniform(-1, 1, case.n_u), rng.uniform(-1, 1, case.n_p)
+    x = op.block_vector(x_u, x_p)
+    dst = op.block_vector()
+    res = {}
+    for variant in (1, 0):
+        op.set_kernel_variant(variant)
+        op.vmult(dst, x)
+        res[variant] = dst.numpy()
+    assert rel_l2(res[1][0], res[0][0]) < TOL and rel_l2(res[1][1], res[0][1]) < TOL
+    op.set_kernel_variant(1)
+    ax_u, ax_p = res[1]
+    x.block(0).set(y_u)
+    x.block(1).set(y_p)
+    op.vmult(dst, x)
+    ay_u, ay_p = dst.numpy()
+    a, b = 0.75, -1.25
+    x.block(0).set(a * x_u + b * y_u)
+    x.block(1).set(a * x_p + b * y_p)
+    op.vmult(dst, x)
+    z_u, z_p = dst.numpy()
+    assert rel_l2(z_u, a * ax_u + b * ay_u) < TOL and rel_l2(z_p, a * ax_p + b * ay_p) < TOL
+
+
+def test_config5_q4_cavity_64cubed_properties():
+    """BASELINE configs[4]: Q4/Q3, 64^3 cells on [0,1]x[0,1]x[0,3], `incompressible stationary`, mu = 0.01"""
+    case = Case((64, 64, 64), k=4, lower=(0., 0., 0.), upper=(1., 1., 3.), physical_type=1, viscosity=0.01)
+    _sweep_vs_generic_and_linearity(case, 125)
+
+
+@pytest.mark.slow
+def test_config3_256cubed_on_one_gpu_properties():
+    """BASELINE configs[2] without the partition: the whole 256^3 Q2/Q1 mesh (422 M DoF, 43.5 GB of
+    Newton state) on one MI355X"""
+    case = Case((256, 256, 256), k=2)
+    _sweep_vs_generic_and_linearity(case, 27)
