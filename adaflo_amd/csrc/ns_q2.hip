@@ -1228,7 +1228,7 @@ namespace adaflo_hip
       const int     c_hi = min(K / (DEG * A.LZ), A.n_chunks - 1);
       const int     lp   = K - DEG * A.LZ * c_hi;
       const bool    zb   = lp == 0 && c_hi > 0; // K is the top plane of the chunk below as well
-      for (int e = threadIdx.x; e < NE; e += 64)
+      for (int e = threadIdx.x & 63; e < NE; e += 64)
         {
           const int comp = e % NC, s = e / NC;
           const int i = s < TN ? s : 0, j = s < TN ? 0 : s - TN + 1; // south row, then west column
@@ -1273,7 +1273,7 @@ namespace adaflo_hip
       constexpr int TN = DEG * TX + 1;
       const int     bx = (int)(bt % A.tiles_x), by = (int)(bt / A.tiles_x);
       const int     K  = DEG * A.LZ * m;
-      for (int e = threadIdx.x; e < TN * TN * NC; e += 64)
+      for (int e = threadIdx.x & 63; e < TN * TN * NC; e += 64)
         {
           const int comp = e % NC, n = e / NC, i = n % TN, j = n / TN;
           const int I = DEG * TX * bx + i, J = DEG * TY * by + j;
@@ -1290,10 +1290,12 @@ namespace adaflo_hip
 
     // blocks [0,n1): velocity rim (tile, K); [n1,n1+n2): velocity z-planes (tile, m);
     // then the same two ranges for the pressure
-    __global__ __launch_bounds__(64) void q2_seam_fixup_kernel(const Q2Args A, const long n1, const long n2,
-                                                               const long n3, const long n4)
+    // (one wave per work item, FIXW waves per workgroup)
+    constexpr int FIXW = 4;
+    __global__ __launch_bounds__(64 * FIXW) void q2_seam_fixup_kernel(const Q2Args A, const long n1, const long n2,
+                                                                      const long n3, const long n4)
     {
-      for (long b = blockIdx.x; b < n1 + n2 + n3 + n4; b += gridDim.x)
+      for (long b = (long)blockIdx.x * FIXW + (threadIdx.x >> 6); b < n1 + n2 + n3 + n4; b += (long)gridDim.x * FIXW)
         {
           if (b < n1)
             fixup_rim<2, 3>(A, b / A.nnz, (int)(b % A.nnz), A.dst_u, A.slab_u, A.zslab_u, A.nnx, A.nny, A.nnz, A.con_u);
@@ -1773,10 +1775,10 @@ namespace adaflo_hip
       const bool fix_p = with_p && A.integrate_p;
       const long n1 = divergence ? 0 : tiles * A.nnz, n2 = divergence ? 0 : tiles * (A.n_chunks - 1);
       const long n3 = fix_p ? tiles * A.npz : 0, n4 = fix_p ? tiles * (A.n_chunks - 1) : 0;
-      long       nb = n1 + n2 + n3 + n4;
-      if (nb > 256 * 512)
-        nb = 256 * 512;
-      hipLaunchKernelGGL(q2_seam_fixup_kernel, dim3((unsigned)nb), dim3(64), 0, ctx->stream, A, n1, n2, n3, n4);
+      long       nb = (n1 + n2 + n3 + n4 + FIXW - 1) / FIXW;
+      if (nb > 256 * 128)
+        nb = 256 * 128;
+      hipLaunchKernelGGL(q2_seam_fixup_kernel, dim3((unsigned)nb), dim3(64 * FIXW), 0, ctx->stream, A, n1, n2, n3, n4);
     }
     return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
   }

@@ -9,7 +9,7 @@ method of Olsson, Kreiss and Zahedi) on a uniform brick, every vector and every 
 
 One engine context carries the Navier-Stokes operator and the level-set operators, so that
 compute_force writes the density / viscosity arrays the two-phase Jacobian reads.  Not mirrored:
-adaptive mesh refinement, convection stabilisation, output."""
+adaptive mesh refinement (hence no `last_refine_step`), output."""
 import numpy as np
 
 from . import level_set_okz as lso
@@ -40,6 +40,12 @@ class LevelSetOKZSolver:
         self.normal_operator = lso.LevelSetOKZSolverComputeNormal(self.ops)
         self.curvature_operator = lso.LevelSetOKZSolverComputeCurvature(self.ops)
         self.n_reinit_steps = n_reinit_steps
+        # level_set_base.cc:61-63: bookkeeping of the "correct excessive residual" branch;
+        # two_phase_base.h:233: range of the level set seen by the last get_concentration_range()
+        self.old_residual = float("inf")
+        self.last_smoothing_step = 0
+        self.last_concentration_range = (0.0, 0.0)
+        self.smoothing_steps = []
         v = self.ops.vector
         self.solution, self.solution_old, self.solution_old_old = v(), v(), v()     # block 0: level set
         self.curvature, self.curvature_old, self.curvature_old_old = v(), v(), v()  # block 1: curvature
@@ -87,6 +93,7 @@ class LevelSetOKZSolver:
 
     def advance_concentration(self):
         ts = self.ts_advect
+        ts.set_desired_time_step(self.time_stepping.step_size())     # advance_concentration.cc:508
         ts.next()
         self._push_ls_parameters(ts)
         vel = self.navier_stokes.navier_stokes_matrix.wrap(self.navier_stokes.solution[0])
@@ -102,10 +109,12 @@ class LevelSetOKZSolver:
 
     def reinitialize(self, stab_steps, diff_steps=0):
         ts = self.ts_reinit
+        ts.set_desired_time_step(self.time_stepping.step_size())     # reinitialization.cc:264
         self._push_ls_parameters(ts)
         its = self.reinit_operator.reinitialize(self.solution, self.normal_vector_field, self.system_rhs,
                                                 self.solution_update, self.preconditioner, stab_steps, diff_steps,
-                                                compute_normal=self.compute_normal)
+                                                compute_normal=self.compute_normal,
+                                                last_concentration_range=self.last_concentration_range)
         ts.next()
         self.reinit_iterations.append(its)
 
@@ -126,14 +135,50 @@ class LevelSetOKZSolver:
                                self.parameters)
 
     def advance_time_step(self):
-        """level_set_base.cc:248-291 (do_iteration = false)"""
+        """level_set_base.cc:248-291 (do_iteration = false).  When the curvature gets bad the initial
+        Navier-Stokes residual jumps: if it is at least twice that of the previous step (and the last
+        smoothing is more than three steps ago) ten additional diffusion steps are taken, the force is
+        recomputed and the residual evaluated again (:262-278)"""
         self.init_time_advance()
         self.advance_concentration()
         self.reinitialize(self.n_reinit_steps)
         self.compute_force()
         ns = self.navier_stokes
-        res = ns.compute_residual()
-        return ns.solve_nonlinear_system(res)
+        actual_res = ns.compute_initial_residual()
+        step_no = self.time_stepping.step_no()
+        if step_no > 3 + self.last_smoothing_step and actual_res >= 2.0 * self.old_residual:
+            self.reinitialize(self.n_reinit_steps, 10)
+            self.compute_force()
+            actual_res = ns.compute_initial_residual()
+            self.last_smoothing_step = step_no
+            self.smoothing_steps.append(step_no)
+        self.old_residual = actual_res
+        return ns.solve_nonlinear_system(actual_res)
+
+    def get_concentration_range(self):
+        """TwoPhaseBaseAlgorithm::get_concentration_range (two_phase_base.cc:515-545): smallest / largest
+        value of the level set on the (s + 2)-times iterated trapezoid points of every cell; remembered
+        for the next reinitialize(), which adds three diffusion steps once the profile has left
+        [-1.02, 1.02] (reinitialization.cc:281-284)"""
+        m, s = self.mesh, self.parameters.concentration_subdivisions
+        nn = [s * n + 1 for n in m.ncell]
+        phi = self.solution.numpy().reshape(nn[2], nn[1], nn[0])
+        t = np.arange(s + 3) / (s + 2.0) * s                 # positions in units of sub-cells
+        i0 = np.minimum(t.astype(int), s - 1)
+        w = np.zeros((s + 3, s + 1))
+        w[np.arange(s + 3), i0] = 1.0 - (t - i0)
+        w[np.arange(s + 3), i0 + 1] = t - i0
+        lo, hi = np.inf, -np.inf
+        for cz in range(m.ncell[2]):                          # one layer of cells at a time (memory)
+            blk = phi[s * cz:s * cz + s + 1]
+            blk = np.einsum("pk,kyx->pyx", w, blk)
+            ys = np.lib.stride_tricks.sliding_window_view(blk, s + 1, axis=1)[:, ::s]       # [p][cy][x][j]
+            blk = np.einsum("qj,pcxj->pcqx", w, ys)
+            xs = np.lib.stride_tricks.sliding_window_view(blk, s + 1, axis=3)[:, :, :, ::s]  # [p][cy][q][cx][i]
+            val = np.einsum("ri,pcqxi->pcqxr", w, xs)
+            lo, hi = min(lo, float(val.min())), max(hi, float(val.max()))
+        self.last_concentration_range = (lo, hi)
+        return self.last_concentration_range
 
     # ---- diagnostics (tests/rising_bubble.cc evaluates the same quantities) ----------------------
     def bubble_volume_and_centre(self):

@@ -47,6 +47,10 @@ class NavierStokes:
         """dirichlet_function(xyz[n][3], t) -> velocity[n][3] on the (all-Dirichlet) boundary;
         ls_degree > 0 adds the level-set spaces to the engine context (two-phase flow)"""
         import torch
+        if parameters.linearization == "projection":
+            # the pressure-projection scheme needs the p^n swap and the phi extrapolation of
+            # navier_stokes.cc:689-717,839-841; the operators support it, this driver does not
+            raise NotImplementedError("linearization = projection is not driven by NavierStokes (operators only)")
         self.parameters, self.mesh, self.time_stepping = parameters, mesh, time_stepping
         self.dirichlet_function = dirichlet_function
         self.device = torch.device("cuda", device)
@@ -74,7 +78,12 @@ class NavierStokes:
         self.solution_update = [mk(nu), mk(npp)]
         self.system_rhs = [mk(nu), mk(npp)]
         self.user_rhs = [mk(nu), mk(npp)]     # surface tension + gravity (LevelSetOKZSolver::compute_force)
+        # when to rebuild the preconditioner (navier_stokes.cc:121-124, 870-970)
         self.update_preconditioner = True
+        self.update_preconditioner_frequency = 0
+        self.n_iterations_last_prec_update = 0
+        self.time_step_last_prec_update = 0
+        self.n_preconditioner_builds = 0
         self.history = []           # (res_u, res_p) per compute_residual, like the reference's table
         self.linear_iterations = []
 
@@ -101,7 +110,6 @@ class NavierStokes:
             cur.copy_(tmp)
         vals = np.ascontiguousarray(self.dirichlet_function(self._bxyz, ts.now()), dtype=np.float64).reshape(-1)
         self.solution[0][self._bdofs] = torch.from_numpy(vals).to(self.device)
-        self.update_preconditioner = True
 
     def compute_residual(self):
         m = self.navier_stokes_matrix
@@ -115,9 +123,11 @@ class NavierStokes:
         self.history.append((res_u, res_p))
         return float(np.hypot(res_u, res_p))
 
+    compute_initial_residual = compute_residual     # (:805-827 only prints a table header before)
+
     def build_preconditioner(self):
         _lib.check(self._ctx, self._lib.adaflo_ns_preconditioner_setup(self._ctx))
-        self.update_preconditioner = False
+        self.n_preconditioner_builds += 1
 
     def solve_system(self, linear_tolerance):
         p = self.parameters
@@ -130,28 +140,59 @@ class NavierStokes:
         return res.iterations, res.final_residual
 
     def solve_nonlinear_system(self, initial_residual):
-        p = self.parameters
+        """navier_stokes.cc:832-975: at least one linear solve; only the fully implicit schemes iterate
+        (the others stop after their one linear system, :906-914); the preconditioner is rebuilt in
+        the first step when requested, early inside the iteration when the linear solver needs 1.5 x
+        the iterations it needed right after the last rebuild (every sixth step of a stationary
+        solve), and requested for the next time step by the iteration-count rules at the end"""
+        p, ts = self.parameters, self.time_stepping
+        implicit = p.linearization in ("coupled implicit Newton", "coupled implicit Picard")
         res = initial_residual
         n_tot = 0
-        for step in range(p.max_nl_iteration):
+        premature_update = False
+        step = 0
+        while step < p.max_nl_iteration:
             linear_tolerance = p.tol_lin_iteration
             if p.rel_lin_iteration:     # :862-876
-                newton = p.linearization in ("coupled implicit Newton", "coupled implicit Picard")
-                if res * p.tol_lin_iteration < 0.5 * p.tol_nl_iteration or not newton:
+                if res * p.tol_lin_iteration < 0.5 * p.tol_nl_iteration or not implicit:
                     linear_tolerance = 0.5 * p.tol_nl_iteration
                 else:
                     linear_tolerance = min(p.tol_lin_iteration * res, p.tol_lin_iteration)
             if step == 0 and self.update_preconditioner:
                 self.build_preconditioner()
+            elif ((not premature_update and ts.step_no() > 1 and n_tot > 1.5 * self.n_iterations_last_prec_update)
+                  or (p.physical_type == "incompressible stationary" and step % 6 == 1)):
+                self.build_preconditioner()
+                premature_update = True
             its, lin_res = self.solve_system(linear_tolerance)
             self.linear_iterations.append((its, lin_res))
             n_tot += its
             self.solution[0] += self.solution_update[0]
             self.solution[1] += self.solution_update[1]
+            if not implicit:
+                break                   # (the reference returns `step` = 0 here)
             res = self.compute_residual()
             if res < p.tol_nl_iteration:
                 break
-        return step + 1, n_tot
+            step += 1
+        # :941-970 does the linear solver deteriorate?
+        no = ts.step_no()
+        if self.update_preconditioner_frequency > 0 and no % (50 * self.update_preconditioner_frequency) == 0:
+            self.update_preconditioner_frequency = 0
+        if self.update_preconditioner:
+            self.n_iterations_last_prec_update = n_tot
+            self.time_step_last_prec_update = no
+            self.update_preconditioner = False
+        if n_tot > 1.2 * self.n_iterations_last_prec_update:
+            if premature_update or n_tot > 2 * self.n_iterations_last_prec_update:
+                self.update_preconditioner_frequency = no - self.time_step_last_prec_update
+            self.update_preconditioner = True
+        if (self.time_step_last_prec_update < 3 and no > 14) or no < 2:
+            self.update_preconditioner = True
+        if (not self.update_preconditioner and not premature_update and self.update_preconditioner_frequency > 0
+                and no + 1 - self.time_step_last_prec_update >= self.update_preconditioner_frequency):
+            self.update_preconditioner = True
+        return step, n_tot
 
     def advance_time_step(self):
         self.init_time_advance()

@@ -29,9 +29,9 @@ class FlowParameters:
     time_step_scheme: str = "bdf_2"
     start_time: float = 0.0
     end_time: float = 1.0
-    time_step_size_start: float = 0.05
-    time_step_size_max: float = 1e10
-    time_step_size_min: float = 0.0
+    time_step_size_start: float = 1e-2     # parameters.cc:377-410 (declare_entry defaults)
+    time_step_size_max: float = 1.0
+    time_step_size_min: float = 0.1
     # two-phase section (parameters.cc:285-330, defaults of the reference)
     surface_tension: float = 1.0
     gravity: float = 0.0
@@ -66,6 +66,10 @@ class FlowParameters:
             raise ValueError("Invalid parameter value")
         if self.physical_type == "stokes":  # parameters.cc:477-478
             self.density = 0.0
+        # parameters.cc:593-595 (applied at parse time in the reference; here also for parameter
+        # objects built in code, so that both behave like an input file with the same keys)
+        if self.time_step_size_min > self.time_step_size_start:
+            self.time_step_size_max = self.time_step_size_min = self.time_step_size_start
 
     @property
     def beta(self):
@@ -161,7 +165,5 @@ def flow_parameters_from_prm(text):
         if v is not None and float(v) > 0.0:
             kw[name] = float(v)
     p = FlowParameters(**kw)
-    if p.time_step_size_min > p.time_step_size_start:          # :593-595
-        p.time_step_size_max = p.time_step_size_min = p.time_step_size_start
     p.unused = unused
     return p

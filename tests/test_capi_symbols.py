@@ -59,7 +59,9 @@ def test_parameter_validation_mirrors_the_reference():
 
 def test_time_stepping_bdf2_weights():
     """source/time_stepping.cc:123-200"""
-    p = adaflo_amd.FlowParameters(time_step_size_start=0.05, end_time=1.0)
+    # (min step size 0: otherwise the reference's rule "min > start => max = min = start",
+    # parameters.cc:593-595, pins the step size and the set_time_step below is clamped by next())
+    p = adaflo_amd.FlowParameters(time_step_size_start=0.05, end_time=1.0, time_step_size_min=0.0)
     ts = adaflo_amd.TimeStepping(p)
     ts.next()
     assert (ts.weight(), ts.weight_old(), ts.weight_old_old()) == (20.0, -20.0, 0.0)
@@ -74,3 +76,11 @@ def test_time_stepping_bdf2_weights():
     ts.next()   # the reference copies the ALREADY modified step into last_step_val (:131-134)
     c, l = 0.1, 0.1
     assert abs(ts.weight() - (2 * c + l) / (c * (c + l))) < 1e-12
+    # reference defaults (parameters.cc:377-410): 0.01 / max 1 / min 0.1 => constant steps of 0.01
+    q = adaflo_amd.FlowParameters()
+    assert (q.time_step_size_start, q.time_step_size_max, q.time_step_size_min) == (0.01, 0.01, 0.01)
+    ts = adaflo_amd.TimeStepping(adaflo_amd.FlowParameters(time_step_size_start=0.05))
+    ts.next()
+    ts.set_time_step(0.1)
+    ts.next()
+    assert abs(ts.step_size() - 0.05) < 1e-15

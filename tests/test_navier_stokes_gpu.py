@@ -89,3 +89,34 @@ def test_beltrami_velocity_errors_at_the_output_times_of_the_reference():
             norm = l2_norm_of_difference(omesh, 2, u, 3, lambda x: np.zeros(3 * len(x)), 2)
             assert "%.4g" % err == expected[key]["absolute"], (key, err)
             assert "%.4g" % (err / norm) == expected[key]["relative"], (key, err / norm)
+
+
+def test_nonlinear_solver_control_flow_follows_the_reference():
+    """navier_stokes.cc:832-975: (i) the preconditioner is not rebuilt in every time step but by the
+    iteration-count rules (always in steps 1 and 2); (ii) schemes that are not fully implicit do ONE linear solve
+    per time step and no second residual; (iii) `projection` is refused by this driver instead of running wrong"""
+    nu = 1.0
+    mesh = adaflo_amd.BrickMesh([8] * 3, [-1.0] * 3, [1.0] * 3)
+    xu, xp = node_coordinates(mesh, 2), node_coordinates(mesh, 1)
+
+    def make(lin):
+        fp = adaflo_amd.FlowParameters(velocity_degree=2, viscosity=nu, time_step_size_start=0.05, end_time=1.0,
+                                       linearization=lin, max_nl_iteration=10, tol_nl_iteration=1e-9,
+                                       max_lin_iteration=200, tol_lin_iteration=1e-5)
+        ns = NavierStokes(fp, mesh, adaflo_amd.TimeStepping(fp), dirichlet_function=lambda x, t: beltrami.velocity(x, t, nu))
+        ns.set_initial_condition(beltrami.velocity(xu, 0.0, nu).reshape(-1), beltrami.pressure(xp, 0.0, nu))
+        return ns
+    ns = make("coupled implicit Newton")
+    for step in range(6):
+        ns.advance_time_step()
+        assert np.hypot(*ns.history[-1]) < 1e-9
+    assert 2 <= ns.n_preconditioner_builds <= 4, ns.n_preconditioner_builds
+    ns = make("coupled velocity semi-implicit")
+    for step in range(3):
+        ns.history.clear()
+        ns.linear_iterations.clear()
+        n_nl, n_lin = ns.advance_time_step()
+        assert n_nl == 0 and len(ns.linear_iterations) == 1 and len(ns.history) == 1
+        assert ns.linear_iterations[0][1] < 0.5 * 1e-9 * 1.0001
+    with pytest.raises(NotImplementedError):
+        make("projection")

@@ -127,3 +127,57 @@ def test_device_start_of_step_equals_the_oracle_for_q3_q2_in_3d():
     assert abs(first - history[0]) < 1e-6 * history[0], (first, history[0])
     assert rel(dev.solution.numpy(), ref.phi) < 1e-6
     assert rel(dev.curvature.numpy(), ref.kappa) < 1e-5
+
+
+def test_robustness_paths_of_the_two_phase_time_step():
+    """LevelSetBaseAlgorithm::advance_time_step (level_set_base.cc:262-278): a residual that doubles triggers ten
+    extra diffusion steps and a second force / residual evaluation; get_concentration_range (two_phase_base.cc:515-545)
+    feeds the three extra diffusion steps of reinitialize (reinitialization.cc:281-284); the sub-steppers follow the
+    global step size (advance_concentration.cc:508, reinitialization.cc:264)"""
+    fp = adaflo_amd.FlowParameters(
+        velocity_degree=2, density=1.0, density_diff=-0.9, viscosity=0.01, viscosity_diff=-0.009,
+        surface_tension=0.0245, gravity=0.98, epsilon=1.5, concentration_subdivisions=2,
+        interpolate_grad_onto_pressure=True, time_step_size_start=0.02, time_step_size_min=0.0, end_time=1.0,
+        max_nl_iteration=10, tol_nl_iteration=1e-8, max_lin_iteration=200, tol_lin_iteration=1e-4)
+    mesh = adaflo_amd.BrickMesh([6, 6, 12], [0., 0., 0.], [1., 1., 2.])
+    centre = np.array([0.5, 0.5, 0.5])
+    solver = LevelSetOKZSolver(fp, mesh, lambda x: np.linalg.norm(x - centre, axis=1) - 0.25)
+    # range of the level set on the iterated trapezoid points against a brute-force evaluation
+    lo, hi = solver.get_concentration_range()
+    s = 2
+    nn = [s * n + 1 for n in mesh.ncell]
+    phi = solver.solution.numpy().reshape(nn[2], nn[1], nn[0])
+    t = np.arange(s + 3) / (s + 2.0)
+    best = [np.inf, -np.inf]
+    for cz in range(mesh.ncell[2]):
+        for cy in range(mesh.ncell[1]):
+            for cx in range(mesh.ncell[0]):
+                loc = phi[s * cz:s * cz + s + 1, s * cy:s * cy + s + 1, s * cx:s * cx + s + 1]
+                ax = np.arange(s + 1) / s
+                v = loc
+                for axis in range(3):
+                    v = np.apply_along_axis(lambda line: np.interp(t, ax, line), axis, v)
+                best = [min(best[0], v.min()), max(best[1], v.max())]
+    assert abs(lo - best[0]) < 1e-14 and abs(hi - best[1]) < 1e-14 and -1.0 <= lo < -0.9 and 0.5 < hi <= 1.0
+    # an out-of-range profile adds three diffusion steps to the next reinitialisation
+    solver.advance_time_step()
+    n_regular = len(solver.reinit_iterations[-1])
+    solver.last_concentration_range = (-1.05, 1.0)
+    solver.reinitialize(2)
+    assert len(solver.reinit_iterations[-1]) == n_regular + 3
+    solver.last_concentration_range = (lo, hi)
+    # the sub-steppers follow a changed global step size
+    solver.time_stepping.set_desired_time_step(0.015)
+    solver.advance_time_step()
+    assert abs(solver.ts_advect.step_size() - 0.015) < 1e-15 and abs(solver.ts_reinit.step_size() - 0.015) < 1e-15
+    # excessive residual: pretend the previous step had a tiny residual
+    for _ in range(3):
+        solver.advance_time_step()
+    assert solver.smoothing_steps == []
+    solver.old_residual *= 1e-3
+    n_before = len(solver.reinit_iterations)
+    solver.advance_time_step()
+    assert solver.smoothing_steps == [solver.time_stepping.step_no()]
+    assert len(solver.reinit_iterations) == n_before + 2 and len(solver.reinit_iterations[-1]) >= 10
+    ns = solver.navier_stokes
+    assert np.hypot(*ns.history[-1]) < fp.tol_nl_iteration
