@@ -45,6 +45,18 @@ class NSParams(C.Structure):
 
 _D = C.c_void_p  # device pointer
 _CTX = C.c_void_p
+_COMM = C.c_void_p
+
+
+class CommUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+_I64P = C.POINTER(C.c_int64)
+_INTP = C.POINTER(C.c_int)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _D, _I64P, _I64P, _INTP, C.c_int, _D, _I64P, _I64P, _INTP, C.c_int,
+                          C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _D, C.c_int, C.c_void_p)
 
 # name -> (restype, argtypes); mirrors include/adaflo_hip.h one to one
 SIGNATURES = {
@@ -84,6 +96,18 @@ SIGNATURES = {
     "adaflo_ns_get_matvec_statistics": (C.c_int, [_CTX, C.POINTER(C.c_uint), C.POINTER(C.c_double)]),
     "adaflo_halo_transfer": (C.c_int, [_CTX, _D, _D, C.POINTER(C.c_int), C.c_int, C.c_int,
                                       C.POINTER(C.c_int), C.c_int]),
+    "adaflo_halo_transfer_ordered": (C.c_int, [_CTX, _D, _D, C.POINTER(C.c_int), C.c_int, C.c_int,
+                                              C.POINTER(C.c_int), C.c_int, C.c_int]),
+    "adaflo_comm_get_unique_id": (C.c_int, [C.POINTER(CommUniqueId)]),
+    "adaflo_comm_create": (C.c_int, [_CTX, C.POINTER(CommUniqueId), C.c_int, C.c_int, _INTP, C.c_int, C.POINTER(_COMM)]),
+    "adaflo_comm_create_custom": (C.c_int, [_CTX, C.c_int, C.c_int, _INTP, EXCHANGE_FN, ALLREDUCE_FN, C.c_void_p, C.c_int,
+                                            C.POINTER(_COMM)]),
+    "adaflo_comm_destroy": (C.c_int, [_COMM]),
+    "adaflo_comm_last_error": (C.c_char_p, [_COMM]),
+    "adaflo_comm_interface_faces": (C.c_uint, [_COMM]),
+    "adaflo_comm_update_ghost_values": (C.c_int, [_COMM, _D, _D]),
+    "adaflo_comm_compress_add": (C.c_int, [_COMM, _D, _D]),
+    "adaflo_ns_vmult_distributed": (C.c_int, [_CTX, _COMM, _D, _D, _D, _D, C.c_int]),
     "adaflo_ls_set_params": (C.c_int, [_CTX, C.POINTER(LSParams)]),
     "adaflo_ls_set_diagonal": (C.c_int, [_CTX, _D]),
     "adaflo_ls_set_evaluated_convection": (C.c_int, [_CTX, C.c_void_p, C.c_int]),
@@ -152,6 +176,12 @@ def load():
 
 class AdafloError(RuntimeError):
     pass
+
+
+class CtxHandle(C.c_void_p):
+    """the engine context as the operator object owns it: vectors and level-set operators keep a
+    reference to this handle and stop calling into the library once the context is destroyed"""
+    alive = False
 
 
 def check(ctx, code):

@@ -174,11 +174,8 @@ const char *adaflo_last_error(const adaflo_ctx *ctx)
   return ctx ? ctx->last_error.c_str() : g_create_error.c_str();
 }
 
-int adaflo_ctx_create(const adaflo_brick_desc *desc, adaflo_ctx **out)
+static int ctx_create_impl(const adaflo_brick_desc *desc, adaflo_ctx *ctx)
 {
-  if (!desc || !out)
-    return fail(nullptr, ADAFLO_EINVAL, "null argument");
-  *out = nullptr;
   if (desc->dim != 3)
     return fail(nullptr, ADAFLO_EUNSUPPORTED, "only dim = 3 is implemented on the device");
   if (desc->velocity_degree < 2 || desc->velocity_degree > 5)
@@ -193,7 +190,6 @@ int adaflo_ctx_create(const adaflo_brick_desc *desc, adaflo_ctx **out)
   if (desc->device < 0 || desc->device >= ndev)
     return fail(nullptr, ADAFLO_EINVAL, "invalid device ordinal");
 
-  adaflo_ctx *ctx = new adaflo_ctx;
   ctx->desc       = *desc;
   HIP_TRY(nullptr, hipSetDevice(desc->device));
   if (desc->stream)
@@ -284,6 +280,27 @@ int adaflo_ctx_create(const adaflo_brick_desc *desc, adaflo_ctx **out)
       ctx->inv_p_weight = 1. / mw;
     }
   HIP_TRY(nullptr, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int adaflo_ctx_destroy(adaflo_ctx *ctx);
+
+int adaflo_ctx_create(const adaflo_brick_desc *desc, adaflo_ctx **out)
+{
+  if (!desc || !out)
+    return fail(nullptr, ADAFLO_EINVAL, "null argument");
+  *out = nullptr;
+  adaflo_ctx *ctx = new adaflo_ctx;
+  const int   rc  = ctx_create_impl(desc, ctx);
+  if (rc != 0)
+    {
+      // (keeps the message of the failure; everything allocated so far goes with the context)
+      const std::string msg = g_create_error;
+      (void)hipGetLastError();
+      adaflo_ctx_destroy(ctx);
+      g_create_error = msg;
+      return rc;
+    }
   *out = ctx;
   return 0;
 }
@@ -291,7 +308,8 @@ int adaflo_ctx_create(const adaflo_brick_desc *desc, adaflo_ctx **out)
 int adaflo_ctx_destroy(adaflo_ctx *ctx)
 {
   CHECK_CTX(ctx);
-  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream || !ctx->own_stream)
+    (void)hipStreamSynchronize(ctx->stream);
   for (DeviceBuffer *b : {&ctx->lin, &ctx->rho, &ctx->mu, &ctx->damp, &ctx->lin_prec, &ctx->rho_prec,
                           &ctx->mu_prec, &ctx->damp_prec, &ctx->lin_q2, &ctx->lin_q2_prec,
                           &ctx->q2_slab_u, &ctx->q2_zslab_u, &ctx->q2_slab_p, &ctx->q2_zslab_p,
@@ -310,7 +328,7 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
     (void)hipHostFree(ctx->h_result);
   ctx->matvec_timer.destroy();
   ctx->kernel_timer.destroy();
-  if (ctx->own_stream)
+  if (ctx->own_stream && ctx->stream)
     (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return 0;
@@ -906,8 +924,8 @@ int adaflo_set_q2_chunk(adaflo_ctx *ctx, int layers)
 /* ------------------------------------------------------------------------- */
 /* inter-GPU exchange helpers                                                 */
 /* ------------------------------------------------------------------------- */
-int adaflo_halo_transfer(adaflo_ctx *ctx, double *vec, double *buf, const int *nn, int ncomp,
-                         int n_regions, const int *regions, int mode)
+static int halo_transfer_impl(adaflo_ctx *ctx, double *vec, double *buf, const int *nn, int ncomp,
+                         int n_regions, const int *regions, int mode, int self_pos)
 {
   CHECK_CTX(ctx);
   if (!vec || !buf || !nn || !regions || n_regions < 0 || n_regions > 26 || mode < 0 || mode > 2)
@@ -918,6 +936,7 @@ int adaflo_halo_transfer(adaflo_ctx *ctx, double *vec, double *buf, const int *n
   for (int d = 0; d < 3; ++d)
     plan.nn[d] = nn[d];
   plan.offset[0] = 0;
+  plan.self_pos  = self_pos;
   for (int r = 0; r < n_regions; ++r)
     {
       long n = ncomp;
@@ -929,10 +948,23 @@ int adaflo_halo_transfer(adaflo_ctx *ctx, double *vec, double *buf, const int *n
             return fail(ctx, ADAFLO_EINVAL, "halo region out of range");
           n *= plan.hi[r][d] - plan.lo[r][d];
         }
+      plan.start[r]      = plan.offset[r];
       plan.offset[r + 1] = plan.offset[r] + n;
     }
   TRY(ctx, launch_halo(ctx, vec, buf, plan, mode), "halo kernel launch failed");
   return 0;
+}
+
+int adaflo_halo_transfer(adaflo_ctx *ctx, double *vec, double *buf, const int *nn, int ncomp, int n_regions,
+                         const int *regions, int mode)
+{
+  return halo_transfer_impl(ctx, vec, buf, nn, ncomp, n_regions, regions, mode, 0);
+}
+
+int adaflo_halo_transfer_ordered(adaflo_ctx *ctx, double *vec, double *buf, const int *nn, int ncomp, int n_regions,
+                                 const int *regions, int mode, int self_pos)
+{
+  return halo_transfer_impl(ctx, vec, buf, nn, ncomp, n_regions, regions, mode, self_pos);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -63,7 +63,9 @@ namespace adaflo_hip
     int  n_regions, ncomp;
     int  nn[3];
     int  lo[26][3], hi[26][3]; // half-open node index ranges
-    long offset[27];           // prefix sums of the region sizes (doubles) in the packed buffer
+    long offset[27];           // prefix sums of the region sizes (doubles): the work items of the kernel
+    long start[26];            // position of region r in the packed buffer (== offset[r] when back to back)
+    int  self_pos;             // add mode: the vector's own value is summed before region self_pos
   };
   int launch_halo(adaflo_ctx *ctx, double *vec, double *buf, const HaloPlan &plan, int mode);
 
@@ -83,6 +85,11 @@ namespace adaflo_hip
   int launch_transpose_state(adaflo_ctx *ctx, double *dst, const double *src, long n_cells, int nq,
                              int ncomp, bool to_generic);
   double host_dot(adaflo_ctx *ctx, const double *a, const double *b, long n);
+  // device-resident scalars of the distributed mean-value projection (comm.hip)
+  int launch_dot_to(adaflo_ctx *ctx, const double *a, const double *b, long n, double *out); // *out = a . b
+  int launch_sum_to(adaflo_ctx *ctx, const double *a, long n, double *out);                  // *out = sum a
+  int launch_reciprocal(adaflo_ctx *ctx, double *out, const double *in);                     // *out = 1 / *in
+  int launch_subtract_scaled(adaflo_ctx *ctx, double *v, const double *s, const double *t, long n); // v -= *s * *t
 
   // level-set operators (ls_kernels.hip); kind: 0 operator application, 1 rhs, 2 advection rhs
   int launch_ls(adaflo_ctx *ctx, int kind, int mode, int flag, double *dst, const double *src,

@@ -47,7 +47,7 @@ namespace adaflo_hip
       __shared__ double red[VT / 64];
       double            s = 0.;
       for (long i = blockIdx.x * (long)VT + threadIdx.x; i < n; i += (long)gridDim.x * VT)
-        s += a[i] * b[i];
+        s += b ? a[i] * b[i] : a[i];
       for (int off = 32; off > 0; off >>= 1)
         s += __shfl_down(s, off, 64);
       if ((threadIdx.x & 63) == 0)
@@ -138,7 +138,11 @@ namespace adaflo_hip
     }
 
     // interface-region copy between a brick vector and a packed message buffer
-    // mode 0: buf <- vec (pack), 1: vec <- buf (unpack, copy), 2: vec += buf (unpack, add)
+    // mode 0: buf <- vec (pack), 1: vec <- buf (unpack, copy), 2: vec += buf (unpack, add).
+    // Regions of different neighbours overlap on edges and corners.  In add mode the FIRST region
+    // that contains a node sums the entries of all regions containing it and the vector's own
+    // value, in region order: no atomics, and the replicas of an interface DoF end up bitwise
+    // identical on every rank and run.
     __global__ __launch_bounds__(VT) void halo_kernel(double *__restrict__ vec, double *__restrict__ buf,
                                                       const HaloPlan plan, const int mode)
     {
@@ -149,6 +153,7 @@ namespace adaflo_hip
           while (t >= plan.offset[r + 1])
             ++r;
           long      e  = t - plan.offset[r];
+          const long el = e;
           const int nc = plan.ncomp, ni = plan.hi[r][0] - plan.lo[r][0], nj = plan.hi[r][1] - plan.lo[r][1];
           const int c  = (int)(e % nc);
           e /= nc;
@@ -158,12 +163,57 @@ namespace adaflo_hip
           const int  k   = (int)(e / nj) + plan.lo[r][2];
           const long idx = ((long)(k * (long)plan.nn[1] + j) * plan.nn[0] + i) * nc + c;
           if (mode == 0)
-            buf[t] = vec[idx];
+            buf[plan.start[r] + el] = vec[idx];
           else if (mode == 1)
-            vec[idx] = buf[t];
-          else // regions of different neighbours overlap on edges / corners
-            unsafeAtomicAdd(&vec[idx], buf[t]);
+            vec[idx] = buf[plan.start[r] + el];
+          else
+            {
+              auto inside = [&](const int q) {
+                return i >= plan.lo[q][0] && i < plan.hi[q][0] && j >= plan.lo[q][1] && j < plan.hi[q][1] &&
+                       k >= plan.lo[q][2] && k < plan.hi[q][2];
+              };
+              bool first = true;
+              for (int q = 0; q < r; ++q)
+                first = first && !inside(q);
+              if (!first)
+                continue;
+              // own value and received partial sums in ONE global order (the regions arrive sorted by
+              // the rank of their sender, self_pos = where this rank sits in that order): all sharers
+              // add the same numbers in the same sequence
+              double sum     = 0.;
+              bool   started = false;
+              auto   add     = [&](const double x) {
+                sum     = started ? sum + x : x;
+                started = true;
+              };
+              for (int q = r; q < plan.n_regions; ++q)
+                {
+                  if (q == plan.self_pos || (q == r && plan.self_pos < r))
+                    add(vec[idx]);
+                  if (inside(q))
+                    {
+                      const int  qi = plan.hi[q][0] - plan.lo[q][0], qj = plan.hi[q][1] - plan.lo[q][1];
+                      const long le = ((long)((k - plan.lo[q][2]) * qj + (j - plan.lo[q][1])) * qi + (i - plan.lo[q][0])) * nc + c;
+                      add(buf[plan.start[q] + le]);
+                    }
+                }
+              if (plan.self_pos >= plan.n_regions)
+                add(vec[idx]);
+              vec[idx] = sum;
+            }
         }
+    }
+
+    __global__ void reciprocal_kernel(double *out, const double *in)
+    {
+      *out = 1. / *in;
+    }
+    __global__ __launch_bounds__(VT) void subtract_scaled_kernel(double *__restrict__ v, const double *__restrict__ s,
+                                                                 const double *__restrict__ t, const long n)
+    {
+      const double f = *s * *t;
+      for (long i = blockIdx.x * (long)VT + threadIdx.x; i < n; i += (long)gridDim.x * VT)
+        v[i] -= f;
     }
 
     int check()
@@ -210,6 +260,34 @@ namespace adaflo_hip
                        ctx->d_scratch + 8);
     hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(VT), 0, ctx->stream, ctx->d_scratch + 8,
                        (int)nb, ctx->d_scratch, to_host ? ctx->h_result_dev : nullptr);
+    return check();
+  }
+
+  int launch_dot_to(adaflo_ctx *ctx, const double *a, const double *b, const long n, double *out)
+  {
+    const unsigned nb = grid_for(n, 4);
+    if (int e = ensure_scratch(ctx, 2 * 32768 + 8))
+      return e;
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(VT), 0, ctx->stream, a, b, n, ctx->d_scratch + 8);
+    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(VT), 0, ctx->stream, ctx->d_scratch + 8, (int)nb, out,
+                       (double *)nullptr);
+    return check();
+  }
+
+  int launch_sum_to(adaflo_ctx *ctx, const double *a, const long n, double *out)
+  {
+    return launch_dot_to(ctx, a, nullptr, n, out);
+  }
+
+  int launch_reciprocal(adaflo_ctx *ctx, double *out, const double *in)
+  {
+    hipLaunchKernelGGL(reciprocal_kernel, dim3(1), dim3(1), 0, ctx->stream, out, in);
+    return check();
+  }
+
+  int launch_subtract_scaled(adaflo_ctx *ctx, double *v, const double *s, const double *t, const long n)
+  {
+    hipLaunchKernelGGL(subtract_scaled_kernel, dim3(grid_for(n)), dim3(VT), 0, ctx->stream, v, s, t, n);
     return check();
   }
 

@@ -25,6 +25,7 @@ class LevelSetOperators:
         self._lib = _lib.load()
         self.mesh, self.s, self.k = mesh, ls_degree, velocity_degree
         self._owns_ctx = navier_stokes_matrix is None
+        self._owner = navier_stokes_matrix     # keeps the shared context's owner alive
         if navier_stokes_matrix is not None:
             self._ctx = navier_stokes_matrix._require()
             assert self._lib.adaflo_n_dofs_ls(self._ctx) > 0, "NavierStokesMatrix was built without ls_degree"
@@ -41,11 +42,12 @@ class LevelSetOperators:
         d.ls_constrained = sum(1 << f for f in constrained_faces)
         d.velocity_constrained = sum(1 << (3 * f + c) for f in dirichlet_faces_u for c in range(3))
         d.device, d.stream = device, None
-        ctx = C.c_void_p()
+        ctx = _lib.CtxHandle()
         code = self._lib.adaflo_ctx_create(C.byref(d), C.byref(ctx))
         if code != 0:
             raise _lib.AdafloError("adaflo_ctx_create failed (%d): %s" % (
                 code, self._lib.adaflo_last_error(None).decode()))
+        ctx.alive = True
         self._ctx = ctx
         if stream is not None:
             _lib.check(ctx, self._lib.adaflo_set_stream(ctx, stream or None))
@@ -59,6 +61,7 @@ class LevelSetOperators:
     def __del__(self):
         try:
             if self._ctx is not None and self._owns_ctx:
+                self._ctx.alive = False
                 self._lib.adaflo_ctx_destroy(self._ctx)
             self._ctx = None
         except Exception:

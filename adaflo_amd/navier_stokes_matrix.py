@@ -74,11 +74,12 @@ class NavierStokesMatrix:
         """NavierStokesMatrix::initialize, source/navier_stokes_matrix.cc:85-168"""
         self.clear()
         self._desc.pressure_average_fix = int(bool(pressure_average_fix))
-        ctx = C.c_void_p()
+        ctx = _lib.CtxHandle()
         code = self._lib.adaflo_ctx_create(C.byref(self._desc), C.byref(ctx))
         if code != 0:
             raise _lib.AdafloError("adaflo_ctx_create failed (%d): %s" % (
                 code, self._lib.adaflo_last_error(None).decode()))
+        ctx.alive = True
         self._ctx = ctx
         if self._stream is not None:
             _lib.check(ctx, self._lib.adaflo_set_stream(ctx, self._stream or None))
@@ -87,6 +88,7 @@ class NavierStokesMatrix:
 
     def clear(self):
         if self._ctx is not None:
+            self._ctx.alive = False      # surviving DeviceVectors must not free into a dead context
             self._lib.adaflo_ctx_destroy(self._ctx)
             self._ctx = None
 

@@ -138,6 +138,11 @@ class HaloExchange:
                 send_list.append((o, nb))
             if mode == "add" or negative:
                 recv_list.append((o, nb))
+        if mode == "add":
+            # partial sums are added in the order of their senders' ranks, this rank's own value at
+            # its place in that order: every sharer of a DoF adds the same numbers in the same
+            # sequence and the replicas stay bitwise identical
+            recv_list.sort(key=lambda t: t[1])
 
         def sizes(o):
             return [int(np.prod([len(range(*sl.indices(n))) for sl, n in
@@ -224,7 +229,8 @@ class HaloExchange:
                     continue
                 if mode == "add":
                     base = seg_recv[(f, recv_list[0][0])][0]
-                    self._native_transfer(v, rbuf[base:], f, [o for o, _ in recv_list], 2)
+                    self._native_transfer(v, rbuf[base:], f, [o for o, _ in recv_list], 2,
+                                          self_pos=sum(1 for _, nb in recv_list if nb < self.part.rank))
                 else:
                     for cls in (1, 2, 3):
                         group = [o for o, _ in recv_list if sum(abs(x) for x in o) == cls]
@@ -234,20 +240,37 @@ class HaloExchange:
         else:
             views = self._views(vecs)
             for f, w in enumerate(views):
+                if mode == "add":
+                    # same summation order as the engine's kernel: contributions sorted by rank
+                    own, total, seen = w.clone(), w.clone(), None
+                    import torch
+                    started = torch.zeros(w.shape, dtype=torch.bool)
+                    entries = [(nb, o) for o, nb in recv_list] + [(self.part.rank, None)]
+                    for nb, o in sorted(entries, key=lambda t: t[0]):
+                        if o is None:
+                            touched = torch.ones(w.shape, dtype=torch.bool)
+                            val = own
+                        else:
+                            a, n = seg_recv[(f, o)]
+                            r = _region(o, self.part.nodes(self.fields[f][0]))
+                            touched = torch.zeros(w.shape, dtype=torch.bool)
+                            touched[r] = True
+                            val = torch.zeros_like(w)
+                            val[r] = rbuf[a:a + n].view(w[r].shape)
+                        total = torch.where(touched & started, total + val, torch.where(touched, val, total))
+                        started |= touched
+                    w.copy_(total)
+                    continue
                 for o, nb in recv_list:
                     a, n = seg_recv[(f, o)]
                     r = _region(o, self.part.nodes(self.fields[f][0]))
-                    piece = rbuf[a:a + n].view(w[r].shape)
-                    if mode == "add":
-                        w[r] += piece
-                    else:
-                        w[r] = piece
+                    w[r] = rbuf[a:a + n].view(w[r].shape)
 
     def _exchange(self, vecs, mode):
         """one blocking round: start + finish"""
         self.finish(self.start(vecs, mode))
 
-    def _native_transfer(self, vec, buf, field, offsets, mode):
+    def _native_transfer(self, vec, buf, field, offsets, mode, self_pos=0):
         """engine halo kernel over the regions of `offsets` (contiguous in buf, in this order)"""
         import ctypes as C
         from . import _lib
@@ -261,8 +284,8 @@ class HaloExchange:
                 regs += [lo, hi]
         arr = (C.c_int * len(regs))(*regs)
         nn_c = (C.c_int * 3)(*nn)
-        _lib.check(self.native, _lib.load().adaflo_halo_transfer(
-            self.native, vec.data_ptr(), buf.data_ptr(), nn_c, nc, len(offsets), arr, mode))
+        _lib.check(self.native, _lib.load().adaflo_halo_transfer_ordered(
+            self.native, vec.data_ptr(), buf.data_ptr(), nn_c, nc, len(offsets), arr, mode, self_pos))
 
     def compress_add(self, vecs):
         """dst.compress(VectorOperation::add): afterwards every replica holds the total"""
@@ -297,10 +320,100 @@ def _all_reduce_sum(t, group):
     return t
 
 
-class DistributedNavierStokesMatrix:
-    """NavierStokesMatrix over a brick partition: local HIP engine + RCCL halo exchange."""
+class NativeCommunicator:
+    """adaflo_comm of the C ABI (csrc/comm.hip): pack, one message per neighbour, unpack and the
+    phased overlap all happen inside the library, ordered by HIP events.  With an nccl group the
+    library opens its own RCCL communicator (the unique id travels through torch.distributed);
+    with any other group (gloo: the tests that run N ranks on one GPU) the packed buffers are
+    moved by callbacks that stage them through host memory."""
 
-    def __init__(self, parameters, part, device=0, stream=None, group=None, local=None):
+    def __init__(self, ctx, part, group, pressure_average_fix):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        self._lib, self._ctx, self.group = _lib.load(), ctx, group
+        self.handle = C.c_void_p()
+        grid = (C.c_int * 3)(*part.grid)
+        backend = dist.get_backend(group) if part.world > 1 else "none"
+        if backend == "nccl":
+            uid = _lib.CommUniqueId()
+            if part.rank == 0:
+                code = self._lib.adaflo_comm_get_unique_id(C.byref(uid))
+                if code != 0:
+                    raise _lib.AdafloError("adaflo_comm_get_unique_id failed (%d)" % code)
+            t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).cuda()
+            dist.broadcast(t, 0, group=group)
+            C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+            code = self._lib.adaflo_comm_create(ctx, C.byref(uid), part.rank, part.world, grid,
+                                                int(pressure_average_fix), C.byref(self.handle))
+        else:
+            lib = self._lib
+
+            def exchange(user, sbuf, soff, scnt, speer, ns, rbuf, roff, rcnt, rpeer, nr, stream):
+                try:
+                    lib.adaflo_synchronize(ctx)
+                    sends = [torch.empty(scnt[q], dtype=torch.float64) for q in range(ns)]
+                    recvs = [torch.empty(rcnt[q], dtype=torch.float64) for q in range(nr)]
+                    for q in range(ns):
+                        lib.adaflo_copy_d2h(ctx, sends[q].data_ptr(), sbuf + 8 * soff[q], 8 * scnt[q])
+                    ops = [dist.P2POp(dist.isend, sends[q], speer[q], group=group) for q in range(ns)]
+                    ops += [dist.P2POp(dist.irecv, recvs[q], rpeer[q], group=group) for q in range(nr)]
+                    for w in dist.batch_isend_irecv(ops):
+                        w.wait()
+                    for q in range(nr):
+                        lib.adaflo_copy_h2d(ctx, rbuf + 8 * roff[q], recvs[q].data_ptr(), 8 * rcnt[q])
+                    return 0
+                except Exception:        # noqa: BLE001 -- must not propagate through the C frame
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+
+            def allreduce(user, buf, n, stream):
+                try:
+                    t = torch.empty(n, dtype=torch.float64)
+                    lib.adaflo_copy_d2h(ctx, t.data_ptr(), buf, 8 * n)
+                    dist.all_reduce(t, group=group)
+                    lib.adaflo_copy_h2d(ctx, buf, t.data_ptr(), 8 * n)
+                    return 0
+                except Exception:        # noqa: BLE001
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = (_lib.EXCHANGE_FN(exchange), _lib.ALLREDUCE_FN(allreduce))      # keep alive
+            code = self._lib.adaflo_comm_create_custom(ctx, part.rank, part.world, grid, self._cb[0], self._cb[1], None,
+                                                       int(pressure_average_fix), C.byref(self.handle))
+        if code != 0:
+            raise _lib.AdafloError("adaflo_comm_create failed (%d): %s" % (code, self._lib.adaflo_last_error(ctx).decode()))
+
+    def _check(self, code):
+        if code != 0:
+            from . import _lib
+            raise _lib.AdafloError("adaflo_comm error %d: %s" % (code, self._lib.adaflo_comm_last_error(self.handle).decode()))
+
+    def vmult(self, dst, src, src_consistent):
+        self._check(self._lib.adaflo_ns_vmult_distributed(self._ctx, self.handle, dst.block(0).ptr, dst.block(1).ptr,
+                                                          src.block(0).ptr, src.block(1).ptr, int(src_consistent)))
+
+    def update_ghost_values(self, vec):
+        self._check(self._lib.adaflo_comm_update_ghost_values(self.handle, vec.block(0).ptr, vec.block(1).ptr))
+
+    def compress_add(self, vec):
+        self._check(self._lib.adaflo_comm_compress_add(self.handle, vec.block(0).ptr, vec.block(1).ptr))
+
+    def close(self):
+        if self.handle:
+            self._lib.adaflo_comm_destroy(self.handle)
+            self.handle = None
+
+
+class DistributedNavierStokesMatrix:
+    """NavierStokesMatrix over a brick partition: local HIP engine + RCCL halo exchange.
+
+    native_comm=True: everything behind the C ABI (adaflo_ns_vmult_distributed, NativeCommunicator);
+    False: the exchange is driven from here through torch.distributed point-to-point operations."""
+
+    def __init__(self, parameters, part, device=0, stream=None, group=None, local=None, native_comm=False):
         """`local`: the per-rank operator; default = the HIP engine on the local brick.  (The
         gloo/CPU tests inject an oracle-backed stand-in to check the exchange logic.)"""
         from .navier_stokes_matrix import BrickMesh, NavierStokesMatrix
@@ -318,6 +431,8 @@ class DistributedNavierStokesMatrix:
             local = NavierStokesMatrix(parameters, mesh, dirichlet_faces_u=part.physical_faces(),
                                        constrained_faces_p=(), device=device, stream=stream)
         self.local = local
+        self.native_comm = native_comm and hasattr(local, "_ctx")
+        self.comm = None
         self.overlap = True       # overlap the exchanges with interior cells where supported
         self.halo = HaloExchange(part, [(k, 3), (k - 1, 1)], group=group)
         self._w_owned = None
@@ -328,7 +443,9 @@ class DistributedNavierStokesMatrix:
         self.local.initialize(time_stepping, pressure_average_fix and single)
         self.halo.native = getattr(self.local, "_ctx", None)
         self.pressure_average_fix = pressure_average_fix
-        if pressure_average_fix and not single:
+        if self.native_comm and not single:
+            self.comm = NativeCommunicator(self.local._ctx, self.part, self.group, pressure_average_fix)
+        elif pressure_average_fix and not single:
             self._setup_projection()
 
     def set_kernel_variant(self, v):
@@ -348,7 +465,9 @@ class DistributedNavierStokesMatrix:
         self._inv = 1.0 / s                       # device scalar, modes == 1 everywhere
 
     def make_consistent(self, vec):
-        if self.part.world > 1:
+        if self.comm is not None:
+            self.comm.update_ghost_values(vec)
+        elif self.part.world > 1:
             self.halo.update_ghost_values([b._keepalive for b in vec.blocks])
 
     def vmult(self, dst, src, src_consistent=False):
@@ -361,6 +480,9 @@ class DistributedNavierStokesMatrix:
           compress(add) of dst  ||  interior cells, second half"""
         if self.part.world == 1:
             self.local.vmult(dst, src)
+            return
+        if self.comm is not None:
+            self.comm.vmult(dst, src, src_consistent)
             return
         tsrc = [b._keepalive for b in src.blocks]
         tdst = [b._keepalive for b in dst.blocks]

@@ -63,7 +63,9 @@ class DeviceVector:
         return float(np.sqrt(self.dot(self)))
 
     def free(self):
-        if self._own and self.ptr:
+        # (the device memory of a destroyed context's vectors is released with hipFree semantics by
+        # the driver at process end; calling into the library with a dangling context is not an option)
+        if self._own and self.ptr and getattr(self.ctx, "alive", True):
             _lib.load().adaflo_free(self.ctx, self.ptr)
         self.ptr = None
 

@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--linearization", default="coupled implicit Newton",
                     help="diagnostic only: e.g. 'coupled velocity explicit' times the kernel without q-state")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: blocking exchange schedule")
+    ap.add_argument("--comm", default="torch", choices=["torch", "native"],
+                    help="N > 1: ghost exchange driven through torch.distributed point-to-point operations, or "
+                         "inside the engine (adaflo_ns_vmult_distributed: RCCL group send/recv on a second stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=48)
     return ap.parse_args()
@@ -228,7 +231,8 @@ def main():
     part = parallel.BrickPartition(grid, rank, cells, lower=lower, upper=upper)
     stream = torch.cuda.current_stream(device).cuda_stream   # 0 = the legacy default stream
     op = parallel.DistributedNavierStokesMatrix(fp, part, device=local_rank, stream=stream,
-                                                group=dist.group.WORLD if world > 1 else None)
+                                                group=dist.group.WORLD if world > 1 else None,
+                                                native_comm=args.comm == "native")
     op.initialize(ts, True)
     op.set_kernel_variant(args.variant)
     op.overlap = not args.no_overlap
@@ -324,7 +328,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": workload, "dofs": n_dofs_global, "cells_per_gpu": n_cells_local,
                    "partition": "x".join(str(g) for g in grid), "kernel_variant": args.variant,
-                   "overlap": bool(op.overlap) if world > 1 else None},
+                   "overlap": bool(op.overlap) if world > 1 else None,
+                   "comm": args.comm if world > 1 else None},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,

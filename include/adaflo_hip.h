@@ -199,10 +199,73 @@ int adaflo_ns_get_matvec_statistics(adaflo_ctx *ctx, unsigned *count, double *se
  * inside update_ghost_values() / compress(add): copy the n_regions node boxes
  * regions[r] = {i0,i1, j0,j1, k0,k1} (half-open) of the brick vector `vec` (nn[3] nodes,
  * ncomp interleaved components) to / from the packed message buffer `buf` (regions back to
- * back).  mode 0: buf <- vec, 1: vec <- buf, 2: vec += buf.  The messages themselves are
- * sent by the caller over RCCL (adaflo_amd/parallel.py).                              */
+ * back).  mode 0: buf <- vec, 1: vec <- buf, 2: vec += buf (overlapping regions are summed in
+ * region order without atomics).  Building block of adaflo_comm_* below; also callable on its
+ * own by a host that sends the messages itself (adaflo_amd/parallel.py over torch.distributed). */
 int adaflo_halo_transfer(adaflo_ctx *ctx, double *vec, double *buf, const int *nn, int ncomp,
                          int n_regions, const int *regions, int mode);
+/* the same with the position of this rank among the senders of the regions (which must arrive
+ * sorted by the rank of their sender): in add mode the vector's own value enters the sum at that
+ * position, so that all sharers of a DoF add the same numbers in the same order and their
+ * replicas stay bitwise identical */
+int adaflo_halo_transfer_ordered(adaflo_ctx *ctx, double *vec, double *buf, const int *nn, int ncomp, int n_regions,
+                                 const int *regions, int mode, int self_pos);
+
+/* ---- multi-GPU: the exchange itself --------------------------------------------------------
+ * What MatrixFree::cell_loop does across MPI ranks for a LinearAlgebra::distributed::Vector
+ * (source/navier_stokes_matrix.cc:232-245): import the ghost values of src, run the local cells,
+ * add the ghost contributions of dst to their owners -- plus the MPI sum of the pressure-mean
+ * projection (:201).  One process per GPU; the mesh is cut into grid[0] x grid[1] x grid[2]
+ * bricks, rank = cx + grid[0] (cy + grid[1] cz); every rank creates its engine context on ITS
+ * brick (Dirichlet faces only where the brick touches the domain boundary,
+ * pressure_average_fix = 0: the communicator applies the global projection).  Nodes on an
+ * inter-rank interface are replicated on the sharers; the sharer with the lowest grid
+ * coordinates owns them.  Per exchange one message per neighbour (<= 26; 7 on 2 x 2 x 2),
+ * posted as ONE ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on a second HIP stream.
+ *
+ * adaflo_comm_create: RCCL transport.  Rank 0 obtains the id with adaflo_comm_get_unique_id and
+ * broadcasts the 128 bytes out of band (MPI_Bcast in a deal.II application); collective over
+ * the `world` ranks.  adaflo_comm_create_custom: the caller moves the packed buffers itself --
+ *   exchange(user, sendbuf, send_offset[], send_count[], send_peer[], n_send,
+ *                  recvbuf, recv_offset[], recv_count[], recv_peer[], n_recv, stream)
+ * sends send_count[q] doubles at sendbuf + send_offset[q] to rank send_peer[q] and receives
+ * likewise (device pointers; everything enqueued on `stream` before the call must be complete
+ * before the data is read, and the received data must be in place when work enqueued on
+ * `stream` afterwards runs); allreduce(user, buf, n, stream) sums n device doubles over all
+ * ranks in place under the same ordering rules.  Both return 0 on success.                   */
+typedef struct adaflo_comm adaflo_comm;
+typedef struct
+{
+  char internal[128]; /* = ncclUniqueId */
+} adaflo_comm_unique_id;
+typedef int (*adaflo_exchange_fn)(void *user, double *sendbuf, const int64_t *send_offset, const int64_t *send_count,
+                                  const int *send_peer, int n_send, double *recvbuf, const int64_t *recv_offset,
+                                  const int64_t *recv_count, const int *recv_peer, int n_recv, void *stream);
+typedef int (*adaflo_allreduce_fn)(void *user, double *buf, int n, void *stream);
+
+int         adaflo_comm_get_unique_id(adaflo_comm_unique_id *id);
+int         adaflo_comm_create(adaflo_ctx *ctx, const adaflo_comm_unique_id *id, int rank, int world, const int *grid,
+                               int pressure_average_fix, adaflo_comm **out);
+int         adaflo_comm_create_custom(adaflo_ctx *ctx, int rank, int world, const int *grid, adaflo_exchange_fn exchange,
+                                      adaflo_allreduce_fn allreduce, void *user, int pressure_average_fix,
+                                      adaflo_comm **out);
+int         adaflo_comm_destroy(adaflo_comm *comm);
+const char *adaflo_comm_last_error(const adaflo_comm *comm);
+/* bit 2 d + side for the faces of the local brick that are shared with another rank */
+unsigned    adaflo_comm_interface_faces(const adaflo_comm *comm);
+/* src.update_ghost_values(): owners -> replicas; dst.compress(VectorOperation::add): afterwards
+ * every replica holds the total (summed in a fixed order: replicas are bitwise identical) */
+int         adaflo_comm_update_ghost_values(adaflo_comm *comm, double *vec_u, double *vec_p);
+int         adaflo_comm_compress_add(adaflo_comm *comm, double *vec_u, double *vec_p);
+/* NavierStokesMatrix::vmult on the global problem.  With the Q2/Q1 sweep kernel the two
+ * exchanges run concurrently with the interior cells (three phases of adaflo_ns_vmult_phase,
+ * HIP events between the engine stream and the communication stream, no host
+ * synchronisation); src_ghosts_valid != 0 skips the ghost update of src (Krylov vectors that
+ * came out of a previous distributed operation are consistent already).  src is not const:
+ * its replicas are refreshed.                                                               */
+int         adaflo_ns_vmult_distributed(adaflo_ctx *ctx, adaflo_comm *comm, double *dst_u, double *dst_p,
+                                        double *src_u, double *src_p, int src_ghosts_valid);
+
 
 /* ---- level-set operators (LevelSetOKZSolver*, source/level_set_okz_*.cc) ---- */
 /* FE_Q_iso_Q1(ls_degree) on the same brick; block vectors with dim blocks (normal

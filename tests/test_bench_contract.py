@@ -52,6 +52,8 @@ def test_bench_self_launches_two_ranks():
     assert r["config"]["dofs"] == 3 * 129 * 65 * 65 + 65 * 33 * 33
     if torch.cuda.device_count() < 2:
         assert r.get("dry_run") is True
+    r = _run(["--gpus", "2", "--cells", "32", "--steps", "3", "--warmup", "1", "--comm", "native"])
+    assert r["n_gpus"] == 2 and r["config"]["comm"] == "native" and r["value"] > 0
 
 
 @pytest.mark.gpu

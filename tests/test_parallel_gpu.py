@@ -67,21 +67,37 @@ def _worker(rank, world, port, grid, cells, gu, gp, glin, ref_u, ref_p, results)
         du, dp = torch.full_like(su, 3.0), torch.full_like(sp, 3.0)
         src = adaflo_amd.BlockVector([V(ctx, su), V(ctx, sp)])
         dst = adaflo_amd.BlockVector([V(ctx, du), V(ctx, dp)])
-        # Q2/Q1 sweep kernel with and without the overlapped (phased) schedule, generic kernel
-        for variant, overlap in ((1, True), (1, False), (0, False)):
-            op.set_kernel_variant(variant)
-            op.overlap = overlap
+        # Q2/Q1 sweep kernel with and without the overlapped (phased) schedule, generic kernel -- exchange
+        # driven from Python (torch.distributed) and inside the library (adaflo_ns_vmult_distributed with the
+        # gloo-staged transport callbacks)
+        nat = parallel.DistributedNavierStokesMatrix(fp, part, device=0, group=dist.group.WORLD, native_comm=True)
+        nat.initialize(_make(fp), True)
+        nat.local.set_linearization(np.ascontiguousarray(glin[cs]).reshape(-1))
+        nctx = nat.local._ctx
+        nsrc = adaflo_amd.BlockVector([V(nctx, su), V(nctx, sp)])
+        ndst = adaflo_amd.BlockVector([V(nctx, du), V(nctx, dp)])
+        for variant, overlap, native in ((1, True, False), (1, False, False), (0, False, False), (1, True, True), (0, False, True)):
+            o, a, b = (nat, ndst, nsrc) if native else (op, dst, src)
+            o.set_kernel_variant(variant)
+            o.overlap = overlap
             du.fill_(3.0)
             dp.fill_(3.0)
             su.copy_(torch.from_numpy(np.where(ou > 0, lu, -5.0)))
             sp.copy_(torch.from_numpy(np.where(opm > 0, lp, -5.0)))
-            op.vmult(dst, src)
+            o.vmult(a, b)
             torch.cuda.synchronize()
             nu = [k * g * c + 1 for g, c in zip(grid, cells)]
             npn = [(k - 1) * g * c + 1 for g, c in zip(grid, cells)]
             ru = _view(ref_u.reshape(nu[2], nu[1], nu[0], 3), part, k).reshape(-1)
             rp = _view(ref_p.reshape(npn[2], npn[1], npn[0], 1), part, k - 1).reshape(-1)
-            results[(rank, variant, overlap)] = (rel_l2(du.cpu().numpy(), ru), rel_l2(dp.cpu().numpy(), rp))
+            results[(rank, variant, overlap, native)] = (rel_l2(du.cpu().numpy(), ru), rel_l2(dp.cpu().numpy(), rp))
+            # the replicas of an interface DoF are bitwise equal on all sharers: importing the owners' values
+            # changes nothing (compress(add) sums in a fixed order on every rank)
+            cu, cp = du.clone(), dp.clone()
+            halo.update_ghost_values([cu, cp])
+            torch.cuda.synchronize()
+            assert torch.equal(cu, du) and torch.equal(cp, dp), (rank, variant, overlap, native)
+        nat.comm.close()
     finally:
         dist.destroy_process_group()
 
@@ -112,6 +128,43 @@ def test_distributed_vmult_on_one_gpu(world, cells):
     results = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), grid, list(cells), gu, gp, glin, ref_u, ref_p, results),
              nprocs=world, join=True)
-    assert len(results) == 3 * world
+    assert len(results) == 5 * world
     for key, (eu, ep) in results.items():
         assert eu < 1e-12 and ep < 1e-12, (key, eu, ep)
+
+
+def test_native_communicator_world_one_over_rccl():
+    """adaflo_comm_create with the RCCL transport on a world of one rank (the only world a one-GPU box
+    offers): the library resolves RCCL, opens a communicator, and adaflo_ns_vmult_distributed equals the
+    local operator including the global form of the mean-value projection"""
+    import ctypes as C
+    from adaflo_amd import _lib
+    lib = _lib.load()
+    k, cells = 2, [9, 8, 5]
+    rng = np.random.default_rng(3)
+    fp = adaflo_amd.FlowParameters(velocity_degree=k)
+    mesh = adaflo_amd.BrickMesh(cells, [-1.0] * 3, [1.0] * 3)
+    lin = rng.uniform(-1, 1, int(np.prod(cells)) * 27 * 12)
+    ref = adaflo_amd.NavierStokesMatrix(fp, mesh)
+    ref.initialize(_make(fp), True)
+    ref.set_linearization(lin)
+    su, sp = rng.uniform(-1, 1, ref.n_dofs_u()), rng.uniform(-1, 1, ref.n_dofs_p())
+    dst = ref.block_vector()
+    ref.vmult(dst, ref.block_vector(su, sp))
+    ref_u, ref_p = dst.numpy()
+    op = adaflo_amd.NavierStokesMatrix(fp, mesh)
+    op.initialize(_make(fp), False)                  # the communicator applies the projection
+    op.set_linearization(lin)
+    uid = _lib.CommUniqueId()
+    assert lib.adaflo_comm_get_unique_id(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    grid = (C.c_int * 3)(1, 1, 1)
+    code = lib.adaflo_comm_create(op._ctx, C.byref(uid), 0, 1, grid, 1, C.byref(comm))
+    assert code == 0, lib.adaflo_last_error(op._ctx)
+    assert lib.adaflo_comm_interface_faces(comm) == 0
+    src, dst = op.block_vector(su, sp), op.block_vector()
+    assert lib.adaflo_ns_vmult_distributed(op._ctx, comm, dst.block(0).ptr, dst.block(1).ptr, src.block(0).ptr,
+                                           src.block(1).ptr, 0) == 0
+    got_u, got_p = dst.numpy()
+    assert rel_l2(got_u, ref_u) < 1e-13 and rel_l2(got_p, ref_p) < 1e-12
+    assert lib.adaflo_comm_destroy(comm) == 0
