@@ -116,6 +116,13 @@ SIGNATURES = {
     "adaflo_ls_get_evaluated_normal": (C.c_int, [_CTX, C.c_void_p, C.c_int]),
     "adaflo_ls_advance_concentration_vmult": (C.c_int, [_CTX, _D, _D]),
     "adaflo_ls_advance_concentration_rhs": (C.c_int, [_CTX, _D, _D, _D, _D, _D, C.c_int]),
+    "adaflo_ls_set_convection_stabilization": (C.c_int, [_CTX, C.c_int, C.c_double, C.c_uint]),
+    "adaflo_ls_set_artificial_viscosities": (C.c_int, [_CTX, C.c_void_p, C.c_int]),
+    "adaflo_ls_get_artificial_viscosities": (C.c_int, [_CTX, C.c_void_p, C.c_int]),
+    "adaflo_ls_max_velocity": (C.c_int, [_CTX, _D, C.POINTER(C.c_double)]),
+    "adaflo_ls_advance_concentration_rhs_stabilized": (C.c_int, [_CTX, _D, _D, _D, _D, _D, _D, _D, C.c_int, C.c_double,
+                                                                C.c_double]),
+    "adaflo_ls_stabilization_boundary_term": (C.c_int, [_CTX, _D, _D, C.c_double]),
     "adaflo_ls_reinitialization_vmult": (C.c_int, [_CTX, _D, _D, C.c_int]),
     "adaflo_ls_reinitialization_rhs": (C.c_int, [_CTX, _D, _D, _D, C.c_int, C.c_int]),
     "adaflo_ls_compute_normal_vmult": (C.c_int, [_CTX, _D, _D]),

@@ -316,10 +316,11 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
                           &ctx->ls_convection, &ctx->ls_normal, &ctx->q1_convection, &ctx->q1_normal,
                           &ctx->q1_slab, &ctx->q1_zslab, &ctx->pc_inv_u, &ctx->pc_inv_pm, &ctx->pc_inv_pl,
                           &ctx->pc_ones_p, &ctx->pc_tmp_u, &ctx->pc_tmp_p, &ctx->pc_tmp_p2, &ctx->pc_work, &ctx->kr_work, &ctx->kr_basis, &ctx->kr_scalars,
-                          &ctx->q1_poisson_coef, &ctx->ho_tab, &ctx->res_sum_u, &ctx->res_sum_p, &ctx->res_old})
+                          &ctx->q1_poisson_coef, &ctx->ho_tab, &ctx->res_sum_u, &ctx->res_sum_p, &ctx->res_old,
+                          &ctx->ls_art_visc, &ctx->ls_stab_vel_sum, &ctx->ls_stab_ls_sum})
     release(*b);
   for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch,
-                    ctx->d_tab_ls, ctx->d_ls_diag, ctx->d_tab_force})
+                    ctx->d_tab_ls, ctx->d_ls_diag, ctx->d_tab_force, ctx->d_tab_maxvel})
     if (p)
       (void)hipFree(p);
   if (ctx->q2_wg_list)
@@ -1085,7 +1086,8 @@ static int ls_vmult(adaflo_ctx *ctx, double *dst, const double *src, const int m
     return e;
   if (!dst || !src)
     return fail(ctx, ADAFLO_EINVAL, "null vector");
-  if (ctx->variant >= 1)
+  const bool stabilised = mode == 0 && ctx->ls_stab; // convection stabilisation: generic kernels
+  if (ctx->variant >= 1 && !stabilised)
     {
       // structured Q1 sweep kernel: FE_Q_iso_Q1(s) = trilinear elements on the refined grid
       if (ctx->brick.con_ls && !ctx->d_ls_diag)
@@ -1135,6 +1137,21 @@ static int ls_vmult(adaflo_ctx *ctx, double *dst, const double *src, const int m
       return 0;
     }
   HIP_TRY(ctx, hipMemsetAsync(dst, 0, sizeof(double) * nblocks * ctx->n_nodes_ls, ctx->stream)); // dst = 0.
+  if (stabilised)
+    {
+      // :248-249 cell term with the artificial viscosities of the last rhs, :419-472 boundary term
+      if (!ctx->ls_art_visc.p)
+        return fail(ctx, ADAFLO_ENOTINIT, "artificial viscosities not set (run the stabilised rhs first)");
+      LSStab st{};
+      st.art_visc = ctx->ls_art_visc.p;
+      st.bsign    = -1.;
+      st.symmetry = ctx->ls_symmetry;
+      TRY(ctx, launch_ls(ctx, 0, mode, flag, dst, src, nullptr, nullptr, nullptr, qstate, nblocks, &st),
+          "level-set kernel launch failed");
+      TRY(ctx, launch_ls(ctx, 3, 0, 0, dst, src, nullptr, nullptr, nullptr, nullptr, 1, &st),
+          "level-set boundary kernel launch failed");
+    }
+  else
   TRY(ctx, launch_ls(ctx, 0, mode, flag, dst, src, nullptr, nullptr, nullptr, qstate, nblocks),
       "level-set kernel launch failed");
   TRY(ctx, launch_ls_constrained_rows(ctx, dst, src, nblocks), "constrained rows need adaflo_ls_set_diagonal");
@@ -1164,6 +1181,138 @@ int adaflo_ls_advance_concentration_rhs(adaflo_ctx *ctx, double *dst, const doub
       launch_ls(ctx, 2, 0, use_old_old, dst, solution, solution_old, solution_old_old, vel_solution,
                 ctx->ls_convection.p, 1),
       "level-set kernel launch failed");
+  return 0;
+}
+
+/* ---- convection stabilisation (parameters.convection_stabilization) -------------------- */
+int adaflo_ls_set_convection_stabilization(adaflo_ctx *ctx, int enabled, double global_omega_diameter,
+                                           unsigned symmetry_faces)
+{
+  CHECK_CTX(ctx);
+  if (int e = ls_ready(ctx))
+    return e;
+  if (enabled && !(global_omega_diameter > 0.))
+    return fail(ctx, ADAFLO_EINVAL, "global_omega_diameter must be positive");
+  ctx->ls_stab           = enabled != 0;
+  ctx->ls_omega_diameter = global_omega_diameter;
+  ctx->ls_symmetry       = symmetry_faces;
+  if (enabled && !ctx->ls_art_visc.p)
+    {
+      TRY(ctx, alloc(ctx, ctx->ls_art_visc, (size_t)ctx->n_cells), ctx->last_error);
+      TRY(ctx, launch_fill(ctx, ctx->ls_art_visc.p, 0., ctx->n_cells), "fill failed");
+    }
+  return 0;
+}
+
+int adaflo_ls_set_artificial_viscosities(adaflo_ctx *ctx, const double *nu, int src_on_device)
+{
+  CHECK_CTX(ctx);
+  if (!nu)
+    return fail(ctx, ADAFLO_EINVAL, "null array");
+  TRY(ctx, alloc(ctx, ctx->ls_art_visc, (size_t)ctx->n_cells), ctx->last_error);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->ls_art_visc.p, nu, ctx->n_cells * sizeof(double),
+                              src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int adaflo_ls_get_artificial_viscosities(adaflo_ctx *ctx, double *nu, int dst_on_device)
+{
+  CHECK_CTX(ctx);
+  if (!nu || !ctx->ls_art_visc.p)
+    return fail(ctx, ADAFLO_ENOTINIT, "artificial viscosities not set");
+  HIP_TRY(ctx, hipMemcpyAsync(nu, ctx->ls_art_visc.p, ctx->n_cells * sizeof(double),
+                              dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int adaflo_ls_max_velocity(adaflo_ctx *ctx, const double *vel_solution, double *max_velocity)
+{
+  CHECK_CTX(ctx);
+  if (!vel_solution || !max_velocity)
+    return fail(ctx, ADAFLO_EINVAL, "null argument");
+  const int k = ctx->k;
+  if (!ctx->d_tab_maxvel)
+    {
+      Quadrature1D trap; // QIterated(QTrapezoid<1>(), k + 1): points j / (k + 1)
+      for (int j = 0; j <= k + 1; ++j)
+        {
+          trap.x.push_back(double(j) / (k + 1));
+          trap.w.push_back(0.);
+        }
+      TRY(ctx, upload(ctx, &ctx->d_tab_maxvel, shape_fe_q(k, trap).S), ctx->last_error);
+    }
+  unsigned long long *res = nullptr;
+  HIP_TRY(ctx, hipMalloc(&res, sizeof(unsigned long long)));
+  HIP_TRY(ctx, hipMemsetAsync(res, 0, sizeof(unsigned long long), ctx->stream));
+  const int e = launch_ls_max_velocity(ctx, vel_solution, ctx->d_tab_maxvel, res);
+  unsigned long long bits = 0;
+  if (!e)
+    (void)hipMemcpyAsync(&bits, res, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(res);
+  if (e)
+    return fail(ctx, e, "maximal-velocity kernel launch failed");
+  std::memcpy(max_velocity, &bits, sizeof(double));
+  return 0;
+}
+
+int adaflo_ls_stabilization_boundary_term(adaflo_ctx *ctx, double *dst, const double *vec, double sign)
+{
+  CHECK_CTX(ctx);
+  if (int e = ls_ready(ctx))
+    return e;
+  if (!dst || !vec || !ctx->ls_art_visc.p)
+    return fail(ctx, ADAFLO_ENOTINIT, "artificial viscosities not set");
+  LSStab st{};
+  st.art_visc = ctx->ls_art_visc.p;
+  st.bsign    = sign;
+  st.symmetry = ctx->ls_symmetry;
+  TRY(ctx, launch_ls(ctx, 3, 0, 0, dst, vec, nullptr, nullptr, nullptr, nullptr, 1, &st),
+      "level-set boundary kernel launch failed");
+  return 0;
+}
+
+int adaflo_ls_advance_concentration_rhs_stabilized(adaflo_ctx *ctx, double *dst, const double *solution,
+                                                   const double *solution_old, const double *solution_old_old,
+                                                   const double *vel_solution, const double *vel_solution_old,
+                                                   const double *vel_solution_old_old, int use_old_old,
+                                                   double old_step_size, double global_max_velocity)
+{
+  CHECK_CTX(ctx);
+  if (int e = ls_ready(ctx))
+    return e;
+  if (!ctx->ls_stab)
+    return fail(ctx, ADAFLO_ENOTINIT, "call adaflo_ls_set_convection_stabilization first");
+  if (!dst || !solution || !solution_old || !solution_old_old || !vel_solution || !vel_solution_old ||
+      !vel_solution_old_old)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  TRY(ctx, alloc(ctx, ctx->ls_convection, ls_q_count(ctx)), ctx->last_error);
+  TRY(ctx, alloc(ctx, ctx->ls_art_visc, (size_t)ctx->n_cells), ctx->last_error);
+  TRY(ctx, alloc(ctx, ctx->ls_stab_vel_sum, (size_t)(3 * ctx->n_nodes_u)), ctx->last_error);
+  TRY(ctx, alloc(ctx, ctx->ls_stab_ls_sum, (size_t)ctx->n_nodes_ls), ctx->last_error);
+  ctx->q1_convection_valid = false;
+  // interpolation is linear: the sums of the two old states are formed at the nodes
+  TRY(ctx, launch_lincomb(ctx, ctx->ls_stab_vel_sum.p, 1., vel_solution_old, 1., vel_solution_old_old, 3 * ctx->n_nodes_u),
+      "sum failed");
+  TRY(ctx, launch_lincomb(ctx, ctx->ls_stab_ls_sum.p, 1., solution_old, 1., solution_old_old, ctx->n_nodes_ls),
+      "sum failed");
+  LSStab st{};
+  st.art_visc       = ctx->ls_art_visc.p;
+  st.vel_sum        = ctx->ls_stab_vel_sum.p;
+  st.ls_sum         = ctx->ls_stab_ls_sum.p;
+  st.old_step_inv   = 1. / old_step_size;
+  st.global_scaling = global_max_velocity * 2. * ctx->ls_omega_diameter; // :361
+  st.bsign          = 1.;
+  st.symmetry       = ctx->ls_symmetry;
+  TRY(ctx,
+      launch_ls(ctx, 2, 0, use_old_old, dst, solution, solution_old, solution_old_old, vel_solution,
+                ctx->ls_convection.p, 1, &st),
+      "level-set kernel launch failed");
+  // :569-617 boundary part of the stabilisation term on the right-hand side
+  TRY(ctx, launch_ls(ctx, 3, 0, 0, dst, solution, nullptr, nullptr, nullptr, nullptr, 1, &st),
+      "level-set boundary kernel launch failed");
   return 0;
 }
 

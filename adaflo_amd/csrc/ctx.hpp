@@ -135,6 +135,12 @@ struct adaflo_ctx
   double                  *d_ls_diag = nullptr; // preconditioner.get_vector() for constrained rows
   double                  *d_tab_force = nullptr; // 1D tables of local_compute_force (ls_force.hip)
   adaflo_hip::DeviceBuffer ls_convection, ls_normal; // evaluated_convection / evaluated_normal [cell][3][q]
+  // `convection stabilization` of the advection operator (advance_concentration.cc:344-369)
+  bool                     ls_stab = false;
+  double                   ls_omega_diameter = 0.;
+  unsigned                 ls_symmetry = 0;
+  adaflo_hip::DeviceBuffer ls_art_visc, ls_stab_vel_sum, ls_stab_ls_sum; // artificial_viscosities [cell], nodal sums
+  double                  *d_tab_maxvel = nullptr;                      // FE_Q(k) at the iterated trapezoid points
   // structured Q1 sweep kernel (q1_sweep.hip): streaming copies of the two arrays, seam partial sums
   adaflo_hip::DeviceBuffer q1_convection, q1_normal, q1_slab, q1_zslab;
   bool                     q1_convection_valid = false, q1_normal_valid = false;

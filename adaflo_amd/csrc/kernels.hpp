@@ -92,9 +92,18 @@ namespace adaflo_hip
   int launch_subtract_scaled(adaflo_ctx *ctx, double *v, const double *s, const double *t, long n); // v -= *s * *t
 
   // level-set operators (ls_kernels.hip); kind: 0 operator application, 1 rhs, 2 advection rhs
+  // optional convection stabilisation of the advection operator (ls_kernels.hip)
+  struct LSStab
+  {
+    double       *art_visc;
+    const double *vel_sum, *ls_sum;
+    double        old_step_inv, global_scaling, bsign;
+    unsigned      symmetry;
+  };
   int launch_ls(adaflo_ctx *ctx, int kind, int mode, int flag, double *dst, const double *src,
                 const double *src2, const double *src3, const double *vel, double *qstate,
-                int ncomp_blocks);
+                int ncomp_blocks, const LSStab *stab = nullptr);
+  int launch_ls_max_velocity(adaflo_ctx *ctx, const double *vel, const double *tab, unsigned long long *result);
   int launch_ls_constrained_rows(adaflo_ctx *ctx, double *dst, const double *src, int nblocks);
 
   // structured Q1 sweep kernel (q1_sweep.hip): level-set operators on the s-times refined grid

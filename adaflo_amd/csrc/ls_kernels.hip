@@ -7,8 +7,10 @@
 //   reinitialization source/level_set_okz_reinitialization.cc:53-106 (vmult), :128-189 (rhs)
 //   normal           source/level_set_okz_compute_normal.cc:82-119 (vmult), :123-156 (rhs)
 //   curvature        source/level_set_okz_compute_curvature.cc:86-133 (vmult), :212-259 (rhs)
-// One workgroup per cell, tensors in LDS (SumFac of fe_kernels.hpp); convection
-// stabilization = 0 (the FEFaceValues branch is out of scope).
+// One workgroup per cell, tensors in LDS (SumFac of fe_kernels.hpp).  The optional
+// `convection stabilization` of the advection operator (advance_concentration.cc:248-249 cell
+// term, :344-369 artificial viscosity, :387-388 rhs term, :419-472 / :569-617 boundary term,
+// :39-68 maximal velocity) is here as well.
 #include "kernels.hpp"
 
 namespace adaflo_hip
@@ -33,6 +35,13 @@ namespace adaflo_hip
     const double *tab;                     // [S D w] of the LS space, then [S_vel] for advect rhs
     long          n_cells, n_nodes;
     int           mode, flag;
+    // convection stabilisation: artificial_viscosities [cell] (read by the operator, written by
+    // the advection rhs), nodal sums u_old + u_old_old / phi_old + phi_old_old, 1 / old step size,
+    // global_max_velocity * 2 * global_omega_diameter, symmetry faces, sign of the boundary term
+    double       *art_visc;
+    const double *vel_sum, *ls_sum;
+    double        old_step_inv, global_scaling, bsign;
+    unsigned      symmetry;
   };
 
   template <int S, int NT>
@@ -100,6 +109,9 @@ namespace adaflo_hip
           {
             case LS_ADVECT: // :244-249
               tv = v * P.weight + qs[q] * g[0] + qs[NQ3 + q] * g[1] + qs[2 * NQ3 + q] * g[2];
+              if (a.art_visc)
+                for (int e = 0; e < 3; ++e)
+                  tg[e] = a.art_visc[c] * g[e];
               break;
             case LS_REINIT: // :88-95
               {
@@ -295,6 +307,7 @@ namespace adaflo_hip
     double *Sm = lds, *Dm = Sm + NQ * C::ND, *wq = Dm + NQ * C::ND;
     double *ul = lds + C::TABP, *val = ul + ND3, *grad = val + NQ3, *tmp = grad + 3 * NQ3;
     double *Sv = tmp + TMPX, *vl = Sv + NQ * (KU + 1), *vq = vl + 3 * NDV3, *vo = vq + 3 * NQ3, *voo = vo + NQ3;
+    double *red = voo + NQ3; // [2][NT] reduction scratch of the stabilisation
 
     const int tid = threadIdx.x;
     for (int o = tid; o < C::TAB; o += NT)
@@ -310,11 +323,6 @@ namespace adaflo_hip
     const double ih[3] = {1. / a.brick.h[0], 1. / a.brick.h[1], 1. / a.brick.h[2]};
     const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
 
-    // velocity values at the LS quadrature points
-    gather_cell<KU, 3, NT, false>(a.vel, vl, cx, cy, cz, vx, vy, vz, 0u);
-    __syncthreads();
-    for (int d = 0; d < 3; ++d)
-      SFV::template evaluate<true, false>(Sv, Sv, vl + d * NDV3, vq + d * NQ3, nullptr, nullptr, nullptr, tmp);
     // old level-set values
     gather_cell<S, 1, NT, false>(a.src2, ul, cx, cy, cz, nx, ny, nz, 0u);
     __syncthreads();
@@ -322,6 +330,50 @@ namespace adaflo_hip
     gather_cell<S, 1, NT, false>(a.src3, ul, cx, cy, cz, nx, ny, nz, 0u);
     __syncthreads();
     SF::template evaluate<true, false>(Sm, Dm, ul, voo, nullptr, nullptr, nullptr, tmp);
+    double nu_cell = 0.;
+    if (a.art_visc)
+      {
+        // :344-369: residual of the concentration equation with the two old states; interpolation
+        // is linear, so u_old + u_old_old and grad(phi_old + phi_old_old) come from nodal sums
+        gather_cell<KU, 3, NT, false>(a.vel_sum, vl, cx, cy, cz, vx, vy, vz, 0u);
+        gather_cell<S, 1, NT, false>(a.ls_sum, ul, cx, cy, cz, nx, ny, nz, 0u);
+        __syncthreads();
+        for (int d = 0; d < 3; ++d)
+          SFV::template evaluate<true, false>(Sv, Sv, vl + d * NDV3, vq + d * NQ3, nullptr, nullptr, nullptr, tmp);
+        SF::template evaluate<false, true>(Sm, Dm, ul, nullptr, grad, grad + NQ3, grad + 2 * NQ3, tmp);
+        double max_res = 0., max_vel = 0.;
+        for (int q = tid; q < NQ3; q += NT)
+          {
+            double ugr = 0., u2 = 0.;
+            for (int e = 0; e < 3; ++e)
+              {
+                const double u = vq[e * NQ3 + q];
+                ugr += u * grad[e * NQ3 + q] * ih[e];
+                u2 += u * u;
+              }
+            max_res = fmax(max_res, fabs((vo[q] - voo[q]) * a.old_step_inv + 0.25 * ugr));
+            max_vel = fmax(max_vel, sqrt(u2));
+          }
+        __syncthreads();
+        red[tid]      = max_res;
+        red[NT + tid] = max_vel;
+        __syncthreads();
+        for (int o = 0; o < NT; ++o) // (every thread reduces: the result is needed by all of them)
+          {
+            max_res = fmax(max_res, red[o]);
+            max_vel = fmax(max_vel, red[NT + o]);
+          }
+        const double hcell = fmax(a.brick.h[0], fmax(a.brick.h[1], a.brick.h[2]));
+        nu_cell            = 0.03 * max_vel * hcell * fmin(1., max_res / a.global_scaling);
+        if (tid == 0)
+          a.art_visc[c] = nu_cell;
+        __syncthreads();
+      }
+    // velocity values at the LS quadrature points
+    gather_cell<KU, 3, NT, false>(a.vel, vl, cx, cy, cz, vx, vy, vz, 0u);
+    __syncthreads();
+    for (int d = 0; d < 3; ++d)
+      SFV::template evaluate<true, false>(Sv, Sv, vl + d * NDV3, vq + d * NQ3, nullptr, nullptr, nullptr, tmp);
     // current level set
     gather_cell<S, 1, NT, false>(a.src, ul, cx, cy, cz, nx, ny, nz, 0u);
     __syncthreads();
@@ -343,10 +395,133 @@ namespace adaflo_hip
             uq[e * NQ3 + q] = u; // :389 evaluated_convection
           }
         val[q] = -(val[q] * P.weight + ug + old_value) * jxw;
+        if (a.art_visc) // :387-388
+          for (int e = 0; e < 3; ++e)
+            grad[e * NQ3 + q] *= -nu_cell * ih[e] * ih[e] * jxw;
       }
     __syncthreads();
-    SF::template integrate<true, false>(Sm, Dm, val, nullptr, nullptr, nullptr, ul, tmp);
+    if (a.art_visc)
+      SF::template integrate<true, true>(Sm, Dm, val, grad, grad + NQ3, grad + 2 * NQ3, ul, tmp);
+    else
+      SF::template integrate<true, false>(Sm, Dm, val, nullptr, nullptr, nullptr, ul, tmp);
     scatter_cell<S, 1, NT>(a.dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+  }
+
+  // boundary part of the stabilisation (:419-472 operator, bsign = -1; :569-617 rhs, bsign = +1):
+  // dst_i += bsign (phi_i, n . nu_cell grad vec) over the boundary faces that are not symmetry
+  // faces; face quadrature QIterated(QGauss<1>(2), s)^2, vec read plainly, constrained rows skipped.
+  // One workgroup per cell (cells away from the boundary return at once).
+  template <int S, int NT>
+  __global__ __launch_bounds__(NT) void ls_advect_boundary_kernel(const LSArgs a)
+  {
+    using C = LSCell<S>;
+    constexpr int ND = C::ND, NQ = C::NQ, ND3 = C::ND3;
+    const long c   = blockIdx.x;
+    const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
+    const int  cc[3] = {(int)(c % ncx), (int)((c / ncx) % ncy), (int)(c / ((long)ncx * ncy))};
+    const int  nc[3] = {ncx, ncy, ncz};
+    unsigned   faces = 0;
+    for (int d = 0; d < 3; ++d)
+      {
+        if (cc[d] == 0 && !(a.symmetry >> (2 * d) & 1u))
+          faces |= 1u << (2 * d);
+        if (cc[d] == nc[d] - 1 && !(a.symmetry >> (2 * d + 1) & 1u))
+          faces |= 1u << (2 * d + 1);
+      }
+    if (!faces)
+      return;
+    extern __shared__ double lds[];
+    double *Sm = lds, *wq = Sm + 2 * NQ * ND, *ul = lds + C::TABP, *flux = ul + ND3; // flux [NQ][NQ]
+    const int tid = threadIdx.x;
+    for (int o = tid; o < C::TAB; o += NT)
+      lds[o] = a.tab[o];
+    const int nx = S * ncx + 1, ny = S * ncy + 1, nz = S * ncz + 1;
+    gather_cell<S, 1, NT, false>(a.src, ul, cc[0], cc[1], cc[2], nx, ny, nz, 0u);
+    __syncthreads();
+    const double nu = a.art_visc[c];
+    for (int f = 0; f < 6; ++f)
+      {
+        if (!(faces >> f & 1u))
+          continue;
+        const int d = f / 2, side = f % 2, t1 = (d + 1) % 3, t2 = (d + 2) % 3;
+        const int e1 = t1 < t2 ? t1 : t2, e2 = t1 < t2 ? t2 : t1; // tangential directions, ascending
+        const double area = a.brick.h[e1] * a.brick.h[e2];
+        const int    in0 = side ? S - 1 : 0; // the two nodes whose hats have a normal derivative at the face
+        const int    stride[3] = {1, ND, ND * ND};
+        // normal derivative of vec at the face points (hats are piecewise linear: -+ s / h between
+        // the two nodes next to the face), times n, nu, JxW and the sign
+        for (int q = tid; q < NQ * NQ; q += NT)
+          {
+            const int q1 = q % NQ, q2 = q / NQ;
+            double    dn = 0.;
+            for (int j2 = 0; j2 < ND; ++j2)
+              for (int j1 = 0; j1 < ND; ++j1)
+                {
+                  const double w = Sm[q1 * ND + j1] * Sm[q2 * ND + j2];
+                  if (w != 0.)
+                    dn += w * (ul[j1 * stride[e1] + j2 * stride[e2] + (in0 + 1) * stride[d]] -
+                               ul[j1 * stride[e1] + j2 * stride[e2] + in0 * stride[d]]);
+                }
+            flux[q] = a.bsign * (side ? 1. : -1.) * nu * dn * ((double)S / a.brick.h[d]) * area * wq[q1] * wq[q2];
+          }
+        __syncthreads();
+        for (int i = tid; i < ND * ND; i += NT)
+          {
+            const int i1 = i % ND, i2 = i / ND;
+            double    r  = 0.;
+            for (int q2 = 0; q2 < NQ; ++q2)
+              for (int q1 = 0; q1 < NQ; ++q1)
+                r += Sm[q1 * ND + i1] * Sm[q2 * ND + i2] * flux[q2 * NQ + q1];
+            int ii[3];
+            ii[e1] = i1;
+            ii[e2] = i2;
+            ii[d]  = side ? S : 0;
+            const int I = cc[0] * S + ii[0], J = cc[1] * S + ii[1], K = cc[2] * S + ii[2];
+            if (!on_constrained_face(I, J, K, nx, ny, nz, a.brick.con_ls, 1, 0))
+              unsafeAtomicAdd(&a.dst[I + (long)nx * (J + (long)ny * K)], r);
+          }
+        __syncthreads();
+      }
+  }
+
+  // get_maximal_velocity (:39-68): largest |u| on the points of QIterated(QTrapezoid<1>(), k + 1)
+  template <int KU>
+  __global__ __launch_bounds__(64) void ls_max_velocity_kernel(const double *__restrict__ vel, const double *__restrict__ tab,
+                                                               const int ncx, const int ncy, const int ncz,
+                                                               unsigned long long *result)
+  {
+    constexpr int ND = KU + 1, NP = KU + 2, ND3 = ND * ND * ND, NP3 = NP * NP * NP;
+    __shared__ double St[NP * ND], vl[3 * ND3], red[64];
+    const int  tid = threadIdx.x;
+    const long c   = blockIdx.x;
+    const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
+    for (int o = tid; o < NP * ND; o += 64)
+      St[o] = tab[o];
+    gather_cell<KU, 3, 64, false>(vel, vl, cx, cy, cz, KU * ncx + 1, KU * ncy + 1, KU * ncz + 1, 0u);
+    __syncthreads();
+    double best = 0.;
+    for (int q = tid; q < NP3; q += 64)
+      {
+        const int qx = q % NP, qy = (q / NP) % NP, qz = q / (NP * NP);
+        double    u[3] = {0., 0., 0.};
+        for (int k = 0; k < ND; ++k)
+          for (int j = 0; j < ND; ++j)
+            for (int i = 0; i < ND; ++i)
+              {
+                const double w = St[qx * ND + i] * St[qy * ND + j] * St[qz * ND + k];
+                for (int e = 0; e < 3; ++e)
+                  u[e] += w * vl[e * ND3 + (k * ND + j) * ND + i];
+              }
+        best = fmax(best, sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]));
+      }
+    red[tid] = best;
+    __syncthreads();
+    if (tid == 0)
+      {
+        for (int o = 1; o < 64; ++o)
+          best = fmax(best, red[o]);
+        atomicMax(result, (unsigned long long)__double_as_longlong(best)); // (non-negative doubles order as integers)
+      }
   }
 
   // dst[c] = diag[c] * src[c] on constrained rows (e.g. reinitialization.cc:227-230)
@@ -387,6 +562,11 @@ namespace adaflo_hip
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((ls_rhs_kernel<S, NT>), grid, block, lds, ctx->stream, a);
       }
+    else if (kind == 3)
+      {
+        const size_t lds = sizeof(double) * (LSCell<S>::TABP + ND3 + 4 * S * S);
+        hipLaunchKernelGGL((ls_advect_boundary_kernel<S, 64>), dim3((unsigned)a.n_cells), dim3(64), lds, ctx->stream, a);
+      }
     else
       {
 #define ADV(KU)                                                                                      \
@@ -394,7 +574,7 @@ namespace adaflo_hip
     constexpr int    NDV3 = (KU + 1) * (KU + 1) * (KU + 1);                                          \
     constexpr size_t tmpv = SumFac<KU + 1, 2 * S, NT>::TMP, tmps = SumFac<S + 1, 2 * S, NT>::TMP;    \
     const size_t     lds  = sizeof(double) * (ls_lds_doubles<S, NT>(0) + (tmpv > tmps ? tmpv - tmps : 0) + \
-                                         2 * S * (KU + 1) + 3 * NDV3 + 5 * NQ3);                      \
+                                         2 * S * (KU + 1) + 3 * NDV3 + 5 * NQ3 + 2 * NT);             \
     if (lds > 64 * 1024)                                                                             \
       err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_advect_rhs_kernel<S, KU, NT>),    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
@@ -421,12 +601,46 @@ namespace adaflo_hip
     return err == hipSuccess ? 0 : ADAFLO_EHIP;
   }
 
-  // kind: 0 operator application, 1 rhs (reinit / normal / curvature), 2 advection rhs
+  int launch_ls_max_velocity(adaflo_ctx *ctx, const double *vel, const double *tab, unsigned long long *result)
+  {
+    const dim3 grid((unsigned)ctx->n_cells), block(64);
+    switch (ctx->k)
+      {
+        case 2:
+          hipLaunchKernelGGL((ls_max_velocity_kernel<2>), grid, block, 0, ctx->stream, vel, tab, ctx->desc.ncell[0],
+                             ctx->desc.ncell[1], ctx->desc.ncell[2], result);
+          break;
+        case 3:
+          hipLaunchKernelGGL((ls_max_velocity_kernel<3>), grid, block, 0, ctx->stream, vel, tab, ctx->desc.ncell[0],
+                             ctx->desc.ncell[1], ctx->desc.ncell[2], result);
+          break;
+        case 4:
+          hipLaunchKernelGGL((ls_max_velocity_kernel<4>), grid, block, 0, ctx->stream, vel, tab, ctx->desc.ncell[0],
+                             ctx->desc.ncell[1], ctx->desc.ncell[2], result);
+          break;
+        default:
+          return ADAFLO_EUNSUPPORTED;
+      }
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+
+  // kind: 0 operator application, 1 rhs (reinit / normal / curvature), 2 advection rhs,
+  // 3 boundary part of the convection stabilisation (src = the vector, stab->bsign)
   int launch_ls(adaflo_ctx *ctx, const int kind, const int mode, const int flag, double *dst,
                 const double *src, const double *src2, const double *src3, const double *vel,
-                double *qstate, const int ncomp_blocks)
+                double *qstate, const int ncomp_blocks, const LSStab *stab)
   {
     LSArgs a{};
+    if (stab)
+      {
+        a.art_visc       = stab->art_visc;
+        a.vel_sum        = stab->vel_sum;
+        a.ls_sum         = stab->ls_sum;
+        a.old_step_inv   = stab->old_step_inv;
+        a.global_scaling = stab->global_scaling;
+        a.bsign          = stab->bsign;
+        a.symmetry       = stab->symmetry;
+      }
     a.brick   = ctx->brick;
     a.ls      = ctx->ls;
     a.src     = src;

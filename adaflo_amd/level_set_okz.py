@@ -137,16 +137,64 @@ class LevelSetOKZSolverAdvanceConcentration:
             self._ctx, dst.ptr, solution.ptr, solution_old.ptr, solution_old_old.ptr,
             vel_solution.ptr, int(use_old_old)))
 
+    # ---- parameters.convection_stabilization (level_set_okz_advance_concentration.cc:248-249,
+    # ---- 344-369, 387-388, 419-472, 569-617)
+    def set_convection_stabilization(self, enabled, symmetry_faces=()):
+        """global_omega_diameter = diameter_on_coarse_grid: the space diagonal of the brick"""
+        m = self.ops.mesh
+        diameter = float(np.sqrt(sum((u - l) ** 2 for u, l in zip(m.upper, m.lower))))
+        mask = sum(1 << f for f in symmetry_faces)
+        _lib.check(self._ctx, self._lib.adaflo_ls_set_convection_stabilization(self._ctx, int(enabled), diameter, mask))
+        self.convection_stabilization = bool(enabled)
+        self.global_omega_diameter = diameter
+
+    def get_maximal_velocity(self, vel_solution):
+        r = C.c_double()
+        _lib.check(self._ctx, self._lib.adaflo_ls_max_velocity(self._ctx, vel_solution.ptr, C.byref(r)))
+        return r.value
+
+    def local_advance_concentration_rhs_stabilized(self, dst, solution, solution_old, solution_old_old, vel_solution,
+                                                   vel_solution_old, vel_solution_old_old, use_old_old, old_step_size,
+                                                   global_max_velocity):
+        """right-hand side with the artificial viscosities of this step (written to the public array)
+        and the boundary part the reference's driver adds afterwards"""
+        _lib.check(self._ctx, self._lib.adaflo_ls_advance_concentration_rhs_stabilized(
+            self._ctx, dst.ptr, solution.ptr, solution_old.ptr, solution_old_old.ptr, vel_solution.ptr,
+            vel_solution_old.ptr, vel_solution_old_old.ptr, int(use_old_old), float(old_step_size),
+            float(global_max_velocity)))
+
+    @property
+    def artificial_viscosities(self):
+        out = np.empty(self.ops.n_cells)
+        _lib.check(self._ctx, self._lib.adaflo_ls_get_artificial_viscosities(self._ctx, out.ctypes.data, 0))
+        return out
+
+    @artificial_viscosities.setter
+    def artificial_viscosities(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.size == self.ops.n_cells
+        _lib.check(self._ctx, self._lib.adaflo_ls_set_artificial_viscosities(self._ctx, a.ctypes.data, 0))
+
     def advance_concentration(self, solution, solution_old, solution_old_old, vel_solution, rhs, increment,
-                              preconditioner, use_old_old=True, tol_nl_iteration=1e-8):
-        """LevelSetOKZSolverAdvanceConcentration::advance_concentration without convection
-        stabilisation (level_set_okz_advance_concentration.cc:549-660): right-hand side, BiCGStab
+                              preconditioner, use_old_old=True, tol_nl_iteration=1e-8, vel_solution_old=None,
+                              vel_solution_old_old=None, old_step_size=None):
+        """LevelSetOKZSolverAdvanceConcentration::advance_concentration
+        (level_set_okz_advance_concentration.cc:549-660): right-hand side, BiCGStab
         with ReductionControl(30, 0.05 tol_nl, 1e-8), solution += increment.  The caller has advanced
-        the level-set TimeStepping and pushed its weights (set_parameters).  Returns
-        (iterations, initial residual) like the reference prints them."""
+        the level-set TimeStepping and pushed its weights (set_parameters).  With
+        set_convection_stabilization(True) the old velocities and the old step size are needed for the
+        artificial viscosities (:344-369).  Returns (iterations, initial residual) like the reference
+        prints them."""
         from .solvers import AdvanceConcentrationMatrix, NoConvergence, ReductionControl, SolverBicgstab
         rhs.fill(0.0)
-        self.local_advance_concentration_rhs(rhs, solution, solution_old, solution_old_old, vel_solution, use_old_old)
+        if getattr(self, "convection_stabilization", False):
+            vmax = self.get_maximal_velocity(vel_solution)          # :548-551
+            self.local_advance_concentration_rhs_stabilized(rhs, solution, solution_old, solution_old_old, vel_solution,
+                                                            vel_solution_old, vel_solution_old_old, use_old_old,
+                                                            old_step_size, vmax)
+        else:
+            self.local_advance_concentration_rhs(rhs, solution, solution_old, solution_old_old, vel_solution,
+                                                 use_old_old)
         control = ReductionControl(30, 0.05 * tol_nl_iteration, 1e-8)
         increment.fill(0.0)
         try:

@@ -36,6 +36,8 @@ class LevelSetOKZSolver:
         # the sub-operators advance their own TimeStepping copies (level_set_okz.cc:94-106)
         self.ts_advect, self.ts_reinit = TimeStepping(p), TimeStepping(p)
         self.advection_operator = lso.LevelSetOKZSolverAdvanceConcentration(self.ops)
+        if p.convection_stabilization:
+            self.advection_operator.set_convection_stabilization(True)
         self.reinit_operator = lso.LevelSetOKZSolverReinitialization(self.ops)
         self.normal_operator = lso.LevelSetOKZSolverComputeNormal(self.ops)
         self.curvature_operator = lso.LevelSetOKZSolverComputeCurvature(self.ops)
@@ -98,9 +100,12 @@ class LevelSetOKZSolver:
         self._push_ls_parameters(ts)
         vel = self.navier_stokes.navier_stokes_matrix.wrap(self.navier_stokes.solution[0])
         use_old_old = ts.scheme == "bdf_2" and ts.step_no() > 1          # advance_concentration.cc:375-378
+        ns, wrap = self.navier_stokes, self.navier_stokes.navier_stokes_matrix.wrap
         it = self.advection_operator.advance_concentration(
             self.solution, self.solution_old, self.solution_old_old, vel, self.system_rhs, self.solution_update,
-            self.preconditioner, use_old_old, self.parameters.tol_nl_iteration)
+            self.preconditioner, use_old_old, self.parameters.tol_nl_iteration,
+            vel_solution_old=wrap(ns.solution_old[0]), vel_solution_old_old=wrap(ns.solution_old_old[0]),
+            old_step_size=ts.old_step_size() if ts.old_step_size() > 0 else ts.step_size())
         self.concentration_iterations.append(it)
 
     def compute_normal(self, fast_computation):

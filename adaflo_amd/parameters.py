@@ -39,6 +39,7 @@ class FlowParameters:
     concentration_subdivisions: int = 2
     interpolate_grad_onto_pressure: bool = False   # "grad pressure compatible"
     curvature_correction: bool = False             # "curvature correction" (parameters.cc:314)
+    convection_stabilization: bool = False         # "convection stabilization" (parameters.cc:360,580)
     # solver section (parameters.cc "Solver": defaults of the reference)
     max_nl_iteration: int = 10
     tol_nl_iteration: float = 1e-6
@@ -112,6 +113,7 @@ _PRM_KEYS = {
     ("Two phase", "epsilon"): ("epsilon", float),
     ("Two phase", "concentration subdivisions"): ("concentration_subdivisions", int),
     ("Two phase", "curvature correction"): ("curvature_correction", lambda v: int(v) > 0),
+    ("Two phase", "convection stabilization"): ("convection_stabilization", lambda v: int(v) > 0),
     ("Two phase", "grad pressure compatible"): ("interpolate_grad_onto_pressure", lambda v: int(v) > 0),
     ("Two phase", "number reinit steps"): ("n_reinit_steps", int),
     ("Two phase", "number initial reinit steps"): ("n_initial_reinit_steps", int),

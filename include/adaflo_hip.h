@@ -295,6 +295,30 @@ int adaflo_ls_advance_concentration_vmult(adaflo_ctx *ctx, double *dst, const do
 int adaflo_ls_advance_concentration_rhs(adaflo_ctx *ctx, double *dst, const double *solution,
                                         const double *solution_old, const double *solution_old_old,
                                         const double *vel_solution, int use_old_old);
+/* `convection stabilization` of the advection operator (parameters.convection_stabilization,
+ * default off).  Once enabled, adaflo_ls_advance_concentration_vmult adds the cell term
+ * (grad w, nu_cell grad v) (level_set_okz_advance_concentration.cc:248-249) and the boundary term
+ * -(w, n . nu_cell grad v) over the boundary faces that are not symmetry faces (:419-472; bit
+ * 2 d + side of symmetry_faces), with the artificial viscosities the last stabilised rhs left
+ * (public array of the reference: set / get below).  global_omega_diameter =
+ * diameter_on_coarse_grid (util.h:70-100; the space diagonal of a box).                       */
+int adaflo_ls_set_convection_stabilization(adaflo_ctx *ctx, int enabled, double global_omega_diameter,
+                                           unsigned symmetry_faces);
+int adaflo_ls_set_artificial_viscosities(adaflo_ctx *ctx, const double *nu_cell, int src_on_device);
+int adaflo_ls_get_artificial_viscosities(adaflo_ctx *ctx, double *nu_cell, int dst_on_device);
+/* get_maximal_velocity (:39-68): largest |u| on the iterated trapezoid points of every cell */
+int adaflo_ls_max_velocity(adaflo_ctx *ctx, const double *vel_solution, double *max_velocity);
+/* local_advance_concentration_rhs with the stabilisation (:344-369 artificial viscosity per cell from
+ * the two old states: 0.03 max|u_old + u_old_old| h min(1, max residual / (global_max_velocity 2
+ * global_omega_diameter)); :387-388 cell term) followed by the boundary part the reference's driver
+ * adds (:569-617).  dst is NOT zeroed.                                                         */
+int adaflo_ls_advance_concentration_rhs_stabilized(adaflo_ctx *ctx, double *dst, const double *solution,
+                                                   const double *solution_old, const double *solution_old_old,
+                                                   const double *vel_solution, const double *vel_solution_old,
+                                                   const double *vel_solution_old_old, int use_old_old,
+                                                   double old_step_size, double global_max_velocity);
+/* dst += sign * boundary part of the stabilisation term of `vec` (building block of the two above) */
+int adaflo_ls_stabilization_boundary_term(adaflo_ctx *ctx, double *dst, const double *vec, double sign);
 /* reinitialization_vmult  level_set_okz_reinitialization.cc:193-231 */
 int adaflo_ls_reinitialization_vmult(adaflo_ctx *ctx, double *dst, const double *src, int diffuse_only);
 /* local_reinitialize_rhs :128-189 (adds into dst; writes evaluated_normal on the first step) */

@@ -917,12 +917,115 @@ int orc_ls_reinit_rhs(const orc_mesh *m, const orc_ls_params *P, int diffuse_onl
   return 0;
 }
 
+/* boundary part of the convection stabilisation, level_set_okz_advance_concentration.cc:419-472
+ * (operator, sign -1, vec = src) and :569-617 (right-hand side, sign +1, vec = solution):
+ *   dst_i += sign * sum over the boundary faces that are not symmetry faces (bit 2 d + side of
+ *            `symmetry`) of (phi_i, n . nu_cell grad vec)_face
+ * with FEFaceValues on the face quadrature of quad_index, QIterated(QGauss<1>(2), s) per tangential
+ * direction; vec is read plainly (get_function_gradients), constrained rows are skipped.  Only the
+ * normal derivative enters (n = -+ e_d), taken from inside the cell. */
+int orc_ls_advect_boundary_term(const orc_mesh *m, const orc_ls_params *P, const double *vec,
+                                const double *art_visc, double sign, unsigned symmetry, double *dst,
+                                const uint8_t *con)
+{
+  const int dim = m->dim, s = P->ls_degree, nd = s + 1, nq = 2 * s;
+  double xq[2 * ORC_MAX1D], wq[2 * ORC_MAX1D], St[4 * ORC_MAX1D * ORC_MAX1D], Dt[4 * ORC_MAX1D * ORC_MAX1D];
+  orc_quadrature_1d(1, s, xq, wq);
+  orc_shape_1d(ORC_FE_Q_ISO_Q1, s, nq, xq, St, Dt);
+  const int ndc = ipow(nd, dim), nqf = ipow(nq, dim - 1);
+  double *l = (double *)malloc(sizeof(double) * ndc), *r = (double *)malloc(sizeof(double) * ndc);
+  const long nc = n_cells(m);
+  for (long c = 0; c < nc; ++c)
+    {
+      long cc[3] = {c % m->ncell[0], dim > 1 ? (c / m->ncell[0]) % m->ncell[1] : 0,
+                    dim > 2 ? c / ((long)m->ncell[0] * m->ncell[1]) : 0};
+      int any = 0;
+      for (int i = 0; i < ndc; ++i) r[i] = 0.;
+      for (int d = 0; d < dim; ++d)
+        for (int side = 0; side < 2; ++side)
+          {
+            if (cc[d] != (side ? m->ncell[d] - 1 : 0) || (symmetry >> (2 * d + side) & 1u)) continue;
+            if (!any) gather(m, s, 1, c, ndc, vec, NULL, l);
+            any = 1;
+            const double xn = side;
+            double Sn[ORC_MAX1D], Dn[ORC_MAX1D];
+            orc_shape_1d(ORC_FE_Q_ISO_Q1, s, 1, &xn, Sn, Dn);
+            double area = 1.;
+            for (int e = 0; e < dim; ++e) if (e != d) area *= m->h[e];
+            for (int q = 0; q < nqf; ++q)
+              {
+                int qt[3] = {0, 0, 0}, rem = q;              /* tangential point indices */
+                for (int e = 0; e < dim; ++e) if (e != d) { qt[e] = rem % nq; rem /= nq; }
+                double jxw = area, dn = 0.;
+                for (int e = 0; e < dim; ++e) if (e != d) jxw *= wq[qt[e]];
+                for (int i = 0; i < ndc; ++i)                 /* normal derivative of vec */
+                  {
+                    int ii[3] = {i % nd, (i / nd) % nd, i / (nd * nd)};
+                    double g = Dn[ii[d]] / m->h[d];
+                    for (int e = 0; e < dim; ++e) if (e != d) g *= St[qt[e] * nd + ii[e]];
+                    dn += g * l[i];
+                  }
+                const double flux = (side ? 1. : -1.) * art_visc[c] * dn * jxw * sign;
+                for (int i = 0; i < ndc; ++i)
+                  {
+                    int ii[3] = {i % nd, (i / nd) % nd, i / (nd * nd)};
+                    double v = Sn[ii[d]];
+                    for (int e = 0; e < dim; ++e) if (e != d) v *= St[qt[e] * nd + ii[e]];
+                    r[i] += v * flux;
+                  }
+              }
+          }
+      if (any) scatter_add(m, s, 1, c, ndc, dst, con, r);
+    }
+  free(l); free(r);
+  return 0;
+}
+
+/* get_maximal_velocity, level_set_okz_advance_concentration.cc:39-68: largest |u| on the points
+ * of QIterated(QTrapezoid<1>(), degree + 1) of every cell */
+double orc_ls_max_velocity(const orc_mesh *m, int ku, const double *vel)
+{
+  const int dim = m->dim, nd = ku + 1, np = ku + 2;
+  double xp[ORC_MAX1D], S[ORC_MAX1D * ORC_MAX1D], D[ORC_MAX1D * ORC_MAX1D];
+  for (int j = 0; j < np; ++j) xp[j] = (double)j / (ku + 1);
+  orc_shape_1d(ORC_FE_Q, ku, np, xp, S, D);
+  const int ndc = ipow(nd, dim), npc = ipow(np, dim);
+  double *lv = (double *)malloc(sizeof(double) * dim * ndc), best = 0.;
+  const long nc = n_cells(m);
+  for (long c = 0; c < nc; ++c)
+    {
+      gather(m, ku, dim, c, ndc, vel, NULL, lv);
+      for (int q = 0; q < npc; ++q)
+        {
+          int qq[3] = {q % np, (q / np) % np, q / (np * np)};
+          double u2 = 0.;
+          for (int k = 0; k < dim; ++k)
+            {
+              double u = 0.;
+              for (int i = 0; i < ndc; ++i)
+                {
+                  int ii[3] = {i % nd, (i / nd) % nd, i / (nd * nd)};
+                  double v = 1.;
+                  for (int e = 0; e < dim; ++e) v *= S[qq[e] * nd + ii[e]];
+                  u += v * lv[k * ndc + i];
+                }
+              u2 += u * u;
+            }
+          if (sqrt(u2) > best) best = sqrt(u2);
+        }
+    }
+  free(lv);
+  return best;
+}
+
 /* advance_concentration_vmult + local_advance_concentration
- * source/level_set_okz_advance_concentration.cc:217-258, :401-480
- * (convection stabilization = 0: no artificial viscosity / face terms).
- * vel_q: evaluated_convection [cell][q][dim].                                 */
+ * source/level_set_okz_advance_concentration.cc:217-258, :401-480.
+ * vel_q: evaluated_convection [cell][q][dim].  art_visc != NULL: parameters.convection_stabilization,
+ * artificial_viscosities [cell]: cell term (grad w, nu grad v) (:248-249) and the boundary term
+ * (:419-472; `symmetry`: faces with a symmetry boundary condition).                          */
 int orc_ls_advect_vmult(const orc_mesh *m, const orc_ls_params *P, const double *src, double *dst,
-                        const uint8_t *con, const double *vel_q, const double *diag)
+                        const uint8_t *con, const double *vel_q, const double *diag,
+                        const double *art_visc, unsigned symmetry)
 {
   const int dim = m->dim, s = P->ls_degree;
   const long nn = orc_n_nodes(m, s);
@@ -943,10 +1046,13 @@ int orc_ls_advect_vmult(const orc_mesh *m, const orc_ls_params *P, const double 
           double ug = 0.;
           for (int e = 0; e < dim; ++e) ug += u[e] * g[e * nq + q];
           v[q] = v[q] * P->weight + ug; /* :244-249 */
+          if (art_visc)
+            for (int e = 0; e < dim; ++e) g[e * nq + q] *= art_visc[c];
         }
-      integrate(&t, m, 1, v, NULL, l);
+      integrate(&t, m, 1, v, art_visc ? g : NULL, l);
       scatter_add(m, s, 1, c, t.ndc, dst, con, l);
     }
+  if (art_visc) orc_ls_advect_boundary_term(m, P, src, art_visc, -1., symmetry, dst, con);
   if (con) for (long i = 0; i < nn; ++i) if (con[i]) dst[i] = diag[i] * src[i]; /* :476-479 */
   free(l); free(v); free(g); table_free(&t);
   return 0;
@@ -1090,13 +1196,19 @@ int orc_ls_curvature_rhs(const orc_mesh *m, const orc_ls_params *P, const double
   return 0;
 }
 
-/* local_advance_concentration_rhs  source/level_set_okz_advance_concentration.cc:288-397
- * (convection stabilization = 0).  dst NOT zeroed.  vel: FE_Q(ku) vector, dof = node*dim+comp;
- * vel_q [cell][q][dim] is WRITTEN (:389).  use_old_old = (bdf_2 && step_no > 1), :375-378.     */
+/* local_advance_concentration_rhs  source/level_set_okz_advance_concentration.cc:288-397.
+ * dst NOT zeroed.  vel: FE_Q(ku) vector, dof = node*dim+comp;
+ * vel_q [cell][q][dim] is WRITTEN (:389).  use_old_old = (bdf_2 && step_no > 1), :375-378.
+ * art_visc != NULL: parameters.convection_stabilization -- artificial_viscosities [cell] is WRITTEN
+ * (:344-369: 0.03 max|u_old + u_old_old| h_cell min(1, max residual / global scaling), global
+ * scaling = global_max_velocity * 2 * global_omega_diameter) and -(grad w, nu grad phi) is added
+ * (:387-388).  The boundary part (:569-617) is orc_ls_advect_boundary_term with sign +1.       */
 int orc_ls_advect_rhs(const orc_mesh *m, const orc_ls_params *P, int ku, int use_old_old,
                       double weight_old, double weight_old_old, const double *solution,
                       const double *solution_old, const double *solution_old_old,
-                      const double *vel, double *dst, const uint8_t *con, double *vel_q)
+                      const double *vel, double *dst, const uint8_t *con, double *vel_q,
+                      const double *vel_old, const double *vel_old_old, double old_step_size,
+                      double global_scaling, double *art_visc)
 {
   const int dim = m->dim, s = P->ls_degree;
   orc_table t, tv;
@@ -1107,15 +1219,40 @@ int orc_ls_advect_rhs(const orc_mesh *m, const orc_ls_params *P, int ku, int use
   double *v = (double *)malloc(sizeof(double) * nq), *g = (double *)malloc(sizeof(double) * 3 * nq);
   double *vo = (double *)malloc(sizeof(double) * nq), *voo = (double *)malloc(sizeof(double) * nq);
   double *uq = (double *)malloc(sizeof(double) * 3 * nq);
+  double *go = (double *)malloc(sizeof(double) * 3 * nq), *goo = (double *)malloc(sizeof(double) * 3 * nq);
+  double *uo = (double *)malloc(sizeof(double) * 3 * nq), *uoo = (double *)malloc(sizeof(double) * 3 * nq);
   const long nc = n_cells(m);
   for (long c = 0; c < nc; ++c)
     {
       gather(m, ku, dim, c, tv.ndc, vel, NULL, lv);
       evaluate(&tv, m, dim, lv, uq, NULL);
       gather(m, s, 1, c, t.ndc, solution_old, NULL, l);
-      evaluate(&t, m, 1, l, vo, NULL);
+      evaluate(&t, m, 1, l, vo, go);
       gather(m, s, 1, c, t.ndc, solution_old_old, NULL, l);
-      evaluate(&t, m, 1, l, voo, NULL);
+      evaluate(&t, m, 1, l, voo, goo);
+      if (art_visc)
+        {
+          gather(m, ku, dim, c, tv.ndc, vel_old, NULL, lv);
+          evaluate(&tv, m, dim, lv, uo, NULL);
+          gather(m, ku, dim, c, tv.ndc, vel_old_old, NULL, lv);
+          evaluate(&tv, m, dim, lv, uoo, NULL);
+          double max_residual = 0., max_velocity = 0.;
+          for (int q = 0; q < nq; ++q)
+            {
+              double ugr = 0., u2 = 0.;
+              for (int e = 0; e < dim; ++e)
+                {
+                  const double u = uo[e * nq + q] + uoo[e * nq + q];
+                  ugr += u * (go[e * nq + q] + goo[e * nq + q]);
+                  u2 += u * u;
+                }
+              const double residual = fabs((vo[q] - voo[q]) / old_step_size + ugr * 0.25);
+              if (residual > max_residual) max_residual = residual;
+              if (sqrt(u2) > max_velocity) max_velocity = sqrt(u2);
+            }
+          const double ratio = max_residual / global_scaling;
+          art_visc[c] = 0.03 * max_velocity * P->cell_diameter * (ratio < 1. ? ratio : 1.);
+        }
       gather(m, s, 1, c, t.ndc, solution, NULL, l);
       evaluate(&t, m, 1, l, v, g);
       for (int q = 0; q < nq; ++q)
@@ -1129,11 +1266,13 @@ int orc_ls_advect_rhs(const orc_mesh *m, const orc_ls_params *P, int ku, int use
               vel_q[((size_t)c * nq + q) * dim + e] = uq[e * nq + q];
             }
           v[q] = -(v[q] * P->weight + ug + old_value);
+          if (art_visc)
+            for (int e = 0; e < dim; ++e) g[e * nq + q] *= -art_visc[c];
         }
-      integrate(&t, m, 1, v, NULL, l);
+      integrate(&t, m, 1, v, art_visc ? g : NULL, l);
       scatter_add(m, s, 1, c, t.ndc, dst, con, l);
     }
-  free(l); free(lv); free(v); free(g); free(vo); free(voo); free(uq);
+  free(l); free(lv); free(v); free(g); free(vo); free(voo); free(uq); free(go); free(goo); free(uo); free(uoo);
   table_free(&t); table_free(&tv);
   return 0;
 }

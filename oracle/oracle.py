@@ -243,11 +243,25 @@ def ls_reinit_rhs(mesh, prm, solution, normal_vec, normal_q, diffuse_only=False,
     return dst
 
 
-def ls_advect_vmult(mesh, prm, src, vel_q, con=None, diag=None):
+def ls_advect_vmult(mesh, prm, src, vel_q, con=None, diag=None, art_visc=None, symmetry=0):
+    """art_visc [cell]: parameters.convection_stabilization (cell + boundary terms)"""
     dst = np.zeros_like(src)
     lib().orc_ls_advect_vmult(C.byref(mesh), C.byref(prm), _p(src), _p(dst), _u8(con), _p(vel_q),
-                              _p(diag))
+                              _p(diag), _p(art_visc), C.c_uint(symmetry))
     return dst
+
+
+def ls_advect_boundary_term(mesh, prm, vec, art_visc, sign, dst, con=None, symmetry=0):
+    dst = dst.copy()
+    lib().orc_ls_advect_boundary_term(C.byref(mesh), C.byref(prm), _p(vec), _p(art_visc), C.c_double(sign),
+                                      C.c_uint(symmetry), _p(dst), _u8(con))
+    return dst
+
+
+def ls_max_velocity(mesh, ku, vel):
+    f = lib().orc_ls_max_velocity
+    f.restype = C.c_double
+    return f(C.byref(mesh), ku, _p(vel))
 
 
 def ls_normal_vmult(mesh, prm, src, con=None, diag=None):
@@ -358,11 +372,14 @@ def fast_ns_vmult(mesh, k, prm, src_u, src_p, con_u=None, con_p=None, lin=None, 
 
 
 def ls_advect_rhs(mesh, prm, ku, solution, solution_old, solution_old_old, vel, vel_q,
-                  weight_old, weight_old_old, use_old_old=True, con=None):
+                  weight_old, weight_old_old, use_old_old=True, con=None, vel_old=None, vel_old_old=None,
+                  old_step_size=1.0, global_scaling=1.0, art_visc=None):
+    """art_visc [cell] (written) switches parameters.convection_stabilization on"""
     dst = np.zeros_like(solution)
     lib().orc_ls_advect_rhs(C.byref(mesh), C.byref(prm), ku, int(use_old_old), C.c_double(weight_old),
                             C.c_double(weight_old_old), _p(solution), _p(solution_old),
-                            _p(solution_old_old), _p(vel), _p(dst), _u8(con), _p(vel_q))
+                            _p(solution_old_old), _p(vel), _p(dst), _u8(con), _p(vel_q), _p(vel_old),
+                            _p(vel_old_old), C.c_double(old_step_size), C.c_double(global_scaling), _p(art_visc))
     return dst
 
 

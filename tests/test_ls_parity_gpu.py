@@ -194,3 +194,53 @@ def test_projection_matrix_and_curvature_correction(s, ncell, faces):
     sel = kappa > 1e-4
     expect[sel] = 1.0 / (1.0 / kappa[sel] + dist[sel] / 2.0)
     assert np.abs(kv.numpy() - expect).max() < 1e-13 * max(1.0, np.abs(expect).max())
+
+
+@pytest.mark.parametrize("s,k,ncell,faces,symmetry", [(2, 2, (3, 3, 4), (), ()), (4, 2, (2, 3, 2), (0, 5), (2,)),
+                                                      (1, 3, (4, 3, 5), (), (0, 1)), (3, 2, (2, 2, 3), (3,), ())])
+def test_advection_with_convection_stabilization(s, k, ncell, faces, symmetry):
+    """parameters.convection_stabilization (level_set_okz_advance_concentration.cc): maximal velocity (:39-68),
+    artificial viscosity per cell (:344-369), cell terms of the right-hand side (:387-388) and of the operator
+    (:248-249), boundary terms (:569-617, :419-472) with symmetry faces left out -- against the oracle"""
+    c = LSCase(ncell, s, k=k, faces=faces)
+    adv = lso.LevelSetOKZSolverAdvanceConcentration(c.ops)
+    adv.set_convection_stabilization(True, symmetry_faces=symmetry)
+    sym = sum(1 << f for f in symmetry)
+    nv = c.mesh.n_nodes(k) * 3
+    vel, vel_o, vel_oo = (c.rng.uniform(-1, 1, nv) for _ in range(3))
+    sol, old, oo = c.rand(), c.rand(), c.rand()
+    vmax = adv.get_maximal_velocity(c.ops.velocity_vector(vel))
+    assert abs(vmax - orc.ls_max_velocity(c.mesh, k, vel)) < 1e-13 * vmax
+    old_step = 0.017
+    scaling = vmax * 2.0 * adv.global_omega_diameter
+    assert abs(adv.global_omega_diameter - np.sqrt(1 + 1 + 4)) < 1e-14
+    for use_oo in (True, False):
+        uq, nu_ref = np.zeros(c.mesh.n_cells * c.nq * 3), np.zeros(c.mesh.n_cells)
+        ref = orc.ls_advect_rhs(c.mesh, c.prm, k, sol, old, oo, vel, uq, c.w_old, c.w_oo, use_oo, con=c.con,
+                                vel_old=vel_o, vel_old_old=vel_oo, old_step_size=old_step, global_scaling=scaling,
+                                art_visc=nu_ref)
+        ref = orc.ls_advect_boundary_term(c.mesh, c.prm, sol, nu_ref, 1.0, ref, con=c.con, symmetry=sym)
+        d = c.ops.vector()
+        adv.local_advance_concentration_rhs_stabilized(d, c.ops.vector(sol), c.ops.vector(old), c.ops.vector(oo),
+                                                       c.ops.velocity_vector(vel), c.ops.velocity_vector(vel_o),
+                                                       c.ops.velocity_vector(vel_oo), use_oo, old_step, vmax)
+        assert rel_l2(adv.artificial_viscosities, nu_ref) < TOL and nu_ref.min() > 0
+        assert rel_l2(d.numpy(), ref) < TOL
+        assert rel_l2(adv.evaluated_convection, uq) < 1e-14
+    # operator with these viscosities, on both kernel variants (the stabilised operator is a generic kernel)
+    src = c.rand()
+    ref = orc.ls_advect_vmult(c.mesh, c.prm, src, uq, con=c.con, diag=c.diag, art_visc=nu_ref, symmetry=sym)
+    for variant in (1, 0):
+        c.ops.set_kernel_variant(variant)
+        d = c.ops.vector(np.full(c.nn, 7.0))
+        adv.advance_concentration_vmult(d, c.ops.vector(src))
+        assert rel_l2(d.numpy(), ref) < TOL, variant
+    # a viscosity array set from outside, stabilisation switched off again
+    nu2 = c.rng.uniform(0.1, 1.0, c.mesh.n_cells)
+    adv.artificial_viscosities = nu2
+    adv.advance_concentration_vmult(d, c.ops.vector(src))
+    assert rel_l2(d.numpy(), orc.ls_advect_vmult(c.mesh, c.prm, src, uq, con=c.con, diag=c.diag, art_visc=nu2,
+                                                 symmetry=sym)) < TOL
+    adv.set_convection_stabilization(False)
+    adv.advance_concentration_vmult(d, c.ops.vector(src))
+    assert rel_l2(d.numpy(), orc.ls_advect_vmult(c.mesh, c.prm, src, uq, con=c.con, diag=c.diag)) < TOL

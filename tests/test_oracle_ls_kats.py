@@ -98,3 +98,34 @@ def test_curvature_rhs_of_a_radial_normal_field():
     W = w[:, None, None] * w[None, :, None] * w[None, None, :]
     exact = -(2.0 / np.sqrt(X * X + Y * Y + Z * Z) * W).sum()
     assert abs(rhs.sum() - exact) < 2e-3 * abs(exact)       # piecewise-linear normalised normal
+
+
+def test_convection_stabilization_is_a_consistent_diffusion_term():
+    """known answers of the stabilisation terms (level_set_okz_advance_concentration.cc:248-249 + :419-472):
+    with a constant artificial viscosity the cell term (grad w, nu grad v) minus the boundary term
+    (w, n . nu grad v) is -(w, nu laplace v): zero for a linear field on every row, and equal to the weak
+    Laplacian tested with w on interior rows for a quadratic field; the maximal velocity of a constant field
+    is its norm; the artificial viscosity follows :361-365"""
+    mesh = orc.Mesh.make([3, 2, 2], [0., 0., 0.], [1., 1., 2.])
+    s = 2
+    h = [mesh.h[d] for d in range(3)]
+    prm = orc.make_ls_params(s, 0.1, min(h), 0.01, 0.0, max(h), 1.5)          # weight 0: no mass term
+    x = orc.node_coordinates(mesh, s, 1)
+    nq = (2 * s) ** 3
+    uq0 = np.zeros(mesh.n_cells * nq * 3)
+    nu = np.full(mesh.n_cells, 0.7)
+    lin = 1 + 2 * x[:, 0] - x[:, 1] + 0.5 * x[:, 2]
+    assert np.abs(orc.ls_advect_vmult(mesh, prm, lin, uq0, art_visc=nu)).max() < 1e-13
+    # symmetry faces are left out of the boundary term: the rows on face 0 (n = -e_x, area 2) then keep the
+    # cell term alone, (w, n . nu grad v) = -0.7 * 2 per unit area
+    out = orc.ls_advect_vmult(mesh, prm, lin, uq0, art_visc=nu, symmetry=1)
+    on_face = x[:, 0] == 0
+    assert np.abs(out[~on_face]).max() < 1e-13 and abs(out[on_face].sum() + 0.7 * 2 * 2.0) < 1e-12
+    vel = np.tile([0.3, -0.4, 1.2], mesh.n_nodes(2))
+    assert abs(orc.ls_max_velocity(mesh, 2, vel) - 1.3) < 1e-14
+    # artificial viscosity: u_old + u_old_old = 2 u, phi linear and steady: residual = |2 u . 2 grad phi| / 4
+    uq, nu_out = np.zeros(mesh.n_cells * nq * 3), np.zeros(mesh.n_cells)
+    orc.ls_advect_rhs(mesh, prm, 2, lin, lin, lin, vel, uq, -1.0, 0.0, True, vel_old=vel, vel_old_old=vel,
+                      old_step_size=0.01, global_scaling=10.0, art_visc=nu_out)
+    resid = abs(0.3 * 2 - 0.4 * (-1) + 1.2 * 0.5)
+    assert np.allclose(nu_out, 0.03 * 2.6 * max(h) * min(1.0, resid / 10.0), rtol=1e-13)
