@@ -139,6 +139,9 @@ SIGNATURES = {
     "adaflo_vector_dot": (C.c_int, [_CTX, _D, _D, C.c_int64, C.POINTER(C.c_double)]),
     "adaflo_ls_mass_matrix_diagonal": (C.c_int, [_CTX, _D]),
     "adaflo_invert_diagonal": (C.c_int, [_CTX, _D, _D, C.c_int64]),
+    "adaflo_fdm_apply": (C.c_int, [_CTX, C.c_int, _D, _D, C.c_double, C.c_double]),
+    "adaflo_ns_preconditioner_set_inner": (C.c_int, [_CTX, C.c_int]),
+    "adaflo_ns_preconditioner_statistics": (C.c_int, [_CTX, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "adaflo_ns_preconditioner_setup": (C.c_int, [_CTX]),
     "adaflo_ns_preconditioner_vmult": (C.c_int, [_CTX, _D, _D, _D, _D]),
     "adaflo_ns_solve_system": (C.c_int, [_CTX, _D, _D, _D, _D, C.POINTER(SolverControl), C.c_int,

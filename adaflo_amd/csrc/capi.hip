@@ -323,6 +323,7 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
                     ctx->d_tab_ls, ctx->d_ls_diag, ctx->d_tab_force, ctx->d_tab_maxvel})
     if (p)
       (void)hipFree(p);
+  fdm_destroy(ctx);
   if (ctx->q2_wg_list)
     (void)hipFree(ctx->q2_wg_list);
   if (ctx->h_result)
@@ -898,6 +899,24 @@ int adaflo_set_timing(adaflo_ctx *ctx, int enabled)
 {
   CHECK_CTX(ctx);
   ctx->timing = enabled != 0;
+  return 0;
+}
+
+int adaflo_fdm_apply(adaflo_ctx *ctx, int field, double *dst, const double *src, double c_mass, double c_lap)
+{
+  CHECK_CTX(ctx);
+  if (!dst || !src || field < 0 || field > 1)
+    return fail(ctx, ADAFLO_EINVAL, "invalid arguments");
+  TRY(ctx, fdm_apply(ctx, field, dst, src, c_mass, c_lap), "fast-diagonalisation solve failed");
+  return 0;
+}
+
+int adaflo_ns_preconditioner_set_inner(adaflo_ctx *ctx, int mode)
+{
+  CHECK_CTX(ctx);
+  if (mode < 0 || mode > 1)
+    return fail(ctx, ADAFLO_EINVAL, "unknown inner-solve mode");
+  ctx->pc_inner = mode;
   return 0;
 }
 

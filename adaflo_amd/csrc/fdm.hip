@@ -1,0 +1,438 @@
+// fdm.hip -- fast-diagonalisation inverses for the inner solves of the block preconditioner.
+//
+// The reference preconditions the inner solves of NavierStokesPreconditioner::vmult
+// (source/navier_stokes_preconditioner.cc:595-737) with ILU / AMG of ASSEMBLED matrices
+// (Trilinos); SURVEY 8f rank 3 asks for matrix-free replacements.  On a structured brick with
+// constant coefficients the operators behind those matrices are sums of Kronecker products of 1D
+// finite element matrices,
+//     c_m  Mx (x) My (x) Mz  +  c_l (Kx (x) My (x) Mz + Mx (x) Ky (x) Mz + Mx (x) My (x) Kz),
+// (pressure mass: c_l = 0; pressure Poisson: c_m = 0; velocity block: its mass + vector-Laplace
+// part), and are inverted EXACTLY by the fast diagonalisation method (Lynch, Rice, Thomas 1964):
+// with the generalised eigenpairs  K_d S_d = M_d S_d Lambda_d,  S_d^T M_d S_d = I  of the three 1D
+// problems (Dirichlet nodes eliminated),
+//     A^{-1} = (Sx (x) Sy (x) Sz)  diag(c_m + c_l (lx + ly + lz))^{-1}  (Sx (x) Sy (x) Sz)^T.
+// One application = six dense 1D transforms: GEMMs of n x n matrices against the n^2 lines of the
+// brick -- 12 n^4 flops per scalar field, the kind of dense FP64 work the chip is good at (tiled
+// LDS kernel below; rocBLAS is deliberately not linked).  Singular cases (pure Neumann Poisson
+// problem) use the pseudo-inverse: the null mode is dropped.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace adaflo_hip
+{
+  namespace
+  {
+    // ---- host: 1D finite element matrices and their generalised eigen-decomposition ----------
+    struct Eig1D
+    {
+      int     n      = 0;
+      double *d_St   = nullptr; // [mode][node]  (forward transform: modes = St . nodes)
+      double *d_S    = nullptr; // [node][mode]  (backward transform)
+      double *d_lam  = nullptr; // eigenvalue per mode; < 0 marks a padding mode (constrained node)
+    };
+
+    // M, K of FE_Q(degree) on ncell cells of size h, quadrature QGauss(nq); dense n x n, row-major
+    void assemble_1d(const int degree, const int ncell, const double h, const int nq, std::vector<double> &M,
+                     std::vector<double> &K)
+    {
+      const Quadrature1D q  = gauss(nq);
+      const Shape1D      sh = shape_fe_q(degree, q);
+      const int          nd = degree + 1, n = degree * ncell + 1;
+      M.assign((size_t)n * n, 0.);
+      K.assign((size_t)n * n, 0.);
+      for (int c = 0; c < ncell; ++c)
+        for (int i = 0; i < nd; ++i)
+          for (int j = 0; j < nd; ++j)
+            {
+              double m = 0., k = 0.;
+              for (int p = 0; p < nq; ++p)
+                {
+                  m += q.w[p] * sh.S[p * nd + i] * sh.S[p * nd + j];
+                  k += q.w[p] * sh.D[p * nd + i] * sh.D[p * nd + j];
+                }
+              M[(size_t)(c * degree + i) * n + c * degree + j] += h * m;
+              K[(size_t)(c * degree + i) * n + c * degree + j] += k / h;
+            }
+    }
+
+    // symmetric eigenproblem by cyclic Jacobi rotations: A (n x n, destroyed) = Q diag(w) Q^T
+    void jacobi_eig(const int n, std::vector<double> &A, std::vector<double> &Q, std::vector<double> &w)
+    {
+      Q.assign((size_t)n * n, 0.);
+      for (int i = 0; i < n; ++i)
+        Q[(size_t)i * n + i] = 1.;
+      double norm = 0.;
+      for (double v : A)
+        norm += v * v;
+      norm = std::sqrt(norm);
+      for (int sweep = 0; sweep < 60; ++sweep)
+        {
+          double off = 0.;
+          for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q)
+              off += A[(size_t)p * n + q] * A[(size_t)p * n + q];
+          if (std::sqrt(2. * off) <= 1e-15 * norm)
+            break;
+          for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q)
+              {
+                const double apq = A[(size_t)p * n + q];
+                if (std::abs(apq) <= 1e-300)
+                  continue;
+                const double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
+                const double theta = (aqq - app) / (2. * apq);
+                const double t     = (theta >= 0. ? 1. : -1.) / (std::abs(theta) + std::sqrt(theta * theta + 1.));
+                const double c = 1. / std::sqrt(t * t + 1.), s = t * c;
+                for (int k = 0; k < n; ++k) // columns p, q
+                  {
+                    const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+                    A[(size_t)k * n + p] = c * akp - s * akq;
+                    A[(size_t)k * n + q] = s * akp + c * akq;
+                  }
+                for (int k = 0; k < n; ++k) // rows p, q
+                  {
+                    const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+                    A[(size_t)p * n + k] = c * apk - s * aqk;
+                    A[(size_t)q * n + k] = s * apk + c * aqk;
+                  }
+                for (int k = 0; k < n; ++k)
+                  {
+                    const double qkp = Q[(size_t)k * n + p], qkq = Q[(size_t)k * n + q];
+                    Q[(size_t)k * n + p] = c * qkp - s * qkq;
+                    Q[(size_t)k * n + q] = s * qkp + c * qkq;
+                  }
+              }
+        }
+      w.resize(n);
+      for (int i = 0; i < n; ++i)
+        w[i] = A[(size_t)i * n + i];
+    }
+
+    // K v = lambda M v on the free nodes; S (n x n, [node][mode]) with S^T M S = I on the free
+    // block, zero rows at constrained nodes, padding modes (lambda = -1) beyond the free count
+    void generalized_eig(const int n, const std::vector<double> &K, const std::vector<double> &M,
+                         const std::vector<char> &constrained, std::vector<double> &S, std::vector<double> &lam)
+    {
+      std::vector<int> fr;
+      for (int i = 0; i < n; ++i)
+        if (!constrained[i])
+          fr.push_back(i);
+      const int m = (int)fr.size();
+      // Cholesky M_ff = L L^T
+      std::vector<double> L((size_t)m * m, 0.);
+      for (int i = 0; i < m; ++i)
+        for (int j = 0; j <= i; ++j)
+          {
+            double s = M[(size_t)fr[i] * n + fr[j]];
+            for (int k = 0; k < j; ++k)
+              s -= L[(size_t)i * m + k] * L[(size_t)j * m + k];
+            L[(size_t)i * m + j] = i == j ? std::sqrt(s) : s / L[(size_t)j * m + j];
+          }
+      // C = L^-1 K_ff L^-T
+      std::vector<double> B((size_t)m * m), C((size_t)m * m);
+      for (int col = 0; col < m; ++col) // B = L^-1 K_ff
+        for (int i = 0; i < m; ++i)
+          {
+            double s = K[(size_t)fr[i] * n + fr[col]];
+            for (int k = 0; k < i; ++k)
+              s -= L[(size_t)i * m + k] * B[(size_t)k * m + col];
+            B[(size_t)i * m + col] = s / L[(size_t)i * m + i];
+          }
+      for (int row = 0; row < m; ++row) // C = B L^-T:  C[row][:] solves L C[row][:]^T = B[row][:]^T
+        for (int i = 0; i < m; ++i)
+          {
+            double s = B[(size_t)row * m + i];
+            for (int k = 0; k < i; ++k)
+              s -= L[(size_t)i * m + k] * C[(size_t)row * m + k];
+            C[(size_t)row * m + i] = s / L[(size_t)i * m + i];
+          }
+      for (int i = 0; i < m; ++i) // symmetrise the round-off
+        for (int j = i + 1; j < m; ++j)
+          C[(size_t)i * m + j] = C[(size_t)j * m + i] = 0.5 * (C[(size_t)i * m + j] + C[(size_t)j * m + i]);
+      std::vector<double> Q, w;
+      jacobi_eig(m, C, Q, w);
+      // S_ff = L^-T Q
+      S.assign((size_t)n * n, 0.);
+      lam.assign(n, -1.);
+      for (int col = 0; col < m; ++col)
+        {
+          std::vector<double> x(m);
+          for (int i = m - 1; i >= 0; --i)
+            {
+              double s = Q[(size_t)i * m + col];
+              for (int k = i + 1; k < m; ++k)
+                s -= L[(size_t)k * m + i] * x[k];
+              x[i] = s / L[(size_t)i * m + i];
+            }
+          for (int i = 0; i < m; ++i)
+            S[(size_t)fr[i] * n + col] = x[i];
+          lam[col] = std::max(w[col], 0.);
+        }
+    }
+
+    // ---- device: strided batched f64 GEMM  C[b] = A[b?] . B[b] --------------------------------
+    // C[i][j] = sum_k A[i * rsA + k * csA] * B[k * rsB + j * csB]; 64 x 64 tiles, K-steps of 8,
+    // 256 threads with 4 x 4 outputs each.  A is the small 1D matrix (shared by all batches) or the
+    // field (x transform), B the other one.
+    constexpr int GT = 64, GK = 8;
+    struct GemmArgs
+    {
+      int           M, N, K;
+      long          rsA, csA, bsA, rsB, csB, bsB, rsC, csC, bsC;
+      const double *A, *B;
+      double       *C;
+    };
+    __global__ __launch_bounds__(256) void fdm_gemm_kernel(const GemmArgs g)
+    {
+      __shared__ double As[GK][GT + 1], Bs[GK][GT + 1];
+      const int     tid = threadIdx.x, tx = tid % 16, ty = tid / 16;
+      const int     i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
+      const double *A = g.A + (long)blockIdx.z * g.bsA, *B = g.B + (long)blockIdx.z * g.bsB;
+      double       *C = g.C + (long)blockIdx.z * g.bsC;
+      double        acc[4][4] = {};
+      // loader mapping: the faster-varying global index gets consecutive threads
+      const bool a_k_fast = g.csA == 1, b_j_fast = g.csB == 1;
+      for (int k0 = 0; k0 < g.K; k0 += GK)
+        {
+          for (int e = tid; e < GT * GK; e += 256)
+            {
+              const int ii = a_k_fast ? e / GK : e % GT, kk = a_k_fast ? e % GK : e / GT;
+              const int i = i0 + ii, k = k0 + kk;
+              As[kk][ii]  = (i < g.M && k < g.K) ? A[i * g.rsA + k * g.csA] : 0.;
+            }
+          for (int e = tid; e < GT * GK; e += 256)
+            {
+              const int jj = b_j_fast ? e % GT : e / GK, kk = b_j_fast ? e / GT : e % GK;
+              const int j = j0 + jj, k = k0 + kk;
+              Bs[kk][jj]  = (j < g.N && k < g.K) ? B[k * g.rsB + j * g.csB] : 0.;
+            }
+          __syncthreads();
+#pragma unroll
+          for (int kk = 0; kk < GK; ++kk)
+            {
+              double a[4], b[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                {
+                  a[r] = As[kk][ty + 16 * r];
+                  b[r] = Bs[kk][tx + 16 * r];
+                }
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                  acc[r][s] += a[r] * b[s];
+            }
+          __syncthreads();
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          {
+            const int i = i0 + ty + 16 * r, j = j0 + tx + 16 * s;
+            if (i < g.M && j < g.N)
+              C[i * g.rsC + j * g.csC] = acc[r][s];
+          }
+    }
+
+    int gemm(adaflo_ctx *ctx, const GemmArgs &g, const int batch)
+    {
+      const dim3 grid((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, batch);
+      hipLaunchKernelGGL(fdm_gemm_kernel, grid, dim3(256), 0, ctx->stream, g);
+      return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+    }
+
+    // w[z][y][x] *= 1 / (c_m + c_l (lx + ly + lz)); padding modes and the null mode give 0
+    __global__ __launch_bounds__(256) void fdm_scale_kernel(double *__restrict__ w, const double *__restrict__ lx,
+                                                            const double *__restrict__ ly, const double *__restrict__ lz,
+                                                            const int nx, const int ny, const long n, const double cm,
+                                                            const double cl, const double eps)
+    {
+      for (long t = blockIdx.x * 256L + threadIdx.x; t < n; t += (long)gridDim.x * 256)
+        {
+          const int    x = t % nx, y = (t / nx) % ny, z = t / ((long)nx * ny);
+          const double a = lx[x], b = ly[y], c = lz[z];
+          const double d = cm + cl * (a + b + c);
+          w[t]           = (a < 0. || b < 0. || c < 0. || std::abs(d) <= eps) ? 0. : w[t] / d;
+        }
+    }
+
+    // scalar field <- component c of an interleaved vector, and back (constrained rows: dst = src)
+    __global__ __launch_bounds__(256) void fdm_take_kernel(double *__restrict__ w, const double *__restrict__ v,
+                                                           const long n, const int ncomp, const int comp)
+    {
+      for (long t = blockIdx.x * 256L + threadIdx.x; t < n; t += (long)gridDim.x * 256)
+        w[t] = v[t * ncomp + comp];
+    }
+    __global__ __launch_bounds__(256) void fdm_put_kernel(double *__restrict__ dst, const double *__restrict__ w,
+                                                          const double *__restrict__ src, const long n, const int ncomp,
+                                                          const int comp, const int nx, const int ny, const int nz,
+                                                          const uint32_t mask, const int stride)
+    {
+      for (long t = blockIdx.x * 256L + threadIdx.x; t < n; t += (long)gridDim.x * 256)
+        {
+          const int  I = t % nx, J = (t / nx) % ny, K = t / ((long)nx * ny);
+          const bool con = mask != 0u && on_constrained_face(I, J, K, nx, ny, nz, mask, stride, comp);
+          dst[t * ncomp + comp] = con ? src[t * ncomp + comp] : w[t];
+        }
+    }
+
+    struct FieldFdm
+    {
+      int   degree = 0, ncomp = 0, nn[3] = {0, 0, 0};
+      Eig1D e[3][3]; // [component][direction]
+    };
+    struct Fdm
+    {
+      FieldFdm                        field[2];
+      std::map<std::vector<long>, Eig1D> cache;
+      double                         *w0 = nullptr, *w1 = nullptr;
+      size_t                          wcount = 0;
+    };
+
+    int upload_eig(Eig1D &E, const int n, const std::vector<double> &S, const std::vector<double> &lam)
+    {
+      std::vector<double> St((size_t)n * n);
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+          St[(size_t)j * n + i] = S[(size_t)i * n + j];
+      E.n = n;
+      if (hipMalloc(&E.d_S, sizeof(double) * n * n) != hipSuccess || hipMalloc(&E.d_St, sizeof(double) * n * n) != hipSuccess ||
+          hipMalloc(&E.d_lam, sizeof(double) * n) != hipSuccess)
+        return ADAFLO_ENOMEM;
+      if (hipMemcpy(E.d_S, S.data(), sizeof(double) * n * n, hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(E.d_St, St.data(), sizeof(double) * n * n, hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(E.d_lam, lam.data(), sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess)
+        return ADAFLO_EHIP;
+      return 0;
+    }
+  } // namespace
+
+  void fdm_destroy(adaflo_ctx *ctx)
+  {
+    Fdm *F = static_cast<Fdm *>(ctx->fdm);
+    if (!F)
+      return;
+    for (auto &kv : F->cache)
+      for (double *p : {kv.second.d_S, kv.second.d_St, kv.second.d_lam})
+        if (p)
+          (void)hipFree(p);
+    for (double *p : {F->w0, F->w1})
+      if (p)
+        (void)hipFree(p);
+    delete F;
+    ctx->fdm = nullptr;
+  }
+
+  // field 0: velocity space FE_Q(k)^3 with quad_index_u, field 1: pressure space FE_Q(k-1) with
+  // quad_index_p; Dirichlet nodes as in the brick's constraint masks
+  int fdm_setup(adaflo_ctx *ctx)
+  {
+    if (ctx->fdm)
+      return 0;
+    Fdm *F   = new Fdm;
+    ctx->fdm = F;
+    for (int f = 0; f < 2; ++f)
+      {
+        FieldFdm &fd = F->field[f];
+        fd.degree    = f == 0 ? ctx->k : ctx->k - 1;
+        fd.ncomp     = f == 0 ? 3 : 1;
+        const int      nq   = f == 0 ? ctx->k + 1 : ctx->k;
+        const uint32_t mask = f == 0 ? ctx->brick.con_u : ctx->brick.con_p;
+        for (int d = 0; d < 3; ++d)
+          fd.nn[d] = fd.degree * ctx->desc.ncell[d] + 1;
+        for (int c = 0; c < fd.ncomp; ++c)
+          for (int d = 0; d < 3; ++d)
+            {
+              const int  stride = fd.ncomp == 1 ? 1 : 3;
+              const bool lo = mask >> (stride * (2 * d) + c) & 1u, hi = mask >> (stride * (2 * d + 1) + c) & 1u;
+              const std::vector<long> key = {fd.degree, ctx->desc.ncell[d], (long)std::llround(ctx->desc.h[d] * 1e15), nq, lo, hi};
+              auto it = F->cache.find(key);
+              if (it == F->cache.end())
+                {
+                  const int           n = fd.nn[d];
+                  std::vector<double> M, K, S, lam;
+                  assemble_1d(fd.degree, ctx->desc.ncell[d], ctx->desc.h[d], nq, M, K);
+                  std::vector<char> con(n, 0);
+                  con[0]     = lo;
+                  con[n - 1] = hi;
+                  generalized_eig(n, K, M, con, S, lam);
+                  Eig1D E;
+                  if (int e = upload_eig(E, n, S, lam))
+                    return e;
+                  it = F->cache.emplace(key, E).first;
+                }
+              fd.e[c][d] = it->second;
+            }
+      }
+    const size_t need = (size_t)std::max(ctx->n_nodes_u, ctx->n_nodes_p);
+    if (hipMalloc(&F->w0, need * sizeof(double)) != hipSuccess || hipMalloc(&F->w1, need * sizeof(double)) != hipSuccess)
+      return ADAFLO_ENOMEM;
+    F->wcount = need;
+    return 0;
+  }
+
+  // dst = (c_mass M + c_lap K)^-1 src on the free rows (pseudo-inverse if singular), dst = src on
+  // the constrained rows; dst == src allowed
+  int fdm_apply(adaflo_ctx *ctx, const int field, double *dst, const double *src, const double c_mass, const double c_lap)
+  {
+    if (int e = fdm_setup(ctx))
+      return e;
+    Fdm            *F  = static_cast<Fdm *>(ctx->fdm);
+    const FieldFdm &fd = F->field[field];
+    const int       nx = fd.nn[0], ny = fd.nn[1], nz = fd.nn[2];
+    const long      n = (long)nx * ny * nz;
+    const uint32_t  mask = field == 0 ? ctx->brick.con_u : ctx->brick.con_p;
+    const unsigned  nb = (unsigned)std::min<long>((n + 255) / 256, 16384);
+    for (int c = 0; c < fd.ncomp; ++c)
+      {
+        double *w0 = F->w0, *w1 = F->w1;
+        hipLaunchKernelGGL(fdm_take_kernel, dim3(nb), dim3(256), 0, ctx->stream, w0, src, n, fd.ncomp, c);
+        const Eig1D &ex = fd.e[c][0], &ey = fd.e[c][1], &ez = fd.e[c][2];
+        for (int dir = 0; dir < 2; ++dir) // 0: nodes -> modes (S^T), 1: modes -> nodes (S)
+          {
+            // x: C[r][i] = sum_k W[r][k] T[i][k],  T = St (forward) or S (backward), both [i][k] row-major
+            GemmArgs g{};
+            g.M = ny * nz, g.N = nx, g.K = nx;
+            g.A = w0, g.rsA = nx, g.csA = 1;
+            g.B = dir == 0 ? ex.d_St : ex.d_S, g.rsB = 1, g.csB = nx;
+            g.C = w1, g.rsC = nx, g.csC = 1;
+            if (int e = gemm(ctx, g, 1))
+              return e;
+            // y: per z-plane C[i][j] = sum_k T[i][k] W[k][j]
+            g   = GemmArgs{};
+            g.M = ny, g.N = nx, g.K = ny;
+            g.A = dir == 0 ? ey.d_St : ey.d_S, g.rsA = ny, g.csA = 1, g.bsA = 0;
+            g.B = w1, g.rsB = nx, g.csB = 1, g.bsB = (long)nx * ny;
+            g.C = w0, g.rsC = nx, g.csC = 1, g.bsC = (long)nx * ny;
+            if (int e = gemm(ctx, g, nz))
+              return e;
+            // z: C[i][j] = sum_k T[i][k] W[k][j], j over the plane
+            g   = GemmArgs{};
+            g.M = nz, g.N = nx * ny, g.K = nz;
+            g.A = dir == 0 ? ez.d_St : ez.d_S, g.rsA = nz, g.csA = 1;
+            g.B = w0, g.rsB = (long)nx * ny, g.csB = 1;
+            g.C = w1, g.rsC = (long)nx * ny, g.csC = 1;
+            if (int e = gemm(ctx, g, 1))
+              return e;
+            if (dir == 0)
+              {
+                // the null mode of a singular operator: |c_m + c_l sum(lambda)| relative to c_l lambda_max
+                const double eps = 1e-10 * (std::abs(c_mass) + std::abs(c_lap) * 12. / (ctx->desc.h[0] * ctx->desc.h[0]));
+                hipLaunchKernelGGL(fdm_scale_kernel, dim3(nb), dim3(256), 0, ctx->stream, w1, ex.d_lam, ey.d_lam, ez.d_lam,
+                                   nx, ny, n, c_mass, c_lap, eps);
+              }
+            std::swap(w0, w1); // the result of this direction is the input of the next
+          }
+        hipLaunchKernelGGL(fdm_put_kernel, dim3(nb), dim3(256), 0, ctx->stream, dst, w0, src, n, fd.ncomp, c, nx, ny, nz,
+                           mask, fd.ncomp == 1 ? 1 : 3);
+      }
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+} // namespace adaflo_hip

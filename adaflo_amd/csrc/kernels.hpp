@@ -148,6 +148,12 @@ namespace adaflo_hip
                       double density, double density_diff, double viscosity, double viscosity_diff,
                       int on_pressure);
 
+  // fast-diagonalisation inverse of c_mass M + c_lap K on the velocity (field 0) / pressure (field 1)
+  // space of the brick (fdm.hip); dst = src on constrained rows
+  int  fdm_setup(adaflo_ctx *ctx);
+  int  fdm_apply(adaflo_ctx *ctx, int field, double *dst, const double *src, double c_mass, double c_lap);
+  void fdm_destroy(adaflo_ctx *ctx);
+
   // Q_k/Q_{k-1} sweep kernel for k = 3, 4, 5 (ns_ho.hip), constant coefficients
   bool ho_supported(const adaflo_ctx *ctx);
   int  launch_ns_vmult_ho(adaflo_ctx *ctx, int op, double *dst_u, double *dst_p, const double *src_u,

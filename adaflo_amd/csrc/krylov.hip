@@ -841,6 +841,18 @@ int adaflo_ns_preconditioner_setup(adaflo_ctx *ctx)
   for (DeviceBuffer *b : {&ctx->pc_inv_pm, &ctx->pc_inv_pl, &ctx->pc_ones_p, &ctx->pc_tmp_p, &ctx->pc_tmp_p2})
     if (int rc = pc_alloc(ctx, *b, np))
       return rc;
+  if (ctx->pc_inner == 1 && !ctx->rho.p && !ctx->mu.p)
+    {
+      // fast diagonalisation of the constant-coefficient parts: no operator diagonals needed
+      if (int rc = fdm_setup(ctx))
+        return kfail(ctx, rc, "fast-diagonalisation setup failed");
+      if (launch_fill(ctx, ctx->pc_ones_p.p, 1., np))
+        return kfail(ctx, ADAFLO_EHIP, "fill failed");
+      if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return kfail(ctx, ADAFLO_EHIP, "preconditioner setup failed");
+      ctx->pc_ready = true;
+      return 0;
+    }
   double *probe_work = persistent(ctx->kr_work, (size_t)nu);
   if (!probe_work)
     return kfail(ctx, ADAFLO_ENOMEM, "out of device memory");
@@ -871,6 +883,18 @@ int adaflo_ns_preconditioner_setup(adaflo_ctx *ctx)
   return 0;
 }
 
+int adaflo_ns_preconditioner_statistics(adaflo_ctx *ctx, int64_t *velocity_solves, int64_t *velocity_iterations)
+{
+  if (!ctx)
+    return ADAFLO_ENOTINIT;
+  if (velocity_solves)
+    *velocity_solves = ctx->pc_velocity_solves;
+  if (velocity_iterations)
+    *velocity_iterations = ctx->pc_velocity_iterations;
+  ctx->pc_velocity_solves = ctx->pc_velocity_iterations = 0;
+  return 0;
+}
+
 int adaflo_ns_preconditioner_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double *src_u,
                                    const double *src_p)
 {
@@ -888,19 +912,46 @@ int adaflo_ns_preconditioner_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p
   {
     double *p;
   } w{ctx->pc_work.p};
+  // fast diagonalisation (fdm.hip) instead of Jacobi for the inner solves: constant coefficients
+  const bool   fdm    = ctx->pc_inner == 1 && !ctx->rho_prec.p && !ctx->rho.p && !ctx->mu.p;
+  const NSDev &P      = ctx->ns;
+  const bool   stokes = P.physical_type == ADAFLO_STOKES;
+  const double gamma  = P.physical_type == ADAFLO_INCOMPRESSIBLE ? P.weight : 0.;
+  // mass + vector-Laplace part of the velocity block: (gamma rho - damping) M + tau1 mu K  (:717,:841-845)
+  const double vm = stokes ? 0. : gamma * P.density - P.damping, vl = P.viscosity * P.tau1;
   // 1. velocity block (:636-666)
   {
     Krylov K{};
     K.ctx = ctx;
     K.n = K.n_block = nu;
-    K.inv_diag      = ctx->pc_inv_u.p;
-    K.A             = [ctx](double *d, const double *s) { return adaflo_ns_velocity_vmult(ctx, d, s); };
     const double norm = std::sqrt(host_dot(ctx, src_u, src_u, nu));
     const adaflo_solver_control c{100, 3e-2 * norm, 0.};
     if (launch_fill(ctx, dst_u, 0., nu))
       return kfail(ctx, ADAFLO_EHIP, "fill failed");
-    if (int rc = solve_bicgstab(K, dst_u, src_u, c, res, w.p))
-      return rc;
+    if (fdm)
+      {
+        // right preconditioning: BiCGStab on A P^-1 (no pointwise preconditioner), du = P^-1 y
+        double *tmp = ctx->pc_tmp_u.p;
+        K.inv_diag  = nullptr;
+        K.A         = [ctx, tmp, vm, vl](double *d, const double *s) {
+          if (int rc = fdm_apply(ctx, 0, tmp, s, vm, vl))
+            return rc;
+          return adaflo_ns_velocity_vmult(ctx, d, tmp);
+        };
+        if (int rc = solve_bicgstab(K, dst_u, src_u, c, res, w.p))
+          return rc;
+        if (int rc = fdm_apply(ctx, 0, dst_u, dst_u, vm, vl))
+          return kfail(ctx, rc, "fast-diagonalisation solve failed");
+      }
+    else
+      {
+        K.inv_diag = ctx->pc_inv_u.p;
+        K.A        = [ctx](double *d, const double *s) { return adaflo_ns_velocity_vmult(ctx, d, s); };
+        if (int rc = solve_bicgstab(K, dst_u, src_u, c, res, w.p))
+          return rc;
+      }
+    ctx->pc_velocity_iterations += res.iterations;
+    ctx->pc_velocity_solves++;
   }
   // 2. t = -r_p + B du (:671-672)
   double *t = ctx->pc_tmp_p.p, *t2 = ctx->pc_tmp_p2.p;
@@ -910,6 +961,25 @@ int adaflo_ns_preconditioner_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p
   Krylov K{};
   K.ctx = ctx;
   K.n = K.n_block = np;
+  // constant-coefficient pressure mass (:1036-1071) and Poisson (:1002-1031) operators: exact inverses
+  const double c_pm = (P.linearization == ADAFLO_PROJECTION || P.physical_type == ADAFLO_INCOMPRESSIBLE_STATIONARY) ?
+                        1. :
+                        1. / (P.viscosity + P.tau_grad_div);
+  const double c_pl = P.physical_type == ADAFLO_INCOMPRESSIBLE_STATIONARY ?
+                        1. :
+                        1. / (P.weight * std::min(P.density, P.density + P.density_diff));
+  if (fdm)
+    {
+      if (int rc = fdm_apply(ctx, 1, dst_p, t, c_pm, 0.))
+        return kfail(ctx, rc, "fast-diagonalisation solve failed");
+      if (ctx->ns.density > 0.)
+        {
+          if (int rc = fdm_apply(ctx, 1, t2, t, 0., c_pl)) // (pseudo-inverse: the constant is dropped)
+            return kfail(ctx, rc, "fast-diagonalisation solve failed");
+          hipLaunchKernelGGL(axpby_kernel, dim3(kgrid(np)), dim3(KT), 0, ctx->stream, dst_p, 1., t2, 1., np);
+        }
+      return hipGetLastError() == hipSuccess ? 0 : kfail(ctx, ADAFLO_EHIP, "preconditioner kernels failed");
+    }
   // 3. pressure mass (:712, :743-773)
   {
     K.inv_diag = ctx->pc_inv_pm.p;

@@ -426,6 +426,20 @@ int adaflo_solve(adaflo_ctx *ctx, int op, int method, double *x, const double *b
                  const double *inverse_diagonal, const adaflo_solver_control *control,
                  adaflo_solver_result *result);
 
+/* Matrix-free replacement of the assembled matrices + ILU / AMG behind the inner solves
+ * (navier_stokes_preconditioner.cc:636-666,:712-733; level_set_okz_compute_normal.cc:
+ * 252-267): exact inverse of  c_mass M + c_lap K  (mass and Laplace matrices of the velocity space,
+ * field 0, per component, or of the pressure space, field 1) on the brick by fast diagonalisation --
+ * six dense 1D transforms per scalar field.  dst = src on constrained rows; pseudo-inverse (null mode
+ * dropped) if the operator is singular.  dst == src allowed.                                     */
+int adaflo_fdm_apply(adaflo_ctx *ctx, int field, double *dst, const double *src, double c_mass, double c_lap);
+/* inner solves of adaflo_ns_preconditioner_vmult: 0 = Krylov solves with the pointwise Jacobi
+ * preconditioner, 1 (default, constant coefficients) = fast diagonalisation: the velocity block's
+ * BiCGStab is right-preconditioned with the inverse of its mass + vector-Laplace part, the pressure
+ * mass and Poisson solves are exact                                                              */
+int adaflo_ns_preconditioner_set_inner(adaflo_ctx *ctx, int mode);
+/* number of velocity-block solves and their BiCGStab iterations since the last query */
+int adaflo_ns_preconditioner_statistics(adaflo_ctx *ctx, int64_t *velocity_solves, int64_t *velocity_iterations);
 /* NavierStokes::solve_system (source/navier_stokes.cc:561-653): FGMRES(restart) on adaflo_ns_vmult,
  * right-preconditioned by NavierStokesPreconditioner::vmult with inner solves
  * (source/navier_stokes_preconditioner.cc:595-737: velocity block BiCGStab, divergence, pressure

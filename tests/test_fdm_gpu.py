@@ -1,0 +1,107 @@
+"""Fast-diagonalisation inverses behind the inner solves of the block preconditioner (csrc/fdm.hip, SURVEY 8f
+rank 3): exact inverses of the constant-coefficient pressure mass / Poisson operators (checked against the engine's
+own operators) and of c_m M + c_l K on the velocity space (checked against a Kronecker-product assembly in numpy),
+and their effect on the Beltrami time step: the velocity-block BiCGStab needs a handful of iterations instead of
+dozens while the reference's output lines are still reproduced (tests/test_navier_stokes_gpu.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import adaflo_amd
+from adaflo_amd import _lib, beltrami
+from adaflo_amd.navier_stokes import NavierStokes, gauss_lobatto_points, node_coordinates
+from common import Case, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _fdm(op, field, src, c_mass, c_lap):
+    ctx = op._require()
+    n = src.size
+    s, d = adaflo_amd.DeviceVector.from_numpy(ctx, src), adaflo_amd.DeviceVector(ctx, n)
+    _lib.check(ctx, _lib.load().adaflo_fdm_apply(ctx, field, d.ptr, s.ptr, c_mass, c_lap))
+    return d.numpy()
+
+
+@pytest.mark.parametrize("k,ncell,faces_p", [(2, (5, 4, 6), ()), (2, (9, 3, 4), (0,)), (3, (3, 4, 2), (1, 4)), (2, (1, 1, 1), ())])
+def test_pressure_mass_and_poisson_are_inverted_exactly(k, ncell, faces_p):
+    case = Case(ncell, k=k, faces_p=faces_p, upper=(1.0, 0.7, 1.5), viscosity=0.3, tau_grad_div=0.2)
+    op = case.engine()
+    rng = np.random.default_rng(4)
+    x = rng.uniform(-1, 1, case.n_p)
+    xs, ys = op.initialize_p_vector(x), op.initialize_p_vector()
+    op.pressure_mass_vmult(ys, xs)                                   # 1 / (mu + tau_gd) * M, constrained rows identity
+    assert rel_l2(_fdm(op, 1, ys.numpy(), 1.0 / (0.3 + 0.2), 0.0), x) < 1e-10
+    op.pressure_poisson_vmult(ys, xs)                                # 1 / (gamma rho) * K
+    c = 1.0 / (case.ts.weight() * 1.0)
+    got = _fdm(op, 1, ys.numpy(), 0.0, c)
+    if faces_p:
+        assert rel_l2(got, x) < 1e-9
+    else:                                                             # pure Neumann: pseudo-inverse, constant dropped
+        zs = op.initialize_p_vector(got)
+        op.pressure_poisson_vmult(xs, zs)
+        assert rel_l2(xs.numpy(), ys.numpy()) < 1e-9
+
+
+def _mass_stiffness_1d(k, n, h):
+    """FE_Q(k) on n cells with QGauss(k+1), as csrc/fdm.hip assembles them (independent numpy restatement)"""
+    xg, wg = np.polynomial.legendre.leggauss(k + 1)
+    xg, wg = 0.5 * (xg + 1), 0.5 * wg
+    nodes = gauss_lobatto_points(k + 1)
+    S = np.array([[np.prod([(x - nodes[j]) / (nodes[i] - nodes[j]) for j in range(k + 1) if j != i]) for i in range(k + 1)] for x in xg])
+    D = np.array([[sum(np.prod([(x - nodes[j]) / (nodes[i] - nodes[j]) for j in range(k + 1) if j not in (i, m)]) / (nodes[i] - nodes[m])
+                       for m in range(k + 1) if m != i) for i in range(k + 1)] for x in xg])
+    N = k * n + 1
+    M, K = np.zeros((N, N)), np.zeros((N, N))
+    for c in range(n):
+        sl = slice(c * k, c * k + k + 1)
+        M[sl, sl] += h * np.einsum("q,qi,qj->ij", wg, S, S)
+        K[sl, sl] += np.einsum("q,qi,qj->ij", wg, D, D) / h
+    return M, K
+
+
+@pytest.mark.parametrize("k,ncell,faces_u", [(2, (3, 2, 4), range(6)), (2, (4, 3, 2), (0, 3)), (3, (2, 2, 3), (4, 5))])
+def test_velocity_space_inverse_against_kronecker_assembly(k, ncell, faces_u):
+    case = Case(ncell, k=k, faces_u=faces_u, upper=(1.0, 0.7, 1.5))
+    op = case.engine()
+    cm, cl = 3.5, 0.8
+    mats = [_mass_stiffness_1d(k, ncell[d], case.mesh.h[d]) for d in range(3)]
+    (Mx, Kx), (My, Ky), (Mz, Kz) = mats
+    rng = np.random.default_rng(5)
+    nn = [k * n + 1 for n in ncell]
+    x = rng.uniform(-1, 1, (nn[2], nn[1], nn[0], 3))
+
+    def apply(v):                                                   # (cm M + cl K) per component, [z][y][x]
+        e = lambda A, B, Cc: np.einsum("zk,yj,xi,kji->zyx", A, B, Cc, v)
+        return cm * e(Mz, My, Mx) + cl * (e(Mz, My, Kx) + e(Mz, Ky, Mx) + e(Kz, My, Mx))
+    con = case.con_u.reshape(nn[2], nn[1], nn[0], 3).astype(bool)
+    xin = np.where(con, 0.0, x)                                     # constrained columns are decoupled
+    y = np.stack([apply(xin[..., c]) for c in range(3)], axis=-1)
+    y = np.where(con, x, y)                                         # constrained rows: identity
+    got = _fdm(op, 0, y.reshape(-1), cm, cl).reshape(x.shape)
+    assert rel_l2(got, x) < 1e-10
+
+
+def test_beltrami_time_step_with_fast_diagonalisation():
+    nu = 1.0
+    mesh = adaflo_amd.BrickMesh([16] * 3, [-1.0] * 3, [1.0] * 3)
+    xu, xp = node_coordinates(mesh, 2), node_coordinates(mesh, 1)
+    stats = {}
+    for inner in (1, 0):
+        fp = adaflo_amd.FlowParameters(velocity_degree=2, viscosity=nu, time_step_size_start=0.05, end_time=1.0,
+                                       max_nl_iteration=10, tol_nl_iteration=1e-9, max_lin_iteration=100, tol_lin_iteration=1e-5)
+        ns = NavierStokes(fp, mesh, adaflo_amd.TimeStepping(fp), dirichlet_function=lambda x, t: beltrami.velocity(x, t, nu))
+        ctx = ns.navier_stokes_matrix._require()
+        _lib.check(ctx, _lib.load().adaflo_ns_preconditioner_set_inner(ctx, inner))
+        ns.set_initial_condition(beltrami.velocity(xu, 0.0, nu).reshape(-1), beltrami.pressure(xp, 0.0, nu))
+        ns.advance_time_step()
+        assert np.hypot(*ns.history[-1]) < 1e-9
+        ns.history.clear()
+        ns.advance_time_step()
+        assert "%.3e" % ns.history[0][0] == "2.348e+00" and "%.3e" % ns.history[0][1] == "5.678e-02"   # beltrami_3d.output:31
+        solves, its = C.c_int64(), C.c_int64()
+        _lib.check(ctx, _lib.load().adaflo_ns_preconditioner_statistics(ctx, C.byref(solves), C.byref(its)))
+        stats[inner] = (its.value / max(solves.value, 1), sum(i for i, _ in ns.linear_iterations))
+    assert stats[1][0] <= 10.0 and stats[1][0] < 0.5 * stats[0][0], stats
+    assert stats[1][1] <= stats[0][1] + 5, stats
