@@ -1046,6 +1046,23 @@ namespace
   }
 } // namespace
 
+// the generic [cell][3][q] copy of evaluated_convection (which = 0) / evaluated_normal (1), re-created
+// from the sweep layout when the sweep right-hand side was the last writer
+static int ls_generic_state(adaflo_ctx *ctx, const int which)
+{
+  DeviceBuffer &gen = which ? ctx->ls_normal : ctx->ls_convection, &swp = which ? ctx->q1_normal : ctx->q1_convection;
+  bool         &gen_valid = which ? ctx->ls_normal_generic_valid : ctx->ls_convection_generic_valid;
+  const bool    swp_valid = which ? ctx->q1_normal_valid : ctx->q1_convection_valid;
+  if (gen_valid && gen.p)
+    return 0;
+  if (!swp_valid || !swp.p)
+    return fail(ctx, ADAFLO_ENOTINIT, "quadrature-point array not set");
+  TRY(ctx, alloc(ctx, gen, ls_q_count(ctx)), ctx->last_error);
+  TRY(ctx, q1_unconvert_state(ctx, gen.p, swp), "state re-layout failed");
+  gen_valid = true;
+  return 0;
+}
+
 int adaflo_ls_set_params(adaflo_ctx *ctx, const adaflo_ls_params *p)
 {
   CHECK_CTX(ctx);
@@ -1073,13 +1090,16 @@ int adaflo_ls_set_evaluated_convection(adaflo_ctx *ctx, const double *u_q, int s
   CHECK_CTX(ctx);
   if (int e = ls_ready(ctx))
     return e;
-  ctx->q1_convection_valid = false;
+  ctx->q1_convection_valid         = false;
+  ctx->ls_convection_generic_valid = true;
   return set_q_array(ctx, ctx->ls_convection, u_q, src_on_device);
 }
 
 int adaflo_ls_get_evaluated_convection(adaflo_ctx *ctx, double *u_q, int dst_on_device)
 {
   CHECK_CTX(ctx);
+  if (int e = ls_generic_state(ctx, 0))
+    return e;
   return get_q_array(ctx, ctx->ls_convection, u_q, dst_on_device);
 }
 
@@ -1088,13 +1108,16 @@ int adaflo_ls_set_evaluated_normal(adaflo_ctx *ctx, const double *n_q, int src_o
   CHECK_CTX(ctx);
   if (int e = ls_ready(ctx))
     return e;
-  ctx->q1_normal_valid = false;
+  ctx->q1_normal_valid         = false;
+  ctx->ls_normal_generic_valid = true;
   return set_q_array(ctx, ctx->ls_normal, n_q, src_on_device);
 }
 
 int adaflo_ls_get_evaluated_normal(adaflo_ctx *ctx, double *n_q, int dst_on_device)
 {
   CHECK_CTX(ctx);
+  if (int e = ls_generic_state(ctx, 1))
+    return e;
   return get_q_array(ctx, ctx->ls_normal, n_q, dst_on_device);
 }
 
@@ -1126,7 +1149,7 @@ static int ls_vmult(adaflo_ctx *ctx, double *dst, const double *src, const int m
           case 0:
             q1mode = Q1_ADVECT;
             if (!ctx->q1_convection_valid)
-              TRY(ctx, q1_convert_state(ctx, ctx->q1_convection, qstate), "state re-layout failed");
+              TRY(ctx, q1_convert_state(ctx, ctx->q1_convection, ctx->ls_convection.p), "state re-layout failed");
             ctx->q1_convection_valid = true;
             state                    = ctx->q1_convection.p;
             break;
@@ -1135,7 +1158,7 @@ static int ls_vmult(adaflo_ctx *ctx, double *dst, const double *src, const int m
             c_mass = dtau_inv;
             c_lap  = diffusion;
             if (!ctx->q1_normal_valid)
-              TRY(ctx, q1_convert_state(ctx, ctx->q1_normal, qstate), "state re-layout failed");
+              TRY(ctx, q1_convert_state(ctx, ctx->q1_normal, ctx->ls_normal.p), "state re-layout failed");
             ctx->q1_normal_valid = true;
             state                = ctx->q1_normal.p;
             break;
@@ -1154,6 +1177,12 @@ static int ls_vmult(adaflo_ctx *ctx, double *dst, const double *src, const int m
                           dst, src, state, nblocks),
           "level-set kernel launch failed");
       return 0;
+    }
+  if (mode == 0 || mode == 1) // the generic kernels read the [cell][3][q] copy
+    {
+      if (int e = ls_generic_state(ctx, mode))
+        return e;
+      qstate = mode ? ctx->ls_normal.p : ctx->ls_convection.p;
     }
   HIP_TRY(ctx, hipMemsetAsync(dst, 0, sizeof(double) * nblocks * ctx->n_nodes_ls, ctx->stream)); // dst = 0.
   if (stabilised)
@@ -1180,7 +1209,7 @@ static int ls_vmult(adaflo_ctx *ctx, double *dst, const double *src, const int m
 int adaflo_ls_advance_concentration_vmult(adaflo_ctx *ctx, double *dst, const double *src)
 {
   CHECK_CTX(ctx);
-  if (!ctx->ls_convection.p)
+  if (!ctx->ls_convection.p && !ctx->q1_convection_valid)
     return fail(ctx, ADAFLO_ENOTINIT, "evaluated_convection not set (run the rhs kernel first)");
   return ls_vmult(ctx, dst, src, 0 /*LS_ADVECT*/, 0, ctx->ls_convection.p, 1);
 }
@@ -1194,8 +1223,24 @@ int adaflo_ls_advance_concentration_rhs(adaflo_ctx *ctx, double *dst, const doub
     return e;
   if (!dst || !solution || !solution_old || !solution_old_old || !vel_solution)
     return fail(ctx, ADAFLO_EINVAL, "null vector");
+  if (ctx->variant >= 1)
+    {
+      // sweep structure, evaluated_convection written in sweep layout (csrc/q1_sweep.hip)
+      TRY(ctx, q1_state_alloc(ctx, ctx->q1_convection), "out of device memory");
+      const int e = launch_q1_rhs(ctx, 1, use_old_old ? 1 : 0, dst, solution, solution_old, solution_old_old, nullptr,
+                                  vel_solution, ctx->q1_convection.p);
+      if (e == 0)
+        {
+          ctx->q1_convection_valid         = true;
+          ctx->ls_convection_generic_valid = false;
+          return 0;
+        }
+      if (e != ADAFLO_EUNSUPPORTED)
+        return fail(ctx, e, "level-set kernel launch failed");
+    }
   TRY(ctx, alloc(ctx, ctx->ls_convection, ls_q_count(ctx)), ctx->last_error);
-  ctx->q1_convection_valid = false;
+  ctx->q1_convection_valid         = false;
+  ctx->ls_convection_generic_valid = true;
   TRY(ctx,
       launch_ls(ctx, 2, 0, use_old_old, dst, solution, solution_old, solution_old_old, vel_solution,
                 ctx->ls_convection.p, 1),
@@ -1311,7 +1356,8 @@ int adaflo_ls_advance_concentration_rhs_stabilized(adaflo_ctx *ctx, double *dst,
   TRY(ctx, alloc(ctx, ctx->ls_art_visc, (size_t)ctx->n_cells), ctx->last_error);
   TRY(ctx, alloc(ctx, ctx->ls_stab_vel_sum, (size_t)(3 * ctx->n_nodes_u)), ctx->last_error);
   TRY(ctx, alloc(ctx, ctx->ls_stab_ls_sum, (size_t)ctx->n_nodes_ls), ctx->last_error);
-  ctx->q1_convection_valid = false;
+  ctx->q1_convection_valid         = false;
+  ctx->ls_convection_generic_valid = true;
   // interpolation is linear: the sums of the two old states are formed at the nodes
   TRY(ctx, launch_lincomb(ctx, ctx->ls_stab_vel_sum.p, 1., vel_solution_old, 1., vel_solution_old_old, 3 * ctx->n_nodes_u),
       "sum failed");
@@ -1338,7 +1384,7 @@ int adaflo_ls_advance_concentration_rhs_stabilized(adaflo_ctx *ctx, double *dst,
 int adaflo_ls_reinitialization_vmult(adaflo_ctx *ctx, double *dst, const double *src, int diffuse_only)
 {
   CHECK_CTX(ctx);
-  if (!diffuse_only && !ctx->ls_normal.p)
+  if (!diffuse_only && !ctx->ls_normal.p && !ctx->q1_normal_valid)
     return fail(ctx, ADAFLO_ENOTINIT, "evaluated_normal not set (run the rhs kernel with first_reinit_step)");
   return ls_vmult(ctx, dst, src, diffuse_only ? 2 : 1, 0, ctx->ls_normal.p, 1);
 }
@@ -1352,17 +1398,47 @@ int adaflo_ls_reinitialization_rhs(adaflo_ctx *ctx, double *dst, const double *s
     return e;
   if (!dst || !solution || (!diffuse_only && first_reinit_step && !normal_vector_field))
     return fail(ctx, ADAFLO_EINVAL, "null vector");
+  if (!diffuse_only && !first_reinit_step && !ctx->ls_normal.p && !ctx->q1_normal_valid)
+    return fail(ctx, ADAFLO_ENOTINIT, "evaluated_normal not set");
+  const int flag = (diffuse_only ? 1 : 0) | (first_reinit_step ? 2 : 0);
+  if (ctx->variant >= 1)
+    {
+      // sweep structure; the normal at the quadrature points lives in sweep layout (csrc/q1_sweep.hip)
+      if (!diffuse_only)
+        {
+          if (first_reinit_step)
+            TRY(ctx, q1_state_alloc(ctx, ctx->q1_normal), "out of device memory");
+          else if (!ctx->q1_normal_valid)
+            {
+              TRY(ctx, q1_convert_state(ctx, ctx->q1_normal, ctx->ls_normal.p), "state re-layout failed");
+              ctx->q1_normal_valid = true;
+            }
+        }
+      const double *nv = normal_vector_field;
+      TRY(ctx,
+          launch_q1_rhs(ctx, 0, flag, dst, solution, nv, nv ? nv + ctx->n_nodes_ls : nullptr,
+                        nv ? nv + 2 * ctx->n_nodes_ls : nullptr, nullptr, ctx->q1_normal.p),
+          "level-set kernel launch failed");
+      if (!diffuse_only && first_reinit_step)
+        {
+          ctx->q1_normal_valid         = true;
+          ctx->ls_normal_generic_valid = false;
+        }
+      return 0;
+    }
   if (!diffuse_only)
     {
-      if (!first_reinit_step && !ctx->ls_normal.p)
-        return fail(ctx, ADAFLO_ENOTINIT, "evaluated_normal not set");
-      TRY(ctx, alloc(ctx, ctx->ls_normal, ls_q_count(ctx)), ctx->last_error);
       if (first_reinit_step)
-        ctx->q1_normal_valid = false;
+        {
+          TRY(ctx, alloc(ctx, ctx->ls_normal, ls_q_count(ctx)), ctx->last_error);
+          ctx->q1_normal_valid         = false;
+          ctx->ls_normal_generic_valid = true;
+        }
+      else if (int e = ls_generic_state(ctx, 1))
+        return e;
     }
   TRY(ctx,
-      launch_ls(ctx, 1, 0 /*RHS_REINIT*/, (diffuse_only ? 1 : 0) | (first_reinit_step ? 2 : 0), dst,
-                solution, normal_vector_field, nullptr, nullptr, ctx->ls_normal.p, 1),
+      launch_ls(ctx, 1, 0 /*RHS_REINIT*/, flag, dst, solution, normal_vector_field, nullptr, nullptr, ctx->ls_normal.p, 1),
       "level-set kernel launch failed");
   return 0;
 }

@@ -144,6 +144,9 @@ struct adaflo_ctx
   // structured Q1 sweep kernel (q1_sweep.hip): streaming copies of the two arrays, seam partial sums
   adaflo_hip::DeviceBuffer q1_convection, q1_normal, q1_slab, q1_zslab;
   bool                     q1_convection_valid = false, q1_normal_valid = false;
+  // the sweep right-hand sides write the quadrature-point arrays in sweep layout only; the generic
+  // [cell][3][q] copies are re-created on demand (adaflo_ls_get_evaluated_*, generic kernels)
+  bool                     ls_convection_generic_valid = false, ls_normal_generic_valid = false;
   adaflo_hip::DeviceBuffer q1_poisson_coef;   // 1 / (weight rho) per point, lane layout (two-phase pressure Poisson)
   const double            *q1_poisson_src = nullptr; // which density array it was built from ...
   double                   q1_poisson_weight = 0.;   // ... and with which time-step weight

@@ -117,6 +117,10 @@ namespace adaflo_hip
   };
   int q1_convert_state(adaflo_ctx *ctx, DeviceBuffer &out, const double *generic_dev);
   int launch_q1_stencil_rhs(adaflo_ctx *ctx, int mode, double *dst, const double *src);
+  int q1_state_alloc(adaflo_ctx *ctx, DeviceBuffer &out);
+  int q1_unconvert_state(adaflo_ctx *ctx, double *generic_dev, const DeviceBuffer &sweep);
+  int launch_q1_rhs(adaflo_ctx *ctx, int kind, int flag, double *dst, const double *f0, const double *f1,
+                    const double *f2, const double *f3, const double *vel, double *state);
   int launch_q1_sweep(adaflo_ctx *ctx, int sub, int mode, double c_mass, double c_lap, double weight,
                       uint32_t con, double con_sign, const double *diag, double *dst, const double *src,
                       const double *state, int n_blocks = 1, const double *coef_cell = nullptr, int coef_stride = 0,

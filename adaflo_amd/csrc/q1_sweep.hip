@@ -537,6 +537,473 @@ namespace adaflo_hip
           out[o] = v;
         }
     }
+
+    // sweep layout -> generic [cell][3][q]: the inverse of q1_convert_state_kernel (one thread per
+    // generic entry), for adaflo_ls_get_evaluated_* and the generic operator kernels
+    __global__ __launch_bounds__(256) void q1_unconvert_state_kernel(double *__restrict__ canon,
+                                                                     const double *__restrict__ sweep,
+                                                                     const int s, const int ncx,
+                                                                     const int ncy, const int nsz,
+                                                                     const int tiles_x, const long total)
+    {
+      const int nq1 = 2 * s, nqc = nq1 * nq1 * nq1;
+      for (long o = blockIdx.x * 256L + threadIdx.x; o < total; o += (long)gridDim.x * 256)
+        {
+          const int  q = (int)(o % nqc), e = (int)((o / nqc) % 3);
+          const long cell = o / (3L * nqc);
+          const int  qx = q % nq1, qy = (q / nq1) % nq1, qz = q / (nq1 * nq1);
+          const int  cx = (int)(cell % ncx), cy = (int)((cell / ncx) % ncy), cz = (int)(cell / ((long)ncx * ncy));
+          const int  x = cx * s + qx / 2, y = cy * s + qy / 2, z = cz * s + qz / 2;
+          const int  k = 3 * ((qx & 1) + 2 * (qy & 1) + 4 * (qz & 1)) + e;
+          const long bt = (long)(y / TS) * tiles_x + x / TS;
+          const int  lane = (y % TS) * TS + x % TS;
+          canon[o] = sweep[(((bt * nsz + z) * 12 + k / 2) * NTQ + lane) * 2 + (k & 1)];
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // Right-hand sides of the reinitialisation and the advection equation on the sweep structure
+    //   Q1RHS_REINIT  LevelSetOKZSolverReinitialization::local_reinitialize_rhs (reinitialization.cc:128-189)
+    //                 dst += (grad w, n (1/2 (1 - phi^2) - diffusion n . grad phi))   [or -diffusion grad phi];
+    //                 on the first step the normal at the Gauss points is interpolated from the nodal
+    //                 normal field, normalised and WRITTEN as quadrature-point state in sweep layout
+    //   Q1RHS_ADVECT  LevelSetOKZSolverAdvanceConcentration::local_advance_concentration_rhs
+    //                 (advance_concentration.cc:288-397 without stabilisation)
+    //                 dst += -(w, weight phi + u . grad phi + weight_old phi_old [+ weight_old_old phi_old_old]);
+    //                 u = the FE_Q(KU) velocity at the level-set Gauss points, written as state
+    // Same tile / lane / seam scheme as q1_sweep_kernel; like the cell loops they replace the kernels
+    // read plainly, ADD into dst and skip constrained rows.  HBM traffic per sub-cell: the nodal
+    // fields once, dst read + write, and the 192 B of quadrature-point state.
+    enum
+    {
+      Q1RHS_REINIT = 0,
+      Q1RHS_ADVECT = 1
+    };
+
+    struct Q1RhsArgs
+    {
+      Q1Args        q;
+      const double *f[4];   // nodal fields staged per plane (reinit: phi, n_0..n_2; advect: phi, phi_old, phi_old_old)
+      int           nf, flag, sub; // reinit: bit 0 diffuse_only, bit 1 first step; advect: use_old_old
+      double        diffusion, weight, weight_old, weight_old_old;
+      double       *state;  // [tile][layer][12][256][2]
+      const double *vel, *svel; // velocity [node][3]; svel[q (2 sub)][KU + 1]
+      int           vnx, vny, wn; // velocity nodes in x, y; edge of the velocity patch of a tile
+    };
+
+    // trilinear evaluation at the 2x2x2 Gauss points: val[qz][qy][qx], gx[qz][qy], gy[qz][qx], gz[qy][qx]
+    __device__ __forceinline__ void q1_evaluate(const double (&u)[2][2][2], const double ga, const double gb,
+                                                const double (&ih)[3], double (&val)[2][2][2], double (&gx)[2][2],
+                                                double (&gy)[2][2], double (&gz)[2][2])
+    {
+      double X[2][2][2], DX[2][2];
+#pragma unroll
+      for (int lk = 0; lk < 2; ++lk)
+#pragma unroll
+        for (int lj = 0; lj < 2; ++lj)
+          {
+            X[lk][lj][0] = ga * u[lk][lj][0] + gb * u[lk][lj][1];
+            X[lk][lj][1] = gb * u[lk][lj][0] + ga * u[lk][lj][1];
+            DX[lk][lj]   = (u[lk][lj][1] - u[lk][lj][0]) * ih[0];
+          }
+      double XY[2][2][2], DY[2][2], DXY[2][2];
+#pragma unroll
+      for (int lk = 0; lk < 2; ++lk)
+        {
+#pragma unroll
+          for (int qx = 0; qx < 2; ++qx)
+            {
+              XY[lk][0][qx] = ga * X[lk][0][qx] + gb * X[lk][1][qx];
+              XY[lk][1][qx] = gb * X[lk][0][qx] + ga * X[lk][1][qx];
+              DY[lk][qx]    = (X[lk][1][qx] - X[lk][0][qx]) * ih[1];
+            }
+          DXY[lk][0] = ga * DX[lk][0] + gb * DX[lk][1];
+          DXY[lk][1] = gb * DX[lk][0] + ga * DX[lk][1];
+        }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          {
+            val[0][a][b] = ga * XY[0][a][b] + gb * XY[1][a][b];
+            val[1][a][b] = gb * XY[0][a][b] + ga * XY[1][a][b];
+            gz[a][b]     = (XY[1][a][b] - XY[0][a][b]) * ih[2];
+          }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+        {
+          gx[0][a] = ga * DXY[0][a] + gb * DXY[1][a];
+          gx[1][a] = gb * DXY[0][a] + ga * DXY[1][a];
+          gy[0][a] = ga * DY[0][a] + gb * DY[1][a];
+          gy[1][a] = gb * DY[0][a] + ga * DY[1][a];
+        }
+    }
+
+    // transpose of q1_evaluate: r[lk][lj][li] = sum_q N tv + dN_x t0 + dN_y t1 + dN_z t2
+    // (t0..t2 already carry the factor 1/h of their direction)
+    __device__ __forceinline__ void q1_integrate(const double (&tv)[2][2][2], const double (&t0)[2][2][2],
+                                                 const double (&t1)[2][2][2], const double (&t2)[2][2][2],
+                                                 const double ga, const double gb, double (&r)[2][2][2])
+    {
+      double Zv[2][2][2], Zx[2][2][2], Zy[2][2][2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          {
+            const double d2 = t2[0][a][b] + t2[1][a][b];
+            Zv[0][a][b] = ga * tv[0][a][b] + gb * tv[1][a][b] - d2;
+            Zv[1][a][b] = gb * tv[0][a][b] + ga * tv[1][a][b] + d2;
+            Zx[0][a][b] = ga * t0[0][a][b] + gb * t0[1][a][b];
+            Zx[1][a][b] = gb * t0[0][a][b] + ga * t0[1][a][b];
+            Zy[0][a][b] = ga * t1[0][a][b] + gb * t1[1][a][b];
+            Zy[1][a][b] = gb * t1[0][a][b] + ga * t1[1][a][b];
+          }
+      double Yv[2][2][2], Yx[2][2][2];
+#pragma unroll
+      for (int lk = 0; lk < 2; ++lk)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          {
+            const double d1 = Zy[lk][0][b] + Zy[lk][1][b];
+            Yv[lk][0][b] = ga * Zv[lk][0][b] + gb * Zv[lk][1][b] - d1;
+            Yv[lk][1][b] = gb * Zv[lk][0][b] + ga * Zv[lk][1][b] + d1;
+            Yx[lk][0][b] = ga * Zx[lk][0][b] + gb * Zx[lk][1][b];
+            Yx[lk][1][b] = gb * Zx[lk][0][b] + ga * Zx[lk][1][b];
+          }
+#pragma unroll
+      for (int lk = 0; lk < 2; ++lk)
+#pragma unroll
+        for (int lj = 0; lj < 2; ++lj)
+          {
+            const double d0 = Yx[lk][lj][0] + Yx[lk][lj][1];
+            r[lk][lj][0] = ga * Yv[lk][lj][0] + gb * Yv[lk][lj][1] - d0;
+            r[lk][lj][1] = gb * Yv[lk][lj][0] + ga * Yv[lk][lj][1] + d0;
+          }
+    }
+
+    // KU: velocity degree (advection) / 1 = first reinitialisation step (normal field staged), 0 = later steps
+    template <int MODE, int KU>
+    __global__ __launch_bounds__(NTQ, 2) void q1_rhs_kernel(const Q1RhsArgs R)
+    {
+      constexpr int NF = MODE == Q1RHS_ADVECT ? 3 : (KU ? 4 : 1), PL = TNQ * TNQ;
+      extern __shared__ double dyn[];
+      double *pl = dyn, *pub = pl + 2 * NF * PL, *W = pub + 6 * NTQ; // [2][NF][PL], [2][3][NTQ], [2][3][wn][wn]
+      const Q1Args &A = R.q;
+
+      const int  tid = threadIdx.x;
+      const int  sx = tid % TS, sy = tid / TS;
+      const long nwg = (long)A.tiles_x * A.tiles_y * A.n_chunks;
+      const long wg  = xcd_remap(blockIdx.x, nwg);
+      const int  bz = (int)(wg % A.n_chunks), bt = (int)(wg / A.n_chunks);
+      const int  bx = bt % A.tiles_x, by = bt / A.tiles_x;
+      const int  cz0 = bz * A.LZ, nl = min(A.LZ, A.nsz - cz0);
+      const int  I0 = TS * bx, J0 = TS * by;
+      const int  tcx = min(TS, A.nsx - I0), tcy = min(TS, A.nsy - J0);
+      const bool valid = sx < tcx && sy < tcy;
+      const bool lastx = valid && sx == tcx - 1, lasty = valid && sy == tcy - 1;
+      const bool hasW = sx > 0, hasS = sy > 0;
+      const size_t wgs = (size_t)bt * A.n_chunks + bz;
+
+      unsigned own = 0, con = 0, seam = 0;
+      for (int lj = 0; lj < 2; ++lj)
+        for (int li = 0; li < 2; ++li)
+          {
+            const int bit = li + 2 * lj, I = I0 + sx + li, J = J0 + sy + lj;
+            if (!(valid && (li == 0 || lastx) && (lj == 0 || lasty)))
+              continue;
+            own |= 1u << bit;
+            if ((I == 0 && (A.con >> 0 & 1)) || (I == A.nnx - 1 && (A.con >> 1 & 1)) || (J == 0 && (A.con >> 2 & 1)) ||
+                (J == A.nny - 1 && (A.con >> 3 & 1)))
+              con |= 1u << bit;
+            if ((sx + li == TS && I < A.nnx - 1) || (sy + lj == TS && J < A.nny - 1))
+              seam |= 1u << bit;
+          }
+      const bool     conz_lo = A.con >> 4 & 1, conz_hi = A.con >> 5 & 1;
+      const unsigned lane_g  = (unsigned)((J0 + sy) * A.nnx + I0 + sx);
+
+      // node planes: global -> registers (issued one layer ahead) -> LDS (after the layer's reads)
+      constexpr int NLD = (PL + NTQ - 1) / NTQ;
+      double        pre[NF][NLD];
+      auto fetch_plane = [&](const int K) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+          if (f < R.nf)
+#pragma unroll
+            for (int r = 0; r < NLD; ++r)
+              {
+                const int e = tid + NTQ * r, i = e % TNQ, j = e / TNQ, I = I0 + i, J = J0 + j;
+                pre[f][r]   = (e < PL && I < A.nnx && J < A.nny && K < A.nnz) ? R.f[f][((size_t)K * A.nny + J) * A.nnx + I] : 0.;
+              }
+      };
+      auto commit_plane = [&](const int slot) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+          if (f < R.nf)
+#pragma unroll
+            for (int r = 0; r < NLD; ++r)
+              if (tid + NTQ * r < PL)
+                pl[(slot * NF + f) * PL + tid + NTQ * r] = pre[f][r];
+      };
+      // (the owner adds into dst: the old values are fetched at the top of the layer)
+      double dold[4];
+      auto emit = [&](const int bit, const int li, const int lj, const int K, const int lp, const double v,
+                      const bool zcon, const bool ztop, const bool prefetched) {
+        if (!(own >> bit & 1u) || (con >> bit & 1u) || zcon)
+          return;
+        const size_t idx = (size_t)K * A.nny * A.nnx + lane_g + (unsigned)(lj * A.nnx + li);
+        if (seam >> bit & 1u)
+          A.slab[(wgs * (A.LZ + 1) + lp) * RIMQ + rim_index_q<TNQ>(sx + li, sy + lj)] = v;
+        else if (ztop)
+          A.zslab[wgs * (TNQ * TNQ) + (sy + lj) * TNQ + sx + li] = v;
+        else
+          A.dst[idx] = (prefetched ? dold[bit] : A.dst[idx]) + v;
+      };
+      auto nodal = [&](const int cz, const int f, double (&u)[2][2][2]) {
+#pragma unroll
+        for (int lk = 0; lk < 2; ++lk)
+#pragma unroll
+          for (int lj = 0; lj < 2; ++lj)
+#pragma unroll
+            for (int li = 0; li < 2; ++li)
+              u[lk][lj][li] = pl[(((cz + lk) & 1) * NF + f) * PL + (sy + lj) * TNQ + sx + li];
+      };
+
+      // advection: this lane's cell within the velocity patch of the tile, 1D shape values of the
+      // velocity space at its two Gauss points per direction
+      const int sub = R.sub, wn = R.wn;
+      int       vx0 = 0, vy0 = 0, ix0 = 0, jy0 = 0;
+      double    Sx[2][KU + 1], Sy[2][KU + 1];
+      if (MODE == Q1RHS_ADVECT)
+        {
+          const int x = min(I0 + sx, A.nsx - 1), y = min(J0 + sy, A.nsy - 1);
+          vx0 = KU * (I0 / sub);
+          vy0 = KU * (J0 / sub);
+          ix0 = KU * (x / sub) - vx0;
+          jy0 = KU * (y / sub) - vy0;
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i <= KU; ++i)
+              {
+                Sx[a][i] = R.svel[(2 * (x % sub) + a) * (KU + 1) + i];
+                Sy[a][i] = R.svel[(2 * (y % sub) + a) * (KU + 1) + i];
+              }
+        }
+      const bool diffuse_only = MODE == Q1RHS_REINIT && (R.flag & 1), first = MODE == Q1RHS_REINIT && KU == 1;
+
+      double carry[4] = {0., 0., 0., 0.};
+      fetch_plane(cz0);
+      commit_plane(cz0 & 1);
+      fetch_plane(cz0 + 1);
+      commit_plane((cz0 + 1) & 1);
+      __syncthreads();
+      for (int layer = 0; layer < nl; ++layer)
+        {
+          const int cz = cz0 + layer;
+          if (layer + 1 < nl)
+            fetch_plane(cz + 2);
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            {
+              dold[n] = 0.;
+              if ((own & ~con & ~seam) >> n & 1u)
+                dold[n] = A.dst[(size_t)cz * A.nny * A.nnx + lane_g + (unsigned)((n >> 1) * A.nnx + (n & 1))];
+            }
+          double2  st[12];
+          double2 *sp = reinterpret_cast<double2 *>(R.state) + ((size_t)bt * A.nsz + cz) * (12 * NTQ) + tid;
+          if (MODE == Q1RHS_REINIT && !diffuse_only && !first)
+            {
+#pragma unroll
+              for (int c = 0; c < 12; ++c)
+                st[c] = sp[c * NTQ];
+            }
+          if (MODE == Q1RHS_ADVECT)
+            {
+              // velocity interpolated in z to the two Gauss planes of this layer, on the node patch of the tile
+              const int     kc = cz / sub, zl = cz % sub;
+              const double *sz = R.svel + 2 * zl * (KU + 1);
+              for (int e = tid; e < 3 * wn * wn; e += NTQ)
+                {
+                  const int comp = e % 3, ix = (e / 3) % wn, jy = e / (3 * wn);
+                  const int I = vx0 + ix, J = vy0 + jy;
+                  double    w0 = 0., w1 = 0.;
+                  if (I < R.vnx && J < R.vny)
+#pragma unroll
+                    for (int k = 0; k <= KU; ++k)
+                      {
+                        const double v = R.vel[(((size_t)(KU * kc + k) * R.vny + J) * R.vnx + I) * 3 + comp];
+                        w0 += sz[k] * v;
+                        w1 += sz[KU + 1 + k] * v;
+                      }
+                  W[(comp * wn + jy) * wn + ix]       = w0;
+                  W[((3 + comp) * wn + jy) * wn + ix] = w1;
+                }
+              __syncthreads();
+            }
+
+          double u[2][2][2], val[2][2][2], gx[2][2], gy[2][2], gz[2][2];
+          nodal(cz, 0, u);
+          q1_evaluate(u, A.ga, A.gb, A.ih, val, gx, gy, gz);
+          double el[24]; // quadrature-point state of this sub-cell, element 3 q + e
+          double tv[2][2][2], t0[2][2][2], t1[2][2][2], t2[2][2][2];
+          if (MODE == Q1RHS_REINIT)
+            {
+              if (KU == 1)
+                {
+                  double dx[2][2], dy[2][2], dz[2][2], nv[3][2][2][2];
+#pragma unroll
+                  for (int e = 0; e < 3; ++e)
+                    {
+                      nodal(cz, NF == 4 ? 1 + e : 0, u);
+                      q1_evaluate(u, A.ga, A.gb, A.ih, nv[e], dx, dy, dz);
+                    }
+#pragma unroll
+                  for (int q = 0; q < 8; ++q)
+                    {
+                      const int    qx = q & 1, qy = q >> 1 & 1, qz = q >> 2;
+                      const double n0 = nv[0][qz][qy][qx], n1 = nv[1][qz][qy][qx], n2 = nv[2][qz][qy][qx];
+                      const double sc = 1. / fmax(1e-4, sqrt(n0 * n0 + n1 * n1 + n2 * n2)); // :167-172
+                      el[3 * q] = n0 * sc, el[3 * q + 1] = n1 * sc, el[3 * q + 2] = n2 * sc;
+                    }
+#pragma unroll
+                  for (int c = 0; c < 12; ++c)
+                    sp[c * NTQ] = make_double2(el[2 * c], el[2 * c + 1]);
+                }
+              else if (!diffuse_only)
+                {
+#pragma unroll
+                  for (int c = 0; c < 12; ++c)
+                    el[2 * c] = st[c].x, el[2 * c + 1] = st[c].y;
+                }
+#pragma unroll
+              for (int q = 0; q < 8; ++q)
+                {
+                  const int    qx = q & 1, qy = q >> 1 & 1, qz = q >> 2;
+                  const double g0 = gx[qz][qy], g1 = gy[qz][qx], g2 = gz[qy][qx];
+                  double       b0, b1, b2;
+                  if (!diffuse_only) // :176-178
+                    {
+                      const double v = val[qz][qy][qx], n0 = el[3 * q], n1 = el[3 * q + 1], n2 = el[3 * q + 2];
+                      const double f = 0.5 * (1. - v * v) - (n0 * g0 + n1 * g1 + n2 * g2) * R.diffusion;
+                      b0 = n0 * f, b1 = n1 * f, b2 = n2 * f;
+                    }
+                  else
+                    b0 = -R.diffusion * g0, b1 = -R.diffusion * g1, b2 = -R.diffusion * g2;
+                  tv[qz][qy][qx] = 0.;
+                  t0[qz][qy][qx] = b0 * (A.jxw * A.ih[0]);
+                  t1[qz][qy][qx] = b1 * (A.jxw * A.ih[1]);
+                  t2[qz][qy][qx] = b2 * (A.jxw * A.ih[2]);
+                }
+            }
+          else
+            {
+              // velocity at the 8 Gauss points from the z-interpolated node patch
+#pragma unroll
+              for (int qz = 0; qz < 2; ++qz)
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+                  {
+                    const double *w = W + ((3 * qz + e) * wn + jy0) * wn + ix0;
+                    double        tx[2][KU + 1];
+#pragma unroll
+                    for (int j = 0; j <= KU; ++j)
+                      {
+                        double a0 = 0., a1 = 0.;
+#pragma unroll
+                        for (int i = 0; i <= KU; ++i)
+                          {
+                            const double v = w[j * wn + i];
+                            a0 += Sx[0][i] * v;
+                            a1 += Sx[1][i] * v;
+                          }
+                        tx[0][j] = a0, tx[1][j] = a1;
+                      }
+#pragma unroll
+                    for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+                      for (int qx = 0; qx < 2; ++qx)
+                        {
+                          double a = 0.;
+#pragma unroll
+                          for (int j = 0; j <= KU; ++j)
+                            a += Sy[qy][j] * tx[qx][j];
+                          el[3 * (qx + 2 * qy + 4 * qz) + e] = a;
+                        }
+                  }
+#pragma unroll
+              for (int c = 0; c < 12; ++c)
+                sp[c * NTQ] = make_double2(el[2 * c], el[2 * c + 1]); // :389 evaluated_convection
+              double vo[2][2][2], voo[2][2][2], dx[2][2], dy[2][2], dz[2][2];
+              nodal(cz, 1, u);
+              q1_evaluate(u, A.ga, A.gb, A.ih, vo, dx, dy, dz);
+              if (R.flag) // bdf_2 && step_no > 1  :375-378
+                {
+                  nodal(cz, 2, u);
+                  q1_evaluate(u, A.ga, A.gb, A.ih, voo, dx, dy, dz);
+                }
+#pragma unroll
+              for (int q = 0; q < 8; ++q)
+                {
+                  const int qx = q & 1, qy = q >> 1 & 1, qz = q >> 2;
+                  double    old_value = R.weight_old * vo[qz][qy][qx];
+                  if (R.flag)
+                    old_value += R.weight_old_old * voo[qz][qy][qx];
+                  const double ug = el[3 * q] * gx[qz][qy] + el[3 * q + 1] * gy[qz][qx] + el[3 * q + 2] * gz[qy][qx];
+                  tv[qz][qy][qx] = -(val[qz][qy][qx] * R.weight + ug + old_value) * A.jxw;
+                  t0[qz][qy][qx] = t1[qz][qy][qx] = t2[qz][qy][qx] = 0.;
+                }
+            }
+          double r[2][2][2];
+          q1_integrate(tv, t0, t1, t2, A.ga, A.gb, r);
+
+          // ---- publish the high faces, combine per owned node (as in q1_sweep_kernel) ----------
+#pragma unroll
+          for (int lk = 0; lk < 2; ++lk)
+            {
+              pub[(lk * 3 + 0) * NTQ + tid] = r[lk][0][1];
+              pub[(lk * 3 + 1) * NTQ + tid] = r[lk][1][0];
+              pub[(lk * 3 + 2) * NTQ + tid] = r[lk][1][1];
+            }
+          __syncthreads();
+          if (layer + 1 < nl) // every lane has read planes cz, cz + 1: plane cz + 2 takes the slot of cz
+            commit_plane(cz & 1);
+#pragma unroll
+          for (int lk = 0; lk < 2; ++lk)
+            {
+              const double *pb = pub + lk * 3 * NTQ;
+              const double  w0 = hasW ? pb[tid - 1] : 0., w1 = hasW ? pb[2 * NTQ + tid - 1] : 0.;
+              const double  s0 = hasS ? pb[NTQ + tid - TS] : 0., s1 = hasS ? pb[2 * NTQ + tid - TS] : 0.;
+              const double  sw = (hasW && hasS) ? pb[2 * NTQ + tid - TS - 1] : 0.;
+              double        nv[4];
+              nv[0] = r[lk][0][0] + w0 + s0 + sw;
+              nv[1] = r[lk][0][1] + s1;
+              nv[2] = r[lk][1][0] + w1;
+              nv[3] = r[lk][1][1];
+              if (lk == 1)
+                {
+#pragma unroll
+                  for (int n = 0; n < 4; ++n)
+                    carry[n] = nv[n];
+                }
+              else
+                {
+                  const bool zcon = cz == 0 && conz_lo;
+#pragma unroll
+                  for (int n = 0; n < 4; ++n)
+                    emit(n, n & 1, n >> 1, cz, layer, nv[n] + carry[n], zcon, false, true);
+                }
+            }
+          __syncthreads();
+        }
+      {
+        const int  cze  = cz0 + nl;
+        const bool ztop = cze < A.nsz, zcon = cze == A.nnz - 1 && conz_hi;
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          emit(n, n & 1, n >> 1, cze, nl, carry[n], zcon, ztop, false);
+      }
+    }
   } // namespace
 
   namespace
@@ -584,6 +1051,7 @@ namespace adaflo_hip
       const double *diag, *src;
       double       *dst;
       double       *dot_partial; // optional: per block (sum of src_i dst_i, 0) for the CG driver (krylov.hip)
+      int           plain;       // right-hand side form: src read plainly, dst += result, constrained rows skipped
     };
 
     // Workgroup = 64 x 8 nodes of a plane (4 waves, two rows per thread), marching LZ planes in z.  A
@@ -614,8 +1082,8 @@ namespace adaflo_hip
       // contributes nothing
       auto rows = [&](const int d, const int idx, const int n, double *m, double *k) {
         const bool lo = idx > 0, hi = idx < n - 1;
-        const bool clo = lo && !(idx - 1 == 0 && (A.con >> (2 * d) & 1));
-        const bool chi = hi && !(idx + 1 == n - 1 && (A.con >> (2 * d + 1) & 1));
+        const bool clo = lo && (A.plain || !(idx - 1 == 0 && (A.con >> (2 * d) & 1)));
+        const bool chi = hi && (A.plain || !(idx + 1 == n - 1 && (A.con >> (2 * d + 1) & 1)));
         m[0] = clo ? A.m_off[d] : 0.;
         m[2] = chi ? A.m_off[d] : 0.;
         m[1] = ((lo ? 1. : 0.) + (hi ? 1. : 0.)) * A.m_ctr[d];
@@ -682,7 +1150,7 @@ namespace adaflo_hip
       };
 
       const int  k0 = chunk * A.LZ, k1 = min(k0 + A.LZ, A.nnz);
-      const bool conz_lo = A.con >> 4 & 1, conz_hi = A.con >> 5 & 1;
+      const bool conz_lo = (A.con >> 4 & 1) && !A.plain, conz_hi = (A.con >> 5 & 1) && !A.plain; // (neighbour planes)
       double     Am[STR], Bm[STR], A0[STR], B0[STR], Ap[STR], Bp[STR], c0[STR], cp[STR], cm, src_dot_dst = 0.;
 #pragma unroll
       for (int r = 0; r < STR; ++r)
@@ -732,14 +1200,20 @@ namespace adaflo_hip
           const double mzc = nz * A.m_ctr[2], kzc = nz * A.k_ctr[2];
           const double mzl = lo ? A.m_off[2] : 0., mzh = hi ? A.m_off[2] : 0.;
           const double kzl = lo ? A.k_off[2] : 0., kzh = hi ? A.k_off[2] : 0.;
-          const bool   conz = (k == 0 && conz_lo) || (k == A.nnz - 1 && conz_hi);
+          const bool   conz = (k == 0 && (A.con >> 4 & 1)) || (k == A.nnz - 1 && (A.con >> 5 & 1));
 #pragma unroll
           for (int r = 0; r < STR; ++r)
             {
               double v = (A.c_mass * mzl + A.c_lap * kzl) * Am[r] + A.c_lap * mzl * Bm[r];
               v += (A.c_mass * mzc + A.c_lap * kzc) * A0[r] + A.c_lap * mzc * B0[r];
               v += (A.c_mass * mzh + A.c_lap * kzh) * Ap[r] + A.c_lap * mzh * Bp[r];
-              if (active[r])
+              if (active[r] && A.plain)
+                {
+                  const long idx = (long)k * A.plane + p[r];
+                  if (!(con_xy[r] || conz))
+                    dst_c[idx] += v;
+                }
+              else if (active[r])
                 {
                   const long idx = (long)k * A.plane + p[r];
                   if (con_xy[r] || conz)
@@ -920,7 +1394,8 @@ namespace adaflo_hip
     return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
   }
 
-  int q1_convert_state(adaflo_ctx *ctx, DeviceBuffer &out, const double *canonical_dev)
+  // quadrature-point state in sweep layout: [tile][layer][12][256 lanes][2]
+  int q1_state_alloc(adaflo_ctx *ctx, DeviceBuffer &out)
   {
     const int    s = ctx->s, nsx = s * ctx->desc.ncell[0], nsy = s * ctx->desc.ncell[1], nsz = s * ctx->desc.ncell[2];
     const int    tiles_x = (nsx + TS - 1) / TS, tiles_y = (nsy + TS - 1) / TS;
@@ -935,6 +1410,16 @@ namespace adaflo_hip
           return ADAFLO_ENOMEM;
         out.count = count;
       }
+    return 0;
+  }
+
+  int q1_convert_state(adaflo_ctx *ctx, DeviceBuffer &out, const double *canonical_dev)
+  {
+    if (const int e = q1_state_alloc(ctx, out))
+      return e;
+    const int    s = ctx->s, nsx = s * ctx->desc.ncell[0], nsy = s * ctx->desc.ncell[1], nsz = s * ctx->desc.ncell[2];
+    const int    tiles_x = (nsx + TS - 1) / TS;
+    const size_t count   = out.count;
     long nb = (long)((count + 255) / 256);
     if (nb > 256 * 64)
       nb = 256 * 64;
@@ -944,63 +1429,23 @@ namespace adaflo_hip
     return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
   }
 
-  // sub = subdivisions of a cell (level set: s, pressure: 1); mode/coefficients as Q1Args
-  int launch_q1_sweep(adaflo_ctx *ctx, const int sub, const int mode, const double c_mass,
-                      const double c_lap, const double weight, const uint32_t con, const double con_sign,
-                      const double *diag, double *dst, const double *src, const double *state,
-                      const int n_blocks, const double *coef_cell, const int coef_stride, const int coef_mid,
-                      const double coef_shift)
+  // sweep layout -> generic [cell][3][q]
+  int q1_unconvert_state(adaflo_ctx *ctx, double *generic_dev, const DeviceBuffer &sweep)
   {
-    if (mode == Q1_MASS_LAPLACE && coef_cell == nullptr)
-      {
-        StencilArgs S{};
-        S.nnx = sub * ctx->desc.ncell[0] + 1;
-        S.nny = sub * ctx->desc.ncell[1] + 1;
-        S.nnz = sub * ctx->desc.ncell[2] + 1;
-        S.plane            = (long)S.nnx * S.nny;
-        S.comp_stride      = S.plane * S.nnz;
-        S.blocks_per_plane = ((S.nnx + STX - 1) / STX) * ((S.nny + STY - 1) / STY); // 64 x 4 node tiles
-        int lz = 32;
-        while (lz > 4 && (long)S.blocks_per_plane * ((S.nnz + lz - 1) / lz) < 2048)
-          lz /= 2;
-        S.LZ       = lz;
-        S.n_chunks = (S.nnz + lz - 1) / lz;
-        for (int d = 0; d < 3; ++d)
-          {
-            const double hs = ctx->desc.h[d] / sub;
-            S.m_off[d] = hs / 6.;
-            S.m_ctr[d] = hs / 3.;
-            S.k_off[d] = -1. / hs;
-            S.k_ctr[d] = 1. / hs;
-          }
-        S.c_mass   = c_mass;
-        S.c_lap    = c_lap;
-        S.con      = con;
-        S.con_sign = con_sign;
-        S.diag     = diag;
-        S.src      = src;
-        S.dst      = dst;
-        // a CG driver asks for src . dst through the context (krylov.hip): granted if the partials fit
-        const long n_partial = (long)S.blocks_per_plane * S.n_chunks * n_blocks;
-        ctx->fused_dot_count = 0;
-        if (ctx->fused_dot_partial && n_partial <= ctx->fused_dot_capacity)
-          {
-            S.dot_partial        = ctx->fused_dot_partial;
-            ctx->fused_dot_count = (int)n_partial;
-          }
-        hipEvent_t stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
-        hipLaunchKernelGGL(q1_stencil_kernel, dim3((unsigned)(S.blocks_per_plane * S.n_chunks), (unsigned)n_blocks),
-                           dim3(256), 0, ctx->stream, S);
-        if (stop)
-          (void)hipEventRecord(stop, ctx->stream);
-        ctx->kernel_timer.count++;
-        return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
-      }
-    Q1Args A{};
-    A.coef_cell   = coef_cell;
-    A.coef_stride = coef_stride;
-    A.coef_mid    = coef_mid;
-    A.coef_shift  = coef_shift;
+    const int  s = ctx->s, nsx = s * ctx->desc.ncell[0], nsz = s * ctx->desc.ncell[2];
+    const int  tiles_x = (nsx + TS - 1) / TS;
+    const long total   = (long)ctx->n_cells * 3 * 8 * s * s * s;
+    long       nb      = (total + 255) / 256;
+    if (nb > 256 * 64)
+      nb = 256 * 64;
+    hipLaunchKernelGGL(q1_unconvert_state_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, generic_dev, sweep.p,
+                       s, ctx->desc.ncell[0], ctx->desc.ncell[1], nsz, tiles_x, total);
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+
+  // geometry of the sweep (tiles, z-chunks, Jacobian factors) and the slab buffers of the seams
+  static int q1_setup(adaflo_ctx *ctx, const int sub, const int mode, const int n_blocks, Q1Args &A)
+  {
     {
       const Quadrature1D g3 = gauss(3);
       for (int q = 0; q < 3; ++q)
@@ -1039,15 +1484,6 @@ namespace adaflo_hip
     A.gb       = 0.5 * (1. - 1. / std::sqrt(3.)); // first Gauss point of QGauss<1>(2) on [0,1]
     A.ga       = 1. - A.gb;
     const size_t n_wg = (size_t)A.tiles_x * A.tiles_y * A.n_chunks;
-    A.c_mass   = c_mass;
-    A.c_lap    = c_lap;
-    A.weight   = weight;
-    A.con      = con;
-    A.con_sign = con_sign;
-    A.diag     = diag;
-    A.src      = src;
-    A.dst      = dst;
-    A.state    = state;
     A.comp_stride  = (long)A.nnx * A.nny * A.nnz;
     A.slab_stride  = (long)(n_wg * (A.LZ + 1) * RIMQ);
     A.zslab_stride = (long)(n_wg * TNQ * TNQ);
@@ -1066,6 +1502,85 @@ namespace adaflo_hip
         }
     A.slab  = ctx->q1_slab.p;
     A.zslab = ctx->q1_zslab.p;
+    return 0;
+  }
+
+  // constant-coefficient c_mass M + c_lap K as 27-point stencil; plain = 1: right-hand side form
+  static int launch_q1_stencil(adaflo_ctx *ctx, const int sub, const double c_mass, const double c_lap, const uint32_t con,
+                               const double con_sign, const double *diag, double *dst, const double *src,
+                               const int n_blocks, const int plain)
+  {
+    StencilArgs S{};
+    S.nnx = sub * ctx->desc.ncell[0] + 1;
+    S.nny = sub * ctx->desc.ncell[1] + 1;
+    S.nnz = sub * ctx->desc.ncell[2] + 1;
+    S.plane            = (long)S.nnx * S.nny;
+    S.comp_stride      = S.plane * S.nnz;
+    S.blocks_per_plane = ((S.nnx + STX - 1) / STX) * ((S.nny + STY - 1) / STY); // 64 x 4 node tiles
+    int lz = 32;
+    while (lz > 4 && (long)S.blocks_per_plane * ((S.nnz + lz - 1) / lz) < 2048)
+      lz /= 2;
+    S.LZ       = lz;
+    S.n_chunks = (S.nnz + lz - 1) / lz;
+    for (int d = 0; d < 3; ++d)
+      {
+        const double hs = ctx->desc.h[d] / sub;
+        S.m_off[d] = hs / 6.;
+        S.m_ctr[d] = hs / 3.;
+        S.k_off[d] = -1. / hs;
+        S.k_ctr[d] = 1. / hs;
+      }
+    S.c_mass   = c_mass;
+    S.c_lap    = c_lap;
+    S.con      = con;
+    S.con_sign = con_sign;
+    S.diag     = diag;
+    S.src      = src;
+    S.dst      = dst;
+    S.plain    = plain;
+    // a CG driver asks for src . dst through the context (krylov.hip): granted if the partials fit
+    const long n_partial = (long)S.blocks_per_plane * S.n_chunks * n_blocks;
+    ctx->fused_dot_count = 0;
+    if (!plain && ctx->fused_dot_partial && n_partial <= ctx->fused_dot_capacity)
+      {
+        S.dot_partial        = ctx->fused_dot_partial;
+        ctx->fused_dot_count = (int)n_partial;
+      }
+    hipEvent_t stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
+    hipLaunchKernelGGL(q1_stencil_kernel, dim3((unsigned)(S.blocks_per_plane * S.n_chunks), (unsigned)n_blocks),
+                       dim3(256), 0, ctx->stream, S);
+    if (stop)
+      (void)hipEventRecord(stop, ctx->stream);
+    ctx->kernel_timer.count++;
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+
+  // sub = subdivisions of a cell (level set: s, pressure: 1); mode/coefficients as Q1Args
+  int launch_q1_sweep(adaflo_ctx *ctx, const int sub, const int mode, const double c_mass,
+                      const double c_lap, const double weight, const uint32_t con, const double con_sign,
+                      const double *diag, double *dst, const double *src, const double *state,
+                      const int n_blocks, const double *coef_cell, const int coef_stride, const int coef_mid,
+                      const double coef_shift)
+  {
+    if (mode == Q1_MASS_LAPLACE && coef_cell == nullptr)
+      return launch_q1_stencil(ctx, sub, c_mass, c_lap, con, con_sign, diag, dst, src, n_blocks, 0);
+    Q1Args A{};
+    A.coef_cell   = coef_cell;
+    A.coef_stride = coef_stride;
+    A.coef_mid    = coef_mid;
+    A.coef_shift  = coef_shift;
+    if (const int e = q1_setup(ctx, sub, mode, n_blocks, A))
+      return e;
+    const size_t n_wg = (size_t)A.tiles_x * A.tiles_y * A.n_chunks;
+    A.c_mass   = c_mass;
+    A.c_lap    = c_lap;
+    A.weight   = weight;
+    A.con      = con;
+    A.con_sign = con_sign;
+    A.diag     = diag;
+    A.src      = src;
+    A.dst      = dst;
+    A.state    = state;
     const dim3 grid((unsigned)n_wg, (unsigned)n_blocks), block(NTQ);
     hipEvent_t stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
     switch (mode)
@@ -1123,6 +1638,94 @@ namespace adaflo_hip
       hipLaunchKernelGGL(q1_stencil_rhs_kernel<0>, grid, dim3(256), 0, ctx->stream, S);
     else
       hipLaunchKernelGGL(q1_stencil_rhs_kernel<1>, grid, dim3(256), 0, ctx->stream, S);
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+  // Right-hand sides on the sweep structure.  kind 0: reinitialisation (f = phi, normal field; flag bit 0
+  // diffuse_only, bit 1 first step), kind 1: advection (f = phi, phi_old, phi_old_old; flag = use_old_old).
+  // `state` is the quadrature-point array in sweep layout (written on the first reinitialisation step and
+  // by the advection, read otherwise).  Returns ADAFLO_EUNSUPPORTED when the velocity patch of a tile does
+  // not fit into LDS (the caller then takes the generic kernels).
+  int launch_q1_rhs(adaflo_ctx *ctx, const int kind, const int flag, double *dst, const double *f0, const double *f1,
+                    const double *f2, const double *f3, const double *vel, double *state)
+  {
+    Q1RhsArgs R{};
+    const int sub = ctx->s, k = ctx->k;
+    if (kind == 0 && (flag & 1))
+      {
+        // diffusion step (:185-187): dst += -(grad w, diffusion grad phi) = -diffusion K phi, a 27-point stencil
+        const double hc = std::max(ctx->desc.h[0], std::max(ctx->desc.h[1], ctx->desc.h[2]));
+        return launch_q1_stencil(ctx, sub, 0., -std::max(ctx->ls.epsilon_used, hc / sub), ctx->brick.con_ls, 0., nullptr, dst,
+                                 f0, 1, 1);
+      }
+    if (const int e = q1_setup(ctx, sub, Q1_ADVECT, 1, R.q))
+      return e;
+    R.q.con = ctx->brick.con_ls;
+    R.q.dst = dst;
+    R.f[0] = f0, R.f[1] = f1, R.f[2] = f2, R.f[3] = f3;
+    R.flag  = flag;
+    R.sub   = sub;
+    R.state = state;
+    const LSDev &P     = ctx->ls;
+    const double hcell = std::max(ctx->desc.h[0], std::max(ctx->desc.h[1], ctx->desc.h[2]));
+    R.diffusion        = std::max(P.epsilon_used, hcell / sub);
+    R.weight           = P.weight;
+    R.weight_old       = P.weight_old;
+    R.weight_old_old   = P.weight_old_old;
+    const size_t n_wg = (size_t)R.q.tiles_x * R.q.tiles_y * R.q.n_chunks;
+    const dim3   grid((unsigned)n_wg), block(NTQ);
+    size_t       lds = 0;
+    hipError_t   err = hipSuccess;
+    if (kind == 0)
+      {
+        const bool first = !(flag & 1) && (flag & 2);
+        R.nf = first ? 4 : 1;
+        lds  = sizeof(double) * (2 * R.nf * TNQ * TNQ + 6 * NTQ);
+        if (first)
+          hipLaunchKernelGGL((q1_rhs_kernel<Q1RHS_REINIT, 1>), grid, block, lds, ctx->stream, R);
+        else
+          hipLaunchKernelGGL((q1_rhs_kernel<Q1RHS_REINIT, 0>), grid, block, lds, ctx->stream, R);
+      }
+    else
+      {
+        R.nf   = flag ? 3 : 2;
+        R.vel  = vel;
+        R.svel = ctx->d_tab_ls + 2 * (2 * sub) * (sub + 1) + 2 * sub;
+        R.vnx  = k * ctx->desc.ncell[0] + 1;
+        R.vny  = k * ctx->desc.ncell[1] + 1;
+        R.wn   = k * ((TS + sub - 2) / sub + 1) + 1;
+        lds    = sizeof(double) * (2 * 3 * TNQ * TNQ + 6 * NTQ + 6 * (size_t)R.wn * R.wn);
+        if (lds > 96 * 1024)
+          return ADAFLO_EUNSUPPORTED;
+#define ADV(KU)                                                                                           \
+  {                                                                                                       \
+    if (lds > 64 * 1024)                                                                                  \
+      err = hipFuncSetAttribute(reinterpret_cast<const void *>(&q1_rhs_kernel<Q1RHS_ADVECT, KU>),         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+    hipLaunchKernelGGL((q1_rhs_kernel<Q1RHS_ADVECT, KU>), grid, block, lds, ctx->stream, R);              \
+  }
+        switch (k)
+          {
+            case 2:
+              ADV(2);
+              break;
+            case 3:
+              ADV(3);
+              break;
+            case 4:
+              ADV(4);
+              break;
+            default:
+              return ADAFLO_EUNSUPPORTED;
+          }
+#undef ADV
+      }
+    if (err != hipSuccess || hipGetLastError() != hipSuccess)
+      return ADAFLO_EHIP;
+    const long tiles = (long)R.q.tiles_x * R.q.tiles_y, n1 = tiles * R.q.nnz, n2 = tiles * (R.q.n_chunks - 1);
+    long       nb    = n1 + n2;
+    if (nb > 256 * 512)
+      nb = 256 * 512;
+    hipLaunchKernelGGL(q1_fixup_kernel, dim3((unsigned)nb, 1u), dim3(64), 0, ctx->stream, R.q, n1, n2);
     return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
   }
 } // namespace adaflo_hip

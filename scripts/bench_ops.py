@@ -147,6 +147,27 @@ def ls_case(s, ncell):
              ("ls_reinit_vmult", lambda: rei.reinitialization_vmult(dst, src, False), 1, 16 * s ** 3 + 24 * nq),
              ("ls_normal_vmult", lambda: nor.compute_normal_vmult(dst3, src3), 3, 3 * 16 * s ** 3),
              ("ls_curvature_vmult", lambda: cur.compute_curvature_vmult(dst, src, True), 1, 16 * s ** 3)]
+    # right-hand sides (velocity of degree 2 needs a context with the flow spaces)
+    ops_v = lso.LevelSetOperators(mesh, s, velocity_degree=2)
+    ops_v.set_parameters(1.5 * max(mesh.h) / s, 0.02, 75.0, -100.0, 25.0, 1.5)
+    adv_v, rei_v = lso.LevelSetOKZSolverAdvanceConcentration(ops_v), lso.LevelSetOKZSolverReinitialization(ops_v)
+    nu = int(np.prod([2 * n + 1 for n in ncell]))
+    vel = adaflo_amd.DeviceVector.from_numpy(ops_v._ctx, rng.uniform(-1, 1, 3 * nu))
+    phi, old, oo, rhs = (ops_v.vector(rng.uniform(-1, 1, ops_v.n_dofs)) for _ in range(4))
+    nrm = ops_v.vector(rng.uniform(-1, 1, 3 * ops_v.n_dofs), blocks=3)
+    sync_v = lambda: adaflo_amd._lib.load().adaflo_synchronize(ops_v._ctx)
+    nodal = 8 * s ** 3          # bytes per cell of one nodal field
+    rhs_cases = [("ls_advect_rhs", lambda: adv_v.local_advance_concentration_rhs(rhs, phi, old, oo, vel, True), 5 * nodal + 24 * nq + 3 * 8 * 8),
+                 ("ls_reinit_rhs_first", lambda: rei_v.local_reinitialize_rhs(rhs, phi, nrm, False, True), 6 * nodal + 24 * nq),
+                 ("ls_reinit_rhs", lambda: rei_v.local_reinitialize_rhs(rhs, phi, nrm, False, False), 3 * nodal + 24 * nq),
+                 ("ls_reinit_rhs_diffuse", lambda: rei_v.local_reinitialize_rhs(rhs, phi, nrm, True, False), 3 * nodal)]
+    for variant in (1, 0):
+        ops_v.set_kernel_variant(variant)
+        for name, fn, bytes_per_cell in rhs_cases:
+            t = timeit(fn, sync_v)
+            print(json.dumps({"op": name, "variant": variant, "s": s, "cells": list(ncell), "ms": round(t * 1e3, 4),
+                              "alg_GB/s": round(bytes_per_cell * ncells / t / 1e9, 1),
+                              "frac_of_8TB/s": round(bytes_per_cell * ncells / t / 8e12, 4)}), flush=True)
     for name, fn, blocks, bytes_per_cell in cases:
         t = timeit(fn, sync)
         print(json.dumps({"op": name, "s": s, "cells": list(ncell), "ms": round(t * 1e3, 4),
@@ -191,6 +212,9 @@ if __name__ == "__main__":
         for v in (1, 0):
             ns_divergence_case((64, 64, 128), v)
             ns_divergence_case((128, 128, 128), v)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ls":
+        ls_case(4, (64, 64, 128))
         sys.exit(0)
     ns_case(2, 128, 1)
     ns_case(2, 128, 0)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Beltrami time steps on one MI355X: wall clock per step, outer FGMRES iterations and the inner velocity-block
+iterations per preconditioner application, with the fast-diagonalisation inner solves (1) and with the
+Jacobi-preconditioned inner Krylov solves (0).  usage: time_beltrami_step.py [cells_per_direction] [steps]"""
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import adaflo_amd  # noqa: E402
+from adaflo_amd import _lib, beltrami  # noqa: E402
+from adaflo_amd.navier_stokes import NavierStokes, node_coordinates  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    nu = 1.0
+    mesh = adaflo_amd.BrickMesh([n] * 3, [-1.0] * 3, [1.0] * 3)
+    xu, xp = node_coordinates(mesh, 2), node_coordinates(mesh, 1)
+    for inner in (1, 0):
+        fp = adaflo_amd.FlowParameters(velocity_degree=2, viscosity=nu, time_step_size_start=0.05 * 16 / n, end_time=1.0,
+                                       max_nl_iteration=10, tol_nl_iteration=1e-9, max_lin_iteration=100, tol_lin_iteration=1e-5)
+        ns = NavierStokes(fp, mesh, adaflo_amd.TimeStepping(fp), dirichlet_function=lambda x, t: beltrami.velocity(x, t, nu))
+        ctx = ns.navier_stokes_matrix._require()
+        lib = _lib.load()
+        _lib.check(ctx, lib.adaflo_ns_preconditioner_set_inner(ctx, inner))
+        ns.set_initial_condition(beltrami.velocity(xu, 0.0, nu).reshape(-1), beltrami.pressure(xp, 0.0, nu))
+        for step in range(steps):
+            s0, i0 = C.c_int64(), C.c_int64()
+            lib.adaflo_ns_preconditioner_statistics(ctx, C.byref(s0), C.byref(i0))
+            ns.linear_iterations.clear()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ns.advance_time_step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            s1, i1 = C.c_int64(), C.c_int64()
+            lib.adaflo_ns_preconditioner_statistics(ctx, C.byref(s1), C.byref(i1))
+            ns_, ni = s1.value - s0.value, i1.value - i0.value
+            print("inner=%d %d^3 step %d: %.3f s, outer iterations %s, %d velocity solves, %.1f inner iterations each"
+                  % (inner, n, step + 1, dt, [i for i, _ in ns.linear_iterations], ns_, ni / max(ns_, 1)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
