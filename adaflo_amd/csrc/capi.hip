@@ -743,9 +743,18 @@ int adaflo_ns_divergence_vmult_add(adaflo_ctx *ctx, double *dst_p, const double 
   CHECK_CTX(ctx);
   if (!dst_p || !src_u)
     return fail(ctx, ADAFLO_EINVAL, "null vector");
-  // Q2/Q1, constant viscosity, constraints of src resolved (:935-939: plain read only for the
-  // projection scheme): divergence mode of the sweep kernel, then dst += sums on the free rows
-  if (ctx->variant >= 1 && ctx->k == 2 && !(weight_by_viscosity && ctx->mu.p) &&
+  // Q2/Q1, constant viscosity: tensor-product stencil (csrc/ns_divergence.hip); constraints of src
+  // resolved except for the projection scheme (:935-939)
+  if (ctx->variant == 1 && divergence_stencil_supported(ctx) && !(weight_by_viscosity && ctx->mu.p))
+    {
+      TRY(ctx,
+          launch_ns_divergence_stencil(ctx, dst_p, src_u, weight_by_viscosity ? -ctx->ns.viscosity : -1.,
+                                       ctx->ns.linearization == ADAFLO_PROJECTION),
+          "divergence kernel launch failed");
+      return 0;
+    }
+  // variant 2: divergence mode of the sweep kernel, then dst += sums on the free rows
+  if (ctx->variant >= 2 && ctx->k == 2 && !(weight_by_viscosity && ctx->mu.p) &&
       ctx->ns.linearization != ADAFLO_PROJECTION)
     {
       TRY(ctx, alloc(ctx, ctx->res_sum_p, ctx->n_nodes_p), ctx->last_error);

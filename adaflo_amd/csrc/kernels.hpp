@@ -117,6 +117,9 @@ namespace adaflo_hip
   };
   int q1_convert_state(adaflo_ctx *ctx, DeviceBuffer &out, const double *generic_dev);
   int launch_q1_stencil_rhs(adaflo_ctx *ctx, int mode, double *dst, const double *src);
+  // Q2/Q1 divergence as tensor-product stencil (ns_divergence.hip)
+  bool divergence_stencil_supported(const adaflo_ctx *ctx);
+  int  launch_ns_divergence_stencil(adaflo_ctx *ctx, double *dst_p, const double *src_u, double weight, bool plain);
   int q1_state_alloc(adaflo_ctx *ctx, DeviceBuffer &out);
   int q1_unconvert_state(adaflo_ctx *ctx, double *generic_dev, const DeviceBuffer &sweep);
   int launch_q1_rhs(adaflo_ctx *ctx, int kind, int flag, double *dst, const double *f0, const double *f1,

@@ -213,6 +213,11 @@ if __name__ == "__main__":
             ns_divergence_case((64, 64, 128), v)
             ns_divergence_case((128, 128, 128), v)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "div":
+        for v in (1, 2, 0):
+            ns_divergence_case((64, 64, 128), v)
+            ns_divergence_case((128, 128, 128), v)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ls":
         ls_case(4, (64, 64, 128))
         sys.exit(0)
@@ -220,7 +225,7 @@ if __name__ == "__main__":
     ns_case(2, 128, 0)
     ns_residual_case(2, 128, 1)
     ns_residual_case(2, 128, 0)
-    for v in (1, 0):
+    for v in (1, 2, 0):
         ns_divergence_case((64, 64, 128), v)
         ns_divergence_case((128, 128, 128), v)
     ns_host_vector_case(128)

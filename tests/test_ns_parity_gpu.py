@@ -136,6 +136,26 @@ def test_scalar_sub_blocks(k, ncell, variant):
                                                                   case.con_p, mu=c["mu"])) < TOL
 
 
+@pytest.mark.parametrize("ncell,faces_u,faces_p,lin", [((3, 2, 4), range(6), (), 0), ((40, 10, 5), (0, 3, 4), (1,), 0),
+                                                        ((33, 9, 20), (), (2, 5), 0), ((34, 17, 9), (1, 2, 5), (), 0),
+                                                        ((5, 4, 3), range(6), (), 4)])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_divergence_as_tensor_product_stencil(ncell, faces_u, faces_p, lin, variant):
+    """variant 1: Q2 -> Q1 stencil kernel (csrc/ns_divergence.hip), variant 2: divergence mode of the sweep
+    kernel; partial Dirichlet sets, tiles cut by the mesh, the plain read of the projection scheme"""
+    case = Case(ncell, k=2, faces_u=faces_u, faces_p=faces_p, upper=(1.0, 0.7, 1.5), viscosity=0.37, linearization=lin)
+    op = case.engine()
+    op.set_kernel_variant(variant)
+    src_u, base = case.random_u(), case.random_p()
+    su = op.initialize_u_vector(src_u)
+    for wv in (False, True):
+        dp = op.initialize_p_vector(base)
+        op.divergence_vmult_add(dp, su, wv)
+        ref = orc.ns_divergence_vmult_add(case.mesh, 2, case.prm, src_u, base, case.con_u, case.con_p, mu=None,
+                                          weight_by_viscosity=wv)
+        assert rel_l2(dp.numpy(), ref) < TOL
+
+
 def test_beltrami_golden_residual_on_device(oracle):
     """tests/beltrami_3d.output:13 reproduced by the HIP residual kernel."""
     case = Case((16, 16, 16), k=2, steps=1)
