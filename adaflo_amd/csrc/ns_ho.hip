@@ -48,7 +48,11 @@ namespace adaflo_hip
     template <>
     struct HOCfg<4>
     {
-      static constexpr int CPW = 2, WX = 2, WY = 2, PLS = 32; // 25 lanes per cell in a 32-lane half
+      // 25 lanes per cell in a 32-lane half.  Measured alternative (round 2): planes packed to 25 slots,
+      // a compact single-buffered publish area (second barrier per layer) and __launch_bounds__(256, 3)
+      // bring the workgroup under 160 KB / 3, but the 168-VGPR budget of three workgroups per CU spills
+      // 186 registers: 64^3 cells 1.78 -> 6.07 ms per vmult
+      static constexpr int CPW = 2, WX = 2, WY = 2, PLS = 32;
     };
     template <>
     struct HOCfg<5>
