@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Copy the summaries of one `scripts/measure_round.sh <tag>` run from gpurun_out/<tag>/ into profiles/ (tracked)
+and rebuild profiles/pmc_traffic.json, which bench.py reads for `roofline.traffic`.
+usage: collect_profiles.py <tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
+
+
+def program_lines(path):
+    """the program's own output: rocprofv3's timer / warning chatter is dropped"""
+    keep = []
+    for line in open(path, errors="replace"):
+        if line[:1] in "WEI" and "] " in line[:120] and ".cpp:" in line[:120]:
+            continue
+        keep.append(line)
+    return "".join(keep)
+
+
+def counters(directory, pattern):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    for f in glob.glob(directory + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if pattern in r["Kernel_Name"]:
+                acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                meta[r["Kernel_Name"]] = dict(vgpr=r["VGPR_Count"], sgpr=r["SGPR_Count"], lds=r["LDS_Block_Size"],
+                                              scratch=r["Scratch_Size"], grid=r["Grid_Size"], wg=r["Workgroup_Size"])
+    return acc, meta
+
+
+for name in sorted(os.listdir(src)):
+    p = os.path.join(src, name)
+    if os.path.isdir(p):
+        for f in glob.glob(p + "/**/*_kernel_stats.csv", recursive=True):
+            shutil.copy(f, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, name)))
+        acc, meta = counters(p, "")
+        if acc:
+            with open(os.path.join(dst, "%s_%s.txt" % (tag, name)), "w") as out:
+                out.write("# rocprofv3 --pmc pass '%s' (scripts/measure_round.sh): mean counter value per launch\n" % name)
+                for k, ctr in acc.items():
+                    if not any(s in k for s in ("ns_q2", "ns_ho", "seam_fixup", "ho_fixup")):
+                        continue
+                    out.write("%s\n   %s\n" % (k[:140], " ".join("%s=%s" % kv for kv in meta[k].items())))
+                    for c, v in sorted(ctr.items()):
+                        out.write("   %-26s launches %3d  mean %.5e\n" % (c, len(v), sum(v) / len(v)))
+    elif name.endswith(".log"):
+        with open(os.path.join(dst, "%s_%s" % (tag, name)), "w") as out:
+            out.write(program_lines(p))
+
+# HBM bytes per launch of the dominant kernels; gfx950: FETCH_SIZE counts 64 B per 128-B request of wide (16 B per
+# lane) coalesced reads, which is how the Q2/Q1 kernel issues all its loads (MI355X_MICROARCH.md, HBM section)
+traffic = {"_comment": "scripts/collect_profiles.py from scripts/measure_round.sh %s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
+                       "separate passes of bench.py --steps 5 --warmup 2; KB per launch averaged.  ns_q2_kernel: hbm_bytes = "
+                       "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction for 16-B-per-lane streaming reads).  ns_ho_kernel "
+                       "reads 8 B per lane: the correction is not calibrated for that width, so both the raw "
+                       "(FETCH_SIZE + WRITE_SIZE) and the doubled figure are given and hbm_bytes is left null." % tag}
+
+
+def mean_kb(pass_name, kernel, counter):
+    acc, _ = counters(os.path.join(src, pass_name), kernel)
+    v = [x for ctr in acc.values() for x in ctr.get(counter, [])]
+    return sum(v) / len(v) if v else None
+
+
+VMULT_Q2 = "ns_q2_kernel<0, true, true, false, false, false>"   # (the residual mode <..., true, false> runs once as set-up)
+f, w = mean_kb("pmc_q2_fetch", VMULT_Q2, "FETCH_SIZE"), mean_kb("pmc_q2_write", VMULT_Q2, "WRITE_SIZE")
+if f and w:
+    traffic["128x128x128 k=2 variant=1"] = {"ns_q2_kernel": {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
+                                                                "hbm_bytes": int((2 * f + w) * 1024)}}
+f, w = mean_kb("pmc_q4_fetch", "ns_ho_kernel", "FETCH_SIZE"), mean_kb("pmc_q4_write", "ns_ho_kernel", "WRITE_SIZE")
+if f and w:
+    traffic["64x64x64 k=4 variant=1"] = {"ns_ho_kernel": {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes": None,
+                                                             "raw_bytes": int((f + w) * 1024),
+                                                             "fetch_doubled_bytes": int((2 * f + w) * 1024)}}
+with open(os.path.join(dst, "pmc_traffic.json"), "w") as out:
+    json.dump(traffic, out, indent=1)
+print(json.dumps(traffic, indent=1))

@@ -1,0 +1,37 @@
+#!/bin/bash
+# All measurements behind DESIGN.md / profiles/ of one round, on the GPU box:
+#   gpurun --timeout 3000 -- 'bash scripts/measure_round.sh r02'
+# writes gpurun_out/<tag>/<name>/*_kernel_stats.csv + <name>.log; scripts/collect_profiles.py copies the
+# summaries into profiles/ and builds profiles/pmc_traffic.json.
+tag=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$tag
+mkdir -p "$O"
+cd /tmp && export TMPDIR=/tmp
+prof() { # name, program ...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$O/$name" -o "$name" -- "$@" > "$O/$name.log" 2>&1
+}
+pmc() { # name, counters, program ...
+  local name=$1 ctr=$2; shift 2
+  rocprofv3 --pmc $ctr --output-format csv -d "$O/$name" -o "$name" -- "$@" > "$O/$name.log" 2>&1
+}
+prof bench_n1 python3 $R/bench.py
+prof bench_cavity_q4 python3 $R/bench.py --config cavity
+prof bench_160cubed python3 $R/bench.py --cells 160 --no-cpu-baseline
+prof ops python3 $R/scripts/bench_ops.py
+prof two_phase_step python3 $R/scripts/time_two_phase.py 64 4
+prof beltrami64_step python3 $R/scripts/time_beltrami_step.py 64 3
+# HBM traffic of the two dominant kernels: separate counter passes (MI355X_MICROARCH.md)
+pmc pmc_q2_fetch FETCH_SIZE python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline
+pmc pmc_q2_write WRITE_SIZE python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline
+pmc pmc_q4_fetch FETCH_SIZE python3 $R/bench.py --config cavity --steps 5 --warmup 2 --no-cpu-baseline
+pmc pmc_q4_write WRITE_SIZE python3 $R/bench.py --config cavity --steps 5 --warmup 2 --no-cpu-baseline
+pmc pmc_q4_sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" python3 $R/bench.py --config cavity --steps 5 --warmup 2 --no-cpu-baseline
+pmc pmc_q4_sq2 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" python3 $R/bench.py --config cavity --steps 5 --warmup 2 --no-cpu-baseline
+# no rocprof: the plain bench lines and the large meshes
+cd $R
+python3 bench.py > "$O/bench_n1_plain.log" 2>&1
+python3 bench.py --cells 256 --steps 20 --warmup 3 --no-cpu-baseline > "$O/bench_256cubed_one_gpu.log" 2>&1
+python3 bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline > "$O/bench_2ranks_one_gpu.log" 2>&1
+echo done > "$O/done"
