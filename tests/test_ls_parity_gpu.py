@@ -130,6 +130,45 @@ def test_ls_right_hand_sides(s, ncell, faces, variant):
         assert rel_l2(adv.evaluated_convection, uq_ref) < TOL
 
 
+@pytest.mark.parametrize("s,k,ncell,faces", [(3, 2, (7, 6, 5), ()), (3, 3, (6, 7, 3), (1, 2)), (4, 4, (5, 3, 2), ()),
+                                             (1, 3, (18, 17, 6), (0,)), (2, 4, (9, 2, 3), (4, 5))])
+def test_sweep_right_hand_sides_unaligned_tiles_and_velocity_degrees(s, k, ncell, faces):
+    """advection / reinitialisation right-hand sides on the sweep structure (csrc/q1_sweep.hip) where the 16 x 16
+    sub-cell tiles are not aligned with the cells (s = 3) and for velocity degrees 3 and 4: the velocity patch of
+    a tile starts inside a cell, several tiles and z-chunks; evaluated_* read back through the generic layout"""
+    c = LSCase(ncell, s, k=k, faces=faces)
+    phi, old, oldold, normal = c.rand(), c.rand(), c.rand(), c.rand(3)
+    vel = c.rng.uniform(-1, 1, c.mesh.n_nodes(k) * 3)
+    adv, rei = lso.LevelSetOKZSolverAdvanceConcentration(c.ops), lso.LevelSetOKZSolverReinitialization(c.ops)
+    for use_oo in (True, False):
+        uq_ref = np.zeros(c.mesh.n_cells * c.nq * 3)
+        base = c.rand()                                     # the kernels ADD into dst
+        ref = base + orc.ls_advect_rhs(c.mesh, c.prm, k, phi, old, oldold, vel, uq_ref, c.w_old, c.w_oo, use_oo, con=c.con)
+        d = c.ops.vector(base)
+        adv.local_advance_concentration_rhs(d, c.ops.vector(phi), c.ops.vector(old), c.ops.vector(oldold),
+                                            c.ops.velocity_vector(vel), use_oo)
+        assert rel_l2(d.numpy(), ref) < TOL
+        assert rel_l2(adv.evaluated_convection, uq_ref) < TOL
+    # the operator reads the state the right-hand side left in sweep layout
+    src, dst = c.rand(), c.ops.vector()
+    adv.advance_concentration_vmult(dst, c.ops.vector(src))
+    ref = orc.ls_advect_vmult(c.mesh, c.prm, src, uq_ref, con=c.con, diag=c.diag if faces else None)
+    assert rel_l2(dst.numpy(), ref) < TOL
+    nq_ref = np.zeros(c.mesh.n_cells * c.nq * 3)
+    for first in (True, False):
+        base = c.rand()
+        ref = base + orc.ls_reinit_rhs(c.mesh, c.prm, phi, normal, nq_ref, diffuse_only=False, first_step=first, con=c.con)
+        d = c.ops.vector(base)
+        rei.local_reinitialize_rhs(d, c.ops.vector(phi), c.ops.vector(normal, blocks=3) if first else None, False, first)
+        assert rel_l2(d.numpy(), ref) < TOL
+    assert rel_l2(rei.evaluated_normal, nq_ref) < TOL
+    base = c.rand()
+    ref = base + orc.ls_reinit_rhs(c.mesh, c.prm, phi, normal, nq_ref, diffuse_only=True, first_step=False, con=c.con)
+    d = c.ops.vector(base)
+    rei.local_reinitialize_rhs(d, c.ops.vector(phi), None, True, False)
+    assert rel_l2(d.numpy(), ref) < TOL
+
+
 def test_full_size_properties_config4():
     """Config 4 (40x40x80 cells, s = 4, 8.3 M level-set DoF): the structured Q1 sweep kernel and
     the generic per-cell kernels (independent code) agree for every operator application, and
