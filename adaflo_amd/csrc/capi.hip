@@ -73,7 +73,7 @@ namespace
   int upload(adaflo_ctx *ctx, double **dptr, const std::vector<double> &host)
   {
     HIP_TRY(ctx, hipMalloc(dptr, host.size() * sizeof(double)));
-    HIP_TRY(ctx, hipMemcpy(*dptr, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, copy_to_device_now(*dptr, host.data(), host.size() * sizeof(double)));
     return 0;
   }
 

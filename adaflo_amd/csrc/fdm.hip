@@ -306,9 +306,9 @@ namespace adaflo_hip
       if (hipMalloc(&E.d_S, sizeof(double) * n * n) != hipSuccess || hipMalloc(&E.d_St, sizeof(double) * n * n) != hipSuccess ||
           hipMalloc(&E.d_lam, sizeof(double) * n) != hipSuccess)
         return ADAFLO_ENOMEM;
-      if (hipMemcpy(E.d_S, S.data(), sizeof(double) * n * n, hipMemcpyHostToDevice) != hipSuccess ||
-          hipMemcpy(E.d_St, St.data(), sizeof(double) * n * n, hipMemcpyHostToDevice) != hipSuccess ||
-          hipMemcpy(E.d_lam, lam.data(), sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess)
+      if (copy_to_device_now(E.d_S, S.data(), sizeof(double) * n * n) != hipSuccess ||
+          copy_to_device_now(E.d_St, St.data(), sizeof(double) * n * n) != hipSuccess ||
+          copy_to_device_now(E.d_lam, lam.data(), sizeof(double) * n) != hipSuccess)
         return ADAFLO_EHIP;
       return 0;
     }

@@ -8,6 +8,20 @@
 
 namespace adaflo_hip
 {
+  // Host -> device copy of set-up data (1D tables, plans) that kernels on the context's stream read next.
+  // A synchronous hipMemcpy from pageable memory may return as soon as the data is staged, and only work on
+  // the NULL stream is ordered after it -- the contexts' streams are created non-blocking, so a kernel
+  // launched right afterwards could read the buffer before the DMA has landed (seen as a 1-in-20 wrong
+  // pressure mass weight vector right after adaflo_ctx_create).  Hence: copy, then wait for the device.
+  inline hipError_t copy_to_device_now(void *dst, const void *src, const size_t bytes)
+  {
+    const hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    return e != hipSuccess ? e : hipDeviceSynchronize();
+  }
+} // namespace adaflo_hip
+
+namespace adaflo_hip
+{
   enum NSOp
   {
     OP_VMULT          = 0, // NavierStokesOps::vmult        include/adaflo/navier_stokes_matrix.h:36-41

@@ -474,7 +474,9 @@ namespace adaflo_hip
     // pressure -> pressure operators
     const bool need_val  = mode == SC_MASS;
     const bool need_grad = mode == SC_POISSON_VARIABLE || mode == SC_POISSON_CELL || mode == SC_CONVDIFF;
-    if (mode != SC_MASS_WEIGHT)
+    if (mode == SC_MASS_WEIGHT)
+      __syncthreads(); // the 1D tables staged above are read across waves below (k = 5: 125 points, 4 waves)
+    else
       {
         gather_cell<K - 1, 1, NT, true>(a.src, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
         __syncthreads();

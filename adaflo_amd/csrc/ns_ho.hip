@@ -1153,7 +1153,7 @@ namespace adaflo_hip
             tab.push_back(A.w[q]);
           if (int e = ensure(ctx->ho_tab, tab.size()))
             return e;
-          if (hipMemcpy(ctx->ho_tab.p, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+          if (copy_to_device_now(ctx->ho_tab.p, tab.data(), tab.size() * sizeof(double)) != hipSuccess)
             return ADAFLO_EHIP;
         }
       A.tab = ctx->ho_tab.p;

@@ -1645,7 +1645,7 @@ namespace adaflo_hip
             ctx->q2_wg_list = nullptr;
             if (hipMalloc(&ctx->q2_wg_list, sizeof(int) * (bnd.size() + 1)) != hipSuccess)
               return ADAFLO_ENOMEM;
-            if (hipMemcpy(ctx->q2_wg_list, bnd.data(), sizeof(int) * bnd.size(), hipMemcpyHostToDevice) != hipSuccess)
+            if (copy_to_device_now(ctx->q2_wg_list, bnd.data(), sizeof(int) * bnd.size()) != hipSuccess)
               return ADAFLO_EHIP;
             std::memcpy(ctx->q2_wg_key, key, sizeof(key));
           }
