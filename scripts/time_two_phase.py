@@ -23,6 +23,9 @@ def main():
     mesh = adaflo_amd.BrickMesh([n, n, 2 * n], [0., 0., 0.], [1., 1., 2.])
     solver = LevelSetOKZSolver(fp, mesh, lambda x: np.linalg.norm(x - 0.5, axis=1) - 0.25)
     ns = solver.navier_stokes
+    if len(sys.argv) > 3:      # inner solves of the block preconditioner: 1 fast diagonalisation, 0 Jacobi
+        ctx = ns.navier_stokes_matrix._require()
+        adaflo_amd._lib.check(ctx, adaflo_amd._lib.load().adaflo_ns_preconditioner_set_inner(ctx, int(sys.argv[3])))
 
     def timed(name, fn, acc):
         torch.cuda.synchronize()
@@ -52,7 +55,11 @@ def main():
             res = timed("compute_residual", ns.compute_residual, acc)
             if res < p.tol_nl_iteration:
                 break
-        print("step %d: total %.3f s | " % (step + 1, sum(acc.values())) + "  ".join("%s %.0f ms" % (k, 1e3 * v) for k, v in acc.items()), flush=True)
+        import ctypes as C
+        sv, iv = C.c_int64(), C.c_int64()
+        adaflo_amd._lib.load().adaflo_ns_preconditioner_statistics(ns.navier_stokes_matrix._require(), C.byref(sv), C.byref(iv))
+        print("step %d: total %.3f s | " % (step + 1, sum(acc.values())) + "  ".join("%s %.0f ms" % (k, 1e3 * v) for k, v in acc.items())
+              + " | %d velocity solves, %.1f inner iterations each" % (sv.value, iv.value / max(sv.value, 1)), flush=True)
 
 
 if __name__ == "__main__":
