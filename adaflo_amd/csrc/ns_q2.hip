@@ -1539,7 +1539,9 @@ namespace adaflo_hip
     // z-chunk length: aim at >= 4 resident rounds of 512 workgroups, chunks >= 8 layers
     {
       const long tiles = (long)A.tiles_x * A.tiles_y;
-      int        lz    = ctx->q2_lz > 0 ? ctx->q2_lz : 16;
+      // z-chunks of 32 cell layers while that leaves >= 1024 workgroups (128^3: 36.1 against 35.5 GDoF/s with 16:
+      // fewer chunk prologues and chunk-boundary planes in the fix-up pass)
+      int        lz    = ctx->q2_lz > 0 ? ctx->q2_lz : 32;
       while (lz > 4 && tiles * ((A.ncz + lz - 1) / lz) < 1024)
         lz /= 2;
       if (lz > A.ncz)
