@@ -1097,7 +1097,7 @@ namespace adaflo_hip
       A.tiles_y = (A.ncy + C::TCY - 1) / C::TCY;
       {
         const long tiles = (long)A.tiles_x * A.tiles_y;
-        int        lz    = 16;
+        int        lz    = 8; // (64^3 Q4: 4 / 8 / 16 / 32 layers per chunk -> 1.534 / 1.533 / 1.584 / 1.578 ms)
         while (lz > 2 && tiles * ((A.ncz + lz - 1) / lz) < 1024)
           lz /= 2;
         if (lz > A.ncz)
