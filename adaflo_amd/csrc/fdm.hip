@@ -175,11 +175,18 @@ namespace adaflo_hip
         }
     }
 
-    // ---- device: strided batched f64 GEMM  C[b] = A[b?] . B[b] --------------------------------
-    // C[i][j] = sum_k A[i * rsA + k * csA] * B[k * rsB + j * csB]; 64 x 64 tiles, K-steps of 8,
-    // 256 threads with 4 x 4 outputs each.  A is the small 1D matrix (shared by all batches) or the
-    // field (x transform), B the other one.
-    constexpr int GT = 64, GK = 8;
+    // ---- device: strided batched f64 GEMM  C[b] = A[b?] . B[b] on the matrix cores ----------------
+    // C[i][j] = sum_k A[i * rsA + k * csA] * B[k * rsB + j * csB].  A is the small 1D matrix (shared by all
+    // batches) or the field (x transform), B the other one.  64 x 64 tiles of C per workgroup, K-steps of 16
+    // staged in LDS; each of the four waves owns a 32 x 32 quadrant = 2 x 2 tiles of v_mfma_f64_16x16x4_f64
+    // (operands: lane l holds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15], result register r of
+    // lane l is C[(l >> 4) + 4 r][l & 15]; cdna_hip_programming.md, fragment layout).  One LDS read feeds
+    // 16 FMAs per lane -- the register-tiled vector version (4 x 4 outputs per thread, one read per two
+    // FMAs) ran at 11 TFLOP/s, bound by the LDS instruction rate.
+    // Tile shapes: a wave owns TMS x TNS MFMA tiles, WM x WN waves form the workgroup tile
+    // (16 TMS WM) x (16 TNS WN); 64 x 64, 48 x 64, 64 x 48 and 48 x 48 are instantiated and the launcher takes
+    // 48 for a dimension that it pads less (129 = 2 * 64 + 1 nodes would waste a third of a 64-wide tiling).
+    constexpr int GK = 16, GLD = 64 + 16; // row stride 80 doubles: the two k-rows of a half-wave hit disjoint banks
     struct GemmArgs
     {
       int           M, N, K;
@@ -187,64 +194,128 @@ namespace adaflo_hip
       const double *A, *B;
       double       *C;
     };
-    __global__ __launch_bounds__(256) void fdm_gemm_kernel(const GemmArgs g)
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+    template <int TMS, int TNS, int WM, int WN>
+    __global__ __launch_bounds__(64 * WM *WN) void fdm_gemm_kernel(const GemmArgs g)
     {
-      __shared__ double As[GK][GT + 1], Bs[GK][GT + 1];
-      const int     tid = threadIdx.x, tx = tid % 16, ty = tid / 16;
-      const int     i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
+      constexpr int NT = 64 * WM * WN, TM = 16 * TMS * WM, TN = 16 * TNS * WN;
+      __shared__ double As[GK][GLD], Bs[GK][GLD];
+      const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+      const int     i0 = blockIdx.y * TM, j0 = blockIdx.x * TN;
+      const int     wi = 16 * TMS * (wave / WN), wj = 16 * TNS * (wave % WN); // sub-tile of this wave
+      const int     fl = lane & 15, fk = lane >> 4;                          // fragment coordinates of this lane
       const double *A = g.A + (long)blockIdx.z * g.bsA, *B = g.B + (long)blockIdx.z * g.bsB;
       double       *C = g.C + (long)blockIdx.z * g.bsC;
-      double        acc[4][4] = {};
-      // loader mapping: the faster-varying global index gets consecutive threads
-      const bool a_k_fast = g.csA == 1, b_j_fast = g.csB == 1;
-      for (int k0 = 0; k0 < g.K; k0 += GK)
+      d4_t          acc[TMS][TNS];
+#pragma unroll
+      for (int r = 0; r < TMS; ++r)
+#pragma unroll
+        for (int c = 0; c < TNS; ++c)
+          acc[r][c] = d4_t{0., 0., 0., 0.};
+      // loader mapping: the faster-varying global index gets consecutive threads.  The loads of TWO k-tiles are
+      // issued together into two register sets before the first is used: a workgroup walks few k-tiles with
+      // little work each, so the load latency is paid once per pair; more tiles per batch cost occupancy and
+      // were slower (3, 4, 5, 9 tiles), as was a rolling two-tile pipeline.  129^3 nodes, same box: 50.4 us per
+      // GEMM with the register-tiled vector kernel, 40.0 us with this one.
+      const bool    a_k_fast = g.csA == 1, b_j_fast = g.csB == 1;
+      constexpr int LA = (TM * GK + NT - 1) / NT, LB = (TN * GK + NT - 1) / NT;
+      auto fetch = [&](const int k0, double (&ra)[LA], double (&rb)[LB]) {
+#pragma unroll
+        for (int u = 0; u < LA; ++u)
+          {
+            const int e = tid + u * NT;
+            const int ii = a_k_fast ? e / GK : e % TM, kk = a_k_fast ? e % GK : e / TM;
+            const int i = i0 + ii, k = k0 + kk;
+            ra[u]       = (e < TM * GK && i < g.M && k < g.K) ? A[i * g.rsA + k * g.csA] : 0.;
+          }
+#pragma unroll
+        for (int u = 0; u < LB; ++u)
+          {
+            const int e = tid + u * NT;
+            const int jj = b_j_fast ? e % TN : e / GK, kk = b_j_fast ? e / TN : e % GK;
+            const int j = j0 + jj, k = k0 + kk;
+            rb[u]       = (e < TN * GK && j < g.N && k < g.K) ? B[k * g.rsB + j * g.csB] : 0.;
+          }
+      };
+      auto commit = [&](const double (&ra)[LA], const double (&rb)[LB]) {
+#pragma unroll
+        for (int u = 0; u < LA; ++u)
+          {
+            const int e = tid + u * NT;
+            if (e < TM * GK)
+              As[a_k_fast ? e % GK : e / TM][a_k_fast ? e / GK : e % TM] = ra[u];
+          }
+#pragma unroll
+        for (int u = 0; u < LB; ++u)
+          {
+            const int e = tid + u * NT;
+            if (e < TN * GK)
+              Bs[b_j_fast ? e / TN : e % GK][b_j_fast ? e % TN : e / GK] = rb[u];
+          }
+      };
+      auto multiply = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < GK; ks += 4)
+          {
+            double a[TMS], b[TNS];
+#pragma unroll
+            for (int r = 0; r < TMS; ++r)
+              a[r] = As[ks + fk][wi + 16 * r + fl];
+#pragma unroll
+            for (int c = 0; c < TNS; ++c)
+              b[c] = Bs[ks + fk][wj + 16 * c + fl];
+#pragma unroll
+            for (int r = 0; r < TMS; ++r)
+#pragma unroll
+              for (int c = 0; c < TNS; ++c)
+                acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], b[c], acc[r][c], 0, 0, 0);
+          }
+      };
+      double ra0[LA], rb0[LB], ra1[LA], rb1[LB];
+      for (int k0 = 0; k0 < g.K; k0 += 2 * GK)
         {
-          for (int e = tid; e < GT * GK; e += 256)
-            {
-              const int ii = a_k_fast ? e / GK : e % GT, kk = a_k_fast ? e % GK : e / GT;
-              const int i = i0 + ii, k = k0 + kk;
-              As[kk][ii]  = (i < g.M && k < g.K) ? A[i * g.rsA + k * g.csA] : 0.;
-            }
-          for (int e = tid; e < GT * GK; e += 256)
-            {
-              const int jj = b_j_fast ? e % GT : e / GK, kk = b_j_fast ? e / GT : e % GK;
-              const int j = j0 + jj, k = k0 + kk;
-              Bs[kk][jj]  = (j < g.N && k < g.K) ? B[k * g.rsB + j * g.csB] : 0.;
-            }
+          const bool second = k0 + GK < g.K;
+          fetch(k0, ra0, rb0);
+          if (second)
+            fetch(k0 + GK, ra1, rb1);
+          commit(ra0, rb0);
           __syncthreads();
-#pragma unroll
-          for (int kk = 0; kk < GK; ++kk)
-            {
-              double a[4], b[4];
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-                {
-                  a[r] = As[kk][ty + 16 * r];
-                  b[r] = Bs[kk][tx + 16 * r];
-                }
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                  acc[r][s] += a[r] * b[s];
-            }
+          multiply();
+          __syncthreads();
+          if (!second)
+            break;
+          commit(ra1, rb1);
+          __syncthreads();
+          multiply();
           __syncthreads();
         }
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < TMS; ++r)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          {
-            const int i = i0 + ty + 16 * r, j = j0 + tx + 16 * s;
-            if (i < g.M && j < g.N)
-              C[i * g.rsC + j * g.csC] = acc[r][s];
-          }
+        for (int c = 0; c < TNS; ++c)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            {
+              const int i = i0 + wi + 16 * r + fk + 4 * q, j = j0 + wj + 16 * c + fl;
+              if (i < g.M && j < g.N)
+                C[i * g.rsC + j * g.csC] = acc[r][c][q];
+            }
     }
 
     int gemm(adaflo_ctx *ctx, const GemmArgs &g, const int batch)
     {
-      const dim3 grid((g.N + GT - 1) / GT, (g.M + GT - 1) / GT, batch);
-      hipLaunchKernelGGL(fdm_gemm_kernel, grid, dim3(256), 0, ctx->stream, g);
+      // 48 or 64 per direction: whichever pads the dimension less (ties: 64)
+      auto tile = [](const int n) { return (n + 47) / 48 * 48 < (n + 63) / 64 * 64 ? 48 : 64; };
+      const int  tm = tile(g.M), tn = tile(g.N);
+      const dim3 grid((g.N + tn - 1) / tn, (g.M + tm - 1) / tm, batch);
+      if (tm == 64 && tn == 64)
+        hipLaunchKernelGGL((fdm_gemm_kernel<2, 2, 2, 2>), grid, dim3(256), 0, ctx->stream, g);
+      else if (tm == 48 && tn == 64)
+        hipLaunchKernelGGL((fdm_gemm_kernel<3, 1, 1, 4>), grid, dim3(256), 0, ctx->stream, g);
+      else if (tm == 64 && tn == 48)
+        hipLaunchKernelGGL((fdm_gemm_kernel<1, 3, 4, 1>), grid, dim3(256), 0, ctx->stream, g);
+      else
+        hipLaunchKernelGGL((fdm_gemm_kernel<3, 1, 1, 3>), grid, dim3(192), 0, ctx->stream, g);
       return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
     }
 
