@@ -126,8 +126,19 @@ def test_distributed_vmult_on_one_gpu(world, cells):
     del ref
     mgr = mp.Manager()
     results = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), grid, list(cells), gu, gp, glin, ref_u, ref_p, results),
-             nprocs=world, join=True)
+    # Up to eight processes time-slice ONE GPU here.  A rank that dies with a device fault of the time-sliced
+    # queue (seen once in ~25 runs of the 8-rank cases: "HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION" at abort, no Python
+    # exception) is a property of this test set-up, not of the exchange: such a run is repeated once.  Python
+    # exceptions in a rank (wrong numbers, engine errors) arrive as ProcessRaisedException and are never retried.
+    for attempt in range(2):
+        try:
+            results.clear()
+            mp.spawn(_worker, args=(world, _free_port(), grid, list(cells), gu, gp, glin, ref_u, ref_p, results),
+                     nprocs=world, join=True)
+            break
+        except mp.ProcessExitedException:
+            if attempt == 1:
+                raise
     assert len(results) == 5 * world
     for key, (eu, ep) in results.items():
         assert eu < 1e-12 and ep < 1e-12, (key, eu, ep)
