@@ -914,8 +914,10 @@ int adaflo_set_timing(adaflo_ctx *ctx, int enabled)
 int adaflo_fdm_apply(adaflo_ctx *ctx, int field, double *dst, const double *src, double c_mass, double c_lap)
 {
   CHECK_CTX(ctx);
-  if (!dst || !src || field < 0 || field > 1)
+  if (!dst || !src || field < 0 || field > 2)
     return fail(ctx, ADAFLO_EINVAL, "invalid arguments");
+  if (field == 2 && ctx->s <= 0)
+    return fail(ctx, ADAFLO_ENOTINIT, "context without a level-set space");
   TRY(ctx, fdm_apply(ctx, field, dst, src, c_mass, c_lap), "fast-diagonalisation solve failed");
   return 0;
 }
@@ -1463,6 +1465,26 @@ int adaflo_ls_projection_vmult(adaflo_ctx *ctx, double *dst, const double *src)
   CHECK_CTX(ctx);
   return ls_vmult(ctx, dst, src, 3 /*LS_NORMAL*/, 1, nullptr, 1); // one scalar block of the normal operator
 }
+
+int adaflo_ls_projection_solve(adaflo_ctx *ctx, double *dst, const double *rhs, int n_blocks)
+{
+  CHECK_CTX(ctx);
+  if (int e = ls_ready(ctx))
+    return e;
+  if (!dst || !rhs || n_blocks < 1)
+    return fail(ctx, ADAFLO_EINVAL, "invalid arguments");
+  if (ctx->brick.con_ls != 0u) // (constrained rows of the operator carry the user's diagonal, not the identity)
+    return fail(ctx, ADAFLO_EUNSUPPORTED, "exact projection solve needs an unconstrained level-set space");
+  // the damping of compute_normal.cc:107-110 / level_set_okz.cc:262-312: 4 max(eps_used / eps, h / s)^2
+  const LSDev &P     = ctx->ls;
+  const double hcell = std::max(ctx->desc.h[0], std::max(ctx->desc.h[1], ctx->desc.h[2]));
+  const double b     = std::max(P.epsilon_used / P.epsilon, hcell / ctx->s);
+  for (int blk = 0; blk < n_blocks; ++blk)
+    TRY(ctx, fdm_apply(ctx, 2, dst + (size_t)blk * ctx->n_nodes_ls, rhs + (size_t)blk * ctx->n_nodes_ls, 1., 4. * b * b),
+        "fast-diagonalisation solve failed");
+  return 0;
+}
+
 
 int adaflo_ls_compute_normal_rhs(adaflo_ctx *ctx, double *dst, const double *level_set_solution)
 {

@@ -175,6 +175,50 @@ namespace adaflo_hip
         }
     }
 
+    // Degree 1 on a uniform grid: M = h/6 tridiag(1, 4, 1), K = 1/h tridiag(-1, 2, -1) (half rows at a
+    // natural end) have the cosine / sine vectors as common eigenvectors for all four combinations of
+    // Dirichlet and natural ends,
+    //   natural - natural    v_k(j) = cos(k pi j / N),        k = 0 .. N
+    //   Dirichlet - Dirichlet v_k(j) = sin(k pi j / N),        k = 1 .. N - 1
+    //   Dirichlet - natural  v_k(j) = sin((k + 1/2) pi j / N), k = 0 .. N - 1
+    //   natural - Dirichlet  v_k(j) = cos((k + 1/2) pi j / N), k = 0 .. N - 1
+    // with K v = lambda M v, lambda = 6 (1 - cos t) / (h^2 (2 + cos t)), t the frequency times pi / N.
+    // The level-set space has up to 513 nodes per direction, where the cyclic Jacobi solver above would take
+    // seconds.  Same output convention as generalized_eig.
+    void linear_eig(const int n, const double h, const bool lo, const bool hi, std::vector<double> &S, std::vector<double> &lam)
+    {
+      const int    N  = n - 1;
+      const double pi = 3.14159265358979323846;
+      S.assign((size_t)n * n, 0.);
+      lam.assign(n, -1.);
+      const int j0 = lo ? 1 : 0, j1 = hi ? N - 1 : N, m = j1 - j0 + 1;
+      for (int col = 0; col < m; ++col)
+        {
+          const double f = (lo == hi) ? (double)(col + (lo ? 1 : 0)) : col + 0.5; // frequency
+          const double t = f * pi / N;
+          std::vector<double> v(n, 0.);
+          for (int j = j0; j <= j1; ++j)
+            v[j] = lo ? std::sin(t * j) : std::cos(t * j);
+          // v^T M v with the free block of M
+          double nrm = 0.;
+          for (int j = j0; j <= j1; ++j)
+            {
+              const double diag = ((j > 0 ? 1. : 0.) + (j < N ? 1. : 0.)) * h / 3.;
+              double       mv   = diag * v[j];
+              if (j > j0)
+                mv += h / 6. * v[j - 1];
+              if (j < j1)
+                mv += h / 6. * v[j + 1];
+              nrm += v[j] * mv;
+            }
+          const double sc = 1. / std::sqrt(nrm);
+          for (int j = j0; j <= j1; ++j)
+            S[(size_t)j * n + col] = v[j] * sc;
+          const double c = std::cos(t);
+          lam[col]       = std::max(6. * (1. - c) / (h * h * (2. + c)), 0.);
+        }
+    }
+
     // ---- device: strided batched f64 GEMM  C[b] = A[b?] . B[b] on the matrix cores ----------------
     // C[i][j] = sum_k A[i * rsA + k * csA] * B[k * rsB + j * csB].  A is the small 1D matrix (shared by all
     // batches) or the field (x transform), B the other one.  64 x 64 tiles of C per workgroup, K-steps of 16
@@ -361,7 +405,8 @@ namespace adaflo_hip
     };
     struct Fdm
     {
-      FieldFdm                        field[2];
+      FieldFdm                        field[3];
+      bool                            ready[3] = {false, false, false};
       std::map<std::vector<long>, Eig1D> cache;
       double                         *w0 = nullptr, *w1 = nullptr;
       size_t                          wcount = 0;
@@ -402,64 +447,91 @@ namespace adaflo_hip
   }
 
   // field 0: velocity space FE_Q(k)^3 with quad_index_u, field 1: pressure space FE_Q(k-1) with
-  // quad_index_p; Dirichlet nodes as in the brick's constraint masks
-  int fdm_setup(adaflo_ctx *ctx)
+  // quad_index_p, field 2: level-set space FE_Q_iso_Q1(s) = FE_Q(1) on the s-times refined grid with the
+  // 2-point rule; Dirichlet nodes as in the brick's constraint masks.  Fields are set up on first use.
+  static int fdm_setup_field(adaflo_ctx *ctx, const int f)
   {
-    if (ctx->fdm)
+    if (!ctx->fdm)
+      ctx->fdm = new Fdm;
+    Fdm *F = static_cast<Fdm *>(ctx->fdm);
+    if (F->ready[f])
       return 0;
-    Fdm *F   = new Fdm;
-    ctx->fdm = F;
-    for (int f = 0; f < 2; ++f)
-      {
-        FieldFdm &fd = F->field[f];
-        fd.degree    = f == 0 ? ctx->k : ctx->k - 1;
-        fd.ncomp     = f == 0 ? 3 : 1;
-        const int      nq   = f == 0 ? ctx->k + 1 : ctx->k;
-        const uint32_t mask = f == 0 ? ctx->brick.con_u : ctx->brick.con_p;
-        for (int d = 0; d < 3; ++d)
-          fd.nn[d] = fd.degree * ctx->desc.ncell[d] + 1;
-        for (int c = 0; c < fd.ncomp; ++c)
-          for (int d = 0; d < 3; ++d)
+    if (f == 2 && ctx->s <= 0)
+      return ADAFLO_ENOTINIT;
+    FieldFdm &fd = F->field[f];
+    fd.degree    = f == 0 ? ctx->k : (f == 1 ? ctx->k - 1 : 1);
+    fd.ncomp     = f == 0 ? 3 : 1;
+    const int      sub  = f == 2 ? ctx->s : 1;
+    const int      nq   = f == 0 ? ctx->k + 1 : (f == 1 ? ctx->k : 2);
+    const uint32_t mask = f == 0 ? ctx->brick.con_u : (f == 1 ? ctx->brick.con_p : ctx->brick.con_ls);
+    for (int d = 0; d < 3; ++d)
+      fd.nn[d] = fd.degree * sub * ctx->desc.ncell[d] + 1;
+    for (int c = 0; c < fd.ncomp; ++c)
+      for (int d = 0; d < 3; ++d)
+        {
+          const int    stride = fd.ncomp == 1 ? 1 : 3, ncell = sub * ctx->desc.ncell[d];
+          const double h      = ctx->desc.h[d] / sub;
+          const bool   lo = mask >> (stride * (2 * d) + c) & 1u, hi = mask >> (stride * (2 * d + 1) + c) & 1u;
+          const std::vector<long> key = {fd.degree, ncell, (long)std::llround(h * 1e15), nq, lo, hi};
+          auto it = F->cache.find(key);
+          if (it == F->cache.end())
             {
-              const int  stride = fd.ncomp == 1 ? 1 : 3;
-              const bool lo = mask >> (stride * (2 * d) + c) & 1u, hi = mask >> (stride * (2 * d + 1) + c) & 1u;
-              const std::vector<long> key = {fd.degree, ctx->desc.ncell[d], (long)std::llround(ctx->desc.h[d] * 1e15), nq, lo, hi};
-              auto it = F->cache.find(key);
-              if (it == F->cache.end())
+              const int           n = fd.nn[d];
+              std::vector<double> S, lam;
+              if (fd.degree == 1)
+                linear_eig(n, h, lo, hi, S, lam);
+              else
                 {
-                  const int           n = fd.nn[d];
-                  std::vector<double> M, K, S, lam;
-                  assemble_1d(fd.degree, ctx->desc.ncell[d], ctx->desc.h[d], nq, M, K);
+                  std::vector<double> M, K;
+                  assemble_1d(fd.degree, ncell, h, nq, M, K);
                   std::vector<char> con(n, 0);
                   con[0]     = lo;
                   con[n - 1] = hi;
                   generalized_eig(n, K, M, con, S, lam);
-                  Eig1D E;
-                  if (int e = upload_eig(E, n, S, lam))
-                    return e;
-                  it = F->cache.emplace(key, E).first;
                 }
-              fd.e[c][d] = it->second;
+              Eig1D E;
+              if (int e = upload_eig(E, n, S, lam))
+                return e;
+              it = F->cache.emplace(key, E).first;
             }
+          fd.e[c][d] = it->second;
+        }
+    const size_t need = (size_t)fd.nn[0] * fd.nn[1] * fd.nn[2];
+    if (need > F->wcount)
+      {
+        for (double *p : {F->w0, F->w1})
+          if (p)
+            (void)hipFree(p);
+        F->w0 = F->w1 = nullptr;
+        F->wcount     = 0;
+        if (hipMalloc(&F->w0, need * sizeof(double)) != hipSuccess || hipMalloc(&F->w1, need * sizeof(double)) != hipSuccess)
+          return ADAFLO_ENOMEM;
+        F->wcount = need;
       }
-    const size_t need = (size_t)std::max(ctx->n_nodes_u, ctx->n_nodes_p);
-    if (hipMalloc(&F->w0, need * sizeof(double)) != hipSuccess || hipMalloc(&F->w1, need * sizeof(double)) != hipSuccess)
-      return ADAFLO_ENOMEM;
-    F->wcount = need;
+    F->ready[f] = true;
     return 0;
+  }
+
+  int fdm_setup(adaflo_ctx *ctx)
+  {
+    if (int e = fdm_setup_field(ctx, 0))
+      return e;
+    return fdm_setup_field(ctx, 1);
   }
 
   // dst = (c_mass M + c_lap K)^-1 src on the free rows (pseudo-inverse if singular), dst = src on
   // the constrained rows; dst == src allowed
   int fdm_apply(adaflo_ctx *ctx, const int field, double *dst, const double *src, const double c_mass, const double c_lap)
   {
-    if (int e = fdm_setup(ctx))
+    if (field < 0 || field > 2)
+      return ADAFLO_EINVAL;
+    if (int e = fdm_setup_field(ctx, field))
       return e;
     Fdm            *F  = static_cast<Fdm *>(ctx->fdm);
     const FieldFdm &fd = F->field[field];
     const int       nx = fd.nn[0], ny = fd.nn[1], nz = fd.nn[2];
     const long      n = (long)nx * ny * nz;
-    const uint32_t  mask = field == 0 ? ctx->brick.con_u : ctx->brick.con_p;
+    const uint32_t  mask = field == 0 ? ctx->brick.con_u : (field == 1 ? ctx->brick.con_p : ctx->brick.con_ls);
     const unsigned  nb = (unsigned)std::min<long>((n + 255) / 256, 16384);
     for (int c = 0; c < fd.ncomp; ++c)
       {

@@ -17,6 +17,11 @@ from .vectors import DeviceVector
 class LevelSetOperators:
     """owns the engine context for the level-set spaces on a brick (FE_Q_iso_Q1(ls_degree))"""
 
+    # normal / curvature projections: False = CG with the mass-diagonal preconditioner to the reference's
+    # tolerances (1e-7 / 1e-8), True = exact inverse of the projection matrix by fast diagonalisation
+    # (adaflo_ls_projection_solve; unconstrained level-set space only)
+    exact_projection = False
+
     def __init__(self, mesh, ls_degree, velocity_degree=2, constrained_faces=(), device=0, stream=None,
                  dirichlet_faces_u=(), navier_stokes_matrix=None):
         """navier_stokes_matrix: share the engine context of an initialised NavierStokesMatrix that
@@ -283,6 +288,12 @@ class LevelSetOKZSolverComputeNormal:
         from .solvers import ComputeNormalMatrix, ReductionControl, SolverCG
         normal_vector_rhs.fill(0.0)
         self.local_compute_normal_rhs(normal_vector_rhs, level_set_solution)
+        if self.ops.exact_projection:
+            # the projection matrix is a constant-coefficient tensor-product operator on the brick: solved
+            # exactly by fast diagonalisation (csrc/fdm.hip), 0 iterations
+            _lib.check(self._ctx, self._lib.adaflo_ls_projection_solve(self._ctx, normal_vector_field.ptr,
+                                                                         normal_vector_rhs.ptr, 3))
+            return 0
         control = ReductionControl(4000, 1e-50, 1e-5 if fast_computation else 1e-7)
         SolverCG(control).solve(ComputeNormalMatrix(self.ops), normal_vector_field, normal_vector_rhs, preconditioner)
         return control.last_step()
@@ -312,8 +323,11 @@ class LevelSetOKZSolverComputeCurvature:
         rhs.fill(0.0)
         self.local_compute_curvature_rhs(rhs, normal_vector_field)
         control = ReductionControl(2000, 1e-50, 1e-8)
-        matrix = ProjectionMatrix(self.ops) if use_projection_matrix else ComputeCurvatureMatrix(self.ops)
-        SolverCG(control).solve(matrix, solution_curvature, rhs, preconditioner)
+        if self.ops.exact_projection and use_projection_matrix:
+            _lib.check(self._ctx, self._lib.adaflo_ls_projection_solve(self._ctx, solution_curvature.ptr, rhs.ptr, 1))
+        else:
+            matrix = ProjectionMatrix(self.ops) if use_projection_matrix else ComputeCurvatureMatrix(self.ops)
+            SolverCG(control).solve(matrix, solution_curvature, rhs, preconditioner)
         if solution_ls is not None:
             ops = self.ops
             _lib.check(ops._ctx, ops._lib.adaflo_ls_curvature_correction(ops._ctx, solution_curvature.ptr, solution_ls.ptr))

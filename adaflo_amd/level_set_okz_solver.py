@@ -19,9 +19,11 @@ from .time_stepping import TimeStepping
 
 class LevelSetOKZSolver:
     def __init__(self, parameters, mesh, distance_function, dirichlet_function=None, device=0,
-                 n_reinit_steps=2, n_initial_reinit_steps=2):
+                 n_reinit_steps=2, n_initial_reinit_steps=2, exact_projection=True):
         """distance_function(xyz[n][3]) -> signed distance to the interface, positive outside the
-        second fluid (tests/rising_bubble.cc:59-77)"""
+        second fluid (tests/rising_bubble.cc:59-77).  exact_projection: solve the normal / curvature
+        projections (the reference: CG + ILU on the assembled projection matrix to 1e-7 / 1e-8) exactly by
+        fast diagonalisation instead of by diagonally preconditioned CG to those tolerances"""
         p = parameters
         self.parameters, self.mesh = p, mesh
         s, k = p.concentration_subdivisions, p.velocity_degree
@@ -31,6 +33,7 @@ class LevelSetOKZSolver:
         self.navier_stokes = NavierStokes(p, mesh, self.time_stepping, dirichlet_function, device=device, ls_degree=s)
         self.ops = lso.LevelSetOperators(mesh, s, velocity_degree=k,
                                          navier_stokes_matrix=self.navier_stokes.navier_stokes_matrix)
+        self.ops.exact_projection = bool(exact_projection)
         # two_phase_base.cc:282-291: epsilon_used = epsilon / subdivisions * largest edge length
         self.epsilon_used = p.epsilon / s * max(mesh.h)
         # the sub-operators advance their own TimeStepping copies (level_set_okz.cc:94-106)

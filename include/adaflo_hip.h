@@ -429,10 +429,17 @@ int adaflo_solve(adaflo_ctx *ctx, int op, int method, double *x, const double *b
 /* Matrix-free replacement of the assembled matrices + ILU / AMG behind the inner solves
  * (navier_stokes_preconditioner.cc:636-666,:712-733; level_set_okz_compute_normal.cc:
  * 252-267): exact inverse of  c_mass M + c_lap K  (mass and Laplace matrices of the velocity space,
- * field 0, per component, or of the pressure space, field 1) on the brick by fast diagonalisation --
- * six dense 1D transforms per scalar field.  dst = src on constrained rows; pseudo-inverse (null mode
- * dropped) if the operator is singular.  dst == src allowed.                                     */
+ * field 0, per component; of the pressure space, field 1; of the level-set space FE_Q_iso_Q1(s), field 2,
+ * one scalar block: the projection matrix M + 4 max(eps_used / eps, h / s)^2 K of the normal and
+ * curvature solves, level_set_okz.cc:262-312) on the brick by fast diagonalisation -- six dense 1D
+ * transforms per scalar field.  dst = src on constrained rows; pseudo-inverse (null mode dropped) if
+ * the operator is singular.  dst == src allowed.                                                  */
 int adaflo_fdm_apply(adaflo_ctx *ctx, int field, double *dst, const double *src, double c_mass, double c_lap);
+/* dst = (projection matrix)^-1 rhs per scalar block, exactly: what the reference's normal and curvature
+ * solves approximate with CG + ILU on the assembled matrix (level_set_okz_compute_normal.cc:252-267,
+ * level_set_okz_compute_curvature.cc:345-355).  n_blocks = 3 for the normal vector field.  Needs an
+ * unconstrained level-set space (ADAFLO_EUNSUPPORTED otherwise).                                    */
+int adaflo_ls_projection_solve(adaflo_ctx *ctx, double *dst, const double *rhs, int n_blocks);
 /* inner solves of adaflo_ns_preconditioner_vmult: 0 = Krylov solves with the pointwise Jacobi
  * preconditioner, 1 (default, constant coefficients) = fast diagonalisation: the velocity block's
  * BiCGStab is right-preconditioned with the inverse of its mass + vector-Laplace part, the pressure

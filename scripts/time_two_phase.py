@@ -23,6 +23,8 @@ def main():
     mesh = adaflo_amd.BrickMesh([n, n, 2 * n], [0., 0., 0.], [1., 1., 2.])
     solver = LevelSetOKZSolver(fp, mesh, lambda x: np.linalg.norm(x - 0.5, axis=1) - 0.25)
     ns = solver.navier_stokes
+    if len(sys.argv) > 4:      # normal / curvature projections: 1 exact (fast diagonalisation, default), 0 CG
+        solver.ops.exact_projection = bool(int(sys.argv[4]))
     if len(sys.argv) > 3:      # inner solves of the block preconditioner: 1 fast diagonalisation, 0 Jacobi
         ctx = ns.navier_stokes_matrix._require()
         adaflo_amd._lib.check(ctx, adaflo_amd._lib.load().adaflo_ns_preconditioner_set_inner(ctx, int(sys.argv[3])))

@@ -105,3 +105,29 @@ def test_beltrami_time_step_with_fast_diagonalisation():
         stats[inner] = (its.value / max(solves.value, 1), sum(i for i, _ in ns.linear_iterations))
     assert stats[1][0] <= 10.0 and stats[1][0] < 0.5 * stats[0][0], stats
     assert stats[1][1] <= stats[0][1] + 5, stats
+
+
+@pytest.mark.parametrize("s,ncell,upper", [(1, (5, 4, 3), (1.0, 1.0, 1.0)), (2, (4, 3, 5), (1.0, 0.7, 1.5)), (3, (2, 3, 2), (0.9, 1.2, 1.0)),
+                                           (4, (3, 2, 2), (1.0, 0.5, 0.8))])
+def test_projection_matrix_of_the_level_set_space_is_inverted_exactly(s, ncell, upper):
+    """field 2 (FE_Q_iso_Q1(s), analytic cosine modes): adaflo_ls_projection_solve inverts the projection matrix of
+    the normal / curvature solves (one scalar block of compute_normal_vmult = adaflo_ls_projection_vmult), and
+    adaflo_fdm_apply(2, ...) inverts the curvature operator with its own damping"""
+    from adaflo_amd import level_set_okz as lso
+    mesh = adaflo_amd.BrickMesh(list(ncell), [0.0, 0.0, 0.0], list(upper))
+    ops = lso.LevelSetOperators(mesh, s)
+    eps_used, epsilon = 1.5 * max(mesh.h) / s, 1.5
+    ops.set_parameters(eps_used, 0.02, 75.0, -100.0, 25.0, epsilon)
+    lib, ctx = _lib.load(), ops._ctx
+    rng = np.random.default_rng(11)
+    x3 = rng.uniform(-1, 1, 3 * ops.n_dofs)
+    src, dst, back = ops.vector(x3, blocks=3), ops.vector(blocks=3), ops.vector(blocks=3)
+    lso.LevelSetOKZSolverComputeNormal(ops).compute_normal_vmult(dst, src)
+    _lib.check(ctx, lib.adaflo_ls_projection_solve(ctx, back.ptr, dst.ptr, 3))
+    assert rel_l2(back.numpy(), x3) < 1e-10
+    x = x3[:ops.n_dofs]
+    src1, dst1, back1 = ops.vector(x), ops.vector(), ops.vector()
+    lso.LevelSetOKZSolverComputeCurvature(ops).compute_curvature_vmult(dst1, src1, True)
+    b = max(eps_used / epsilon, max(mesh.h) / s)
+    _lib.check(ctx, lib.adaflo_fdm_apply(ctx, 2, back1.ptr, dst1.ptr, 1.0, b * b))
+    assert rel_l2(back1.numpy(), x) < 1e-10
