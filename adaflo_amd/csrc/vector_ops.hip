@@ -88,12 +88,27 @@ namespace adaflo_hip
     }
 
     // v -= (*prod) * inv * modes
+    // v -= (sum of the np partial dot products) * inv * modes.  Every block adds up the partials itself (a
+    // few thousand doubles from L2, the same fixed order in every block: all blocks use the same factor),
+    // which saves the separate one-block reduction launch between the dot product and the update.
     __global__ __launch_bounds__(VT) void project_kernel(double *__restrict__ v,
                                                          const double *__restrict__ modes,
-                                                         const double *__restrict__ prod,
+                                                         const double *__restrict__ part, const int np,
                                                          const double inv, const long n)
     {
-      const double f = prod[0] * inv;
+      __shared__ double red[VT / 64];
+      double            s = 0.;
+      for (int i = threadIdx.x; i < np; i += VT)
+        s += part[i];
+      for (int off = 32; off > 0; off >>= 1)
+        s += __shfl_down(s, off, 64);
+      if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = s;
+      __syncthreads();
+      double t = 0.;
+      for (int w = 0; w < VT / 64; ++w)
+        t += red[w];
+      const double f = t * inv;
       for (long i = blockIdx.x * (long)VT + threadIdx.x; i < n; i += (long)gridDim.x * VT)
         v[i] -= f * modes[i];
     }
@@ -294,10 +309,12 @@ namespace adaflo_hip
   int launch_mean_projection(adaflo_ctx *ctx, double *v, const double *w, const double *modes,
                              const long n, const double inv)
   {
-    if (int e = launch_dot(ctx, w, v, n))
+    const unsigned nb = grid_for(n, 4);
+    if (int e = ensure_scratch(ctx, 2 * 32768 + 8))
       return e;
-    hipLaunchKernelGGL(project_kernel, dim3(grid_for(n)), dim3(VT), 0, ctx->stream, v, modes,
-                       ctx->d_scratch, inv, n);
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(VT), 0, ctx->stream, w, v, n, ctx->d_scratch + 8);
+    hipLaunchKernelGGL(project_kernel, dim3(grid_for(n, 4)), dim3(VT), 0, ctx->stream, v, modes, ctx->d_scratch + 8,
+                       (int)nb, inv, n);
     return check();
   }
 
