@@ -2,6 +2,8 @@
 // zero + constrained-row fix-up, pressure-mean projection, state re-layout.
 #include "kernels.hpp"
 
+#include <algorithm>
+
 namespace adaflo_hip
 {
   namespace
@@ -309,7 +311,7 @@ namespace adaflo_hip
   int launch_mean_projection(adaflo_ctx *ctx, double *v, const double *w, const double *modes,
                              const long n, const double inv)
   {
-    const unsigned nb = grid_for(n, 4);
+    const unsigned nb = std::min(grid_for(n, 4), 512u); // (every block of the update re-reads the partials)
     if (int e = ensure_scratch(ctx, 2 * 32768 + 8))
       return e;
     hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(VT), 0, ctx->stream, w, v, n, ctx->d_scratch + 8);
