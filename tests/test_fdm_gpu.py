@@ -131,3 +131,15 @@ def test_projection_matrix_of_the_level_set_space_is_inverted_exactly(s, ncell, 
     b = max(eps_used / epsilon, max(mesh.h) / s)
     _lib.check(ctx, lib.adaflo_fdm_apply(ctx, 2, back1.ptr, dst1.ptr, 1.0, b * b))
     assert rel_l2(back1.numpy(), x) < 1e-10
+
+
+def test_projection_solve_refuses_a_constrained_level_set_space():
+    """constrained rows of the projection operator carry the user's diagonal, not the identity: the exact solve is
+    only offered for the unconstrained space (the drivers then keep the CG path)"""
+    from adaflo_amd import level_set_okz as lso
+    mesh = adaflo_amd.BrickMesh([3, 3, 3], [0.0] * 3, [1.0] * 3)
+    ops = lso.LevelSetOperators(mesh, 2, constrained_faces=(0,))
+    ops.set_parameters(1.5 * max(mesh.h) / 2, 0.02, 75.0, -100.0, 25.0, 1.5)
+    v, w = ops.vector(np.ones(ops.n_dofs)), ops.vector()
+    code = _lib.load().adaflo_ls_projection_solve(ops._ctx, w.ptr, v.ptr, 1)
+    assert code != 0 and b"unconstrained" in _lib.load().adaflo_last_error(ops._ctx)
