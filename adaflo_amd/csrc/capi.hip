@@ -922,6 +922,15 @@ int adaflo_fdm_apply(adaflo_ctx *ctx, int field, double *dst, const double *src,
   return 0;
 }
 
+int adaflo_ns_set_iterations_before_inner_solvers(adaflo_ctx *ctx, int iterations)
+{
+  CHECK_CTX(ctx);
+  if (iterations < 0)
+    return fail(ctx, ADAFLO_EINVAL, "negative iteration count");
+  ctx->pc_its_before_inner = iterations;
+  return 0;
+}
+
 int adaflo_ns_preconditioner_set_inner(adaflo_ctx *ctx, int mode)
 {
   CHECK_CTX(ctx);

@@ -158,6 +158,8 @@ struct adaflo_ctx
   void                    *fdm = nullptr;      // fast-diagonalisation data of the inner solves (fdm.hip)
   long                     pc_velocity_iterations = 0, pc_velocity_solves = 0; // statistics of the velocity-block solves
   int                      pc_inner = 1;       // 0: Jacobi-preconditioned inner Krylov solves, 1: fast diagonalisation
+  int                      pc_its_before_inner = 50; // parameters.iterations_before_inner_solvers (0: inner solves at once)
+  bool                     pc_simple = false;  // current stage of adaflo_ns_solve_system: do_inner_solves == false
 
   // pressure constant mode (mode 0) data, source/navier_stokes_matrix.cc:117-168
   double *d_p_weights = nullptr, *d_p_modes = nullptr;

@@ -924,12 +924,20 @@ int adaflo_ns_preconditioner_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p
     Krylov K{};
     K.ctx = ctx;
     K.n = K.n_block = nu;
-    const double norm = std::sqrt(host_dot(ctx, src_u, src_u, nu));
-    const adaflo_solver_control c{100, 3e-2 * norm, 0.};
-    if (launch_fill(ctx, dst_u, 0., nu))
-      return kfail(ctx, ADAFLO_EHIP, "fill failed");
-    if (fdm)
+    if (fdm && ctx->pc_simple)
       {
+        // do_inner_solves == false (:605-635): the approximate inverse of the velocity block is applied once --
+        // here the exact inverse of its symmetric part; the convective part is left to the outer iteration
+        if (int rc = fdm_apply(ctx, 0, dst_u, src_u, vm, vl))
+          return kfail(ctx, rc, "fast-diagonalisation solve failed");
+        res.iterations = 0;
+      }
+    else if (fdm)
+      {
+        const double norm = std::sqrt(host_dot(ctx, src_u, src_u, nu));
+        const adaflo_solver_control c{100, 3e-2 * norm, 0.};
+        if (launch_fill(ctx, dst_u, 0., nu))
+          return kfail(ctx, ADAFLO_EHIP, "fill failed");
         // right preconditioning: BiCGStab on A P^-1 (no pointwise preconditioner), du = P^-1 y
         double *tmp = ctx->pc_tmp_u.p;
         K.inv_diag  = nullptr;
@@ -945,6 +953,10 @@ int adaflo_ns_preconditioner_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p
       }
     else
       {
+        const double norm = std::sqrt(host_dot(ctx, src_u, src_u, nu));
+        const adaflo_solver_control c{100, 3e-2 * norm, 0.};
+        if (launch_fill(ctx, dst_u, 0., nu))
+          return kfail(ctx, ADAFLO_EHIP, "fill failed");
         K.inv_diag = ctx->pc_inv_u.p;
         K.A        = [ctx](double *d, const double *s) { return adaflo_ns_velocity_vmult(ctx, d, s); };
         if (int rc = solve_bicgstab(K, dst_u, src_u, c, res, w.p))
@@ -1055,9 +1067,24 @@ int adaflo_ns_solve_system(adaflo_ctx *ctx, double *update_u, double *update_p, 
   result->iterations       = 0;
   result->converged        = beta <= control->abs_tol;
   std::vector<double> H((size_t)(m + 1) * m), g(m + 1), cs(m), sn(m), y(m);
+  // :571-617: first the cheap solver whose preconditioner applies the approximate inverses once
+  // (do_inner_solves = false) for `lin its before inner solvers` iterations, then -- from the iterate reached --
+  // the solver with inner Krylov solves.  The cheap stage needs approximate inverses that deserve the name:
+  // it is taken with the fast-diagonalisation inverses (constant coefficients), not with the Jacobi diagonals.
+  const bool two_stage = ctx->pc_inner == 1 && !ctx->rho_prec.p && !ctx->rho.p && !ctx->mu.p && ctx->pc_its_before_inner > 0;
+  const int  simple_limit = two_stage ? std::min(ctx->pc_its_before_inner, control->max_iterations) : 0;
+  struct StageGuard // (error returns below must not leave the context in the cheap stage)
+  {
+    adaflo_ctx *c;
+    ~StageGuard() { c->pc_simple = false; }
+  } stage_guard{ctx};
+  ctx->pc_simple = two_stage;
   while (!result->converged && result->iterations < control->max_iterations)
     {
-      const int mm = std::min(m, control->max_iterations - result->iterations);
+      if (ctx->pc_simple && result->iterations >= simple_limit)
+        ctx->pc_simple = false; // the strong solver takes over for the remaining iterations
+      const int limit = ctx->pc_simple ? simple_limit : control->max_iterations;
+      const int mm    = std::min(m, limit - result->iterations);
       axpy(vec(V, 0), 1. / beta, vec(V, 0), 0.); // v_0 = r / |r|
       std::fill(g.begin(), g.end(), 0.);
       g[0]   = beta;
@@ -1119,6 +1146,7 @@ int adaflo_ns_solve_system(adaflo_ctx *ctx, double *update_u, double *update_p, 
       result->converged = beta <= control->abs_tol;
     }
   result->final_residual = beta;
+  ctx->pc_simple         = false;
   if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
     return kfail(ctx, ADAFLO_EHIP, "FGMRES kernels failed");
   return 0;

@@ -134,6 +134,8 @@ class NavierStokes:
         ctl = _lib.SolverControl(p.max_lin_iteration, linear_tolerance, 0.0)
         res = _lib.SolverResult()
         upd, rhs = self.solution_update, self.system_rhs
+        _lib.check(self._ctx, self._lib.adaflo_ns_set_iterations_before_inner_solvers(
+            self._ctx, int(p.iterations_before_inner_solvers)))
         _lib.check(self._ctx, self._lib.adaflo_ns_solve_system(
             self._ctx, upd[0].data_ptr(), upd[1].data_ptr(), rhs[0].data_ptr(), rhs[1].data_ptr(),
             C.byref(ctl), 50, C.byref(res)))

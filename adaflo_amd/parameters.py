@@ -44,6 +44,7 @@ class FlowParameters:
     max_nl_iteration: int = 10
     tol_nl_iteration: float = 1e-6
     max_lin_iteration: int = 500
+    iterations_before_inner_solvers: int = 50        # "lin its before inner solvers", parameters.cc:212-223
     tol_lin_iteration: float = 1e-3
     rel_lin_iteration: bool = True
     # level-set driver (parameters.cc:351-357) and mesh keys a driver needs
@@ -104,6 +105,7 @@ _PRM_KEYS = {
     ("Navier-Stokes/Solver", "linearization scheme"): ("linearization", str),
     ("Navier-Stokes/Solver", "tau grad div"): ("tau_grad_div", float),
     ("Navier-Stokes/Solver", "lin max iterations"): ("max_lin_iteration", int),
+    ("Navier-Stokes/Solver", "lin its before inner solvers"): ("iterations_before_inner_solvers", int),
     ("Navier-Stokes/Solver", "lin tolerance"): ("tol_lin_iteration", float),
     ("Navier-Stokes/Solver", "lin relative tolerance"): ("rel_lin_iteration", lambda v: int(v) > 0),
     ("Two phase", "density difference"): ("density_diff", float),

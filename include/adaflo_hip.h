@@ -445,6 +445,14 @@ int adaflo_ls_projection_solve(adaflo_ctx *ctx, double *dst, const double *rhs, 
  * BiCGStab is right-preconditioned with the inverse of its mass + vector-Laplace part, the pressure
  * mass and Poisson solves are exact                                                              */
 int adaflo_ns_preconditioner_set_inner(adaflo_ctx *ctx, int mode);
+/* FlowParameters::iterations_before_inner_solvers ("lin its before inner solvers", default 50;
+ * navier_stokes.cc:571-617): adaflo_ns_solve_system first runs the cheap solver whose preconditioner
+ * applies the approximate inverses once (do_inner_solves = false, navier_stokes_preconditioner.cc:605-635,
+ * :719-720) for that many iterations and only then, from the iterate reached, the solver with inner
+ * Krylov solves.  The cheap stage is taken with the fast-diagonalisation inverses (mode 1, constant
+ * coefficients); with Jacobi diagonals the solver with inner solves runs from the start.  0 = inner
+ * solves at once.                                                                                 */
+int adaflo_ns_set_iterations_before_inner_solvers(adaflo_ctx *ctx, int iterations);
 /* number of velocity-block solves and their BiCGStab iterations since the last query */
 int adaflo_ns_preconditioner_statistics(adaflo_ctx *ctx, int64_t *velocity_solves, int64_t *velocity_iterations);
 /* NavierStokes::solve_system (source/navier_stokes.cc:561-653): FGMRES(restart) on adaflo_ns_vmult,

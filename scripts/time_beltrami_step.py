@@ -20,13 +20,14 @@ def main():
     nu = 1.0
     mesh = adaflo_amd.BrickMesh([n] * 3, [-1.0] * 3, [1.0] * 3)
     xu, xp = node_coordinates(mesh, 2), node_coordinates(mesh, 1)
-    for inner in (1, 0):
+    for inner in (1, -1, 0):        # 1: fast diagonalisation, two-stage solver; -1: inner solves from the start; 0: Jacobi
         fp = adaflo_amd.FlowParameters(velocity_degree=2, viscosity=nu, time_step_size_start=0.05 * 16 / n, end_time=1.0,
-                                       max_nl_iteration=10, tol_nl_iteration=1e-9, max_lin_iteration=100, tol_lin_iteration=1e-5)
+                                       max_nl_iteration=10, tol_nl_iteration=1e-9, max_lin_iteration=100, tol_lin_iteration=1e-5,
+                                       iterations_before_inner_solvers=0 if inner < 0 else 50)
         ns = NavierStokes(fp, mesh, adaflo_amd.TimeStepping(fp), dirichlet_function=lambda x, t: beltrami.velocity(x, t, nu))
         ctx = ns.navier_stokes_matrix._require()
         lib = _lib.load()
-        _lib.check(ctx, lib.adaflo_ns_preconditioner_set_inner(ctx, inner))
+        _lib.check(ctx, lib.adaflo_ns_preconditioner_set_inner(ctx, abs(inner)))
         ns.set_initial_condition(beltrami.velocity(xu, 0.0, nu).reshape(-1), beltrami.pressure(xp, 0.0, nu))
         for step in range(steps):
             s0, i0 = C.c_int64(), C.c_int64()

@@ -84,13 +84,19 @@ def test_velocity_space_inverse_against_kronecker_assembly(k, ncell, faces_u):
 
 
 def test_beltrami_time_step_with_fast_diagonalisation():
+    """three ways through NavierStokes::solve_system on the 16^3 Beltrami case, all reproducing the reference's
+    output line of time step #2: (1, 50) fast-diagonalisation inverses with the reference's two-stage strategy --
+    the cheap solver without inner solves converges before `lin its before inner solvers` = 50 --, (1, 0) inner
+    solves from the start (<= 10 BiCGStab iterations per velocity solve), (1, 4) the switch to the
+    solver with inner solves after four cheap iterations, (0, .) Jacobi inner solves as in round 1"""
     nu = 1.0
     mesh = adaflo_amd.BrickMesh([16] * 3, [-1.0] * 3, [1.0] * 3)
     xu, xp = node_coordinates(mesh, 2), node_coordinates(mesh, 1)
     stats = {}
-    for inner in (1, 0):
+    for inner, before in ((1, 50), (1, 0), (1, 4), (0, 50)):
         fp = adaflo_amd.FlowParameters(velocity_degree=2, viscosity=nu, time_step_size_start=0.05, end_time=1.0,
-                                       max_nl_iteration=10, tol_nl_iteration=1e-9, max_lin_iteration=100, tol_lin_iteration=1e-5)
+                                       max_nl_iteration=10, tol_nl_iteration=1e-9, max_lin_iteration=100, tol_lin_iteration=1e-5,
+                                       iterations_before_inner_solvers=before)
         ns = NavierStokes(fp, mesh, adaflo_amd.TimeStepping(fp), dirichlet_function=lambda x, t: beltrami.velocity(x, t, nu))
         ctx = ns.navier_stokes_matrix._require()
         _lib.check(ctx, _lib.load().adaflo_ns_preconditioner_set_inner(ctx, inner))
@@ -102,9 +108,12 @@ def test_beltrami_time_step_with_fast_diagonalisation():
         assert "%.3e" % ns.history[0][0] == "2.348e+00" and "%.3e" % ns.history[0][1] == "5.678e-02"   # beltrami_3d.output:31
         solves, its = C.c_int64(), C.c_int64()
         _lib.check(ctx, _lib.load().adaflo_ns_preconditioner_statistics(ctx, C.byref(solves), C.byref(its)))
-        stats[inner] = (its.value / max(solves.value, 1), sum(i for i, _ in ns.linear_iterations))
-    assert stats[1][0] <= 10.0 and stats[1][0] < 0.5 * stats[0][0], stats
-    assert stats[1][1] <= stats[0][1] + 5, stats
+        stats[(inner, before)] = (its.value / max(solves.value, 1), [i for i, _ in ns.linear_iterations])
+    cheap, strong, switch, jacobi = stats[(1, 50)], stats[(1, 0)], stats[(1, 4)], stats[(0, 50)]
+    assert cheap[0] == 0.0 and max(cheap[1]) < 50, stats                        # never needs the inner solves
+    assert 0.0 < strong[0] <= 10.0 and strong[0] < 0.5 * jacobi[0], stats
+    assert sum(strong[1]) <= sum(jacobi[1]) + 5, stats
+    assert switch[0] > 0.0 and all(4 < i < max(cheap[1]) + 1 for i in switch[1] if i > 4), stats
 
 
 @pytest.mark.parametrize("s,ncell,upper", [(1, (5, 4, 3), (1.0, 1.0, 1.0)), (2, (4, 3, 5), (1.0, 0.7, 1.5)), (3, (2, 3, 2), (0.9, 1.2, 1.0)),
