@@ -19,7 +19,8 @@ def main():
         velocity_degree=2, density=1.0, density_diff=-0.9, viscosity=0.01, viscosity_diff=-0.009,
         surface_tension=0.0245, gravity=0.98, epsilon=1.5, concentration_subdivisions=s,
         interpolate_grad_onto_pressure=True, curvature_correction=True, time_step_size_start=0.02, end_time=3.0,
-        max_nl_iteration=10, tol_nl_iteration=1e-9, max_lin_iteration=200, tol_lin_iteration=1e-4)
+        max_nl_iteration=10, tol_nl_iteration=1e-9, max_lin_iteration=200, tol_lin_iteration=1e-4,
+        iterations_before_inner_solvers=int(sys.argv[5]) if len(sys.argv) > 5 else 50)
     mesh = adaflo_amd.BrickMesh([n, n, 2 * n], [0., 0., 0.], [1., 1., 2.])
     solver = LevelSetOKZSolver(fp, mesh, lambda x: np.linalg.norm(x - 0.5, axis=1) - 0.25)
     ns = solver.navier_stokes
