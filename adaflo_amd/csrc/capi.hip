@@ -328,6 +328,10 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
     (void)hipFree(ctx->q2_wg_list);
   if (ctx->h_result)
     (void)hipHostFree(ctx->h_result);
+  if (ctx->gs_host)
+    (void)hipHostFree(ctx->gs_host);
+  if (ctx->gs_dev)
+    (void)hipFree(ctx->gs_dev);
   ctx->matvec_timer.destroy();
   ctx->kernel_timer.destroy();
   if (ctx->own_stream && ctx->stream)

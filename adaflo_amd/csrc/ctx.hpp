@@ -166,6 +166,7 @@ struct adaflo_ctx
   double  inv_p_weight = 0.;
   double *d_scratch    = nullptr; // reduction scratch (partials + result)
   double *h_result = nullptr, *h_result_dev = nullptr; // pinned host copy of reduction results + its device address
+  double *gs_dev = nullptr, *gs_host = nullptr;        // Gram-Schmidt coefficients of one FGMRES iteration (device, pinned host)
   // operator kernels that can leave the partial sums of src . dst on the way (the stencil kernels):
   // request (pointer + capacity in pairs) set by the CG driver, answer (pairs written, 0 = not done)
   double *fused_dot_partial = nullptr;

@@ -39,6 +39,15 @@ namespace adaflo_hip
     }
 
     // y = a*x + b*y   (b == 0: y is not read -- it may be uninitialised memory; x may alias y)
+  // y -= (*s) x with the coefficient in device memory (Gram-Schmidt of FGMRES)
+  __global__ __launch_bounds__(KT) void axpy_dev_kernel(double *__restrict__ y, const double *__restrict__ s,
+                                                        const double *__restrict__ x, const long n)
+  {
+    const double a = -*s;
+    for (long i = blockIdx.x * (long)KT + threadIdx.x; i < n; i += (long)gridDim.x * KT)
+      y[i] = a * x[i] + 1. * y[i];
+  }
+
     __global__ __launch_bounds__(KT) void axpby_kernel(double *y, const double a, const double *x, const double b,
                                                        const long n)
     {
@@ -1066,6 +1075,12 @@ int adaflo_ns_solve_system(adaflo_ctx *ctx, double *update_u, double *update_p, 
   result->initial_residual = beta;
   result->iterations       = 0;
   result->converged        = beta <= control->abs_tol;
+  // buffers of the device-resident Gram-Schmidt coefficients (restart lengths beyond 62 take the host path)
+  const bool gs = m <= 62;
+  if (gs && !ctx->gs_dev)
+    if (hipMalloc(&ctx->gs_dev, 64 * sizeof(double)) != hipSuccess ||
+        hipHostMalloc((void **)&ctx->gs_host, 64 * sizeof(double), hipHostMallocDefault) != hipSuccess)
+      return kfail(ctx, ADAFLO_ENOMEM, "out of memory for the Gram-Schmidt coefficients");
   std::vector<double> H((size_t)(m + 1) * m), g(m + 1), cs(m), sn(m), y(m);
   // :571-617: first the cheap solver whose preconditioner applies the approximate inverses once
   // (do_inner_solves = false) for `lin its before inner solvers` iterations, then -- from the iterate reached --
@@ -1095,13 +1110,37 @@ int adaflo_ns_solve_system(adaflo_ctx *ctx, double *update_u, double *update_p, 
             return rc;
           if (int rc = A(wv, vec(Z, j)))
             return rc;
-          for (int i = 0; i <= j; ++i) // modified Gram-Schmidt
+          // modified Gram-Schmidt.  The coefficients stay on the device while the vector is orthogonalised (each
+          // update kernel reads its coefficient from device memory): the host waits ONCE per iteration, for all
+          // j + 1 coefficients and the norm, instead of after every dot product; same arithmetic, same order.
+          double hn;
+          if (gs)
             {
-              const double h = dotn(wv, vec(V, i));
-              H[(size_t)i * m + j] = h;
-              axpy(wv, -h, vec(V, i), 1.);
+              for (int i = 0; i <= j; ++i)
+                {
+                  if (launch_dot_to(ctx, wv, vec(V, i), n, ctx->gs_dev + i))
+                    return kfail(ctx, ADAFLO_EHIP, "dot product failed");
+                  hipLaunchKernelGGL(axpy_dev_kernel, dim3(kgrid(n)), dim3(KT), 0, ctx->stream, wv, ctx->gs_dev + i, vec(V, i), n);
+                }
+              if (launch_dot_to(ctx, wv, wv, n, ctx->gs_dev + j + 1))
+                return kfail(ctx, ADAFLO_EHIP, "dot product failed");
+              if (hipMemcpyAsync(ctx->gs_host, ctx->gs_dev, (j + 2) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                  hipStreamSynchronize(ctx->stream) != hipSuccess)
+                return kfail(ctx, ADAFLO_EHIP, "Gram-Schmidt coefficients did not arrive");
+              for (int i = 0; i <= j; ++i)
+                H[(size_t)i * m + j] = ctx->gs_host[i];
+              hn = std::sqrt(ctx->gs_host[j + 1]);
             }
-          const double hn          = std::sqrt(dotn(wv, wv));
+          else
+            {
+              for (int i = 0; i <= j; ++i)
+                {
+                  const double h = dotn(wv, vec(V, i));
+                  H[(size_t)i * m + j] = h;
+                  axpy(wv, -h, vec(V, i), 1.);
+                }
+              hn = std::sqrt(dotn(wv, wv));
+            }
           H[(size_t)(j + 1) * m + j] = hn;
           hipLaunchKernelGGL(axpby_kernel, dim3(kgrid(n)), dim3(KT), 0, ctx->stream, vec(V, j + 1), hn > 0. ? 1. / hn : 1.,
                              wv, 0., n);
