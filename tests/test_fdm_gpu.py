@@ -24,7 +24,8 @@ def _fdm(op, field, src, c_mass, c_lap):
     return d.numpy()
 
 
-@pytest.mark.parametrize("k,ncell,faces_p", [(2, (5, 4, 6), ()), (2, (9, 3, 4), (0,)), (3, (3, 4, 2), (1, 4)), (2, (1, 1, 1), ())])
+@pytest.mark.parametrize("k,ncell,faces_p", [(2, (5, 4, 6), ()), (2, (9, 3, 4), (0,)), (3, (3, 4, 2), (1, 4)), (2, (1, 1, 1), ()),
+                                             (2, (1, 3, 2), (0, 1)), (2, (2, 1, 3), (2, 3, 5))])
 def test_pressure_mass_and_poisson_are_inverted_exactly(k, ncell, faces_p):
     case = Case(ncell, k=k, faces_p=faces_p, upper=(1.0, 0.7, 1.5), viscosity=0.3, tau_grad_div=0.2)
     op = case.engine()
@@ -117,7 +118,7 @@ def test_beltrami_time_step_with_fast_diagonalisation():
 
 
 @pytest.mark.parametrize("s,ncell,upper", [(1, (5, 4, 3), (1.0, 1.0, 1.0)), (2, (4, 3, 5), (1.0, 0.7, 1.5)), (3, (2, 3, 2), (0.9, 1.2, 1.0)),
-                                           (4, (3, 2, 2), (1.0, 0.5, 0.8))])
+                                           (4, (3, 2, 2), (1.0, 0.5, 0.8)), (1, (1, 1, 1), (1.0, 1.0, 1.0)), (2, (1, 5, 1), (0.3, 1.0, 0.2))])
 def test_projection_matrix_of_the_level_set_space_is_inverted_exactly(s, ncell, upper):
     """field 2 (FE_Q_iso_Q1(s), analytic cosine modes): adaflo_ls_projection_solve inverts the projection matrix of
     the normal / curvature solves (one scalar block of compute_normal_vmult = adaflo_ls_projection_vmult), and
