@@ -943,6 +943,19 @@ namespace adaflo_hip
                 }
             }
           lds_barrier();
+#if defined(Q2_SKIP_E)
+          // diagnostic: no combine / no stores (the integrated values stay live through a fake use)
+          {
+            double acc = 0.;
+#pragma unroll
+            for (int n = 0; n < 27; ++n)
+              acc += R[n];
+            if (acc == 1.2345e300)
+              A.dst_u[0] = acc;
+            lds_barrier();
+            continue;
+          }
+#endif
 
           // ---- E: combine per owned node and write the two finished planes -----------------
           // Re-derive the lane coordinates from an opaque copy of the thread id: otherwise the
@@ -1504,6 +1517,19 @@ namespace adaflo_hip
     return 0;
   }
 
+  // development builds (scripts/exp_q2.sh -DQ2_FAST_BUILD): only the instantiations of the headline
+  // benchmark (Newton, with pressure, cubic cells, constant coefficients; vmult and residual)
+  static constexpr bool q2_instantiated(const int lin_mode, const bool with_p, const bool iso, const bool varco,
+                                        const bool div)
+  {
+#if defined(Q2_FAST_BUILD)
+    return lin_mode == 0 && with_p && iso && !varco && !div;
+#else
+    (void)lin_mode, (void)with_p, (void)iso, (void)varco, (void)div;
+    return true;
+#endif
+  }
+
   // phase -1: the whole operator.  Phases 0/1/2 (multi-GPU overlap): 0 = first half of the
   // workgroups that touch no node of the inter-GPU interface faces `iface` (bit = face 2*dim+side),
   // 1 = the workgroups that do + seam fix-up of the interface nodes (dst is then final there and
@@ -1666,6 +1692,10 @@ namespace adaflo_hip
     hipError_t   err       = hipSuccess;
 #define Q2_LAUNCH_V(LM, WP, IS, VC, RS)                                                               \
   {                                                                                             \
+  if constexpr (!q2_instantiated(LM, WP, IS, VC, false))                                        \
+    err = hipErrorNotSupported;                                                                 \
+  else                                                                                          \
+  {                                                                                             \
     static bool attr_set = false;                                                               \
     if (!attr_set)                                                                              \
       {                                                                                         \
@@ -1675,8 +1705,13 @@ namespace adaflo_hip
       }                                                                                         \
     if (err == hipSuccess && nwg > 0)                                                           \
       hipLaunchKernelGGL((ns_q2_kernel<LM, WP, IS, VC, RS>), grid, block, lds_bytes, ctx->stream, A); \
+  }                                                                                             \
   }
 #define Q2_LAUNCH_V6(LM, WP, IS, VC, RS, DV)                                                          \
+  {                                                                                             \
+  if constexpr (!q2_instantiated(LM, WP, IS, VC, DV))                                           \
+    err = hipErrorNotSupported;                                                                 \
+  else                                                                                          \
   {                                                                                             \
     static bool attr_set = false;                                                               \
     if (!attr_set)                                                                              \
@@ -1687,6 +1722,7 @@ namespace adaflo_hip
       }                                                                                         \
     if (err == hipSuccess && nwg > 0)                                                           \
       hipLaunchKernelGGL((ns_q2_kernel<LM, WP, IS, VC, RS, DV>), grid, block, lds_bytes, ctx->stream, A); \
+  }                                                                                             \
   }
 #define Q2_LAUNCH_I(LM, WP, IS)              \
   {                                          \

@@ -60,9 +60,17 @@ def parse():
     ap.add_argument("--linearization", default="coupled implicit Newton",
                     help="diagnostic only: e.g. 'coupled velocity explicit' times the kernel without q-state")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: blocking exchange schedule")
-    ap.add_argument("--comm", default="torch", choices=["torch", "native"],
-                    help="N > 1: ghost exchange driven through torch.distributed point-to-point operations, or "
-                         "inside the engine (adaflo_ns_vmult_distributed: RCCL group send/recv on a second stream)")
+    ap.add_argument("--comm", default="native", choices=["torch", "native"],
+                    help="N > 1: ghost exchange inside the engine (default; adaflo_ns_vmult_distributed of the C ABI: "
+                         "RCCL group send/recv on a second stream) or driven through torch.distributed point-to-point "
+                         "operations.  A failing RCCL set-up ends the run with the RCCL error string and a non-zero "
+                         "exit code (no fallback).")
+    ap.add_argument("--src-consistent", action="store_true",
+                    help="N > 1: skip the owner->ghost update of src in the timed vmult (valid inside a Krylov loop, "
+                         "where the replicas of an interface DoF are bitwise identical after the rank-ordered "
+                         "compress).  Default: the full cell_loop exchange of the reference, update_ghost_values(src) "
+                         "+ compress(add) of dst (navier_stokes_matrix.cc:232-245)")
+    ap.add_argument("--full-exchange", action="store_true", help="(default since round 3; kept for scripts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--print-steps", action="store_true", help="per-step device times on stderr")
     ap.add_argument("--cpu-sample-cells", type=int, default=48)
@@ -143,8 +151,8 @@ def beltrami_nodal(torch, lower, h, ncell, degree, t, device, pressure=False):
     return torch.stack([u0, u1, u2], dim=-1).reshape(-1).contiguous()
 
 
-def cpu_baseline(sample_cells, budget_s=12.0):
-    """time the CPU restatement (oracle/adaflo_oracle_fast.c) on a bounded sample"""
+def cpu_baseline(sample_cells, k=2, budget_s=12.0):
+    """time the CPU restatement (oracle/adaflo_oracle_fast.c) on a bounded sample of the SAME element"""
     from oracle import oracle as orc
     orc.build()
     orc.fast_set_threads(orc.usable_cores())          # the container's CPU quota, not the visible core count
@@ -152,25 +160,25 @@ def cpu_baseline(sample_cells, budget_s=12.0):
     mesh = orc.Mesh.make([n] * 3, [-1.0] * 3, [1.0] * 3)
     prm = orc.NSParams.make(weight=1.5 / 0.05, weight_old=-2 / 0.05, weight_old_old=0.5 / 0.05)
     rng = np.random.default_rng(SEED)
-    nu, npr = mesh.n_nodes(2) * 3, mesh.n_nodes(1)
+    nu, npr = mesh.n_nodes(k) * 3, mesh.n_nodes(k - 1)
     su, sp = rng.uniform(-1, 1, nu), rng.uniform(-1, 1, npr)
-    lin = rng.uniform(-1, 1, mesh.n_cells * 27 * 12)
-    con_u = orc.boundary_mask(mesh, 2, 3)
-    w = orc.ns_pressure_mass_weight(mesh, 2)
+    lin = rng.uniform(-1, 1, mesh.n_cells * (k + 1) ** 3 * 12)
+    con_u = orc.boundary_mask(mesh, k, 3)
+    w = orc.ns_pressure_mass_weight(mesh, k)
     modes = np.ones(npr)
     out = (np.empty(nu), np.empty(npr))
-    orc.fast_ns_vmult(mesh, 2, prm, su, sp, con_u, None, lin=lin, weights=w, modes=modes, out=out)
+    orc.fast_ns_vmult(mesh, k, prm, su, sp, con_u, None, lin=lin, weights=w, modes=modes, out=out)
     reps, t0 = 0, time.perf_counter()
     while True:
-        orc.fast_ns_vmult(mesh, 2, prm, su, sp, con_u, None, lin=lin, weights=w, modes=modes, out=out)
+        orc.fast_ns_vmult(mesh, k, prm, su, sp, con_u, None, lin=lin, weights=w, modes=modes, out=out)
         reps += 1
         el = time.perf_counter() - t0
         if el > budget_s or reps >= 5000:
             break
     return {"value": round((nu + npr) * reps / el / 1e6, 2), "unit": "MDoF/s",
             "cores": orc.fast_n_threads(), "kind": "port",
-            "sample": "%d^3-cell Q2/Q1 brick, %d vmults of the sum-factorised OpenMP restatement "
-                      "of the adaflo path (deal.II unavailable), %.1f s" % (n, reps, el)}
+            "sample": "%d^3-cell Q%d/Q%d brick, %d vmults of the sum-factorised OpenMP restatement "
+                      "of the adaflo path (deal.II unavailable), %.1f s" % (n, k, k - 1, reps, el)}
 
 
 def main():
@@ -278,7 +286,7 @@ def main():
     barrier()
     t_pre = time.perf_counter()
     for _ in range(4):
-        op.vmult(dst, src, src_consistent=True)
+        op.vmult(dst, src, src_consistent=args.src_consistent)
     barrier()
     est = (time.perf_counter() - t_pre) / 4
     if world > 1:
@@ -286,10 +294,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         est = float(t.item())
     for _ in range(int(min(160, max(8, 0.25 / max(est, 1e-6))))):
-        op.vmult(dst, src, src_consistent=True)
+        op.vmult(dst, src, src_consistent=args.src_consistent)
     barrier()
     for _ in range(args.warmup):
-        op.vmult(dst, src, src_consistent=True)
+        op.vmult(dst, src, src_consistent=args.src_consistent)
     op.local.get_kernel_statistics()
     op.local.get_matvec_statistics()
     # per-step device time: events on the stream the engine launches on (= torch's current stream)
@@ -298,7 +306,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         events[i].record()
-        op.vmult(dst, src, src_consistent=True)
+        op.vmult(dst, src, src_consistent=args.src_consistent)
     events[args.steps].record()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -320,7 +328,7 @@ def main():
     achieved = b_alg_launch / kernel_avg / 1e9 if kernel_avg > 0 else None
     ms_per_step = 1e3 * elapsed / args.steps
     frac_vmult = b_alg_launch / (1e-3 * ms_per_step) / 1e9 / HBM_PEAK_GBS
-    if not torch.isfinite(dst_u).all():
+    if not torch.isfinite(dst_u).all() and not os.environ.get("ADAFLO_BENCH_NOCHECK"):  # (diagnostic kernel builds)
         raise SystemExit("non-finite result")
 
     kernel_name = "ns_q2_kernel" if (k == 2 and args.variant >= 1) else (
@@ -351,7 +359,10 @@ def main():
         "config": {"workload": workload, "dofs": n_dofs_global, "cells_per_gpu": n_cells_local,
                    "partition": "x".join(str(g) for g in grid), "kernel_variant": args.variant,
                    "overlap": bool(op.overlap) if world > 1 else None,
-                   "comm": args.comm if world > 1 else None},
+                   "comm": args.comm if world > 1 else None,
+                   # N > 1: does a timed vmult include the owner->ghost update of src (the reference's
+                   # update_ghost_values in cell_loop)?  False only with --src-consistent
+                   "src_ghost_update": (not args.src_consistent) if world > 1 else None},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
@@ -365,7 +376,8 @@ def main():
     if dry_run:
         out["dry_run"] = True       # ranks share one GPU, gloo messages: functional check only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_cells)
+        # same element as the metric; the sample holds about as many DoFs as the 48^3 Q2/Q1 default
+        out["cpu_baseline"] = cpu_baseline(max(4, args.cpu_sample_cells * 2 // k), k)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
