@@ -173,13 +173,15 @@ namespace adaflo_hip
     constexpr int L_UPL_    = L_UPL;
     static_assert(3 * (PNY * 52) <= 4 * RING * PIECE, "the residual mode keeps the old-solution planes in the ring area");
     constexpr int L_PPL     = L_UPL + 3 * UPLANE_L;       // 2 pressure node planes
-    constexpr int L_SCRU    = L_PPL + 2 * PPLANE_L;       // [3 planes][5 slots][192]
+    // publish scratch: the masked reads "west / south of the first cells" reach up to 27 doubles below a
+    // slot, i.e. (slot 0 of plane 0) below the scratch itself: 4 zeroed doubles in front (cell 0 reads
+    // [-3, -1]), and the scratch is zeroed once at kernel start, so that every such read returns a finite
+    // number (it is multiplied by a 0 mask)
+    constexpr int L_SCRU    = L_PPL + 2 * PPLANE_L + 4;   // [3 planes][5 slots][192]
     constexpr int L_SCRP    = L_SCRU + 15 * NCELL * 3;    // [2 planes][3 slots][64]
-    constexpr int L_CEX     = L_SCRP + 6 * NCELL;         // carry of the far x column  [17][3]
-    constexpr int L_CEY     = L_CEX + PNY * 3;            // carry of the far y row     [17][3]
-    constexpr int L_CPX     = L_CEY + PNX * 3;            // pressure far column [9], far row [9]
-    constexpr int L_CPY     = L_CPX + QNY;
-    constexpr int L_TOTAL   = L_CPY + QNX;
+    constexpr int L_RIMT    = L_SCRP + 6 * NCELL;         // rim-thread descriptors: 192 x int4 (waves 0..2)
+    constexpr int L_TOTAL   = L_RIMT + 384;
+    static_assert(L_TOTAL * 8 <= 80 * 1024, "two workgroups per CU");
     [[maybe_unused]] constexpr int XQ = 18;             // doubles per quad record: 4 lanes x 4 + pad (bank spread, 16-B aligned)
     constexpr int NPL_U     = 5;              // plane-DMA instructions per wave and layer (fixed count)
     constexpr int NPL_P     = 1;
@@ -307,6 +309,67 @@ namespace adaflo_hip
                    : "memory");
     }
 
+#if !defined(Q2_DST_POL) || Q2_DST_POL == 0
+#define Q2_DST_POLICY "nt" // dst is written once and not re-read by this kernel
+#elif Q2_DST_POL == 1
+#define Q2_DST_POLICY ""
+#elif Q2_DST_POL == 2
+#define Q2_DST_POLICY "sc1"
+#elif Q2_DST_POL == 3
+#define Q2_DST_POLICY "sc0"
+#else
+#define Q2_DST_POLICY "sc0 sc1"
+#endif
+    // Stores of phase E: sbase + voff for the lanes of `mask` that are active at the call site (these run
+    // inside divergent code: EXEC is narrowed and restored, not set to all ones), 8 or 16 bytes per lane
+    __device__ __forceinline__ void store_b64_masked(const void *sbase, const unsigned voff, const double a,
+                                                     const unsigned long long mask)
+    {
+#if defined(Q2_NOSTORE) || defined(Q2_NODST)
+      if (a != 1.2345e300)
+        return;
+#endif
+      unsigned long long saved;
+      asm volatile("s_and_saveexec_b64 %0, %4\n\t"
+                   "global_store_dwordx2 %1, %2, %3 " Q2_DST_POLICY "\n\t"
+                   "s_mov_b64 exec, %0"
+                   : "=&s"(saved)
+                   : "v"(voff), "v"(a), "s"(sbase), "s"(mask)
+                   : "memory", "scc");
+    }
+    __device__ __forceinline__ void store_b128_dst(const void *sbase, const unsigned voff, const double a,
+                                                   const double b, const unsigned long long mask)
+    {
+#if defined(Q2_NOSTORE) || defined(Q2_NODST)
+      if (a != 1.2345e300)
+        return;
+#endif
+      double2v v;
+      v.x = a;
+      v.y = b;
+      unsigned long long saved;
+      asm volatile("s_and_saveexec_b64 %0, %4\n\t"
+                   "global_store_dwordx4 %1, %2, %3 " Q2_DST_POLICY "\n\t"
+                   "s_mov_b64 exec, %0"
+                   : "=&s"(saved)
+                   : "v"(voff), "v"(v), "s"(sbase), "s"(mask)
+                   : "memory", "scc");
+    }
+    // Load of a single double inside a RARELY taken branch (constrained rows of boundary tiles), waited for
+    // on the spot.  A load the compiler can see would make it put `s_waitcnt vmcnt(0)` at the join behind the
+    // branch -- executed by every wave in every layer, draining the asynchronous LDS-DMA queue (this cost the
+    // round-2 kernel about 0.2 ms of 1.34 ms at 128^3).
+    __device__ __forceinline__ double load_now(const double *p)
+    {
+      double v;
+      asm volatile("global_load_dwordx2 %0, %1, off\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=v"(v)
+                   : "v"(p)
+                   : "memory");
+      return v;
+    }
+
     __device__ __forceinline__ unsigned lds_addr(const void *p)
     {
       return (unsigned)(size_t)p; // LDS aperture: the low 32 bits are the LDS byte address
@@ -335,7 +398,9 @@ namespace adaflo_hip
       const int  jg  = min(j, last_row); // rows beyond the domain: harmless duplicate
       const unsigned voff = 8u * (unsigned)(row0_dbl + jg * row_stride_dbl + dbl);
       const unsigned long long mask = __ballot(act) | 1ull;
-      dma_b128(plane, act ? voff : 8u * (unsigned)(row0_dbl), lds_addr(lds_row0), mask);
+      // (the plane pointer is wave-uniform; say so explicitly: the "s" operand must not end up in VGPRs)
+      dma_b128(reinterpret_cast<const void *>(uniform64(reinterpret_cast<unsigned long long>(plane))),
+               act ? voff : 8u * (unsigned)(row0_dbl), lds_addr(lds_row0), mask);
     }
 
     // the NPL_U row-pair copies one wave contributes to velocity planes K0 and K0+1
@@ -441,52 +506,31 @@ namespace adaflo_hip
       const double tmu_l = is_p ? 0. : A.tmu; // the pressure lane integrates no gradient terms
       const double d0 = d == 0 ? 1. : 0., d1 = d == 1 ? 1. : 0., d2 = d == 2 ? 1. : 0.;
 
-      // ---- per-lane flags of the nodes this lane combines and writes ("owned" nodes) ---------
-      // velocity lanes: local (li,lj) in {0,1}^2, plus li = 2 / lj = 2 for the last valid cell of
-      // the tile in x / y; pressure lane: (0,0) plus li = 1 / lj = 1 likewise.  Bit li + 3*lj.
       const bool valid = cxl < tcx && cyl < tcy;
-      const bool lastx = valid && cxl == tcx - 1, lasty = valid && cyl == tcy - 1; // valid cells only
-      unsigned flags; // bits 0-8 owned, 9-17 constrained, 18-26 seam; m_zero separately (gather)
+      const bool lastx = valid && cxl == tcx - 1; // last valid cell of its row (fix_last below)
+      // ---- per-lane flags: in-plane positions that read_dof_values returns as zero (gather) ---
+      // bit li + 3*lj, local (li, lj) in {0,1,2}^2 (pressure lane: {0,1}^2 in the same bit positions)
       unsigned m_zero = 0;
-      {
-        unsigned m_own = 0, m_con = 0, m_seam = 0;
-        const int  nn_x = is_p ? A.npx : A.nnx, nn_y = is_p ? A.npy : A.nny;
-        const int  deg  = is_p ? 1 : 2;
-        const int  ib = (is_p ? Ip0 : I0) + deg * cxl, jb = (is_p ? Jp0 : J0) + deg * cyl;
-        const uint32_t con = is_p ? A.con_p : A.con_u;
-        const int  st = is_p ? 1 : 3, cc = is_p ? 0 : d;
-        for (int lj = 0; lj <= 2; ++lj)
-          for (int li = 0; li <= 2; ++li)
-            {
-              const int  bit = li + 3 * lj;
-              const int  I = ib + li, J = jb + lj;
-              const bool cx_ = (I == 0 && (con >> (st * 0 + cc) & 1)) || (I == nn_x - 1 && (con >> (st * 1 + cc) & 1));
-              const bool cy_ = (J == 0 && (con >> (st * 2 + cc) & 1)) || (J == nn_y - 1 && (con >> (st * 3 + cc) & 1));
-              if (!RES && (cx_ || cy_))
-                m_zero |= 1u << bit; // read-as-zero in the gather (all 9 in-plane positions)
-              if (li > deg || lj > deg)
-                continue;
-              const bool own = valid && (li < deg || lastx) && (lj < deg || lasty);
-              if (!own)
-                continue;
-              m_own |= 1u << bit;
-              if (cx_ || cy_)
-                m_con |= 1u << bit;
-              // node on the HIGH lateral rim of the tile (and not of the domain): its final value is
-              // assembled by the tile that has it on its low rim (the owner, which stores its own
-              // partial sum straight to dst); this tile's partial sum goes to the slab
-              const int  ti = deg * cxl + li, tj = deg * cyl + lj; // tile-local node index
-              const int  tnx = deg * TX, tny = deg * TY;
-              const bool seam = (ti == tnx && I < nn_x - 1) || (tj == tny && J < nn_y - 1);
-              if (seam)
-                m_seam |= 1u << bit;
-            }
-        flags = m_own | (m_con << 9) | (m_seam << 18);
-      }
-      // keep ONE packed register alive across the quadrature loop (register pressure)
-#define m_own (flags & 0x1ffu)
-#define m_con ((flags >> 9) & 0x1ffu)
-#define m_seam ((flags >> 18) & 0x1ffu)
+      if (!RES)
+        {
+          const int  nn_x = is_p ? A.npx : A.nnx, nn_y = is_p ? A.npy : A.nny;
+          const int  deg  = is_p ? 1 : 2;
+          const int  ib = (is_p ? Ip0 : I0) + deg * cxl, jb = (is_p ? Jp0 : J0) + deg * cyl;
+          const uint32_t con = is_p ? A.con_p : A.con_u;
+          const int  st = is_p ? 1 : 3, cc = is_p ? 0 : d;
+          for (int lj = 0; lj <= 2; ++lj)
+            for (int li = 0; li <= 2; ++li)
+              {
+                const int  I = ib + li, J = jb + lj;
+                const bool cx_ = (I == 0 && (con >> (st * 0 + cc) & 1)) || (I == nn_x - 1 && (con >> (st * 1 + cc) & 1));
+                const bool cy_ = (J == 0 && (con >> (st * 2 + cc) & 1)) || (J == nn_y - 1 && (con >> (st * 3 + cc) & 1));
+                if (cx_ || cy_)
+                  m_zero |= 1u << (li + 3 * lj);
+              }
+        }
+      // does a regular node of this tile sit on a constrained low face of the domain (phase E1)?
+      const bool con_lat_tile = (I0 == 0 && (((A.con_u)&7u) != 0u || (A.con_p & 1u) != 0u)) ||
+                                (J0 == 0 && (((A.con_u >> 6) & 7u) != 0u || ((A.con_p >> 2) & 1u) != 0u));
       const bool     conz_lo = is_p ? (A.con_p >> 4 & 1) : (A.con_u >> (12 + d) & 1);
       const bool     conz_hi = is_p ? (A.con_p >> 5 & 1) : (A.con_u >> (15 + d) & 1);
       const unsigned lane_g  = is_p ? (unsigned)((Jp0 + cyl) * A.npx + Ip0 + cxl) :
@@ -497,9 +541,63 @@ namespace adaflo_hip
       const int fix_last = (lastx && (nv_row & 1) && (is_p || d == 2)) ? 1 : 0;
 
       double cu[4] = {0., 0., 0., 0.}; // carried top-plane sums of the regular owned nodes
-      // zero the LDS carries of the far column / row
-      for (int e = tid; e < L_TOTAL - L_CEX; e += NT)
-        lds[L_CEX + e] = 0.;
+      double rim_carry = 0.;           // ... and of this thread's high-rim entry (rim threads, phase E2)
+      // zero the publish scratch once (masked reads of absent neighbours must see finite numbers)
+      for (int e = tid; e < L_RIMT - (L_SCRU - 4); e += NT)
+        lds[L_SCRU - 4 + e] = 0.;
+      // Descriptor of the high-rim node entry this thread assembles in phase E2: thread e < 99 = velocity
+      // entry (node m = e / 3, component e % 3), thread 128 + e, e < 17 = pressure entry.  Nodes: the north
+      // row (i = m, j = ey) for m < TN, then the east column (i = ex, j = m - TN) below the corner, where
+      // (ex, ey) = high rim of the VALID cells of the tile (= TN - 1 except in tiles clipped by the domain).
+      // Its value in a plane = A + B, A and B being what one or two cells of the last column / row published:
+      // .x = LDS offsets of A and B inside a plane block (16 bits each), .y = offset in a dst plane,
+      // .z = offset in a slab plane | offset in a z-slab plane << 16, .w = flags: 1 entry exists, 2 / 4 A / B
+      // present, 8 seam (partial sum -> slab), 16 on a constrained lateral face, 32 / 64 constrained on the
+      // bottom / top face of the domain.
+      if (tid < 192) // (all lanes of waves 0..2 read their descriptor in phase E2)
+        {
+          const bool rp  = tid >= 128;
+          const int  e   = rp ? tid - 128 : tid;
+          const int  deg = rp ? 1 : 2, nc = rp ? 1 : 3, TN = deg * TX + 1;
+          const int  m = e / nc, comp = e - m * nc;
+          const int  ex = deg * tcx, ey = deg * tcy;
+          const bool north = m < TN;
+          const int  ti = north ? m : ex, tj = north ? ey : m - TN;
+          bool       ok = m < 2 * TN - 1 && (north ? ti <= ex : tj < ey);
+          if (rp ? !(WITH_P) : DIV)
+            ok = false;
+          const int  c   = (north ? ti : tj) / deg;          // cell index along the rim
+          const bool odd = deg == 2 && ((north ? ti : tj) & 1);
+          const int  cmax = north ? tcx : tcy;               // cells along the rim
+          const bool hasA = c < cmax, hasB = !odd && c >= 1;
+          const int  ca = min(c, cmax - 1), cb = max(c - 1, 0);
+          const int  cellA = north ? (tcy - 1) * TX + ca : ca * TX + tcx - 1;
+          const int  cellB = north ? (tcy - 1) * TX + cb : cb * TX + tcx - 1;
+          int        slotA;
+          if (rp)
+            slotA = north ? 1 : 0;
+          else
+            slotA = north ? (odd ? 4 : 3) : (odd ? 1 : 0);
+          const int offA = rp ? slotA * NCELL + cellA : slotA * (NCELL * 3) + cellA * 3 + comp;
+          const int offB = rp ? 2 * NCELL + cellB : 2 * (NCELL * 3) + cellB * 3 + comp;
+          const int nn_x = rp ? A.npx : A.nnx, nn_y = rp ? A.npy : A.nny;
+          const int I = (rp ? Ip0 : I0) + ti, J = (rp ? Jp0 : J0) + tj;
+          const uint32_t con = rp ? A.con_p : A.con_u;
+          const int  st = rp ? 1 : 3;
+          const bool cx_ = (I == 0 && (con >> (st * 0 + comp) & 1)) || (I == nn_x - 1 && (con >> (st * 1 + comp) & 1));
+          const bool cy_ = (J == 0 && (con >> (st * 2 + comp) & 1)) || (J == nn_y - 1 && (con >> (st * 3 + comp) & 1));
+          const bool seam = (ti == TN - 1 && I < nn_x - 1) || (tj == TN - 1 && J < nn_y - 1);
+          const bool czl = rp ? (A.con_p >> 4 & 1) : (A.con_u >> (12 + comp) & 1);
+          const bool czh = rp ? (A.con_p >> 5 & 1) : (A.con_u >> (15 + comp) & 1);
+          int4       rd;
+          rd.x = offA | (offB << 16);
+          rd.y = (J * nn_x + I) * nc + comp;
+          rd.z = ((rp ? rim_index<QNX>(min(ti, QNX - 1), min(tj, QNY - 1)) : rim_index<PNX>(min(ti, PNX - 1), min(tj, PNY - 1))) * nc + comp) |
+                 (((tj * TN + ti) * nc + comp) << 16);
+          rd.w = (ok ? 1 : 0) | (hasA ? 2 : 0) | (hasB ? 4 : 0) | (seam ? 8 : 0) | ((cx_ || cy_) ? 16 : 0) |
+                 (czl ? 32 : 0) | (czh ? 64 : 0);
+          reinterpret_cast<int4 *>(lds + L_RIMT)[tid] = rd;
+        }
 
       // ---- prologue: first node planes and first state pieces ---------------------------------
       const double2 *state = reinterpret_cast<const double2 *>(A.state);
@@ -958,192 +1056,173 @@ namespace adaflo_hip
 #endif
 
           // ---- E: combine per owned node and write the two finished planes -----------------
+          // (round 3: straight-line code.  The old version cost 0.34 ms of a 1.34 ms kernel at 128^3 --
+          // measured with -DQ2_SKIP_E -- for ~0.1 ms worth of stores: per-node branches, one LDS
+          // round trip per neighbour value, 64-bit address arithmetic.)
+          // E1: every lane finishes the REGULAR nodes of its cell, local (li, lj) in {0,1}^2 (pressure:
+          //     (0,0)): own value + what the west / south / south-west cells published, all LDS reads
+          //     issued together, absent neighbours masked by 0/1 factors in the FMAs;
+          // E2: the nodes on the HIGH rim of the tile (partial sums for the seam slabs, or final values on
+          //     the domain boundary) are assembled by dedicated "rim threads" from the same published
+          //     values, one node entry per thread, descriptors in LDS (L_RIMT), carry in one register.
           // Re-derive the lane coordinates from an opaque copy of the thread id: otherwise the
           // compiler hoists all per-lane address arithmetic of this phase out of the layer loop
           // and spills it around the quadrature loop (scratch reloads = s_waitcnt vmcnt(0) = a
           // drained DMA queue every layer).
           int tid_e = threadIdx.x;
           asm volatile("" : "+v"(tid_e));
-          const int  lane_e = tid_e & 63;
-          const int  d = lane_e & 3, cq_e = lane_e >> 2;
-          const int  cxl = cq_e & 7, cyl = 2 * wave + (cq_e >> 3), cell = cyl * TX + cxl;
+          const int  d = tid_e & 3, cell = tid_e >> 2; // cell = cyl * TX + cxl
+          const int  cxl = cell & 7, cyl = cell >> 3;
           const bool is_p = d == 3;
           const bool valid = cxl < tcx && cyl < tcy;
-          const bool lastx = valid && cxl == tcx - 1, lasty = valid && cyl == tcy - 1; // valid cells only
           const bool hasW = cxl > 0, hasS = cyl > 0;
+          const double fW = hasW ? 1. : 0., fS = hasS ? 1. : 0., fSW = (hasW && hasS) ? 1. : 0.;
+          const unsigned long long vmask_u = __ballot(valid && !is_p), vmask_p = __ballot(valid && is_p);
+          // constrained rows among the regular nodes: only on the low domain faces (the high faces are rim
+          // nodes) and on the bottom plane; wave-uniform test, boundary tiles only
+          const bool zc_lo = cz == 0 && (((A.con_u >> 12) & 7u) != 0u || ((A.con_p >> 4) & 1u) != 0u);
+          const bool slow  = con_lat_tile || zc_lo;
           if (DIV && !is_p)
             {
             }
           else if (!is_p)
             {
               const double *sc = lds + L_SCRU + cell * 3 + d;
+              double        w0[3], w1[3], t0[3], t1[3], sw[3];
 #pragma unroll
               for (int lk = 0; lk < 3; ++lk)
                 {
-                  // contributions of the west / south / south-west cells
-                  const double w0 = hasW ? sc[(lk * 5 + 0) * (NCELL * 3) - 3] : 0.;
-                  const double w1 = hasW ? sc[(lk * 5 + 1) * (NCELL * 3) - 3] : 0.;
-                  const double w2 = hasW ? sc[(lk * 5 + 2) * (NCELL * 3) - 3] : 0.;
-                  const double t0 = hasS ? sc[(lk * 5 + 3) * (NCELL * 3) - 24] : 0.;
-                  const double t1 = hasS ? sc[(lk * 5 + 4) * (NCELL * 3) - 24] : 0.;
-                  const double t2 = hasS ? sc[(lk * 5 + 2) * (NCELL * 3) - 24] : 0.;
-                  const double sw = (hasW && hasS) ? sc[(lk * 5 + 2) * (NCELL * 3) - 27] : 0.;
-                  double       nv[9];
-                  nv[0] = R[0 + 9 * lk] + w0 + t0 + sw;
-                  nv[1] = R[1 + 9 * lk] + t1;
-                  nv[2] = R[2 + 9 * lk] + t2;
-                  nv[3] = R[3 + 9 * lk] + w1;
-                  nv[4] = R[4 + 9 * lk];
-                  nv[5] = R[5 + 9 * lk];
-                  nv[6] = R[6 + 9 * lk] + w2;
-                  nv[7] = R[7 + 9 * lk];
-                  nv[8] = R[8 + 9 * lk];
-                  double *cex = lds + L_CEX + (2 * cyl) * 3 + d, *cey = lds + L_CEY + (2 * cxl) * 3 + d;
+                  w0[lk] = sc[(lk * 5 + 0) * (NCELL * 3) - 3];  // west cell's (2,0) = my (0,0)
+                  w1[lk] = sc[(lk * 5 + 1) * (NCELL * 3) - 3];  //             (2,1) = my (0,1)
+                  t0[lk] = sc[(lk * 5 + 3) * (NCELL * 3) - 24]; // south cell's (0,2) = my (0,0)
+                  t1[lk] = sc[(lk * 5 + 4) * (NCELL * 3) - 24]; //              (1,2) = my (1,0)
+                  sw[lk] = sc[(lk * 5 + 2) * (NCELL * 3) - 27]; // south-west cell's (2,2) = my (0,0)
+                }
+              const unsigned voff = 8u * (unsigned)(lane_g + d); // (lane_g - d) + 2 d
+#pragma unroll
+              for (int lk = 0; lk < 3; ++lk)
+                {
+                  double a0 = fma(fSW, sw[lk], fma(fS, t0[lk], fma(fW, w0[lk], R[0 + 9 * lk])));
+                  double a1 = fma(fS, t1[lk], R[1 + 9 * lk]);
+                  double a3 = fma(fW, w1[lk], R[3 + 9 * lk]);
+                  double a4 = R[4 + 9 * lk];
                   if (lk == 2)
                     {
                       // top plane: finished only after the next layer -> carry
-                      cu[0] = nv[0];
-                      cu[1] = nv[1];
-                      cu[2] = nv[3];
-                      cu[3] = nv[4];
-                      if (lastx)
-                        {
-                          cex[0] = nv[2];
-                          cex[3] = nv[5];
-                        }
-                      if (lasty)
-                        {
-                          cey[0] = nv[6];
-                          cey[3] = nv[7];
-                        }
-                      if (lastx && lasty)
-                        cex[6] = nv[8];
+                      cu[0] = a0, cu[1] = a1, cu[2] = a3, cu[3] = a4;
                     }
                   else
                     {
-                      const int K = 2 * cz + lk;
                       if (lk == 0)
+                        a0 += cu[0], a1 += cu[1], a3 += cu[2], a4 += cu[3];
+                      const int     K  = 2 * cz + lk;
+                      const double *sp = A.src_u + (size_t)K * A.nny * A.nnx * 3;
+                      double       *dp = A.dst_u + (size_t)K * A.nny * A.nnx * 3;
+                      if (slow)
                         {
-                          nv[0] += cu[0];
-                          nv[1] += cu[1];
-                          nv[3] += cu[2];
-                          nv[4] += cu[3];
-                          if (lastx)
-                            {
-                              nv[2] += cex[0];
-                              nv[5] += cex[3];
-                            }
-                          if (lasty)
-                            {
-                              nv[6] += cey[0];
-                              nv[7] += cey[3];
-                            }
-                          if (lastx && lasty)
-                            nv[8] += cex[6];
+                          // constrained rows carry +src (:247-256), 0 in the residual
+                          const bool zc = lk == 0 && cz == 0 && ((A.con_u >> (12 + d)) & 1u);
+                          const bool cw = cxl == 0 && I0 == 0 && ((A.con_u >> d) & 1u);
+                          const bool cs = cyl == 0 && J0 == 0 && ((A.con_u >> (6 + d)) & 1u);
+                          if (valid && (zc || cw || cs))
+                            a0 = RES ? 0. : load_now(sp + lane_g);
+                          if (valid && (zc || cs))
+                            a1 = RES ? 0. : load_now(sp + lane_g + 3);
+                          if (valid && (zc || cw))
+                            a3 = RES ? 0. : load_now(sp + lane_g + (unsigned)(A.nnx * 3));
+                          if (valid && zc)
+                            a4 = RES ? 0. : load_now(sp + lane_g + (unsigned)(A.nnx * 3 + 3));
                         }
-                      const bool   zcon  = (K == 0 && conz_lo);
-                      const size_t pbase = (size_t)K * A.nny * A.nnx * 3;
-                      // constrained rows carry +src (:247-256); boundary tiles only
-                      if (m_con != 0u || zcon)
-                        {
-#pragma unroll
-                          for (int n = 0; n < 9; ++n)
-                            if ((m_own >> n & 1u) && ((m_con >> n & 1u) || zcon))
-                              nv[n] = RES ? 0. : A.src_u[pbase + lane_g + (unsigned)(((n / 3) * A.nnx + n % 3) * 3)];
-                        }
-                      // partial sums of high-rim nodes shared with other workgroups -> slab
-                      // (q2_seam_fixup_kernel adds them to the owner tile's partial sum in dst)
-                      if (m_seam != 0u)
-                        {
-#pragma unroll
-                          for (int n = 0; n < 9; ++n)
-                            if ((m_own & m_seam & ~m_con) >> n & 1u)
-                              Q2_STORE_SLAB(A.slab_u[((wgs * (2 * A.LZ + 1) + 2 * layer + lk) * RIM_U +
-                                                 rim_index<PNX>(2 * cxl + n % 3, 2 * cyl + n / 3)) * 3 + d], nv[n]);
-                        }
-                      // regular nodes (li, lj in {0,1}): the quad's 2 nodes x 3 components of a row are 48
-                      // contiguous bytes; regroup them inside the quad so that every lane stores 16 B
-#pragma unroll
-                      for (int lj = 0; lj < 2; ++lj)
-                        {
-                          const double x0 = nv[3 * lj], x1 = nv[3 * lj + 1];
-                          const double b00 = quad_bcast<0>(x0), b01 = quad_bcast<1>(x0), b02 = quad_bcast<2>(x0);
-                          const double b10 = quad_bcast<0>(x1), b11 = quad_bcast<1>(x1), b12 = quad_bcast<2>(x1);
-                          const double first = sel3(d, b00, b02, b11), second = sel3(d, b01, b10, b12);
-                          if (valid)
-                            store_b128(A.dst_u + pbase + (lane_g - d) + (unsigned)(lj * A.nnx * 3 + 2 * d), first, second);
-                        }
-                      // far rim of the tile (li = 2 / lj = 2): last cells only
-                      if (lastx || lasty)
-                        {
-#pragma unroll
-                          for (int n = 0; n < 9; ++n)
-                            if ((n % 3 == 2 || n / 3 == 2) && (m_own >> n & 1u) &&
-                                (((m_con | ~m_seam) >> n & 1u) || zcon))
-                              Q2_STORE(A.dst_u[pbase + lane_g + (unsigned)(((n / 3) * A.nnx + n % 3) * 3)], nv[n]);
-                        }
+                      // the quad's 2 nodes x 3 components of a row are 48 contiguous bytes; regroup them
+                      // inside the quad so that every lane stores 16 B (scalar row base + lane offset)
+                      {
+                        const double b00 = quad_bcast<0>(a0), b01 = quad_bcast<1>(a0), b02 = quad_bcast<2>(a0);
+                        const double b10 = quad_bcast<0>(a1), b11 = quad_bcast<1>(a1), b12 = quad_bcast<2>(a1);
+                        store_b128_dst(dp, voff, sel3(d, b00, b02, b11), sel3(d, b01, b10, b12), vmask_u);
+                      }
+                      {
+                        const double b00 = quad_bcast<0>(a3), b01 = quad_bcast<1>(a3), b02 = quad_bcast<2>(a3);
+                        const double b10 = quad_bcast<0>(a4), b11 = quad_bcast<1>(a4), b12 = quad_bcast<2>(a4);
+                        store_b128_dst(dp + A.nnx * 3, voff, sel3(d, b00, b02, b11), sel3(d, b01, b10, b12), vmask_u);
+                      }
                     }
                 }
             }
           else if (WITH_P && A.integrate_p)
             {
               const double *sc = lds + L_SCRP + cell;
+              double        w0[2], t0[2], sw[2];
 #pragma unroll
               for (int lk = 0; lk < 2; ++lk)
                 {
-                  const double w0 = hasW ? sc[(lk * 3 + 0) * NCELL - 1] : 0.;            // W (1,0)
-                  const double w1 = hasW ? sc[(lk * 3 + 2) * NCELL - 1] : 0.;            // W (1,1)
-                  const double t0 = hasS ? sc[(lk * 3 + 1) * NCELL - 8] : 0.;            // S (0,1)
-                  const double t1 = hasS ? sc[(lk * 3 + 2) * NCELL - 8] : 0.;            // S (1,1)
-                  const double sw = (hasW && hasS) ? sc[(lk * 3 + 2) * NCELL - 9] : 0.;  // SW (1,1)
-                  double       nv[4];
-                  nv[0] = R[0 + 18 * lk] + w0 + t0 + sw;
-                  nv[1] = R[2 + 18 * lk] + t1; // local (1,0)
-                  nv[2] = R[6 + 18 * lk] + w1; // local (0,1)
-                  nv[3] = R[8 + 18 * lk];      // local (1,1)
-                  double *cpx = lds + L_CPX + cyl, *cpy = lds + L_CPY + cxl;
-                  if (lk == 1)
-                    {
-                      cu[0] = nv[0];
-                      if (lastx)
-                        cpx[0] = nv[1];
-                      if (lasty)
-                        cpy[0] = nv[2];
-                      if (lastx && lasty)
-                        cpx[1] = nv[3];
-                    }
-                  else
-                    {
-                      nv[0] += cu[0];
-                      if (lastx)
-                        nv[1] += cpx[0];
-                      if (lasty)
-                        nv[2] += cpy[0];
-                      if (lastx && lasty)
-                        nv[3] += cpx[1];
-                      const int    K     = cz;
-                      const bool   zcon  = (K == 0 && conz_lo);
-                      const size_t pbase = (size_t)K * A.npy * A.npx;
+                  w0[lk] = sc[(lk * 3 + 0) * NCELL - 1]; // W (1,0)
+                  t0[lk] = sc[(lk * 3 + 1) * NCELL - 8]; // S (0,1)
+                  sw[lk] = sc[(lk * 3 + 2) * NCELL - 9]; // SW (1,1)
+                }
+              double a0 = fma(fSW, sw[0], fma(fS, t0[0], fma(fW, w0[0], R[0]))) + cu[0];
+              cu[0]     = fma(fSW, sw[1], fma(fS, t0[1], fma(fW, w0[1], R[18])));
+              const double *sp = A.src_p + (size_t)cz * A.npy * A.npx;
+              double       *dp = A.dst_p + (size_t)cz * A.npy * A.npx;
+              if (slow)
+                {
+                  const bool con = (cz == 0 && ((A.con_p >> 4) & 1u)) || (cxl == 0 && Ip0 == 0 && (A.con_p & 1u)) ||
+                                   (cyl == 0 && Jp0 == 0 && ((A.con_p >> 2) & 1u));
+                  if (valid && con)
+                    a0 = RES ? 0. : -load_now(sp + lane_g); // -1 on the pressure block of vmult
+                }
+              store_b64_masked(dp, 8u * lane_g, a0, vmask_p);
+            }
+
+          // ---- E2: rim threads (waves 0, 1: velocity entries; wave 2: pressure entries) ----------
+          if (wave < 2 && !DIV)
+            {
+              const int4 rd = reinterpret_cast<const int4 *>(lds + L_RIMT)[tid_e];
+              const int  fl = rd.w;
+              const double *pa = lds + L_SCRU + (rd.x & 0xffff), *pb = lds + L_SCRU + (rd.x >> 16);
+              const double x0 = pa[0], y0 = pb[0], x1 = pa[5 * NCELL * 3], y1 = pb[5 * NCELL * 3];
+              const double x2 = pa[10 * NCELL * 3], y2 = pb[10 * NCELL * 3];
+              const bool   mA = fl & 2, mB = fl & 4;
+              const double v0 = ((mA ? x0 : 0.) + (mB ? y0 : 0.)) + rim_carry;
+              const double v1 = (mA ? x1 : 0.) + (mB ? y1 : 0.);
+              rim_carry       = (mA ? x2 : 0.) + (mB ? y2 : 0.);
+              if (fl & 1)
+                {
 #pragma unroll
-                      for (int n = 0; n < 4; ++n)
-                        {
-                          const int li = n % 2, lj = n / 2, bit = li + 3 * lj;
-                          if (m_own >> bit & 1u)
-                            {
-                              const size_t idx = pbase + lane_g + (unsigned)(lj * A.npx + li);
-                              if ((m_con >> bit & 1u) || zcon)
-                                Q2_STORE(A.dst_p[idx], RES ? 0. : -A.src_p[idx]); // -1 on the pressure block of vmult
-                              else if (m_seam >> bit & 1u)
-                                Q2_STORE_SLAB(A.slab_p[(wgs * (A.LZ + 1) + layer) * RIM_P +
-                                         rim_index<QNX>(cxl + li, cyl + lj)], nv[n]);
-                              else
-                                Q2_STORE(A.dst_p[idx], nv[n]);
-                            }
-                        }
+                  for (int lk = 0; lk < 2; ++lk)
+                    {
+                      const int    K   = 2 * cz + lk;
+                      const size_t idx = (size_t)K * A.nny * A.nnx * 3 + (unsigned)rd.y;
+                      const double v   = lk == 0 ? v0 : v1;
+                      if ((fl & 16) || (K == 0 && (fl & 32)))
+                        Q2_STORE(A.dst_u[idx], RES ? 0. : load_now(A.src_u + idx));
+                      else if (fl & 8)
+                        Q2_STORE_SLAB(A.slab_u[(wgs * (2 * A.LZ + 1) + 2 * layer + lk) * (RIM_U * 3) + (rd.z & 0xffff)], v);
+                      else
+                        Q2_STORE(A.dst_u[idx], v);
                     }
                 }
             }
-          // scratch may be overwritten / carries read by the next layer only after everybody is done
+          else if (wave == 2 && WITH_P && A.integrate_p)
+            {
+              const int4 rd = reinterpret_cast<const int4 *>(lds + L_RIMT)[tid_e];
+              const int  fl = rd.w;
+              const double *pa = lds + L_SCRP + (rd.x & 0xffff), *pb = lds + L_SCRP + (rd.x >> 16);
+              const double x0 = pa[0], y0 = pb[0], x1 = pa[3 * NCELL], y1 = pb[3 * NCELL];
+              const bool   mA = fl & 2, mB = fl & 4;
+              const double v0 = ((mA ? x0 : 0.) + (mB ? y0 : 0.)) + rim_carry;
+              rim_carry       = (mA ? x1 : 0.) + (mB ? y1 : 0.);
+              if (fl & 1)
+                {
+                  const size_t idx = (size_t)cz * A.npy * A.npx + (unsigned)rd.y;
+                  if ((fl & 16) || (cz == 0 && (fl & 32)))
+                    Q2_STORE(A.dst_p[idx], RES ? 0. : -load_now(A.src_p + idx));
+                  else if (fl & 8)
+                    Q2_STORE_SLAB(A.slab_p[(wgs * (A.LZ + 1) + layer) * RIM_P + (rd.z & 0xffff)], v0);
+                  else
+                    Q2_STORE(A.dst_p[idx], v0);
+                }
+            }
+          // scratch may be overwritten by the next layer only after everybody is done
           lds_barrier();
         }
 
@@ -1151,77 +1230,87 @@ namespace adaflo_hip
       {
         const int  cze   = cz0 + nl;
         const bool zseam = cze < A.ncz;
+        const int  cxl = cell & 7, cyl = cell >> 3;
+        const bool valid = cxl < tcx && cyl < tcy;
         if (DIV && !is_p)
           {
           }
         else if (!is_p)
           {
-            const int     K     = 2 * cze;
-            const bool    zcon  = (K == A.nnz - 1 && conz_hi);
-            const size_t  pbase = (size_t)K * A.nny * A.nnx * 3;
-            const double *cex = lds + L_CEX + (2 * cyl) * 3 + d, *cey = lds + L_CEY + (2 * cxl) * 3 + d;
-            double        nv[9];
-            nv[0] = cu[0];
-            nv[1] = cu[1];
-            nv[3] = cu[2];
-            nv[4] = cu[3];
-            nv[2] = lastx ? cex[0] : 0.;
-            nv[5] = lastx ? cex[3] : 0.;
-            nv[6] = lasty ? cey[0] : 0.;
-            nv[7] = lasty ? cey[3] : 0.;
-            nv[8] = (lastx && lasty) ? cex[6] : 0.;
+            const int    K     = 2 * cze;
+            const bool   zcon  = K == A.nnz - 1 && ((A.con_u >> (15 + d)) & 1u);
+            const bool   cw    = cxl == 0 && I0 == 0 && ((A.con_u >> d) & 1u);
+            const bool   cs    = cyl == 0 && J0 == 0 && ((A.con_u >> (6 + d)) & 1u);
+            const size_t pbase = (size_t)K * A.nny * A.nnx * 3;
 #pragma unroll
-            for (int n = 0; n < 9; ++n)
-              if (m_own >> n & 1u)
+            for (int n = 0; n < 4; ++n)
+              if (valid)
                 {
-                  const int    li = n % 3, lj = n / 3;
+                  const int    li = n & 1, lj = n >> 1;
                   const size_t idx = pbase + lane_g + (unsigned)((lj * A.nnx + li) * 3);
-                  if ((m_con >> n & 1u) || zcon)
-                    Q2_STORE(A.dst_u[idx], RES ? 0. : A.src_u[idx]);
-                  else if (m_seam >> n & 1u)
-                    Q2_STORE_SLAB(A.slab_u[((wgs * (2 * A.LZ + 1) + 2 * nl) * RIM_U +
-                              rim_index<PNX>(2 * cxl + li, 2 * cyl + lj)) * 3 + d], nv[n]);
+                  if (zcon || (li == 0 && cw) || (lj == 0 && cs))
+                    Q2_STORE(A.dst_u[idx], RES ? 0. : load_now(A.src_u + idx));
                   else if (zseam)
-                    Q2_STORE_SLAB(A.zslab_u[(wgs * (PNX * PNY) + (2 * cyl + lj) * PNX + 2 * cxl + li) * 3 + d], nv[n]);
+                    Q2_STORE_SLAB(A.zslab_u[(wgs * (PNX * PNY) + (2 * cyl + lj) * PNX + 2 * cxl + li) * 3 + d], cu[n]);
                   else
-                    Q2_STORE(A.dst_u[idx], nv[n]);
+                    Q2_STORE(A.dst_u[idx], cu[n]);
                 }
           }
         else if (WITH_P && A.integrate_p)
           {
-            const int     K     = cze;
-            const bool    zcon  = (K == A.npz - 1 && conz_hi);
-            const size_t  pbase = (size_t)K * A.npy * A.npx;
-            const double *cpx = lds + L_CPX + cyl, *cpy = lds + L_CPY + cxl;
-            double        nv[4];
-            nv[0] = cu[0];
-            nv[1] = lastx ? cpx[0] : 0.;
-            nv[2] = lasty ? cpy[0] : 0.;
-            nv[3] = (lastx && lasty) ? cpx[1] : 0.;
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
+            const int    K    = cze;
+            const bool   con  = (K == A.npz - 1 && ((A.con_p >> 5) & 1u)) || (cxl == 0 && Ip0 == 0 && (A.con_p & 1u)) ||
+                                (cyl == 0 && Jp0 == 0 && ((A.con_p >> 2) & 1u));
+            const size_t idx  = (size_t)K * A.npy * A.npx + lane_g;
+            if (valid)
               {
-                const int li = n % 2, lj = n / 2, bit = li + 3 * lj;
-                if (m_own >> bit & 1u)
+                if (con)
+                  Q2_STORE(A.dst_p[idx], RES ? 0. : -load_now(A.src_p + idx));
+                else if (zseam)
+                  Q2_STORE_SLAB(A.zslab_p[wgs * PPLANE + cyl * QNX + cxl], cu[0]);
+                else
+                  Q2_STORE(A.dst_p[idx], cu[0]);
+              }
+          }
+        // rim entries of the top plane
+        const bool rim_u = wave < 2 && !DIV, rim_p = wave == 2 && WITH_P && A.integrate_p;
+        if (rim_u || rim_p)
+          {
+            const int4 rd = reinterpret_cast<const int4 *>(lds + L_RIMT)[tid];
+            const int  fl = rd.w;
+            if (fl & 1)
+              {
+                if (rim_u)
                   {
-                    const size_t idx = pbase + lane_g + (unsigned)(lj * A.npx + li);
-                    if ((m_con >> bit & 1u) || zcon)
-                      Q2_STORE(A.dst_p[idx], RES ? 0. : -A.src_p[idx]);
-                    else if (m_seam >> bit & 1u)
-                      Q2_STORE_SLAB(A.slab_p[(wgs * (A.LZ + 1) + nl) * RIM_P + rim_index<QNX>(cxl + li, cyl + lj)], nv[n]);
+                    const int    K   = 2 * cze;
+                    const size_t idx = (size_t)K * A.nny * A.nnx * 3 + (unsigned)rd.y;
+                    if ((fl & 16) || (K == A.nnz - 1 && (fl & 64)))
+                      Q2_STORE(A.dst_u[idx], RES ? 0. : load_now(A.src_u + idx));
+                    else if (fl & 8)
+                      Q2_STORE_SLAB(A.slab_u[(wgs * (2 * A.LZ + 1) + 2 * nl) * (RIM_U * 3) + (rd.z & 0xffff)], rim_carry);
                     else if (zseam)
-                      Q2_STORE_SLAB(A.zslab_p[wgs * PPLANE + (cyl + lj) * QNX + cxl + li], nv[n]);
+                      Q2_STORE_SLAB(A.zslab_u[wgs * (PNX * PNY * 3) + (rd.z >> 16)], rim_carry);
                     else
-                      Q2_STORE(A.dst_p[idx], nv[n]);
+                      Q2_STORE(A.dst_u[idx], rim_carry);
+                  }
+                else
+                  {
+                    const int    K   = cze;
+                    const size_t idx = (size_t)K * A.npy * A.npx + (unsigned)rd.y;
+                    if ((fl & 16) || (K == A.npz - 1 && (fl & 64)))
+                      Q2_STORE(A.dst_p[idx], RES ? 0. : -load_now(A.src_p + idx));
+                    else if (fl & 8)
+                      Q2_STORE_SLAB(A.slab_p[(wgs * (A.LZ + 1) + nl) * RIM_P + (rd.z & 0xffff)], rim_carry);
+                    else if (zseam)
+                      Q2_STORE_SLAB(A.zslab_p[wgs * PPLANE + (rd.z >> 16)], rim_carry);
+                    else
+                      Q2_STORE(A.dst_p[idx], rim_carry);
                   }
               }
           }
       }
     }
 
-#undef m_own
-#undef m_con
-#undef m_seam
 
     // second pass: add the seam partials per node (fixed order -> reproducible).
     // One wave per (tile, plane): lane = low-rim entry, so the south row (contiguous in dst and
