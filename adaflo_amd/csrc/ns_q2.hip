@@ -20,6 +20,7 @@
 //    four lanes of a quad run the identical Q2 interpolation code.
 #include "kernels.hpp"
 #include <cstring>
+#include <utility>
 #include <vector>
 
 namespace adaflo_hip
@@ -174,14 +175,105 @@ namespace adaflo_hip
     static_assert(3 * (PNY * 52) <= 4 * RING * PIECE, "the residual mode keeps the old-solution planes in the ring area");
     constexpr int L_PPL     = L_UPL + 3 * UPLANE_L;       // 2 pressure node planes
     // publish scratch: the masked reads "west / south of the first cells" reach up to 27 doubles below a
-    // slot, i.e. (slot 0 of plane 0) below the scratch itself: 4 zeroed doubles in front (cell 0 reads
-    // [-3, -1]), and the scratch is zeroed once at kernel start, so that every such read returns a finite
-    // number (it is multiplied by a 0 mask)
-    constexpr int L_SCRU    = L_PPL + 2 * PPLANE_L + 4;   // [3 planes][5 slots][192]
+    // slot, i.e. (slot 0 of plane 0) below the scratch itself: 4 doubles in front (cell 0 reads [-3, -1]);
+    // every such read must return a finite number (it is multiplied by a 0 mask): the area is zeroed once
+    // at kernel start and afterwards only ever holds published sums or state pieces.
+    // The scratch is only live between the quadrature loop and the end of a layer.  During the loop it
+    // serves as an EXTENSION OF THE STATE RING (NRING_X more slots per wave, see RingSched): the kernel is
+    // limited by how well the state stream overlaps with the arithmetic, i.e. by the pieces in flight.
+    constexpr int NRING_X   = 9;                          // extension slots per wave (constant coefficients)
+    constexpr int L_EXT     = L_PPL + 2 * PPLANE_L;       // [4 waves][NRING_X][PIECE]
+    constexpr int L_SCRU    = L_EXT + 4;                  // [3 planes][5 slots][192]
     constexpr int L_SCRP    = L_SCRU + 15 * NCELL * 3;    // [2 planes][3 slots][64]
-    constexpr int L_RIMT    = L_SCRP + 6 * NCELL;         // rim-thread descriptors: 192 x int4 (waves 0..2)
+    constexpr int L_RIMT    = L_EXT + 4 * NRING_X * PIECE; // rim-thread descriptors: 192 x int4 (waves 0..2)
+    static_assert(L_SCRP + 6 * NCELL <= L_RIMT, "the publish scratch lives inside the ring extension");
     constexpr int L_TOTAL   = L_RIMT + 384;
     static_assert(L_TOTAL * 8 <= 80 * 1024, "two workgroups per CU");
+
+    // Issue schedule of the state ring, all compile time.  A layer has 54 pieces p = 2q + half per wave;
+    // piece p lives in slot p % NS, NS = NR real + NX extension slots (NS divides 54: the slots do not
+    // depend on the layer).  After point q has been consumed the pieces LA ahead are issued into the two
+    // slots that became free (LA = NS for even NS, NS - 1 for odd NS); pieces of the NEXT layer are issued
+    // that way only into real slots -- the extension is the publish scratch and is busy between the loop
+    // and the end of the layer -- and the next layer's pieces in extension slots follow as one burst at the
+    // top of that layer.  younger(q) = number of vector-memory operations issued after the later of the
+    // pieces 2q, 2q+1 and before point q waits for them (vmcnt counts in order of issue): the burst, the
+    // node-plane copies (npl), the pieces of the points in between -- and at least `nst` stores of the
+    // combine phase (fewer than the real count only makes the wait stronger).
+    template <int NR, int NX>
+    struct RingSched
+    {
+      static constexpr int NS = NR + NX, LA = (NS % 2 == 0) ? NS : NS - 1;
+      static_assert(54 % NS == 0, "ring geometry");
+      static constexpr bool real_slot(const int p) { return p % NS < NR; }
+      // does point q issue piece t = 2q + LA + j (t >= 54: piece t - 54 of the next layer)?
+      static constexpr bool issues(const int t) { return t < 54 || real_slot(t - 54); }
+      static constexpr int n_issued(const int q) { return (issues(2 * q + LA) ? 1 : 0) + (issues(2 * q + LA + 1) ? 1 : 0); }
+      static constexpr int n_burst()
+      {
+        int n = 0;
+        for (int p = 0; p < LA; ++p)
+          n += real_slot(p) ? 0 : 1;
+        return n;
+      }
+      // position of piece p of the current layer in the sequence
+      // [pieces issued by the previous layer][nst stores][burst][npl plane copies][points 0, 1, ...]
+      static constexpr int position(const int p, const int npl, const int nst)
+      {
+        int pos = 0;
+        if (p < LA && real_slot(p))
+          {
+            for (int r = 0; r < p; ++r)
+              pos += real_slot(r) ? 1 : 0;
+            return pos;
+          }
+        for (int r = 0; r < LA; ++r)
+          pos += real_slot(r) ? 1 : 0;
+        pos += nst;
+        if (p < LA)
+          {
+            for (int r = 0; r < p; ++r)
+              pos += real_slot(r) ? 0 : 1;
+            return pos;
+          }
+        pos += n_burst() + npl;
+        for (int q = 0; 2 * q + LA < p; ++q)
+          pos += (2 * q + LA + 1 < p) ? n_issued(q) : (issues(2 * q + LA) ? 1 : 0);
+        return pos;
+      }
+      static constexpr int younger(const int q, const int npl, const int nst)
+      {
+        int total = 0; // operations in the sequence before point q issues its own
+        for (int r = 0; r < LA; ++r)
+          total += 1;  // every piece below LA: previous layer or burst
+        total += nst + npl;
+        for (int i = 0; i < q; ++i)
+          total += n_issued(i);
+        const int pa = position(2 * q, npl, nst), pb = position(2 * q + 1, npl, nst);
+        return total - ((pa > pb ? pa : pb) + 1);
+      }
+    };
+    // younger(q, ...) as a table: an index that is constant after unrolling folds to an immediate
+    template <int NR, int NX, int NPL, int NST>
+    struct RingWaits
+    {
+      struct Table
+      {
+        int v[27];
+      };
+      static constexpr Table make()
+      {
+        Table t{};
+        for (int q = 0; q < 27; ++q)
+          t.v[q] = RingSched<NR, NX>::younger(q, NPL, NST);
+        return t;
+      }
+      static constexpr Table table = make();
+    };
+    // (the schedule of round 1 / 2: 9 slots, 8 pieces ahead -- 6 behind the pieces of a point)
+    static_assert(RingSched<9, 0>::younger(0, 6, 0) == 12 && RingSched<9, 0>::younger(3, 6, 0) == 12 &&
+                    RingSched<9, 0>::younger(4, 6, 0) == 6 && RingSched<9, 0>::younger(26, 6, 0) == 6,
+                  "ring schedule");
     [[maybe_unused]] constexpr int XQ = 18;             // doubles per quad record: 4 lanes x 4 + pad (bank spread, 16-B aligned)
     constexpr int NPL_U     = 5;              // plane-DMA instructions per wave and layer (fixed count)
     constexpr int NPL_P     = 1;
@@ -476,9 +568,20 @@ namespace adaflo_hip
       // Variable rho/mu/damping (two-phase flow): lanes 48..63 of every piece carry the
       // coefficients of the wave's 16 cells -- (rho, mu) in half 0, (damping, -) in half 1 --
       // so the DMA instruction count per point stays at two; 6 slots of 64 lanes x 16 B.
-      constexpr int PIECE_ = VARCO ? 128 : PIECE, RING_ = VARCO ? 6 : RING, AHEAD_ = VARCO ? 4 : AHEAD;
+      constexpr int PIECE_ = VARCO ? 128 : PIECE, RING_ = VARCO ? 6 : RING;
       constexpr int PLANES_ = VARCO ? 64 : 48; // double2 per wave and piece
-      static_assert(54 % RING_ == 0 && 4 * RING_ * PIECE_ <= 4 * RING * PIECE, "ring geometry");
+      // + extension slots in the publish scratch while the quadrature loop runs (RingSched)
+      // (measured at 128^3, round 3: 18 instead of 8 pieces in flight per wave change nothing, 1.39 ms either
+      // way -- the kernel sits at the mixed read/write ceiling of the HBM system, scripts/dev/mix_probe.hip --
+      // and the extension costs a fourth barrier per layer: off by default)
+#if defined(Q2_RING_EXT)
+      constexpr int NX_ = RING_ON ? (VARCO ? 3 : NRING_X) : 0;
+#else
+      constexpr int NX_ = 0;
+#endif
+      using RS = RingSched<RING_, NX_>;
+      constexpr int NS_ = RS::NS, LA_ = RS::LA;
+      static_assert(4 * RING_ * PIECE_ <= 4 * RING * PIECE && (3 * RING_ + NX_) * PIECE_ <= 4 * NRING_X * PIECE, "ring geometry");
 
       const int tid = threadIdx.x, lane = tid & 63;
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform by construction
@@ -543,8 +646,8 @@ namespace adaflo_hip
       double cu[4] = {0., 0., 0., 0.}; // carried top-plane sums of the regular owned nodes
       double rim_carry = 0.;           // ... and of this thread's high-rim entry (rim threads, phase E2)
       // zero the publish scratch once (masked reads of absent neighbours must see finite numbers)
-      for (int e = tid; e < L_RIMT - (L_SCRU - 4); e += NT)
-        lds[L_SCRU - 4 + e] = 0.;
+      for (int e = tid; e < L_RIMT - L_EXT; e += NT)
+        lds[L_EXT + e] = 0.;
       // Descriptor of the high-rim node entry this thread assembles in phase E2: thread e < 99 = velocity
       // entry (node m = e / 3, component e % 3), thread 128 + e, e < 17 = pressure entry.  Nodes: the north
       // row (i = m, j = ey) for m < TN, then the east column (i = ex, j = m - TN) below the corner, where
@@ -623,25 +726,38 @@ namespace adaflo_hip
       const int      xq = cq * XQ;
 #endif
       const unsigned ring_byte = lds_addr(ringw);
+      const unsigned ext_byte  = ring_byte + (L_EXT - L_RING) * 8; // same wave stride as the real ring
       const unsigned piece_voff = 16u * (unsigned)(VARCO ? lane : min(lane, 47));
       auto issue_piece = [&](const int layer_cz, const int p) {
         // piece p (= 2q + half) of cell layer layer_cz: 48 consecutive double2 of this wave
         const double2 *g = state + ((size_t)bt * A.ncz + layer_cz) * A.state_stride +
                            (size_t)p * (4 * PLANES_) + wave * PLANES_;
-        dma_b128(g, piece_voff, ring_byte + (p % RING_) * (PIECE_ * 8),
+        const int      sl = p % NS_; // slot: real ring or extension
+        dma_b128(g, piece_voff, sl < RING_ ? ring_byte + sl * (PIECE_ * 8) : ext_byte + (sl - RING_) * (PIECE_ * 8),
                  VARCO ? 0xffffffffffffffffull : 0x0000ffffffffffffull);
+      };
+      // the pieces of a layer that live in extension slots and were not issued by the layer before
+      auto issue_burst = [&](const int layer_cz) {
+#pragma unroll
+        for (int p = 0; p < LA_; ++p)
+          if (!RS::real_slot(p))
+            issue_piece(layer_cz, p);
       };
       if (RING_ON)
         {
 #pragma unroll
-          for (int p = 0; p < AHEAD_; ++p)
-            issue_piece(cz0, p);
+          for (int p = 0; p < LA_; ++p)
+            if (RS::real_slot(p))
+              issue_piece(cz0, p);
+          if (NX_ > 0)
+            {
+              lds_barrier(); // the extension has been zeroed by everybody
+              issue_burst(cz0);
+            }
         }
-      // planes must have landed before anybody gathers from them
-      if (RING_ON)
-        wait_vmcnt<AHEAD_>();
-      else
-        wait_vmcnt<0>();
+      // planes (and, to keep the first layer's counted waits valid whatever was issued here, everything
+      // else) must have landed before anybody gathers from them
+      wait_vmcnt<0>();
       lds_barrier();
       // residual mode: the state of a point leaves as two 16-byte stores per velocity lane
       const unsigned           sout_voff = 16u * (unsigned)(wave * 48 + cq * 3 + (is_p ? 0 : d));
@@ -666,6 +782,10 @@ namespace adaflo_hip
         {
           const int cz      = cz0 + layer;
           const int cz_next = layer + 1 < nl ? cz + 1 : cz;
+          // the publish scratch is free again: this layer's pieces that live in extension slots
+          // (the first layer's were issued in the prologue)
+          if (NX_ > 0 && layer > 0)
+            issue_burst(cz);
 
           double R[27];
           if (RES)
@@ -787,34 +907,28 @@ namespace adaflo_hip
               double    r_rho = 0., r_mu = 0., r_damp = 0.;
               if (RING_ON)
                 {
-                  // outstanding after the pieces of q: AHEAD - 2 younger pieces, plus, right
-                  // after the plane refill was issued (q < 4), the plane copies of this wave
-                  constexpr int younger = AHEAD_ - 2;
-#if defined(Q2_EXP) && (Q2_EXP == 1 || Q2_EXP == 2)
-                  if (false)
-#else
-                  if (q < AHEAD_ / 2)
-#endif
-                    {
-                      if (WITH_P)
-                        wait_vmcnt<younger + NPL_U + NPL_P>();
-                      else
-                        wait_vmcnt<younger + NPL_U>();
-                    }
+                  // counted wait: everything but the operations issued after the pieces of this point
+                  // (RingSched::younger)
+                  constexpr int npl_ = NPL_U + (WITH_P ? NPL_P : 0);
 #if !defined(Q2_EXP) || (Q2_EXP != 1 && Q2_EXP != 2)
-                  else
-                    wait_vmcnt<younger>();
+                  // (q is a constant once the loop is unrolled: the count folds to an immediate)
+                  // (no stores assumed: a wave of a clipped tile may own no valid cell, and a store with an empty
+                  // EXEC mask may not count)
+                  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(RingWaits<RING_, NX_, npl_, 0>::table.v[q]) : "memory");
 #endif
-                  const double2 *rs = reinterpret_cast<const double2 *>(ringw);
-                  st0 = rs[((2 * q) % RING_) * (PIECE_ / 2) + slan - wave * 48];
-                  st1 = rs[((2 * q + 1) % RING_) * (PIECE_ / 2) + slan - wave * 48];
+                  const int sl0 = (2 * q) % NS_, sl1 = (2 * q + 1) % NS_;
+                  // (one base register: the extension uses the wave stride of the real ring)
+                  const double *pc0 = ringw + (sl0 < RING_ ? sl0 * PIECE_ : (L_EXT - L_RING) + (sl0 - RING_) * PIECE_);
+                  const double *pc1 = ringw + (sl1 < RING_ ? sl1 * PIECE_ : (L_EXT - L_RING) + (sl1 - RING_) * PIECE_);
+                  st0 = reinterpret_cast<const double2 *>(pc0)[slan - wave * 48];
+                  st1 = reinterpret_cast<const double2 *>(pc1)[slan - wave * 48];
                   // the quad's three (u_lin_e, grad_e0) and (grad_e1, grad_e2) entries
-                  const double *rq0 = ringw + ((2 * q) % RING_) * PIECE_ + 6 * cq;
-                  const double *rq1 = ringw + ((2 * q + 1) % RING_) * PIECE_ + 6 * cq;
+                  const double *rq0 = pc0 + 6 * cq;
+                  const double *rq1 = pc1 + 6 * cq;
                   if (VARCO) // quad-uniform reads of the cell's (rho, mu) and damping
                     {
-                      const double *rc0 = ringw + ((2 * q) % RING_) * PIECE_ + 96 + 2 * cq;
-                      const double *rc1 = ringw + ((2 * q + 1) % RING_) * PIECE_ + 96 + 2 * cq;
+                      const double *rc0 = pc0 + 96 + 2 * cq;
+                      const double *rc1 = pc1 + 96 + 2 * cq;
                       r_rho = rc0[0], r_mu = rc0[1], r_damp = rc1[0];
                     }
                   if (LIN_MODE == 0)
@@ -827,27 +941,17 @@ namespace adaflo_hip
                   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                   // refill the two slots that became free (after the last layer of the chunk
                   // the same pieces are harmlessly fetched again: fixed VMEM op count)
-#if defined(Q2_EXP) && Q2_EXP == 2
-                  if (false)
-                    {
-                    }
-                  else if (false)
-#else
-                  if (2 * q + AHEAD_ < 54)
-#endif
-                    {
-                      issue_piece(cz, 2 * q + AHEAD_);
-                      issue_piece(cz, 2 * q + AHEAD_ + 1);
-                    }
 #if !defined(Q2_EXP) || Q2_EXP != 2
-                  else
-#else
-                  else if (false)
-#endif
+#pragma unroll
+                  for (int j = 0; j < 2; ++j)
                     {
-                      issue_piece(cz_next, 2 * q + AHEAD_ - 54);
-                      issue_piece(cz_next, 2 * q + AHEAD_ + 1 - 54);
+                      const int t = 2 * q + LA_ + j;
+                      if (t < 54)
+                        issue_piece(cz, t);
+                      else if (RS::real_slot(t - 54))
+                        issue_piece(cz_next, t - 54);
                     }
+#endif
                 }
 #if defined(Q2_EXP) && Q2_EXP == 4
               // diagnostic: stream only -- consume the state minimally, skip the arithmetic
@@ -976,7 +1080,16 @@ namespace adaflo_hip
           // my plane copies for the next layer are older than the AHEAD pieces issued last (residual
           // mode: than the 54 state stores of this layer)
           if (RING_ON)
-            wait_vmcnt<AHEAD_>();
+            {
+              // (the plane copies are older than the pieces of the next layer issued by the last points)
+              constexpr int tail = RS::n_issued(26) + RS::n_issued(25) + RS::n_issued(24) + RS::n_issued(23) +
+                                   RS::n_issued(22) + RS::n_issued(21) + RS::n_issued(20) + RS::n_issued(19) + RS::n_issued(18);
+              constexpr int last9 = NX_ > 0 ? tail : LA_;
+              wait_vmcnt<(last9 < LA_ ? last9 : LA_)>();
+              // every wave must have consumed its pieces in the extension (= publish scratch) before anybody publishes
+              if (NX_ > 0)
+                lds_barrier();
+            }
           else if (RES && LIN_MODE != 2)
             wait_vmcnt<54>();
           else
@@ -1088,24 +1201,28 @@ namespace adaflo_hip
           else if (!is_p)
             {
               const double *sc = lds + L_SCRU + cell * 3 + d;
-              double        w0[3], w1[3], t0[3], t1[3], sw[3];
+              // (summed into R in place: nothing but R is live across the stores below)
 #pragma unroll
               for (int lk = 0; lk < 3; ++lk)
                 {
-                  w0[lk] = sc[(lk * 5 + 0) * (NCELL * 3) - 3];  // west cell's (2,0) = my (0,0)
-                  w1[lk] = sc[(lk * 5 + 1) * (NCELL * 3) - 3];  //             (2,1) = my (0,1)
-                  t0[lk] = sc[(lk * 5 + 3) * (NCELL * 3) - 24]; // south cell's (0,2) = my (0,0)
-                  t1[lk] = sc[(lk * 5 + 4) * (NCELL * 3) - 24]; //              (1,2) = my (1,0)
-                  sw[lk] = sc[(lk * 5 + 2) * (NCELL * 3) - 27]; // south-west cell's (2,2) = my (0,0)
+                  const double w0 = sc[(lk * 5 + 0) * (NCELL * 3) - 3];  // west cell's (2,0) = my (0,0)
+                  const double w1 = sc[(lk * 5 + 1) * (NCELL * 3) - 3];  //             (2,1) = my (0,1)
+                  const double t0 = sc[(lk * 5 + 3) * (NCELL * 3) - 24]; // south cell's (0,2) = my (0,0)
+                  const double t1 = sc[(lk * 5 + 4) * (NCELL * 3) - 24]; //              (1,2) = my (1,0)
+                  const double sw = sc[(lk * 5 + 2) * (NCELL * 3) - 27]; // south-west cell's (2,2) = my (0,0)
+                  R[0 + 9 * lk] = fma(fSW, sw, fma(fS, t0, fma(fW, w0, R[0 + 9 * lk])));
+                  R[1 + 9 * lk] = fma(fS, t1, R[1 + 9 * lk]);
+                  R[3 + 9 * lk] = fma(fW, w1, R[3 + 9 * lk]);
                 }
+#if defined(Q2_DST_WRAP)
+              const unsigned voff = (8u * (unsigned)(lane_g + d)) & (Q2_DST_WRAP - 1u);
+#else
               const unsigned voff = 8u * (unsigned)(lane_g + d); // (lane_g - d) + 2 d
+#endif
 #pragma unroll
               for (int lk = 0; lk < 3; ++lk)
                 {
-                  double a0 = fma(fSW, sw[lk], fma(fS, t0[lk], fma(fW, w0[lk], R[0 + 9 * lk])));
-                  double a1 = fma(fS, t1[lk], R[1 + 9 * lk]);
-                  double a3 = fma(fW, w1[lk], R[3 + 9 * lk]);
-                  double a4 = R[4 + 9 * lk];
+                  double a0 = R[0 + 9 * lk], a1 = R[1 + 9 * lk], a3 = R[3 + 9 * lk], a4 = R[4 + 9 * lk];
                   if (lk == 2)
                     {
                       // top plane: finished only after the next layer -> carry
