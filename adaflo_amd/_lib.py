@@ -5,6 +5,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libadaflo_hip.so")
 
+# status codes of include/adaflo_hip.h
+ADAFLO_OK, ADAFLO_EINVAL, ADAFLO_ENOTINIT, ADAFLO_EHIP, ADAFLO_ENOMEM, ADAFLO_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+
 
 class BrickDesc(C.Structure):
     _fields_ = [("dim", C.c_int), ("ncell", C.c_int * 3), ("h", C.c_double * 3),

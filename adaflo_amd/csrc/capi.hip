@@ -421,6 +421,11 @@ int adaflo_ns_set_params(adaflo_ctx *ctx, const adaflo_ns_params *p)
       p->linearization != ADAFLO_COUPLED_IMPLICIT_NEWTON)
     return fail(ctx, ADAFLO_EINVAL,
                 "stationary equation requires coupled implicit Newton (parameters.cc:501-504)");
+  // The sweep-kernel residual leaves the linearisation state only in the streaming layout of the scheme it
+  // ran with; another scheme re-creates its streaming copy from the generic one: bring that up to date
+  // while the layout of the stored copy is still known.
+  if (ctx->ns_params_set && (p->physical_type != ctx->ns.physical_type || p->linearization != ctx->ns.linearization))
+    TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
   ctx->ns = NSDev{p->physical_type, p->linearization, p->beta, p->tau_grad_div, p->density,
                   p->viscosity, p->damping, p->density_diff, p->weight, p->weight_old,
                   p->weight_old_old, p->tau1, p->extrap_old, p->extrap_old_old};
@@ -940,6 +945,8 @@ int adaflo_ns_preconditioner_set_inner(adaflo_ctx *ctx, int mode)
   CHECK_CTX(ctx);
   if (mode < 0 || mode > 1)
     return fail(ctx, ADAFLO_EINVAL, "unknown inner-solve mode");
+  if (mode != ctx->pc_inner)
+    ctx->pc_ready = false; // the other flavour of inner solves needs its own set-up data
   ctx->pc_inner = mode;
   return 0;
 }

@@ -155,6 +155,7 @@ struct adaflo_ctx
   // block, the pressure mass and the pressure Poisson operator, work vectors
   adaflo_hip::DeviceBuffer pc_inv_u, pc_inv_pm, pc_inv_pl, pc_ones_p, pc_tmp_u, pc_tmp_p, pc_tmp_p2, pc_work, kr_work, kr_basis, kr_scalars;
   bool                     pc_ready = false;
+  bool                     pc_built_fdm = false; // what adaflo_ns_preconditioner_setup built: fast-diagonalisation inverses or Jacobi diagonals
   void                    *fdm = nullptr;      // fast-diagonalisation data of the inner solves (fdm.hip)
   long                     pc_velocity_iterations = 0, pc_velocity_solves = 0; // statistics of the velocity-block solves
   int                      pc_inner = 1;       // 0: Jacobi-preconditioned inner Krylov solves, 1: fast diagonalisation

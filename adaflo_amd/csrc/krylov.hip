@@ -836,6 +836,25 @@ namespace
   }
 } // namespace
 
+// The inner solves come in two flavours that need different set-up data: fast-diagonalisation inverses
+// (constant coefficients, pc_inner == 1) or Jacobi diagonals of the operators.  The flavour is chosen from the
+// state of the context; it must still be the one adaflo_ns_preconditioner_setup has built when the
+// preconditioner is applied (a change of adaflo_ns_preconditioner_set_inner or of the presence of variable
+// coefficients in between would otherwise run Krylov solves on uninitialised inverse diagonals).
+static bool pc_wants_fdm(const adaflo_ctx *ctx)
+{
+  return ctx->pc_inner == 1 && !ctx->rho.p && !ctx->mu.p;
+}
+static int pc_check_built(adaflo_ctx *ctx)
+{
+  if (!ctx->pc_ready)
+    return kfail(ctx, ADAFLO_ENOTINIT, "call adaflo_ns_preconditioner_setup first");
+  if (pc_wants_fdm(ctx) != ctx->pc_built_fdm)
+    return kfail(ctx, ADAFLO_ENOTINIT,
+                 "the inner-solve mode or the coefficients changed since adaflo_ns_preconditioner_setup: call it again");
+  return 0;
+}
+
 int adaflo_ns_preconditioner_setup(adaflo_ctx *ctx)
 {
   if (!ctx)
@@ -850,7 +869,8 @@ int adaflo_ns_preconditioner_setup(adaflo_ctx *ctx)
   for (DeviceBuffer *b : {&ctx->pc_inv_pm, &ctx->pc_inv_pl, &ctx->pc_ones_p, &ctx->pc_tmp_p, &ctx->pc_tmp_p2})
     if (int rc = pc_alloc(ctx, *b, np))
       return rc;
-  if (ctx->pc_inner == 1 && !ctx->rho.p && !ctx->mu.p)
+  ctx->pc_ready = false;
+  if (pc_wants_fdm(ctx))
     {
       // fast diagonalisation of the constant-coefficient parts: no operator diagonals needed
       if (int rc = fdm_setup(ctx))
@@ -859,7 +879,8 @@ int adaflo_ns_preconditioner_setup(adaflo_ctx *ctx)
         return kfail(ctx, ADAFLO_EHIP, "fill failed");
       if (hipStreamSynchronize(ctx->stream) != hipSuccess)
         return kfail(ctx, ADAFLO_EHIP, "preconditioner setup failed");
-      ctx->pc_ready = true;
+      ctx->pc_built_fdm = true;
+      ctx->pc_ready     = true;
       return 0;
     }
   double *probe_work = persistent(ctx->kr_work, (size_t)nu);
@@ -888,7 +909,8 @@ int adaflo_ns_preconditioner_setup(adaflo_ctx *ctx)
     return kfail(ctx, ADAFLO_EHIP, "fill failed");
   if (hipStreamSynchronize(ctx->stream) != hipSuccess)
     return kfail(ctx, ADAFLO_EHIP, "preconditioner setup failed");
-  ctx->pc_ready = true;
+  ctx->pc_built_fdm = false;
+  ctx->pc_ready     = true;
   return 0;
 }
 
@@ -909,8 +931,8 @@ int adaflo_ns_preconditioner_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p
 {
   if (!ctx)
     return ADAFLO_ENOTINIT;
-  if (!ctx->pc_ready)
-    return kfail(ctx, ADAFLO_ENOTINIT, "call adaflo_ns_preconditioner_setup first");
+  if (int rc = pc_check_built(ctx))
+    return rc;
   if (!dst_u || !dst_p || !src_u || !src_p)
     return kfail(ctx, ADAFLO_EINVAL, "null vector");
   const long nu = 3 * ctx->n_nodes_u, np = ctx->n_nodes_p;
@@ -922,7 +944,7 @@ int adaflo_ns_preconditioner_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p
     double *p;
   } w{ctx->pc_work.p};
   // fast diagonalisation (fdm.hip) instead of Jacobi for the inner solves: constant coefficients
-  const bool   fdm    = ctx->pc_inner == 1 && !ctx->rho_prec.p && !ctx->rho.p && !ctx->mu.p;
+  const bool   fdm    = ctx->pc_built_fdm && !ctx->rho_prec.p;
   const NSDev &P      = ctx->ns;
   const bool   stokes = P.physical_type == ADAFLO_STOKES;
   const double gamma  = P.physical_type == ADAFLO_INCOMPRESSIBLE ? P.weight : 0.;
@@ -1048,8 +1070,8 @@ int adaflo_ns_solve_system(adaflo_ctx *ctx, double *update_u, double *update_p, 
     return ADAFLO_ENOTINIT;
   if (!update_u || !update_p || !rhs_u || !rhs_p || !control || !result || restart < 1)
     return kfail(ctx, ADAFLO_EINVAL, "bad argument");
-  if (!ctx->pc_ready)
-    return kfail(ctx, ADAFLO_ENOTINIT, "call adaflo_ns_preconditioner_setup first");
+  if (int rc = pc_check_built(ctx))
+    return rc;
   const long nu = 3 * ctx->n_nodes_u, np = ctx->n_nodes_p, n = nu + np;
   const int  m  = restart;
   // Krylov basis V_0..V_m and the preconditioned vectors Z_0..Z_{m-1}; block vectors stored [u | p]
@@ -1086,7 +1108,7 @@ int adaflo_ns_solve_system(adaflo_ctx *ctx, double *update_u, double *update_p, 
   // (do_inner_solves = false) for `lin its before inner solvers` iterations, then -- from the iterate reached --
   // the solver with inner Krylov solves.  The cheap stage needs approximate inverses that deserve the name:
   // it is taken with the fast-diagonalisation inverses (constant coefficients), not with the Jacobi diagonals.
-  const bool two_stage = ctx->pc_inner == 1 && !ctx->rho_prec.p && !ctx->rho.p && !ctx->mu.p && ctx->pc_its_before_inner > 0;
+  const bool two_stage = ctx->pc_built_fdm && !ctx->rho_prec.p && ctx->pc_its_before_inner > 0;
   const int  simple_limit = two_stage ? std::min(ctx->pc_its_before_inner, control->max_iterations) : 0;
   struct StageGuard // (error returns below must not leave the context in the cheap stage)
   {

@@ -68,6 +68,9 @@ namespace adaflo_hip
 #ifndef HO_LB
 #define HO_LB 2
 #endif
+#ifndef HO_PIPE
+#define HO_PIPE 3
+#endif
     constexpr int NTH  = 256;
     constexpr int NMAX = 6;
     constexpr int L_TAB_D = NMAX * NMAX, L_TAB_SP = 2 * NMAX * NMAX, L_WAVE = 3 * NMAX * NMAX;
@@ -582,21 +585,25 @@ namespace adaflo_hip
                   // over the components
                   const unsigned off = (unsigned)c * (PLS * 8);
                   const unsigned xb = ax_ + off, yb = ay_ + off, ob = ao_ + off;
-                  double         Dx[N], Dy[N], lx[3][N], ly[3][N], lz[3][N];
+                  // HO_PIPE line-buffer sets: 2 = the reads of component d + 1 are in flight while the
+                  // gradient of component d is formed (90 -> 60 VGPRs of line buffers: the Q4/Q3 Newton kernel
+                  // spilled 31 registers with three sets, and every scratch reload drains the state prefetch)
+                  constexpr int NB = HO_PIPE;
+                  double         Dx[N], Dy[N], lx[NB][N], ly[NB][N], lz[NB][N];
                   rd_line<8 * L_TAB_D, 1>(a_ri, Dx);
                   rd_line<8 * L_TAB_D, 1>(a_rj, Dy);
                   auto issue = [&](auto dt) {
-                    constexpr int d = decltype(dt)::value;
-                    rd_line<8 * d * N * PLS, 1>(xb, lx[d]);
-                    rd_line<8 * d * N * PLS, N>(yb, ly[d]);
-                    rd_line<8 * d * N * PLS, PLS>(ao_, lz[d]); // my z-line (all planes)
+                    constexpr int d = decltype(dt)::value, b = d % NB;
+                    rd_line<8 * d * N * PLS, 1>(xb, lx[b]);
+                    rd_line<8 * d * N * PLS, N>(yb, ly[b]);
+                    rd_line<8 * d * N * PLS, PLS>(ao_, lz[b]); // my z-line (all planes)
                     u[d] = ds_rd<8 * d * N * PLS>(ob);
                   };
                   auto grad = [&](auto dt, auto cnt) {
-                    constexpr int d = decltype(dt)::value, CNT = decltype(cnt)::value;
-                    ds_wait<CNT>(lx[d]);
-                    ds_wait<CNT>(ly[d]);
-                    ds_wait<CNT>(lz[d]);
+                    constexpr int d = decltype(dt)::value, CNT = decltype(cnt)::value, b = d % NB;
+                    ds_wait<CNT>(lx[b]);
+                    ds_wait<CNT>(ly[b]);
+                    ds_wait<CNT>(lz[b]);
                     ds_wait1<CNT>(u[d]);
                     if (d == 0)
                       {
@@ -607,9 +614,9 @@ namespace adaflo_hip
 #pragma unroll
                     for (int m = 0; m < N; ++m)
                       {
-                        sx += Dx[m] * lx[d][m];
-                        sy += Dy[m] * ly[d][m];
-                        sz += Dz[m] * lz[d][m];
+                        sx += Dx[m] * lx[b][m];
+                        sy += Dy[m] * ly[b][m];
+                        sz += Dz[m] * lz[b][m];
                       }
                     g[d][0] = sx * A.ih[0];
                     g[d][1] = sy * A.ih[1];
@@ -619,14 +626,39 @@ namespace adaflo_hip
                   using I1 = std::integral_constant<int, 1>;
                   using I2 = std::integral_constant<int, 2>;
                   constexpr int PER = 3 * N + 1, NPQ = WITH_P ? 1 : 0;
-                  issue(I0{});
-                  issue(I1{});
-                  grad(I0{}, std::integral_constant<int, PER>{});
-                  issue(I2{});
-                  if (WITH_P)
-                    pq = ds_rd<8 * 3 * N * PLS>(ob);
-                  grad(I1{}, std::integral_constant<int, PER + NPQ>{});
-                  grad(I2{}, std::integral_constant<int, NPQ>{});
+                  if constexpr (NB >= 3)
+                    {
+                      issue(I0{});
+                      issue(I1{});
+                      grad(I0{}, std::integral_constant<int, PER>{});
+                      issue(I2{});
+                      if (WITH_P)
+                        pq = ds_rd<8 * 3 * N * PLS>(ob);
+                      grad(I1{}, std::integral_constant<int, PER + NPQ>{});
+                      grad(I2{}, std::integral_constant<int, NPQ>{});
+                    }
+                  else if constexpr (NB == 2)
+                    {
+                      issue(I0{});
+                      issue(I1{});
+                      grad(I0{}, std::integral_constant<int, PER>{});
+                      issue(I2{}); // (into the buffers of component 0)
+                      if (WITH_P)
+                        pq = ds_rd<8 * 3 * N * PLS>(ob);
+                      grad(I1{}, std::integral_constant<int, PER + NPQ>{});
+                      grad(I2{}, std::integral_constant<int, NPQ>{});
+                    }
+                  else
+                    {
+                      issue(I0{});
+                      grad(I0{}, std::integral_constant<int, 0>{});
+                      issue(I1{});
+                      grad(I1{}, std::integral_constant<int, 0>{});
+                      issue(I2{});
+                      if (WITH_P)
+                        pq = ds_rd<8 * 3 * N * PLS>(ob);
+                      grad(I2{}, std::integral_constant<int, NPQ>{});
+                    }
                   if (WITH_P)
                     ds_wait1<0>(pq);
                 }

@@ -19,6 +19,8 @@
 //  * The Q1 pressure is expanded to the Q2 nodal basis at gather time, so all
 //    four lanes of a quad run the identical Q2 interpolation code.
 #include "kernels.hpp"
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -1683,6 +1685,10 @@ namespace adaflo_hip
   {
     if (ctx->lin_q2_valid || q2_lin_mode(ctx) == 2)
       return 0;
+    // (the streaming copy is rebuilt from the generic one, which must exist and be current:
+    // adaflo_ns_set_params / adaflo_ns_set_coefficients see to that before they invalidate anything)
+    if (!ctx->lin.p || !ctx->lin_generic_valid)
+      return ADAFLO_ENOTINIT;
     const int    tiles_x = (ctx->desc.ncell[0] + TX - 1) / TX, tiles_y = (ctx->desc.ncell[1] + TY - 1) / TY;
     const bool   varco     = q2_varco(ctx);
     const long   per_layer = 27L * 2 * 4 * (varco ? 64 : 48) * 2;
@@ -1891,6 +1897,9 @@ namespace adaflo_hip
         A.iface     = iface;
         nwg         = A.wg_count;
       }
+    if (static const bool dbg = std::getenv("ADAFLO_DEBUG_PTR") != nullptr; dbg)
+      std::fprintf(stderr, "q2_launch: state %p src_u %p dst_u %p slab_u %p zslab_u %p\n", (const void *)A.state,
+                   (const void *)A.src_u, (const void *)A.dst_u, (const void *)A.slab_u, (const void *)A.zslab_u);
     hipEvent_t stop = (ctx->timing && nwg > 0) ? ctx->kernel_timer.start(ctx->stream) : nullptr;
     const bool   iso = ctx->desc.h[0] == ctx->desc.h[1] && ctx->desc.h[1] == ctx->desc.h[2];
     const dim3   grid((unsigned)(nwg > 0 ? nwg : 1)), block(NT);
