@@ -87,6 +87,7 @@ SIGNATURES = {
     "adaflo_ns_fix_linearization_point": (C.c_int, [_CTX]),
     "adaflo_ns_vmult": (C.c_int, [_CTX, _D, _D, _D, _D]),
     "adaflo_ns_vmult_phase": (C.c_int, [_CTX, _D, _D, _D, _D, C.c_int, C.c_uint]),
+    "adaflo_ns_supports_phases": (C.c_int, [_CTX]),
     "adaflo_ns_residual": (C.c_int, [_CTX, _D, _D, _D, _D, _D, _D, _D, _D]),
     "adaflo_ns_velocity_vmult": (C.c_int, [_CTX, _D, _D]),
     "adaflo_ns_divergence_vmult_add": (C.c_int, [_CTX, _D, _D, C.c_int]),

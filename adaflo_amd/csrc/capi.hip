@@ -617,6 +617,15 @@ int adaflo_ns_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double 
   return adaflo_ns_apply_pressure_average_projection(ctx, dst_p); // :258
 }
 
+int adaflo_ns_supports_phases(adaflo_ctx *ctx)
+{
+  if (!ctx)
+    return 0;
+  if (ctx->variant >= 1 && q2_supported(ctx))
+    return 1;
+  return ho_supported(ctx) && (ctx->variant == 2 || (ctx->variant == 1 && ctx->k <= 4)) ? 1 : 0;
+}
+
 int adaflo_ns_vmult_phase(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double *src_u,
                           const double *src_p, int phase, unsigned interface_faces)
 {
@@ -625,12 +634,21 @@ int adaflo_ns_vmult_phase(adaflo_ctx *ctx, double *dst_u, double *dst_p, const d
     return fail(ctx, ADAFLO_EINVAL, "null vector");
   if (phase < 0 || phase > 2)
     return fail(ctx, ADAFLO_EINVAL, "phase must be 0, 1 or 2");
-  if (!(ctx->variant >= 1 && q2_supported(ctx)))
-    return fail(ctx, ADAFLO_EUNSUPPORTED, "phased vmult needs the Q2/Q1 sweep kernel");
+  if (!adaflo_ns_supports_phases(ctx))
+    return fail(ctx, ADAFLO_EUNSUPPORTED, "phased vmult needs one of the sweep kernels (Q2/Q1, or Q3..Q5 with constant coefficients)");
   if (needs_lin(ctx) && !has_lin(ctx))
     return fail(ctx, ADAFLO_ENOTINIT, "linearization data not set (call residual or set_linearization)");
-  TRY(ctx, launch_ns_vmult_q2(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p, phase, interface_faces),
-      "Q2 kernel launch failed");
+  if (ctx->variant >= 1 && q2_supported(ctx))
+    {
+      TRY(ctx, launch_ns_vmult_q2(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p, phase, interface_faces),
+          "Q2 kernel launch failed");
+    }
+  else
+    {
+      TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
+      TRY(ctx, launch_ns_vmult_ho(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p, phase, interface_faces),
+          "high-order kernel launch failed");
+    }
   if (phase == 1)
     ctx->matvec_timer.count++;
   return 0;

@@ -550,7 +550,8 @@ int adaflo_ns_vmult_distributed(adaflo_ctx *ctx, adaflo_comm *c, double *dst_u, 
 {
   if (!ctx || !c || c->ctx != ctx || !dst_u || !dst_p || !src_u || !src_p)
     return ADAFLO_EINVAL;
-  const bool phased = c->world > 1 && ctx->variant >= 1 && q2_supported(ctx) && !ctx->rho.p;
+  // (every sweep kernel has the three-phase form: Q2/Q1 with constant or variable coefficients, Q3..Q5)
+  const bool phased = c->world > 1 && adaflo_ns_supports_phases(ctx) != 0;
   if (c->world == 1)
     {
       // (the context was created without the local mean-value fix when a communicator takes care of it)

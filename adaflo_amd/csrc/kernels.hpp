@@ -178,5 +178,5 @@ namespace adaflo_hip
   // Q_k/Q_{k-1} sweep kernel for k = 3, 4, 5 (ns_ho.hip), constant coefficients
   bool ho_supported(const adaflo_ctx *ctx);
   int  launch_ns_vmult_ho(adaflo_ctx *ctx, int op, double *dst_u, double *dst_p, const double *src_u,
-                          const double *src_p);
+                          const double *src_p, int phase = -1, uint32_t iface = 0);
 } // namespace adaflo_hip

@@ -31,7 +31,9 @@
 #include "basis.hpp"
 #include "kernels.hpp"
 
+#include <cstring>
 #include <utility>
+#include <vector>
 
 namespace adaflo_hip
 {
@@ -98,7 +100,24 @@ namespace adaflo_hip
       double       *dst_u, *dst_p;
       double       *slab_u, *zslab_u, *slab_p, *zslab_p;
       const double *tab; // [S N*N | D N*N | Sp N*NP | w N] for the scalar loads of the z contractions
+      // phased execution for the multi-GPU overlap (as in ns_q2.hip): explicit workgroup list for the main
+      // kernel, node filter for the fix-up (1: only nodes on the inter-GPU interface faces `iface`,
+      // 2: all other nodes, 0: everything)
+      const int *wg_list;
+      int        wg_offset, wg_count, fix_mode;
+      uint32_t   iface;
     };
+
+    __device__ __forceinline__ bool ho_fix_skip(const HOArgs &A, const int I, const int J, const int Kz,
+                                                const int nn_x, const int nn_y, const int nn_z)
+    {
+      if (A.fix_mode == 0)
+        return false;
+      const bool on = (I == 0 && (A.iface & 1u)) || (I == nn_x - 1 && (A.iface & 2u)) ||
+                      (J == 0 && (A.iface & 4u)) || (J == nn_y - 1 && (A.iface & 8u)) ||
+                      (Kz == 0 && (A.iface & 16u)) || (Kz == nn_z - 1 && (A.iface & 32u));
+      return A.fix_mode == 1 ? !on : on;
+    }
 
     template <int TNX, int TNY>
     __device__ __forceinline__ int rim_index_ho(const int i, const int j)
@@ -260,8 +279,10 @@ namespace adaflo_hip
         }
       __syncthreads();
 
-      const long nwg = (long)A.tiles_x * A.tiles_y * A.n_chunks;
-      const long wg  = xcd_remap(blockIdx.x, nwg);
+      const long nwg = A.wg_list ? (long)A.wg_count : (long)A.tiles_x * A.tiles_y * A.n_chunks;
+      long       wg  = xcd_remap(blockIdx.x, nwg);
+      if (A.wg_list)
+        wg = A.wg_list[A.wg_offset + wg];
       const int  bz = (int)(wg % A.n_chunks), bt = (int)(wg / A.n_chunks);
       const int  bx = bt % A.tiles_x, by = bt / A.tiles_x;
       const int  cz0 = bz * A.LZ, nl = min(A.LZ, A.ncz - cz0);
@@ -1030,6 +1051,8 @@ namespace adaflo_hip
             continue; // owned by another tile
           if (on_constrained_face(I, J, Kz, nn_x, nn_y, nn_z, con, NC == 1 ? 1 : 3, comp))
             continue;
+          if (ho_fix_skip(A, I, J, Kz, nn_x, nn_y, nn_z))
+            continue;
           double sum = 0.;
           for (int dy = 0; dy <= (seam_y ? 1 : 0); ++dy)
             for (int dx = 0; dx <= (seam_x ? 1 : 0); ++dx)
@@ -1063,7 +1086,8 @@ namespace adaflo_hip
             continue;
           const bool seam = (i == 0 && I > 0) || (i == TNX - 1 && I < nn_x - 1) || (j == 0 && J > 0) ||
                             (j == TNY - 1 && J < nn_y - 1);
-          if (seam || on_constrained_face(I, J, Kz, nn_x, nn_y, nn_z, con, NC == 1 ? 1 : 3, comp))
+          if (seam || on_constrained_face(I, J, Kz, nn_x, nn_y, nn_z, con, NC == 1 ? 1 : 3, comp) ||
+              ho_fix_skip(A, I, J, Kz, nn_x, nn_y, nn_z))
             continue;
           dst[((long)(Kz * (long)nn_y + J) * nn_x + I) * NC + comp] += zslab[(bt * A.n_chunks + m - 1) * (TNX * TNY * NC) + e];
         }
@@ -1107,9 +1131,12 @@ namespace adaflo_hip
       return 0;
     }
 
+    // phase -1: the whole operator; phases 0 / 1 / 2 as in launch_ns_vmult_q2 (ns_q2.hip): 0 = first half of the
+    // workgroups that touch no node of the inter-GPU interface faces `iface`, 1 = the workgroups that do + fix-up
+    // of the interface nodes, 2 = the other interior workgroups + the rest of the fix-up
     template <int K>
     int launch_ho(adaflo_ctx *ctx, const int op, double *dst_u, double *dst_p, const double *src_u,
-                  const double *src_p)
+                  const double *src_p, const int phase, const uint32_t iface)
     {
       using C = HOTile<K>;
       constexpr int N = K + 1, NP = K;
@@ -1206,13 +1233,51 @@ namespace adaflo_hip
       A.zslab_u = ctx->q2_zslab_u.p;
       A.slab_p  = ctx->q2_slab_p.p;
       A.zslab_p = ctx->q2_zslab_p.p;
-      if (with_p && !A.integrate_p)
+      if (with_p && !A.integrate_p && phase <= 0)
         if (int e = launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, A.npx, A.npy, A.npz, A.con_p, -1., true))
           return e;
+      long nwg = (long)n_wg;
+      if (phase >= 0)
+        {
+          // workgroup list [interface | interior A | interior B], cached per (grid, iface)
+          const long key[4] = {A.tiles_x, A.tiles_y, A.n_chunks, (long)iface};
+          if (!ctx->q2_wg_list || std::memcmp(key, ctx->q2_wg_key, sizeof(key)) != 0)
+            {
+              std::vector<int> bnd, inner;
+              for (int by = 0; by < A.tiles_y; ++by)
+                for (int bx = 0; bx < A.tiles_x; ++bx)
+                  for (int bz = 0; bz < A.n_chunks; ++bz)
+                    {
+                      const bool b = (bx == 0 && (iface & 1u)) || (bx == A.tiles_x - 1 && (iface & 2u)) ||
+                                     (by == 0 && (iface & 4u)) || (by == A.tiles_y - 1 && (iface & 8u)) ||
+                                     (bz == 0 && (iface & 16u)) || (bz == A.n_chunks - 1 && (iface & 32u));
+                      (b ? bnd : inner).push_back((by * A.tiles_x + bx) * A.n_chunks + bz);
+                    }
+              ctx->q2_wg_counts[0] = (int)bnd.size();
+              ctx->q2_wg_counts[1] = (int)(inner.size() / 2);
+              ctx->q2_wg_counts[2] = (int)(inner.size() - inner.size() / 2);
+              bnd.insert(bnd.end(), inner.begin(), inner.end());
+              if (ctx->q2_wg_list)
+                (void)hipFree(ctx->q2_wg_list);
+              ctx->q2_wg_list = nullptr;
+              if (hipMalloc(&ctx->q2_wg_list, sizeof(int) * (bnd.size() + 1)) != hipSuccess)
+                return ADAFLO_ENOMEM;
+              if (copy_to_device_now(ctx->q2_wg_list, bnd.data(), sizeof(int) * bnd.size()) != hipSuccess)
+                return ADAFLO_EHIP;
+              std::memcpy(ctx->q2_wg_key, key, sizeof(key));
+            }
+          const int nb = ctx->q2_wg_counts[0], na = ctx->q2_wg_counts[1], nc = ctx->q2_wg_counts[2];
+          A.wg_list   = ctx->q2_wg_list;
+          A.wg_offset = phase == 1 ? 0 : (phase == 0 ? nb : nb + na);
+          A.wg_count  = phase == 1 ? nb : (phase == 0 ? na : nc);
+          A.fix_mode  = phase; // 1: interface nodes, 2: the others (phase 0 runs no fix-up)
+          A.iface     = iface;
+          nwg         = A.wg_count;
+        }
       const size_t lds_bytes = sizeof(double) * (size_t)ho_lds_doubles<K>();
-      const dim3   grid((unsigned)n_wg), block(NTH);
+      const dim3   grid((unsigned)(nwg > 0 ? nwg : 1)), block(NTH);
       hipError_t   err  = hipSuccess;
-      hipEvent_t   stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
+      hipEvent_t   stop = (ctx->timing && nwg > 0) ? ctx->kernel_timer.start(ctx->stream) : nullptr;
 #define HO_LAUNCH(LM, WP)                                                                                 \
   {                                                                                                       \
     static bool attr_set = false;                                                                         \
@@ -1222,7 +1287,7 @@ namespace adaflo_hip
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);      \
         attr_set = err == hipSuccess;                                                                     \
       }                                                                                                   \
-    if (err == hipSuccess)                                                                                \
+    if (err == hipSuccess && nwg > 0)                                                                     \
       hipLaunchKernelGGL((ns_ho_kernel<K, LM, WP>), grid, block, lds_bytes, ctx->stream, A);              \
   }
       if (with_p)
@@ -1254,7 +1319,10 @@ namespace adaflo_hip
         return ADAFLO_EHIP;
       if (stop)
         (void)hipEventRecord(stop, ctx->stream);
-      ctx->kernel_timer.count++;
+      if (phase == -1 || phase == 1)
+        ctx->kernel_timer.count++;
+      if (phase == 0)
+        return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
       const long tiles = (long)A.tiles_x * A.tiles_y;
       const bool fix_p = with_p && A.integrate_p;
       const long n1 = tiles * A.nnz, n2 = tiles * (A.n_chunks - 1);
@@ -1273,16 +1341,16 @@ namespace adaflo_hip
   }
 
   int launch_ns_vmult_ho(adaflo_ctx *ctx, const int op, double *dst_u, double *dst_p, const double *src_u,
-                         const double *src_p)
+                         const double *src_p, const int phase, const uint32_t iface)
   {
     switch (ctx->k)
       {
         case 3:
-          return launch_ho<3>(ctx, op, dst_u, dst_p, src_u, src_p);
+          return launch_ho<3>(ctx, op, dst_u, dst_p, src_u, src_p, phase, iface);
         case 4:
-          return launch_ho<4>(ctx, op, dst_u, dst_p, src_u, src_p);
+          return launch_ho<4>(ctx, op, dst_u, dst_p, src_u, src_p, phase, iface);
         case 5:
-          return launch_ho<5>(ctx, op, dst_u, dst_p, src_u, src_p);
+          return launch_ho<5>(ctx, op, dst_u, dst_p, src_u, src_p, phase, iface);
         default:
           return ADAFLO_EUNSUPPORTED;
       }

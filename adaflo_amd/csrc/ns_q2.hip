@@ -176,10 +176,9 @@ namespace adaflo_hip
     constexpr int L_UPL_    = L_UPL;
     static_assert(3 * (PNY * 52) <= 4 * RING * PIECE, "the residual mode keeps the old-solution planes in the ring area");
     constexpr int L_PPL     = L_UPL + 3 * UPLANE_L;       // 2 pressure node planes
-    // publish scratch: the masked reads "west / south of the first cells" reach up to 27 doubles below a
-    // slot, i.e. (slot 0 of plane 0) below the scratch itself: 4 doubles in front (cell 0 reads [-3, -1]);
-    // every such read must return a finite number (it is multiplied by a 0 mask): the area is zeroed once
-    // at kernel start and afterwards only ever holds published sums or state pieces.
+    // publish scratch: the unconditional reads "west / south of the first cells" (deselected afterwards) reach
+    // up to 27 doubles below a slot, i.e. (slot 0 of plane 0) below the scratch itself: 4 doubles in front
+    // (cell 0 reads [-3, -1]).
     // The scratch is only live between the quadrature loop and the end of a layer.  During the loop it
     // serves as an EXTENSION OF THE STATE RING (NRING_X more slots per wave, see RingSched): the kernel is
     // limited by how well the state stream overlaps with the arithmetic, i.e. by the pieces in flight.
@@ -1191,7 +1190,6 @@ namespace adaflo_hip
           const bool is_p = d == 3;
           const bool valid = cxl < tcx && cyl < tcy;
           const bool hasW = cxl > 0, hasS = cyl > 0;
-          const double fW = hasW ? 1. : 0., fS = hasS ? 1. : 0., fSW = (hasW && hasS) ? 1. : 0.;
           const unsigned long long vmask_u = __ballot(valid && !is_p), vmask_p = __ballot(valid && is_p);
           // constrained rows among the regular nodes: only on the low domain faces (the high faces are rim
           // nodes) and on the bottom plane; wave-uniform test, boundary tiles only
@@ -1212,9 +1210,11 @@ namespace adaflo_hip
                   const double t0 = sc[(lk * 5 + 3) * (NCELL * 3) - 24]; // south cell's (0,2) = my (0,0)
                   const double t1 = sc[(lk * 5 + 4) * (NCELL * 3) - 24]; //              (1,2) = my (1,0)
                   const double sw = sc[(lk * 5 + 2) * (NCELL * 3) - 27]; // south-west cell's (2,2) = my (0,0)
-                  R[0 + 9 * lk] = fma(fSW, sw, fma(fS, t0, fma(fW, w0, R[0 + 9 * lk])));
-                  R[1 + 9 * lk] = fma(fS, t1, R[1 + 9 * lk]);
-                  R[3 + 9 * lk] = fma(fW, w1, R[3 + 9 * lk]);
+                  // (selects, not 0/1 factors: what an absent neighbour's slot holds may be anything -- the cells
+                  // of a clipped tile beyond the mesh publish sums of uninitialised LDS)
+                  R[0 + 9 * lk] = ((R[0 + 9 * lk] + (hasW ? w0 : 0.)) + (hasS ? t0 : 0.)) + (hasW && hasS ? sw : 0.);
+                  R[1 + 9 * lk] += hasS ? t1 : 0.;
+                  R[3 + 9 * lk] += hasW ? w1 : 0.;
                 }
 #if defined(Q2_DST_WRAP)
               const unsigned voff = (8u * (unsigned)(lane_g + d)) & (Q2_DST_WRAP - 1u);
@@ -1278,8 +1278,8 @@ namespace adaflo_hip
                   t0[lk] = sc[(lk * 3 + 1) * NCELL - 8]; // S (0,1)
                   sw[lk] = sc[(lk * 3 + 2) * NCELL - 9]; // SW (1,1)
                 }
-              double a0 = fma(fSW, sw[0], fma(fS, t0[0], fma(fW, w0[0], R[0]))) + cu[0];
-              cu[0]     = fma(fSW, sw[1], fma(fS, t0[1], fma(fW, w0[1], R[18])));
+              double a0 = (((R[0] + (hasW ? w0[0] : 0.)) + (hasS ? t0[0] : 0.)) + (hasW && hasS ? sw[0] : 0.)) + cu[0];
+              cu[0]     = ((R[18] + (hasW ? w0[1] : 0.)) + (hasS ? t0[1] : 0.)) + (hasW && hasS ? sw[1] : 0.);
               const double *sp = A.src_p + (size_t)cz * A.npy * A.npx;
               double       *dp = A.dst_p + (size_t)cz * A.npy * A.npx;
               if (slow)

@@ -211,9 +211,8 @@ class NavierStokesMatrix:
                                                         interface_faces))
 
     def supports_phases(self):
-        """phased execution exists for the Q2/Q1 sweep kernel only"""
-        return (self.parameters.velocity_degree == 2 and getattr(self, "_variant", 1) >= 1
-                and not self._has_variable_coefficients)
+        """phased execution exists for the sweep kernels (Q2/Q1; Q3..Q5 with constant coefficients)"""
+        return bool(self._lib.adaflo_ns_supports_phases(self._require()))
 
     def residual(self, residual_vector, src, user_rhs, solution_old, solution_old_old):
         """solution_old / solution_old_old are constructor references in the reference

@@ -155,9 +155,12 @@ int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx);       /* :1144-1152 */
  *            (ready for compress(add)); requires the ghost values of src
  *   phase 2: the remaining interior cells and seam sums
  * After phase 2 dst equals the result of adaflo_ns_vmult without the mean-value projection.
- * Only with the Q2/Q1 sweep kernel (ADAFLO_EUNSUPPORTED otherwise). */
+ * Only with the sweep kernels -- Q2/Q1 (constant or variable coefficients) and Q3/Q2 .. Q5/Q4 (constant
+ * coefficients) --, ADAFLO_EUNSUPPORTED otherwise; adaflo_ns_supports_phases tells (1 / 0) for the
+ * current degree, coefficients and kernel variant. */
 int adaflo_ns_vmult_phase(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double *src_u,
                           const double *src_p, int phase, unsigned interface_faces);
+int adaflo_ns_supports_phases(adaflo_ctx *ctx);
 
 /* ---- Navier-Stokes operators (source/navier_stokes_matrix.cc) ----------- */
 /* vmult :221-262 */

@@ -107,7 +107,13 @@ def _worker(rank, world, port, grid, cells, k, gu, gp, glin, gcoef, ref_u, ref_p
             cu, cp = du.clone(), dp.clone()
             halo.update_ghost_values([cu, cp])
             torch.cuda.synchronize()
-            assert torch.equal(cu, du) and torch.equal(cp, dp), (rank, variant, overlap, native)
+            if not (torch.equal(cu, du) and torch.equal(cp, dp)):
+                bad_u, bad_p = torch.nonzero(cu != du).reshape(-1), torch.nonzero(cp != dp).reshape(-1)
+                raise AssertionError("replicas differ: rank %d variant %d overlap %s native %s: %d velocity entries "
+                                     "(first %s: %r vs %r), %d pressure entries (first %s)"
+                                     % (rank, variant, overlap, native, bad_u.numel(),
+                                        bad_u[:4].tolist(), cu[bad_u[:4]].tolist(), du[bad_u[:4]].tolist(),
+                                        bad_p.numel(), bad_p[:4].tolist()))
     finally:
         # explicit, ordered teardown: nothing of the engine is left to the interpreter's exit sequence
         torch.cuda.synchronize()
