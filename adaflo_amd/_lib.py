@@ -138,6 +138,8 @@ SIGNATURES = {
     "adaflo_ls_curvature_correction": (C.c_int, [_CTX, _D, _D]),
     "adaflo_ls_projection_vmult": (C.c_int, [_CTX, _D, _D]),
     "adaflo_ls_compute_force": (C.c_int, [_CTX, _D, _D, _D, C.POINTER(ForceParams)]),
+    "adaflo_vector_gather": (C.c_int, [_CTX, _D, _D, C.c_void_p, C.c_int64]),
+    "adaflo_vector_scatter": (C.c_int, [_CTX, _D, _D, C.c_void_p, C.c_int64, C.c_int]),
     "adaflo_vector_fill": (C.c_int, [_CTX, _D, C.c_double, C.c_int64]),
     "adaflo_vector_sadd": (C.c_int, [_CTX, _D, C.c_double, C.c_double, _D, C.c_int64]),
     "adaflo_vector_dot": (C.c_int, [_CTX, _D, _D, C.c_int64, C.POINTER(C.c_double)]),

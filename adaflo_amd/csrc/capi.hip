@@ -178,8 +178,9 @@ static int ctx_create_impl(const adaflo_brick_desc *desc, adaflo_ctx *ctx)
 {
   if (desc->dim != 3)
     return fail(nullptr, ADAFLO_EUNSUPPORTED, "only dim = 3 is implemented on the device");
-  if (desc->velocity_degree < 2 || desc->velocity_degree > 5)
-    return fail(nullptr, ADAFLO_EUNSUPPORTED, "velocity degree must be in [2,5] (reference: ExcNotImplemented)");
+  // EXPAND_OPERATIONS (source/navier_stokes_matrix.cc:64-82): degree_p = 1 .. 5, i.e. velocity degrees 2 .. 6
+  if (desc->velocity_degree < 2 || desc->velocity_degree > 6)
+    return fail(nullptr, ADAFLO_EUNSUPPORTED, "velocity degree must be in [2,6] (reference: ExcNotImplemented)");
   for (int d = 0; d < 3; ++d)
     if (desc->ncell[d] < 1 || !(desc->h[d] > 0.))
       return fail(nullptr, ADAFLO_EINVAL, "invalid brick extents");

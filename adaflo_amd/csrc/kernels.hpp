@@ -92,6 +92,9 @@ namespace adaflo_hip
   int launch_mean_projection(adaflo_ctx *ctx, double *v, const double *w, const double *modes,
                              long n, double inv);
   int launch_sadd(adaflo_ctx *ctx, double *x, double a, const double *y, long n); // x = a*x + y
+  // engine numbering <-> an application's numbering through a device-resident index map
+  int launch_map_gather(adaflo_ctx *ctx, double *eng, const double *ext, const long long *map, long n);
+  int launch_map_scatter(adaflo_ctx *ctx, double *ext, const double *eng, const long long *map, long n, int add);
   int launch_lincomb(adaflo_ctx *ctx, double *z, double a, const double *x, double b, const double *y, long n); // z = a x + b y
   int launch_residual_finish(adaflo_ctx *ctx, double *rhs, const double *sum, const double *user, long n); // rhs = user - rhs - sum
   int launch_fill(adaflo_ctx *ctx, double *x, double v, long n);

@@ -649,6 +649,32 @@ extern "C" {
 
 // ---- small vector algebra for the drivers around the solvers (LinearAlgebra::distributed::Vector
 // operator=, sadd, operator*, l2_norm on device-resident vectors)
+int adaflo_vector_gather(adaflo_ctx *ctx, double *engine_vec, const double *dealii_vec, const int64_t *index_map,
+                         int64_t n)
+{
+  if (!ctx)
+    return ADAFLO_ENOTINIT;
+  if (!engine_vec || !dealii_vec || !index_map || n < 0)
+    return kfail(ctx, ADAFLO_EINVAL, "null vector or index map");
+  static_assert(sizeof(long long) == sizeof(int64_t), "index type");
+  return launch_map_gather(ctx, engine_vec, dealii_vec, reinterpret_cast<const long long *>(index_map), (long)n) == 0 ?
+           0 :
+           kfail(ctx, ADAFLO_EHIP, "gather failed");
+}
+
+int adaflo_vector_scatter(adaflo_ctx *ctx, double *dealii_vec, const double *engine_vec, const int64_t *index_map,
+                          int64_t n, int add)
+{
+  if (!ctx)
+    return ADAFLO_ENOTINIT;
+  if (!engine_vec || !dealii_vec || !index_map || n < 0)
+    return kfail(ctx, ADAFLO_EINVAL, "null vector or index map");
+  return launch_map_scatter(ctx, dealii_vec, engine_vec, reinterpret_cast<const long long *>(index_map), (long)n,
+                            add ? 1 : 0) == 0 ?
+           0 :
+           kfail(ctx, ADAFLO_EHIP, "scatter failed");
+}
+
 int adaflo_vector_fill(adaflo_ctx *ctx, double *x, double value, int64_t n)
 {
   if (!ctx)

@@ -384,6 +384,9 @@ namespace adaflo_hip
         case 5:
           rc = launch_k<5, 256>(ctx, op, args);
           break;
+        case 6: // degree_p = 5, the last instance of EXPAND_OPERATIONS (:80-81): 343 quadrature points per cell
+          rc = launch_k<6, 384>(ctx, op, args);
+          break;
         default:
           rc = ADAFLO_EUNSUPPORTED;
       }
@@ -567,6 +570,8 @@ namespace adaflo_hip
           return launch_sc<4, 128>(ctx, args);
         case 5:
           return launch_sc<5, 256>(ctx, args);
+        case 6:
+          return launch_sc<6, 384>(ctx, args);
         default:
           return ADAFLO_EUNSUPPORTED;
       }

@@ -337,6 +337,43 @@ namespace adaflo_hip
     return check();
   }
 
+  namespace
+  {
+    // engine numbering <-> deal.II numbering through a device-resident index map (adaflo_vector_gather / _scatter)
+    __global__ __launch_bounds__(VT) void map_gather_kernel(double *__restrict__ eng, const double *__restrict__ ext,
+                                                            const long long *__restrict__ map, const long n)
+    {
+      for (long i = blockIdx.x * (long)VT + threadIdx.x; i < n; i += (long)gridDim.x * VT)
+        {
+          const long long m = map[i];
+          eng[i] = m >= 0 ? ext[m] : 0.;
+        }
+    }
+    __global__ __launch_bounds__(VT) void map_scatter_kernel(double *__restrict__ ext, const double *__restrict__ eng,
+                                                             const long long *__restrict__ map, const long n, const int add)
+    {
+      for (long i = blockIdx.x * (long)VT + threadIdx.x; i < n; i += (long)gridDim.x * VT)
+        {
+          const long long m = map[i];
+          if (m >= 0)
+            ext[m] = (add ? ext[m] : 0.) + eng[i];
+        }
+    }
+  } // namespace
+
+  int launch_map_gather(adaflo_ctx *ctx, double *eng, const double *ext, const long long *map, const long n)
+  {
+    if (n > 0)
+      hipLaunchKernelGGL(map_gather_kernel, dim3(grid_for(n)), dim3(VT), 0, ctx->stream, eng, ext, map, n);
+    return check();
+  }
+  int launch_map_scatter(adaflo_ctx *ctx, double *ext, const double *eng, const long long *map, const long n, const int add)
+  {
+    if (n > 0)
+      hipLaunchKernelGGL(map_scatter_kernel, dim3(grid_for(n)), dim3(VT), 0, ctx->stream, ext, eng, map, n, add);
+    return check();
+  }
+
   int launch_sadd(adaflo_ctx *ctx, double *x, const double a, const double *y, const long n)
   {
     hipLaunchKernelGGL(sadd_kernel, dim3(grid_for(n)), dim3(VT), 0, ctx->stream, x, a, y, n);

@@ -408,6 +408,24 @@ typedef struct adaflo_solver_result
   double initial_residual, final_residual;
 } adaflo_solver_result;
 
+/* ---- deal.II-numbered vectors at the boundary ------------------------------------------------
+ * The engine numbers the DoFs of its brick node-lexicographically (header comment of adaflo_brick_desc).
+ * A LinearAlgebra::distributed::Vector<double> of the application stores them in deal.II's numbering,
+ * locally owned entries first, ghost entries appended (source/navier_stokes.cc:79-83,
+ * include/adaflo/block_matrix_extension.h:48-49 use begin() as one contiguous double[owned + ghost]).
+ * With a DEVICE-resident index map  map[i] = position of engine DoF i in that array (-1: no counterpart,
+ * e.g. a DoF deal.II eliminated) an adapter moves between the two numberings without a host permutation:
+ *   adaflo_vector_gather   engine[i] = map[i] >= 0 ? dealii[map[i]] : 0            i < n
+ *   adaflo_vector_scatter  dealii[map[i]] = (add ? dealii[map[i]] : 0) + engine[i]  for map[i] >= 0
+ * One coalesced pass each (the engine side is contiguous).  The map must not name a deal.II entry twice
+ * (a brick holds every node once); scatter with add = 1 into the owned + ghost array followed by the
+ * application's compress(add) is the cell_loop convention (navier_stokes_matrix.cc:232-245), add = 0 copies
+ * final values (after adaflo_ns_vmult_distributed, which has done the exchange itself).               */
+int adaflo_vector_gather(adaflo_ctx *ctx, double *engine_vec, const double *dealii_vec, const int64_t *index_map,
+                         int64_t n);
+int adaflo_vector_scatter(adaflo_ctx *ctx, double *dealii_vec, const double *engine_vec, const int64_t *index_map,
+                          int64_t n, int add);
+
 /* vector algebra of the drivers on device vectors: x = value; x = a x + b y; (x, y) */
 int adaflo_vector_fill(adaflo_ctx *ctx, double *x, double value, int64_t n);
 int adaflo_vector_sadd(adaflo_ctx *ctx, double *x, double a, double b, const double *y, int64_t n);

@@ -7,7 +7,8 @@
  * evaluate, quadrature-point loop with STORED linearisation state, integrate,
  * scatter-add -- with conflict-free 8-colouring of the cells instead of
  * deal.II's TBB partitioning, all host cores via OpenMP.  It is validated
- * against the naive oracle in tests/test_oracle_fast.py.  It is NOT deal.II's
+ * against the naive oracle in tests/test_oracle_kats.py and
+ * tests/test_golden_fixtures.py.  It is NOT deal.II's
  * tuned AVX-512 kernel (no cross-cell SIMD batching, no even-odd trick);
  * bench.py labels it accordingly.
  *

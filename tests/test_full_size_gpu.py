@@ -1,8 +1,8 @@
 """Full-size parity of the BASELINE configurations on one MI355X:
   config 2  128^3 Q2/Q1 Newton vmult against the oracle's OpenMP restatement (oracle/adaflo_oracle_fast.c,
             itself checked against the naive oracle in tests/test_oracle_kats.py) on the same seeded inputs;
-  config 5  64^3 Q4/Q3 stationary driven-cavity operator: wave-private sweep kernel against the generic
-            per-cell kernel (independent code) + linearity;
+  config 5  64^3 Q4/Q3 stationary driven-cavity operator: wave-private sweep kernel against the same OpenMP
+            restatement (degree 4), and against the generic per-cell kernel (independent code) + linearity;
   config 3  the whole 256^3 Q2/Q1 problem (422 M DoF) on ONE GPU: sweep kernel against the generic kernel +
             linearity (marked slow)."""
 import numpy as np
@@ -64,6 +64,27 @@ def _sweep_vs_generic_and_linearity(case, nq):
     op.vmult(dst, x)
     z_u, z_p = dst.numpy()
     assert rel_l2(z_u, a * ax_u + b * ay_u) < TOL and rel_l2(z_p, a * ax_p + b * ay_p) < TOL
+
+
+def test_config5_q4_cavity_64cubed_against_openmp_oracle():
+    """BASELINE configs[4]: Q4/Q3, 64^3 cells on [0,1]x[0,1]x[0,3], `incompressible stationary`, mu = 0.01: the
+    high-order sweep kernel against the oracle's OpenMP restatement (adaflo_oracle_fast.c takes any degree)
+    on the same seeded inputs, entry by entry"""
+    case = Case((64, 64, 64), k=4, lower=(0., 0., 0.), upper=(1., 1., 3.), physical_type=1, viscosity=0.01)
+    rng = np.random.default_rng(20260515)
+    src_u, src_p = rng.uniform(-1, 1, case.n_u), rng.uniform(-1, 1, case.n_p)
+    lin = rng.uniform(-1, 1, case.n_cells * 125 * 12)
+    w, modes = case.weights_modes()
+    orc.fast_set_threads(orc.usable_cores())
+    ref_u, ref_p = orc.fast_ns_vmult(case.mesh, 4, case.prm, src_u, src_p, case.con_u, None, lin=lin,
+                                     weights=w, modes=modes)
+    op = case.engine()
+    op.set_linearization(lin)
+    del lin
+    dst = op.block_vector()
+    op.vmult(dst, op.block_vector(src_u, src_p))
+    got_u, got_p = dst.numpy()
+    assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL, (rel_l2(got_u, ref_u), rel_l2(got_p, ref_p))
 
 
 def test_config5_q4_cavity_64cubed_properties():

@@ -169,6 +169,44 @@ def test_sweep_right_hand_sides_unaligned_tiles_and_velocity_degrees(s, k, ncell
     assert rel_l2(d.numpy(), ref) < TOL
 
 
+def test_config4_full_size_against_oracle():
+    """BASELINE configs[3] at full size (40 x 40 x 80 cells, s = 4: 8.3 M level-set DoF, 65.5 M quadrature points):
+    the sweep kernels of advance_concentration_vmult, reinitialization_vmult and of the two right-hand sides
+    against the CPU oracle's cell loops on identical inputs, entry by entry.  The four oracle evaluations
+    (naive restatement, tens of seconds each) run concurrently in threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    c = LSCase((40, 40, 80), 4)
+    src, phi, old, oldold, normal = c.rand(), c.rand(), c.rand(), c.rand(), c.rand(3)
+    uq, nq = c.rand_q(), c.rand_q()
+    vel = c.rng.uniform(-1, 1, c.mesh.n_nodes(c.k) * 3)
+    uq_ref, nq_ref = np.zeros_like(uq), np.zeros_like(nq)
+    with ThreadPoolExecutor(4) as pool:          # (ctypes calls release the interpreter lock)
+        f_adv = pool.submit(orc.ls_advect_vmult, c.mesh, c.prm, src, uq)
+        f_rei = pool.submit(orc.ls_reinit_vmult, c.mesh, c.prm, src, nq, diffuse_only=False)
+        f_arhs = pool.submit(orc.ls_advect_rhs, c.mesh, c.prm, c.k, phi, old, oldold, vel, uq_ref, c.w_old, c.w_oo, True)
+        f_rrhs = pool.submit(orc.ls_reinit_rhs, c.mesh, c.prm, phi, normal, nq_ref, diffuse_only=False, first_step=True)
+        # the device side meanwhile
+        adv, rei = lso.LevelSetOKZSolverAdvanceConcentration(c.ops), lso.LevelSetOKZSolverReinitialization(c.ops)
+        d = c.ops.vector()
+        adv.evaluated_convection = uq
+        adv.advance_concentration_vmult(d, c.ops.vector(src))
+        got_adv = d.numpy()
+        rei.evaluated_normal = nq
+        rei.reinitialization_vmult(d, c.ops.vector(src), False)
+        got_rei = d.numpy()
+        d = c.ops.vector()
+        adv.local_advance_concentration_rhs(d, c.ops.vector(phi), c.ops.vector(old), c.ops.vector(oldold),
+                                            c.ops.velocity_vector(vel), True)
+        got_arhs, got_uq = d.numpy(), adv.evaluated_convection
+        d = c.ops.vector()
+        rei.local_reinitialize_rhs(d, c.ops.vector(phi), c.ops.vector(normal, blocks=3), False, True)
+        got_rrhs, got_nq = d.numpy(), rei.evaluated_normal
+        assert rel_l2(got_adv, f_adv.result()) < TOL, "advance_concentration_vmult vs oracle"
+        assert rel_l2(got_rei, f_rei.result()) < TOL, "reinitialization_vmult vs oracle"
+        assert rel_l2(got_arhs, f_arhs.result()) < TOL and rel_l2(got_uq, uq_ref) < TOL, "advection rhs vs oracle"
+        assert rel_l2(got_rrhs, f_rrhs.result()) < TOL and rel_l2(got_nq, nq_ref) < TOL, "reinitialisation rhs vs oracle"
+
+
 def test_full_size_properties_config4():
     """Config 4 (40x40x80 cells, s = 4, 8.3 M level-set DoF): the structured Q1 sweep kernel and
     the generic per-cell kernels (independent code) agree for every operator application, and

@@ -43,6 +43,31 @@ def test_vmult_linearizations_generic(lin):
     assert eu < TOL and ep < TOL, (eu, ep)
 
 
+def test_velocity_degree_six():
+    """degree_p = 5, the last instance of EXPAND_OPERATIONS (navier_stokes_matrix.cc:64-82): vmult, residual with the
+    state it stores and velocity_vmult of the Q6/Q5 pair on the generic kernels (sub-blocks: test_scalar_sub_blocks)"""
+    case = Case((2, 2, 3), k=6, upper=(1.0, 0.5, 2.0), tau_grad_div=0.2, steps=3)
+    eu, ep = run_vmult(case, variant=1)
+    assert eu < TOL and ep < TOL, (eu, ep)
+    src_u, src_p = case.smooth_u(0.1) + 0.01 * case.random_u(), case.smooth_p(0.1)
+    old_u, oldold_u = case.smooth_u(0.05), case.smooth_u(0.0)
+    lin_ref = np.zeros(case.n_cells * case.nq * 12)
+    ref_u, ref_p = orc.ns_residual(case.mesh, case.k, case.prm, src_u, src_p, old_u, oldold_u,
+                                   con_u=case.con_u, con_p=case.con_p, lin=lin_ref)
+    op = case.engine()
+    rhs = op.block_vector()
+    op.residual(rhs, op.block_vector(src_u, src_p), None, op.block_vector(old_u), op.block_vector(oldold_u))
+    got_u, got_p = rhs.numpy()
+    assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL
+    assert rel_l2(op.get_linearization(), lin_ref) < TOL
+    su = case.random_u()
+    ref = orc.ns_velocity_vmult(case.mesh, case.k, case.prm, su, case.con_u, lin=lin_ref)
+    op.fix_linearization_point()
+    dst = op.initialize_u_vector()
+    op.velocity_vmult(dst, op.initialize_u_vector(su))
+    assert rel_l2(dst.numpy(), ref) < TOL
+
+
 @pytest.mark.parametrize("phys", [1, 2])
 def test_vmult_physical_types_generic(phys):
     case = Case((3, 3, 3), k=2, physical_type=phys, viscosity=0.1)
@@ -101,7 +126,7 @@ def test_velocity_vmult_and_fixed_point():
 
 
 @pytest.mark.parametrize("k,ncell,variant", [(2, (3, 2, 4), 0), (3, (3, 2, 4), 0), (2, (3, 2, 4), 1),
-                                             (2, (18, 17, 35), 1)])
+                                             (2, (18, 17, 35), 1), (6, (2, 2, 2), 0)])
 def test_scalar_sub_blocks(k, ncell, variant):
     """variant 1 with k = 2: constant-coefficient pressure mass / Poisson run on the structured
     Q1 sweep kernel, everything else on the generic kernels"""
