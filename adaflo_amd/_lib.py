@@ -86,6 +86,7 @@ SIGNATURES = {
     "adaflo_ns_get_coefficients": (C.c_int, [_CTX, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "adaflo_ns_fix_linearization_point": (C.c_int, [_CTX]),
     "adaflo_ns_vmult": (C.c_int, [_CTX, _D, _D, _D, _D]),
+    "adaflo_ns_preconditioner_set_cheap_velocity_iterations": (C.c_int, [_CTX, C.c_int]),
     "adaflo_ns_vmult_phase": (C.c_int, [_CTX, _D, _D, _D, _D, C.c_int, C.c_uint]),
     "adaflo_ns_supports_phases": (C.c_int, [_CTX]),
     "adaflo_ns_residual": (C.c_int, [_CTX, _D, _D, _D, _D, _D, _D, _D, _D]),

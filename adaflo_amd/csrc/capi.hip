@@ -959,6 +959,15 @@ int adaflo_ns_set_iterations_before_inner_solvers(adaflo_ctx *ctx, int iteration
   return 0;
 }
 
+int adaflo_ns_preconditioner_set_cheap_velocity_iterations(adaflo_ctx *ctx, int iterations)
+{
+  CHECK_CTX(ctx);
+  if (iterations < 0)
+    return fail(ctx, ADAFLO_EINVAL, "negative iteration count");
+  ctx->pc_simple_velocity_its = iterations;
+  return 0;
+}
+
 int adaflo_ns_preconditioner_set_inner(adaflo_ctx *ctx, int mode)
 {
   CHECK_CTX(ctx);

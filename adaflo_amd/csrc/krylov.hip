@@ -1011,7 +1011,10 @@ int adaflo_ns_preconditioner_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p
     else
       {
         const double norm = std::sqrt(host_dot(ctx, src_u, src_u, nu));
-        const adaflo_solver_control c{100, 3e-2 * norm, 0.};
+        // cheap stage with Jacobi diagonals (variable coefficients): the velocity solve is cut off after a few
+        // BiCGStab iterations -- an approximate inverse in the sense of do_inner_solves == false (:605-635),
+        // FGMRES outside copes with the varying operator
+        const adaflo_solver_control c{ctx->pc_simple ? ctx->pc_simple_velocity_its : 100, 3e-2 * norm, 0.};
         if (launch_fill(ctx, dst_u, 0., nu))
           return kfail(ctx, ADAFLO_EHIP, "fill failed");
         K.inv_diag = ctx->pc_inv_u.p;
@@ -1134,7 +1137,8 @@ int adaflo_ns_solve_system(adaflo_ctx *ctx, double *update_u, double *update_p, 
   // (do_inner_solves = false) for `lin its before inner solvers` iterations, then -- from the iterate reached --
   // the solver with inner Krylov solves.  The cheap stage needs approximate inverses that deserve the name:
   // it is taken with the fast-diagonalisation inverses (constant coefficients), not with the Jacobi diagonals.
-  const bool two_stage = ctx->pc_built_fdm && !ctx->rho_prec.p && ctx->pc_its_before_inner > 0;
+  const bool two_stage = ctx->pc_its_before_inner > 0 &&
+                         ((ctx->pc_built_fdm && !ctx->rho_prec.p) || (!ctx->pc_built_fdm && ctx->pc_simple_velocity_its > 0));
   const int  simple_limit = two_stage ? std::min(ctx->pc_its_before_inner, control->max_iterations) : 0;
   struct StageGuard // (error returns below must not leave the context in the cheap stage)
   {

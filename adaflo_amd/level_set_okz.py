@@ -14,6 +14,17 @@ from . import _lib
 from .vectors import DeviceVector
 
 
+def _projection_solve(solver, dst, rhs, n_blocks):
+    """exact inverse of the projection matrix (adaflo_ls_projection_solve); False when the engine refuses it -- a
+    level-set space with constrained faces, ADAFLO_EUNSUPPORTED -- so that the caller keeps the CG path of the
+    reference; any other error is raised"""
+    code = solver._lib.adaflo_ls_projection_solve(solver._ctx, dst.ptr, rhs.ptr, n_blocks)
+    if code == _lib.ADAFLO_EUNSUPPORTED:
+        return False
+    _lib.check(solver._ctx, code)
+    return True
+
+
 class LevelSetOperators:
     """owns the engine context for the level-set spaces on a brick (FE_Q_iso_Q1(ls_degree))"""
 
@@ -279,16 +290,6 @@ class LevelSetOKZSolverComputeNormal:
     def local_compute_normal_rhs(self, dst, level_set_solution):
         _lib.check(self._ctx, self._lib.adaflo_ls_compute_normal_rhs(self._ctx, dst.ptr, level_set_solution.ptr))
 
-    def _projection_solve(self, dst, rhs, n_blocks):
-        """exact inverse of the projection matrix (adaflo_ls_projection_solve); False when the engine
-        refuses it -- a level-set space with constrained faces, ADAFLO_EUNSUPPORTED -- so that the caller
-        keeps the CG path of the reference; any other error is raised"""
-        code = self._lib.adaflo_ls_projection_solve(self._ctx, dst.ptr, rhs.ptr, n_blocks)
-        if code == _lib.ADAFLO_EUNSUPPORTED:
-            return False
-        _lib.check(self._ctx, code)
-        return True
-
     def compute_normal(self, normal_vector_field, normal_vector_rhs, level_set_solution, preconditioner,
                        fast_computation=False):
         """LevelSetOKZSolverComputeNormal::compute_normal (level_set_okz_compute_normal.cc:207-285) in
@@ -298,7 +299,7 @@ class LevelSetOKZSolverComputeNormal:
         from .solvers import ComputeNormalMatrix, ReductionControl, SolverCG
         normal_vector_rhs.fill(0.0)
         self.local_compute_normal_rhs(normal_vector_rhs, level_set_solution)
-        if self.ops.exact_projection and self._projection_solve(normal_vector_field, normal_vector_rhs, 3):
+        if self.ops.exact_projection and _projection_solve(self, normal_vector_field, normal_vector_rhs, 3):
             # the projection matrix is a constant-coefficient tensor-product operator on the brick: solved
             # exactly by fast diagonalisation (csrc/fdm.hip), 0 iterations
             return 0
@@ -332,7 +333,7 @@ class LevelSetOKZSolverComputeCurvature:
         self.local_compute_curvature_rhs(rhs, normal_vector_field)
         control = ReductionControl(2000, 1e-50, 1e-8)
         if not (self.ops.exact_projection and use_projection_matrix
-                and self._projection_solve(solution_curvature, rhs, 1)):
+                and _projection_solve(self, solution_curvature, rhs, 1)):
             matrix = ProjectionMatrix(self.ops) if use_projection_matrix else ComputeCurvatureMatrix(self.ops)
             SolverCG(control).solve(matrix, solution_curvature, rhs, preconditioner)
         if solution_ls is not None:

@@ -474,6 +474,10 @@ int adaflo_ns_preconditioner_set_inner(adaflo_ctx *ctx, int mode);
  * coefficients); with Jacobi diagonals the solver with inner solves runs from the start.  0 = inner
  * solves at once.                                                                                 */
 int adaflo_ns_set_iterations_before_inner_solvers(adaflo_ctx *ctx, int iterations);
+/* Variable coefficients (Jacobi diagonals, mode 0 or two-phase flow): the cheap stage applies, as approximate
+ * inverse of the velocity block, a BiCGStab solve cut off after `iterations` iterations (0 = no cheap stage:
+ * inner solves to their tolerance from the start, the behaviour of rounds 1 and 2).                        */
+int adaflo_ns_preconditioner_set_cheap_velocity_iterations(adaflo_ctx *ctx, int iterations);
 /* number of velocity-block solves and their BiCGStab iterations since the last query */
 int adaflo_ns_preconditioner_statistics(adaflo_ctx *ctx, int64_t *velocity_solves, int64_t *velocity_iterations);
 /* NavierStokes::solve_system (source/navier_stokes.cc:561-653): FGMRES(restart) on adaflo_ns_vmult,

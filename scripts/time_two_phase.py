@@ -30,6 +30,10 @@ def main():
         ctx = ns.navier_stokes_matrix._require()
         adaflo_amd._lib.check(ctx, adaflo_amd._lib.load().adaflo_ns_preconditioner_set_inner(ctx, int(sys.argv[3])))
 
+    if len(sys.argv) > 6:      # cheap stage of the two-phase solver: BiCGStab iterations of the velocity block (0 = off)
+        ctx = ns.navier_stokes_matrix._require()
+        adaflo_amd._lib.check(ctx, adaflo_amd._lib.load().adaflo_ns_preconditioner_set_cheap_velocity_iterations(ctx, int(sys.argv[6])))
+
     def timed(name, fn, acc):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -53,6 +57,7 @@ def main():
             if it == 0:
                 timed("build_preconditioner", ns.build_preconditioner, acc)
             its, _ = timed("solve_system", lambda: ns.solve_system(tol), acc)
+            acc["outer_its"] = acc.get("outer_its", 0) + its * 1e-3
             ns.solution[0] += ns.solution_update[0]
             ns.solution[1] += ns.solution_update[1]
             res = timed("compute_residual", ns.compute_residual, acc)
