@@ -1,9 +1,9 @@
 #!/bin/bash
 # All measurements behind DESIGN.md / profiles/ of one round, on the GPU box:
-#   gpurun --timeout 3000 -- 'bash scripts/measure_round.sh r02'
+#   gpurun --timeout 3000 -- 'bash scripts/measure_round.sh r03'
 # writes gpurun_out/<tag>/<name>/*_kernel_stats.csv + <name>.log; scripts/collect_profiles.py copies the
 # summaries into profiles/ and builds profiles/pmc_traffic.json.
-tag=${1:-r02}
+tag=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$tag
 mkdir -p "$O"
@@ -29,9 +29,14 @@ pmc pmc_q4_fetch FETCH_SIZE python3 $R/bench.py --config cavity --steps 5 --warm
 pmc pmc_q4_write WRITE_SIZE python3 $R/bench.py --config cavity --steps 5 --warmup 2 --no-cpu-baseline
 pmc pmc_q4_sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" python3 $R/bench.py --config cavity --steps 5 --warmup 2 --no-cpu-baseline
 pmc pmc_q4_sq2 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" python3 $R/bench.py --config cavity --steps 5 --warmup 2 --no-cpu-baseline
+# calibration of the FETCH_SIZE counter for 8-B-per-lane reads (the access width of ns_ho_kernel)
+hipcc --offload-arch=gfx950 -O3 $R/scripts/dev/fetch_probe.hip -o /tmp/fetch_probe > "$O/fetch_probe_build.log" 2>&1
+pmc pmc_fetch_probe FETCH_SIZE /tmp/fetch_probe
 # no rocprof: the plain bench lines and the large meshes
 cd $R
 python3 bench.py > "$O/bench_n1_plain.log" 2>&1
 python3 bench.py --cells 256 --steps 20 --warmup 3 --no-cpu-baseline > "$O/bench_256cubed_one_gpu.log" 2>&1
 python3 bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline > "$O/bench_2ranks_one_gpu.log" 2>&1
+python3 bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline --src-consistent > "$O/bench_2ranks_one_gpu_src_consistent.log" 2>&1
+python3 bench.py --gpus 2 --config cavity --steps 10 --warmup 2 --no-cpu-baseline > "$O/bench_cavity_2ranks_one_gpu.log" 2>&1
 echo done > "$O/done"
