@@ -61,8 +61,9 @@ for name in sorted(os.listdir(src)):
 traffic = {"_comment": "scripts/collect_profiles.py from scripts/measure_round.sh %s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
                        "separate passes of bench.py --steps 5 --warmup 2; KB per launch averaged.  ns_q2_kernel: hbm_bytes = "
                        "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction for 16-B-per-lane streaming reads).  ns_ho_kernel "
-                       "reads 8 B per lane: the correction is not calibrated for that width, so both the raw "
-                       "(FETCH_SIZE + WRITE_SIZE) and the doubled figure are given and hbm_bytes is left null." % tag}
+                       "reads its state 8 B per lane in runs of 25 lanes: hbm_bytes = FETCH_SIZE / r + WRITE_SIZE with the "
+                       "ratio r measured by scripts/dev/fetch_probe.hip in the same round (fetch_size_calibration); the "
+                       "raw and the doubled figure are given beside it." % tag}
 
 
 def mean_kb(pass_name, kernel, counter):
@@ -76,9 +77,23 @@ f, w = mean_kb("pmc_q2_fetch", VMULT_Q2, "FETCH_SIZE"), mean_kb("pmc_q2_write", 
 if f and w:
     traffic["128x128x128 k=2 variant=1"] = {"ns_q2_kernel": {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
                                                                 "hbm_bytes": int((2 * f + w) * 1024)}}
+# calibration of FETCH_SIZE for the access shape of ns_ho_kernel<4> (8 B per lane in runs of 25 lanes):
+# scripts/dev/fetch_probe.hip reads a known number of bytes in that shape (and 8 / 16 B per lane contiguously)
+PROBE_BYTES = {"read16_contiguous": 2147483648, "read8_contiguous": 2147483648, "read8_runs_of_25": 2147472000}
+ratio = {}
+for name, nbytes in PROBE_BYTES.items():
+    kb = mean_kb("pmc_fetch_probe", name, "FETCH_SIZE")
+    if kb:
+        ratio[name] = kb * 1024 / nbytes
+if ratio:
+    traffic["fetch_size_calibration"] = {"FETCH_SIZE_bytes_per_byte_read": ratio,
+                                         "note": "gfx950: 0.5 for contiguous 8- and 16-B-per-lane reads, ~0.8 for the "
+                                                 "runs of 25 x 8 B of the Q4/Q3 state reads"}
 f, w = mean_kb("pmc_q4_fetch", "ns_ho_kernel", "FETCH_SIZE"), mean_kb("pmc_q4_write", "ns_ho_kernel", "WRITE_SIZE")
 if f and w:
-    traffic["64x64x64 k=4 variant=1"] = {"ns_ho_kernel": {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes": None,
+    r25 = ratio.get("read8_runs_of_25")
+    traffic["64x64x64 k=4 variant=1"] = {"ns_ho_kernel": {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
+                                                             "hbm_bytes": int((f / r25 + w) * 1024) if r25 else None,
                                                              "raw_bytes": int((f + w) * 1024),
                                                              "fetch_doubled_bytes": int((2 * f + w) * 1024)}}
 with open(os.path.join(dst, "pmc_traffic.json"), "w") as out:
