@@ -159,10 +159,11 @@ def _run_distributed_case(world, cells, k=2, two_phase=False):
     # workers now tear the engine down explicitly; 20 repetitions of the 4-rank case and a torch-only job of
     # 8 processes x 6 streams ran clean on a warm box (scripts/dev/stress_parallel.py, noop_multiprocess.py); the
     # two deaths seen this round both hit the very first GPU command on a fresh box (cold caches, ranks loading the
-    # code objects while others already run).  Not reproduced since, so: a death by SIGNAL is reported loudly (a
-    # warning in the test summary, counted) and that run is repeated once; Python exceptions in a rank (wrong
-    # numbers, engine errors) arrive as ProcessRaisedException and are never retried.
-    for attempt in range(2):
+    # code objects while others already run); eight later runs of the largest 8-rank case lost one rank once.  Not
+    # root-caused (it needs several processes on one device), so: a death by SIGNAL is reported loudly (a warning in
+    # the test summary, counted) and that run is repeated, at most twice; Python exceptions in a rank (wrong numbers,
+    # engine errors) arrive as ProcessRaisedException and are never retried.
+    for attempt in range(3):
         try:
             results.clear()
             mp.spawn(_worker, args=(world, _free_port(), grid, list(cells), k, gu, gp, glin, gcoef, ref_u, ref_p, results),
@@ -174,7 +175,7 @@ def _run_distributed_case(world, cells, k=2, two_phase=False):
             import warnings
             warnings.warn("a rank of the %d-process job died by signal (%s); death number %d of this session, attempt %d"
                           % (world, e, RANK_DEATHS, attempt + 1), RuntimeWarning)
-            if attempt == 1:
+            if attempt == 2:
                 raise
     assert len(results) == (5 if not os.environ.get("ADAFLO_TEST_VARIANTS") else len(results) // world) * world
     for key, (eu, ep) in results.items():
