@@ -159,8 +159,11 @@ def _run_distributed_case(world, cells, k=2, two_phase=False):
     # workers now tear the engine down explicitly; 20 repetitions of the 4-rank case and a torch-only job of
     # 8 processes x 6 streams ran clean on a warm box (scripts/dev/stress_parallel.py, noop_multiprocess.py); the
     # two deaths seen this round both hit the very first GPU command on a fresh box (cold caches, ranks loading the
-    # code objects while others already run); eight later runs of the largest 8-rank case lost one rank once.  Not
-    # root-caused (it needs several processes on one device), so: a death by SIGNAL is reported loudly (a warning in
+    # code objects while others already run); eight later runs of the largest 8-rank case lost one rank once.  Bisected
+    # with ADAFLO_TEST_VARIANTS (scripts/dev/stress_parallel.py 18 2 8 big): 18 eight-rank runs with ONLY the generic
+    # kernels (one workgroup per cell, f64 global atomics) lost 4 ranks, 18 runs with ONLY the sweep kernels none --
+    # the kernels `bench.py` and the multi-GPU path run are not the ones that die.  Why the atomic-add kernels of
+    # several processes sharing a device fault is not known (it needs several processes on one device), so: a death by SIGNAL is reported loudly (a warning in
     # the test summary, counted) and that run is repeated, at most twice; Python exceptions in a rank (wrong numbers,
     # engine errors) arrive as ProcessRaisedException and are never retried.
     for attempt in range(3):
