@@ -21,7 +21,19 @@ namespace adaflo_hip
     int      ncell[3];
     double   h[3];
     uint32_t con_u, con_p, con_ls;
+    // Cell loops with a scatter-add run once per COLOUR of the cells (parities of cx, cy, cz: bit d of `colour`):
+    // two cells of one colour share no node, so the scatter needs no atomics and the result is bitwise
+    // reproducible.  -1: all cells in one launch (kernels that do not scatter).
+    int      colour = -1;
   };
+  // number of cells of a colour
+  inline long n_cells_of_colour(const int ncell[3], const int colour)
+  {
+    long n = 1;
+    for (int d = 0; d < 3; ++d)
+      n *= (ncell[d] - (colour >> d & 1) + 1) / 2;
+    return n;
+  }
 
   // lexicographic cell index -> XCD-aware remap of blockIdx (workgroups are
   // dealt round-robin to the 8 XCDs; give each XCD a contiguous range of cells
@@ -32,6 +44,19 @@ namespace adaflo_hip
     if (b >= per * 8)
       return b; // tail
     return (b % 8) * per + b / 8;
+  }
+
+  // lexicographic index of the cell a workgroup works on: workgroup `blk` of the launch for brick.colour
+  // (or of the one launch over all n_cells cells)
+  __device__ __forceinline__ long brick_cell(const BrickDev &b, const long blk, const long n_cells)
+  {
+    if (b.colour < 0)
+      return xcd_remap(blk, n_cells);
+    const int  px = b.colour & 1, py = b.colour >> 1 & 1, pz = b.colour >> 2 & 1;
+    const int  nx = (b.ncell[0] - px + 1) / 2, ny = (b.ncell[1] - py + 1) / 2, nz = (b.ncell[2] - pz + 1) / 2;
+    const long r  = xcd_remap(blk, (long)nx * ny * nz);
+    const int  i = (int)(r % nx), j = (int)((r / nx) % ny), k = (int)(r / ((long)nx * ny));
+    return (2 * i + px) + (long)b.ncell[0] * ((2 * j + py) + (long)b.ncell[1] * (2 * k + pz));
   }
 
   // is node (I,J,K) of a space with nn[d] nodes per direction on a constrained
@@ -417,7 +442,8 @@ namespace adaflo_hip
       }
   }
 
-  // distribute_local_to_global: atomic scatter-add, constrained rows skipped
+  // distribute_local_to_global: scatter-add, constrained rows skipped.  No atomics: the cell loops run colour by
+  // colour (BrickDev::colour), the cells of one launch share no node.
   template <int DEG, int NC, int NT>
   __device__ void scatter_cell(double *__restrict__ vec, const double *loc, const int cx,
                                const int cy, const int cz, const int nnx, const int nny,
@@ -431,7 +457,7 @@ namespace adaflo_hip
         const int  I = cx * DEG + i, J = cy * DEG + j, K = cz * DEG + k;
         const long node = I + (long)nnx * (J + (long)nny * K);
         if (!on_constrained_face(I, J, K, nnx, nny, nnz, mask, NC == 1 ? 1 : 3, c))
-          unsafeAtomicAdd(&vec[node * NC + c], loc[c * ND3 + l]);
+          vec[node * NC + c] += loc[c * ND3 + l];
       }
   }
 } // namespace adaflo_hip

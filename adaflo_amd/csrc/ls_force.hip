@@ -164,7 +164,7 @@ namespace adaflo_hip
       const int tid = threadIdx.x;
       for (int o = tid; o < C::TAB; o += NT)
         lds[o] = a.tab[o];
-      const long c   = xcd_remap(blockIdx.x, a.n_cells);
+      const long c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
       const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
       const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
       const int  nx = S * ncx + 1, ny = S * ncy + 1, nz = S * ncz + 1;
@@ -207,7 +207,7 @@ namespace adaflo_hip
     }
 
     template <int S, int KU>
-    int launch_force_sk(adaflo_ctx *ctx, const ForceArgs &a)
+    int launch_force_sk(adaflo_ctx *ctx, const ForceArgs &args)
     {
       constexpr int NT = 128;
       using C          = ForceCfg<S, KU, NT>;
@@ -216,8 +216,13 @@ namespace adaflo_hip
       if (lds > 64 * 1024)
         err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_force_kernel<S, KU, NT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (err == hipSuccess)
-        hipLaunchKernelGGL((ls_force_kernel<S, KU, NT>), dim3((unsigned)a.n_cells), dim3(NT), lds, ctx->stream, a);
+      ForceArgs a = args;
+      for (int colour = 0; colour < 8 && err == hipSuccess; ++colour) // (no atomics in the scatter, fe_kernels.hpp)
+        if (const long nc = n_cells_of_colour(a.brick.ncell, colour))
+          {
+            a.brick.colour = colour;
+            hipLaunchKernelGGL((ls_force_kernel<S, KU, NT>), dim3((unsigned)nc), dim3(NT), lds, ctx->stream, a);
+          }
       if (err == hipSuccess)
         err = hipGetLastError();
       return err == hipSuccess ? 0 : ADAFLO_EHIP;

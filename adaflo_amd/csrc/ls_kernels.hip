@@ -72,7 +72,7 @@ namespace adaflo_hip
     const int tid = threadIdx.x;
     for (int o = tid; o < C::TAB; o += NT)
       lds[o] = a.tab[o];
-    const long c   = xcd_remap(blockIdx.x, a.n_cells);
+    const long c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
     const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
     const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
     const int  nx = S * ncx + 1, ny = S * ncy + 1, nz = S * ncz + 1;
@@ -164,7 +164,7 @@ namespace adaflo_hip
     const int tid = threadIdx.x;
     for (int o = tid; o < C::TAB; o += NT)
       lds[o] = a.tab[o];
-    const long c   = xcd_remap(blockIdx.x, a.n_cells);
+    const long c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
     const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
     const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
     const int  nx = S * ncx + 1, ny = S * ncy + 1, nz = S * ncz + 1;
@@ -314,7 +314,7 @@ namespace adaflo_hip
       lds[o] = a.tab[o];
     for (int o = tid; o < NQ * (KU + 1); o += NT)
       Sv[o] = a.tab[C::TAB + o];
-    const long c   = xcd_remap(blockIdx.x, a.n_cells);
+    const long c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
     const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
     const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
     const int  nx = S * ncx + 1, ny = S * ncy + 1, nz = S * ncz + 1;
@@ -416,7 +416,7 @@ namespace adaflo_hip
   {
     using C = LSCell<S>;
     constexpr int ND = C::ND, NQ = C::NQ, ND3 = C::ND3;
-    const long c   = blockIdx.x;
+    const long c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
     const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
     const int  cc[3] = {(int)(c % ncx), (int)((c / ncx) % ncy), (int)(c / ((long)ncx * ncy))};
     const int  nc[3] = {ncx, ncy, ncz};
@@ -478,7 +478,7 @@ namespace adaflo_hip
             ii[d]  = side ? S : 0;
             const int I = cc[0] * S + ii[0], J = cc[1] * S + ii[1], K = cc[2] * S + ii[2];
             if (!on_constrained_face(I, J, K, nx, ny, nz, a.brick.con_ls, 1, 0))
-              unsafeAtomicAdd(&a.dst[I + (long)nx * (J + (long)ny * K)], r);
+              a.dst[I + (long)nx * (J + (long)ny * K)] += r; // (cells of one colour share no node)
           }
         __syncthreads();
       }
@@ -544,8 +544,16 @@ namespace adaflo_hip
   {
     constexpr int NT = S >= 3 ? 256 : 64;
     constexpr int NQ3 = 8 * S * S * S, ND3 = (S + 1) * (S + 1) * (S + 1);
-    const dim3    grid((unsigned)a.n_cells, (unsigned)ncomp_blocks), block(NT);
+    const dim3    block(NT);
     hipError_t    err = hipSuccess;
+    // one launch per colour of the cells (no atomics in the scatter, fe_kernels.hpp)
+    for (int colour = 0; colour < 8 && err == hipSuccess; ++colour)
+    {
+    const long n_colour = n_cells_of_colour(a.brick.ncell, colour);
+    if (n_colour == 0)
+      continue;
+    a.brick.colour = colour;
+    const dim3 grid((unsigned)n_colour, (unsigned)ncomp_blocks);
     if (kind == 0)
       {
         const size_t lds = sizeof(double) * ls_lds_doubles<S, NT>(0);
@@ -565,7 +573,7 @@ namespace adaflo_hip
     else if (kind == 3)
       {
         const size_t lds = sizeof(double) * (LSCell<S>::TABP + ND3 + 4 * S * S);
-        hipLaunchKernelGGL((ls_advect_boundary_kernel<S, 64>), dim3((unsigned)a.n_cells), dim3(64), lds, ctx->stream, a);
+        hipLaunchKernelGGL((ls_advect_boundary_kernel<S, 64>), dim3((unsigned)n_colour), dim3(64), lds, ctx->stream, a);
       }
     else
       {
@@ -596,6 +604,8 @@ namespace adaflo_hip
           }
 #undef ADV
       }
+    }
+    a.brick.colour = -1;
     if (err == hipSuccess)
       err = hipGetLastError();
     return err == hipSuccess ? 0 : ADAFLO_EHIP;

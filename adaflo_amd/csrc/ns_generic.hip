@@ -86,7 +86,7 @@ namespace adaflo_hip
     for (int o = tid; o < L::TAB; o += NT)
       lds[o] = a.tab[o];
 
-    const long c   = xcd_remap(blockIdx.x, a.n_cells);
+    const long c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
     const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
     const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
     const int  nux = K * ncx + 1, nuy = K * ncy + 1, nuz = K * ncz + 1;
@@ -334,16 +334,22 @@ namespace adaflo_hip
   template <int K, int NT>
   static int launch_k(adaflo_ctx *ctx, const int op, const NSArgs &args)
   {
-    const dim3 grid((unsigned)args.n_cells), block(NT);
+    const dim3   block(NT);
     const size_t lds = sizeof(double) * ns_lds_doubles<K, NT>(op == OP_RESIDUAL);
     hipError_t   err = hipSuccess;
+    NSArgs       a   = args;
+    // one launch per colour of the cells (no atomics in the scatter, fe_kernels.hpp)
 #define LAUNCH(OPV)                                                                              \
   {                                                                                              \
     if (lds > 64 * 1024)                                                                         \
       err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_cell_kernel<K, OPV, NT>),     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-    if (err == hipSuccess)                                                                       \
-      hipLaunchKernelGGL((ns_cell_kernel<K, OPV, NT>), grid, block, lds, ctx->stream, args);     \
+    for (int colour = 0; colour < 8 && err == hipSuccess; ++colour)                              \
+      if (const long nc = n_cells_of_colour(a.brick.ncell, colour))                              \
+        {                                                                                        \
+          a.brick.colour = colour;                                                               \
+          hipLaunchKernelGGL((ns_cell_kernel<K, OPV, NT>), dim3((unsigned)nc), block, lds, ctx->stream, a); \
+        }                                                                                        \
   }
     switch (op)
       {
@@ -435,7 +441,7 @@ namespace adaflo_hip
     for (int o = tid; o < ntab; o += NT)
       lds[o] = a.tab[o];
 
-    const long c   = xcd_remap(blockIdx.x, a.n_cells);
+    const long c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
     const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
     const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
     const int  nux = K * ncx + 1, nuy = K * ncy + 1, nuz = K * ncz + 1;
@@ -536,7 +542,8 @@ namespace adaflo_hip
   template <int K, int NT>
   static int launch_sc(adaflo_ctx *ctx, const ScalarArgs &args)
   {
-    const dim3 grid((unsigned)args.n_cells), block(NT);
+    const dim3 block(NT);
+    ScalarArgs a = args;
     const bool qu = args.mode == SC_DIVERGENCE || args.mode == SC_DIVERGENCE_VISC ||
                     args.mode == SC_POISSON_VARIABLE || args.mode == SC_CONVDIFF;
     hipError_t err = hipSuccess;
@@ -546,12 +553,22 @@ namespace adaflo_hip
         if (lds > 64 * 1024)
           err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_scalar_kernel<K, true, NT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((ns_scalar_kernel<K, true, NT>), grid, block, lds, ctx->stream, args);
+        for (int colour = 0; colour < 8 && err == hipSuccess; ++colour) // (no atomics in the scatter, fe_kernels.hpp)
+          if (const long nc = n_cells_of_colour(a.brick.ncell, colour))
+            {
+              a.brick.colour = colour;
+              hipLaunchKernelGGL((ns_scalar_kernel<K, true, NT>), dim3((unsigned)nc), block, lds, ctx->stream, a);
+            }
       }
     else
       {
         const size_t lds = sizeof(double) * sc_lds_doubles<K, false, NT>();
-        hipLaunchKernelGGL((ns_scalar_kernel<K, false, NT>), grid, block, lds, ctx->stream, args);
+        for (int colour = 0; colour < 8; ++colour)
+          if (const long nc = n_cells_of_colour(a.brick.ncell, colour))
+            {
+              a.brick.colour = colour;
+              hipLaunchKernelGGL((ns_scalar_kernel<K, false, NT>), dim3((unsigned)nc), block, lds, ctx->stream, a);
+            }
       }
     if (err == hipSuccess)
       err = hipGetLastError();

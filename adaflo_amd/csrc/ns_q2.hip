@@ -161,7 +161,6 @@ namespace adaflo_hip
 #define Q2_RING 9
 #endif
     constexpr int RING      = Q2_RING;        // state pieces per wave in the LDS ring (54 % RING == 0)
-    constexpr int AHEAD     = (RING - 1) & ~1; // pieces issued ahead of the consumer (even)
     constexpr int PIECE     = 96;             // doubles per piece: 48 lanes x 16 B
     constexpr int L_RING    = 0;
     // node planes in LDS: rows padded to a multiple of 16 B so that one 16-B-per-lane LDS-DMA
