@@ -18,8 +18,11 @@
 // partial sums in slabs that a small second kernel adds (no atomics, bitwise reproducible).
 // The kernel is register-light, so occupancy (not a DMA ring) hides the latency of the
 // quadrature-point state stream, which is laid out [tile][layer][12][256 lanes][2 doubles].
+#include <type_traits>
+
 #include "basis.hpp"
 #include "kernels.hpp"
+#include "lds_dma.hpp"
 
 namespace adaflo_hip
 {
@@ -1044,7 +1047,7 @@ namespace adaflo_hip
     struct StencilArgs
     {
       int           nnx, nny, nnz, LZ, n_chunks, blocks_per_plane;
-      long          plane, comp_stride;
+      long          plane, comp_stride, flat;               // flat = bands of rows x nnx (see the kernel)
       double        m_off[3], m_ctr[3], k_off[3], k_ctr[3]; // h/6, h/3, -1/h, 1/h per direction
       double        c_mass, c_lap, con_sign;
       uint32_t      con;
@@ -1054,175 +1057,170 @@ namespace adaflo_hip
       int           plain;       // right-hand side form: src read plainly, dst += result, constrained rows skipped
     };
 
-    // Workgroup = 64 x 8 nodes of a plane (4 waves, two rows per thread), marching LZ planes in z.  A
-    // plane of src is staged through LDS with its one-node halo (66 x 10 values, 1.29 global loads per
-    // node) and the nine in-plane neighbours come from LDS: a probe kernel with the same marching
-    // pattern moves 7.5 / 5.8 / 2.9 TB/s with 1 / 3 / 9 global loads per node
-    // (scripts/dev/march_copy.hip) -- the texture path, not HBM, bounded the first version, which
-    // loaded all nine neighbours from global memory (33.9 M nodes: 0.215 ms; one row per thread
-    // 0.182 ms; two rows 0.158 ms; four rows 0.188 ms).
-    constexpr int STX = 64, STW = 4, STR = 2, STY = STW * STR; // 4 waves x STR rows per thread
-    constexpr int SHX = STX + 2, SHY = STY + 2, SHN = SHX * SHY, SLD = (SHN + 255) / 256;
+    // No LDS staging, no barrier: a lane owns FSR vertically adjacent nodes of a plane and marches in
+    // z.  With  n = lo + hi (number of neighbours in the mesh), S(u) = [lo'] u_- + [hi'] u_+  (a
+    // neighbour on a constrained face, or outside the mesh, does not count) the 1D rows are
+    //   M u = h/6 (2 n u_0 + S(u)),   K u = 1/h (n u_0 - S(u)),
+    // so that y costs 5 operations per node for both (t1 = 2 n u_0 + S, t2 = n u_0 - S), z 8 (the scales
+    // h/6, 1/h of all directions are folded into six plane-uniform coefficients) and x 5:
+    //   P = hx/6 [c_mass My Mz + c_lap (Ky Mz + My Kz)] u,   Q = c_lap / hx My Mz u,
+    //   dst = n_x (2 P + Q) + [lo'] (P - Q)_west + [hi'] (P - Q)_east,
+    // i.e. ONE value per node crosses lanes (ds_bpermute, the LDS crossbar is idle otherwise) --
+    // 18 f64 operations per node instead of the 45 of the version that summed the nine in-plane
+    // neighbours per plane out of an LDS tile (0.154 -> see DESIGN.md 4.4 for the measurements: that
+    // version was bound by its own instruction stream, with and without its loads).  The lanes of a
+    // wave are 62 consecutive positions of the FLATTENED band space [band of FSR rows][x] plus one
+    // halo lane on either side: neighbours in x are neighbours in the flat index, the row ends need no
+    // care (their weights are zero), and no lane idles on meshes with 2^m + 1 nodes per row.  A lane
+    // reads FSR + 2 values per plane (one plane ahead), 8-byte coalesced.
+    constexpr int FSW = 62; // owned lanes of a wave
+#ifndef Q1_STENCIL_ROWS
+#define Q1_STENCIL_ROWS 3
+#endif
+    constexpr int FSR = Q1_STENCIL_ROWS;
     __global__ __launch_bounds__(256) void q1_stencil_kernel(const StencilArgs A)
     {
-      __shared__ double tile[2][SHN];
+      using lds_dma::load_now;
       const long nwg   = (long)A.blocks_per_plane * A.n_chunks;
       const long wg    = xcd_remap(blockIdx.x, nwg);
       const int  chunk = (int)(wg / A.blocks_per_plane);
-      const int  tiles_x = (A.nnx + STX - 1) / STX;
-      const int  bt = (int)(wg % A.blocks_per_plane), bx = bt % tiles_x, by = bt / tiles_x;
-      const int  tx = threadIdx.x % STX, ty = threadIdx.x / STX;
-      const int  i0 = bx * STX, j0 = by * STY;
-      const int  i_raw = i0 + tx;
-      const int  i     = min(i_raw, A.nnx - 1);
+      const int  lane  = threadIdx.x & 63;
+      const long g_raw = ((wg % A.blocks_per_plane) * 4 + (threadIdx.x >> 6)) * FSW + lane - 1;
+      const long g     = min(max(g_raw, 0L), A.flat - 1);
+      const int  band = (int)(g / A.nnx), i = (int)(g - (long)band * A.nnx);
+      const bool own  = lane >= 1 && lane <= FSW && g_raw < A.flat;
       const double *__restrict__ src_c = A.src + blockIdx.y * A.comp_stride;
       double *__restrict__       dst_c = A.dst + blockIdx.y * A.comp_stride;
 
-      // 1D rows of M and K at this node; a neighbour outside the mesh or on a constrained face
-      // contributes nothing
-      auto rows = [&](const int d, const int idx, const int n, double *m, double *k) {
+      // n, [lo'], [hi'] of a 1D row
+      auto row = [&](const int d, const int idx, const int n, double &cnt, double &wl, double &wh) {
         const bool lo = idx > 0, hi = idx < n - 1;
-        const bool clo = lo && (A.plain || !(idx - 1 == 0 && (A.con >> (2 * d) & 1)));
-        const bool chi = hi && (A.plain || !(idx + 1 == n - 1 && (A.con >> (2 * d + 1) & 1)));
-        m[0] = clo ? A.m_off[d] : 0.;
-        m[2] = chi ? A.m_off[d] : 0.;
-        m[1] = ((lo ? 1. : 0.) + (hi ? 1. : 0.)) * A.m_ctr[d];
-        k[0] = clo ? A.k_off[d] : 0.;
-        k[2] = chi ? A.k_off[d] : 0.;
-        k[1] = ((lo ? 1. : 0.) + (hi ? 1. : 0.)) * A.k_ctr[d];
+        wl  = lo && (A.plain || !(idx - 1 == 0 && (A.con >> (2 * d) & 1))) ? 1. : 0.;
+        wh  = hi && (A.plain || !(idx + 1 == n - 1 && (A.con >> (2 * d + 1) & 1))) ? 1. : 0.;
+        cnt = (lo ? 1. : 0.) + (hi ? 1. : 0.);
       };
-      double mx[3], kx[3], my[STR][3], ky[STR][3];
-      bool   active[STR], con_xy[STR];
-      long   p[STR];
-      int    lc[STR]; // this thread's nodes in the halo tile
-      rows(0, i, A.nnx, mx, kx);
+      double nx, wxl, wxh, ny[FSR], wyl[FSR], wyh[FSR];
+      bool   active[FSR], con_xy[FSR];
+      unsigned off[FSR + 2]; // byte offsets of rows j-1 .. j+FSR of this lane's column in a plane (clamped to the mesh)
+      row(0, i, A.nnx, nx, wxl, wxh);
 #pragma unroll
-      for (int r = 0; r < STR; ++r)
+      for (int r = 0; r < FSR; ++r)
         {
-          const int j_raw = j0 + ty + STW * r, j = min(j_raw, A.nny - 1);
-          rows(1, j, A.nny, my[r], ky[r]);
-          active[r] = i_raw < A.nnx && j_raw < A.nny;
-          p[r]      = (long)j * A.nnx + i;
-          lc[r]     = (ty + STW * r + 1) * SHX + tx + 1;
+          const int j_raw = band * FSR + r, j = min(j_raw, A.nny - 1);
+          row(1, j, A.nny, ny[r], wyl[r], wyh[r]);
+          active[r] = own && j_raw < A.nny;
           con_xy[r] = (i == 0 && (A.con >> 0 & 1)) || (i == A.nnx - 1 && (A.con >> 1 & 1)) ||
                       (j == 0 && (A.con >> 2 & 1)) || (j == A.nny - 1 && (A.con >> 3 & 1));
         }
-      // (rows of constrained nodes are overwritten below, so their own weights do not matter)
+#pragma unroll
+      for (int r = 0; r < FSR + 2; ++r)
+        off[r] = (unsigned)(min(max(band * FSR + r - 1, 0), A.nny - 1) * A.nnx + i) * 8u;
 
-      // the halo-tile entries this thread stages per plane; out-of-mesh entries are zero
-      long g_off[SLD];
-      int  l_off[SLD];
-      bool g_ok[SLD];
-#pragma unroll
-      for (int r = 0; r < SLD; ++r)
-        {
-          const int e = threadIdx.x + 256 * r;
-          const int hx = e % SHX, hy = e / SHX, gi = i0 - 1 + hx, gj = j0 - 1 + hy;
-          l_off[r] = e < SHN ? e : -1;
-          g_ok[r]  = e < SHN && gi >= 0 && gi < A.nnx && gj >= 0 && gj < A.nny;
-          g_off[r] = g_ok[r] ? (long)gj * A.nnx + gi : 0;
-        }
-      auto stage = [&](const int k, double *buf) {
-        const double *s = src_c + (long)k * A.plane;
-        double        v[SLD];
-#pragma unroll
-        for (int r = 0; r < SLD; ++r)
-          v[r] = g_ok[r] ? s[g_off[r]] : 0.;
-#pragma unroll
-        for (int r = 0; r < SLD; ++r)
-          if (l_off[r] >= 0)
-            buf[l_off[r]] = v[r];
-      };
-      auto plane_sums = [&](const double *buf, const int r, double &Ap, double &Bp, double &centre) {
-        double a[3], b[3];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-          {
-            const double *q  = buf + lc[r] + (dy - 1) * SHX;
-            const double  v0 = q[-1], v1 = q[0], v2 = q[1];
-            a[dy] = mx[0] * v0 + mx[1] * v1 + mx[2] * v2;
-            b[dy] = kx[0] * v0 + kx[1] * v1 + kx[2] * v2;
-            if (dy == 1)
-              centre = v1;
-          }
-        Ap = my[r][0] * a[0] + my[r][1] * a[1] + my[r][2] * a[2];
-        Bp = my[r][0] * b[0] + my[r][1] * b[1] + my[r][2] * b[2] + ky[r][0] * a[0] + ky[r][1] * a[1] + ky[r][2] * a[2];
-      };
+      // plane-uniform coefficients of  P' = a_off (t1_- + t1_+) + n_z a_ctr t1_0 + b_off (t2_- + t2_+) + n_z b_ctr t2_0
+      // and  Q' = q_off (t1_- + t1_+) + n_z q_ctr t1_0  (planes that do not count are zero in t1, t2)
+      const double sx = A.m_off[0], sy = A.m_off[1], mz = A.m_off[2], kz = A.k_ctr[2]; // h/6, h/6, h/6, 1/h
+      const double a_off = sx * sy * (A.c_mass * mz - A.c_lap * kz), a_ctr = sx * sy * (2. * A.c_mass * mz + A.c_lap * kz); // (n_z = 1)
+      const double b_off = sx * A.c_lap * A.k_ctr[1] * mz, b_ctr = 2. * b_off;
+      const double q_off = A.c_lap * A.k_ctr[0] * sy * mz, q_ctr = 2. * q_off;
 
       const int  k0 = chunk * A.LZ, k1 = min(k0 + A.LZ, A.nnz);
+      const int  kb = max(k0 - 1, 0), ke = min(k1, A.nnz - 1); // planes read
       const bool conz_lo = (A.con >> 4 & 1) && !A.plain, conz_hi = (A.con >> 5 & 1) && !A.plain; // (neighbour planes)
-      double     Am[STR], Bm[STR], A0[STR], B0[STR], Ap[STR], Bp[STR], c0[STR], cp[STR], cm, src_dot_dst = 0.;
+      // y-sums of three planes and the values of four (the one being finished, the one being summed
+      // and two on their way), rotating: the loop is unrolled twelve times so that nothing is copied
+      // between registers (a copy of a value just loaded would wait for it), and the read two planes
+      // ahead is unconditional (a load behind a branch makes the compiler assume at the join that it
+      // may be the youngest one, i.e. wait for everything)
+      double t1[3][FSR], t2[3][FSR], u[4][FSR + 2], src_dot_dst = 0.;
 #pragma unroll
-      for (int r = 0; r < STR; ++r)
-        Am[r] = Bm[r] = Ap[r] = Bp[r] = cp[r] = 0.;
-      int cur = 0;
-      if (k0 > 0) // (block-uniform)
+      for (int r = 0; r < FSR; ++r)
+        t1[0][r] = t2[0][r] = t1[1][r] = t2[1][r] = t1[2][r] = t2[2][r] = 0.;
+#pragma unroll
+      for (int r = 0; r < FSR + 2; ++r)
+        u[3][r] = 0.;
+      auto read_plane = [&](const int k, double *v) {
+        const char *s = reinterpret_cast<const char *>(src_c + (long)k * A.plane);
+#pragma unroll
+        for (int r = 0; r < FSR + 2; ++r)
+          v[r] = *reinterpret_cast<const double *>(s + off[r]);
+      };
+      read_plane(kb, u[0]);
+      read_plane(min(kb + 1, ke), u[1]);
+      // plane q is summed in y (its values are in u[PH % 4]), plane k = q - 1 is finished
+      auto step = [&](auto phase, const int q) {
+        constexpr int PH = decltype(phase)::value, nw = PH % 3, c3 = (PH + 2) % 3, od = (PH + 1) % 3;
+        constexpr int un = PH % 4, uc = (PH + 3) % 4;
+        read_plane(min(q + 2, ke), u[(PH + 2) % 4]);
+        if (q > ke || (q == 0 && conz_lo) || (q == A.nnz - 1 && conz_hi)) // (block-uniform)
+          {
+#pragma unroll
+            for (int r = 0; r < FSR; ++r)
+              {
+                t1[nw][r] = 0.; // (same order of the assignments in both arms: the compiler merges their
+                t2[nw][r] = 0.; //  tails, and with different orders the merged store gets a run-time index)
+              }
+          }
+        else
+          {
+#pragma unroll
+            for (int r = 0; r < FSR; ++r)
+              {
+                const double c = ny[r] * u[un][r + 1], sum = wyl[r] * u[un][r] + wyh[r] * u[un][r + 2];
+                t1[nw][r] = 2. * c + sum;
+                t2[nw][r] = c - sum;
+              }
+          }
+        const int k = q - 1;
+        if (k >= k0)
+          {
+            const bool   edge = k == 0 || k == A.nnz - 1; // one neighbour plane (n_z = 1)
+            const double a_c = edge ? a_ctr : 2. * a_ctr, b_c = edge ? b_ctr : 2. * b_ctr, q_c = edge ? q_ctr : 2. * q_ctr;
+            const bool   conz = (k == 0 && (A.con >> 4 & 1)) || (k == A.nnz - 1 && (A.con >> 5 & 1));
+            char        *d    = reinterpret_cast<char *>(dst_c + (long)k * A.plane);
+#pragma unroll
+            for (int r = 0; r < FSR; ++r)
+              {
+                const double s1 = t1[od][r] + t1[nw][r], s2 = t2[od][r] + t2[nw][r];
+                const double P = (a_off * s1 + a_c * t1[c3][r]) + (b_off * s2 + b_c * t2[c3][r]);
+                const double Q = q_off * s1 + q_c * t1[c3][r];
+                const double T = P - Q;
+                const double Tw = __shfl_up(T, 1, 64), Te = __shfl_down(T, 1, 64);
+                double       v  = nx * (2. * P + Q) + (wxl * Tw + wxh * Te);
+                const double c0 = u[uc][r + 1];
+                double      *dp = reinterpret_cast<double *>(d + off[r + 1]);
+                if (active[r] && A.plain)
+                  {
+                    if (!(con_xy[r] || conz))
+                      *dp += v;
+                  }
+                else if (active[r])
+                  {
+                    if (con_xy[r] || conz)
+                      v = (A.diag ? load_now(A.diag + (long)k * A.plane + off[r + 1] / 8) : A.con_sign) * c0;
+                    __builtin_nontemporal_store(v, dp);
+                    src_dot_dst += c0 * v;
+                  }
+              }
+          }
+      };
+      for (int q = kb; q <= k1; q += 12)
         {
-          stage(k0 - 1, tile[cur]);
-          __syncthreads();
-          if (!(k0 - 1 == 0 && conz_lo))
-#pragma unroll
-            for (int r = 0; r < STR; ++r)
-              plane_sums(tile[cur], r, Am[r], Bm[r], cm);
-          cur ^= 1;
-        }
-      stage(k0, tile[cur]);
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < STR; ++r)
-        {
-          plane_sums(tile[cur], r, A0[r], B0[r], c0[r]);
-          if (k0 == 0 && conz_lo)
-            A0[r] = B0[r] = 0.;
-        }
-      cur ^= 1;
-      for (int k = k0; k < k1; ++k)
-        {
-          const bool hi = k < A.nnz - 1, lo = k > 0;
-          if (hi)
-            {
-              stage(k + 1, tile[cur]);
-              __syncthreads();
-#pragma unroll
-              for (int r = 0; r < STR; ++r)
-                {
-                  plane_sums(tile[cur], r, Ap[r], Bp[r], cp[r]);
-                  if (k + 1 == A.nnz - 1 && conz_hi)
-                    Ap[r] = Bp[r] = 0.;
-                }
-              cur ^= 1;
-            }
-          else
-#pragma unroll
-            for (int r = 0; r < STR; ++r)
-              Ap[r] = Bp[r] = 0.;
-          const double nz  = (lo ? 1. : 0.) + (hi ? 1. : 0.);
-          const double mzc = nz * A.m_ctr[2], kzc = nz * A.k_ctr[2];
-          const double mzl = lo ? A.m_off[2] : 0., mzh = hi ? A.m_off[2] : 0.;
-          const double kzl = lo ? A.k_off[2] : 0., kzh = hi ? A.k_off[2] : 0.;
-          const bool   conz = (k == 0 && (A.con >> 4 & 1)) || (k == A.nnz - 1 && (A.con >> 5 & 1));
-#pragma unroll
-          for (int r = 0; r < STR; ++r)
-            {
-              double v = (A.c_mass * mzl + A.c_lap * kzl) * Am[r] + A.c_lap * mzl * Bm[r];
-              v += (A.c_mass * mzc + A.c_lap * kzc) * A0[r] + A.c_lap * mzc * B0[r];
-              v += (A.c_mass * mzh + A.c_lap * kzh) * Ap[r] + A.c_lap * mzh * Bp[r];
-              if (active[r] && A.plain)
-                {
-                  const long idx = (long)k * A.plane + p[r];
-                  if (!(con_xy[r] || conz))
-                    dst_c[idx] += v;
-                }
-              else if (active[r])
-                {
-                  const long idx = (long)k * A.plane + p[r];
-                  if (con_xy[r] || conz)
-                    v = (A.diag ? A.diag[idx] : A.con_sign) * c0[r];
-                  __builtin_nontemporal_store(v, dst_c + idx);
-                  src_dot_dst += c0[r] * v;
-                }
-              Am[r] = A0[r], Bm[r] = B0[r], A0[r] = Ap[r], B0[r] = Bp[r], c0[r] = cp[r];
-            }
+          step(std::integral_constant<int, 0>(), q);
+#define Q1_STENCIL_STEP(ph)                                                                                           \
+  if (q + ph <= k1)                                                                                                   \
+    step(std::integral_constant<int, ph>(), q + ph);
+          Q1_STENCIL_STEP(1)
+          Q1_STENCIL_STEP(2)
+          Q1_STENCIL_STEP(3)
+          Q1_STENCIL_STEP(4)
+          Q1_STENCIL_STEP(5)
+          Q1_STENCIL_STEP(6)
+          Q1_STENCIL_STEP(7)
+          Q1_STENCIL_STEP(8)
+          Q1_STENCIL_STEP(9)
+          Q1_STENCIL_STEP(10)
+          Q1_STENCIL_STEP(11)
+#undef Q1_STENCIL_STEP
         }
       if (A.dot_partial) // p . A p of the CG iteration for free: the centre value is in a register anyway
         {
@@ -1516,10 +1514,17 @@ namespace adaflo_hip
     S.nnz = sub * ctx->desc.ncell[2] + 1;
     S.plane            = (long)S.nnx * S.nny;
     S.comp_stride      = S.plane * S.nnz;
-    S.blocks_per_plane = ((S.nnx + STX - 1) / STX) * ((S.nny + STY - 1) / STY); // 64 x 4 node tiles
-    int lz = 32;
-    while (lz > 4 && (long)S.blocks_per_plane * ((S.nnz + lz - 1) / lz) < 2048)
-      lz /= 2;
+    S.flat             = (long)((S.nny + FSR - 1) / FSR) * S.nnx;
+    S.blocks_per_plane = (int)(((S.flat + FSW - 1) / FSW + 3) / 4); // four independent waves per workgroup
+    // z-chunk: the longest of 12 / 8 / 6 / 4 planes that still gives two rounds of the ~768 resident
+    // workgroups (measured, scripts/dev/stencil_probe.hip: 257 x 257 x 513 nodes 0.114 / 0.110 / 0.103 /
+    // 0.099 / 0.102 / 0.105 ms for 4 / 6 / 8 / 12 / 16 / 32 planes; 161 x 161 x 321: 0.026 ms at 6..8)
+    int lz = 4;
+    for (const int c : {6, 8, 12})
+      if ((long)S.blocks_per_plane * ((S.nnz + c - 1) / c) * n_blocks >= 1536)
+        lz = c;
+    if (const char *e = getenv("ADAFLO_STENCIL_LZ")) // (tuning knob of scripts/bench_ops.py)
+      lz = std::max(1, atoi(e));
     S.LZ       = lz;
     S.n_chunks = (S.nnz + lz - 1) / lz;
     for (int d = 0; d < 3; ++d)

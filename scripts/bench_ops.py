@@ -126,7 +126,7 @@ def ns_host_vector_case(n):
                       "pcie_GB/s": round(16 * (nu + npp) / t / 1e9, 1)}), flush=True)
 
 
-def ls_case(s, ncell):
+def ls_case(s, ncell, only=None):
     mesh = adaflo_amd.BrickMesh(list(ncell), [0, 0, 0], [1, 1, 2])
     ops = lso.LevelSetOperators(mesh, s)
     ops.set_parameters(1.5 * max(mesh.h) / s, 0.02, 75.0, -100.0, 25.0, 1.5)
@@ -161,6 +161,9 @@ def ls_case(s, ncell):
                  ("ls_reinit_rhs_first", lambda: rei_v.local_reinitialize_rhs(rhs, phi, nrm, False, True), 6 * nodal + 24 * nq),
                  ("ls_reinit_rhs", lambda: rei_v.local_reinitialize_rhs(rhs, phi, nrm, False, False), 3 * nodal + 24 * nq),
                  ("ls_reinit_rhs_diffuse", lambda: rei_v.local_reinitialize_rhs(rhs, phi, nrm, True, False), 3 * nodal)]
+    if only is not None:
+        cases = [c for c in cases if c[0] in only]
+        rhs_cases = [c for c in rhs_cases if c[0] in only]
     for variant in (1, 0):
         ops_v.set_kernel_variant(variant)
         for name, fn, bytes_per_cell in rhs_cases:
@@ -217,6 +220,11 @@ if __name__ == "__main__":
         for v in (1, 2, 0):
             ns_divergence_case((64, 64, 128), v)
             ns_divergence_case((128, 128, 128), v)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "stencil":
+        ls_case(4, (40, 40, 80), only=("ls_normal_vmult", "ls_curvature_vmult"))
+        ls_case(4, (64, 64, 128), only=("ls_normal_vmult", "ls_curvature_vmult"))
+        krylov_case(4, (40, 40, 80))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ls":
         ls_case(4, (64, 64, 128))
