@@ -7,12 +7,23 @@
 //   (q_I, d_x u_x) = Cx (x) My (x) Mz u_x,   C = int N^p_I (N^u_j)' ,   M = int N^p_I N^u_j
 // with 5-wide 1D rows (pressure node I couples to the velocity nodes 2I-2 .. 2I+2; one half of the
 // row is missing at the domain boundary).  Pure gather: no seams, no atomics, bitwise reproducible.
-// A thread owns one pressure node column (I, J) of a z-chunk and marches through the velocity planes,
-// which are staged through LDS once per workgroup (zeroing constrained entries, :935-939) with even
-// and odd x-nodes split so that the 25 x 3 reads per plane are stride-1 across the lanes.  Per plane
-// it forms  A = Cx My u_x + Mx Cy u_y  and  B = Mx My u_z  and keeps the last five planes in
-// registers: div(K) = sum_t Mz[t] A[2K-2+t] + Cz[t] B[2K-2+t].
-// HBM traffic: the velocity once (+ halo planes per chunk and tile, mostly L2 hits), dst_p read + write.
+// A lane owns one pressure node column (I, J) of a z-chunk and marches through the velocity planes
+// WITHOUT staging them in LDS: it reads the velocity nodes 2I, 2I+1 (48 contiguous bytes) of the five
+// rows 2J-2 .. 2J+2, sums them in y, forms its own share of the x-sums and the shares its two columns
+// have in the rows of the pressure nodes I-1 (node 2I as the last node of their right cell) and I+1
+// (both nodes in their left cell), which travel one lane to the left / right (ds_bpermute; the lanes of
+// a wave are 62 consecutive nodes of the flattened (J, I) index plus a halo lane on either side, so the
+// row ends need no care beyond the masks "has a left / right cell").  Per plane that is
+//   A = Cx My u_x + Mx Cy u_y,   B = Mx My u_z,
+// and every plane adds  Mz[t] A + Cz[t] B  to the two or three pressure planes it couples to; three
+// accumulators rotate in registers (the loop is unrolled over six planes).  Constrained velocity
+// entries (:935-939) only occur on node 2I of the first / last pressure column, on the rows 0 and nvy - 1 and on the first / last plane: they are masked by
+// per-lane factors.
+// History: the first version staged every plane through LDS and gathered 75 values per
+// node and plane from it -- bound by its own LDS / VALU instruction stream (0.19 ms at 128^3), not by
+// memory.  HBM traffic: the velocity once (+ halo planes per chunk, mostly L2 hits), dst_p read + write.
+#include <type_traits>
+
 #include "basis.hpp"
 #include "kernels.hpp"
 
@@ -20,13 +31,12 @@ namespace adaflo_hip
 {
   namespace
   {
-    constexpr int DPX = 32, DPY = 8;     // pressure nodes per tile (32 x 4 tiles measured 7 % slower)
-    constexpr int DVX = 2 * DPX + 3;     // velocity nodes of a tile row
-    constexpr int DEW = DPX + 2;         // even x-nodes per row (then DPX + 1 odd ones)
+    constexpr int DSW = 62; // owned lanes of a wave
 
     struct DivArgs
     {
-      int           npx, npy, npz, nvx, nvy, nvz, tiles_x, tiles_y, LZ, n_chunks;
+      int           npx, npy, npz, nvx, nvy, nvz, LZ, n_chunks, blocks_per_chunk;
+      long          flat;                // npx * npy
       double        m[3][2][3], c[2][3]; // per direction h_d int N^p_a N^u_b;  int N^p_a (N^u_b)'
       double        weight;
       uint32_t      con_u, con_p;
@@ -52,138 +62,146 @@ namespace adaflo_hip
       C[4] = hi ? c[0][2] : 0.;
     }
 
-    __global__ __launch_bounds__(DPX *DPY) void q2q1_divergence_kernel(const DivArgs A)
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    typedef dbl2 dbl2_a8 __attribute__((aligned(8)));
+
+    __global__ __launch_bounds__(256) void q2q1_divergence_kernel(const DivArgs A)
     {
-      constexpr int DNT = DPX * DPY, DVY = 2 * DPY + 3; // threads, velocity rows of a tile plane
-      constexpr int DPLANE = 3 * DVY * DVX;             // doubles per staged plane
-      constexpr int DLD = (DPLANE + DNT - 1) / DNT;     // staging loads per thread
-      __shared__ double lds[2][DPLANE];
-      const int  tid = threadIdx.x, tx = tid % DPX, ty = tid / DPX;
-      const long nwg = (long)A.tiles_x * A.tiles_y * A.n_chunks;
-      const long wg  = xcd_remap(blockIdx.x, nwg);
-      const int  chunk = (int)(wg % A.n_chunks), bt = (int)(wg / A.n_chunks);
-      const int  bx = bt % A.tiles_x, by = bt / A.tiles_x;
-      const int  I0 = bx * DPX, J0 = by * DPY;
-      const int  I = min(I0 + tx, A.npx - 1), J = min(J0 + ty, A.npy - 1);
-      const bool active = I0 + tx < A.npx && J0 + ty < A.npy;
+      const long nwg   = (long)A.blocks_per_chunk * A.n_chunks;
+      const long wg    = xcd_remap(blockIdx.x, nwg);
+      const int  chunk = (int)(wg / A.blocks_per_chunk);
+      const int  lane  = threadIdx.x & 63;
+      const long g_raw = ((wg % A.blocks_per_chunk) * 4 + (threadIdx.x >> 6)) * DSW + lane - 1;
+      const long g     = min(max(g_raw, 0L), A.flat - 1);
+      const int  J = (int)(g / A.npx), I = (int)(g - (long)J * A.npx);
+      const bool own = lane >= 1 && lane <= DSW && g_raw < A.flat;
+      const bool xlo = I > 0, xhi = I < A.npx - 1;
       const bool con_xy = (I == 0 && (A.con_p >> 0 & 1)) || (I == A.npx - 1 && (A.con_p >> 1 & 1)) ||
                           (J == 0 && (A.con_p >> 2 & 1)) || (J == A.npy - 1 && (A.con_p >> 3 & 1));
-      double Mx[5], Cx[5], My[5], Cy[5];
-      div_rows(A.m[0], A.c, I, A.npx, Mx, Cx);
-      div_rows(A.m[1], A.c, J, A.npy, My, Cy);
 
-      // staging pattern of this thread: entry e = (jl, il, comp) of the velocity tile plane
-      int  l_off[DLD];
-      long g_off[DLD];
-      unsigned ok = 0, zero_lo = 0, zero_hi = 0; // in-plane validity; entries constrained on the z faces only
+      // y: the five rows 2J-2 .. 2J+2 (clamped to the mesh, their weights are zero beyond it), with the
+      // constraint masks of the y faces per component (rows 0 and nvy - 1): My for u_x, u_z, Cy for u_y
+      double wy[3][5];
+      {
+        double My[5], Cy[5];
+        div_rows(A.m[1], A.c, J, A.npy, My, Cy);
 #pragma unroll
-      for (int r = 0; r < DLD; ++r)
+        for (int comp = 0; comp < 3; ++comp)
+#pragma unroll
+          for (int r = 0; r < 5; ++r)
+            {
+              const int  row = 2 * J - 2 + r;
+              const bool con = !A.plain && ((row == 0 && (A.con_u >> (6 + comp) & 1)) || (row == A.nvy - 1 && (A.con_u >> (9 + comp) & 1)));
+              wy[comp][r]    = con ? 0. : (comp == 1 ? Cy[r] : My[r]);
+            }
+      }
+      // x: the lane reads two velocity nodes F, S = 2I, 2I+1 -- the last pressure column 2I-1, 2I
+      // instead (node 2I+1 would be the first node of the next row, or beyond the vector); weights of
+      // F and S in this node's own row (o), in the row of the node to the left (l); to the right the
+      // weights are those of a left cell for everybody.  fx: constraint masks of the x faces (node 2I).
+      const bool   last = !xhi;
+      const double (&mx)[2][3] = A.m[0];
+      const double o_m0 = (xlo ? mx[1][2] : 0.) + (xhi ? mx[0][0] : 0.), o_c0 = (xlo ? A.c[1][2] : 0.) + (xhi ? A.c[0][0] : 0.);
+      const double oMF = last ? 0. : o_m0, oMS = last ? o_m0 : mx[0][1], oCF = last ? 0. : o_c0, oCS = last ? o_c0 : A.c[0][1];
+      const double lMF = last ? 0. : mx[0][2], lMS = last ? mx[0][2] : 0., lCF = last ? 0. : A.c[0][2], lCS = last ? A.c[0][2] : 0.;
+      const double from_l = xlo ? 1. : 0., from_r = xhi ? 1. : 0.;
+      double       fF[3], fS[3];
+#pragma unroll
+      for (int comp = 0; comp < 3; ++comp)
         {
-          const int e = tid + DNT * r, comp = e % 3, il = (e / 3) % DVX, jl = e / (3 * DVX);
-          const int Iv = 2 * I0 - 2 + il, Jv = 2 * J0 - 2 + jl;
-          l_off[r] = e < DPLANE ? (comp * DVY + jl) * DVX + ((il & 1) ? DEW + il / 2 : il / 2) : -1;
-          bool v   = e < DPLANE && Iv >= 0 && Iv < A.nvx && Jv >= 0 && Jv < A.nvy;
-          if (v && !A.plain &&
-              ((Iv == 0 && (A.con_u >> (0 + comp) & 1)) || (Iv == A.nvx - 1 && (A.con_u >> (3 + comp) & 1)) ||
-               (Jv == 0 && (A.con_u >> (6 + comp) & 1)) || (Jv == A.nvy - 1 && (A.con_u >> (9 + comp) & 1))))
-            v = false;
-          g_off[r] = v ? ((long)Jv * A.nvx + Iv) * 3 + comp : 0;
-          if (v)
-            ok |= 1u << r;
-          if (v && !A.plain && (A.con_u >> (12 + comp) & 1))
-            zero_lo |= 1u << r;
-          if (v && !A.plain && (A.con_u >> (15 + comp) & 1))
-            zero_hi |= 1u << r;
+          const bool con = !A.plain && ((I == 0 && (A.con_u >> (0 + comp) & 1)) || (I == A.npx - 1 && (A.con_u >> (3 + comp) & 1)));
+          fF[comp]       = con && !last ? 0. : 1.;
+          fS[comp]       = con && last ? 0. : 1.;
         }
-      // planes travel global -> registers (one plane ahead) -> LDS (two buffers, one barrier per plane; a
-      // single buffer with two barriers and a two-plane look-ahead measured 30 % slower)
-      auto fetch = [&](double (&pre)[DLD], const int p) {
-        const double  *s = A.src_u + (long)p * A.nvy * A.nvx * 3;
-        const unsigned m = ok & ~(p == 0 ? zero_lo : 0u) & ~(p == A.nvz - 1 ? zero_hi : 0u);
+      unsigned off[5]; // byte offsets of node F in the five rows of a velocity plane
 #pragma unroll
-        for (int r = 0; r < DLD; ++r)
-          pre[r] = (m >> r & 1u) ? s[g_off[r]] : 0.;
-      };
-      auto commit = [&](const double (&pre)[DLD], double *buf) {
-#pragma unroll
-        for (int r = 0; r < DLD; ++r)
-          if (l_off[r] >= 0)
-            buf[l_off[r]] = pre[r];
-      };
-      // in-plane sums of the staged plane at this thread's node
-      auto plane_sums = [&](const double *buf, double &Ap, double &Bp) {
-        double a = 0., b = 0.;
-#pragma unroll
-        for (int j = 0; j < 5; ++j)
-          {
-            const double *r0 = buf + (2 * ty + j) * DVX + tx, *r1 = r0 + DVY * DVX, *r2 = r1 + DVY * DVX;
-            // nodes 2I-2 .. 2I+2 = E[tx], O[tx], E[tx+1], O[tx+1], E[tx+2]
-            const double x0 = r0[0], x1 = r0[DEW], x2 = r0[1], x3 = r0[DEW + 1], x4 = r0[2];
-            const double y0 = r1[0], y1 = r1[DEW], y2 = r1[1], y3 = r1[DEW + 1], y4 = r1[2];
-            const double z0 = r2[0], z1 = r2[DEW], z2 = r2[1], z3 = r2[DEW + 1], z4 = r2[2];
-            const double cx = Cx[0] * x0 + Cx[1] * x1 + Cx[2] * x2 + Cx[3] * x3 + Cx[4] * x4;
-            const double my = Mx[0] * y0 + Mx[1] * y1 + Mx[2] * y2 + Mx[3] * y3 + Mx[4] * y4;
-            const double mz = Mx[0] * z0 + Mx[1] * z1 + Mx[2] * z2 + Mx[3] * z3 + Mx[4] * z4;
-            a += My[j] * cx + Cy[j] * my;
-            b += My[j] * mz;
-          }
-        Ap = a;
-        Bp = b;
-      };
+      for (int r = 0; r < 5; ++r)
+        off[r] = (unsigned)(min(max(2 * J - 2 + r, 0), A.nvy - 1) * A.nvx + (last ? 2 * I - 1 : 2 * I)) * 24u;
 
       const int K0 = chunk * A.LZ, K1 = min(K0 + A.LZ, A.npz);
-      const int p0 = max(2 * K0 - 2, 0), p1 = min(2 * (K1 - 1) + 2, A.nvz - 1); // velocity planes of the chunk
-      double    Aw[5] = {0., 0., 0., 0., 0.}, Bw[5] = {0., 0., 0., 0., 0.};      // planes 2K-2 .. 2K+2 of the next K
-      int K = K0;
-      // plane p is window slot p - (2K - 2); slots fill in order and the window moves by two planes per K
-      auto process = [&](const int p) {
-        double a, b;
-        plane_sums(lds[p & 1], a, b);
-        const int t = p - (2 * K - 2);
-        if (t == 2)
-          Aw[2] = a, Bw[2] = b;
-        else if (t == 3)
-          Aw[3] = a, Bw[3] = b;
-        else if (t == 4)
-          Aw[4] = a, Bw[4] = b;
-        else if (t == 0)
-          Aw[0] = a, Bw[0] = b;
-        else
-          Aw[1] = a, Bw[1] = b;
-        // (the top pressure layer has no planes above it: it is due together with the layer below)
-        while (K < K1 && (p - (2 * K - 2) == 4 || p == p1))
+      const int pbase = 2 * K0 - 2, t0 = K0 > 0 ? 0 : 2, t1 = min(2 * (K1 - 1) + 2, A.nvz - 1) - pbase; // planes pbase + t
+      const double (&mz)[2][3] = A.m[2];
+      double acc[3] = {0., 0., 0.};
+      // dst_p is read-modify-write: its old value is requested together with the velocity plane whose
+      // sums complete the pressure layer (a load right before the store would add one memory latency
+      // to every second plane)
+      auto writes = [&](const int K) {
+        const bool conz = (K == 0 && (A.con_p >> 4 & 1)) || (K == A.npz - 1 && (A.con_p >> 5 & 1));
+        return K >= K0 && K < K1 && own && !(con_xy || conz);
+      };
+      // plane pbase + t, t = 6 n + PH: pressure planes K0 - 1 + t / 2 (+- 1) in the slots (t / 2) % 3 = PH / 2 (+- 1)
+      auto step = [&](auto phase, const int t) {
+        constexpr int PH = decltype(phase)::value, sc = (PH / 2) % 3, sm = (PH / 2 + 2) % 3, sp = (PH / 2 + 1) % 3;
+        const int     p = pbase + t;
+        const int     K = K0 - 1 + t / 2; // the pressure plane of an even velocity plane
+        const char   *s = reinterpret_cast<const char *>(A.src_u + (long)p * A.nvy * A.nvx * 3);
+        double       *d = A.dst_p + (long)(K - 1) * A.flat + g;
+        const bool    wr = PH % 2 == 0 && writes(K - 1);
+        double        old = 0.;
+        if (wr)
+          old = *d;
+        dbl2 v[5][3];
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+          for (int w = 0; w < 3; ++w)
+            v[r][w] = *reinterpret_cast<const dbl2_a8 *>(s + off[r] + 16 * w);
+        // (F.x F.y) (F.z S.x) (S.y S.z): y-sums of  My u_x,  Cy u_y,  My u_z  in the columns F and S
+        double pF[3], pS[3];
+#pragma unroll
+        for (int comp = 0; comp < 3; ++comp)
           {
+            const double *w5 = wy[comp];
+            auto          f = [&](const int r) { return comp == 0 ? v[r][0].x : comp == 1 ? v[r][0].y : v[r][1].x; };
+            auto          g2 = [&](const int r) { return comp == 0 ? v[r][1].y : comp == 1 ? v[r][2].x : v[r][2].y; };
+            pF[comp] = fF[comp] * (((w5[0] * f(0) + w5[1] * f(1)) + (w5[3] * f(3) + w5[4] * f(4))) + w5[2] * f(2));
+            pS[comp] = fS[comp] * (((w5[0] * g2(0) + w5[1] * g2(1)) + (w5[3] * g2(3) + w5[4] * g2(4))) + w5[2] * g2(2));
+          }
+        if (!A.plain && (p == 0 || p == A.nvz - 1)) // (block-uniform) constraints on the z faces
+#pragma unroll
+          for (int comp = 0; comp < 3; ++comp)
+            if (A.con_u >> ((p == 0 ? 12 : 15) + comp) & 1)
+              pF[comp] = pS[comp] = 0.;
+        const double a_r = (A.c[1][0] * pF[0] + A.c[1][1] * pS[0]) + (mx[1][0] * pF[1] + mx[1][1] * pS[1]);
+        const double b_r = mx[1][0] * pF[2] + mx[1][1] * pS[2];
+        const double a_l = (lCF * pF[0] + lCS * pS[0]) + (lMF * pF[1] + lMS * pS[1]);
+        const double b_l = lMF * pF[2] + lMS * pS[2];
+        const double a = ((oCF * pF[0] + oCS * pS[0]) + (oMF * pF[1] + oMS * pS[1])) +
+                         (from_l * __shfl_up(a_r, 1, 64) + from_r * __shfl_down(a_l, 1, 64));
+        const double b = (oMF * pF[2] + oMS * pS[2]) + (from_l * __shfl_up(b_r, 1, 64) + from_r * __shfl_down(b_l, 1, 64));
+        if (PH % 2 == 0)
+          {
+            if (wr)
+              *d = old + A.weight * (acc[sm] + (mz[0][2] * a + A.c[0][2] * b));
             const bool lo = K > 0, hi = K < A.npz - 1;
-            const double (&mz)[2][3] = A.m[2];
-            const double M0 = lo ? mz[1][0] : 0., M1 = lo ? mz[1][1] : 0., M2 = (lo ? mz[1][2] : 0.) + (hi ? mz[0][0] : 0.),
-                         M3 = hi ? mz[0][1] : 0., M4 = hi ? mz[0][2] : 0.;
-            const double C0 = lo ? A.c[1][0] : 0., C1 = lo ? A.c[1][1] : 0., C2 = (lo ? A.c[1][2] : 0.) + (hi ? A.c[0][0] : 0.),
-                         C3 = hi ? A.c[0][1] : 0., C4 = hi ? A.c[0][2] : 0.;
-            const double div = M0 * Aw[0] + M1 * Aw[1] + M2 * Aw[2] + M3 * Aw[3] + M4 * Aw[4] + C0 * Bw[0] + C1 * Bw[1] +
-                               C2 * Bw[2] + C3 * Bw[3] + C4 * Bw[4];
-            const bool conz = (K == 0 && (A.con_p >> 4 & 1)) || (K == A.npz - 1 && (A.con_p >> 5 & 1));
-            if (active && !(con_xy || conz))
-              {
-                const long idx = ((long)K * A.npy + J) * A.npx + I;
-                A.dst_p[idx] += A.weight * div;
-              }
-            Aw[0] = Aw[2], Aw[1] = Aw[3], Aw[2] = Aw[4], Aw[3] = 0., Aw[4] = 0.;
-            Bw[0] = Bw[2], Bw[1] = Bw[3], Bw[2] = Bw[4], Bw[3] = 0., Bw[4] = 0.;
-            ++K;
+            acc[sc] += ((lo ? mz[1][2] : 0.) + (hi ? mz[0][0] : 0.)) * a + ((lo ? A.c[1][2] : 0.) + (hi ? A.c[0][0] : 0.)) * b;
+            acc[sp] = mz[1][0] * a + A.c[1][0] * b;
+          }
+        else
+          {
+            acc[sc] += mz[0][1] * a + A.c[0][1] * b;
+            acc[sp] += mz[1][1] * a + A.c[1][1] * b;
           }
       };
-      double pre[DLD];
-      fetch(pre, p0);
-      commit(pre, lds[p0 & 1]);
-      __syncthreads();
-      for (int p = p0; p <= p1; ++p)
+      for (int t = 0; t <= t1; t += 6)
         {
-          if (p < p1)
-            fetch(pre, p + 1);
-          process(p);
-          if (p < p1)
-            commit(pre, lds[(p + 1) & 1]);
-          __syncthreads();
+#define DIV_STEP(ph)                                                                                                  \
+  if (t + ph >= t0 && t + ph <= t1)                                                                                   \
+    step(std::integral_constant<int, ph>(), t + ph);
+          DIV_STEP(0)
+          DIV_STEP(1)
+          DIV_STEP(2)
+          DIV_STEP(3)
+          DIV_STEP(4)
+          DIV_STEP(5)
+#undef DIV_STEP
+        }
+      // the top pressure layer of the mesh has no planes above it
+      if (K1 == A.npz)
+        {
+          const int kk = (K1 - 1) - (K0 - 1); // = t / 2 of its own plane
+          if (writes(K1 - 1))
+            A.dst_p[(long)(K1 - 1) * A.flat + g] += A.weight * (kk % 3 == 0 ? acc[0] : kk % 3 == 1 ? acc[1] : acc[2]);
         }
     }
   } // namespace
@@ -200,11 +218,21 @@ namespace adaflo_hip
     DivArgs A{};
     A.npx = ctx->desc.ncell[0] + 1, A.npy = ctx->desc.ncell[1] + 1, A.npz = ctx->desc.ncell[2] + 1;
     A.nvx = 2 * ctx->desc.ncell[0] + 1, A.nvy = 2 * ctx->desc.ncell[1] + 1, A.nvz = 2 * ctx->desc.ncell[2] + 1;
-    // chunks of 8 pressure layers (measured best for 64 x 64 x 128 and 128^3 cells among 4 .. 32)
-    A.LZ       = 8;
+    A.flat             = (long)A.npx * A.npy;
+    A.blocks_per_chunk = (int)(((A.flat + DSW - 1) / DSW + 3) / 4); // four independent waves per workgroup
+    // z-chunk: 2 LZ + 3 velocity planes per LZ pressure layers; the halo planes are read from HBM again
+    // (FETCH_SIZE 1.24 x the vector at LZ = 8) and the kernel is bound by what it reads (loads with trivial
+    // sums 0.108 ms, arithmetic without loads 0.023 ms of 0.117 ms; scripts/dev/div_probe.hip), so: the
+    // longest chunk that leaves ~200 workgroups (128^3 cells: 0.137 / 0.128 / 0.133 / 0.117 / 0.145 ms for
+    // LZ = 4 / 6 / 8 / 12 / 16 -- at 12 the 748 workgroups are one round of the chip; 64 x 64 x 128: 0.025 ms)
+    int lz = 2;
+    for (const int c : {4, 6, 8, 12})
+      if ((long)A.blocks_per_chunk * ((A.npz + c - 1) / c) >= 192)
+        lz = c;
+    if (const char *e = getenv("ADAFLO_DIV_LZ")) // (tuning knob of scripts/bench_ops.py)
+      lz = std::max(1, atoi(e));
+    A.LZ       = lz;
     A.n_chunks = (A.npz + A.LZ - 1) / A.LZ;
-    A.tiles_x  = (A.npx + DPX - 1) / DPX;
-    A.tiles_y  = (A.npy + DPY - 1) / DPY;
     const Quadrature1D g  = gauss(3);
     const Shape1D      su = shape_fe_q(2, g), sp = shape_fe_q(1, g);
     for (int a = 0; a < 2; ++a)
@@ -226,9 +254,9 @@ namespace adaflo_hip
     A.plain  = plain;
     A.src_u  = src_u;
     A.dst_p  = dst_p;
-    const long  n_wg = (long)A.tiles_x * A.tiles_y * A.n_chunks;
+    const long  n_wg = (long)A.blocks_per_chunk * A.n_chunks;
     hipEvent_t stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
-    hipLaunchKernelGGL(q2q1_divergence_kernel, dim3((unsigned)n_wg), dim3(DPX * DPY), 0, ctx->stream, A);
+    hipLaunchKernelGGL(q2q1_divergence_kernel, dim3((unsigned)n_wg), dim3(256), 0, ctx->stream, A);
     if (stop)
       (void)hipEventRecord(stop, ctx->stream);
     ctx->kernel_timer.count++;
