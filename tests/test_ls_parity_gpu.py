@@ -42,7 +42,9 @@ class LSCase:
 @pytest.mark.parametrize("s,ncell,faces", [(4, (2, 3, 2), ()), (2, (3, 3, 4), (0, 5)), (1, (4, 4, 4), ()),
                                            (3, (2, 2, 2), (2,)), (4, (5, 9, 3), (1, 2, 4)),
                                            (2, (9, 8, 20), (0, 1, 2, 3, 4, 5)), (1, (33, 17, 40), (3,)),
-                                           (1, (1, 1, 1), ()), (2, (1, 2, 1), (0, 5)), (4, (1, 1, 2), ())])
+                                           (1, (1, 1, 1), ()), (2, (1, 2, 1), (0, 5)), (4, (1, 1, 2), ()),
+                                           # rows longer than / exactly as long as the 62 owned lanes of a wave
+                                           (4, (20, 3, 2), (0, 1)), (2, (31, 2, 3), (2, 3)), (1, (61, 4, 13), (4, 5))])
 def test_ls_operator_applications(s, ncell, faces, variant):
     """variant 1: structured Q1 sweep kernel (multi-tile, partial tiles, z-chunks in the larger
     cases); variant 0: generic per-cell kernels"""

@@ -164,7 +164,9 @@ def test_scalar_sub_blocks(k, ncell, variant):
 @pytest.mark.parametrize("ncell,faces_u,faces_p,lin", [((3, 2, 4), range(6), (), 0), ((40, 10, 5), (0, 3, 4), (1,), 0),
                                                         ((33, 9, 20), (), (2, 5), 0), ((34, 17, 9), (1, 2, 5), (), 0),
                                                         ((5, 4, 3), range(6), (), 4), ((1, 1, 1), (), (), 0),
-                                                        ((1, 2, 1), (2,), (3,), 0), ((65, 1, 17), (0, 1), (), 0)])
+                                                        ((1, 2, 1), (2,), (3,), 0), ((65, 1, 17), (0, 1), (), 0),
+                                                        # pressure rows of exactly 62 / 124 nodes (the owned lanes of a wave)
+                                                        ((61, 3, 2), (0, 1, 2), (4,), 0), ((123, 2, 13), (3, 4, 5), (0,), 0)])
 @pytest.mark.parametrize("variant", [1, 2])
 def test_divergence_as_tensor_product_stencil(ncell, faces_u, faces_p, lin, variant):
     """variant 1: Q2 -> Q1 stencil kernel (csrc/ns_divergence.hip), variant 2: divergence mode of the sweep
