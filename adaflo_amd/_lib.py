@@ -91,6 +91,7 @@ SIGNATURES = {
     "adaflo_ns_supports_phases": (C.c_int, [_CTX]),
     "adaflo_ns_residual": (C.c_int, [_CTX, _D, _D, _D, _D, _D, _D, _D, _D]),
     "adaflo_ns_velocity_vmult": (C.c_int, [_CTX, _D, _D]),
+    "adaflo_ns_velocity_block_diagonal": (C.c_int, [_CTX, _D]),
     "adaflo_ns_divergence_vmult_add": (C.c_int, [_CTX, _D, _D, C.c_int]),
     "adaflo_ns_pressure_poisson_vmult": (C.c_int, [_CTX, _D, _D]),
     "adaflo_ns_pressure_mass_vmult": (C.c_int, [_CTX, _D, _D]),

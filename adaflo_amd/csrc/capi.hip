@@ -742,6 +742,28 @@ int adaflo_ns_velocity_vmult(adaflo_ctx *ctx, double *dst_u, const double *src_u
   return 0;
 }
 
+int adaflo_ns_velocity_block_diagonal(adaflo_ctx *ctx, double *diagonal_u)
+{
+  CHECK_CTX(ctx);
+  if (!diagonal_u)
+    return fail(ctx, ADAFLO_EINVAL, "null vector");
+  if (needs_lin(ctx) && !has_lin(ctx))
+    return fail(ctx, ADAFLO_ENOTINIT, "linearization data not set");
+  // the same (possibly frozen) state velocity_vmult operates on, in the generic layout
+  TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
+  TRY(ctx, ensure_lin_prec_generic(ctx), "state re-layout failed");
+  const int k = ctx->k;
+  TRY(ctx, launch_fill(ctx, diagonal_u, 1., 3 * ctx->n_nodes_u) ? ADAFLO_EHIP : 0, "fill failed");
+  // zero on the free rows, 1 (= the operator applied to a unit vector) on the constrained ones
+  TRY(ctx,
+      launch_prepare_dst(ctx, diagonal_u, diagonal_u, ctx->n_nodes_u, 3, nn(ctx, k, 0), nn(ctx, k, 1), nn(ctx, k, 2),
+                         ctx->brick.con_u, 1., true),
+      "prepare failed");
+  const NSArgs a = make_ns_args(ctx, true);
+  TRY(ctx, launch_ns_velocity_diagonal(ctx, a, diagonal_u), "diagonal kernel launch failed");
+  return 0;
+}
+
 static int scalar_op(adaflo_ctx *ctx, double *dst, const double *src, const int mode,
                      const double *coef, const bool quad_u, const bool zero_dst)
 {

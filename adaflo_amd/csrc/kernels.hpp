@@ -46,6 +46,8 @@ namespace adaflo_hip
 
   // generic cell kernels (ns_generic.hip)
   int launch_ns_cell_generic(adaflo_ctx *ctx, int op, const NSArgs &args);
+  // diagonal of the velocity block, added into diag (zero on entry)
+  int launch_ns_velocity_diagonal(adaflo_ctx *ctx, const NSArgs &args, double *diag);
 
   struct ScalarArgs
   {

@@ -912,8 +912,17 @@ int adaflo_ns_preconditioner_setup(adaflo_ctx *ctx)
   double *probe_work = persistent(ctx->kr_work, (size_t)nu);
   if (!probe_work)
     return kfail(ctx, ADAFLO_ENOMEM, "out of device memory");
-  if (int rc = probe_diagonal(ctx, [ctx](double *d, const double *s) { return adaflo_ns_velocity_vmult(ctx, d, s); },
-                              ctx->pc_inv_u.p, ctx->pc_tmp_u.p, probe_work, ctx->k, 3))
+  // velocity block: the diagonal straight from the quadrature-point operation (ns_generic.hip) -- the
+  // (k + 1)^3 * 3 operator applications of the coloured probing were 34 of the 48 ms of this set-up in the
+  // two-phase step; ADAFLO_PROBE_VELOCITY_DIAGONAL=1 keeps the probing (tests compare the two)
+  static const bool probe_u = getenv("ADAFLO_PROBE_VELOCITY_DIAGONAL") != nullptr;
+  if (probe_u)
+    {
+      if (int rc = probe_diagonal(ctx, [ctx](double *d, const double *s) { return adaflo_ns_velocity_vmult(ctx, d, s); },
+                                  ctx->pc_inv_u.p, ctx->pc_tmp_u.p, probe_work, ctx->k, 3))
+        return rc;
+    }
+  else if (int rc = adaflo_ns_velocity_block_diagonal(ctx, ctx->pc_inv_u.p))
     return rc;
   if (int rc = probe_diagonal(ctx, [ctx](double *d, const double *s) { return adaflo_ns_pressure_mass_vmult(ctx, d, s); },
                               ctx->pc_inv_pm.p, ctx->pc_tmp_p.p, probe_work, ctx->k - 1, 1))

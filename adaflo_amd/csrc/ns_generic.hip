@@ -403,6 +403,146 @@ namespace adaflo_hip
   }
 
   // ------------------------------------------------------------------------
+  // diagonal of the velocity block
+  // ------------------------------------------------------------------------
+  // diag[(node, c)] = a(phi_i e_c, phi_i e_c) of the operator of OP_VMULT_VELOCITY (the Jacobi diagonal of
+  // the inner velocity solves; the reference takes it from the assembled preconditioner matrix,
+  // source/navier_stokes_preconditioner.cc:135-300).  The quadrature-point operation of ns_cell_kernel
+  // applied to the trial function u = phi_i e_c -- values delta_dc v, gradients delta_dc grad_e -- and
+  // tested with the same function gives, per point,
+  //   jxw [ conv_c v + tmu |grad|^2 + (tmu + tau_grad_div) grad_c^2 ],
+  //   conv_c = rho (w0 v + tau1 res_c) - damping v,
+  //   res_c  = beta grad_c lu_c + beta tr(lg) v + lu . grad + v lg_cc      (Newton)
+  //          = beta ldiv v + lu . grad                                     (convection frozen)
+  // One thread per node of the cell, the cell's coefficients staged in LDS; 27^2 x ~40 flops per Q2 cell
+  // instead of the 81 operator applications of the coloured probing (krylov.hip).
+  template <int K, int NT>
+  __global__ __launch_bounds__(NT) void ns_velocity_diagonal_kernel(const NSArgs a, double *__restrict__ diag)
+  {
+    using L = NSLayout<K>;
+    constexpr int NQ = L::NQ, NQ3 = L::NQ3, ND = L::NDU, ND3 = L::NDU3, NCF = NLIN + 3;
+    extern __shared__ double lds[];
+    const double *S_u = lds, *D_u = S_u + NQ * ND, *wq = D_u + NQ * ND + 2 * NQ * L::NDP;
+    double       *cf  = lds + L::TABP; // [NCF][NQ3]: lin state (12), rho, damping, tau1 mu
+    const int     tid = threadIdx.x;
+    for (int o = tid; o < L::TAB; o += NT)
+      lds[o] = a.tab[o];
+    const long   c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
+    const int    ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
+    const int    cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
+    const int    nux = K * ncx + 1, nuy = K * ncy + 1, nuz = K * ncz + 1;
+    const NSDev &P = a.ns;
+    const bool   stokes = P.physical_type == ADAFLO_STOKES;
+    const bool   newton = P.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON;
+    const bool   frozen = !newton && P.linearization != ADAFLO_COUPLED_VELOCITY_EXPLICIT;
+    for (int o = tid; o < NCF * NQ3; o += NT)
+      {
+        const int f = o / NQ3, q = o - f * NQ3;
+        double    v;
+        if (f < NLIN)
+          v = (a.lin && !stokes && (newton || frozen)) ? a.lin[(size_t)c * NLIN * NQ3 + o] : 0.;
+        else if (f == NLIN)
+          v = a.rho ? a.rho[(size_t)c * NQ3 + q] : P.density;
+        else if (f == NLIN + 1)
+          v = a.damp ? a.damp[(size_t)c * NQ3 + q] : P.damping;
+        else
+          v = (a.mu ? a.mu[(size_t)c * NQ3 + q] : P.viscosity) * P.tau1;
+        cf[o] = v;
+      }
+    __syncthreads();
+    const double w0 = P.physical_type == ADAFLO_INCOMPRESSIBLE ? P.weight : 0.;
+    const double ih[3] = {1. / a.brick.h[0], 1. / a.brick.h[1], 1. / a.brick.h[2]};
+    const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
+    for (int l = tid; l < ND3; l += NT)
+      {
+        const int i = l % ND, j = (l / ND) % ND, k = l / (ND * ND);
+        double    d[3] = {0., 0., 0.};
+        for (int qz = 0; qz < NQ; ++qz)
+          for (int qy = 0; qy < NQ; ++qy)
+            {
+              const double syz = S_u[qy * ND + j] * S_u[qz * ND + k];
+              const double gy_ = D_u[qy * ND + j] * S_u[qz * ND + k] * ih[1], gz_ = S_u[qy * ND + j] * D_u[qz * ND + k] * ih[2];
+              const double wyz = det * wq[qy] * wq[qz];
+#pragma unroll
+              for (int qx = 0; qx < NQ; ++qx)
+                {
+                  const int    q = qx + NQ * (qy + NQ * qz);
+                  const double sx = S_u[qx * ND + i], v = sx * syz;
+                  const double g[3] = {D_u[qx * ND + i] * syz * ih[0], sx * gy_, sx * gz_};
+                  const double jxw = wyz * wq[qx], tmu = cf[(NLIN + 2) * NQ3 + q];
+                  const double visc = tmu * (g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+                  double       common = 0., lu[3] = {0., 0., 0.};
+                  if (!stokes)
+                    {
+                      double res = 0.;
+                      if (newton || frozen)
+                        {
+#pragma unroll
+                          for (int e = 0; e < 3; ++e)
+                            lu[e] = cf[e * NQ3 + q];
+                          res = lu[0] * g[0] + lu[1] * g[1] + lu[2] * g[2];
+                          if (newton)
+                            res += P.beta * (cf[3 * NQ3 + q] + cf[7 * NQ3 + q] + cf[11 * NQ3 + q]) * v;
+                          else
+                            res += P.beta * cf[3 * NQ3 + q] * v;
+                        }
+                      common = (cf[NLIN * NQ3 + q] * (w0 * v + P.tau1 * res) - cf[(NLIN + 1) * NQ3 + q] * v) * v;
+                    }
+#pragma unroll
+                  for (int e = 0; e < 3; ++e)
+                    {
+                      double t = common + visc + (tmu + P.tau_grad_div) * g[e] * g[e];
+                      if (!stokes && newton) // beta grad_c lu_c + v lg_cc
+                        t += cf[NLIN * NQ3 + q] * P.tau1 * (P.beta * g[e] * lu[e] + v * cf[(3 + 4 * e) * NQ3 + q]) * v;
+                      d[e] += jxw * t;
+                    }
+                }
+            }
+        const int  I = cx * K + i, J = cy * K + j, Kz = cz * K + k;
+        const long node = I + (long)nux * (J + (long)nuy * Kz);
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+          if (!on_constrained_face(I, J, Kz, nux, nuy, nuz, a.brick.con_u, 3, e))
+            diag[node * 3 + e] += d[e];
+      }
+  }
+
+  template <int K, int NT>
+  static int launch_diag(adaflo_ctx *ctx, const NSArgs &args, double *diag)
+  {
+    using L          = NSLayout<K>;
+    const size_t lds = sizeof(double) * (L::TABP + (NLIN + 3) * L::NQ3);
+    NSArgs       a   = args;
+    for (int colour = 0; colour < 8; ++colour) // (cells of one colour share no node: plain adds)
+      if (const long nc = n_cells_of_colour(a.brick.ncell, colour))
+        {
+          a.brick.colour = colour;
+          hipLaunchKernelGGL((ns_velocity_diagonal_kernel<K, NT>), dim3((unsigned)nc), dim3(NT), lds, ctx->stream, a, diag);
+        }
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+  }
+
+  // diag must be zero on entry (constrained rows stay zero)
+  int launch_ns_velocity_diagonal(adaflo_ctx *ctx, const NSArgs &args, double *diag)
+  {
+    switch (ctx->k)
+      {
+        case 2:
+          return launch_diag<2, 64>(ctx, args, diag);
+        case 3:
+          return launch_diag<3, 64>(ctx, args, diag);
+        case 4:
+          return launch_diag<4, 128>(ctx, args, diag);
+        case 5:
+          return launch_diag<5, 256>(ctx, args, diag);
+        case 6:
+          return launch_diag<6, 384>(ctx, args, diag);
+        default:
+          return ADAFLO_EUNSUPPORTED;
+      }
+  }
+
+  // ------------------------------------------------------------------------
   // scalar sub-block kernels
   // ------------------------------------------------------------------------
   template <int K, bool QU>

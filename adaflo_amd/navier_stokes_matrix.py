@@ -230,6 +230,12 @@ class NavierStokesMatrix:
         ctx = self._require()
         _lib.check(ctx, self._lib.adaflo_ns_velocity_vmult(ctx, dst.ptr, src.ptr))
 
+    def velocity_block_diagonal(self, dst):
+        """diagonal of the operator of velocity_vmult (what the Jacobi-preconditioned inner velocity solves
+        of the block preconditioner use); 1 on constrained rows"""
+        ctx = self._require()
+        _lib.check(ctx, self._lib.adaflo_ns_velocity_block_diagonal(ctx, dst.ptr))
+
     def divergence_vmult_add(self, dst, src, weight_by_viscosity=False):
         ctx = self._require()
         _lib.check(ctx, self._lib.adaflo_ns_divergence_vmult_add(ctx, dst.ptr, src.ptr,

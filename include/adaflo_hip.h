@@ -175,6 +175,11 @@ int adaflo_ns_residual(adaflo_ctx *ctx, double *rhs_u, double *rhs_p, const doub
                        const double *old_u, const double *old_old_u);
 /* velocity_vmult :337-382 */
 int adaflo_ns_velocity_vmult(adaflo_ctx *ctx, double *dst_u, const double *src_u);
+/* Diagonal of the operator of velocity_vmult (1 on constrained rows, like A e_i there), computed cell by cell
+ * from the quadrature-point operation itself.  It stands for the diagonal of the velocity block of the
+ * preconditioner matrix the reference assembles (navier_stokes_preconditioner.cc:135-300, used by its
+ * ILU / AMG); here it is the Jacobi diagonal of the inner velocity solves for variable coefficients. */
+int adaflo_ns_velocity_block_diagonal(adaflo_ctx *ctx, double *diagonal_u);
 /* divergence_vmult_add :300-332 (dst NOT zeroed) */
 int adaflo_ns_divergence_vmult_add(adaflo_ctx *ctx, double *dst_p, const double *src_u,
                                    int weight_by_viscosity);

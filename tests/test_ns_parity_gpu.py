@@ -406,6 +406,35 @@ def test_velocity_vmult_variable_coefficients_uses_the_frozen_state():
         op.set_coefficients(None, None, None)
 
 
+@pytest.mark.parametrize("k,ncell,lin,phys,coefficients,faces_u",
+                         [(2, (3, 2, 2), 0, 0, True, range(6)), (2, (2, 3, 2), 1, 0, True, (0, 3)), (2, (2, 2, 2), 4, 0, False, ()),
+                          (2, (2, 2, 3), 0, 2, True, (1, 4)), (3, (2, 2, 1), 0, 0, True, range(6)), (3, (2, 1, 2), 0, 1, False, (2,)), (3, (1, 2, 2), 2, 0, True, ()),
+                          (4, (1, 2, 1), 0, 0, True, (5,))])
+def test_velocity_block_diagonal_is_the_diagonal_of_velocity_vmult(k, ncell, lin, phys, coefficients, faces_u):
+    """adaflo_ns_velocity_block_diagonal (cell-wise from the quadrature-point operation) against column by
+    column applications of velocity_vmult to unit vectors, for every linearisation branch of the kernel,
+    frozen variable coefficients and partial Dirichlet sets"""
+    case = Case(ncell, k=k, linearization=lin, physical_type=phys, faces_u=faces_u, density_diff=0.5 if coefficients else 0.0,
+                damping=0.3, tau_grad_div=0.2, upper=(1.0, 0.6, 1.7))
+    op = case.engine()
+    op.set_kernel_variant(0)
+    op.set_linearization(case.random_lin())
+    if coefficients:
+        op.set_coefficients(*case.random_coefficients())
+    diag = op.initialize_u_vector(np.full(case.n_u, 7.0))
+    op.velocity_block_diagonal(diag)
+    got = diag.numpy()
+    ref = np.empty(case.n_u)
+    e = np.zeros(case.n_u)
+    dst = op.initialize_u_vector(e)
+    for i in range(case.n_u):
+        e[:] = 0.0
+        e[i] = 1.0
+        op.velocity_vmult(dst, op.initialize_u_vector(e))
+        ref[i] = dst.numpy()[i]
+    assert np.max(np.abs(got - ref)) < 1e-12 * np.max(np.abs(ref)), np.max(np.abs(got - ref))
+
+
 # ----------------------------------------------------------------------------- Q3..Q5 sweep kernel
 @pytest.mark.parametrize("k,ncell", [(3, (4, 4, 3)), (3, (9, 5, 6)), (3, (8, 8, 20)), (4, (4, 2, 3)), (4, (5, 3, 4)),
                                      (4, (9, 6, 10)), (5, (3, 2, 2)), (5, (4, 3, 3))])
