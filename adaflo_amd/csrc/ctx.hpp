@@ -162,6 +162,7 @@ struct adaflo_ctx
   int                      pc_its_before_inner = 50; // parameters.iterations_before_inner_solvers (0: inner solves at once)
   bool                     pc_simple = false;  // current stage of adaflo_ns_solve_system: do_inner_solves == false
   int                      pc_simple_velocity_its = 0; // Jacobi mode: BiCGStab iterations of the velocity block in the cheap stage (0: no cheap stage)
+  bool                     pc_poisson_fdm = true;      // Jacobi mode: pressure Poisson CG preconditioned by the constant-coefficient inverse
 
   // pressure constant mode (mode 0) data, source/navier_stokes_matrix.cc:117-168
   double *d_p_weights = nullptr, *d_p_modes = nullptr;

@@ -164,6 +164,7 @@ namespace adaflo_hip
       const double *inv_diag;
       Operator      A;
       bool          fuse_dot = false; // A is ONE stencil launch that can leave the partials of src . dst
+      Operator      P;                // a preconditioner that is not a diagonal (CG only); inv_diag is ignored then
 
       double dot(const double *a, const double *b)
       {
@@ -173,9 +174,12 @@ namespace adaflo_hip
       {
         hipLaunchKernelGGL(axpby_kernel, dim3(kgrid(n)), dim3(KT), 0, ctx->stream, y, a, x, b, n);
       }
-      void precondition(double *dst, const double *src)
+      int precondition(double *dst, const double *src)
       {
+        if (P)
+          return P(dst, src);
         hipLaunchKernelGGL(precond_kernel, dim3(kgrid(n)), dim3(KT), 0, ctx->stream, dst, src, inv_diag, n_block, n);
+        return 0;
       }
     };
 
@@ -401,6 +405,30 @@ namespace adaflo_hip
         }
       block_reduce2(s0, s1, partial);
     }
+    // CG with a general preconditioner: the second partial (r.z) of the update pass, once z = P r exists
+    __global__ __launch_bounds__(KT) void cg_rz_dev_kernel(const double *__restrict__ r, const double *__restrict__ z,
+                                                           const long n, double *__restrict__ partial,
+                                                           const double *__restrict__ S)
+    {
+      if (S[S_DONE] != 0.)
+        return;
+      double s1 = 0.;
+      for (long i = blockIdx.x * (long)KT + threadIdx.x; i < n; i += (long)gridDim.x * KT)
+        s1 += r[i] * z[i];
+      __shared__ double red[KT / 64];
+      for (int off = 32; off > 0; off >>= 1)
+        s1 += __shfl_down(s1, off, 64);
+      if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = s1;
+      __syncthreads();
+      if (threadIdx.x == 0)
+        {
+          double t1 = 0.;
+          for (int w = 0; w < KT / 64; ++w)
+            t1 += red[w];
+          partial[2 * blockIdx.x + 1] = t1;
+        }
+    }
     // CG: p = z + beta p
     __global__ __launch_bounds__(KT) void cg_p_dev_kernel(double *__restrict__ p, const double *__restrict__ z,
                                                           const long n, const double *__restrict__ S)
@@ -542,7 +570,8 @@ namespace adaflo_hip
           out.converged      = 1;
           return 0;
         }
-      K.precondition(z, r);
+      if (int e = K.precondition(z, r))
+        return e;
       (void)hipMemcpyAsync(p, z, n * sizeof(double), hipMemcpyDeviceToDevice, K.ctx->stream);
       const double rz = K.dot(r, z);
       double      *S = krylov_scalars(K.ctx), *H = K.ctx->h_result_dev, *partial = K.ctx->d_scratch + 8;
@@ -572,8 +601,14 @@ namespace adaflo_hip
             }
           K.ctx->fused_dot_count = 0;
           hipLaunchKernelGGL(kr_final_kernel, dim3(1), dim3(KT), 0, st, partial, n_partial, S, H, (int)ST_CG_ALPHA, it);
-          hipLaunchKernelGGL(cg_update_dev_kernel, dim3(nb), dim3(KT), 0, st, x, r, z, p, Ap, K.inv_diag, K.n_block, n,
-                             partial, S);
+          hipLaunchKernelGGL(cg_update_dev_kernel, dim3(nb), dim3(KT), 0, st, x, r, z, p, Ap, K.P ? nullptr : K.inv_diag,
+                             K.n_block, n, partial, S);
+          if (K.P) // z = P r by the operator (it also runs once after convergence, like A), then r . z
+            {
+              if (const int e_P = K.P(z, r))
+                return e_P;
+              hipLaunchKernelGGL(cg_rz_dev_kernel, dim3(nb), dim3(KT), 0, st, r, z, n, partial, S);
+            }
           hipLaunchKernelGGL(kr_final_kernel, dim3(1), dim3(KT), 0, st, partial, (int)nb, S, H, (int)ST_CG_UPDATE, it);
           return 0;
         },
@@ -1084,6 +1119,11 @@ int adaflo_ns_preconditioner_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p
         }
       K.inv_diag = ctx->pc_inv_pl.p;
       K.A        = [ctx](double *d, const double *s) { return adaflo_ns_pressure_poisson_vmult(ctx, d, s); };
+      // variable 1 / rho: CG preconditioned with the exact inverse of the CONSTANT-coefficient Laplacian
+      // (fast diagonalisation; the reference has ML-AMG here, :243-300) -- the condition number is the density
+      // ratio instead of h^-2.  With the Jacobi diagonal the solve ran into its 30-iteration cap every time.
+      if (ctx->pc_inner == 1 && ctx->pc_poisson_fdm) // (set_inner(0) keeps the all-Jacobi solves the oracle mirrors)
+        K.P = [ctx, c_pl](double *d, const double *s) { return fdm_apply(ctx, 1, d, s, 0., c_pl); };
       const double norm = std::sqrt(host_dot(ctx, t, t, np));
       const adaflo_solver_control c{30, 3e-2 * norm, 0.};
       if (launch_fill(ctx, t2, 0., np))
