@@ -32,6 +32,12 @@ pmc pmc_q4_sq2 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INS
 # calibration of the FETCH_SIZE counter for 8-B-per-lane reads (the access width of ns_ho_kernel)
 hipcc --offload-arch=gfx950 -O3 $R/scripts/dev/fetch_probe.hip -o /tmp/fetch_probe > "$O/fetch_probe_build.log" 2>&1
 pmc pmc_fetch_probe FETCH_SIZE /tmp/fetch_probe
+# the two stencil kernels alone (built here: hipcc ... scripts/dev/stencil_probe.hip / div_probe.hip -o scripts/dev/build/...)
+for p in stencil_probe div_probe; do
+  [ -x $R/scripts/dev/build/$p ] && $R/scripts/dev/build/$p > "$O/$p.log" 2>&1
+done
+[ -x $R/scripts/dev/build/stencil_probe ] && $R/scripts/dev/build/stencil_probe 161 321 >> "$O/stencil_probe.log" 2>&1
+[ -x $R/scripts/dev/build/div_probe ] && $R/scripts/dev/build/div_probe 64 128 >> "$O/div_probe.log" 2>&1
 # no rocprof: the plain bench lines and the large meshes
 cd $R
 python3 bench.py > "$O/bench_n1_plain.log" 2>&1
