@@ -106,6 +106,8 @@ namespace adaflo_hip
   double host_dot(adaflo_ctx *ctx, const double *a, const double *b, long n);
   // device-resident scalars of the distributed mean-value projection (comm.hip)
   int launch_dot_to(adaflo_ctx *ctx, const double *a, const double *b, long n, double *out); // *out = a . b
+  int launch_gs_step(adaflo_ctx *ctx, double *w, const double *coefficient, const double *v, const double *next, long n,
+                     double *out);
   int launch_sum_to(adaflo_ctx *ctx, const double *a, long n, double *out);                  // *out = sum a
   int launch_reciprocal(adaflo_ctx *ctx, double *out, const double *in);                     // *out = 1 / *in
   int launch_subtract_scaled(adaflo_ctx *ctx, double *v, const double *s, const double *t, long n); // v -= *s * *t

@@ -1225,14 +1225,12 @@ int adaflo_ns_solve_system(adaflo_ctx *ctx, double *update_u, double *update_p, 
           double hn;
           if (gs)
             {
-              for (int i = 0; i <= j; ++i)
-                {
-                  if (launch_dot_to(ctx, wv, vec(V, i), n, ctx->gs_dev + i))
-                    return kfail(ctx, ADAFLO_EHIP, "dot product failed");
-                  hipLaunchKernelGGL(axpy_dev_kernel, dim3(kgrid(n)), dim3(KT), 0, ctx->stream, wv, ctx->gs_dev + i, vec(V, i), n);
-                }
-              if (launch_dot_to(ctx, wv, wv, n, ctx->gs_dev + j + 1))
+              // (the update with v_i and the dot product with v_{i+1} -- or the norm -- in one pass over w)
+              if (launch_dot_to(ctx, wv, vec(V, 0), n, ctx->gs_dev))
                 return kfail(ctx, ADAFLO_EHIP, "dot product failed");
+              for (int i = 0; i <= j; ++i)
+                if (launch_gs_step(ctx, wv, ctx->gs_dev + i, vec(V, i), i < j ? vec(V, i + 1) : nullptr, n, ctx->gs_dev + i + 1))
+                  return kfail(ctx, ADAFLO_EHIP, "Gram-Schmidt step failed");
               if (hipMemcpyAsync(ctx->gs_host, ctx->gs_dev, (j + 2) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                   hipStreamSynchronize(ctx->stream) != hipSuccess)
                 return kfail(ctx, ADAFLO_EHIP, "Gram-Schmidt coefficients did not arrive");

@@ -64,6 +64,37 @@ namespace adaflo_hip
         }
     }
 
+    // One step of the modified Gram-Schmidt of FGMRES in one pass: w -= (*s) v (the update axpy_dev_kernel of krylov.hip
+    // does, same expression) and, with the updated values, the partial sums of w . next -- the dot product the next
+    // step needs (next == nullptr: w . w).  Thread / block mapping and summation order of dot_partial_kernel, so that
+    // the result is bitwise the one of the two separate kernels.
+    __global__ __launch_bounds__(VT) void gs_step_kernel(double *__restrict__ w, const double *__restrict__ s,
+                                                         const double *__restrict__ v, const double *__restrict__ next,
+                                                         const long n, double *__restrict__ part)
+    {
+      __shared__ double red[VT / 64];
+      const double      a = -*s;
+      double            sum = 0.;
+      for (long i = blockIdx.x * (long)VT + threadIdx.x; i < n; i += (long)gridDim.x * VT)
+        {
+          const double wi = a * v[i] + 1. * w[i];
+          w[i]            = wi;
+          sum += wi * (next ? next[i] : wi);
+        }
+      for (int off = 32; off > 0; off >>= 1)
+        sum += __shfl_down(sum, off, 64);
+      if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = sum;
+      __syncthreads();
+      if (threadIdx.x == 0)
+        {
+          double t = 0.;
+          for (int k = 0; k < VT / 64; ++k)
+            t += red[k];
+          part[blockIdx.x] = t;
+        }
+    }
+
     // single block: result[0] = sum(part[0..np))  (fixed order -> deterministic)
     __global__ __launch_bounds__(VT) void dot_final_kernel(const double *__restrict__ part,
                                                            const int np, double *__restrict__ result,
@@ -286,6 +317,19 @@ namespace adaflo_hip
     if (int e = ensure_scratch(ctx, 2 * 32768 + 8))
       return e;
     hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(VT), 0, ctx->stream, a, b, n, ctx->d_scratch + 8);
+    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(VT), 0, ctx->stream, ctx->d_scratch + 8, (int)nb, out,
+                       (double *)nullptr);
+    return check();
+  }
+
+  // w -= (*coefficient) v, then out = w . next (next == nullptr: w . w), see gs_step_kernel
+  int launch_gs_step(adaflo_ctx *ctx, double *w, const double *coefficient, const double *v, const double *next,
+                     const long n, double *out)
+  {
+    const unsigned nb = grid_for(n, 4);
+    if (int e = ensure_scratch(ctx, 2 * 32768 + 8))
+      return e;
+    hipLaunchKernelGGL(gs_step_kernel, dim3(nb), dim3(VT), 0, ctx->stream, w, coefficient, v, next, n, ctx->d_scratch + 8);
     hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(VT), 0, ctx->stream, ctx->d_scratch + 8, (int)nb, out,
                        (double *)nullptr);
     return check();
