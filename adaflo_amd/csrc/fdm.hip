@@ -34,6 +34,11 @@ namespace adaflo_hip
       double *d_St   = nullptr; // [mode][node]  (forward transform: modes = St . nodes)
       double *d_S    = nullptr; // [node][mode]  (backward transform)
       double *d_lam  = nullptr; // eigenvalue per mode; < 0 marks a padding mode (constrained node)
+      // A 1D problem that is symmetric about its midpoint (same kind of end on both sides) has eigenvectors that are
+      // even or odd about it.  The modes are then ordered [even | odd] and the transforms fold the nodes j and n-1-j
+      // onto each other: two products of half the size instead of one, half the flops (fdm_apply).
+      bool sym = false;
+      int  n_even = 0; // number of even modes (they come first)
     };
 
     // M, K of FE_Q(degree) on ncell cells of size h, quadrature QGauss(nq); dense n x n, row-major
@@ -237,9 +242,14 @@ namespace adaflo_hip
       long          rsA, csA, bsA, rsB, csB, bsB, rsC, csC, bsC;
       const double *A, *B;
       double       *C;
+      // folded transforms: the operand that holds the field is read as X[k] + fold X[nfold-1-k] along the contraction
+      // index (fold = +1 / -1; the midpoint of an odd length counts once); the result is stored plainly (mirror = 0),
+      // to an index and its mirror image nmirror-1-index (1), or added there / subtracted at the mirror image (2)
+      int fold = 0, fold_on_A = 0, nfold = 0, mirror = 0, mirror_on_i = 0, nmirror = 0;
     };
     typedef double d4_t __attribute__((ext_vector_type(4)));
-    template <int TMS, int TNS, int WM, int WN>
+    // FM: 0 plain, 1 / 2 the field operand A / B is folded on load, 3 / 4 mirrored stores along j / i (GemmArgs)
+    template <int TMS, int TNS, int WM, int WN, int FM>
     __global__ __launch_bounds__(64 * WM *WN) void fdm_gemm_kernel(const GemmArgs g)
     {
       constexpr int NT = 64 * WM * WN, TM = 16 * TMS * WM, TN = 16 * TNS * WN;
@@ -262,6 +272,9 @@ namespace adaflo_hip
       // were slower (3, 4, 5, 9 tiles), as was a rolling two-tile pipeline.  129^3 nodes, same box: 50.4 us per
       // GEMM with the register-tiled vector kernel, 40.0 us with this one.
       const bool    a_k_fast = g.csA == 1, b_j_fast = g.csB == 1;
+      constexpr bool fold_a = FM == 1, fold_b = FM == 2;
+      const double  fold_sign = g.fold;
+      const int     fold_mid = (g.fold > 0 && (g.nfold & 1)) ? (g.nfold - 1) / 2 : -1;
       constexpr int LA = (TM * GK + NT - 1) / NT, LB = (TN * GK + NT - 1) / NT;
       auto fetch = [&](const int k0, double (&ra)[LA], double (&rb)[LB]) {
 #pragma unroll
@@ -270,7 +283,10 @@ namespace adaflo_hip
             const int e = tid + u * NT;
             const int ii = a_k_fast ? e / GK : e % TM, kk = a_k_fast ? e % GK : e / TM;
             const int i = i0 + ii, k = k0 + kk;
-            ra[u]       = (e < TM * GK && i < g.M && k < g.K) ? A[i * g.rsA + k * g.csA] : 0.;
+            double    v = (e < TM * GK && i < g.M && k < g.K) ? A[i * g.rsA + k * g.csA] : 0.;
+            if (fold_a && e < TM * GK && i < g.M && k < g.K && k != fold_mid)
+              v += fold_sign * A[i * g.rsA + (g.nfold - 1 - k) * g.csA];
+            ra[u] = v;
           }
 #pragma unroll
         for (int u = 0; u < LB; ++u)
@@ -278,7 +294,10 @@ namespace adaflo_hip
             const int e = tid + u * NT;
             const int jj = b_j_fast ? e % TN : e / GK, kk = b_j_fast ? e / TN : e % GK;
             const int j = j0 + jj, k = k0 + kk;
-            rb[u]       = (e < TN * GK && j < g.N && k < g.K) ? B[k * g.rsB + j * g.csB] : 0.;
+            double    v = (e < TN * GK && j < g.N && k < g.K) ? B[k * g.rsB + j * g.csB] : 0.;
+            if (fold_b && e < TN * GK && j < g.N && k < g.K && k != fold_mid)
+              v += fold_sign * B[(g.nfold - 1 - k) * g.rsB + j * g.csB];
+            rb[u] = v;
           }
       };
       auto commit = [&](const double (&ra)[LA], const double (&rb)[LB]) {
@@ -342,7 +361,27 @@ namespace adaflo_hip
             {
               const int i = i0 + wi + 16 * r + fk + 4 * q, j = j0 + wj + 16 * c + fl;
               if (i < g.M && j < g.N)
-                C[i * g.rsC + j * g.csC] = acc[r][c][q];
+                {
+                  const long idx = i * g.rsC + j * g.csC;
+                  if (FM < 3)
+                    C[idx] = acc[r][c][q];
+                  else
+                    {
+                      const int  o = FM == 4 ? i : j, om = g.nmirror - 1 - o;
+                      const long idm = FM == 4 ? om * g.rsC + j * g.csC : i * g.rsC + om * g.csC;
+                      if (g.mirror == 1)
+                        {
+                          C[idx] = acc[r][c][q];
+                          if (om != o)
+                            C[idm] = acc[r][c][q];
+                        }
+                      else
+                        {
+                          C[idx] += acc[r][c][q];
+                          C[idm] -= acc[r][c][q];
+                        }
+                    }
+                }
             }
     }
 
@@ -352,14 +391,32 @@ namespace adaflo_hip
       auto tile = [](const int n) { return (n + 47) / 48 * 48 < (n + 63) / 64 * 64 ? 48 : 64; };
       const int  tm = tile(g.M), tn = tile(g.N);
       const dim3 grid((g.N + tn - 1) / tn, (g.M + tm - 1) / tm, batch);
-      if (tm == 64 && tn == 64)
-        hipLaunchKernelGGL((fdm_gemm_kernel<2, 2, 2, 2>), grid, dim3(256), 0, ctx->stream, g);
-      else if (tm == 48 && tn == 64)
-        hipLaunchKernelGGL((fdm_gemm_kernel<3, 1, 1, 4>), grid, dim3(256), 0, ctx->stream, g);
-      else if (tm == 64 && tn == 48)
-        hipLaunchKernelGGL((fdm_gemm_kernel<1, 3, 4, 1>), grid, dim3(256), 0, ctx->stream, g);
-      else
-        hipLaunchKernelGGL((fdm_gemm_kernel<3, 1, 1, 3>), grid, dim3(192), 0, ctx->stream, g);
+      const int fm = g.fold != 0 ? (g.fold_on_A ? 1 : 2) : (g.mirror != 0 ? (g.mirror_on_i ? 4 : 3) : 0);
+#define FDM_GEMM(FM)                                                                                                  \
+  {                                                                                                                   \
+    if (tm == 64 && tn == 64)                                                                                         \
+      hipLaunchKernelGGL((fdm_gemm_kernel<2, 2, 2, 2, FM>), grid, dim3(256), 0, ctx->stream, g);                       \
+    else if (tm == 48 && tn == 64)                                                                                    \
+      hipLaunchKernelGGL((fdm_gemm_kernel<3, 1, 1, 4, FM>), grid, dim3(256), 0, ctx->stream, g);                       \
+    else if (tm == 64 && tn == 48)                                                                                    \
+      hipLaunchKernelGGL((fdm_gemm_kernel<1, 3, 4, 1, FM>), grid, dim3(256), 0, ctx->stream, g);                       \
+    else                                                                                                              \
+      hipLaunchKernelGGL((fdm_gemm_kernel<3, 1, 1, 3, FM>), grid, dim3(192), 0, ctx->stream, g);                       \
+  }
+      switch (fm)
+        {
+          case 0:
+            FDM_GEMM(0) break;
+          case 1:
+            FDM_GEMM(1) break;
+          case 2:
+            FDM_GEMM(2) break;
+          case 3:
+            FDM_GEMM(3) break;
+          default:
+            FDM_GEMM(4) break;
+        }
+#undef FDM_GEMM
       return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
     }
 
@@ -412,8 +469,58 @@ namespace adaflo_hip
       size_t                          wcount = 0;
     };
 
-    int upload_eig(Eig1D &E, const int n, const std::vector<double> &S, const std::vector<double> &lam)
+    // modes even / odd about the midpoint first / last (padding modes, whose columns never matter -- the scaling
+    // sets their coefficient to zero --, are zeroed and fill up the even block); false: the problem is not symmetric
+    bool order_modes_by_symmetry(const int n, std::vector<double> &S, std::vector<double> &lam, int &n_even)
     {
+      std::vector<int> kind(n); // +1 even, -1 odd, 0 padding
+      for (int m = 0; m < n; ++m)
+        {
+          if (lam[m] < 0.)
+            {
+              kind[m] = 0;
+              continue;
+            }
+          double p = 0., q = 0.;
+          for (int j = 0; j < n; ++j)
+            {
+              p += S[(size_t)j * n + m] * S[(size_t)(n - 1 - j) * n + m];
+              q += S[(size_t)j * n + m] * S[(size_t)j * n + m];
+            }
+          if (q <= 0. || std::abs(std::abs(p / q) - 1.) > 1e-9)
+            return false;
+          kind[m] = p > 0. ? 1 : -1;
+        }
+      std::vector<int> order;
+      for (int m = 0; m < n; ++m)
+        if (kind[m] == 1)
+          order.push_back(m);
+      for (int m = 0; m < n; ++m) // padding modes behind the even ones, up to half of the nodes
+        if (kind[m] == 0 && (int)order.size() < (n + 1) / 2)
+          {
+            order.push_back(m);
+            kind[m] = 2;
+          }
+      n_even = (int)order.size();
+      for (int m = 0; m < n; ++m)
+        if (kind[m] == -1 || kind[m] == 0)
+          order.push_back(m);
+      std::vector<double> S2((size_t)n * n), lam2(n);
+      for (int c = 0; c < n; ++c)
+        {
+          const int m = order[c];
+          lam2[c]     = lam[m];
+          for (int j = 0; j < n; ++j)
+            S2[(size_t)j * n + c] = lam[m] < 0. ? 0. : S[(size_t)j * n + m];
+        }
+      S.swap(S2);
+      lam.swap(lam2);
+      return true;
+    }
+
+    int upload_eig(Eig1D &E, const int n, std::vector<double> S, std::vector<double> lam)
+    {
+      E.sym = order_modes_by_symmetry(n, S, lam, E.n_even);
       std::vector<double> St((size_t)n * n);
       for (int i = 0; i < n; ++i)
         for (int j = 0; j < n; ++j)
@@ -519,6 +626,83 @@ namespace adaflo_hip
     return fdm_setup_field(ctx, 1);
   }
 
+  // One 1D transform of the field in [z][y][x] along `axis`: nodes -> modes with St (forward) or modes -> nodes with S
+  // (backward), as strided (batched) GEMM.  For a symmetric 1D problem with at least FOLD_MIN nodes the transform is
+  // folded (Eig1D): forward, the even modes see w_j + w_{n-1-j} and the odd ones w_j - w_{n-1-j} for j in the lower
+  // half only; backward, the even and the odd sums u_e, u_o of the lower half give w_j = u_e + u_o and
+  // w_{n-1-j} = u_e - u_o.  Two launches of a quarter of the flops each.
+  static int transform_axis(adaflo_ctx *ctx, const int axis, const bool backward, const Eig1D &E, const double *in, double *out,
+                            const int nx, const int ny, const int nz)
+  {
+    constexpr int FOLD_MIN = 96;
+    const int     n = axis == 0 ? nx : (axis == 1 ? ny : nz);
+    const double *T = backward ? E.d_S : E.d_St; // [out index][contraction index], row-major n x n
+    GemmArgs      g{};
+    int           batch = 1;
+    if (axis == 0) // C[r][i] = sum_k W[r][k] T[i][k]
+      {
+        g.M = ny * nz, g.N = nx, g.K = nx;
+        g.A = in, g.rsA = nx, g.csA = 1;
+        g.B = T, g.rsB = 1, g.csB = nx;
+        g.C = out, g.rsC = nx, g.csC = 1;
+      }
+    else if (axis == 1) // per z-plane C[i][j] = sum_k T[i][k] W[k][j]
+      {
+        g.M = ny, g.N = nx, g.K = ny;
+        g.A = T, g.rsA = ny, g.csA = 1, g.bsA = 0;
+        g.B = in, g.rsB = nx, g.csB = 1, g.bsB = (long)nx * ny;
+        g.C = out, g.rsC = nx, g.csC = 1, g.bsC = (long)nx * ny;
+        batch = nz;
+      }
+    else // C[i][j] = sum_k T[i][k] W[k][j], j over the plane
+      {
+        g.M = nz, g.N = nx * ny, g.K = nz;
+        g.A = T, g.rsA = nz, g.csA = 1;
+        g.B = in, g.rsB = (long)nx * ny, g.csB = 1;
+        g.C = out, g.rsC = (long)nx * ny, g.csC = 1;
+      }
+    if (!E.sym || n < FOLD_MIN || getenv("ADAFLO_FDM_NO_FOLD"))
+      return gemm(ctx, g, batch);
+    const int  nE = E.n_even, nO = n - nE, lo_e = (n + 1) / 2, lo_o = n / 2; // modes; nodes of the lower half (with / without midpoint)
+    const long sw = axis == 0 ? 1 : (axis == 1 ? nx : (long)nx * ny);         // stride of the field along the axis
+    for (int part = 0; part < 2; ++part) // even, odd
+      {
+        GemmArgs h = g;
+        const int n_out = backward ? (part == 0 ? lo_e : lo_o) : (part == 0 ? nE : nO); // output indices of this launch
+        const int n_con = backward ? (part == 0 ? nE : nO) : (part == 0 ? lo_e : lo_o); // contraction length
+        const int o_out = backward ? 0 : (part == 0 ? 0 : nE);                          // first output index (forward: modes)
+        const int o_con = backward ? (part == 0 ? 0 : nE) : 0;                          // first contraction index (backward: modes)
+        if (n_out == 0 || n_con == 0)
+          continue;
+        h.K = n_con;
+        if (axis == 0)
+          {
+            h.N = n_out;
+            h.A = in + o_con;                           // field, contraction along its rows
+            h.B = T + (long)o_out * n + o_con;          // B[k][j] = T[o_out + j][o_con + k]
+            h.C = out + o_out;
+          }
+        else
+          {
+            h.M = n_out;
+            h.A = T + (long)o_out * n + o_con;          // A[i][k] = T[o_out + i][o_con + k]
+            h.B = in + (long)o_con * sw;                // field, contraction along its columns
+            h.C = out + (long)o_out * sw;
+          }
+        if (!backward)
+          {
+            h.fold = part == 0 ? 1 : -1, h.fold_on_A = axis == 0, h.nfold = n;
+          }
+        else
+          {
+            h.mirror = part == 0 ? 1 : 2, h.mirror_on_i = axis != 0, h.nmirror = n;
+          }
+        if (int e = gemm(ctx, h, batch))
+          return e;
+      }
+    return 0;
+  }
+
   // dst = (c_mass M + c_lap K)^-1 src on the free rows (pseudo-inverse if singular), dst = src on
   // the constrained rows; dst == src allowed
   int fdm_apply(adaflo_ctx *ctx, const int field, double *dst, const double *src, const double c_mass, const double c_lap)
@@ -540,29 +724,11 @@ namespace adaflo_hip
         const Eig1D &ex = fd.e[c][0], &ey = fd.e[c][1], &ez = fd.e[c][2];
         for (int dir = 0; dir < 2; ++dir) // 0: nodes -> modes (S^T), 1: modes -> nodes (S)
           {
-            // x: C[r][i] = sum_k W[r][k] T[i][k],  T = St (forward) or S (backward), both [i][k] row-major
-            GemmArgs g{};
-            g.M = ny * nz, g.N = nx, g.K = nx;
-            g.A = w0, g.rsA = nx, g.csA = 1;
-            g.B = dir == 0 ? ex.d_St : ex.d_S, g.rsB = 1, g.csB = nx;
-            g.C = w1, g.rsC = nx, g.csC = 1;
-            if (int e = gemm(ctx, g, 1))
+            if (int e = transform_axis(ctx, 0, dir == 1, ex, w0, w1, nx, ny, nz))
               return e;
-            // y: per z-plane C[i][j] = sum_k T[i][k] W[k][j]
-            g   = GemmArgs{};
-            g.M = ny, g.N = nx, g.K = ny;
-            g.A = dir == 0 ? ey.d_St : ey.d_S, g.rsA = ny, g.csA = 1, g.bsA = 0;
-            g.B = w1, g.rsB = nx, g.csB = 1, g.bsB = (long)nx * ny;
-            g.C = w0, g.rsC = nx, g.csC = 1, g.bsC = (long)nx * ny;
-            if (int e = gemm(ctx, g, nz))
+            if (int e = transform_axis(ctx, 1, dir == 1, ey, w1, w0, nx, ny, nz))
               return e;
-            // z: C[i][j] = sum_k T[i][k] W[k][j], j over the plane
-            g   = GemmArgs{};
-            g.M = nz, g.N = nx * ny, g.K = nz;
-            g.A = dir == 0 ? ez.d_St : ez.d_S, g.rsA = nz, g.csA = 1;
-            g.B = w0, g.rsB = (long)nx * ny, g.csB = 1;
-            g.C = w1, g.rsC = (long)nx * ny, g.csC = 1;
-            if (int e = gemm(ctx, g, 1))
+            if (int e = transform_axis(ctx, 2, dir == 1, ez, w0, w1, nx, ny, nz))
               return e;
             if (dir == 0)
               {
