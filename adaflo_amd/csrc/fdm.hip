@@ -627,14 +627,14 @@ namespace adaflo_hip
   }
 
   // One 1D transform of the field in [z][y][x] along `axis`: nodes -> modes with St (forward) or modes -> nodes with S
-  // (backward), as strided (batched) GEMM.  For a symmetric 1D problem with at least FOLD_MIN nodes the transform is
+  // (backward), as strided (batched) GEMM.  For a symmetric 1D problem with at least FOLD_MIN nodes (the level-set grids) the transform is
   // folded (Eig1D): forward, the even modes see w_j + w_{n-1-j} and the odd ones w_j - w_{n-1-j} for j in the lower
   // half only; backward, the even and the odd sums u_e, u_o of the lower half give w_j = u_e + u_o and
   // w_{n-1-j} = u_e - u_o.  Two launches of a quarter of the flops each.
   static int transform_axis(adaflo_ctx *ctx, const int axis, const bool backward, const Eig1D &E, const double *in, double *out,
                             const int nx, const int ny, const int nz)
   {
-    constexpr int FOLD_MIN = 96;
+    constexpr int FOLD_MIN = 192; // (129-node directions: 2 % on the velocity space, a loss on the 65 x 65 x 129 pressure grid)
     const int     n = axis == 0 ? nx : (axis == 1 ? ny : nz);
     const double *T = backward ? E.d_S : E.d_St; // [out index][contraction index], row-major n x n
     GemmArgs      g{};

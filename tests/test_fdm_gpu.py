@@ -26,11 +26,11 @@ def _fdm(op, field, src, c_mass, c_lap):
 
 @pytest.mark.parametrize("k,ncell,faces_p", [(2, (5, 4, 6), ()), (2, (9, 3, 4), (0,)), (3, (3, 4, 2), (1, 4)), (2, (1, 1, 1), ()),
                                              (2, (1, 3, 2), (0, 1)), (2, (2, 1, 3), (2, 3, 5)),
-                                             # >= 96 nodes in a direction: the folded (even / odd) transforms of a symmetric 1D
+                                             # >= 192 nodes in a direction: the folded (even / odd) transforms of a symmetric 1D
                                              # problem -- natural ends, Dirichlet ends (padding modes), one Dirichlet end (not
                                              # symmetric: plain transform), an even number of nodes
-                                             (2, (100, 2, 3), ()), (2, (2, 97, 2), (2, 3)), (2, (3, 2, 128), (4,)), (2, (95, 2, 2), (0, 1)),
-                                             (3, (2, 3, 50), ())])
+                                             (2, (200, 2, 3), ()), (2, (2, 193, 2), (2, 3)), (2, (3, 2, 256), (4,)), (2, (191, 2, 2), (0, 1)),
+                                             (3, (2, 3, 100), ())])
 def test_pressure_mass_and_poisson_are_inverted_exactly(k, ncell, faces_p):
     case = Case(ncell, k=k, faces_p=faces_p, upper=(1.0, 0.7, 1.5), viscosity=0.3, tau_grad_div=0.2)
     op = case.engine()
@@ -68,7 +68,7 @@ def _mass_stiffness_1d(k, n, h):
 
 
 @pytest.mark.parametrize("k,ncell,faces_u", [(2, (3, 2, 4), range(6)), (2, (4, 3, 2), (0, 3)), (3, (2, 2, 3), (4, 5)),
-                                             (2, (48, 1, 2), range(6)), (2, (1, 50, 1), (0, 1)), (2, (1, 2, 49), (4,))])
+                                             (2, (96, 1, 2), range(6)), (2, (1, 100, 1), (0, 1)), (2, (1, 2, 97), (4,))])
 def test_velocity_space_inverse_against_kronecker_assembly(k, ncell, faces_u):
     case = Case(ncell, k=k, faces_u=faces_u, upper=(1.0, 0.7, 1.5))
     op = case.engine()
@@ -126,7 +126,7 @@ def test_beltrami_time_step_with_fast_diagonalisation():
 
 @pytest.mark.parametrize("s,ncell,upper", [(1, (5, 4, 3), (1.0, 1.0, 1.0)), (2, (4, 3, 5), (1.0, 0.7, 1.5)), (3, (2, 3, 2), (0.9, 1.2, 1.0)),
                                            (4, (3, 2, 2), (1.0, 0.5, 0.8)), (1, (1, 1, 1), (1.0, 1.0, 1.0)), (2, (1, 5, 1), (0.3, 1.0, 0.2)),
-                                           (4, (24, 1, 2), (1.0, 0.1, 0.2)), (3, (1, 2, 33), (0.1, 0.2, 1.0))])
+                                           (4, (48, 1, 2), (1.0, 0.1, 0.2)), (3, (1, 2, 65), (0.1, 0.2, 1.0))])
 def test_projection_matrix_of_the_level_set_space_is_inverted_exactly(s, ncell, upper):
     """field 2 (FE_Q_iso_Q1(s), analytic cosine modes): adaflo_ls_projection_solve inverts the projection matrix of
     the normal / curvature solves (one scalar block of compute_normal_vmult = adaflo_ls_projection_vmult), and
