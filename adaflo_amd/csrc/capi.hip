@@ -314,7 +314,7 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
   for (DeviceBuffer *b : {&ctx->lin, &ctx->rho, &ctx->mu, &ctx->damp, &ctx->lin_prec, &ctx->rho_prec,
                           &ctx->mu_prec, &ctx->damp_prec, &ctx->lin_q2, &ctx->lin_q2_prec,
                           &ctx->q2_slab_u, &ctx->q2_zslab_u, &ctx->q2_slab_p, &ctx->q2_zslab_p,
-                          &ctx->ls_convection, &ctx->ls_normal, &ctx->q1_convection, &ctx->q1_normal,
+                          &ctx->ls_convection, &ctx->ls_normal, &ctx->q1_convection, &ctx->q1_normal, &ctx->q1_normal_nodal,
                           &ctx->q1_slab, &ctx->q1_zslab, &ctx->pc_inv_u, &ctx->pc_inv_pm, &ctx->pc_inv_pl,
                           &ctx->pc_ones_p, &ctx->pc_tmp_u, &ctx->pc_tmp_p, &ctx->pc_tmp_p2, &ctx->pc_work, &ctx->kr_work, &ctx->kr_basis, &ctx->kr_scalars,
                           &ctx->q1_poisson_coef, &ctx->ho_tab, &ctx->res_sum_u, &ctx->res_sum_p, &ctx->res_old,
@@ -1190,6 +1190,7 @@ int adaflo_ls_set_evaluated_normal(adaflo_ctx *ctx, const double *n_q, int src_o
   if (int e = ls_ready(ctx))
     return e;
   ctx->q1_normal_valid         = false;
+  ctx->q1_normal_nodal_valid   = false;
   ctx->ls_normal_generic_valid = true;
   return set_q_array(ctx, ctx->ls_normal, n_q, src_on_device);
 }
@@ -1238,6 +1239,12 @@ static int ls_vmult(adaflo_ctx *ctx, double *dst, const double *src, const int m
             q1mode = Q1_REINIT;
             c_mass = dtau_inv;
             c_lap  = diffusion;
+            if (ctx->q1_normal_nodal_valid) // evaluated_normal came from a nodal field: recompute it per Gauss point
+              {
+                q1mode = Q1_REINIT_NODAL;
+                state  = ctx->q1_normal_nodal.p;
+                break;
+              }
             if (!ctx->q1_normal_valid)
               TRY(ctx, q1_convert_state(ctx, ctx->q1_normal, ctx->ls_normal.p), "state re-layout failed");
             ctx->q1_normal_valid = true;
@@ -1504,6 +1511,16 @@ int adaflo_ls_reinitialization_rhs(adaflo_ctx *ctx, double *dst, const double *s
         {
           ctx->q1_normal_valid         = true;
           ctx->ls_normal_generic_valid = false;
+          ctx->q1_normal_nodal_valid   = false;
+          static const bool nodal = getenv("ADAFLO_LS_STREAM_NORMAL") == nullptr;
+          if (nodal)
+            {
+              const size_t count = 3 * (size_t)ctx->n_nodes_ls;
+              if (ctx->q1_normal_nodal.count != count)
+                TRY(ctx, alloc(ctx, ctx->q1_normal_nodal, count), ctx->last_error);
+              HIP_TRY(ctx, hipMemcpyAsync(ctx->q1_normal_nodal.p, nv, count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+              ctx->q1_normal_nodal_valid = true;
+            }
         }
       return 0;
     }
@@ -1513,6 +1530,7 @@ int adaflo_ls_reinitialization_rhs(adaflo_ctx *ctx, double *dst, const double *s
         {
           TRY(ctx, alloc(ctx, ctx->ls_normal, ls_q_count(ctx)), ctx->last_error);
           ctx->q1_normal_valid         = false;
+          ctx->q1_normal_nodal_valid   = false;
           ctx->ls_normal_generic_valid = true;
         }
       else if (int e = ls_generic_state(ctx, 1))

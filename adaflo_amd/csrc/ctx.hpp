@@ -144,6 +144,10 @@ struct adaflo_ctx
   // structured Q1 sweep kernel (q1_sweep.hip): streaming copies of the two arrays, seam partial sums
   adaflo_hip::DeviceBuffer q1_convection, q1_normal, q1_slab, q1_zslab;
   bool                     q1_convection_valid = false, q1_normal_valid = false;
+  // copy of the nodal normal field of the last first-step reinitialisation rhs: the reinitialisation vmult recomputes
+  // the unit normal at the Gauss points from it instead of streaming the 192 B per sub-cell (q1_sweep.hip)
+  adaflo_hip::DeviceBuffer q1_normal_nodal;
+  bool                     q1_normal_nodal_valid = false;
   // the sweep right-hand sides write the quadrature-point arrays in sweep layout only; the generic
   // [cell][3][q] copies are re-created on demand (adaflo_ls_get_evaluated_*, generic kernels)
   bool                     ls_convection_generic_valid = false, ls_normal_generic_valid = false;

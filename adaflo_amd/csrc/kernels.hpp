@@ -134,7 +134,9 @@ namespace adaflo_hip
     Q1_MASS_LAPLACE = 0, // (w, c_mass v) + (grad w, c_lap grad v)
     Q1_ADVECT       = 1, // (w, weight v + u . grad v)
     Q1_REINIT       = 2, // (w, c_mass v) + (grad w, c_lap (n . grad v) n)
-    Q1_LAPLACE_Q3   = 3  // (grad w, c(x_q) grad v) with the 3x3x3 Gauss rule, c per point (pressure Poisson)
+    Q1_LAPLACE_Q3   = 3, // (grad w, c(x_q) grad v) with the 3x3x3 Gauss rule, c per point (pressure Poisson)
+    Q1_REINIT_NODAL = 4  // Q1_REINIT with the unit normal at the Gauss points recomputed from the NODAL normal field
+                         // (`state` = three nodal fields) instead of streamed: 24 B instead of 192 B per sub-cell
   };
   int q1_convert_state(adaflo_ctx *ctx, DeviceBuffer &out, const double *generic_dev);
   int launch_q1_stencil_rhs(adaflo_ctx *ctx, int mode, double *dst, const double *src);

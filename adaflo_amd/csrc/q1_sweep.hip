@@ -73,6 +73,8 @@ namespace adaflo_hip
     {
       __shared__ double pl[2][TNQ * TNQ]; // node planes K, K+1 (ring)
       __shared__ double pub[2][3][NTQ];   // published high faces: [plane lk][(1,0),(0,1),(1,1)][lane]
+      constexpr bool NODAL = MODE == Q1_REINIT_NODAL;
+      __shared__ double pln[NODAL ? 2 * 3 * TNQ * TNQ : 1]; // planes K, K+1 of the three components of the normal field
 
       const int  tid = threadIdx.x;
       const int  sx = tid % TS, sy = tid / TS;
@@ -116,8 +118,14 @@ namespace adaflo_hip
       auto load_plane = [&](const int K, double *p) {
         for (int e = tid; e < TNQ * TNQ; e += NTQ)
           {
-            const int i = e % TNQ, j = e / TNQ, I = I0 + i, J = J0 + j;
-            p[e] = (I < A.nnx && J < A.nny && K < A.nnz) ? src_c[((size_t)K * A.nny + J) * A.nnx + I] : 0.;
+            const int  i = e % TNQ, j = e / TNQ, I = I0 + i, J = J0 + j;
+            const bool in = I < A.nnx && J < A.nny && K < A.nnz;
+            const size_t g = ((size_t)K * A.nny + J) * A.nnx + I;
+            p[e] = in ? src_c[g] : 0.;
+            if (NODAL)
+#pragma unroll
+              for (int c = 0; c < 3; ++c)
+                pln[((K & 1) * 3 + c) * (TNQ * TNQ) + e] = in ? A.state[c * A.comp_stride + g] : 0.;
           }
       };
       // store of one owned node value (constrained rows, slabs, plain stores)
@@ -154,7 +162,7 @@ namespace adaflo_hip
               for (int q = 0; q < 27; ++q)
                 cf[q] = cp[q * NTQ];
             }
-          else if (MODE != Q1_MASS_LAPLACE)
+          else if (MODE != Q1_MASS_LAPLACE && !NODAL)
             {
               const double2 *sp = state + ((size_t)bt * A.nsz + cz) * (12 * NTQ) + tid;
 #pragma unroll
@@ -309,6 +317,65 @@ namespace adaflo_hip
               gy[0][a] = ga * DY[0][a] + gb * DY[1][a];
               gy[1][a] = gb * DY[0][a] + ga * DY[1][a];
             }
+          // ---- unit normal at the Gauss points from the nodal field (as q1_rhs_kernel computes evaluated_normal on
+          // the first reinitialisation step, level_set_okz_reinitialization.cc:167-172)
+          double nq[NODAL ? 24 : 1];
+          if (NODAL)
+            {
+              double nv[3][2][2][2];
+#pragma unroll
+              for (int c = 0; c < 3; ++c)
+                {
+                  double w[2][2][2];
+#pragma unroll
+                  for (int lk = 0; lk < 2; ++lk)
+#pragma unroll
+                    for (int lj = 0; lj < 2; ++lj)
+#pragma unroll
+                      for (int li = 0; li < 2; ++li)
+                        w[lk][lj][li] = pln[((((cz + lk) & 1) * 3 + c) * TNQ + sy + lj) * TNQ + sx + li];
+                  double Xn[2][2][2], XYn[2][2][2];
+#pragma unroll
+                  for (int lk = 0; lk < 2; ++lk)
+#pragma unroll
+                    for (int lj = 0; lj < 2; ++lj)
+                      {
+                        Xn[lk][lj][0] = ga * w[lk][lj][0] + gb * w[lk][lj][1];
+                        Xn[lk][lj][1] = gb * w[lk][lj][0] + ga * w[lk][lj][1];
+                      }
+#pragma unroll
+                  for (int lk = 0; lk < 2; ++lk)
+#pragma unroll
+                    for (int qx = 0; qx < 2; ++qx)
+                      {
+                        XYn[lk][0][qx] = ga * Xn[lk][0][qx] + gb * Xn[lk][1][qx];
+                        XYn[lk][1][qx] = gb * Xn[lk][0][qx] + ga * Xn[lk][1][qx];
+                      }
+#pragma unroll
+                  for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                      {
+                        nv[c][0][a][b] = ga * XYn[0][a][b] + gb * XYn[1][a][b];
+                        nv[c][1][a][b] = gb * XYn[0][a][b] + ga * XYn[1][a][b];
+                      }
+                }
+#pragma unroll
+              for (int q = 0; q < 8; ++q)
+                {
+                  const int    qx = q & 1, qy = q >> 1 & 1, qz = q >> 2;
+                  const double n0 = nv[0][qz][qy][qx], n1 = nv[1][qz][qy][qx], n2 = nv[2][qz][qy][qx];
+                  // 1 / max(1e-4, |n|) = rsqrt(max(|n|^2, 1e-8)): hardware estimate + three Newton steps (to the last
+                  // bit or two; the f64 square root and division of the literal form cost three times as many
+                  // instructions and made this mode VALU-bound)
+                  const double x = fmax(n0 * n0 + n1 * n1 + n2 * n2, 1e-8), hx = 0.5 * x;
+                  double       sc = __builtin_amdgcn_rsq(x);
+#pragma unroll
+                  for (int it = 0; it < 3; ++it)
+                    sc = sc * (1.5 - hx * sc * sc);
+                  nq[3 * q] = n0 * sc, nq[3 * q + 1] = n1 * sc, nq[3 * q + 2] = n2 * sc;
+                }
+            }
           // ---- quadrature-point operation -------------------------------------------------------
           double tv[2][2][2], t0[2][2][2], t1[2][2][2], t2[2][2][2];
 #pragma unroll
@@ -331,9 +398,9 @@ namespace adaflo_hip
                   else
                     {
                       // state element 3q+e of this lane: double2 index (3q+e)/2, component (3q+e)&1
-                      const double s0 = (3 * q) & 1 ? st[(3 * q) / 2].y : st[(3 * q) / 2].x;
-                      const double s1 = (3 * q + 1) & 1 ? st[(3 * q + 1) / 2].y : st[(3 * q + 1) / 2].x;
-                      const double s2 = (3 * q + 2) & 1 ? st[(3 * q + 2) / 2].y : st[(3 * q + 2) / 2].x;
+                      const double s0 = NODAL ? nq[NODAL ? 3 * q : 0] : ((3 * q) & 1 ? st[(3 * q) / 2].y : st[(3 * q) / 2].x);
+                      const double s1 = NODAL ? nq[NODAL ? 3 * q + 1 : 0] : ((3 * q + 1) & 1 ? st[(3 * q + 1) / 2].y : st[(3 * q + 1) / 2].x);
+                      const double s2 = NODAL ? nq[NODAL ? 3 * q + 2 : 0] : ((3 * q + 2) & 1 ? st[(3 * q + 2) / 2].y : st[(3 * q + 2) / 2].x);
                       if (MODE == Q1_ADVECT) // level_set_okz_advance_concentration.cc:244-249
                         a = A.weight * v + s0 * g0 + s1 * g1 + s2 * g2;
                       else // Q1_REINIT: level_set_okz_reinitialization.cc:88-95
@@ -1598,6 +1665,9 @@ namespace adaflo_hip
           break;
         case Q1_ADVECT:
           hipLaunchKernelGGL((q1_sweep_kernel<Q1_ADVECT>), grid, block, 0, ctx->stream, A);
+          break;
+        case Q1_REINIT_NODAL:
+          hipLaunchKernelGGL((q1_sweep_kernel<Q1_REINIT_NODAL>), grid, block, 0, ctx->stream, A);
           break;
         default:
           hipLaunchKernelGGL((q1_sweep_kernel<Q1_REINIT>), grid, block, 0, ctx->stream, A);

@@ -132,6 +132,30 @@ def test_ls_right_hand_sides(s, ncell, faces, variant):
         assert rel_l2(adv.evaluated_convection, uq_ref) < TOL
 
 
+@pytest.mark.parametrize("s,ncell,faces", [(4, (5, 4, 3), ()), (2, (9, 17, 6), (0, 3)), (1, (20, 18, 35), (4, 5)), (3, (1, 1, 1), ())])
+def test_reinitialization_vmult_recomputes_the_normal_from_the_nodal_field(s, ncell, faces):
+    """after a first-step reinitialisation rhs the engine keeps the nodal normal field and the reinitialisation vmult
+    recomputes the unit normal at the Gauss points (Q1_REINIT_NODAL, csrc/q1_sweep.hip) instead of streaming
+    evaluated_normal: same result as the oracle fed with the evaluated_normal the rhs produced, and as the streaming
+    kernel once evaluated_normal is set explicitly"""
+    c = LSCase(ncell, s, faces=faces)
+    c.ops.set_kernel_variant(1)
+    rei = lso.LevelSetOKZSolverReinitialization(c.ops)
+    phi, nrm = c.ops.vector(c.rand()), c.ops.vector(c.rand(3), blocks=3)
+    rhs = c.ops.vector()
+    rei.local_reinitialize_rhs(rhs, phi, nrm, False, True)
+    src = c.rand()
+    d = c.ops.vector(np.full(c.nn, 9.0))
+    rei.reinitialization_vmult(d, c.ops.vector(src), False)          # nodal path
+    got_nodal = d.numpy().copy()
+    nq = np.array(rei.evaluated_normal)                              # what the rhs kernel stored per Gauss point
+    ref = orc.ls_reinit_vmult(c.mesh, c.prm, src, nq, diffuse_only=False, con=c.con, diag=c.diag)
+    assert rel_l2(got_nodal, ref) < TOL
+    rei.evaluated_normal = nq                                        # explicit state: streaming path
+    rei.reinitialization_vmult(d, c.ops.vector(src), False)
+    assert rel_l2(d.numpy(), got_nodal) < 1e-13
+
+
 @pytest.mark.parametrize("s,k,ncell,faces", [(3, 2, (7, 6, 5), ()), (3, 3, (6, 7, 3), (1, 2)), (4, 4, (5, 3, 2), ()),
                                              (1, 3, (18, 17, 6), (0,)), (2, 4, (9, 2, 3), (4, 5))])
 def test_sweep_right_hand_sides_unaligned_tiles_and_velocity_degrees(s, k, ncell, faces):
