@@ -31,8 +31,7 @@ def main():
         adaflo_amd._lib.check(ctx, adaflo_amd._lib.load().adaflo_ns_preconditioner_set_inner(ctx, int(sys.argv[3])))
 
     if len(sys.argv) > 6:      # cheap stage of the two-phase solver: BiCGStab iterations of the velocity block (0 = off)
-        ctx = ns.navier_stokes_matrix._require()
-        adaflo_amd._lib.check(ctx, adaflo_amd._lib.load().adaflo_ns_preconditioner_set_cheap_velocity_iterations(ctx, int(sys.argv[6])))
+        ns.cheap_velocity_iterations = int(sys.argv[6])
 
     def timed(name, fn, acc):
         torch.cuda.synchronize()
