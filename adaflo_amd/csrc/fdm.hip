@@ -655,7 +655,8 @@ namespace adaflo_hip
   static int transform_axis(adaflo_ctx *ctx, const int axis, const bool backward, const Eig1D &E, const double *in, double *out,
                             const int nx, const int ny, const int nz, const int nstack = 1)
   {
-    constexpr int FOLD_MIN = 192; // (129-node directions: 2 % on the velocity space, a loss on the 65 x 65 x 129 pressure grid)
+    // (directions of 129 nodes: a loss on the 65 x 65 x 129 pressure grid, where a launch is 10-16 us whatever it computes)
+    const int FOLD_MIN = (long)nx * ny * nz * nstack >= 4000000 ? 96 : 192;
     const int     n = axis == 0 ? nx : (axis == 1 ? ny : nz);
     const double *T = backward ? E.d_S : E.d_St; // [out index][contraction index], row-major n x n
     GemmArgs      g{};

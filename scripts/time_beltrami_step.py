@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Beltrami time steps on one MI355X: wall clock per step, outer FGMRES iterations and the inner velocity-block
 iterations per preconditioner application, with the fast-diagonalisation inner solves (1) and with the
-Jacobi-preconditioned inner Krylov solves (0).  usage: time_beltrami_step.py [cells_per_direction] [steps]"""
+Jacobi-preconditioned inner Krylov solves (0).  usage: time_beltrami_step.py [cells_per_direction] [steps] [only this mode]"""
 import ctypes as C
 import os
 import sys
@@ -20,7 +20,8 @@ def main():
     nu = 1.0
     mesh = adaflo_amd.BrickMesh([n] * 3, [-1.0] * 3, [1.0] * 3)
     xu, xp = node_coordinates(mesh, 2), node_coordinates(mesh, 1)
-    for inner in (1, -1, 0):        # 1: fast diagonalisation, two-stage solver; -1: inner solves from the start; 0: Jacobi
+    modes = (int(sys.argv[3]),) if len(sys.argv) > 3 else (1, -1, 0)
+    for inner in modes:             # 1: fast diagonalisation, two-stage solver; -1: inner solves from the start; 0: Jacobi
         fp = adaflo_amd.FlowParameters(velocity_degree=2, viscosity=nu, time_step_size_start=0.05 * 16 / n, end_time=1.0,
                                        max_nl_iteration=10, tol_nl_iteration=1e-9, max_lin_iteration=100, tol_lin_iteration=1e-5,
                                        iterations_before_inner_solvers=0 if inner < 0 else 50)
