@@ -1,7 +1,7 @@
 # development: PMC passes on the stencil probe (one counter set per run)
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03/stencil_pmc; mkdir -p $O
-P=$R/scripts/dev/build/stencil_probe_rows3
+P=$R/scripts/dev/build/stencil_probe
 run() { name=$1; ctr=$2; timeout 120 rocprofv3 --pmc $ctr --output-format csv -d $O/$name -o $name -- $P > $O/$name.log 2>&1; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
