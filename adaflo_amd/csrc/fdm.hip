@@ -685,7 +685,8 @@ namespace adaflo_hip
         g.C = out, g.rsC = (long)nx * ny, g.csC = 1, g.bsC = (long)nx * ny * nz;
         batch = nstack;
       }
-    if (!E.sym || n < FOLD_MIN || getenv("ADAFLO_FDM_NO_FOLD"))
+    static const bool no_fold = getenv("ADAFLO_FDM_NO_FOLD") != nullptr; // (tests / timing of the plain transforms)
+    if (!E.sym || n < FOLD_MIN || no_fold)
       return gemm(ctx, g, batch);
     const int  nE = E.n_even, nO = n - nE, lo_e = (n + 1) / 2, lo_o = n / 2; // modes; nodes of the lower half (with / without midpoint)
     const long sw = axis == 0 ? 1 : (axis == 1 ? nx : (long)nx * ny);         // stride of the field along the axis
