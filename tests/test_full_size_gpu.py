@@ -4,7 +4,9 @@
   config 5  64^3 Q4/Q3 stationary driven-cavity operator: wave-private sweep kernel against the same OpenMP
             restatement (degree 4), and against the generic per-cell kernel (independent code) + linearity;
   config 3  the whole 256^3 Q2/Q1 problem (422 M DoF) on ONE GPU: sweep kernel against the generic kernel +
-            linearity (marked slow)."""
+            linearity (marked slow);
+  128^3     divergence_vmult_add (the Q2 -> Q1 stencil of the block preconditioner) against the oracle's cell loop and
+            two more device kernels."""
 import numpy as np
 import pytest
 
@@ -99,3 +101,23 @@ def test_config3_256cubed_on_one_gpu_properties():
     Newton state) on one MI355X"""
     case = Case((256, 256, 256), k=2)
     _sweep_vs_generic_and_linearity(case, 27)
+
+
+def test_divergence_128cubed_against_the_oracle_and_two_more_kernels():
+    """divergence_vmult_add at the size of BASELINE configs[1]: the register-marching Q2 -> Q1 stencil (variant 1)
+    against the oracle's cell loop on the same seeded inputs (about ten seconds of CPU), and against the divergence mode
+    of the sweep kernel (variant 2) and the generic per-cell kernel (variant 0) -- independent implementations"""
+    case = Case((128, 128, 128), k=2, faces_u=(0, 3, 4), faces_p=(1,), viscosity=0.37)
+    rng = np.random.default_rng(7)
+    src_u, base = rng.uniform(-1, 1, case.n_u), rng.uniform(-1, 1, case.n_p)
+    op = case.engine()
+    res = {}
+    for variant in (1, 2, 0):
+        op.set_kernel_variant(variant)
+        dp = op.initialize_p_vector(base)
+        op.divergence_vmult_add(dp, op.initialize_u_vector(src_u), True)
+        res[variant] = dp.numpy()
+    assert rel_l2(res[1], res[2]) < TOL and rel_l2(res[1], res[0]) < TOL, (rel_l2(res[1], res[2]), rel_l2(res[1], res[0]))
+    ref = orc.ns_divergence_vmult_add(case.mesh, 2, case.prm, src_u, base, case.con_u, case.con_p, mu=None,
+                                      weight_by_viscosity=True)
+    assert rel_l2(res[1], ref) < TOL, rel_l2(res[1], ref)
