@@ -197,8 +197,9 @@ def test_sweep_right_hand_sides_unaligned_tiles_and_velocity_degrees(s, k, ncell
 
 def test_config4_full_size_against_oracle():
     """BASELINE configs[3] at full size (40 x 40 x 80 cells, s = 4: 8.3 M level-set DoF, 65.5 M quadrature points):
-    the sweep kernels of advance_concentration_vmult, reinitialization_vmult and of the two right-hand sides
-    against the CPU oracle's cell loops on identical inputs, entry by entry.  The four oracle evaluations
+    the sweep kernels of advance_concentration_vmult, reinitialization_vmult and of the two right-hand sides, and
+    the 27-point stencil kernel of the normal / curvature operators,
+    against the CPU oracle's cell loops on identical inputs, entry by entry.  The six oracle evaluations
     (naive restatement, tens of seconds each) run concurrently in threads."""
     from concurrent.futures import ThreadPoolExecutor
     c = LSCase((40, 40, 80), 4)
@@ -206,7 +207,10 @@ def test_config4_full_size_against_oracle():
     uq, nq = c.rand_q(), c.rand_q()
     vel = c.rng.uniform(-1, 1, c.mesh.n_nodes(c.k) * 3)
     uq_ref, nq_ref = np.zeros_like(uq), np.zeros_like(nq)
-    with ThreadPoolExecutor(4) as pool:          # (ctypes calls release the interpreter lock)
+    src3 = c.rand(3)
+    with ThreadPoolExecutor(6) as pool:          # (ctypes calls release the interpreter lock)
+        f_nor = pool.submit(orc.ls_normal_vmult, c.mesh, c.prm, src3)
+        f_cur = pool.submit(orc.ls_curvature_vmult, c.mesh, c.prm, src, apply_diffusion=True)
         f_adv = pool.submit(orc.ls_advect_vmult, c.mesh, c.prm, src, uq)
         f_rei = pool.submit(orc.ls_reinit_vmult, c.mesh, c.prm, src, nq, diffuse_only=False)
         f_arhs = pool.submit(orc.ls_advect_rhs, c.mesh, c.prm, c.k, phi, old, oldold, vel, uq_ref, c.w_old, c.w_oo, True)
@@ -227,6 +231,22 @@ def test_config4_full_size_against_oracle():
         d = c.ops.vector()
         rei.local_reinitialize_rhs(d, c.ops.vector(phi), c.ops.vector(normal, blocks=3), False, True)
         got_rrhs, got_nq = d.numpy(), rei.evaluated_normal
+        # after the first-step rhs the operator recomputes the normal from the nodal field (Q1_REINIT_NODAL); with the
+        # state set explicitly it streams it: both at full size
+        d = c.ops.vector()
+        rei.reinitialization_vmult(d, c.ops.vector(src), False)
+        got_nodal = d.numpy()
+        rei.evaluated_normal = np.array(got_nq)
+        rei.reinitialization_vmult(d, c.ops.vector(src), False)
+        assert rel_l2(got_nodal, d.numpy()) < 1e-13, "reinitialization_vmult: nodal normal vs streamed state"
+        # the 27-point stencil kernel: normal (three blocks) and curvature operators
+        d3 = c.ops.vector(blocks=3)
+        lso.LevelSetOKZSolverComputeNormal(c.ops).compute_normal_vmult(d3, c.ops.vector(src3, blocks=3))
+        got_nor = d3.numpy()
+        lso.LevelSetOKZSolverComputeCurvature(c.ops).compute_curvature_vmult(d, c.ops.vector(src), True)
+        got_cur = d.numpy()
+        assert rel_l2(got_nor, f_nor.result()) < TOL, "compute_normal_vmult vs oracle"
+        assert rel_l2(got_cur, f_cur.result()) < TOL, "compute_curvature_vmult vs oracle"
         assert rel_l2(got_adv, f_adv.result()) < TOL, "advance_concentration_vmult vs oracle"
         assert rel_l2(got_rei, f_rei.result()) < TOL, "reinitialization_vmult vs oracle"
         assert rel_l2(got_arhs, f_arhs.result()) < TOL and rel_l2(got_uq, uq_ref) < TOL, "advection rhs vs oracle"
