@@ -235,7 +235,10 @@ namespace adaflo_hip
     // Tile shapes: a wave owns TMS x TNS MFMA tiles, WM x WN waves form the workgroup tile
     // (16 TMS WM) x (16 TNS WN); 64 x 64, 48 x 64, 64 x 48 and 48 x 48 are instantiated and the launcher takes
     // 48 for a dimension that it pads less (129 = 2 * 64 + 1 nodes would waste a third of a 64-wide tiling).
-    constexpr int GK = 16, GLD = 64 + 16; // row stride 80 doubles: the two k-rows of a half-wave hit disjoint banks
+#ifndef GEMM_BATCH
+#define GEMM_BATCH 2
+#endif
+    constexpr int GK = 8, GLD = 64 + 16; // row stride 80 doubles: the two k-rows of a half-wave hit disjoint banks
     struct GemmArgs
     {
       int           M, N, K;
@@ -270,7 +273,9 @@ namespace adaflo_hip
       // issued together into two register sets before the first is used: a workgroup walks few k-tiles with
       // little work each, so the load latency is paid once per pair; more tiles per batch cost occupancy and
       // were slower (3, 4, 5, 9 tiles), as was a rolling two-tile pipeline.  129^3 nodes, same box: 50.4 us per
-      // GEMM with the register-tiled vector kernel, 40.0 us with this one.
+      // GEMM with the register-tiled vector kernel, 40.0 us with this one.  Round 3: k-tiles of 8 instead of 16
+      // (less LDS and fewer staging registers per workgroup, more workgroups in flight) are 5-8 % faster on every
+      // transform size (32: 30 % slower; 4: as 8; 3 or 4 tiles of 8 in flight: as 2).
       const bool    a_k_fast = g.csA == 1, b_j_fast = g.csB == 1;
       constexpr bool fold_a = FM == 1, fold_b = FM == 2;
       const double  fold_sign = g.fold;
@@ -334,23 +339,23 @@ namespace adaflo_hip
                 acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], b[c], acc[r][c], 0, 0, 0);
           }
       };
-      double ra0[LA], rb0[LB], ra1[LA], rb1[LB];
-      for (int k0 = 0; k0 < g.K; k0 += 2 * GK)
+      constexpr int NB = GEMM_BATCH; // k-tiles whose loads are issued together
+      double        ra[NB][LA], rb[NB][LB];
+      for (int k0 = 0; k0 < g.K; k0 += NB * GK)
         {
-          const bool second = k0 + GK < g.K;
-          fetch(k0, ra0, rb0);
-          if (second)
-            fetch(k0 + GK, ra1, rb1);
-          commit(ra0, rb0);
-          __syncthreads();
-          multiply();
-          __syncthreads();
-          if (!second)
-            break;
-          commit(ra1, rb1);
-          __syncthreads();
-          multiply();
-          __syncthreads();
+#pragma unroll
+          for (int t = 0; t < NB; ++t)
+            if (k0 + t * GK < g.K)
+              fetch(k0 + t * GK, ra[t], rb[t]);
+#pragma unroll
+          for (int t = 0; t < NB; ++t)
+            if (k0 + t * GK < g.K)
+              {
+                commit(ra[t], rb[t]);
+                __syncthreads();
+                multiply();
+                __syncthreads();
+              }
         }
 #pragma unroll
       for (int r = 0; r < TMS; ++r)
