@@ -275,7 +275,8 @@ namespace adaflo_hip
       // were slower (3, 4, 5, 9 tiles), as was a rolling two-tile pipeline.  129^3 nodes, same box: 50.4 us per
       // GEMM with the register-tiled vector kernel, 40.0 us with this one.  Round 3: k-tiles of 8 instead of 16
       // (less LDS and fewer staging registers per workgroup, more workgroups in flight) are 5-8 % faster on every
-      // transform size (32: 30 % slower; 4: as 8; 3 or 4 tiles of 8 in flight: as 2).
+      // transform size (32: 30 % slower; 4: as 8; 3 or 4 tiles of 8 in flight: as 2; one wave per 48 x 48 tile with nine
+      // accumulators and no workgroup barrier: 14 % slower).
       const bool    a_k_fast = g.csA == 1, b_j_fast = g.csB == 1;
       constexpr bool fold_a = FM == 1, fold_b = FM == 2;
       const double  fold_sign = g.fold;
