@@ -758,6 +758,31 @@ namespace adaflo_hip
       for (int d = 0; d < 3; ++d)
         together = together && fd.e[c][d].d_S == fd.e[0][d].d_S;
     const int nstack = together ? fd.ncomp : 1;
+    if (fd.ncomp == 1)
+      {
+        // scalar field: no re-layout on the way in, and none on the way out when no row is constrained -- the first
+        // transform reads src, the last one writes dst (dst == src is fine: src is only read by the first)
+        const Eig1D &ex = fd.e[0][0], &ey = fd.e[0][1], &ez = fd.e[0][2];
+        double      *B = F->w1, *Cb = F->w0;
+        if (int e = transform_axis(ctx, 0, false, ex, src, B, nx, ny, nz))
+          return e;
+        if (int e = transform_axis(ctx, 1, false, ey, B, Cb, nx, ny, nz))
+          return e;
+        if (int e = transform_axis(ctx, 2, false, ez, Cb, B, nx, ny, nz))
+          return e;
+        hipLaunchKernelGGL(fdm_scale_kernel, dim3(nb), dim3(256), 0, ctx->stream, B, ex.d_lam, ey.d_lam, ez.d_lam, nx, ny, nz, n,
+                           c_mass, c_lap, eps);
+        if (int e = transform_axis(ctx, 0, true, ex, B, Cb, nx, ny, nz))
+          return e;
+        if (int e = transform_axis(ctx, 1, true, ey, Cb, B, nx, ny, nz))
+          return e;
+        if (mask == 0u)
+          return transform_axis(ctx, 2, true, ez, B, dst, nx, ny, nz);
+        if (int e = transform_axis(ctx, 2, true, ez, B, Cb, nx, ny, nz))
+          return e;
+        hipLaunchKernelGGL(fdm_put_kernel, dim3(nb), dim3(256), 0, ctx->stream, dst, Cb, src, n, 1, 0, nx, ny, nz, mask, 1);
+        return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+      }
     for (int c = 0; c < fd.ncomp; c += nstack)
       {
         double        *w0 = F->w0, *w1 = F->w1;
