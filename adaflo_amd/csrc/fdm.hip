@@ -249,6 +249,11 @@ namespace adaflo_hip
       // index (fold = +1 / -1; the midpoint of an odd length counts once); the result is stored plainly (mirror = 0),
       // to an index and its mirror image nmirror-1-index (1), or added there / subtracted at the mirror image (2)
       int fold = 0, fold_on_A = 0, nfold = 0, mirror = 0, mirror_on_i = 0, nmirror = 0;
+      // scaling of the mode coefficients fused into the forward z transform (rows i = z modes, columns j = x + nx y, batch =
+      // stacked component): C *= 1 / (c_m + c_l (lx[x] + ly[y] + lz[i0 + i])), padding modes and the null mode give 0
+      const double *lx = nullptr, *ly = nullptr, *lz = nullptr;
+      int           scale = 0, scale_nx = 0, scale_i0 = 0;
+      double        scale_cm = 0., scale_cl = 0., scale_eps = 0.;
     };
     typedef double d4_t __attribute__((ext_vector_type(4)));
     // FM: 0 plain, 1 / 2 the field operand A / B is folded on load, 3 / 4 mirrored stores along j / i (GemmArgs)
@@ -278,7 +283,7 @@ namespace adaflo_hip
       // transform size (32: 30 % slower; 4: as 8; 3 or 4 tiles of 8 in flight: as 2; one wave per 48 x 48 tile with nine
       // accumulators and no workgroup barrier: 14 % slower).
       const bool    a_k_fast = g.csA == 1, b_j_fast = g.csB == 1;
-      constexpr bool fold_a = FM == 1, fold_b = FM == 2;
+      constexpr bool fold_a = FM == 1, fold_b = FM == 2 || FM == 6, scaled = FM == 5 || FM == 6;
       const double  fold_sign = g.fold;
       const int     fold_mid = (g.fold > 0 && (g.nfold & 1)) ? (g.nfold - 1) / 2 : -1;
       constexpr int LA = (TM * GK + NT - 1) / NT, LB = (TN * GK + NT - 1) / NT;
@@ -369,7 +374,13 @@ namespace adaflo_hip
               if (i < g.M && j < g.N)
                 {
                   const long idx = i * g.rsC + j * g.csC;
-                  if (FM < 3)
+                  if (scaled)
+                    {
+                      const double a = g.lx[j % g.scale_nx], b = g.ly[j / g.scale_nx], l = g.lz[g.scale_i0 + i];
+                      const double d = g.scale_cm + g.scale_cl * (a + b + l);
+                      C[idx] = (a < 0. || b < 0. || l < 0. || std::abs(d) <= g.scale_eps) ? 0. : acc[r][c][q] / d;
+                    }
+                  else if (FM < 3)
                     C[idx] = acc[r][c][q];
                   else
                     {
@@ -397,7 +408,7 @@ namespace adaflo_hip
       auto tile = [](const int n) { return (n + 47) / 48 * 48 < (n + 63) / 64 * 64 ? 48 : 64; };
       const int  tm = tile(g.M), tn = tile(g.N);
       const dim3 grid((g.N + tn - 1) / tn, (g.M + tm - 1) / tm, batch);
-      const int fm = g.fold != 0 ? (g.fold_on_A ? 1 : 2) : (g.mirror != 0 ? (g.mirror_on_i ? 4 : 3) : 0);
+      const int fm = g.scale ? (g.fold != 0 ? 6 : 5) : (g.fold != 0 ? (g.fold_on_A ? 1 : 2) : (g.mirror != 0 ? (g.mirror_on_i ? 4 : 3) : 0));
 #define FDM_GEMM(FM)                                                                                                  \
   {                                                                                                                   \
     if (tm == 64 && tn == 64)                                                                                         \
@@ -419,27 +430,17 @@ namespace adaflo_hip
             FDM_GEMM(2) break;
           case 3:
             FDM_GEMM(3) break;
-          default:
+          case 4:
             FDM_GEMM(4) break;
+          case 5:
+            FDM_GEMM(5) break;
+          default:
+            FDM_GEMM(6) break;
         }
 #undef FDM_GEMM
       return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
     }
 
-    // w[z][y][x] *= 1 / (c_m + c_l (lx + ly + lz)); padding modes and the null mode give 0
-    __global__ __launch_bounds__(256) void fdm_scale_kernel(double *__restrict__ w, const double *__restrict__ lx,
-                                                            const double *__restrict__ ly, const double *__restrict__ lz,
-                                                            const int nx, const int ny, const int nz, const long n,
-                                                            const double cm, const double cl, const double eps)
-    {
-      for (long t = blockIdx.x * 256L + threadIdx.x; t < n; t += (long)gridDim.x * 256)
-        {
-          const int    x = t % nx, y = (t / nx) % ny, z = (t / ((long)nx * ny)) % nz; // (components stacked along z)
-          const double a = lx[x], b = ly[y], c = lz[z];
-          const double d = cm + cl * (a + b + c);
-          w[t]           = (a < 0. || b < 0. || c < 0. || std::abs(d) <= eps) ? 0. : w[t] / d;
-        }
-    }
 
     // scalar field <- component c of an interleaved vector, and back (constrained rows: dst = src)
     __global__ __launch_bounds__(256) void fdm_take_kernel(double *__restrict__ w, const double *__restrict__ v,
@@ -658,8 +659,13 @@ namespace adaflo_hip
   // folded (Eig1D): forward, the even modes see w_j + w_{n-1-j} and the odd ones w_j - w_{n-1-j} for j in the lower
   // half only; backward, the even and the odd sums u_e, u_o of the lower half give w_j = u_e + u_o and
   // w_{n-1-j} = u_e - u_o.  Two launches of a quarter of the flops each.
+  struct ModeScaling // w *= 1 / (c_m + c_l (lx + ly + lz)), padding modes and the null mode give 0: epilogue of the forward z transform
+  {
+    const double *lx, *ly, *lz;
+    double        cm, cl, eps;
+  };
   static int transform_axis(adaflo_ctx *ctx, const int axis, const bool backward, const Eig1D &E, const double *in, double *out,
-                            const int nx, const int ny, const int nz, const int nstack = 1)
+                            const int nx, const int ny, const int nz, const int nstack = 1, const ModeScaling *sc = nullptr)
   {
     // (directions of 129 nodes: a loss on the 65 x 65 x 129 pressure grid, where a launch is 10-16 us whatever it computes)
     const int FOLD_MIN = (long)nx * ny * nz * nstack >= 4000000 ? 96 : 192;
@@ -690,6 +696,12 @@ namespace adaflo_hip
         g.B = in, g.rsB = (long)nx * ny, g.csB = 1, g.bsB = (long)nx * ny * nz;
         g.C = out, g.rsC = (long)nx * ny, g.csC = 1, g.bsC = (long)nx * ny * nz;
         batch = nstack;
+        if (sc && !backward)
+          {
+            g.scale = 1, g.scale_nx = nx, g.scale_i0 = 0;
+            g.lx = sc->lx, g.ly = sc->ly, g.lz = sc->lz;
+            g.scale_cm = sc->cm, g.scale_cl = sc->cl, g.scale_eps = sc->eps;
+          }
       }
     static const bool no_fold = getenv("ADAFLO_FDM_NO_FOLD") != nullptr; // (tests / timing of the plain transforms)
     if (!E.sym || n < FOLD_MIN || no_fold)
@@ -723,6 +735,7 @@ namespace adaflo_hip
         if (!backward)
           {
             h.fold = part == 0 ? 1 : -1, h.fold_on_A = axis == 0, h.nfold = n;
+            h.scale_i0 = o_out; // (rows of this launch are the modes o_out ...)
           }
         else
           {
@@ -768,10 +781,9 @@ namespace adaflo_hip
           return e;
         if (int e = transform_axis(ctx, 1, false, ey, B, Cb, nx, ny, nz))
           return e;
-        if (int e = transform_axis(ctx, 2, false, ez, Cb, B, nx, ny, nz))
+        const ModeScaling sc{ex.d_lam, ey.d_lam, ez.d_lam, c_mass, c_lap, eps};
+        if (int e = transform_axis(ctx, 2, false, ez, Cb, B, nx, ny, nz, 1, &sc))
           return e;
-        hipLaunchKernelGGL(fdm_scale_kernel, dim3(nb), dim3(256), 0, ctx->stream, B, ex.d_lam, ey.d_lam, ez.d_lam, nx, ny, nz, n,
-                           c_mass, c_lap, eps);
         if (int e = transform_axis(ctx, 0, true, ex, B, Cb, nx, ny, nz))
           return e;
         if (int e = transform_axis(ctx, 1, true, ey, Cb, B, nx, ny, nz))
@@ -799,11 +811,9 @@ namespace adaflo_hip
               return e;
             if (int e = transform_axis(ctx, 1, dir == 1, ey, w1, w0, nx, ny, nz, nstack))
               return e;
-            if (int e = transform_axis(ctx, 2, dir == 1, ez, w0, w1, nx, ny, nz, nstack))
+            const ModeScaling sc{ex.d_lam, ey.d_lam, ez.d_lam, c_mass, c_lap, eps};
+            if (int e = transform_axis(ctx, 2, dir == 1, ez, w0, w1, nx, ny, nz, nstack, dir == 0 ? &sc : nullptr))
               return e;
-            if (dir == 0)
-              hipLaunchKernelGGL(fdm_scale_kernel, dim3(nbs), dim3(256), 0, ctx->stream, w1, ex.d_lam, ey.d_lam, ez.d_lam, nx,
-                                 ny, nz, ns, c_mass, c_lap, eps);
             std::swap(w0, w1); // the result of this direction is the input of the next
           }
         if (together)
