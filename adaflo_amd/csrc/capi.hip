@@ -141,6 +141,7 @@ namespace
     if (int e = q2_unconvert_state(ctx, ctx->lin.p, ctx->lin_q2.p, ctx->lin_q2_mode))
       return e;
     ctx->lin_generic_valid = true;
+    ctx->lin_gen++;
     return 0;
   }
   int ensure_lin_prec_generic(adaflo_ctx *ctx)
@@ -318,7 +319,8 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
                           &ctx->q1_slab, &ctx->q1_zslab, &ctx->pc_inv_u, &ctx->pc_inv_pm, &ctx->pc_inv_pl,
                           &ctx->pc_ones_p, &ctx->pc_tmp_u, &ctx->pc_tmp_p, &ctx->pc_tmp_p2, &ctx->pc_work, &ctx->kr_work, &ctx->kr_basis, &ctx->kr_scalars,
                           &ctx->q1_poisson_coef, &ctx->ho_tab, &ctx->res_sum_u, &ctx->res_sum_p, &ctx->res_old,
-                          &ctx->ls_art_visc, &ctx->ls_stab_vel_sum, &ctx->ls_stab_ls_sum})
+                          &ctx->ls_art_visc, &ctx->ls_stab_vel_sum, &ctx->ls_stab_ls_sum, &ctx->hox_lin, &ctx->hox_lin_prec,
+                          &ctx->hox_slab_u, &ctx->hox_xslab_u, &ctx->hox_slab_p, &ctx->hox_xslab_p, &ctx->hox_tab})
     release(*b);
   for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch,
                     ctx->d_tab_ls, ctx->d_ls_diag, ctx->d_tab_force, ctx->d_tab_maxvel})
@@ -327,6 +329,8 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
   fdm_destroy(ctx);
   if (ctx->q2_wg_list)
     (void)hipFree(ctx->q2_wg_list);
+  if (ctx->hox_wg_list)
+    (void)hipFree(ctx->hox_wg_list);
   if (ctx->h_result)
     (void)hipHostFree(ctx->h_result);
   if (ctx->gs_host)
@@ -451,6 +455,7 @@ int adaflo_ns_set_linearization(adaflo_ctx *ctx, const double *lin, int src_on_d
       "state re-layout failed");
   ctx->lin_q2_valid      = false;
   ctx->lin_generic_valid = true;
+  ctx->lin_gen++;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (staging)
     (void)hipFree(staging);
@@ -541,6 +546,7 @@ int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx)
   if (!streaming_only)
     TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
   ctx->lin_prec_generic_valid = !streaming_only;
+  ctx->lin_prec_gen++;
   for (int i = streaming_only ? 1 : 0; i < 4; ++i)
     {
       TRY(ctx, alloc(ctx, *dst[i], src[i]->count), ctx->last_error);
@@ -592,7 +598,11 @@ int adaflo_ns_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double 
     {
       TRY(ctx, launch_ns_vmult_q2(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p), "Q2 kernel launch failed");
     }
-  else if (ho_supported(ctx) && (ctx->variant == 2 || (ctx->variant == 1 && ctx->k <= 4))) // ns_ho.hip
+  else if (ctx->variant == 1 && hox_supported(ctx)) // ns_hox.hip: x-marching kernel (round 4)
+    {
+      TRY(ctx, launch_ns_vmult_hox(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p), "x-marching kernel launch failed");
+    }
+  else if (ctx->variant == 2 && ho_supported(ctx)) // ns_ho.hip: z-sweep kernel of round 2, kept for comparison
     {
       TRY(ctx, launch_ns_vmult_ho(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p), "sweep kernel launch failed");
     }
@@ -624,7 +634,7 @@ int adaflo_ns_supports_phases(adaflo_ctx *ctx)
     return 0;
   if (ctx->variant >= 1 && q2_supported(ctx))
     return 1;
-  return ho_supported(ctx) && (ctx->variant == 2 || (ctx->variant == 1 && ctx->k <= 4)) ? 1 : 0;
+  return (ctx->variant == 1 && hox_supported(ctx)) || (ctx->variant == 2 && ho_supported(ctx)) ? 1 : 0;
 }
 
 int adaflo_ns_vmult_phase(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double *src_u,
@@ -643,6 +653,11 @@ int adaflo_ns_vmult_phase(adaflo_ctx *ctx, double *dst_u, double *dst_p, const d
     {
       TRY(ctx, launch_ns_vmult_q2(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p, phase, interface_faces),
           "Q2 kernel launch failed");
+    }
+  else if (ctx->variant == 1)
+    {
+      TRY(ctx, launch_ns_vmult_hox(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p, phase, interface_faces),
+          "x-marching kernel launch failed");
     }
   else
     {
@@ -691,6 +706,7 @@ int adaflo_ns_residual(adaflo_ctx *ctx, double *rhs_u, double *rhs_p, const doub
     {
       TRY(ctx, alloc(ctx, ctx->lin, (size_t)ctx->n_cells * ctx->nq_u * NLIN), ctx->last_error);
       ctx->lin_generic_valid = true;
+      ctx->lin_gen++;
     }
   NSArgs a   = make_ns_args(ctx, false);
   a.src_u    = src_u;
@@ -722,7 +738,13 @@ int adaflo_ns_velocity_vmult(adaflo_ctx *ctx, double *dst_u, const double *src_u
           "Q2 kernel launch failed");
       return 0;
     }
-  if (ho_supported(ctx) && (ctx->variant == 2 || (ctx->variant == 1 && ctx->k <= 4)) && !ctx->rho_prec.p)
+  if (ctx->variant == 1 && hox_supported(ctx) && !ctx->rho_prec.p)
+    {
+      TRY(ctx, launch_ns_vmult_hox(ctx, OP_VMULT_VELOCITY, dst_u, nullptr, src_u, nullptr),
+          "x-marching kernel launch failed");
+      return 0;
+    }
+  if (ctx->variant == 2 && ho_supported(ctx) && !ctx->rho_prec.p)
     {
       TRY(ctx, launch_ns_vmult_ho(ctx, OP_VMULT_VELOCITY, dst_u, nullptr, src_u, nullptr),
           "sweep kernel launch failed");

@@ -116,6 +116,15 @@ struct adaflo_ctx
   adaflo_hip::DeviceBuffer lin_q2, lin_q2_prec;
   adaflo_hip::DeviceBuffer q2_slab_u, q2_zslab_u, q2_slab_p, q2_zslab_p; // seam partial sums
   adaflo_hip::DeviceBuffer ho_tab;                                        // 1D tables of the Q3..Q5 sweep kernel
+  // x-marching Q3..Q5 kernel (ns_hox.hip): streaming copies of the (frozen) linearisation state and the generation
+  // of the generic copy they were converted from, seam slabs, 1D tables, workgroup list of the phased schedule
+  adaflo_hip::DeviceBuffer hox_lin, hox_lin_prec, hox_slab_u, hox_xslab_u, hox_slab_p, hox_xslab_p, hox_tab;
+  unsigned long            lin_gen = 1, lin_prec_gen = 1, hox_lin_gen = 0, hox_lin_prec_gen = 0;
+  int                      hox_lin_mode = -1, hox_lin_prec_mode = -1;
+  int                      hox_lx = 0; // x-chunk length override (0 = heuristic)
+  int                     *hox_wg_list = nullptr;
+  long                     hox_wg_key[4] = {0, 0, 0, 0};
+  int                      hox_wg_counts[3] = {0, 0, 0};
   int                     *q2_wg_list = nullptr;     // [interface | interior A | interior B] workgroups
   long                     q2_wg_key[4] = {0, 0, 0, 0};
   int                      q2_wg_counts[3] = {0, 0, 0};

@@ -1,0 +1,282 @@
+// ns_hox.hip -- host side of the x-marching Taylor-Hood Q_k/Q_{k-1} kernel (k = 3, 4, 5); the device source
+// and the description of the decomposition are in ns_hox_kernel.hpp.
+// NavierStokesMatrix::vmult / velocity_vmult with constant coefficients
+// (source/navier_stokes_matrix.cc:221-262, 337-382, 601-916).
+#include "basis.hpp"
+#include "kernels.hpp"
+
+#include <cstring>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "hox_intrin.hpp"
+#include "ns_hox_kernel.hpp"
+
+namespace adaflo_hip
+{
+  namespace
+  {
+    using namespace hox;
+
+    int ensure(DeviceBuffer &b, const size_t need)
+    {
+      if (b.count >= need)
+        return 0;
+      if (b.p)
+        (void)hipFree(b.p);
+      b.p     = nullptr;
+      b.count = 0;
+      if (hipMalloc(&b.p, need * sizeof(double)) != hipSuccess)
+        return ADAFLO_ENOMEM;
+      b.count = need;
+      return 0;
+    }
+
+    int lin_mode_of(const adaflo_ctx *ctx)
+    {
+      const NSDev &P = ctx->ns;
+      if (P.physical_type == ADAFLO_STOKES || P.linearization == ADAFLO_COUPLED_VELOCITY_EXPLICIT)
+        return 2;
+      return P.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON ? 0 : 1;
+    }
+
+    template <int K>
+    size_t state_doubles(const adaflo_ctx *ctx, const int lin_mode)
+    {
+      using G         = Geo<K>;
+      const size_t ngy = (ctx->desc.ncell[1] + G::CWY - 1) / G::CWY, ngz = (ctx->desc.ncell[2] + G::CWZ - 1) / G::CWZ;
+      return ngz * ngy * (size_t)ctx->desc.ncell[0] * G::N * (nst_of(lin_mode) / 2) * G::CPW * G::NL * 2;
+    }
+
+    // streaming copy of the (frozen) linearisation state, rebuilt when the generic copy it was made from changed
+    template <int K>
+    int prepare_state(adaflo_ctx *ctx, const bool prec, const int lin_mode, const double **out)
+    {
+      using G = Geo<K>;
+      *out    = nullptr;
+      if (lin_mode == 2)
+        return 0;
+      const bool          use_prec = prec && ctx->lin_prec.p;
+      const DeviceBuffer &gen      = use_prec ? ctx->lin_prec : ctx->lin;
+      DeviceBuffer       &str      = use_prec ? ctx->hox_lin_prec : ctx->hox_lin;
+      unsigned long      &have     = use_prec ? ctx->hox_lin_prec_gen : ctx->hox_lin_gen;
+      int                &mode     = use_prec ? ctx->hox_lin_prec_mode : ctx->hox_lin_mode;
+      const unsigned long want     = use_prec ? ctx->lin_prec_gen : ctx->lin_gen;
+      if (!gen.p)
+        return ADAFLO_ENOTINIT;
+      const size_t need = state_doubles<K>(ctx, lin_mode);
+      if (str.p && have == want && mode == lin_mode && str.count >= need)
+        {
+          *out = str.p;
+          return 0;
+        }
+      if (int e = ensure(str, need))
+        return e;
+      const int  ncx = ctx->desc.ncell[0], ncy = ctx->desc.ncell[1], ncz = ctx->desc.ncell[2];
+      const int  ngy = (ncy + G::CWY - 1) / G::CWY, ngz = (ncz + G::CWZ - 1) / G::CWZ;
+      const long pieces = (long)(need / 2);
+      long       nb     = (pieces + 255) / 256;
+      if (nb > 256 * 64)
+        nb = 256 * 64;
+      hipLaunchKernelGGL((hox_convert_state_kernel<K>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, str.p, gen.p, ncx, ncy,
+                         ncz, ngy, ngz, nst_of(lin_mode) / 2);
+      if (hipGetLastError() != hipSuccess)
+        return ADAFLO_EHIP;
+      have = want;
+      mode = lin_mode;
+      *out = str.p;
+      return 0;
+    }
+
+    // phase -1: the whole operator; phases 0 / 1 / 2 as in launch_ns_vmult_q2 (ns_q2.hip)
+    template <int K>
+    int launch_hox(adaflo_ctx *ctx, const int op, double *dst_u, double *dst_p, const double *src_u, const double *src_p,
+                   const int phase, const uint32_t iface)
+    {
+      using G         = Geo<K>;
+      constexpr int N = K + 1, NP = K;
+      HXArgs        A{};
+      const int     lin_mode = lin_mode_of(ctx);
+      {
+        int lx = ctx->hox_lx > 0 ? ctx->hox_lx : 0;
+        if (lx == 0)
+          {
+            // as long as possible (fewer x seams), but at least ~1024 workgroups for the 256 CUs
+            const long tiles = (long)((ctx->desc.ncell[1] + G::CY - 1) / G::CY) * ((ctx->desc.ncell[2] + G::CZ - 1) / G::CZ);
+            lx               = ctx->desc.ncell[0];
+            while (lx > 4 && tiles * ((ctx->desc.ncell[0] + lx - 1) / lx) < 1024)
+              lx = (lx + 1) / 2;
+          }
+        hox_geometry<K>(A, ctx->desc.ncell, lx);
+      }
+      if ((size_t)A.nnx * A.nny * A.nnz * 3 >= ((size_t)1 << 32))
+        return ADAFLO_EUNSUPPORTED; // 32-bit row offsets
+      std::vector<double> tab;
+      {
+        const Quadrature1D        qu = gauss(N);
+        const Shape1D             su = shape_fe_q(K, qu), sp = shape_fe_q(K - 1, qu);
+        const std::vector<double> dc = collocation_derivative(qu);
+        for (int q = 0; q < N; ++q)
+          A.w[q] = qu.w[q];
+        for (int q = 0; q < N * N; ++q)
+          tab.push_back(su.S[q]);
+        for (int q = 0; q < N * N; ++q)
+          tab.push_back(dc[q]);
+        for (int q = 0; q < N * NP; ++q)
+          tab.push_back(sp.S[q]);
+      }
+      if (!ctx->hox_tab.p)
+        {
+          if (int e = ensure(ctx->hox_tab, tab.size()))
+            return e;
+          if (copy_to_device_now(ctx->hox_tab.p, tab.data(), tab.size() * sizeof(double)) != hipSuccess)
+            return ADAFLO_EHIP;
+        }
+      A.tab = ctx->hox_tab.p;
+      for (int e = 0; e < 3; ++e)
+        A.ih[e] = 1. / ctx->desc.h[e];
+      A.det = ctx->desc.h[0] * ctx->desc.h[1] * ctx->desc.h[2];
+      const NSDev &P      = ctx->ns;
+      const bool   stokes = P.physical_type == ADAFLO_STOKES;
+      const double gamma  = P.physical_type == ADAFLO_INCOMPRESSIBLE ? P.weight : 0.;
+      A.cA          = stokes ? 0. : gamma * P.density - P.damping; // :717,:827-835; Stokes: no value terms (:708)
+      A.cB          = stokes ? 0. : P.tau1 * P.density;
+      A.beta        = P.beta;
+      A.tau_gd      = P.tau_grad_div;
+      A.tmu         = P.viscosity * P.tau1; // :841-845
+      A.integrate_p = P.linearization != ADAFLO_PROJECTION;
+      A.con_u       = ctx->brick.con_u;
+      A.con_p       = ctx->brick.con_p;
+      A.src_u       = src_u;
+      A.src_p       = src_p;
+      A.dst_u       = dst_u;
+      A.dst_p       = dst_p;
+      if (int e = prepare_state<K>(ctx, op == OP_VMULT_VELOCITY, lin_mode, &A.lin))
+        return e;
+      const bool   with_p = op == OP_VMULT;
+      const size_t n_wg   = (size_t)A.tiles_y * A.tiles_z * A.n_chunks;
+      if (int e = ensure(ctx->hox_slab_u, n_wg * G::RIMU * (K * A.LX + 1) * 3))
+        return e;
+      if (int e = ensure(ctx->hox_xslab_u, n_wg * G::TNY * G::TNZ * 3))
+        return e;
+      if (int e = ensure(ctx->hox_slab_p, n_wg * G::RIMP * ((K - 1) * A.LX + 1)))
+        return e;
+      if (int e = ensure(ctx->hox_xslab_p, n_wg * G::TPY * G::TPZ))
+        return e;
+      A.slab_u  = ctx->hox_slab_u.p;
+      A.xslab_u = ctx->hox_xslab_u.p;
+      A.slab_p  = ctx->hox_slab_p.p;
+      A.xslab_p = ctx->hox_xslab_p.p;
+      if (with_p && !A.integrate_p && phase <= 0)
+        if (int e = launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, A.npx, A.npy, A.npz, A.con_p, -1., true))
+          return e;
+      long nwg = (long)n_wg;
+      if (phase >= 0)
+        {
+          // workgroup list [interface | interior A | interior B], cached per (grid, iface)
+          const long key[4] = {A.tiles_y, A.tiles_z, A.n_chunks, (long)iface};
+          if (!ctx->hox_wg_list || std::memcmp(key, ctx->hox_wg_key, sizeof(key)) != 0)
+            {
+              std::vector<int> bnd;
+              hox_wg_lists(A, iface, bnd, ctx->hox_wg_counts);
+              if (ctx->hox_wg_list)
+                (void)hipFree(ctx->hox_wg_list);
+              ctx->hox_wg_list = nullptr;
+              if (hipMalloc(&ctx->hox_wg_list, sizeof(int) * (bnd.size() + 1)) != hipSuccess)
+                return ADAFLO_ENOMEM;
+              if (copy_to_device_now(ctx->hox_wg_list, bnd.data(), sizeof(int) * bnd.size()) != hipSuccess)
+                return ADAFLO_EHIP;
+              std::memcpy(ctx->hox_wg_key, key, sizeof(key));
+            }
+          const int nb = ctx->hox_wg_counts[0], na = ctx->hox_wg_counts[1], nc = ctx->hox_wg_counts[2];
+          A.wg_list   = ctx->hox_wg_list;
+          A.wg_offset = phase == 1 ? 0 : (phase == 0 ? nb : nb + na);
+          A.wg_count  = phase == 1 ? nb : (phase == 0 ? na : nc);
+          A.fix_mode  = phase; // 1: interface nodes, 2: the others (phase 0 runs no fix-up)
+          A.iface     = iface;
+          nwg         = A.wg_count;
+        }
+      const size_t lds_bytes = sizeof(double) * (size_t)G::LDS_DOUBLES;
+      const dim3   grid((unsigned)(nwg > 0 ? nwg : 1)), block(NTH);
+      hipError_t   err  = hipSuccess;
+      hipEvent_t   stop = (ctx->timing && nwg > 0) ? ctx->kernel_timer.start(ctx->stream) : nullptr;
+#define HOX_LAUNCH(LM, WP)                                                                                \
+  {                                                                                                       \
+    static bool attr_set = false;                                                                         \
+    if (!attr_set)                                                                                        \
+      {                                                                                                   \
+        err      = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_hox_kernel<K, LM, WP>),         \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);      \
+        attr_set = err == hipSuccess;                                                                     \
+      }                                                                                                   \
+    if (err == hipSuccess && nwg > 0)                                                                     \
+      hipLaunchKernelGGL((ns_hox_kernel<K, LM, WP>), grid, block, lds_bytes, ctx->stream, A);             \
+  }
+      if (with_p)
+        switch (lin_mode)
+          {
+            case 0:
+              HOX_LAUNCH(0, true);
+              break;
+            case 1:
+              HOX_LAUNCH(1, true);
+              break;
+            default:
+              HOX_LAUNCH(2, true);
+          }
+      else
+        switch (lin_mode)
+          {
+            case 0:
+              HOX_LAUNCH(0, false);
+              break;
+            case 1:
+              HOX_LAUNCH(1, false);
+              break;
+            default:
+              HOX_LAUNCH(2, false);
+          }
+#undef HOX_LAUNCH
+      if (err != hipSuccess)
+        return ADAFLO_EHIP;
+      if (stop)
+        (void)hipEventRecord(stop, ctx->stream);
+      if (phase == -1 || phase == 1)
+        ctx->kernel_timer.count++;
+      if (phase == 0)
+        return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+      const bool fix_p = with_p && A.integrate_p;
+      const long items = hox_fix_items(A, fix_p);
+      if (items > 0)
+        {
+          long nb = (items + 255) / 256;
+          if (nb > 256 * 32)
+            nb = 256 * 32;
+          hipLaunchKernelGGL((ns_hox_fixup_kernel<K>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, A, fix_p ? 1 : 0);
+        }
+      return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+    }
+  } // namespace
+
+  bool hox_supported(const adaflo_ctx *ctx)
+  {
+    return ctx->k >= 3 && ctx->k <= 5 && !ctx->rho.p && !ctx->mu.p && !ctx->damp.p;
+  }
+
+  int launch_ns_vmult_hox(adaflo_ctx *ctx, const int op, double *dst_u, double *dst_p, const double *src_u,
+                          const double *src_p, const int phase, const uint32_t iface)
+  {
+    switch (ctx->k)
+      {
+        case 3:
+          return launch_hox<3>(ctx, op, dst_u, dst_p, src_u, src_p, phase, iface);
+        case 4:
+          return launch_hox<4>(ctx, op, dst_u, dst_p, src_u, src_p, phase, iface);
+        case 5:
+          return launch_hox<5>(ctx, op, dst_u, dst_p, src_u, src_p, phase, iface);
+        default:
+          return ADAFLO_EUNSUPPORTED;
+      }
+  }
+} // namespace adaflo_hip

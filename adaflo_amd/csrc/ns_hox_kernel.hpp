@@ -1,0 +1,889 @@
+// ns_hox_kernel.hpp -- device source of the x-marching Taylor-Hood Q_k/Q_{k-1} kernel (k = 3, 4, 5):
+// NavierStokesMatrix::vmult / velocity_vmult with constant coefficients
+// (source/navier_stokes_matrix.cc:601-916, vmult and vmult_velocity branches of local_operation).
+//
+// Round-4 decomposition.  The round-2 kernel (ns_ho.hip) keeps a z-line per lane and
+// lets lane (a,b) read the x- / y-line it needs for EVERY output it produces: (k+1) LDS reads per output,
+// ~1000 ds_read_b64 per lane and cell layer -- the LDS pipe and the ~60 dependent exchanges bound it at a
+// third of the HBM roofline.  Here a lane owns a whole LINE in the direction that is being contracted:
+//   * x-layout: lane (j,k) holds the (k+1) values of its x-line in registers and applies the 1D matrix to
+//     them with wave-uniform coefficients (scalar registers): (k+1)^2 FMAs for (k+1) LDS reads;
+//   * between two directions the data are TRANSPOSED through a wave-private LDS buffer: every lane writes
+//     its line and reads the line of the next direction -- (k+1) writes + (k+1) reads per lane and direction.
+//     One wave's LDS operations execute in order, so the transpositions need no s_barrier;
+//   * per component: x interpolation in registers, y, z (values at the Gauss points), collocation
+//     derivative in z, then y, then x; the x-layout lane ends up with value and gradient of its (k+1)
+//     quadrature points; the integration is the transposed chain.  55 + 60 LDS operations per lane and
+//     component instead of ~300;
+//   * the workgroup (4 waves) owns a CY x CZ cross-section of cells and MARCHES ALONG X: the x-face shared
+//     by consecutive cells is carried in registers, every lane reads a contiguous run of (k+1) nodes x 3
+//     components of src and writes k nodes x 3 components of dst (96 B for k = 4).  Nodes shared between the
+//     cells of the cross-section are combined through an LDS publish area (one workgroup barrier per step),
+//     nodes shared between workgroups go through slabs + a fix-up kernel: all y/z seams are ROWS CONTIGUOUS IN
+//     X (the round-2 tiles had x-seams: 24 useful bytes per 128-B line), no atomics, bitwise reproducible;
+//   * the linearisation state is streamed in a layout of its own, [cell group][cx][i][piece][cell][line][2]:
+//     one 16-byte load per lane, piece and quadrature point, consecutive lanes consecutive addresses.
+//
+// This header contains only device code written against the primitives of hox_intrin.hpp; it includes nothing
+// itself so that tests/emu can run the same source on the host lane emulator.
+#pragma once
+
+namespace adaflo_hip
+{
+  namespace hox
+  {
+    constexpr int NTH  = 256;
+    constexpr int NMAX = 6;
+    constexpr int NLIN_ = 12;
+
+    // cells per wave (CWY x CWZ) and waves of the workgroup (WY x WZ) over the y-z cross-section
+    template <int K>
+    struct Cfg;
+    template <>
+    struct Cfg<3>
+    {
+      static constexpr int CWY = 2, CWZ = 2, WY = 2, WZ = 2;
+    };
+    template <>
+    struct Cfg<4>
+    {
+      static constexpr int CWY = 2, CWZ = 1, WY = 1, WZ = 4;
+    };
+    template <>
+    struct Cfg<5>
+    {
+      static constexpr int CWY = 1, CWZ = 1, WY = 2, WZ = 2;
+    };
+
+    template <int K>
+    struct Geo
+    {
+      using C                  = Cfg<K>;
+      static constexpr int N   = K + 1, NP = K, KP = K - 1, NL = N * N, N3 = N * N * N;
+      static constexpr int CWY = C::CWY, CWZ = C::CWZ, WY = C::WY, WZ = C::WZ;
+      static constexpr int CPW = CWY * CWZ, PL = 64 / CPW; // cells per wave, lanes per cell slot
+      static constexpr int CY = CWY * WY, CZ = CWZ * WZ, NCELL = CY * CZ;
+      static constexpr int TNY = K * CY + 1, TNZ = K * CZ + 1, TPY = KP * CY + 1, TPZ = KP * CZ + 1;
+      static constexpr int RIMU = TNY + TNZ - 1, RIMP = TPY + TPZ - 1;
+      static constexpr int BUF  = CPW * N3;        // one transposition buffer of a wave (doubles)
+      static constexpr int WAVE = 3 * BUF;         // three buffers per wave
+      static constexpr int PUBD = NCELL * N * 4 * K; // publish area of one direction (doubles)
+      static constexpr int PUBSZ = 2 * PUBD;       // [Y | Z]
+      static constexpr int LDS_DOUBLES = 4 * WAVE + 2 * PUBSZ;
+      static_assert(NL <= PL, "cell does not fit its lane slot");
+      static_assert(WY * WZ == 4, "four waves per workgroup");
+    };
+
+    // number of doubles of state per quadrature point the kernel reads
+    constexpr int nst_of(const int lin_mode)
+    {
+      return lin_mode == 0 ? 12 : (lin_mode == 1 ? 4 : 0);
+    }
+
+    struct HXArgs
+    {
+      int    ncx, ncy, ncz, nnx, nny, nnz, npx, npy, npz, tiles_y, tiles_z, LX, n_chunks, ngy, ngz;
+      double w[NMAX];
+      double ih[3], det, cA, cB, beta, tau_gd, tmu;
+      int    integrate_p;
+      uint32_t con_u, con_p;
+      const double *src_u, *src_p, *lin; // lin: streaming layout of this kernel (hox_state_offset)
+      double       *dst_u, *dst_p;
+      double       *slab_u, *xslab_u, *slab_p, *xslab_p;
+      const double *tab; // [S N*N | D N*N | Sp N*NP]: S[q][i] nodal -> Gauss, D collocation derivative, Sp pressure
+      // phased execution for the multi-GPU overlap (as in ns_q2.hip / ns_ho.hip)
+      const int *wg_list;
+      int        wg_offset, wg_count, fix_mode;
+      uint32_t   iface;
+    };
+
+    // mesh-dependent integers of the launch (host)
+    template <int K>
+    inline void hox_geometry(HXArgs &A, const int ncell[3], const int lx)
+    {
+      using G = Geo<K>;
+      A.ncx   = ncell[0];
+      A.ncy   = ncell[1];
+      A.ncz   = ncell[2];
+      A.nnx   = K * A.ncx + 1;
+      A.nny   = K * A.ncy + 1;
+      A.nnz   = K * A.ncz + 1;
+      A.npx   = (K - 1) * A.ncx + 1;
+      A.npy   = (K - 1) * A.ncy + 1;
+      A.npz   = (K - 1) * A.ncz + 1;
+      A.tiles_y  = (A.ncy + G::CY - 1) / G::CY;
+      A.tiles_z  = (A.ncz + G::CZ - 1) / G::CZ;
+      A.LX       = lx < 1 ? 1 : (lx > A.ncx ? A.ncx : lx);
+      A.n_chunks = (A.ncx + A.LX - 1) / A.LX;
+      A.ngy      = (A.ncy + G::CWY - 1) / G::CWY;
+      A.ngz      = (A.ncz + G::CWZ - 1) / G::CWZ;
+    }
+
+    // workgroup list [interface | interior A | interior B] of the phased schedule (host): a workgroup is "interface"
+    // if its chunk / cross-section touches one of the brick faces `iface` (bit 2 d + side)
+    inline void hox_wg_lists(const HXArgs &A, const uint32_t iface, std::vector<int> &list, int counts[3])
+    {
+      std::vector<int> bnd, inner;
+      for (int bz = 0; bz < A.tiles_z; ++bz)
+        for (int by = 0; by < A.tiles_y; ++by)
+          for (int bx = 0; bx < A.n_chunks; ++bx)
+            {
+              const bool b = (bx == 0 && (iface & 1u)) || (bx == A.n_chunks - 1 && (iface & 2u)) || (by == 0 && (iface & 4u)) ||
+                             (by == A.tiles_y - 1 && (iface & 8u)) || (bz == 0 && (iface & 16u)) ||
+                             (bz == A.tiles_z - 1 && (iface & 32u));
+              (b ? bnd : inner).push_back((bz * A.tiles_y + by) * A.n_chunks + bx);
+            }
+      counts[0] = (int)bnd.size();
+      counts[1] = (int)(inner.size() / 2);
+      counts[2] = (int)(inner.size() - inner.size() / 2);
+      list      = bnd;
+      list.insert(list.end(), inner.begin(), inner.end());
+    }
+    // number of work items of the fix-up pass
+    inline long hox_fix_items(const HXArgs &A, const bool with_p)
+    {
+      long items = 0;
+      for (int space = 0; space < (with_p ? 2 : 1); ++space)
+        {
+          const long nx = space ? A.npx : A.nnx, ny = space ? A.npy : A.nny, nz = space ? A.npz : A.nnz, nc = space ? 1 : 3;
+          const long it = ((long)(A.tiles_y - 1) * nz + (long)(A.tiles_z - 1) * ny) * nx * nc + (long)(A.n_chunks - 1) * ny * nz * nc;
+          items         = it > items ? it : items;
+        }
+      return items;
+    }
+
+    // rim line of the cross-section node grid (TY x TZ nodes): the high rim in y, then the high rim in z
+    template <int TY, int TZ>
+    __device__ __forceinline__ int rim_line(const int jl, const int kl)
+    {
+      return jl == TY - 1 ? kl : TZ + jl;
+    }
+
+    // position (in doubles) of the 16-byte piece `piece` of quadrature point (i, line l) of cell (cx, cy, cz) in
+    // the streaming state: [group gz][group gy][cx][i][piece][cell of the group][line][2]
+    template <int K>
+    __device__ __forceinline__ size_t hox_state_offset(const int ncx, const int ngy, const int npc, const int cx,
+                                                       const int cy, const int cz, const int i, const int piece,
+                                                       const int l)
+    {
+      using G           = Geo<K>;
+      const int    gy = cy / G::CWY, gz = cz / G::CWZ, scw = (cz % G::CWZ) * G::CWY + cy % G::CWY;
+      const size_t grp = (size_t)gz * ngy + gy;
+      return (((((grp * ncx + cx) * G::N + i) * npc + piece) * G::CPW + scw) * G::NL + l) * 2;
+    }
+
+    // ---- small dense helpers on register lines; M from scalar loads ----------------------------------------
+    // out[q] = sum_i M[q * NI + i] in[i]
+    template <int NQ, int NI>
+    __device__ __forceinline__ void mat_apply(const ctab_t M, const double (&in)[NI], double (&out)[NQ])
+    {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        {
+          double s = M[q * NI] * in[0];
+#pragma unroll
+          for (int i = 1; i < NI; ++i)
+            s += M[q * NI + i] * in[i];
+          out[q] = s;
+        }
+    }
+    // out[i] (+)= sum_q M[q * NI + i] in[q]
+    template <int NQ, int NI, bool ADD>
+    __device__ __forceinline__ void mat_apply_t(const ctab_t M, const double (&in)[NQ], double (&out)[NI])
+    {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        {
+          double s = ADD ? out[i] : 0.;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            s += M[q * NI + i] * in[q];
+          out[i] = s;
+        }
+    }
+    // x[m] = lds[addr + 8 (BOFF + m STRIDE)]
+    template <int BOFF, int STRIDE, int NM, int M = 0>
+    __device__ __forceinline__ void rd_line(const unsigned addr, double (&x)[NM])
+    {
+      if constexpr (M < NM)
+        {
+          x[M] = ds_rd<8 * (BOFF + M * STRIDE)>(addr);
+          rd_line<BOFF, STRIDE, NM, M + 1>(addr, x);
+        }
+    }
+    template <int BOFF, int STRIDE, int NM>
+    __device__ __forceinline__ void wr_line(double *const p, const double (&x)[NM])
+    {
+#pragma unroll
+      for (int m = 0; m < NM; ++m)
+        p[BOFF + m * STRIDE] = x[m];
+    }
+
+#ifndef HOX_LB
+#define HOX_LB 2
+#endif
+
+    template <int K, int LIN_MODE, bool WITH_P>
+    __global__ __launch_bounds__(NTH, HOX_LB) void ns_hox_kernel(const HXArgs A)
+    {
+      using G           = Geo<K>;
+      constexpr int N = G::N, NP = G::NP, KP = G::KP, NL = G::NL, N3 = G::N3, NN = N * N;
+      constexpr int CPW = G::CPW, PL = G::PL, CY = G::CY, CZ = G::CZ, CWY = G::CWY, CWZ = G::CWZ, WY = G::WY;
+      constexpr int TNY = G::TNY, TNZ = G::TNZ, TPY = G::TPY, TPZ = G::TPZ, RIMU = G::RIMU, RIMP = G::RIMP;
+      constexpr int BUF = G::BUF, PUBD = G::PUBD, PUBSZ = G::PUBSZ;
+      constexpr int NST = nst_of(LIN_MODE), NPC = NST / 2;
+      constexpr int TS = 0, TD = NN, TSP = 2 * NN; // table offsets
+      double *const lds = dyn_lds();
+
+      const int tid = threadIdx.x, lane = tid & 63;
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+      const int cw = lane / PL, l = lane % PL;
+      const bool active = l < NL;
+      const int  lc = active ? l : NL - 1; // lanes beyond the cell shadow its last lane
+      const int  a = lc % N, b = lc / N;
+      const int  cyl = (wave % WY) * CWY + cw % CWY, czl = (wave / WY) * CWZ + cw / CWY, cell = czl * CY + cyl;
+
+      const long nwg = A.wg_list ? (long)A.wg_count : (long)A.tiles_y * A.tiles_z * A.n_chunks;
+      long       wg  = xcd_remap(blockIdx.x, nwg);
+      if (A.wg_list)
+        wg = A.wg_list[A.wg_offset + wg];
+      const int bx = (int)(wg % A.n_chunks), bt = (int)(wg / A.n_chunks);
+      const int by = bt % A.tiles_y, bz = bt / A.tiles_y;
+      const int cx0 = bx * A.LX, ns = min(A.LX, A.ncx - cx0);
+      const int tcy = min(CY, A.ncy - by * CY), tcz = min(CZ, A.ncz - bz * CZ);
+      const bool cell_ok = cyl < tcy && czl < tcz, valid = active && cell_ok;
+      // cells outside the mesh compute on cell (0,0) of the cross-section: nothing of theirs is emitted and no
+      // valid cell collects from them; all addresses stay legal
+      const int  cy = by * CY + (cell_ok ? cyl : 0), cz = bz * CZ + (cell_ok ? czl : 0);
+      const bool lasty = cyl == tcy - 1, lastz = czl == tcz - 1;
+      const bool x_seam_end = cx0 + ns < A.ncx; // the chunk ends inside the mesh
+
+      // ---- x-layout roles of this lane: x-line (j,k) = (a,b) of its cell -------------------------------------
+      const int  J = K * cy + a, Kz = K * cz + b;
+      const int  jl = K * cyl + a, kl = K * czl + b;
+      const bool own_u  = valid && (a < K || lasty) && (b < K || lastz);
+      const bool seam_u = (a == K && J < A.nny - 1) || (b == K && Kz < A.nnz - 1); // (given own_u: high rim of the workgroup)
+      unsigned   cmask  = 0; // components constrained on the whole line (y / z faces)
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        if ((J == 0 && (A.con_u >> (6 + d) & 1)) || (J == A.nny - 1 && (A.con_u >> (9 + d) & 1)) ||
+            (Kz == 0 && (A.con_u >> (12 + d) & 1)) || (Kz == A.nnz - 1 && (A.con_u >> (15 + d) & 1)))
+          cmask |= 1u << d;
+      const bool pth = active && a < NP && b < NP;
+      const int  ap = min(a, KP), bp = min(b, KP);
+      const int  Jp = KP * cy + ap, Kp = KP * cz + bp;
+      const int  jlp = KP * cyl + ap, klp = KP * czl + bp;
+      const bool own_p  = valid && pth && (a < KP || lasty) && (b < KP || lastz);
+      const bool seam_p = (a == KP && Jp < A.npy - 1) || (b == KP && Kp < A.npz - 1);
+      const bool pcon   = (Jp == 0 && (A.con_p >> 2 & 1)) || (Jp == A.npy - 1 && (A.con_p >> 3 & 1)) ||
+                        (Kp == 0 && (A.con_p >> 4 & 1)) || (Kp == A.npz - 1 && (A.con_p >> 5 & 1));
+      // does this workgroup touch a constrained face at all (wave-uniform: guards the rare +-src stores)
+      const bool wg_con_yz = (by == 0 && ((A.con_u >> 6 & 7u) || (A.con_p >> 2 & 1u))) ||
+                             (by == A.tiles_y - 1 && ((A.con_u >> 9 & 7u) || (A.con_p >> 3 & 1u))) ||
+                             (bz == 0 && ((A.con_u >> 12 & 7u) || (A.con_p >> 4 & 1u))) ||
+                             (bz == A.tiles_z - 1 && ((A.con_u >> 15 & 7u) || (A.con_p >> 5 & 1u)));
+
+      enum
+      {
+        F_OWN_U = 1, F_SEAM_U = 2, F_CON0 = 4, F_OWN_P = 32, F_SEAM_P = 64, F_PCON = 128, F_CY = 256, F_CZ = 512,
+        F_AK = 1024, F_BK = 2048, F_PTH = 4096, F_AKP = 8192, F_BKP = 16384, F_ACT = 32768
+      };
+      const unsigned flags = (own_u ? F_OWN_U : 0) | (seam_u ? F_SEAM_U : 0) | (cmask * F_CON0) | (own_p ? F_OWN_P : 0) |
+                             (seam_p ? F_SEAM_P : 0) | (pcon ? F_PCON : 0) | ((active && a == 0 && cyl > 0) ? F_CY : 0) |
+                             ((active && b == 0 && czl > 0) ? F_CZ : 0) | ((active && a == K) ? F_AK : 0) |
+                             ((active && b == K) ? F_BK : 0) | (pth ? F_PTH : 0) | ((pth && a == KP) ? F_AKP : 0) |
+                             ((pth && b == KP) ? F_BKP : 0) | (active ? F_ACT : 0);
+
+      const double wab = A.det * A.w[a] * A.w[b];
+
+      // global rows: wave-uniform base pointer + 32-bit per-lane offset (doubles)
+      const unsigned urow = (unsigned)(((size_t)Kz * A.nny + J) * A.nnx * 3), prow = (unsigned)(((size_t)Kp * A.npy + Jp) * A.npx);
+      // state: per-lane pointer to the first piece of the first cell of my row of cell groups
+      const double *const stp = A.lin + (NST > 0 ? hox_state_offset<K>(A.ncx, A.ngy, NPC, 0, cy, cz, 0, 0, lc) : 0);
+      constexpr size_t ST_POINT = (size_t)NPC * CPW * NL * 2, ST_CELL = N * ST_POINT; // doubles per point / cell step
+
+      // wave-private transposition buffers T0, T1, T2 and the lane's line bases in the three layouts
+      double *const  WB  = lds + wave * G::WAVE + cw * N3;
+      double *const  px  = WB + N * a + NN * b; // x-line (., a, b): stride 1
+      double *const  py  = WB + a + NN * b;     // y-line (a, ., b): stride N
+      double *const  pz  = WB + a + N * b;      // z-line (a, b, .): stride N*N
+      const unsigned ax = lds_byte_addr(px), ay = lds_byte_addr(py), az = lds_byte_addr(pz);
+      double *const  PUB = lds + 4 * G::WAVE;   // [buffer 2][Y | Z][cell][line][4][K]
+
+      const ctab_t tab = as_ctab(A.tab);
+
+      // nodal x-lines of the step to come
+      double Un[3][N], Pn[NP];
+      auto   load_nodes = [&](const int cxn) {
+        const int     cxc = min(cxn, A.ncx - 1);
+        const double *pu  = A.src_u + (size_t)(K * cxc) * 3;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+          for (int d = 0; d < 3; ++d)
+            Un[d][i] = pu[urow + i * 3 + d];
+        if (WITH_P)
+          {
+            const double *pp = A.src_p + (size_t)(KP * cxc);
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+              Pn[i] = pp[prow + i];
+          }
+      };
+      double st[NST > 0 ? NST : 1];
+      auto   load_state = [&](const double *p) {
+#pragma unroll
+        for (int e = 0; e < NPC; ++e)
+          {
+            st[2 * e]     = p[e * (CPW * NL * 2)];
+            st[2 * e + 1] = p[e * (CPW * NL * 2) + 1];
+          }
+      };
+
+      // ---- combine the partial sums of the cross-section per owned line, emit NV nodes -------------------------
+      // R / Rp: the lane's x-line sums, nodes 0 .. NV-1 (NVP-1) are final in x.  I0 / Ip0: global x index of
+      // node 0; xl0: its index inside the chunk; endplane: the nodes form the chunk's last plane
+      auto combine = [&](auto nv_, auto nvp_, double (&R)[3][N], double (&Rp)[NP], const unsigned fl, const int parity,
+                         const int I0, const int Ip0, const int xl0, const int xlp0, const bool endplane) {
+        constexpr int NV = decltype(nv_)::value, NVP = decltype(nvp_)::value;
+        double *const PY = PUB + parity * PUBSZ, *const PZ = PY + PUBD;
+        if (fl & F_AK)
+          {
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+              for (int i = 0; i < NV; ++i)
+                PY[((cell * N + b) * 4 + d) * K + i] = R[d][i];
+          }
+        if (fl & F_BK)
+          {
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+              for (int i = 0; i < NV; ++i)
+                PZ[((cell * N + a) * 4 + d) * K + i] = R[d][i];
+          }
+        if (WITH_P)
+          {
+            if (fl & F_AKP)
+              {
+#pragma unroll
+                for (int i = 0; i < NVP; ++i)
+                  PY[((cell * N + b) * 4 + 3) * K + i] = Rp[i];
+              }
+            if (fl & F_BKP)
+              {
+#pragma unroll
+                for (int i = 0; i < NVP; ++i)
+                  PZ[((cell * N + a) * 4 + 3) * K + i] = Rp[i];
+              }
+          }
+        __syncthreads();
+        // lower neighbour in y: its line (K, b); in z: its line (a, K); both: the corner line (K, K) of the diagonal cell
+        if (fl & F_CY)
+          {
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+              for (int i = 0; i < NV; ++i)
+                R[d][i] += PY[(((cell - 1) * N + b) * 4 + d) * K + i];
+            if (WITH_P && (fl & F_PTH))
+              {
+#pragma unroll
+                for (int i = 0; i < NVP; ++i)
+                  Rp[i] += PY[(((cell - 1) * N + b) * 4 + 3) * K + i];
+              }
+          }
+        if (fl & F_CZ)
+          {
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+              for (int i = 0; i < NV; ++i)
+                R[d][i] += PZ[(((cell - CY) * N + a) * 4 + d) * K + i];
+            if (WITH_P && (fl & F_PTH))
+              {
+#pragma unroll
+                for (int i = 0; i < NVP; ++i)
+                  Rp[i] += PZ[(((cell - CY) * N + a) * 4 + 3) * K + i];
+              }
+          }
+        if ((fl & (F_CY | F_CZ)) == (F_CY | F_CZ))
+          {
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+#pragma unroll
+              for (int i = 0; i < NV; ++i)
+                R[d][i] += PY[(((cell - CY - 1) * N + K) * 4 + d) * K + i];
+            if (WITH_P && (fl & F_PTH))
+              {
+#pragma unroll
+                for (int i = 0; i < NVP; ++i)
+                  Rp[i] += PY[(((cell - CY - 1) * N + KP) * 4 + 3) * K + i];
+              }
+          }
+        // ---- emit: dst, or the slab on the high rim of the workgroup, or the x-slab at the end of a chunk ------
+        const bool to_xslab = endplane && x_seam_end;
+        if (fl & F_OWN_U)
+          {
+            double *tp;
+            if (to_xslab)
+              tp = A.xslab_u + (((size_t)wg * TNZ + kl) * TNY + jl) * 3;
+            else if (fl & F_SEAM_U)
+              tp = A.slab_u + (((size_t)wg * RIMU + rim_line<TNY, TNZ>(jl, kl)) * (K * A.LX + 1) + xl0) * 3;
+            else
+              tp = A.dst_u + (size_t)I0 * 3 + urow;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+              for (int d = 0; d < 3; ++d)
+                tp[i * 3 + d] = R[d][i];
+          }
+        if (WITH_P && A.integrate_p && (fl & F_OWN_P))
+          {
+            double *tp;
+            if (to_xslab)
+              tp = A.xslab_p + (((size_t)wg * TPZ + klp) * TPY + jlp);
+            else if (fl & F_SEAM_P)
+              tp = A.slab_p + (((size_t)wg * RIMP + rim_line<TPY, TPZ>(jlp, klp)) * (KP * A.LX + 1) + xlp0);
+            else
+              tp = A.dst_p + (size_t)Ip0 + prow;
+#pragma unroll
+            for (int i = 0; i < NVP; ++i)
+              tp[i] = Rp[i];
+          }
+        // constrained rows are then set to +-src (:247-256): a later store of the same lane to the same
+        // address, or an entry the fix-up kernel skips (workgroups at the domain boundary only)
+        const bool xcon = (I0 == 0 && ((A.con_u & 7u) || (A.con_p & 1u))) ||
+                          (I0 + NV - 1 == A.nnx - 1 && ((A.con_u >> 3 & 7u) || (A.con_p >> 1 & 1u)));
+        if ((wg_con_yz || xcon) && !to_xslab)
+          {
+            if ((fl & F_OWN_U) && !(fl & F_SEAM_U))
+              {
+#pragma unroll 1
+                for (int i = 0; i < NV; ++i)
+                  {
+                    const size_t po = (size_t)(I0 + i) * 3 + urow;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+                      if ((fl & (F_CON0 << d)) || (I0 + i == 0 && (A.con_u >> d & 1)) ||
+                          (I0 + i == A.nnx - 1 && (A.con_u >> (3 + d) & 1)))
+                        A.dst_u[po + d] = A.src_u[po + d];
+                  }
+              }
+            if (WITH_P && A.integrate_p && (fl & F_OWN_P) && !(fl & F_SEAM_P))
+              {
+#pragma unroll 1
+                for (int i = 0; i < NVP; ++i)
+                  {
+                    const size_t po = (size_t)(Ip0 + i) + prow;
+                    if ((fl & F_PCON) || (Ip0 + i == 0 && (A.con_p & 1)) || (Ip0 + i == A.npx - 1 && (A.con_p >> 1 & 1)))
+                      A.dst_p[po] = -A.src_p[po];
+                  }
+              }
+          }
+      };
+
+      double carry[3] = {0., 0., 0.}, carry_p = 0.;
+      load_nodes(cx0);
+
+#pragma unroll 1
+      for (int step = 0; step < ns; ++step)
+        {
+          const int cx = cx0 + step;
+          unsigned  fl = flags;
+          opaque(fl);
+          ctab_t tz = tab;
+          opaque(tz);
+
+          // G[d][0..3][i]: value, d/dx, d/dy, d/dz (reference cell) of component d at my N quadrature points;
+          // after the quadrature loop: tested value and tested gradient
+          double G[3][4][N], PQ[N];
+          const double *const stc = stp + (size_t)cx * ST_CELL;
+          if (NST > 0)
+            load_state(stc);
+
+          // ================= evaluate (FEEvaluation::evaluate, :668-671) =====================================
+#pragma unroll
+          for (int d = 0; d < 3; ++d)
+            {
+              double U[N], T[N], ln[N];
+#pragma unroll
+              for (int i = 0; i < N; ++i)
+                U[i] = (fl & (F_CON0 << d)) ? 0. : Un[d][i]; // read_dof_values: constrained entries read as zero
+              if (cx == 0 && (A.con_u >> d & 1))
+                U[0] = 0.;
+              if (cx == A.ncx - 1 && (A.con_u >> (3 + d) & 1))
+                U[K] = 0.;
+              mat_apply<N, N>(tz + TS, U, T); // x: nodes -> Gauss points
+              if (fl & F_ACT)
+                wr_line<0, 1, N>(px, T);
+              wave_sync();
+              rd_line<0, N, N>(ay, ln);
+              ds_wait<0>(ln);
+              mat_apply<N, N>(tz + TS, ln, T); // y
+              wave_sync();
+              if (fl & F_ACT)
+                wr_line<BUF, N, N>(py, T);
+              wave_sync();
+              rd_line<BUF, NN, N>(az, ln);
+              ds_wait<0>(ln);
+              mat_apply<N, N>(tz + TS, ln, T); // z: values at the Gauss points of my z-line
+              mat_apply<N, N>(tz + TD, T, ln); // d/dz (collocation)
+              wave_sync();
+              if (fl & F_ACT)
+                {
+                  wr_line<0, NN, N>(pz, T);
+                  wr_line<2 * BUF, NN, N>(pz, ln);
+                }
+              wave_sync();
+              rd_line<0, N, N>(ay, ln);
+              ds_wait<0>(ln);
+              mat_apply<N, N>(tz + TD, ln, T); // d/dy
+              wave_sync();
+              if (fl & F_ACT)
+                wr_line<BUF, N, N>(py, T);
+              wave_sync();
+              rd_line<0, 1, N>(ax, G[d][0]);
+              rd_line<BUF, 1, N>(ax, G[d][2]);
+              rd_line<2 * BUF, 1, N>(ax, G[d][3]);
+              ds_wait<2 * N>(G[d][0]);
+              mat_apply<N, N>(tz + TD, G[d][0], G[d][1]); // d/dx
+              ds_wait<0>(G[d][2]);
+              ds_wait<0>(G[d][3]);
+              wave_sync();
+            }
+          if (WITH_P)
+            {
+              double P[NP], T[N], ln[NP];
+#pragma unroll
+              for (int i = 0; i < NP; ++i)
+                P[i] = (fl & F_PCON) ? 0. : Pn[i];
+              if (cx == 0 && (A.con_p & 1))
+                P[0] = 0.;
+              if (cx == A.ncx - 1 && (A.con_p >> 1 & 1))
+                P[KP] = 0.;
+              mat_apply<N, NP>(tz + TSP, P, T); // x: [N][NP x NP lines]
+              if (fl & F_PTH)
+                wr_line<0, 1, N>(px, T);
+              wave_sync();
+              rd_line<0, N, NP>(ay, ln); // y-line (a, ., b), b < NP (other lanes read defined-or-not values they never use)
+              ds_wait<0>(ln);
+              mat_apply<N, NP>(tz + TSP, ln, T);
+              wave_sync();
+              if ((fl & F_ACT) && b < NP)
+                wr_line<BUF, N, N>(py, T);
+              wave_sync();
+              rd_line<BUF, NN, NP>(az, ln); // z-line (a, b, .)
+              ds_wait<0>(ln);
+              mat_apply<N, NP>(tz + TSP, ln, T);
+              wave_sync();
+              if (fl & F_ACT)
+                wr_line<0, NN, N>(pz, T);
+              wave_sync();
+              rd_line<0, 1, N>(ax, PQ);
+              ds_wait<0>(PQ);
+              wave_sync();
+            }
+          else
+            {
+#pragma unroll
+              for (int i = 0; i < N; ++i)
+                PQ[i] = 0.;
+            }
+
+          // ================= quadrature points of my x-line (:702-893) ==========================================
+#pragma unroll
+          for (int i = 0; i < N; ++i)
+            {
+              const double jxw = wab * A.w[i];
+              double       g[3][3], u[3];
+#pragma unroll
+              for (int d = 0; d < 3; ++d)
+                {
+                  u[d] = G[d][0][i];
+#pragma unroll
+                  for (int e = 0; e < 3; ++e)
+                    g[d][e] = G[d][1 + e][i] * A.ih[e];
+                }
+              const double div = g[0][0] + g[1][1] + g[2][2];
+              double       conv[3];
+#pragma unroll
+              for (int d = 0; d < 3; ++d)
+                {
+                  double res = 0.;
+                  if (LIN_MODE == 0) // Newton :802-816; st = (u_lin[3], grad u_lin[3][3])
+                    {
+                      res = A.beta * (div * st[d] + (st[3] + st[7] + st[11]) * u[d]);
+#pragma unroll
+                      for (int e = 0; e < 3; ++e)
+                        res += st[e] * g[d][e] + u[e] * st[3 + 3 * d + e];
+                    }
+                  else if (LIN_MODE == 1) // Picard-type :817-826; st = (u_lin[3], div u_lin)
+                    {
+                      res = A.beta * st[3] * u[d];
+#pragma unroll
+                      for (int e = 0; e < 3; ++e)
+                        res += st[e] * g[d][e];
+                    }
+                  conv[d] = (A.cA * u[d] + A.cB * res) * jxw; // :717,:827-835
+                }
+              if (NST > 0 && i + 1 < N)
+                load_state(stc + (i + 1) * ST_POINT);
+              const double diag = A.tau_gd * div - PQ[i];
+#pragma unroll
+              for (int d = 0; d < 3; ++d)
+                {
+                  G[d][0][i] = conv[d];
+#pragma unroll
+                  for (int e = 0; e < 3; ++e) // :859-892 row d of tmu (grad u + grad u^T) + (tau_gd div - p) I, times JxW J^{-1}
+                    G[d][1 + e][i] = (A.tmu * (g[d][e] + g[e][d]) + (d == e ? diag : 0.)) * (jxw * A.ih[e]);
+                }
+              PQ[i] = -div * jxw; // :853-856
+            }
+          // the nodal lines of the next step arrive during the integration
+          load_nodes(cx + 1);
+
+          // ================= integrate (:897-907): the transposed chain =========================================
+          double R[3][N], Rp[NP];
+#pragma unroll
+          for (int d = 0; d < 3; ++d)
+            {
+              double W[N], ln[N], l2[N];
+              mat_apply_t<N, N, true>(tz + TD, G[d][1], G[d][0]); // W = tested value + D^T (x) in registers
+              if (fl & F_ACT)
+                {
+                  wr_line<0, 1, N>(px, G[d][0]);
+                  wr_line<BUF, 1, N>(px, G[d][2]);
+                  wr_line<2 * BUF, 1, N>(px, G[d][3]);
+                }
+              wave_sync();
+              rd_line<0, N, N>(ay, W);
+              rd_line<BUF, N, N>(ay, ln);
+              ds_wait<N>(W);
+              ds_wait<0>(ln);
+              mat_apply_t<N, N, true>(tz + TD, ln, W); // + D^T (y)
+              wave_sync();
+              if (fl & F_ACT)
+                wr_line<0, N, N>(py, W);
+              wave_sync();
+              rd_line<0, NN, N>(az, W);
+              rd_line<2 * BUF, NN, N>(az, ln);
+              ds_wait<N>(W);
+              ds_wait<0>(ln);
+              mat_apply_t<N, N, true>(tz + TD, ln, W);  // + D^T (z)
+              mat_apply_t<N, N, false>(tz + TS, W, l2); // S^T (z): Gauss points -> nodes
+              wave_sync();
+              if (fl & F_ACT)
+                wr_line<BUF, NN, N>(pz, l2);
+              wave_sync();
+              rd_line<BUF, N, N>(ay, ln);
+              ds_wait<0>(ln);
+              mat_apply_t<N, N, false>(tz + TS, ln, l2); // S^T (y)
+              wave_sync();
+              if (fl & F_ACT)
+                wr_line<0, N, N>(py, l2);
+              wave_sync();
+              rd_line<0, 1, N>(ax, ln);
+              ds_wait<0>(ln);
+              mat_apply_t<N, N, false>(tz + TS, ln, R[d]); // S^T (x)
+              wave_sync();
+            }
+#pragma unroll
+          for (int i = 0; i < NP; ++i)
+            Rp[i] = 0.;
+          if (WITH_P)
+            {
+              double ln[N], T[NP];
+              if (fl & F_ACT)
+                wr_line<0, 1, N>(px, PQ);
+              wave_sync();
+              rd_line<0, NN, N>(az, ln);
+              ds_wait<0>(ln);
+              mat_apply_t<N, NP, false>(tz + TSP, ln, T); // z: [N][N][NP]
+              wave_sync();
+              if (fl & F_ACT)
+                wr_line<BUF, NN, NP>(pz, T);
+              wave_sync();
+              rd_line<BUF, N, N>(ay, ln); // y-line (a, ., b), b < NP
+              ds_wait<0>(ln);
+              mat_apply_t<N, NP, false>(tz + TSP, ln, T);
+              wave_sync();
+              if ((fl & F_ACT) && b < NP)
+                wr_line<0, N, NP>(py, T);
+              wave_sync();
+              rd_line<0, 1, N>(ax, ln); // x-line (., a, b), a, b < NP
+              ds_wait<0>(ln);
+              mat_apply_t<N, NP, false>(tz + TSP, ln, Rp);
+              wave_sync();
+            }
+
+          // ================= carry in x, combine in y / z, emit the K finished nodes ============================
+#pragma unroll
+          for (int d = 0; d < 3; ++d)
+            {
+              R[d][0] += carry[d];
+              carry[d] = R[d][K];
+            }
+          Rp[0] += carry_p;
+          carry_p = Rp[KP];
+          combine(std::integral_constant<int, K>{}, std::integral_constant<int, KP>{}, R, Rp, fl, step & 1, K * cx,
+                  KP * cx, K * step, KP * step, false);
+        }
+      // ---- the last node plane of the chunk ------------------------------------------------------------------
+      {
+        double R[3][N], Rp[NP];
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          R[d][0] = carry[d];
+        Rp[0] = carry_p;
+        combine(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, R, Rp, flags, ns & 1, K * (cx0 + ns),
+                KP * (cx0 + ns), K * ns, KP * ns, true);
+      }
+    }
+
+    // ---- second pass: the owner of a shared node (low rim in every direction) adds the partial sums of the
+    // other sharers in a fixed order --------------------------------------------------------------------------
+    __device__ __forceinline__ bool hox_fix_skip(const HXArgs &A, const int I, const int J, const int Kz, const int nn_x,
+                                                 const int nn_y, const int nn_z)
+    {
+      if (A.fix_mode == 0)
+        return false;
+      const bool on = (I == 0 && (A.iface & 1u)) || (I == nn_x - 1 && (A.iface & 2u)) || (J == 0 && (A.iface & 4u)) ||
+                      (J == nn_y - 1 && (A.iface & 8u)) || (Kz == 0 && (A.iface & 16u)) ||
+                      (Kz == nn_z - 1 && (A.iface & 32u));
+      return A.fix_mode == 1 ? !on : on;
+    }
+
+    // one shared entry (I, J, Kz, comp) of a space with DEG nodes per cell direction and NC components
+    template <int DEG, int CY, int CZ, int NC>
+    __device__ __forceinline__ void hox_fix_entry(const HXArgs &A, const int I, const int J, const int Kz, const int comp,
+                                                  double *dst, const double *slab, const double *xslab, const int nn_x,
+                                                  const int nn_y, const int nn_z, const uint32_t con)
+    {
+      constexpr int TY = DEG * CY + 1, TZ = DEG * CZ + 1, RIM = TY + TZ - 1;
+      const int     px = DEG * A.LX, py = DEG * CY, pz = DEG * CZ;
+      const bool    sx = I > 0 && I < nn_x - 1 && I % px == 0, sy = J > 0 && J < nn_y - 1 && J % py == 0,
+                 sz = Kz > 0 && Kz < nn_z - 1 && Kz % pz == 0;
+      if (!(sx || sy || sz))
+        return;
+      if (on_constrained_face(I, J, Kz, nn_x, nn_y, nn_z, con, NC == 1 ? 1 : 3, comp) ||
+          hox_fix_skip(A, I, J, Kz, nn_x, nn_y, nn_z))
+        return;
+      const int bx = min(I / px, A.n_chunks - 1), by = min(J / py, A.tiles_y - 1), bz = min(Kz / pz, A.tiles_z - 1);
+      double    sum = 0.;
+      for (int dz = 0; dz <= (sz ? 1 : 0); ++dz)
+        for (int dy = 0; dy <= (sy ? 1 : 0); ++dy)
+          for (int dx = 0; dx <= (sx ? 1 : 0); ++dx)
+            {
+              if (dx == 0 && dy == 0 && dz == 0)
+                continue;
+              const size_t tb = ((size_t)(bz - dz) * A.tiles_y + (by - dy)) * A.n_chunks + (bx - dx);
+              const int    jl = dy ? TY - 1 : J - py * by, kl = dz ? TZ - 1 : Kz - pz * bz;
+              if (dx)
+                sum += xslab[((tb * TZ + kl) * TY + jl) * NC + comp];
+              else
+                sum += slab[((tb * RIM + rim_line<TY, TZ>(jl, kl)) * (px + 1) + (I - px * bx)) * NC + comp];
+            }
+      dst[(((size_t)Kz * nn_y + J) * nn_x + I) * NC + comp] += sum;
+    }
+
+    // work items: [rows on y seams | rows on z seams (not on y seams) | x-seam planes (rows not on a seam)], for the
+    // velocity and then the pressure space; a row item = one entry (I, comp) of a seam row
+    template <int K>
+    __global__ __launch_bounds__(256) void ns_hox_fixup_kernel(const HXArgs A, const int with_p)
+    {
+      using G = Geo<K>;
+      for (int space = 0; space < (with_p ? 2 : 1); ++space)
+        {
+          const int      deg = space == 0 ? K : K - 1, nc = space == 0 ? 3 : 1;
+          const int      nn_x = space == 0 ? A.nnx : A.npx, nn_y = space == 0 ? A.nny : A.npy, nn_z = space == 0 ? A.nnz : A.npz;
+          const long     rowlen = (long)nn_x * nc;
+          const long     n_y = (long)(A.tiles_y - 1) * nn_z, n_z = (long)(A.tiles_z - 1) * nn_y;
+          const long     n_rows = n_y + n_z;
+          const long     n_xpl = (long)(A.n_chunks - 1) * nn_y * nn_z * nc;
+          const long     total = n_rows * rowlen + n_xpl;
+          double        *dst   = space == 0 ? A.dst_u : A.dst_p;
+          const double  *slab = space == 0 ? A.slab_u : A.slab_p, *xslab = space == 0 ? A.xslab_u : A.xslab_p;
+          const uint32_t con  = space == 0 ? A.con_u : A.con_p;
+          for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x)
+            {
+              int I, J, Kz, comp;
+              if (it < n_rows * rowlen)
+                {
+                  const long row = it / rowlen;
+                  const int  e   = (int)(it % rowlen);
+                  I    = e / nc;
+                  comp = e % nc;
+                  if (row < n_y)
+                    {
+                      J  = (int)(row / nn_z + 1) * deg * G::CY;
+                      Kz = (int)(row % nn_z);
+                    }
+                  else
+                    {
+                      Kz = (int)((row - n_y) / nn_y + 1) * deg * G::CZ;
+                      J  = (int)((row - n_y) % nn_y);
+                      if (J > 0 && J < nn_y - 1 && J % (deg * G::CY) == 0)
+                        continue; // on a y seam: done above
+                    }
+                }
+              else
+                {
+                  long e = it - n_rows * rowlen;
+                  comp   = (int)(e % nc);
+                  e /= nc;
+                  J = (int)(e % nn_y);
+                  e /= nn_y;
+                  Kz = (int)(e % nn_z);
+                  I  = (int)(e / nn_z + 1) * deg * A.LX;
+                  if ((J > 0 && J < nn_y - 1 && J % (deg * G::CY) == 0) || (Kz > 0 && Kz < nn_z - 1 && Kz % (deg * G::CZ) == 0))
+                    continue; // on a seam row: done above
+                }
+              if (space == 0)
+                hox_fix_entry<K, G::CY, G::CZ, 3>(A, I, J, Kz, comp, dst, slab, xslab, nn_x, nn_y, nn_z, con);
+              else
+                hox_fix_entry<K - 1, G::CY, G::CZ, 1>(A, I, J, Kz, comp, dst, slab, xslab, nn_x, nn_y, nn_z, con);
+            }
+        }
+    }
+
+    // generic state [cell][12][N^3] (q = (k N + j) N + i) -> streaming layout of ns_hox_kernel; one thread per
+    // 16-byte piece of the output
+    template <int K>
+    __global__ __launch_bounds__(256) void hox_convert_state_kernel(double *out, const double *generic, const int ncx,
+                                                                    const int ncy, const int ncz, const int ngy,
+                                                                    const int ngz, const int npc)
+    {
+      using G          = Geo<K>;
+      constexpr int N = G::N, NL = G::NL, N3 = G::N3, CPW = G::CPW;
+      const long    total = (long)ngz * ngy * ncx * N * npc * CPW * NL;
+      for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x)
+        {
+          long      r = it;
+          const int l = (int)(r % NL);
+          r /= NL;
+          const int scw = (int)(r % CPW);
+          r /= CPW;
+          const int piece = (int)(r % npc);
+          r /= npc;
+          const int i = (int)(r % N);
+          r /= N;
+          const int cx = (int)(r % ncx);
+          r /= ncx;
+          const int gy = (int)(r % ngy), gz = (int)(r / ngy);
+          const int cy = gy * G::CWY + scw % G::CWY, cz = gz * G::CWZ + scw / G::CWY;
+          double    v0 = 0., v1 = 0.;
+          if (cy < ncy && cz < ncz)
+            {
+              const size_t cellg = ((size_t)cz * ncy + cy) * ncx + cx;
+              const int    q     = ((l / N) * N + l % N) * N + i; // line l = (j, k) = (l % N, l / N)
+              v0                 = generic[(cellg * NLIN_ + 2 * piece) * N3 + q];
+              v1                 = generic[(cellg * NLIN_ + 2 * piece + 1) * N3 + q];
+            }
+          out[2 * it]     = v0;
+          out[2 * it + 1] = v1;
+        }
+    }
+  } // namespace hox
+} // namespace adaflo_hip

@@ -1,0 +1,145 @@
+// hox_emu.cpp -- TEST INFRASTRUCTURE ONLY: runs the device source of the x-marching Q3..Q5 kernel
+// (adaflo_amd/csrc/ns_hox_kernel.hpp: state conversion, main kernel, seam fix-up) on the host lane emulator
+// (hip_emu.hpp) so that tests/test_hox_emulated.py can compare it with the oracle without a GPU.  The product
+// never loads this library.
+#include "hip_emu.hpp"
+
+#include <type_traits>
+#include <vector>
+
+#include "../../adaflo_amd/csrc/basis.hpp"
+#include "../../adaflo_amd/csrc/ns_hox_kernel.hpp"
+
+using namespace adaflo_hip;
+using namespace adaflo_hip::hox;
+
+namespace
+{
+  template <int K, int LM, bool WP>
+  void run_main(const HXArgs &A, const long nwg)
+  {
+    if (nwg > 0)
+      emu::launch((unsigned)nwg, NTH, [&] { ns_hox_kernel<K, LM, WP>(A); });
+  }
+
+  template <int K>
+  int run(const int *ncell, const double *h, const int op, const int lin_mode, const int integrate_p, const double *coef,
+          const unsigned con_u, const unsigned con_p, const double *lin_generic, const double *src_u, const double *src_p,
+          double *dst_u, double *dst_p, const int lx, const unsigned iface, const int phased)
+  {
+    using G         = Geo<K>;
+    constexpr int N = K + 1, NP = K;
+    HXArgs        A{};
+    hox_geometry<K>(A, ncell, lx);
+    std::vector<double> tab;
+    {
+      const Quadrature1D        qu = gauss(N);
+      const Shape1D             su = shape_fe_q(K, qu), sp = shape_fe_q(K - 1, qu);
+      const std::vector<double> dc = collocation_derivative(qu);
+      for (int q = 0; q < N; ++q)
+        A.w[q] = qu.w[q];
+      for (int q = 0; q < N * N; ++q)
+        tab.push_back(su.S[q]);
+      for (int q = 0; q < N * N; ++q)
+        tab.push_back(dc[q]);
+      for (int q = 0; q < N * NP; ++q)
+        tab.push_back(sp.S[q]);
+    }
+    A.tab = tab.data();
+    for (int e = 0; e < 3; ++e)
+      A.ih[e] = 1. / h[e];
+    A.det         = h[0] * h[1] * h[2];
+    A.cA          = coef[0];
+    A.cB          = coef[1];
+    A.beta        = coef[2];
+    A.tau_gd      = coef[3];
+    A.tmu         = coef[4];
+    A.integrate_p = integrate_p;
+    A.con_u       = con_u;
+    A.con_p       = con_p;
+    A.src_u       = src_u;
+    A.src_p       = src_p;
+    A.dst_u       = dst_u;
+    A.dst_p       = dst_p;
+    const int           npc = nst_of(lin_mode) / 2;
+    std::vector<double> state((size_t)A.ngz * A.ngy * A.ncx * N * npc * G::CPW * G::NL * 2 + 2);
+    if (npc > 0)
+      emu::launch(4, 256, [&] { hox_convert_state_kernel<K>(state.data(), lin_generic, A.ncx, A.ncy, A.ncz, A.ngy, A.ngz, npc); });
+    A.lin = state.data();
+    const size_t        n_wg = (size_t)A.tiles_y * A.tiles_z * A.n_chunks;
+    const double        nan  = std::nan("");
+    std::vector<double> slab_u(n_wg * G::RIMU * (K * A.LX + 1) * 3, nan), xslab_u(n_wg * G::TNY * G::TNZ * 3, nan),
+      slab_p(n_wg * G::RIMP * ((K - 1) * A.LX + 1), nan), xslab_p(n_wg * G::TPY * G::TPZ, nan);
+    A.slab_u  = slab_u.data();
+    A.xslab_u = xslab_u.data();
+    A.slab_p  = slab_p.data();
+    A.xslab_p = xslab_p.data();
+    const bool with_p = op == 0;
+    auto       main_k = [&](const long nwg) {
+      if (with_p)
+        {
+          if (lin_mode == 0)
+            run_main<K, 0, true>(A, nwg);
+          else if (lin_mode == 1)
+            run_main<K, 1, true>(A, nwg);
+          else
+            run_main<K, 2, true>(A, nwg);
+        }
+      else
+        {
+          if (lin_mode == 0)
+            run_main<K, 0, false>(A, nwg);
+          else if (lin_mode == 1)
+            run_main<K, 1, false>(A, nwg);
+          else
+            run_main<K, 2, false>(A, nwg);
+        }
+    };
+    const bool fix_p = with_p && integrate_p;
+    auto       fixup = [&] {
+      if (hox_fix_items(A, fix_p) > 0)
+        emu::launch(3, 256, [&] { ns_hox_fixup_kernel<K>(A, fix_p ? 1 : 0); });
+    };
+    if (!phased)
+      {
+        main_k((long)n_wg);
+        fixup();
+      }
+    else
+      {
+        std::vector<int> list;
+        int              counts[3];
+        hox_wg_lists(A, iface, list, counts);
+        list.push_back(0);
+        A.wg_list = list.data();
+        A.iface   = iface;
+        for (const int phase : {0, 1, 2})
+          {
+            A.wg_offset = phase == 1 ? 0 : (phase == 0 ? counts[0] : counts[0] + counts[1]);
+            A.wg_count  = phase == 1 ? counts[0] : (phase == 0 ? counts[1] : counts[2]);
+            A.fix_mode  = phase;
+            main_k(A.wg_count);
+            if (phase > 0)
+              fixup();
+          }
+      }
+    return 0;
+  }
+} // namespace
+
+extern "C" int hox_emu_vmult(const int K, const int *ncell, const double *h, const int op, const int lin_mode,
+                             const int integrate_p, const double *coef, const unsigned con_u, const unsigned con_p,
+                             const double *lin_generic, const double *src_u, const double *src_p, double *dst_u,
+                             double *dst_p, const int lx, const unsigned iface, const int phased)
+{
+  switch (K)
+    {
+      case 3:
+        return run<3>(ncell, h, op, lin_mode, integrate_p, coef, con_u, con_p, lin_generic, src_u, src_p, dst_u, dst_p, lx, iface, phased);
+      case 4:
+        return run<4>(ncell, h, op, lin_mode, integrate_p, coef, con_u, con_p, lin_generic, src_u, src_p, dst_u, dst_p, lx, iface, phased);
+      case 5:
+        return run<5>(ncell, h, op, lin_mode, integrate_p, coef, con_u, con_p, lin_generic, src_u, src_p, dst_u, dst_p, lx, iface, phased);
+    }
+  return -1;
+}
