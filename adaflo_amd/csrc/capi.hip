@@ -1043,6 +1043,15 @@ int adaflo_set_q2_chunk(adaflo_ctx *ctx, int layers)
   return 0;
 }
 
+int adaflo_set_hox_chunk(adaflo_ctx *ctx, int cells)
+{
+  CHECK_CTX(ctx);
+  if (cells < 0)
+    return fail(ctx, ADAFLO_EINVAL, "negative chunk length");
+  ctx->hox_lx = cells;
+  return 0;
+}
+
 
 /* ------------------------------------------------------------------------- */
 /* inter-GPU exchange helpers                                                 */

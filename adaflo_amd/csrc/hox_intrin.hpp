@@ -17,6 +17,11 @@ namespace adaflo_hip
   __device__ __forceinline__ void opaque(int &v) { asm volatile("" : "+v"(v)); }
   __device__ __forceinline__ void opaque(unsigned &v) { asm volatile("" : "+v"(v)); }
 
+  // the offset becomes known only after `v` has been computed: pins a prefetch behind the arithmetic that frees its
+  // destination registers (otherwise all loads of an unrolled loop are hoisted to its top and stay live together).
+  // (An offset, not the pointer: behind an opaque pointer the compiler no longer knows the address space.)
+  __device__ __forceinline__ void pin_after(unsigned &off, const double v) { asm volatile("" : "+v"(off) : "v"(v)); }
+
   // the workgroup's dynamic LDS
   __device__ __forceinline__ double *dyn_lds()
   {
@@ -31,6 +36,8 @@ namespace adaflo_hip
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_sched_barrier(0); // phases stay phases: the scheduler otherwise interleaves them for ILP and the
+                                       // kernel needs 440 instead of ~230 registers
   }
 
   __device__ __forceinline__ unsigned lds_byte_addr(const void *p)

@@ -95,7 +95,7 @@ namespace adaflo_hip
                    const int phase, const uint32_t iface)
     {
       using G         = Geo<K>;
-      constexpr int N = K + 1, NP = K;
+      constexpr int N = K + 1;
       HXArgs        A{};
       const int     lin_mode = lin_mode_of(ctx);
       {
@@ -112,39 +112,31 @@ namespace adaflo_hip
       }
       if ((size_t)A.nnx * A.nny * A.nnz * 3 >= ((size_t)1 << 32))
         return ADAFLO_EUNSUPPORTED; // 32-bit row offsets
-      std::vector<double> tab;
-      {
-        const Quadrature1D        qu = gauss(N);
-        const Shape1D             su = shape_fe_q(K, qu), sp = shape_fe_q(K - 1, qu);
-        const std::vector<double> dc = collocation_derivative(qu);
-        for (int q = 0; q < N; ++q)
-          A.w[q] = qu.w[q];
-        for (int q = 0; q < N * N; ++q)
-          tab.push_back(su.S[q]);
-        for (int q = 0; q < N * N; ++q)
-          tab.push_back(dc[q]);
-        for (int q = 0; q < N * NP; ++q)
-          tab.push_back(sp.S[q]);
-      }
-      if (!ctx->hox_tab.p)
-        {
-          if (int e = ensure(ctx->hox_tab, tab.size()))
-            return e;
-          if (copy_to_device_now(ctx->hox_tab.p, tab.data(), tab.size() * sizeof(double)) != hipSuccess)
-            return ADAFLO_EHIP;
-        }
-      A.tab = ctx->hox_tab.p;
-      for (int e = 0; e < 3; ++e)
-        A.ih[e] = 1. / ctx->desc.h[e];
-      A.det = ctx->desc.h[0] * ctx->desc.h[1] * ctx->desc.h[2];
       const NSDev &P      = ctx->ns;
       const bool   stokes = P.physical_type == ADAFLO_STOKES;
       const double gamma  = P.physical_type == ADAFLO_INCOMPRESSIBLE ? P.weight : 0.;
-      A.cA          = stokes ? 0. : gamma * P.density - P.damping; // :717,:827-835; Stokes: no value terms (:708)
-      A.cB          = stokes ? 0. : P.tau1 * P.density;
-      A.beta        = P.beta;
-      A.tau_gd      = P.tau_grad_div;
-      A.tmu         = P.viscosity * P.tau1; // :841-845
+      {
+        // 1D matrices (even / odd form) and the constants of the quadrature-point operation: one small table,
+        // re-uploaded when a parameter changed
+        const Quadrature1D        qu = gauss(N);
+        const Shape1D             su = shape_fe_q(K, qu), sp = shape_fe_q(K - 1, qu);
+        const std::vector<double> dc = collocation_derivative(qu);
+        const double cA = stokes ? 0. : gamma * P.density - P.damping; // :717,:827-835; Stokes: no value terms (:708)
+        const double cB = stokes ? 0. : P.tau1 * P.density;
+        const std::vector<double> tab = hox_table<K>(su.S.data(), dc.data(), sp.S.data(), qu.w.data(), ctx->desc.h, cA, cB,
+                                                     P.beta, P.tau_grad_div, P.viscosity * P.tau1 /* :841-845 */);
+        if (tab != ctx->hox_tab_host)
+          {
+            if (int e = ensure(ctx->hox_tab, tab.size()))
+              return e;
+            // (stream-ordered: earlier launches that read the old table are finished first)
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess ||
+                copy_to_device_now(ctx->hox_tab.p, tab.data(), tab.size() * sizeof(double)) != hipSuccess)
+              return ADAFLO_EHIP;
+            ctx->hox_tab_host = tab;
+          }
+      }
+      A.tab         = ctx->hox_tab.p;
       A.integrate_p = P.linearization != ADAFLO_PROJECTION;
       A.con_u       = ctx->brick.con_u;
       A.con_p       = ctx->brick.con_p;

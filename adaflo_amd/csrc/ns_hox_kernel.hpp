@@ -83,14 +83,12 @@ namespace adaflo_hip
     struct HXArgs
     {
       int    ncx, ncy, ncz, nnx, nny, nnz, npx, npy, npz, tiles_y, tiles_z, LX, n_chunks, ngy, ngz;
-      double w[NMAX];
-      double ih[3], det, cA, cB, beta, tau_gd, tmu;
       int    integrate_p;
       uint32_t con_u, con_p;
       const double *src_u, *src_p, *lin; // lin: streaming layout of this kernel (hox_state_offset)
       double       *dst_u, *dst_p;
       double       *slab_u, *xslab_u, *slab_p, *xslab_p;
-      const double *tab; // [S N*N | D N*N | Sp N*NP]: S[q][i] nodal -> Gauss, D collocation derivative, Sp pressure
+      const double *tab; // Tab<K>: the 1D matrices in even / odd form and the constants of the quadrature-point operation
       // phased execution for the multi-GPU overlap (as in ns_q2.hip / ns_ho.hip)
       const int *wg_list;
       int        wg_offset, wg_count, fix_mode;
@@ -172,33 +170,123 @@ namespace adaflo_hip
       return (((((grp * ncx + cx) * G::N + i) * npc + piece) * G::CPW + scw) * G::NL + l) * 2;
     }
 
-    // ---- small dense helpers on register lines; M from scalar loads ----------------------------------------
-    // out[q] = sum_i M[q * NI + i] in[i]
-    template <int NQ, int NI>
-    __device__ __forceinline__ void mat_apply(const ctab_t M, const double (&in)[NI], double (&out)[NQ])
+    // ---- 1D matrices in even / odd form -------------------------------------------------------------------------
+    // Gauss and Gauss-Lobatto points are symmetric about 1/2, so every 1D matrix here satisfies
+    // M[q][i] = sigma M[NQ-1-q][NI-1-i] (sigma = +1: interpolation, -1: derivative).  With e_i = in[i] + in[NI-1-i],
+    // o_i = in[i] - in[NI-1-i] the products are  out[q] = A + B,  out[NQ-1-q] = sigma (A - B),
+    //   A = sum_{i < NI/2} E[q][i] e_i + C[q] in[mid],   B = sum_{i < NI/2} O[q][i] o_i,
+    //   E = (M[q][i] + M[q][NI-1-i]) / 2,  C = M[q][mid],  O = (M[q][i] - M[q][NI-1-i]) / 2
+    // -- what deal.II's FEEvaluation does ("even-odd decomposition"): 13 instead of 25 coefficients for 5 x 5, i.e.
+    // 26 instead of 50 scalar registers per matrix, and 21 instead of 25 vector operations per line.
+    // Compact table of one matrix: [E: RQ x HI | C: RQ (NI odd) | O: RQ x HI], RQ = ceil(NQ / 2), HI = NI / 2.
+    constexpr int eo_size(const int nq, const int ni)
     {
-#pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        {
-          double s = M[q * NI] * in[0];
-#pragma unroll
-          for (int i = 1; i < NI; ++i)
-            s += M[q * NI + i] * in[i];
-          out[q] = s;
-        }
+      return ((nq + 1) / 2) * (2 * (ni / 2) + (ni & 1));
     }
-    // out[i] (+)= sum_q M[q * NI + i] in[q]
-    template <int NQ, int NI, bool ADD>
-    __device__ __forceinline__ void mat_apply_t(const ctab_t M, const double (&in)[NQ], double (&out)[NI])
+    // (host) M is [NQ][NI] row-major; transpose = true stores the table of M^T
+    inline void eo_table(std::vector<double> &out, const double *M, const int nq, const int ni, const bool transpose)
     {
+      const int NQ = transpose ? ni : nq, NI = transpose ? nq : ni;
+      auto      m  = [&](const int q, const int i) { return transpose ? M[i * ni + q] : M[q * ni + i]; };
+      const int RQ = (NQ + 1) / 2, HI = NI / 2;
+      for (int q = 0; q < RQ; ++q)
+        for (int i = 0; i < HI; ++i)
+          out.push_back(0.5 * (m(q, i) + m(q, NI - 1 - i)));
+      if (NI & 1)
+        for (int q = 0; q < RQ; ++q)
+          out.push_back(m(q, HI));
+      for (int q = 0; q < RQ; ++q)
+        for (int i = 0; i < HI; ++i)
+          out.push_back(0.5 * (m(q, i) - m(q, NI - 1 - i)));
+    }
+    // table of a launch: [S | S^T | D | D^T | Sp | Sp^T | w[N] | 1/h[3] | det | cA | cB | beta | tau_gd | tmu]
+    template <int K>
+    struct Tab
+    {
+      static constexpr int N = K + 1, NP = K;
+      static constexpr int S = 0, ST = S + eo_size(N, N), D = ST + eo_size(N, N), DT = D + eo_size(N, N),
+                           SP = DT + eo_size(N, N), SPT = SP + eo_size(N, NP), C = SPT + eo_size(NP, N);
+      static constexpr int C_W = 0, C_IH = N, C_DET = N + 3, C_CA = N + 4, C_CB = N + 5, C_BETA = N + 6, C_TGD = N + 7,
+                           C_TMU = N + 8, SIZE = C + N + 9;
+    };
+    // (host) S[q][i] nodal -> Gauss points (N x N), Dc collocation derivative (N x N), Sp pressure (N x NP)
+    template <int K>
+    inline std::vector<double> hox_table(const double *S, const double *Dc, const double *Sp, const double *w,
+                                         const double h[3], const double cA, const double cB, const double beta,
+                                         const double tau_gd, const double tmu)
+    {
+      constexpr int       N = K + 1, NP = K;
+      std::vector<double> t;
+      eo_table(t, S, N, N, false);
+      eo_table(t, S, N, N, true);
+      eo_table(t, Dc, N, N, false);
+      eo_table(t, Dc, N, N, true);
+      eo_table(t, Sp, N, NP, false);
+      eo_table(t, Sp, N, NP, true);
+      for (int q = 0; q < N; ++q)
+        t.push_back(w[q]);
+      for (int e = 0; e < 3; ++e)
+        t.push_back(1. / h[e]);
+      t.push_back(h[0] * h[1] * h[2]);
+      t.push_back(cA);
+      t.push_back(cB);
+      t.push_back(beta);
+      t.push_back(tau_gd);
+      t.push_back(tmu);
+      return t;
+    }
+
+    // out[q] (+)= sum_i M[q][i] in[i] with M in even / odd form (coefficients from scalar loads)
+    template <int NQ, int NI, int SIGMA, bool ADD>
+    __device__ __forceinline__ void eo_apply(const ctab_t T, const double (&in)[NI], double (&out)[NQ])
+    {
+      constexpr int  RQ = (NQ + 1) / 2, HQ = NQ / 2, HI = NI / 2;
+      constexpr bool MID = (NI & 1) != 0, QMID = (NQ & 1) != 0;
+      constexpr int  OE = 0, OC = RQ * HI, OO = OC + (MID ? RQ : 0);
+      double         e[HI], o[HI];
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
+      for (int i = 0; i < HI; ++i)
         {
-          double s = ADD ? out[i] : 0.;
+          e[i] = in[i] + in[NI - 1 - i];
+          o[i] = in[i] - in[NI - 1 - i];
+        }
+      const double mid = in[HI]; // (used only if NI is odd)
 #pragma unroll
-          for (int q = 0; q < NQ; ++q)
-            s += M[q * NI + i] * in[q];
-          out[i] = s;
+      for (int q = 0; q < HQ; ++q)
+        {
+          double a = T[OE + q * HI] * e[0], b = T[OO + q * HI] * o[0];
+#pragma unroll
+          for (int i = 1; i < HI; ++i)
+            {
+              a += T[OE + q * HI + i] * e[i];
+              b += T[OO + q * HI + i] * o[i];
+            }
+          if (MID)
+            a += T[OC + q] * mid;
+          const double lo = a + b, hi = SIGMA > 0 ? a - b : b - a;
+          out[q]          = ADD ? out[q] + lo : lo;
+          out[NQ - 1 - q] = ADD ? out[NQ - 1 - q] + hi : hi;
+        }
+      if (QMID)
+        {
+          double v;
+          if (SIGMA > 0)
+            {
+              v = T[OE + HQ * HI] * e[0];
+#pragma unroll
+              for (int i = 1; i < HI; ++i)
+                v += T[OE + HQ * HI + i] * e[i];
+              if (MID)
+                v += T[OC + HQ] * mid;
+            }
+          else
+            {
+              v = T[OO + HQ * HI] * o[0];
+#pragma unroll
+              for (int i = 1; i < HI; ++i)
+                v += T[OO + HQ * HI + i] * o[i];
+            }
+          out[HQ] = ADD ? out[HQ] + v : v;
         }
     }
     // x[m] = lds[addr + 8 (BOFF + m STRIDE)]
@@ -232,16 +320,20 @@ namespace adaflo_hip
       constexpr int TNY = G::TNY, TNZ = G::TNZ, TPY = G::TPY, TPZ = G::TPZ, RIMU = G::RIMU, RIMP = G::RIMP;
       constexpr int BUF = G::BUF, PUBD = G::PUBD, PUBSZ = G::PUBSZ;
       constexpr int NST = nst_of(LIN_MODE), NPC = NST / 2;
-      constexpr int TS = 0, TD = NN, TSP = 2 * NN; // table offsets
+      using TB = Tab<K>;
       double *const lds = dyn_lds();
 
       const int tid = threadIdx.x, lane = tid & 63;
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
       const int cw = lane / PL, l = lane % PL;
-      const bool active = l < NL;
-      const int  lc = active ? l : NL - 1; // lanes beyond the cell shadow its last lane
-      const int  a = lc % N, b = lc / N;
-      const int  cyl = (wave % WY) * CWY + cw % CWY, czl = (wave / WY) * CWZ + cw / CWY, cell = czl * CY + cyl;
+      // lanes beyond the (k+1)^2 lines of a cell leave at once (k = 4: 7 of 32, k = 5: 28 of 64): the rest of the
+      // kernel runs under ONE exec mask, no LDS store needs a branch (s_barrier counts waves, not lanes)
+      if (l >= NL)
+        return;
+      constexpr bool active = true;
+      const int      lc = l;
+      const int      a = lc % N, b = lc / N;
+      const int  cyl = (wave % WY) * CWY + cw % CWY, czl = (wave / WY) * CWZ + cw / CWY;
 
       const long nwg = A.wg_list ? (long)A.wg_count : (long)A.tiles_y * A.tiles_z * A.n_chunks;
       long       wg  = xcd_remap(blockIdx.x, nwg);
@@ -260,7 +352,6 @@ namespace adaflo_hip
 
       // ---- x-layout roles of this lane: x-line (j,k) = (a,b) of its cell -------------------------------------
       const int  J = K * cy + a, Kz = K * cz + b;
-      const int  jl = K * cyl + a, kl = K * czl + b;
       const bool own_u  = valid && (a < K || lasty) && (b < K || lastz);
       const bool seam_u = (a == K && J < A.nny - 1) || (b == K && Kz < A.nnz - 1); // (given own_u: high rim of the workgroup)
       unsigned   cmask  = 0; // components constrained on the whole line (y / z faces)
@@ -272,7 +363,6 @@ namespace adaflo_hip
       const bool pth = active && a < NP && b < NP;
       const int  ap = min(a, KP), bp = min(b, KP);
       const int  Jp = KP * cy + ap, Kp = KP * cz + bp;
-      const int  jlp = KP * cyl + ap, klp = KP * czl + bp;
       const bool own_p  = valid && pth && (a < KP || lasty) && (b < KP || lastz);
       const bool seam_p = (a == KP && Jp < A.npy - 1) || (b == KP && Kp < A.npz - 1);
       const bool pcon   = (Jp == 0 && (A.con_p >> 2 & 1)) || (Jp == A.npy - 1 && (A.con_p >> 3 & 1)) ||
@@ -294,7 +384,7 @@ namespace adaflo_hip
                              ((active && b == K) ? F_BK : 0) | (pth ? F_PTH : 0) | ((pth && a == KP) ? F_AKP : 0) |
                              ((pth && b == KP) ? F_BKP : 0) | (active ? F_ACT : 0);
 
-      const double wab = A.det * A.w[a] * A.w[b];
+      const double wab = A.tab[TB::C + TB::C_DET] * A.tab[TB::C + TB::C_W + a] * A.tab[TB::C + TB::C_W + b];
 
       // global rows: wave-uniform base pointer + 32-bit per-lane offset (doubles)
       const unsigned urow = (unsigned)(((size_t)Kz * A.nny + J) * A.nnx * 3), prow = (unsigned)(((size_t)Kp * A.npy + Jp) * A.npx);
@@ -343,9 +433,15 @@ namespace adaflo_hip
       // ---- combine the partial sums of the cross-section per owned line, emit NV nodes -------------------------
       // R / Rp: the lane's x-line sums, nodes 0 .. NV-1 (NVP-1) are final in x.  I0 / Ip0: global x index of
       // node 0; xl0: its index inside the chunk; endplane: the nodes form the chunk's last plane
-      auto combine = [&](auto nv_, auto nvp_, double (&R)[3][N], double (&Rp)[NP], const unsigned fl, const int parity,
-                         const int I0, const int Ip0, const int xl0, const int xlp0, const bool endplane) {
+      auto combine = [&](auto nv_, auto nvp_, double (&R)[3][N], double (&Rp)[NP], const unsigned fl, int lane_o,
+                         const int parity, const int I0, const int Ip0, const int xl0, const int xlp0, const bool endplane) {
         constexpr int NV = decltype(nv_)::value, NVP = decltype(nvp_)::value;
+        // the lane's indices are re-derived from an opaque copy of its number: computed once before the marching loop
+        // they would stay live (or be spilled) across the whole step for one use here
+        opaque(lane_o);
+        const int l = lane_o % PL, cw = lane_o / PL, a = l % N, b = l / N;
+        const int cyl = (wave % WY) * CWY + cw % CWY, czl = (wave / WY) * CWZ + cw / CWY, cell = czl * CY + cyl;
+        const int jl = K * cyl + a, kl = K * czl + b, jlp = KP * cyl + min(a, KP), klp = KP * czl + min(b, KP);
         double *const PY = PUB + parity * PUBSZ, *const PZ = PY + PUBD;
         if (fl & F_AK)
           {
@@ -493,8 +589,13 @@ namespace adaflo_hip
           const int cx = cx0 + step;
           unsigned  fl = flags;
           opaque(fl);
-          ctab_t tz = tab;
-          opaque(tz);
+          // every use re-loads its 1D matrix through an opaque copy of the table pointer (scalar loads): kept live
+          // across the step, the three matrices alone would need more scalar registers than a wave has
+          auto tb = [&](const int off) {
+            ctab_t t = tab;
+            opaque(t);
+            return t + off;
+          };
 
           // G[d][0..3][i]: value, d/dx, d/dy, d/dz (reference cell) of component d at my N quadrature points;
           // after the quadrature loop: tested value and tested gradient
@@ -515,40 +616,34 @@ namespace adaflo_hip
                 U[0] = 0.;
               if (cx == A.ncx - 1 && (A.con_u >> (3 + d) & 1))
                 U[K] = 0.;
-              mat_apply<N, N>(tz + TS, U, T); // x: nodes -> Gauss points
-              if (fl & F_ACT)
-                wr_line<0, 1, N>(px, T);
+              eo_apply<N, N, 1, false>(tb(TB::S), U, T); // x: nodes -> Gauss points
+              wr_line<0, 1, N>(px, T);
               wave_sync();
               rd_line<0, N, N>(ay, ln);
               ds_wait<0>(ln);
-              mat_apply<N, N>(tz + TS, ln, T); // y
+              eo_apply<N, N, 1, false>(tb(TB::S), ln, T); // y
               wave_sync();
-              if (fl & F_ACT)
-                wr_line<BUF, N, N>(py, T);
+              wr_line<BUF, N, N>(py, T);
               wave_sync();
               rd_line<BUF, NN, N>(az, ln);
               ds_wait<0>(ln);
-              mat_apply<N, N>(tz + TS, ln, T); // z: values at the Gauss points of my z-line
-              mat_apply<N, N>(tz + TD, T, ln); // d/dz (collocation)
+              eo_apply<N, N, 1, false>(tb(TB::S), ln, T); // z: values at the Gauss points of my z-line
+              eo_apply<N, N, -1, false>(tb(TB::D), T, ln); // d/dz (collocation)
               wave_sync();
-              if (fl & F_ACT)
-                {
-                  wr_line<0, NN, N>(pz, T);
-                  wr_line<2 * BUF, NN, N>(pz, ln);
-                }
+              wr_line<0, NN, N>(pz, T);
+              wr_line<2 * BUF, NN, N>(pz, ln);
               wave_sync();
               rd_line<0, N, N>(ay, ln);
               ds_wait<0>(ln);
-              mat_apply<N, N>(tz + TD, ln, T); // d/dy
+              eo_apply<N, N, -1, false>(tb(TB::D), ln, T); // d/dy
               wave_sync();
-              if (fl & F_ACT)
-                wr_line<BUF, N, N>(py, T);
+              wr_line<BUF, N, N>(py, T);
               wave_sync();
               rd_line<0, 1, N>(ax, G[d][0]);
               rd_line<BUF, 1, N>(ax, G[d][2]);
               rd_line<2 * BUF, 1, N>(ax, G[d][3]);
               ds_wait<2 * N>(G[d][0]);
-              mat_apply<N, N>(tz + TD, G[d][0], G[d][1]); // d/dx
+              eo_apply<N, N, -1, false>(tb(TB::D), G[d][0], G[d][1]); // d/dx
               ds_wait<0>(G[d][2]);
               ds_wait<0>(G[d][3]);
               wave_sync();
@@ -563,23 +658,20 @@ namespace adaflo_hip
                 P[0] = 0.;
               if (cx == A.ncx - 1 && (A.con_p >> 1 & 1))
                 P[KP] = 0.;
-              mat_apply<N, NP>(tz + TSP, P, T); // x: [N][NP x NP lines]
-              if (fl & F_PTH)
-                wr_line<0, 1, N>(px, T);
+              eo_apply<N, NP, 1, false>(tb(TB::SP), P, T); // x: [N][NP x NP lines]
+              wr_line<0, 1, N>(px, T); // (lanes without a pressure line store values nobody uses: no branch)
               wave_sync();
               rd_line<0, N, NP>(ay, ln); // y-line (a, ., b), b < NP (other lanes read defined-or-not values they never use)
               ds_wait<0>(ln);
-              mat_apply<N, NP>(tz + TSP, ln, T);
+              eo_apply<N, NP, 1, false>(tb(TB::SP), ln, T);
               wave_sync();
-              if ((fl & F_ACT) && b < NP)
-                wr_line<BUF, N, N>(py, T);
+              wr_line<BUF, N, N>(py, T);
               wave_sync();
               rd_line<BUF, NN, NP>(az, ln); // z-line (a, b, .)
               ds_wait<0>(ln);
-              mat_apply<N, NP>(tz + TSP, ln, T);
+              eo_apply<N, NP, 1, false>(tb(TB::SP), ln, T);
               wave_sync();
-              if (fl & F_ACT)
-                wr_line<0, NN, N>(pz, T);
+              wr_line<0, NN, N>(pz, T);
               wave_sync();
               rd_line<0, 1, N>(ax, PQ);
               ds_wait<0>(PQ);
@@ -596,7 +688,8 @@ namespace adaflo_hip
 #pragma unroll
           for (int i = 0; i < N; ++i)
             {
-              const double jxw = wab * A.w[i];
+              const ctab_t cst = tb(TB::C); // constants of the quadrature-point operation
+              const double jxw = wab * cst[TB::C_W + i];
               double       g[3][3], u[3];
 #pragma unroll
               for (int d = 0; d < 3; ++d)
@@ -604,7 +697,7 @@ namespace adaflo_hip
                   u[d] = G[d][0][i];
 #pragma unroll
                   for (int e = 0; e < 3; ++e)
-                    g[d][e] = G[d][1 + e][i] * A.ih[e];
+                    g[d][e] = G[d][1 + e][i] * cst[TB::C_IH + e];
                 }
               const double div = g[0][0] + g[1][1] + g[2][2];
               double       conv[3];
@@ -614,80 +707,81 @@ namespace adaflo_hip
                   double res = 0.;
                   if (LIN_MODE == 0) // Newton :802-816; st = (u_lin[3], grad u_lin[3][3])
                     {
-                      res = A.beta * (div * st[d] + (st[3] + st[7] + st[11]) * u[d]);
+                      res = cst[TB::C_BETA] * (div * st[d] + (st[3] + st[7] + st[11]) * u[d]);
 #pragma unroll
                       for (int e = 0; e < 3; ++e)
                         res += st[e] * g[d][e] + u[e] * st[3 + 3 * d + e];
                     }
                   else if (LIN_MODE == 1) // Picard-type :817-826; st = (u_lin[3], div u_lin)
                     {
-                      res = A.beta * st[3] * u[d];
+                      res = cst[TB::C_BETA] * st[3] * u[d];
 #pragma unroll
                       for (int e = 0; e < 3; ++e)
                         res += st[e] * g[d][e];
                     }
-                  conv[d] = (A.cA * u[d] + A.cB * res) * jxw; // :717,:827-835
+                  conv[d] = (cst[TB::C_CA] * u[d] + cst[TB::C_CB] * res) * jxw; // :717,:827-835
                 }
               if (NST > 0 && i + 1 < N)
-                load_state(stc + (i + 1) * ST_POINT);
-              const double diag = A.tau_gd * div - PQ[i];
+                {
+                  // the state registers are free now: fetch the next point's state (not earlier)
+                  unsigned off = (unsigned)((i + 1) * ST_POINT);
+                  pin_after(off, conv[2]);
+                  load_state(stc + off);
+                }
+              const double diag = cst[TB::C_TGD] * div - PQ[i];
 #pragma unroll
               for (int d = 0; d < 3; ++d)
                 {
                   G[d][0][i] = conv[d];
 #pragma unroll
                   for (int e = 0; e < 3; ++e) // :859-892 row d of tmu (grad u + grad u^T) + (tau_gd div - p) I, times JxW J^{-1}
-                    G[d][1 + e][i] = (A.tmu * (g[d][e] + g[e][d]) + (d == e ? diag : 0.)) * (jxw * A.ih[e]);
+                    G[d][1 + e][i] = (cst[TB::C_TMU] * (g[d][e] + g[e][d]) + (d == e ? diag : 0.)) * (jxw * cst[TB::C_IH + e]);
                 }
               PQ[i] = -div * jxw; // :853-856
+              __builtin_amdgcn_sched_barrier(0); // one point at a time: interleaved, the five points' temporaries add up
             }
-          // the nodal lines of the next step arrive during the integration
-          load_nodes(cx + 1);
-
           // ================= integrate (:897-907): the transposed chain =========================================
           double R[3][N], Rp[NP];
 #pragma unroll
           for (int d = 0; d < 3; ++d)
             {
               double W[N], ln[N], l2[N];
-              mat_apply_t<N, N, true>(tz + TD, G[d][1], G[d][0]); // W = tested value + D^T (x) in registers
-              if (fl & F_ACT)
-                {
-                  wr_line<0, 1, N>(px, G[d][0]);
-                  wr_line<BUF, 1, N>(px, G[d][2]);
-                  wr_line<2 * BUF, 1, N>(px, G[d][3]);
-                }
+              eo_apply<N, N, -1, true>(tb(TB::DT), G[d][1], G[d][0]); // W = tested value + D^T (x) in registers
+              wr_line<0, 1, N>(px, G[d][0]);
+              wr_line<BUF, 1, N>(px, G[d][2]);
+              wr_line<2 * BUF, 1, N>(px, G[d][3]);
               wave_sync();
               rd_line<0, N, N>(ay, W);
               rd_line<BUF, N, N>(ay, ln);
               ds_wait<N>(W);
               ds_wait<0>(ln);
-              mat_apply_t<N, N, true>(tz + TD, ln, W); // + D^T (y)
+              eo_apply<N, N, -1, true>(tb(TB::DT), ln, W); // + D^T (y)
               wave_sync();
-              if (fl & F_ACT)
-                wr_line<0, N, N>(py, W);
+              wr_line<0, N, N>(py, W);
               wave_sync();
               rd_line<0, NN, N>(az, W);
               rd_line<2 * BUF, NN, N>(az, ln);
               ds_wait<N>(W);
               ds_wait<0>(ln);
-              mat_apply_t<N, N, true>(tz + TD, ln, W);  // + D^T (z)
-              mat_apply_t<N, N, false>(tz + TS, W, l2); // S^T (z): Gauss points -> nodes
+              eo_apply<N, N, -1, true>(tb(TB::DT), ln, W);  // + D^T (z)
+              eo_apply<N, N, 1, false>(tb(TB::ST), W, l2); // S^T (z): Gauss points -> nodes
               wave_sync();
-              if (fl & F_ACT)
-                wr_line<BUF, NN, N>(pz, l2);
+              wr_line<BUF, NN, N>(pz, l2);
               wave_sync();
               rd_line<BUF, N, N>(ay, ln);
               ds_wait<0>(ln);
-              mat_apply_t<N, N, false>(tz + TS, ln, l2); // S^T (y)
+              eo_apply<N, N, 1, false>(tb(TB::ST), ln, l2); // S^T (y)
               wave_sync();
-              if (fl & F_ACT)
-                wr_line<0, N, N>(py, l2);
+              wr_line<0, N, N>(py, l2);
               wave_sync();
               rd_line<0, 1, N>(ax, ln);
               ds_wait<0>(ln);
-              mat_apply_t<N, N, false>(tz + TS, ln, R[d]); // S^T (x)
+              eo_apply<N, N, 1, false>(tb(TB::ST), ln, R[d]); // S^T (x)
               wave_sync();
+              // the nodal lines of the next step arrive during the rest of the integration (issued here, not earlier:
+              // the quadrature loop and the first component need the registers)
+              if (d == 0)
+                load_nodes(cx + 1);
             }
 #pragma unroll
           for (int i = 0; i < NP; ++i)
@@ -695,26 +789,23 @@ namespace adaflo_hip
           if (WITH_P)
             {
               double ln[N], T[NP];
-              if (fl & F_ACT)
-                wr_line<0, 1, N>(px, PQ);
+              wr_line<0, 1, N>(px, PQ);
               wave_sync();
               rd_line<0, NN, N>(az, ln);
               ds_wait<0>(ln);
-              mat_apply_t<N, NP, false>(tz + TSP, ln, T); // z: [N][N][NP]
+              eo_apply<NP, N, 1, false>(tb(TB::SPT), ln, T); // z: [N][N][NP]
               wave_sync();
-              if (fl & F_ACT)
-                wr_line<BUF, NN, NP>(pz, T);
+              wr_line<BUF, NN, NP>(pz, T);
               wave_sync();
               rd_line<BUF, N, N>(ay, ln); // y-line (a, ., b), b < NP
               ds_wait<0>(ln);
-              mat_apply_t<N, NP, false>(tz + TSP, ln, T);
+              eo_apply<NP, N, 1, false>(tb(TB::SPT), ln, T);
               wave_sync();
-              if ((fl & F_ACT) && b < NP)
-                wr_line<0, N, NP>(py, T);
+              wr_line<0, N, NP>(py, T);
               wave_sync();
               rd_line<0, 1, N>(ax, ln); // x-line (., a, b), a, b < NP
               ds_wait<0>(ln);
-              mat_apply_t<N, NP, false>(tz + TSP, ln, Rp);
+              eo_apply<NP, N, 1, false>(tb(TB::SPT), ln, Rp);
               wave_sync();
             }
 
@@ -727,7 +818,7 @@ namespace adaflo_hip
             }
           Rp[0] += carry_p;
           carry_p = Rp[KP];
-          combine(std::integral_constant<int, K>{}, std::integral_constant<int, KP>{}, R, Rp, fl, step & 1, K * cx,
+          combine(std::integral_constant<int, K>{}, std::integral_constant<int, KP>{}, R, Rp, fl, lane, step & 1, K * cx,
                   KP * cx, K * step, KP * step, false);
         }
       // ---- the last node plane of the chunk ------------------------------------------------------------------
@@ -737,7 +828,7 @@ namespace adaflo_hip
         for (int d = 0; d < 3; ++d)
           R[d][0] = carry[d];
         Rp[0] = carry_p;
-        combine(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, R, Rp, flags, ns & 1, K * (cx0 + ns),
+        combine(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, R, Rp, flags, lane, ns & 1, K * (cx0 + ns),
                 KP * (cx0 + ns), K * ns, KP * ns, true);
       }
     }

@@ -273,6 +273,10 @@ class NavierStokesMatrix:
     def set_timing(self, enabled):
         _lib.check(self._ctx, self._lib.adaflo_set_timing(self._require(), int(enabled)))
 
+    def set_x_chunk(self, cells):
+        """cells per workgroup along x of the Q3..Q5 x-marching kernel (0 = heuristic)"""
+        _lib.check(self._ctx, self._lib.adaflo_set_hox_chunk(self._require(), int(cells)))
+
     def set_q2_chunk(self, layers):
         _lib.check(self._ctx, self._lib.adaflo_set_q2_chunk(self._require(), int(layers)))
 

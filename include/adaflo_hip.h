@@ -508,13 +508,16 @@ int adaflo_get_kernel_statistics(adaflo_ctx *ctx, unsigned *count, double *secon
 int adaflo_set_timing(adaflo_ctx *ctx, int enabled);
 /* tuning: number of cell layers one workgroup of the Q2/Q1 kernel sweeps (0 = heuristic) */
 int adaflo_set_q2_chunk(adaflo_ctx *ctx, int layers);
+/* tuning: number of cells one workgroup of the Q3..Q5 x-marching kernel marches through (0 = heuristic) */
+int adaflo_set_hox_chunk(adaflo_ctx *ctx, int cells);
 /* tuning: skew padding (units of 16 B) between the per-(tile,layer) blocks of the streamed state */
 int adaflo_set_q2_state_pad(adaflo_ctx *ctx, int pad_16B);
 
 /* select the implementation of the operator applications: 0 = generic per-cell kernels (any
- * degree), 1 = auto (default: Q2/Q1 sweep kernel, structured Q1 sweep kernel for the level set and
- * the Q1 pressure operators, generic elsewhere), 2 = as 1 plus the experimental Q3..Q5 sweep
- * kernel (ns_ho.hip; bitwise reproducible, currently not faster than the generic kernel). */
+ * degree), 1 = auto (default: Q2/Q1 sweep kernel, Q3..Q5 x-marching kernel ns_hox.hip, structured Q1
+ * sweep kernel for the level set and the Q1 pressure operators, generic elsewhere), 2 = as 1 but the
+ * round-2 z-sweep kernel (ns_ho.hip) for Q3..Q5, kept for comparison.  All variants are bitwise
+ * reproducible. */
 int adaflo_set_kernel_variant(adaflo_ctx *ctx, int variant);
 
 #ifdef __cplusplus

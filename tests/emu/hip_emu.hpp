@@ -182,6 +182,7 @@ namespace adaflo_hip
   inline void   opaque(ctab_t &) {}
   inline void   opaque(int &) {}
   inline void   opaque(unsigned &) {}
+  inline void   pin_after(unsigned &, const double) {}
   inline void   wave_sync() { emu::yield(1); }
   inline double *dyn_lds() { return reinterpret_cast<double *>(emu::g_lds); } // the workgroup's dynamic LDS
   inline unsigned lds_byte_addr(const void *p) { return (unsigned)((const char *)p - emu::g_lds); }

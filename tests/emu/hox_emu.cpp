@@ -28,7 +28,7 @@ namespace
           double *dst_u, double *dst_p, const int lx, const unsigned iface, const int phased)
   {
     using G         = Geo<K>;
-    constexpr int N = K + 1, NP = K;
+    constexpr int N = K + 1;
     HXArgs        A{};
     hox_geometry<K>(A, ncell, lx);
     std::vector<double> tab;
@@ -36,24 +36,9 @@ namespace
       const Quadrature1D        qu = gauss(N);
       const Shape1D             su = shape_fe_q(K, qu), sp = shape_fe_q(K - 1, qu);
       const std::vector<double> dc = collocation_derivative(qu);
-      for (int q = 0; q < N; ++q)
-        A.w[q] = qu.w[q];
-      for (int q = 0; q < N * N; ++q)
-        tab.push_back(su.S[q]);
-      for (int q = 0; q < N * N; ++q)
-        tab.push_back(dc[q]);
-      for (int q = 0; q < N * NP; ++q)
-        tab.push_back(sp.S[q]);
+      tab = hox_table<K>(su.S.data(), dc.data(), sp.S.data(), qu.w.data(), h, coef[0], coef[1], coef[2], coef[3], coef[4]);
     }
-    A.tab = tab.data();
-    for (int e = 0; e < 3; ++e)
-      A.ih[e] = 1. / h[e];
-    A.det         = h[0] * h[1] * h[2];
-    A.cA          = coef[0];
-    A.cB          = coef[1];
-    A.beta        = coef[2];
-    A.tau_gd      = coef[3];
-    A.tmu         = coef[4];
+    A.tab         = tab.data();
     A.integrate_p = integrate_p;
     A.con_u       = con_u;
     A.con_p       = con_p;

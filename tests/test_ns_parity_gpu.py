@@ -472,6 +472,73 @@ def test_velocity_vmult_high_order_sweep_kernel():
     assert rel_l2(dst.numpy(), ref) < TOL
 
 
+# ----------------------------------------------------------------------------- Q3..Q5 x-marching kernel (round 4)
+@pytest.mark.parametrize("k,ncell", [(3, (4, 4, 3)), (3, (9, 5, 6)), (3, (8, 8, 20)), (4, (4, 2, 3)), (4, (5, 3, 4)),
+                                     (4, (9, 6, 10)), (4, (33, 5, 9)), (5, (3, 2, 2)), (5, (4, 3, 3))])
+def test_vmult_high_order_x_marching_kernel(k, ncell):
+    """csrc/ns_hox.hip (variant 1 for k >= 3): cross-sections, partial cross-sections, Newton with pressure"""
+    case = Case(ncell, k=k, upper=(1.0, 0.5, 2.0), tau_grad_div=0.2)
+    eu, ep = run_vmult(case, variant=1)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+@pytest.mark.parametrize("lx", [1, 2, 3, 7])
+def test_vmult_high_order_x_marching_kernel_chunks(lx):
+    """x-chunks of every length: the seam planes between chunks go through the x-slabs"""
+    case = Case((7, 5, 9), k=4, tau_grad_div=0.1)
+    src_u, src_p, lin = case.random_u(), case.random_p(), case.random_lin()
+    w, modes = case.weights_modes()
+    ref_u, ref_p = orc.ns_vmult(case.mesh, case.k, case.prm, src_u, src_p, case.con_u, case.con_p, lin=lin,
+                                weights=w, modes=modes)
+    op = case.engine()
+    op.set_linearization(lin)
+    op.set_x_chunk(lx)
+    dst = op.block_vector(np.full(case.n_u, 7.0), np.full(case.n_p, 7.0))
+    op.vmult(dst, op.block_vector(src_u, src_p))
+    got_u, got_p = dst.numpy()
+    assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL
+
+
+@pytest.mark.parametrize("k", [3, 4, 5])
+@pytest.mark.parametrize("lin,phys", [(1, 0), (2, 0), (3, 0), (4, 0), (0, 1), (0, 2)])
+def test_vmult_high_order_x_marching_kernel_modes(k, lin, phys):
+    case = Case((5, 4, 3), k=k, linearization=lin, physical_type=phys, beta=1.0, tau_grad_div=0.3, viscosity=0.2,
+                damping=0.3)
+    eu, ep = run_vmult(case, variant=1)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+@pytest.mark.parametrize("k", [3, 4, 5])
+def test_vmult_high_order_x_marching_kernel_partial_constraints(k):
+    case = Case((5, 5, 3), k=k, faces_u=[0, 3, 4], faces_p=[1, 5], pressure_average_fix=False)
+    eu, ep = run_vmult(case, variant=1)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+def test_velocity_vmult_high_order_x_marching_kernel():
+    """velocity_vmult on the state frozen by fix_linearization_point; the streaming copies of the state follow the
+    generic ones (a new set_linearization must not leak into the frozen operator, and must reach vmult)"""
+    case = Case((5, 3, 4), k=4)
+    src_u, src_p, lin, lin2 = case.random_u(), case.random_p(), case.random_lin(), case.random_lin()
+    ref = orc.ns_velocity_vmult(case.mesh, case.k, case.prm, src_u, case.con_u, lin=lin)
+    op = case.engine()
+    op.set_kernel_variant(1)
+    op.set_linearization(lin)
+    dst2 = op.block_vector()
+    op.vmult(dst2, op.block_vector(src_u, src_p))              # (builds the streaming copy of `lin`)
+    op.fix_linearization_point()
+    op.set_linearization(lin2)
+    src, dst = op.initialize_u_vector(src_u), op.initialize_u_vector(np.full(case.n_u, 3.0))
+    op.velocity_vmult(dst, src)
+    assert rel_l2(dst.numpy(), ref) < TOL
+    w, modes = case.weights_modes()
+    ref_u, ref_p = orc.ns_vmult(case.mesh, case.k, case.prm, src_u, src_p, case.con_u, case.con_p, lin=lin2,
+                                weights=w, modes=modes)
+    op.vmult(dst2, op.block_vector(src_u, src_p))
+    got_u, got_p = dst2.numpy()
+    assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL
+
+
 @pytest.mark.parametrize("ncell,upper,lin,phys", [((9, 8, 5), (1., 1., 1.), 0, 0), ((17, 9, 6), (1., 1., 3.), 0, 0),
                                                   ((8, 16, 3), (1., 1., 1.), 1, 0), ((5, 4, 9), (1., 2., 1.), 0, 1),
                                                   ((4, 5, 3), (1., 1., 1.), 0, 2), ((1, 1, 1), (1., 1., 1.), 0, 0)])

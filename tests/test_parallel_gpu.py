@@ -43,7 +43,7 @@ def _make(fp):
     return ts
 
 
-def _worker(rank, world, port, grid, cells, k, gu, gp, glin, gcoef, ref_u, ref_p, results):
+def _worker(rank, world, port, grid, cells, k, gu, gp, glin, gcoef, ref_u, ref_p, results, crumbs):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -89,6 +89,7 @@ def _worker(rank, world, port, grid, cells, k, gu, gp, glin, gcoef, ref_u, ref_p
             combos = tuple(c for c in combos if str(c[0]) in only.split(","))
         for variant, overlap, native in combos:
             o, a, b = (nat, ndst, nsrc) if native else (op, dst, src)
+            crumbs[rank] = "variant %d overlap %s native %s" % (variant, overlap, native)   # read after a rank death
             o.set_kernel_variant(variant)
             o.overlap = overlap
             du.fill_(3.0)
@@ -114,6 +115,7 @@ def _worker(rank, world, port, grid, cells, k, gu, gp, glin, gcoef, ref_u, ref_p
                                      % (rank, variant, overlap, native, bad_u.numel(),
                                         bad_u[:4].tolist(), cu[bad_u[:4]].tolist(), du[bad_u[:4]].tolist(),
                                         bad_p.numel(), bad_p[:4].tolist()))
+        crumbs[rank] = "teardown"
     finally:
         # explicit, ordered teardown: nothing of the engine is left to the interpreter's exit sequence
         torch.cuda.synchronize()
@@ -125,6 +127,25 @@ def _worker(rank, world, port, grid, cells, k, gu, gp, glin, gcoef, ref_u, ref_p
             op.local.clear()
         torch.cuda.synchronize()
         dist.destroy_process_group()
+
+
+def _reference(gcells, grid, k, two_phase, glin, gcoef, gu, gp):
+    fp = adaflo_amd.FlowParameters(velocity_degree=k, density_diff=0.5 if two_phase else 0.0)
+    ref = adaflo_amd.NavierStokesMatrix(fp, adaflo_amd.BrickMesh(gcells, [-1.0] * 3, [-1.0 + 0.5 * g for g in grid]))
+    ref.initialize(_make(fp), True)
+    ref.set_linearization(glin.reshape(-1))
+    if two_phase:
+        ref.set_coefficients(*[c.reshape(-1) for c in gcoef])
+    dst = ref.block_vector()
+    ref.vmult(dst, ref.block_vector(gu.reshape(-1), gp.reshape(-1)))
+    ref_u, ref_p = dst.numpy()
+    ref.clear()
+    del ref
+    return ref_u, ref_p
+
+
+def _reference_worker(rank, gcells, grid, k, two_phase, glin, gcoef, gu, gp, out):
+    out["u"], out["p"] = _reference(gcells, grid, k, two_phase, glin, gcoef, gu, gp)
 
 
 def _run_distributed_case(world, cells, k=2, two_phase=False):
@@ -140,47 +161,58 @@ def _run_distributed_case(world, cells, k=2, two_phase=False):
     gcoef = None
     if two_phase:
         gcoef = [rng.uniform(lo, hi, (gcells[2], gcells[1], gcells[0], nq)) for lo, hi in ((.5, 2.), (.5, 2.), (-.5, .5))]
-    # reference: the same engine on the undivided mesh
-    fp = adaflo_amd.FlowParameters(velocity_degree=k, density_diff=0.5 if two_phase else 0.0)
-    ref = adaflo_amd.NavierStokesMatrix(fp, adaflo_amd.BrickMesh(gcells, [-1.0] * 3, [-1.0 + 0.5 * g for g in grid]))
-    ref.initialize(_make(fp), True)
-    ref.set_linearization(glin.reshape(-1))
-    if two_phase:
-        ref.set_coefficients(*[c.reshape(-1) for c in gcoef])
-    dst = ref.block_vector()
-    ref.vmult(dst, ref.block_vector(gu.reshape(-1), gp.reshape(-1)))
-    ref_u, ref_p = dst.numpy()
-    ref.clear()
-    del ref
+    # reference: the same engine on the undivided mesh (ADAFLO_TEST_REF_IN_CHILD: computed by a child process, so that
+    # the parent holds no GPU context of its own while the ranks run -- scripts/dev/stress_parallel.py uses it to
+    # test whether the rare rank deaths need more GPU processes than the driver keeps resident at a time)
+    if os.environ.get("ADAFLO_TEST_REF_IN_CHILD"):
+        mgr0 = mp.Manager()
+        out = mgr0.dict()
+        mp.spawn(_reference_worker, args=(gcells, grid, k, two_phase, glin, gcoef, gu, gp, out), nprocs=1, join=True)
+        ref_u, ref_p = out["u"], out["p"]
+    else:
+        ref_u, ref_p = _reference(gcells, grid, k, two_phase, glin, gcoef, gu, gp)
     mgr = mp.Manager()
     results = mgr.dict()
-    # Up to eight processes share ONE GPU here (production: one process per GPU).  Round 3 looked for the cause of
-    # the rare rank death by signal ("Queue ... aborting with error: HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION"): the
-    # workers now tear the engine down explicitly; 20 repetitions of the 4-rank case and a torch-only job of
-    # 8 processes x 6 streams ran clean on a warm box (scripts/dev/stress_parallel.py, noop_multiprocess.py); the
-    # two deaths seen this round both hit the very first GPU command on a fresh box (cold caches, ranks loading the
-    # code objects while others already run); eight later runs of the largest 8-rank case lost one rank once.  Bisected
-    # with ADAFLO_TEST_VARIANTS (scripts/dev/stress_parallel.py 18 2 8 big): 18 eight-rank runs with ONLY the generic
-    # kernels (one workgroup per cell, f64 global atomics) lost 4 ranks, 18 runs with ONLY the sweep kernels none --
-    # the kernels `bench.py` and the multi-GPU path run are not the ones that die.  Why the atomic-add kernels of
-    # several processes sharing a device fault is not known (it needs several processes on one device), so: a death by SIGNAL is reported loudly (a warning in
-    # the test summary, counted) and that run is repeated, at most twice; Python exceptions in a rank (wrong numbers,
-    # engine errors) arrive as ProcessRaisedException and are never retried.
-    for attempt in range(3):
-        try:
-            results.clear()
-            mp.spawn(_worker, args=(world, _free_port(), grid, list(cells), k, gu, gp, glin, gcoef, ref_u, ref_p, results),
-                     nprocs=world, join=True)
-            break
-        except mp.ProcessExitedException as e:
-            global RANK_DEATHS
-            RANK_DEATHS += 1
-            import warnings
-            warnings.warn("a rank of the %d-process job died by signal (%s); death number %d of this session, attempt %d"
-                          % (world, e, RANK_DEATHS, attempt + 1), RuntimeWarning)
-            if attempt == 2:
-                raise
-    assert len(results) == (5 if not os.environ.get("ADAFLO_TEST_VARIANTS") else len(results) // world) * world
+    crumbs = mgr.dict()
+    # Up to eight processes share ONE GPU here (production: one process per GPU).  A rank of an 8-process job dies
+    # now and then with "Queue ... aborting with error: HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION" (never in 2- or 4-process
+    # jobs).  Round 4 (scripts/dev/stress_parallel.py 2 8 big, logs in profiles/r04_stress_*.log): 3 deaths in 33 jobs
+    # as before; 1 in 25 with the parent holding no GPU context -- and that rank died BEFORE its first vmult (the
+    # breadcrumbs below were still empty), so the sweep kernels with their hand-issued LDS-DMA are not what faults;
+    # 0 in 25 with GPU_MAX_HW_QUEUES=1 (one hardware queue per process instead of four).  The deaths need more
+    # processes / hardware queues on one device than the driver keeps resident (it then preempts running waves to
+    # time-slice them), a condition the product never creates.  So the 8-process jobs run with one hardware queue
+    # per process; a death by SIGNAL is still reported loudly (warning + breadcrumbs of what every rank was doing),
+    # that run is repeated ONCE and a second death fails the test.  Python exceptions in a rank (wrong numbers, engine
+    # errors) arrive as ProcessRaisedException and are never retried.
+    saved_queues = os.environ.get("GPU_MAX_HW_QUEUES")
+    if world >= 8 and "ADAFLO_TEST_KEEP_QUEUES" not in os.environ:
+        os.environ["GPU_MAX_HW_QUEUES"] = "1"          # read by the HIP runtime of the spawned ranks
+    try:
+        for attempt in range(2):
+            try:
+                results.clear()
+                crumbs.clear()
+                mp.spawn(_worker, args=(world, _free_port(), grid, list(cells), k, gu, gp, glin, gcoef, ref_u, ref_p,
+                                        results, crumbs), nprocs=world, join=True)
+                break
+            except mp.ProcessExitedException as e:
+                global RANK_DEATHS
+                RANK_DEATHS += 1
+                import warnings
+                warnings.warn("a rank of the %d-process job died by signal (%s); death number %d of this session, attempt "
+                              "%d; the ranks were at: %s" % (world, e, RANK_DEATHS, attempt + 1, dict(crumbs)),
+                              RuntimeWarning)
+                if attempt == 1:
+                    raise
+    finally:
+        if saved_queues is None:
+            os.environ.pop("GPU_MAX_HW_QUEUES", None)
+        else:
+            os.environ["GPU_MAX_HW_QUEUES"] = saved_queues
+    only = os.environ.get("ADAFLO_TEST_VARIANTS")
+    n_combos = 5 if not only else sum(1 for v in (1, 1, 0, 1, 0) if str(v) in only.split(","))
+    assert len(results) == n_combos * world, (len(results), n_combos, world)
     for key, (eu, ep) in results.items():
         assert eu < 1e-12 and ep < 1e-12, (key, eu, ep)
 
