@@ -16,11 +16,19 @@ namespace adaflo_hip
   __device__ __forceinline__ void opaque(ctab_t &t) { asm volatile("" : "+s"(t)); }
   __device__ __forceinline__ void opaque(int &v) { asm volatile("" : "+v"(v)); }
   __device__ __forceinline__ void opaque(unsigned &v) { asm volatile("" : "+v"(v)); }
+  __device__ __forceinline__ void opaque(double &v) { asm volatile("" : "+v"(v)); } // (also: "this load has arrived")
 
   // the offset becomes known only after `v` has been computed: pins a prefetch behind the arithmetic that frees its
   // destination registers (otherwise all loads of an unrolled loop are hoisted to its top and stay live together).
   // (An offset, not the pointer: behind an opaque pointer the compiler no longer knows the address space.)
   __device__ __forceinline__ void pin_after(unsigned &off, const double v) { asm volatile("" : "+v"(off) : "v"(v)); }
+
+  // about 2048 cycles of nothing
+  __device__ __forceinline__ void stall_cycles() { asm volatile("s_sleep 32" ::: "memory"); }
+  // diagnostic builds (-DHOX_STAMP): shader clock
+  __device__ __forceinline__ unsigned long long clock_now() { return __builtin_amdgcn_s_memtime(); }
+  // diagnostic builds (-DHOX_EXP=...): keeps a value alive without storing it anywhere
+  __device__ __forceinline__ void sink(const double v) { asm volatile("" : : "v"(v)); }
 
   // the workgroup's dynamic LDS
   __device__ __forceinline__ double *dyn_lds()
@@ -38,6 +46,52 @@ namespace adaflo_hip
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_sched_barrier(0); // phases stay phases: the scheduler otherwise interleaves them for ILP and the
                                        // kernel needs 440 instead of ~230 registers
+  }
+
+  // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load and store of
+  // the wave (vmcnt(0)) -- that would drain the prefetches in flight at every step of the marching loop
+  __device__ __forceinline__ void lds_barrier()
+  {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // LDS-DMA: every active lane copies 16 bytes from sbase + voff to LDS byte lds_byte + 16 * lane (sbase, lds_byte
+  // wave-uniform; `nt`: a once-read stream).  Asynchronous and invisible to the compiler's vmcnt bookkeeping: the
+  // consumer waits with wait_vmcnt<N>() (VMEM operations of a wave retire in issue order: "at most N outstanding"
+  // means everything older than the N youngest has landed) before it reads the slot with ds_rd128
+  __device__ __forceinline__ void dma_b128(const double *sbase, const unsigned voff, const unsigned lds_byte)
+  {
+    asm volatile("s_mov_b32 m0, %0\n\t"
+                 "global_load_lds_dwordx4 %1, %2 nt" ::"s"(lds_byte),
+                 "v"(voff), "s"(sbase)
+                 : "memory"); // (m0 cannot be named as a clobber; on gfx950 the compiler itself loads M0 right before
+                              // each of the few instructions that read it and keeps nothing in it)
+  }
+  template <int N>
+  __device__ __forceinline__ void wait_vmcnt()
+  {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  }
+  // a pointer the compiler must keep in scalar registers (operand of dma_b128)
+  __device__ __forceinline__ const double *uniform_ptr(const double *p)
+  {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned           lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v),
+                   hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return reinterpret_cast<const double *>(((unsigned long long)hi << 32) | lo);
+  }
+  // 16 bytes of LDS -> two doubles; completes with the next s_waitcnt lgkmcnt (lds_wait_all)
+  typedef double hox_double2 __attribute__((ext_vector_type(2)));
+  template <int OFF>
+  __device__ __forceinline__ void ds_rd128(const unsigned a, double &x, double &y)
+  {
+    hox_double2 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+    x = v.x;
+    y = v.y;
   }
 
   __device__ __forceinline__ unsigned lds_byte_addr(const void *p)

@@ -5,6 +5,8 @@
 #include "basis.hpp"
 #include "kernels.hpp"
 
+#include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <type_traits>
 #include <utility>
@@ -156,6 +158,14 @@ namespace adaflo_hip
         return e;
       if (int e = ensure(ctx->hox_xslab_p, n_wg * G::TPY * G::TPZ))
         return e;
+#if HOX_STAMP
+      {
+        static unsigned long long *stamps = nullptr;
+        if (!stamps)
+          (void)hipMalloc(&stamps, (size_t)1 << 24);
+        A.stamps = stamps;
+      }
+#endif
       A.slab_u  = ctx->hox_slab_u.p;
       A.xslab_u = ctx->hox_xslab_u.p;
       A.slab_p  = ctx->hox_slab_p.p;
@@ -189,7 +199,7 @@ namespace adaflo_hip
           A.iface     = iface;
           nwg         = A.wg_count;
         }
-      const size_t lds_bytes = sizeof(double) * (size_t)G::LDS_DOUBLES;
+      const size_t lds_bytes = (size_t)G::LDS_BYTES;
       const dim3   grid((unsigned)(nwg > 0 ? nwg : 1)), block(NTH);
       hipError_t   err  = hipSuccess;
       hipEvent_t   stop = (ctx->timing && nwg > 0) ? ctx->kernel_timer.start(ctx->stream) : nullptr;
@@ -234,6 +244,32 @@ namespace adaflo_hip
         return ADAFLO_EHIP;
       if (stop)
         (void)hipEventRecord(stop, ctx->stream);
+#if HOX_STAMP
+      {
+        // development aid: medians over the waves of the per-phase cycle sums of the launch just made
+        static int calls = 0;
+        if (++calls == 20)
+          {
+            (void)hipDeviceSynchronize();
+            std::vector<unsigned long long> h(n_wg * 4 * 10);
+            (void)hipMemcpy(h.data(), A.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            const char *name[9] = {"top-of-step wait", "evaluate u", "evaluate p", "quadrature loop", "integrate u", "integrate p", "publish", "barrier + collect", "emit"};
+            double      total   = 0;
+            for (int j = 0; j < 9; ++j)
+              {
+                std::vector<double> v;
+                for (size_t w = 0; w < n_wg * 4; ++w)
+                  if (h[w * 10 + 9])
+                    v.push_back((double)h[w * 10 + j] / (double)h[w * 10 + 9]);
+                std::sort(v.begin(), v.end());
+                std::fprintf(stderr, "hox stamp: %-18s median %8.0f  p10 %8.0f  p90 %8.0f cycles per step\n", name[j],
+                             v[v.size() / 2], v[v.size() / 10], v[v.size() * 9 / 10]);
+                total += v[v.size() / 2];
+              }
+            std::fprintf(stderr, "hox stamp: sum of medians %.0f cycles per step\n", total);
+          }
+      }
+#endif
       if (phase == -1 || phase == 1)
         ctx->kernel_timer.count++;
       if (phase == 0)

@@ -32,6 +32,24 @@ namespace adaflo_hip
 {
   namespace hox
   {
+    // Diagnostic builds (scripts/exp_ho.sh, results are WRONG, timing only): HOX_EXP & 1 = no LDS traffic (the
+    // transpositions become register copies), & 2 = no 1D contractions, & 4 = no state stream, & 8 = state from L2,
+    // & 16 = no stores, & 32 = no loads of the nodal lines, & 64 = no publish / barrier / collect
+#ifndef HOX_EXP
+#define HOX_EXP 0
+#endif
+    // HOX_STAMP: s_memtime stamps at the phase boundaries of a step, summed per wave into HXArgs::stamps
+    // ([workgroup * 4 + wave][10] cycles: top-of-step wait, evaluate, pressure evaluate, quadrature loop, integrate,
+    // pressure integrate, publish, barrier + collect, emit, steps) -- the launcher prints the medians (development aid)
+#ifndef HOX_STAMP
+#define HOX_STAMP 0
+#endif
+#ifndef HOX_STAGGER
+#define HOX_STAGGER 0
+#endif
+#ifndef HOX_REGPT
+#define HOX_REGPT 2
+#endif
     constexpr int NTH  = 256;
     constexpr int NMAX = 6;
     constexpr int NLIN_ = 12;
@@ -67,9 +85,16 @@ namespace adaflo_hip
       static constexpr int RIMU = TNY + TNZ - 1, RIMP = TPY + TPZ - 1;
       static constexpr int BUF  = CPW * N3;        // one transposition buffer of a wave (doubles)
       static constexpr int WAVE = 3 * BUF;         // three buffers per wave
-      static constexpr int PUBD = NCELL * N * 4 * K; // publish area of one direction (doubles)
-      static constexpr int PUBSZ = 2 * PUBD;       // [Y | Z]
-      static constexpr int LDS_DOUBLES = 4 * WAVE + 2 * PUBSZ;
+      // publish area of one direction: velocity [cell][line N][3][K] then pressure [cell][line NP][KP] (doubles)
+      static constexpr int PUBV = NCELL * N * 3 * K, PUBD = PUBV + NCELL * NP * KP;
+      // y neighbours inside one wave (WY == 1) exchange without the workgroup barrier: one buffer; z: two
+      static constexpr int PUBY_BUFS = WY == 1 ? 1 : 2, PUB_DOUBLES = (PUBY_BUFS + 2) * PUBD;
+      // state ring of a wave (LDS-DMA, k = 4 only): two quadrature points = 2 * 6 slots; a slot holds what ONE
+      // global_load_lds_dwordx4 writes, 16 bytes per lane at M0 + 16 * lane, up to the last active lane
+      static constexpr bool RING = K == 4;
+      static constexpr int  SLOT = 16 * ((CPW - 1) * PL + NL);          // bytes
+      static constexpr int  RING_BYTES = RING ? 2 * (NLIN_ / 2) * SLOT : 0; // per wave
+      static constexpr int  LDS_BYTES = 8 * (4 * WAVE + PUB_DOUBLES) + 4 * RING_BYTES;
       static_assert(NL <= PL, "cell does not fit its lane slot");
       static_assert(WY * WZ == 4, "four waves per workgroup");
     };
@@ -93,6 +118,7 @@ namespace adaflo_hip
       const int *wg_list;
       int        wg_offset, wg_count, fix_mode;
       uint32_t   iface;
+      unsigned long long *stamps; // diagnostic builds only (HOX_STAMP)
     };
 
     // mesh-dependent integers of the launch (host)
@@ -236,66 +262,91 @@ namespace adaflo_hip
       return t;
     }
 
-    // out[q] (+)= sum_i M[q][i] in[i] with M in even / odd form (coefficients from scalar loads)
-    template <int NQ, int NI, int SIGMA, bool ADD>
-    __device__ __forceinline__ void eo_apply(const ctab_t T, const double (&in)[NI], double (&out)[NQ])
+    // A 1D matrix in even / odd form, its coefficients in scalar registers.  load() goes BEFORE the LDS reads of the
+    // phase that uses the matrix, so that the scalar loads travel while the line is read; apply<ADD>():
+    // out[q] (+)= sum_i M[q][i] in[i]
+    template <int NQ, int NI, int SIGMA>
+    struct EoMat
     {
-      constexpr int  RQ = (NQ + 1) / 2, HQ = NQ / 2, HI = NI / 2;
-      constexpr bool MID = (NI & 1) != 0, QMID = (NQ & 1) != 0;
-      constexpr int  OE = 0, OC = RQ * HI, OO = OC + (MID ? RQ : 0);
-      double         e[HI], o[HI];
+      static constexpr int  RQ = (NQ + 1) / 2, HQ = NQ / 2, HI = NI / 2;
+      static constexpr bool MID = (NI & 1) != 0, QMID = (NQ & 1) != 0;
+      static constexpr int  OE = 0, OC = RQ * HI, OO = OC + (MID ? RQ : 0), SIZE = OO + RQ * HI;
+      double                c[SIZE];
+
+      __device__ __forceinline__ void load(const ctab_t T)
+      {
 #pragma unroll
-      for (int i = 0; i < HI; ++i)
-        {
-          e[i] = in[i] + in[NI - 1 - i];
-          o[i] = in[i] - in[NI - 1 - i];
-        }
-      const double mid = in[HI]; // (used only if NI is odd)
+        for (int i = 0; i < SIZE; ++i)
+          c[i] = T[i];
+      }
+      template <bool ADD>
+      __device__ __forceinline__ void apply(const double (&in)[NI], double (&out)[NQ]) const
+      {
+        if constexpr ((HOX_EXP & 2) != 0)
+          {
 #pragma unroll
-      for (int q = 0; q < HQ; ++q)
-        {
-          double a = T[OE + q * HI] * e[0], b = T[OO + q * HI] * o[0];
+            for (int q = 0; q < NQ; ++q)
+              out[q] = ADD ? out[q] + in[q % NI] : in[q % NI] * c[0];
+            return;
+          }
+        double e[HI], o[HI];
 #pragma unroll
-          for (int i = 1; i < HI; ++i)
-            {
-              a += T[OE + q * HI + i] * e[i];
-              b += T[OO + q * HI + i] * o[i];
-            }
-          if (MID)
-            a += T[OC + q] * mid;
-          const double lo = a + b, hi = SIGMA > 0 ? a - b : b - a;
-          out[q]          = ADD ? out[q] + lo : lo;
-          out[NQ - 1 - q] = ADD ? out[NQ - 1 - q] + hi : hi;
-        }
-      if (QMID)
-        {
-          double v;
-          if (SIGMA > 0)
-            {
-              v = T[OE + HQ * HI] * e[0];
+        for (int i = 0; i < HI; ++i)
+          {
+            e[i] = in[i] + in[NI - 1 - i];
+            o[i] = in[i] - in[NI - 1 - i];
+          }
+        const double mid = in[HI]; // (used only if NI is odd)
 #pragma unroll
-              for (int i = 1; i < HI; ++i)
-                v += T[OE + HQ * HI + i] * e[i];
-              if (MID)
-                v += T[OC + HQ] * mid;
-            }
-          else
-            {
-              v = T[OO + HQ * HI] * o[0];
+        for (int q = 0; q < HQ; ++q)
+          {
+            double a = c[OE + q * HI] * e[0], b = c[OO + q * HI] * o[0];
 #pragma unroll
-              for (int i = 1; i < HI; ++i)
-                v += T[OO + HQ * HI + i] * o[i];
-            }
-          out[HQ] = ADD ? out[HQ] + v : v;
-        }
-    }
+            for (int i = 1; i < HI; ++i)
+              {
+                a += c[OE + q * HI + i] * e[i];
+                b += c[OO + q * HI + i] * o[i];
+              }
+            if (MID)
+              a += c[OC + q] * mid;
+            const double lo = a + b, hi = SIGMA > 0 ? a - b : b - a;
+            out[q]          = ADD ? out[q] + lo : lo;
+            out[NQ - 1 - q] = ADD ? out[NQ - 1 - q] + hi : hi;
+          }
+        if (QMID)
+          {
+            double v;
+            if (SIGMA > 0)
+              {
+                v = c[OE + HQ * HI] * e[0];
+#pragma unroll
+                for (int i = 1; i < HI; ++i)
+                  v += c[OE + HQ * HI + i] * e[i];
+                if (MID)
+                  v += c[OC + HQ] * mid;
+              }
+            else
+              {
+                v = c[OO + HQ * HI] * o[0];
+#pragma unroll
+                for (int i = 1; i < HI; ++i)
+                  v += c[OO + HQ * HI + i] * o[i];
+              }
+            out[HQ] = ADD ? out[HQ] + v : v;
+          }
+      }
+    };
+
     // x[m] = lds[addr + 8 (BOFF + m STRIDE)]
     template <int BOFF, int STRIDE, int NM, int M = 0>
     __device__ __forceinline__ void rd_line(const unsigned addr, double (&x)[NM])
     {
       if constexpr (M < NM)
         {
-          x[M] = ds_rd<8 * (BOFF + M * STRIDE)>(addr);
+          if constexpr ((HOX_EXP & 1) != 0)
+            x[M] = 1. + M;
+          else
+            x[M] = ds_rd<8 * (BOFF + M * STRIDE)>(addr);
           rd_line<BOFF, STRIDE, NM, M + 1>(addr, x);
         }
     }
@@ -304,7 +355,33 @@ namespace adaflo_hip
     {
 #pragma unroll
       for (int m = 0; m < NM; ++m)
-        p[BOFF + m * STRIDE] = x[m];
+        {
+          if constexpr ((HOX_EXP & 1) != 0)
+            sink(x[m]);
+          else
+            p[BOFF + m * STRIDE] = x[m];
+        }
+    }
+
+    // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+    template <int N, class F, int I = 0>
+    __device__ __forceinline__ void static_for(F &&f)
+    {
+      if constexpr (I < N)
+        {
+          f(std::integral_constant<int, I>{});
+          static_for<N, F, I + 1>(static_cast<F &&>(f));
+        }
+    }
+    // st[2 e], st[2 e + 1] = the 16 bytes of piece Q0 + e of my lane in the state ring
+    template <int Q0, int NPC, int RS, int SLOT, int NSTA, int E = 0>
+    __device__ __forceinline__ void ring_read_impl(const unsigned ring_lane, double (&st)[NSTA])
+    {
+      if constexpr (E < NPC)
+        {
+          ds_rd128<((Q0 + E) % RS) * SLOT>(ring_lane, st[2 * E], st[2 * E + 1]);
+          ring_read_impl<Q0, NPC, RS, SLOT, NSTA, E + 1>(ring_lane, st);
+        }
     }
 
 #ifndef HOX_LB
@@ -318,7 +395,7 @@ namespace adaflo_hip
       constexpr int N = G::N, NP = G::NP, KP = G::KP, NL = G::NL, N3 = G::N3, NN = N * N;
       constexpr int CPW = G::CPW, PL = G::PL, CY = G::CY, CZ = G::CZ, CWY = G::CWY, CWZ = G::CWZ, WY = G::WY;
       constexpr int TNY = G::TNY, TNZ = G::TNZ, TPY = G::TPY, TPZ = G::TPZ, RIMU = G::RIMU, RIMP = G::RIMP;
-      constexpr int BUF = G::BUF, PUBD = G::PUBD, PUBSZ = G::PUBSZ;
+      constexpr int BUF = G::BUF, PUBD = G::PUBD, PUBV = G::PUBV;
       constexpr int NST = nst_of(LIN_MODE), NPC = NST / 2;
       using TB = Tab<K>;
       double *const lds = dyn_lds();
@@ -389,8 +466,12 @@ namespace adaflo_hip
       // global rows: wave-uniform base pointer + 32-bit per-lane offset (doubles)
       const unsigned urow = (unsigned)(((size_t)Kz * A.nny + J) * A.nnx * 3), prow = (unsigned)(((size_t)Kp * A.npy + Jp) * A.npx);
       // state: per-lane pointer to the first piece of the first cell of my row of cell groups
-      const double *const stp = A.lin + (NST > 0 ? hox_state_offset<K>(A.ncx, A.ngy, NPC, 0, cy, cz, 0, 0, lc) : 0);
-      constexpr size_t ST_POINT = (size_t)NPC * CPW * NL * 2, ST_CELL = N * ST_POINT; // doubles per point / cell step
+      // state: wave-uniform base of my wave's row of cell groups + 32-bit lane offset.  (A cell beyond the mesh reads
+      // its own slot of the zero-padded group, a group beyond the mesh the last one: legal addresses, unused values.)
+      constexpr unsigned ST_PIECE = CPW * NL * 2, ST_POINT = NPC * ST_PIECE, ST_CELL = N * ST_POINT; // doubles
+      const int          gyw = min((by * CY + (wave % WY) * CWY) / CWY, A.ngy - 1), gzw = min((bz * CZ + (wave / WY) * CWZ) / CWZ, A.ngz - 1);
+      const double *const stg = A.lin + (NST > 0 ? ((size_t)gzw * A.ngy + gyw) * A.ncx * ST_CELL : 0);
+      const unsigned      st_lane = (unsigned)(cw * NL + lc) * 2;
 
       // wave-private transposition buffers T0, T1, T2 and the lane's line bases in the three layouts
       double *const  WB  = lds + wave * G::WAVE + cw * N3;
@@ -398,13 +479,21 @@ namespace adaflo_hip
       double *const  py  = WB + a + NN * b;     // y-line (a, ., b): stride N
       double *const  pz  = WB + a + N * b;      // z-line (a, b, .): stride N*N
       const unsigned ax = lds_byte_addr(px), ay = lds_byte_addr(py), az = lds_byte_addr(pz);
-      double *const  PUB = lds + 4 * G::WAVE;   // [buffer 2][Y | Z][cell][line][4][K]
+      double *const  PUBY = lds + 4 * G::WAVE, *const PUBZ = PUBY + G::PUBY_BUFS * PUBD; // publish areas (Geo)
+      // state ring of my wave
+      constexpr bool RING = G::RING && NST > 0 && !(HOX_EXP & 4);
+      constexpr int  SLOT = G::SLOT, RS = 2 * (NST / 2 > 0 ? NST / 2 : 1);
+      constexpr int  RP = HOX_REGPT; // the quadrature point whose state travels through registers (-1: none)
+      char *const    ring = reinterpret_cast<char *>(lds + 4 * G::WAVE + G::PUB_DOUBLES) + wave * G::RING_BYTES;
+      const unsigned ring_m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_byte_addr(ring)), ring_lane = lds_byte_addr(ring) + 16 * lane;
 
       const ctab_t tab = as_ctab(A.tab);
 
       // nodal x-lines of the step to come
       double Un[3][N], Pn[NP];
       auto   load_nodes = [&](const int cxn) {
+        if ((HOX_EXP & 32) && cxn > cx0)
+          return;
         const int     cxc = min(cxn, A.ncx - 1);
         const double *pu  = A.src_u + (size_t)(K * cxc) * 3;
 #pragma unroll
@@ -421,14 +510,43 @@ namespace adaflo_hip
           }
       };
       double st[NST > 0 ? NST : 1];
-      auto   load_state = [&](const double *p) {
+      auto   load_state = [&](const double *const base, const unsigned off) { // base wave-uniform, off per lane
 #pragma unroll
         for (int e = 0; e < NPC; ++e)
           {
-            st[2 * e]     = p[e * (CPW * NL * 2)];
-            st[2 * e + 1] = p[e * (CPW * NL * 2) + 1];
+            st[2 * e]     = base[off + e * ST_PIECE];
+            st[2 * e + 1] = base[off + e * ST_PIECE + 1];
           }
       };
+
+#if HOX_STAMP
+      unsigned long long acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock_now();
+#define HOX_MARK(j)                          \
+  {                                          \
+    const unsigned long long tn = clock_now(); \
+    acc[j] += tn - tlast;                    \
+    tlast = tn;                              \
+  }
+#else
+#define HOX_MARK(j)
+#endif
+      // ---- state ring (k = 4): the quadrature loop eats a point's state in ~200 cycles, an HBM round trip takes
+      // ~2700, and there are no registers to fetch points ahead.  LDS-DMA moves the pieces into a ring of two
+      // points per wave; a point's pieces are re-issued two points ahead as soon as its slots have been read, the
+      // first two points of the NEXT step while this step integrates.  Piece q = point * NPC + e lives in slot q % RS.
+      auto ring_issue = [&](const double *const cell_base, auto pt_, auto half_) {
+        constexpr int PT = decltype(pt_)::value, H = decltype(half_)::value;
+        const double *const sb = uniform_ptr(cell_base);
+#pragma unroll
+        for (int e = 0; e < NPC; ++e)
+          dma_b128(sb + (PT * NPC + e) * ST_PIECE, st_lane * 8, ring_m0 + (H * NPC + e) * SLOT);
+      };
+      if (RING)
+        {
+          const double *const c0 = stg + (size_t)cx0 * ST_CELL;
+          ring_issue(c0, std::integral_constant<int, (RP == 0 ? 1 : 0)>{}, std::integral_constant<int, 0>{});
+          ring_issue(c0, std::integral_constant<int, (RP >= 0 && RP <= 1 ? 2 : 1)>{}, std::integral_constant<int, 1>{});
+        }
 
       // ---- combine the partial sums of the cross-section per owned line, emit NV nodes -------------------------
       // R / Rp: the lane's x-line sums, nodes 0 .. NV-1 (NVP-1) are final in x.  I0 / Ip0: global x index of
@@ -442,14 +560,17 @@ namespace adaflo_hip
         const int l = lane_o % PL, cw = lane_o / PL, a = l % N, b = l / N;
         const int cyl = (wave % WY) * CWY + cw % CWY, czl = (wave / WY) * CWZ + cw / CWY, cell = czl * CY + cyl;
         const int jl = K * cyl + a, kl = K * czl + b, jlp = KP * cyl + min(a, KP), klp = KP * czl + min(b, KP);
-        double *const PY = PUB + parity * PUBSZ, *const PZ = PY + PUBD;
+        double *const PY = PUBY + (G::PUBY_BUFS == 2 ? parity * PUBD : 0), *const PZ = PUBZ + parity * PUBD;
+        wave_sync(); // (the single y buffer: every lane of the wave is done with the last collect)
+        if (!(HOX_EXP & 64))
+          {
         if (fl & F_AK)
           {
 #pragma unroll
             for (int d = 0; d < 3; ++d)
 #pragma unroll
               for (int i = 0; i < NV; ++i)
-                PY[((cell * N + b) * 4 + d) * K + i] = R[d][i];
+                PY[((cell * N + b) * 3 + d) * K + i] = R[d][i];
           }
         if (fl & F_BK)
           {
@@ -457,7 +578,7 @@ namespace adaflo_hip
             for (int d = 0; d < 3; ++d)
 #pragma unroll
               for (int i = 0; i < NV; ++i)
-                PZ[((cell * N + a) * 4 + d) * K + i] = R[d][i];
+                PZ[((cell * N + a) * 3 + d) * K + i] = R[d][i];
           }
         if (WITH_P)
           {
@@ -465,29 +586,31 @@ namespace adaflo_hip
               {
 #pragma unroll
                 for (int i = 0; i < NVP; ++i)
-                  PY[((cell * N + b) * 4 + 3) * K + i] = Rp[i];
+                  PY[PUBV + (cell * NP + b) * KP + i] = Rp[i];
               }
             if (fl & F_BKP)
               {
 #pragma unroll
                 for (int i = 0; i < NVP; ++i)
-                  PZ[((cell * N + a) * 4 + 3) * K + i] = Rp[i];
+                  PZ[PUBV + (cell * NP + a) * KP + i] = Rp[i];
               }
           }
-        __syncthreads();
-        // lower neighbour in y: its line (K, b); in z: its line (a, K); both: the corner line (K, K) of the diagonal cell
+        HOX_MARK(6)
+        lds_barrier(); // (LDS only: the prefetches and stores of the step stay in flight)
+        // lower neighbour in y: its line (K, b); in z: its line (a, K); both: the corner line (K, K) of the diagonal
+        // cell, which that cell published in both directions -- taken from the z area (double-buffered)
         if (fl & F_CY)
           {
 #pragma unroll
             for (int d = 0; d < 3; ++d)
 #pragma unroll
               for (int i = 0; i < NV; ++i)
-                R[d][i] += PY[(((cell - 1) * N + b) * 4 + d) * K + i];
+                R[d][i] += PY[(((cell - 1) * N + b) * 3 + d) * K + i];
             if (WITH_P && (fl & F_PTH))
               {
 #pragma unroll
                 for (int i = 0; i < NVP; ++i)
-                  Rp[i] += PY[(((cell - 1) * N + b) * 4 + 3) * K + i];
+                  Rp[i] += PY[PUBV + ((cell - 1) * NP + b) * KP + i];
               }
           }
         if (fl & F_CZ)
@@ -496,12 +619,12 @@ namespace adaflo_hip
             for (int d = 0; d < 3; ++d)
 #pragma unroll
               for (int i = 0; i < NV; ++i)
-                R[d][i] += PZ[(((cell - CY) * N + a) * 4 + d) * K + i];
+                R[d][i] += PZ[(((cell - CY) * N + a) * 3 + d) * K + i];
             if (WITH_P && (fl & F_PTH))
               {
 #pragma unroll
                 for (int i = 0; i < NVP; ++i)
-                  Rp[i] += PZ[(((cell - CY) * N + a) * 4 + 3) * K + i];
+                  Rp[i] += PZ[PUBV + ((cell - CY) * NP + a) * KP + i];
               }
           }
         if ((fl & (F_CY | F_CZ)) == (F_CY | F_CZ))
@@ -510,16 +633,23 @@ namespace adaflo_hip
             for (int d = 0; d < 3; ++d)
 #pragma unroll
               for (int i = 0; i < NV; ++i)
-                R[d][i] += PY[(((cell - CY - 1) * N + K) * 4 + d) * K + i];
+                R[d][i] += PZ[(((cell - CY - 1) * N + K) * 3 + d) * K + i];
             if (WITH_P && (fl & F_PTH))
               {
 #pragma unroll
                 for (int i = 0; i < NVP; ++i)
-                  Rp[i] += PY[(((cell - CY - 1) * N + KP) * 4 + 3) * K + i];
+                  Rp[i] += PZ[PUBV + ((cell - CY - 1) * NP + KP) * KP + i];
               }
           }
+          }
+        HOX_MARK(7)
         // ---- emit: dst, or the slab on the high rim of the workgroup, or the x-slab at the end of a chunk ------
         const bool to_xslab = endplane && x_seam_end;
+        if ((HOX_EXP & 16) && I0 >= 0) // (diagnostic: keep the sums alive, store nothing)
+          {
+            sink(R[0][0] + R[1][0] + R[2][0] + Rp[0]);
+            return;
+          }
         if (fl & F_OWN_U)
           {
             double *tp;
@@ -582,6 +712,12 @@ namespace adaflo_hip
 
       double carry[3] = {0., 0., 0.}, carry_p = 0.;
       load_nodes(cx0);
+#if HOX_STAGGER
+      // workgroups that share a CU march in lockstep otherwise: all in the quadrature loop (memory) or all in the
+      // contractions (LDS / VALU) at the same time
+      for (int w = 0; w < (int)(blockIdx.x & 3) * HOX_STAGGER; ++w)
+        stall_cycles();
+#endif
 
 #pragma unroll 1
       for (int step = 0; step < ns; ++step)
@@ -600,10 +736,22 @@ namespace adaflo_hip
           // G[d][0..3][i]: value, d/dx, d/dy, d/dz (reference cell) of component d at my N quadrature points;
           // after the quadrature loop: tested value and tested gradient
           double G[3][4][N], PQ[N];
-          const double *const stc = stp + (size_t)cx * ST_CELL;
-          if (NST > 0)
-            load_state(stc);
+          const double *const stc = (HOX_EXP & 8) ? A.lin : stg + (size_t)cx * ST_CELL; // (& 8: every wave streams the same 24 KB: L2 hits)
+          const double *const stn = (HOX_EXP & 8) ? A.lin : stg + (size_t)min(cx + 1, cx0 + ns - 1) * ST_CELL;
+          if (NST > 0 && !(HOX_EXP & 4) && !RING)
+            load_state(stc, st_lane);
+          double stq[NST > 0 ? NST : 1];
+          if (RING && RP >= 0)
+            {
+#pragma unroll
+              for (int e = 0; e < NPC; ++e)
+                {
+                  stq[2 * e]     = stc[st_lane + RP * ST_POINT + e * ST_PIECE];
+                  stq[2 * e + 1] = stc[st_lane + RP * ST_POINT + e * ST_PIECE + 1];
+                }
+            }
 
+          HOX_MARK(0)
           // ================= evaluate (FEEvaluation::evaluate, :668-671) =====================================
 #pragma unroll
           for (int d = 0; d < 3; ++d)
@@ -616,38 +764,47 @@ namespace adaflo_hip
                 U[0] = 0.;
               if (cx == A.ncx - 1 && (A.con_u >> (3 + d) & 1))
                 U[K] = 0.;
-              eo_apply<N, N, 1, false>(tb(TB::S), U, T); // x: nodes -> Gauss points
+              EoMat<N, N, 1>  mS;
+              EoMat<N, N, -1> mD;
+              mS.load(tb(TB::S));
+              mS.template apply<false>(U, T); // x: nodes -> Gauss points
               wr_line<0, 1, N>(px, T);
               wave_sync();
+              mS.load(tb(TB::S));
               rd_line<0, N, N>(ay, ln);
               ds_wait<0>(ln);
-              eo_apply<N, N, 1, false>(tb(TB::S), ln, T); // y
+              mS.template apply<false>(ln, T); // y
               wave_sync();
               wr_line<BUF, N, N>(py, T);
               wave_sync();
+              mS.load(tb(TB::S));
+              mD.load(tb(TB::D));
               rd_line<BUF, NN, N>(az, ln);
               ds_wait<0>(ln);
-              eo_apply<N, N, 1, false>(tb(TB::S), ln, T); // z: values at the Gauss points of my z-line
-              eo_apply<N, N, -1, false>(tb(TB::D), T, ln); // d/dz (collocation)
+              mS.template apply<false>(ln, T); // z: values at the Gauss points of my z-line
+              mD.template apply<false>(T, ln); // d/dz (collocation)
               wave_sync();
               wr_line<0, NN, N>(pz, T);
               wr_line<2 * BUF, NN, N>(pz, ln);
               wave_sync();
+              mD.load(tb(TB::D));
               rd_line<0, N, N>(ay, ln);
               ds_wait<0>(ln);
-              eo_apply<N, N, -1, false>(tb(TB::D), ln, T); // d/dy
+              mD.template apply<false>(ln, T); // d/dy
               wave_sync();
               wr_line<BUF, N, N>(py, T);
               wave_sync();
+              mD.load(tb(TB::D));
               rd_line<0, 1, N>(ax, G[d][0]);
               rd_line<BUF, 1, N>(ax, G[d][2]);
               rd_line<2 * BUF, 1, N>(ax, G[d][3]);
               ds_wait<2 * N>(G[d][0]);
-              eo_apply<N, N, -1, false>(tb(TB::D), G[d][0], G[d][1]); // d/dx
+              mD.template apply<false>(G[d][0], G[d][1]); // d/dx
               ds_wait<0>(G[d][2]);
               ds_wait<0>(G[d][3]);
               wave_sync();
             }
+          HOX_MARK(1)
           if (WITH_P)
             {
               double P[NP], T[N], ln[NP];
@@ -658,18 +815,22 @@ namespace adaflo_hip
                 P[0] = 0.;
               if (cx == A.ncx - 1 && (A.con_p >> 1 & 1))
                 P[KP] = 0.;
-              eo_apply<N, NP, 1, false>(tb(TB::SP), P, T); // x: [N][NP x NP lines]
+              EoMat<N, NP, 1> mP;
+              mP.load(tb(TB::SP));
+              mP.template apply<false>(P, T); // x: [N][NP x NP lines]
               wr_line<0, 1, N>(px, T); // (lanes without a pressure line store values nobody uses: no branch)
               wave_sync();
+              mP.load(tb(TB::SP));
               rd_line<0, N, NP>(ay, ln); // y-line (a, ., b), b < NP (other lanes read defined-or-not values they never use)
               ds_wait<0>(ln);
-              eo_apply<N, NP, 1, false>(tb(TB::SP), ln, T);
+              mP.template apply<false>(ln, T);
               wave_sync();
               wr_line<BUF, N, N>(py, T);
               wave_sync();
+              mP.load(tb(TB::SP));
               rd_line<BUF, NN, NP>(az, ln); // z-line (a, b, .)
               ds_wait<0>(ln);
-              eo_apply<N, NP, 1, false>(tb(TB::SP), ln, T);
+              mP.template apply<false>(ln, T);
               wave_sync();
               wr_line<0, NN, N>(pz, T);
               wave_sync();
@@ -684,10 +845,54 @@ namespace adaflo_hip
                 PQ[i] = 0.;
             }
 
+          HOX_MARK(2)
           // ================= quadrature points of my x-line (:702-893) ==========================================
+          static_for<N>([&](auto i_) {
+              constexpr int i_c = decltype(i_)::value, i = i_c;
+              if constexpr (RING && RP >= 0)
+                {
+                  // Ring + one point in registers.  The ring serves the points other than RP in sequence, two at a
+                  // time (sequence number j: half j % 2); point RP was loaded into registers at the top of the step.
+                  constexpr int J = i_c < RP ? i_c : i_c - 1, NRING = N - 1; // my sequence number among the ring points
+                  if (i == 0)
+                    {
+                      wait_vmcnt<0>();
 #pragma unroll
-          for (int i = 0; i < N; ++i)
-            {
+                      for (int e = 0; e < NST; ++e)
+                        opaque(stq[e]); // (the register point has arrived as well: no compiler-made wait later on)
+                    }
+                  if constexpr (i_c == RP)
+                    {
+#pragma unroll
+                      for (int e = 0; e < NST; ++e)
+                        st[e] = stq[e];
+                    }
+                  else
+                    {
+                      if (J >= 2)
+                        wait_vmcnt<NPC>();
+                      ring_read_impl<(J % 2) * NPC, NPC, RS, SLOT>(ring_lane, st);
+                      // the half is free again: it takes the ring point two sequence numbers on (this step or the next)
+                      constexpr int JN = J + 2, PN = JN < NRING ? (JN < RP ? JN : JN + 1) : (JN - NRING < RP ? JN - NRING : JN - NRING + 1);
+                      ring_issue(JN < NRING ? stc : stn, std::integral_constant<int, PN>{}, std::integral_constant<int, J % 2>{});
+                    }
+                }
+              else if constexpr (RING)
+                {
+                  // pieces of point i: issued two points ago (or during the last step); everything younger is the
+                  // NPC pieces issued one point ago
+                  if (i == 0)
+                    wait_vmcnt<0>();
+                  else if (i >= 2)
+                    wait_vmcnt<NPC>();
+                  ring_read_impl<(i_c % 2) * NPC, NPC, RS, SLOT>(ring_lane, st);
+                  // the slots are free again: the same half of the ring takes the next point of its parity (in the
+                  // last step of the chunk that is the same cell once more, never read: no branch in this loop)
+                  if constexpr (i_c + 2 < N)
+                    ring_issue(stc, std::integral_constant<int, i_c + 2>{}, std::integral_constant<int, i_c % 2>{});
+                  else
+                    ring_issue(stn, std::integral_constant<int, i_c % 2>{}, std::integral_constant<int, i_c % 2>{});
+                }
               const ctab_t cst = tb(TB::C); // constants of the quadrature-point operation
               const double jxw = wab * cst[TB::C_W + i];
               double       g[3][3], u[3];
@@ -705,14 +910,14 @@ namespace adaflo_hip
               for (int d = 0; d < 3; ++d)
                 {
                   double res = 0.;
-                  if (LIN_MODE == 0) // Newton :802-816; st = (u_lin[3], grad u_lin[3][3])
+                  if constexpr (LIN_MODE == 0) // Newton :802-816; st = (u_lin[3], grad u_lin[3][3])
                     {
                       res = cst[TB::C_BETA] * (div * st[d] + (st[3] + st[7] + st[11]) * u[d]);
 #pragma unroll
                       for (int e = 0; e < 3; ++e)
                         res += st[e] * g[d][e] + u[e] * st[3 + 3 * d + e];
                     }
-                  else if (LIN_MODE == 1) // Picard-type :817-826; st = (u_lin[3], div u_lin)
+                  else if constexpr (LIN_MODE == 1) // Picard-type :817-826; st = (u_lin[3], div u_lin)
                     {
                       res = cst[TB::C_BETA] * st[3] * u[d];
 #pragma unroll
@@ -721,12 +926,12 @@ namespace adaflo_hip
                     }
                   conv[d] = (cst[TB::C_CA] * u[d] + cst[TB::C_CB] * res) * jxw; // :717,:827-835
                 }
-              if (NST > 0 && i + 1 < N)
+              if (NST > 0 && i + 1 < N && !(HOX_EXP & 4) && !RING)
                 {
                   // the state registers are free now: fetch the next point's state (not earlier)
-                  unsigned off = (unsigned)((i + 1) * ST_POINT);
+                  unsigned off = st_lane + (unsigned)((i + 1) * ST_POINT);
                   pin_after(off, conv[2]);
-                  load_state(stc + off);
+                  load_state(stc, off);
                 }
               const double diag = cst[TB::C_TGD] * div - PQ[i];
 #pragma unroll
@@ -739,50 +944,60 @@ namespace adaflo_hip
                 }
               PQ[i] = -div * jxw; // :853-856
               __builtin_amdgcn_sched_barrier(0); // one point at a time: interleaved, the five points' temporaries add up
-            }
+            });
+          HOX_MARK(3)
           // ================= integrate (:897-907): the transposed chain =========================================
           double R[3][N], Rp[NP];
 #pragma unroll
           for (int d = 0; d < 3; ++d)
             {
               double W[N], ln[N], l2[N];
-              eo_apply<N, N, -1, true>(tb(TB::DT), G[d][1], G[d][0]); // W = tested value + D^T (x) in registers
+              EoMat<N, N, 1>  mS;
+              EoMat<N, N, -1> mD;
+              mD.load(tb(TB::DT));
+              mD.template apply<true>(G[d][1], G[d][0]); // W = tested value + D^T (x) in registers
               wr_line<0, 1, N>(px, G[d][0]);
               wr_line<BUF, 1, N>(px, G[d][2]);
               wr_line<2 * BUF, 1, N>(px, G[d][3]);
               wave_sync();
+              mD.load(tb(TB::DT));
               rd_line<0, N, N>(ay, W);
               rd_line<BUF, N, N>(ay, ln);
               ds_wait<N>(W);
               ds_wait<0>(ln);
-              eo_apply<N, N, -1, true>(tb(TB::DT), ln, W); // + D^T (y)
+              mD.template apply<true>(ln, W); // + D^T (y)
               wave_sync();
               wr_line<0, N, N>(py, W);
               wave_sync();
+              mD.load(tb(TB::DT));
+              mS.load(tb(TB::ST));
               rd_line<0, NN, N>(az, W);
               rd_line<2 * BUF, NN, N>(az, ln);
               ds_wait<N>(W);
               ds_wait<0>(ln);
-              eo_apply<N, N, -1, true>(tb(TB::DT), ln, W);  // + D^T (z)
-              eo_apply<N, N, 1, false>(tb(TB::ST), W, l2); // S^T (z): Gauss points -> nodes
+              mD.template apply<true>(ln, W);   // + D^T (z)
+              mS.template apply<false>(W, l2); // S^T (z): Gauss points -> nodes
               wave_sync();
               wr_line<BUF, NN, N>(pz, l2);
               wave_sync();
+              mS.load(tb(TB::ST));
               rd_line<BUF, N, N>(ay, ln);
               ds_wait<0>(ln);
-              eo_apply<N, N, 1, false>(tb(TB::ST), ln, l2); // S^T (y)
+              mS.template apply<false>(ln, l2); // S^T (y)
               wave_sync();
               wr_line<0, N, N>(py, l2);
               wave_sync();
+              mS.load(tb(TB::ST));
               rd_line<0, 1, N>(ax, ln);
               ds_wait<0>(ln);
-              eo_apply<N, N, 1, false>(tb(TB::ST), ln, R[d]); // S^T (x)
+              mS.template apply<false>(ln, R[d]); // S^T (x)
               wave_sync();
               // the nodal lines of the next step arrive during the rest of the integration (issued here, not earlier:
               // the quadrature loop and the first component need the registers)
               if (d == 0)
                 load_nodes(cx + 1);
             }
+          HOX_MARK(4)
 #pragma unroll
           for (int i = 0; i < NP; ++i)
             Rp[i] = 0.;
@@ -791,24 +1006,29 @@ namespace adaflo_hip
               double ln[N], T[NP];
               wr_line<0, 1, N>(px, PQ);
               wave_sync();
+              EoMat<NP, N, 1> mP;
+              mP.load(tb(TB::SPT));
               rd_line<0, NN, N>(az, ln);
               ds_wait<0>(ln);
-              eo_apply<NP, N, 1, false>(tb(TB::SPT), ln, T); // z: [N][N][NP]
+              mP.template apply<false>(ln, T); // z: [N][N][NP]
               wave_sync();
               wr_line<BUF, NN, NP>(pz, T);
               wave_sync();
+              mP.load(tb(TB::SPT));
               rd_line<BUF, N, N>(ay, ln); // y-line (a, ., b), b < NP
               ds_wait<0>(ln);
-              eo_apply<NP, N, 1, false>(tb(TB::SPT), ln, T);
+              mP.template apply<false>(ln, T);
               wave_sync();
               wr_line<0, N, NP>(py, T);
               wave_sync();
+              mP.load(tb(TB::SPT));
               rd_line<0, 1, N>(ax, ln); // x-line (., a, b), a, b < NP
               ds_wait<0>(ln);
-              eo_apply<NP, N, 1, false>(tb(TB::SPT), ln, Rp);
+              mP.template apply<false>(ln, Rp);
               wave_sync();
             }
 
+          HOX_MARK(5)
           // ================= carry in x, combine in y / z, emit the K finished nodes ============================
 #pragma unroll
           for (int d = 0; d < 3; ++d)
@@ -820,7 +1040,18 @@ namespace adaflo_hip
           carry_p = Rp[KP];
           combine(std::integral_constant<int, K>{}, std::integral_constant<int, KP>{}, R, Rp, fl, lane, step & 1, K * cx,
                   KP * cx, K * step, KP * step, false);
+          HOX_MARK(8)
+#if HOX_STAMP
+          acc[9] += 1;
+#endif
         }
+#if HOX_STAMP
+      if (A.stamps && lane == 0)
+        for (int j = 0; j < 10; ++j)
+          A.stamps[((size_t)wg * 4 + wave) * 10 + j] = acc[j];
+#endif
+      if (RING)
+        wait_vmcnt<0>(); // no copy may land in LDS after the wave has left
       // ---- the last node plane of the chunk ------------------------------------------------------------------
       {
         double R[3][N], Rp[NP];

@@ -182,8 +182,13 @@ namespace adaflo_hip
   inline void   opaque(ctab_t &) {}
   inline void   opaque(int &) {}
   inline void   opaque(unsigned &) {}
+  inline void   opaque(double &) {}
   inline void   pin_after(unsigned &, const double) {}
+  inline void   sink(const double) {}
+  inline void   stall_cycles() {}
+  inline unsigned long long clock_now() { return 0; }
   inline void   wave_sync() { emu::yield(1); }
+  inline void   lds_barrier() { emu::yield(2); }
   inline double *dyn_lds() { return reinterpret_cast<double *>(emu::g_lds); } // the workgroup's dynamic LDS
   inline unsigned lds_byte_addr(const void *p) { return (unsigned)((const char *)p - emu::g_lds); }
   template <int OFF>
@@ -201,6 +206,21 @@ namespace adaflo_hip
   template <int CNT, int NM>
   inline void ds_wait(double (&)[NM])
   {}
+  // LDS-DMA, synchronous here: lane l copies 16 bytes to lds_byte + 16 * l
+  inline void dma_b128(const double *sbase, const unsigned voff, const unsigned lds_byte)
+  {
+    std::memcpy(emu::g_lds + lds_byte + 16 * (emu::g_threadIdx.x & 63), reinterpret_cast<const char *>(sbase) + voff, 16);
+  }
+  template <int N>
+  inline void wait_vmcnt()
+  {}
+  inline const double *uniform_ptr(const double *p) { return p; }
+  template <int OFF>
+  inline void ds_rd128(const unsigned a, double &x, double &y)
+  {
+    std::memcpy(&x, emu::g_lds + a + OFF, 8);
+    std::memcpy(&y, emu::g_lds + a + OFF + 8, 8);
+  }
   template <int CNT>
   inline void ds_wait1(double &)
   {}
