@@ -23,8 +23,6 @@ namespace adaflo_hip
   // (An offset, not the pointer: behind an opaque pointer the compiler no longer knows the address space.)
   __device__ __forceinline__ void pin_after(unsigned &off, const double v) { asm volatile("" : "+v"(off) : "v"(v)); }
 
-  // about 2048 cycles of nothing
-  __device__ __forceinline__ void stall_cycles() { asm volatile("s_sleep 32" ::: "memory"); }
   // diagnostic builds (-DHOX_STAMP): shader clock
   __device__ __forceinline__ unsigned long long clock_now() { return __builtin_amdgcn_s_memtime(); }
   // diagnostic builds (-DHOX_EXP=...): keeps a value alive without storing it anywhere
@@ -83,15 +81,17 @@ namespace adaflo_hip
                    hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
     return reinterpret_cast<const double *>(((unsigned long long)hi << 32) | lo);
   }
-  // 16 bytes of LDS -> two doubles; completes with the next s_waitcnt lgkmcnt (lds_wait_all)
+  // 16 bytes of LDS -> two doubles; usable after lds_arrived() on the pair
   typedef double hox_double2 __attribute__((ext_vector_type(2)));
   template <int OFF>
-  __device__ __forceinline__ void ds_rd128(const unsigned a, double &x, double &y)
+  __device__ __forceinline__ void ds_rd128(const unsigned a, hox_double2 &v)
   {
-    hox_double2 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
-    x = v.x;
-    y = v.y;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+  }
+  // all LDS reads of the wave have returned; the values listed become usable
+  __device__ __forceinline__ void lds_arrived(hox_double2 &a, hox_double2 &b)
+  {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b));
   }
 
   __device__ __forceinline__ unsigned lds_byte_addr(const void *p)

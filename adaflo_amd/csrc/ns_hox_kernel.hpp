@@ -44,12 +44,6 @@ namespace adaflo_hip
 #ifndef HOX_STAMP
 #define HOX_STAMP 0
 #endif
-#ifndef HOX_STAGGER
-#define HOX_STAGGER 0
-#endif
-#ifndef HOX_REGPT
-#define HOX_REGPT 2
-#endif
     constexpr int NTH  = 256;
     constexpr int NMAX = 6;
     constexpr int NLIN_ = 12;
@@ -373,14 +367,31 @@ namespace adaflo_hip
           static_for<N, F, I + 1>(static_cast<F &&>(f));
         }
     }
-    // st[2 e], st[2 e + 1] = the 16 bytes of piece Q0 + e of my lane in the state ring
-    template <int Q0, int NPC, int RS, int SLOT, int NSTA, int E = 0>
-    __device__ __forceinline__ void ring_read_impl(const unsigned ring_lane, double (&st)[NSTA])
+    // st[2 e], st[2 e + 1] = the 16 bytes of piece Q0 + e of my lane in the state ring: all reads in flight together
+    template <int Q0, int NPC, int RS, int SLOT, int E = 0>
+    __device__ __forceinline__ void ring_read_issue(const unsigned ring_lane, hox_double2 (&v)[NPC])
     {
       if constexpr (E < NPC)
         {
-          ds_rd128<((Q0 + E) % RS) * SLOT>(ring_lane, st[2 * E], st[2 * E + 1]);
-          ring_read_impl<Q0, NPC, RS, SLOT, NSTA, E + 1>(ring_lane, st);
+          ds_rd128<((Q0 + E) % RS) * SLOT>(ring_lane, v[E]);
+          ring_read_issue<Q0, NPC, RS, SLOT, E + 1>(ring_lane, v);
+        }
+    }
+    template <int Q0, int NPC, int RS, int SLOT, int NSTA>
+    __device__ __forceinline__ void ring_read_impl(const unsigned ring_lane, double (&st)[NSTA])
+    {
+      hox_double2 v[NPC];
+      ring_read_issue<Q0, NPC, RS, SLOT>(ring_lane, v);
+#pragma unroll
+      for (int e = 0; e + 1 < NPC; e += 2)
+        lds_arrived(v[e], v[e + 1]);
+      if (NPC & 1)
+        lds_arrived(v[NPC - 1], v[NPC - 1]);
+#pragma unroll
+      for (int e = 0; e < NPC; ++e)
+        {
+          st[2 * e]     = v[e].x;
+          st[2 * e + 1] = v[e].y;
         }
     }
 
@@ -483,7 +494,6 @@ namespace adaflo_hip
       // state ring of my wave
       constexpr bool RING = G::RING && NST > 0 && !(HOX_EXP & 4);
       constexpr int  SLOT = G::SLOT, RS = 2 * (NST / 2 > 0 ? NST / 2 : 1);
-      constexpr int  RP = HOX_REGPT; // the quadrature point whose state travels through registers (-1: none)
       char *const    ring = reinterpret_cast<char *>(lds + 4 * G::WAVE + G::PUB_DOUBLES) + wave * G::RING_BYTES;
       const unsigned ring_m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_byte_addr(ring)), ring_lane = lds_byte_addr(ring) + 16 * lane;
 
@@ -544,8 +554,8 @@ namespace adaflo_hip
       if (RING)
         {
           const double *const c0 = stg + (size_t)cx0 * ST_CELL;
-          ring_issue(c0, std::integral_constant<int, (RP == 0 ? 1 : 0)>{}, std::integral_constant<int, 0>{});
-          ring_issue(c0, std::integral_constant<int, (RP >= 0 && RP <= 1 ? 2 : 1)>{}, std::integral_constant<int, 1>{});
+          ring_issue(c0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+          ring_issue(c0, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
         }
 
       // ---- combine the partial sums of the cross-section per owned line, emit NV nodes -------------------------
@@ -560,6 +570,10 @@ namespace adaflo_hip
         const int l = lane_o % PL, cw = lane_o / PL, a = l % N, b = l / N;
         const int cyl = (wave % WY) * CWY + cw % CWY, czl = (wave / WY) * CWZ + cw / CWY, cell = czl * CY + cyl;
         const int jl = K * cyl + a, kl = K * czl + b, jlp = KP * cyl + min(a, KP), klp = KP * czl + min(b, KP);
+        const bool     ok_ = cyl < tcy && czl < tcz;
+        const int      cy_ = by * CY + (ok_ ? cyl : 0), cz_ = bz * CZ + (ok_ ? czl : 0);
+        const unsigned urow = (unsigned)(((size_t)(K * cz_ + b) * A.nny + (K * cy_ + a)) * A.nnx * 3),
+                       prow = (unsigned)(((size_t)(KP * cz_ + min(b, KP)) * A.npy + (KP * cy_ + min(a, KP))) * A.npx);
         double *const PY = PUBY + (G::PUBY_BUFS == 2 ? parity * PUBD : 0), *const PZ = PUBZ + parity * PUBD;
         wave_sync(); // (the single y buffer: every lane of the wave is done with the last collect)
         if (!(HOX_EXP & 64))
@@ -712,12 +726,6 @@ namespace adaflo_hip
 
       double carry[3] = {0., 0., 0.}, carry_p = 0.;
       load_nodes(cx0);
-#if HOX_STAGGER
-      // workgroups that share a CU march in lockstep otherwise: all in the quadrature loop (memory) or all in the
-      // contractions (LDS / VALU) at the same time
-      for (int w = 0; w < (int)(blockIdx.x & 3) * HOX_STAGGER; ++w)
-        stall_cycles();
-#endif
 
 #pragma unroll 1
       for (int step = 0; step < ns; ++step)
@@ -740,105 +748,109 @@ namespace adaflo_hip
           const double *const stn = (HOX_EXP & 8) ? A.lin : stg + (size_t)min(cx + 1, cx0 + ns - 1) * ST_CELL;
           if (NST > 0 && !(HOX_EXP & 4) && !RING)
             load_state(stc, st_lane);
-          double stq[NST > 0 ? NST : 1];
-          if (RING && RP >= 0)
-            {
-#pragma unroll
-              for (int e = 0; e < NPC; ++e)
-                {
-                  stq[2 * e]     = stc[st_lane + RP * ST_POINT + e * ST_PIECE];
-                  stq[2 * e + 1] = stc[st_lane + RP * ST_POINT + e * ST_PIECE + 1];
-                }
-            }
 
           HOX_MARK(0)
           // ================= evaluate (FEEvaluation::evaluate, :668-671) =====================================
+          auto nodal_u = [&](auto d_, double (&U)[N]) {
+            constexpr int d = decltype(d_)::value;
 #pragma unroll
-          for (int d = 0; d < 3; ++d)
-            {
-              double U[N], T[N], ln[N];
+            for (int i = 0; i < N; ++i)
+              U[i] = (fl & (F_CON0 << d)) ? 0. : Un[d][i]; // read_dof_values: constrained entries read as zero
+            if (cx == 0 && (A.con_u >> d & 1))
+              U[0] = 0.;
+            if (cx == A.ncx - 1 && (A.con_u >> (3 + d) & 1))
+              U[K] = 0.;
+          };
+          auto nodal_p = [&](double (&P)[NP]) {
 #pragma unroll
-              for (int i = 0; i < N; ++i)
-                U[i] = (fl & (F_CON0 << d)) ? 0. : Un[d][i]; // read_dof_values: constrained entries read as zero
-              if (cx == 0 && (A.con_u >> d & 1))
-                U[0] = 0.;
-              if (cx == A.ncx - 1 && (A.con_u >> (3 + d) & 1))
-                U[K] = 0.;
-              EoMat<N, N, 1>  mS;
-              EoMat<N, N, -1> mD;
-              mS.load(tb(TB::S));
-              mS.template apply<false>(U, T); // x: nodes -> Gauss points
-              wr_line<0, 1, N>(px, T);
-              wave_sync();
-              mS.load(tb(TB::S));
-              rd_line<0, N, N>(ay, ln);
-              ds_wait<0>(ln);
-              mS.template apply<false>(ln, T); // y
-              wave_sync();
-              wr_line<BUF, N, N>(py, T);
-              wave_sync();
-              mS.load(tb(TB::S));
-              mD.load(tb(TB::D));
-              rd_line<BUF, NN, N>(az, ln);
-              ds_wait<0>(ln);
-              mS.template apply<false>(ln, T); // z: values at the Gauss points of my z-line
-              mD.template apply<false>(T, ln); // d/dz (collocation)
-              wave_sync();
-              wr_line<0, NN, N>(pz, T);
-              wr_line<2 * BUF, NN, N>(pz, ln);
-              wave_sync();
-              mD.load(tb(TB::D));
-              rd_line<0, N, N>(ay, ln);
-              ds_wait<0>(ln);
-              mD.template apply<false>(ln, T); // d/dy
-              wave_sync();
-              wr_line<BUF, N, N>(py, T);
-              wave_sync();
-              mD.load(tb(TB::D));
-              rd_line<0, 1, N>(ax, G[d][0]);
-              rd_line<BUF, 1, N>(ax, G[d][2]);
-              rd_line<2 * BUF, 1, N>(ax, G[d][3]);
-              ds_wait<2 * N>(G[d][0]);
-              mD.template apply<false>(G[d][0], G[d][1]); // d/dx
-              ds_wait<0>(G[d][2]);
-              ds_wait<0>(G[d][3]);
-              wave_sync();
-            }
+            for (int i = 0; i < NP; ++i)
+              P[i] = (fl & F_PCON) ? 0. : Pn[i];
+            if (cx == 0 && (A.con_p & 1))
+              P[0] = 0.;
+            if (cx == A.ncx - 1 && (A.con_p >> 1 & 1))
+              P[KP] = 0.;
+          };
+          // one velocity component: x in registers, y, z (values at the Gauss points), d/dz, d/dy, d/dx
+          auto eval_single = [&](auto d_) {
+            constexpr int d = decltype(d_)::value;
+            double        U[N], T[N], ln[N];
+            nodal_u(d_, U);
+            EoMat<N, N, 1>  mS;
+            EoMat<N, N, -1> mD;
+            mS.load(tb(TB::S));
+            mS.template apply<false>(U, T); // x: nodes -> Gauss points
+            wr_line<0, 1, N>(px, T);
+            wave_sync();
+            mS.load(tb(TB::S));
+            rd_line<0, N, N>(ay, ln);
+            ds_wait<0>(ln);
+            mS.template apply<false>(ln, T); // y
+            wave_sync();
+            wr_line<BUF, N, N>(py, T);
+            wave_sync();
+            mS.load(tb(TB::S));
+            mD.load(tb(TB::D));
+            rd_line<BUF, NN, N>(az, ln);
+            ds_wait<0>(ln);
+            mS.template apply<false>(ln, T); // z: values at the Gauss points of my z-line
+            mD.template apply<false>(T, ln); // d/dz (collocation)
+            wave_sync();
+            wr_line<0, NN, N>(pz, T);
+            wr_line<2 * BUF, NN, N>(pz, ln);
+            wave_sync();
+            mD.load(tb(TB::D));
+            rd_line<0, N, N>(ay, ln);
+            ds_wait<0>(ln);
+            mD.template apply<false>(ln, T); // d/dy
+            wave_sync();
+            wr_line<BUF, N, N>(py, T);
+            wave_sync();
+            mD.load(tb(TB::D));
+            rd_line<0, 1, N>(ax, G[d][0]);
+            rd_line<BUF, 1, N>(ax, G[d][2]);
+            rd_line<2 * BUF, 1, N>(ax, G[d][3]);
+            ds_wait<2 * N>(G[d][0]);
+            mD.template apply<false>(G[d][0], G[d][1]); // d/dx
+            ds_wait<0>(G[d][2]);
+            ds_wait<0>(G[d][3]);
+            wave_sync();
+          };
+          auto eval_p = [&]() {
+            double P[NP], T[N], ln[NP];
+            nodal_p(P);
+            EoMat<N, NP, 1> mP;
+            mP.load(tb(TB::SP));
+            mP.template apply<false>(P, T); // x: [N][NP x NP lines]
+            wr_line<0, 1, N>(px, T); // (lanes without a pressure line store values nobody uses: no branch)
+            wave_sync();
+            mP.load(tb(TB::SP));
+            rd_line<0, N, NP>(ay, ln); // y-line (a, ., b), b < NP (other lanes read defined-or-not values they never use)
+            ds_wait<0>(ln);
+            mP.template apply<false>(ln, T);
+            wave_sync();
+            wr_line<BUF, N, N>(py, T);
+            wave_sync();
+            mP.load(tb(TB::SP));
+            rd_line<BUF, NN, NP>(az, ln); // z-line (a, b, .)
+            ds_wait<0>(ln);
+            mP.template apply<false>(ln, T);
+            wave_sync();
+            wr_line<0, NN, N>(pz, T);
+            wave_sync();
+            rd_line<0, 1, N>(ax, PQ);
+            ds_wait<0>(PQ);
+            wave_sync();
+          };
+          using I0_ = std::integral_constant<int, 0>;
+          using I1_ = std::integral_constant<int, 1>;
+          using I2_ = std::integral_constant<int, 2>;
+          eval_single(I0_{});
+          eval_single(I1_{});
+          eval_single(I2_{});
           HOX_MARK(1)
-          if (WITH_P)
-            {
-              double P[NP], T[N], ln[NP];
-#pragma unroll
-              for (int i = 0; i < NP; ++i)
-                P[i] = (fl & F_PCON) ? 0. : Pn[i];
-              if (cx == 0 && (A.con_p & 1))
-                P[0] = 0.;
-              if (cx == A.ncx - 1 && (A.con_p >> 1 & 1))
-                P[KP] = 0.;
-              EoMat<N, NP, 1> mP;
-              mP.load(tb(TB::SP));
-              mP.template apply<false>(P, T); // x: [N][NP x NP lines]
-              wr_line<0, 1, N>(px, T); // (lanes without a pressure line store values nobody uses: no branch)
-              wave_sync();
-              mP.load(tb(TB::SP));
-              rd_line<0, N, NP>(ay, ln); // y-line (a, ., b), b < NP (other lanes read defined-or-not values they never use)
-              ds_wait<0>(ln);
-              mP.template apply<false>(ln, T);
-              wave_sync();
-              wr_line<BUF, N, N>(py, T);
-              wave_sync();
-              mP.load(tb(TB::SP));
-              rd_line<BUF, NN, NP>(az, ln); // z-line (a, b, .)
-              ds_wait<0>(ln);
-              mP.template apply<false>(ln, T);
-              wave_sync();
-              wr_line<0, NN, N>(pz, T);
-              wave_sync();
-              rd_line<0, 1, N>(ax, PQ);
-              ds_wait<0>(PQ);
-              wave_sync();
-            }
-          else
+          if constexpr (WITH_P)
+            eval_p();
+          if constexpr (!WITH_P)
             {
 #pragma unroll
               for (int i = 0; i < N; ++i)
@@ -849,35 +861,7 @@ namespace adaflo_hip
           // ================= quadrature points of my x-line (:702-893) ==========================================
           static_for<N>([&](auto i_) {
               constexpr int i_c = decltype(i_)::value, i = i_c;
-              if constexpr (RING && RP >= 0)
-                {
-                  // Ring + one point in registers.  The ring serves the points other than RP in sequence, two at a
-                  // time (sequence number j: half j % 2); point RP was loaded into registers at the top of the step.
-                  constexpr int J = i_c < RP ? i_c : i_c - 1, NRING = N - 1; // my sequence number among the ring points
-                  if (i == 0)
-                    {
-                      wait_vmcnt<0>();
-#pragma unroll
-                      for (int e = 0; e < NST; ++e)
-                        opaque(stq[e]); // (the register point has arrived as well: no compiler-made wait later on)
-                    }
-                  if constexpr (i_c == RP)
-                    {
-#pragma unroll
-                      for (int e = 0; e < NST; ++e)
-                        st[e] = stq[e];
-                    }
-                  else
-                    {
-                      if (J >= 2)
-                        wait_vmcnt<NPC>();
-                      ring_read_impl<(J % 2) * NPC, NPC, RS, SLOT>(ring_lane, st);
-                      // the half is free again: it takes the ring point two sequence numbers on (this step or the next)
-                      constexpr int JN = J + 2, PN = JN < NRING ? (JN < RP ? JN : JN + 1) : (JN - NRING < RP ? JN - NRING : JN - NRING + 1);
-                      ring_issue(JN < NRING ? stc : stn, std::integral_constant<int, PN>{}, std::integral_constant<int, J % 2>{});
-                    }
-                }
-              else if constexpr (RING)
+              if constexpr (RING)
                 {
                   // pieces of point i: issued two points ago (or during the last step); everything younger is the
                   // NPC pieces issued one point ago
@@ -948,85 +932,87 @@ namespace adaflo_hip
           HOX_MARK(3)
           // ================= integrate (:897-907): the transposed chain =========================================
           double R[3][N], Rp[NP];
-#pragma unroll
-          for (int d = 0; d < 3; ++d)
-            {
-              double W[N], ln[N], l2[N];
-              EoMat<N, N, 1>  mS;
-              EoMat<N, N, -1> mD;
-              mD.load(tb(TB::DT));
-              mD.template apply<true>(G[d][1], G[d][0]); // W = tested value + D^T (x) in registers
-              wr_line<0, 1, N>(px, G[d][0]);
-              wr_line<BUF, 1, N>(px, G[d][2]);
-              wr_line<2 * BUF, 1, N>(px, G[d][3]);
-              wave_sync();
-              mD.load(tb(TB::DT));
-              rd_line<0, N, N>(ay, W);
-              rd_line<BUF, N, N>(ay, ln);
-              ds_wait<N>(W);
-              ds_wait<0>(ln);
-              mD.template apply<true>(ln, W); // + D^T (y)
-              wave_sync();
-              wr_line<0, N, N>(py, W);
-              wave_sync();
-              mD.load(tb(TB::DT));
-              mS.load(tb(TB::ST));
-              rd_line<0, NN, N>(az, W);
-              rd_line<2 * BUF, NN, N>(az, ln);
-              ds_wait<N>(W);
-              ds_wait<0>(ln);
-              mD.template apply<true>(ln, W);   // + D^T (z)
-              mS.template apply<false>(W, l2); // S^T (z): Gauss points -> nodes
-              wave_sync();
-              wr_line<BUF, NN, N>(pz, l2);
-              wave_sync();
-              mS.load(tb(TB::ST));
-              rd_line<BUF, N, N>(ay, ln);
-              ds_wait<0>(ln);
-              mS.template apply<false>(ln, l2); // S^T (y)
-              wave_sync();
-              wr_line<0, N, N>(py, l2);
-              wave_sync();
-              mS.load(tb(TB::ST));
-              rd_line<0, 1, N>(ax, ln);
-              ds_wait<0>(ln);
-              mS.template apply<false>(ln, R[d]); // S^T (x)
-              wave_sync();
-              // the nodal lines of the next step arrive during the rest of the integration (issued here, not earlier:
-              // the quadrature loop and the first component need the registers)
-              if (d == 0)
-                load_nodes(cx + 1);
-            }
-          HOX_MARK(4)
+          auto integ_single = [&](auto d_) {
+            constexpr int d = decltype(d_)::value;
+            double        W[N], ln[N], l2[N];
+            EoMat<N, N, 1>  mS;
+            EoMat<N, N, -1> mD;
+            mD.load(tb(TB::DT));
+            mD.template apply<true>(G[d][1], G[d][0]); // W = tested value + D^T (x) in registers
+            wr_line<0, 1, N>(px, G[d][0]);
+            wr_line<BUF, 1, N>(px, G[d][2]);
+            wr_line<2 * BUF, 1, N>(px, G[d][3]);
+            wave_sync();
+            mD.load(tb(TB::DT));
+            rd_line<0, N, N>(ay, W);
+            rd_line<BUF, N, N>(ay, ln);
+            ds_wait<N>(W);
+            ds_wait<0>(ln);
+            mD.template apply<true>(ln, W); // + D^T (y)
+            wave_sync();
+            wr_line<0, N, N>(py, W);
+            wave_sync();
+            mD.load(tb(TB::DT));
+            mS.load(tb(TB::ST));
+            rd_line<0, NN, N>(az, W);
+            rd_line<2 * BUF, NN, N>(az, ln);
+            ds_wait<N>(W);
+            ds_wait<0>(ln);
+            mD.template apply<true>(ln, W);   // + D^T (z)
+            mS.template apply<false>(W, l2); // S^T (z): Gauss points -> nodes
+            wave_sync();
+            wr_line<BUF, NN, N>(pz, l2);
+            wave_sync();
+            mS.load(tb(TB::ST));
+            rd_line<BUF, N, N>(ay, ln);
+            ds_wait<0>(ln);
+            mS.template apply<false>(ln, l2); // S^T (y)
+            wave_sync();
+            wr_line<0, N, N>(py, l2);
+            wave_sync();
+            mS.load(tb(TB::ST));
+            rd_line<0, 1, N>(ax, ln);
+            ds_wait<0>(ln);
+            mS.template apply<false>(ln, R[d]); // S^T (x)
+            wave_sync();
+          };
+          auto integ_p = [&]() {
+            double ln[N], T[NP];
+            wr_line<0, 1, N>(px, PQ);
+            wave_sync();
+            EoMat<NP, N, 1> mP;
+            mP.load(tb(TB::SPT));
+            rd_line<0, NN, N>(az, ln);
+            ds_wait<0>(ln);
+            mP.template apply<false>(ln, T); // z: [N][N][NP]
+            wave_sync();
+            wr_line<BUF, NN, NP>(pz, T);
+            wave_sync();
+            mP.load(tb(TB::SPT));
+            rd_line<BUF, N, N>(ay, ln); // y-line (a, ., b), b < NP
+            ds_wait<0>(ln);
+            mP.template apply<false>(ln, T);
+            wave_sync();
+            wr_line<0, N, NP>(py, T);
+            wave_sync();
+            mP.load(tb(TB::SPT));
+            rd_line<0, 1, N>(ax, ln); // x-line (., a, b), a, b < NP
+            ds_wait<0>(ln);
+            mP.template apply<false>(ln, Rp);
+            wave_sync();
+          };
 #pragma unroll
           for (int i = 0; i < NP; ++i)
             Rp[i] = 0.;
-          if (WITH_P)
-            {
-              double ln[N], T[NP];
-              wr_line<0, 1, N>(px, PQ);
-              wave_sync();
-              EoMat<NP, N, 1> mP;
-              mP.load(tb(TB::SPT));
-              rd_line<0, NN, N>(az, ln);
-              ds_wait<0>(ln);
-              mP.template apply<false>(ln, T); // z: [N][N][NP]
-              wave_sync();
-              wr_line<BUF, NN, NP>(pz, T);
-              wave_sync();
-              mP.load(tb(TB::SPT));
-              rd_line<BUF, N, N>(ay, ln); // y-line (a, ., b), b < NP
-              ds_wait<0>(ln);
-              mP.template apply<false>(ln, T);
-              wave_sync();
-              wr_line<0, N, NP>(py, T);
-              wave_sync();
-              mP.load(tb(TB::SPT));
-              rd_line<0, 1, N>(ax, ln); // x-line (., a, b), a, b < NP
-              ds_wait<0>(ln);
-              mP.template apply<false>(ln, Rp);
-              wave_sync();
-            }
+          integ_single(I0_{});
+          // the nodal lines of the next step arrive during the rest of the integration (issued here, not earlier: the
+          // quadrature loop and the first component need the registers)
+          load_nodes(cx + 1);
+          integ_single(I1_{});
+          integ_single(I2_{});
+          HOX_MARK(4)
+          if constexpr (WITH_P)
+            integ_p();
 
           HOX_MARK(5)
           // ================= carry in x, combine in y / z, emit the K finished nodes ============================

@@ -332,7 +332,8 @@ def main():
         raise SystemExit("non-finite result")
 
     kernel_name = "ns_q2_kernel" if (k == 2 and args.variant >= 1) else (
-        "ns_ho_kernel" if (k > 2 and (args.variant == 2 or (args.variant == 1 and k <= 4))) else "ns_cell_kernel")
+        "ns_hox_kernel" if (3 <= k <= 5 and args.variant == 1) else (
+            "ns_ho_kernel" if (3 <= k <= 5 and args.variant == 2) else "ns_cell_kernel"))
     traffic = None
     try:  # PMC-measured HBM bytes per launch of the dominant kernel (profiles/, collected with rocprofv3)
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:

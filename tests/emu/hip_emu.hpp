@@ -185,7 +185,6 @@ namespace adaflo_hip
   inline void   opaque(double &) {}
   inline void   pin_after(unsigned &, const double) {}
   inline void   sink(const double) {}
-  inline void   stall_cycles() {}
   inline unsigned long long clock_now() { return 0; }
   inline void   wave_sync() { emu::yield(1); }
   inline void   lds_barrier() { emu::yield(2); }
@@ -215,15 +214,16 @@ namespace adaflo_hip
   inline void wait_vmcnt()
   {}
   inline const double *uniform_ptr(const double *p) { return p; }
-  template <int OFF>
-  inline void ds_rd128(const unsigned a, double &x, double &y)
+  struct hox_double2
   {
-    std::memcpy(&x, emu::g_lds + a + OFF, 8);
-    std::memcpy(&y, emu::g_lds + a + OFF + 8, 8);
+    double x, y;
+  };
+  template <int OFF>
+  inline void ds_rd128(const unsigned a, hox_double2 &v)
+  {
+    std::memcpy(&v, emu::g_lds + a + OFF, 16);
   }
-  template <int CNT>
-  inline void ds_wait1(double &)
-  {}
+  inline void lds_arrived(hox_double2 &, hox_double2 &) {}
   inline long xcd_remap(const long b, const long n)
   {
     const long per = n / 8;
