@@ -114,6 +114,7 @@ SIGNATURES = {
     "adaflo_comm_update_ghost_values": (C.c_int, [_COMM, _D, _D]),
     "adaflo_comm_compress_add": (C.c_int, [_COMM, _D, _D]),
     "adaflo_ns_vmult_distributed": (C.c_int, [_CTX, _COMM, _D, _D, _D, _D, C.c_int]),
+    "adaflo_comm_force_phased_schedule": (C.c_int, [_COMM, C.c_int]),
     "adaflo_ls_set_params": (C.c_int, [_CTX, C.POINTER(LSParams)]),
     "adaflo_ls_set_diagonal": (C.c_int, [_CTX, _D]),
     "adaflo_ls_set_evaluated_convection": (C.c_int, [_CTX, C.c_void_p, C.c_int]),

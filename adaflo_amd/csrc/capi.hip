@@ -899,13 +899,12 @@ int adaflo_ns_apply_constrained_rows(adaflo_ctx *ctx, double *dst_u, double *dst
   const int k = ctx->k;
   if (dst_u && ctx->brick.con_u)
     TRY(ctx,
-        launch_prepare_dst(ctx, dst_u, src_u, ctx->n_nodes_u, 3, nn(ctx, k, 0), nn(ctx, k, 1),
-                           nn(ctx, k, 2), ctx->brick.con_u, 1., false),
+        launch_constrained_faces(ctx, dst_u, src_u, 3, nn(ctx, k, 0), nn(ctx, k, 1), nn(ctx, k, 2), ctx->brick.con_u, 1.),
         "constrained rows failed");
   if (dst_p && ctx->brick.con_p)
     TRY(ctx,
-        launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, nn(ctx, k - 1, 0), nn(ctx, k - 1, 1),
-                           nn(ctx, k - 1, 2), ctx->brick.con_p, -1., false),
+        launch_constrained_faces(ctx, dst_p, src_p, 1, nn(ctx, k - 1, 0), nn(ctx, k - 1, 1), nn(ctx, k - 1, 2),
+                                 ctx->brick.con_p, -1.),
         "constrained rows failed");
   return 0;
 }

@@ -100,6 +100,7 @@ namespace
     HaloPlan pack[2];
     HaloPlan unpack_add[2];
     HaloPlan unpack_copy[2][3];
+    HaloPlan unpack_copy_all[2]; // all classes, ordered faces, edges, corners (one launch, "last region wins")
     long     n_send = 0, n_recv = 0;
   };
 } // namespace
@@ -124,6 +125,7 @@ struct adaflo_comm
   // 1 / (global sum) on the device
   double *w_owned = nullptr, *d_inv = nullptr, *d_dot = nullptr;
   bool    projection = false;
+  bool    force_phased = false; // measurement aid: the three-phase schedule also with world == 1
   std::string last_error;
 };
 
@@ -187,7 +189,7 @@ namespace
     layout(R.recv_nb, R.recv_off, R.recv_cnt, R.recv_peer, R.n_recv);
     // by_rank: regions in the order of their senders' ranks (add mode: one global summation order)
     auto plan_for = [&](const std::vector<int> &list, const std::vector<long> &off, const int f, const int only_cls,
-                        const bool by_rank = false) {
+                        const bool by_rank = false, const bool by_class = false) {
       HaloPlan P{};
       P.ncomp = c->field[f].ncomp;
       for (int d = 0; d < 3; ++d)
@@ -198,6 +200,9 @@ namespace
       std::vector<size_t> order(list.size());
       for (size_t q = 0; q < list.size(); ++q)
         order[q] = q;
+      if (by_class)
+        std::stable_sort(order.begin(), order.end(),
+                         [&](const size_t a, const size_t b) { return c->nbrs[list[a]].cls < c->nbrs[list[b]].cls; });
       if (by_rank)
         {
           std::stable_sort(order.begin(), order.end(),
@@ -224,6 +229,7 @@ namespace
         R.unpack_add[f] = plan_for(R.recv_nb, R.recv_off, f, 0, true);
         for (int cls = 1; cls <= 3; ++cls)
           R.unpack_copy[f][cls - 1] = plan_for(R.recv_nb, R.recv_off, f, cls);
+        R.unpack_copy_all[f] = plan_for(R.recv_nb, R.recv_off, f, 0, false, true);
       }
   }
 
@@ -275,10 +281,8 @@ namespace
   int exchange_start(adaflo_comm *c, const Round &R, double *u, double *p)
   {
     adaflo_ctx *ctx = c->ctx;
-    double     *v[2] = {u, p};
-    for (int f = 0; f < 2; ++f)
-      if (int e = launch_halo(ctx, v[f], c->sbuf, R.pack[f], 0))
-        return cfail(c, e, "halo pack failed");
+    if (int e = launch_halo_pair(ctx, u, p, c->sbuf, R.pack[0], R.pack[1], 0)) // both fields, one launch
+      return cfail(c, e, "halo pack failed");
     if (hipEventRecord(c->ev_packed, ctx->stream) != hipSuccess ||
         hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0) != hipSuccess)
       return cfail(c, ADAFLO_EHIP, "event failed");
@@ -297,19 +301,14 @@ namespace
     adaflo_ctx *ctx = c->ctx;
     if (hipStreamWaitEvent(ctx->stream, c->ev_arrived, 0) != hipSuccess)
       return cfail(c, ADAFLO_EHIP, "event failed");
-    double *v[2] = {u, p};
-    for (int f = 0; f < 2; ++f)
+    // one launch for both fields; copy: the regions of all classes in one plan, the last one containing a node wins
+    if (add_mode)
       {
-        if (add_mode)
-          {
-            if (int e = launch_halo(ctx, v[f], c->rbuf, R.unpack_add[f], 2))
-              return cfail(c, e, "halo unpack failed");
-          }
-        else
-          for (int cls = 0; cls < 3; ++cls)
-            if (int e = launch_halo(ctx, v[f], c->rbuf, R.unpack_copy[f][cls], 1))
-              return cfail(c, e, "halo unpack failed");
+        if (int e = launch_halo_pair(ctx, u, p, c->rbuf, R.unpack_add[0], R.unpack_add[1], 2))
+          return cfail(c, e, "halo unpack failed");
       }
+    else if (int e = launch_halo_pair(ctx, u, p, c->rbuf, R.unpack_copy_all[0], R.unpack_copy_all[1], 3))
+      return cfail(c, e, "halo unpack failed");
     // the next pack / exchange must not overwrite the buffers before these kernels have read them
     if (hipEventRecord(c->ev_packed, ctx->stream) != hipSuccess ||
         hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0) != hipSuccess)
@@ -545,14 +544,22 @@ int adaflo_comm_compress_add(adaflo_comm *c, double *vec_u, double *vec_p)
   return exchange_finish(c, c->add, vec_u, vec_p, true);
 }
 
+int adaflo_comm_force_phased_schedule(adaflo_comm *c, int enabled)
+{
+  if (!c)
+    return ADAFLO_EINVAL;
+  c->force_phased = enabled != 0;
+  return 0;
+}
+
 int adaflo_ns_vmult_distributed(adaflo_ctx *ctx, adaflo_comm *c, double *dst_u, double *dst_p, double *src_u,
                                 double *src_p, int src_ghosts_valid)
 {
   if (!ctx || !c || c->ctx != ctx || !dst_u || !dst_p || !src_u || !src_p)
     return ADAFLO_EINVAL;
   // (every sweep kernel has the three-phase form: Q2/Q1 with constant or variable coefficients, Q3..Q5)
-  const bool phased = c->world > 1 && adaflo_ns_supports_phases(ctx) != 0;
-  if (c->world == 1)
+  const bool phased = (c->world > 1 || c->force_phased) && adaflo_ns_supports_phases(ctx) != 0;
+  if (c->world == 1 && !phased)
     {
       // (the context was created without the local mean-value fix when a communicator takes care of it)
       if (int e = adaflo_ns_vmult(ctx, dst_u, dst_p, src_u, src_p))
@@ -590,7 +597,7 @@ int adaflo_ns_vmult_distributed(adaflo_ctx *ctx, adaflo_comm *c, double *dst_u, 
       if (int e = adaflo_comm_compress_add(c, dst_u, dst_p))
         return e;
     }
-  if (c->world > 1) // rows on boundary x interface: the sharers added their +-src as well
+  if (c->world > 1 || phased) // rows on boundary x interface: the sharers added their +-src as well
     if (int e = adaflo_ns_apply_constrained_rows(ctx, dst_u, dst_p, src_u, src_p))
       return e;
   // :191-205 with the global weights; skipped for the projection scheme and the stationary equation

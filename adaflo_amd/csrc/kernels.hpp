@@ -88,12 +88,18 @@ namespace adaflo_hip
     int  self_pos;             // add mode: the vector's own value is summed before region self_pos
   };
   int launch_halo(adaflo_ctx *ctx, double *vec, double *buf, const HaloPlan &plan, int mode);
+  // two fields in one launch; mode 3: copy, the last region that contains a node wins (regions ordered by class)
+  int launch_halo_pair(adaflo_ctx *ctx, double *vec0, double *vec1, double *buf, const HaloPlan &plan0,
+                       const HaloPlan &plan1, int mode);
 
   // vector helpers (vector_ops.hip)
   // dst = constrained ? sign*src : 0  (fuses `dst = 0` with the constrained-row
   // fix-up of source/navier_stokes_matrix.cc:229,247-256)
   int launch_prepare_dst(adaflo_ctx *ctx, double *dst, const double *src, long n_nodes, int ncomp,
                          int nnx, int nny, int nnz, uint32_t mask, double sign, bool zero_rest);
+  // dst = sign * src on the constrained faces only (the rows of :247-256), nothing else touched
+  int launch_constrained_faces(adaflo_ctx *ctx, double *dst, const double *src, int ncomp, int nnx, int nny, int nnz,
+                               uint32_t mask, double sign);
   // v -= (w.v) * inv * modes   (apply_pressure_average_projection :191-205)
   int launch_mean_projection(adaflo_ctx *ctx, double *v, const double *w, const double *modes,
                              long n, double inv);

@@ -1330,7 +1330,8 @@ namespace adaflo_hip
       long       nb = n1 + n2 + n3 + n4;
       if (nb > 256 * 512)
         nb = 256 * 512;
-      hipLaunchKernelGGL((ns_ho_fixup_kernel<K>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, A, n1, n2, n3, n4);
+      if (!(phase == 1 && iface == 0u)) // (no interface: phase 1 has nothing to fix up)
+        hipLaunchKernelGGL((ns_ho_fixup_kernel<K>), dim3((unsigned)nb), dim3(64), 0, ctx->stream, A, n1, n2, n3, n4);
       return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
     }
   } // namespace

@@ -276,7 +276,7 @@ namespace adaflo_hip
         return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
       const bool fix_p = with_p && A.integrate_p;
       const long items = hox_fix_items(A, fix_p);
-      if (items > 0)
+      if (items > 0 && !(phase == 1 && iface == 0u)) // (no interface: phase 1 has nothing to fix up)
         {
           long nb = (items + 255) / 256;
           if (nb > 256 * 32)

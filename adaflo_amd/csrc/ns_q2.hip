@@ -2021,7 +2021,7 @@ namespace adaflo_hip
       (void)hipEventRecord(stop, ctx->stream);
     if (phase == -1 || phase == 1)
       ctx->kernel_timer.count++;
-    if (phase != 0)
+    if (phase != 0 && !(phase == 1 && iface == 0u)) // (no interface: phase 1 has nothing to fix up)
     {
       const long tiles = (long)A.tiles_x * A.tiles_y;
       const bool fix_p = with_p && A.integrate_p;

@@ -42,6 +42,54 @@ namespace adaflo_hip
         }
     }
 
+    // dst = sign * src on the constrained faces only (:247-256): one work item per (face, node of the face,
+    // component) -- 6 n^2 instead of n^3 entries; a node on several constrained faces is written more than once,
+    // with the same value
+    __global__ __launch_bounds__(VT) void constrained_faces_kernel(double *__restrict__ dst, const double *__restrict__ src,
+                                                                   const int ncomp, const int nnx, const int nny,
+                                                                   const int nnz, const uint32_t mask, const double sign)
+    {
+      const int  stride = ncomp == 1 ? 1 : 3;
+      const long fs[3] = {(long)nny * nnz, (long)nnx * nnz, (long)nnx * nny}; // nodes of an x / y / z face
+      const long total = 2 * (fs[0] + fs[1] + fs[2]) * ncomp;
+      for (long it = blockIdx.x * (long)VT + threadIdx.x; it < total; it += (long)gridDim.x * VT)
+        {
+          const int c = (int)(it % ncomp);
+          long      r = it / ncomp;
+          int       f = 0;
+          for (; f < 6; ++f)
+            {
+              if (r < fs[f / 2])
+                break;
+              r -= fs[f / 2];
+            }
+          if (!(mask >> (stride * f + c) & 1u))
+            continue;
+          const int d = f / 2, side = f & 1;
+          int       I, J, K;
+          if (d == 0)
+            {
+              I = side ? nnx - 1 : 0;
+              J = (int)(r % nny);
+              K = (int)(r / nny);
+            }
+          else if (d == 1)
+            {
+              J = side ? nny - 1 : 0;
+              I = (int)(r % nnx);
+              K = (int)(r / nnx);
+            }
+          else
+            {
+              K = side ? nnz - 1 : 0;
+              I = (int)(r % nnx);
+              J = (int)(r / nnx);
+            }
+          const long i = (((long)K * nny + J) * nnx + I) * ncomp + c;
+          dst[i]       = sign * src[i];
+        }
+    }
+
     __global__ __launch_bounds__(VT) void dot_partial_kernel(const double *__restrict__ a,
                                                              const double *__restrict__ b,
                                                              const long n, double *__restrict__ part)
@@ -191,64 +239,92 @@ namespace adaflo_hip
     // that contains a node sums the entries of all regions containing it and the vector's own
     // value, in region order: no atomics, and the replicas of an interface DoF end up bitwise
     // identical on every rank and run.
+    // one entry t of a plan.  mode 3: copy where the LAST region that contains a node wins -- with the regions ordered
+    // faces, edges, corners this equals three passes (faces first, corners last: the lowest sharer, the owner, wins)
+    __device__ __forceinline__ void halo_item(double *__restrict__ vec, double *__restrict__ buf, const HaloPlan &plan,
+                                              const int mode, const long t)
+    {
+      int r = 0;
+      while (t >= plan.offset[r + 1])
+        ++r;
+      long       e  = t - plan.offset[r];
+      const long el = e;
+      const int  nc = plan.ncomp, ni = plan.hi[r][0] - plan.lo[r][0], nj = plan.hi[r][1] - plan.lo[r][1];
+      const int  c  = (int)(e % nc);
+      e /= nc;
+      const int i = (int)(e % ni) + plan.lo[r][0];
+      e /= ni;
+      const int  j   = (int)(e % nj) + plan.lo[r][1];
+      const int  k   = (int)(e / nj) + plan.lo[r][2];
+      const long idx = ((long)(k * (long)plan.nn[1] + j) * plan.nn[0] + i) * nc + c;
+      auto       inside = [&](const int q) {
+        return i >= plan.lo[q][0] && i < plan.hi[q][0] && j >= plan.lo[q][1] && j < plan.hi[q][1] && k >= plan.lo[q][2] &&
+               k < plan.hi[q][2];
+      };
+      if (mode == 0)
+        buf[plan.start[r] + el] = vec[idx];
+      else if (mode == 1)
+        vec[idx] = buf[plan.start[r] + el];
+      else if (mode == 3)
+        {
+          bool last = true;
+          for (int q = r + 1; q < plan.n_regions; ++q)
+            last = last && !inside(q);
+          if (last)
+            vec[idx] = buf[plan.start[r] + el];
+        }
+      else
+        {
+          bool first = true;
+          for (int q = 0; q < r; ++q)
+            first = first && !inside(q);
+          if (!first)
+            return;
+          // own value and received partial sums in ONE global order (the regions arrive sorted by
+          // the rank of their sender, self_pos = where this rank sits in that order): all sharers
+          // add the same numbers in the same sequence
+          double sum     = 0.;
+          bool   started = false;
+          auto   add     = [&](const double x) {
+            sum     = started ? sum + x : x;
+            started = true;
+          };
+          for (int q = r; q < plan.n_regions; ++q)
+            {
+              if (q == plan.self_pos || (q == r && plan.self_pos < r))
+                add(vec[idx]);
+              if (inside(q))
+                {
+                  const int  qi = plan.hi[q][0] - plan.lo[q][0], qj = plan.hi[q][1] - plan.lo[q][1];
+                  const long le = ((long)((k - plan.lo[q][2]) * qj + (j - plan.lo[q][1])) * qi + (i - plan.lo[q][0])) * nc + c;
+                  add(buf[plan.start[q] + le]);
+                }
+            }
+          if (plan.self_pos >= plan.n_regions)
+            add(vec[idx]);
+          vec[idx] = sum;
+        }
+    }
+
     __global__ __launch_bounds__(VT) void halo_kernel(double *__restrict__ vec, double *__restrict__ buf,
                                                       const HaloPlan plan, const int mode)
     {
       const long total = plan.offset[plan.n_regions];
       for (long t = blockIdx.x * (long)VT + threadIdx.x; t < total; t += (long)gridDim.x * VT)
+        halo_item(vec, buf, plan, mode, t);
+    }
+    // both fields of a block vector in ONE launch (the exchanges of a distributed vmult are launch-bound on small bricks)
+    __global__ __launch_bounds__(VT) void halo_pair_kernel(double *__restrict__ vec0, double *__restrict__ vec1,
+                                                           double *__restrict__ buf, const HaloPlan plan0,
+                                                           const HaloPlan plan1, const int mode)
+    {
+      const long n0 = plan0.offset[plan0.n_regions], total = n0 + plan1.offset[plan1.n_regions];
+      for (long t = blockIdx.x * (long)VT + threadIdx.x; t < total; t += (long)gridDim.x * VT)
         {
-          int r = 0;
-          while (t >= plan.offset[r + 1])
-            ++r;
-          long      e  = t - plan.offset[r];
-          const long el = e;
-          const int nc = plan.ncomp, ni = plan.hi[r][0] - plan.lo[r][0], nj = plan.hi[r][1] - plan.lo[r][1];
-          const int c  = (int)(e % nc);
-          e /= nc;
-          const int i = (int)(e % ni) + plan.lo[r][0];
-          e /= ni;
-          const int  j   = (int)(e % nj) + plan.lo[r][1];
-          const int  k   = (int)(e / nj) + plan.lo[r][2];
-          const long idx = ((long)(k * (long)plan.nn[1] + j) * plan.nn[0] + i) * nc + c;
-          if (mode == 0)
-            buf[plan.start[r] + el] = vec[idx];
-          else if (mode == 1)
-            vec[idx] = buf[plan.start[r] + el];
+          if (t < n0)
+            halo_item(vec0, buf, plan0, mode, t);
           else
-            {
-              auto inside = [&](const int q) {
-                return i >= plan.lo[q][0] && i < plan.hi[q][0] && j >= plan.lo[q][1] && j < plan.hi[q][1] &&
-                       k >= plan.lo[q][2] && k < plan.hi[q][2];
-              };
-              bool first = true;
-              for (int q = 0; q < r; ++q)
-                first = first && !inside(q);
-              if (!first)
-                continue;
-              // own value and received partial sums in ONE global order (the regions arrive sorted by
-              // the rank of their sender, self_pos = where this rank sits in that order): all sharers
-              // add the same numbers in the same sequence
-              double sum     = 0.;
-              bool   started = false;
-              auto   add     = [&](const double x) {
-                sum     = started ? sum + x : x;
-                started = true;
-              };
-              for (int q = r; q < plan.n_regions; ++q)
-                {
-                  if (q == plan.self_pos || (q == r && plan.self_pos < r))
-                    add(vec[idx]);
-                  if (inside(q))
-                    {
-                      const int  qi = plan.hi[q][0] - plan.lo[q][0], qj = plan.hi[q][1] - plan.lo[q][1];
-                      const long le = ((long)((k - plan.lo[q][2]) * qj + (j - plan.lo[q][1])) * qi + (i - plan.lo[q][0])) * nc + c;
-                      add(buf[plan.start[q] + le]);
-                    }
-                }
-              if (plan.self_pos >= plan.n_regions)
-                add(vec[idx]);
-              vec[idx] = sum;
-            }
+            halo_item(vec1, buf, plan1, mode, t - n0);
         }
     }
 
@@ -276,6 +352,17 @@ namespace adaflo_hip
   {
     hipLaunchKernelGGL(prepare_dst_kernel, dim3(grid_for(n_nodes * ncomp)), dim3(VT), 0, ctx->stream,
                        dst, src, n_nodes, ncomp, nnx, nny, nnz, mask, sign, zero_rest);
+    return check();
+  }
+
+  int launch_constrained_faces(adaflo_ctx *ctx, double *dst, const double *src, const int ncomp, const int nnx, const int nny,
+                               const int nnz, const uint32_t mask, const double sign)
+  {
+    if (mask == 0u)
+      return 0;
+    const long total = 2 * ((long)nny * nnz + (long)nnx * nnz + (long)nnx * nny) * ncomp;
+    hipLaunchKernelGGL(constrained_faces_kernel, dim3(grid_for(total)), dim3(VT), 0, ctx->stream, dst, src, ncomp, nnx, nny,
+                       nnz, mask, sign);
     return check();
   }
 
@@ -370,6 +457,16 @@ namespace adaflo_hip
       return 0.;
     (void)hipStreamSynchronize(ctx->stream);
     return ctx->h_result[0];
+  }
+
+  int launch_halo_pair(adaflo_ctx *ctx, double *vec0, double *vec1, double *buf, const HaloPlan &plan0, const HaloPlan &plan1,
+                       const int mode)
+  {
+    const long total = plan0.offset[plan0.n_regions] + plan1.offset[plan1.n_regions];
+    if (total == 0)
+      return 0;
+    hipLaunchKernelGGL(halo_pair_kernel, dim3(grid_for(total)), dim3(VT), 0, ctx->stream, vec0, vec1, buf, plan0, plan1, mode);
+    return check();
   }
 
   int launch_halo(adaflo_ctx *ctx, double *vec, double *buf, const HaloPlan &plan, const int mode)

@@ -335,7 +335,7 @@ class NativeCommunicator:
         self._lib, self._ctx, self.group = _lib.load(), ctx, group
         self.handle = C.c_void_p()
         grid = (C.c_int * 3)(*part.grid)
-        backend = dist.get_backend(group) if part.world > 1 else "none"
+        backend = dist.get_backend(group) if (part.world > 1 and group is not None) else "none"
         if backend == "nccl":
             uid = _lib.CommUniqueId()
             if part.rank == 0:
@@ -401,6 +401,10 @@ class NativeCommunicator:
     def compress_add(self, vec):
         self._check(self._lib.adaflo_comm_compress_add(self.handle, vec.block(0).ptr, vec.block(1).ptr))
 
+    def force_phased_schedule(self, enabled=True):
+        """measurement aid: the three-phase schedule also with one rank (bench.py --through-comm)"""
+        self._check(self._lib.adaflo_comm_force_phased_schedule(self.handle, int(enabled)))
+
     def close(self):
         if self.handle:
             self._lib.adaflo_comm_destroy(self.handle)
@@ -413,7 +417,8 @@ class DistributedNavierStokesMatrix:
     native_comm=True: everything behind the C ABI (adaflo_ns_vmult_distributed, NativeCommunicator);
     False: the exchange is driven from here through torch.distributed point-to-point operations."""
 
-    def __init__(self, parameters, part, device=0, stream=None, group=None, local=None, native_comm=False):
+    def __init__(self, parameters, part, device=0, stream=None, group=None, local=None, native_comm=False,
+                 through_comm=False):
         """`local`: the per-rank operator; default = the HIP engine on the local brick.  (The
         gloo/CPU tests inject an oracle-backed stand-in to check the exchange logic.)"""
         from .navier_stokes_matrix import BrickMesh, NavierStokesMatrix
@@ -432,6 +437,7 @@ class DistributedNavierStokesMatrix:
                                        constrained_faces_p=(), device=device, stream=stream)
         self.local = local
         self.native_comm = native_comm and hasattr(local, "_ctx")
+        self.through_comm = through_comm      # one rank, but through adaflo_ns_vmult_distributed (phased schedule)
         self.comm = None
         self.overlap = True       # overlap the exchanges with interior cells where supported
         self.halo = HaloExchange(part, [(k, 3), (k - 1, 1)], group=group)
@@ -439,12 +445,14 @@ class DistributedNavierStokesMatrix:
         self._inv = None
 
     def initialize(self, time_stepping, pressure_average_fix):
-        single = self.part.world == 1
+        single = self.part.world == 1 and not self.through_comm
         self.local.initialize(time_stepping, pressure_average_fix and single)
         self.halo.native = getattr(self.local, "_ctx", None)
         self.pressure_average_fix = pressure_average_fix
         if self.native_comm and not single:
             self.comm = NativeCommunicator(self.local._ctx, self.part, self.group, pressure_average_fix)
+            if self.through_comm:
+                self.comm.force_phased_schedule(True)
         elif pressure_average_fix and not single:
             self._setup_projection()
 
@@ -478,7 +486,7 @@ class DistributedNavierStokesMatrix:
           ghost update of src   ||  interior cells, first half
           cells at the interface, seam sums of the interface nodes
           compress(add) of dst  ||  interior cells, second half"""
-        if self.part.world == 1:
+        if self.part.world == 1 and self.comm is None:
             self.local.vmult(dst, src)
             return
         if self.comm is not None:

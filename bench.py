@@ -71,6 +71,9 @@ def parse():
                          "compress).  Default: the full cell_loop exchange of the reference, update_ghost_values(src) "
                          "+ compress(add) of dst (navier_stokes_matrix.cc:232-245)")
     ap.add_argument("--full-exchange", action="store_true", help="(default since round 3; kept for scripts)")
+    ap.add_argument("--through-comm", action="store_true",
+                    help="N = 1 only: run the vmult through adaflo_ns_vmult_distributed with the three-phase schedule "
+                         "forced (packs, events, second stream, three launches): the fixed cost of the multi-GPU path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--print-steps", action="store_true", help="per-step device times on stderr")
     ap.add_argument("--cpu-sample-cells", type=int, default=48)
@@ -243,7 +246,8 @@ def main():
     stream = torch.cuda.current_stream(device).cuda_stream   # 0 = the legacy default stream
     op = parallel.DistributedNavierStokesMatrix(fp, part, device=local_rank, stream=stream,
                                                 group=dist.group.WORLD if world > 1 else None,
-                                                native_comm=args.comm == "native")
+                                                native_comm=args.comm == "native",
+                                                through_comm=args.through_comm and world == 1)
     op.initialize(ts, True)
     op.set_kernel_variant(args.variant)
     op.overlap = not args.no_overlap
@@ -360,7 +364,8 @@ def main():
         "config": {"workload": workload, "dofs": n_dofs_global, "cells_per_gpu": n_cells_local,
                    "partition": "x".join(str(g) for g in grid), "kernel_variant": args.variant,
                    "overlap": bool(op.overlap) if world > 1 else None,
-                   "comm": args.comm if world > 1 else None,
+                   "comm": args.comm if (world > 1 or args.through_comm) else None,
+                   "through_comm": bool(args.through_comm) if world == 1 else None,
                    # N > 1: does a timed vmult include the owner->ghost update of src (the reference's
                    # update_ghost_values in cell_loop)?  False only with --src-consistent
                    "src_ghost_update": (not args.src_consistent) if world > 1 else None},
@@ -376,9 +381,18 @@ def main():
     }
     if dry_run:
         out["dry_run"] = True       # ranks share one GPU, gloo messages: functional check only
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # same element as the metric; the sample holds about as many DoFs as the 48^3 Q2/Q1 default
-        out["cpu_baseline"] = cpu_baseline(max(4, args.cpu_sample_cells * 2 // k), k)
+    if not args.no_cpu_baseline:
+        # same element as the metric; the sample holds about as many DoFs as the 48^3 Q2/Q1 default.  Timed on rank 0,
+        # after the timed region; with N > 1 the other ranks sleep on the rendezvous store meanwhile (a blocking
+        # socket wait: they do not spin on cores the baseline is using)
+        store = dist.distributed_c10d._get_default_store() if world > 1 else None
+        if rank == 0:
+            out["cpu_baseline"] = cpu_baseline(max(4, args.cpu_sample_cells * 2 // k), k)
+            if store is not None:
+                store.set("adaflo_bench_cpu_baseline_done", "1")
+        elif store is not None:
+            import datetime
+            store.wait(["adaflo_bench_cpu_baseline_done"], datetime.timedelta(seconds=600))
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -273,6 +273,10 @@ int         adaflo_comm_compress_add(adaflo_comm *comm, double *vec_u, double *v
  * its replicas are refreshed.                                                               */
 int         adaflo_ns_vmult_distributed(adaflo_ctx *ctx, adaflo_comm *comm, double *dst_u, double *dst_p,
                                         double *src_u, double *src_p, int src_ghosts_valid);
+/* measurement aid (bench.py --through-comm): take the three-phase schedule -- packs, events, second stream,
+ * three kernel launches, unpacks, constrained rows -- also with world = 1, where adaflo_ns_vmult_distributed
+ * otherwise forwards to adaflo_ns_vmult.  Shows the fixed cost of the distributed path on one GPU.          */
+int         adaflo_comm_force_phased_schedule(adaflo_comm *comm, int enabled);
 
 
 /* ---- level-set operators (LevelSetOKZSolver*, source/level_set_okz_*.cc) ---- */

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing of the Q3..Q5 kernels (development aid): variant 1 = x-marching kernel (ns_hox.hip), 2 = z-sweep kernel of
-round 2 (ns_ho.hip), 0 = generic.   usage: bench_ho.py [k,k,...] [variants] [x-chunks]"""
+round 2 (ns_ho.hip), 0 = generic.   usage: bench_ho.py [k,k,...] [variants] [x-chunks] [cells per direction]"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,7 +42,7 @@ if __name__ == "__main__":
     variants = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 0]
     chunks = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
     for k in ks:
-        n = {3: 64, 4: 64, 5: 48}[k]
+        n = int(sys.argv[4]) if len(sys.argv) > 4 else {3: 64, 4: 64, 5: 48}[k]
         for v in variants:
             for lx in (chunks if v == 1 else [0]):
                 run(k, n, v, "incompressible stationary" if k == 4 else "incompressible", lx)

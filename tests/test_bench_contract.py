@@ -60,6 +60,6 @@ def test_bench_self_launches_two_ranks():
 def test_bench_cavity_configuration():
     r = _run(["--config", "cavity", "--cells", "16", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
     assert "Q4/Q3" in r["metric"] and "incompressible stationary" in r["config"]["workload"]
-    assert r["roofline"]["alg_bytes_per_dof"] == 70.8 and r["roofline"]["kernel"] == "ns_ho_kernel"
+    assert r["roofline"]["alg_bytes_per_dof"] == 70.8 and r["roofline"]["kernel"] == "ns_hox_kernel"
     r = _run(["--config", "cavity", "--cells", "16", "--gpus", "2", "--steps", "2", "--warmup", "1"])
     assert r["scaling"] == "strong" and r["config"]["cells_per_gpu"] == 8 * 16 * 16
