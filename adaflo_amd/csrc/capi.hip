@@ -164,7 +164,7 @@ namespace
 
   int nn(const adaflo_ctx *ctx, const int degree, const int d)
   {
-    return degree * ctx->desc.ncell[d] + 1;
+    return (ctx->flat && d == 2) ? 1 : degree * ctx->desc.ncell[d] + 1;
   }
 } // namespace
 
@@ -177,8 +177,14 @@ const char *adaflo_last_error(const adaflo_ctx *ctx)
 
 static int ctx_create_impl(const adaflo_brick_desc *desc, adaflo_ctx *ctx)
 {
-  if (desc->dim != 3)
-    return fail(nullptr, ADAFLO_EUNSUPPORTED, "only dim = 3 is implemented on the device");
+  // dim = 2 (NavierStokesMatrix<2>, navier_stokes_matrix.cc:1211; all level-set golden outputs of the reference are
+  // 2D): the generic kernels with a FLAT third direction -- one node, one quadrature point of weight 1, h_z = 1, the
+  // third velocity component constrained everywhere -- i.e. the same templates as dim = 3 (fe_kernels.hpp: SumFac<.., ZF>).
+  // Velocity degree 2 or 3 (the reference's 2D tests); the specialised 3D kernels are not used.
+  if (desc->dim != 3 && desc->dim != 2)
+    return fail(nullptr, ADAFLO_EUNSUPPORTED, "dim must be 2 or 3");
+  if (desc->dim == 2 && (desc->ncell[2] != 1 || desc->velocity_degree > 3))
+    return fail(nullptr, ADAFLO_EUNSUPPORTED, "dim = 2: ncell[2] must be 1 and the velocity degree 2 or 3");
   // EXPAND_OPERATIONS (source/navier_stokes_matrix.cc:64-82): degree_p = 1 .. 5, i.e. velocity degrees 2 .. 6
   if (desc->velocity_degree < 2 || desc->velocity_degree > 6)
     return fail(nullptr, ADAFLO_EUNSUPPORTED, "velocity degree must be in [2,6] (reference: ExcNotImplemented)");
@@ -193,6 +199,15 @@ static int ctx_create_impl(const adaflo_brick_desc *desc, adaflo_ctx *ctx)
     return fail(nullptr, ADAFLO_EINVAL, "invalid device ordinal");
 
   ctx->desc       = *desc;
+  ctx->flat       = desc->dim == 2;
+  if (ctx->flat)
+    {
+      ctx->desc.h[2] = 1.; // the single z point has weight 1: integrals over the brick are integrals over the x-y domain
+      ctx->variant   = 0;  // generic kernels only
+      ctx->pc_inner  = 0;  // (the fast-diagonalisation inverses are 3D)
+      // the third velocity component does not exist in 2D: constrained on both z faces = everywhere
+      ctx->desc.velocity_constrained |= (1u << (3 * 4 + 2)) | (1u << (3 * 5 + 2));
+    }
   HIP_TRY(nullptr, hipSetDevice(desc->device));
   if (desc->stream)
     ctx->stream = static_cast<hipStream_t>(desc->stream);
@@ -208,13 +223,13 @@ static int ctx_create_impl(const adaflo_brick_desc *desc, adaflo_ctx *ctx)
   ctx->n_nodes_u = (int64_t)nn(ctx, k, 0) * nn(ctx, k, 1) * nn(ctx, k, 2);
   ctx->n_nodes_p = (int64_t)nn(ctx, k - 1, 0) * nn(ctx, k - 1, 1) * nn(ctx, k - 1, 2);
   ctx->n_nodes_ls = ctx->s > 0 ? (int64_t)nn(ctx, ctx->s, 0) * nn(ctx, ctx->s, 1) * nn(ctx, ctx->s, 2) : 0;
-  ctx->nq_u       = (k + 1) * (k + 1) * (k + 1);
+  ctx->nq_u       = (k + 1) * (k + 1) * (ctx->flat ? 1 : k + 1);
   for (int d = 0; d < 3; ++d)
     {
       ctx->brick.ncell[d] = desc->ncell[d];
-      ctx->brick.h[d]     = desc->h[d];
+      ctx->brick.h[d]     = ctx->desc.h[d];
     }
-  ctx->brick.con_u  = desc->velocity_constrained;
+  ctx->brick.con_u  = ctx->desc.velocity_constrained;
   ctx->brick.con_p  = desc->pressure_constrained;
   ctx->brick.con_ls = desc->ls_constrained;
 
@@ -411,6 +426,8 @@ int adaflo_set_kernel_variant(adaflo_ctx *ctx, int variant)
   CHECK_CTX(ctx);
   if (variant < 0 || variant > 2)
     return fail(ctx, ADAFLO_EINVAL, "unknown kernel variant");
+  if (ctx->flat && variant != 0)
+    return fail(ctx, ADAFLO_EUNSUPPORTED, "dim = 2 runs on the generic kernels (variant 0) only");
   ctx->variant = variant;
   return 0;
 }
@@ -985,6 +1002,8 @@ int adaflo_set_timing(adaflo_ctx *ctx, int enabled)
 int adaflo_fdm_apply(adaflo_ctx *ctx, int field, double *dst, const double *src, double c_mass, double c_lap)
 {
   CHECK_CTX(ctx);
+  if (ctx->flat)
+    return fail(ctx, ADAFLO_EUNSUPPORTED, "the fast-diagonalisation inverses are dim = 3 only");
   if (!dst || !src || field < 0 || field > 2)
     return fail(ctx, ADAFLO_EINVAL, "invalid arguments");
   if (field == 2 && ctx->s <= 0)
@@ -1016,6 +1035,8 @@ int adaflo_ns_preconditioner_set_inner(adaflo_ctx *ctx, int mode)
   CHECK_CTX(ctx);
   if (mode < 0 || mode > 1)
     return fail(ctx, ADAFLO_EINVAL, "unknown inner-solve mode");
+  if (ctx->flat && mode == 1)
+    return fail(ctx, ADAFLO_EUNSUPPORTED, "the fast-diagonalisation inverses are dim = 3 only");
   if (mode != ctx->pc_inner)
     ctx->pc_ready = false; // the other flavour of inner solves needs its own set-up data
   ctx->pc_inner = mode;
@@ -1247,7 +1268,7 @@ static int ls_vmult(adaflo_ctx *ctx, double *dst, const double *src, const int m
       if (ctx->brick.con_ls && !ctx->d_ls_diag)
         return fail(ctx, ADAFLO_ENOTINIT, "constrained rows need adaflo_ls_set_diagonal");
       const LSDev &P     = ctx->ls;
-      const double hcell = std::max(ctx->desc.h[0], std::max(ctx->desc.h[1], ctx->desc.h[2]));
+      const double hcell = ctx->flat ? std::max(ctx->desc.h[0], ctx->desc.h[1]) : std::max(ctx->desc.h[0], std::max(ctx->desc.h[1], ctx->desc.h[2]));
       // level_set_okz_reinitialization.cc:65-67,:82-85; compute_normal.cc:107-110;
       // compute_curvature.cc:112-118
       const double dtau_inv  = std::max(0.95 / (1. / 9. * P.minimal_edge_length / ctx->s), 1. / (5. * P.time_step));
@@ -1593,6 +1614,8 @@ int adaflo_ls_projection_solve(adaflo_ctx *ctx, double *dst, const double *rhs, 
     return fail(ctx, ADAFLO_EINVAL, "invalid arguments");
   if (ctx->brick.con_ls != 0u) // (constrained rows of the operator carry the user's diagonal, not the identity)
     return fail(ctx, ADAFLO_EUNSUPPORTED, "exact projection solve needs an unconstrained level-set space");
+  if (ctx->flat)
+    return fail(ctx, ADAFLO_EUNSUPPORTED, "the fast-diagonalisation inverses are dim = 3 only");
   // the damping of compute_normal.cc:107-110 / level_set_okz.cc:262-312: 4 max(eps_used / eps, h / s)^2
   const LSDev &P     = ctx->ls;
   const double hcell = std::max(ctx->desc.h[0], std::max(ctx->desc.h[1], ctx->desc.h[2]));

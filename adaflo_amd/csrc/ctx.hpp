@@ -95,6 +95,7 @@ struct adaflo_ctx
   bool              own_stream = false;
   int               variant    = 1;
 
+  bool    flat = false; // dim = 2: flat third direction (capi.hip: ctx_create_impl)
   int     k = 0, s = 0;
   int64_t n_cells = 0, n_nodes_u = 0, n_nodes_p = 0, n_nodes_ls = 0;
   int     nq_u = 0; // (k+1)^3

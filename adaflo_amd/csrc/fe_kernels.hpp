@@ -76,15 +76,22 @@ namespace adaflo_hip
     return (f & mask) != 0u;
   }
 
-  template <int ND, int NQ, int NT>
+  // ZF ("flat z"): the z direction has ONE node and ONE quadrature point of weight 1 -- value = the nodal value,
+  // d/dz = 0.  This is how the engine runs dim = 2 (NavierStokesMatrix<2>, navier_stokes_matrix.cc:1211; the
+  // reference's level-set golden outputs are all 2D): the same kernels with a degenerate third direction, the
+  // 1D tables of x / y untouched.
+  template <int ND, int NQ, int NT, bool ZF = false>
   struct SumFac
   {
-    static constexpr int ND3 = ND * ND * ND;
+    static constexpr int NDZ = ZF ? 1 : ND, NQZ = ZF ? 1 : NQ;
+    static constexpr int ND3 = ND * ND * NDZ;
     static constexpr int NQ2 = NQ * NQ;
-    static constexpr int NQ3 = NQ * NQ * NQ;
-    static constexpr int T1  = NQ * ND * ND;
-    static constexpr int T2  = NQ * NQ * ND;
+    static constexpr int NQ3 = NQ * NQ * NQZ;
+    static constexpr int T1  = NQ * ND * NDZ;
+    static constexpr int T2  = NQ * NQ * NDZ;
     static constexpr int TMP = 2 * T1 + 3 * T2;
+    // entries of the z matrices
+    static __device__ __forceinline__ double Sz(const double *S, const int idx) { return ZF ? 1. : S[idx]; }
 
     // u[ND3] -> val[NQ3], gx/gy/gz[NQ3] (reference-cell derivatives)
     template <bool VAL, bool GRAD>
@@ -138,15 +145,16 @@ namespace adaflo_hip
           const int rq = o % NQ2, s = o / NQ2;
           double    a = 0., dz = 0., dy = 0., dx = 0.;
 #pragma unroll
-          for (int k = 0; k < ND; ++k)
+          for (int k = 0; k < NDZ; ++k)
             {
               const double v = t2[k * NQ2 + rq];
-              a += S[s * ND + k] * v;
+              a += Sz(S, s * ND + k) * v;
               if (GRAD)
                 {
-                  dz += D[s * ND + k] * v;
-                  dy += S[s * ND + k] * t2dy[k * NQ2 + rq];
-                  dx += S[s * ND + k] * t2dx[k * NQ2 + rq];
+                  if constexpr (!ZF)
+                    dz += D[s * ND + k] * v;
+                  dy += Sz(S, s * ND + k) * t2dy[k * NQ2 + rq];
+                  dx += Sz(S, s * ND + k) * t2dx[k * NQ2 + rq];
                 }
             }
           if (VAL)
@@ -215,15 +223,16 @@ namespace adaflo_hip
         {
           const int rq = tid % NQ2, s = tid / NQ2;
 #pragma unroll
-          for (int k = 0; k < ND; ++k)
+          for (int k = 0; k < NDZ; ++k)
             {
               const double v = t2[k * NQ2 + rq];
-              val += S[s * ND + k] * v;
+              val += Sz(S, s * ND + k) * v;
               if (GRAD)
                 {
-                  gz += D[s * ND + k] * v;
-                  gy += S[s * ND + k] * t2dy[k * NQ2 + rq];
-                  gx += S[s * ND + k] * t2dx[k * NQ2 + rq];
+                  if constexpr (!ZF)
+                    gz += D[s * ND + k] * v;
+                  gy += Sz(S, s * ND + k) * t2dy[k * NQ2 + rq];
+                  gx += Sz(S, s * ND + k) * t2dx[k * NQ2 + rq];
                 }
             }
         }
@@ -282,13 +291,14 @@ namespace adaflo_hip
           const double *t2 = tmp + b * TMP + 2 * T1, *t2dy = t2 + T2, *t2dx = t2 + 2 * T2;
           double        a = 0., dz = 0., dy = 0., dx = 0.;
 #pragma unroll
-          for (int k = 0; k < ND; ++k)
+          for (int k = 0; k < NDZ; ++k)
             {
               const double v = t2[k * NQ2 + rq];
-              a += S[s * ND + k] * v;
-              dz += D[s * ND + k] * v;
-              dy += S[s * ND + k] * t2dy[k * NQ2 + rq];
-              dx += S[s * ND + k] * t2dx[k * NQ2 + rq];
+              a += Sz(S, s * ND + k) * v;
+              if constexpr (!ZF)
+                dz += D[s * ND + k] * v;
+              dy += Sz(S, s * ND + k) * t2dy[k * NQ2 + rq];
+              dx += Sz(S, s * ND + k) * t2dx[k * NQ2 + rq];
             }
           val[b * NQ3 + o]           = a;
           g[(3 * b + 0) * NQ3 + o] = dx;
@@ -311,11 +321,13 @@ namespace adaflo_hip
           const double *v = tv + b * NQ3, *gx = tg + (3 * b) * NQ3, *gy = gx + NQ3, *gz = gy + NQ3;
           double        a = 0., ay = 0., ax = 0.;
 #pragma unroll
-          for (int s = 0; s < NQ; ++s)
+          for (int s = 0; s < NQZ; ++s)
             {
-              a += S[s * ND + k] * v[s * NQ2 + rq] + D[s * ND + k] * gz[s * NQ2 + rq];
-              ay += S[s * ND + k] * gy[s * NQ2 + rq];
-              ax += S[s * ND + k] * gx[s * NQ2 + rq];
+              a += Sz(S, s * ND + k) * v[s * NQ2 + rq];
+              if constexpr (!ZF)
+                a += D[s * ND + k] * gz[s * NQ2 + rq];
+              ay += Sz(S, s * ND + k) * gy[s * NQ2 + rq];
+              ax += Sz(S, s * ND + k) * gx[s * NQ2 + rq];
             }
           double *t2 = tmp + b * TMP + 2 * T1;
           t2[o]          = a;
@@ -366,15 +378,16 @@ namespace adaflo_hip
           const int rq = o % NQ2, k = o / NQ2;
           double    a = 0., ay = 0., ax = 0.;
 #pragma unroll
-          for (int s = 0; s < NQ; ++s)
+          for (int s = 0; s < NQZ; ++s)
             {
               if (VAL)
-                a += S[s * ND + k] * tv[s * NQ2 + rq];
+                a += Sz(S, s * ND + k) * tv[s * NQ2 + rq];
               if (GRAD)
                 {
-                  a += D[s * ND + k] * tgz[s * NQ2 + rq];
-                  ay += S[s * ND + k] * tgy[s * NQ2 + rq];
-                  ax += S[s * ND + k] * tgx[s * NQ2 + rq];
+                  if constexpr (!ZF)
+                    a += D[s * ND + k] * tgz[s * NQ2 + rq];
+                  ay += Sz(S, s * ND + k) * tgy[s * NQ2 + rq];
+                  ax += Sz(S, s * ND + k) * tgx[s * NQ2 + rq];
                 }
             }
           t2[o] = a;
@@ -423,12 +436,12 @@ namespace adaflo_hip
 
   // gather the (DEG+1)^3 x NC local values of cell (cx,cy,cz); dof = node*NC+c.
   // RESOLVE: constrained entries read as zero (read_dof_values), else plain.
-  template <int DEG, int NC, int NT, bool RESOLVE>
+  template <int DEG, int NC, int NT, bool RESOLVE, bool ZF = false>
   __device__ void gather_cell(const double *__restrict__ vec, double *loc, const int cx,
                               const int cy, const int cz, const int nnx, const int nny,
                               const int nnz, const uint32_t mask)
   {
-    constexpr int ND = DEG + 1, ND3 = ND * ND * ND;
+    constexpr int ND = DEG + 1, ND3 = ND * ND * (ZF ? 1 : ND);
     for (int o = threadIdx.x; o < ND3 * NC; o += NT)
       {
         const int  c = o % NC, l = o / NC;
@@ -444,12 +457,12 @@ namespace adaflo_hip
 
   // distribute_local_to_global: scatter-add, constrained rows skipped.  No atomics: the cell loops run colour by
   // colour (BrickDev::colour), the cells of one launch share no node.
-  template <int DEG, int NC, int NT>
+  template <int DEG, int NC, int NT, bool ZF = false>
   __device__ void scatter_cell(double *__restrict__ vec, const double *loc, const int cx,
                                const int cy, const int cz, const int nnx, const int nny,
                                const int nnz, const uint32_t mask)
   {
-    constexpr int ND = DEG + 1, ND3 = ND * ND * ND;
+    constexpr int ND = DEG + 1, ND3 = ND * ND * (ZF ? 1 : ND);
     for (int o = threadIdx.x; o < ND3 * NC; o += NT)
       {
         const int  c = o % NC, l = o / NC;

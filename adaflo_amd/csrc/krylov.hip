@@ -882,10 +882,10 @@ namespace
                      const int ncomp)
   {
     const int  nnx = degree * ctx->desc.ncell[0] + 1, nny = degree * ctx->desc.ncell[1] + 1;
-    const long n_nodes = (long)nnx * nny * (degree * ctx->desc.ncell[2] + 1);
+    const long n_nodes = (long)nnx * nny * (ctx->flat ? 1 : degree * ctx->desc.ncell[2] + 1);
     const int  period = degree + 1;
     const long n = n_nodes * ncomp;
-    for (int colour = 0; colour < period * period * period; ++colour)
+    for (int colour = 0; colour < period * period * (ctx->flat ? 1 : period); ++colour) // (dim = 2: one node layer)
       for (int comp = 0; comp < ncomp; ++comp)
         {
           hipLaunchKernelGGL(probe_fill_kernel, dim3(kgrid(n)), dim3(KT), 0, ctx->stream, e, nnx, nny, n_nodes, ncomp,

@@ -37,15 +37,16 @@ namespace adaflo_hip
     // one thread per cell: is some |phi| of the cell below tanh(2)?  (:493-503)
     __global__ __launch_bounds__(256) void heaviside_flag_kernel(unsigned char *__restrict__ flag,
                                                                  const double *__restrict__ phi, const int s,
-                                                                 const int ncx, const int ncy, const long n_cells)
+                                                                 const int ncx, const int ncy, const long n_cells,
+                                                                 const int flat)
     {
       const double cutoff = tanh(2.);
-      const int    nx = s * ncx + 1, ny = s * ncy + 1;
+      const int    nx = s * ncx + 1, ny = s * ncy + 1, sz = flat ? 0 : s; // (dim = 2: one node layer)
       for (long c = blockIdx.x * 256L + threadIdx.x; c < n_cells; c += (long)gridDim.x * 256)
         {
           const int cx = (int)(c % ncx), cy = (int)((c / ncx) % ncy), cz = (int)(c / ((long)ncx * ncy));
           bool      consider = false;
-          for (int k = 0; k <= s && !consider; ++k)
+          for (int k = 0; k <= sz && !consider; ++k)
             for (int j = 0; j <= s && !consider; ++j)
               for (int i = 0; i <= s; ++i)
                 if (fabs(phi[(cx * s + i) + (long)nx * ((cy * s + j) + (long)ny * (cz * s + k))]) < cutoff)
@@ -81,7 +82,7 @@ namespace adaflo_hip
             for (int cy = max((J - 1) / s, 0); cy <= min(J / s, ncy - 1); ++cy)
               for (int cx = max((I - 1) / s, 0); cx <= min(I / s, ncx - 1); ++cx)
                 {
-                  if (I < cx * s || I > cx * s + s || J < cy * s || J > cy * s + s || K < cz * s || K > cz * s + s)
+                  if (I < cx * s || I > cx * s + s || J < cy * s || J > cy * s + s || K < cz * s || K > cz * s + s) // (dim = 2: K = cz = 0)
                     continue;
                   const long c = cx + (long)ncx * (cy + (long)ncy * cz);
                   if (flag[c])
@@ -119,7 +120,7 @@ namespace adaflo_hip
       for (long g = blockIdx.x * 256L + threadIdx.x; g < n_nodes; g += (long)gridDim.x * 256)
         {
           const int I = (int)(g % nx), J = (int)((g / nx) % ny), K = (int)(g / ((long)nx * ny));
-          const int cnt = ((I > 0) + (I < nx - 1)) * ((J > 0) + (J < ny - 1)) * ((K > 0) + (K < nz - 1));
+          const int cnt = ((I > 0) + (I < nx - 1)) * ((J > 0) + (J < ny - 1)) * (nz == 1 ? 1 : (K > 0) + (K < nz - 1));
           diag[g]       = unit * cnt;
         }
     }
@@ -134,27 +135,29 @@ namespace adaflo_hip
       long          n_cells;
     };
 
-    template <int S, int KU, int NT>
+    // ZF: flat third direction (dim = 2), see SumFac in fe_kernels.hpp
+    template <int S, int KU, int NT, bool ZF = false>
     struct ForceCfg
     {
       static constexpr int NDL = S + 1, NQ = KU + 1, NDP = KU, NDV = KU + 1;
-      static constexpr int NDL3 = NDL * NDL * NDL, NQ3 = NQ * NQ * NQ, NDP3 = NDP * NDP * NDP, NDV3 = NDV * NDV * NDV;
+      static constexpr int NDL3 = NDL * NDL * (ZF ? 1 : NDL), NQ3 = NQ * NQ * (ZF ? 1 : NQ), NDP3 = NDP * NDP * (ZF ? 1 : NDP),
+                           NDV3 = NDV * NDV * (ZF ? 1 : NDV);
       // tables: S_l D_l [NQ x NDL] | I1 [NDP x NDL] | S_p D_p [NQ x NDP] | S_v [NQ x NDV] | w [NQ]
       static constexpr int TAB = 2 * NQ * NDL + NDP * NDL + 2 * NQ * NDP + NQ * NDV + NQ, TABP = (TAB + 1) & ~1;
-      using SFL = SumFac<NDL, NQ, NT>;  // level-set space -> Gauss points
-      using SFI = SumFac<NDL, NDP, NT>; // level-set space -> pressure support points
-      using SFP = SumFac<NDP, NQ, NT>;  // pressure space -> Gauss points
-      using SFV = SumFac<NDV, NQ, NT>;  // velocity test functions
+      using SFL = SumFac<NDL, NQ, NT, ZF>;  // level-set space -> Gauss points
+      using SFI = SumFac<NDL, NDP, NT, ZF>; // level-set space -> pressure support points
+      using SFP = SumFac<NDP, NQ, NT, ZF>;  // pressure space -> Gauss points
+      using SFV = SumFac<NDV, NQ, NT, ZF>;  // velocity test functions
       static constexpr int TMP = (SFL::TMP > SFI::TMP ? SFL::TMP : SFI::TMP) > (SFP::TMP > SFV::TMP ? SFP::TMP : SFV::TMP) ?
                                    (SFL::TMP > SFI::TMP ? SFL::TMP : SFI::TMP) :
                                    (SFP::TMP > SFV::TMP ? SFP::TMP : SFV::TMP);
       static constexpr size_t LDS = TABP + 2 * NDL3 + NDP3 + 5 * NQ3 + 3 * NDV3 + TMP;
     };
 
-    template <int S, int KU, int NT>
+    template <int S, int KU, int NT, bool ZF = false>
     __global__ __launch_bounds__(NT) void ls_force_kernel(const ForceArgs a)
     {
-      using C = ForceCfg<S, KU, NT>;
+      using C = ForceCfg<S, KU, NT, ZF>;
       constexpr int NQ = C::NQ, NQ3 = C::NQ3, NDL = C::NDL, NDP = C::NDP, NDV = C::NDV;
       extern __shared__ double lds[];
       double *Sl = lds, *Dl = Sl + NQ * NDL, *I1 = Dl + NQ * NDL, *Sp = I1 + NDP * NDL, *Dp = Sp + NQ * NDP,
@@ -167,13 +170,13 @@ namespace adaflo_hip
       const long c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
       const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
       const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
-      const int  nx = S * ncx + 1, ny = S * ncy + 1, nz = S * ncz + 1;
-      const int  vx = KU * ncx + 1, vy = KU * ncy + 1, vz = KU * ncz + 1;
+      const int  nx = S * ncx + 1, ny = S * ncy + 1, nz = ZF ? 1 : S * ncz + 1;
+      const int  vx = KU * ncx + 1, vy = KU * ncy + 1, vz = ZF ? 1 : KU * ncz + 1;
       const double ih[3] = {1. / a.brick.h[0], 1. / a.brick.h[1], 1. / a.brick.h[2]};
       const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
 
-      gather_cell<S, 1, NT, false>(a.heaviside, hl, cx, cy, cz, nx, ny, nz, 0u); // read_dof_values_plain :348
-      gather_cell<S, 1, NT, false>(a.curvature, cl, cx, cy, cz, nx, ny, nz, 0u); // :384
+      gather_cell<S, 1, NT, false, ZF>(a.heaviside, hl, cx, cy, cz, nx, ny, nz, 0u); // read_dof_values_plain :348
+      gather_cell<S, 1, NT, false, ZF>(a.curvature, cl, cx, cy, cz, nx, ny, nz, 0u); // :384
       __syncthreads();
       // H and (unless taken from the pressure space) its gradient, curvature values
       C::SFL::template evaluate<true, true>(Sl, Dl, hl, hv, hg, hg + NQ3, hg + 2 * NQ3, tmp);
@@ -187,7 +190,7 @@ namespace adaflo_hip
       for (int q = tid; q < NQ3; q += NT)
         {
           const int    qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
-          const double jxw = det * wq[qx] * wq[qy] * wq[qz];
+          const double jxw = det * wq[qx] * wq[qy] * (ZF ? 1. : wq[qz]);
           double       rho = a.density;
           if (variable) // :352-365
             {
@@ -196,32 +199,33 @@ namespace adaflo_hip
               a.mu[(size_t)c * NQ3 + q]  = a.viscosity + a.viscosity_diff * hv[q];
             }
           const double sk = a.surface_tension * cv[q]; // :391-397
+          // gravity acts on component dim - 1 (:400-404)
           hg[q]           = sk * hg[q] * ih[0] * jxw;
-          hg[NQ3 + q]     = sk * hg[NQ3 + q] * ih[1] * jxw;
-          hg[2 * NQ3 + q] = (sk * hg[2 * NQ3 + q] * ih[2] - a.gravity * rho) * jxw; // :400-404
+          hg[NQ3 + q]     = (sk * hg[NQ3 + q] * ih[1] - (ZF ? a.gravity * rho : 0.)) * jxw;
+          hg[2 * NQ3 + q] = ZF ? 0. : (sk * hg[2 * NQ3 + q] * ih[2] - a.gravity * rho) * jxw;
         }
       __syncthreads();
       for (int d = 0; d < 3; ++d)
         C::SFV::template integrate<true, false>(Sv, Sv, hg + d * NQ3, nullptr, nullptr, nullptr, vl + d * C::NDV3, tmp);
-      scatter_cell<KU, 3, NT>(a.dst_u, vl, cx, cy, cz, vx, vy, vz, a.brick.con_u);
+      scatter_cell<KU, 3, NT, ZF>(a.dst_u, vl, cx, cy, cz, vx, vy, vz, a.brick.con_u);
     }
 
-    template <int S, int KU>
+    template <int S, int KU, bool ZF = false>
     int launch_force_sk(adaflo_ctx *ctx, const ForceArgs &args)
     {
       constexpr int NT = 128;
-      using C          = ForceCfg<S, KU, NT>;
+      using C          = ForceCfg<S, KU, NT, ZF>;
       const size_t lds = sizeof(double) * C::LDS;
       hipError_t   err = hipSuccess;
       if (lds > 64 * 1024)
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_force_kernel<S, KU, NT>),
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_force_kernel<S, KU, NT, ZF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       ForceArgs a = args;
       for (int colour = 0; colour < 8 && err == hipSuccess; ++colour) // (no atomics in the scatter, fe_kernels.hpp)
         if (const long nc = n_cells_of_colour(a.brick.ncell, colour))
           {
             a.brick.colour = colour;
-            hipLaunchKernelGGL((ls_force_kernel<S, KU, NT>), dim3((unsigned)nc), dim3(NT), lds, ctx->stream, a);
+            hipLaunchKernelGGL((ls_force_kernel<S, KU, NT, ZF>), dim3((unsigned)nc), dim3(NT), lds, ctx->stream, a);
           }
       if (err == hipSuccess)
         err = hipGetLastError();
@@ -231,6 +235,8 @@ namespace adaflo_hip
     template <int S>
     int launch_force_s(adaflo_ctx *ctx, const ForceArgs &a)
     {
+      if (ctx->flat)
+        return ctx->k == 2 ? launch_force_sk<S, 2, true>(ctx, a) : (ctx->k == 3 ? launch_force_sk<S, 3, true>(ctx, a) : ADAFLO_EUNSUPPORTED);
       switch (ctx->k)
         {
           case 2:
@@ -254,7 +260,7 @@ namespace adaflo_hip
       return ADAFLO_ENOMEM;
     long nb = (n_cells + 255) / 256;
     hipLaunchKernelGGL(heaviside_flag_kernel, dim3((unsigned)(nb > 65536 ? 65536 : nb)), dim3(256), 0, ctx->stream, flag,
-                       phi, s, ncx, ncy, n_cells);
+                       phi, s, ncx, ncy, n_cells, ctx->flat ? 1 : 0);
     nb = (n_nodes + 255) / 256;
     hipLaunchKernelGGL(heaviside_node_kernel, dim3((unsigned)(nb > 65536 ? 65536 : nb)), dim3(256), 0, ctx->stream,
                        heaviside, phi, flag, s, ncx, ncy, ncz, epsilon, n_nodes);
@@ -264,9 +270,9 @@ namespace adaflo_hip
   }
 
   // level_set_okz_compute_curvature.cc:360-376: extend the curvature along the normal direction to
-  // the value at the interface, 1 / (1 / kappa + distance / (dim - 1)) with dim = 3
+  // the value at the interface, 1 / (1 / kappa + distance / (dim - 1))
   __global__ void curvature_correction_kernel(double *__restrict__ kappa, const double *__restrict__ phi,
-                                              const double epsilon_used, const long n)
+                                              const double epsilon_used, const long n, const double dim_minus_1)
   {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
       {
@@ -275,7 +281,7 @@ namespace adaflo_hip
           {
             const double c        = phi[i];
             const double distance = (1 - c * c) > 1e-2 ? epsilon_used * log((1. + c) / (1. - c)) : 0.;
-            kappa[i]              = 1. / (1. / kv + distance / 2.);
+            kappa[i]              = 1. / (1. / kv + distance / dim_minus_1);
           }
       }
   }
@@ -285,15 +291,16 @@ namespace adaflo_hip
     const long n  = ctx->n_nodes_ls;
     const long nb = (n + 255) / 256;
     hipLaunchKernelGGL(curvature_correction_kernel, dim3((unsigned)(nb > 65536 ? 65536 : nb)), dim3(256), 0, ctx->stream,
-                       curvature, phi, ctx->ls.epsilon_used, n);
+                       curvature, phi, ctx->ls.epsilon_used, n, ctx->flat ? 1. : 2.);
     return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
   }
 
   int launch_ls_mass_diagonal(adaflo_ctx *ctx, double *diag)
   {
-    const int  s = ctx->s, nx = s * ctx->desc.ncell[0] + 1, ny = s * ctx->desc.ncell[1] + 1, nz = s * ctx->desc.ncell[2] + 1;
+    const int  s = ctx->s, nx = s * ctx->desc.ncell[0] + 1, ny = s * ctx->desc.ncell[1] + 1,
+              nz = ctx->flat ? 1 : s * ctx->desc.ncell[2] + 1;
     const long n = ctx->n_nodes_ls;
-    const double unit = (ctx->desc.h[0] / s / 3.) * (ctx->desc.h[1] / s / 3.) * (ctx->desc.h[2] / s / 3.);
+    const double unit = (ctx->desc.h[0] / s / 3.) * (ctx->desc.h[1] / s / 3.) * (ctx->flat ? 1. : ctx->desc.h[2] / s / 3.);
     long nb = (n + 255) / 256;
     hipLaunchKernelGGL(ls_mass_diagonal_kernel, dim3((unsigned)(nb > 65536 ? 65536 : nb)), dim3(256), 0, ctx->stream, diag,
                        nx, ny, nz, unit, n);

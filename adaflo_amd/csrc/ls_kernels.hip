@@ -44,26 +44,27 @@ namespace adaflo_hip
     unsigned      symmetry;
   };
 
-  template <int S, int NT>
+  // ZF: flat third direction (dim = 2), see SumFac in fe_kernels.hpp
+  template <int S, int NT, bool ZF = false>
   constexpr size_t ls_lds_doubles(const int extra)
   {
     constexpr int ND = S + 1, NQ = 2 * S;
-    return ((2 * NQ * ND + NQ + 1) & ~1) + ND * ND * ND + 4 * NQ * NQ * NQ + SumFac<ND, NQ, NT>::TMP + extra;
+    return ((2 * NQ * ND + NQ + 1) & ~1) + ND * ND * (ZF ? 1 : ND) + 4 * NQ * NQ * (ZF ? 1 : NQ) + SumFac<ND, NQ, NT, ZF>::TMP + extra;
   }
 
-  template <int S>
+  template <int S, bool ZF = false>
   struct LSCell
   {
-    static constexpr int ND = S + 1, NQ = 2 * S, ND3 = ND * ND * ND, NQ3 = NQ * NQ * NQ;
+    static constexpr int ND = S + 1, NQ = 2 * S, ND3 = ND * ND * (ZF ? 1 : ND), NQ3 = NQ * NQ * (ZF ? 1 : NQ);
     static constexpr int TAB = 2 * NQ * ND + NQ, TABP = (TAB + 1) & ~1;
   };
 
   // ------------------------------------------------------------------ operator applications
-  template <int S, int NT>
+  template <int S, int NT, bool ZF = false>
   __global__ __launch_bounds__(NT) void ls_vmult_kernel(const LSArgs a)
   {
-    using C  = LSCell<S>;
-    using SF = SumFac<C::ND, C::NQ, NT>;
+    using C  = LSCell<S, ZF>;
+    using SF = SumFac<C::ND, C::NQ, NT, ZF>;
     constexpr int NQ = C::NQ, NQ3 = C::NQ3;
     extern __shared__ double lds[];
     double *Sm = lds, *Dm = Sm + NQ * C::ND, *wq = Dm + NQ * C::ND;
@@ -75,19 +76,19 @@ namespace adaflo_hip
     const long c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
     const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
     const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
-    const int  nx = S * ncx + 1, ny = S * ncy + 1, nz = S * ncz + 1;
+    const int  nx = S * ncx + 1, ny = S * ncy + 1, nz = ZF ? 1 : S * ncz + 1;
     const int  comp = blockIdx.y; // LS_NORMAL: one scalar block per component
     const double *src = a.src + (size_t)comp * a.n_nodes;
     double       *dst = a.dst + (size_t)comp * a.n_nodes;
 
-    gather_cell<S, 1, NT, true>(src, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+    gather_cell<S, 1, NT, true, ZF>(src, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
     __syncthreads();
     SF::template evaluate<true, true>(Sm, Dm, ul, val, grad, grad + NQ3, grad + 2 * NQ3, tmp);
 
     const LSDev &P     = a.ls;
     const double ih[3] = {1. / a.brick.h[0], 1. / a.brick.h[1], 1. / a.brick.h[2]};
     const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
-    const double hcell = fmax(a.brick.h[0], fmax(a.brick.h[1], a.brick.h[2])); // util.h:47-120
+    const double hcell = (ZF ? fmax(a.brick.h[0], a.brick.h[1]) : fmax(a.brick.h[0], fmax(a.brick.h[1], a.brick.h[2]))); // util.h:47-120
     // level_set_okz_reinitialization.cc:65-67,:82-85
     const double dtau_inv  = fmax(0.95 / (1. / 9. * P.minimal_edge_length / S), 1. / (5. * P.time_step));
     const double diffusion = fmax(P.epsilon_used, hcell / (double)S);
@@ -99,7 +100,7 @@ namespace adaflo_hip
     for (int q = tid; q < NQ3; q += NT)
       {
         const int    qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
-        const double jxw = det * wq[qx] * wq[qy] * wq[qz];
+        const double jxw = det * wq[qx] * wq[qy] * (ZF ? 1. : wq[qz]);
         const double v   = val[q];
         double       g[3];
         for (int e = 0; e < 3; ++e)
@@ -139,7 +140,7 @@ namespace adaflo_hip
       }
     __syncthreads();
     SF::template integrate<true, true>(Sm, Dm, val, grad, grad + NQ3, grad + 2 * NQ3, ul, tmp);
-    scatter_cell<S, 1, NT>(dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+    scatter_cell<S, 1, NT, ZF>(dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
   }
 
   // ------------------------------------------------------------------ right-hand sides
@@ -150,11 +151,11 @@ namespace adaflo_hip
     RHS_CURVATURE
   };
 
-  template <int S, int NT>
+  template <int S, int NT, bool ZF = false>
   __global__ __launch_bounds__(NT) void ls_rhs_kernel(const LSArgs a)
   {
-    using C  = LSCell<S>;
-    using SF = SumFac<C::ND, C::NQ, NT>;
+    using C  = LSCell<S, ZF>;
+    using SF = SumFac<C::ND, C::NQ, NT, ZF>;
     constexpr int NQ = C::NQ, NQ3 = C::NQ3, ND3 = C::ND3;
     extern __shared__ double lds[];
     double *Sm = lds, *Dm = Sm + NQ * C::ND, *wq = Dm + NQ * C::ND;
@@ -167,11 +168,11 @@ namespace adaflo_hip
     const long c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
     const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
     const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
-    const int  nx = S * ncx + 1, ny = S * ncy + 1, nz = S * ncz + 1;
+    const int  nx = S * ncx + 1, ny = S * ncy + 1, nz = ZF ? 1 : S * ncz + 1;
     const LSDev &P     = a.ls;
     const double ih[3] = {1. / a.brick.h[0], 1. / a.brick.h[1], 1. / a.brick.h[2]};
     const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
-    const double hcell = fmax(a.brick.h[0], fmax(a.brick.h[1], a.brick.h[2]));
+    const double hcell = (ZF ? fmax(a.brick.h[0], a.brick.h[1]) : fmax(a.brick.h[0], fmax(a.brick.h[1], a.brick.h[2])));
     const double diffusion = fmax(P.epsilon_used, hcell / (double)S);
 
     if (a.mode == RHS_CURVATURE)
@@ -179,7 +180,7 @@ namespace adaflo_hip
         // :229-259: normalise the normal at the DoFs, rhs = (w, -div(n/|n|))
         int nonzero = 0;
         for (int d = 0; d < 3; ++d)
-          gather_cell<S, 1, NT, false>(a.src + (size_t)d * a.n_nodes, nl + d * ND3, cx, cy, cz, nx, ny, nz, 0u);
+          gather_cell<S, 1, NT, false, ZF>(a.src + (size_t)d * a.n_nodes, nl + d * ND3, cx, cy, cz, nx, ny, nz, 0u);
         __syncthreads();
         for (int i = tid; i < ND3; i += NT)
           {
@@ -209,16 +210,16 @@ namespace adaflo_hip
         for (int q = tid; q < NQ3; q += NT)
           {
             const int qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
-            val[q] *= det * wq[qx] * wq[qy] * wq[qz];
+            val[q] *= det * wq[qx] * wq[qy] * (ZF ? 1. : wq[qz]);
           }
         __syncthreads();
         SF::template integrate<true, false>(Sm, Dm, val, nullptr, nullptr, nullptr, ul, tmp);
-        scatter_cell<S, 1, NT>(a.dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+        scatter_cell<S, 1, NT, ZF>(a.dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
         return;
       }
 
     // level-set value and gradient (plain read)
-    gather_cell<S, 1, NT, false>(a.src, ul, cx, cy, cz, nx, ny, nz, 0u);
+    gather_cell<S, 1, NT, false, ZF>(a.src, ul, cx, cy, cz, nx, ny, nz, 0u);
     __syncthreads();
     SF::template evaluate<true, true>(Sm, Dm, ul, val, grad, grad + NQ3, grad + 2 * NQ3, tmp);
 
@@ -230,11 +231,11 @@ namespace adaflo_hip
             for (int q = tid; q < NQ3; q += NT)
               {
                 const int qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
-                grad[d * NQ3 + q] *= ih[d] * det * wq[qx] * wq[qy] * wq[qz];
+                grad[d * NQ3 + q] *= ih[d] * det * wq[qx] * wq[qy] * (ZF ? 1. : wq[qz]);
               }
             __syncthreads();
             SF::template integrate<true, false>(Sm, Dm, grad + d * NQ3, nullptr, nullptr, nullptr, ul, tmp);
-            scatter_cell<S, 1, NT>(a.dst + (size_t)d * a.n_nodes, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+            scatter_cell<S, 1, NT, ZF>(a.dst + (size_t)d * a.n_nodes, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
             __syncthreads();
           }
         return;
@@ -247,7 +248,7 @@ namespace adaflo_hip
       {
         for (int d = 0; d < 3; ++d)
           {
-            gather_cell<S, 1, NT, false>(a.src2 + (size_t)d * a.n_nodes, ul, cx, cy, cz, nx, ny, nz, 0u);
+            gather_cell<S, 1, NT, false, ZF>(a.src2 + (size_t)d * a.n_nodes, ul, cx, cy, cz, nx, ny, nz, 0u);
             __syncthreads();
             SF::template evaluate<true, false>(Sm, Dm, ul, nl + d * NQ3, nullptr, nullptr, nullptr, tmp);
           }
@@ -255,7 +256,7 @@ namespace adaflo_hip
     for (int q = tid; q < NQ3; q += NT)
       {
         const int    qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
-        const double jxw = det * wq[qx] * wq[qy] * wq[qz];
+        const double jxw = det * wq[qx] * wq[qy] * (ZF ? 1. : wq[qz]);
         double       g[3];
         for (int e = 0; e < 3; ++e)
           g[e] = grad[e * NQ3 + q] * ih[e];
@@ -291,17 +292,17 @@ namespace adaflo_hip
       }
     __syncthreads();
     SF::template integrate<false, true>(Sm, Dm, nullptr, grad, grad + NQ3, grad + 2 * NQ3, ul, tmp);
-    scatter_cell<S, 1, NT>(a.dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+    scatter_cell<S, 1, NT, ZF>(a.dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
   }
 
   // advection right-hand side :288-397 (velocity of degree KU evaluated at the LS quadrature)
-  template <int S, int KU, int NT>
+  template <int S, int KU, int NT, bool ZF = false>
   __global__ __launch_bounds__(NT) void ls_advect_rhs_kernel(const LSArgs a)
   {
-    using C   = LSCell<S>;
-    using SF  = SumFac<C::ND, C::NQ, NT>;
-    using SFV = SumFac<KU + 1, C::NQ, NT>;
-    constexpr int NQ = C::NQ, NQ3 = C::NQ3, ND3 = C::ND3, NDV3 = (KU + 1) * (KU + 1) * (KU + 1);
+    using C   = LSCell<S, ZF>;
+    using SF  = SumFac<C::ND, C::NQ, NT, ZF>;
+    using SFV = SumFac<KU + 1, C::NQ, NT, ZF>;
+    constexpr int NQ = C::NQ, NQ3 = C::NQ3, ND3 = C::ND3, NDV3 = (KU + 1) * (KU + 1) * (ZF ? 1 : KU + 1);
     constexpr int TMPX = SF::TMP > SFV::TMP ? SF::TMP : SFV::TMP;
     extern __shared__ double lds[];
     double *Sm = lds, *Dm = Sm + NQ * C::ND, *wq = Dm + NQ * C::ND;
@@ -317,17 +318,17 @@ namespace adaflo_hip
     const long c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
     const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
     const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
-    const int  nx = S * ncx + 1, ny = S * ncy + 1, nz = S * ncz + 1;
-    const int  vx = KU * ncx + 1, vy = KU * ncy + 1, vz = KU * ncz + 1;
+    const int  nx = S * ncx + 1, ny = S * ncy + 1, nz = ZF ? 1 : S * ncz + 1;
+    const int  vx = KU * ncx + 1, vy = KU * ncy + 1, vz = ZF ? 1 : KU * ncz + 1;
     const LSDev &P     = a.ls;
     const double ih[3] = {1. / a.brick.h[0], 1. / a.brick.h[1], 1. / a.brick.h[2]};
     const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
 
     // old level-set values
-    gather_cell<S, 1, NT, false>(a.src2, ul, cx, cy, cz, nx, ny, nz, 0u);
+    gather_cell<S, 1, NT, false, ZF>(a.src2, ul, cx, cy, cz, nx, ny, nz, 0u);
     __syncthreads();
     SF::template evaluate<true, false>(Sm, Dm, ul, vo, nullptr, nullptr, nullptr, tmp);
-    gather_cell<S, 1, NT, false>(a.src3, ul, cx, cy, cz, nx, ny, nz, 0u);
+    gather_cell<S, 1, NT, false, ZF>(a.src3, ul, cx, cy, cz, nx, ny, nz, 0u);
     __syncthreads();
     SF::template evaluate<true, false>(Sm, Dm, ul, voo, nullptr, nullptr, nullptr, tmp);
     double nu_cell = 0.;
@@ -335,8 +336,8 @@ namespace adaflo_hip
       {
         // :344-369: residual of the concentration equation with the two old states; interpolation
         // is linear, so u_old + u_old_old and grad(phi_old + phi_old_old) come from nodal sums
-        gather_cell<KU, 3, NT, false>(a.vel_sum, vl, cx, cy, cz, vx, vy, vz, 0u);
-        gather_cell<S, 1, NT, false>(a.ls_sum, ul, cx, cy, cz, nx, ny, nz, 0u);
+        gather_cell<KU, 3, NT, false, ZF>(a.vel_sum, vl, cx, cy, cz, vx, vy, vz, 0u);
+        gather_cell<S, 1, NT, false, ZF>(a.ls_sum, ul, cx, cy, cz, nx, ny, nz, 0u);
         __syncthreads();
         for (int d = 0; d < 3; ++d)
           SFV::template evaluate<true, false>(Sv, Sv, vl + d * NDV3, vq + d * NQ3, nullptr, nullptr, nullptr, tmp);
@@ -363,19 +364,19 @@ namespace adaflo_hip
             max_res = fmax(max_res, red[o]);
             max_vel = fmax(max_vel, red[NT + o]);
           }
-        const double hcell = fmax(a.brick.h[0], fmax(a.brick.h[1], a.brick.h[2]));
+        const double hcell = (ZF ? fmax(a.brick.h[0], a.brick.h[1]) : fmax(a.brick.h[0], fmax(a.brick.h[1], a.brick.h[2])));
         nu_cell            = 0.03 * max_vel * hcell * fmin(1., max_res / a.global_scaling);
         if (tid == 0)
           a.art_visc[c] = nu_cell;
         __syncthreads();
       }
     // velocity values at the LS quadrature points
-    gather_cell<KU, 3, NT, false>(a.vel, vl, cx, cy, cz, vx, vy, vz, 0u);
+    gather_cell<KU, 3, NT, false, ZF>(a.vel, vl, cx, cy, cz, vx, vy, vz, 0u);
     __syncthreads();
     for (int d = 0; d < 3; ++d)
       SFV::template evaluate<true, false>(Sv, Sv, vl + d * NDV3, vq + d * NQ3, nullptr, nullptr, nullptr, tmp);
     // current level set
-    gather_cell<S, 1, NT, false>(a.src, ul, cx, cy, cz, nx, ny, nz, 0u);
+    gather_cell<S, 1, NT, false, ZF>(a.src, ul, cx, cy, cz, nx, ny, nz, 0u);
     __syncthreads();
     SF::template evaluate<true, true>(Sm, Dm, ul, val, grad, grad + NQ3, grad + 2 * NQ3, tmp);
 
@@ -383,7 +384,7 @@ namespace adaflo_hip
     for (int q = tid; q < NQ3; q += NT)
       {
         const int    qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
-        const double jxw = det * wq[qx] * wq[qy] * wq[qz];
+        const double jxw = det * wq[qx] * wq[qy] * (ZF ? 1. : wq[qz]);
         double old_value = P.weight_old * vo[q];
         if (a.flag) // bdf_2 && step_no > 1  :375-378
           old_value += P.weight_old_old * voo[q];
@@ -404,7 +405,7 @@ namespace adaflo_hip
       SF::template integrate<true, true>(Sm, Dm, val, grad, grad + NQ3, grad + 2 * NQ3, ul, tmp);
     else
       SF::template integrate<true, false>(Sm, Dm, val, nullptr, nullptr, nullptr, ul, tmp);
-    scatter_cell<S, 1, NT>(a.dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+    scatter_cell<S, 1, NT, ZF>(a.dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
   }
 
   // boundary part of the stabilisation (:419-472 operator, bsign = -1; :569-617 rhs, bsign = +1):
@@ -539,11 +540,13 @@ namespace adaflo_hip
   }
 
   // ------------------------------------------------------------------ launchers
-  template <int S>
+  template <int S, bool ZF = false>
   static int launch_ls_s(adaflo_ctx *ctx, const int kind, LSArgs &a, const int ncomp_blocks)
   {
     constexpr int NT = S >= 3 ? 256 : 64;
-    constexpr int NQ3 = 8 * S * S * S, ND3 = (S + 1) * (S + 1) * (S + 1);
+    constexpr int NQ3 = 4 * S * S * (ZF ? 1 : 2 * S), ND3 = (S + 1) * (S + 1) * (ZF ? 1 : S + 1);
+    if (ZF && kind == 3)
+      return ADAFLO_EUNSUPPORTED; // (the boundary term of the convection stabilisation: dim = 3 only)
     const dim3    block(NT);
     hipError_t    err = hipSuccess;
     // one launch per colour of the cells (no atomics in the scatter, fe_kernels.hpp)
@@ -556,19 +559,19 @@ namespace adaflo_hip
     const dim3 grid((unsigned)n_colour, (unsigned)ncomp_blocks);
     if (kind == 0)
       {
-        const size_t lds = sizeof(double) * ls_lds_doubles<S, NT>(0);
+        const size_t lds = sizeof(double) * ls_lds_doubles<S, NT, ZF>(0);
         if (lds > 64 * 1024)
-          err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_vmult_kernel<S, NT>),
+          err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_vmult_kernel<S, NT, ZF>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((ls_vmult_kernel<S, NT>), grid, block, lds, ctx->stream, a);
+        hipLaunchKernelGGL((ls_vmult_kernel<S, NT, ZF>), grid, block, lds, ctx->stream, a);
       }
     else if (kind == 1)
       {
-        const size_t lds = sizeof(double) * ls_lds_doubles<S, NT>(3 * (NQ3 > ND3 ? NQ3 : ND3));
+        const size_t lds = sizeof(double) * ls_lds_doubles<S, NT, ZF>(3 * (NQ3 > ND3 ? NQ3 : ND3));
         if (lds > 64 * 1024)
-          err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_rhs_kernel<S, NT>),
+          err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_rhs_kernel<S, NT, ZF>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((ls_rhs_kernel<S, NT>), grid, block, lds, ctx->stream, a);
+        hipLaunchKernelGGL((ls_rhs_kernel<S, NT, ZF>), grid, block, lds, ctx->stream, a);
       }
     else if (kind == 3)
       {
@@ -579,14 +582,14 @@ namespace adaflo_hip
       {
 #define ADV(KU)                                                                                      \
   {                                                                                                  \
-    constexpr int    NDV3 = (KU + 1) * (KU + 1) * (KU + 1);                                          \
-    constexpr size_t tmpv = SumFac<KU + 1, 2 * S, NT>::TMP, tmps = SumFac<S + 1, 2 * S, NT>::TMP;    \
-    const size_t     lds  = sizeof(double) * (ls_lds_doubles<S, NT>(0) + (tmpv > tmps ? tmpv - tmps : 0) + \
+    constexpr int    NDV3 = (KU + 1) * (KU + 1) * (ZF ? 1 : KU + 1);                                          \
+    constexpr size_t tmpv = SumFac<KU + 1, 2 * S, NT, ZF>::TMP, tmps = SumFac<S + 1, 2 * S, NT, ZF>::TMP;    \
+    const size_t     lds  = sizeof(double) * (ls_lds_doubles<S, NT, ZF>(0) + (tmpv > tmps ? tmpv - tmps : 0) + \
                                          2 * S * (KU + 1) + 3 * NDV3 + 5 * NQ3 + 2 * NT);             \
     if (lds > 64 * 1024)                                                                             \
-      err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_advect_rhs_kernel<S, KU, NT>),    \
+      err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ls_advect_rhs_kernel<S, KU, NT, ZF>),    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
-    hipLaunchKernelGGL((ls_advect_rhs_kernel<S, KU, NT>), grid, block, lds, ctx->stream, a);         \
+    hipLaunchKernelGGL((ls_advect_rhs_kernel<S, KU, NT, ZF>), grid, block, lds, ctx->stream, a);         \
   }
         switch (ctx->k)
           {
@@ -665,6 +668,20 @@ namespace adaflo_hip
     a.n_nodes = ctx->n_nodes_ls;
     a.mode    = mode;
     a.flag    = flag;
+    if (ctx->flat)
+      switch (ctx->s)
+        {
+          case 1:
+            return launch_ls_s<1, true>(ctx, kind, a, ncomp_blocks);
+          case 2:
+            return launch_ls_s<2, true>(ctx, kind, a, ncomp_blocks);
+          case 3:
+            return launch_ls_s<3, true>(ctx, kind, a, ncomp_blocks);
+          case 4:
+            return launch_ls_s<4, true>(ctx, kind, a, ncomp_blocks);
+          default:
+            return ADAFLO_EUNSUPPORTED;
+        }
     switch (ctx->s)
       {
         case 1:
@@ -687,7 +704,7 @@ namespace adaflo_hip
     if (!ctx->d_ls_diag)
       return ADAFLO_ENOTINIT;
     const int nx = ctx->s * ctx->desc.ncell[0] + 1, ny = ctx->s * ctx->desc.ncell[1] + 1,
-              nz = ctx->s * ctx->desc.ncell[2] + 1;
+              nz = ctx->flat ? 1 : ctx->s * ctx->desc.ncell[2] + 1;
     long nb = (ctx->n_nodes_ls + 255) / 256;
     if (nb > 4096)
       nb = 4096;

@@ -208,7 +208,7 @@ namespace adaflo_hip
 
   bool divergence_stencil_supported(const adaflo_ctx *ctx)
   {
-    return ctx->k == 2;
+    return ctx->k == 2 && !ctx->flat;
   }
 
   // dst_p += weight (q, div u) on the free pressure rows; `plain`: velocity read without resolving constraints

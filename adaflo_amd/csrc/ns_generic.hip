@@ -10,11 +10,12 @@
 
 namespace adaflo_hip
 {
-  template <int K>
+  // ZF: flat third direction (dim = 2), see SumFac in fe_kernels.hpp
+  template <int K, bool ZF = false>
   struct NSLayout
   {
     static constexpr int NDU = K + 1, NDP = K, NQ = K + 1;
-    static constexpr int NDU3 = NDU * NDU * NDU, NDP3 = NDP * NDP * NDP, NQ3 = NQ * NQ * NQ;
+    static constexpr int NDU3 = NDU * NDU * (ZF ? 1 : NDU), NDP3 = NDP * NDP * (ZF ? 1 : NDP), NQ3 = NQ * NQ * (ZF ? 1 : NQ);
     static constexpr int TAB = 2 * NQ * NDU + 2 * NQ * NDP + NQ;
     static constexpr int TABP = (TAB + 1) & ~1;
     // Q2: the three velocity components go through the sum factorisation together (a third of the
@@ -32,25 +33,25 @@ namespace adaflo_hip
     static constexpr bool REGQ = K >= 3;
   };
 
-  template <int K, int NT>
+  template <int K, int NT, bool ZF = false>
   constexpr size_t ns_lds_doubles(const bool residual)
   {
-    using L = NSLayout<K>;
+    using L = NSLayout<K, ZF>;
     if (L::REGQ || residual)
-      return L::TABP + 3 * L::NDU3 + L::NDP3 + 4 * L::NQ3 + SumFac<L::NDU, L::NQ, NT>::TMP;
+      return L::TABP + 3 * L::NDU3 + L::NDP3 + 4 * L::NQ3 + SumFac<L::NDU, L::NQ, NT, ZF>::TMP;
     size_t n = L::TABP + 3 * L::NDU3 + L::NDP3 + 3 * L::NQ3 + 9 * L::NQ3 + L::NQ3 +
-               NSLayout<K>::NBATCH * SumFac<L::NDU, L::NQ, NT>::TMP;
+               L::NBATCH * SumFac<L::NDU, L::NQ, NT, ZF>::TMP;
     if (residual)
       n += 2 * (3 * L::NQ3 + 9 * L::NQ3);
     return n;
   }
 
-  template <int K, int OP, int NT>
+  template <int K, int OP, int NT, bool ZF = false>
   __global__ __launch_bounds__(NT) void ns_cell_kernel(const NSArgs a)
   {
-    using L   = NSLayout<K>;
-    using SFU = SumFac<L::NDU, L::NQ, NT>;
-    using SFP = SumFac<L::NDP, L::NQ, NT>;
+    using L   = NSLayout<K, ZF>;
+    using SFU = SumFac<L::NDU, L::NQ, NT, ZF>;
+    using SFP = SumFac<L::NDP, L::NQ, NT, ZF>;
     constexpr int NQ = L::NQ, NQ3 = L::NQ3, NDU3 = L::NDU3, NDP3 = L::NDP3;
     constexpr bool RES = OP == OP_RESIDUAL;
 
@@ -89,15 +90,15 @@ namespace adaflo_hip
     const long c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
     const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
     const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
-    const int  nux = K * ncx + 1, nuy = K * ncy + 1, nuz = K * ncz + 1;
-    const int  npx = (K - 1) * ncx + 1, npy = (K - 1) * ncy + 1, npz = (K - 1) * ncz + 1;
+    const int  nux = K * ncx + 1, nuy = K * ncy + 1, nuz = ZF ? 1 : K * ncz + 1;
+    const int  npx = (K - 1) * ncx + 1, npy = (K - 1) * ncy + 1, npz = ZF ? 1 : (K - 1) * ncz + 1;
 
     const NSDev &P = a.ns;
 
     // :662-667 velocity: plain read for the residual, constraints resolved otherwise
-    gather_cell<K, 3, NT, !RES>(a.src_u, ul, cx, cy, cz, nux, nuy, nuz, a.brick.con_u);
+    gather_cell<K, 3, NT, !RES, ZF>(a.src_u, ul, cx, cy, cz, nux, nuy, nuz, a.brick.con_u);
     if (OP != OP_VMULT_VELOCITY)
-      gather_cell<K - 1, 1, NT, !RES>(a.src_p, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
+      gather_cell<K - 1, 1, NT, !RES, ZF>(a.src_p, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
     __syncthreads();
 
     // :668-671
@@ -120,13 +121,13 @@ namespace adaflo_hip
     // :673-686 old solutions for the residual
     if (RES && P.physical_type == ADAFLO_INCOMPRESSIBLE)
       {
-        gather_cell<K, 3, NT, false>(a.old_u, ul, cx, cy, cz, nux, nuy, nuz, 0u);
+        gather_cell<K, 3, NT, false, ZF>(a.old_u, ul, cx, cy, cz, nux, nuy, nuz, 0u);
         __syncthreads();
         if constexpr (REGQ)
           evaluate_u_reg(ul, rvo, rgo);
         else
           evaluate_u(ul, vo, go);
-        gather_cell<K, 3, NT, false>(a.oldold_u, ul, cx, cy, cz, nux, nuy, nuz, 0u);
+        gather_cell<K, 3, NT, false, ZF>(a.oldold_u, ul, cx, cy, cz, nux, nuy, nuz, 0u);
         __syncthreads();
         if constexpr (REGQ)
           evaluate_u_reg(ul, rvoo, rgoo);
@@ -149,7 +150,7 @@ namespace adaflo_hip
     for (int q = tid; q < NQ3; q += NT)
       {
         const int    qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
-        const double jxw = det * wq[qx] * wq[qy] * wq[qz];
+        const double jxw = det * wq[qx] * wq[qy] * (ZF ? 1. : wq[qz]);
         double       g[3][3], val[3], conv[3] = {0., 0., 0.};
         for (int d = 0; d < 3; ++d)
           {
@@ -315,7 +316,7 @@ namespace adaflo_hip
       for (int d = 0; d < 3; ++d)
         SFU::template integrate<true, true>(S_u, D_u, vu + d * NQ3, gu + (3 * d + 0) * NQ3, gu + (3 * d + 1) * NQ3,
                                             gu + (3 * d + 2) * NQ3, ul + d * NDU3, tmp);
-    scatter_cell<K, 3, NT>(a.dst_u, ul, cx, cy, cz, nux, nuy, nuz, a.brick.con_u);
+    scatter_cell<K, 3, NT, ZF>(a.dst_u, ul, cx, cy, cz, nux, nuy, nuz, a.brick.con_u);
     if (OP != OP_VMULT_VELOCITY && P.linearization != ADAFLO_PROJECTION)
       {
         if constexpr (REGQ)
@@ -327,28 +328,28 @@ namespace adaflo_hip
           }
         else
           SFP::template integrate<true, false>(S_p, D_p, vp, nullptr, nullptr, nullptr, pl, tmp);
-        scatter_cell<K - 1, 1, NT>(a.dst_p, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
+        scatter_cell<K - 1, 1, NT, ZF>(a.dst_p, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
       }
   }
 
-  template <int K, int NT>
+  template <int K, int NT, bool ZF>
   static int launch_k(adaflo_ctx *ctx, const int op, const NSArgs &args)
   {
     const dim3   block(NT);
-    const size_t lds = sizeof(double) * ns_lds_doubles<K, NT>(op == OP_RESIDUAL);
+    const size_t lds = sizeof(double) * ns_lds_doubles<K, NT, ZF>(op == OP_RESIDUAL);
     hipError_t   err = hipSuccess;
     NSArgs       a   = args;
     // one launch per colour of the cells (no atomics in the scatter, fe_kernels.hpp)
 #define LAUNCH(OPV)                                                                              \
   {                                                                                              \
     if (lds > 64 * 1024)                                                                         \
-      err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_cell_kernel<K, OPV, NT>),     \
+      err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_cell_kernel<K, OPV, NT, ZF>),     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
     for (int colour = 0; colour < 8 && err == hipSuccess; ++colour)                              \
       if (const long nc = n_cells_of_colour(a.brick.ncell, colour))                              \
         {                                                                                        \
           a.brick.colour = colour;                                                               \
-          hipLaunchKernelGGL((ns_cell_kernel<K, OPV, NT>), dim3((unsigned)nc), block, lds, ctx->stream, a); \
+          hipLaunchKernelGGL((ns_cell_kernel<K, OPV, NT, ZF>), dim3((unsigned)nc), block, lds, ctx->stream, a); \
         }                                                                                        \
   }
     switch (op)
@@ -376,26 +377,39 @@ namespace adaflo_hip
     hipEvent_t stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
     int        rc;
     // EXPAND_OPERATIONS, source/navier_stokes_matrix.cc:64-82 (degree_p = k-1)
-    switch (ctx->k)
-      {
-        case 2:
-          rc = launch_k<2, 64>(ctx, op, args);
-          break;
-        case 3:
-          rc = launch_k<3, 64>(ctx, op, args);
-          break;
-        case 4:
-          rc = launch_k<4, 128>(ctx, op, args);
-          break;
-        case 5:
-          rc = launch_k<5, 256>(ctx, op, args);
-          break;
-        case 6: // degree_p = 5, the last instance of EXPAND_OPERATIONS (:80-81): 343 quadrature points per cell
-          rc = launch_k<6, 384>(ctx, op, args);
-          break;
-        default:
-          rc = ADAFLO_EUNSUPPORTED;
-      }
+    if (ctx->flat) // dim = 2 (degrees of the reference's 2D tests: Q2/Q1 and Q3/Q2)
+      switch (ctx->k)
+        {
+          case 2:
+            rc = launch_k<2, 64, true>(ctx, op, args);
+            break;
+          case 3:
+            rc = launch_k<3, 64, true>(ctx, op, args);
+            break;
+          default:
+            rc = ADAFLO_EUNSUPPORTED;
+        }
+    else
+      switch (ctx->k)
+        {
+          case 2:
+            rc = launch_k<2, 64, false>(ctx, op, args);
+            break;
+          case 3:
+            rc = launch_k<3, 64, false>(ctx, op, args);
+            break;
+          case 4:
+            rc = launch_k<4, 128, false>(ctx, op, args);
+            break;
+          case 5:
+            rc = launch_k<5, 256, false>(ctx, op, args);
+            break;
+          case 6: // degree_p = 5, the last instance of EXPAND_OPERATIONS (:80-81): 343 quadrature points per cell
+            rc = launch_k<6, 384, false>(ctx, op, args);
+            break;
+          default:
+            rc = ADAFLO_EUNSUPPORTED;
+        }
     if (stop)
       (void)hipEventRecord(stop, ctx->stream);
     ctx->kernel_timer.count++;
@@ -416,10 +430,10 @@ namespace adaflo_hip
   //          = beta ldiv v + lu . grad                                     (convection frozen)
   // One thread per node of the cell, the cell's coefficients staged in LDS; 27^2 x ~40 flops per Q2 cell
   // instead of the 81 operator applications of the coloured probing (krylov.hip).
-  template <int K, int NT>
+  template <int K, int NT, bool ZF = false>
   __global__ __launch_bounds__(NT) void ns_velocity_diagonal_kernel(const NSArgs a, double *__restrict__ diag)
   {
-    using L = NSLayout<K>;
+    using L = NSLayout<K, ZF>;
     constexpr int NQ = L::NQ, NQ3 = L::NQ3, ND = L::NDU, ND3 = L::NDU3, NCF = NLIN + 3;
     extern __shared__ double lds[];
     const double *S_u = lds, *D_u = S_u + NQ * ND, *wq = D_u + NQ * ND + 2 * NQ * L::NDP;
@@ -430,7 +444,7 @@ namespace adaflo_hip
     const long   c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
     const int    ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
     const int    cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
-    const int    nux = K * ncx + 1, nuy = K * ncy + 1, nuz = K * ncz + 1;
+    const int    nux = K * ncx + 1, nuy = K * ncy + 1, nuz = ZF ? 1 : K * ncz + 1;
     const NSDev &P = a.ns;
     const bool   stokes = P.physical_type == ADAFLO_STOKES;
     const bool   newton = P.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON;
@@ -457,12 +471,13 @@ namespace adaflo_hip
       {
         const int i = l % ND, j = (l / ND) % ND, k = l / (ND * ND);
         double    d[3] = {0., 0., 0.};
-        for (int qz = 0; qz < NQ; ++qz)
+        for (int qz = 0; qz < (ZF ? 1 : NQ); ++qz)
           for (int qy = 0; qy < NQ; ++qy)
             {
-              const double syz = S_u[qy * ND + j] * S_u[qz * ND + k];
-              const double gy_ = D_u[qy * ND + j] * S_u[qz * ND + k] * ih[1], gz_ = S_u[qy * ND + j] * D_u[qz * ND + k] * ih[2];
-              const double wyz = det * wq[qy] * wq[qz];
+              const double sz_ = ZF ? 1. : S_u[qz * ND + k], dz_ = ZF ? 0. : D_u[qz * ND + k];
+              const double syz = S_u[qy * ND + j] * sz_;
+              const double gy_ = D_u[qy * ND + j] * sz_ * ih[1], gz_ = S_u[qy * ND + j] * dz_ * ih[2];
+              const double wyz = det * wq[qy] * (ZF ? 1. : wq[qz]);
 #pragma unroll
               for (int qx = 0; qx < NQ; ++qx)
                 {
@@ -507,17 +522,17 @@ namespace adaflo_hip
       }
   }
 
-  template <int K, int NT>
+  template <int K, int NT, bool ZF = false>
   static int launch_diag(adaflo_ctx *ctx, const NSArgs &args, double *diag)
   {
-    using L          = NSLayout<K>;
+    using L          = NSLayout<K, ZF>;
     const size_t lds = sizeof(double) * (L::TABP + (NLIN + 3) * L::NQ3);
     NSArgs       a   = args;
     for (int colour = 0; colour < 8; ++colour) // (cells of one colour share no node: plain adds)
       if (const long nc = n_cells_of_colour(a.brick.ncell, colour))
         {
           a.brick.colour = colour;
-          hipLaunchKernelGGL((ns_velocity_diagonal_kernel<K, NT>), dim3((unsigned)nc), dim3(NT), lds, ctx->stream, a, diag);
+          hipLaunchKernelGGL((ns_velocity_diagonal_kernel<K, NT, ZF>), dim3((unsigned)nc), dim3(NT), lds, ctx->stream, a, diag);
         }
     return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
   }
@@ -525,6 +540,9 @@ namespace adaflo_hip
   // diag must be zero on entry (constrained rows stay zero)
   int launch_ns_velocity_diagonal(adaflo_ctx *ctx, const NSArgs &args, double *diag)
   {
+    if (ctx->flat)
+      return ctx->k == 2 ? launch_diag<2, 64, true>(ctx, args, diag) :
+                           (ctx->k == 3 ? launch_diag<3, 64, true>(ctx, args, diag) : ADAFLO_EUNSUPPORTED);
     switch (ctx->k)
       {
         case 2:
@@ -545,29 +563,29 @@ namespace adaflo_hip
   // ------------------------------------------------------------------------
   // scalar sub-block kernels
   // ------------------------------------------------------------------------
-  template <int K, bool QU>
+  template <int K, bool QU, bool ZF = false>
   struct ScLayout
   {
     static constexpr int NDU = K + 1, NDP = K, NQ = QU ? K + 1 : K;
-    static constexpr int NDU3 = NDU * NDU * NDU, NDP3 = NDP * NDP * NDP, NQ3 = NQ * NQ * NQ;
+    static constexpr int NDU3 = NDU * NDU * (ZF ? 1 : NDU), NDP3 = NDP * NDP * (ZF ? 1 : NDP), NQ3 = NQ * NQ * (ZF ? 1 : NQ);
   };
 
-  template <int K, bool QU, int NT>
+  template <int K, bool QU, int NT, bool ZF = false>
   constexpr size_t sc_lds_doubles()
   {
-    using L = ScLayout<K, QU>;
+    using L = ScLayout<K, QU, ZF>;
     return NSLayout<K>::TABP + 3 * L::NDU3 + L::NDP3 + 9 * L::NQ3 + 4 * L::NQ3 +
-           SumFac<L::NDU, L::NQ, NT>::TMP;
+           SumFac<L::NDU, L::NQ, NT, ZF>::TMP;
   }
 
   // QU: quadrature = quad_index_u (k+1 points, table layout of NSLayout) else
   // quad_index_p (k points, table [S_pp D_pp w_pp])
-  template <int K, bool QU, int NT>
+  template <int K, bool QU, int NT, bool ZF = false>
   __global__ __launch_bounds__(NT) void ns_scalar_kernel(const ScalarArgs a)
   {
-    using L   = ScLayout<K, QU>;
-    using SFU = SumFac<L::NDU, L::NQ, NT>;
-    using SFP = SumFac<L::NDP, L::NQ, NT>;
+    using L   = ScLayout<K, QU, ZF>;
+    using SFU = SumFac<L::NDU, L::NQ, NT, ZF>;
+    using SFP = SumFac<L::NDP, L::NQ, NT, ZF>;
     constexpr int NQ = L::NQ, NQ3 = L::NQ3, NDU3 = L::NDU3, NDP3 = L::NDP3;
 
     extern __shared__ double lds[];
@@ -584,8 +602,8 @@ namespace adaflo_hip
     const long c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
     const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
     const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
-    const int  nux = K * ncx + 1, nuy = K * ncy + 1, nuz = K * ncz + 1;
-    const int  npx = (K - 1) * ncx + 1, npy = (K - 1) * ncy + 1, npz = (K - 1) * ncz + 1;
+    const int  nux = K * ncx + 1, nuy = K * ncy + 1, nuz = ZF ? 1 : K * ncz + 1;
+    const int  npx = (K - 1) * ncx + 1, npy = (K - 1) * ncy + 1, npz = ZF ? 1 : (K - 1) * ncz + 1;
     const NSDev &P = a.ns;
     const double ih[3] = {1. / a.brick.h[0], 1. / a.brick.h[1], 1. / a.brick.h[2]};
     const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
@@ -595,9 +613,9 @@ namespace adaflo_hip
       {
         // :935-939: plain read for the projection scheme
         if (P.linearization == ADAFLO_PROJECTION)
-          gather_cell<K, 3, NT, false>(a.src, ul, cx, cy, cz, nux, nuy, nuz, 0u);
+          gather_cell<K, 3, NT, false, ZF>(a.src, ul, cx, cy, cz, nux, nuy, nuz, 0u);
         else
-          gather_cell<K, 3, NT, true>(a.src, ul, cx, cy, cz, nux, nuy, nuz, a.brick.con_u);
+          gather_cell<K, 3, NT, true, ZF>(a.src, ul, cx, cy, cz, nux, nuy, nuz, a.brick.con_u);
         __syncthreads();
         if (QU)
           for (int d = 0; d < 3; ++d)
@@ -607,7 +625,7 @@ namespace adaflo_hip
         for (int q = tid; q < NQ3; q += NT)
           {
             const int    qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
-            const double jxw = det * wq[qx] * wq[qy] * wq[qz];
+            const double jxw = det * wq[qx] * wq[qy] * (ZF ? 1. : wq[qz]);
             const double div = gu[0 * NQ3 + q] * ih[0] + gu[4 * NQ3 + q] * ih[1] + gu[8 * NQ3 + q] * ih[2];
             const double w   = mode == SC_DIVERGENCE_VISC ?
                                  (a.coef_q ? -a.coef_q[(size_t)c * NQ3 + q] : -P.viscosity) :
@@ -616,7 +634,7 @@ namespace adaflo_hip
           }
         __syncthreads();
         SFP::template integrate<true, false>(S_p, D_p, vp, nullptr, nullptr, nullptr, pl, tmp);
-        scatter_cell<K - 1, 1, NT>(a.dst, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
+        scatter_cell<K - 1, 1, NT, ZF>(a.dst, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
         return;
       }
 
@@ -627,7 +645,7 @@ namespace adaflo_hip
       __syncthreads(); // the 1D tables staged above are read across waves below (k = 5: 125 points, 4 waves)
     else
       {
-        gather_cell<K - 1, 1, NT, true>(a.src, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
+        gather_cell<K - 1, 1, NT, true, ZF>(a.src, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
         __syncthreads();
         if (need_grad)
           SFP::template evaluate<false, true>(S_p, D_p, pl, nullptr, gp, gp + NQ3, gp + 2 * NQ3, tmp);
@@ -657,7 +675,7 @@ namespace adaflo_hip
     for (int q = tid; q < NQ3; q += NT)
       {
         const int    qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
-        const double jxw = det * wq[qx] * wq[qy] * wq[qz];
+        const double jxw = det * wq[qx] * wq[qy] * (ZF ? 1. : wq[qz]);
         if (mode == SC_MASS_WEIGHT)
           vp[q] = jxw;
         else if (need_val)
@@ -676,10 +694,10 @@ namespace adaflo_hip
       SFP::template integrate<false, true>(S_p, D_p, nullptr, gp, gp + NQ3, gp + 2 * NQ3, pl, tmp);
     else
       SFP::template integrate<true, false>(S_p, D_p, vp, nullptr, nullptr, nullptr, pl, tmp);
-    scatter_cell<K - 1, 1, NT>(a.dst, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
+    scatter_cell<K - 1, 1, NT, ZF>(a.dst, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
   }
 
-  template <int K, int NT>
+  template <int K, int NT, bool ZF = false>
   static int launch_sc(adaflo_ctx *ctx, const ScalarArgs &args)
   {
     const dim3 block(NT);
@@ -689,25 +707,25 @@ namespace adaflo_hip
     hipError_t err = hipSuccess;
     if (qu)
       {
-        const size_t lds = sizeof(double) * sc_lds_doubles<K, true, NT>();
+        const size_t lds = sizeof(double) * sc_lds_doubles<K, true, NT, ZF>();
         if (lds > 64 * 1024)
-          err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_scalar_kernel<K, true, NT>),
+          err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_scalar_kernel<K, true, NT, ZF>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         for (int colour = 0; colour < 8 && err == hipSuccess; ++colour) // (no atomics in the scatter, fe_kernels.hpp)
           if (const long nc = n_cells_of_colour(a.brick.ncell, colour))
             {
               a.brick.colour = colour;
-              hipLaunchKernelGGL((ns_scalar_kernel<K, true, NT>), dim3((unsigned)nc), block, lds, ctx->stream, a);
+              hipLaunchKernelGGL((ns_scalar_kernel<K, true, NT, ZF>), dim3((unsigned)nc), block, lds, ctx->stream, a);
             }
       }
     else
       {
-        const size_t lds = sizeof(double) * sc_lds_doubles<K, false, NT>();
+        const size_t lds = sizeof(double) * sc_lds_doubles<K, false, NT, ZF>();
         for (int colour = 0; colour < 8; ++colour)
           if (const long nc = n_cells_of_colour(a.brick.ncell, colour))
             {
               a.brick.colour = colour;
-              hipLaunchKernelGGL((ns_scalar_kernel<K, false, NT>), dim3((unsigned)nc), block, lds, ctx->stream, a);
+              hipLaunchKernelGGL((ns_scalar_kernel<K, false, NT, ZF>), dim3((unsigned)nc), block, lds, ctx->stream, a);
             }
       }
     if (err == hipSuccess)
@@ -717,6 +735,8 @@ namespace adaflo_hip
 
   int launch_ns_scalar_generic(adaflo_ctx *ctx, const ScalarArgs &args)
   {
+    if (ctx->flat)
+      return ctx->k == 2 ? launch_sc<2, 64, true>(ctx, args) : (ctx->k == 3 ? launch_sc<3, 64, true>(ctx, args) : ADAFLO_EUNSUPPORTED);
     switch (ctx->k)
       {
         case 2:

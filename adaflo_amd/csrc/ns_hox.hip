@@ -289,7 +289,7 @@ namespace adaflo_hip
 
   bool hox_supported(const adaflo_ctx *ctx)
   {
-    return ctx->k >= 3 && ctx->k <= 5 && !ctx->rho.p && !ctx->mu.p && !ctx->damp.p;
+    return ctx->k >= 3 && ctx->k <= 5 && !ctx->flat && !ctx->rho.p && !ctx->mu.p && !ctx->damp.p;
   }
 
   int launch_ns_vmult_hox(adaflo_ctx *ctx, const int op, double *dst_u, double *dst_p, const double *src_u,

@@ -1673,7 +1673,7 @@ namespace adaflo_hip
 
   bool q2_supported(const adaflo_ctx *ctx)
   {
-    if (ctx->k != 2)
+    if (ctx->k != 2 || ctx->flat)
       return false;
     if (!ctx->rho.p && !ctx->mu.p && !ctx->damp.p)
       return true;
@@ -2052,7 +2052,7 @@ namespace adaflo_hip
   // that of the solution itself) and Stokes, constant coefficients
   bool q2_residual_supported(const adaflo_ctx *ctx)
   {
-    if (ctx->k != 2 || ctx->rho.p || ctx->mu.p || ctx->damp.p)
+    if (ctx->k != 2 || ctx->flat || ctx->rho.p || ctx->mu.p || ctx->damp.p)
       return false;
     const NSDev &P = ctx->ns;
     return P.physical_type == ADAFLO_STOKES || P.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON ||
