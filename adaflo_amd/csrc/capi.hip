@@ -388,7 +388,7 @@ int64_t adaflo_n_dofs_u(const adaflo_ctx *ctx) { return ctx ? 3 * ctx->n_nodes_u
 int64_t adaflo_n_dofs_p(const adaflo_ctx *ctx) { return ctx ? ctx->n_nodes_p : 0; }
 int64_t adaflo_n_dofs_ls(const adaflo_ctx *ctx) { return ctx ? ctx->n_nodes_ls : 0; }
 int     adaflo_n_q_points_u(const adaflo_ctx *ctx) { return ctx ? ctx->nq_u : 0; }
-int     adaflo_n_q_points_ls(const adaflo_ctx *ctx) { return ctx ? 8 * ctx->s * ctx->s * ctx->s : 0; }
+int     adaflo_n_q_points_ls(const adaflo_ctx *ctx) { return ctx ? (ctx->flat ? 4 * ctx->s * ctx->s : 8 * ctx->s * ctx->s * ctx->s) : 0; }
 
 int adaflo_malloc(adaflo_ctx *ctx, size_t bytes, void **dptr)
 {
@@ -1133,7 +1133,7 @@ namespace
 
   size_t ls_q_count(const adaflo_ctx *ctx)
   {
-    return (size_t)ctx->n_cells * 3 * 8 * ctx->s * ctx->s * ctx->s;
+    return (size_t)ctx->n_cells * 3 * adaflo_n_q_points_ls(ctx);
   }
 
   int set_q_array(adaflo_ctx *ctx, DeviceBuffer &buf, const double *canonical, const int on_device)
@@ -1148,7 +1148,7 @@ namespace
         HIP_TRY(ctx, hipMemcpyAsync(staging, canonical, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         src = staging;
       }
-    TRY(ctx, launch_transpose_state(ctx, buf.p, src, ctx->n_cells, 8 * ctx->s * ctx->s * ctx->s, 3, true),
+    TRY(ctx, launch_transpose_state(ctx, buf.p, src, ctx->n_cells, adaflo_n_q_points_ls(ctx), 3, true),
         "state re-layout failed");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (staging)
@@ -1167,7 +1167,7 @@ namespace
         HIP_TRY(ctx, hipMalloc(&staging, count * sizeof(double)));
         dst = staging;
       }
-    TRY(ctx, launch_transpose_state(ctx, dst, buf.p, ctx->n_cells, 8 * ctx->s * ctx->s * ctx->s, 3, false),
+    TRY(ctx, launch_transpose_state(ctx, dst, buf.p, ctx->n_cells, adaflo_n_q_points_ls(ctx), 3, false),
         "state re-layout failed");
     if (staging)
       HIP_TRY(ctx, hipMemcpyAsync(canonical, staging, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1271,7 +1271,7 @@ static int ls_vmult(adaflo_ctx *ctx, double *dst, const double *src, const int m
       const double hcell = ctx->flat ? std::max(ctx->desc.h[0], ctx->desc.h[1]) : std::max(ctx->desc.h[0], std::max(ctx->desc.h[1], ctx->desc.h[2]));
       // level_set_okz_reinitialization.cc:65-67,:82-85; compute_normal.cc:107-110;
       // compute_curvature.cc:112-118
-      const double dtau_inv  = std::max(0.95 / (1. / 9. * P.minimal_edge_length / ctx->s), 1. / (5. * P.time_step));
+      const double dtau_inv  = std::max(0.95 / (1. / (ctx->flat ? 4. : 9.) * P.minimal_edge_length / ctx->s), 1. / (5. * P.time_step));
       const double diffusion = std::max(P.epsilon_used, hcell / ctx->s);
       const double b         = std::max(P.epsilon_used / P.epsilon, hcell / ctx->s);
       int          q1mode = Q1_MASS_LAPLACE;

@@ -90,7 +90,7 @@ namespace adaflo_hip
     const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
     const double hcell = (ZF ? fmax(a.brick.h[0], a.brick.h[1]) : fmax(a.brick.h[0], fmax(a.brick.h[1], a.brick.h[2]))); // util.h:47-120
     // level_set_okz_reinitialization.cc:65-67,:82-85
-    const double dtau_inv  = fmax(0.95 / (1. / 9. * P.minimal_edge_length / S), 1. / (5. * P.time_step));
+    const double dtau_inv  = fmax(0.95 / (1. / (ZF ? 4. : 9.) * P.minimal_edge_length / S), 1. / (5. * P.time_step)); // (1 / dim^2)
     const double diffusion = fmax(P.epsilon_used, hcell / (double)S);
     const double b         = fmax(P.epsilon_used / P.epsilon, hcell / (double)S);
     // compute_normal.cc:107-110 (damping_scale_factor = 4), compute_curvature.cc:112-118
@@ -486,30 +486,30 @@ namespace adaflo_hip
   }
 
   // get_maximal_velocity (:39-68): largest |u| on the points of QIterated(QTrapezoid<1>(), k + 1)
-  template <int KU>
+  template <int KU, bool ZF = false>
   __global__ __launch_bounds__(64) void ls_max_velocity_kernel(const double *__restrict__ vel, const double *__restrict__ tab,
                                                                const int ncx, const int ncy, const int ncz,
                                                                unsigned long long *result)
   {
-    constexpr int ND = KU + 1, NP = KU + 2, ND3 = ND * ND * ND, NP3 = NP * NP * NP;
+    constexpr int ND = KU + 1, NP = KU + 2, NDZ = ZF ? 1 : ND, NPZ = ZF ? 1 : NP, ND3 = ND * ND * NDZ, NP3 = NP * NP * NPZ;
     __shared__ double St[NP * ND], vl[3 * ND3], red[64];
     const int  tid = threadIdx.x;
     const long c   = blockIdx.x;
     const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
     for (int o = tid; o < NP * ND; o += 64)
       St[o] = tab[o];
-    gather_cell<KU, 3, 64, false>(vel, vl, cx, cy, cz, KU * ncx + 1, KU * ncy + 1, KU * ncz + 1, 0u);
+    gather_cell<KU, 3, 64, false, ZF>(vel, vl, cx, cy, cz, KU * ncx + 1, KU * ncy + 1, ZF ? 1 : KU * ncz + 1, 0u);
     __syncthreads();
     double best = 0.;
     for (int q = tid; q < NP3; q += 64)
       {
         const int qx = q % NP, qy = (q / NP) % NP, qz = q / (NP * NP);
         double    u[3] = {0., 0., 0.};
-        for (int k = 0; k < ND; ++k)
+        for (int k = 0; k < NDZ; ++k)
           for (int j = 0; j < ND; ++j)
             for (int i = 0; i < ND; ++i)
               {
-                const double w = St[qx * ND + i] * St[qy * ND + j] * St[qz * ND + k];
+                const double w = St[qx * ND + i] * St[qy * ND + j] * (ZF ? 1. : St[qz * ND + k]);
                 for (int e = 0; e < 3; ++e)
                   u[e] += w * vl[e * ND3 + (k * ND + j) * ND + i];
               }
@@ -620,12 +620,20 @@ namespace adaflo_hip
     switch (ctx->k)
       {
         case 2:
-          hipLaunchKernelGGL((ls_max_velocity_kernel<2>), grid, block, 0, ctx->stream, vel, tab, ctx->desc.ncell[0],
-                             ctx->desc.ncell[1], ctx->desc.ncell[2], result);
+          if (ctx->flat)
+            hipLaunchKernelGGL((ls_max_velocity_kernel<2, true>), grid, block, 0, ctx->stream, vel, tab, ctx->desc.ncell[0],
+                               ctx->desc.ncell[1], 1, result);
+          else
+            hipLaunchKernelGGL((ls_max_velocity_kernel<2>), grid, block, 0, ctx->stream, vel, tab, ctx->desc.ncell[0],
+                               ctx->desc.ncell[1], ctx->desc.ncell[2], result);
           break;
         case 3:
-          hipLaunchKernelGGL((ls_max_velocity_kernel<3>), grid, block, 0, ctx->stream, vel, tab, ctx->desc.ncell[0],
-                             ctx->desc.ncell[1], ctx->desc.ncell[2], result);
+          if (ctx->flat)
+            hipLaunchKernelGGL((ls_max_velocity_kernel<3, true>), grid, block, 0, ctx->stream, vel, tab, ctx->desc.ncell[0],
+                               ctx->desc.ncell[1], 1, result);
+          else
+            hipLaunchKernelGGL((ls_max_velocity_kernel<3>), grid, block, 0, ctx->stream, vel, tab, ctx->desc.ncell[0],
+                               ctx->desc.ncell[1], ctx->desc.ncell[2], result);
           break;
         case 4:
           hipLaunchKernelGGL((ls_max_velocity_kernel<4>), grid, block, 0, ctx->stream, vel, tab, ctx->desc.ncell[0],

@@ -48,10 +48,10 @@ class LevelSetOperators:
             self.n_dofs = self._lib.adaflo_n_dofs_ls(self._ctx)
             self.n_q = self._lib.adaflo_n_q_points_ls(self._ctx)
             self.n_cells = self._lib.adaflo_n_cells(self._ctx)
-            self.cell_diameter, self.minimal_edge_length = max(mesh.h), min(mesh.h)
+            self.cell_diameter, self.minimal_edge_length = max(mesh.hd), min(mesh.hd)
             return
         d = _lib.BrickDesc()
-        d.dim = 3
+        d.dim = mesh.dim
         for i in range(3):
             d.ncell[i], d.h[i], d.origin[i] = mesh.ncell[i], mesh.h[i], mesh.lower[i]
         d.velocity_degree, d.ls_degree = velocity_degree, ls_degree
@@ -71,8 +71,8 @@ class LevelSetOperators:
         self.n_q = self._lib.adaflo_n_q_points_ls(ctx)
         self.n_cells = self._lib.adaflo_n_cells(ctx)
         # compute_cell_diameters on a Cartesian mesh, include/adaflo/util.h:47-120
-        self.cell_diameter = max(mesh.h)
-        self.minimal_edge_length = min(mesh.h)
+        self.cell_diameter = max(mesh.hd)
+        self.minimal_edge_length = min(mesh.hd)
 
     def __del__(self):
         try:
@@ -158,7 +158,7 @@ class LevelSetOKZSolverAdvanceConcentration:
     def set_convection_stabilization(self, enabled, symmetry_faces=()):
         """global_omega_diameter = diameter_on_coarse_grid: the space diagonal of the brick"""
         m = self.ops.mesh
-        diameter = float(np.sqrt(sum((u - l) ** 2 for u, l in zip(m.upper, m.lower))))
+        diameter = float(np.sqrt(sum((u - l) ** 2 for u, l in zip(m.upper[:m.dim], m.lower[:m.dim]))))
         mask = sum(1 << f for f in symmetry_faces)
         _lib.check(self._ctx, self._lib.adaflo_ls_set_convection_stabilization(self._ctx, int(enabled), diameter, mask))
         self.convection_stabilization = bool(enabled)

@@ -19,23 +19,27 @@ from .time_stepping import TimeStepping
 
 class LevelSetOKZSolver:
     def __init__(self, parameters, mesh, distance_function, dirichlet_function=None, device=0,
-                 n_reinit_steps=2, n_initial_reinit_steps=2, exact_projection=True):
+                 n_reinit_steps=2, n_initial_reinit_steps=2, exact_projection=None, symmetry_faces=()):
         """distance_function(xyz[n][3]) -> signed distance to the interface, positive outside the
         second fluid (tests/rising_bubble.cc:59-77).  exact_projection: solve the normal / curvature
         projections (the reference: CG + ILU on the assembled projection matrix to 1e-7 / 1e-8) exactly by
-        fast diagonalisation instead of by diagonally preconditioned CG to those tolerances"""
+        fast diagonalisation instead of by diagonally preconditioned CG to those tolerances (default: where the engine
+        has the inverses, i.e. for dim = 3); symmetry_faces: see NavierStokes"""
         p = parameters
         self.parameters, self.mesh = p, mesh
         s, k = p.concentration_subdivisions, p.velocity_degree
         if dirichlet_function is None:
             dirichlet_function = lambda x, t: np.zeros_like(x)          # no-slip box
         self.time_stepping = TimeStepping(p)
-        self.navier_stokes = NavierStokes(p, mesh, self.time_stepping, dirichlet_function, device=device, ls_degree=s)
+        self.navier_stokes = NavierStokes(p, mesh, self.time_stepping, dirichlet_function, device=device, ls_degree=s,
+                                          symmetry_faces=symmetry_faces)
         self.ops = lso.LevelSetOperators(mesh, s, velocity_degree=k,
                                          navier_stokes_matrix=self.navier_stokes.navier_stokes_matrix)
+        if exact_projection is None:            # default: exact where the engine can (the inverses are dim = 3 only)
+            exact_projection = mesh.dim == 3
         self.ops.exact_projection = bool(exact_projection)
         # two_phase_base.cc:282-291: epsilon_used = epsilon / subdivisions * largest edge length
-        self.epsilon_used = p.epsilon / s * max(mesh.h)
+        self.epsilon_used = p.epsilon / s * max(mesh.hd)
         # the sub-operators advance their own TimeStepping copies (level_set_okz.cc:94-106)
         self.ts_advect, self.ts_reinit = TimeStepping(p), TimeStepping(p)
         self.advection_operator = lso.LevelSetOKZSolverAdvanceConcentration(self.ops)
@@ -73,7 +77,7 @@ class LevelSetOKZSolver:
     # ------------------------------------------------------------------------------------------
     def _ls_node_coordinates(self):
         m, s = self.mesh, self.parameters.concentration_subdivisions
-        ax = [np.linspace(m.lower[d], m.upper[d], s * m.ncell[d] + 1) for d in range(3)]
+        ax = [np.linspace(m.lower[d], m.upper[d], s * m.ncell[d] + 1) if d < m.dim else np.zeros(1) for d in range(3)]
         z, y, x = np.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
         return np.stack([x.reshape(-1), y.reshape(-1), z.reshape(-1)], axis=1)
 
@@ -169,7 +173,7 @@ class LevelSetOKZSolver:
         for the next reinitialize(), which adds three diffusion steps once the profile has left
         [-1.02, 1.02] (reinitialization.cc:281-284)"""
         m, s = self.mesh, self.parameters.concentration_subdivisions
-        nn = [s * n + 1 for n in m.ncell]
+        nn = m.nodes(s)
         phi = self.solution.numpy().reshape(nn[2], nn[1], nn[0])
         t = np.arange(s + 3) / (s + 2.0) * s                 # positions in units of sub-cells
         i0 = np.minimum(t.astype(int), s - 1)
@@ -178,8 +182,11 @@ class LevelSetOKZSolver:
         w[np.arange(s + 3), i0 + 1] = t - i0
         lo, hi = np.inf, -np.inf
         for cz in range(m.ncell[2]):                          # one layer of cells at a time (memory)
-            blk = phi[s * cz:s * cz + s + 1]
-            blk = np.einsum("pk,kyx->pyx", w, blk)
+            if m.dim == 2:
+                blk = phi                                   # one node layer: nothing to interpolate in z
+            else:
+                blk = phi[s * cz:s * cz + s + 1]
+                blk = np.einsum("pk,kyx->pyx", w, blk)
             ys = np.lib.stride_tricks.sliding_window_view(blk, s + 1, axis=1)[:, ::s]       # [p][cy][x][j]
             blk = np.einsum("qj,pcxj->pcqx", w, ys)
             xs = np.lib.stride_tricks.sliding_window_view(blk, s + 1, axis=3)[:, :, :, ::s]  # [p][cy][q][cx][i]

@@ -31,10 +31,13 @@ def gauss_lobatto_points(n):
 
 
 def node_coordinates(mesh, degree):
-    """coordinates [n_nodes][3] of the lexicographic nodes of FE_Q(degree) on the brick"""
+    """coordinates [n_nodes][3] of the lexicographic nodes of FE_Q(degree) on the brick (dim = 2: z = 0)"""
     axes = []
     gl = gauss_lobatto_points(degree + 1)
     for d in range(3):
+        if d >= mesh.dim:
+            axes.append(np.zeros(1))
+            continue
         h = mesh.h[d]
         x = np.concatenate([[mesh.lower[d]]] + [mesh.lower[d] + h * (c + gl[1:]) for c in range(mesh.ncell[d])])
         axes.append(x)
@@ -43,8 +46,10 @@ def node_coordinates(mesh, degree):
 
 
 class NavierStokes:
-    def __init__(self, parameters, mesh, time_stepping, dirichlet_function, device=0, ls_degree=0):
-        """dirichlet_function(xyz[n][3], t) -> velocity[n][3] on the (all-Dirichlet) boundary;
+    def __init__(self, parameters, mesh, time_stepping, dirichlet_function, device=0, ls_degree=0, symmetry_faces=()):
+        """dirichlet_function(xyz[n][3], t) -> velocity[n][3] (dim = 2: [n][2] is fine) on the Dirichlet boundary = every
+        face not in symmetry_faces; on those only the normal component is constrained, to zero
+        (FlowBaseAlgorithm::set_symmetry_boundary; tests/rising_bubble.cc:133-150 uses it for the side walls);
         ls_degree > 0 adds the level-set spaces to the engine context (two-phase flow)"""
         import torch
         if parameters.linearization == "projection":
@@ -55,21 +60,29 @@ class NavierStokes:
         self.dirichlet_function = dirichlet_function
         self.device = torch.device("cuda", device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        self.navier_stokes_matrix = NavierStokesMatrix(parameters, mesh, device=device, stream=stream,
-                                                       ls_degree=ls_degree)
+        symmetry_faces = sorted(set(int(f) for f in symmetry_faces))
+        assert all(0 <= f < 2 * mesh.dim for f in symmetry_faces)
+        dirichlet_faces = [f for f in range(2 * mesh.dim) if f not in symmetry_faces]
+        self.navier_stokes_matrix = NavierStokesMatrix(parameters, mesh, dirichlet_faces_u=dirichlet_faces,
+                                                       symmetry_faces_u=symmetry_faces,
+                                                       device=device, stream=stream, ls_degree=ls_degree)
         self.navier_stokes_matrix.initialize(time_stepping, True)
         m = self.navier_stokes_matrix
         k = parameters.velocity_degree
         self._lib, self._ctx = _lib.load(), m._require()
         # boundary nodes and their coordinates (apply_boundary_conditions :1216-1257)
-        nn = [k * n + 1 for n in mesh.ncell]
+        nn = mesh.nodes(k)
         idx = np.indices((nn[2], nn[1], nn[0]))
-        on_b = ((idx[0] == 0) | (idx[0] == nn[2] - 1) | (idx[1] == 0) | (idx[1] == nn[1] - 1) |
-                (idx[2] == 0) | (idx[2] == nn[0] - 1)).reshape(-1)
+        on_face = lambda f: (idx[2 - f // 2] == (nn[f // 2] - 1 if f % 2 else 0)).reshape(-1)
+        on_b = np.zeros(mesh.n_nodes(k), dtype=bool)
+        for f in dirichlet_faces:
+            on_b |= on_face(f)
         self._bnodes = np.nonzero(on_b)[0]
         self._bxyz = node_coordinates(mesh, k)[self._bnodes]
         dof = (3 * self._bnodes[:, None] + np.arange(3)[None, :]).reshape(-1)
         self._bdofs = torch.from_numpy(dof).to(self.device)
+        sym = [3 * np.nonzero(on_face(f) & ~on_b)[0] + f // 2 for f in symmetry_faces]
+        self._symdofs = torch.from_numpy(np.concatenate(sym) if sym else np.zeros(0, dtype=np.int64)).to(self.device)
         mk = lambda n: torch.zeros(n, dtype=torch.float64, device=self.device)
         nu, npp = m.n_dofs_u(), m.n_dofs_p()
         self.solution = [mk(nu), mk(npp)]
@@ -108,8 +121,13 @@ class NavierStokes:
             oo.copy_(old)
             old.copy_(cur)
             cur.copy_(tmp)
-        vals = np.ascontiguousarray(self.dirichlet_function(self._bxyz, ts.now()), dtype=np.float64).reshape(-1)
+        vals = np.asarray(self.dirichlet_function(self._bxyz, ts.now()), dtype=np.float64).reshape(len(self._bxyz), -1)
+        if vals.shape[1] < 3:       # dim = 2: the third component does not exist (constrained to zero on the device)
+            vals = np.concatenate([vals, np.zeros((len(vals), 3 - vals.shape[1]))], axis=1)
+        vals = np.ascontiguousarray(vals).reshape(-1)
         self.solution[0][self._bdofs] = torch.from_numpy(vals).to(self.device)
+        if len(self._symdofs):
+            self.solution[0][self._symdofs] = 0.0
 
     def compute_residual(self):
         m = self.navier_stokes_matrix

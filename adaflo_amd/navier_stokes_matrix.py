@@ -15,21 +15,36 @@ from .vectors import BlockVector, DeviceVector
 
 class BrickMesh:
     """ncell[d] hexahedra on [lower, upper]; faces numbered 2*d+side as deal.II's
-    GridGenerator::subdivided_hyper_rectangle(colorize=true) boundary ids."""
+    GridGenerator::subdivided_hyper_rectangle(colorize=true) boundary ids.
+
+    dim = 2 (two entries per argument): the engine runs the same kernels with a FLAT third direction -- one node,
+    one quadrature point of weight 1 (csrc/fe_kernels.hpp, SumFac<.., ZF>).  The mesh then reports ncell[2] = 1,
+    h[2] = 1 and one node layer; vectors keep three velocity components per node, the third one constrained."""
 
     def __init__(self, ncell, lower, upper):
-        assert len(ncell) == 3, "the device engine is dim = 3"
-        self.ncell = [int(n) for n in ncell]
-        self.lower = [float(x) for x in lower]
-        self.upper = [float(x) for x in upper]
+        assert len(ncell) in (2, 3) and len(lower) == len(ncell) == len(upper)
+        self.dim = len(ncell)
+        flat = self.dim == 2
+        self.ncell = [int(n) for n in ncell] + ([1] if flat else [])
+        self.lower = [float(x) for x in lower] + ([0.0] if flat else [])
+        self.upper = [float(x) for x in upper] + ([1.0] if flat else [])
         self.h = [(u - l) / n for u, l, n in zip(self.upper, self.lower, self.ncell)]
+
+    @property
+    def hd(self):
+        """edge lengths of the directions that exist"""
+        return self.h[:self.dim]
+
+    def nodes(self, degree):
+        """nodes per direction of a degree-`degree` space (one layer in the flat direction)"""
+        return [degree * n + 1 for n in self.ncell[:self.dim]] + ([1] if self.dim == 2 else [])
 
     @property
     def n_cells(self):
         return int(np.prod(self.ncell))
 
     def n_nodes(self, degree):
-        return int(np.prod([degree * n + 1 for n in self.ncell]))
+        return int(np.prod(self.nodes(degree)))
 
 
 def face_mask(faces, ncomp=1, comps=None):
@@ -45,22 +60,28 @@ class NavierStokesMatrix:
     """Operator object usable by any Krylov solver that needs `vmult(dst, src)`."""
 
     def __init__(self, parameters, mesh, dirichlet_faces_u=range(6), constrained_faces_p=(),
-                 device=0, stream=None, ls_degree=0):
+                 device=0, stream=None, ls_degree=0, symmetry_faces_u=()):
+        """dirichlet_faces_u: all velocity components constrained; symmetry_faces_u: only the component normal to
+        the face (FlowBaseAlgorithm::set_symmetry_boundary, source/flow_base_algorithm.cc:95-101)"""
         self.parameters = parameters
         self.mesh = mesh
         self._lib = _lib.load()
         self._ctx = None
         self._desc = _lib.BrickDesc()
         d = self._desc
-        d.dim = 3
+        d.dim = mesh.dim
         for i in range(3):
             d.ncell[i] = mesh.ncell[i]
             d.h[i] = mesh.h[i]
             d.origin[i] = mesh.lower[i]
         d.velocity_degree = parameters.velocity_degree
         d.ls_degree = ls_degree
-        d.velocity_constrained = face_mask(dirichlet_faces_u, 3)
-        d.pressure_constrained = face_mask(constrained_faces_p, 1)
+        # dim = 2: only the faces of the directions that exist (the engine constrains the third component itself)
+        d.velocity_constrained = face_mask([f for f in dirichlet_faces_u if f < 2 * mesh.dim], 3)
+        for f in symmetry_faces_u:
+            if f < 2 * mesh.dim:
+                d.velocity_constrained |= face_mask([f], 3, comps=[f // 2])
+        d.pressure_constrained = face_mask([f for f in constrained_faces_p if f < 2 * mesh.dim], 1)
         d.ls_constrained = 0
         d.device = device
         d.stream = None
