@@ -11,18 +11,42 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_adaflo_oracle.so")
-_SRCS = [os.path.join(_HERE, f) for f in ("adaflo_oracle.c", "adaflo_oracle_fast.c")]
+_SRCS = [os.path.join(_HERE, f) for f in ("adaflo_oracle.c", "adaflo_oracle_fast.c", "adaflo_oracle_batched.c")]
+_DEPS = _SRCS + [os.path.join(_HERE, "adaflo_oracle_batched_body.h")]
+_HOST = _SO + ".host"
+
+
+def _host_signature():
+    """-march=native ties the library to the CPU it was built on: model name + the SIMD flags that matter"""
+    model, flags = "?", ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "?":
+                model = line.split(":", 1)[1].strip()
+            if line.startswith("flags") and not flags:
+                have = set(line.split(":", 1)[1].split())
+                flags = " ".join(f for f in ("avx2", "fma", "avx512f", "avx512dq", "avx512vl") if f in have)
+    except OSError:
+        pass
+    return model + " | " + flags
 
 
 def build(force=False):
     """Compile the oracle with gcc (plain C, OpenMP for the fast variant)."""
     srcs = [s for s in _SRCS if os.path.exists(s)]
-    stale = force or not os.path.exists(_SO) or any(
-        os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    sig = _host_signature()
+    try:
+        built_on = open(_HOST).read()
+    except OSError:
+        built_on = None
+    stale = force or not os.path.exists(_SO) or built_on != sig or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in _DEPS)
     if stale:
         cmd = ["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-Wall",
                "-o", _SO] + srcs + ["-lm"]
         subprocess.check_call(cmd)
+        with open(_HOST, "w") as f:
+            f.write(sig)
     return _SO
 
 
@@ -369,6 +393,37 @@ def fast_ns_vmult(mesh, k, prm, src_u, src_p, con_u=None, con_p=None, lin=None, 
                                  _p(damp), _p(weights), _p(modes))
     assert rc == 0
     return dst_u, dst_p
+
+
+class BatchedNSVmult:
+    """cell-batched restatement (adaflo_oracle_batched.c): W cells per SIMD register, state in the batched layout,
+    compile-time loop bounds, optional even-odd 1D kernels -- the data flow of deal.II's FEEvaluation path"""
+
+    def __init__(self, mesh, k, con_u=None, con_p=None, lin=None):
+        L = lib()
+        L.orc_batched_prepare.restype = C.c_void_p
+        L.orc_batched_isa.restype = C.c_char_p
+        self._keep = (mesh, None if con_u is None else np.ascontiguousarray(con_u, dtype=np.uint8),
+                      None if con_p is None else np.ascontiguousarray(con_p, dtype=np.uint8))
+        self.mesh, self.k = mesh, k
+        self._h = L.orc_batched_prepare(C.byref(mesh), k, _u8(self._keep[1]), _u8(self._keep[2]), _p(lin))
+        assert self._h, "orc_batched_prepare refused (3D, 2 <= k <= 5)"
+        self.isa, self.width = L.orc_batched_isa().decode(), int(L.orc_batched_width())
+
+    def vmult(self, prm, src_u, src_p, weights=None, modes=None, even_odd=True, out=None):
+        dst_u, dst_p = out if out is not None else (np.empty_like(src_u), np.empty_like(src_p))
+        rc = lib().orc_batched_ns_vmult(C.c_void_p(self._h), C.byref(prm), _p(src_u), _p(src_p), _p(dst_u), _p(dst_p),
+                                        _p(weights), _p(modes), int(even_odd))
+        assert rc == 0, rc
+        return dst_u, dst_p
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().orc_batched_free(C.c_void_p(self._h))
+                self._h = None
+        except Exception:
+            pass
 
 
 def ls_advect_rhs(mesh, prm, ku, solution, solution_old, solution_old_old, vel, vel_q,

@@ -47,7 +47,7 @@ for name in sorted(os.listdir(src)):
             with open(os.path.join(dst, "%s_%s.txt" % (tag, name)), "w") as out:
                 out.write("# rocprofv3 --pmc pass '%s' (scripts/measure_round.sh): mean counter value per launch\n" % name)
                 for k, ctr in acc.items():
-                    if not any(s in k for s in ("ns_q2", "ns_ho", "seam_fixup", "ho_fixup")):
+                    if not any(s in k for s in ("ns_q2", "ns_ho", "seam_fixup", "ho_fixup", "hox_")):
                         continue
                     out.write("%s\n   %s\n" % (k[:140], " ".join("%s=%s" % kv for kv in meta[k].items())))
                     for c, v in sorted(ctr.items()):
@@ -60,10 +60,9 @@ for name in sorted(os.listdir(src)):
 # lane) coalesced reads, which is how the Q2/Q1 kernel issues all its loads (MI355X_MICROARCH.md, HBM section)
 traffic = {"_comment": "scripts/collect_profiles.py from scripts/measure_round.sh %s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
                        "separate passes of bench.py --steps 5 --warmup 2; KB per launch averaged.  ns_q2_kernel: hbm_bytes = "
-                       "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction for 16-B-per-lane streaming reads).  ns_ho_kernel "
-                       "reads its state 8 B per lane in runs of 25 lanes: hbm_bytes = FETCH_SIZE / r + WRITE_SIZE with the "
-                       "ratio r measured by scripts/dev/fetch_probe.hip in the same round (fetch_size_calibration); the "
-                       "raw and the doubled figure are given beside it." % tag}
+                       "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction for 16-B-per-lane streaming reads), the same for "
+                       "ns_hox_kernel (state by 16-B-per-lane LDS-DMA, node lines 8 B per lane contiguous: both count 0.5 "
+                       "per scripts/dev/fetch_probe.hip, fetch_size_calibration); the raw figure is given beside it." % tag}
 
 
 def mean_kb(pass_name, kernel, counter):
@@ -89,13 +88,13 @@ if ratio:
     traffic["fetch_size_calibration"] = {"FETCH_SIZE_bytes_per_byte_read": ratio,
                                          "note": "gfx950: 0.5 for contiguous 8- and 16-B-per-lane reads, ~0.8 for the "
                                                  "runs of 25 x 8 B of the Q4/Q3 state reads"}
-f, w = mean_kb("pmc_q4_fetch", "ns_ho_kernel", "FETCH_SIZE"), mean_kb("pmc_q4_write", "ns_ho_kernel", "WRITE_SIZE")
+# round 4: the x-marching kernel (ns_hox_kernel) streams its state with 16-B-per-lane LDS-DMA copies like ns_q2_kernel
+# (FETCH_SIZE counts half of those bytes) and reads node lines 8 B per lane (also 0.5 per the calibration above)
+f, w = mean_kb("pmc_q4_fetch", "ns_hox_kernel", "FETCH_SIZE"), mean_kb("pmc_q4_write", "ns_hox_kernel", "WRITE_SIZE")
 if f and w:
-    r25 = ratio.get("read8_runs_of_25")
-    traffic["64x64x64 k=4 variant=1"] = {"ns_ho_kernel": {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
-                                                             "hbm_bytes": int((f / r25 + w) * 1024) if r25 else None,
-                                                             "raw_bytes": int((f + w) * 1024),
-                                                             "fetch_doubled_bytes": int((2 * f + w) * 1024)}}
+    traffic["64x64x64 k=4 variant=1"] = {"ns_hox_kernel": {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
+                                                              "hbm_bytes": int((2 * f + w) * 1024),
+                                                              "raw_bytes": int((f + w) * 1024)}}
 with open(os.path.join(dst, "pmc_traffic.json"), "w") as out:
     json.dump(traffic, out, indent=1)
 print(json.dumps(traffic, indent=1))

@@ -1,9 +1,9 @@
 #!/bin/bash
 # All measurements behind DESIGN.md / profiles/ of one round, on the GPU box:
-#   gpurun --timeout 3000 -- 'bash scripts/measure_round.sh r03'
+#   gpurun --timeout 3000 -- 'bash scripts/measure_round.sh r04'
 # writes gpurun_out/<tag>/<name>/*_kernel_stats.csv + <name>.log; scripts/collect_profiles.py copies the
 # summaries into profiles/ and builds profiles/pmc_traffic.json.
-tag=${1:-r03}
+tag=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$tag
 mkdir -p "$O"
@@ -45,4 +45,9 @@ python3 bench.py --cells 256 --steps 20 --warmup 3 --no-cpu-baseline > "$O/bench
 python3 bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline > "$O/bench_2ranks_one_gpu.log" 2>&1
 python3 bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline --src-consistent > "$O/bench_2ranks_one_gpu_src_consistent.log" 2>&1
 python3 bench.py --gpus 2 --config cavity --steps 10 --warmup 2 --no-cpu-baseline > "$O/bench_cavity_2ranks_one_gpu.log" 2>&1
+# fixed overhead of the distributed path on one rank (world = 1 through adaflo_ns_vmult_distributed, phased schedule forced)
+python3 bench.py --through-comm --steps 30 --warmup 5 --no-cpu-baseline > "$O/bench_through_comm_q2_128.log" 2>&1
+python3 bench.py --config cavity --cells 32 --steps 50 --warmup 5 --no-cpu-baseline > "$O/bench_cavity_q4_32.log" 2>&1
+python3 bench.py --config cavity --cells 32 --through-comm --steps 50 --warmup 5 --no-cpu-baseline > "$O/bench_through_comm_q4_32.log" 2>&1
+python3 scripts/bench_ho.py > "$O/bench_ho.log" 2>&1
 echo done > "$O/done"

@@ -169,6 +169,40 @@ def test_ns_operators_equal_the_2d_oracle(k, ncell, phys, lin, variable):
         assert rel_l2(u2(du), ref_u) < TOL and rel_l2(dp, ref_p) < TOL
 
 
+def test_config0_2d_beltrami_64x64_on_the_device():
+    """BASELINE configs[0] (2D Q2/Q1, uniform 64 x 64 on [-1,1]^2, 33 282 + 4 225 DoF; the reference's CPU plumbing
+    case, tests/test_oracle_kats.py) has a device counterpart: residual at the Beltrami interpolant, then the Newton
+    vmult on the state the residual stored, against the oracle"""
+    omesh = orc.Mesh.make([64, 64], [-1.0, -1.0], [1.0, 1.0])
+    mesh = adaflo_amd.BrickMesh([64, 64], [-1.0, -1.0], [1.0, 1.0])
+    k, dt = 2, 0.01
+    fp = adaflo_amd.FlowParameters(velocity_degree=k, viscosity=1.0, density=1.0, time_step_size_start=dt, end_time=1.0)
+    ts = adaflo_amd.TimeStepping(fp)
+    ts.next(), ts.next()
+    prm = orc.NSParams.make(beta=0.5, weight=ts.weight(), weight_old=ts.weight_old(), weight_old_old=ts.weight_old_old(),
+                            tau1=ts.tau1(), extrap_old=ts.factor_extrapol_old, extrap_old_old=ts.factor_extrapol_old_old)
+    op = adaflo_amd.NavierStokesMatrix(fp, mesh, dirichlet_faces_u=range(4))
+    op.initialize(ts, False)
+    assert (op.n_cells(), op.n_dofs_u() * 2 // 3, op.n_dofs_p()) == (4096, 33282, 4225)
+    xu, xp = orc.node_coordinates(omesh, k), orc.node_coordinates(omesh, k - 1)
+    u, p = orc.beltrami_u(xu, 0.0).reshape(-1), orc.beltrami_p(xp, 0.0).reshape(-1)
+    u_old, u_oo = orc.beltrami_u(xu, -dt).reshape(-1), orc.beltrami_u(xu, -2 * dt).reshape(-1)
+    con_u = orc.boundary_mask(omesh, k, 2)
+    lin = np.zeros(omesh.n_cells * 9 * 6)
+    ref_u, ref_p = orc.ns_residual(omesh, k, prm, u, p, u_old, u_oo, con_u=con_u, lin=lin)
+    res = op.block_vector()
+    op.residual(res, op.block_vector(u3(u), p), None, op.block_vector(u3(u_old)), op.block_vector(u3(u_oo)))
+    ru, rp = res.numpy()
+    assert rel_l2(u2(ru), ref_u) < TOL and rel_l2(rp, ref_p) < TOL
+    rng = np.random.default_rng(7)
+    du, dp = rng.uniform(-1, 1, u.size), rng.uniform(-1, 1, p.size)
+    ju, jp = orc.ns_vmult(omesh, k, prm, du, dp, con_u, None, lin=lin)
+    dst = op.block_vector()
+    op.vmult(dst, op.block_vector(u3(du), dp))
+    gu, gp = dst.numpy()
+    assert rel_l2(u2(gu), ju) < TOL and rel_l2(gp, jp) < TOL
+
+
 # ---- level-set operators --------------------------------------------------------------------------------------------
 class LS2D:
     def __init__(self, ncell, s, k=2, faces=(), seed=5):

@@ -143,3 +143,27 @@ def test_config1_2d_beltrami_64x64_vmult_is_the_jacobian_of_the_residual():
     ju3, jp3 = orc.ns_vmult(mesh, k, prm, a * du + b * du2, a * dp + b * dp2, con_u, None, lin=lin)
     assert np.linalg.norm(ju3 - (a * ju + b * ju2)) < 1e-12 * np.linalg.norm(ju3)
     assert np.linalg.norm(jp3 - (a * jp + b * jp2)) < 1e-12 * np.linalg.norm(jp3)
+
+
+@pytest.mark.parametrize("k,ncell,phys,lin", [(2, (5, 4, 3), 0, 0), (2, (4, 4, 4), 0, 1), (3, (3, 2, 3), 0, 0), (4, (2, 3, 2), 0, 2),
+                                              (2, (3, 3, 3), 2, 0), (5, (2, 2, 1), 0, 0), (2, (9, 1, 1), 0, 3), (4, (3, 3, 3), 0, 0)])
+def test_cell_batched_cpu_baseline_equals_the_naive_oracle(k, ncell, phys, lin):
+    """oracle/adaflo_oracle_batched.c (bench.py's cpu_baseline: W cells per SIMD register, batched state, even-odd
+    kernels) against the naive oracle: ragged last batches, constrained velocity and pressure rows, mean projection"""
+    mesh = orc.Mesh.make(list(ncell), [-1.0] * 3, [1.0, 2.0, 1.5])
+    prm = orc.NSParams.make(physical_type=phys, linearization=lin, weight=30.0, tau_grad_div=0.3, viscosity=0.2,
+                            density=1.1, damping=0.1)
+    rng = np.random.default_rng(k)
+    nu, npr = mesh.n_nodes(k) * 3, mesh.n_nodes(k - 1)
+    su, sp = rng.uniform(-1, 1, nu), rng.uniform(-1, 1, npr)
+    lin_q = rng.uniform(-1, 1, mesh.n_cells * (k + 1) ** 3 * 12)
+    con_u = orc.boundary_mask(mesh, k, 3, faces=[0, 1, 2, 5])
+    con_p = orc.boundary_mask(mesh, k - 1, 1, faces=[3])
+    w, modes = orc.ns_pressure_mass_weight(mesh, k, con_p), np.ones(npr)
+    ref_u, ref_p = orc.ns_vmult(mesh, k, prm, su, sp, con_u, con_p, lin=lin_q, weights=w, modes=modes)
+    batched = orc.BatchedNSVmult(mesh, k, con_u, con_p, lin_q)
+    assert batched.width in (2, 4, 8)
+    for even_odd in (False, True):
+        got_u, got_p = batched.vmult(prm, su, sp, weights=w, modes=modes, even_odd=even_odd)
+        assert np.linalg.norm(got_u - ref_u) < 1e-13 * np.linalg.norm(ref_u)
+        assert np.linalg.norm(got_p - ref_p) < 1e-13 * np.linalg.norm(ref_p)
