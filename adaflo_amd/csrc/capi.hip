@@ -447,7 +447,15 @@ int adaflo_ns_set_params(adaflo_ctx *ctx, const adaflo_ns_params *p)
   // ran with; another scheme re-creates its streaming copy from the generic one: bring that up to date
   // while the layout of the stored copy is still known.
   if (ctx->ns_params_set && (p->physical_type != ctx->ns.physical_type || p->linearization != ctx->ns.linearization))
-    TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
+    {
+      TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
+      // ... and the streaming copies of the old scheme are dropped: the next vmult re-creates its copy in the new
+      // layout; the frozen copy of velocity_vmult falls back to its generic form until the next
+      // adaflo_ns_fix_linearization_point (its kernel would be instantiated for the NEW scheme)
+      TRY(ctx, ensure_lin_prec_generic(ctx), "state re-layout failed");
+      ctx->lin_q2_valid = false;
+      release(ctx->lin_q2_prec);
+    }
   ctx->ns = NSDev{p->physical_type, p->linearization, p->beta, p->tau_grad_div, p->density,
                   p->viscosity, p->damping, p->density_diff, p->weight, p->weight_old,
                   p->weight_old_old, p->tau1, p->extrap_old, p->extrap_old_old};
@@ -748,8 +756,10 @@ int adaflo_ns_velocity_vmult(adaflo_ctx *ctx, double *dst_u, const double *src_u
   if (needs_lin(ctx) && !has_lin(ctx))
     return fail(ctx, ADAFLO_ENOTINIT, "linearization data not set");
   const int k = ctx->k;
-  // (frozen coefficient copies without a frozen streaming copy: generic kernel)
-  if (ctx->variant >= 1 && q2_supported(ctx) && (!ctx->rho_prec.p || ctx->lin_q2_prec.p))
+  // (frozen coefficient copies without a frozen streaming copy: generic kernel; likewise a frozen state that exists in
+  // the generic layout only -- after a change of scheme, adaflo_ns_set_params)
+  const bool frozen_generic_only = ctx->lin_prec.p && ctx->lin_prec_generic_valid && !ctx->lin_q2_prec.p;
+  if (ctx->variant >= 1 && q2_supported(ctx) && !frozen_generic_only && (!ctx->rho_prec.p || ctx->lin_q2_prec.p))
     {
       TRY(ctx, launch_ns_vmult_q2(ctx, OP_VMULT_VELOCITY, dst_u, nullptr, src_u, nullptr),
           "Q2 kernel launch failed");

@@ -456,12 +456,15 @@ namespace adaflo_hip
   }
 
   // distribute_local_to_global: scatter-add, constrained rows skipped.  No atomics: the cell loops run colour by
-  // colour (BrickDev::colour), the cells of one launch share no node.
+  // colour (BrickDev::colour), the cells of one launch share no node.  A launcher that forgot the colour loop
+  // (colour < 0 = all cells in one launch) would race silently: the kernel traps instead.
   template <int DEG, int NC, int NT, bool ZF = false>
   __device__ void scatter_cell(double *__restrict__ vec, const double *loc, const int cx,
                                const int cy, const int cz, const int nnx, const int nny,
-                               const int nnz, const uint32_t mask)
+                               const int nnz, const uint32_t mask, const int colour)
   {
+    if (colour < 0)
+      __builtin_trap();
     constexpr int ND = DEG + 1, ND3 = ND * ND * (ZF ? 1 : ND);
     for (int o = threadIdx.x; o < ND3 * NC; o += NT)
       {

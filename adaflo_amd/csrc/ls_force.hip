@@ -207,7 +207,7 @@ namespace adaflo_hip
       __syncthreads();
       for (int d = 0; d < 3; ++d)
         C::SFV::template integrate<true, false>(Sv, Sv, hg + d * NQ3, nullptr, nullptr, nullptr, vl + d * C::NDV3, tmp);
-      scatter_cell<KU, 3, NT, ZF>(a.dst_u, vl, cx, cy, cz, vx, vy, vz, a.brick.con_u);
+      scatter_cell<KU, 3, NT, ZF>(a.dst_u, vl, cx, cy, cz, vx, vy, vz, a.brick.con_u, a.brick.colour);
     }
 
     template <int S, int KU, bool ZF = false>

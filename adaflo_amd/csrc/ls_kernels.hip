@@ -140,7 +140,7 @@ namespace adaflo_hip
       }
     __syncthreads();
     SF::template integrate<true, true>(Sm, Dm, val, grad, grad + NQ3, grad + 2 * NQ3, ul, tmp);
-    scatter_cell<S, 1, NT, ZF>(dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+    scatter_cell<S, 1, NT, ZF>(dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls, a.brick.colour);
   }
 
   // ------------------------------------------------------------------ right-hand sides
@@ -214,7 +214,7 @@ namespace adaflo_hip
           }
         __syncthreads();
         SF::template integrate<true, false>(Sm, Dm, val, nullptr, nullptr, nullptr, ul, tmp);
-        scatter_cell<S, 1, NT, ZF>(a.dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+        scatter_cell<S, 1, NT, ZF>(a.dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls, a.brick.colour);
         return;
       }
 
@@ -235,7 +235,7 @@ namespace adaflo_hip
               }
             __syncthreads();
             SF::template integrate<true, false>(Sm, Dm, grad + d * NQ3, nullptr, nullptr, nullptr, ul, tmp);
-            scatter_cell<S, 1, NT, ZF>(a.dst + (size_t)d * a.n_nodes, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+            scatter_cell<S, 1, NT, ZF>(a.dst + (size_t)d * a.n_nodes, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls, a.brick.colour);
             __syncthreads();
           }
         return;
@@ -292,7 +292,7 @@ namespace adaflo_hip
       }
     __syncthreads();
     SF::template integrate<false, true>(Sm, Dm, nullptr, grad, grad + NQ3, grad + 2 * NQ3, ul, tmp);
-    scatter_cell<S, 1, NT, ZF>(a.dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+    scatter_cell<S, 1, NT, ZF>(a.dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls, a.brick.colour);
   }
 
   // advection right-hand side :288-397 (velocity of degree KU evaluated at the LS quadrature)
@@ -405,7 +405,7 @@ namespace adaflo_hip
       SF::template integrate<true, true>(Sm, Dm, val, grad, grad + NQ3, grad + 2 * NQ3, ul, tmp);
     else
       SF::template integrate<true, false>(Sm, Dm, val, nullptr, nullptr, nullptr, ul, tmp);
-    scatter_cell<S, 1, NT, ZF>(a.dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls);
+    scatter_cell<S, 1, NT, ZF>(a.dst, ul, cx, cy, cz, nx, ny, nz, a.brick.con_ls, a.brick.colour);
   }
 
   // boundary part of the stabilisation (:419-472 operator, bsign = -1; :569-617 rhs, bsign = +1):

@@ -316,7 +316,7 @@ namespace adaflo_hip
       for (int d = 0; d < 3; ++d)
         SFU::template integrate<true, true>(S_u, D_u, vu + d * NQ3, gu + (3 * d + 0) * NQ3, gu + (3 * d + 1) * NQ3,
                                             gu + (3 * d + 2) * NQ3, ul + d * NDU3, tmp);
-    scatter_cell<K, 3, NT, ZF>(a.dst_u, ul, cx, cy, cz, nux, nuy, nuz, a.brick.con_u);
+    scatter_cell<K, 3, NT, ZF>(a.dst_u, ul, cx, cy, cz, nux, nuy, nuz, a.brick.con_u, a.brick.colour);
     if (OP != OP_VMULT_VELOCITY && P.linearization != ADAFLO_PROJECTION)
       {
         if constexpr (REGQ)
@@ -328,7 +328,7 @@ namespace adaflo_hip
           }
         else
           SFP::template integrate<true, false>(S_p, D_p, vp, nullptr, nullptr, nullptr, pl, tmp);
-        scatter_cell<K - 1, 1, NT, ZF>(a.dst_p, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
+        scatter_cell<K - 1, 1, NT, ZF>(a.dst_p, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p, a.brick.colour);
       }
   }
 
@@ -634,7 +634,7 @@ namespace adaflo_hip
           }
         __syncthreads();
         SFP::template integrate<true, false>(S_p, D_p, vp, nullptr, nullptr, nullptr, pl, tmp);
-        scatter_cell<K - 1, 1, NT, ZF>(a.dst, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
+        scatter_cell<K - 1, 1, NT, ZF>(a.dst, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p, a.brick.colour);
         return;
       }
 
@@ -694,7 +694,7 @@ namespace adaflo_hip
       SFP::template integrate<false, true>(S_p, D_p, nullptr, gp, gp + NQ3, gp + 2 * NQ3, pl, tmp);
     else
       SFP::template integrate<true, false>(S_p, D_p, vp, nullptr, nullptr, nullptr, pl, tmp);
-    scatter_cell<K - 1, 1, NT, ZF>(a.dst, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
+    scatter_cell<K - 1, 1, NT, ZF>(a.dst, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p, a.brick.colour);
   }
 
   template <int K, int NT, bool ZF = false>

@@ -34,7 +34,8 @@ namespace adaflo_hip
   {
     // Diagnostic builds (scripts/exp_ho.sh, results are WRONG, timing only): HOX_EXP & 1 = no LDS traffic (the
     // transpositions become register copies), & 2 = no 1D contractions, & 4 = no state stream, & 8 = state from L2,
-    // & 16 = no stores, & 32 = no loads of the nodal lines, & 64 = no publish / barrier / collect
+    // & 16 = no stores, & 32 = no loads of the nodal lines, & 64 = no publish / barrier / collect, & 128 = the 96-byte
+    // velocity chunks a lane stores per step start on a 32-byte boundary (no partially written 32-byte granules)
 #ifndef HOX_EXP
 #define HOX_EXP 0
 #endif
@@ -673,6 +674,8 @@ namespace adaflo_hip
               tp = A.slab_u + (((size_t)wg * RIMU + rim_line<TNY, TNZ>(jl, kl)) * (K * A.LX + 1) + xl0) * 3;
             else
               tp = A.dst_u + (size_t)I0 * 3 + urow;
+            if (HOX_EXP & 128) // (diagnostic, wrong results: every chunk starts on a 32-byte boundary)
+              tp = (double *)((size_t)tp & ~(size_t)31);
 #pragma unroll
             for (int i = 0; i < NV; ++i)
 #pragma unroll

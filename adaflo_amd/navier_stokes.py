@@ -143,7 +143,7 @@ class NavierStokes:
 
     compute_initial_residual = compute_residual     # (:805-827 only prints a table header before)
 
-    cheap_velocity_iterations = 3
+    cheap_velocity_iterations = 3       # two-phase flow only, see solve_system
 
     def build_preconditioner(self):
         _lib.check(self._ctx, self._lib.adaflo_ns_preconditioner_setup(self._ctx))
@@ -160,8 +160,11 @@ class NavierStokes:
         # solve cut off after a few BiCGStab iterations as approximate inverse (measured, 64 x 64 x 128 cells: 3
         # iterations -> 19-22 outer iterations instead of 15-18 with inner solves to their tolerance, linear solve
         # 0.22-0.26 -> 0.17-0.20 s per time step)
+        # (only there: with constant coefficients the first stage is the reference's -- one application of the
+        # approximate inverses -- and the header's default 0 stands)
+        variable = p.density_diff != 0.0 or p.viscosity_diff != 0.0
         _lib.check(self._ctx, self._lib.adaflo_ns_preconditioner_set_cheap_velocity_iterations(
-            self._ctx, self.cheap_velocity_iterations))
+            self._ctx, self.cheap_velocity_iterations if variable else 0))
         _lib.check(self._ctx, self._lib.adaflo_ns_solve_system(
             self._ctx, upd[0].data_ptr(), upd[1].data_ptr(), rhs[0].data_ptr(), rhs[1].data_ptr(),
             C.byref(ctl), 50, C.byref(res)))

@@ -239,11 +239,9 @@ if __name__ == "__main__":
     ns_host_vector_case(128)
     ns_case(2, 128, 1, two_phase=True)
     ns_case(2, 128, 0, two_phase=True)
-    ns_case(3, 64, 2)
-    ns_case(3, 64, 0)
-    ns_case(4, 64, 2)
-    ns_case(4, 64, 0)
-    ns_case(5, 48, 2)
-    ns_case(5, 48, 0)
+    for k, n in ((3, 64), (4, 64), (5, 48)):        # 1: x-marching kernel (round 4), 2: z-sweep kernel (round 2), 0: generic
+        for v in (1, 2, 0):
+            ns_case(k, n, v)
+    ns_residual_case(4, 64, 1)
     ls_case(4, (40, 40, 80))
     krylov_case(4, (40, 40, 80))

@@ -89,12 +89,21 @@ if ratio:
                                          "note": "gfx950: 0.5 for contiguous 8- and 16-B-per-lane reads, ~0.8 for the "
                                                  "runs of 25 x 8 B of the Q4/Q3 state reads"}
 # round 4: the x-marching kernel (ns_hox_kernel) streams its state with 16-B-per-lane LDS-DMA copies like ns_q2_kernel
-# (FETCH_SIZE counts half of those bytes) and reads node lines 8 B per lane (also 0.5 per the calibration above)
+# (FETCH_SIZE counts half of those bytes: calibrated with the no-state build of the same kernel, pass
+# pmc_q4_fetch_nostate -- (FETCH - FETCH_nostate) / known state bytes = 0.51); its node-line reads (8 B per lane, 120-B
+# runs in different rows) count in full
 f, w = mean_kb("pmc_q4_fetch", "ns_hox_kernel", "FETCH_SIZE"), mean_kb("pmc_q4_write", "ns_hox_kernel", "WRITE_SIZE")
+f0 = mean_kb("pmc_q4_fetch_nostate", "ns_hox_kernel", "FETCH_SIZE")
 if f and w:
-    traffic["64x64x64 k=4 variant=1"] = {"ns_hox_kernel": {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
-                                                              "hbm_bytes": int((2 * f + w) * 1024),
-                                                              "raw_bytes": int((f + w) * 1024)}}
+    entry = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "raw_bytes": int((f + w) * 1024)}
+    if f0:
+        state_bytes = 64 ** 3 * 125 * 12 * 8
+        entry.update({"FETCH_SIZE_KB_without_state_stream": f0, "state_bytes_algorithmic": state_bytes,
+                      "FETCH_SIZE_bytes_per_state_byte": (f - f0) * 1024 / state_bytes,
+                      "hbm_bytes": int((2 * (f - f0) + f0 + w) * 1024)})
+    else:
+        entry["hbm_bytes"] = int((2 * f + w) * 1024)
+    traffic["64x64x64 k=4 variant=1"] = {"ns_hox_kernel": entry}
 with open(os.path.join(dst, "pmc_traffic.json"), "w") as out:
     json.dump(traffic, out, indent=1)
 print(json.dumps(traffic, indent=1))

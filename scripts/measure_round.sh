@@ -50,4 +50,11 @@ python3 bench.py --through-comm --steps 30 --warmup 5 --no-cpu-baseline > "$O/be
 python3 bench.py --config cavity --cells 32 --steps 50 --warmup 5 --no-cpu-baseline > "$O/bench_cavity_q4_32.log" 2>&1
 python3 bench.py --config cavity --cells 32 --through-comm --steps 50 --warmup 5 --no-cpu-baseline > "$O/bench_through_comm_q4_32.log" 2>&1
 python3 scripts/bench_ho.py > "$O/bench_ho.log" 2>&1
+# calibration of FETCH_SIZE for ns_hox_kernel: the same pass without the state stream (diagnostic build, then the product
+# build again); state bytes are known, so (FETCH - FETCH_nostate) / state bytes is the counter's unit for the LDS-DMA reads
+bash scripts/exp_ho.sh "-DHOX_EXP=4" > "$O/exp_nostate_build.log" 2>&1
+cd /tmp
+pmc pmc_q4_fetch_nostate FETCH_SIZE python3 $R/bench.py --config cavity --steps 5 --warmup 2 --no-cpu-baseline
+cd $R
+bash scripts/exp_ho.sh "-DHOX_EXP=0" >> "$O/exp_nostate_build.log" 2>&1
 echo done > "$O/done"

@@ -539,6 +539,39 @@ def test_velocity_vmult_high_order_x_marching_kernel():
     assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL
 
 
+@pytest.mark.parametrize("k", [2, 4])
+def test_change_of_scheme_after_the_state_was_frozen(k):
+    """adaflo_ns_set_params with another linearisation while streaming copies of the state exist (the sweep kernels
+    keep the state in a scheme-specific layout): vmult re-creates its copy for the new scheme, velocity_vmult keeps
+    operating on the FROZEN state -- read the way the new scheme reads a stored state -- and a later
+    fix_linearization_point freezes the current one again"""
+    case = Case((9, 8, 3) if k == 2 else (4, 3, 3), k=k)
+    picard = Case(case.ncell, k=k, linearization=1)
+    src_u, src_p, lin, lin2 = case.random_u(), case.random_p(), case.random_lin(), case.random_lin()
+    op = case.engine()
+    op.set_kernel_variant(1)
+    op.set_linearization(lin)
+    dst2 = op.block_vector()
+    op.vmult(dst2, op.block_vector(src_u, src_p))              # (streaming copy in the Newton layout)
+    op.fix_linearization_point()
+    op.set_linearization(lin2)
+    op.vmult(dst2, op.block_vector(src_u, src_p))
+    op.parameters = picard.fp
+    op.update_parameters()
+    src, dst = op.initialize_u_vector(src_u), op.initialize_u_vector(np.full(case.n_u, 3.0))
+    op.velocity_vmult(dst, src)
+    assert rel_l2(dst.numpy(), orc.ns_velocity_vmult(case.mesh, k, picard.prm, src_u, case.con_u, lin=lin)) < TOL
+    w, modes = case.weights_modes()
+    ref_u, ref_p = orc.ns_vmult(case.mesh, k, picard.prm, src_u, src_p, case.con_u, case.con_p, lin=lin2,
+                                weights=w, modes=modes)
+    op.vmult(dst2, op.block_vector(src_u, src_p))
+    got_u, got_p = dst2.numpy()
+    assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL
+    op.fix_linearization_point()
+    op.velocity_vmult(dst, src)
+    assert rel_l2(dst.numpy(), orc.ns_velocity_vmult(case.mesh, k, picard.prm, src_u, case.con_u, lin=lin2)) < TOL
+
+
 @pytest.mark.parametrize("ncell,upper,lin,phys", [((9, 8, 5), (1., 1., 1.), 0, 0), ((17, 9, 6), (1., 1., 3.), 0, 0),
                                                   ((8, 16, 3), (1., 1., 1.), 1, 0), ((5, 4, 9), (1., 2., 1.), 0, 1),
                                                   ((4, 5, 3), (1., 1., 1.), 0, 2), ((1, 1, 1), (1., 1., 1.), 0, 0)])
