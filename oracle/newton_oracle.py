@@ -12,7 +12,7 @@ the converged solution.  This file uses the same block-triangular structure
 approximated by  S^-1 ~ M_p(1/(mu+tau))^-1 + L_p(1/(gamma rho))^-1 ) with Jacobi-preconditioned
 CG / BiCGStab as the inner solvers.  A converged Newton iteration gives the same discrete solution
 whatever the linear solver, which is what pins the oracle to the reference's SECOND time step
-(tests/beltrami_3d.output:31)."""
+(tests/beltrami_3d.output:35)."""
 import numpy as np
 
 from . import krylov_oracle as ko

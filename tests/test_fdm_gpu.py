@@ -113,7 +113,7 @@ def test_beltrami_time_step_with_fast_diagonalisation():
         assert np.hypot(*ns.history[-1]) < 1e-9
         ns.history.clear()
         ns.advance_time_step()
-        assert "%.3e" % ns.history[0][0] == "2.348e+00" and "%.3e" % ns.history[0][1] == "5.678e-02"   # beltrami_3d.output:31
+        assert "%.3e" % ns.history[0][0] == "2.348e+00" and "%.3e" % ns.history[0][1] == "5.678e-02"   # beltrami_3d.output:35
         solves, its = C.c_int64(), C.c_int64()
         _lib.check(ctx, _lib.load().adaflo_ns_preconditioner_statistics(ctx, C.byref(solves), C.byref(its)))
         stats[(inner, before)] = (its.value / max(solves.value, 1), [i for i, _ in ns.linear_iterations])

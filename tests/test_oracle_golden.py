@@ -44,7 +44,7 @@ def test_residual_distinguishes_the_convective_formulations():
 
 
 def test_second_and_third_time_step_first_residuals_match_reference_output():
-    """tests/beltrami_3d.output:31 -- time step #2 starts from the CONVERGED solution of step #1
+    """tests/beltrami_3d.output:35 -- time step #2 starts from the CONVERGED solution of step #1
     (NL tolerance 1e-9 in the reference), which no longer depends on the reference's ILU-preconditioned
     linear solver: the oracle's residual, its Jacobian (vmult with the state the residual stored),
     BDF-2 start-up weights, the shift of the old solutions and the boundary values must all be right
@@ -65,7 +65,7 @@ def test_second_and_third_time_step_first_residuals_match_reference_output():
     # quadratic convergence of the exact Newton method: 2.6 -> 9e-3 -> 2e-8
     assert len(history) == 3 and history[1][0] < 1e-2 and history[2][0] < 1e-7
     assert "%.3e" % history2[0][0] == "2.348e+00" and "%.3e" % history2[0][1] == "5.678e-02"
-    # tests/beltrami_3d.output:49 -- time step #3 (full BDF-2 weights and extrapolated start value:
+    # tests/beltrami_3d.output:57 -- time step #3 (full BDF-2 weights and extrapolated start value:
     # TimeStepping with step_no > 1) from the converged step #2
     assert "%.3e" % np.linalg.norm(ru) == "2.793e-01"
     assert "%.3e" % np.linalg.norm(rp) == "6.590e-03"
