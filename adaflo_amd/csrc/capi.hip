@@ -121,13 +121,29 @@ namespace
   // is a linearisation point stored (in either layout)?
   bool has_lin(const adaflo_ctx *ctx)
   {
-    return (ctx->lin.p && ctx->lin_generic_valid) || (ctx->lin_q2.p && ctx->lin_q2_valid);
+    return (ctx->lin.p && ctx->lin_generic_valid) || (ctx->lin_q2.p && ctx->lin_q2_valid) || ctx->hox_lin_primary;
   }
 
   // the generic copy [cell][12][q] of the state, rebuilt from the streaming copy the sweep-kernel
   // residual wrote if it is stale
   int ensure_lin_generic(adaflo_ctx *ctx)
   {
+    if (!ctx->lin_generic_valid && ctx->hox_lin_primary)
+      {
+        // the residual mode of the x-marching kernel left the state in its streaming layout only
+        const size_t count = (size_t)ctx->n_cells * ctx->nq_u * NLIN;
+        if (ctx->lin.count != count)
+          {
+            if (int e = alloc(ctx, ctx->lin, count))
+              return e;
+            if (hipMemsetAsync(ctx->lin.p, 0, count * sizeof(double), ctx->stream) != hipSuccess)
+              return ADAFLO_EHIP;
+          }
+        if (int e = hox_unconvert_state(ctx, ctx->lin.p))
+          return e;
+        ctx->lin_generic_valid = true; // (same content: lin_gen stays, the streaming copy remains current)
+        return 0;
+      }
     if (ctx->lin_generic_valid || !(ctx->lin_q2.p && ctx->lin_q2_valid) || ctx->lin_q2_varco)
       return 0;
     const size_t count = (size_t)ctx->n_cells * ctx->nq_u * NLIN;
@@ -453,7 +469,8 @@ int adaflo_ns_set_params(adaflo_ctx *ctx, const adaflo_ns_params *p)
       // layout; the frozen copy of velocity_vmult falls back to its generic form until the next
       // adaflo_ns_fix_linearization_point (its kernel would be instantiated for the NEW scheme)
       TRY(ctx, ensure_lin_prec_generic(ctx), "state re-layout failed");
-      ctx->lin_q2_valid = false;
+      ctx->lin_q2_valid    = false;
+      ctx->hox_lin_primary = false; // (the generic copy is current now; the x-marching kernel re-creates its own)
       release(ctx->lin_q2_prec);
     }
   ctx->ns = NSDev{p->physical_type, p->linearization, p->beta, p->tau_grad_div, p->density,
@@ -481,6 +498,7 @@ int adaflo_ns_set_linearization(adaflo_ctx *ctx, const double *lin, int src_on_d
   ctx->lin_q2_valid      = false;
   ctx->lin_generic_valid = true;
   ctx->lin_gen++;
+  ctx->hox_lin_primary = false;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (staging)
     (void)hipFree(staging);
@@ -727,11 +745,32 @@ int adaflo_ns_residual(adaflo_ctx *ctx, double *rhs_u, double *rhs_p, const doub
       TRY(ctx, launch_residual_finish(ctx, rhs_p, ctx->res_sum_p.p, user_p, np), "residual update failed");
       return 0;
     }
+  if (ctx->variant == 1 && hox_residual_supported(ctx))
+    {
+      // x-marching kernel in residual mode (k = 3, 4, 5): as above, the state goes out in its streaming layout
+      const long nu = 3 * ctx->n_nodes_u, np = ctx->n_nodes_p;
+      TRY(ctx, alloc(ctx, ctx->res_sum_u, nu), ctx->last_error);
+      TRY(ctx, alloc(ctx, ctx->res_sum_p, np), ctx->last_error);
+      const double *old_comb = nullptr;
+      if (ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE)
+        {
+          TRY(ctx, alloc(ctx, ctx->res_old, nu), ctx->last_error);
+          TRY(ctx, launch_lincomb(ctx, ctx->res_old.p, ctx->ns.weight_old, old_u, ctx->ns.weight_old_old, old_old_u, nu),
+              "old-solution combination failed");
+          old_comb = ctx->res_old.p;
+        }
+      TRY(ctx, launch_ns_residual_hox(ctx, ctx->res_sum_u.p, ctx->res_sum_p.p, src_u, src_p, old_comb),
+          "x-marching residual kernel launch failed");
+      TRY(ctx, launch_residual_finish(ctx, rhs_u, ctx->res_sum_u.p, user_u, nu), "residual update failed");
+      TRY(ctx, launch_residual_finish(ctx, rhs_p, ctx->res_sum_p.p, user_p, np), "residual update failed");
+      return 0;
+    }
   if (needs_lin(ctx))
     {
       TRY(ctx, alloc(ctx, ctx->lin, (size_t)ctx->n_cells * ctx->nq_u * NLIN), ctx->last_error);
       ctx->lin_generic_valid = true;
       ctx->lin_gen++;
+      ctx->hox_lin_primary = false;
     }
   NSArgs a   = make_ns_args(ctx, false);
   a.src_u    = src_u;
@@ -1701,8 +1740,8 @@ int adaflo_ls_compute_force(adaflo_ctx *ctx, double *user_rhs_u, const double *h
     return e;
   if (!user_rhs_u || !heaviside || !curvature || !p)
     return fail(ctx, ADAFLO_EINVAL, "null argument");
-  if (ctx->k > 4)
-    return fail(ctx, ADAFLO_EUNSUPPORTED, "compute_force: velocity degree <= 4");
+  if (ctx->k > 5)
+    return fail(ctx, ADAFLO_EUNSUPPORTED, "compute_force: velocity degree <= 5 (level_set_okz_template_instantations.h)");
   if (!ctx->d_tab_force)
     {
       const std::vector<double> tab = force_tables(ctx->s, ctx->k);

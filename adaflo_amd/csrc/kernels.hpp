@@ -20,6 +20,10 @@ namespace adaflo_hip
   }
   // x-marching Q_k/Q_{k-1} kernel for k = 3, 4, 5 (ns_hox.hip), constant coefficients: the default since round 4
   bool hox_supported(const adaflo_ctx *ctx);
+  bool hox_residual_supported(const adaflo_ctx *ctx);
+  int  launch_ns_residual_hox(adaflo_ctx *ctx, double *sum_u, double *sum_p, const double *src_u, const double *src_p,
+                              const double *old_comb);
+  int  hox_unconvert_state(adaflo_ctx *ctx, double *generic);
   int  launch_ns_vmult_hox(adaflo_ctx *ctx, int op, double *dst_u, double *dst_p, const double *src_u,
                            const double *src_p, int phase = -1, uint32_t iface = 0);
 } // namespace adaflo_hip

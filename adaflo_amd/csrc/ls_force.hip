@@ -245,6 +245,8 @@ namespace adaflo_hip
             return launch_force_sk<S, 3>(ctx, a);
           case 4:
             return launch_force_sk<S, 4>(ctx, a);
+          case 5: // (level_set_okz_template_instantations.h:32-80: degree_u 2..5 with every ls_degree 1..4)
+            return launch_force_sk<S, 5>(ctx, a);
           default:
             return ADAFLO_EUNSUPPORTED;
         }

@@ -602,6 +602,9 @@ namespace adaflo_hip
             case 4:
               ADV(4);
               break;
+            case 5:
+              ADV(5);
+              break;
             default:
               return ADAFLO_EUNSUPPORTED;
           }
@@ -637,6 +640,10 @@ namespace adaflo_hip
           break;
         case 4:
           hipLaunchKernelGGL((ls_max_velocity_kernel<4>), grid, block, 0, ctx->stream, vel, tab, ctx->desc.ncell[0],
+                             ctx->desc.ncell[1], ctx->desc.ncell[2], result);
+          break;
+        case 5:
+          hipLaunchKernelGGL((ls_max_velocity_kernel<5>), grid, block, 0, ctx->stream, vel, tab, ctx->desc.ncell[0],
                              ctx->desc.ncell[1], ctx->desc.ncell[2], result);
           break;
         default:

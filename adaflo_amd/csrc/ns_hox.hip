@@ -65,14 +65,16 @@ namespace adaflo_hip
       unsigned long      &have     = use_prec ? ctx->hox_lin_prec_gen : ctx->hox_lin_gen;
       int                &mode     = use_prec ? ctx->hox_lin_prec_mode : ctx->hox_lin_mode;
       const unsigned long want     = use_prec ? ctx->lin_prec_gen : ctx->lin_gen;
-      if (!gen.p)
-        return ADAFLO_ENOTINIT;
       const size_t need = state_doubles<K>(ctx, lin_mode);
       if (str.p && have == want && mode == lin_mode && str.count >= need)
         {
           *out = str.p;
           return 0;
         }
+      // (a state that exists in the streaming layout only -- written by the residual mode -- is current by
+      // construction; a change of scheme brings the generic copy up to date first, adaflo_ns_set_params)
+      if (!gen.p || (!use_prec && !ctx->lin_generic_valid))
+        return ADAFLO_ENOTINIT;
       if (int e = ensure(str, need))
         return e;
       const int  ncx = ctx->desc.ncell[0], ncy = ctx->desc.ncell[1], ncz = ctx->desc.ncell[2];
@@ -92,9 +94,11 @@ namespace adaflo_hip
     }
 
     // phase -1: the whole operator; phases 0 / 1 / 2 as in launch_ns_vmult_q2 (ns_q2.hip)
+    // residual = true: dst_u / dst_p receive the cell-loop sums, old_comb is the nodal combination of the old solutions
+    // (or null), the state is WRITTEN to ctx->hox_lin
     template <int K>
     int launch_hox(adaflo_ctx *ctx, const int op, double *dst_u, double *dst_p, const double *src_u, const double *src_p,
-                   const int phase, const uint32_t iface)
+                   const int phase, const uint32_t iface, const bool residual = false, const double *old_comb = nullptr)
     {
       using G         = Geo<K>;
       constexpr int N = K + 1;
@@ -146,9 +150,20 @@ namespace adaflo_hip
       A.src_p       = src_p;
       A.dst_u       = dst_u;
       A.dst_p       = dst_p;
-      if (int e = prepare_state<K>(ctx, op == OP_VMULT_VELOCITY, lin_mode, &A.lin))
+      if (residual)
+        {
+          A.old_u = old_comb;
+          A.c_old = old_comb ? P.density : 0.;
+          if (lin_mode != 2)
+            {
+              if (int e = ensure(ctx->hox_lin, state_doubles<K>(ctx, lin_mode)))
+                return e;
+              A.lin_out = ctx->hox_lin.p;
+            }
+        }
+      else if (int e = prepare_state<K>(ctx, op == OP_VMULT_VELOCITY, lin_mode, &A.lin))
         return e;
-      const bool   with_p = op == OP_VMULT;
+      const bool   with_p = op == OP_VMULT || residual;
       const size_t n_wg   = (size_t)A.tiles_y * A.tiles_z * A.n_chunks;
       if (int e = ensure(ctx->hox_slab_u, n_wg * G::RIMU * (K * A.LX + 1) * 3))
         return e;
@@ -215,7 +230,31 @@ namespace adaflo_hip
     if (err == hipSuccess && nwg > 0)                                                                     \
       hipLaunchKernelGGL((ns_hox_kernel<K, LM, WP>), grid, block, lds_bytes, ctx->stream, A);             \
   }
-      if (with_p)
+#define HOX_LAUNCH_RES(LM)                                                                                \
+  {                                                                                                       \
+    static bool attr_set = false;                                                                         \
+    if (!attr_set)                                                                                        \
+      {                                                                                                   \
+        err      = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_hox_kernel<K, LM, true, true>), \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);      \
+        attr_set = err == hipSuccess;                                                                     \
+      }                                                                                                   \
+    if (err == hipSuccess && nwg > 0)                                                                     \
+      hipLaunchKernelGGL((ns_hox_kernel<K, LM, true, true>), grid, block, lds_bytes, ctx->stream, A);     \
+  }
+      if (residual)
+        switch (lin_mode)
+          {
+            case 0:
+              HOX_LAUNCH_RES(0);
+              break;
+            case 1:
+              HOX_LAUNCH_RES(1);
+              break;
+            default:
+              HOX_LAUNCH_RES(2);
+          }
+      else if (with_p)
         switch (lin_mode)
           {
             case 0:
@@ -240,6 +279,7 @@ namespace adaflo_hip
               HOX_LAUNCH(2, false);
           }
 #undef HOX_LAUNCH
+#undef HOX_LAUNCH_RES
       if (err != hipSuccess)
         return ADAFLO_EHIP;
       if (stop)
@@ -270,6 +310,16 @@ namespace adaflo_hip
           }
       }
 #endif
+      if (residual && lin_mode != 2)
+        {
+          // the streaming copy is now THE state: the generic copy is stale until somebody asks for it
+          ctx->lin_gen++;
+          ctx->hox_lin_gen       = ctx->lin_gen;
+          ctx->hox_lin_mode      = lin_mode;
+          ctx->hox_lin_primary   = true;
+          ctx->lin_generic_valid = false;
+          ctx->lin_q2_valid      = false;
+        }
       if (phase == -1 || phase == 1)
         ctx->kernel_timer.count++;
       if (phase == 0)
@@ -290,6 +340,65 @@ namespace adaflo_hip
   bool hox_supported(const adaflo_ctx *ctx)
   {
     return ctx->k >= 3 && ctx->k <= 5 && !ctx->flat && !ctx->rho.p && !ctx->mu.p && !ctx->damp.p;
+  }
+
+  // schemes whose residual needs no extrapolated old velocities (navier_stokes_matrix.cc:740-782 stay on the generic kernel)
+  bool hox_residual_supported(const adaflo_ctx *ctx)
+  {
+    const int lin = ctx->ns.linearization;
+    return hox_supported(ctx) && lin != ADAFLO_PROJECTION &&
+           (ctx->ns.physical_type == ADAFLO_STOKES || lin == ADAFLO_COUPLED_IMPLICIT_NEWTON || lin == ADAFLO_COUPLED_IMPLICIT_PICARD);
+  }
+
+  int launch_ns_residual_hox(adaflo_ctx *ctx, double *sum_u, double *sum_p, const double *src_u, const double *src_p,
+                             const double *old_comb)
+  {
+    switch (ctx->k)
+      {
+        case 3:
+          return launch_hox<3>(ctx, OP_VMULT, sum_u, sum_p, src_u, src_p, -1, 0u, true, old_comb);
+        case 4:
+          return launch_hox<4>(ctx, OP_VMULT, sum_u, sum_p, src_u, src_p, -1, 0u, true, old_comb);
+        case 5:
+          return launch_hox<5>(ctx, OP_VMULT, sum_u, sum_p, src_u, src_p, -1, 0u, true, old_comb);
+        default:
+          return ADAFLO_EUNSUPPORTED;
+      }
+  }
+
+  // streaming state of the residual mode -> generic layout [cell][12][q] (entries the scheme does not store stay as they are)
+  int hox_unconvert_state(adaflo_ctx *ctx, double *generic)
+  {
+    if (!ctx->hox_lin.p || ctx->hox_lin_mode < 0 || ctx->hox_lin_mode > 1)
+      return ADAFLO_ENOTINIT;
+    const int ncx = ctx->desc.ncell[0], ncy = ctx->desc.ncell[1], ncz = ctx->desc.ncell[2], npc = nst_of(ctx->hox_lin_mode) / 2;
+#define HOX_UNCONVERT(K)                                                                                                     \
+  {                                                                                                                          \
+    using G          = Geo<K>;                                                                                               \
+    const int  ngy = (ncy + G::CWY - 1) / G::CWY, ngz = (ncz + G::CWZ - 1) / G::CWZ;                                         \
+    const long pieces = (long)ngz * ngy * ncx * G::N * npc * G::CPW * G::NL;                                                 \
+    long       nb     = (pieces + 255) / 256;                                                                                \
+    if (nb > 256 * 64)                                                                                                       \
+      nb = 256 * 64;                                                                                                         \
+    hipLaunchKernelGGL((hox_unconvert_state_kernel<K>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, generic, ctx->hox_lin.p, \
+                       ncx, ncy, ncz, ngy, ngz, npc);                                                                        \
+  }
+    switch (ctx->k)
+      {
+        case 3:
+          HOX_UNCONVERT(3);
+          break;
+        case 4:
+          HOX_UNCONVERT(4);
+          break;
+        case 5:
+          HOX_UNCONVERT(5);
+          break;
+        default:
+          return ADAFLO_EUNSUPPORTED;
+      }
+#undef HOX_UNCONVERT
+    return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
   }
 
   int launch_ns_vmult_hox(adaflo_ctx *ctx, const int op, double *dst_u, double *dst_p, const double *src_u,

@@ -107,6 +107,11 @@ namespace adaflo_hip
       uint32_t con_u, con_p;
       const double *src_u, *src_p, *lin; // lin: streaming layout of this kernel (hox_state_offset)
       double       *dst_u, *dst_p;
+      // residual mode (template RES): nodal combination weight_old u_old + weight_old_old u_old_old (or null), its
+      // factor (the density), and the streaming state the kernel WRITES for the vmults of this Newton step
+      const double *old_u;
+      double        c_old;
+      double       *lin_out;
       double       *slab_u, *xslab_u, *slab_p, *xslab_p;
       const double *tab; // Tab<K>: the 1D matrices in even / odd form and the constants of the quadrature-point operation
       // phased execution for the multi-GPU overlap (as in ns_q2.hip / ns_ho.hip)
@@ -400,7 +405,12 @@ namespace adaflo_hip
 #define HOX_LB 2
 #endif
 
-    template <int K, int LIN_MODE, bool WITH_P>
+    // RES: residual mode (source/navier_stokes_matrix.cc:266-293, 663-686, 725-800 for the schemes without
+    // extrapolated old velocities): plain reads of the current solution (boundary values included), the nonlinear
+    // quadrature-point operation, the values (u, grad u) or (u, div u) STORED as the streaming state of the next vmults
+    // instead of read; constrained rows of the sums get 0 (the scatter skips them); the driver forms
+    // rhs = user_rhs - rhs - sums.  LIN_MODE 0 / 1 / 2 = which state is written (Newton / Picard-type / none).
+    template <int K, int LIN_MODE, bool WITH_P, bool RES = false>
     __global__ __launch_bounds__(NTH, HOX_LB) void ns_hox_kernel(const HXArgs A)
     {
       using G           = Geo<K>;
@@ -408,7 +418,9 @@ namespace adaflo_hip
       constexpr int CPW = G::CPW, PL = G::PL, CY = G::CY, CZ = G::CZ, CWY = G::CWY, CWZ = G::CWZ, WY = G::WY;
       constexpr int TNY = G::TNY, TNZ = G::TNZ, TPY = G::TPY, TPZ = G::TPZ, RIMU = G::RIMU, RIMP = G::RIMP;
       constexpr int BUF = G::BUF, PUBD = G::PUBD, PUBV = G::PUBV;
-      constexpr int NST = nst_of(LIN_MODE), NPC = NST / 2;
+      constexpr int NST = RES ? 0 : nst_of(LIN_MODE), NPC = NST / 2; // state values READ per point
+      constexpr int NSO = RES ? nst_of(LIN_MODE) : 0, NPO = NSO / 2;  // ... WRITTEN per point (residual mode)
+      static_assert(!RES || WITH_P, "the residual has both blocks");
       using TB = Tab<K>;
       double *const lds = dyn_lds();
 
@@ -465,13 +477,13 @@ namespace adaflo_hip
       enum
       {
         F_OWN_U = 1, F_SEAM_U = 2, F_CON0 = 4, F_OWN_P = 32, F_SEAM_P = 64, F_PCON = 128, F_CY = 256, F_CZ = 512,
-        F_AK = 1024, F_BK = 2048, F_PTH = 4096, F_AKP = 8192, F_BKP = 16384, F_ACT = 32768
+        F_AK = 1024, F_BK = 2048, F_PTH = 4096, F_AKP = 8192, F_BKP = 16384, F_ACT = 32768, F_CELL = 65536
       };
       const unsigned flags = (own_u ? F_OWN_U : 0) | (seam_u ? F_SEAM_U : 0) | (cmask * F_CON0) | (own_p ? F_OWN_P : 0) |
                              (seam_p ? F_SEAM_P : 0) | (pcon ? F_PCON : 0) | ((active && a == 0 && cyl > 0) ? F_CY : 0) |
                              ((active && b == 0 && czl > 0) ? F_CZ : 0) | ((active && a == K) ? F_AK : 0) |
                              ((active && b == K) ? F_BK : 0) | (pth ? F_PTH : 0) | ((pth && a == KP) ? F_AKP : 0) |
-                             ((pth && b == KP) ? F_BKP : 0) | (active ? F_ACT : 0);
+                             ((pth && b == KP) ? F_BKP : 0) | (active ? F_ACT : 0) | (valid ? F_CELL : 0);
 
       const double wab = A.tab[TB::C + TB::C_DET] * A.tab[TB::C + TB::C_W + a] * A.tab[TB::C + TB::C_W + b];
 
@@ -480,9 +492,10 @@ namespace adaflo_hip
       // state: per-lane pointer to the first piece of the first cell of my row of cell groups
       // state: wave-uniform base of my wave's row of cell groups + 32-bit lane offset.  (A cell beyond the mesh reads
       // its own slot of the zero-padded group, a group beyond the mesh the last one: legal addresses, unused values.)
-      constexpr unsigned ST_PIECE = CPW * NL * 2, ST_POINT = NPC * ST_PIECE, ST_CELL = N * ST_POINT; // doubles
+      constexpr unsigned ST_PIECE = CPW * NL * 2, ST_POINT = (RES ? NPO : NPC) * ST_PIECE, ST_CELL = N * ST_POINT; // doubles
       const int          gyw = min((by * CY + (wave % WY) * CWY) / CWY, A.ngy - 1), gzw = min((bz * CZ + (wave / WY) * CWZ) / CWZ, A.ngz - 1);
       const double *const stg = A.lin + (NST > 0 ? ((size_t)gzw * A.ngy + gyw) * A.ncx * ST_CELL : 0);
+      double *const       sog = RES && NSO > 0 ? A.lin_out + ((size_t)gzw * A.ngy + gyw) * A.ncx * ST_CELL : nullptr;
       const unsigned      st_lane = (unsigned)(cw * NL + lc) * 2;
 
       // wave-private transposition buffers T0, T1, T2 and the lane's line bases in the three layouts
@@ -711,7 +724,7 @@ namespace adaflo_hip
                     for (int d = 0; d < 3; ++d)
                       if ((fl & (F_CON0 << d)) || (I0 + i == 0 && (A.con_u >> d & 1)) ||
                           (I0 + i == A.nnx - 1 && (A.con_u >> (3 + d) & 1)))
-                        A.dst_u[po + d] = A.src_u[po + d];
+                        A.dst_u[po + d] = RES ? 0. : A.src_u[po + d];
                   }
               }
             if (WITH_P && A.integrate_p && (fl & F_OWN_P) && !(fl & F_SEAM_P))
@@ -721,7 +734,7 @@ namespace adaflo_hip
                   {
                     const size_t po = (size_t)(Ip0 + i) + prow;
                     if ((fl & F_PCON) || (Ip0 + i == 0 && (A.con_p & 1)) || (Ip0 + i == A.npx - 1 && (A.con_p >> 1 & 1)))
-                      A.dst_p[po] = -A.src_p[po];
+                      A.dst_p[po] = RES ? 0. : -A.src_p[po];
                   }
               }
           }
@@ -758,7 +771,9 @@ namespace adaflo_hip
             constexpr int d = decltype(d_)::value;
 #pragma unroll
             for (int i = 0; i < N; ++i)
-              U[i] = (fl & (F_CON0 << d)) ? 0. : Un[d][i]; // read_dof_values: constrained entries read as zero
+              U[i] = (!RES && (fl & (F_CON0 << d))) ? 0. : Un[d][i]; // read_dof_values: constrained entries read as zero
+            if (RES) // (read_dof_values_plain: the boundary values take part, :662-671)
+              return;
             if (cx == 0 && (A.con_u >> d & 1))
               U[0] = 0.;
             if (cx == A.ncx - 1 && (A.con_u >> (3 + d) & 1))
@@ -767,7 +782,9 @@ namespace adaflo_hip
           auto nodal_p = [&](double (&P)[NP]) {
 #pragma unroll
             for (int i = 0; i < NP; ++i)
-              P[i] = (fl & F_PCON) ? 0. : Pn[i];
+              P[i] = (!RES && (fl & F_PCON)) ? 0. : Pn[i];
+            if (RES)
+              return;
             if (cx == 0 && (A.con_p & 1))
               P[0] = 0.;
             if (cx == A.ncx - 1 && (A.con_p >> 1 & 1))
@@ -844,9 +861,59 @@ namespace adaflo_hip
             ds_wait<0>(PQ);
             wave_sync();
           };
+          // residual mode: values of the old-solution combination at my quadrature points (interpolation is linear:
+          // weight_old u_old + weight_old_old u_old_old was formed once per node by the launcher); x, y, z, back to x-lines
+          double OQ[RES ? 3 : 1][N];
+          auto   eval_old = [&](auto d_) {
+            constexpr int d = decltype(d_)::value;
+            double        U[N], T[N], ln[N];
+            const double *po = A.old_u + (size_t)(K * cx) * 3;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+              U[i] = po[urow + i * 3 + d];
+            EoMat<N, N, 1> mS;
+            mS.load(tb(TB::S));
+            mS.template apply<false>(U, T);
+            wr_line<0, 1, N>(px, T);
+            wave_sync();
+            mS.load(tb(TB::S));
+            rd_line<0, N, N>(ay, ln);
+            ds_wait<0>(ln);
+            mS.template apply<false>(ln, T);
+            wave_sync();
+            wr_line<BUF, N, N>(py, T);
+            wave_sync();
+            mS.load(tb(TB::S));
+            rd_line<BUF, NN, N>(az, ln);
+            ds_wait<0>(ln);
+            mS.template apply<false>(ln, T);
+            wave_sync();
+            wr_line<0, NN, N>(pz, T);
+            wave_sync();
+            rd_line<0, 1, N>(ax, OQ[RES ? d : 0]);
+            ds_wait<0>(OQ[RES ? d : 0]);
+            wave_sync();
+          };
           using I0_ = std::integral_constant<int, 0>;
           using I1_ = std::integral_constant<int, 1>;
           using I2_ = std::integral_constant<int, 2>;
+          if constexpr (RES)
+            {
+              if (A.old_u) // (wave-uniform)
+                {
+                  eval_old(I0_{});
+                  eval_old(I1_{});
+                  eval_old(I2_{});
+                }
+              else
+                {
+#pragma unroll
+                  for (int d = 0; d < 3; ++d)
+#pragma unroll
+                    for (int i = 0; i < N; ++i)
+                      OQ[d][i] = 0.;
+                }
+            }
           eval_single(I0_{});
           eval_single(I1_{});
           eval_single(I2_{});
@@ -897,7 +964,17 @@ namespace adaflo_hip
               for (int d = 0; d < 3; ++d)
                 {
                   double res = 0.;
-                  if constexpr (LIN_MODE == 0) // Newton :802-816; st = (u_lin[3], grad u_lin[3][3])
+                  if constexpr (RES) // :783-799 the nonlinear term of the solution itself (no extrapolation)
+                    {
+                      if constexpr (LIN_MODE != 2)
+                        {
+                          res = cst[TB::C_BETA] * div * u[d];
+#pragma unroll
+                          for (int e = 0; e < 3; ++e)
+                            res += u[e] * g[d][e];
+                        }
+                    }
+                  else if constexpr (LIN_MODE == 0) // Newton :802-816; st = (u_lin[3], grad u_lin[3][3])
                     {
                       res = cst[TB::C_BETA] * (div * st[d] + (st[3] + st[7] + st[11]) * u[d]);
 #pragma unroll
@@ -911,7 +988,30 @@ namespace adaflo_hip
                       for (int e = 0; e < 3; ++e)
                         res += st[e] * g[d][e];
                     }
-                  conv[d] = (cst[TB::C_CA] * u[d] + cst[TB::C_CB] * res) * jxw; // :717,:827-835
+                  if constexpr (RES) // :717-732 with the time derivative of BDF: weight u + (weight_old u_old + ...)
+                    conv[d] = (cst[TB::C_CA] * u[d] + A.c_old * OQ[d][i] + cst[TB::C_CB] * res) * jxw;
+                  else
+                    conv[d] = (cst[TB::C_CA] * u[d] + cst[TB::C_CB] * res) * jxw; // :717,:827-835
+                }
+              if constexpr (RES && NSO > 0)
+                {
+                  // the state of the vmults to come, in their streaming layout: piece e = values (2 e, 2 e + 1) of
+                  // (u, grad u) row-major (Newton) or (u, div u) (Picard-type); cells beyond the mesh store nothing
+                  if (fl & F_CELL)
+                    {
+                      double *const so = sog + ((size_t)cx * ST_CELL + (unsigned)(i * ST_POINT) + st_lane);
+                      so[0] = u[0], so[1] = u[1];
+                      if constexpr (LIN_MODE == 0)
+                        {
+                          so[ST_PIECE] = u[2], so[ST_PIECE + 1] = g[0][0];
+                          so[2 * ST_PIECE] = g[0][1], so[2 * ST_PIECE + 1] = g[0][2];
+                          so[3 * ST_PIECE] = g[1][0], so[3 * ST_PIECE + 1] = g[1][1];
+                          so[4 * ST_PIECE] = g[1][2], so[4 * ST_PIECE + 1] = g[2][0];
+                          so[5 * ST_PIECE] = g[2][1], so[5 * ST_PIECE + 1] = g[2][2];
+                        }
+                      else
+                        so[ST_PIECE] = u[2], so[ST_PIECE + 1] = div;
+                    }
                 }
               if (NST > 0 && i + 1 < N && !(HOX_EXP & 4) && !RING)
                 {
@@ -1194,6 +1294,40 @@ namespace adaflo_hip
             }
           out[2 * it]     = v0;
           out[2 * it + 1] = v1;
+        }
+    }
+    // ... and back (the residual mode leaves the state in the streaming layout only; the generic copy is rebuilt on
+    // demand: adaflo_ns_get_linearization, generic kernels, the velocity-block diagonal)
+    template <int K>
+    __global__ __launch_bounds__(256) void hox_unconvert_state_kernel(double *generic, const double *in, const int ncx,
+                                                                      const int ncy, const int ncz, const int ngy,
+                                                                      const int ngz, const int npc)
+    {
+      using G          = Geo<K>;
+      constexpr int N = G::N, NL = G::NL, N3 = G::N3, CPW = G::CPW;
+      const long    total = (long)ngz * ngy * ncx * N * npc * CPW * NL;
+      for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x)
+        {
+          long      r = it;
+          const int l = (int)(r % NL);
+          r /= NL;
+          const int scw = (int)(r % CPW);
+          r /= CPW;
+          const int piece = (int)(r % npc);
+          r /= npc;
+          const int i = (int)(r % N);
+          r /= N;
+          const int cx = (int)(r % ncx);
+          r /= ncx;
+          const int gy = (int)(r % ngy), gz = (int)(r / ngy);
+          const int cy = gy * G::CWY + scw % G::CWY, cz = gz * G::CWZ + scw / G::CWY;
+          if (cy < ncy && cz < ncz)
+            {
+              const size_t cellg = ((size_t)cz * ncy + cy) * ncx + cx;
+              const int    q     = ((l / N) * N + l % N) * N + i;
+              generic[(cellg * NLIN_ + 2 * piece) * N3 + q]     = in[2 * it];
+              generic[(cellg * NLIN_ + 2 * piece + 1) * N3 + q] = in[2 * it + 1];
+            }
         }
     }
   } // namespace hox

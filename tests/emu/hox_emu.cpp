@@ -112,6 +112,77 @@ namespace
   }
 } // namespace
 
+namespace
+{
+  // residual mode: cell-loop sums, and the state the kernel wrote (converted back to the generic layout)
+  template <int K>
+  int run_residual(const int *ncell, const double *h, const int lin_mode, const double *coef, const double c_old,
+                   const unsigned con_u, const unsigned con_p, const double *src_u, const double *src_p,
+                   const double *old_comb, double *sum_u, double *sum_p, double *lin_generic, const int lx)
+  {
+    using G         = Geo<K>;
+    constexpr int N = K + 1;
+    HXArgs        A{};
+    hox_geometry<K>(A, ncell, lx);
+    std::vector<double> tab;
+    {
+      const Quadrature1D        qu = gauss(N);
+      const Shape1D             su = shape_fe_q(K, qu), sp = shape_fe_q(K - 1, qu);
+      const std::vector<double> dc = collocation_derivative(qu);
+      tab = hox_table<K>(su.S.data(), dc.data(), sp.S.data(), qu.w.data(), h, coef[0], coef[1], coef[2], coef[3], coef[4]);
+    }
+    A.tab         = tab.data();
+    A.integrate_p = 1;
+    A.con_u       = con_u;
+    A.con_p       = con_p;
+    A.src_u       = src_u;
+    A.src_p       = src_p;
+    A.dst_u       = sum_u;
+    A.dst_p       = sum_p;
+    A.old_u       = old_comb;
+    A.c_old       = c_old;
+    const int           npc = nst_of(lin_mode) / 2;
+    std::vector<double> state((size_t)A.ngz * A.ngy * A.ncx * N * npc * G::CPW * G::NL * 2 + 2, std::nan(""));
+    A.lin_out = state.data();
+    const size_t        n_wg = (size_t)A.tiles_y * A.tiles_z * A.n_chunks;
+    const double        nan  = std::nan("");
+    std::vector<double> slab_u(n_wg * G::RIMU * (K * A.LX + 1) * 3, nan), xslab_u(n_wg * G::TNY * G::TNZ * 3, nan),
+      slab_p(n_wg * G::RIMP * ((K - 1) * A.LX + 1), nan), xslab_p(n_wg * G::TPY * G::TPZ, nan);
+    A.slab_u  = slab_u.data();
+    A.xslab_u = xslab_u.data();
+    A.slab_p  = slab_p.data();
+    A.xslab_p = xslab_p.data();
+    if (lin_mode == 0)
+      emu::launch((unsigned)n_wg, NTH, [&] { ns_hox_kernel<K, 0, true, true>(A); });
+    else if (lin_mode == 1)
+      emu::launch((unsigned)n_wg, NTH, [&] { ns_hox_kernel<K, 1, true, true>(A); });
+    else
+      emu::launch((unsigned)n_wg, NTH, [&] { ns_hox_kernel<K, 2, true, true>(A); });
+    if (hox_fix_items(A, true) > 0)
+      emu::launch(3, 256, [&] { ns_hox_fixup_kernel<K>(A, 1); });
+    if (npc > 0)
+      emu::launch(4, 256, [&] { hox_unconvert_state_kernel<K>(lin_generic, state.data(), A.ncx, A.ncy, A.ncz, A.ngy, A.ngz, npc); });
+    return 0;
+  }
+} // namespace
+
+extern "C" int hox_emu_residual(const int K, const int *ncell, const double *h, const int lin_mode, const double *coef,
+                                const double c_old, const unsigned con_u, const unsigned con_p, const double *src_u,
+                                const double *src_p, const double *old_comb, double *sum_u, double *sum_p,
+                                double *lin_generic, const int lx)
+{
+  switch (K)
+    {
+      case 3:
+        return run_residual<3>(ncell, h, lin_mode, coef, c_old, con_u, con_p, src_u, src_p, old_comb, sum_u, sum_p, lin_generic, lx);
+      case 4:
+        return run_residual<4>(ncell, h, lin_mode, coef, c_old, con_u, con_p, src_u, src_p, old_comb, sum_u, sum_p, lin_generic, lx);
+      case 5:
+        return run_residual<5>(ncell, h, lin_mode, coef, c_old, con_u, con_p, src_u, src_p, old_comb, sum_u, sum_p, lin_generic, lx);
+    }
+  return -1;
+}
+
 extern "C" int hox_emu_vmult(const int K, const int *ncell, const double *h, const int op, const int lin_mode,
                              const int integrate_p, const double *coef, const unsigned con_u, const unsigned con_p,
                              const double *lin_generic, const double *src_u, const double *src_p, double *dst_u,

@@ -96,3 +96,38 @@ def test_emulated_partial_constraints_and_velocity_block(emu):
 def test_emulated_phased_schedule(emu, iface):
     eu, ep = run_emulated(emu, Case((6, 5, 9), k=4), lx=2, iface=iface, phased=1)
     assert eu < TOL and ep < TOL, (eu, ep)
+
+
+@pytest.mark.parametrize("k,ncell,lx,lin,phys", [(4, (3, 2, 5), 2, 0, 0), (4, (2, 3, 4), 0, 1, 0), (3, (3, 5, 5), 2, 0, 0),
+                                                  (5, (2, 3, 2), 1, 0, 0), (4, (3, 3, 2), 0, 0, 1), (4, (2, 2, 5), 1, 0, 2)])
+def test_emulated_residual_mode(emu, k, ncell, lx, lin, phys):
+    """residual mode of the same kernel (template RES): cell-loop sums against the oracle's residual (which returns
+    -sums), the state it stores in the streaming layout (converted back), BDF-2 history, partial constraints whose
+    boundary values are read plainly, stationary and Stokes equations, Picard-type state"""
+    case = Case(ncell, k=k, faces_u=[0, 3, 4, 5], faces_p=[1], linearization=lin, physical_type=phys, tau_grad_div=0.3,
+                damping=0.2, density=1.3, steps=3)
+    prm = case.prm
+    src_u, src_p, old_u, oo_u = case.random_u(), case.random_p(), case.random_u(), case.random_u()
+    lin_ref = np.zeros(case.n_cells * case.nq * 12)
+    ref_u, ref_p = orc.ns_residual(case.mesh, k, prm, src_u, src_p, old_u, oo_u, con_u=case.con_u, con_p=case.con_p,
+                                   lin=lin_ref)
+    stokes = prm.physical_type == 2
+    lin_mode = 2 if stokes else (0 if prm.linearization == 0 else 1)
+    gamma = prm.weight if prm.physical_type == 0 else 0.0
+    coef = np.array([0.0 if stokes else gamma * prm.density - prm.damping, 0.0 if stokes else prm.tau1 * prm.density,
+                     prm.beta, prm.tau_grad_div, prm.viscosity * prm.tau1])
+    old_comb = prm.weight_old * old_u + prm.weight_old_old * oo_u if prm.physical_type == 0 else None
+    sum_u, sum_p = np.full(case.n_u, np.nan), np.full(case.n_p, np.nan)
+    lin_generic = np.zeros(case.n_cells * 12 * case.nq)
+    dp = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+    emu.hox_emu_residual.restype = C.c_int
+    rc = emu.hox_emu_residual(k, (C.c_int * 3)(*case.ncell), (C.c_double * 3)(*[case.mesh.h[d] for d in range(3)]), lin_mode,
+                              dp(coef), C.c_double(prm.density if prm.physical_type == 0 else 0.0),
+                              face_bits(case.faces_u, 3), face_bits(case.faces_p, 1), dp(src_u), dp(src_p), dp(old_comb),
+                              dp(sum_u), dp(sum_p), dp(lin_generic), lx if lx else case.ncell[0])
+    assert rc == 0
+    assert rel_l2(-sum_u, ref_u) < TOL and rel_l2(-sum_p, ref_p) < TOL
+    if lin_mode != 2:
+        got = lin_generic.reshape(case.n_cells, 12, case.nq).transpose(0, 2, 1)
+        ncomp = 12 if lin_mode == 0 else 4
+        assert rel_l2(got[:, :, :ncomp], lin_ref.reshape(case.n_cells, case.nq, 12)[:, :, :ncomp]) < TOL

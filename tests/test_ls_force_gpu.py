@@ -36,7 +36,8 @@ def test_compute_heaviside(s, k, ncell, eps):
 
 
 @pytest.mark.parametrize("on_pressure", [True, False])
-@pytest.mark.parametrize("s,k,ncell", [(4, 2, (3, 2, 3)), (2, 2, (4, 4, 3)), (2, 3, (3, 2, 2)), (1, 4, (2, 2, 2))])
+@pytest.mark.parametrize("s,k,ncell", [(4, 2, (3, 2, 3)), (2, 2, (4, 4, 3)), (2, 3, (3, 2, 2)), (1, 4, (2, 2, 2)),
+                                       (3, 5, (2, 2, 2)), (4, 5, (2, 1, 2))])
 def test_compute_force_and_variable_parameters(s, k, ncell, on_pressure):
     mesh, bmesh, fp = setup(ncell, s, k, surface_tension=0.7, gravity=9.81, density=1.2, density_diff=-0.7,
                             viscosity=0.05, viscosity_diff=0.2, interpolate_grad_onto_pressure=on_pressure)

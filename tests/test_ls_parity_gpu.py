@@ -157,7 +157,9 @@ def test_reinitialization_vmult_recomputes_the_normal_from_the_nodal_field(s, nc
 
 
 @pytest.mark.parametrize("s,k,ncell,faces", [(3, 2, (7, 6, 5), ()), (3, 3, (6, 7, 3), (1, 2)), (4, 4, (5, 3, 2), ()),
-                                             (1, 3, (18, 17, 6), (0,)), (2, 4, (9, 2, 3), (4, 5))])
+                                             (1, 3, (18, 17, 6), (0,)), (2, 4, (9, 2, 3), (4, 5)),
+                                             # velocity degree 5 (level_set_okz_template_instantations.h: 2 .. 5): generic kernels
+                                             (2, 5, (3, 2, 3), (1,)), (4, 5, (2, 2, 2), ())])
 def test_sweep_right_hand_sides_unaligned_tiles_and_velocity_degrees(s, k, ncell, faces):
     """advection / reinitialisation right-hand sides on the sweep structure (csrc/q1_sweep.hip) where the 16 x 16
     sub-cell tiles are not aligned with the cells (s = 3) and for velocity degrees 3 and 4: the velocity patch of
@@ -175,6 +177,8 @@ def test_sweep_right_hand_sides_unaligned_tiles_and_velocity_degrees(s, k, ncell
                                             c.ops.velocity_vector(vel), use_oo)
         assert rel_l2(d.numpy(), ref) < TOL
         assert rel_l2(adv.evaluated_convection, uq_ref) < TOL
+    vmax = adv.get_maximal_velocity(c.ops.velocity_vector(vel))
+    assert abs(vmax - orc.ls_max_velocity(c.mesh, k, vel)) < 1e-13 * vmax
     # the operator reads the state the right-hand side left in sweep layout
     src, dst = c.rand(), c.ops.vector()
     adv.advance_concentration_vmult(dst, c.ops.vector(src))

@@ -539,6 +539,64 @@ def test_velocity_vmult_high_order_x_marching_kernel():
     assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL
 
 
+@pytest.mark.parametrize("k,ncell,lin,phys,chunk", [(4, (5, 4, 9), 0, 0, 0), (4, (9, 3, 2), 1, 0, 4), (3, (6, 5, 5), 0, 0, 2),
+                                                    (5, (3, 2, 3), 0, 0, 0), (4, (4, 4, 4), 0, 1, 0), (4, (3, 5, 2), 0, 2, 1),
+                                                    (3, (4, 4, 3), 1, 0, 0)])
+def test_residual_x_marching_kernel(k, ncell, lin, phys, chunk):
+    """residual mode of the Q3..Q5 x-marching kernel (round 4; navier_stokes_matrix.cc:266-293, 663-686, 725-800): the
+    right-hand side with the read-modify-write semantics of the reference, partial constraints whose boundary values are
+    read plainly, the state it leaves in the STREAMING layout only -- read back through the generic one, used by the
+    next vmult, frozen by fix_linearization_point while a later residual replaces it --, Picard-type state, stationary
+    and Stokes equations; the generic kernel on the same inputs"""
+    case = Case(ncell, k=k, lower=(0., 0., 0.), upper=(1., 1.5, 1.), faces_u=[0, 2, 3, 5], faces_p=[1],
+                linearization=lin, physical_type=phys, tau_grad_div=0.2, damping=0.1, density=1.2, steps=3)
+    src_u, src_p = case.smooth_u(0.1) + 0.01 * case.random_u(), case.smooth_p(0.1)
+    old_u, oldold_u = case.smooth_u(0.05), case.smooth_u(0.0)
+    rhs0_u, rhs0_p, usr_u, usr_p = case.random_u(), case.random_p(), case.random_u(), case.random_p()
+    lin_ref = np.zeros(case.n_cells * case.nq * 12)
+    ref_u, ref_p = orc.ns_residual(case.mesh, k, case.prm, src_u, src_p, old_u, oldold_u, con_u=case.con_u, con_p=case.con_p,
+                                   lin=lin_ref, rhs_u=rhs0_u, rhs_p=rhs0_p, user_u=usr_u, user_p=usr_p)
+    vm_u, vm_p = case.random_u(), case.random_p()
+    w, modes = case.weights_modes()
+    ref_vu, ref_vp = orc.ns_vmult(case.mesh, k, case.prm, vm_u, vm_p, case.con_u, case.con_p, lin=lin_ref,
+                                  weights=w, modes=modes)
+    for variant in (1, 0):
+        op = case.engine()
+        op.set_kernel_variant(variant)
+        op.set_x_chunk(chunk)
+        rhs = op.block_vector(rhs0_u, rhs0_p)
+        op.residual(rhs, op.block_vector(src_u, src_p), op.block_vector(usr_u, usr_p), op.block_vector(old_u),
+                    op.block_vector(oldold_u))
+        got_u, got_p = rhs.numpy()
+        assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL, (variant, rel_l2(got_u, ref_u), rel_l2(got_p, ref_p))
+        dst = op.block_vector()
+        op.vmult(dst, op.block_vector(vm_u, vm_p))      # on the state the residual wrote
+        gu, gp = dst.numpy()
+        assert rel_l2(gu, ref_vu) < TOL and rel_l2(gp, ref_vp) < TOL, (variant, rel_l2(gu, ref_vu))
+        if phys != 2:
+            ncomp = 12 if lin == 0 else 4
+            got_lin = op.get_linearization().reshape(-1, 12)
+            assert rel_l2(got_lin[:, :ncomp], lin_ref.reshape(-1, 12)[:, :ncomp]) < TOL
+            op.vmult(dst, op.block_vector(vm_u, vm_p))  # (the streaming copy is still the current one)
+            gu, gp = dst.numpy()
+            assert rel_l2(gu, ref_vu) < TOL and rel_l2(gp, ref_vp) < TOL
+            # frozen state of the preconditioner: velocity_vmult keeps using it after a new residual
+            op.fix_linearization_point()
+            ref_vel = orc.ns_velocity_vmult(case.mesh, k, case.prm, vm_u, case.con_u, lin=lin_ref)
+            op.residual(rhs, op.block_vector(0.5 * src_u, src_p), None, op.block_vector(old_u), op.block_vector(oldold_u))
+            vsrc, vdst = op.initialize_u_vector(vm_u), op.initialize_u_vector()
+            op.velocity_vmult(vdst, vsrc)
+            assert rel_l2(vdst.numpy(), ref_vel) < TOL, variant
+            # ... and vmult uses the NEW state
+            lin2 = np.zeros_like(lin_ref)
+            orc.ns_residual(case.mesh, k, case.prm, 0.5 * src_u, src_p, old_u, oldold_u, con_u=case.con_u, con_p=case.con_p,
+                            lin=lin2)
+            r2u, r2p = orc.ns_vmult(case.mesh, k, case.prm, vm_u, vm_p, case.con_u, case.con_p, lin=lin2, weights=w, modes=modes)
+            op.vmult(dst, op.block_vector(vm_u, vm_p))
+            gu, gp = dst.numpy()
+            assert rel_l2(gu, r2u) < TOL and rel_l2(gp, r2p) < TOL, variant
+
+
 @pytest.mark.parametrize("k", [2, 4])
 def test_change_of_scheme_after_the_state_was_frozen(k):
     """adaflo_ns_set_params with another linearisation while streaming copies of the state exist (the sweep kernels
