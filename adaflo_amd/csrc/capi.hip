@@ -162,6 +162,21 @@ namespace
   }
   int ensure_lin_prec_generic(adaflo_ctx *ctx)
   {
+    if (!ctx->lin_prec_generic_valid && ctx->hox_lin_prec_primary)
+      {
+        const size_t count = (size_t)ctx->n_cells * ctx->nq_u * NLIN;
+        if (ctx->lin_prec.count != count)
+          {
+            if (int e = alloc(ctx, ctx->lin_prec, count))
+              return e;
+            if (hipMemsetAsync(ctx->lin_prec.p, 0, count * sizeof(double), ctx->stream) != hipSuccess)
+              return ADAFLO_EHIP;
+          }
+        if (int e = hox_unconvert_state(ctx, ctx->lin_prec.p, true))
+          return e;
+        ctx->lin_prec_generic_valid = true;
+        return 0;
+      }
     if (ctx->lin_prec_generic_valid || !ctx->lin_q2_prec.p || ctx->lin_q2_prec_varco)
       return 0;
     const size_t count = (size_t)ctx->n_cells * ctx->nq_u * NLIN;
@@ -470,7 +485,8 @@ int adaflo_ns_set_params(adaflo_ctx *ctx, const adaflo_ns_params *p)
       // adaflo_ns_fix_linearization_point (its kernel would be instantiated for the NEW scheme)
       TRY(ctx, ensure_lin_prec_generic(ctx), "state re-layout failed");
       ctx->lin_q2_valid    = false;
-      ctx->hox_lin_primary = false; // (the generic copy is current now; the x-marching kernel re-creates its own)
+      ctx->hox_lin_primary      = false; // (the generic copies are current now; the x-marching kernel re-creates its own)
+      ctx->hox_lin_prec_primary = false;
       release(ctx->lin_q2_prec);
     }
   ctx->ns = NSDev{p->physical_type, p->linearization, p->beta, p->tau_grad_div, p->density,
@@ -584,6 +600,24 @@ int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx)
   // from it on demand (ensure_lin_prec_generic)
   const bool streaming_only = ctx->variant >= 1 && q2_supported(ctx) && needs_lin(ctx) && ctx->lin_q2.p &&
                               ctx->lin_q2_valid && !ctx->lin_q2_varco;
+  if (ctx->variant == 1 && hox_supported(ctx) && needs_lin(ctx) && ctx->hox_lin_primary && !ctx->lin_generic_valid)
+    {
+      // the state exists in the streaming layout of the x-marching kernel only (its residual mode wrote it): freeze
+      // that copy; the generic frozen copy is rebuilt from it on demand (ensure_lin_prec_generic)
+      TRY(ctx, alloc(ctx, ctx->hox_lin_prec, ctx->hox_lin.count), ctx->last_error);
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->hox_lin_prec.p, ctx->hox_lin.p, ctx->hox_lin.count * sizeof(double),
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+      ctx->lin_prec_gen++;
+      ctx->hox_lin_prec_gen       = ctx->lin_prec_gen;
+      ctx->hox_lin_prec_mode      = ctx->hox_lin_mode;
+      ctx->hox_lin_prec_primary   = true;
+      ctx->lin_prec_generic_valid = false;
+      release(ctx->rho_prec), release(ctx->mu_prec), release(ctx->damp_prec); // (hox_supported: no variable coefficients)
+      release(ctx->lin_q2_prec);
+      ctx->q1_poisson_src = nullptr;
+      return 0;
+    }
+  ctx->hox_lin_prec_primary    = false;
   const DeviceBuffer *src[4] = {&ctx->lin, &ctx->rho, &ctx->mu, &ctx->damp};
   DeviceBuffer       *dst[4] = {&ctx->lin_prec, &ctx->rho_prec, &ctx->mu_prec, &ctx->damp_prec};
   if (!streaming_only)

@@ -123,6 +123,7 @@ struct adaflo_ctx
   unsigned long            lin_gen = 1, lin_prec_gen = 1, hox_lin_gen = 0, hox_lin_prec_gen = 0;
   int                      hox_lin_mode = -1, hox_lin_prec_mode = -1;
   bool                     hox_lin_primary = false; // hox_lin (written by the residual mode) is THE state, `lin` is stale
+  bool                     hox_lin_prec_primary = false; // ... and its frozen copy exists in the streaming layout only
   std::vector<double>      hox_tab_host; // what hox_tab holds
   int                      hox_lx = 0; // x-chunk length override (0 = heuristic)
   int                     *hox_wg_list = nullptr;

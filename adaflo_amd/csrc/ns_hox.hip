@@ -59,7 +59,7 @@ namespace adaflo_hip
       *out    = nullptr;
       if (lin_mode == 2)
         return 0;
-      const bool          use_prec = prec && ctx->lin_prec.p;
+      const bool          use_prec = prec && (ctx->lin_prec.p || ctx->hox_lin_prec_primary);
       const DeviceBuffer &gen      = use_prec ? ctx->lin_prec : ctx->lin;
       DeviceBuffer       &str      = use_prec ? ctx->hox_lin_prec : ctx->hox_lin;
       unsigned long      &have     = use_prec ? ctx->hox_lin_prec_gen : ctx->hox_lin_gen;
@@ -73,7 +73,7 @@ namespace adaflo_hip
         }
       // (a state that exists in the streaming layout only -- written by the residual mode -- is current by
       // construction; a change of scheme brings the generic copy up to date first, adaflo_ns_set_params)
-      if (!gen.p || (!use_prec && !ctx->lin_generic_valid))
+      if (!gen.p || !(use_prec ? ctx->lin_prec_generic_valid : ctx->lin_generic_valid))
         return ADAFLO_ENOTINIT;
       if (int e = ensure(str, need))
         return e;
@@ -367,11 +367,13 @@ namespace adaflo_hip
   }
 
   // streaming state of the residual mode -> generic layout [cell][12][q] (entries the scheme does not store stay as they are)
-  int hox_unconvert_state(adaflo_ctx *ctx, double *generic)
+  int hox_unconvert_state(adaflo_ctx *ctx, double *generic, const bool frozen_copy)
   {
-    if (!ctx->hox_lin.p || ctx->hox_lin_mode < 0 || ctx->hox_lin_mode > 1)
+    const double *const src  = frozen_copy ? ctx->hox_lin_prec.p : ctx->hox_lin.p;
+    const int           mode = frozen_copy ? ctx->hox_lin_prec_mode : ctx->hox_lin_mode;
+    if (!src || mode < 0 || mode > 1)
       return ADAFLO_ENOTINIT;
-    const int ncx = ctx->desc.ncell[0], ncy = ctx->desc.ncell[1], ncz = ctx->desc.ncell[2], npc = nst_of(ctx->hox_lin_mode) / 2;
+    const int ncx = ctx->desc.ncell[0], ncy = ctx->desc.ncell[1], ncz = ctx->desc.ncell[2], npc = nst_of(mode) / 2;
 #define HOX_UNCONVERT(K)                                                                                                     \
   {                                                                                                                          \
     using G          = Geo<K>;                                                                                               \
@@ -380,7 +382,7 @@ namespace adaflo_hip
     long       nb     = (pieces + 255) / 256;                                                                                \
     if (nb > 256 * 64)                                                                                                       \
       nb = 256 * 64;                                                                                                         \
-    hipLaunchKernelGGL((hox_unconvert_state_kernel<K>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, generic, ctx->hox_lin.p, \
+    hipLaunchKernelGGL((hox_unconvert_state_kernel<K>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, generic, src,            \
                        ncx, ncy, ncz, ngy, ngz, npc);                                                                        \
   }
     switch (ctx->k)

@@ -120,3 +120,42 @@ def test_nonlinear_solver_control_flow_follows_the_reference():
         assert ns.linear_iterations[0][1] < 0.5 * 1e-9 * 1.0001
     with pytest.raises(NotImplementedError):
         make("projection")
+
+
+@pytest.mark.parametrize("k,n", [(4, 6), (3, 8)])
+def test_high_order_time_steps_on_the_x_marching_kernels(k, n):
+    """Taylor-Hood Q4/Q3 and Q3/Q2 through the Navier-Stokes driver: residual (x-marching kernel in residual mode: the
+    state goes out in the streaming layout only), Newton on that state, frozen copy for the velocity block of the
+    preconditioner.  Two implicit Beltrami steps converge; the residual the device computes at the start of step #3
+    (BDF-2 history of two converged steps) equals the oracle's residual of the same vectors"""
+    from oracle import oracle as orc
+    nu = 1.0
+    fp = adaflo_amd.FlowParameters(velocity_degree=k, viscosity=nu, time_step_size_start=0.05, end_time=1.0,
+                                   max_nl_iteration=10, tol_nl_iteration=1e-9, max_lin_iteration=200, tol_lin_iteration=1e-5)
+    mesh = adaflo_amd.BrickMesh([n] * 3, [-1.0] * 3, [1.0] * 3)
+    ts = adaflo_amd.TimeStepping(fp)
+    ns = NavierStokes(fp, mesh, ts, dirichlet_function=lambda x, t: beltrami.velocity(x, t, nu))
+    xu, xp = node_coordinates(mesh, k), node_coordinates(mesh, k - 1)
+    ns.set_initial_condition(beltrami.velocity(xu, 0.0, nu).reshape(-1), beltrami.pressure(xp, 0.0, nu))
+    for step in range(2):
+        ns.history.clear()
+        n_newton, _ = ns.advance_time_step()
+        assert np.hypot(*ns.history[-1]) < 1e-9 and n_newton <= 6, ns.history
+    err = np.abs(ns.solution[0].cpu().numpy() - beltrami.velocity(xu, ts.now(), nu).reshape(-1)).max()
+    assert err < 1e-2, err          # (sanity: the BDF start-up error of dt = 0.05 dominates, 7.5e-4 in L2 for the reference's run)
+    ns.history.clear()
+    ns.init_time_advance()
+    ns.compute_residual()
+    omesh = orc.Mesh.make([n] * 3, [-1.0] * 3, [1.0] * 3)
+    prm = orc.NSParams.make(beta=0.5, viscosity=nu, weight=ts.weight(), weight_old=ts.weight_old(),
+                            weight_old_old=ts.weight_old_old(), tau1=ts.tau1(), extrap_old=ts.factor_extrapol_old,
+                            extrap_old_old=ts.factor_extrapol_old_old)
+    to_np = lambda t: t.cpu().numpy()
+    ru, rp = orc.ns_residual(omesh, k, prm, to_np(ns.solution[0]), to_np(ns.solution[1]), to_np(ns.solution_old[0]),
+                             to_np(ns.solution_old_old[0]), con_u=orc.boundary_mask(omesh, k, 3),
+                             lin=np.zeros(omesh.n_cells * (k + 1) ** 3 * 12))
+    w = orc.ns_pressure_mass_weight(omesh, k)
+    rp = orc.ns_pressure_projection(rp, w, np.ones_like(w))
+    assert abs(ns.history[0][0] - np.linalg.norm(ru)) < 1e-10 * np.linalg.norm(ru)
+    assert abs(ns.history[0][1] - np.linalg.norm(rp)) < 1e-9 * np.linalg.norm(rp)
+    assert np.linalg.norm(to_np(ns.system_rhs[0]) - ru) < 1e-10 * np.linalg.norm(ru)

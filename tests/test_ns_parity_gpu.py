@@ -595,6 +595,12 @@ def test_residual_x_marching_kernel(k, ncell, lin, phys, chunk):
             op.vmult(dst, op.block_vector(vm_u, vm_p))
             gu, gp = dst.numpy()
             assert rel_l2(gu, r2u) < TOL and rel_l2(gp, r2p) < TOL, variant
+            op.set_kernel_variant(0)                      # generic kernel on the frozen streaming copy
+            op.velocity_vmult(vdst, vsrc)
+            assert rel_l2(vdst.numpy(), ref_vel) < TOL, variant
+            op.vmult(dst, op.block_vector(vm_u, vm_p))
+            gu, gp = dst.numpy()
+            assert rel_l2(gu, r2u) < TOL and rel_l2(gp, r2p) < TOL, variant
 
 
 @pytest.mark.parametrize("k", [2, 4])
