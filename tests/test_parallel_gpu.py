@@ -182,9 +182,10 @@ def _run_distributed_case(world, cells, k=2, two_phase=False):
     # 0 in 25 with GPU_MAX_HW_QUEUES=1 (one hardware queue per process instead of four).  The deaths need more
     # processes / hardware queues on one device than the driver keeps resident (it then preempts running waves to
     # time-slice them), a condition the product never creates.  So the 8-process jobs run with one hardware queue
-    # per process; a death by SIGNAL is still reported loudly (warning + breadcrumbs of what every rank was doing),
-    # that run is repeated ONCE and a second death fails the test.  Python exceptions in a rank (wrong numbers, engine
-    # errors) arrive as ProcessRaisedException and are never retried.
+    # per process; a death by SIGNAL is still reported loudly (warning + breadcrumbs of what every rank was doing).  It
+    # is repeated ONCE, and only if the dead rank had not yet applied an operator (no breadcrumb: the observed deaths);
+    # a rank that dies after it started operator applications fails the test at once, as does a second death.  Python
+    # exceptions in a rank (wrong numbers, engine errors) arrive as ProcessRaisedException and are never retried.
     saved_queues = os.environ.get("GPU_MAX_HW_QUEUES")
     if world >= 8 and "ADAFLO_TEST_KEEP_QUEUES" not in os.environ:
         os.environ["GPU_MAX_HW_QUEUES"] = "1"          # read by the HIP runtime of the spawned ranks
@@ -200,10 +201,14 @@ def _run_distributed_case(world, cells, k=2, two_phase=False):
                 global RANK_DEATHS
                 RANK_DEATHS += 1
                 import warnings
+                where = dict(crumbs)
                 warnings.warn("a rank of the %d-process job died by signal (%s); death number %d of this session, attempt "
-                              "%d; the ranks were at: %s" % (world, e, RANK_DEATHS, attempt + 1, dict(crumbs)),
-                              RuntimeWarning)
-                if attempt == 1:
+                              "%d; the ranks were at: %s" % (world, e, RANK_DEATHS, attempt + 1, where), RuntimeWarning)
+                # only a death BEFORE the rank launched anything of this engine (no breadcrumb yet: runtime / context
+                # start-up of one of eight processes on one device) is repeated, once; a rank that had started operator
+                # applications may have died of a kernel fault and fails the test at once
+                died = getattr(e, "error_index", None)
+                if attempt == 1 or world < 8 or died is None or where.get(died) is not None:
                     raise
     finally:
         if saved_queues is None:
