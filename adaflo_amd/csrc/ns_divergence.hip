@@ -7,9 +7,10 @@
 //   (q_I, d_x u_x) = Cx (x) My (x) Mz u_x,   C = int N^p_I (N^u_j)' ,   M = int N^p_I N^u_j
 // with 5-wide 1D rows (pressure node I couples to the velocity nodes 2I-2 .. 2I+2; one half of the
 // row is missing at the domain boundary).  Pure gather: no seams, no atomics, bitwise reproducible.
-// A lane owns one pressure node column (I, J) of a z-chunk and marches through the velocity planes
-// WITHOUT staging them in LDS: it reads the velocity nodes 2I, 2I+1 (48 contiguous bytes) of the five
-// rows 2J-2 .. 2J+2, sums them in y, forms its own share of the x-sums and the shares its two columns
+// A lane owns the pressure node columns (I, J), (I, J + 1) of a z-chunk (two rows per lane since round 4: seven velocity
+// rows for two results instead of ten) and marches through the velocity planes
+// WITHOUT staging them in LDS: it reads the velocity nodes 2I, 2I+1 (48 contiguous bytes) of the
+// rows 2J-2 .. 2J+4, sums them in y per pressure row, forms its own share of the x-sums and the shares its two columns
 // have in the rows of the pressure nodes I-1 (node 2I as the last node of their right cell) and I+1
 // (both nodes in their left cell), which travel one lane to the left / right (ds_bpermute; the lanes of
 // a wave are 62 consecutive nodes of the flattened (J, I) index plus a halo lane on either side, so the
@@ -36,7 +37,7 @@ namespace adaflo_hip
     struct DivArgs
     {
       int           npx, npy, npz, nvx, nvy, nvz, LZ, n_chunks, blocks_per_chunk;
-      long          flat;                // npx * npy
+      long          flat;                // npx * (row groups of NR pressure rows)
       double        m[3][2][3], c[2][3]; // per direction h_d int N^p_a N^u_b;  int N^p_a (N^u_b)'
       double        weight;
       uint32_t      con_u, con_p;
@@ -65,36 +66,58 @@ namespace adaflo_hip
     typedef double dbl2 __attribute__((ext_vector_type(2)));
     typedef dbl2 dbl2_a8 __attribute__((aligned(8)));
 
-    __global__ __launch_bounds__(256) void q2q1_divergence_kernel(const DivArgs A)
+    // NR pressure rows per lane (round 4: 2): the rows J0, J0 + 1 share three of their five velocity rows, so a lane
+    // reads 7 rows for two results instead of 10 -- the kernel is bound by what its lanes pull through L1 / L2
+    // (every velocity row used to be requested 2.5 times), not by HBM
+#ifndef DIV_OCC
+#define DIV_OCC 2
+#endif
+#ifndef DIV_NR
+#define DIV_NR 2
+#endif
+    constexpr int NR = DIV_NR, NROWS = 2 * NR + 3;
+
+    __global__ __launch_bounds__(256, DIV_OCC) void q2q1_divergence_kernel(const DivArgs A)
     {
       const long nwg   = (long)A.blocks_per_chunk * A.n_chunks;
       const long wg    = xcd_remap(blockIdx.x, nwg);
       const int  chunk = (int)(wg / A.blocks_per_chunk);
       const int  lane  = threadIdx.x & 63;
       const long g_raw = ((wg % A.blocks_per_chunk) * 4 + (threadIdx.x >> 6)) * DSW + lane - 1;
-      const long g     = min(max(g_raw, 0L), A.flat - 1);
-      const int  J = (int)(g / A.npx), I = (int)(g - (long)J * A.npx);
+      const long g     = min(max(g_raw, 0L), A.flat - 1); // flattened (row pair, I)
+      const int  JP = (int)(g / A.npx), I = (int)(g - (long)JP * A.npx), J0 = NR * JP;
       const bool own = lane >= 1 && lane <= DSW && g_raw < A.flat;
       const bool xlo = I > 0, xhi = I < A.npx - 1;
-      const bool con_xy = (I == 0 && (A.con_p >> 0 & 1)) || (I == A.npx - 1 && (A.con_p >> 1 & 1)) ||
-                          (J == 0 && (A.con_p >> 2 & 1)) || (J == A.npy - 1 && (A.con_p >> 3 & 1));
+      bool       row_ok[NR], con_xy[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+        {
+          const int J = J0 + r;
+          row_ok[r]   = J < A.npy;
+          con_xy[r]   = (I == 0 && (A.con_p >> 0 & 1)) || (I == A.npx - 1 && (A.con_p >> 1 & 1)) ||
+                      (J == 0 && (A.con_p >> 2 & 1)) || (J == A.npy - 1 && (A.con_p >> 3 & 1));
+        }
 
-      // y: the five rows 2J-2 .. 2J+2 (clamped to the mesh, their weights are zero beyond it), with the
-      // constraint masks of the y faces per component (rows 0 and nvy - 1): My for u_x, u_z, Cy for u_y
-      double wy[3][5];
-      {
-        double My[5], Cy[5];
-        div_rows(A.m[1], A.c, J, A.npy, My, Cy);
+      // y: pressure row J0 + r uses the velocity rows 2 (J0 + r) - 2 .. + 2 = rows 2 r .. 2 r + 4 of the lane's NROWS rows
+      // (clamped to the mesh, their weights are zero beyond it), with the constraint masks of the y faces per component
+      // (rows 0 and nvy - 1): My for u_x, u_z, Cy for u_y
+      double wy[NR][3][5];
 #pragma unroll
-        for (int comp = 0; comp < 3; ++comp)
+      for (int r = 0; r < NR; ++r)
+        {
+          double    My[5], Cy[5];
+          const int J = min(J0 + r, A.npy - 1);
+          div_rows(A.m[1], A.c, J, A.npy, My, Cy);
 #pragma unroll
-          for (int r = 0; r < 5; ++r)
-            {
-              const int  row = 2 * J - 2 + r;
-              const bool con = !A.plain && ((row == 0 && (A.con_u >> (6 + comp) & 1)) || (row == A.nvy - 1 && (A.con_u >> (9 + comp) & 1)));
-              wy[comp][r]    = con ? 0. : (comp == 1 ? Cy[r] : My[r]);
-            }
-      }
+          for (int comp = 0; comp < 3; ++comp)
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+              {
+                const int  row = 2 * J - 2 + q;
+                const bool con = !A.plain && ((row == 0 && (A.con_u >> (6 + comp) & 1)) || (row == A.nvy - 1 && (A.con_u >> (9 + comp) & 1)));
+                wy[r][comp][q] = (con || !row_ok[r]) ? 0. : (comp == 1 ? Cy[q] : My[q]);
+              }
+        }
       // x: the lane reads two velocity nodes F, S = 2I, 2I+1 -- the last pressure column 2I-1, 2I
       // instead (node 2I+1 would be the first node of the next row, or beyond the vector); weights of
       // F and S in this node's own row (o), in the row of the node to the left (l); to the right the
@@ -113,74 +136,89 @@ namespace adaflo_hip
           fF[comp]       = con && !last ? 0. : 1.;
           fS[comp]       = con && last ? 0. : 1.;
         }
-      unsigned off[5]; // byte offsets of node F in the five rows of a velocity plane
+      unsigned off[NROWS]; // byte offsets of node F in the lane's rows of a velocity plane
 #pragma unroll
-      for (int r = 0; r < 5; ++r)
-        off[r] = (unsigned)(min(max(2 * J - 2 + r, 0), A.nvy - 1) * A.nvx + (last ? 2 * I - 1 : 2 * I)) * 24u;
+      for (int q = 0; q < NROWS; ++q)
+        off[q] = (unsigned)(min(max(2 * J0 - 2 + q, 0), A.nvy - 1) * A.nvx + (last ? 2 * I - 1 : 2 * I)) * 24u;
 
       const int K0 = chunk * A.LZ, K1 = min(K0 + A.LZ, A.npz);
       const int pbase = 2 * K0 - 2, t0 = K0 > 0 ? 0 : 2, t1 = min(2 * (K1 - 1) + 2, A.nvz - 1) - pbase; // planes pbase + t
       const double (&mz)[2][3] = A.m[2];
-      double acc[3] = {0., 0., 0.};
+      double acc[NR][3];
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+        acc[r][0] = acc[r][1] = acc[r][2] = 0.;
       // dst_p is read-modify-write: its old value is requested together with the velocity plane whose
       // sums complete the pressure layer (a load right before the store would add one memory latency
       // to every second plane)
-      auto writes = [&](const int K) {
+      auto writes = [&](const int K, const int r) {
         const bool conz = (K == 0 && (A.con_p >> 4 & 1)) || (K == A.npz - 1 && (A.con_p >> 5 & 1));
-        return K >= K0 && K < K1 && own && !(con_xy || conz);
+        return K >= K0 && K < K1 && own && row_ok[r] && !(con_xy[r] || conz);
       };
+      const long pnode = (long)J0 * A.npx + I; // node (I, J0) of a pressure plane; row r: + r * npx
       // plane pbase + t, t = 6 n + PH: pressure planes K0 - 1 + t / 2 (+- 1) in the slots (t / 2) % 3 = PH / 2 (+- 1)
       auto step = [&](auto phase, const int t) {
         constexpr int PH = decltype(phase)::value, sc = (PH / 2) % 3, sm = (PH / 2 + 2) % 3, sp = (PH / 2 + 1) % 3;
         const int     p = pbase + t;
         const int     K = K0 - 1 + t / 2; // the pressure plane of an even velocity plane
         const char   *s = reinterpret_cast<const char *>(A.src_u + (long)p * A.nvy * A.nvx * 3);
-        double       *d = A.dst_p + (long)(K - 1) * A.flat + g;
-        const bool    wr = PH % 2 == 0 && writes(K - 1);
-        double        old = 0.;
-        if (wr)
-          old = *d;
-        dbl2 v[5][3];
+        double       *d = A.dst_p + (long)(K - 1) * A.npx * A.npy + pnode;
+        bool          wr[NR];
+        double        old[NR];
 #pragma unroll
-        for (int r = 0; r < 5; ++r)
+        for (int r = 0; r < NR; ++r)
+          {
+            wr[r]  = PH % 2 == 0 && writes(K - 1, r);
+            old[r] = 0.;
+            if (wr[r])
+              old[r] = d[(long)r * A.npx];
+          }
+        dbl2 v[NROWS][3];
+#pragma unroll
+        for (int q = 0; q < NROWS; ++q)
 #pragma unroll
           for (int w = 0; w < 3; ++w)
-            v[r][w] = *reinterpret_cast<const dbl2_a8 *>(s + off[r] + 16 * w);
-        // (F.x F.y) (F.z S.x) (S.y S.z): y-sums of  My u_x,  Cy u_y,  My u_z  in the columns F and S
-        double pF[3], pS[3];
+            v[q][w] = *reinterpret_cast<const dbl2_a8 *>(s + off[q] + 16 * w);
+        const bool zcon = !A.plain && (p == 0 || p == A.nvz - 1); // (block-uniform) constraints on the z faces
 #pragma unroll
-        for (int comp = 0; comp < 3; ++comp)
+        for (int r = 0; r < NR; ++r)
           {
-            const double *w5 = wy[comp];
-            auto          f = [&](const int r) { return comp == 0 ? v[r][0].x : comp == 1 ? v[r][0].y : v[r][1].x; };
-            auto          g2 = [&](const int r) { return comp == 0 ? v[r][1].y : comp == 1 ? v[r][2].x : v[r][2].y; };
-            pF[comp] = fF[comp] * (((w5[0] * f(0) + w5[1] * f(1)) + (w5[3] * f(3) + w5[4] * f(4))) + w5[2] * f(2));
-            pS[comp] = fS[comp] * (((w5[0] * g2(0) + w5[1] * g2(1)) + (w5[3] * g2(3) + w5[4] * g2(4))) + w5[2] * g2(2));
-          }
-        if (!A.plain && (p == 0 || p == A.nvz - 1)) // (block-uniform) constraints on the z faces
+            // (F.x F.y) (F.z S.x) (S.y S.z): y-sums of  My u_x,  Cy u_y,  My u_z  in the columns F and S
+            double pF[3], pS[3];
 #pragma unroll
-          for (int comp = 0; comp < 3; ++comp)
-            if (A.con_u >> ((p == 0 ? 12 : 15) + comp) & 1)
-              pF[comp] = pS[comp] = 0.;
-        const double a_r = (A.c[1][0] * pF[0] + A.c[1][1] * pS[0]) + (mx[1][0] * pF[1] + mx[1][1] * pS[1]);
-        const double b_r = mx[1][0] * pF[2] + mx[1][1] * pS[2];
-        const double a_l = (lCF * pF[0] + lCS * pS[0]) + (lMF * pF[1] + lMS * pS[1]);
-        const double b_l = lMF * pF[2] + lMS * pS[2];
-        const double a = ((oCF * pF[0] + oCS * pS[0]) + (oMF * pF[1] + oMS * pS[1])) +
-                         (from_l * __shfl_up(a_r, 1, 64) + from_r * __shfl_down(a_l, 1, 64));
-        const double b = (oMF * pF[2] + oMS * pS[2]) + (from_l * __shfl_up(b_r, 1, 64) + from_r * __shfl_down(b_l, 1, 64));
-        if (PH % 2 == 0)
-          {
-            if (wr)
-              *d = old + A.weight * (acc[sm] + (mz[0][2] * a + A.c[0][2] * b));
-            const bool lo = K > 0, hi = K < A.npz - 1;
-            acc[sc] += ((lo ? mz[1][2] : 0.) + (hi ? mz[0][0] : 0.)) * a + ((lo ? A.c[1][2] : 0.) + (hi ? A.c[0][0] : 0.)) * b;
-            acc[sp] = mz[1][0] * a + A.c[1][0] * b;
-          }
-        else
-          {
-            acc[sc] += mz[0][1] * a + A.c[0][1] * b;
-            acc[sp] += mz[1][1] * a + A.c[1][1] * b;
+            for (int comp = 0; comp < 3; ++comp)
+              {
+                const double *w5 = wy[r][comp];
+                auto          f  = [&](const int q) { return comp == 0 ? v[2 * r + q][0].x : comp == 1 ? v[2 * r + q][0].y : v[2 * r + q][1].x; };
+                auto          g2 = [&](const int q) { return comp == 0 ? v[2 * r + q][1].y : comp == 1 ? v[2 * r + q][2].x : v[2 * r + q][2].y; };
+                pF[comp] = fF[comp] * (((w5[0] * f(0) + w5[1] * f(1)) + (w5[3] * f(3) + w5[4] * f(4))) + w5[2] * f(2));
+                pS[comp] = fS[comp] * (((w5[0] * g2(0) + w5[1] * g2(1)) + (w5[3] * g2(3) + w5[4] * g2(4))) + w5[2] * g2(2));
+              }
+            if (zcon)
+#pragma unroll
+              for (int comp = 0; comp < 3; ++comp)
+                if (A.con_u >> ((p == 0 ? 12 : 15) + comp) & 1)
+                  pF[comp] = pS[comp] = 0.;
+            const double a_r = (A.c[1][0] * pF[0] + A.c[1][1] * pS[0]) + (mx[1][0] * pF[1] + mx[1][1] * pS[1]);
+            const double b_r = mx[1][0] * pF[2] + mx[1][1] * pS[2];
+            const double a_l = (lCF * pF[0] + lCS * pS[0]) + (lMF * pF[1] + lMS * pS[1]);
+            const double b_l = lMF * pF[2] + lMS * pS[2];
+            const double a = ((oCF * pF[0] + oCS * pS[0]) + (oMF * pF[1] + oMS * pS[1])) +
+                             (from_l * __shfl_up(a_r, 1, 64) + from_r * __shfl_down(a_l, 1, 64));
+            const double b = (oMF * pF[2] + oMS * pS[2]) + (from_l * __shfl_up(b_r, 1, 64) + from_r * __shfl_down(b_l, 1, 64));
+            if (PH % 2 == 0)
+              {
+                if (wr[r])
+                  d[(long)r * A.npx] = old[r] + A.weight * (acc[r][sm] + (mz[0][2] * a + A.c[0][2] * b));
+                const bool lo = K > 0, hi = K < A.npz - 1;
+                acc[r][sc] += ((lo ? mz[1][2] : 0.) + (hi ? mz[0][0] : 0.)) * a + ((lo ? A.c[1][2] : 0.) + (hi ? A.c[0][0] : 0.)) * b;
+                acc[r][sp] = mz[1][0] * a + A.c[1][0] * b;
+              }
+            else
+              {
+                acc[r][sc] += mz[0][1] * a + A.c[0][1] * b;
+                acc[r][sp] += mz[1][1] * a + A.c[1][1] * b;
+              }
           }
       };
       for (int t = 0; t <= t1; t += 6)
@@ -200,8 +238,11 @@ namespace adaflo_hip
       if (K1 == A.npz)
         {
           const int kk = (K1 - 1) - (K0 - 1); // = t / 2 of its own plane
-          if (writes(K1 - 1))
-            A.dst_p[(long)(K1 - 1) * A.flat + g] += A.weight * (kk % 3 == 0 ? acc[0] : kk % 3 == 1 ? acc[1] : acc[2]);
+#pragma unroll
+          for (int r = 0; r < NR; ++r)
+            if (writes(K1 - 1, r))
+              A.dst_p[(long)(K1 - 1) * A.npx * A.npy + pnode + (long)r * A.npx] +=
+                A.weight * (kk % 3 == 0 ? acc[r][0] : kk % 3 == 1 ? acc[r][1] : acc[r][2]);
         }
     }
   } // namespace
@@ -218,17 +259,21 @@ namespace adaflo_hip
     DivArgs A{};
     A.npx = ctx->desc.ncell[0] + 1, A.npy = ctx->desc.ncell[1] + 1, A.npz = ctx->desc.ncell[2] + 1;
     A.nvx = 2 * ctx->desc.ncell[0] + 1, A.nvy = 2 * ctx->desc.ncell[1] + 1, A.nvz = 2 * ctx->desc.ncell[2] + 1;
-    A.flat             = (long)A.npx * A.npy;
+    A.flat             = (long)A.npx * ((A.npy + NR - 1) / NR); // (row pairs x columns)
     A.blocks_per_chunk = (int)(((A.flat + DSW - 1) / DSW + 3) / 4); // four independent waves per workgroup
-    // z-chunk: 2 LZ + 3 velocity planes per LZ pressure layers; the halo planes are read from HBM again
-    // (FETCH_SIZE 1.24 x the vector at LZ = 8) and the kernel is bound by what it reads (loads with trivial
-    // sums 0.108 ms, arithmetic without loads 0.023 ms of 0.117 ms; scripts/dev/div_probe.hip), so: the
-    // longest chunk that leaves ~200 workgroups (128^3 cells: 0.137 / 0.128 / 0.133 / 0.117 / 0.145 ms for
-    // LZ = 4 / 6 / 8 / 12 / 16 -- at 12 the 748 workgroups are one round of the chip; 64 x 64 x 128: 0.025 ms)
-    int lz = 2;
-    for (const int c : {4, 6, 8, 12})
-      if ((long)A.blocks_per_chunk * ((A.npz + c - 1) / c) >= 192)
-        lz = c;
+    // z-chunk: 2 LZ + 3 velocity planes per LZ pressure layers; the halo planes are read again (mostly L2 hits).  With
+    // two pressure rows per lane (218 VGPRs: two waves per SIMD, 512 workgroups fill the chip) the best chunk is the
+    // shortest one that still fits ONE round of workgroups -- 128^3 cells: 0.128 / 0.119 / 0.111 / 0.132 / 0.109 /
+    // 0.116 / 0.127 ms for LZ = 2 / 3 / 6 / 8 / 9 (510 workgroups) / 10 / 12 -- but not below 5 layers, where the halo
+    // planes and the prologue dominate (64 x 64 x 128: 0.040 / 0.033 / 0.034 / 0.041 ms for LZ = 3 / 5 / 6 / 9);
+    // meshes too large for one round take many rounds of 24-layer chunks
+    int lz = 24;
+    for (int c = 5; c < 24; ++c)
+      if ((long)A.blocks_per_chunk * ((A.npz + c - 1) / c) <= 512)
+        {
+          lz = c;
+          break;
+        }
     if (const char *e = getenv("ADAFLO_DIV_LZ")) // (tuning knob of scripts/bench_ops.py)
       lz = std::max(1, atoi(e));
     A.LZ       = lz;

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Beltrami time steps on one MI355X: wall clock per step, outer FGMRES iterations and the inner velocity-block
 iterations per preconditioner application, with the fast-diagonalisation inner solves (1) and with the
-Jacobi-preconditioned inner Krylov solves (0).  usage: time_beltrami_step.py [cells_per_direction] [steps] [only this mode]"""
+Jacobi-preconditioned inner Krylov solves (0).
+usage: time_beltrami_step.py [cells_per_direction] [steps] [only this mode] [velocity degree]"""
 import ctypes as C
 import os
 import sys
@@ -19,10 +20,11 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     nu = 1.0
     mesh = adaflo_amd.BrickMesh([n] * 3, [-1.0] * 3, [1.0] * 3)
-    xu, xp = node_coordinates(mesh, 2), node_coordinates(mesh, 1)
+    k = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+    xu, xp = node_coordinates(mesh, k), node_coordinates(mesh, k - 1)
     modes = (int(sys.argv[3]),) if len(sys.argv) > 3 else (1, -1, 0)
     for inner in modes:             # 1: fast diagonalisation, two-stage solver; -1: inner solves from the start; 0: Jacobi
-        fp = adaflo_amd.FlowParameters(velocity_degree=2, viscosity=nu, time_step_size_start=0.05 * 16 / n, end_time=1.0,
+        fp = adaflo_amd.FlowParameters(velocity_degree=k, viscosity=nu, time_step_size_start=0.05 * 32 / (n * k), end_time=1.0,
                                        max_nl_iteration=10, tol_nl_iteration=1e-9, max_lin_iteration=100, tol_lin_iteration=1e-5,
                                        iterations_before_inner_solvers=0 if inner < 0 else 50)
         ns = NavierStokes(fp, mesh, adaflo_amd.TimeStepping(fp), dirichlet_function=lambda x, t: beltrami.velocity(x, t, nu))
@@ -42,8 +44,8 @@ def main():
             s1, i1 = C.c_int64(), C.c_int64()
             lib.adaflo_ns_preconditioner_statistics(ctx, C.byref(s1), C.byref(i1))
             ns_, ni = s1.value - s0.value, i1.value - i0.value
-            print("inner=%d %d^3 step %d: %.3f s, outer iterations %s, %d velocity solves, %.1f inner iterations each"
-                  % (inner, n, step + 1, dt, [i for i, _ in ns.linear_iterations], ns_, ni / max(ns_, 1)), flush=True)
+            print("inner=%d Q%d %d^3 step %d: %.3f s, outer iterations %s, %d velocity solves, %.1f inner iterations each"
+                  % (inner, k, n, step + 1, dt, [i for i, _ in ns.linear_iterations], ns_, ni / max(ns_, 1)), flush=True)
 
 
 if __name__ == "__main__":
