@@ -553,7 +553,9 @@ int adaflo_ns_set_coefficients(adaflo_ctx *ctx, const double *rho, const double 
   CHECK_CTX(ctx);
   const size_t count = (size_t)ctx->n_cells * ctx->nq_u;
   TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
-  ctx->lin_q2_valid   = false; // the streaming copy of the Q2/Q1 kernel carries the coefficients
+  ctx->lin_q2_valid    = false; // the streaming copies of the sweep kernels carry the coefficients
+  ctx->hox_lin_primary = false; // (ensure_lin_generic above brought the generic copy up to date)
+  ctx->lin_gen++;
   ctx->q1_poisson_src = nullptr;
   if (!rho && !mu && !damping)
     {
@@ -612,7 +614,7 @@ int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx)
       ctx->hox_lin_prec_mode      = ctx->hox_lin_mode;
       ctx->hox_lin_prec_primary   = true;
       ctx->lin_prec_generic_valid = false;
-      release(ctx->rho_prec), release(ctx->mu_prec), release(ctx->damp_prec); // (hox_supported: no variable coefficients)
+      release(ctx->rho_prec), release(ctx->mu_prec), release(ctx->damp_prec); // (the residual mode runs with constant coefficients only)
       release(ctx->lin_q2_prec);
       ctx->q1_poisson_src = nullptr;
       return 0;
@@ -838,7 +840,7 @@ int adaflo_ns_velocity_vmult(adaflo_ctx *ctx, double *dst_u, const double *src_u
           "Q2 kernel launch failed");
       return 0;
     }
-  if (ctx->variant == 1 && hox_supported(ctx) && !ctx->rho_prec.p)
+  if (ctx->variant == 1 && hox_supported(ctx)) // (its frozen streaming copy carries the frozen coefficients)
     {
       TRY(ctx, launch_ns_vmult_hox(ctx, OP_VMULT_VELOCITY, dst_u, nullptr, src_u, nullptr),
           "x-marching kernel launch failed");
@@ -1792,7 +1794,9 @@ int adaflo_ls_compute_force(adaflo_ctx *ctx, double *user_rhs_u, const double *h
       TRY(ctx, alloc(ctx, ctx->damp, count), ctx->last_error);
       if (!had_damping) // variable_damping_coefficients default to parameters.damping
         TRY(ctx, launch_fill(ctx, ctx->damp.p, ctx->ns.damping, (long)count), "fill failed");
-      ctx->lin_q2_valid   = false; // the streaming copy of the Q2/Q1 kernel carries the coefficients
+      ctx->lin_q2_valid    = false; // the streaming copies of the sweep kernels carry the coefficients
+      ctx->hox_lin_primary = false;
+      ctx->lin_gen++;
       ctx->q1_poisson_src = nullptr;
     }
   TRY(ctx,

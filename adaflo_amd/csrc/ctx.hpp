@@ -122,6 +122,7 @@ struct adaflo_ctx
   adaflo_hip::DeviceBuffer hox_lin, hox_lin_prec, hox_slab_u, hox_xslab_u, hox_slab_p, hox_xslab_p, hox_tab;
   unsigned long            lin_gen = 1, lin_prec_gen = 1, hox_lin_gen = 0, hox_lin_prec_gen = 0;
   int                      hox_lin_mode = -1, hox_lin_prec_mode = -1;
+  bool                     hox_lin_varco = false, hox_lin_prec_varco = false; // the streaming copy carries rho / mu / damping
   bool                     hox_lin_primary = false; // hox_lin (written by the residual mode) is THE state, `lin` is stale
   bool                     hox_lin_prec_primary = false; // ... and its frozen copy exists in the streaming layout only
   std::vector<double>      hox_tab_host; // what hox_tab holds

@@ -44,36 +44,40 @@ namespace adaflo_hip
     }
 
     template <int K>
-    size_t state_doubles(const adaflo_ctx *ctx, const int lin_mode)
+    size_t state_doubles(const adaflo_ctx *ctx, const int lin_mode, const bool varco = false)
     {
       using G         = Geo<K>;
       const size_t ngy = (ctx->desc.ncell[1] + G::CWY - 1) / G::CWY, ngz = (ctx->desc.ncell[2] + G::CWZ - 1) / G::CWZ;
-      return ngz * ngy * (size_t)ctx->desc.ncell[0] * G::N * (nst_of(lin_mode) / 2) * G::CPW * G::NL * 2;
+      return ngz * ngy * (size_t)ctx->desc.ncell[0] * G::N * (nst_of(lin_mode) / 2 + (varco ? 2 : 0)) * G::CPW * G::NL * 2;
     }
 
-    // streaming copy of the (frozen) linearisation state, rebuilt when the generic copy it was made from changed
+    // streaming copy of the (frozen) linearisation state -- and of the variable coefficients, if any --, rebuilt when the
+    // generic copies it was made from changed (lin_gen / lin_prec_gen count every change of state AND coefficients)
     template <int K>
-    int prepare_state(adaflo_ctx *ctx, const bool prec, const int lin_mode, const double **out)
+    int prepare_state(adaflo_ctx *ctx, const bool prec, const int lin_mode, const double **out, bool *varco_out)
     {
       using G = Geo<K>;
       *out    = nullptr;
-      if (lin_mode == 2)
+      const bool          use_prec = prec && (ctx->lin_prec.p || ctx->hox_lin_prec_primary || ctx->rho_prec.p);
+      const bool          varco    = use_prec ? ctx->rho_prec.p != nullptr : ctx->rho.p != nullptr;
+      *varco_out                   = varco;
+      if (lin_mode == 2 && !varco)
         return 0;
-      const bool          use_prec = prec && (ctx->lin_prec.p || ctx->hox_lin_prec_primary);
       const DeviceBuffer &gen      = use_prec ? ctx->lin_prec : ctx->lin;
       DeviceBuffer       &str      = use_prec ? ctx->hox_lin_prec : ctx->hox_lin;
       unsigned long      &have     = use_prec ? ctx->hox_lin_prec_gen : ctx->hox_lin_gen;
       int                &mode     = use_prec ? ctx->hox_lin_prec_mode : ctx->hox_lin_mode;
+      bool               &has_co   = use_prec ? ctx->hox_lin_prec_varco : ctx->hox_lin_varco;
       const unsigned long want     = use_prec ? ctx->lin_prec_gen : ctx->lin_gen;
-      const size_t need = state_doubles<K>(ctx, lin_mode);
-      if (str.p && have == want && mode == lin_mode && str.count >= need)
+      const size_t need = state_doubles<K>(ctx, lin_mode, varco);
+      if (str.p && have == want && mode == lin_mode && has_co == varco && str.count >= need)
         {
           *out = str.p;
           return 0;
         }
       // (a state that exists in the streaming layout only -- written by the residual mode -- is current by
       // construction; a change of scheme brings the generic copy up to date first, adaflo_ns_set_params)
-      if (!gen.p || !(use_prec ? ctx->lin_prec_generic_valid : ctx->lin_generic_valid))
+      if (lin_mode != 2 && (!gen.p || !(use_prec ? ctx->lin_prec_generic_valid : ctx->lin_generic_valid)))
         return ADAFLO_ENOTINIT;
       if (int e = ensure(str, need))
         return e;
@@ -83,17 +87,20 @@ namespace adaflo_hip
       long       nb     = (pieces + 255) / 256;
       if (nb > 256 * 64)
         nb = 256 * 64;
+      const int     npl = nst_of(lin_mode) / 2;
+      const double *rho = use_prec ? ctx->rho_prec.p : ctx->rho.p, *mu = use_prec ? ctx->mu_prec.p : ctx->mu.p,
+                   *damp = use_prec ? ctx->damp_prec.p : ctx->damp.p;
       hipLaunchKernelGGL((hox_convert_state_kernel<K>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, str.p, gen.p, ncx, ncy,
-                         ncz, ngy, ngz, nst_of(lin_mode) / 2);
+                         ncz, ngy, ngz, npl + (varco ? 2 : 0), varco ? npl : -1, rho, mu, damp);
       if (hipGetLastError() != hipSuccess)
         return ADAFLO_EHIP;
-      have = want;
-      mode = lin_mode;
-      *out = str.p;
+      have   = want;
+      mode   = lin_mode;
+      has_co = varco;
+      *out   = str.p;
       return 0;
     }
 
-    // phase -1: the whole operator; phases 0 / 1 / 2 as in launch_ns_vmult_q2 (ns_q2.hip)
     // residual = true: dst_u / dst_p receive the cell-loop sums, old_comb is the nodal combination of the old solutions
     // (or null), the state is WRITTEN to ctx->hox_lin
     template <int K>
@@ -130,7 +137,8 @@ namespace adaflo_hip
         const double cA = stokes ? 0. : gamma * P.density - P.damping; // :717,:827-835; Stokes: no value terms (:708)
         const double cB = stokes ? 0. : P.tau1 * P.density;
         const std::vector<double> tab = hox_table<K>(su.S.data(), dc.data(), sp.S.data(), qu.w.data(), ctx->desc.h, cA, cB,
-                                                     P.beta, P.tau_grad_div, P.viscosity * P.tau1 /* :841-845 */);
+                                                     P.beta, P.tau_grad_div, P.viscosity * P.tau1 /* :841-845 */,
+                                                     stokes ? 0. : gamma, stokes ? 0. : P.tau1, stokes ? 0. : 1., P.tau1);
         if (tab != ctx->hox_tab_host)
           {
             if (int e = ensure(ctx->hox_tab, tab.size()))
@@ -150,6 +158,7 @@ namespace adaflo_hip
       A.src_p       = src_p;
       A.dst_u       = dst_u;
       A.dst_p       = dst_p;
+      bool varco = false;
       if (residual)
         {
           A.old_u = old_comb;
@@ -161,7 +170,7 @@ namespace adaflo_hip
               A.lin_out = ctx->hox_lin.p;
             }
         }
-      else if (int e = prepare_state<K>(ctx, op == OP_VMULT_VELOCITY, lin_mode, &A.lin))
+      else if (int e = prepare_state<K>(ctx, op == OP_VMULT_VELOCITY, lin_mode, &A.lin, &varco))
         return e;
       const bool   with_p = op == OP_VMULT || residual;
       const size_t n_wg   = (size_t)A.tiles_y * A.tiles_z * A.n_chunks;
@@ -218,17 +227,24 @@ namespace adaflo_hip
       const dim3   grid((unsigned)(nwg > 0 ? nwg : 1)), block(NTH);
       hipError_t   err  = hipSuccess;
       hipEvent_t   stop = (ctx->timing && nwg > 0) ? ctx->kernel_timer.start(ctx->stream) : nullptr;
-#define HOX_LAUNCH(LM, WP)                                                                                \
-  {                                                                                                       \
-    static bool attr_set = false;                                                                         \
-    if (!attr_set)                                                                                        \
-      {                                                                                                   \
-        err      = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_hox_kernel<K, LM, WP>),         \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);      \
-        attr_set = err == hipSuccess;                                                                     \
-      }                                                                                                   \
-    if (err == hipSuccess && nwg > 0)                                                                     \
-      hipLaunchKernelGGL((ns_hox_kernel<K, LM, WP>), grid, block, lds_bytes, ctx->stream, A);             \
+#define HOX_LAUNCH_V(LM, WP, VC)                                                                                \
+  {                                                                                                            \
+    static bool attr_set = false;                                                                              \
+    if (!attr_set)                                                                                             \
+      {                                                                                                        \
+        err      = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_hox_kernel<K, LM, WP, false, VC>),   \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);           \
+        attr_set = err == hipSuccess;                                                                          \
+      }                                                                                                        \
+    if (err == hipSuccess && nwg > 0)                                                                          \
+      hipLaunchKernelGGL((ns_hox_kernel<K, LM, WP, false, VC>), grid, block, lds_bytes, ctx->stream, A);       \
+  }
+#define HOX_LAUNCH(LM, WP)       \
+  {                              \
+    if (varco)                   \
+      HOX_LAUNCH_V(LM, WP, true) \
+    else                         \
+      HOX_LAUNCH_V(LM, WP, false) \
   }
 #define HOX_LAUNCH_RES(LM)                                                                                \
   {                                                                                                       \
@@ -279,6 +295,7 @@ namespace adaflo_hip
               HOX_LAUNCH(2, false);
           }
 #undef HOX_LAUNCH
+#undef HOX_LAUNCH_V
 #undef HOX_LAUNCH_RES
       if (err != hipSuccess)
         return ADAFLO_EHIP;
@@ -339,14 +356,14 @@ namespace adaflo_hip
 
   bool hox_supported(const adaflo_ctx *ctx)
   {
-    return ctx->k >= 3 && ctx->k <= 5 && !ctx->flat && !ctx->rho.p && !ctx->mu.p && !ctx->damp.p;
+    return ctx->k >= 3 && ctx->k <= 5 && !ctx->flat; // (constant and, since the two-phase mode, variable coefficients)
   }
 
   // schemes whose residual needs no extrapolated old velocities (navier_stokes_matrix.cc:740-782 stay on the generic kernel)
   bool hox_residual_supported(const adaflo_ctx *ctx)
   {
     const int lin = ctx->ns.linearization;
-    return hox_supported(ctx) && lin != ADAFLO_PROJECTION &&
+    return hox_supported(ctx) && !ctx->rho.p && lin != ADAFLO_PROJECTION &&
            (ctx->ns.physical_type == ADAFLO_STOKES || lin == ADAFLO_COUPLED_IMPLICIT_NEWTON || lin == ADAFLO_COUPLED_IMPLICIT_PICARD);
   }
 

@@ -225,7 +225,9 @@ namespace adaflo_hip
         for (int i = 0; i < HI; ++i)
           out.push_back(0.5 * (m(q, i) - m(q, NI - 1 - i)));
     }
-    // table of a launch: [S | S^T | D | D^T | Sp | Sp^T | w[N] | 1/h[3] | det | cA | cB | beta | tau_gd | tmu]
+    // table of a launch: [S | S^T | D | D^T | Sp | Sp^T | w[N] | 1/h[3] | det | cA | cB | beta | tau_gd | tmu |
+    // variable coefficients (rho, mu, damping per point): gamma, tau1 (factor of rho), 1 (factor of damping; all three 0
+    // for Stokes), tau1 (factor of mu)]
     template <int K>
     struct Tab
     {
@@ -233,13 +235,15 @@ namespace adaflo_hip
       static constexpr int S = 0, ST = S + eo_size(N, N), D = ST + eo_size(N, N), DT = D + eo_size(N, N),
                            SP = DT + eo_size(N, N), SPT = SP + eo_size(N, NP), C = SPT + eo_size(NP, N);
       static constexpr int C_W = 0, C_IH = N, C_DET = N + 3, C_CA = N + 4, C_CB = N + 5, C_BETA = N + 6, C_TGD = N + 7,
-                           C_TMU = N + 8, SIZE = C + N + 9;
+                           C_TMU = N + 8, C_GAMMA = N + 9, C_T1RHO = N + 10, C_DAMPF = N + 11, C_TAU1 = N + 12,
+                           SIZE = C + N + 13;
     };
     // (host) S[q][i] nodal -> Gauss points (N x N), Dc collocation derivative (N x N), Sp pressure (N x NP)
     template <int K>
     inline std::vector<double> hox_table(const double *S, const double *Dc, const double *Sp, const double *w,
                                          const double h[3], const double cA, const double cB, const double beta,
-                                         const double tau_gd, const double tmu)
+                                         const double tau_gd, const double tmu, const double gamma = 0.,
+                                         const double t1rho = 0., const double dampf = 0., const double tau1 = 0.)
     {
       constexpr int       N = K + 1, NP = K;
       std::vector<double> t;
@@ -259,6 +263,10 @@ namespace adaflo_hip
       t.push_back(beta);
       t.push_back(tau_gd);
       t.push_back(tmu);
+      t.push_back(gamma);
+      t.push_back(t1rho);
+      t.push_back(dampf);
+      t.push_back(tau1);
       return t;
     }
 
@@ -410,7 +418,10 @@ namespace adaflo_hip
     // quadrature-point operation, the values (u, grad u) or (u, div u) STORED as the streaming state of the next vmults
     // instead of read; constrained rows of the sums get 0 (the scatter skips them); the driver forms
     // rhs = user_rhs - rhs - sums.  LIN_MODE 0 / 1 / 2 = which state is written (Newton / Picard-type / none).
-    template <int K, int LIN_MODE, bool WITH_P, bool RES = false>
+    // VARCO: variable density / viscosity / damping at the quadrature points (two-phase flow, :636-642, :827-845): two
+    // more pieces per point in the state stream, (rho, mu) and (damping, -); register prefetch also for k = 4 (the
+    // ring would not fit the LDS of two workgroups per CU)
+    template <int K, int LIN_MODE, bool WITH_P, bool RES = false, bool VARCO = false>
     __global__ __launch_bounds__(NTH, HOX_LB) void ns_hox_kernel(const HXArgs A)
     {
       using G           = Geo<K>;
@@ -418,7 +429,9 @@ namespace adaflo_hip
       constexpr int CPW = G::CPW, PL = G::PL, CY = G::CY, CZ = G::CZ, CWY = G::CWY, CWZ = G::CWZ, WY = G::WY;
       constexpr int TNY = G::TNY, TNZ = G::TNZ, TPY = G::TPY, TPZ = G::TPZ, RIMU = G::RIMU, RIMP = G::RIMP;
       constexpr int BUF = G::BUF, PUBD = G::PUBD, PUBV = G::PUBV;
-      constexpr int NST = RES ? 0 : nst_of(LIN_MODE), NPC = NST / 2; // state values READ per point
+      constexpr int NSTL = RES ? 0 : nst_of(LIN_MODE);                // linearisation values READ per point
+      constexpr int NST = NSTL + (VARCO ? 4 : 0), NPC = NST / 2;       // ... with the coefficients (rho, mu | damping, -)
+      static_assert(!(RES && VARCO), "residual mode: constant coefficients only");
       constexpr int NSO = RES ? nst_of(LIN_MODE) : 0, NPO = NSO / 2;  // ... WRITTEN per point (residual mode)
       static_assert(!RES || WITH_P, "the residual has both blocks");
       using TB = Tab<K>;
@@ -506,7 +519,7 @@ namespace adaflo_hip
       const unsigned ax = lds_byte_addr(px), ay = lds_byte_addr(py), az = lds_byte_addr(pz);
       double *const  PUBY = lds + 4 * G::WAVE, *const PUBZ = PUBY + G::PUBY_BUFS * PUBD; // publish areas (Geo)
       // state ring of my wave
-      constexpr bool RING = G::RING && NST > 0 && !(HOX_EXP & 4);
+      constexpr bool RING = G::RING && NST > 0 && !VARCO && !(HOX_EXP & 4);
       constexpr int  SLOT = G::SLOT, RS = 2 * (NST / 2 > 0 ? NST / 2 : 1);
       char *const    ring = reinterpret_cast<char *>(lds + 4 * G::WAVE + G::PUB_DOUBLES) + wave * G::RING_BYTES;
       const unsigned ring_m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_byte_addr(ring)), ring_lane = lds_byte_addr(ring) + 16 * lane;
@@ -959,6 +972,21 @@ namespace adaflo_hip
                     g[d][e] = G[d][1 + e][i] * cst[TB::C_IH + e];
                 }
               const double div = g[0][0] + g[1][1] + g[2][2];
+              // :717, :827-835, :841-845 with the coefficients of this point (taken before the next point's state
+              // overwrites the registers)
+              double cA_q, cB_q, tmu_q;
+              if constexpr (VARCO)
+                {
+                  cA_q  = cst[TB::C_GAMMA] * st[NSTL] - cst[TB::C_DAMPF] * st[NSTL + 2];
+                  cB_q  = cst[TB::C_T1RHO] * st[NSTL];
+                  tmu_q = cst[TB::C_TAU1] * st[NSTL + 1];
+                }
+              else
+                {
+                  cA_q  = cst[TB::C_CA];
+                  cB_q  = cst[TB::C_CB];
+                  tmu_q = cst[TB::C_TMU];
+                }
               double       conv[3];
 #pragma unroll
               for (int d = 0; d < 3; ++d)
@@ -989,9 +1017,9 @@ namespace adaflo_hip
                         res += st[e] * g[d][e];
                     }
                   if constexpr (RES) // :717-732 with the time derivative of BDF: weight u + (weight_old u_old + ...)
-                    conv[d] = (cst[TB::C_CA] * u[d] + A.c_old * OQ[d][i] + cst[TB::C_CB] * res) * jxw;
+                    conv[d] = (cA_q * u[d] + A.c_old * OQ[d][i] + cB_q * res) * jxw;
                   else
-                    conv[d] = (cst[TB::C_CA] * u[d] + cst[TB::C_CB] * res) * jxw; // :717,:827-835
+                    conv[d] = (cA_q * u[d] + cB_q * res) * jxw; // :717,:827-835
                 }
               if constexpr (RES && NSO > 0)
                 {
@@ -1027,7 +1055,7 @@ namespace adaflo_hip
                   G[d][0][i] = conv[d];
 #pragma unroll
                   for (int e = 0; e < 3; ++e) // :859-892 row d of tmu (grad u + grad u^T) + (tau_gd div - p) I, times JxW J^{-1}
-                    G[d][1 + e][i] = (cst[TB::C_TMU] * (g[d][e] + g[e][d]) + (d == e ? diag : 0.)) * (jxw * cst[TB::C_IH + e]);
+                    G[d][1 + e][i] = (tmu_q * (g[d][e] + g[e][d]) + (d == e ? diag : 0.)) * (jxw * cst[TB::C_IH + e]);
                 }
               PQ[i] = -div * jxw; // :853-856
               __builtin_amdgcn_sched_barrier(0); // one point at a time: interleaved, the five points' temporaries add up
@@ -1261,10 +1289,14 @@ namespace adaflo_hip
 
     // generic state [cell][12][N^3] (q = (k N + j) N + i) -> streaming layout of ns_hox_kernel; one thread per
     // 16-byte piece of the output
+    // rho / mu / damp (generic [cell][q], all three or none): two more pieces per point, (rho, mu) and (damping, 0),
+    // behind the npl pieces of the linearisation state (npc = npl + 2 then)
     template <int K>
     __global__ __launch_bounds__(256) void hox_convert_state_kernel(double *out, const double *generic, const int ncx,
                                                                     const int ncy, const int ncz, const int ngy,
-                                                                    const int ngz, const int npc)
+                                                                    const int ngz, const int npc, const int npl = -1,
+                                                                    const double *rho = nullptr, const double *mu = nullptr,
+                                                                    const double *damp = nullptr)
     {
       using G          = Geo<K>;
       constexpr int N = G::N, NL = G::NL, N3 = G::N3, CPW = G::CPW;
@@ -1289,8 +1321,18 @@ namespace adaflo_hip
             {
               const size_t cellg = ((size_t)cz * ncy + cy) * ncx + cx;
               const int    q     = ((l / N) * N + l % N) * N + i; // line l = (j, k) = (l % N, l / N)
-              v0                 = generic[(cellg * NLIN_ + 2 * piece) * N3 + q];
-              v1                 = generic[(cellg * NLIN_ + 2 * piece + 1) * N3 + q];
+              if (npl < 0 || piece < npl)
+                {
+                  v0 = generic[(cellg * NLIN_ + 2 * piece) * N3 + q];
+                  v1 = generic[(cellg * NLIN_ + 2 * piece + 1) * N3 + q];
+                }
+              else if (piece == npl)
+                {
+                  v0 = rho[cellg * N3 + q];
+                  v1 = mu[cellg * N3 + q];
+                }
+              else
+                v0 = damp[cellg * N3 + q];
             }
           out[2 * it]     = v0;
           out[2 * it + 1] = v1;

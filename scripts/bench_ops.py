@@ -243,5 +243,8 @@ if __name__ == "__main__":
         for v in (1, 2, 0):
             ns_case(k, n, v)
     ns_residual_case(4, 64, 1)
+    for k in (3, 4):                                 # two-phase Jacobian on the x-marching kernel (round 4) / generic
+        for v in (1, 0):
+            ns_case(k, 64, v, two_phase=True)
     ls_case(4, (40, 40, 80))
     krylov_case(4, (40, 40, 80))

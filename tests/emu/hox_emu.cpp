@@ -15,17 +15,18 @@ using namespace adaflo_hip::hox;
 
 namespace
 {
-  template <int K, int LM, bool WP>
+  template <int K, int LM, bool WP, bool VARCO = false>
   void run_main(const HXArgs &A, const long nwg)
   {
     if (nwg > 0)
-      emu::launch((unsigned)nwg, NTH, [&] { ns_hox_kernel<K, LM, WP>(A); });
+      emu::launch((unsigned)nwg, NTH, [&] { ns_hox_kernel<K, LM, WP, false, VARCO>(A); });
   }
 
   template <int K>
   int run(const int *ncell, const double *h, const int op, const int lin_mode, const int integrate_p, const double *coef,
           const unsigned con_u, const unsigned con_p, const double *lin_generic, const double *src_u, const double *src_p,
-          double *dst_u, double *dst_p, const int lx, const unsigned iface, const int phased)
+          double *dst_u, double *dst_p, const int lx, const unsigned iface, const int phased, const double *rho = nullptr,
+          const double *mu = nullptr, const double *damp = nullptr)
   {
     using G         = Geo<K>;
     constexpr int N = K + 1;
@@ -36,7 +37,8 @@ namespace
       const Quadrature1D        qu = gauss(N);
       const Shape1D             su = shape_fe_q(K, qu), sp = shape_fe_q(K - 1, qu);
       const std::vector<double> dc = collocation_derivative(qu);
-      tab = hox_table<K>(su.S.data(), dc.data(), sp.S.data(), qu.w.data(), h, coef[0], coef[1], coef[2], coef[3], coef[4]);
+      tab = hox_table<K>(su.S.data(), dc.data(), sp.S.data(), qu.w.data(), h, coef[0], coef[1], coef[2], coef[3], coef[4],
+                         coef[5], coef[6], coef[7], coef[8]);
     }
     A.tab         = tab.data();
     A.integrate_p = integrate_p;
@@ -46,10 +48,13 @@ namespace
     A.src_p       = src_p;
     A.dst_u       = dst_u;
     A.dst_p       = dst_p;
-    const int           npc = nst_of(lin_mode) / 2;
+    const bool          varco = rho != nullptr;
+    const int           npl = nst_of(lin_mode) / 2, npc = npl + (varco ? 2 : 0);
     std::vector<double> state((size_t)A.ngz * A.ngy * A.ncx * N * npc * G::CPW * G::NL * 2 + 2);
     if (npc > 0)
-      emu::launch(4, 256, [&] { hox_convert_state_kernel<K>(state.data(), lin_generic, A.ncx, A.ncy, A.ncz, A.ngy, A.ngz, npc); });
+      emu::launch(4, 256, [&] {
+        hox_convert_state_kernel<K>(state.data(), lin_generic, A.ncx, A.ncy, A.ncz, A.ngy, A.ngz, npc, varco ? npl : -1, rho, mu, damp);
+      });
     A.lin = state.data();
     const size_t        n_wg = (size_t)A.tiles_y * A.tiles_z * A.n_chunks;
     const double        nan  = std::nan("");
@@ -61,6 +66,28 @@ namespace
     A.xslab_p = xslab_p.data();
     const bool with_p = op == 0;
     auto       main_k = [&](const long nwg) {
+      if (varco)
+        {
+          if (with_p)
+            {
+              if (lin_mode == 0)
+                run_main<K, 0, true, true>(A, nwg);
+              else if (lin_mode == 1)
+                run_main<K, 1, true, true>(A, nwg);
+              else
+                run_main<K, 2, true, true>(A, nwg);
+            }
+          else
+            {
+              if (lin_mode == 0)
+                run_main<K, 0, false, true>(A, nwg);
+              else if (lin_mode == 1)
+                run_main<K, 1, false, true>(A, nwg);
+              else
+                run_main<K, 2, false, true>(A, nwg);
+            }
+          return;
+        }
       if (with_p)
         {
           if (lin_mode == 0)
@@ -186,16 +213,17 @@ extern "C" int hox_emu_residual(const int K, const int *ncell, const double *h, 
 extern "C" int hox_emu_vmult(const int K, const int *ncell, const double *h, const int op, const int lin_mode,
                              const int integrate_p, const double *coef, const unsigned con_u, const unsigned con_p,
                              const double *lin_generic, const double *src_u, const double *src_p, double *dst_u,
-                             double *dst_p, const int lx, const unsigned iface, const int phased)
+                             double *dst_p, const int lx, const unsigned iface, const int phased, const double *rho,
+                             const double *mu, const double *damp)
 {
   switch (K)
     {
       case 3:
-        return run<3>(ncell, h, op, lin_mode, integrate_p, coef, con_u, con_p, lin_generic, src_u, src_p, dst_u, dst_p, lx, iface, phased);
+        return run<3>(ncell, h, op, lin_mode, integrate_p, coef, con_u, con_p, lin_generic, src_u, src_p, dst_u, dst_p, lx, iface, phased, rho, mu, damp);
       case 4:
-        return run<4>(ncell, h, op, lin_mode, integrate_p, coef, con_u, con_p, lin_generic, src_u, src_p, dst_u, dst_p, lx, iface, phased);
+        return run<4>(ncell, h, op, lin_mode, integrate_p, coef, con_u, con_p, lin_generic, src_u, src_p, dst_u, dst_p, lx, iface, phased, rho, mu, damp);
       case 5:
-        return run<5>(ncell, h, op, lin_mode, integrate_p, coef, con_u, con_p, lin_generic, src_u, src_p, dst_u, dst_p, lx, iface, phased);
+        return run<5>(ncell, h, op, lin_mode, integrate_p, coef, con_u, con_p, lin_generic, src_u, src_p, dst_u, dst_p, lx, iface, phased, rho, mu, damp);
     }
   return -1;
 }

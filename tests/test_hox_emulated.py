@@ -37,7 +37,7 @@ def face_bits(faces, ncomp):
     return m
 
 
-def run_emulated(lib, case, op=0, lx=0, iface=0, phased=0, seed_src=True):
+def run_emulated(lib, case, op=0, lx=0, iface=0, phased=0, seed_src=True, varco=False):
     k, prm = case.k, case.prm
     src_u, src_p = case.random_u(), case.random_p()
     lin = case.random_lin()                                  # canonical [cell][q][12]
@@ -48,23 +48,28 @@ def run_emulated(lib, case, op=0, lx=0, iface=0, phased=0, seed_src=True):
     gamma = prm.weight if prm.physical_type == 0 else 0.0
     # the oracle's NSParams carries damping with the sign flipped (parameters.cc:466-467), as the engine's NSDev
     coef = np.array([0.0 if stokes else gamma * prm.density - prm.damping, 0.0 if stokes else prm.tau1 * prm.density,
-                     prm.beta, prm.tau_grad_div, prm.viscosity * prm.tau1])
+                     prm.beta, prm.tau_grad_div, prm.viscosity * prm.tau1,
+                     0.0 if stokes else gamma, 0.0 if stokes else prm.tau1, 0.0 if stokes else 1.0, prm.tau1])
+    co = {}
+    if varco:                                                # variable density / viscosity / damping per quadrature point
+        rho, mu, damp = case.random_coefficients()
+        co = dict(rho=rho, mu=mu, damp=damp)
     integrate_p = 0 if prm.linearization == 4 else 1
     dst_u = np.full(case.n_u, np.nan)
     dst_p = np.full(case.n_p, np.nan)
     ncell = (C.c_int * 3)(*case.ncell)
     h = (C.c_double * 3)(*[case.mesh.h[d] for d in range(3)])
-    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    dp = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
     rc = lib.hox_emu_vmult(k, ncell, h, op, lin_mode, integrate_p, dp(coef), face_bits(case.faces_u, 3),
                            face_bits(case.faces_p, 1), dp(lin_generic), dp(src_u), dp(src_p), dp(dst_u), dp(dst_p),
-                           lx if lx else case.ncell[0], iface, phased)
+                           lx if lx else case.ncell[0], iface, phased, dp(co.get("rho")), dp(co.get("mu")), dp(co.get("damp")))
     assert rc == 0
     if op == 0:
-        ref_u, ref_p = orc.ns_vmult(case.mesh, k, prm, src_u, src_p, case.con_u, case.con_p, lin=lin)
+        ref_u, ref_p = orc.ns_vmult(case.mesh, k, prm, src_u, src_p, case.con_u, case.con_p, lin=lin, **co)
         if not integrate_p:
             dst_p = ref_p          # projection scheme: the host prepares dst_p, the kernel does not touch it
         return rel_l2(dst_u, ref_u), rel_l2(dst_p, ref_p)
-    ref_u = orc.ns_velocity_vmult(case.mesh, k, prm, src_u, case.con_u, lin=lin)
+    ref_u = orc.ns_velocity_vmult(case.mesh, k, prm, src_u, case.con_u, lin=lin, **co)
     return rel_l2(dst_u, ref_u), 0.0
 
 
@@ -131,3 +136,14 @@ def test_emulated_residual_mode(emu, k, ncell, lx, lin, phys):
         got = lin_generic.reshape(case.n_cells, 12, case.nq).transpose(0, 2, 1)
         ncomp = 12 if lin_mode == 0 else 4
         assert rel_l2(got[:, :, :ncomp], lin_ref.reshape(case.n_cells, case.nq, 12)[:, :, :ncomp]) < TOL
+
+
+@pytest.mark.parametrize("k,ncell,lin,phys,op", [(4, (3, 2, 5), 0, 0, 0), (3, (3, 5, 3), 1, 0, 0), (5, (2, 3, 2), 0, 0, 0),
+                                                 (4, (2, 3, 4), 0, 2, 0), (4, (3, 3, 3), 0, 0, 2), (3, (4, 3, 5), 2, 0, 0)])
+def test_emulated_variable_coefficients(emu, k, ncell, lin, phys, op):
+    """two-phase Jacobian (template VARCO): density, viscosity and damping per quadrature point travel as two more
+    pieces of the state stream; Newton, Picard-type, Stokes, velocity block"""
+    case = Case(ncell, k=k, faces_u=[0, 3, 4], faces_p=[1], linearization=lin, physical_type=phys, tau_grad_div=0.3,
+                density_diff=-0.5)
+    eu, ep = run_emulated(emu, case, op=op, lx=2, varco=True)
+    assert eu < TOL and ep < TOL, (eu, ep)

@@ -539,6 +539,51 @@ def test_velocity_vmult_high_order_x_marching_kernel():
     assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL
 
 
+@pytest.mark.parametrize("k,ncell,lin,phys,chunk", [(4, (5, 4, 9), 0, 0, 0), (3, (6, 5, 5), 1, 0, 2), (5, (3, 2, 3), 0, 0, 0),
+                                                    (4, (3, 5, 2), 0, 2, 1), (3, (9, 4, 3), 0, 0, 4), (4, (4, 3, 3), 2, 0, 0)])
+def test_two_phase_vmult_x_marching_kernel(k, ncell, lin, phys, chunk):
+    """variable density / viscosity / damping at the quadrature points on the Q3..Q5 x-marching kernel (template VARCO:
+    the coefficients travel as two more pieces of the state stream): vmult and velocity block against the oracle, a
+    frozen copy (state AND coefficients) that survives new coefficients, and the way back to constant coefficients"""
+    case = Case(ncell, k=k, lower=(0., 0., 0.), upper=(1., 1.5, 1.), faces_u=[0, 2, 3, 5], faces_p=[1],
+                linearization=lin, physical_type=phys, tau_grad_div=0.2, density_diff=-0.5, steps=3)
+    src_u, src_p, lin_q = case.random_u(), case.random_p(), case.random_lin()
+    rho, mu, damp = case.random_coefficients()
+    rho2, mu2, damp2 = case.random_coefficients()
+    w, modes = case.weights_modes()
+    ref_u, ref_p = orc.ns_vmult(case.mesh, k, case.prm, src_u, src_p, case.con_u, case.con_p, lin=lin_q, rho=rho, mu=mu,
+                                damp=damp, weights=w, modes=modes)
+    ref_vel = orc.ns_velocity_vmult(case.mesh, k, case.prm, src_u, case.con_u, lin=lin_q, rho=rho, mu=mu, damp=damp)
+    ref2_u, ref2_p = orc.ns_vmult(case.mesh, k, case.prm, src_u, src_p, case.con_u, case.con_p, lin=lin_q, rho=rho2, mu=mu2,
+                                  damp=damp2, weights=w, modes=modes)
+    ref3_u, ref3_p = orc.ns_vmult(case.mesh, k, case.prm, src_u, src_p, case.con_u, case.con_p, lin=lin_q, weights=w, modes=modes)
+    for variant in (1, 0):
+        op = case.engine()
+        op.set_kernel_variant(variant)
+        op.set_x_chunk(chunk)
+        if phys != 2:
+            op.set_linearization(lin_q)
+        op.set_coefficients(rho, mu, damp)
+        src, dst = op.block_vector(src_u, src_p), op.block_vector()
+        op.vmult(dst, src)
+        gu, gp = dst.numpy()
+        assert rel_l2(gu, ref_u) < TOL and rel_l2(gp, ref_p) < TOL, (variant, rel_l2(gu, ref_u), rel_l2(gp, ref_p))
+        op.fix_linearization_point()
+        op.set_coefficients(rho2, mu2, damp2)
+        vdst = op.initialize_u_vector()
+        op.velocity_vmult(vdst, src.block(0))                   # frozen coefficients
+        assert rel_l2(vdst.numpy(), ref_vel) < TOL, variant
+        op.vmult(dst, src)                                      # current coefficients
+        gu, gp = dst.numpy()
+        assert rel_l2(gu, ref2_u) < TOL and rel_l2(gp, ref2_p) < TOL, variant
+        op.set_coefficients(None, None, None)
+        op.vmult(dst, src)
+        gu, gp = dst.numpy()
+        assert rel_l2(gu, ref3_u) < TOL and rel_l2(gp, ref3_p) < TOL, variant
+        op.velocity_vmult(vdst, src.block(0))                   # (still the frozen two-phase operator)
+        assert rel_l2(vdst.numpy(), ref_vel) < TOL, variant
+
+
 @pytest.mark.parametrize("k,ncell,lin,phys,chunk", [(4, (5, 4, 9), 0, 0, 0), (4, (9, 3, 2), 1, 0, 4), (3, (6, 5, 5), 0, 0, 2),
                                                     (5, (3, 2, 3), 0, 0, 0), (4, (4, 4, 4), 0, 1, 0), (4, (3, 5, 2), 0, 2, 1),
                                                     (3, (4, 4, 3), 1, 0, 0)])
