@@ -6,7 +6,12 @@ vector on one MI355X.  Prints the lines of the reference's output (verbosity 1):
     Residual/iterations: [<residual>/<FGMRES its>] ... [<residual>/conv.]
 
     python examples/rising_bubble_3d.py [cells_x] [subdivisions] [time steps]
-    python examples/rising_bubble_3d.py --prm case.prm [time steps]     # 5 * 2^"global refinements" cells in x"""
+    python examples/rising_bubble_3d.py --prm case.prm [time steps]     # 5 * 2^"global refinements" cells in x
+
+A parameter file with `set dimension = 2` (examples/rising_bubble_2d.prm = the values of the reference's
+tests/rising_bubble_ls.prm) runs the reference's own 2D case -- [0,1] x [0,2], symmetry on the side walls, no-slip at the
+bottom and the top (tests/rising_bubble.cc:119-150) -- on the device's flat-third-direction path; with 3 global
+refinements (40 x 80 cells) the printed lines are those of tests/rising_bubble_ls.output."""
 import os
 import sys
 import time
@@ -23,7 +28,6 @@ def main():
     if args and args[0] == "--prm":
         with open(args[1]) as f:
             fp = adaflo_amd.flow_parameters_from_prm(f.read())
-        fp.dimension = 3                                       # this engine is 3D: the case is extruded
         n = 5 * 2 ** fp.global_refinements                    # rising_bubble.cc:125-133
         steps = int(args[2]) if len(args) > 2 else 5
     else:
@@ -36,13 +40,22 @@ def main():
             interpolate_grad_onto_pressure=True, curvature_correction=True, time_step_size_start=0.02, end_time=3.0,
             max_nl_iteration=10, tol_nl_iteration=1e-9, max_lin_iteration=200, tol_lin_iteration=1e-4,
             n_reinit_steps=2, n_initial_reinit_steps=2)
-    mesh = adaflo_amd.BrickMesh([n, n, 2 * n], [0., 0., 0.], [1., 1., 2.])
-    centre = np.array([0.5, 0.5, 0.5])
+    dim = 2 if fp.dimension == 2 else 3
+    if dim == 2:
+        mesh = adaflo_amd.BrickMesh([n, 2 * n], [0., 0.], [1., 2.])
+        centre = np.array([0.5, 0.5, 0.0])
+        symmetry = [0, 1]                                      # side walls (rising_bubble.cc:133-150)
+    else:
+        mesh = adaflo_amd.BrickMesh([n, n, 2 * n], [0., 0., 0.], [1., 1., 2.])
+        centre = np.array([0.5, 0.5, 0.5])
+        symmetry = []                                          # the extruded case is a no-slip box
     solver = LevelSetOKZSolver(fp, mesh, lambda x: np.linalg.norm(x - centre, axis=1) - 0.25,
-                               n_reinit_steps=fp.n_reinit_steps, n_initial_reinit_steps=fp.n_initial_reinit_steps)
+                               n_reinit_steps=fp.n_reinit_steps, n_initial_reinit_steps=fp.n_initial_reinit_steps,
+                               symmetry_faces=symmetry)
     m = solver.navier_stokes.navier_stokes_matrix
     print("Number of active cells: %d." % mesh.n_cells)
-    print("Number of Navier-Stokes degrees of freedom: %d (%d + %d)." % (m.n_dofs_u() + m.n_dofs_p(), m.n_dofs_u(), m.n_dofs_p()))
+    nu_ = m.n_dofs_u() * dim // 3                              # (dim = 2: the engine carries a third, constrained component)
+    print("Number of Navier-Stokes degrees of freedom: %d (%d + %d)." % (nu_ + m.n_dofs_p(), nu_, m.n_dofs_p()))
     print("Number of level set degrees of freedom: %d." % solver.ops.n_dofs)
     print("  reinitialize (%s)" % " + ".join(str(i) for i in solver.initial_reinit_iterations))
     solver.ops.compute_heaviside(solver.heaviside, solver.solution, fp.epsilon)
@@ -66,7 +79,7 @@ def main():
         res = [float(np.hypot(*h)) for h in ns.history]
         its = [i for i, _ in ns.linear_iterations]
         print("  Residual/iterations: " + " ".join("[%.3g/%d]" % (r, i) for r, i in zip(res, its)) + " [%.3g/conv.]" % res[-1])
-        print("  Position of the center of mass:  %.8g  %.8g  %.8g" % tuple(c))
+        print("  Position of the center of mass:  " + "  ".join("%.8g" % v for v in c[:dim]) + "   (lumped Heaviside)")
         print("  (bubble volume drift %+.2e, |u|max %.3e, %.2f s wall)" % (vol / vol0 - 1, float(ns.solution[0].abs().max()), wall), flush=True)
 
 
