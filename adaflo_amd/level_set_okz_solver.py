@@ -196,6 +196,18 @@ class LevelSetOKZSolver:
         return self.last_concentration_range
 
     # ---- diagnostics (tests/rising_bubble.cc evaluates the same quantities) ----------------------
+    def compute_bubble_statistics(self):
+        """TwoPhaseBaseAlgorithm<2>::compute_bubble_statistics (two_phase_base.cc:621-905; dim = 2 only, as the
+        reference's tests use it): dict(area, perimeter, circularity, velocity, centre) and the three printed lines"""
+        from .two_phase_statistics import compute_bubble_statistics, format_bubble_statistics
+        p, m = self.parameters, self.mesh
+        stat = compute_bubble_statistics(m, p.concentration_subdivisions, p.velocity_degree, self.solution.numpy(),
+                                         self.navier_stokes.solution[0].cpu().numpy().reshape(-1, 3))
+        diameter = float(np.sqrt(sum((u - l) ** 2 for u, l in zip(m.upper[:m.dim], m.lower[:m.dim]))))
+        stat["lines"] = format_bubble_statistics(stat, diameter)
+        return stat
+
+
     def bubble_volume_and_centre(self):
         """integral of H and centre of mass of the second fluid (lumped with the mass diagonal)"""
         w = self.preconditioner.diagonal_vector.numpy()          # (phi_i, phi_i); proportional to the lumped weight

@@ -58,6 +58,8 @@ def main():
     print("Number of Navier-Stokes degrees of freedom: %d (%d + %d)." % (nu_ + m.n_dofs_p(), nu_, m.n_dofs_p()))
     print("Number of level set degrees of freedom: %d." % solver.ops.n_dofs)
     print("  reinitialize (%s)" % " + ".join(str(i) for i in solver.initial_reinit_iterations))
+    if dim == 2:
+        print("\n".join(solver.compute_bubble_statistics()["lines"]))
     solver.ops.compute_heaviside(solver.heaviside, solver.solution, fp.epsilon)
     vol0, c0 = solver.bubble_volume_and_centre()
     ts = solver.time_stepping
@@ -79,7 +81,10 @@ def main():
         res = [float(np.hypot(*h)) for h in ns.history]
         its = [i for i, _ in ns.linear_iterations]
         print("  Residual/iterations: " + " ".join("[%.3g/%d]" % (r, i) for r, i in zip(res, its)) + " [%.3g/conv.]" % res[-1])
-        print("  Position of the center of mass:  " + "  ".join("%.8g" % v for v in c[:dim]) + "   (lumped Heaviside)")
+        if dim == 2:                                            # the reference's statistics (two_phase_base.cc:621-905)
+            print("\n".join(solver.compute_bubble_statistics()["lines"]))
+        else:
+            print("  Position of the center of mass:  " + "  ".join("%.8g" % v for v in c[:dim]) + "   (lumped Heaviside)")
         print("  (bubble volume drift %+.2e, |u|max %.3e, %.2f s wall)" % (vol / vol0 - 1, float(ns.solution[0].abs().max()), wall), flush=True)
 
 

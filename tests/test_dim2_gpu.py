@@ -395,6 +395,10 @@ def _check_steps(dev, ref, ncell, statistics="bubble", physics=None):
         sim = _as_oracle_sim(dev, ncell, physics)
         if statistics == "bubble":
             circ, vel, centre, _ = tpo.bubble_statistics_2d(sim)
+            mine = dev.compute_bubble_statistics()                  # the product's own evaluation prints the same lines
+            assert abs(mine["circularity"] - circ) < 1e-12 and np.allclose(mine["velocity"], vel, rtol=1e-11, atol=1e-16)
+            assert np.allclose(mine["centre"], centre, rtol=1e-12)
+            assert mine["lines"][0].startswith("  Degree of circularity: " + expected["circularity"][:8])
             assert abs(circ - float(expected["circularity"])) < 1.5e-8, (no, circ)
             # (three units of the last printed digit: both codes stop their Newton iteration at a residual of 1e-9, the
             # reference with its ILU-preconditioned linear solves, the device with Jacobi-type inner solves)
