@@ -45,11 +45,65 @@ def node_coordinates(mesh, degree):
     return np.stack([x.reshape(-1), y.reshape(-1), z.reshape(-1)], axis=1)
 
 
+def open_boundary_rhs(mesh, k, open_faces, t):
+    """const_rhs of NavierStokes::apply_boundary_conditions (source/navier_stokes.cc:1259-1310): for every open face
+    int_face (phi_i . n) p_ext dS with QGauss(k + 1) per face direction, p_ext(x[n][3], t) the prescribed pressure.
+    Returns [n_nodes][3] (constrained rows are NOT removed here)."""
+    nn = mesh.nodes(k)
+    rhs = np.zeros((nn[2], nn[1], nn[0], 3))
+    gl = gauss_lobatto_points(k + 1)
+    xg, wg = np.polynomial.legendre.leggauss(k + 1)
+    xg, wg = 0.5 * (xg + 1.0), 0.5 * wg
+    S = np.ones((len(xg), k + 1))                                # S[q][i]: Lagrange basis through the GL points
+    for i in range(k + 1):
+        for j in range(k + 1):
+            if i != j:
+                S[:, i] *= (xg - gl[j]) / (gl[i] - gl[j])
+    for f, pressure in open_faces.items():
+        d, side = f // 2, f % 2
+        normal = 1.0 if side else -1.0
+        other = [e for e in range(mesh.dim) if e != d]
+        # quadrature points of all face cells: coordinate arrays per remaining direction [cell][q]
+        coords = [mesh.lower[e] + mesh.h[e] * (np.arange(mesh.ncell[e])[:, None] + xg[None, :]) for e in other]
+        x = np.zeros([len(c.reshape(-1)) for c in coords] + [3])
+        x[..., d] = mesh.upper[d] if side else mesh.lower[d]
+        if len(other) == 1:
+            x[:, other[0]] = coords[0].reshape(-1)
+        else:
+            x[:, :, other[0]] = coords[0].reshape(-1)[:, None]
+            x[:, :, other[1]] = coords[1].reshape(-1)[None, :]
+        pq = np.asarray(pressure(x.reshape(-1, 3), t), dtype=np.float64)
+        idx = [np.arange(mesh.ncell[e])[:, None] * k + np.arange(k + 1)[None, :] for e in other]   # [cell][i]
+        plane = [slice(None)] * 3
+        plane[2 - d] = nn[d] - 1 if side else 0
+        if len(other) == 1:
+            e = other[0]
+            pq = pq.reshape(mesh.ncell[e], k + 1)
+            loc = normal * mesh.h[e] * np.einsum("qi,cq,q->ci", S, pq, wg)
+            line = np.zeros(nn[e])
+            np.add.at(line, idx[0], loc)
+            target = rhs[tuple(plane)]                       # the two remaining axes (z, e) -> flat dim: z has one node
+            target.reshape(-1, 3)[:, d] += line
+        else:
+            e0, e1 = other                                   # e0 < e1: x[...] axes are (cells of e0, cells of e1)
+            pq = pq.reshape(mesh.ncell[e0], k + 1, mesh.ncell[e1], k + 1)
+            loc = normal * mesh.h[e0] * mesh.h[e1] * np.einsum("qi,rj,aqbr,q,r->aibj", S, S, pq, wg, wg)
+            face = np.zeros((nn[e0], nn[e1]))
+            np.add.at(face, (idx[0][:, :, None, None], idx[1][None, None, :, :]), loc)
+            target = rhs[tuple(plane)]                       # axes in (slower, faster) memory order = (e1, e0)
+            target[..., d] += face.T
+    return rhs.reshape(-1, 3)
+
+
 class NavierStokes:
-    def __init__(self, parameters, mesh, time_stepping, dirichlet_function, device=0, ls_degree=0, symmetry_faces=()):
+    def __init__(self, parameters, mesh, time_stepping, dirichlet_function, device=0, ls_degree=0, symmetry_faces=(),
+                 open_faces=None):
         """dirichlet_function(xyz[n][3], t) -> velocity[n][3] (dim = 2: [n][2] is fine) on the Dirichlet boundary = every
         face not in symmetry_faces; on those only the normal component is constrained, to zero
         (FlowBaseAlgorithm::set_symmetry_boundary; tests/rising_bubble.cc:133-150 uses it for the side walls);
+        open_faces {face: p_ext(x[n][3], t)}: open boundaries with normal flux (set_open_boundary_with_normal_flux,
+        tests/poiseuille.cc:252-255): tangential components constrained to zero, the prescribed pressure enters the
+        residual as a face integral, and the pressure level is fixed by it (no mean-value projection);
         ls_degree > 0 adds the level-set spaces to the engine context (two-phase flow)"""
         import torch
         if parameters.linearization == "projection":
@@ -61,12 +115,15 @@ class NavierStokes:
         self.device = torch.device("cuda", device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         symmetry_faces = sorted(set(int(f) for f in symmetry_faces))
-        assert all(0 <= f < 2 * mesh.dim for f in symmetry_faces)
-        dirichlet_faces = [f for f in range(2 * mesh.dim) if f not in symmetry_faces]
+        self.open_faces = dict(open_faces or {})
+        assert all(0 <= f < 2 * mesh.dim for f in symmetry_faces) and not set(symmetry_faces) & set(self.open_faces)
+        dirichlet_faces = [f for f in range(2 * mesh.dim) if f not in symmetry_faces and f not in self.open_faces]
         self.navier_stokes_matrix = NavierStokesMatrix(parameters, mesh, dirichlet_faces_u=dirichlet_faces,
                                                        symmetry_faces_u=symmetry_faces,
+                                                       normal_flux_faces_u=sorted(self.open_faces),
                                                        device=device, stream=stream, ls_degree=ls_degree)
-        self.navier_stokes_matrix.initialize(time_stepping, True)
+        # constant pressure modes only without an open boundary (navier_stokes.cc:330-346)
+        self.navier_stokes_matrix.initialize(time_stepping, not self.open_faces)
         m = self.navier_stokes_matrix
         k = parameters.velocity_degree
         self._lib, self._ctx = _lib.load(), m._require()
@@ -82,7 +139,10 @@ class NavierStokes:
         dof = (3 * self._bnodes[:, None] + np.arange(3)[None, :]).reshape(-1)
         self._bdofs = torch.from_numpy(dof).to(self.device)
         sym = [3 * np.nonzero(on_face(f) & ~on_b)[0] + f // 2 for f in symmetry_faces]
+        for f in self.open_faces:                                # tangential components on the open faces
+            sym += [3 * np.nonzero(on_face(f) & ~on_b)[0] + c for c in range(mesh.dim) if c != f // 2]
         self._symdofs = torch.from_numpy(np.concatenate(sym) if sym else np.zeros(0, dtype=np.int64)).to(self.device)
+        self.const_rhs_u = None                                  # open-boundary face integrals of the time level
         mk = lambda n: torch.zeros(n, dtype=torch.float64, device=self.device)
         nu, npp = m.n_dofs_u(), m.n_dofs_p()
         self.solution = [mk(nu), mk(npp)]
@@ -128,11 +188,21 @@ class NavierStokes:
         self.solution[0][self._bdofs] = torch.from_numpy(vals).to(self.device)
         if len(self._symdofs):
             self.solution[0][self._symdofs] = 0.0
+        if self.open_faces:                                      # const_rhs, navier_stokes.cc:1259-1310
+            rhs = open_boundary_rhs(self.mesh, self.parameters.velocity_degree, self.open_faces, ts.now()).reshape(-1)
+            rhs[self._bdofs.cpu().numpy()] = 0.0                 # distribute_local_to_global skips constrained rows
+            rhs[self._symdofs.cpu().numpy()] = 0.0
+            if self.mesh.dim == 2:
+                rhs[2::3] = 0.0
+            self.const_rhs_u = torch.from_numpy(rhs).to(self.device)
 
     def compute_residual(self):
         m = self.navier_stokes_matrix
-        # system_rhs.equ(1., const_rhs) with const_rhs = 0 (:784): the residual cell loop accumulates
-        self.system_rhs[0].zero_()
+        # system_rhs.equ(1., const_rhs) (:784; const_rhs = 0 without open boundaries): the residual cell loop accumulates
+        if self.const_rhs_u is not None:
+            self.system_rhs[0].copy_(self.const_rhs_u)
+        else:
+            self.system_rhs[0].zero_()
         self.system_rhs[1].zero_()
         m.residual(self._bv(self.system_rhs), self._bv(self.solution), self._bv(self.user_rhs),
                    self._bv(self.solution_old), self._bv(self.solution_old_old))

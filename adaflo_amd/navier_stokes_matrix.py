@@ -60,9 +60,11 @@ class NavierStokesMatrix:
     """Operator object usable by any Krylov solver that needs `vmult(dst, src)`."""
 
     def __init__(self, parameters, mesh, dirichlet_faces_u=range(6), constrained_faces_p=(),
-                 device=0, stream=None, ls_degree=0, symmetry_faces_u=()):
+                 device=0, stream=None, ls_degree=0, symmetry_faces_u=(), normal_flux_faces_u=()):
         """dirichlet_faces_u: all velocity components constrained; symmetry_faces_u: only the component normal to
-        the face (FlowBaseAlgorithm::set_symmetry_boundary, source/flow_base_algorithm.cc:95-101)"""
+        the face (FlowBaseAlgorithm::set_symmetry_boundary, source/flow_base_algorithm.cc:95-101); normal_flux_faces_u:
+        only the tangential components (set_open_boundary_with_normal_flux, :140-155 with
+        VectorTools::compute_normal_flux_constraints, source/navier_stokes.cc:294-297)"""
         self.parameters = parameters
         self.mesh = mesh
         self._lib = _lib.load()
@@ -81,6 +83,9 @@ class NavierStokesMatrix:
         for f in symmetry_faces_u:
             if f < 2 * mesh.dim:
                 d.velocity_constrained |= face_mask([f], 3, comps=[f // 2])
+        for f in normal_flux_faces_u:
+            if f < 2 * mesh.dim:
+                d.velocity_constrained |= face_mask([f], 3, comps=[c for c in range(mesh.dim) if c != f // 2])
         d.pressure_constrained = face_mask([f for f in constrained_faces_p if f < 2 * mesh.dim], 1)
         d.ls_constrained = 0
         d.device = device

@@ -477,3 +477,75 @@ def test_spurious_currents_prints_its_reference_output():
     assert (m.n_cells(), m.n_dofs_u() * 2 // 3, m.n_dofs_p(), dev.ops.n_dofs) == (
         ref["cells"], ref["dofs_u"], ref["dofs_p"], ref["dofs_ls"])
     _check_steps(dev, ref, (80, 80), statistics="spurious", physics=ph)
+
+
+@pytest.mark.parametrize("refinements", [4, 6])
+def test_poiseuille_stokes_prints_its_reference_output(refinements):
+    """tests/poiseuille_stokes.output (tests/poiseuille.cc, poiseuille_stokes.prm; 6 global refinements = 256 x 64 cells,
+    132 354 + 16 705 DoF): Stokes flow in the half channel [-2, 2] x [-1, 0], no-slip wall at the bottom, symmetry at
+    y = 0, open boundaries with normal flux and the pressure 2 - x at both ends.  The first residual -- the open-boundary
+    face integrals on the free rows -- prints `3.722e-01`; the exact solution u = (1 - y^2) / (2 nu), p = 2 - x lies in the
+    Q2/Q1 space, so the converged errors are round-off (the reference prints 9.5e-12 / 5.4e-12)."""
+    nu = 0.1
+    n = 2 ** refinements
+    mesh = adaflo_amd.BrickMesh([4 * n, n], [-2.0, -1.0], [2.0, 0.0])
+    fp = adaflo_amd.FlowParameters(velocity_degree=2, physical_type="stokes", viscosity=nu, time_step_size_start=0.01,
+                                   end_time=1.0, max_nl_iteration=10, tol_nl_iteration=1e-10, max_lin_iteration=500,
+                                   tol_lin_iteration=1e-5)
+    from adaflo_amd.navier_stokes import NavierStokes, node_coordinates
+    p_ext = lambda x, t: 2.0 - x[:, 0]
+    ns = NavierStokes(fp, mesh, adaflo_amd.TimeStepping(fp), dirichlet_function=lambda x, t: np.zeros((len(x), 2)),
+                      symmetry_faces=[3], open_faces={0: p_ext, 1: p_ext})
+    m = ns.navier_stokes_matrix
+    if refinements == 6:
+        assert (m.n_cells(), m.n_dofs_u() * 2 // 3, m.n_dofs_p()) == (16384, 132354, 16705)   # poiseuille_stokes.output:2-3
+    ns.init_time_advance()
+    res = ns.compute_residual()
+    if refinements == 6:
+        assert "%.3e" % res == "3.722e-01"                                                   # poiseuille_stokes.output:11
+    ns.solve_nonlinear_system(res)
+    assert np.hypot(*ns.history[-1]) < 1e-10, ns.history
+    xu, xp = node_coordinates(mesh, 2), node_coordinates(mesh, 1)
+    u = ns.solution[0].cpu().numpy().reshape(-1, 3)
+    p = ns.solution[1].cpu().numpy()
+    assert np.abs(u[:, 0] - 0.5 / nu * (1 - xu[:, 1] ** 2)).max() < 1e-8 and np.abs(u[:, 1:]).max() < 1e-8
+    assert np.abs(p - (2.0 - xp[:, 0])).max() < 1e-8
+
+
+def test_poiseuille_navier_stokes_prints_its_reference_output():
+    """tests/poiseuille_ns.output (poiseuille_ns.prm: 64 x 16 cells, 8 514 + 1 105 DoF, nu = 0.5, BDF-2 with dt = 0.5 from
+    rest): the channel flow develops towards the parabolic profile.  The first nonlinear residual of every time step
+    depends only on the converged steps before it: `7.419e-01`, `5.800e-02`, `2.307e-02`, `1.560e-02` (:11, :31, :40,
+    :49); after four steps the velocity error against the STEADY profile prints `0.1321` (:56, QGauss(4) per cell)."""
+    from adaflo_amd.navier_stokes import NavierStokes, node_coordinates
+    from common import l2_norm_of_difference
+    nu = 0.5
+    mesh = adaflo_amd.BrickMesh([64, 16], [-2.0, -1.0], [2.0, 0.0])
+    fp = adaflo_amd.FlowParameters(velocity_degree=2, viscosity=nu, time_step_size_start=0.5, end_time=20.0,
+                                   max_nl_iteration=10, tol_nl_iteration=1e-11, max_lin_iteration=500, tol_lin_iteration=1e-5)
+    p_ext = lambda x, t: 2.0 - x[:, 0]
+    ns = NavierStokes(fp, mesh, adaflo_amd.TimeStepping(fp), dirichlet_function=lambda x, t: np.zeros((len(x), 2)),
+                      symmetry_faces=[3], open_faces={0: p_ext, 1: p_ext})
+    m = ns.navier_stokes_matrix
+    assert (m.n_cells(), m.n_dofs_u() * 2 // 3, m.n_dofs_p()) == (1024, 8514, 1105)           # poiseuille_ns.output:2-3
+    for expected in ("7.419e-01", "5.800e-02", "2.307e-02", "1.560e-02"):
+        ns.history.clear()
+        ns.advance_time_step()
+        assert "%.3e" % np.hypot(*ns.history[0]) == expected, ns.history
+        assert np.hypot(*ns.history[-1]) < 1e-11, ns.history
+    # ||e_u||_L2 against u = (1 - y^2) / (2 nu) e_x with QGauss(k + 2) (tests/poiseuille.cc:150-190)
+    omesh = orc.Mesh.make([64, 16], (-2.0, -1.0), (2.0, 0.0))
+    u = u2(ns.solution[0].cpu().numpy())
+    xq, wq = orc.gauss_legendre(4)
+    S, _ = orc.shape_1d(0, 2, xq)
+    uu = u.reshape(33, 129, 2)
+    iy = np.arange(16)[:, None] * 2 + np.arange(3)[None, :]
+    ix = np.arange(64)[:, None] * 2 + np.arange(3)[None, :]
+    loc = uu[iy[:, None, :, None], ix[None, :, None, :]]                                    # [cy][cx][j][i][c]
+    val = np.einsum("qj,pi,yxjic->yxqpc", S, S, loc)
+    yq = -1.0 + (np.arange(16)[:, None] + xq[None, :]) / 16.0                                 # [cy][q]
+    exact = np.zeros_like(val)
+    exact[..., 0] = (0.5 / nu * (1 - yq ** 2))[:, None, :, None]
+    w = np.outer(wq, wq) / 16.0 / 16.0
+    err = np.sqrt(np.einsum("yxqpc,qp->", (val - exact) ** 2, w))
+    assert "%.4g" % err == "0.1321", err
