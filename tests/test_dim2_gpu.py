@@ -549,3 +549,24 @@ def test_poiseuille_navier_stokes_prints_its_reference_output():
     w = np.outer(wq, wq) / 16.0 / 16.0
     err = np.sqrt(np.einsum("yxqpc,qp->", (val - exact) ** 2, w))
     assert "%.4g" % err == "0.1321", err
+
+
+def test_couette_prints_its_reference_output():
+    """tests/couette.output (tests/couette.cc, couette.prm: 64 x 16 cells, nu = 0.5, BDF-2 with dt = 0.5): the top wall
+    moves with velocity (2, 0), the bottom wall rests, both ends are open (normal flux, zero pressure).  First nonlinear
+    residuals of the two time steps: `1.601e+01` (:10) and `1.930e-01` (:31)."""
+    from adaflo_amd.navier_stokes import NavierStokes
+    mesh = adaflo_amd.BrickMesh([64, 16], [-2.0, -1.0], [2.0, 0.0])
+    fp = adaflo_amd.FlowParameters(velocity_degree=2, viscosity=0.5, time_step_size_start=0.5, end_time=1.0,
+                                   max_nl_iteration=10, tol_nl_iteration=1e-11, max_lin_iteration=500, tol_lin_iteration=1e-5)
+    wall = lambda x, t: np.stack([np.where(np.abs(x[:, 1]) < 1e-13, 2.0, 0.0), np.zeros(len(x))], axis=1)
+    zero = lambda x, t: np.zeros(len(x))
+    ns = NavierStokes(fp, mesh, adaflo_amd.TimeStepping(fp), dirichlet_function=wall, open_faces={0: zero, 1: zero})
+    for expected in ("1.601e+01", "1.930e-01"):
+        ns.history.clear()
+        ns.advance_time_step()
+        assert "%.3e" % np.hypot(*ns.history[0]) == expected, ns.history
+        assert np.hypot(*ns.history[-1]) < 1e-11, ns.history
+    # the steady state is the linear profile u = 2 (1 + y): after two steps the flow is on its way there
+    u = ns.solution[0].cpu().numpy().reshape(33, 129, 3)
+    assert np.all(np.diff(u[:, 64, 0]) > 0) and abs(u[-1, 64, 0] - 2.0) < 1e-14 and np.abs(u[:, :, 1]).max() < 1e-9
