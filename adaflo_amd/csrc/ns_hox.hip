@@ -342,12 +342,10 @@ namespace adaflo_hip
       if (phase == 0)
         return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
       const bool fix_p = with_p && A.integrate_p;
-      const long items = hox_fix_items(A, fix_p);
-      if (items > 0 && !(phase == 1 && iface == 0u)) // (no interface: phase 1 has nothing to fix up)
+      const long blocks = hox_fix_blocks(A, fix_p); // one per seam row, one per 256 entries of the x-seam planes
+      if (blocks > 0 && !(phase == 1 && iface == 0u)) // (no interface: phase 1 has nothing to fix up)
         {
-          long nb = (items + 255) / 256;
-          if (nb > 256 * 32)
-            nb = 256 * 32;
+          const long nb = blocks > 256 * 256 ? 256 * 256 : blocks;
           hipLaunchKernelGGL((ns_hox_fixup_kernel<K>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, A, fix_p ? 1 : 0);
         }
       return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;

@@ -163,19 +163,6 @@ namespace adaflo_hip
       list      = bnd;
       list.insert(list.end(), inner.begin(), inner.end());
     }
-    // number of work items of the fix-up pass
-    inline long hox_fix_items(const HXArgs &A, const bool with_p)
-    {
-      long items = 0;
-      for (int space = 0; space < (with_p ? 2 : 1); ++space)
-        {
-          const long nx = space ? A.npx : A.nnx, ny = space ? A.npy : A.nny, nz = space ? A.npz : A.nnz, nc = space ? 1 : 3;
-          const long it = ((long)(A.tiles_y - 1) * nz + (long)(A.tiles_z - 1) * ny) * nx * nc + (long)(A.n_chunks - 1) * ny * nz * nc;
-          items         = it > items ? it : items;
-        }
-      return items;
-    }
-
     // rim line of the cross-section node grid (TY x TZ nodes): the high rim in y, then the high rim in z
     template <int TY, int TZ>
     __device__ __forceinline__ int rim_line(const int jl, const int kl)
@@ -1227,63 +1214,87 @@ namespace adaflo_hip
       dst[(((size_t)Kz * nn_y + J) * nn_x + I) * NC + comp] += sum;
     }
 
-    // work items: [rows on y seams | rows on z seams (not on y seams) | x-seam planes (rows not on a seam)], for the
-    // velocity and then the pressure space; a row item = one entry (I, comp) of a seam row
+    // work of the fix-up pass: per space (velocity, then pressure) one BLOCK ITEM per seam row -- rows on y seams, then
+    // rows on z seams (those also on a y seam are done there) -- and one per 256 entries of the x-seam planes.  The row of
+    // a block item is block-uniform (scalar divisions only); a thread walks the entries (I, comp) of the row
+    inline long hox_fix_blocks(const HXArgs &A, const bool with_p)
+    {
+      long blocks = 0;
+      for (int space = 0; space < (with_p ? 2 : 1); ++space)
+        {
+          const long ny = space ? A.npy : A.nny, nz = space ? A.npz : A.nnz, nc = space ? 1 : 3;
+          blocks += (long)(A.tiles_y - 1) * nz + (long)(A.tiles_z - 1) * ny + ((long)(A.n_chunks - 1) * ny * nz * nc + 255) / 256;
+        }
+      return blocks;
+    }
+
+    template <int K, int SPACE>
+    __device__ __forceinline__ void hox_fix_block(const HXArgs &A, long bb, bool &done)
+    {
+      using G             = Geo<K>;
+      constexpr int  DEG = SPACE == 0 ? K : K - 1, NC = SPACE == 0 ? 3 : 1;
+      const int      nn_x = SPACE == 0 ? A.nnx : A.npx, nn_y = SPACE == 0 ? A.nny : A.npy, nn_z = SPACE == 0 ? A.nnz : A.npz;
+      const long     n_y = (long)(A.tiles_y - 1) * nn_z, n_z = (long)(A.tiles_z - 1) * nn_y;
+      const long     n_xpl = (long)(A.n_chunks - 1) * nn_y * nn_z * NC, n_xb = (n_xpl + 255) / 256;
+      double        *dst = SPACE == 0 ? A.dst_u : A.dst_p;
+      const double  *slab = SPACE == 0 ? A.slab_u : A.slab_p, *xslab = SPACE == 0 ? A.xslab_u : A.xslab_p;
+      const uint32_t con = SPACE == 0 ? A.con_u : A.con_p;
+      done               = true;
+      if (bb < n_y + n_z)
+        {
+          int J, Kz;
+          if (bb < n_y)
+            {
+              J  = (int)(bb / nn_z + 1) * DEG * G::CY;
+              Kz = (int)(bb % nn_z);
+            }
+          else
+            {
+              Kz = (int)((bb - n_y) / nn_y + 1) * DEG * G::CZ;
+              J  = (int)((bb - n_y) % nn_y);
+              if (J > 0 && J < nn_y - 1 && J % (DEG * G::CY) == 0)
+                return; // on a y seam: done there
+            }
+          for (int e = threadIdx.x; e < nn_x * NC; e += blockDim.x)
+            hox_fix_entry<DEG, G::CY, G::CZ, NC>(A, e / NC, J, Kz, e % NC, dst, slab, xslab, nn_x, nn_y, nn_z, con);
+          return;
+        }
+      bb -= n_y + n_z;
+      if (bb < n_xb)
+        {
+          long e = bb * 256 + threadIdx.x;
+          if (e < n_xpl)
+            {
+              const int comp = (int)(e % NC);
+              e /= NC;
+              const int J = (int)(e % nn_y);
+              e /= nn_y;
+              const int Kz = (int)(e % nn_z), I = (int)(e / nn_z + 1) * DEG * A.LX;
+              if (!((J > 0 && J < nn_y - 1 && J % (DEG * G::CY) == 0) || (Kz > 0 && Kz < nn_z - 1 && Kz % (DEG * G::CZ) == 0)))
+                hox_fix_entry<DEG, G::CY, G::CZ, NC>(A, I, J, Kz, comp, dst, slab, xslab, nn_x, nn_y, nn_z, con);
+            }
+          return;
+        }
+      done = false;
+    }
+
     template <int K>
     __global__ __launch_bounds__(256) void ns_hox_fixup_kernel(const HXArgs A, const int with_p)
     {
-      using G = Geo<K>;
-      for (int space = 0; space < (with_p ? 2 : 1); ++space)
+      long total = 0, first_p = 0;
+      {
+        const long nu_ = (long)(A.tiles_y - 1) * A.nnz + (long)(A.tiles_z - 1) * A.nny + ((long)(A.n_chunks - 1) * A.nny * A.nnz * 3 + 255) / 256;
+        const long np_ = (long)(A.tiles_y - 1) * A.npz + (long)(A.tiles_z - 1) * A.npy + ((long)(A.n_chunks - 1) * A.npy * A.npz + 255) / 256;
+        first_p        = nu_;
+        total          = nu_ + (with_p ? np_ : 0);
+      }
+      for (long bb = blockIdx.x; bb < total; bb += gridDim.x)
         {
-          const int      deg = space == 0 ? K : K - 1, nc = space == 0 ? 3 : 1;
-          const int      nn_x = space == 0 ? A.nnx : A.npx, nn_y = space == 0 ? A.nny : A.npy, nn_z = space == 0 ? A.nnz : A.npz;
-          const long     rowlen = (long)nn_x * nc;
-          const long     n_y = (long)(A.tiles_y - 1) * nn_z, n_z = (long)(A.tiles_z - 1) * nn_y;
-          const long     n_rows = n_y + n_z;
-          const long     n_xpl = (long)(A.n_chunks - 1) * nn_y * nn_z * nc;
-          const long     total = n_rows * rowlen + n_xpl;
-          double        *dst   = space == 0 ? A.dst_u : A.dst_p;
-          const double  *slab = space == 0 ? A.slab_u : A.slab_p, *xslab = space == 0 ? A.xslab_u : A.xslab_p;
-          const uint32_t con  = space == 0 ? A.con_u : A.con_p;
-          for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x)
-            {
-              int I, J, Kz, comp;
-              if (it < n_rows * rowlen)
-                {
-                  const long row = it / rowlen;
-                  const int  e   = (int)(it % rowlen);
-                  I    = e / nc;
-                  comp = e % nc;
-                  if (row < n_y)
-                    {
-                      J  = (int)(row / nn_z + 1) * deg * G::CY;
-                      Kz = (int)(row % nn_z);
-                    }
-                  else
-                    {
-                      Kz = (int)((row - n_y) / nn_y + 1) * deg * G::CZ;
-                      J  = (int)((row - n_y) % nn_y);
-                      if (J > 0 && J < nn_y - 1 && J % (deg * G::CY) == 0)
-                        continue; // on a y seam: done above
-                    }
-                }
-              else
-                {
-                  long e = it - n_rows * rowlen;
-                  comp   = (int)(e % nc);
-                  e /= nc;
-                  J = (int)(e % nn_y);
-                  e /= nn_y;
-                  Kz = (int)(e % nn_z);
-                  I  = (int)(e / nn_z + 1) * deg * A.LX;
-                  if ((J > 0 && J < nn_y - 1 && J % (deg * G::CY) == 0) || (Kz > 0 && Kz < nn_z - 1 && Kz % (deg * G::CZ) == 0))
-                    continue; // on a seam row: done above
-                }
-              if (space == 0)
-                hox_fix_entry<K, G::CY, G::CZ, 3>(A, I, J, Kz, comp, dst, slab, xslab, nn_x, nn_y, nn_z, con);
-              else
-                hox_fix_entry<K - 1, G::CY, G::CZ, 1>(A, I, J, Kz, comp, dst, slab, xslab, nn_x, nn_y, nn_z, con);
-            }
+          bool done;
+          if (bb < first_p)
+            hox_fix_block<K, 0>(A, bb, done);
+          else
+            hox_fix_block<K, 1>(A, bb - first_p, done);
         }
     }
 

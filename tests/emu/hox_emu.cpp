@@ -109,7 +109,7 @@ namespace
     };
     const bool fix_p = with_p && integrate_p;
     auto       fixup = [&] {
-      if (hox_fix_items(A, fix_p) > 0)
+      if (hox_fix_blocks(A, fix_p) > 0)
         emu::launch(3, 256, [&] { ns_hox_fixup_kernel<K>(A, fix_p ? 1 : 0); });
     };
     if (!phased)
@@ -185,7 +185,7 @@ namespace
       emu::launch((unsigned)n_wg, NTH, [&] { ns_hox_kernel<K, 1, true, true>(A); });
     else
       emu::launch((unsigned)n_wg, NTH, [&] { ns_hox_kernel<K, 2, true, true>(A); });
-    if (hox_fix_items(A, true) > 0)
+    if (hox_fix_blocks(A, true) > 0)
       emu::launch(3, 256, [&] { ns_hox_fixup_kernel<K>(A, 1); });
     if (npc > 0)
       emu::launch(4, 256, [&] { hox_unconvert_state_kernel<K>(lin_generic, state.data(), A.ncx, A.ncy, A.ncz, A.ngy, A.ngz, npc); });
