@@ -26,6 +26,11 @@ TOL = 1e-12
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_outputs.json")
 
 
+def _ref(case):
+    with open(GOLDEN) as f:
+        return json.load(f)[case]
+
+
 # ---- 2-component (oracle, reference) <-> 3-component (device) layouts -----------------------------------------------
 def u3(u2):
     a = np.zeros((u2.size // 2, 3))
@@ -502,7 +507,7 @@ def test_poiseuille_stokes_prints_its_reference_output(refinements):
     ns.init_time_advance()
     res = ns.compute_residual()
     if refinements == 6:
-        assert "%.3e" % res == "3.722e-01"                                                   # poiseuille_stokes.output:11
+        assert "%.3e" % res == _ref("poiseuille_stokes")["first_residual"]                                                   # poiseuille_stokes.output:11
     ns.solve_nonlinear_system(res)
     assert np.hypot(*ns.history[-1]) < 1e-10, ns.history
     xu, xp = node_coordinates(mesh, 2), node_coordinates(mesh, 1)
@@ -528,7 +533,7 @@ def test_poiseuille_navier_stokes_prints_its_reference_output():
                       symmetry_faces=[3], open_faces={0: p_ext, 1: p_ext})
     m = ns.navier_stokes_matrix
     assert (m.n_cells(), m.n_dofs_u() * 2 // 3, m.n_dofs_p()) == (1024, 8514, 1105)           # poiseuille_ns.output:2-3
-    for expected in ("7.419e-01", "5.800e-02", "2.307e-02", "1.560e-02"):
+    for expected in _ref("poiseuille_ns")["first_residuals"]:
         ns.history.clear()
         ns.advance_time_step()
         assert "%.3e" % np.hypot(*ns.history[0]) == expected, ns.history
@@ -548,7 +553,7 @@ def test_poiseuille_navier_stokes_prints_its_reference_output():
     exact[..., 0] = (0.5 / nu * (1 - yq ** 2))[:, None, :, None]
     w = np.outer(wq, wq) / 16.0 / 16.0
     err = np.sqrt(np.einsum("yxqpc,qp->", (val - exact) ** 2, w))
-    assert "%.4g" % err == "0.1321", err
+    assert "%.4g" % err == _ref("poiseuille_ns")["l2_error_u_after_four_steps"], err
 
 
 def test_couette_prints_its_reference_output():
@@ -562,7 +567,7 @@ def test_couette_prints_its_reference_output():
     wall = lambda x, t: np.stack([np.where(np.abs(x[:, 1]) < 1e-13, 2.0, 0.0), np.zeros(len(x))], axis=1)
     zero = lambda x, t: np.zeros(len(x))
     ns = NavierStokes(fp, mesh, adaflo_amd.TimeStepping(fp), dirichlet_function=wall, open_faces={0: zero, 1: zero})
-    for expected in ("1.601e+01", "1.930e-01"):
+    for expected in _ref("couette")["first_residuals"]:
         ns.history.clear()
         ns.advance_time_step()
         assert "%.3e" % np.hypot(*ns.history[0]) == expected, ns.history
