@@ -128,6 +128,25 @@ namespace adaflo_hip
                    : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5])
                    : "n"(C));
   }
+  // point-to-point hand-off between the waves of a workgroup through a 32-bit flag in LDS (ns_hox_kernel, HOX_FLAGS):
+  // the LDS pipeline serves the requests of a CU in order, so data written before the flag is visible to a wave that has
+  // read the flag
+  __device__ __forceinline__ void lds_flag_set(const unsigned byte_addr, const int value)
+  {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" : : "v"(byte_addr), "v"(value) : "memory");
+  }
+  __device__ __forceinline__ void lds_flag_wait(const unsigned byte_addr, const int target)
+  {
+    int v;
+    do
+      {
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(byte_addr) : "memory");
+        v = __builtin_amdgcn_readfirstlane(v);
+        if (v < target)
+          __builtin_amdgcn_s_sleep(1);
+      }
+    while (v < target);
+  }
   template <int CNT>
   __device__ __forceinline__ void ds_wait1(double &x)
   {

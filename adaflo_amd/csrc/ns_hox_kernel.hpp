@@ -45,6 +45,11 @@ namespace adaflo_hip
 #ifndef HOX_STAMP
 #define HOX_STAMP 0
 #endif
+    // HOX_FLAGS: the waves of a workgroup hand their published face sums to the neighbours through flags in LDS (a
+    // wave waits for its lower neighbours in y / z only) instead of meeting at a workgroup barrier every step
+#ifndef HOX_FLAGS
+#define HOX_FLAGS 0
+#endif
     constexpr int NTH  = 256;
     constexpr int NMAX = 6;
     constexpr int NLIN_ = 12;
@@ -89,7 +94,8 @@ namespace adaflo_hip
       static constexpr bool RING = K == 4;
       static constexpr int  SLOT = 16 * ((CPW - 1) * PL + NL);          // bytes
       static constexpr int  RING_BYTES = RING ? 2 * (NLIN_ / 2) * SLOT : 0; // per wave
-      static constexpr int  LDS_BYTES = 8 * (4 * WAVE + PUB_DOUBLES) + 4 * RING_BYTES;
+      static constexpr int  FLAG_BYTES = 64; // pub[4], done[4] (HOX_FLAGS)
+      static constexpr int  LDS_BYTES = 8 * (4 * WAVE + PUB_DOUBLES) + 4 * RING_BYTES + FLAG_BYTES;
       static_assert(NL <= PL, "cell does not fit its lane slot");
       static_assert(WY * WZ == 4, "four waves per workgroup");
     };
@@ -510,6 +516,15 @@ namespace adaflo_hip
       constexpr int  SLOT = G::SLOT, RS = 2 * (NST / 2 > 0 ? NST / 2 : 1);
       char *const    ring = reinterpret_cast<char *>(lds + 4 * G::WAVE + G::PUB_DOUBLES) + wave * G::RING_BYTES;
       const unsigned ring_m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_byte_addr(ring)), ring_lane = lds_byte_addr(ring) + 16 * lane;
+      // hand-off flags (HOX_FLAGS): pub[w] = number of combines wave w has published, done[w] = ... has collected
+      const unsigned flag0 = lds_byte_addr(reinterpret_cast<char *>(lds + 4 * G::WAVE + G::PUB_DOUBLES) + 4 * G::RING_BYTES);
+      int            seq   = 0;
+      if (HOX_FLAGS)
+        {
+          if (lane < 8 && wave == 0)
+            lds_flag_set(flag0 + 4 * lane, 0);
+          __syncthreads();
+        }
 
       const ctab_t tab = as_ctab(A.tab);
 
@@ -589,6 +604,22 @@ namespace adaflo_hip
         const unsigned urow = (unsigned)(((size_t)(K * cz_ + b) * A.nny + (K * cy_ + a)) * A.nnx * 3),
                        prow = (unsigned)(((size_t)(KP * cz_ + min(b, KP)) * A.npy + (KP * cy_ + min(a, KP))) * A.npx);
         double *const PY = PUBY + (G::PUBY_BUFS == 2 ? parity * PUBD : 0), *const PZ = PUBZ + parity * PUBD;
+        constexpr int WZ_ = G::WZ;
+        const int     wy_ = wave % WY, wz_ = wave / WY;
+        if (HOX_FLAGS)
+          {
+            // the buffers of this parity were last filled two combines ago: my upper neighbours must have collected them
+            ++seq;
+            if (seq > 2)
+              {
+                if (wy_ + 1 < WY)
+                  lds_flag_wait(flag0 + 16 + 4 * (wave + 1), seq - 2);
+                if (wz_ + 1 < WZ_)
+                  lds_flag_wait(flag0 + 16 + 4 * (wave + WY), seq - 2);
+                if (wy_ + 1 < WY && wz_ + 1 < WZ_)
+                  lds_flag_wait(flag0 + 16 + 4 * (wave + WY + 1), seq - 2);
+              }
+          }
         wave_sync(); // (the single y buffer: every lane of the wave is done with the last collect)
         if (!(HOX_EXP & 64))
           {
@@ -624,7 +655,19 @@ namespace adaflo_hip
               }
           }
         HOX_MARK(6)
-        lds_barrier(); // (LDS only: the prefetches and stores of the step stay in flight)
+        if (HOX_FLAGS)
+          {
+            lds_flag_set(flag0 + 4 * wave, seq); // (after my publish writes: the LDS serves a wave's requests in order)
+            if (wy_ > 0)
+              lds_flag_wait(flag0 + 4 * (wave - 1), seq);
+            if (wz_ > 0)
+              lds_flag_wait(flag0 + 4 * (wave - WY), seq);
+            if (wy_ > 0 && wz_ > 0)
+              lds_flag_wait(flag0 + 4 * (wave - WY - 1), seq);
+            wave_sync();
+          }
+        else
+          lds_barrier(); // (LDS only: the prefetches and stores of the step stay in flight)
         // lower neighbour in y: its line (K, b); in z: its line (a, K); both: the corner line (K, K) of the diagonal
         // cell, which that cell published in both directions -- taken from the z area (double-buffered)
         if (fl & F_CY)
@@ -670,6 +713,8 @@ namespace adaflo_hip
               }
           }
           }
+        if (HOX_FLAGS)
+          lds_flag_set(flag0 + 16 + 4 * wave, seq); // (waits for my collect reads: lgkmcnt(0))
         HOX_MARK(7)
         // ---- emit: dst, or the slab on the high rim of the workgroup, or the x-slab at the end of a chunk ------
         const bool to_xslab = endplane && x_seam_end;

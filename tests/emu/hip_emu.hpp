@@ -188,6 +188,12 @@ namespace adaflo_hip
   inline unsigned long long clock_now() { return 0; }
   inline void   wave_sync() { emu::yield(1); }
   inline void   lds_barrier() { emu::yield(2); }
+  inline void   lds_flag_set(const unsigned a, const int v) { *reinterpret_cast<volatile int *>(emu::g_lds + a) = v; }
+  inline void   lds_flag_wait(const unsigned a, const int target)
+  {
+    while (*reinterpret_cast<volatile int *>(emu::g_lds + a) < target)
+      emu::yield(0); // (cooperative spin: the other fibers run in between)
+  }
   inline double *dyn_lds() { return reinterpret_cast<double *>(emu::g_lds); } // the workgroup's dynamic LDS
   inline unsigned lds_byte_addr(const void *p) { return (unsigned)((const char *)p - emu::g_lds); }
   template <int OFF>

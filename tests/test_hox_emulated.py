@@ -22,9 +22,11 @@ LIB = os.path.join(HERE, "emu", "_hox_emu.so")
 
 @pytest.fixture(scope="module")
 def emu():
-    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC])
-    lib = C.CDLL(LIB)
+    defines = os.environ.get("HOX_EMU_DEFINES", "").split()        # e.g. -DHOX_FLAGS=1 (development: another build)
+    lib_path = LIB if not defines else LIB.replace(".so", "_" + "".join(c for c in "".join(defines) if c.isalnum()) + ".so")
+    if not os.path.exists(lib_path) or any(os.path.getmtime(d) > os.path.getmtime(lib_path) for d in DEPS):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC"] + defines + ["-o", lib_path, SRC])
+    lib = C.CDLL(lib_path)
     lib.hox_emu_vmult.restype = C.c_int
     return lib
 
