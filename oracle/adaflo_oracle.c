@@ -19,9 +19,9 @@
  * Parity pins (the reference's own golden outputs, reproduced through this file):
  *   tests/beltrami_3d.output:13   first nonlinear residual of time step #1, 2.590e+00 / 6.423e-02
  *   tests/beltrami_3d.output:5-6  L2 errors of the initial interpolant, 0.02383 / 0.0001993 (shape functions)
- *   tests/beltrami_3d.output:31   first residual of time step #2 after a converged Newton
+ *   tests/beltrami_3d.output:35   first residual of time step #2 after a converged Newton
  *                                 iteration, 2.348e+00 / 5.678e-02   (tests/test_oracle_golden.py)
- *   tests/beltrami_3d.output:49   first residual of time step #3, 2.793e-01 / 6.590e-03
+ *   tests/beltrami_3d.output:57   first residual of time step #3, 2.793e-01 / 6.590e-03
  *   tests/rising_bubble_ls.output:5-29   initial state and time steps #1-#3 of the 2D rising bubble:
  *                                 advection residual / iterations, reinitialisation iterations,
  *                                 first two-phase residual of every step
@@ -32,6 +32,10 @@
  *   tests/spurious_currents_ls.output:2-25  static bubble, constant coefficients (0.365, 0.00024, 0.00014)
  *   ... and, for the five rising-bubble outputs, the 8-digit bubble statistics of the CONVERGED solutions
  *   (circularity, mean bubble velocity, centre of mass; oracle/two_phase_oracle.py::bubble_statistics_2d)
+ *   tests/poiseuille_stokes.output:11, tests/poiseuille_ns.output:11,31,40,49,56, tests/couette.output:10,31
+ *                                 2D channel flows with open boundaries / symmetry / a moving wall: first residuals of
+ *                                 the time steps and the velocity error (oracle/channel_oracle.py,
+ *                                 tests/test_oracle_golden_channel.py)
  * deal.II cannot be built here (needs cmake + Trilinos + p4est, none present): the reference
  * build is "unbuildable", see DESIGN.md.
  *
