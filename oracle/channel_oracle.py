@@ -83,3 +83,41 @@ class ChannelFlow:
             self.u += d[:nu]
             self.p += d[nu:]
         return history
+
+
+class Flow1D:
+    """tests/1d_flow.cc (1d_flow.prm, 1d_flow_damped.prm): NavierStokes<1> on [0, 2.5] with 2048 cells, velocity 2 at
+    t = 0, open ends with the pressures 2 and 1 (in 1D the face integrals are the point values -2 and +1 on the first and
+    the last velocity row), tau grad div = 1e-5, optional damping; exact Newton steps as in ChannelFlow"""
+
+    def __init__(self, time_stepping, n=2048, k=2, viscosity=0.01, damping=0.0, tau_grad_div=1e-5):
+        self.ts, self.k, self.viscosity, self.damping, self.tau_grad_div = time_stepping, k, viscosity, damping, tau_grad_div
+        self.mesh = orc.Mesh.make([n], [0.0], [2.5])
+        self.nu, self.np_ = self.mesh.n_nodes(k), self.mesh.n_nodes(k - 1)
+        self.u, self.p = np.full(self.nu, 2.0), np.zeros(self.np_)
+        self.u_old, self.u_oo, self.p_old = np.zeros(self.nu), np.zeros(self.nu), np.zeros(self.np_)
+        self.const_rhs = np.zeros(self.nu)
+        self.const_rhs[0], self.const_rhs[-1] = -2.0, 1.0
+
+    def advance_time_step(self, tol_nl=1e-12, max_nl=8):
+        ts, mesh, k, nu = self.ts, self.mesh, self.k, self.nu
+        ts.next()
+        u_new, p_new = ts.extrapolate(self.u, self.u_old), ts.extrapolate(self.p, self.p_old)
+        self.u_oo, self.u_old, self.u = self.u_old, self.u, u_new.copy()
+        self.p_old, self.p = self.p, p_new.copy()
+        # (the oracle's NSParams carries the damping with the stored, flipped sign: parameters.cc:466-467)
+        prm = orc.NSParams.make(beta=0.5, viscosity=self.viscosity, damping=-self.damping, tau_grad_div=self.tau_grad_div,
+                                weight=ts.weight(), weight_old=ts.weight_old(), weight_old_old=ts.weight_old_old(),
+                                tau1=ts.tau1(), extrap_old=ts.factor_extrapol_old, extrap_old_old=ts.factor_extrapol_old_old)
+        lin, history = np.zeros(mesh.n_cells * (k + 1) * 2), []
+        helper = types.SimpleNamespace(mesh=mesh, k=k, nu=nu, np_=self.np_, dim=1)
+        for it in range(max_nl + 1):
+            ru, rp = orc.ns_residual(mesh, k, prm, self.u, self.p, self.u_old, self.u_oo, lin=lin, rhs_u=self.const_rhs)
+            history.append(float(np.hypot(np.linalg.norm(ru), np.linalg.norm(rp))))
+            if history[-1] < tol_nl or it == max_nl:
+                break
+            J = tpo.RisingBubble._assemble(helper, lambda a, b: orc.ns_vmult(mesh, k, prm, a, b, None, None, lin=lin))
+            d = spla.spsolve(J.tocsc(), np.concatenate([ru, rp]))
+            self.u += d[:nu]
+            self.p += d[nu:]
+        return history

@@ -70,3 +70,23 @@ def test_poiseuille_stokes_first_residual_and_exact_solution():
     assert np.abs(small.u.reshape(-1, 2)[:, 0] - 5.0 * (1 - small.x[:, 1] ** 2)).max() < 1e-9
     xp = orc.node_coordinates(small.mesh, 1)
     assert np.abs(small.p - (2.0 - xp[:, 0])).max() < 1e-9
+
+
+def test_one_dimensional_flows_match_their_reference_outputs():
+    """tests/1d_flow.output:10,30 and tests/1d_flow_damped.output:10,30,39,47,55 (NavierStokesMatrix<1>,
+    navier_stokes_matrix.cc:1210): the first residual of every time step -- the only reference outputs that exercise the
+    damping term (:831-835) and tau grad div; the undamped run drops to round-off after two steps (the reference prints
+    its solver noise there), the damped one keeps printing 2e-6"""
+    import pytest
+    for case in ("1d_flow", "1d_flow_damped"):
+        ref = _ref(case)
+        fp = adaflo_amd.FlowParameters(velocity_degree=2, viscosity=ref["viscosity"], damping=ref["damping"],
+                                       tau_grad_div=ref["tau_grad_div"], time_step_size_start=ref["dt"], end_time=1.0)
+        sim = co.Flow1D(adaflo_amd.TimeStepping(fp), n=ref["cells"], viscosity=ref["viscosity"], damping=ref["damping"],
+                        tau_grad_div=ref["tau_grad_div"])
+        assert (sim.nu, sim.np_) == (ref["dofs_u"], ref["dofs_p"])
+        for expected in ref["first_residuals"]:
+            history = sim.advance_time_step()
+            assert "%.3e" % history[0] == expected and history[-1] < 1e-11, (case, history)
+        # incompressibility in 1D: the velocity stays uniform
+        assert np.abs(sim.u - sim.u[0]).max() < 1e-10
