@@ -195,7 +195,7 @@ namespace
 
   int nn(const adaflo_ctx *ctx, const int degree, const int d)
   {
-    return (ctx->flat && d == 2) ? 1 : degree * ctx->desc.ncell[d] + 1;
+    return ((ctx->flat && d == 2) || (ctx->flat_y && d == 1)) ? 1 : degree * ctx->desc.ncell[d] + 1;
   }
 } // namespace
 
@@ -212,10 +212,13 @@ static int ctx_create_impl(const adaflo_brick_desc *desc, adaflo_ctx *ctx)
   // 2D): the generic kernels with a FLAT third direction -- one node, one quadrature point of weight 1, h_z = 1, the
   // third velocity component constrained everywhere -- i.e. the same templates as dim = 3 (fe_kernels.hpp: SumFac<.., ZF>).
   // Velocity degree 2 or 3 (the reference's 2D tests); the specialised 3D kernels are not used.
-  if (desc->dim != 3 && desc->dim != 2)
-    return fail(nullptr, ADAFLO_EUNSUPPORTED, "dim must be 2 or 3");
+  // dim = 1 (NavierStokesMatrix<1>, :1210; tests/1d_flow*.prm): the second direction flat as well, no level-set spaces.
+  if (desc->dim < 1 || desc->dim > 3)
+    return fail(nullptr, ADAFLO_EUNSUPPORTED, "dim must be 1, 2 or 3");
   if (desc->dim == 2 && (desc->ncell[2] != 1 || desc->velocity_degree > 3))
     return fail(nullptr, ADAFLO_EUNSUPPORTED, "dim = 2: ncell[2] must be 1 and the velocity degree 2 or 3");
+  if (desc->dim == 1 && (desc->ncell[1] != 1 || desc->ncell[2] != 1 || desc->velocity_degree > 3 || desc->ls_degree > 0))
+    return fail(nullptr, ADAFLO_EUNSUPPORTED, "dim = 1: ncell[1] = ncell[2] = 1, velocity degree 2 or 3, no level-set spaces");
   // EXPAND_OPERATIONS (source/navier_stokes_matrix.cc:64-82): degree_p = 1 .. 5, i.e. velocity degrees 2 .. 6
   if (desc->velocity_degree < 2 || desc->velocity_degree > 6)
     return fail(nullptr, ADAFLO_EUNSUPPORTED, "velocity degree must be in [2,6] (reference: ExcNotImplemented)");
@@ -230,7 +233,14 @@ static int ctx_create_impl(const adaflo_brick_desc *desc, adaflo_ctx *ctx)
     return fail(nullptr, ADAFLO_EINVAL, "invalid device ordinal");
 
   ctx->desc       = *desc;
-  ctx->flat       = desc->dim == 2;
+  ctx->flat       = desc->dim <= 2;
+  ctx->flat_y     = desc->dim == 1;
+  if (ctx->flat_y)
+    {
+      ctx->desc.h[1] = 1.;
+      // ... nor does the second one in 1D (every node lies on the z faces)
+      ctx->desc.velocity_constrained |= (1u << (3 * 4 + 1)) | (1u << (3 * 5 + 1));
+    }
   if (ctx->flat)
     {
       ctx->desc.h[2] = 1.; // the single z point has weight 1: integrals over the brick are integrals over the x-y domain
@@ -254,7 +264,7 @@ static int ctx_create_impl(const adaflo_brick_desc *desc, adaflo_ctx *ctx)
   ctx->n_nodes_u = (int64_t)nn(ctx, k, 0) * nn(ctx, k, 1) * nn(ctx, k, 2);
   ctx->n_nodes_p = (int64_t)nn(ctx, k - 1, 0) * nn(ctx, k - 1, 1) * nn(ctx, k - 1, 2);
   ctx->n_nodes_ls = ctx->s > 0 ? (int64_t)nn(ctx, ctx->s, 0) * nn(ctx, ctx->s, 1) * nn(ctx, ctx->s, 2) : 0;
-  ctx->nq_u       = (k + 1) * (k + 1) * (ctx->flat ? 1 : k + 1);
+  ctx->nq_u       = (k + 1) * (ctx->flat_y ? 1 : k + 1) * (ctx->flat ? 1 : k + 1);
   for (int d = 0; d < 3; ++d)
     {
       ctx->brick.ncell[d] = desc->ncell[d];
@@ -365,7 +375,7 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
                           &ctx->q1_slab, &ctx->q1_zslab, &ctx->pc_inv_u, &ctx->pc_inv_pm, &ctx->pc_inv_pl,
                           &ctx->pc_ones_p, &ctx->pc_tmp_u, &ctx->pc_tmp_p, &ctx->pc_tmp_p2, &ctx->pc_work, &ctx->kr_work, &ctx->kr_basis, &ctx->kr_scalars,
                           &ctx->q1_poisson_coef, &ctx->ho_tab, &ctx->res_sum_u, &ctx->res_sum_p, &ctx->res_old,
-                          &ctx->ls_art_visc, &ctx->ls_stab_vel_sum, &ctx->ls_stab_ls_sum, &ctx->hox_lin, &ctx->hox_lin_prec,
+                          &ctx->ls_art_visc, &ctx->ls_stab_vel_sum, &ctx->ls_stab_ls_sum, &ctx->hox_lin, &ctx->hox_lin_prec, &ctx->pc_tridiag,
                           &ctx->hox_slab_u, &ctx->hox_xslab_u, &ctx->hox_slab_p, &ctx->hox_xslab_p, &ctx->hox_tab})
     release(*b);
   for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch,

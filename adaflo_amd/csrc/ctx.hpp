@@ -95,7 +95,8 @@ struct adaflo_ctx
   bool              own_stream = false;
   int               variant    = 1;
 
-  bool    flat = false; // dim = 2: flat third direction (capi.hip: ctx_create_impl)
+  bool    flat = false; // dim <= 2: flat third direction (capi.hip: ctx_create_impl)
+  bool    flat_y = false; // dim = 1: the second direction is flat as well
   int     k = 0, s = 0;
   int64_t n_cells = 0, n_nodes_u = 0, n_nodes_p = 0, n_nodes_ls = 0;
   int     nq_u = 0; // (k+1)^3
@@ -171,7 +172,7 @@ struct adaflo_ctx
 
   // block preconditioner of the coupled system (krylov.hip): inverse diagonals of the velocity
   // block, the pressure mass and the pressure Poisson operator, work vectors
-  adaflo_hip::DeviceBuffer pc_inv_u, pc_inv_pm, pc_inv_pl, pc_ones_p, pc_tmp_u, pc_tmp_p, pc_tmp_p2, pc_work, kr_work, kr_basis, kr_scalars;
+  adaflo_hip::DeviceBuffer pc_inv_u, pc_inv_pm, pc_inv_pl, pc_ones_p, pc_tmp_u, pc_tmp_p, pc_tmp_p2, pc_work, kr_work, kr_basis, kr_scalars, pc_tridiag;
   bool                     pc_ready = false;
   bool                     pc_built_fdm = false; // what adaflo_ns_preconditioner_setup built: fast-diagonalisation inverses or Jacobi diagonals
   void                    *fdm = nullptr;      // fast-diagonalisation data of the inner solves (fdm.hip)

@@ -80,18 +80,23 @@ namespace adaflo_hip
   // d/dz = 0.  This is how the engine runs dim = 2 (NavierStokesMatrix<2>, navier_stokes_matrix.cc:1211; the
   // reference's level-set golden outputs are all 2D): the same kernels with a degenerate third direction, the
   // 1D tables of x / y untouched.
-  template <int ND, int NQ, int NT, bool ZF = false>
+  // ZF == 2: the y direction is flat as well -- dim = 1 (NavierStokesMatrix<1>, navier_stokes_matrix.cc:1210;
+  // tests/1d_flow*.prm).  (ZF is an int: 0 = 3D, 1 = flat z, 2 = flat y and z; `true` still means 1.)
+  template <int ND, int NQ, int NT, int ZF = 0>
   struct SumFac
   {
-    static constexpr int NDZ = ZF ? 1 : ND, NQZ = ZF ? 1 : NQ;
-    static constexpr int ND3 = ND * ND * NDZ;
-    static constexpr int NQ2 = NQ * NQ;
-    static constexpr int NQ3 = NQ * NQ * NQZ;
-    static constexpr int T1  = NQ * ND * NDZ;
-    static constexpr int T2  = NQ * NQ * NDZ;
+    static constexpr bool YF = ZF == 2;
+    static constexpr int NDZ = ZF ? 1 : ND, NQZ = ZF ? 1 : NQ, NDY = YF ? 1 : ND, NQY = YF ? 1 : NQ;
+    static constexpr int ND3 = ND * NDY * NDZ;
+    static constexpr int NQ2 = NQ * NQY;
+    static constexpr int NQ3 = NQ * NQY * NQZ;
+    static constexpr int T1  = NQ * NDY * NDZ;
+    static constexpr int T2  = NQ * NQY * NDZ;
     static constexpr int TMP = 2 * T1 + 3 * T2;
-    // entries of the z matrices
+    // entries of the z (y) matrices
     static __device__ __forceinline__ double Sz(const double *S, const int idx) { return ZF ? 1. : S[idx]; }
+    static __device__ __forceinline__ double Sy(const double *S, const int idx) { return YF ? 1. : S[idx]; }
+    static __device__ __forceinline__ double Dy(const double *D, const int idx) { return YF ? 0. : D[idx]; }
 
     // u[ND3] -> val[NQ3], gx/gy/gz[NQ3] (reference-cell derivatives)
     template <bool VAL, bool GRAD>
@@ -119,17 +124,17 @@ namespace adaflo_hip
       __syncthreads();
       for (int o = tid; o < T2; o += NT)
         {
-          const int q = o % NQ, r = (o / NQ) % NQ, k = o / NQ2;
+          const int q = o % NQ, r = (o / NQ) % NQY, k = o / NQ2;
           double    a = 0., dy = 0., dx = 0.;
 #pragma unroll
-          for (int j = 0; j < ND; ++j)
+          for (int j = 0; j < NDY; ++j)
             {
-              const double v = t1[(k * ND + j) * NQ + q];
-              a += S[r * ND + j] * v;
+              const double v = t1[(k * NDY + j) * NQ + q];
+              a += Sy(S, r * ND + j) * v;
               if (GRAD)
                 {
-                  dy += D[r * ND + j] * v;
-                  dx += S[r * ND + j] * t1d[(k * ND + j) * NQ + q];
+                  dy += Dy(D, r * ND + j) * v;
+                  dx += Sy(S, r * ND + j) * t1d[(k * NDY + j) * NQ + q];
                 }
             }
           t2[o] = a;
@@ -197,17 +202,17 @@ namespace adaflo_hip
       __syncthreads();
       for (int o = tid; o < T2; o += NT)
         {
-          const int q = o % NQ, r = (o / NQ) % NQ, k = o / NQ2;
+          const int q = o % NQ, r = (o / NQ) % NQY, k = o / NQ2;
           double    a = 0., dy = 0., dx = 0.;
 #pragma unroll
-          for (int j = 0; j < ND; ++j)
+          for (int j = 0; j < NDY; ++j)
             {
-              const double v = t1[(k * ND + j) * NQ + q];
-              a += S[r * ND + j] * v;
+              const double v = t1[(k * NDY + j) * NQ + q];
+              a += Sy(S, r * ND + j) * v;
               if (GRAD)
                 {
-                  dy += D[r * ND + j] * v;
-                  dx += S[r * ND + j] * t1d[(k * ND + j) * NQ + q];
+                  dy += Dy(D, r * ND + j) * v;
+                  dx += Sy(S, r * ND + j) * t1d[(k * NDY + j) * NQ + q];
                 }
             }
           t2[o] = a;
@@ -267,16 +272,16 @@ namespace adaflo_hip
       for (int ob = tid; ob < NB * T2; ob += NT)
         {
           const int b = ob / T2, o = ob - b * T2;
-          const int q = o % NQ, r = (o / NQ) % NQ, k = o / NQ2;
+          const int q = o % NQ, r = (o / NQ) % NQY, k = o / NQ2;
           const double *t1 = tmp + b * TMP, *t1d = t1 + T1;
           double        a = 0., dy = 0., dx = 0.;
 #pragma unroll
-          for (int j = 0; j < ND; ++j)
+          for (int j = 0; j < NDY; ++j)
             {
-              const double v = t1[(k * ND + j) * NQ + q];
-              a += S[r * ND + j] * v;
-              dy += D[r * ND + j] * v;
-              dx += S[r * ND + j] * t1d[(k * ND + j) * NQ + q];
+              const double v = t1[(k * NDY + j) * NQ + q];
+              a += Sy(S, r * ND + j) * v;
+              dy += Dy(D, r * ND + j) * v;
+              dx += Sy(S, r * ND + j) * t1d[(k * NDY + j) * NQ + q];
             }
           double *t2 = tmp + b * TMP + 2 * T1;
           t2[o]          = a;
@@ -338,14 +343,14 @@ namespace adaflo_hip
       for (int ob = tid; ob < NB * T1; ob += NT)
         {
           const int b = ob / T1, o = ob - b * T1;
-          const int q = o % NQ, j = (o / NQ) % ND, k = o / (NQ * ND);
+          const int q = o % NQ, j = (o / NQ) % NDY, k = o / (NQ * NDY);
           const double *t2 = tmp + b * TMP + 2 * T1, *t2dy = t2 + T2, *t2dx = t2 + 2 * T2;
           double        bb = 0., bx = 0.;
 #pragma unroll
-          for (int r = 0; r < NQ; ++r)
+          for (int r = 0; r < NQY; ++r)
             {
-              bb += S[r * ND + j] * t2[(k * NQ + r) * NQ + q] + D[r * ND + j] * t2dy[(k * NQ + r) * NQ + q];
-              bx += S[r * ND + j] * t2dx[(k * NQ + r) * NQ + q];
+              bb += Sy(S, r * ND + j) * t2[(k * NQY + r) * NQ + q] + Dy(D, r * ND + j) * t2dy[(k * NQY + r) * NQ + q];
+              bx += Sy(S, r * ND + j) * t2dx[(k * NQY + r) * NQ + q];
             }
           tmp[b * TMP + o]      = bb;
           tmp[b * TMP + T1 + o] = bx;
@@ -400,16 +405,16 @@ namespace adaflo_hip
       __syncthreads();
       for (int o = tid; o < T1; o += NT)
         {
-          const int q = o % NQ, j = (o / NQ) % ND, k = o / (NQ * ND);
+          const int q = o % NQ, j = (o / NQ) % NDY, k = o / (NQ * NDY);
           double    b = 0., bx = 0.;
 #pragma unroll
-          for (int r = 0; r < NQ; ++r)
+          for (int r = 0; r < NQY; ++r)
             {
-              b += S[r * ND + j] * t2[(k * NQ + r) * NQ + q];
+              b += Sy(S, r * ND + j) * t2[(k * NQY + r) * NQ + q];
               if (GRAD)
                 {
-                  b += D[r * ND + j] * t2dy[(k * NQ + r) * NQ + q];
-                  bx += S[r * ND + j] * t2dx[(k * NQ + r) * NQ + q];
+                  b += Dy(D, r * ND + j) * t2dy[(k * NQY + r) * NQ + q];
+                  bx += Sy(S, r * ND + j) * t2dx[(k * NQY + r) * NQ + q];
                 }
             }
           t1[o] = b;
@@ -436,16 +441,16 @@ namespace adaflo_hip
 
   // gather the (DEG+1)^3 x NC local values of cell (cx,cy,cz); dof = node*NC+c.
   // RESOLVE: constrained entries read as zero (read_dof_values), else plain.
-  template <int DEG, int NC, int NT, bool RESOLVE, bool ZF = false>
+  template <int DEG, int NC, int NT, bool RESOLVE, int ZF = 0>
   __device__ void gather_cell(const double *__restrict__ vec, double *loc, const int cx,
                               const int cy, const int cz, const int nnx, const int nny,
                               const int nnz, const uint32_t mask)
   {
-    constexpr int ND = DEG + 1, ND3 = ND * ND * (ZF ? 1 : ND);
+    constexpr int ND = DEG + 1, NDY = ZF == 2 ? 1 : ND, ND3 = ND * NDY * (ZF ? 1 : ND);
     for (int o = threadIdx.x; o < ND3 * NC; o += NT)
       {
         const int  c = o % NC, l = o / NC;
-        const int  i = l % ND, j = (l / ND) % ND, k = l / (ND * ND);
+        const int  i = l % ND, j = (l / ND) % NDY, k = l / (ND * NDY);
         const int  I = cx * DEG + i, J = cy * DEG + j, K = cz * DEG + k;
         const long node = I + (long)nnx * (J + (long)nny * K);
         double     v    = vec[node * NC + c];
@@ -458,18 +463,18 @@ namespace adaflo_hip
   // distribute_local_to_global: scatter-add, constrained rows skipped.  No atomics: the cell loops run colour by
   // colour (BrickDev::colour), the cells of one launch share no node.  A launcher that forgot the colour loop
   // (colour < 0 = all cells in one launch) would race silently: the kernel traps instead.
-  template <int DEG, int NC, int NT, bool ZF = false>
+  template <int DEG, int NC, int NT, int ZF = 0>
   __device__ void scatter_cell(double *__restrict__ vec, const double *loc, const int cx,
                                const int cy, const int cz, const int nnx, const int nny,
                                const int nnz, const uint32_t mask, const int colour)
   {
     if (colour < 0)
       __builtin_trap();
-    constexpr int ND = DEG + 1, ND3 = ND * ND * (ZF ? 1 : ND);
+    constexpr int ND = DEG + 1, NDY = ZF == 2 ? 1 : ND, ND3 = ND * NDY * (ZF ? 1 : ND);
     for (int o = threadIdx.x; o < ND3 * NC; o += NT)
       {
         const int  c = o % NC, l = o / NC;
-        const int  i = l % ND, j = (l / ND) % ND, k = l / (ND * ND);
+        const int  i = l % ND, j = (l / ND) % NDY, k = l / (ND * NDY);
         const int  I = cx * DEG + i, J = cy * DEG + j, K = cz * DEG + k;
         const long node = I + (long)nnx * (J + (long)nny * K);
         if (!on_constrained_face(I, J, K, nnx, nny, nnz, mask, NC == 1 ? 1 : 3, c))

@@ -123,6 +123,41 @@ namespace adaflo_hip
         }
     }
     // x -= m   (mean-free rhs / solution of the pure Neumann pressure Poisson problem)
+    // dim = 1: exact (pseudo-)inverse of the constant-coefficient Q1 Laplacian (1/h) tridiag(-1, 2, -1) with Neumann
+    // ends -- the last value pinned to zero, then the mean removed --, the preconditioner of the pressure Poisson solve
+    // where a Jacobi-preconditioned CG would need O(n) iterations.  One lane, two sequential sweeps (Thomas).
+    __global__ void tridiag_laplace_1d_kernel(double *__restrict__ x, const double *__restrict__ b,
+                                              double *__restrict__ work, const int n, const double h)
+    {
+      if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+      // unknowns 0 .. n-2 (x[n-1] = 0): diag (1/h)(1, 2, ..., 2), off-diagonals -1/h
+      const double ih = 1. / h;
+      double       dprev = ih; // pivot of row 0
+      work[0]            = dprev;
+      x[0]               = b[0];
+      for (int i = 1; i < n - 1; ++i)
+        {
+          const double l = -ih / dprev;
+          dprev          = 2. * ih - l * (-ih);
+          work[i]        = dprev;
+          x[i]           = b[i] - l * x[i - 1];
+        }
+      x[n - 1]  = 0.;
+      double xn = 0.;
+      for (int i = n - 2; i >= 0; --i)
+        {
+          xn   = (x[i] + ih * xn) / work[i];
+          x[i] = xn;
+        }
+      double mean = 0.;
+      for (int i = 0; i < n; ++i)
+        mean += x[i];
+      mean /= n;
+      for (int i = 0; i < n; ++i)
+        x[i] -= mean;
+    }
+
     __global__ __launch_bounds__(KT) void shift_kernel(double *__restrict__ x, const double m, const long n)
     {
       for (long i = blockIdx.x * (long)KT + threadIdx.x; i < n; i += (long)gridDim.x * KT)
@@ -881,11 +916,11 @@ namespace
   int probe_diagonal(adaflo_ctx *ctx, const Operator &A, double *diag, double *e, double *y, const int degree,
                      const int ncomp)
   {
-    const int  nnx = degree * ctx->desc.ncell[0] + 1, nny = degree * ctx->desc.ncell[1] + 1;
+    const int  nnx = degree * ctx->desc.ncell[0] + 1, nny = ctx->flat_y ? 1 : degree * ctx->desc.ncell[1] + 1;
     const long n_nodes = (long)nnx * nny * (ctx->flat ? 1 : degree * ctx->desc.ncell[2] + 1);
     const int  period = degree + 1;
     const long n = n_nodes * ncomp;
-    for (int colour = 0; colour < period * period * (ctx->flat ? 1 : period); ++colour) // (dim = 2: one node layer)
+    for (int colour = 0; colour < period * (ctx->flat_y ? 1 : period) * (ctx->flat ? 1 : period); ++colour) // (dim < 3: one node layer)
       for (int comp = 0; comp < ncomp; ++comp)
         {
           hipLaunchKernelGGL(probe_fill_kernel, dim3(kgrid(n)), dim3(KT), 0, ctx->stream, e, nnx, nny, n_nodes, ncomp,
@@ -1133,6 +1168,15 @@ int adaflo_ns_preconditioner_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p
       // ratio instead of h^-2.  With the Jacobi diagonal the solve ran into its 30-iteration cap every time.
       if (ctx->pc_inner == 1 && ctx->pc_poisson_fdm) // (set_inner(0) keeps the all-Jacobi solves the oracle mirrors)
         K.P = [ctx, c_pl](double *d, const double *s) { return fdm_apply(ctx, 1, d, s, 0., c_pl); };
+      else if (ctx->flat_y) // dim = 1: the Laplacian is tridiagonal -- exact inverse (the reference has ILU here: exact too)
+        K.P = [ctx, np](double *d, const double *s) {
+          double *work = persistent(ctx->pc_tridiag, (size_t)np);
+          if (!work)
+            return (int)ADAFLO_ENOMEM;
+          hipLaunchKernelGGL(tridiag_laplace_1d_kernel, dim3(1), dim3(1), 0, ctx->stream, d, s, work, (int)np,
+                             ctx->desc.h[0]);
+          return hipGetLastError() == hipSuccess ? 0 : (int)ADAFLO_EHIP;
+        };
       const adaflo_solver_control c{30, 0., 3e-2}; // (3e-2 |rhs| of :723 = relative to the initial residual of the zero guess)
       if (launch_fill(ctx, t2, 0., np))
         return kfail(ctx, ADAFLO_EHIP, "fill failed");

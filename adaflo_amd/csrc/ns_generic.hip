@@ -11,11 +11,12 @@
 namespace adaflo_hip
 {
   // ZF: flat third direction (dim = 2), see SumFac in fe_kernels.hpp
-  template <int K, bool ZF = false>
+  template <int K, int ZF = 0>
   struct NSLayout
   {
     static constexpr int NDU = K + 1, NDP = K, NQ = K + 1;
-    static constexpr int NDU3 = NDU * NDU * (ZF ? 1 : NDU), NDP3 = NDP * NDP * (ZF ? 1 : NDP), NQ3 = NQ * NQ * (ZF ? 1 : NQ);
+    static constexpr int NDU3 = NDU * (ZF == 2 ? 1 : NDU) * (ZF ? 1 : NDU), NDP3 = NDP * (ZF == 2 ? 1 : NDP) * (ZF ? 1 : NDP),
+                         NQ3 = NQ * (ZF == 2 ? 1 : NQ) * (ZF ? 1 : NQ);
     static constexpr int TAB = 2 * NQ * NDU + 2 * NQ * NDP + NQ;
     static constexpr int TABP = (TAB + 1) & ~1;
     // Q2: the three velocity components go through the sum factorisation together (a third of the
@@ -33,7 +34,7 @@ namespace adaflo_hip
     static constexpr bool REGQ = K >= 3;
   };
 
-  template <int K, int NT, bool ZF = false>
+  template <int K, int NT, int ZF = 0>
   constexpr size_t ns_lds_doubles(const bool residual)
   {
     using L = NSLayout<K, ZF>;
@@ -46,7 +47,7 @@ namespace adaflo_hip
     return n;
   }
 
-  template <int K, int OP, int NT, bool ZF = false>
+  template <int K, int OP, int NT, int ZF = 0>
   __global__ __launch_bounds__(NT) void ns_cell_kernel(const NSArgs a)
   {
     using L   = NSLayout<K, ZF>;
@@ -90,8 +91,8 @@ namespace adaflo_hip
     const long c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
     const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
     const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
-    const int  nux = K * ncx + 1, nuy = K * ncy + 1, nuz = ZF ? 1 : K * ncz + 1;
-    const int  npx = (K - 1) * ncx + 1, npy = (K - 1) * ncy + 1, npz = ZF ? 1 : (K - 1) * ncz + 1;
+    const int  nux = K * ncx + 1, nuy = ZF == 2 ? 1 : K * ncy + 1, nuz = ZF ? 1 : K * ncz + 1;
+    const int  npx = (K - 1) * ncx + 1, npy = ZF == 2 ? 1 : (K - 1) * ncy + 1, npz = ZF ? 1 : (K - 1) * ncz + 1;
 
     const NSDev &P = a.ns;
 
@@ -150,7 +151,7 @@ namespace adaflo_hip
     for (int q = tid; q < NQ3; q += NT)
       {
         const int    qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
-        const double jxw = det * wq[qx] * wq[qy] * (ZF ? 1. : wq[qz]);
+        const double jxw = det * wq[qx] * (ZF == 2 ? 1. : wq[qy]) * (ZF ? 1. : wq[qz]);
         double       g[3][3], val[3], conv[3] = {0., 0., 0.};
         for (int d = 0; d < 3; ++d)
           {
@@ -332,7 +333,7 @@ namespace adaflo_hip
       }
   }
 
-  template <int K, int NT, bool ZF>
+  template <int K, int NT, int ZF>
   static int launch_k(adaflo_ctx *ctx, const int op, const NSArgs &args)
   {
     const dim3   block(NT);
@@ -377,14 +378,26 @@ namespace adaflo_hip
     hipEvent_t stop = ctx->timing ? ctx->kernel_timer.start(ctx->stream) : nullptr;
     int        rc;
     // EXPAND_OPERATIONS, source/navier_stokes_matrix.cc:64-82 (degree_p = k-1)
-    if (ctx->flat) // dim = 2 (degrees of the reference's 2D tests: Q2/Q1 and Q3/Q2)
+    if (ctx->flat_y) // dim = 1 (tests/1d_flow*.prm: Q2/Q1)
       switch (ctx->k)
         {
           case 2:
-            rc = launch_k<2, 64, true>(ctx, op, args);
+            rc = launch_k<2, 64, 2>(ctx, op, args);
             break;
           case 3:
-            rc = launch_k<3, 64, true>(ctx, op, args);
+            rc = launch_k<3, 64, 2>(ctx, op, args);
+            break;
+          default:
+            rc = ADAFLO_EUNSUPPORTED;
+        }
+    else if (ctx->flat) // dim = 2 (degrees of the reference's 2D tests: Q2/Q1 and Q3/Q2)
+      switch (ctx->k)
+        {
+          case 2:
+            rc = launch_k<2, 64, 1>(ctx, op, args);
+            break;
+          case 3:
+            rc = launch_k<3, 64, 1>(ctx, op, args);
             break;
           default:
             rc = ADAFLO_EUNSUPPORTED;
@@ -393,19 +406,19 @@ namespace adaflo_hip
       switch (ctx->k)
         {
           case 2:
-            rc = launch_k<2, 64, false>(ctx, op, args);
+            rc = launch_k<2, 64, 0>(ctx, op, args);
             break;
           case 3:
-            rc = launch_k<3, 64, false>(ctx, op, args);
+            rc = launch_k<3, 64, 0>(ctx, op, args);
             break;
           case 4:
-            rc = launch_k<4, 128, false>(ctx, op, args);
+            rc = launch_k<4, 128, 0>(ctx, op, args);
             break;
           case 5:
-            rc = launch_k<5, 256, false>(ctx, op, args);
+            rc = launch_k<5, 256, 0>(ctx, op, args);
             break;
           case 6: // degree_p = 5, the last instance of EXPAND_OPERATIONS (:80-81): 343 quadrature points per cell
-            rc = launch_k<6, 384, false>(ctx, op, args);
+            rc = launch_k<6, 384, 0>(ctx, op, args);
             break;
           default:
             rc = ADAFLO_EUNSUPPORTED;
@@ -430,7 +443,7 @@ namespace adaflo_hip
   //          = beta ldiv v + lu . grad                                     (convection frozen)
   // One thread per node of the cell, the cell's coefficients staged in LDS; 27^2 x ~40 flops per Q2 cell
   // instead of the 81 operator applications of the coloured probing (krylov.hip).
-  template <int K, int NT, bool ZF = false>
+  template <int K, int NT, int ZF = 0>
   __global__ __launch_bounds__(NT) void ns_velocity_diagonal_kernel(const NSArgs a, double *__restrict__ diag)
   {
     using L = NSLayout<K, ZF>;
@@ -444,7 +457,7 @@ namespace adaflo_hip
     const long   c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
     const int    ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
     const int    cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
-    const int    nux = K * ncx + 1, nuy = K * ncy + 1, nuz = ZF ? 1 : K * ncz + 1;
+    const int    nux = K * ncx + 1, nuy = ZF == 2 ? 1 : K * ncy + 1, nuz = ZF ? 1 : K * ncz + 1;
     const NSDev &P = a.ns;
     const bool   stokes = P.physical_type == ADAFLO_STOKES;
     const bool   newton = P.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON;
@@ -469,19 +482,21 @@ namespace adaflo_hip
     const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
     for (int l = tid; l < ND3; l += NT)
       {
-        const int i = l % ND, j = (l / ND) % ND, k = l / (ND * ND);
-        double    d[3] = {0., 0., 0.};
+        constexpr int NDY = ZF == 2 ? 1 : ND, NQY = ZF == 2 ? 1 : NQ;
+        const int     i = l % ND, j = (l / ND) % NDY, k = l / (ND * NDY);
+        double        d[3] = {0., 0., 0.};
         for (int qz = 0; qz < (ZF ? 1 : NQ); ++qz)
-          for (int qy = 0; qy < NQ; ++qy)
+          for (int qy = 0; qy < NQY; ++qy)
             {
               const double sz_ = ZF ? 1. : S_u[qz * ND + k], dz_ = ZF ? 0. : D_u[qz * ND + k];
-              const double syz = S_u[qy * ND + j] * sz_;
-              const double gy_ = D_u[qy * ND + j] * sz_ * ih[1], gz_ = S_u[qy * ND + j] * dz_ * ih[2];
-              const double wyz = det * wq[qy] * (ZF ? 1. : wq[qz]);
+              const double sy_ = ZF == 2 ? 1. : S_u[qy * ND + j], dy_ = ZF == 2 ? 0. : D_u[qy * ND + j];
+              const double syz = sy_ * sz_;
+              const double gy_ = dy_ * sz_ * ih[1], gz_ = sy_ * dz_ * ih[2];
+              const double wyz = det * (ZF == 2 ? 1. : wq[qy]) * (ZF ? 1. : wq[qz]);
 #pragma unroll
               for (int qx = 0; qx < NQ; ++qx)
                 {
-                  const int    q = qx + NQ * (qy + NQ * qz);
+                  const int    q = qx + NQ * (qy + NQY * qz);
                   const double sx = S_u[qx * ND + i], v = sx * syz;
                   const double g[3] = {D_u[qx * ND + i] * syz * ih[0], sx * gy_, sx * gz_};
                   const double jxw = wyz * wq[qx], tmu = cf[(NLIN + 2) * NQ3 + q];
@@ -522,7 +537,7 @@ namespace adaflo_hip
       }
   }
 
-  template <int K, int NT, bool ZF = false>
+  template <int K, int NT, int ZF = 0>
   static int launch_diag(adaflo_ctx *ctx, const NSArgs &args, double *diag)
   {
     using L          = NSLayout<K, ZF>;
@@ -540,9 +555,12 @@ namespace adaflo_hip
   // diag must be zero on entry (constrained rows stay zero)
   int launch_ns_velocity_diagonal(adaflo_ctx *ctx, const NSArgs &args, double *diag)
   {
+    if (ctx->flat_y)
+      return ctx->k == 2 ? launch_diag<2, 64, 2>(ctx, args, diag) :
+                           (ctx->k == 3 ? launch_diag<3, 64, 2>(ctx, args, diag) : ADAFLO_EUNSUPPORTED);
     if (ctx->flat)
-      return ctx->k == 2 ? launch_diag<2, 64, true>(ctx, args, diag) :
-                           (ctx->k == 3 ? launch_diag<3, 64, true>(ctx, args, diag) : ADAFLO_EUNSUPPORTED);
+      return ctx->k == 2 ? launch_diag<2, 64, 1>(ctx, args, diag) :
+                           (ctx->k == 3 ? launch_diag<3, 64, 1>(ctx, args, diag) : ADAFLO_EUNSUPPORTED);
     switch (ctx->k)
       {
         case 2:
@@ -563,14 +581,15 @@ namespace adaflo_hip
   // ------------------------------------------------------------------------
   // scalar sub-block kernels
   // ------------------------------------------------------------------------
-  template <int K, bool QU, bool ZF = false>
+  template <int K, bool QU, int ZF = 0>
   struct ScLayout
   {
     static constexpr int NDU = K + 1, NDP = K, NQ = QU ? K + 1 : K;
-    static constexpr int NDU3 = NDU * NDU * (ZF ? 1 : NDU), NDP3 = NDP * NDP * (ZF ? 1 : NDP), NQ3 = NQ * NQ * (ZF ? 1 : NQ);
+    static constexpr int NDU3 = NDU * (ZF == 2 ? 1 : NDU) * (ZF ? 1 : NDU), NDP3 = NDP * (ZF == 2 ? 1 : NDP) * (ZF ? 1 : NDP),
+                         NQ3 = NQ * (ZF == 2 ? 1 : NQ) * (ZF ? 1 : NQ);
   };
 
-  template <int K, bool QU, int NT, bool ZF = false>
+  template <int K, bool QU, int NT, int ZF = 0>
   constexpr size_t sc_lds_doubles()
   {
     using L = ScLayout<K, QU, ZF>;
@@ -580,7 +599,7 @@ namespace adaflo_hip
 
   // QU: quadrature = quad_index_u (k+1 points, table layout of NSLayout) else
   // quad_index_p (k points, table [S_pp D_pp w_pp])
-  template <int K, bool QU, int NT, bool ZF = false>
+  template <int K, bool QU, int NT, int ZF = 0>
   __global__ __launch_bounds__(NT) void ns_scalar_kernel(const ScalarArgs a)
   {
     using L   = ScLayout<K, QU, ZF>;
@@ -602,8 +621,8 @@ namespace adaflo_hip
     const long c   = brick_cell(a.brick, blockIdx.x, a.n_cells);
     const int  ncx = a.brick.ncell[0], ncy = a.brick.ncell[1], ncz = a.brick.ncell[2];
     const int  cx = c % ncx, cy = (c / ncx) % ncy, cz = c / ((long)ncx * ncy);
-    const int  nux = K * ncx + 1, nuy = K * ncy + 1, nuz = ZF ? 1 : K * ncz + 1;
-    const int  npx = (K - 1) * ncx + 1, npy = (K - 1) * ncy + 1, npz = ZF ? 1 : (K - 1) * ncz + 1;
+    const int  nux = K * ncx + 1, nuy = ZF == 2 ? 1 : K * ncy + 1, nuz = ZF ? 1 : K * ncz + 1;
+    const int  npx = (K - 1) * ncx + 1, npy = ZF == 2 ? 1 : (K - 1) * ncy + 1, npz = ZF ? 1 : (K - 1) * ncz + 1;
     const NSDev &P = a.ns;
     const double ih[3] = {1. / a.brick.h[0], 1. / a.brick.h[1], 1. / a.brick.h[2]};
     const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
@@ -625,7 +644,7 @@ namespace adaflo_hip
         for (int q = tid; q < NQ3; q += NT)
           {
             const int    qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
-            const double jxw = det * wq[qx] * wq[qy] * (ZF ? 1. : wq[qz]);
+            const double jxw = det * wq[qx] * (ZF == 2 ? 1. : wq[qy]) * (ZF ? 1. : wq[qz]);
             const double div = gu[0 * NQ3 + q] * ih[0] + gu[4 * NQ3 + q] * ih[1] + gu[8 * NQ3 + q] * ih[2];
             const double w   = mode == SC_DIVERGENCE_VISC ?
                                  (a.coef_q ? -a.coef_q[(size_t)c * NQ3 + q] : -P.viscosity) :
@@ -675,7 +694,7 @@ namespace adaflo_hip
     for (int q = tid; q < NQ3; q += NT)
       {
         const int    qx = q % NQ, qy = (q / NQ) % NQ, qz = q / (NQ * NQ);
-        const double jxw = det * wq[qx] * wq[qy] * (ZF ? 1. : wq[qz]);
+        const double jxw = det * wq[qx] * (ZF == 2 ? 1. : wq[qy]) * (ZF ? 1. : wq[qz]);
         if (mode == SC_MASS_WEIGHT)
           vp[q] = jxw;
         else if (need_val)
@@ -697,7 +716,7 @@ namespace adaflo_hip
     scatter_cell<K - 1, 1, NT, ZF>(a.dst, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p, a.brick.colour);
   }
 
-  template <int K, int NT, bool ZF = false>
+  template <int K, int NT, int ZF = 0>
   static int launch_sc(adaflo_ctx *ctx, const ScalarArgs &args)
   {
     const dim3 block(NT);
@@ -735,8 +754,10 @@ namespace adaflo_hip
 
   int launch_ns_scalar_generic(adaflo_ctx *ctx, const ScalarArgs &args)
   {
+    if (ctx->flat_y)
+      return ctx->k == 2 ? launch_sc<2, 64, 2>(ctx, args) : (ctx->k == 3 ? launch_sc<3, 64, 2>(ctx, args) : ADAFLO_EUNSUPPORTED);
     if (ctx->flat)
-      return ctx->k == 2 ? launch_sc<2, 64, true>(ctx, args) : (ctx->k == 3 ? launch_sc<3, 64, true>(ctx, args) : ADAFLO_EUNSUPPORTED);
+      return ctx->k == 2 ? launch_sc<2, 64, 1>(ctx, args) : (ctx->k == 3 ? launch_sc<3, 64, 1>(ctx, args) : ADAFLO_EUNSUPPORTED);
     switch (ctx->k)
       {
         case 2:

@@ -67,6 +67,10 @@ def open_boundary_rhs(mesh, k, open_faces, t):
         coords = [mesh.lower[e] + mesh.h[e] * (np.arange(mesh.ncell[e])[:, None] + xg[None, :]) for e in other]
         x = np.zeros([len(c.reshape(-1)) for c in coords] + [3])
         x[..., d] = mesh.upper[d] if side else mesh.lower[d]
+        if len(other) == 0:                                  # dim = 1: the "face integral" is the point value
+            node = (nn[0] - 1) if side else 0
+            rhs.reshape(-1, 3)[node, 0] += normal * float(np.asarray(pressure(x.reshape(-1, 3), t)).reshape(-1)[0])
+            continue
         if len(other) == 1:
             x[:, other[0]] = coords[0].reshape(-1)
         else:
@@ -181,19 +185,20 @@ class NavierStokes:
             oo.copy_(old)
             old.copy_(cur)
             cur.copy_(tmp)
-        vals = np.asarray(self.dirichlet_function(self._bxyz, ts.now()), dtype=np.float64).reshape(len(self._bxyz), -1)
-        if vals.shape[1] < 3:       # dim = 2: the third component does not exist (constrained to zero on the device)
-            vals = np.concatenate([vals, np.zeros((len(vals), 3 - vals.shape[1]))], axis=1)
-        vals = np.ascontiguousarray(vals).reshape(-1)
-        self.solution[0][self._bdofs] = torch.from_numpy(vals).to(self.device)
+        if len(self._bnodes):
+            vals = np.asarray(self.dirichlet_function(self._bxyz, ts.now()), dtype=np.float64).reshape(len(self._bxyz), -1)
+            if vals.shape[1] < 3:   # dim < 3: the other components do not exist (constrained to zero on the device)
+                vals = np.concatenate([vals, np.zeros((len(vals), 3 - vals.shape[1]))], axis=1)
+            vals = np.ascontiguousarray(vals).reshape(-1)
+            self.solution[0][self._bdofs] = torch.from_numpy(vals).to(self.device)
         if len(self._symdofs):
             self.solution[0][self._symdofs] = 0.0
         if self.open_faces:                                      # const_rhs, navier_stokes.cc:1259-1310
             rhs = open_boundary_rhs(self.mesh, self.parameters.velocity_degree, self.open_faces, ts.now()).reshape(-1)
             rhs[self._bdofs.cpu().numpy()] = 0.0                 # distribute_local_to_global skips constrained rows
             rhs[self._symdofs.cpu().numpy()] = 0.0
-            if self.mesh.dim == 2:
-                rhs[2::3] = 0.0
+            for c in range(self.mesh.dim, 3):               # components that do not exist
+                rhs[c::3] = 0.0
             self.const_rhs_u = torch.from_numpy(rhs).to(self.device)
 
     def compute_residual(self):

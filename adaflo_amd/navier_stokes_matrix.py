@@ -22,12 +22,12 @@ class BrickMesh:
     h[2] = 1 and one node layer; vectors keep three velocity components per node, the third one constrained."""
 
     def __init__(self, ncell, lower, upper):
-        assert len(ncell) in (2, 3) and len(lower) == len(ncell) == len(upper)
+        assert len(ncell) in (1, 2, 3) and len(lower) == len(ncell) == len(upper)
         self.dim = len(ncell)
-        flat = self.dim == 2
-        self.ncell = [int(n) for n in ncell] + ([1] if flat else [])
-        self.lower = [float(x) for x in lower] + ([0.0] if flat else [])
-        self.upper = [float(x) for x in upper] + ([1.0] if flat else [])
+        pad = 3 - self.dim                      # flat directions (dim = 1: tests/1d_flow.cc, NavierStokesMatrix<1>)
+        self.ncell = [int(n) for n in ncell] + [1] * pad
+        self.lower = [float(x) for x in lower] + [0.0] * pad
+        self.upper = [float(x) for x in upper] + [1.0] * pad
         self.h = [(u - l) / n for u, l, n in zip(self.upper, self.lower, self.ncell)]
 
     @property
@@ -37,7 +37,7 @@ class BrickMesh:
 
     def nodes(self, degree):
         """nodes per direction of a degree-`degree` space (one layer in the flat direction)"""
-        return [degree * n + 1 for n in self.ncell[:self.dim]] + ([1] if self.dim == 2 else [])
+        return [degree * n + 1 for n in self.ncell[:self.dim]] + [1] * (3 - self.dim)
 
     @property
     def n_cells(self):

@@ -13,3 +13,9 @@ def test_two_dimensional_brick_reports_a_flat_third_direction():
     assert x.shape == (13041, 3) and np.all(x[:, 2] == 0.0) and x[:, 0].max() == 1.0 and x[:, 1].max() == 2.0
     m3 = adaflo_amd.BrickMesh([2, 3, 4], [0., 0., 0.], [1., 1., 2.])
     assert m3.dim == 3 and m3.nodes(3) == [7, 10, 13] and m3.hd == m3.h
+
+
+def test_one_dimensional_brick():
+    m = adaflo_amd.BrickMesh([2048], [0.0], [2.5])
+    assert m.dim == 1 and m.ncell == [2048, 1, 1] and m.nodes(2) == [4097, 1, 1] and m.n_nodes(1) == 2049
+    assert m.hd == [2.5 / 2048] and node_coordinates(m, 2).shape == (4097, 3)

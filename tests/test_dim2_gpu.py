@@ -1,4 +1,4 @@
-"""GPU tier, dim = 2: the reference's own test suite is two-dimensional (tests/rising_bubble*.prm, spurious_currents*.prm),
+"""GPU tier, dim = 2 (and dim = 1 at the end): the reference's own test suite is two-dimensional (tests/rising_bubble*.prm, spurious_currents*.prm),
 so this is where the HIP kernels meet the reference's printed numbers directly.  The engine runs the generic
 kernels with a FLAT third direction (one node, one quadrature point of weight 1: csrc/fe_kernels.hpp, SumFac<.., ZF>);
 vectors keep three velocity components per node (the third one constrained), quadrature-point arrays keep their
@@ -575,3 +575,99 @@ def test_couette_prints_its_reference_output():
     # the steady state is the linear profile u = 2 (1 + y): after two steps the flow is on its way there
     u = ns.solution[0].cpu().numpy().reshape(33, 129, 3)
     assert np.all(np.diff(u[:, 64, 0]) > 0) and abs(u[-1, 64, 0] - 2.0) < 1e-14 and np.abs(u[:, :, 1]).max() < 1e-9
+
+
+@pytest.mark.parametrize("case", ["1d_flow", "1d_flow_damped"])
+def test_one_dimensional_flows_print_their_reference_outputs(case):
+    """dim = 1 on the device (NavierStokesMatrix<1>, navier_stokes_matrix.cc:1210: both transverse directions flat):
+    tests/1d_flow.output:10,30 and tests/1d_flow_damped.output:10,30,39,47,55 -- [0, 2.5] with 2048 cells, u = 2 at
+    t = 0, open ends with the pressures 2 and 1, tau grad div = 1e-5; the damped run is the only reference output that
+    exercises the damping term of the operator (:831-835)"""
+    from adaflo_amd.navier_stokes import NavierStokes
+    ref = _ref(case)
+    mesh = adaflo_amd.BrickMesh([ref["cells"]], [0.0], [2.5])
+    fp = adaflo_amd.FlowParameters(velocity_degree=2, viscosity=ref["viscosity"], damping=ref["damping"],
+                                   tau_grad_div=ref["tau_grad_div"], time_step_size_start=ref["dt"], end_time=1.0,
+                                   max_nl_iteration=10, tol_nl_iteration=1e-11, max_lin_iteration=500, tol_lin_iteration=1e-5)
+    ns = NavierStokes(fp, mesh, adaflo_amd.TimeStepping(fp), dirichlet_function=lambda x, t: np.zeros((len(x), 1)),
+                      open_faces={0: lambda x, t: np.full(len(x), 2.0), 1: lambda x, t: np.full(len(x), 1.0)})
+    m = ns.navier_stokes_matrix
+    assert (m.n_cells(), m.n_dofs_u() // 3, m.n_dofs_p()) == (ref["cells"], ref["dofs_u"], ref["dofs_p"])
+    u0 = np.zeros((ref["dofs_u"], 3))
+    u0[:, 0] = 2.0
+    ns.set_initial_condition(u0.reshape(-1), np.zeros(ref["dofs_p"]))
+    for expected in ref["first_residuals"]:
+        ns.history.clear()
+        ns.advance_time_step()
+        assert "%.3e" % np.hypot(*ns.history[0]) == expected, (case, ns.history)
+        assert np.hypot(*ns.history[-1]) < 1e-11, (case, ns.history)
+    u = ns.solution[0].cpu().numpy().reshape(-1, 3)
+    assert np.abs(u[:, 0] - u[0, 0]).max() < 1e-9 and np.all(u[:, 1:] == 0.0)      # incompressible in 1D: uniform
+
+
+@pytest.mark.parametrize("k,n,phys,lin", [(2, 37, 0, 0), (3, 16, 0, 1), (2, 1, 0, 0), (2, 64, 2, 0), (3, 9, 1, 0)])
+def test_ns_operators_equal_the_1d_oracle(k, n, phys, lin):
+    """dim = 1: vmult / velocity block / divergence / pressure operators / residual with its stored state against the
+    oracle's one-dimensional operators (damping, tau grad div, an open and a Dirichlet end)"""
+    rng = np.random.default_rng(5 * k + n)
+    omesh = orc.Mesh.make([n], (0.3,), (2.8,))
+    mesh = adaflo_amd.BrickMesh([n], [0.3], [2.8])
+    fp = adaflo_amd.FlowParameters(velocity_degree=k, physical_type=PHYS[phys], linearization=LIN[lin], viscosity=0.07,
+                                   density=1.3, damping=0.2, tau_grad_div=0.3, time_step_size_start=0.05, end_time=5.0)
+    ts = adaflo_amd.TimeStepping(fp)
+    ts.next(), ts.next()
+    prm = orc.NSParams.make(physical_type=phys, linearization=lin, beta=0.5, tau_grad_div=0.3, density=fp.density,
+                            viscosity=0.07, damping=-0.2, weight=ts.weight(), weight_old=ts.weight_old(),
+                            weight_old_old=ts.weight_old_old(), tau1=ts.tau1(), extrap_old=ts.factor_extrapol_old,
+                            extrap_old_old=ts.factor_extrapol_old_old)
+    con_u = orc.boundary_mask(omesh, k, 1, faces=[1])
+    op = adaflo_amd.NavierStokesMatrix(fp, mesh, dirichlet_faces_u=[1])
+    op.initialize(ts, False)
+    n_u, n_p, nq = omesh.n_nodes(k), omesh.n_nodes(k - 1), k + 1
+    assert op.n_q_points() == nq and op.n_dofs_u() == 3 * n_u and op.n_dofs_p() == n_p
+
+    def u3_(u1):
+        a = np.zeros((u1.size, 3))
+        a[:, 0] = u1
+        return a.reshape(-1)
+
+    def u1_(u3v):
+        a = np.asarray(u3v).reshape(-1, 3)
+        assert np.all(a[:, 1:] == 0.0)
+        return a[:, 0].copy()
+
+    def lin3_(l1):                                              # [u | du/dx] -> the 12-double record
+        b = np.zeros((l1.size // 2, 12))
+        b[:, 0], b[:, 3] = l1.reshape(-1, 2)[:, 0], l1.reshape(-1, 2)[:, 1]
+        return b.reshape(-1)
+    src_u, src_p = rng.uniform(-1, 1, n_u), rng.uniform(-1, 1, n_p)
+    old_u, oo_u = rng.uniform(-1, 1, n_u), rng.uniform(-1, 1, n_u)
+    lin_q = rng.uniform(-1, 1, omesh.n_cells * nq * 2)
+    if phys != 2:
+        op.set_linearization(lin3_(lin_q))
+    src, dst = op.block_vector(u3_(src_u), src_p), op.block_vector()
+    op.vmult(dst, src)
+    ref_u, ref_p = orc.ns_vmult(omesh, k, prm, src_u, src_p, con_u, None, lin=lin_q)
+    du, dp = dst.numpy()
+    assert rel_l2(u1_(du), ref_u) < TOL and rel_l2(dp, ref_p) < TOL
+    du = op.initialize_u_vector()
+    op.velocity_vmult(du, src.block(0))
+    assert rel_l2(u1_(du.numpy()), orc.ns_velocity_vmult(omesh, k, prm, src_u, con_u, lin=lin_q)) < TOL
+    dp = op.initialize_p_vector(src_p)
+    op.divergence_vmult_add(dp, src.block(0), False)
+    assert rel_l2(dp.numpy(), orc.ns_divergence_vmult_add(omesh, k, prm, src_u, src_p, con_u, None)) < TOL
+    if phys != 2:
+        op.pressure_poisson_vmult(dp, src.block(1))
+        assert rel_l2(dp.numpy(), orc.ns_pressure_poisson_vmult(omesh, k, prm, src_p, None)) < TOL
+    op.pressure_mass_vmult(dp, src.block(1))
+    assert rel_l2(dp.numpy(), orc.ns_pressure_mass_vmult(omesh, k, prm, src_p, None)) < TOL
+    lin_out = np.zeros_like(lin_q)
+    ref_u, ref_p = orc.ns_residual(omesh, k, prm, src_u, src_p, old_u, oo_u, con_u=con_u, lin=lin_out)
+    res = op.block_vector()
+    op.residual(res, src, None, op.block_vector(u3_(old_u)), op.block_vector(u3_(oo_u)))
+    ru, rp = res.numpy()
+    assert rel_l2(u1_(ru), ref_u) < TOL and rel_l2(rp, ref_p) < TOL
+    if phys != 2:
+        got = op.get_linearization().reshape(-1, 12)
+        # (Picard-type states hold (u, div u); in 1D div u = du/dx, so slot 3 is right for both schemes)
+        assert rel_l2(got[:, [0, 3]], lin_out.reshape(-1, 2)) < TOL
