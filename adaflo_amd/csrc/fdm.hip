@@ -15,6 +15,9 @@
 // brick -- 12 n^4 flops per scalar field, the kind of dense FP64 work the chip is good at (tiled
 // LDS kernel below; rocBLAS is deliberately not linked).  Singular cases (pure Neumann Poisson
 // problem) use the pseudo-inverse: the null mode is dropped.
+// Degree-1 spaces with natural ends and 2^m intervals per direction (the level-set grid and the Q1 pressure grid of
+// the two-phase runs) do not need the matrices at all: their eigenvectors are cosines and the transforms are fast
+// cosine transforms in LDS, five memory-bound passes per application (fdm_dct_kernel.hpp).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -22,6 +25,8 @@
 #include <vector>
 
 #include "kernels.hpp"
+
+#include "fdm_dct_kernel.hpp" // (after the HIP runtime: the header includes nothing itself)
 
 namespace adaflo_hip
 {
@@ -39,6 +44,12 @@ namespace adaflo_hip
       // onto each other: two products of half the size instead of one, half the flops (fdm_apply).
       bool sym = false;
       int  n_even = 0; // number of even modes (they come first)
+      // degree 1, natural ends, n - 1 = 2^log2n intervals: the eigenvectors are sqrt(a2[k]) cos(pi j k / (n - 1)) and the
+      // transforms run as fast cosine transforms (fdm_dct_kernel.hpp); modes in natural order k = 0 .. n - 1 there
+      int     log2n = 0;         // 0: not available
+      double *d_tw  = nullptr;   // [n][2]: exp(-i pi m / (n - 1))
+      double *d_a2  = nullptr;   // squared normalisation of mode k
+      double *d_lamn = nullptr;  // eigenvalue of mode k
     };
 
     // M, K of FE_Q(degree) on ncell cells of size h, quadrature QGauss(nq); dense n x n, row-major
@@ -190,8 +201,11 @@ namespace adaflo_hip
     // with K v = lambda M v, lambda = 6 (1 - cos t) / (h^2 (2 + cos t)), t the frequency times pi / N.
     // The level-set space has up to 513 nodes per direction, where the cyclic Jacobi solver above would take
     // seconds.  Same output convention as generalized_eig.
-    void linear_eig(const int n, const double h, const bool lo, const bool hi, std::vector<double> &S, std::vector<double> &lam)
+    void linear_eig(const int n, const double h, const bool lo, const bool hi, std::vector<double> &S, std::vector<double> &lam,
+                    std::vector<double> *norm2 = nullptr)
     {
+      if (norm2)
+        norm2->assign(n, 0.);
       const int    N  = n - 1;
       const double pi = 3.14159265358979323846;
       S.assign((size_t)n * n, 0.);
@@ -217,6 +231,8 @@ namespace adaflo_hip
               nrm += v[j] * mv;
             }
           const double sc = 1. / std::sqrt(nrm);
+          if (norm2)
+            (*norm2)[col] = 1. / nrm;
           for (int j = j0; j <= j1; ++j)
             S[(size_t)j * n + col] = v[j] * sc;
           const double c = std::cos(t);
@@ -483,6 +499,49 @@ namespace adaflo_hip
         }
     }
 
+    // ---- fast cosine transforms (fdm_dct_kernel.hpp) -----------------------------------------------------------
+    template <int LOG2N, bool FUSED>
+    __global__ __launch_bounds__(dct::NT) void fdm_dct_kernel(const dct::DctArgs A)
+    {
+      extern __shared__ double dct_lds[];
+      dct::dct_body<LOG2N, FUSED>(A, dct_lds);
+    }
+    template <int LOG2N, bool FUSED>
+    int launch_dct_t(adaflo_ctx *ctx, const dct::DctArgs &A)
+    {
+      using G            = dct::Geo<LOG2N>;
+      const size_t lds   = sizeof(double) * G::L_TOTAL;
+      static bool  attr_set = false;
+      if (!attr_set)
+        {
+          if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fdm_dct_kernel<LOG2N, FUSED>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ADAFLO_EHIP;
+          attr_set = true;
+        }
+      const long nb = (A.n_lines + G::LB - 1) / G::LB;
+      hipLaunchKernelGGL((fdm_dct_kernel<LOG2N, FUSED>), dim3((unsigned)nb), dim3(dct::NT), lds, ctx->stream, A);
+      return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
+    }
+    template <bool FUSED>
+    int launch_dct(adaflo_ctx *ctx, const int log2n, const dct::DctArgs &A)
+    {
+      switch (log2n)
+        {
+          case 6:
+            return launch_dct_t<6, FUSED>(ctx, A);
+          case 7:
+            return launch_dct_t<7, FUSED>(ctx, A);
+          case 8:
+            return launch_dct_t<8, FUSED>(ctx, A);
+          case 9:
+            return launch_dct_t<9, FUSED>(ctx, A);
+          case 10:
+            return launch_dct_t<10, FUSED>(ctx, A);
+        }
+      return ADAFLO_EINVAL;
+    }
+
     struct FieldFdm
     {
       int   degree = 0, ncomp = 0, nn[3] = {0, 0, 0};
@@ -571,7 +630,7 @@ namespace adaflo_hip
     if (!F)
       return;
     for (auto &kv : F->cache)
-      for (double *p : {kv.second.d_S, kv.second.d_St, kv.second.d_lam})
+      for (double *p : {kv.second.d_S, kv.second.d_St, kv.second.d_lam, kv.second.d_tw, kv.second.d_a2, kv.second.d_lamn})
         if (p)
           (void)hipFree(p);
     for (double *p : {F->w0, F->w1})
@@ -612,9 +671,9 @@ namespace adaflo_hip
           if (it == F->cache.end())
             {
               const int           n = fd.nn[d];
-              std::vector<double> S, lam;
+              std::vector<double> S, lam, norm2;
               if (fd.degree == 1)
-                linear_eig(n, h, lo, hi, S, lam);
+                linear_eig(n, h, lo, hi, S, lam, &norm2);
               else
                 {
                   std::vector<double> M, K;
@@ -625,6 +684,27 @@ namespace adaflo_hip
                   generalized_eig(n, K, M, con, S, lam);
                 }
               Eig1D E;
+              int   log2n = 0;
+              while ((1 << log2n) < n - 1)
+                ++log2n;
+              if (fd.degree == 1 && !lo && !hi && (1 << log2n) == n - 1 && log2n >= 6 && log2n <= 10)
+                {
+                  // natural order of the modes here (upload_eig reorders its copy by symmetry)
+                  std::vector<double> tw(2 * (size_t)n);
+                  for (int m = 0; m < n; ++m)
+                    {
+                      tw[2 * m]     = std::cos(3.14159265358979323846 * m / (n - 1));
+                      tw[2 * m + 1] = -std::sin(3.14159265358979323846 * m / (n - 1));
+                    }
+                  if (hipMalloc(&E.d_tw, sizeof(double) * 2 * n) != hipSuccess || hipMalloc(&E.d_a2, sizeof(double) * n) != hipSuccess ||
+                      hipMalloc(&E.d_lamn, sizeof(double) * n) != hipSuccess)
+                    return ADAFLO_ENOMEM;
+                  if (copy_to_device_now(E.d_tw, tw.data(), sizeof(double) * 2 * n) != hipSuccess ||
+                      copy_to_device_now(E.d_a2, norm2.data(), sizeof(double) * n) != hipSuccess ||
+                      copy_to_device_now(E.d_lamn, lam.data(), sizeof(double) * n) != hipSuccess)
+                    return ADAFLO_EHIP;
+                  E.log2n = log2n;
+                }
               if (int e = upload_eig(E, n, S, lam))
                 return e;
               it = F->cache.emplace(key, E).first;
@@ -777,6 +857,27 @@ namespace adaflo_hip
         // transform reads src, the last one writes dst (dst == src is fine: src is only read by the first)
         const Eig1D &ex = fd.e[0][0], &ey = fd.e[0][1], &ez = fd.e[0][2];
         double      *B = F->w1, *Cb = F->w0;
+        const bool no_dct = getenv("ADAFLO_FDM_NO_DCT") != nullptr; // (tests / timing of the matrix products; read per call)
+        if (mask == 0u && ex.log2n && ey.log2n && ez.log2n && !no_dct)
+          {
+            // cosine modes in all directions: x, y forward, z forward + scaling + z back in one pass, y, x back
+            dct::DctArgs A{};
+            A.nx = nx, A.ny = ny, A.nz = nz;
+            A.lx = ex.d_lamn, A.ly = ey.d_lamn, A.lz = ez.d_lamn, A.ax = ex.d_a2, A.ay = ey.d_a2, A.az = ez.d_a2;
+            A.cm = c_mass, A.cl = c_lap, A.eps = eps;
+            const double *in[5]  = {src, B, Cb, B, Cb};
+            double       *out[5] = {B, Cb, B, Cb, dst};
+            const int     axis[5] = {0, 1, 2, 1, 0};
+            for (int pass = 0; pass < 5; ++pass)
+              {
+                const Eig1D &E = axis[pass] == 0 ? ex : (axis[pass] == 1 ? ey : ez);
+                A.in = in[pass], A.out = out[pass], A.tw = E.d_tw, A.axis = axis[pass];
+                A.n_lines = n / E.n;
+                if (int e = pass == 2 ? launch_dct<true>(ctx, E.log2n, A) : launch_dct<false>(ctx, E.log2n, A))
+                  return e;
+              }
+            return 0;
+          }
         if (int e = transform_axis(ctx, 0, false, ex, src, B, nx, ny, nz))
           return e;
         if (int e = transform_axis(ctx, 1, false, ey, B, Cb, nx, ny, nz))

@@ -1,0 +1,65 @@
+// dct_emu.cpp -- TEST INFRASTRUCTURE ONLY: runs the device source of the fast cosine transforms
+// (adaflo_amd/csrc/fdm_dct_kernel.hpp) on the host lane emulator (hip_emu.hpp) so that tests/test_dct_emulated.py can
+// compare it with the plain cosine sums without a GPU.  The product never loads this library.
+#include "hip_emu.hpp"
+
+#include <cmath>
+#include <vector>
+
+#include "../../adaflo_amd/csrc/fdm_dct_kernel.hpp"
+
+using namespace adaflo_hip::dct;
+
+namespace
+{
+  template <int LOG2N>
+  int run(const DctArgs &A, const int fused)
+  {
+    using G = Geo<LOG2N>;
+    static_assert(G::L_TOTAL * 8 <= (int)emu::LDS_BYTES, "LDS");
+    const long nb = (A.n_lines + G::LB - 1) / G::LB;
+    if (fused)
+      emu::launch((unsigned)nb, NT, [&] { dct_body<LOG2N, true>(A, reinterpret_cast<double *>(emu::g_lds)); });
+    else
+      emu::launch((unsigned)nb, NT, [&] { dct_body<LOG2N, false>(A, reinterpret_cast<double *>(emu::g_lds)); });
+    return 0;
+  }
+} // namespace
+
+// out = cosine sums of `in` ([z][y][x]) along `axis`; fused (axis 2 only): forward, scaling, back
+extern "C" int dct_emu_apply(const int axis, const int fused, const int nx, const int ny, const int nz, const double *in,
+                             double *out, const double *lx, const double *ly, const double *lz, const double *ax,
+                             const double *ay, const double *az, const double cm, const double cl, const double eps)
+{
+  const int n = axis == 0 ? nx : (axis == 1 ? ny : nz), N = n - 1;
+  int       log2n = 0;
+  while ((1 << log2n) < N)
+    ++log2n;
+  if ((1 << log2n) != N || (fused && axis != 2))
+    return 1;
+  std::vector<double> tw(2 * (N + 1));
+  for (int m = 0; m <= N; ++m)
+    {
+      tw[2 * m]     = std::cos(M_PI * m / N);
+      tw[2 * m + 1] = -std::sin(M_PI * m / N);
+    }
+  DctArgs A{};
+  A.in = in, A.out = out, A.tw = tw.data();
+  A.n_lines = (long)nx * ny * nz / n;
+  A.axis = axis, A.nx = nx, A.ny = ny, A.nz = nz;
+  A.lx = lx, A.ly = ly, A.lz = lz, A.ax = ax, A.ay = ay, A.az = az, A.cm = cm, A.cl = cl, A.eps = eps;
+  switch (log2n)
+    {
+      case 6:
+        return run<6>(A, fused);
+      case 7:
+        return run<7>(A, fused);
+      case 8:
+        return run<8>(A, fused);
+      case 9:
+        return run<9>(A, fused);
+      case 10:
+        return run<10>(A, fused);
+    }
+  return 1;
+}

