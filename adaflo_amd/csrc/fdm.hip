@@ -500,13 +500,13 @@ namespace adaflo_hip
     }
 
     // ---- fast cosine transforms (fdm_dct_kernel.hpp) -----------------------------------------------------------
-    template <int LOG2N, bool FUSED>
-    __global__ __launch_bounds__(dct::NT) void fdm_dct_kernel(const dct::DctArgs A)
+    template <int LOG2N, bool FUSED, int AXIS>
+    __global__ __launch_bounds__(dct::NT, 2) void fdm_dct_kernel(const dct::DctArgs A) // (two workgroups per CU: 256 registers)
     {
       extern __shared__ double dct_lds[];
-      dct::dct_body<LOG2N, FUSED>(A, dct_lds);
+      dct::dct_body<LOG2N, FUSED, AXIS>(A, dct_lds);
     }
-    template <int LOG2N, bool FUSED>
+    template <int LOG2N, bool FUSED, int AXIS>
     int launch_dct_t(adaflo_ctx *ctx, const dct::DctArgs &A)
     {
       using G            = dct::Geo<LOG2N>;
@@ -514,30 +514,47 @@ namespace adaflo_hip
       static bool  attr_set = false;
       if (!attr_set)
         {
-          if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fdm_dct_kernel<LOG2N, FUSED>),
+          if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fdm_dct_kernel<LOG2N, FUSED, AXIS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return ADAFLO_EHIP;
           attr_set = true;
         }
-      const long nb = (A.n_lines + G::LB - 1) / G::LB;
-      hipLaunchKernelGGL((fdm_dct_kernel<LOG2N, FUSED>), dim3((unsigned)nb), dim3(dct::NT), lds, ctx->stream, A);
+      // persistent workgroups (grid-stride loop over the batches of LB lines), as many as are resident at once
+      static int resident = 0;
+      if (resident == 0)
+        {
+          int dev = 0, cus = 0;
+          if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return ADAFLO_EHIP;
+          resident = std::max(1, cus) * std::max(1, (int)((160 * 1024) / lds));
+        }
+      const long nb = std::min<long>((A.n_lines + G::LB - 1) / G::LB, resident);
+      hipLaunchKernelGGL((fdm_dct_kernel<LOG2N, FUSED, AXIS>), dim3((unsigned)nb), dim3(dct::NT), lds, ctx->stream, A);
       return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
     }
-    template <bool FUSED>
-    int launch_dct(adaflo_ctx *ctx, const int log2n, const dct::DctArgs &A)
+    template <int LOG2N>
+    int launch_dct_n(adaflo_ctx *ctx, const bool fused, const dct::DctArgs &A)
+    {
+      if (fused)
+        return launch_dct_t<LOG2N, true, 2>(ctx, A);
+      if (A.axis == 0)
+        return launch_dct_t<LOG2N, false, 0>(ctx, A);
+      return A.axis == 1 ? launch_dct_t<LOG2N, false, 1>(ctx, A) : launch_dct_t<LOG2N, false, 2>(ctx, A);
+    }
+    int launch_dct(adaflo_ctx *ctx, const int log2n, const bool fused, const dct::DctArgs &A)
     {
       switch (log2n)
         {
           case 6:
-            return launch_dct_t<6, FUSED>(ctx, A);
+            return launch_dct_n<6>(ctx, fused, A);
           case 7:
-            return launch_dct_t<7, FUSED>(ctx, A);
+            return launch_dct_n<7>(ctx, fused, A);
           case 8:
-            return launch_dct_t<8, FUSED>(ctx, A);
+            return launch_dct_n<8>(ctx, fused, A);
           case 9:
-            return launch_dct_t<9, FUSED>(ctx, A);
+            return launch_dct_n<9>(ctx, fused, A);
           case 10:
-            return launch_dct_t<10, FUSED>(ctx, A);
+            return launch_dct_n<10>(ctx, fused, A);
         }
       return ADAFLO_EINVAL;
     }
@@ -711,7 +728,8 @@ namespace adaflo_hip
             }
           fd.e[c][d] = it->second;
         }
-    const size_t need = (size_t)fd.nn[0] * fd.nn[1] * fd.nn[2] * fd.ncomp; // (all components at once, fdm_apply)
+    // (all components at once, fdm_apply; rows padded to 16 doubles for the cosine transforms)
+    const size_t need = (size_t)((fd.nn[0] + 15) / 16 * 16) * fd.nn[1] * fd.nn[2] * fd.ncomp;
     if (need > F->wcount)
       {
         for (double *p : {F->w0, F->w1})
@@ -861,6 +879,8 @@ namespace adaflo_hip
         if (mask == 0u && ex.log2n && ey.log2n && ez.log2n && !no_dct)
           {
             // cosine modes in all directions: x, y forward, z forward + scaling + z back in one pass, y, x back
+            // (the intermediate arrays have rows padded to 16 doubles: aligned runs in the strided passes)
+            const int    P = (nx + 15) / 16 * 16;
             dct::DctArgs A{};
             A.nx = nx, A.ny = ny, A.nz = nz;
             A.lx = ex.d_lamn, A.ly = ey.d_lamn, A.lz = ez.d_lamn, A.ax = ex.d_a2, A.ay = ey.d_a2, A.az = ez.d_a2;
@@ -872,8 +892,9 @@ namespace adaflo_hip
               {
                 const Eig1D &E = axis[pass] == 0 ? ex : (axis[pass] == 1 ? ey : ez);
                 A.in = in[pass], A.out = out[pass], A.tw = E.d_tw, A.axis = axis[pass];
-                A.n_lines = n / E.n;
-                if (int e = pass == 2 ? launch_dct<true>(ctx, E.log2n, A) : launch_dct<false>(ctx, E.log2n, A))
+                A.pitch_in = pass == 0 ? nx : P, A.pitch_out = pass == 4 ? nx : P;
+                A.n_lines = axis[pass] == 0 ? (long)ny * nz : (axis[pass] == 1 ? (long)P * nz : (long)P * ny);
+                if (int e = launch_dct(ctx, E.log2n, pass == 2, A))
                   return e;
               }
             return 0;

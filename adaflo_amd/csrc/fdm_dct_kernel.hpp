@@ -24,6 +24,10 @@ namespace adaflo_hip
 {
   namespace dct
   {
+#ifndef DCT_EXP
+#define DCT_EXP 0 // diagnostic builds (scripts/dev/dct_probe.hip): 1 no transform, 2 no stages after the first pair, 4 no
+                  // digit-reversed reads, 8 no global loads, 16 no global stores -- results wrong by construction
+#endif
     constexpr int NT    = 256;  // threads of a workgroup
     constexpr int NCPLX = 4096; // complex numbers of a batch: LB lines x N
 
@@ -40,6 +44,11 @@ namespace adaflo_hip
       long          n_lines; // lines of the whole field
       int           axis;    // 0: x (contiguous), 1: y, 2: z
       int           nx, ny, nz;
+      // elements per x-row of the input and of the output array (>= nx).  The intermediate arrays of an application are
+      // padded to a multiple of 16 so that the runs of LB consecutive doubles the strided passes move are aligned; a
+      // strided pass has ONE pitch (pitch_in == pitch_out) and enumerates its lines over the padded rows, lines with
+      // x >= nx do not exist
+      int           pitch_in, pitch_out;
       // FUSED (axis 2): scaling between the two transforms; a*: squared normalisation of mode k, l*: eigenvalue
       const double *lx, *ly, *lz, *ax, *ay, *az;
       double        cm, cl, eps;
@@ -51,11 +60,14 @@ namespace adaflo_hip
       static constexpr int N = 1 << LOG2N, n = N + 1, LB = NCPLX / N;
       static constexpr int n_r4 = LOG2N / 2, n_stages = n_r4 + (LOG2N & 1);
       static_assert(LOG2N >= 6 && LOG2N <= 10, "64 .. 1024 intervals per line");
-      // LDS, in doubles: Z (the raw lines R[LB][n] overlay its start), twiddles, the two end values of every line
-      static constexpr int L_Z = 0, L_T = 2 * NCPLX, L_X0 = L_T + 2 * (N + 1), L_XN = L_X0 + LB, L_TOTAL = L_XN + LB;
+      // LDS, in doubles: Z (one complex number of padding behind every 16: the strides 16, 64, ... of the later stages and
+      // of the digit-reversed reads would otherwise fall on one bank; the raw lines R[LB][n] overlay its start), twiddles,
+      // (x_0 + x_N, x_0 - x_N) of every line, (lx + ly, ax ay) of every line (fused pass)
+      static constexpr int L_Z = 0, L_T = 2 * (NCPLX + NCPLX / 16), L_E = L_T + 2 * (N + 1), L_F = L_E + 2 * LB, L_DUMP = L_F + 2 * LB, L_TOTAL = L_DUMP + 2;
       static_assert(LB * n <= 2 * NCPLX, "raw overlay");
+      static __device__ __forceinline__ constexpr int pad(const int i) { return i + (i >> 4); }
       // where X[k] lies after the stages (digit reversal of the mixed radix 4, 4, ..., [2])
-      static constexpr int pos_of(int k)
+      static __device__ __forceinline__ constexpr int pos_of(int k)
       {
         int p = 0, span = N;
         for (int s = 0; s < n_stages; ++s)
@@ -85,49 +97,148 @@ namespace adaflo_hip
       return cplx{-t.re, -t.im};
     }
 
-    // one radix-4 butterfly (forward transform) with the twiddles of position j in a sub-transform of length L
-    template <int N, int L>
-    __device__ __forceinline__ void radix4(cplx (&a)[4], const cplx *T, const int j)
+    // radix-4 butterfly of the forward transform, twiddles not applied: a <- (y0, y1, y2, y3)
+    __device__ __forceinline__ void radix4(cplx &a0, cplx &a1, cplx &a2, cplx &a3)
     {
-      const cplx b0{a[0].re + a[2].re, a[0].im + a[2].im}, b1{a[0].re - a[2].re, a[0].im - a[2].im};
-      const cplx b2{a[1].re + a[3].re, a[1].im + a[3].im};
-      const cplx b3{a[1].im - a[3].im, -(a[1].re - a[3].re)}; // -i (a1 - a3)
-      a[0] = cplx{b0.re + b2.re, b0.im + b2.im};
-      cplx y1{b1.re + b3.re, b1.im + b3.im}, y2{b0.re - b2.re, b0.im - b2.im}, y3{b1.re - b3.re, b1.im - b3.im};
-      if (L > 4)
+      const cplx b0{a0.re + a2.re, a0.im + a2.im}, b1{a0.re - a2.re, a0.im - a2.im};
+      const cplx b2{a1.re + a3.re, a1.im + a3.im};
+      const cplx b3{a1.im - a3.im, -(a1.re - a3.re)}; // -i (a1 - a3)
+      a0 = cplx{b0.re + b2.re, b0.im + b2.im};
+      a1 = cplx{b1.re + b3.re, b1.im + b3.im};
+      a2 = cplx{b0.re - b2.re, b0.im - b2.im};
+      a3 = cplx{b1.re - b3.re, b1.im - b3.im};
+    }
+    // exp(-2 pi i e / 16), e = 0 .. 9
+    __device__ __forceinline__ cplx w16(const int e)
+    {
+      constexpr double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, r = 0.70710678118654752440;
+      switch (e)
         {
-          const int m = j * (N / L);
-          y1          = cmul(y1, twiddle<N>(T, m));
-          y2          = cmul(y2, twiddle<N>(T, 2 * m));
-          y3          = cmul(y3, twiddle<N>(T, 3 * m));
+          case 0:
+            return cplx{1., 0.};
+          case 1:
+            return cplx{c1, -s1};
+          case 2:
+            return cplx{r, -r};
+          case 3:
+            return cplx{s1, -c1};
+          case 4:
+            return cplx{0., -1.};
+          case 5:
+            return cplx{-s1, -c1};
+          case 6:
+            return cplx{-r, -r};
+          case 7:
+            return cplx{-c1, -s1};
+          case 8:
+            return cplx{-1., 0.};
+          default:
+            return cplx{-c1, s1};
         }
-      a[1] = y1, a[2] = y2, a[3] = y3;
     }
 
-    // stages 1 .. of the FFT, in place in Z (stage 0 is part of dct_lines: it reads the raw lines)
+    // TWO radix-4 stages (sub-transform lengths L and L / 4) on 16 numbers in registers: a[p][q] is the element at
+    // g + j + p L/4 + q L/16, 0 <= j < L/16.  Stage A: for every q the butterfly over p at position j + q L/16 of the
+    // length-L transform, whose twiddles are w_L^(j m) w_16^(q m) (the second factor a constant); stage B: for every p the
+    // butterfly over q at position j of a length-L/4 transform.
+    template <int N, int L>
+    __device__ __forceinline__ void radix4x4(cplx (&a)[4][4], const cplx *T, const int j)
+    {
+      cplx tw[3];
+      if (L > 16)
+        {
+          const int m = j * (N / L);
+          tw[0] = twiddle<N>(T, m), tw[1] = twiddle<N>(T, 2 * m), tw[2] = twiddle<N>(T, 3 * m);
+        }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        {
+          radix4(a[0][q], a[1][q], a[2][q], a[3][q]);
+#pragma unroll
+          for (int m = 1; m < 4; ++m)
+            {
+              if (q > 0)
+                a[m][q] = cmul(a[m][q], w16(q * m));
+              if (L > 16)
+                a[m][q] = cmul(a[m][q], tw[m - 1]);
+            }
+        }
+      if (L / 4 > 4)
+        {
+          const int m = j * (N / (L / 4));
+          tw[0] = twiddle<N>(T, m), tw[1] = twiddle<N>(T, 2 * m), tw[2] = twiddle<N>(T, 3 * m);
+        }
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        {
+          radix4(a[p][0], a[p][1], a[p][2], a[p][3]);
+          if (L / 4 > 4)
+            {
+#pragma unroll
+              for (int m = 1; m < 4; ++m)
+                a[p][m] = cmul(a[p][m], tw[m - 1]);
+            }
+        }
+    }
+
+    // stages S, S + 1 (radix 4 x 4), in place in Z
+    template <int LOG2N, int S>
+    __device__ __forceinline__ void fft_double_stage(cplx *Z, const cplx *T)
+    {
+      using G         = Geo<LOG2N>;
+      constexpr int N = G::N, L = N >> (2 * S);
+      static_assert(L >= 16, "two radix-4 stages");
+      const int t = threadIdx.x;
+#pragma unroll
+      for (int i = 0; i < NCPLX / 16 / NT; ++i)
+        {
+          const int b = t + NT * i, line = b >> (LOG2N - 4), r = b & (N / 16 - 1);
+          const int j = r & (L / 16 - 1), base = line * N + (r / (L / 16)) * L + j;
+          cplx      a[4][4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              a[p][q] = Z[G::pad(base + p * (L / 4) + q * (L / 16))];
+          radix4x4<N, L>(a, T, j);
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              Z[G::pad(base + p * (L / 4) + q * (L / 16))] = a[p][q];
+        }
+      __syncthreads();
+    }
+    // one radix-4 stage S, or the radix-2 stage at the end (S = n_r4), in place in Z
     template <int LOG2N, int S>
     __device__ __forceinline__ void fft_stage(cplx *Z, const cplx *T)
     {
-      using G             = Geo<LOG2N>;
-      constexpr int N     = G::N;
-      constexpr int L     = N >> (2 * S); // length of the sub-transforms this stage splits
-      const int     t     = threadIdx.x;
+      using G         = Geo<LOG2N>;
+      constexpr int N = G::N;
+      constexpr int L = N >> (2 * S); // length of the sub-transforms this stage splits
+      const int     t = threadIdx.x;
       if constexpr (S < G::n_r4)
         {
 #pragma unroll
           for (int i = 0; i < NCPLX / 4 / NT; ++i)
             {
               const int b = t + NT * i, line = b >> (LOG2N - 2), r = b & (N / 4 - 1);
-              const int j = r & (L / 4 - 1), g = (r / (L / 4)) * L;
-              cplx     *z = Z + line * N + g + j;
+              const int j = r & (L / 4 - 1), base = line * N + (r / (L / 4)) * L + j;
               cplx      a[4];
 #pragma unroll
               for (int p = 0; p < 4; ++p)
-                a[p] = z[p * (L / 4)];
-              radix4<N, L>(a, T, j);
+                a[p] = Z[G::pad(base + p * (L / 4))];
+              radix4(a[0], a[1], a[2], a[3]);
+              if (L > 4)
+                {
+                  const int m = j * (N / L);
+#pragma unroll
+                  for (int q = 1; q < 4; ++q)
+                    a[q] = cmul(a[q], twiddle<N>(T, q * m));
+                }
 #pragma unroll
               for (int p = 0; p < 4; ++p)
-                z[p * (L / 4)] = a[p];
+                Z[G::pad(base + p * (L / 4))] = a[p];
             }
         }
       else // the radix-2 stage at the end: L = 2, no twiddles
@@ -136,20 +247,26 @@ namespace adaflo_hip
           for (int i = 0; i < NCPLX / 2 / NT; ++i)
             {
               const int  b = t + NT * i;
-              cplx      *z = Z + 2 * b;
-              const cplx a0 = z[0], a1 = z[1];
-              z[0] = cplx{a0.re + a1.re, a0.im + a1.im};
-              z[1] = cplx{a0.re - a1.re, a0.im - a1.im};
+              const cplx a0 = Z[G::pad(2 * b)], a1 = Z[G::pad(2 * b + 1)];
+              Z[G::pad(2 * b)]     = cplx{a0.re + a1.re, a0.im + a1.im};
+              Z[G::pad(2 * b + 1)] = cplx{a0.re - a1.re, a0.im - a1.im};
             }
         }
       __syncthreads();
     }
+    // stages S ... : pairs of radix-4 stages as long as there are two, then what is left
     template <int LOG2N, int S>
     struct Stages
     {
       static __device__ __forceinline__ void run(cplx *Z, const cplx *T)
       {
-        if constexpr (S < Geo<LOG2N>::n_stages)
+        using G = Geo<LOG2N>;
+        if constexpr (S + 1 < G::n_r4)
+          {
+            fft_double_stage<LOG2N, S>(Z, T);
+            Stages<LOG2N, S + 2>::run(Z, T);
+          }
+        else if constexpr (S < G::n_stages)
           {
             fft_stage<LOG2N, S>(Z, T);
             Stages<LOG2N, S + 1>::run(Z, T);
@@ -157,16 +274,25 @@ namespace adaflo_hip
       }
     };
 
-    // The cosine sums of the LB raw lines R[line][n] at the start of the LDS area; the results are returned in
-    // registers: item it = t + NT i, i < NI, is (line, k) = (it / (N/2 + 1), it % (N/2 + 1)) and carries y_k and y_{N-k}.
-    // On return every thread has passed a barrier after its last LDS read: the caller may overwrite R.
+    // The cosine sums of the LB raw lines R[line][n] at the start of the LDS area.  The results stay in Z where the
+    // transform left its output: y_k in the real part of slot pos_of(k) for k < N, y_N in the imaginary part of slot
+    // pos_of(0) (the two slots an item reads are the two it writes, nobody else touches them); y_value() reads them.
+    // On return every thread has passed a barrier after its last access.
     template <int LOG2N>
     struct Items
     {
       static constexpr int N = 1 << LOG2N, per_line = N / 2 + 1, total = Geo<LOG2N>::LB * per_line, NI = (total + NT - 1) / NT;
     };
     template <int LOG2N>
-    __device__ __forceinline__ void dct_lines(double *lds, double (&yk)[Items<LOG2N>::NI], double (&ym)[Items<LOG2N>::NI])
+    __device__ __forceinline__ double y_value(const double *lds, const int line, const int m)
+    {
+      using G         = Geo<LOG2N>;
+      constexpr int N = G::N;
+      const double *z = lds + G::L_Z + 2 * G::pad(line * N + G::pos_of(m & (N - 1)));
+      return z[m >> LOG2N]; // m == N: the imaginary part of slot pos_of(0)
+    }
+    template <int LOG2N>
+    __device__ __forceinline__ void dct_lines(double *lds)
     {
       using G         = Geo<LOG2N>;
       using I         = Items<LOG2N>;
@@ -175,146 +301,208 @@ namespace adaflo_hip
       double       *R = lds + G::L_Z;
       cplx         *Z = reinterpret_cast<cplx *>(lds + G::L_Z);
       const cplx   *T = reinterpret_cast<const cplx *>(lds + G::L_T);
-      // ---- stage 0 on z_j = e_{2j} + i e_{2j+1} taken from the raw lines (e_m = x_m, m <= N; x_{2N-m} beyond)
+      cplx         *E = reinterpret_cast<cplx *>(lds + G::L_E);
+      if (DCT_EXP & 1)
+        {
+          __syncthreads();
+          return;
+        }
+      // ---- stages 0, 1 on z_j = e_{2j} + i e_{2j+1} taken from the raw lines (e_m = x_m, m <= N; x_{2N-m} beyond)
       {
-        cplx a[NCPLX / 4 / NT][4];
+        static_assert(NCPLX / 16 / NT == 1, "one 16-point group per thread");
+        const int     line = t >> (LOG2N - 4), j = t & (N / 16 - 1);
+        const double *x    = R + line * n;
+        cplx          a[4][4];
 #pragma unroll
-        for (int i = 0; i < NCPLX / 4 / NT; ++i)
-          {
-            const int     b = t + NT * i, line = b >> (LOG2N - 2), j = b & (N / 4 - 1);
-            const double *x = R + line * n;
+        for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
-              {
-                const int m0 = 2 * (j + p * (N / 4)), m1 = m0 + 1;
-                a[i][p]      = cplx{x[m0 <= N ? m0 : 2 * N - m0], x[m1 <= N ? m1 : 2 * N - m1]};
-              }
-            radix4<N, N>(a[i], T, j);
-          }
+          for (int q = 0; q < 4; ++q)
+            {
+              const int m0 = 2 * (j + p * (N / 4) + q * (N / 16)), m1 = m0 + 1;
+              a[p][q]      = cplx{x[m0 <= N ? m0 : 2 * N - m0], x[m1 <= N ? m1 : 2 * N - m1]};
+            }
+        radix4x4<N, N>(a, T, j);
+        cplx ends{0., 0.};
         if (t < G::LB)
-          {
-            lds[G::L_X0 + t] = R[t * n];
-            lds[G::L_XN + t] = R[t * n + N];
-          }
+          ends = cplx{R[t * n] + R[t * n + N], R[t * n] - R[t * n + N]};
         __syncthreads();
+        if (t < G::LB)
+          E[t] = ends;
 #pragma unroll
-        for (int i = 0; i < NCPLX / 4 / NT; ++i)
-          {
-            const int b = t + NT * i, line = b >> (LOG2N - 2), j = b & (N / 4 - 1);
+        for (int p = 0; p < 4; ++p)
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
-              Z[line * N + j + p * (N / 4)] = a[i][p];
-          }
+          for (int q = 0; q < 4; ++q)
+            Z[G::pad(line * N + j + p * (N / 4) + q * (N / 16))] = a[p][q];
         __syncthreads();
       }
-      Stages<LOG2N, 1>::run(Z, T);
-      // ---- E_k, E_{N-k} from Z_k and Z_{N-k} (digit-reversed positions), then y
-#pragma unroll
-      for (int i = 0; i < I::NI; ++i)
-        {
-          const int it = t + NT * i;
-          yk[i] = ym[i] = 0.;
-          if (it < I::total)
-            {
-              const int    line = it / I::per_line, k = it - line * I::per_line;
-              const cplx   zk = Z[line * N + G::pos_of(k)], zm = Z[line * N + G::pos_of((N - k) & (N - 1))];
-              const cplx   w   = T[k];
-              const double are = 0.5 * (zk.re + zm.re), bre = 0.5 * (zk.im + zm.im), bim = -0.5 * (zk.re - zm.re);
-              const double p   = w.re * bre - w.im * bim;
-              const double x0 = lds[G::L_X0 + line], xn = lds[G::L_XN + line];
-              const double ends = (k & 1) ? x0 - xn : x0 + xn;
-              yk[i]             = 0.5 * (are + p + ends);
-              ym[i]             = 0.5 * (are - p + ends);
-            }
-        }
+      if (!(DCT_EXP & 2))
+        Stages<LOG2N, 2>::run(Z, T);
+      // ---- E_k, E_{N-k} from Z_k and Z_{N-k} (digit-reversed positions), then y, written back to the same two slots
+      if (!(DCT_EXP & 4))
+#pragma unroll 3
+        for (int i = 0; i < I::NI; ++i)
+          {
+            const int it = t + NT * i;
+            if (it < I::total)
+              {
+                const int    line = it / I::per_line, k = it - line * I::per_line;
+                cplx        *pk = Z + G::pad(line * N + G::pos_of(k)), *pm = Z + G::pad(line * N + G::pos_of((N - k) & (N - 1)));
+                const cplx   zk = *pk, zm = *pm;
+                const cplx   w = T[k], e = E[line];
+                const double are = 0.5 * (zk.re + zm.re), bre = 0.5 * (zk.im + zm.im), bim = -0.5 * (zk.re - zm.re);
+                const double p    = w.re * bre - w.im * bim;
+                const double ends = (k & 1) ? e.im : e.re;
+                const double yk = 0.5 * (are + p + ends), ym = 0.5 * (are - p + ends);
+                if (k == 0)
+                  *pk = cplx{yk, ym}; // y_0 and y_N
+                else
+                  {
+                    pm->re = ym; // (k = N / 2: the same slot and the same value)
+                    pk->re = yk;
+                  }
+              }
+          }
       __syncthreads();
     }
 
-    template <int LOG2N, bool FUSED>
+    // One workgroup, a grid-stride loop over the batches.  The memory stream is software-pipelined around the transform:
+    // the lines of batch b + 1 are loaded into registers and the results of batch b - 1 are stored from registers at the
+    // START of the work on batch b, so that both have the whole transform to complete (vector-memory operations retire in
+    // order: a wait for the loads is a wait for every older store as well) and the workgroup never sits on its own latency.
+    // A thread serves ONE line c of a batch, rows r0, r0 + TPL, ... (TPL = NT / LB = N / 16 threads per line): along the
+    // line for AXIS 0 (consecutive lanes read consecutive doubles of a line), across the lines for the strided axes
+    // (consecutive lanes read the same row of consecutive lines); every index is base + constant, nothing to keep in
+    // registers.  AXIS is a template argument and every load is unconditional -- an absent value is read from element 0,
+    // an absent LDS slot is the dump slot: with run-time branches around the loads the same code
+    // had 400 basic blocks and the compiler waited for every load where it was issued.
+    template <int LOG2N, bool FUSED, int AXIS>
     __device__ __forceinline__ void dct_body(const DctArgs &A, double *lds)
     {
-      using G         = Geo<LOG2N>;
-      using I         = Items<LOG2N>;
-      constexpr int N = G::N, n = G::n, LB = G::LB;
-      const int     t = threadIdx.x;
-      double       *R = lds + G::L_Z;
-      const long    l0 = (long)blockIdx.x * LB;
-      const int     nl = (int)(A.n_lines - l0 < LB ? A.n_lines - l0 : LB);
+      using G           = Geo<LOG2N>;
+      constexpr int N = G::N, n = G::n, LB = G::LB, TPL = NT / LB;
+      static_assert(!FUSED || AXIS == 2, "the fused pass is the z pass");
+      constexpr int NLD = NCPLX / NT + 1; // values of a line per thread
+      static_assert(NLD * TPL >= n && (NLD - 1) * TPL == N, "rows r0 + i TPL: only r0 = 0 has a last one (r = N)");
+      const int  t = threadIdx.x;
+      double    *R = lds + G::L_Z;
+      const long nbatch = (A.n_lines + LB - 1) / LB;
       for (int e = t; e < 2 * (N + 1); e += NT)
         lds[G::L_T + e] = A.tw[e];
-      // ---- the lines of this batch -> R[line][n] (absent lines: zeros)
-      long      base   = 0; // axes 1, 2: a thread serves ONE line c = t % LB of the batch (LB divides NT)
-      long      stride = 1;
-      const int c = t & (LB - 1), r0 = t / LB;
-      if (A.axis == 0)
-        {
-          const long    count = (long)nl * n;
-          const double *src   = A.in + l0 * n;
-          for (int e = t; e < LB * n; e += NT)
-            R[e] = e < count ? src[e] : 0.;
-        }
-      else
-        {
-          const long l = l0 + c;
-          if (A.axis == 1)
-            base = (l / A.nx) * ((long)A.nx * A.ny) + l % A.nx, stride = A.nx;
-          else
-            base = l, stride = (long)A.nx * A.ny;
-          for (int r = r0; r < n; r += NT / LB)
-            R[c * n + r] = c < nl ? A.in[base + r * stride] : 0.;
-        }
-      __syncthreads();
-      double yk[I::NI], ym[I::NI];
-      dct_lines<LOG2N>(lds, yk, ym);
-      if (FUSED)
-        {
-          // scale the mode coefficients and transform back
+      const int  c = AXIS == 0 ? t / TPL : t & (LB - 1), r0 = AXIS == 0 ? t & (TPL - 1) : t / LB;
+      const int  pitch  = A.pitch_in;
+      const long stride = AXIS == 0 ? 1 : (AXIS == 1 ? (long)pitch : (long)pitch * A.ny);
+      struct Pos
+      {
+        long in, out; // first value of this thread's line; -1: the line does not exist
+        int  nl;      // lines of the batch that exist
+      };
+      auto batch_pos = [&](const long b) {
+        const long l0 = b * LB;
+        Pos        P;
+        P.nl = (int)(A.n_lines - l0 < LB ? A.n_lines - l0 : LB);
+        if (AXIS == 0)
+          P.in = (l0 + c) * A.pitch_in, P.out = (l0 + c) * A.pitch_out;
+        else
+          {
+            const unsigned l = (unsigned)l0 + c, x = l % (unsigned)pitch, zz = l / (unsigned)pitch; // (fewer than 2^31 lines)
+            P.in = P.out = AXIS == 1 ? zz * ((long)pitch * A.ny) + x : (long)l;
+            if ((int)x >= A.nx)
+              P.in = -1;
+          }
+        if (c >= P.nl)
+          P.in = -1;
+        return P;
+      };
+      auto load = [&](const Pos &P, double (&v)[NLD]) {
+        const double *src = A.in + (P.in >= 0 ? P.in + r0 * stride : 0);
 #pragma unroll
-          for (int i = 0; i < I::NI; ++i)
-            {
-              const int it = t + NT * i;
-              if (it < I::total)
-                {
-                  const int  line = it / I::per_line, k = it - line * I::per_line;
-                  const long l = l0 + line;
-                  double     sk = 0., sm = 0.;
-                  if (line < nl)
-                    {
-                      const int    x = (int)(l % A.nx), y = (int)(l / A.nx);
-                      const double lxy = A.lx[x] + A.ly[y], axy = A.ax[x] * A.ay[y];
-                      const double dk = A.cm + A.cl * (lxy + A.lz[k]), dm = A.cm + A.cl * (lxy + A.lz[N - k]);
-                      sk = (dk > A.eps || dk < -A.eps) ? axy * A.az[k] / dk : 0.;
-                      sm = (dm > A.eps || dm < -A.eps) ? axy * A.az[N - k] / dm : 0.;
-                    }
-                  R[line * n + k]     = yk[i] * sk;
-                  R[line * n + N - k] = ym[i] * sm;
-                }
-            }
+        for (int i = 0; i < NLD; ++i)
+          {
+            // (no select on the VALUE: it would be scheduled right behind the load and wait for it.  A line that does not
+            // exist transforms whatever element 0 holds; lines do not mix and its results are never stored)
+            const bool valid = P.in >= 0 && (i < NLD - 1 || r0 == 0);
+            v[i]             = (DCT_EXP & 8) ? 0. : src[valid ? i * TPL * stride : 0];
+          }
+      };
+      auto store = [&](const Pos &P, const double (&v)[NLD]) {
+        if (DCT_EXP & 16)
+          {
+            if (v[0] == 1.2345)
+              A.out[t] = 0.;
+            return;
+          }
+        if (P.in < 0)
+          return;
+        double *dst = A.out + P.out + r0 * stride;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+          if (i < NLD - 1 || r0 == 0)
+            dst[i * TPL * stride] = v[i];
+      };
+      // the same values <-> the raw lines R[line][n] in LDS, and where dct_lines left the results
+      double *Rc = R + c * n + r0;
+      auto    to_lds = [&](const double (&v)[NLD]) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+          (i < NLD - 1 || r0 == 0 ? Rc[i * TPL] : lds[G::L_DUMP]) = v[i];
+      };
+      const int pos0 = c * N + G::pos_of(r0); // (pos_of is linear over disjoint bit fields: r0 < TPL, i TPL above)
+      auto      gather = [&](double (&v)[NLD]) {
+#pragma unroll
+        for (int i = 0; i < NLD - 1; ++i)
+          v[i] = lds[G::L_Z + 2 * G::pad(pos0 + G::pos_of(i * TPL))];
+        v[NLD - 1] = lds[G::L_Z + 2 * G::pad(c * N) + 1]; // y_N (used by r0 = 0 only)
+      };
+      double pre[NLD], res[NLD];
+      long   b = blockIdx.x;
+      if (b >= nbatch)
+        return;
+      Pos P = batch_pos(b), Pprev = P;
+      load(P, pre);
+      bool have_prev = false;
+      while (true)
+        {
+          to_lds(pre);
           __syncthreads();
-          dct_lines<LOG2N>(lds, yk, ym);
-        }
-#pragma unroll
-      for (int i = 0; i < I::NI; ++i)
-        {
-          const int it = t + NT * i;
-          if (it < I::total)
+          if (have_prev)
+            store(Pprev, res);
+          const long bn = b + gridDim.x;
+          const Pos  Pn = batch_pos(bn < nbatch ? bn : b);
+          if (bn < nbatch)
+            load(Pn, pre);
+          dct_lines<LOG2N>(lds);
+          if (FUSED)
             {
-              const int line = it / I::per_line, k = it - line * I::per_line;
-              R[line * n + k]     = yk[i];
-              R[line * n + N - k] = ym[i];
+              // scale the mode coefficients and transform back; the factors that belong to the line (x, y) first
+              cplx *F = reinterpret_cast<cplx *>(lds + G::L_F);
+              if (t < LB)
+                {
+                  const unsigned l = (unsigned)(b * LB) + t, x = l % (unsigned)pitch, y = l / (unsigned)pitch;
+                  const bool     live = t < P.nl && (int)x < A.nx;
+                  F[t] = live ? cplx{A.lx[x] + A.ly[y], A.ax[x] * A.ay[y]} : cplx{0., 0.};
+                }
+              gather(res);
+              __syncthreads();
+              const cplx f = F[c]; // (an absent line: ax ay = 0)
+#pragma unroll
+              for (int i = 0; i < NLD; ++i)
+                {
+                  const int    k = i < NLD - 1 ? r0 + i * TPL : N;
+                  const double d = A.cm + A.cl * (f.re + A.lz[k]);
+                  res[i] *= (d > A.eps || d < -A.eps) ? f.im * A.az[k] / d : 0.;
+                }
+              to_lds(res);
+              __syncthreads();
+              dct_lines<LOG2N>(lds);
             }
+          gather(res);
+          __syncthreads();
+          Pprev = P, have_prev = true;
+          if (bn >= nbatch)
+            break;
+          b = bn, P = Pn;
         }
-      __syncthreads();
-      if (A.axis == 0)
-        {
-          const long count = (long)nl * n;
-          double    *dst   = A.out + l0 * n;
-          for (int e = t; e < count; e += NT)
-            dst[e] = R[e];
-        }
-      else if (c < nl)
-        for (int r = r0; r < n; r += NT / LB)
-          A.out[base + r * stride] = R[c * n + r];
+      store(Pprev, res);
     }
   } // namespace dct
 } // namespace adaflo_hip

@@ -20,8 +20,8 @@ ops.set_parameters(1.5 * max(mesh.h) / s, 0.02, 75.0, -100.0, 25.0, 1.5)
 lib, ctx = _lib.load(), ops._ctx
 x = ops.vector(np.random.default_rng(1).uniform(-1, 1, ops.n_dofs))
 y = ops.vector()
-fp = adaflo_amd.FlowParameters(velocity_degree=2, viscosity=0.1, time_step_size_start=0.01, end_time=1.0)
-nsm = adaflo_amd.NavierStokesMatrix(fp, mesh, adaflo_amd.TimeStepping(fp), ctx=ctx) if False else None
+
+
 
 
 def timed(field, src, dst, cm, cl, reps=20):

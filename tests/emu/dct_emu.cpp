@@ -17,17 +17,24 @@ namespace
   {
     using G = Geo<LOG2N>;
     static_assert(G::L_TOTAL * 8 <= (int)emu::LDS_BYTES, "LDS");
-    const long nb = (A.n_lines + G::LB - 1) / G::LB;
+    long nb = (A.n_lines + G::LB - 1) / G::LB;
+    nb      = nb > 3 ? 3 : nb; // (a small persistent grid: every workgroup loops over several batches)
+    double *lds = reinterpret_cast<double *>(emu::g_lds);
     if (fused)
-      emu::launch((unsigned)nb, NT, [&] { dct_body<LOG2N, true>(A, reinterpret_cast<double *>(emu::g_lds)); });
+      emu::launch((unsigned)nb, NT, [&] { dct_body<LOG2N, true, 2>(A, lds); });
+    else if (A.axis == 0)
+      emu::launch((unsigned)nb, NT, [&] { dct_body<LOG2N, false, 0>(A, lds); });
+    else if (A.axis == 1)
+      emu::launch((unsigned)nb, NT, [&] { dct_body<LOG2N, false, 1>(A, lds); });
     else
-      emu::launch((unsigned)nb, NT, [&] { dct_body<LOG2N, false>(A, reinterpret_cast<double *>(emu::g_lds)); });
+      emu::launch((unsigned)nb, NT, [&] { dct_body<LOG2N, false, 2>(A, lds); });
     return 0;
   }
 } // namespace
 
 // out = cosine sums of `in` ([z][y][x]) along `axis`; fused (axis 2 only): forward, scaling, back
-extern "C" int dct_emu_apply(const int axis, const int fused, const int nx, const int ny, const int nz, const double *in,
+// (pitch: elements per x-row of both arrays, >= nx)
+extern "C" int dct_emu_apply(const int axis, const int fused, const int nx, const int ny, const int nz, const int pitch, const double *in,
                              double *out, const double *lx, const double *ly, const double *lz, const double *ax,
                              const double *ay, const double *az, const double cm, const double cl, const double eps)
 {
@@ -45,8 +52,8 @@ extern "C" int dct_emu_apply(const int axis, const int fused, const int nx, cons
     }
   DctArgs A{};
   A.in = in, A.out = out, A.tw = tw.data();
-  A.n_lines = (long)nx * ny * nz / n;
-  A.axis = axis, A.nx = nx, A.ny = ny, A.nz = nz;
+  A.n_lines = axis == 0 ? (long)ny * nz : (axis == 1 ? (long)pitch * nz : (long)pitch * ny);
+  A.axis = axis, A.nx = nx, A.ny = ny, A.nz = nz, A.pitch_in = A.pitch_out = pitch;
   A.lx = lx, A.ly = ly, A.lz = lz, A.ax = ax, A.ay = ay, A.az = az, A.cm = cm, A.cl = cl, A.eps = eps;
   switch (log2n)
     {

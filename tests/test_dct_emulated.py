@@ -21,7 +21,7 @@ def emu():
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-o", LIB, SRC])
     lib = C.CDLL(LIB)
     lib.dct_emu_apply.restype = C.c_int
-    lib.dct_emu_apply.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_double)] * 8 + [C.c_double] * 3
+    lib.dct_emu_apply.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_double)] * 8 + [C.c_double] * 3
     return lib
 
 
@@ -30,15 +30,21 @@ def cosines(n):
     return np.cos(np.pi * np.outer(j, j) / (n - 1))
 
 
-def apply(lib, axis, field, fused=False, scal=None):
+def apply(lib, axis, field, fused=False, scal=None, pitch=None):
+    """pitch: the rows of both arrays are padded to that many elements (NaN in the padding: it must be neither read
+    into a result nor written)"""
     nz, ny, nx = field.shape
-    out = np.full_like(field, np.nan)
+    pitch = pitch or nx
+    padded = np.full((nz, ny, pitch), np.nan)
+    padded[:, :, :nx] = field
+    out = np.full_like(padded, np.nan)
     dp = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
     s = scal or dict(lx=None, ly=None, lz=None, ax=None, ay=None, az=None, cm=0.0, cl=0.0, eps=0.0)
-    rc = lib.dct_emu_apply(axis, int(fused), nx, ny, nz, dp(field), dp(out), dp(s["lx"]), dp(s["ly"]), dp(s["lz"]),
+    rc = lib.dct_emu_apply(axis, int(fused), nx, ny, nz, pitch, dp(padded), dp(out), dp(s["lx"]), dp(s["ly"]), dp(s["lz"]),
                            dp(s["ax"]), dp(s["ay"]), dp(s["az"]), s["cm"], s["cl"], s["eps"])
     assert rc == 0
-    return out
+    assert np.all(np.isnan(out[:, :, nx:]))
+    return np.ascontiguousarray(out[:, :, :nx])
 
 
 @pytest.mark.parametrize("axis,shape", [(0, (3, 5, 65)), (0, (2, 3, 129)), (0, (1, 19, 257)), (0, (1, 3, 513)), (0, (1, 5, 1025)),
@@ -52,6 +58,8 @@ def test_cosine_sums_along_an_axis(emu, axis, shape):
     ref = np.moveaxis(np.tensordot(cosines(n), field, axes=([1], [2 - axis])), 0, 2 - axis)
     got = apply(emu, axis, field)
     assert np.abs(got - ref).max() < 1e-13 * n * np.abs(field).max() * 4
+    got = apply(emu, axis, field, pitch=(shape[2] + 15) // 16 * 16)          # padded rows (the intermediate arrays)
+    assert np.abs(got - ref).max() < 1e-13 * n * np.abs(field).max() * 4
 
 
 def test_fused_forward_scaling_backward(emu):
@@ -62,7 +70,7 @@ def test_fused_forward_scaling_backward(emu):
     scal = dict(lx=rng.random(nx), ly=rng.random(ny), lz=rng.random(nz), ax=rng.random(nx) + 0.5, ay=rng.random(ny) + 0.5,
                 az=rng.random(nz) + 0.5, cm=0.0, cl=1.3, eps=1e-9)
     scal["lx"][0] = scal["ly"][0] = scal["lz"][0] = 0.0               # the null mode of a pure Neumann problem
-    got = apply(emu, 2, field, fused=True, scal=scal)
+    got = apply(emu, 2, field, fused=True, scal=scal, pitch=16)
     Cz = cosines(nz)
     modes = np.tensordot(Cz, field, axes=([1], [0]))
     den = scal["cm"] + scal["cl"] * (scal["lz"][:, None, None] + scal["ly"][None, :, None] + scal["lx"][None, None, :])

@@ -202,4 +202,3 @@ def test_fast_cosine_transforms_of_the_q1_pressure_space():
     zs = op.initialize_p_vector(got)
     op.pressure_poisson_vmult(xs, zs)
     assert rel_l2(xs.numpy(), ys.numpy()) < 1e-9
-    assert abs(got.mean()) < 1e-10 * np.abs(got).max() or True     # (the null mode carries no weight: checked through K)
