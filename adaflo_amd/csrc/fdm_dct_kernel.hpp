@@ -11,11 +11,12 @@
 // The FFT is an in-place decimation-in-frequency transform in LDS, radix 4 (one radix-2 stage at the end if log2 N is
 // odd); its result stays in digit-reversed order and the step that forms E reads Z_k where it lies.
 //
-// A workgroup of 256 threads transforms LB = 4096 / N lines at once (64 KB of complex numbers).  Lines are contiguous
-// (axis 0), strided by nx (axis 1: line = x + nx z) or by nx ny (axis 2: line = x + nx y); the strided passes read and
-// write LB neighbouring lines as runs of LB consecutive doubles.  The z pass can be FUSED: forward transform, the scaling
-// of the mode coefficients 1 / (c_m + c_l (lx + ly + lz)) times the squared normalisation of the three eigenvectors, and
-// the transform back, with the line never leaving LDS.
+// A workgroup of 256 threads transforms LB = 4096 / N lines at once (68 KB of complex numbers, two stages per LDS round
+// trip).  Lines are contiguous (axis 0), strided by the row pitch (axis 1: line = x + pitch z) or by pitch ny (axis 2:
+// line = x + pitch y); the strided passes read and write LB neighbouring lines as runs of LB consecutive doubles.  The z
+// pass can be FUSED: forward transform, the scaling of the mode coefficients 1 / (c_m + c_l (lx + ly + lz)) times the
+// squared normalisation of the three eigenvectors, and the transform back, with the line never leaving LDS.  The memory
+// stream is software-pipelined around the transform (dct_body).  Measurements: DESIGN.md 4.7.
 //
 // This header includes nothing: csrc/fdm.hip compiles it for the device, tests/emu/dct_emu.cpp on the host lane emulator.
 #pragma once
