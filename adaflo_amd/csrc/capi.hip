@@ -371,7 +371,7 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
   for (DeviceBuffer *b : {&ctx->lin, &ctx->rho, &ctx->mu, &ctx->damp, &ctx->lin_prec, &ctx->rho_prec,
                           &ctx->mu_prec, &ctx->damp_prec, &ctx->lin_q2, &ctx->lin_q2_prec,
                           &ctx->q2_slab_u, &ctx->q2_zslab_u, &ctx->q2_slab_p, &ctx->q2_zslab_p,
-                          &ctx->ls_convection, &ctx->ls_normal, &ctx->q1_convection, &ctx->q1_normal, &ctx->q1_normal_nodal,
+                          &ctx->ls_convection, &ctx->ls_normal, &ctx->q1_convection, &ctx->q1_normal, &ctx->q1_normal_nodal, &ctx->q1_velocity_nodal,
                           &ctx->q1_slab, &ctx->q1_zslab, &ctx->pc_inv_u, &ctx->pc_inv_pm, &ctx->pc_inv_pl,
                           &ctx->pc_ones_p, &ctx->pc_tmp_u, &ctx->pc_tmp_p, &ctx->pc_tmp_p2, &ctx->pc_work, &ctx->kr_work, &ctx->kr_basis, &ctx->kr_scalars,
                           &ctx->q1_poisson_coef, &ctx->ho_tab, &ctx->res_sum_u, &ctx->res_sum_p, &ctx->res_old,
@@ -1279,9 +1279,17 @@ static int ls_generic_state(adaflo_ctx *ctx, const int which)
 {
   DeviceBuffer &gen = which ? ctx->ls_normal : ctx->ls_convection, &swp = which ? ctx->q1_normal : ctx->q1_convection;
   bool         &gen_valid = which ? ctx->ls_normal_generic_valid : ctx->ls_convection_generic_valid;
-  const bool    swp_valid = which ? ctx->q1_normal_valid : ctx->q1_convection_valid;
   if (gen_valid && gen.p)
     return 0;
+  if (which == 0 && !ctx->q1_convection_valid && ctx->q1_convection_nodal_valid)
+    {
+      // the sweep right-hand side kept the nodal velocity only: write evaluated_convection from it now
+      TRY(ctx, q1_state_alloc(ctx, ctx->q1_convection), "out of device memory");
+      TRY(ctx, launch_q1_rhs(ctx, 1, 0, nullptr, nullptr, nullptr, nullptr, nullptr, ctx->q1_velocity_nodal.p, ctx->q1_convection.p, true),
+          "level-set kernel launch failed");
+      ctx->q1_convection_valid = true;
+    }
+  const bool    swp_valid = which ? ctx->q1_normal_valid : ctx->q1_convection_valid;
   if (!swp_valid || !swp.p)
     return fail(ctx, ADAFLO_ENOTINIT, "quadrature-point array not set");
   TRY(ctx, alloc(ctx, gen, ls_q_count(ctx)), ctx->last_error);
@@ -1319,6 +1327,7 @@ int adaflo_ls_set_evaluated_convection(adaflo_ctx *ctx, const double *u_q, int s
     return e;
   ctx->q1_convection_valid         = false;
   ctx->ls_convection_generic_valid = true;
+  ctx->q1_convection_nodal_valid   = false;
   return set_q_array(ctx, ctx->ls_convection, u_q, src_on_device);
 }
 
@@ -1376,6 +1385,12 @@ static int ls_vmult(adaflo_ctx *ctx, double *dst, const double *src, const int m
         {
           case 0:
             q1mode = Q1_ADVECT;
+            if (ctx->q1_convection_nodal_valid) // evaluated_convection came from a nodal velocity: evaluate it per Gauss point
+              {
+                q1mode = Q1_ADVECT_NODAL;
+                state  = ctx->q1_velocity_nodal.p;
+                break;
+              }
             if (!ctx->q1_convection_valid)
               TRY(ctx, q1_convert_state(ctx, ctx->q1_convection, ctx->ls_convection.p), "state re-layout failed");
             ctx->q1_convection_valid = true;
@@ -1443,7 +1458,7 @@ static int ls_vmult(adaflo_ctx *ctx, double *dst, const double *src, const int m
 int adaflo_ls_advance_concentration_vmult(adaflo_ctx *ctx, double *dst, const double *src)
 {
   CHECK_CTX(ctx);
-  if (!ctx->ls_convection.p && !ctx->q1_convection_valid)
+  if (!ctx->ls_convection.p && !ctx->q1_convection_valid && !ctx->q1_convection_nodal_valid)
     return fail(ctx, ADAFLO_ENOTINIT, "evaluated_convection not set (run the rhs kernel first)");
   return ls_vmult(ctx, dst, src, 0 /*LS_ADVECT*/, 0, ctx->ls_convection.p, 1);
 }
@@ -1459,13 +1474,26 @@ int adaflo_ls_advance_concentration_rhs(adaflo_ctx *ctx, double *dst, const doub
     return fail(ctx, ADAFLO_EINVAL, "null vector");
   if (ctx->variant >= 1)
     {
-      // sweep structure, evaluated_convection written in sweep layout (csrc/q1_sweep.hip)
-      TRY(ctx, q1_state_alloc(ctx, ctx->q1_convection), "out of device memory");
+      // sweep structure (csrc/q1_sweep.hip).  evaluated_convection is a function of the nodal velocity: the kernel does
+      // not write it (192 B per sub-cell) when the operator can evaluate the velocity itself -- a copy of the velocity
+      // vector is kept instead; otherwise it is written in sweep layout
+      const bool nodal = q1_advect_nodal_supported(ctx) && getenv("ADAFLO_LS_STREAM_CONVECTION") == nullptr;
+      if (nodal)
+        {
+          const size_t count = 3 * (size_t)ctx->n_nodes_u;
+          if (ctx->q1_velocity_nodal.count != count)
+            TRY(ctx, alloc(ctx, ctx->q1_velocity_nodal, count), ctx->last_error);
+          HIP_TRY(ctx, hipMemcpyAsync(ctx->q1_velocity_nodal.p, vel_solution, count * sizeof(double), hipMemcpyDeviceToDevice,
+                                      ctx->stream));
+        }
+      else
+        TRY(ctx, q1_state_alloc(ctx, ctx->q1_convection), "out of device memory");
       const int e = launch_q1_rhs(ctx, 1, use_old_old ? 1 : 0, dst, solution, solution_old, solution_old_old, nullptr,
-                                  vel_solution, ctx->q1_convection.p);
+                                  vel_solution, nodal ? nullptr : ctx->q1_convection.p);
       if (e == 0)
         {
-          ctx->q1_convection_valid         = true;
+          ctx->q1_convection_valid         = !nodal;
+          ctx->q1_convection_nodal_valid   = nodal;
           ctx->ls_convection_generic_valid = false;
           return 0;
         }
@@ -1474,6 +1502,7 @@ int adaflo_ls_advance_concentration_rhs(adaflo_ctx *ctx, double *dst, const doub
     }
   TRY(ctx, alloc(ctx, ctx->ls_convection, ls_q_count(ctx)), ctx->last_error);
   ctx->q1_convection_valid         = false;
+  ctx->q1_convection_nodal_valid   = false;
   ctx->ls_convection_generic_valid = true;
   TRY(ctx,
       launch_ls(ctx, 2, 0, use_old_old, dst, solution, solution_old, solution_old_old, vel_solution,
@@ -1591,6 +1620,7 @@ int adaflo_ls_advance_concentration_rhs_stabilized(adaflo_ctx *ctx, double *dst,
   TRY(ctx, alloc(ctx, ctx->ls_stab_vel_sum, (size_t)(3 * ctx->n_nodes_u)), ctx->last_error);
   TRY(ctx, alloc(ctx, ctx->ls_stab_ls_sum, (size_t)ctx->n_nodes_ls), ctx->last_error);
   ctx->q1_convection_valid         = false;
+  ctx->q1_convection_nodal_valid   = false;
   ctx->ls_convection_generic_valid = true;
   // interpolation is linear: the sums of the two old states are formed at the nodes
   TRY(ctx, launch_lincomb(ctx, ctx->ls_stab_vel_sum.p, 1., vel_solution_old, 1., vel_solution_old_old, 3 * ctx->n_nodes_u),

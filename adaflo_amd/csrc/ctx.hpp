@@ -163,6 +163,11 @@ struct adaflo_ctx
   // the unit normal at the Gauss points from it instead of streaming the 192 B per sub-cell (q1_sweep.hip)
   adaflo_hip::DeviceBuffer q1_normal_nodal;
   bool                     q1_normal_nodal_valid = false;
+  // the advection right-hand side on the sweep structure keeps the nodal velocity it was given instead of writing
+  // evaluated_convection; the advection operator evaluates the velocity from it (Q1_ADVECT_NODAL), the quadrature-point
+  // array is materialised only when somebody asks for it
+  adaflo_hip::DeviceBuffer q1_velocity_nodal;
+  bool                     q1_convection_nodal_valid = false;
   // the sweep right-hand sides write the quadrature-point arrays in sweep layout only; the generic
   // [cell][3][q] copies are re-created on demand (adaflo_ls_get_evaluated_*, generic kernels)
   bool                     ls_convection_generic_valid = false, ls_normal_generic_valid = false;

@@ -149,8 +149,10 @@ namespace adaflo_hip
     Q1_ADVECT       = 1, // (w, weight v + u . grad v)
     Q1_REINIT       = 2, // (w, c_mass v) + (grad w, c_lap (n . grad v) n)
     Q1_LAPLACE_Q3   = 3, // (grad w, c(x_q) grad v) with the 3x3x3 Gauss rule, c per point (pressure Poisson)
-    Q1_REINIT_NODAL = 4  // Q1_REINIT with the unit normal at the Gauss points recomputed from the NODAL normal field
+    Q1_REINIT_NODAL = 4, // Q1_REINIT with the unit normal at the Gauss points recomputed from the NODAL normal field
                          // (`state` = three nodal fields) instead of streamed: 24 B instead of 192 B per sub-cell
+    Q1_ADVECT_NODAL = 5  // Q1_ADVECT with the FE_Q(k) velocity evaluated at the Gauss points from the NODAL velocity
+                         // (`state` = velocity vector [node][3]) as the advection right-hand side does, instead of streamed
   };
   int q1_convert_state(adaflo_ctx *ctx, DeviceBuffer &out, const double *generic_dev);
   int launch_q1_stencil_rhs(adaflo_ctx *ctx, int mode, double *dst, const double *src);
@@ -159,13 +161,15 @@ namespace adaflo_hip
   int  launch_ns_divergence_stencil(adaflo_ctx *ctx, double *dst_p, const double *src_u, double weight, bool plain);
   int q1_state_alloc(adaflo_ctx *ctx, DeviceBuffer &out);
   int q1_unconvert_state(adaflo_ctx *ctx, double *generic_dev, const DeviceBuffer &sweep);
+  // (state == nullptr: the advection does not write evaluated_convection; state_only: nothing but that array)
   int launch_q1_rhs(adaflo_ctx *ctx, int kind, int flag, double *dst, const double *f0, const double *f1,
-                    const double *f2, const double *f3, const double *vel, double *state);
+                    const double *f2, const double *f3, const double *vel, double *state, bool state_only = false);
   int launch_q1_sweep(adaflo_ctx *ctx, int sub, int mode, double c_mass, double c_lap, double weight,
                       uint32_t con, double con_sign, const double *diag, double *dst, const double *src,
                       const double *state, int n_blocks = 1, const double *coef_cell = nullptr, int coef_stride = 0,
                       int coef_mid = 0, double coef_shift = 0.);
   int q1_convert_poisson_coef(adaflo_ctx *ctx, DeviceBuffer &out, const double *rho_generic, double weight);
+  bool q1_advect_nodal_supported(const adaflo_ctx *ctx);
 
   // specialised 3D Q2/Q1 sweep kernel (ns_q2.hip)
   bool q2_supported(const adaflo_ctx *ctx);

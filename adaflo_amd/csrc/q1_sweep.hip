@@ -54,6 +54,10 @@ namespace adaflo_hip
       const double *state;
       double       *slab, *zslab;
       long          comp_stride, slab_stride, zslab_stride; // blockIdx.y = scalar block (normal vector: 3)
+      // Q1_ADVECT_NODAL: velocity [node][3] in `state`; svel[q (2 sub)][KU + 1] 1D shape values of FE_Q(KU) at the Gauss
+      // points of the sub-cells; velocity nodes in x, y; edge of the velocity patch of a tile; subdivisions
+      const double *svel;
+      int           vnx, vny, wn, sub;
     };
 
     template <int TN>
@@ -68,12 +72,13 @@ namespace adaflo_hip
       return 3 * TN - 3 + j;
     }
 
-    template <int MODE>
+    template <int MODE, int KU = 0>
     __global__ __launch_bounds__(NTQ) void q1_sweep_kernel(const Q1Args A)
     {
       __shared__ double pl[2][TNQ * TNQ]; // node planes K, K+1 (ring)
       __shared__ double pub[2][3][NTQ];   // published high faces: [plane lk][(1,0),(0,1),(1,1)][lane]
-      constexpr bool NODAL = MODE == Q1_REINIT_NODAL;
+      constexpr bool NODAL = MODE == Q1_REINIT_NODAL, NODALV = MODE == Q1_ADVECT_NODAL;
+      extern __shared__ double W[];       // NODALV: velocity of the tile's node patch at the two Gauss planes [2][3][wn][wn]
       __shared__ double pln[NODAL ? 2 * 3 * TNQ * TNQ : 1]; // planes K, K+1 of the three components of the normal field
 
       const int  tid = threadIdx.x;
@@ -144,6 +149,27 @@ namespace adaflo_hip
           dst_c[idx] = v;
       };
 
+      // advection from the nodal velocity: this lane's cell within the velocity patch of the tile, 1D shape values of the
+      // velocity space at its two Gauss points per direction (as q1_rhs_kernel)
+      const int wn = A.wn;
+      int       vx0 = 0, vy0 = 0, ix0 = 0, jy0 = 0;
+      double    Sx[2][KU + 1], Sy[2][KU + 1];
+      if (NODALV)
+        {
+          const int x = min(I0 + sx, A.nsx - 1), y = min(J0 + sy, A.nsy - 1);
+          vx0 = KU * (I0 / A.sub);
+          vy0 = KU * (J0 / A.sub);
+          ix0 = KU * (x / A.sub) - vx0;
+          jy0 = KU * (y / A.sub) - vy0;
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int i = 0; i <= KU; ++i)
+              {
+                Sx[a][i] = A.svel[(2 * (x % A.sub) + a) * (KU + 1) + i];
+                Sy[a][i] = A.svel[(2 * (y % A.sub) + a) * (KU + 1) + i];
+              }
+        }
       double carry[4] = {0., 0., 0., 0.}; // top-plane sums of the owned nodes, kept for the next layer
       load_plane(cz0, pl[cz0 & 1]);
       const double2 *state = reinterpret_cast<const double2 *>(A.state);
@@ -162,12 +188,35 @@ namespace adaflo_hip
               for (int q = 0; q < 27; ++q)
                 cf[q] = cp[q * NTQ];
             }
-          else if (MODE != Q1_MASS_LAPLACE && !NODAL)
+          else if (MODE != Q1_MASS_LAPLACE && !NODAL && !NODALV)
             {
               const double2 *sp = state + ((size_t)bt * A.nsz + cz) * (12 * NTQ) + tid;
 #pragma unroll
               for (int c = 0; c < 12; ++c)
                 st[c] = sp[c * NTQ];
+            }
+          if (NODALV)
+            {
+              // velocity interpolated in z to the two Gauss planes of this layer, on the node patch of the tile (the last
+              // barrier of the previous layer is behind every read of W)
+              const int     kc = cz / A.sub, zl = cz % A.sub;
+              const double *sz = A.svel + 2 * zl * (KU + 1);
+              for (int e = tid; e < 3 * wn * wn; e += NTQ)
+                {
+                  const int comp = e % 3, ix = (e / 3) % wn, jy = e / (3 * wn);
+                  const int I = vx0 + ix, J = vy0 + jy;
+                  double    w0 = 0., w1 = 0.;
+                  if (I < A.vnx && J < A.vny)
+#pragma unroll
+                    for (int k = 0; k <= KU; ++k)
+                      {
+                        const double v = A.state[(((size_t)(KU * kc + k) * A.vny + J) * A.vnx + I) * 3 + comp];
+                        w0 += sz[k] * v;
+                        w1 += sz[KU + 1 + k] * v;
+                      }
+                  W[(comp * wn + jy) * wn + ix]       = w0;
+                  W[((3 + comp) * wn + jy) * wn + ix] = w1;
+                }
             }
           __syncthreads();
 
@@ -376,6 +425,43 @@ namespace adaflo_hip
                   nq[3 * q] = n0 * sc, nq[3 * q + 1] = n1 * sc, nq[3 * q + 2] = n2 * sc;
                 }
             }
+          // ---- velocity at the 8 Gauss points from the z-interpolated node patch (level_set_okz_advance_concentration.cc:389)
+          double vq[NODALV ? 24 : 1];
+          if (NODALV)
+            {
+#pragma unroll
+              for (int qz = 0; qz < 2; ++qz)
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+                  {
+                    const double *w = W + ((3 * qz + e) * wn + jy0) * wn + ix0;
+                    double        tx[2][KU + 1];
+#pragma unroll
+                    for (int j = 0; j <= KU; ++j)
+                      {
+                        double a0 = 0., a1 = 0.;
+#pragma unroll
+                        for (int i = 0; i <= KU; ++i)
+                          {
+                            const double v = w[j * wn + i];
+                            a0 += Sx[0][i] * v;
+                            a1 += Sx[1][i] * v;
+                          }
+                        tx[0][j] = a0, tx[1][j] = a1;
+                      }
+#pragma unroll
+                    for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+                      for (int qx = 0; qx < 2; ++qx)
+                        {
+                          double a = 0.;
+#pragma unroll
+                          for (int j = 0; j <= KU; ++j)
+                            a += Sy[qy][j] * tx[qx][j];
+                          vq[NODALV ? 3 * (qx + 2 * qy + 4 * qz) + e : 0] = a;
+                        }
+                  }
+            }
           // ---- quadrature-point operation -------------------------------------------------------
           double tv[2][2][2], t0[2][2][2], t1[2][2][2], t2[2][2][2];
 #pragma unroll
@@ -398,10 +484,10 @@ namespace adaflo_hip
                   else
                     {
                       // state element 3q+e of this lane: double2 index (3q+e)/2, component (3q+e)&1
-                      const double s0 = NODAL ? nq[NODAL ? 3 * q : 0] : ((3 * q) & 1 ? st[(3 * q) / 2].y : st[(3 * q) / 2].x);
-                      const double s1 = NODAL ? nq[NODAL ? 3 * q + 1 : 0] : ((3 * q + 1) & 1 ? st[(3 * q + 1) / 2].y : st[(3 * q + 1) / 2].x);
-                      const double s2 = NODAL ? nq[NODAL ? 3 * q + 2 : 0] : ((3 * q + 2) & 1 ? st[(3 * q + 2) / 2].y : st[(3 * q + 2) / 2].x);
-                      if (MODE == Q1_ADVECT) // level_set_okz_advance_concentration.cc:244-249
+                      const double s0 = NODALV ? vq[NODALV ? 3 * q : 0] : (NODAL ? nq[NODAL ? 3 * q : 0] : ((3 * q) & 1 ? st[(3 * q) / 2].y : st[(3 * q) / 2].x));
+                      const double s1 = NODALV ? vq[NODALV ? 3 * q + 1 : 0] : (NODAL ? nq[NODAL ? 3 * q + 1 : 0] : ((3 * q + 1) & 1 ? st[(3 * q + 1) / 2].y : st[(3 * q + 1) / 2].x));
+                      const double s2 = NODALV ? vq[NODALV ? 3 * q + 2 : 0] : (NODAL ? nq[NODAL ? 3 * q + 2 : 0] : ((3 * q + 2) & 1 ? st[(3 * q + 2) / 2].y : st[(3 * q + 2) / 2].x));
+                      if (MODE == Q1_ADVECT || NODALV) // level_set_okz_advance_concentration.cc:244-249
                         a = A.weight * v + s0 * g0 + s1 * g1 + s2 * g2;
                       else // Q1_REINIT: level_set_okz_reinitialization.cc:88-95
                         {
@@ -656,7 +742,8 @@ namespace adaflo_hip
       const double *f[4];   // nodal fields staged per plane (reinit: phi, n_0..n_2; advect: phi, phi_old, phi_old_old)
       int           nf, flag, sub; // reinit: bit 0 diffuse_only, bit 1 first step; advect: use_old_old
       double        diffusion, weight, weight_old, weight_old_old;
-      double       *state;  // [tile][layer][12][256][2]
+      double       *state;  // [tile][layer][12][256][2]; advection: nullptr = evaluated_convection is not written
+      int           state_only; // advection: write `state` and nothing else (no fields staged, no sums)
       const double *vel, *svel; // velocity [node][3]; svel[q (2 sub)][KU + 1]
       int           vnx, vny, wn; // velocity nodes in x, y; edge of the velocity patch of a tile
     };
@@ -877,7 +964,7 @@ namespace adaflo_hip
           for (int n = 0; n < 4; ++n)
             {
               dold[n] = 0.;
-              if ((own & ~con & ~seam) >> n & 1u)
+              if (((own & ~con & ~seam) >> n & 1u) && !R.state_only)
                 dold[n] = A.dst[(size_t)cz * A.nny * A.nnx + lane_g + (unsigned)((n >> 1) * A.nnx + (n & 1))];
             }
           double2  st[12];
@@ -1001,9 +1088,15 @@ namespace adaflo_hip
                           el[3 * (qx + 2 * qy + 4 * qz) + e] = a;
                         }
                   }
+              if (R.state)
 #pragma unroll
-              for (int c = 0; c < 12; ++c)
-                sp[c * NTQ] = make_double2(el[2 * c], el[2 * c + 1]); // :389 evaluated_convection
+                for (int c = 0; c < 12; ++c)
+                  sp[c * NTQ] = make_double2(el[2 * c], el[2 * c + 1]); // :389 evaluated_convection
+              if (R.state_only)
+                {
+                  __syncthreads(); // (W is overwritten at the top of the next layer)
+                  continue;
+                }
               double vo[2][2][2], voo[2][2][2], dx[2][2], dy[2][2], dz[2][2];
               nodal(cz, 1, u);
               q1_evaluate(u, A.ga, A.gb, A.ih, vo, dx, dy, dz);
@@ -1066,13 +1159,14 @@ namespace adaflo_hip
             }
           __syncthreads();
         }
-      {
-        const int  cze  = cz0 + nl;
-        const bool ztop = cze < A.nsz, zcon = cze == A.nnz - 1 && conz_hi;
+      if (!(MODE == Q1RHS_ADVECT && R.state_only))
+        {
+          const int  cze  = cz0 + nl;
+          const bool ztop = cze < A.nsz, zcon = cze == A.nnz - 1 && conz_hi;
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
-          emit(n, n & 1, n >> 1, cze, nl, carry[n], zcon, ztop, false);
-      }
+          for (int n = 0; n < 4; ++n)
+            emit(n, n & 1, n >> 1, cze, nl, carry[n], zcon, ztop, false);
+        }
     }
   } // namespace
 
@@ -1627,6 +1721,14 @@ namespace adaflo_hip
     return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
   }
 
+  // the advection operator can evaluate the velocity itself when the patch of a tile fits (as the right-hand side kernel)
+  bool q1_advect_nodal_supported(const adaflo_ctx *ctx)
+  {
+    const int    k = ctx->k, sub = ctx->s, wn = k * ((TS + sub - 2) / sub + 1) + 1;
+    const size_t lds = sizeof(double) * 6 * (size_t)wn * wn;
+    return k >= 2 && k <= 4 && !ctx->flat && lds <= 48 * 1024;
+  }
+
   // sub = subdivisions of a cell (level set: s, pressure: 1); mode/coefficients as Q1Args
   int launch_q1_sweep(adaflo_ctx *ctx, const int sub, const int mode, const double c_mass,
                       const double c_lap, const double weight, const uint32_t con, const double con_sign,
@@ -1669,6 +1771,41 @@ namespace adaflo_hip
         case Q1_REINIT_NODAL:
           hipLaunchKernelGGL((q1_sweep_kernel<Q1_REINIT_NODAL>), grid, block, 0, ctx->stream, A);
           break;
+        case Q1_ADVECT_NODAL:
+          {
+            const int k = ctx->k;
+            A.sub  = sub;
+            A.svel = ctx->d_tab_ls + 2 * (2 * sub) * (sub + 1) + 2 * sub;
+            A.vnx  = k * ctx->desc.ncell[0] + 1;
+            A.vny  = k * ctx->desc.ncell[1] + 1;
+            A.wn   = k * ((TS + sub - 2) / sub + 1) + 1;
+            const size_t lds = sizeof(double) * 6 * (size_t)A.wn * A.wn;
+            if (!q1_advect_nodal_supported(ctx))
+              return ADAFLO_EUNSUPPORTED;
+            hipError_t err = hipSuccess;
+#define ADVN(KU)                                                                                              \
+  {                                                                                                           \
+    if (lds > 40 * 1024)                                                                                      \
+      err = hipFuncSetAttribute(reinterpret_cast<const void *>(&q1_sweep_kernel<Q1_ADVECT_NODAL, KU>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+    hipLaunchKernelGGL((q1_sweep_kernel<Q1_ADVECT_NODAL, KU>), grid, block, lds, ctx->stream, A);             \
+  }
+            switch (k)
+              {
+                case 2:
+                  ADVN(2);
+                  break;
+                case 3:
+                  ADVN(3);
+                  break;
+                default:
+                  ADVN(4);
+              }
+#undef ADVN
+            if (err != hipSuccess)
+              return ADAFLO_EHIP;
+            break;
+          }
         default:
           hipLaunchKernelGGL((q1_sweep_kernel<Q1_REINIT>), grid, block, 0, ctx->stream, A);
       }
@@ -1721,7 +1858,7 @@ namespace adaflo_hip
   // by the advection, read otherwise).  Returns ADAFLO_EUNSUPPORTED when the velocity patch of a tile does
   // not fit into LDS (the caller then takes the generic kernels).
   int launch_q1_rhs(adaflo_ctx *ctx, const int kind, const int flag, double *dst, const double *f0, const double *f1,
-                    const double *f2, const double *f3, const double *vel, double *state)
+                    const double *f2, const double *f3, const double *vel, double *state, const bool state_only)
   {
     Q1RhsArgs R{};
     const int sub = ctx->s, k = ctx->k;
@@ -1762,8 +1899,9 @@ namespace adaflo_hip
       }
     else
       {
-        R.nf   = flag ? 3 : 2;
-        R.vel  = vel;
+        R.nf         = state_only ? 0 : (flag ? 3 : 2);
+        R.state_only = state_only;
+        R.vel        = vel;
         R.svel = ctx->d_tab_ls + 2 * (2 * sub) * (sub + 1) + 2 * sub;
         R.vnx  = k * ctx->desc.ncell[0] + 1;
         R.vny  = k * ctx->desc.ncell[1] + 1;
@@ -1800,7 +1938,8 @@ namespace adaflo_hip
     long       nb    = n1 + n2;
     if (nb > 256 * 512)
       nb = 256 * 512;
-    hipLaunchKernelGGL(q1_fixup_kernel, dim3((unsigned)nb, 1u), dim3(64), 0, ctx->stream, R.q, n1, n2);
+    if (!state_only)
+      hipLaunchKernelGGL(q1_fixup_kernel, dim3((unsigned)nb, 1u), dim3(64), 0, ctx->stream, R.q, n1, n2);
     return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
   }
 } // namespace adaflo_hip

@@ -157,13 +157,24 @@ def ls_case(s, ncell, only=None):
     nrm = ops_v.vector(rng.uniform(-1, 1, 3 * ops_v.n_dofs), blocks=3)
     sync_v = lambda: adaflo_amd._lib.load().adaflo_synchronize(ops_v._ctx)
     nodal = 8 * s ** 3          # bytes per cell of one nodal field
-    rhs_cases = [("ls_advect_rhs", lambda: adv_v.local_advance_concentration_rhs(rhs, phi, old, oo, vel, True), 5 * nodal + 24 * nq + 3 * 8 * 8),
+    # (the advection right-hand side of the sweep structure no longer writes evaluated_convection: 24 nq less)
+    rhs_cases = [("ls_advect_rhs", lambda: adv_v.local_advance_concentration_rhs(rhs, phi, old, oo, vel, True), 5 * nodal + 3 * 8 * 8),
                  ("ls_reinit_rhs_first", lambda: rei_v.local_reinitialize_rhs(rhs, phi, nrm, False, True), 6 * nodal + 24 * nq),
                  ("ls_reinit_rhs", lambda: rei_v.local_reinitialize_rhs(rhs, phi, nrm, False, False), 3 * nodal + 24 * nq),
                  ("ls_reinit_rhs_diffuse", lambda: rei_v.local_reinitialize_rhs(rhs, phi, nrm, True, False), 3 * nodal)]
     if only is not None:
         cases = [c for c in cases if c[0] in only]
         rhs_cases = [c for c in rhs_cases if c[0] in only]
+    # the advection operator right after a sweep right-hand side: the velocity is evaluated from the nodal field the
+    # engine kept (Q1_ADVECT_NODAL); algorithmic bytes: two nodal fields + the velocity nodes of a cell
+    if only is None or "ls_advect_vmult_nodal" in only:
+        ops_v.set_kernel_variant(1)
+        adv_v.local_advance_concentration_rhs(rhs, phi, old, oo, vel, True)
+        t = timeit(lambda: adv_v.advance_concentration_vmult(rhs, phi), sync_v)
+        b = 2 * nodal + 3 * 8 * 8
+        print(json.dumps({"op": "ls_advect_vmult_nodal", "s": s, "cells": list(ncell), "ms": round(t * 1e3, 4),
+                          "MDoF/s": round(ops_v.n_dofs / t / 1e6, 1), "alg_GB/s": round(b * ncells / t / 1e9, 1),
+                          "frac_of_8TB/s": round(b * ncells / t / 8e12, 4)}), flush=True)
     for variant in (1, 0):
         ops_v.set_kernel_variant(variant)
         for name, fn, bytes_per_cell in rhs_cases:

@@ -156,6 +156,51 @@ def test_reinitialization_vmult_recomputes_the_normal_from_the_nodal_field(s, nc
     assert rel_l2(d.numpy(), got_nodal) < 1e-13
 
 
+@pytest.mark.parametrize("s,k,ncell,faces", [(4, 2, (5, 4, 3), ()), (3, 2, (7, 6, 5), (0, 3)), (2, 3, (9, 5, 6), ()), (4, 4, (5, 3, 2), (4, 5)),
+                                             (1, 2, (20, 18, 9), (1,)), (2, 2, (1, 1, 1), ())])
+def test_advection_vmult_evaluates_the_velocity_from_the_nodal_field(s, k, ncell, faces, monkeypatch):
+    """after an advection rhs on the sweep structure the engine keeps the nodal velocity instead of writing
+    evaluated_convection (192 B per sub-cell) and the advection vmult evaluates the FE_Q(k) velocity at the Gauss points
+    itself (Q1_ADVECT_NODAL, csrc/q1_sweep.hip): same result as the oracle fed with the evaluated_convection of ITS rhs,
+    as the streaming kernel (ADAFLO_LS_STREAM_CONVECTION: the rhs writes the array, the operator streams it), and as the
+    streaming kernel on the array the engine materialises on demand"""
+    c = LSCase(ncell, s, k=k, faces=faces)
+    c.ops.set_kernel_variant(1)
+    adv = lso.LevelSetOKZSolverAdvanceConcentration(c.ops)
+    phi, old, oldold = c.rand(), c.rand(), c.rand()
+    vel = c.rng.uniform(-1, 1, c.mesh.n_nodes(k) * 3)
+    uq_ref = np.zeros(c.mesh.n_cells * c.nq * 3)
+    ref_rhs = orc.ls_advect_rhs(c.mesh, c.prm, k, phi, old, oldold, vel, uq_ref, c.w_old, c.w_oo, True, con=c.con)
+    src = c.rand()
+    ref = orc.ls_advect_vmult(c.mesh, c.prm, src, uq_ref, con=c.con, diag=c.diag if faces else None)
+
+    def rhs_then_vmult():
+        d = c.ops.vector()
+        vv = c.ops.velocity_vector(vel)
+        adv.local_advance_concentration_rhs(d, c.ops.vector(phi), c.ops.vector(old), c.ops.vector(oldold), vv, True)
+        assert rel_l2(d.numpy(), ref_rhs) < TOL
+        del vv                                                # (the engine keeps its own copy of the velocity)
+        junk = c.ops.velocity_vector(np.full_like(vel, 1e30))  # (likely the same device memory)
+        out = c.ops.vector(np.full(c.nn, 7.0))
+        adv.advance_concentration_vmult(out, c.ops.vector(src))
+        del junk
+        return out.numpy().copy()
+    got_nodal = rhs_then_vmult()
+    assert rel_l2(got_nodal, ref) < TOL
+    monkeypatch.setenv("ADAFLO_LS_STREAM_CONVECTION", "1")
+    got_stream = rhs_then_vmult()
+    monkeypatch.delenv("ADAFLO_LS_STREAM_CONVECTION")
+    assert rel_l2(got_stream, ref) < TOL and rel_l2(got_nodal, got_stream) < 1e-13
+    # the quadrature-point array on demand (written from the kept velocity), then set explicitly: streaming kernel
+    rhs_then_vmult()
+    uq = np.array(adv.evaluated_convection)
+    assert rel_l2(uq, uq_ref) < TOL
+    adv.evaluated_convection = uq
+    out = c.ops.vector()
+    adv.advance_concentration_vmult(out, c.ops.vector(src))
+    assert rel_l2(out.numpy(), got_nodal) < 1e-13
+
+
 @pytest.mark.parametrize("s,k,ncell,faces", [(3, 2, (7, 6, 5), ()), (3, 3, (6, 7, 3), (1, 2)), (4, 4, (5, 3, 2), ()),
                                              (1, 3, (18, 17, 6), (0,)), (2, 4, (9, 2, 3), (4, 5)),
                                              # velocity degree 5 (level_set_okz_template_instantations.h: 2 .. 5): generic kernels
