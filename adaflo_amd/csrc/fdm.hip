@@ -44,9 +44,9 @@ namespace adaflo_hip
       // onto each other: two products of half the size instead of one, half the flops (fdm_apply).
       bool sym = false;
       int  n_even = 0; // number of even modes (they come first)
-      // degree 1, natural ends, n - 1 = 2^log2n intervals: the eigenvectors are sqrt(a2[k]) cos(pi j k / (n - 1)) and the
+      // degree 1, natural ends, n - 1 = 2^m or 5 2^m intervals: the eigenvectors are sqrt(a2[k]) cos(pi j k / (n - 1)) and the
       // transforms run as fast cosine transforms (fdm_dct_kernel.hpp); modes in natural order k = 0 .. n - 1 there
-      int     log2n = 0;         // 0: not available
+      int     nfft = 0;          // n - 1; 0: not available
       double *d_tw  = nullptr;   // [n][2]: exp(-i pi m / (n - 1))
       double *d_a2  = nullptr;   // squared normalisation of mode k
       double *d_lamn = nullptr;  // eigenvalue of mode k
@@ -500,21 +500,21 @@ namespace adaflo_hip
     }
 
     // ---- fast cosine transforms (fdm_dct_kernel.hpp) -----------------------------------------------------------
-    template <int LOG2N, bool FUSED, int AXIS>
+    template <int N, bool FUSED, int AXIS>
     __global__ __launch_bounds__(dct::NT, 2) void fdm_dct_kernel(const dct::DctArgs A) // (two workgroups per CU: 256 registers)
     {
       extern __shared__ double dct_lds[];
-      dct::dct_body<LOG2N, FUSED, AXIS>(A, dct_lds);
+      dct::dct_body<N, FUSED, AXIS>(A, dct_lds);
     }
-    template <int LOG2N, bool FUSED, int AXIS>
+    template <int N, bool FUSED, int AXIS>
     int launch_dct_t(adaflo_ctx *ctx, const dct::DctArgs &A)
     {
-      using G            = dct::Geo<LOG2N>;
+      using G            = dct::Geo<N>;
       const size_t lds   = sizeof(double) * G::L_TOTAL;
       static bool  attr_set = false;
       if (!attr_set)
         {
-          if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fdm_dct_kernel<LOG2N, FUSED, AXIS>),
+          if (hipFuncSetAttribute(reinterpret_cast<const void *>(&fdm_dct_kernel<N, FUSED, AXIS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return ADAFLO_EHIP;
           attr_set = true;
@@ -529,32 +529,35 @@ namespace adaflo_hip
           resident = std::max(1, cus) * std::max(1, (int)((160 * 1024) / lds));
         }
       const long nb = std::min<long>((A.n_lines + G::LB - 1) / G::LB, resident);
-      hipLaunchKernelGGL((fdm_dct_kernel<LOG2N, FUSED, AXIS>), dim3((unsigned)nb), dim3(dct::NT), lds, ctx->stream, A);
+      hipLaunchKernelGGL((fdm_dct_kernel<N, FUSED, AXIS>), dim3((unsigned)nb), dim3(dct::NT), lds, ctx->stream, A);
       return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
     }
-    template <int LOG2N>
+    template <int N>
     int launch_dct_n(adaflo_ctx *ctx, const bool fused, const dct::DctArgs &A)
     {
       if (fused)
-        return launch_dct_t<LOG2N, true, 2>(ctx, A);
+        return launch_dct_t<N, true, 2>(ctx, A);
       if (A.axis == 0)
-        return launch_dct_t<LOG2N, false, 0>(ctx, A);
-      return A.axis == 1 ? launch_dct_t<LOG2N, false, 1>(ctx, A) : launch_dct_t<LOG2N, false, 2>(ctx, A);
+        return launch_dct_t<N, false, 0>(ctx, A);
+      return A.axis == 1 ? launch_dct_t<N, false, 1>(ctx, A) : launch_dct_t<N, false, 2>(ctx, A);
     }
-    int launch_dct(adaflo_ctx *ctx, const int log2n, const bool fused, const dct::DctArgs &A)
+    int launch_dct(adaflo_ctx *ctx, const int nfft, const bool fused, const dct::DctArgs &A)
     {
-      switch (log2n)
+      switch (nfft)
         {
-          case 6:
-            return launch_dct_n<6>(ctx, fused, A);
-          case 7:
-            return launch_dct_n<7>(ctx, fused, A);
-          case 8:
-            return launch_dct_n<8>(ctx, fused, A);
-          case 9:
-            return launch_dct_n<9>(ctx, fused, A);
-          case 10:
-            return launch_dct_n<10>(ctx, fused, A);
+#define DCT_CASE(N_) \
+  case N_:           \
+    return launch_dct_n<N_>(ctx, fused, A);
+          DCT_CASE(64)
+          DCT_CASE(128)
+          DCT_CASE(256)
+          DCT_CASE(512)
+          DCT_CASE(1024)
+          DCT_CASE(80)
+          DCT_CASE(160)
+          DCT_CASE(320)
+          DCT_CASE(640)
+#undef DCT_CASE
         }
       return ADAFLO_EINVAL;
     }
@@ -701,10 +704,7 @@ namespace adaflo_hip
                   generalized_eig(n, K, M, con, S, lam);
                 }
               Eig1D E;
-              int   log2n = 0;
-              while ((1 << log2n) < n - 1)
-                ++log2n;
-              if (fd.degree == 1 && !lo && !hi && (1 << log2n) == n - 1 && log2n >= 6 && log2n <= 10)
+              if (fd.degree == 1 && !lo && !hi && dct::dct_length_supported(n - 1))
                 {
                   // natural order of the modes here (upload_eig reorders its copy by symmetry)
                   std::vector<double> tw(2 * (size_t)n);
@@ -720,7 +720,7 @@ namespace adaflo_hip
                       copy_to_device_now(E.d_a2, norm2.data(), sizeof(double) * n) != hipSuccess ||
                       copy_to_device_now(E.d_lamn, lam.data(), sizeof(double) * n) != hipSuccess)
                     return ADAFLO_EHIP;
-                  E.log2n = log2n;
+                  E.nfft = n - 1;
                 }
               if (int e = upload_eig(E, n, S, lam))
                 return e;
@@ -876,7 +876,7 @@ namespace adaflo_hip
         const Eig1D &ex = fd.e[0][0], &ey = fd.e[0][1], &ez = fd.e[0][2];
         double      *B = F->w1, *Cb = F->w0;
         const bool no_dct = getenv("ADAFLO_FDM_NO_DCT") != nullptr; // (tests / timing of the matrix products; read per call)
-        if (mask == 0u && ex.log2n && ey.log2n && ez.log2n && !no_dct)
+        if (mask == 0u && ex.nfft && ey.nfft && ez.nfft && !no_dct)
           {
             // cosine modes in all directions: x, y forward, z forward + scaling + z back in one pass, y, x back
             // (the intermediate arrays have rows padded to 16 doubles: aligned runs in the strided passes)
@@ -894,7 +894,7 @@ namespace adaflo_hip
                 A.in = in[pass], A.out = out[pass], A.tw = E.d_tw, A.axis = axis[pass];
                 A.pitch_in = pass == 0 ? nx : P, A.pitch_out = pass == 4 ? nx : P;
                 A.n_lines = axis[pass] == 0 ? (long)ny * nz : (axis[pass] == 1 ? (long)P * nz : (long)P * ny);
-                if (int e = launch_dct(ctx, E.log2n, pass == 2, A))
+                if (int e = launch_dct(ctx, E.nfft, pass == 2, A))
                   return e;
               }
             return 0;

@@ -3,15 +3,16 @@
 // On a uniform grid with natural ends the generalised eigenvectors of the 1D pair (K, M) of FE_Q(1) are
 // v_k(j) = cos(pi j k / N), j, k = 0 .. N (fdm.hip: linear_eig), so nodes -> modes and modes -> nodes are both the
 // plain cosine sum  y_k = sum_{j = 0}^{N} cos(pi j k / N) x_j  (DCT-I without the customary half weights at the ends)
-// followed / preceded by a scaling.  For N a power of two this kernel computes it in O(N log N) instead of the
+// followed / preceded by a scaling.  For N = 2^m or 5 2^m this kernel computes it in O(N log N) instead of the
 // (N + 1)^2 of the matrix product:
 //   e = even extension of x to length 2N;  z_j = e_{2j} + i e_{2j+1}, j = 0 .. N-1;  Z = FFT_N(z)
 //   E_k = (Z_k + conj Z_{N-k}) / 2 + w^k (Z_k - conj Z_{N-k}) / (2i),  w = exp(-i pi / N)   (real: e is real and even)
 //   y_k = (E_k + x_0 + (-1)^k x_N) / 2
-// The FFT is an in-place decimation-in-frequency transform in LDS, radix 4 (one radix-2 stage at the end if log2 N is
-// odd); its result stays in digit-reversed order and the step that forms E reads Z_k where it lies.
+// The FFT is an in-place decimation-in-frequency transform in LDS: a radix-5 stage if 5 divides N, then radix 4 (two
+// stages per LDS round trip, one radix-2 stage at the end if needed); its result stays in digit-reversed order and the
+// step that forms E reads Z_k where it lies.
 //
-// A workgroup of 256 threads transforms LB = 4096 / N lines at once (68 KB of complex numbers, two stages per LDS round
+// A workgroup of 256 threads transforms LB = 4096 / N (rounded down) lines at once (68 KB of complex numbers, two stages per LDS round
 // trip).  Lines are contiguous (axis 0), strided by the row pitch (axis 1: line = x + pitch z) or by pitch ny (axis 2:
 // line = x + pitch y); the strided passes read and write LB neighbouring lines as runs of LB consecutive doubles.  The z
 // pass can be FUSED: forward transform, the scaling of the mode coefficients 1 / (c_m + c_l (lx + ly + lz)) times the
@@ -55,22 +56,34 @@ namespace adaflo_hip
       double        cm, cl, eps;
     };
 
-    template <int LOG2N>
+    // N = F 2^m intervals per line, F = 1 or 5 (the reference's meshes are 5 x 10 coarse cells refined: 5 2^m), 2^m >= 16:
+    // an optional radix-5 stage, then radix-4 stages in pairs, then what is left (radix 4, radix 2)
+    constexpr bool dct_length_supported(const int N)
+    {
+      const int M = N % 5 == 0 ? N / 5 : N;
+      return N >= 64 && N <= 1024 && M >= 16 && (M & (M - 1)) == 0;
+    }
+    template <int N_>
     struct Geo
     {
-      static constexpr int N = 1 << LOG2N, n = N + 1, LB = NCPLX / N;
-      static constexpr int n_r4 = LOG2N / 2, n_stages = n_r4 + (LOG2N & 1);
-      static_assert(LOG2N >= 6 && LOG2N <= 10, "64 .. 1024 intervals per line");
+      static constexpr int N = N_, n = N + 1, F = N % 5 == 0 ? 5 : 1, M = N / F;
+      static_assert(dct_length_supported(N), "N = 2^m or 5 2^m, 64 <= N <= 1024, 2^m >= 16");
+      static constexpr int log2(const int v) { return v <= 1 ? 0 : 1 + log2(v / 2); }
+      static constexpr int LOG2M = log2(M), n_r4 = LOG2M / 2, n_stages = n_r4 + (LOG2M & 1); // stages of the length-M part
+      // a thread serves one line: TPL threads per line, LB lines per batch, LB TPL <= NT threads are active
+      static constexpr int TPL = N / 16, LB = NT / TPL, NACT = LB * TPL, ZC = LB * N;
+      static_assert(N % 16 == 0 && ZC <= NCPLX && LB >= 1, "batch");
       // LDS, in doubles: Z (one complex number of padding behind every 16: the strides 16, 64, ... of the later stages and
       // of the digit-reversed reads would otherwise fall on one bank; the raw lines R[LB][n] overlay its start), twiddles,
       // (x_0 + x_N, x_0 - x_N) of every line, (lx + ly, ax ay) of every line (fused pass)
-      static constexpr int L_Z = 0, L_T = 2 * (NCPLX + NCPLX / 16), L_E = L_T + 2 * (N + 1), L_F = L_E + 2 * LB, L_DUMP = L_F + 2 * LB, L_TOTAL = L_DUMP + 2;
-      static_assert(LB * n <= 2 * NCPLX, "raw overlay");
+      static constexpr int L_Z = 0, L_T = 2 * (ZC + ZC / 16 + 1), L_E = L_T + 2 * (N + 1), L_F = L_E + 2 * LB, L_DUMP = L_F + 2 * LB,
+                           L_TOTAL = L_DUMP + 2;
+      static_assert(LB * n <= 2 * ZC, "raw overlay");
       static __device__ __forceinline__ constexpr int pad(const int i) { return i + (i >> 4); }
-      // where X[k] lies after the stages (digit reversal of the mixed radix 4, 4, ..., [2])
-      static __device__ __forceinline__ constexpr int pos_of(int k)
+      // where X[k] lies after the stages (digit reversal of the mixed radix [5], 4, 4, ..., [2])
+      static __device__ __forceinline__ constexpr int pos_of_m(int k) // the length-M part
       {
-        int p = 0, span = N;
+        int p = 0, span = M;
         for (int s = 0; s < n_stages; ++s)
           {
             const int r = s < n_r4 ? 4 : 2;
@@ -79,6 +92,10 @@ namespace adaflo_hip
             k /= r;
           }
         return p;
+      }
+      static __device__ __forceinline__ constexpr int pos_of(const int k)
+      {
+        return F == 1 ? pos_of_m(k) : (k % F) * M + pos_of_m(k / F);
       }
     };
 
@@ -182,18 +199,35 @@ namespace adaflo_hip
         }
     }
 
-    // stages S, S + 1 (radix 4 x 4), in place in Z
-    template <int LOG2N, int S>
+    // radix-5 butterfly of the forward transform, twiddles not applied
+    __device__ __forceinline__ void radix5(cplx (&a)[5])
+    {
+      constexpr double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410; // cos(2 pi / 5), cos(4 pi / 5)
+      constexpr double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;  // sin(2 pi / 5), sin(4 pi / 5)
+      const cplx t1{a[1].re + a[4].re, a[1].im + a[4].im}, t2{a[2].re + a[3].re, a[2].im + a[3].im};
+      const cplx d1{a[1].re - a[4].re, a[1].im - a[4].im}, d2{a[2].re - a[3].re, a[2].im - a[3].im};
+      const cplx m1{a[0].re + c1 * t1.re + c2 * t2.re, a[0].im + c1 * t1.im + c2 * t2.im};
+      const cplx m2{a[0].re + c2 * t1.re + c1 * t2.re, a[0].im + c2 * t1.im + c1 * t2.im};
+      // -i (s1 d1 + s2 d2) and -i (s2 d1 - s1 d2)
+      const cplx n1{s1 * d1.im + s2 * d2.im, -(s1 * d1.re + s2 * d2.re)}, n2{s2 * d1.im - s1 * d2.im, -(s2 * d1.re - s1 * d2.re)};
+      a[0] = cplx{a[0].re + t1.re + t2.re, a[0].im + t1.im + t2.im};
+      a[1] = cplx{m1.re + n1.re, m1.im + n1.im};
+      a[4] = cplx{m1.re - n1.re, m1.im - n1.im};
+      a[2] = cplx{m2.re + n2.re, m2.im + n2.im};
+      a[3] = cplx{m2.re - n2.re, m2.im - n2.im};
+    }
+
+    // stages S, S + 1 (radix 4 x 4) of the length-M part, in place in Z
+    template <int N, int S>
     __device__ __forceinline__ void fft_double_stage(cplx *Z, const cplx *T)
     {
-      using G         = Geo<LOG2N>;
-      constexpr int N = G::N, L = N >> (2 * S);
+      using G         = Geo<N>;
+      constexpr int L = G::M >> (2 * S);
       static_assert(L >= 16, "two radix-4 stages");
       const int t = threadIdx.x;
-#pragma unroll
-      for (int i = 0; i < NCPLX / 16 / NT; ++i)
+      if (G::ZC / 16 == NT || t < G::ZC / 16) // (one 16-point group per thread)
         {
-          const int b = t + NT * i, line = b >> (LOG2N - 4), r = b & (N / 16 - 1);
+          const int line = t / (N / 16), r = t - line * (N / 16);
           const int j = r & (L / 16 - 1), base = line * N + (r / (L / 16)) * L + j;
           cplx      a[4][4];
 #pragma unroll
@@ -210,94 +244,94 @@ namespace adaflo_hip
         }
       __syncthreads();
     }
-    // one radix-4 stage S, or the radix-2 stage at the end (S = n_r4), in place in Z
-    template <int LOG2N, int S>
+    // one radix-4 stage S of the length-M part, or the radix-2 stage at its end (S = n_r4), in place in Z
+    template <int N, int S>
     __device__ __forceinline__ void fft_stage(cplx *Z, const cplx *T)
     {
-      using G         = Geo<LOG2N>;
-      constexpr int N = G::N;
-      constexpr int L = N >> (2 * S); // length of the sub-transforms this stage splits
+      using G         = Geo<N>;
+      constexpr int L = G::M >> (2 * S); // length of the sub-transforms this stage splits
       const int     t = threadIdx.x;
       if constexpr (S < G::n_r4)
         {
+          constexpr int NB = G::ZC / 4;
 #pragma unroll
-          for (int i = 0; i < NCPLX / 4 / NT; ++i)
+          for (int i = 0; i < (NB + NT - 1) / NT; ++i)
             {
-              const int b = t + NT * i, line = b >> (LOG2N - 2), r = b & (N / 4 - 1);
-              const int j = r & (L / 4 - 1), base = line * N + (r / (L / 4)) * L + j;
-              cplx      a[4];
-#pragma unroll
-              for (int p = 0; p < 4; ++p)
-                a[p] = Z[G::pad(base + p * (L / 4))];
-              radix4(a[0], a[1], a[2], a[3]);
-              if (L > 4)
+              const int b = t + NT * i;
+              if (NB % NT == 0 || b < NB)
                 {
-                  const int m = j * (N / L);
+                  const int line = b / (N / 4), r = b - line * (N / 4);
+                  const int j = r & (L / 4 - 1), base = line * N + (r / (L / 4)) * L + j;
+                  cplx      a[4];
 #pragma unroll
-                  for (int q = 1; q < 4; ++q)
-                    a[q] = cmul(a[q], twiddle<N>(T, q * m));
+                  for (int p = 0; p < 4; ++p)
+                    a[p] = Z[G::pad(base + p * (L / 4))];
+                  radix4(a[0], a[1], a[2], a[3]);
+                  if (L > 4)
+                    {
+                      const int m = j * (N / L);
+#pragma unroll
+                      for (int q = 1; q < 4; ++q)
+                        a[q] = cmul(a[q], twiddle<N>(T, q * m));
+                    }
+#pragma unroll
+                  for (int p = 0; p < 4; ++p)
+                    Z[G::pad(base + p * (L / 4))] = a[p];
                 }
-#pragma unroll
-              for (int p = 0; p < 4; ++p)
-                Z[G::pad(base + p * (L / 4))] = a[p];
             }
         }
       else // the radix-2 stage at the end: L = 2, no twiddles
         {
+          constexpr int NB = G::ZC / 2;
 #pragma unroll
-          for (int i = 0; i < NCPLX / 2 / NT; ++i)
+          for (int i = 0; i < (NB + NT - 1) / NT; ++i)
             {
-              const int  b = t + NT * i;
-              const cplx a0 = Z[G::pad(2 * b)], a1 = Z[G::pad(2 * b + 1)];
-              Z[G::pad(2 * b)]     = cplx{a0.re + a1.re, a0.im + a1.im};
-              Z[G::pad(2 * b + 1)] = cplx{a0.re - a1.re, a0.im - a1.im};
+              const int b = t + NT * i;
+              if (NB % NT == 0 || b < NB)
+                {
+                  const cplx a0 = Z[G::pad(2 * b)], a1 = Z[G::pad(2 * b + 1)];
+                  Z[G::pad(2 * b)]     = cplx{a0.re + a1.re, a0.im + a1.im};
+                  Z[G::pad(2 * b + 1)] = cplx{a0.re - a1.re, a0.im - a1.im};
+                }
             }
         }
       __syncthreads();
     }
-    // stages S ... : pairs of radix-4 stages as long as there are two, then what is left
-    template <int LOG2N, int S>
+    // stages S ... of the length-M part: pairs of radix-4 stages as long as there are two, then what is left
+    template <int N, int S>
     struct Stages
     {
       static __device__ __forceinline__ void run(cplx *Z, const cplx *T)
       {
-        using G = Geo<LOG2N>;
+        using G = Geo<N>;
         if constexpr (S + 1 < G::n_r4)
           {
-            fft_double_stage<LOG2N, S>(Z, T);
-            Stages<LOG2N, S + 2>::run(Z, T);
+            fft_double_stage<N, S>(Z, T);
+            Stages<N, S + 2>::run(Z, T);
           }
         else if constexpr (S < G::n_stages)
           {
-            fft_stage<LOG2N, S>(Z, T);
-            Stages<LOG2N, S + 1>::run(Z, T);
+            fft_stage<N, S>(Z, T);
+            Stages<N, S + 1>::run(Z, T);
           }
       }
     };
 
     // The cosine sums of the LB raw lines R[line][n] at the start of the LDS area.  The results stay in Z where the
     // transform left its output: y_k in the real part of slot pos_of(k) for k < N, y_N in the imaginary part of slot
-    // pos_of(0) (the two slots an item reads are the two it writes, nobody else touches them); y_value() reads them.
+    // pos_of(0) (the two slots an item reads are the two it writes, nobody else touches them).
     // On return every thread has passed a barrier after its last access.
-    template <int LOG2N>
+    template <int N>
     struct Items
     {
-      static constexpr int N = 1 << LOG2N, per_line = N / 2 + 1, total = Geo<LOG2N>::LB * per_line, NI = (total + NT - 1) / NT;
+      static constexpr int per_line = N / 2 + 1, total = Geo<N>::LB * per_line, NI = (total + NT - 1) / NT;
     };
-    template <int LOG2N>
-    __device__ __forceinline__ double y_value(const double *lds, const int line, const int m)
-    {
-      using G         = Geo<LOG2N>;
-      constexpr int N = G::N;
-      const double *z = lds + G::L_Z + 2 * G::pad(line * N + G::pos_of(m & (N - 1)));
-      return z[m >> LOG2N]; // m == N: the imaginary part of slot pos_of(0)
-    }
-    template <int LOG2N>
+    template <int N>
     __device__ __forceinline__ void dct_lines(double *lds)
     {
-      using G         = Geo<LOG2N>;
-      using I         = Items<LOG2N>;
-      constexpr int N = G::N, n = G::n;
+      using G         = Geo<N>;
+      using I         = Items<N>;
+      constexpr int n = G::n, M = G::M;
       const int     t = threadIdx.x;
       double       *R = lds + G::L_Z;
       cplx         *Z = reinterpret_cast<cplx *>(lds + G::L_Z);
@@ -308,52 +342,97 @@ namespace adaflo_hip
           __syncthreads();
           return;
         }
-      // ---- stages 0, 1 on z_j = e_{2j} + i e_{2j+1} taken from the raw lines (e_m = x_m, m <= N; x_{2N-m} beyond)
-      {
-        static_assert(NCPLX / 16 / NT == 1, "one 16-point group per thread");
-        const int     line = t >> (LOG2N - 4), j = t & (N / 16 - 1);
-        const double *x    = R + line * n;
-        cplx          a[4][4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
+      // z_j = e_{2j} + i e_{2j+1} from the raw lines (e_m = x_m, m <= N; x_{2N-m} beyond)
+      auto zraw = [&](const double *x, const int j) {
+        const int m0 = 2 * j, m1 = m0 + 1;
+        return cplx{x[m0 <= N ? m0 : 2 * N - m0], x[m1 <= N ? m1 : 2 * N - m1]};
+      };
+      cplx ends{0., 0.};
+      if (t < G::LB)
+        ends = cplx{R[t * n] + R[t * n + N], R[t * n] - R[t * n + N]};
+      if constexpr (G::F == 1)
+        {
+          // ---- stages 0, 1 on the raw lines
+          const int line = t / (N / 16), j = t - line * (N / 16);
+          cplx      a[4][4];
+          if (G::ZC / 16 == NT || t < G::ZC / 16)
             {
-              const int m0 = 2 * (j + p * (N / 4) + q * (N / 16)), m1 = m0 + 1;
-              a[p][q]      = cplx{x[m0 <= N ? m0 : 2 * N - m0], x[m1 <= N ? m1 : 2 * N - m1]};
+#pragma unroll
+              for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                  a[p][q] = zraw(R + line * n, j + p * (N / 4) + q * (N / 16));
+              radix4x4<N, N>(a, T, j);
             }
-        radix4x4<N, N>(a, T, j);
-        cplx ends{0., 0.};
-        if (t < G::LB)
-          ends = cplx{R[t * n] + R[t * n + N], R[t * n] - R[t * n + N]};
-        __syncthreads();
-        if (t < G::LB)
-          E[t] = ends;
+          __syncthreads();
+          if (t < G::LB)
+            E[t] = ends;
+          if (G::ZC / 16 == NT || t < G::ZC / 16)
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+            for (int p = 0; p < 4; ++p)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            Z[G::pad(line * N + j + p * (N / 4) + q * (N / 16))] = a[p][q];
-        __syncthreads();
-      }
-      if (!(DCT_EXP & 2))
-        Stages<LOG2N, 2>::run(Z, T);
+              for (int q = 0; q < 4; ++q)
+                Z[G::pad(line * N + j + p * (N / 4) + q * (N / 16))] = a[p][q];
+          __syncthreads();
+          if (!(DCT_EXP & 2))
+            Stages<N, 2>::run(Z, T);
+        }
+      else
+        {
+          // ---- the radix-5 stage on the raw lines: sub-transform q of length M gets y_q w_N^(q j) at position j
+          constexpr int NB = G::ZC / 5, NIT = (NB + NT - 1) / NT;
+          cplx          a[NIT][5];
+#pragma unroll
+          for (int i = 0; i < NIT; ++i)
+            {
+              const int b = t + NT * i;
+              if (b < NB)
+                {
+                  const int line = b / M, j = b - line * M;
+#pragma unroll
+                  for (int p = 0; p < 5; ++p)
+                    a[i][p] = zraw(R + line * n, j + p * M);
+                  radix5(a[i]);
+#pragma unroll
+                  for (int q = 1; q < 5; ++q)
+                    a[i][q] = cmul(a[i][q], twiddle<N>(T, q * j));
+                }
+            }
+          __syncthreads();
+          if (t < G::LB)
+            E[t] = ends;
+#pragma unroll
+          for (int i = 0; i < NIT; ++i)
+            {
+              const int b = t + NT * i;
+              if (b < NB)
+                {
+                  const int line = b / M, j = b - line * M;
+#pragma unroll
+                  for (int q = 0; q < 5; ++q)
+                    Z[G::pad(line * N + q * M + j)] = a[i][q];
+                }
+            }
+          __syncthreads();
+          if (!(DCT_EXP & 2))
+            Stages<N, 0>::run(Z, T);
+        }
       // ---- E_k, E_{N-k} from Z_k and Z_{N-k} (digit-reversed positions), then y, written back to the same two slots
       if (!(DCT_EXP & 4))
 #pragma unroll 3
         for (int i = 0; i < I::NI; ++i)
           {
             const int it = t + NT * i;
-            if (it < I::total)
+            if (I::total % NT == 0 || it < I::total)
               {
                 const int    line = it / I::per_line, k = it - line * I::per_line;
-                cplx        *pk = Z + G::pad(line * N + G::pos_of(k)), *pm = Z + G::pad(line * N + G::pos_of((N - k) & (N - 1)));
+                cplx        *pk = Z + G::pad(line * N + G::pos_of(k)), *pm = Z + G::pad(line * N + G::pos_of(k == 0 ? 0 : N - k));
                 const cplx   zk = *pk, zm = *pm;
                 const cplx   w = T[k], e = E[line];
                 const double are = 0.5 * (zk.re + zm.re), bre = 0.5 * (zk.im + zm.im), bim = -0.5 * (zk.re - zm.re);
                 const double p    = w.re * bre - w.im * bim;
-                const double ends = (k & 1) ? e.im : e.re;
-                const double yk = 0.5 * (are + p + ends), ym = 0.5 * (are - p + ends);
+                const double ends_k = (k & 1) ? e.im : e.re;
+                const double yk = 0.5 * (are + p + ends_k), ym = 0.5 * (are - p + ends_k);
                 if (k == 0)
                   *pk = cplx{yk, ym}; // y_0 and y_N
                 else
@@ -376,20 +455,22 @@ namespace adaflo_hip
     // registers.  AXIS is a template argument and every load is unconditional -- an absent value is read from element 0,
     // an absent LDS slot is the dump slot: with run-time branches around the loads the same code
     // had 400 basic blocks and the compiler waited for every load where it was issued.
-    template <int LOG2N, bool FUSED, int AXIS>
+    template <int N, bool FUSED, int AXIS>
     __device__ __forceinline__ void dct_body(const DctArgs &A, double *lds)
     {
-      using G           = Geo<LOG2N>;
-      constexpr int N = G::N, n = G::n, LB = G::LB, TPL = NT / LB;
+      using G           = Geo<N>;
+      constexpr int n = G::n, LB = G::LB, TPL = G::TPL;
       static_assert(!FUSED || AXIS == 2, "the fused pass is the z pass");
-      constexpr int NLD = NCPLX / NT + 1; // values of a line per thread
-      static_assert(NLD * TPL >= n && (NLD - 1) * TPL == N, "rows r0 + i TPL: only r0 = 0 has a last one (r = N)");
+      constexpr int NLD = 17; // values of a line per thread
+      static_assert((NLD - 1) * TPL == N, "rows r0 + i TPL: only r0 = 0 has a last one (r = N)");
       const int  t = threadIdx.x;
       double    *R = lds + G::L_Z;
       const long nbatch = (A.n_lines + LB - 1) / LB;
       for (int e = t; e < 2 * (N + 1); e += NT)
         lds[G::L_T + e] = A.tw[e];
-      const int  c = AXIS == 0 ? t / TPL : t & (LB - 1), r0 = AXIS == 0 ? t & (TPL - 1) : t / LB;
+      // (LB TPL <= NT: the last threads of a workgroup may have no line)
+      const bool active = G::NACT == NT || t < G::NACT;
+      const int  c = !active ? 0 : (AXIS == 0 ? t / TPL : t % LB), r0 = !active ? 1 : (AXIS == 0 ? t % TPL : t / LB);
       const int  pitch  = A.pitch_in;
       const long stride = AXIS == 0 ? 1 : (AXIS == 1 ? (long)pitch : (long)pitch * A.ny);
       struct Pos
@@ -410,7 +491,7 @@ namespace adaflo_hip
             if ((int)x >= A.nx)
               P.in = -1;
           }
-        if (c >= P.nl)
+        if (c >= P.nl || !active)
           P.in = -1;
         return P;
       };
@@ -445,13 +526,13 @@ namespace adaflo_hip
       auto    to_lds = [&](const double (&v)[NLD]) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-          (i < NLD - 1 || r0 == 0 ? Rc[i * TPL] : lds[G::L_DUMP]) = v[i];
+          ((i < NLD - 1 || r0 == 0) && active ? Rc[i * TPL] : lds[G::L_DUMP]) = v[i];
       };
-      const int pos0 = c * N + G::pos_of(r0); // (pos_of is linear over disjoint bit fields: r0 < TPL, i TPL above)
+      const int pos0 = c * N + (G::F == 1 ? G::pos_of(r0) : 0); // (F = 1: pos_of is linear over disjoint bit fields, r0 < TPL, i TPL above)
       auto      gather = [&](double (&v)[NLD]) {
 #pragma unroll
         for (int i = 0; i < NLD - 1; ++i)
-          v[i] = lds[G::L_Z + 2 * G::pad(pos0 + G::pos_of(i * TPL))];
+          v[i] = lds[G::L_Z + 2 * G::pad(pos0 + (G::F == 1 ? G::pos_of(i * TPL) : G::pos_of(r0 + i * TPL)))];
         v[NLD - 1] = lds[G::L_Z + 2 * G::pad(c * N) + 1]; // y_N (used by r0 = 0 only)
       };
       double pre[NLD], res[NLD];
@@ -471,7 +552,7 @@ namespace adaflo_hip
           const Pos  Pn = batch_pos(bn < nbatch ? bn : b);
           if (bn < nbatch)
             load(Pn, pre);
-          dct_lines<LOG2N>(lds);
+          dct_lines<N>(lds);
           if (FUSED)
             {
               // scale the mode coefficients and transform back; the factors that belong to the line (x, y) first
@@ -494,7 +575,7 @@ namespace adaflo_hip
                 }
               to_lds(res);
               __syncthreads();
-              dct_lines<LOG2N>(lds);
+              dct_lines<N>(lds);
             }
           gather(res);
           __syncthreads();

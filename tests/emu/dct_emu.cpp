@@ -12,22 +12,22 @@ using namespace adaflo_hip::dct;
 
 namespace
 {
-  template <int LOG2N>
+  template <int N>
   int run(const DctArgs &A, const int fused)
   {
-    using G = Geo<LOG2N>;
+    using G = Geo<N>;
     static_assert(G::L_TOTAL * 8 <= (int)emu::LDS_BYTES, "LDS");
     long nb = (A.n_lines + G::LB - 1) / G::LB;
     nb      = nb > 3 ? 3 : nb; // (a small persistent grid: every workgroup loops over several batches)
     double *lds = reinterpret_cast<double *>(emu::g_lds);
     if (fused)
-      emu::launch((unsigned)nb, NT, [&] { dct_body<LOG2N, true, 2>(A, lds); });
+      emu::launch((unsigned)nb, NT, [&] { dct_body<N, true, 2>(A, lds); });
     else if (A.axis == 0)
-      emu::launch((unsigned)nb, NT, [&] { dct_body<LOG2N, false, 0>(A, lds); });
+      emu::launch((unsigned)nb, NT, [&] { dct_body<N, false, 0>(A, lds); });
     else if (A.axis == 1)
-      emu::launch((unsigned)nb, NT, [&] { dct_body<LOG2N, false, 1>(A, lds); });
+      emu::launch((unsigned)nb, NT, [&] { dct_body<N, false, 1>(A, lds); });
     else
-      emu::launch((unsigned)nb, NT, [&] { dct_body<LOG2N, false, 2>(A, lds); });
+      emu::launch((unsigned)nb, NT, [&] { dct_body<N, false, 2>(A, lds); });
     return 0;
   }
 } // namespace
@@ -39,10 +39,7 @@ extern "C" int dct_emu_apply(const int axis, const int fused, const int nx, cons
                              const double *ay, const double *az, const double cm, const double cl, const double eps)
 {
   const int n = axis == 0 ? nx : (axis == 1 ? ny : nz), N = n - 1;
-  int       log2n = 0;
-  while ((1 << log2n) < N)
-    ++log2n;
-  if ((1 << log2n) != N || (fused && axis != 2))
+  if (!dct_length_supported(N) || (fused && axis != 2))
     return 1;
   std::vector<double> tw(2 * (N + 1));
   for (int m = 0; m <= N; ++m)
@@ -55,18 +52,26 @@ extern "C" int dct_emu_apply(const int axis, const int fused, const int nx, cons
   A.n_lines = axis == 0 ? (long)ny * nz : (axis == 1 ? (long)pitch * nz : (long)pitch * ny);
   A.axis = axis, A.nx = nx, A.ny = ny, A.nz = nz, A.pitch_in = A.pitch_out = pitch;
   A.lx = lx, A.ly = ly, A.lz = lz, A.ax = ax, A.ay = ay, A.az = az, A.cm = cm, A.cl = cl, A.eps = eps;
-  switch (log2n)
+  switch (N)
     {
-      case 6:
-        return run<6>(A, fused);
-      case 7:
-        return run<7>(A, fused);
-      case 8:
-        return run<8>(A, fused);
-      case 9:
-        return run<9>(A, fused);
-      case 10:
-        return run<10>(A, fused);
+      case 64:
+        return run<64>(A, fused);
+      case 128:
+        return run<128>(A, fused);
+      case 256:
+        return run<256>(A, fused);
+      case 512:
+        return run<512>(A, fused);
+      case 1024:
+        return run<1024>(A, fused);
+      case 80:
+        return run<80>(A, fused);
+      case 160:
+        return run<160>(A, fused);
+      case 320:
+        return run<320>(A, fused);
+      case 640:
+        return run<640>(A, fused);
     }
   return 1;
 }

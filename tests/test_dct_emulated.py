@@ -49,7 +49,11 @@ def apply(lib, axis, field, fused=False, scal=None, pitch=None):
 
 @pytest.mark.parametrize("axis,shape", [(0, (3, 5, 65)), (0, (2, 3, 129)), (0, (1, 19, 257)), (0, (1, 3, 513)), (0, (1, 5, 1025)),
                                         (1, (3, 65, 7)), (1, (2, 129, 37)), (1, (1, 257, 18)),
-                                        (2, (65, 5, 15)), (2, (257, 3, 7)), (2, (513, 2, 5))])
+                                        (2, (65, 5, 15)), (2, (257, 3, 7)), (2, (513, 2, 5)),
+                                        # 5 2^m intervals (the reference's meshes: 5 x 10 coarse cells): radix-5 stage first, batches of
+                                        # 51 / 25 / 12 / 6 lines that do not fill the workgroup
+                                        (0, (2, 30, 81)), (0, (1, 27, 161)), (0, (1, 13, 321)), (0, (1, 7, 641)),
+                                        (1, (2, 81, 53)), (1, (1, 161, 26)), (2, (161, 3, 9)), (2, (321, 2, 7))])
 def test_cosine_sums_along_an_axis(emu, axis, shape):
     """ragged batches (line counts that are no multiple of the batch), every supported length, all three axes"""
     rng = np.random.default_rng(7)
@@ -62,10 +66,10 @@ def test_cosine_sums_along_an_axis(emu, axis, shape):
     assert np.abs(got - ref).max() < 1e-13 * n * np.abs(field).max() * 4
 
 
-def test_fused_forward_scaling_backward(emu):
+@pytest.mark.parametrize("nz,ny,nx", [(65, 3, 6), (81, 2, 5), (161, 2, 3)])
+def test_fused_forward_scaling_backward(emu, nz, ny, nx):
     """z pass of the inverse: S diag(1 / (c_m + c_l (lx + ly + lz))) S^T with S = cosines . diag(sqrt(a)), null mode dropped"""
     rng = np.random.default_rng(11)
-    nz, ny, nx = 65, 3, 6
     field = rng.standard_normal((nz, ny, nx))
     scal = dict(lx=rng.random(nx), ly=rng.random(ny), lz=rng.random(nz), ax=rng.random(nx) + 0.5, ay=rng.random(ny) + 0.5,
                 az=rng.random(nz) + 0.5, cm=0.0, cl=1.3, eps=1e-9)
