@@ -71,7 +71,8 @@ namespace adaflo_hip
       static constexpr int log2(const int v) { return v <= 1 ? 0 : 1 + log2(v / 2); }
       static constexpr int LOG2M = log2(M), n_r4 = LOG2M / 2, n_stages = n_r4 + (LOG2M & 1); // stages of the length-M part
       // a thread serves one line: TPL threads per line, LB lines per batch, LB TPL <= NT threads are active
-      static constexpr int TPL = N / 16, LB = NT / TPL, NACT = LB * TPL, ZC = LB * N;
+      // (F = 5: at most three radix-5 butterflies per thread -- their results wait in registers for a barrier)
+      static constexpr int TPL = N / 16, LB_ = NT / TPL, LB = F == 5 && LB_ > 3 * NT * 5 / N ? 3 * NT * 5 / N : LB_, NACT = LB * TPL, ZC = LB * N;
       static_assert(N % 16 == 0 && ZC <= NCPLX && LB >= 1, "batch");
       // LDS, in doubles: Z (one complex number of padding behind every 16: the strides 16, 64, ... of the later stages and
       // of the digit-reversed reads would otherwise fall on one bank; the raw lines R[LB][n] overlay its start), twiddles,
