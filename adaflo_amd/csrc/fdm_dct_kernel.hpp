@@ -37,6 +37,24 @@ namespace adaflo_hip
     {
       double re, im;
     };
+    // hides a value from the optimiser (no instruction): what is derived from it is not hoisted out of a loop
+#if defined(__HIPCC__)
+    __device__ __forceinline__ void opaque(int &v) { asm volatile("" : "+v"(v)); }
+#else
+    inline void opaque(int &) {}
+#endif
+    // 1 / d to the last bit or two: hardware estimate + two Newton steps (the IEEE division sequence, unrolled 17 times
+    // in the scaling of the fused pass, needed 450 B of scratch per lane)
+#if defined(__HIPCC__)
+    __device__ __forceinline__ double fast_rcp(const double d)
+    {
+      double r = __builtin_amdgcn_rcp(d);
+      r        = r * (2. - d * r);
+      return r * (2. - d * r);
+    }
+#else
+    inline double fast_rcp(const double d) { return 1. / d; }
+#endif
 
     struct DctArgs
     {
@@ -225,7 +243,8 @@ namespace adaflo_hip
       using G         = Geo<N>;
       constexpr int L = G::M >> (2 * S);
       static_assert(L >= 16, "two radix-4 stages");
-      const int t = threadIdx.x;
+      int t = threadIdx.x; // (opaque: the index arithmetic below depends on the thread only and would be hoisted out
+      opaque(t);           //  of the batch loop of dct_body -- dozens of registers held, or spilled, for the whole kernel)
       if (G::ZC / 16 == NT || t < G::ZC / 16) // (one 16-point group per thread)
         {
           const int line = t / (N / 16), r = t - line * (N / 16);
@@ -251,7 +270,8 @@ namespace adaflo_hip
     {
       using G         = Geo<N>;
       constexpr int L = G::M >> (2 * S); // length of the sub-transforms this stage splits
-      const int     t = threadIdx.x;
+      int t = threadIdx.x; // (opaque: the index arithmetic below depends on the thread only and would be hoisted out
+      opaque(t);           //  of the batch loop of dct_body -- dozens of registers held, or spilled, for the whole kernel)
       if constexpr (S < G::n_r4)
         {
           constexpr int NB = G::ZC / 4;
@@ -318,22 +338,15 @@ namespace adaflo_hip
       }
     };
 
-    // The cosine sums of the LB raw lines R[line][n] at the start of the LDS area.  The results stay in Z where the
-    // transform left its output: y_k in the real part of slot pos_of(k) for k < N, y_N in the imaginary part of slot
-    // pos_of(0) (the two slots an item reads are the two it writes, nobody else touches them).
-    // On return every thread has passed a barrier after its last access.
-    template <int N>
-    struct Items
-    {
-      static constexpr int per_line = N / 2 + 1, total = Geo<N>::LB * per_line, NI = (total + NT - 1) / NT;
-    };
+    // The FFT of the LB raw lines R[line][n] at the start of the LDS area: Z_k of line c lies at pad(c N + pos_of(k)),
+    // (x_0 + x_N, x_0 - x_N) of the line in E[c].  On return every thread has passed a barrier after its last access.
     template <int N>
     __device__ __forceinline__ void dct_lines(double *lds)
     {
       using G         = Geo<N>;
-      using I         = Items<N>;
       constexpr int n = G::n, M = G::M;
-      const int     t = threadIdx.x;
+      int t = threadIdx.x; // (opaque: the index arithmetic below depends on the thread only and would be hoisted out
+      opaque(t);           //  of the batch loop of dct_body -- dozens of registers held, or spilled, for the whole kernel)
       double       *R = lds + G::L_Z;
       cplx         *Z = reinterpret_cast<cplx *>(lds + G::L_Z);
       const cplx   *T = reinterpret_cast<const cplx *>(lds + G::L_T);
@@ -418,32 +431,6 @@ namespace adaflo_hip
           if (!(DCT_EXP & 2))
             Stages<N, 0>::run(Z, T);
         }
-      // ---- E_k, E_{N-k} from Z_k and Z_{N-k} (digit-reversed positions), then y, written back to the same two slots
-      if (!(DCT_EXP & 4))
-#pragma unroll 3
-        for (int i = 0; i < I::NI; ++i)
-          {
-            const int it = t + NT * i;
-            if (I::total % NT == 0 || it < I::total)
-              {
-                const int    line = it / I::per_line, k = it - line * I::per_line;
-                cplx        *pk = Z + G::pad(line * N + G::pos_of(k)), *pm = Z + G::pad(line * N + G::pos_of(k == 0 ? 0 : N - k));
-                const cplx   zk = *pk, zm = *pm;
-                const cplx   w = T[k], e = E[line];
-                const double are = 0.5 * (zk.re + zm.re), bre = 0.5 * (zk.im + zm.im), bim = -0.5 * (zk.re - zm.re);
-                const double p    = w.re * bre - w.im * bim;
-                const double ends_k = (k & 1) ? e.im : e.re;
-                const double yk = 0.5 * (are + p + ends_k), ym = 0.5 * (are - p + ends_k);
-                if (k == 0)
-                  *pk = cplx{yk, ym}; // y_0 and y_N
-                else
-                  {
-                    pm->re = ym; // (k = N / 2: the same slot and the same value)
-                    pk->re = yk;
-                  }
-              }
-          }
-      __syncthreads();
     }
 
     // One workgroup, a grid-stride loop over the batches.  The memory stream is software-pipelined around the transform:
@@ -529,12 +516,43 @@ namespace adaflo_hip
         for (int i = 0; i < NLD; ++i)
           ((i < NLD - 1 || r0 == 0) && active ? Rc[i * TPL] : lds[G::L_DUMP]) = v[i];
       };
-      const int pos0 = c * N + (G::F == 1 ? G::pos_of(r0) : 0); // (F = 1: pos_of is linear over disjoint bit fields, r0 < TPL, i TPL above)
-      auto      gather = [&](double (&v)[NLD]) {
+      // The cosine sums of this thread's values from the FFT:  E_k = (Z_k + conj Z_{N-k}) / 2 + w^k (Z_k - conj Z_{N-k}) / (2i)
+      // (real), y_k = (E_k + x_0 + (-1)^k x_N) / 2 for k = r0 + i TPL < N, and y_N = (Re Z_0 - Im Z_0 + x_0 + x_N) / 2.
+      // F = 1: pos_of is linear over disjoint bit fields, so the slots of k and of N - k = (15 - i [+ 1 if r0 = 0]) TPL +
+      // (TPL - r0) are a per-thread base plus a constant.
+      const cplx *Zc = reinterpret_cast<const cplx *>(lds + G::L_Z);
+      const cplx *Tc = reinterpret_cast<const cplx *>(lds + G::L_T), *Ec = reinterpret_cast<const cplx *>(lds + G::L_E);
+      auto        finish = [&](double (&v)[NLD]) {
+        // (the 51 LDS addresses below depend on the thread only: computed outside the batch loop they would occupy 51
+        // registers for the whole kernel -- with them the fused pass spilled 500 B per lane)
+        int c_ = c, r0_ = r0;
+        opaque(c_), opaque(r0_);
+        const int c = c_, r0 = r0_;
+        // k = r0 + i TPL with TPL = F Q, Q a power of two: k mod F = r0 mod F and k / F = r0 / F + i Q (disjoint bit
+        // fields), so the slot of Z_k is a per-thread base plus a constant; the same for N - k = u TPL + rm
+        constexpr int F = G::F, Q = TPL / F;
+        const int     rm = r0 ? TPL - r0 : 0;
+        const int     posk0 = c * N + (r0 % F) * G::M + G::pos_of_m(r0 / F), posm0 = c * N + (rm % F) * G::M + G::pos_of_m(rm / F);
+        if (DCT_EXP & 4)
+          {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+              v[i] = lds[G::L_Z + c * N + r0 + i];
+            return;
+          }
+        const cplx e = Ec[c];
 #pragma unroll
         for (int i = 0; i < NLD - 1; ++i)
-          v[i] = lds[G::L_Z + 2 * G::pad(pos0 + (G::F == 1 ? G::pos_of(i * TPL) : G::pos_of(r0 + i * TPL)))];
-        v[NLD - 1] = lds[G::L_Z + 2 * G::pad(c * N) + 1]; // y_N (used by r0 = 0 only)
+          {
+            const int k  = r0 + i * TPL;
+            const int pk = posk0 + G::pos_of_m(i * Q);
+            const int pm = posm0 + (r0 ? G::pos_of_m((15 - i) * Q) : G::pos_of_m(((16 - i) & 15) * Q));
+            const cplx   zk = Zc[G::pad(pk)], zm = Zc[G::pad(pm)], w = Tc[k];
+            const double are = 0.5 * (zk.re + zm.re), bre = 0.5 * (zk.im + zm.im), bim = -0.5 * (zk.re - zm.re);
+            v[i] = 0.5 * (are + (w.re * bre - w.im * bim) + ((k & 1) ? e.im : e.re));
+          }
+        const cplx z0 = Zc[G::pad(c * N)];
+        v[NLD - 1]    = 0.5 * (z0.re - z0.im + e.re); // y_N (used by r0 = 0 only)
       };
       double pre[NLD], res[NLD];
       long   b = blockIdx.x;
@@ -564,7 +582,7 @@ namespace adaflo_hip
                   const bool     live = t < P.nl && (int)x < A.nx;
                   F[t] = live ? cplx{A.lx[x] + A.ly[y], A.ax[x] * A.ay[y]} : cplx{0., 0.};
                 }
-              gather(res);
+              finish(res);
               __syncthreads();
               const cplx f = F[c]; // (an absent line: ax ay = 0)
 #pragma unroll
@@ -572,13 +590,14 @@ namespace adaflo_hip
                 {
                   const int    k = i < NLD - 1 ? r0 + i * TPL : N;
                   const double d = A.cm + A.cl * (f.re + A.lz[k]);
-                  res[i] *= (d > A.eps || d < -A.eps) ? f.im * A.az[k] / d : 0.;
+                  const double az = A.az[k], sc = f.im * az * fast_rcp(d); // (unconditional: a load behind the condition is a branch)
+                  res[i] *= (d > A.eps || d < -A.eps) ? sc : 0.;
                 }
               to_lds(res);
               __syncthreads();
               dct_lines<N>(lds);
             }
-          gather(res);
+          finish(res);
           __syncthreads();
           Pprev = P, have_prev = true;
           if (bn >= nbatch)
