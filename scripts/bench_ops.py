@@ -175,6 +175,15 @@ def ls_case(s, ncell, only=None):
         print(json.dumps({"op": "ls_advect_vmult_nodal", "s": s, "cells": list(ncell), "ms": round(t * 1e3, 4),
                           "MDoF/s": round(ops_v.n_dofs / t / 1e6, 1), "alg_GB/s": round(b * ncells / t / 1e9, 1),
                           "frac_of_8TB/s": round(b * ncells / t / 8e12, 4)}), flush=True)
+    # the reinitialisation operator right after a first-step right-hand side: unit normal recomputed from the nodal field
+    if only is None or "ls_reinit_vmult_nodal" in only:
+        ops_v.set_kernel_variant(1)
+        rei_v.local_reinitialize_rhs(rhs, phi, nrm, False, True)
+        t = timeit(lambda: rei_v.reinitialization_vmult(rhs, phi, False), sync_v)
+        b = 5 * nodal
+        print(json.dumps({"op": "ls_reinit_vmult_nodal", "s": s, "cells": list(ncell), "ms": round(t * 1e3, 4),
+                          "MDoF/s": round(ops_v.n_dofs / t / 1e6, 1), "alg_GB/s": round(b * ncells / t / 1e9, 1),
+                          "frac_of_8TB/s": round(b * ncells / t / 8e12, 4)}), flush=True)
     for variant in (1, 0):
         ops_v.set_kernel_variant(variant)
         for name, fn, bytes_per_cell in rhs_cases:

@@ -9,4 +9,4 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import bench_ops  # noqa: E402
 
 for nc in ((40, 40, 80), (64, 64, 128)):
-    bench_ops.ls_case(4, nc, only=("ls_advect_rhs", "ls_advect_vmult", "ls_advect_vmult_nodal"))
+    bench_ops.ls_case(4, nc, only=("ls_advect_rhs", "ls_advect_vmult", "ls_advect_vmult_nodal", "ls_reinit_vmult", "ls_reinit_vmult_nodal"))
