@@ -295,7 +295,10 @@ int adaflo_ls_set_params(adaflo_ctx *ctx, const adaflo_ls_params *p);
 /* preconditioner.get_vector(): diagonal used for constrained rows (device pointer),
  * e.g. level_set_okz_reinitialization.cc:227-230 */
 int adaflo_ls_set_diagonal(adaflo_ctx *ctx, const double *diag);
-/* evaluated_convection / evaluated_normal (written by the rhs kernels, readable for tests) */
+/* evaluated_convection / evaluated_normal: the quadrature-point arrays the reference's rhs loops fill
+ * (level_set_okz_advance_concentration.cc:389, level_set_okz_reinitialization.cc:167-172).  On the sweep kernels the
+ * engine keeps the NODAL velocity / normal field of the last right-hand side instead and the operators evaluate it at
+ * the Gauss points themselves; get_* materialises the array on demand, set_* makes the operators stream the given one. */
 int adaflo_ls_set_evaluated_convection(adaflo_ctx *ctx, const double *u_q, int src_on_device);
 int adaflo_ls_get_evaluated_convection(adaflo_ctx *ctx, double *u_q, int dst_on_device);
 int adaflo_ls_set_evaluated_normal(adaflo_ctx *ctx, const double *n_q, int src_on_device);
