@@ -172,8 +172,7 @@ def _run_distributed_case(world, cells, k=2, two_phase=False):
     else:
         ref_u, ref_p = _reference(gcells, grid, k, two_phase, glin, gcoef, gu, gp)
     mgr = mp.Manager()
-    results = mgr.dict()
-    crumbs = mgr.dict()
+    results, crumbs = None, None
     # Up to eight processes share ONE GPU here (production: one process per GPU).  A rank of an 8-process job dies
     # now and then with "Queue ... aborting with error: HSA_STATUS_ERROR_ILLEGAL_INSTRUCTION" (never in 2- or 4-process
     # jobs).  Round 4 (scripts/dev/stress_parallel.py 2 8 big, logs in profiles/r04_stress_*.log): 3 deaths in 33 jobs
@@ -192,8 +191,11 @@ def _run_distributed_case(world, cells, k=2, two_phase=False):
     try:
         for attempt in range(2):
             try:
-                results.clear()
-                crumbs.clear()
+                # fresh dictionaries per attempt: ranks of an aborted attempt that are still being torn down must not be
+                # able to write into what the repetition collects (round 4: the one wrong pressure block of the stress
+                # series, profiles/r04_stress_8rank_refchild.log repetition 15, came out of exactly such a repetition --
+                # a rank death, then the retry -- with the dictionary of the first attempt cleared and re-used)
+                results, crumbs = mgr.dict(), mgr.dict()
                 mp.spawn(_worker, args=(world, _free_port(), grid, list(cells), k, gu, gp, glin, gcoef, ref_u, ref_p,
                                         results, crumbs), nprocs=world, join=True)
                 break
