@@ -44,7 +44,7 @@ namespace adaflo_hip
       // onto each other: two products of half the size instead of one, half the flops (fdm_apply).
       bool sym = false;
       int  n_even = 0; // number of even modes (they come first)
-      // degree 1, natural ends, n - 1 = 2^m or 5 2^m intervals: the eigenvectors are sqrt(a2[k]) cos(pi j k / (n - 1)) and the
+      // degree 1, natural ends, n - 1 = 2^m, 3 2^m or 5 2^m intervals: the eigenvectors are sqrt(a2[k]) cos(pi j k / (n - 1)) and the
       // transforms run as fast cosine transforms (fdm_dct_kernel.hpp); modes in natural order k = 0 .. n - 1 there
       int     nfft = 0;          // n - 1; 0: not available
       double *d_tw  = nullptr;   // [n][2]: exp(-i pi m / (n - 1))
@@ -557,6 +557,10 @@ namespace adaflo_hip
           DCT_CASE(160)
           DCT_CASE(320)
           DCT_CASE(640)
+          DCT_CASE(96)
+          DCT_CASE(192)
+          DCT_CASE(384)
+          DCT_CASE(768)
 #undef DCT_CASE
         }
       return ADAFLO_EINVAL;

@@ -3,12 +3,12 @@
 // On a uniform grid with natural ends the generalised eigenvectors of the 1D pair (K, M) of FE_Q(1) are
 // v_k(j) = cos(pi j k / N), j, k = 0 .. N (fdm.hip: linear_eig), so nodes -> modes and modes -> nodes are both the
 // plain cosine sum  y_k = sum_{j = 0}^{N} cos(pi j k / N) x_j  (DCT-I without the customary half weights at the ends)
-// followed / preceded by a scaling.  For N = 2^m or 5 2^m this kernel computes it in O(N log N) instead of the
+// followed / preceded by a scaling.  For N = 2^m, 3 2^m or 5 2^m this kernel computes it in O(N log N) instead of the
 // (N + 1)^2 of the matrix product:
 //   e = even extension of x to length 2N;  z_j = e_{2j} + i e_{2j+1}, j = 0 .. N-1;  Z = FFT_N(z)
 //   E_k = (Z_k + conj Z_{N-k}) / 2 + w^k (Z_k - conj Z_{N-k}) / (2i),  w = exp(-i pi / N)   (real: e is real and even)
 //   y_k = (E_k + x_0 + (-1)^k x_N) / 2
-// The FFT is an in-place decimation-in-frequency transform in LDS: a radix-5 stage if 5 divides N, then radix 4 (two
+// The FFT is an in-place decimation-in-frequency transform in LDS: a radix-3 / radix-5 stage if 3 / 5 divides N, then radix 4 (two
 // stages per LDS round trip, one radix-2 stage at the end if needed); its result stays in digit-reversed order and the
 // step that forms E reads Z_k where it lies.
 //
@@ -74,23 +74,25 @@ namespace adaflo_hip
       double        cm, cl, eps;
     };
 
-    // N = F 2^m intervals per line, F = 1 or 5 (the reference's meshes are 5 x 10 coarse cells refined: 5 2^m), 2^m >= 16:
-    // an optional radix-5 stage, then radix-4 stages in pairs, then what is left (radix 4, radix 2)
+    // N = F 2^m intervals per line, F = 1, 3 or 5 (the reference's meshes are 5 x 10 coarse cells refined: 5 2^m), 2^m >= 16:
+    // an optional radix-3 / radix-5 stage, then radix-4 stages in pairs, then what is left (radix 4, radix 2)
+    constexpr int dct_odd_factor(const int N) { return N % 5 == 0 ? 5 : (N % 3 == 0 ? 3 : 1); }
     constexpr bool dct_length_supported(const int N)
     {
-      const int M = N % 5 == 0 ? N / 5 : N;
+      const int M = N / dct_odd_factor(N);
       return N >= 64 && N <= 1024 && M >= 16 && (M & (M - 1)) == 0;
     }
     template <int N_>
     struct Geo
     {
-      static constexpr int N = N_, n = N + 1, F = N % 5 == 0 ? 5 : 1, M = N / F;
-      static_assert(dct_length_supported(N), "N = 2^m or 5 2^m, 64 <= N <= 1024, 2^m >= 16");
+      static constexpr int N = N_, n = N + 1, F = dct_odd_factor(N_), M = N / F;
+      static_assert(dct_length_supported(N), "N = 2^m, 3 2^m or 5 2^m, 64 <= N <= 1024, 2^m >= 16");
       static constexpr int log2(const int v) { return v <= 1 ? 0 : 1 + log2(v / 2); }
       static constexpr int LOG2M = log2(M), n_r4 = LOG2M / 2, n_stages = n_r4 + (LOG2M & 1); // stages of the length-M part
       // a thread serves one line: TPL threads per line, LB lines per batch, LB TPL <= NT threads are active
-      // (F = 5: at most three radix-5 butterflies per thread -- their results wait in registers for a barrier)
-      static constexpr int TPL = N / 16, LB_ = NT / TPL, LB = F == 5 && LB_ > 3 * NT * 5 / N ? 3 * NT * 5 / N : LB_, NACT = LB * TPL, ZC = LB * N;
+      // (F = 5: at most three radix-5 butterflies per thread -- their results wait in registers for a barrier; F = 3: five)
+      static constexpr int TPL = N / 16, LB_ = NT / TPL, NBMAX = F == 5 ? 3 : 5,
+                           LB = F > 1 && LB_ > NBMAX * NT * F / N ? NBMAX * NT * F / N : LB_, NACT = LB * TPL, ZC = LB * N;
       static_assert(N % 16 == 0 && ZC <= NCPLX && LB >= 1, "batch");
       // LDS, in doubles: Z (one complex number of padding behind every 16: the strides 16, 64, ... of the later stages and
       // of the digit-reversed reads would otherwise fall on one bank; the raw lines R[LB][n] overlay its start), twiddles,
@@ -235,6 +237,19 @@ namespace adaflo_hip
       a[2] = cplx{m2.re + n2.re, m2.im + n2.im};
       a[3] = cplx{m2.re - n2.re, m2.im - n2.im};
     }
+
+    // radix-3 butterfly of the forward transform, twiddles not applied
+    __device__ __forceinline__ void radix3(cplx (&a)[3])
+    {
+      constexpr double s = 0.86602540378443864676; // sin(2 pi / 3)
+      const cplx t{a[1].re + a[2].re, a[1].im + a[2].im}, d{a[1].re - a[2].re, a[1].im - a[2].im};
+      const cplx m{a[0].re - 0.5 * t.re, a[0].im - 0.5 * t.im}, n{s * d.im, -s * d.re}; // -i s d
+      a[0] = cplx{a[0].re + t.re, a[0].im + t.im};
+      a[1] = cplx{m.re + n.re, m.im + n.im};
+      a[2] = cplx{m.re - n.re, m.im - n.im};
+    }
+    __device__ __forceinline__ void radix_odd(cplx (&a)[3]) { radix3(a); }
+    __device__ __forceinline__ void radix_odd(cplx (&a)[5]) { radix5(a); }
 
     // stages S, S + 1 (radix 4 x 4) of the length-M part, in place in Z
     template <int N, int S>
@@ -393,9 +408,9 @@ namespace adaflo_hip
         }
       else
         {
-          // ---- the radix-5 stage on the raw lines: sub-transform q of length M gets y_q w_N^(q j) at position j
-          constexpr int NB = G::ZC / 5, NIT = (NB + NT - 1) / NT;
-          cplx          a[NIT][5];
+          // ---- the radix-3 / radix-5 stage on the raw lines: sub-transform q of length M gets y_q w_N^(q j) at position j
+          constexpr int F = G::F, NB = G::ZC / F, NIT = (NB + NT - 1) / NT;
+          cplx          a[NIT][F];
 #pragma unroll
           for (int i = 0; i < NIT; ++i)
             {
@@ -404,11 +419,11 @@ namespace adaflo_hip
                 {
                   const int line = b / M, j = b - line * M;
 #pragma unroll
-                  for (int p = 0; p < 5; ++p)
+                  for (int p = 0; p < F; ++p)
                     a[i][p] = zraw(R + line * n, j + p * M);
-                  radix5(a[i]);
+                  radix_odd(a[i]);
 #pragma unroll
-                  for (int q = 1; q < 5; ++q)
+                  for (int q = 1; q < F; ++q)
                     a[i][q] = cmul(a[i][q], twiddle<N>(T, q * j));
                 }
             }
@@ -423,7 +438,7 @@ namespace adaflo_hip
                 {
                   const int line = b / M, j = b - line * M;
 #pragma unroll
-                  for (int q = 0; q < 5; ++q)
+                  for (int q = 0; q < F; ++q)
                     Z[G::pad(line * N + q * M + j)] = a[i][q];
                 }
             }

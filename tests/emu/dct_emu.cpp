@@ -72,6 +72,14 @@ extern "C" int dct_emu_apply(const int axis, const int fused, const int nx, cons
         return run<320>(A, fused);
       case 640:
         return run<640>(A, fused);
+      case 96:
+        return run<96>(A, fused);
+      case 192:
+        return run<192>(A, fused);
+      case 384:
+        return run<384>(A, fused);
+      case 768:
+        return run<768>(A, fused);
     }
   return 1;
 }

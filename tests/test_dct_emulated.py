@@ -53,7 +53,9 @@ def apply(lib, axis, field, fused=False, scal=None, pitch=None):
                                         # 5 2^m intervals (the reference's meshes: 5 x 10 coarse cells): radix-5 stage first, batches of
                                         # 51 / 25 / 12 / 6 lines that do not fill the workgroup
                                         (0, (2, 30, 81)), (0, (1, 27, 161)), (0, (1, 13, 321)), (0, (1, 7, 641)),
-                                        (1, (2, 81, 53)), (1, (1, 161, 26)), (2, (161, 3, 9)), (2, (321, 2, 7))])
+                                        (1, (2, 81, 53)), (1, (1, 161, 26)), (2, (161, 3, 9)), (2, (321, 2, 7)),
+                                        # 3 2^m intervals: radix-3 stage first
+                                        (0, (2, 23, 97)), (0, (1, 21, 193)), (0, (1, 11, 385)), (0, (1, 6, 769)), (1, (1, 97, 44)), (2, (193, 2, 9))])
 def test_cosine_sums_along_an_axis(emu, axis, shape):
     """ragged batches (line counts that are no multiple of the batch), every supported length, all three axes"""
     rng = np.random.default_rng(7)
@@ -66,7 +68,7 @@ def test_cosine_sums_along_an_axis(emu, axis, shape):
     assert np.abs(got - ref).max() < 1e-13 * n * np.abs(field).max() * 4
 
 
-@pytest.mark.parametrize("nz,ny,nx", [(65, 3, 6), (81, 2, 5), (161, 2, 3)])
+@pytest.mark.parametrize("nz,ny,nx", [(65, 3, 6), (81, 2, 5), (161, 2, 3), (97, 2, 4)])
 def test_fused_forward_scaling_backward(emu, nz, ny, nx):
     """z pass of the inverse: S diag(1 / (c_m + c_l (lx + ly + lz))) S^T with S = cosines . diag(sqrt(a)), null mode dropped"""
     rng = np.random.default_rng(11)

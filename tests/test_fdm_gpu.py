@@ -165,10 +165,12 @@ def test_projection_solve_refuses_a_constrained_level_set_space():
 
 @pytest.mark.parametrize("s,ncell", [(4, (16, 16, 32)), (2, (32, 64, 32)), (1, (64, 128, 256)), (4, (16, 128, 16)), (4, (256, 16, 16)),
                                      # 5 2^m intervals per direction: the reference's meshes (5 x 10 coarse cells refined)
-                                     (4, (20, 20, 40)), (4, (40, 20, 20)), (2, (40, 80, 160)), (4, (20, 160, 20)), (4, (20, 16, 40))])
+                                     (4, (20, 20, 40)), (4, (40, 20, 20)), (2, (40, 80, 160)), (4, (20, 160, 20)), (4, (20, 16, 40)),
+                                     # 3 2^m intervals
+                                     (4, (24, 24, 48)), (2, (48, 96, 192)), (4, (96, 24, 20)), (4, (24, 192, 16))])
 def test_fast_cosine_transforms_of_the_level_set_space(s, ncell, monkeypatch):
-    """2^m or 5 2^m intervals per direction and natural ends: the transforms run as fast cosine transforms in LDS
-    (csrc/fdm_dct_kernel.hpp; 65 ... 1025 nodes per line, all nine lengths over the cases).  The result is the inverse
+    """2^m, 3 2^m or 5 2^m intervals per direction and natural ends: the transforms run as fast cosine transforms in LDS
+    (csrc/fdm_dct_kernel.hpp; 65 ... 1025 nodes per line, all thirteen lengths over the cases).  The result is the inverse
     of the projection matrix, and equal to what the matrix products give (ADAFLO_FDM_NO_DCT) to rounding"""
     from adaflo_amd import level_set_okz as lso
     mesh = adaflo_amd.BrickMesh(list(ncell), [0.0, 0.0, 0.0], [1.0, 0.7, 1.5])
