@@ -149,6 +149,7 @@ SIGNATURES = {
     "adaflo_ls_mass_matrix_diagonal": (C.c_int, [_CTX, _D]),
     "adaflo_invert_diagonal": (C.c_int, [_CTX, _D, _D, C.c_int64]),
     "adaflo_fdm_apply": (C.c_int, [_CTX, C.c_int, _D, _D, C.c_double, C.c_double]),
+    "adaflo_fdm_apply_sum": (C.c_int, [_CTX, C.c_int, _D, _D, C.c_double, C.c_double, C.c_double, C.c_double]),
     "adaflo_ls_projection_solve": (C.c_int, [_CTX, _D, _D, C.c_int]),
     "adaflo_ns_set_iterations_before_inner_solvers": (C.c_int, [_CTX, C.c_int]),
     "adaflo_ns_preconditioner_set_inner": (C.c_int, [_CTX, C.c_int]),

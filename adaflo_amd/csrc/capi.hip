@@ -1107,6 +1107,23 @@ int adaflo_fdm_apply(adaflo_ctx *ctx, int field, double *dst, const double *src,
   return 0;
 }
 
+int adaflo_fdm_apply_sum(adaflo_ctx *ctx, int field, double *dst, const double *src, double c_mass, double c_lap,
+                         double c_mass2, double c_lap2)
+{
+  CHECK_CTX(ctx);
+  if (ctx->flat)
+    return fail(ctx, ADAFLO_EUNSUPPORTED, "the fast-diagonalisation inverses are dim = 3 only");
+  if (!dst || !src || field < 0 || field > 2 || (c_mass2 == 0. && c_lap2 == 0.))
+    return fail(ctx, ADAFLO_EINVAL, "invalid arguments");
+  if (field == 2 && ctx->s <= 0)
+    return fail(ctx, ADAFLO_ENOTINIT, "context without a level-set space");
+  const uint32_t mask = field == 0 ? ctx->brick.con_u : (field == 1 ? ctx->brick.con_p : ctx->brick.con_ls);
+  if (mask != 0u)
+    return fail(ctx, ADAFLO_EUNSUPPORTED, "constrained rows: apply the two inverses separately");
+  TRY(ctx, fdm_apply(ctx, field, dst, src, c_mass, c_lap, c_mass2, c_lap2), "fast-diagonalisation solve failed");
+  return 0;
+}
+
 int adaflo_ns_set_iterations_before_inner_solvers(adaflo_ctx *ctx, int iterations)
 {
   CHECK_CTX(ctx);

@@ -72,6 +72,8 @@ namespace adaflo_hip
       // FUSED (axis 2): scaling between the two transforms; a*: squared normalisation of mode k, l*: eigenvalue
       const double *lx, *ly, *lz, *ax, *ay, *az;
       double        cm, cl, eps;
+      // a second inverse applied to the same source and added (cm2 == cl2 == 0: none): both are diagonal in the same modes
+      double        cm2, cl2;
     };
 
     // N = F 2^m intervals per line, F = 1, 3 or 5 (the reference's meshes are 5 x 10 coarse cells refined: 5 2^m), 2^m >= 16:
@@ -604,9 +606,12 @@ namespace adaflo_hip
               for (int i = 0; i < NLD; ++i)
                 {
                   const int    k = i < NLD - 1 ? r0 + i * TPL : N;
-                  const double d = A.cm + A.cl * (f.re + A.lz[k]);
-                  const double az = A.az[k], sc = f.im * az * fast_rcp(d); // (unconditional: a load behind the condition is a branch)
-                  res[i] *= (d > A.eps || d < -A.eps) ? sc : 0.;
+                  const double lam = f.re + A.lz[k], d = A.cm + A.cl * lam, d2 = A.cm2 + A.cl2 * lam;
+                  const double az = A.az[k]; // (unconditional: a load behind the condition is a branch)
+                  double       sc = (d > A.eps || d < -A.eps) ? fast_rcp(d) : 0.;
+                  if (A.cm2 != 0. || A.cl2 != 0.)
+                    sc += (d2 > A.eps || d2 < -A.eps) ? fast_rcp(d2) : 0.;
+                  res[i] *= f.im * az * sc;
                 }
               to_lds(res);
               __syncthreads();

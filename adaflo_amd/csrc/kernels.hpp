@@ -199,7 +199,8 @@ namespace adaflo_hip
   // fast-diagonalisation inverse of c_mass M + c_lap K on the velocity (field 0) / pressure (field 1)
   // space of the brick (fdm.hip); dst = src on constrained rows
   int  fdm_setup(adaflo_ctx *ctx);
-  int  fdm_apply(adaflo_ctx *ctx, int field, double *dst, const double *src, double c_mass, double c_lap);
+  int  fdm_apply(adaflo_ctx *ctx, int field, double *dst, const double *src, double c_mass, double c_lap,
+                 double c_mass2 = 0., double c_lap2 = 0.);
   void fdm_destroy(adaflo_ctx *ctx);
 
   // Q_k/Q_{k-1} sweep kernel for k = 3, 4, 5 (ns_ho.hip), constant coefficients

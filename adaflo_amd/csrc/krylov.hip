@@ -1129,11 +1129,20 @@ int adaflo_ns_preconditioner_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p
                         1. / (P.weight * std::min(P.density, P.density + P.density_diff));
   if (fdm)
     {
+      if (ctx->brick.con_p == 0u)
+        {
+          // M_p^-1 t + K_p^+ t (pseudo-inverse: the constant is dropped): both inverses are diagonal in the same modes --
+          // one application with the sum of the two scalings instead of two applications and an addition
+          if (int rc = fdm_apply(ctx, 1, dst_p, t, c_pm, 0., 0., ctx->ns.density > 0. ? c_pl : 0.))
+            return kfail(ctx, rc, "fast-diagonalisation solve failed");
+          return hipGetLastError() == hipSuccess ? 0 : kfail(ctx, ADAFLO_EHIP, "preconditioner kernels failed");
+        }
+      // (constrained pressure rows: each inverse returns its source there -- kept as two applications)
       if (int rc = fdm_apply(ctx, 1, dst_p, t, c_pm, 0.))
         return kfail(ctx, rc, "fast-diagonalisation solve failed");
       if (ctx->ns.density > 0.)
         {
-          if (int rc = fdm_apply(ctx, 1, t2, t, 0., c_pl)) // (pseudo-inverse: the constant is dropped)
+          if (int rc = fdm_apply(ctx, 1, t2, t, 0., c_pl))
             return kfail(ctx, rc, "fast-diagonalisation solve failed");
           hipLaunchKernelGGL(axpby_kernel, dim3(kgrid(np)), dim3(KT), 0, ctx->stream, dst_p, 1., t2, 1., np);
         }

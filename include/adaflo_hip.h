@@ -468,6 +468,11 @@ int adaflo_solve(adaflo_ctx *ctx, int op, int method, double *x, const double *b
  * transforms per scalar field.  dst = src on constrained rows; pseudo-inverse (null mode dropped) if
  * the operator is singular.  dst == src allowed.                                                  */
 int adaflo_fdm_apply(adaflo_ctx *ctx, int field, double *dst, const double *src, double c_mass, double c_lap);
+/* dst = [(c_mass M + c_lap K)^-1 + (c_mass2 M + c_lap2 K)^-1] src in ONE application (both inverses are diagonal in the
+ * same modes): the pressure mass + pressure Poisson inverses of the Schur complement approximation
+ * (navier_stokes_preconditioner.cc:712-733) for constant coefficients.  Unconstrained fields only. */
+int adaflo_fdm_apply_sum(adaflo_ctx *ctx, int field, double *dst, const double *src, double c_mass, double c_lap,
+                         double c_mass2, double c_lap2);
 /* dst = (projection matrix)^-1 rhs per scalar block, exactly: what the reference's normal and curvature
  * solves approximate with CG + ILU on the assembled matrix (level_set_okz_compute_normal.cc:252-267,
  * level_set_okz_compute_curvature.cc:345-355).  n_blocks = 3 for the normal vector field.  Needs an

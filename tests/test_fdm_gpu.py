@@ -206,3 +206,21 @@ def test_fast_cosine_transforms_of_the_q1_pressure_space():
     zs = op.initialize_p_vector(got)
     op.pressure_poisson_vmult(xs, zs)
     assert rel_l2(xs.numpy(), ys.numpy()) < 1e-9
+
+
+@pytest.mark.parametrize("ncell,env", [((64, 64, 128), None), ((20, 20, 40), None), ((5, 4, 6), None), ((64, 32, 16), "1")])
+def test_sum_of_two_inverses_in_one_application(ncell, env, monkeypatch):
+    """adaflo_fdm_apply_sum: pressure mass + pressure Poisson (pseudo-)inverse of the Schur complement approximation as ONE
+    fast-diagonalisation application (what the block preconditioner runs for constant coefficients) = the sum of the two
+    separate applications, through the cosine transforms and through the matrix products (small grid / ADAFLO_FDM_NO_DCT)"""
+    if env:
+        monkeypatch.setenv("ADAFLO_FDM_NO_DCT", env)
+    case = Case(ncell, k=2, upper=(1.0, 1.0, 2.0), viscosity=0.3, tau_grad_div=0.2)
+    op = case.engine()
+    ctx = op._require()
+    x = np.random.default_rng(8).uniform(-1, 1, case.n_p)
+    c_pm, c_pl = 1.0 / (0.3 + 0.2), 1.0 / case.ts.weight()
+    ref = _fdm(op, 1, x, c_pm, 0.0) + _fdm(op, 1, x, 0.0, c_pl)
+    s, d = adaflo_amd.DeviceVector.from_numpy(ctx, x), adaflo_amd.DeviceVector(ctx, x.size)
+    _lib.check(ctx, _lib.load().adaflo_fdm_apply_sum(ctx, 1, d.ptr, s.ptr, c_pm, 0.0, 0.0, c_pl))
+    assert rel_l2(d.numpy(), ref) < 1e-12
