@@ -602,15 +602,16 @@ namespace adaflo_hip
               finish(res);
               __syncthreads();
               const cplx f = F[c]; // (an absent line: ax ay = 0)
+              const bool second = A.cm2 != 0. || A.cl2 != 0.;
 #pragma unroll
               for (int i = 0; i < NLD; ++i)
                 {
                   const int    k = i < NLD - 1 ? r0 + i * TPL : N;
                   const double lam = f.re + A.lz[k], d = A.cm + A.cl * lam, d2 = A.cm2 + A.cl2 * lam;
                   const double az = A.az[k]; // (unconditional: a load behind the condition is a branch)
-                  double       sc = (d > A.eps || d < -A.eps) ? fast_rcp(d) : 0.;
-                  if (A.cm2 != 0. || A.cl2 != 0.)
-                    sc += (d2 > A.eps || d2 < -A.eps) ? fast_rcp(d2) : 0.;
+                  // (selects only: seventeen branches here put 350 B per lane into scratch)
+                  const double r1 = fast_rcp(d), r2 = fast_rcp(d2);
+                  const double sc = ((d > A.eps || d < -A.eps) ? r1 : 0.) + ((second && (d2 > A.eps || d2 < -A.eps)) ? r2 : 0.);
                   res[i] *= f.im * az * sc;
                 }
               to_lds(res);
