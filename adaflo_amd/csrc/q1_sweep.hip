@@ -121,17 +121,41 @@ namespace adaflo_hip
       const bool     conz_lo = A.con >> 4 & 1, conz_hi = A.con >> 5 & 1;
       const unsigned lane_g  = (unsigned)((J0 + sy) * A.nnx + I0 + sx);
 
-      auto load_plane = [&](const int K, double *p) {
-        for (int e = tid; e < TNQ * TNQ; e += NTQ)
+      // Node planes travel global -> registers (issued ONE LAYER AHEAD, unconditionally: an absent node reads element 0 and
+      // is replaced by zero when the value is committed) -> LDS.  Loaded straight into LDS behind `in ? load : 0` -- a
+      // branch per element, the data needed on the spot -- the planes cost the nodal modes a quarter of their time
+      // (reinitialisation operator 1.21 -> 0.93 ms without them, scripts/dev/exp_q1.sh).
+      constexpr int NPF = NODAL ? 4 : 1, NPE = (TNQ * TNQ + NTQ - 1) / NTQ;
+      double        pf[NPF][NPE];
+      auto fetch_plane = [&](const int K) {
+#pragma unroll
+        for (int r = 0; r < NPE; ++r)
           {
-            const int  i = e % TNQ, j = e / TNQ, I = I0 + i, J = J0 + j;
-            const bool in = I < A.nnx && J < A.nny && K < A.nnz;
-            const size_t g = ((size_t)K * A.nny + J) * A.nnx + I;
-            p[e] = in ? src_c[g] : 0.;
+            const int    e = tid + NTQ * r, i = e % TNQ, j = e / TNQ, I = I0 + i, J = J0 + j;
+            const bool   in = e < TNQ * TNQ && I < A.nnx && J < A.nny && K < A.nnz;
+            const size_t g = in ? ((size_t)K * A.nny + J) * A.nnx + I : 0;
+            pf[0][r] = src_c[g];
             if (NODAL)
 #pragma unroll
               for (int c = 0; c < 3; ++c)
-                pln[((K & 1) * 3 + c) * (TNQ * TNQ) + e] = in ? A.state[c * A.comp_stride + g] : 0.;
+                pf[NODAL ? 1 + c : 0][r] = A.state[c * A.comp_stride + g];
+          }
+      };
+      auto commit_plane = [&](const int K) {
+        double *p = pl[K & 1];
+#pragma unroll
+        for (int r = 0; r < NPE; ++r)
+          {
+            const int  e = tid + NTQ * r, i = e % TNQ, j = e / TNQ, I = I0 + i, J = J0 + j;
+            const bool in = I < A.nnx && J < A.nny && K < A.nnz;
+            if (e < TNQ * TNQ)
+              {
+                p[e] = in ? pf[0][r] : 0.;
+                if (NODAL)
+#pragma unroll
+                  for (int c = 0; c < 3; ++c)
+                    pln[((K & 1) * 3 + c) * (TNQ * TNQ) + e] = in ? pf[NODAL ? 1 + c : 0][r] : 0.;
+              }
           }
       };
       // store of one owned node value (constrained rows, slabs, plain stores)
@@ -172,13 +196,30 @@ namespace adaflo_hip
               }
         }
       double carry[4] = {0., 0., 0., 0.}; // top-plane sums of the owned nodes, kept for the next layer
-      load_plane(cz0, pl[cz0 & 1]);
+      // (the nodal advection mode is capped at 168 registers for three workgroups per CU: there the two more values in
+      // flight cost more in scratch than the prefetch gains -- measured 1.29 vs 1.26 ms --, its planes are loaded on the spot)
+#if defined(Q1_SYNC_PLANES)
+      constexpr bool PLANES_AHEAD = false;
+#else
+      constexpr bool PLANES_AHEAD = !NODALV;
+#endif
+      fetch_plane(cz0);
+      commit_plane(cz0);
+      if (PLANES_AHEAD)
+        fetch_plane(cz0 + 1);
       const double2 *state = reinterpret_cast<const double2 *>(A.state);
 
       for (int layer = 0; layer < nl; ++layer)
         {
           const int cz = cz0 + layer;
-          load_plane(cz + 1, pl[(cz + 1) & 1]);
+          if (!PLANES_AHEAD)
+            fetch_plane(cz + 1);
+          commit_plane(cz + 1); // (PLANES_AHEAD: fetched during the previous layer; the slot was last read two layers ago)
+#if defined(Q1_EXP_NOLOAD)      // (diagnostic, wrong results: what the plane loads cost)
+          if (layer < 0)
+#endif
+          if (PLANES_AHEAD)
+            fetch_plane(cz + 2);
           // quadrature-point state of this sub-cell: issued before the barrier, used after it
           double2 st[12];
           double  cf[27];
@@ -883,6 +924,8 @@ namespace adaflo_hip
       // node planes: global -> registers (issued one layer ahead) -> LDS (after the layer's reads)
       constexpr int NLD = (PL + NTQ - 1) / NTQ;
       double        pre[NF][NLD];
+      // (unconditional loads: an absent node reads element 0 and becomes zero when the plane is committed -- behind
+      // `in ? load : 0` every element was a branch with a wait at its join)
       auto fetch_plane = [&](const int K) {
 #pragma unroll
         for (int f = 0; f < NF; ++f)
@@ -890,18 +933,24 @@ namespace adaflo_hip
 #pragma unroll
             for (int r = 0; r < NLD; ++r)
               {
-                const int e = tid + NTQ * r, i = e % TNQ, j = e / TNQ, I = I0 + i, J = J0 + j;
-                pre[f][r]   = (e < PL && I < A.nnx && J < A.nny && K < A.nnz) ? R.f[f][((size_t)K * A.nny + J) * A.nnx + I] : 0.;
+                const int    e = tid + NTQ * r, i = e % TNQ, j = e / TNQ, I = I0 + i, J = J0 + j;
+                const bool   in = e < PL && I < A.nnx && J < A.nny && K < A.nnz;
+                pre[f][r]       = R.f[f][in ? ((size_t)K * A.nny + J) * A.nnx + I : 0];
               }
       };
-      auto commit_plane = [&](const int slot) {
+      auto commit_plane = [&](const int K) {
+        const int slot = K & 1;
 #pragma unroll
         for (int f = 0; f < NF; ++f)
           if (f < R.nf)
 #pragma unroll
             for (int r = 0; r < NLD; ++r)
-              if (tid + NTQ * r < PL)
-                pl[(slot * NF + f) * PL + tid + NTQ * r] = pre[f][r];
+              {
+                const int  e = tid + NTQ * r, i = e % TNQ, j = e / TNQ, I = I0 + i, J = J0 + j;
+                const bool in = I < A.nnx && J < A.nny && K < A.nnz;
+                if (e < PL)
+                  pl[(slot * NF + f) * PL + e] = in ? pre[f][r] : 0.;
+              }
       };
       // (the owner adds into dst: the old values are fetched at the top of the layer)
       double dold[4];
@@ -952,9 +1001,9 @@ namespace adaflo_hip
 
       double carry[4] = {0., 0., 0., 0.};
       fetch_plane(cz0);
-      commit_plane(cz0 & 1);
+      commit_plane(cz0);
       fetch_plane(cz0 + 1);
-      commit_plane((cz0 + 1) & 1);
+      commit_plane(cz0 + 1);
       __syncthreads();
       for (int layer = 0; layer < nl; ++layer)
         {
@@ -1131,7 +1180,7 @@ namespace adaflo_hip
             }
           __syncthreads();
           if (layer + 1 < nl) // every lane has read planes cz, cz + 1: plane cz + 2 takes the slot of cz
-            commit_plane(cz & 1);
+            commit_plane(cz + 2);
 #pragma unroll
           for (int lk = 0; lk < 2; ++lk)
             {
