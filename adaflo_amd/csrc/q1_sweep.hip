@@ -246,9 +246,9 @@ namespace adaflo_hip
               for (int e = tid; e < 3 * wn * wn; e += NTQ)
                 {
                   const int comp = e % 3, ix = (e / 3) % wn, jy = e / (3 * wn);
-                  const int I = vx0 + ix, J = vy0 + jy;
+                  // (patch entries beyond the mesh are never read: clamped, so that the loads are unconditional)
+                  const int I = min(vx0 + ix, A.vnx - 1), J = min(vy0 + jy, A.vny - 1);
                   double    w0 = 0., w1 = 0.;
-                  if (I < A.vnx && J < A.vny)
 #pragma unroll
                     for (int k = 0; k <= KU; ++k)
                       {
@@ -1033,9 +1033,9 @@ namespace adaflo_hip
               for (int e = tid; e < 3 * wn * wn; e += NTQ)
                 {
                   const int comp = e % 3, ix = (e / 3) % wn, jy = e / (3 * wn);
-                  const int I = vx0 + ix, J = vy0 + jy;
+                  // (patch entries beyond the mesh are never read: clamped, so that the loads are unconditional)
+                  const int I = min(vx0 + ix, R.vnx - 1), J = min(vy0 + jy, R.vny - 1);
                   double    w0 = 0., w1 = 0.;
-                  if (I < R.vnx && J < R.vny)
 #pragma unroll
                     for (int k = 0; k <= KU; ++k)
                       {
