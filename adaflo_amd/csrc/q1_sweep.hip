@@ -649,34 +649,44 @@ namespace adaflo_hip
               const int  ppc = A.LZ + 1, c_hi = min(K / A.LZ, A.n_chunks - 1), lp = K - A.LZ * c_hi;
               const bool zb = lp == 0 && c_hi > 0;
               const bool zc = (K == 0 && (A.con >> 4 & 1)) || (K == A.nnz - 1 && (A.con >> 5 & 1));
+              // (straight-line: every load unconditional with a clamped address and issued before the first use, absent
+              // terms deselected afterwards -- the loop over the sharers with its loads behind branches was a chain of three
+              // to five dependent memory round trips per node; same order of the additions)
               for (int e = threadIdx.x; e < 2 * TNQ - 1; e += 64)
                 {
-                  const int i = e < TNQ ? e : 0, j = e < TNQ ? 0 : e - TNQ + 1;
-                  const int I = TS * bx + i, J = TS * by + j;
-                  if (I >= A.nnx || J >= A.nny)
-                    continue;
+                  const int  i = e < TNQ ? e : 0, j = e < TNQ ? 0 : e - TNQ + 1;
+                  const int  I = TS * bx + i, J = TS * by + j;
+                  const bool inside = I < A.nnx && J < A.nny;
                   const bool seam_x = i == 0 && I > 0, seam_y = j == 0 && J > 0;
-                  if (!(seam_x || seam_y) || (i == TS && I < A.nnx - 1) || (j == TS && J < A.nny - 1))
-                    continue;
-                  const bool c = zc || (I == 0 && (A.con >> 0 & 1)) || (I == A.nnx - 1 && (A.con >> 1 & 1)) ||
-                                 (J == 0 && (A.con >> 2 & 1)) || (J == A.nny - 1 && (A.con >> 3 & 1));
-                  if (c)
-                    continue;
-                  double sum = 0.;
-                  for (int dy = 0; dy <= (seam_y ? 1 : 0); ++dy)
-                    for (int dx = 0; dx <= (seam_x ? 1 : 0); ++dx)
-                      {
-                        if (dx == 0 && dy == 0)
-                          continue;
-                        const long tb = (long)(by - dy) * A.tiles_x + bx - dx;
-                        const int  r  = rim_index_q<TNQ>(i + TS * dx, j + TS * dy);
-                        sum += A.slab[((tb * A.n_chunks + c_hi) * ppc + lp) * RIMQ + r];
-                        if (zb)
-                          sum += A.slab[((tb * A.n_chunks + c_hi - 1) * ppc + A.LZ) * RIMQ + r];
-                      }
-                  if (zb)
-                    sum += A.zslab[(bt * A.n_chunks + c_hi - 1) * (TNQ * TNQ) + j * TNQ + i];
-                  A.dst[((size_t)K * A.nny + J) * A.nnx + I] += sum;
+                  const bool con = zc || (I == 0 && (A.con >> 0 & 1)) || (I == A.nnx - 1 && (A.con >> 1 & 1)) ||
+                                   (J == 0 && (A.con >> 2 & 1)) || (J == A.nny - 1 && (A.con >> 3 & 1));
+                  const bool act = inside && (seam_x || seam_y) && !((i == TS && I < A.nnx - 1) || (j == TS && J < A.nny - 1)) && !con;
+                  // the sharers (dx, dy) = (1, 0), (0, 1), (1, 1); an absent one reads from this tile, entry 0
+                  const bool has[3] = {seam_x, seam_y, seam_x && seam_y};
+                  double     hi[3], lo[3];
+#pragma unroll
+                  for (int q = 0; q < 3; ++q)
+                    {
+                      const int  dx = q != 1 ? 1 : 0, dy = q != 0 ? 1 : 0;
+                      const bool ok = act && has[q];
+                      const long tb = ok ? (long)(by - dy) * A.tiles_x + bx - dx : bt;
+                      const int  r  = ok ? rim_index_q<TNQ>(i + TS * dx, j + TS * dy) : 0;
+                      hi[q] = A.slab[((tb * A.n_chunks + c_hi) * ppc + lp) * RIMQ + r];
+                      lo[q] = A.slab[((tb * A.n_chunks + (zb ? c_hi - 1 : c_hi)) * ppc + (zb ? A.LZ : lp)) * RIMQ + r];
+                    }
+                  const double zs = A.zslab[(bt * A.n_chunks + (zb ? c_hi - 1 : 0)) * (TNQ * TNQ) + j * TNQ + i];
+                  const size_t idx = ((size_t)K * A.nny + min(J, A.nny - 1)) * A.nnx + min(I, A.nnx - 1);
+                  const double old = A.dst[idx];
+                  double       sum = 0.;
+#pragma unroll
+                  for (int q = 0; q < 3; ++q)
+                    {
+                      sum += has[q] ? hi[q] : 0.;
+                      sum += has[q] && zb ? lo[q] : 0.;
+                    }
+                  sum += zb ? zs : 0.;
+                  if (act)
+                    A.dst[idx] = old + sum;
                 }
             }
           else
