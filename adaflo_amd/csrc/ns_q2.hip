@@ -1448,6 +1448,7 @@ namespace adaflo_hip
       const int     c_hi = min(K / (DEG * A.LZ), A.n_chunks - 1);
       const int     lp   = K - DEG * A.LZ * c_hi;
       const bool    zb   = lp == 0 && c_hi > 0; // K is the top plane of the chunk below as well
+#if defined(Q2_FIXUP_LOOP) // (the form of rounds 1-3, kept for A/B timing: loads behind branches, one dependent chain per node)
       for (int e = threadIdx.x & 63; e < NE; e += 64)
         {
           const int comp = e % NC, s = e / NC;
@@ -1481,6 +1482,50 @@ namespace adaflo_hip
             sum += zslab[((bt * A.n_chunks + c_hi - 1) * (TN * TN) + j * TN + i) * NC + comp];
           dst[((long)(K * (long)nn_y + J) * nn_x + I) * NC + comp] += sum;
         }
+#else
+      // Straight-line: every load unconditional with a clamped address and issued before the first use, absent terms
+      // deselected afterwards, the additions in the order of the loop above (bitwise the same sums).
+      for (int e = threadIdx.x & 63; e < NE; e += 64)
+        {
+          const int  comp = e % NC, s = e / NC;
+          const int  i = s < TN ? s : 0, j = s < TN ? 0 : s - TN + 1; // south row, then west column
+          const int  I = DEG * TX * bx + i, J = DEG * TY * by + j;
+          const bool seam_x = i == 0 && I > 0, seam_y = j == 0 && J > 0;
+          // (a node on this tile's HIGH rim in the other direction belongs to another owner; on a constrained face
+          // dst = +-src was written by every sharer)
+          const bool act = I < nn_x && J < nn_y && (seam_x || seam_y) &&
+                           !((i == TN - 1 && I < nn_x - 1) || (j == TN - 1 && J < nn_y - 1)) &&
+                           !on_constrained_face(I, J, K, nn_x, nn_y, nn_z, con, NC == 1 ? 1 : 3, comp) &&
+                           !fix_skip(A, I, J, K, nn_x, nn_y, nn_z);
+          // the sharers (dx, dy) = (1, 0), (0, 1), (1, 1); an absent one reads from this tile, entry 0
+          const bool has[3] = {seam_x, seam_y, seam_x && seam_y};
+          double     hi[3], lo[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            {
+              const int  dx = q != 1 ? 1 : 0, dy = q != 0 ? 1 : 0;
+              const bool ok = act && has[q];
+              const long tb = ok ? (long)(by - dy) * A.tiles_x + bx - dx : bt;
+              const int  r  = ok ? rim_index<TN>(i + (TN - 1) * dx, j + (TN - 1) * dy) : 0;
+              hi[q] = slab[(((tb * A.n_chunks + c_hi) * ppc + lp) * RIM + r) * NC + comp];
+              lo[q] = slab[(((tb * A.n_chunks + (zb ? c_hi - 1 : c_hi)) * ppc + (zb ? DEG * A.LZ : lp)) * RIM + r) * NC + comp];
+            }
+          // this tile's own partial of the chunk below
+          const double zs  = zslab[((bt * A.n_chunks + (zb ? c_hi - 1 : 0)) * (TN * TN) + j * TN + i) * NC + comp];
+          const long   idx = ((long)(K * (long)nn_y + min(J, nn_y - 1)) * nn_x + min(I, nn_x - 1)) * NC + comp;
+          const double old = dst[idx];
+          double       sum = 0.;
+#pragma unroll
+          for (int q = 0; q < 3; ++q)
+            {
+              sum += has[q] ? hi[q] : 0.;
+              sum += has[q] && zb ? lo[q] : 0.;
+            }
+          sum += zb ? zs : 0.;
+          if (act)
+            dst[idx] = old + sum;
+        }
+#endif
     }
 
     // interior (non-seam) nodes of a chunk-boundary plane: dst (bottom partial of the upper chunk)
