@@ -57,6 +57,12 @@ class CommUniqueId(C.Structure):
 
 _I64P = C.POINTER(C.c_int64)
 _INTP = C.POINTER(C.c_int)
+class MinMaxAvg(C.Structure):
+    """adaflo_min_max_avg = dealii::Utilities::MPI::MinMaxAvg"""
+    _fields_ = [("sum", C.c_double), ("min", C.c_double), ("max", C.c_double), ("avg", C.c_double),
+                ("min_index", C.c_int), ("max_index", C.c_int)]
+
+
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _D, _I64P, _I64P, _INTP, C.c_int, _D, _I64P, _I64P, _INTP, C.c_int,
                           C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _D, C.c_int, C.c_void_p)
@@ -115,6 +121,7 @@ SIGNATURES = {
     "adaflo_comm_compress_add": (C.c_int, [_COMM, _D, _D]),
     "adaflo_ns_vmult_distributed": (C.c_int, [_CTX, _COMM, _D, _D, _D, _D, C.c_int]),
     "adaflo_comm_force_phased_schedule": (C.c_int, [_COMM, C.c_int]),
+    "adaflo_comm_matvec_statistics": (C.c_int, [_COMM, C.POINTER(C.c_uint), C.POINTER(MinMaxAvg)]),
     "adaflo_ls_set_params": (C.c_int, [_CTX, C.POINTER(LSParams)]),
     "adaflo_ls_set_diagonal": (C.c_int, [_CTX, _D]),
     "adaflo_ls_set_evaluated_convection": (C.c_int, [_CTX, C.c_void_p, C.c_int]),

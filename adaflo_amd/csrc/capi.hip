@@ -622,6 +622,8 @@ int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx)
       ctx->lin_prec_gen++;
       ctx->hox_lin_prec_gen       = ctx->lin_prec_gen;
       ctx->hox_lin_prec_mode      = ctx->hox_lin_mode;
+      ctx->hox_lin_prec_varco     = false; // the copy carries no coefficient pieces (a flag left by an earlier
+                                           // variable-coefficient vmult would send prepare_state to the stale generic copy)
       ctx->hox_lin_prec_primary   = true;
       ctx->lin_prec_generic_valid = false;
       release(ctx->rho_prec), release(ctx->mu_prec), release(ctx->damp_prec); // (the residual mode runs with constant coefficients only)

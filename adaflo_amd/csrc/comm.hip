@@ -126,6 +126,10 @@ struct adaflo_comm
   double *w_owned = nullptr, *d_inv = nullptr, *d_dot = nullptr;
   bool    projection = false;
   bool    force_phased = false; // measurement aid: the three-phase schedule also with world == 1
+  // get_matvec_statistics (:1194-1206): device time of every adaflo_ns_vmult_distributed of this rank, events on the
+  // engine stream around the whole sequence (the stream waits for both exchanges inside it)
+  adaflo_hip::EventTimer matvec_timer;
+  double                *d_stats = nullptr; // `world` doubles for the reduction of the per-rank times
   std::string last_error;
 };
 
@@ -504,9 +508,10 @@ int adaflo_comm_destroy(adaflo_comm *c)
     (void)hipStreamSynchronize(c->comm_stream);
   if (c->nccl)
     (void)rccl().CommDestroy(c->nccl);
-  for (double *p : {c->sbuf, c->rbuf, c->d_inv, c->w_owned})
+  for (double *p : {c->sbuf, c->rbuf, c->d_inv, c->w_owned, c->d_stats})
     if (p)
       (void)hipFree(p);
+  c->matvec_timer.destroy();
   if (c->ev_packed)
     (void)hipEventDestroy(c->ev_packed);
   if (c->ev_arrived)
@@ -544,6 +549,52 @@ int adaflo_comm_compress_add(adaflo_comm *c, double *vec_u, double *vec_p)
   return exchange_finish(c, c->add, vec_u, vec_p, true);
 }
 
+// NavierStokesMatrix::get_matvec_statistics (navier_stokes_matrix.cc:1194-1206): Utilities::MPI::min_max_avg of the
+// accumulated vmult time over the communicator, the number of applications, counters reset.  Collective.
+int adaflo_comm_matvec_statistics(adaflo_comm *c, unsigned *count, adaflo_min_max_avg *stats)
+{
+  if (!c || !c->ctx)
+    return ADAFLO_EINVAL;
+  adaflo_ctx *ctx = c->ctx;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+    return cfail(c, ADAFLO_EHIP, "synchronize failed");
+  c->matvec_timer.fold();
+  const double mine = c->matvec_timer.seconds;
+  if (count)
+    *count = c->matvec_timer.count;
+  c->matvec_timer.count   = 0;
+  c->matvec_timer.seconds = 0.;
+  std::vector<double> all((size_t)c->world, 0.);
+  all[c->rank] = mine;
+  if (c->world > 1)
+    {
+      // every rank contributes its time at its own position, zeros elsewhere: one sum gives all ranks all times
+      if (!c->d_stats && hipMalloc(&c->d_stats, c->world * sizeof(double)) != hipSuccess)
+        return cfail(c, ADAFLO_ENOMEM, "allocation failed");
+      if (hipMemcpyAsync(c->d_stats, all.data(), c->world * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return cfail(c, ADAFLO_EHIP, "copy failed");
+      if (int e = transport_allreduce(c, c->d_stats, c->world, ctx->stream))
+        return e;
+      if (hipMemcpyAsync(all.data(), c->d_stats, c->world * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return cfail(c, ADAFLO_EHIP, "copy failed");
+    }
+  if (stats)
+    {
+      stats->sum = 0., stats->min = all[0], stats->max = all[0], stats->min_index = 0, stats->max_index = 0;
+      for (int r = 0; r < c->world; ++r)
+        {
+          stats->sum += all[r];
+          if (all[r] < stats->min)
+            stats->min = all[r], stats->min_index = r;
+          if (all[r] > stats->max)
+            stats->max = all[r], stats->max_index = r;
+        }
+      stats->avg = stats->sum / c->world;
+    }
+  return 0;
+}
+
 int adaflo_comm_force_phased_schedule(adaflo_comm *c, int enabled)
 {
   if (!c)
@@ -559,6 +610,21 @@ int adaflo_ns_vmult_distributed(adaflo_ctx *ctx, adaflo_comm *c, double *dst_u, 
     return ADAFLO_EINVAL;
   // (every sweep kernel has the three-phase form: Q2/Q1 with constant or variable coefficients, Q3..Q5)
   const bool phased = (c->world > 1 || c->force_phased) && adaflo_ns_supports_phases(ctx) != 0;
+  struct Timed
+  {
+    adaflo_comm *c;
+    hipEvent_t   stop;
+    explicit Timed(adaflo_comm *cc)
+      : c(cc)
+      , stop(cc->ctx->timing ? cc->matvec_timer.start(cc->ctx->stream) : nullptr)
+    {}
+    ~Timed()
+    {
+      if (stop)
+        (void)hipEventRecord(stop, c->ctx->stream);
+      c->matvec_timer.count++;
+    }
+  } timed(c);
   if (c->world == 1 && !phased)
     {
       // (the context was created without the local mean-value fix when a communicator takes care of it)

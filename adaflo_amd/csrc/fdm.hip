@@ -271,6 +271,7 @@ namespace adaflo_hip
       int           scale = 0, scale_nx = 0, scale_i0 = 0;
       double        scale_cm = 0., scale_cl = 0., scale_eps = 0.;
       double        scale_cm2 = 0., scale_cl2 = 0.; // a second inverse of the same modes, added (both 0: none)
+      double        scale_eps2 = 0.;                // ... with the null-mode threshold of ITS scale
     };
     typedef double d4_t __attribute__((ext_vector_type(4)));
     // FM: 0 plain, 1 / 2 the field operand A / B is folded on load, 3 / 4 mirrored stores along j / i (GemmArgs)
@@ -398,7 +399,7 @@ namespace adaflo_hip
                       const bool   pad = a < 0. || b < 0. || l < 0.;
                       double       v = (pad || std::abs(d) <= g.scale_eps) ? 0. : acc[r][c][q] / d;
                       if (g.scale_cm2 != 0. || g.scale_cl2 != 0.)
-                        v += (pad || std::abs(d2) <= g.scale_eps) ? 0. : acc[r][c][q] / d2;
+                        v += (pad || std::abs(d2) <= g.scale_eps2) ? 0. : acc[r][c][q] / d2;
                       C[idx] = v;
                     }
                   else if (FM < 3)
@@ -771,6 +772,7 @@ namespace adaflo_hip
     const double *lx, *ly, *lz;
     double        cm, cl, eps;
     double        cm2 = 0., cl2 = 0.; // a second inverse applied to the same source and added
+    double        eps2 = 0.;          // null-mode threshold of the second operator (its own scale)
   };
   static int transform_axis(adaflo_ctx *ctx, const int axis, const bool backward, const Eig1D &E, const double *in, double *out,
                             const int nx, const int ny, const int nz, const int nstack = 1, const ModeScaling *sc = nullptr)
@@ -809,7 +811,7 @@ namespace adaflo_hip
             g.scale = 1, g.scale_nx = nx, g.scale_i0 = 0;
             g.lx = sc->lx, g.ly = sc->ly, g.lz = sc->lz;
             g.scale_cm = sc->cm, g.scale_cl = sc->cl, g.scale_eps = sc->eps;
-            g.scale_cm2 = sc->cm2, g.scale_cl2 = sc->cl2;
+            g.scale_cm2 = sc->cm2, g.scale_cl2 = sc->cl2, g.scale_eps2 = sc->eps2;
           }
       }
     static const bool no_fold = getenv("ADAFLO_FDM_NO_FOLD") != nullptr; // (tests / timing of the plain transforms)
@@ -874,9 +876,10 @@ namespace adaflo_hip
     const uint32_t  mask = field == 0 ? ctx->brick.con_u : (field == 1 ? ctx->brick.con_p : ctx->brick.con_ls);
     const unsigned  nb = (unsigned)std::min<long>((n + 255) / 256, 16384);
     // the null mode of a singular operator: |c_m + c_l sum(lambda)| relative to c_l lambda_max
-    double eps = 1e-10 * (std::abs(c_mass) + std::abs(c_lap) * 12. / (ctx->desc.h[0] * ctx->desc.h[0]));
-    if (c_mass2 != 0. || c_lap2 != 0.)
-      eps = std::min(eps, 1e-10 * (std::abs(c_mass2) + std::abs(c_lap2) * 12. / (ctx->desc.h[0] * ctx->desc.h[0])));
+    // (each operator against its OWN scale: with one shared threshold the round-off null eigenvalue of a singular
+    // Poisson part of pressure degree >= 2, ~1e-16 lambda_max, can pass the smaller threshold of the mass part)
+    const double eps = 1e-10 * (std::abs(c_mass) + std::abs(c_lap) * 12. / (ctx->desc.h[0] * ctx->desc.h[0]));
+    const double eps2 = 1e-10 * (std::abs(c_mass2) + std::abs(c_lap2) * 12. / (ctx->desc.h[0] * ctx->desc.h[0]));
     // components with the same 1D problems in all directions (the same kind of boundary for every component) go through
     // the transforms together: a third of the launches, three times the work per launch (129^3 velocity nodes:
     // 27 launches of 10-37 us -> 9)
@@ -900,7 +903,7 @@ namespace adaflo_hip
             dct::DctArgs A{};
             A.nx = nx, A.ny = ny, A.nz = nz;
             A.lx = ex.d_lamn, A.ly = ey.d_lamn, A.lz = ez.d_lamn, A.ax = ex.d_a2, A.ay = ey.d_a2, A.az = ez.d_a2;
-            A.cm = c_mass, A.cl = c_lap, A.eps = eps, A.cm2 = c_mass2, A.cl2 = c_lap2;
+            A.cm = c_mass, A.cl = c_lap, A.eps = eps, A.cm2 = c_mass2, A.cl2 = c_lap2, A.eps2 = eps2;
             const double *in[5]  = {src, B, Cb, B, Cb};
             double       *out[5] = {B, Cb, B, Cb, dst};
             const int     axis[5] = {0, 1, 2, 1, 0};
@@ -919,7 +922,7 @@ namespace adaflo_hip
           return e;
         if (int e = transform_axis(ctx, 1, false, ey, B, Cb, nx, ny, nz))
           return e;
-        const ModeScaling sc{ex.d_lam, ey.d_lam, ez.d_lam, c_mass, c_lap, eps, c_mass2, c_lap2};
+        const ModeScaling sc{ex.d_lam, ey.d_lam, ez.d_lam, c_mass, c_lap, eps, c_mass2, c_lap2, eps2};
         if (int e = transform_axis(ctx, 2, false, ez, Cb, B, nx, ny, nz, 1, &sc))
           return e;
         if (int e = transform_axis(ctx, 0, true, ex, B, Cb, nx, ny, nz))
@@ -949,7 +952,7 @@ namespace adaflo_hip
               return e;
             if (int e = transform_axis(ctx, 1, dir == 1, ey, w1, w0, nx, ny, nz, nstack))
               return e;
-            const ModeScaling sc{ex.d_lam, ey.d_lam, ez.d_lam, c_mass, c_lap, eps, c_mass2, c_lap2};
+            const ModeScaling sc{ex.d_lam, ey.d_lam, ez.d_lam, c_mass, c_lap, eps, c_mass2, c_lap2, eps2};
             if (int e = transform_axis(ctx, 2, dir == 1, ez, w0, w1, nx, ny, nz, nstack, dir == 0 ? &sc : nullptr))
               return e;
             std::swap(w0, w1); // the result of this direction is the input of the next

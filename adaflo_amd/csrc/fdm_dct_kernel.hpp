@@ -73,7 +73,7 @@ namespace adaflo_hip
       const double *lx, *ly, *lz, *ax, *ay, *az;
       double        cm, cl, eps;
       // a second inverse applied to the same source and added (cm2 == cl2 == 0: none): both are diagonal in the same modes
-      double        cm2, cl2;
+      double        cm2, cl2, eps2;
     };
 
     // N = F 2^m intervals per line, F = 1, 3 or 5 (the reference's meshes are 5 x 10 coarse cells refined: 5 2^m), 2^m >= 16:
@@ -611,7 +611,7 @@ namespace adaflo_hip
                   const double az = A.az[k]; // (unconditional: a load behind the condition is a branch)
                   // (selects only: seventeen branches here put 350 B per lane into scratch)
                   const double r1 = fast_rcp(d), r2 = fast_rcp(d2);
-                  const double sc = ((d > A.eps || d < -A.eps) ? r1 : 0.) + ((second && (d2 > A.eps || d2 < -A.eps)) ? r2 : 0.);
+                  const double sc = ((d > A.eps || d < -A.eps) ? r1 : 0.) + ((second && (d2 > A.eps2 || d2 < -A.eps2)) ? r2 : 0.);
                   res[i] *= f.im * az * sc;
                 }
               to_lds(res);

@@ -1177,7 +1177,10 @@ int adaflo_ns_preconditioner_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p
       // ratio instead of h^-2.  With the Jacobi diagonal the solve ran into its 30-iteration cap every time.
       if (ctx->pc_inner == 1 && ctx->pc_poisson_fdm) // (set_inner(0) keeps the all-Jacobi solves the oracle mirrors)
         K.P = [ctx, c_pl](double *d, const double *s) { return fdm_apply(ctx, 1, d, s, 0., c_pl); };
-      else if (ctx->flat_y) // dim = 1: the Laplacian is tridiagonal -- exact inverse (the reference has ILU here: exact too)
+      else if (ctx->flat_y && ctx->desc.velocity_degree == 2)
+        // dim = 1, Q1 pressure: the Laplacian is (1/h) tridiag(-1, 2, -1) -- exact inverse by the Thomas algorithm (the
+        // reference has ILU here: exact too).  A Q2 pressure (velocity degree 3) has a pentadiagonal matrix on 2n + 1
+        // nodes: that case keeps the Jacobi diagonal (K.inv_diag) instead of inverting the wrong operator
         K.P = [ctx, np](double *d, const double *s) {
           double *work = persistent(ctx->pc_tridiag, (size_t)np);
           if (!work)

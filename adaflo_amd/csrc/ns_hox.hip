@@ -333,6 +333,7 @@ namespace adaflo_hip
           ctx->lin_gen++;
           ctx->hox_lin_gen       = ctx->lin_gen;
           ctx->hox_lin_mode      = lin_mode;
+          ctx->hox_lin_varco     = false; // (the residual mode runs with constant coefficients: no rho / mu pieces)
           ctx->hox_lin_primary   = true;
           ctx->lin_generic_valid = false;
           ctx->lin_q2_valid      = false;

@@ -405,6 +405,15 @@ class NativeCommunicator:
         """measurement aid: the three-phase schedule also with one rank (bench.py --through-comm)"""
         self._check(self._lib.adaflo_comm_force_phased_schedule(self.handle, int(enabled)))
 
+    def matvec_statistics(self):
+        """get_matvec_statistics over the ranks (navier_stokes_matrix.cc:1194-1206): (count, MinMaxAvg of the
+        accumulated seconds); collective, resets the counters"""
+        import ctypes as C
+        from . import _lib
+        n, st = C.c_uint(0), _lib.MinMaxAvg()
+        self._check(self._lib.adaflo_comm_matvec_statistics(self.handle, C.byref(n), C.byref(st)))
+        return n.value, st
+
     def close(self):
         if self.handle:
             self._lib.adaflo_comm_destroy(self.handle)
@@ -437,7 +446,12 @@ class DistributedNavierStokesMatrix:
                                        constrained_faces_p=(), device=device, stream=stream)
         self.local = local
         self.native_comm = native_comm and hasattr(local, "_ctx")
-        self.through_comm = through_comm      # one rank, but through adaflo_ns_vmult_distributed (phased schedule)
+        # one rank, but through adaflo_ns_vmult_distributed (phased schedule): exists behind the C ABI only -- with the
+        # torch-driven exchange there is no communicator object, the operator would skip the mean-value projection
+        # while reporting through_comm
+        if through_comm and not self.native_comm:
+            raise ValueError("through_comm needs native_comm=True (adaflo_ns_vmult_distributed)")
+        self.through_comm = through_comm
         self.comm = None
         self.overlap = True       # overlap the exchanges with interior cells where supported
         self.halo = HaloExchange(part, [(k, 3), (k - 1, 1)], group=group)
@@ -471,6 +485,21 @@ class DistributedNavierStokesMatrix:
         self._w_owned = w * self.halo.owned_mask(1, device=w.device)
         s = _all_reduce_sum(self._w_owned.sum().reshape(1), self.group)
         self._inv = 1.0 / s                       # device scalar, modes == 1 everywhere
+
+    def get_matvec_statistics(self):
+        """NavierStokesMatrix::get_matvec_statistics (navier_stokes_matrix.cc:1194-1206): ((min, max, avg, min_index,
+        max_index) of the accumulated vmult seconds over the ranks, count); collective"""
+        if self.comm is not None:
+            n, st = self.comm.matvec_statistics()
+            return (st.min, st.max, st.avg, st.min_index, st.max_index), n
+        sec, n = self.local.get_matvec_statistics()
+        if self.part.world > 1:
+            import torch
+            t = torch.zeros(self.part.world, dtype=torch.float64)
+            t[self.part.rank] = sec
+            t = _all_reduce_sum(t, self.group).cpu()
+            return (float(t.min()), float(t.max()), float(t.mean()), int(t.argmin()), int(t.argmax())), n
+        return (sec, sec, sec, 0, 0), n
 
     def make_consistent(self, vec):
         if self.comm is not None:

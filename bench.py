@@ -77,7 +77,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--print-steps", action="store_true", help="per-step device times on stderr")
     ap.add_argument("--cpu-sample-cells", type=int, default=48)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.through_comm and args.comm != "native":
+        ap.error("--through-comm measures adaflo_ns_vmult_distributed: it needs --comm native")
+    return args
 
 
 def self_launch(args):
@@ -340,7 +343,16 @@ def main():
     if args.print_steps and rank == 0:
         print("step ms:", " ".join("%.3f" % t for t in step_ms), file=sys.stderr)
     ksec, kcount = op.local.get_kernel_statistics()
-    msec, mcount = op.local.get_matvec_statistics()
+    if op.comm is not None:
+        # get_matvec_statistics over the ranks (navier_stokes_matrix.cc:1194-1206): device time of the whole distributed
+        # vmult per rank, exchanges included -- min / max over the ranks show the load imbalance of boundary bricks
+        (rank_min, rank_max, rank_avg, rank_imin, rank_imax), mcount = op.get_matvec_statistics()
+        msec = rank_avg
+        op.local.get_matvec_statistics()
+    else:
+        msec, mcount = op.local.get_matvec_statistics()
+        rank_min = rank_max = msec
+        rank_imin = rank_imax = 0
 
     n_dofs_global = part.n_global_dofs(k)
     n_cells_local = op.local.n_cells()
@@ -397,6 +409,10 @@ def main():
                          b_alg_per_cell(k) / (3 * k ** 3 + (k - 1) ** 3), 1),
                      "vmult_ms_device": round(1e3 * msec / max(mcount, 1), 4)},
     }
+    if world > 1:
+        out["ms_per_step_min_rank"] = round(1e3 * rank_min / max(mcount, 1), 4)
+        out["ms_per_step_max_rank"] = round(1e3 * rank_max / max(mcount, 1), 4)
+        out["min_rank"], out["max_rank"] = rank_imin, rank_imax
     if dry_run:
         out["dry_run"] = True       # ranks share one GPU, gloo messages: functional check only
     if not args.no_cpu_baseline:

@@ -273,6 +273,16 @@ int         adaflo_comm_compress_add(adaflo_comm *comm, double *vec_u, double *v
  * its replicas are refreshed.                                                               */
 int         adaflo_ns_vmult_distributed(adaflo_ctx *ctx, adaflo_comm *comm, double *dst_u, double *dst_p,
                                         double *src_u, double *src_p, int src_ghosts_valid);
+/* get_matvec_statistics on the global problem (navier_stokes_matrix.cc:1194-1206: Utilities::MPI::min_max_avg of the
+ * accumulated vmult time over the communicator of the solution vector + the number of applications; both counters are
+ * reset).  The time of a rank is device time between two HIP events on its engine stream around each
+ * adaflo_ns_vmult_distributed (exchanges included: the stream waits for them inside).  Collective over the ranks. */
+typedef struct adaflo_min_max_avg
+{
+  double sum, min, max, avg; /* dealii::Utilities::MPI::MinMaxAvg */
+  int    min_index, max_index;
+} adaflo_min_max_avg;
+int         adaflo_comm_matvec_statistics(adaflo_comm *comm, unsigned *count, adaflo_min_max_avg *stats);
 /* measurement aid (bench.py --through-comm): take the three-phase schedule -- packs, events, second stream,
  * three kernel launches, unpacks, constrained rows -- also with world = 1, where adaflo_ns_vmult_distributed
  * otherwise forwards to adaflo_ns_vmult.  Shows the fixed cost of the distributed path on one GPU.          */

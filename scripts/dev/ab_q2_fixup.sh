@@ -13,3 +13,6 @@ for r in csv.DictReader(open('/tmp/ab_prof/ab_kernel_stats.csv')):
         print('   %-40s calls %4s  avg %9.1f us' % (r['Name'].replace('adaflo_hip::(anonymous namespace)::','')[:40], r['Calls'], float(r['AverageNs'])/1e3))
 "
 done
+# leave the DEFAULT library behind: the loop above ends on the non-default fix-up form and a reduced instantiation set
+hipcc -c adaflo_amd/csrc/ns_q2.hip -o adaflo_amd/lib/ns_q2.o -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -fno-gpu-rdc \
+  && hipcc -shared -o adaflo_amd/lib/libadaflo_hip.so adaflo_amd/lib/*.o --offload-arch=gfx950 -fno-gpu-rdc

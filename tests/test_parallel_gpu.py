@@ -144,11 +144,35 @@ def _reference(gcells, grid, k, two_phase, glin, gcoef, gu, gp):
     return ref_u, ref_p
 
 
+def _oracle_reference(gcells, grid, k, two_phase, glin, gcoef, gu, gp):
+    """the same global operator application by the CPU oracle (oracle/adaflo_oracle.c, the restatement of
+    navier_stokes_matrix.cc:221-262,601-916) -- the distributed result is then pinned to the oracle directly, not only
+    to the undivided engine (round-4 review, Weak #2)"""
+    from common import BETA, LIN, PHYS
+    from oracle import oracle as orc
+    fp = adaflo_amd.FlowParameters(velocity_degree=k, density_diff=0.5 if two_phase else 0.0)
+    ts = _make(fp)
+    mesh = orc.Mesh.make(list(gcells), [-1.0] * 3, [-1.0 + 0.5 * g for g in grid])
+    inv = lambda table, v: [a for a, b in table.items() if b == v][0]   # noqa: E731
+    prm = orc.NSParams.make(
+        physical_type=inv(PHYS, fp.physical_type), linearization=inv(LIN, fp.linearization),
+        beta=inv(BETA, fp.formulation_convective_term), tau_grad_div=fp.tau_grad_div, density=fp.density,
+        viscosity=fp.viscosity, damping=-fp.damping, density_diff=fp.density_diff, weight=ts.weight(),
+        weight_old=ts.weight_old(), weight_old_old=ts.weight_old_old(), tau1=ts.tau1(),
+        extrap_old=ts.factor_extrapol_old, extrap_old_old=ts.factor_extrapol_old_old)
+    con_u = orc.boundary_mask(mesh, k, 3, faces=range(6))
+    con_p = orc.boundary_mask(mesh, k - 1, 1, faces=())
+    w = orc.ns_pressure_mass_weight(mesh, k, con_p)
+    co = {} if not two_phase else dict(rho=gcoef[0].reshape(-1), mu=gcoef[1].reshape(-1), damp=gcoef[2].reshape(-1))
+    return orc.ns_vmult(mesh, k, prm, gu.reshape(-1), gp.reshape(-1), con_u, con_p, lin=glin.reshape(-1),
+                        weights=w, modes=np.ones(mesh.n_nodes(k - 1)), **co)
+
+
 def _reference_worker(rank, gcells, grid, k, two_phase, glin, gcoef, gu, gp, out):
     out["u"], out["p"] = _reference(gcells, grid, k, two_phase, glin, gcoef, gu, gp)
 
 
-def _run_distributed_case(world, cells, k=2, two_phase=False):
+def _run_distributed_case(world, cells, k=2, two_phase=False, against_oracle=False):
     grid = parallel.brick_grid(world)
     rng = np.random.default_rng(5)
     gcells = [g * c for g, c in zip(grid, cells)]
@@ -171,6 +195,12 @@ def _run_distributed_case(world, cells, k=2, two_phase=False):
         ref_u, ref_p = out["u"], out["p"]
     else:
         ref_u, ref_p = _reference(gcells, grid, k, two_phase, glin, gcoef, gu, gp)
+    if against_oracle:
+        # the ranks are compared with the ORACLE's application of the global operator; the undivided engine has to agree
+        # with it as well (it is what the other cases use)
+        eng_u, eng_p = ref_u, ref_p
+        ref_u, ref_p = _oracle_reference(gcells, grid, k, two_phase, glin, gcoef, gu, gp)
+        assert rel_l2(eng_u, ref_u) < 1e-12 and rel_l2(eng_p, ref_p) < 1e-12
     mgr = mp.Manager()
     results, crumbs = None, None
     # Up to eight processes share ONE GPU here (production: one process per GPU).  A rank of an 8-process job dies
@@ -229,6 +259,15 @@ def _run_distributed_case(world, cells, k=2, two_phase=False):
                                          (8, (24, 17, 12))])
 def test_distributed_vmult_on_one_gpu(world, cells):
     _run_distributed_case(world, cells)
+
+
+@pytest.mark.parametrize("world,cells,k,two_phase", [(2, (40, 24, 12), 2, False), (8, (24, 17, 12), 2, False),
+                                                     (8, (4, 3, 3), 4, False), (2, (9, 8, 5), 2, True)])
+def test_distributed_vmult_against_the_oracle(world, cells, k, two_phase):
+    """2 and 8 ranks of the real engine (phased and plain schedules, Python-driven and native exchange) against the CPU
+    ORACLE's application of the undivided operator, entry by entry on every rank's brick -- Q2/Q1 on bricks with workgroups
+    in all three phases, Q4/Q3 on 2 x 2 x 2 bricks, the two-phase operator"""
+    _run_distributed_case(world, cells, k=k, two_phase=two_phase, against_oracle=True)
 
 
 @pytest.mark.parametrize("world,cells", [(2, (5, 4, 3)), (8, (4, 3, 3))])
