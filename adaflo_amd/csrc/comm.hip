@@ -375,8 +375,13 @@ namespace
         hipMalloc(&c->rbuf, std::max(nr, 1L) * sizeof(double)) != hipSuccess ||
         hipMalloc(&c->d_inv, 2 * sizeof(double)) != hipSuccess ||
         hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_arrived, hipEventDisableTiming) != hipSuccess)
+        // (events that order the two streams of ONE device: no system-scope fence.  A default event makes every record
+        // a cache write-back + invalidate of the whole device -- behind a sweep kernel that is 25-30 us during which
+        // the next phase kernel cannot start, profiles/r05_trace_through_comm_before.log; the kernel boundaries already
+        // carry the device-scope release / acquire that the pack -> RCCL -> unpack chain needs, RCCL's own kernels fence
+        // what they move between devices)
+        hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_arrived, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess)
       return cfail(c, ADAFLO_ENOMEM, "communicator allocation failed");
     c->d_dot = c->d_inv + 1;
     return 0;

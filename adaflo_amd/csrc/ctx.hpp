@@ -70,7 +70,9 @@ namespace adaflo_hip
             for (int i = 0; i < 2; ++i)
               {
                 hipEvent_t e;
-                if (hipEventCreate(&e) != hipSuccess)
+                // (timing only, read after a stream synchronisation: no system-scope fence -- a default event writes
+                // back and invalidates the caches at every record, which costs the NEXT kernel)
+                if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess)
                   return nullptr;
                 pool.push_back(e);
               }
