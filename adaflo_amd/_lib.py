@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libadaflo_hip.so")
+# (ADAFLO_LIB_PATH: development only -- A/B runs of differently compiled engines, scripts/dev; never a CPU fallback)
+LIB_PATH = os.environ.get("ADAFLO_LIB_PATH") or os.path.join(_HERE, "lib", "libadaflo_hip.so")
 
 # status codes of include/adaflo_hip.h
 ADAFLO_OK, ADAFLO_EINVAL, ADAFLO_ENOTINIT, ADAFLO_EHIP, ADAFLO_ENOMEM, ADAFLO_EUNSUPPORTED = 0, -1, -2, -3, -4, -5

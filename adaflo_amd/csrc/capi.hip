@@ -376,7 +376,8 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
                           &ctx->pc_ones_p, &ctx->pc_tmp_u, &ctx->pc_tmp_p, &ctx->pc_tmp_p2, &ctx->pc_work, &ctx->kr_work, &ctx->kr_basis, &ctx->kr_scalars,
                           &ctx->q1_poisson_coef, &ctx->ho_tab, &ctx->res_sum_u, &ctx->res_sum_p, &ctx->res_old,
                           &ctx->ls_art_visc, &ctx->ls_stab_vel_sum, &ctx->ls_stab_ls_sum, &ctx->hox_lin, &ctx->hox_lin_prec, &ctx->pc_tridiag,
-                          &ctx->hox_slab_u, &ctx->hox_xslab_u, &ctx->hox_slab_p, &ctx->hox_xslab_p, &ctx->hox_tab})
+                          &ctx->hox_slab_u, &ctx->hox_xslab_u, &ctx->hox_slab_p, &ctx->hox_xslab_p, &ctx->hox_tab,
+                          &ctx->hop_lin, &ctx->hop_lin_prec, &ctx->hop_tab})
     release(*b);
   for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch,
                     ctx->d_tab_ls, ctx->d_ls_diag, ctx->d_tab_force, ctx->d_tab_maxvel})
@@ -387,6 +388,8 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
     (void)hipFree(ctx->q2_wg_list);
   if (ctx->hox_wg_list)
     (void)hipFree(ctx->hox_wg_list);
+  if (ctx->hop_wg_list)
+    (void)hipFree(ctx->hop_wg_list);
   if (ctx->h_result)
     (void)hipHostFree(ctx->h_result);
   if (ctx->gs_host)
@@ -465,11 +468,13 @@ int adaflo_copy_d2h(adaflo_ctx *ctx, void *dst, const void *src, size_t bytes)
 int adaflo_set_kernel_variant(adaflo_ctx *ctx, int variant)
 {
   CHECK_CTX(ctx);
-  if (variant < 0 || variant > 2)
+  if (variant < 0 || variant > 3)
     return fail(ctx, ADAFLO_EINVAL, "unknown kernel variant");
   if (ctx->flat && variant != 0)
     return fail(ctx, ADAFLO_EUNSUPPORTED, "dim = 2 runs on the generic kernels (variant 0) only");
-  ctx->variant = variant;
+  // 3 = 1 with the plane-per-lane kernel for Q4/Q3 constant-coefficient vmult / velocity_vmult (ns_hop.hip)
+  ctx->hop     = variant == 3;
+  ctx->variant = variant == 3 ? 1 : variant;
   return 0;
 }
 
@@ -689,6 +694,11 @@ int adaflo_ns_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double 
     {
       TRY(ctx, launch_ns_vmult_q2(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p), "Q2 kernel launch failed");
     }
+  else if (ctx->variant == 1 && ctx->hop && hop_supported(ctx, OP_VMULT)) // ns_hop.hip: plane-per-lane kernel (round 5)
+    {
+      TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
+      TRY(ctx, launch_ns_vmult_hop(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p), "plane-per-lane kernel launch failed");
+    }
   else if (ctx->variant == 1 && hox_supported(ctx)) // ns_hox.hip: x-marching kernel (round 4)
     {
       TRY(ctx, launch_ns_vmult_hox(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p), "x-marching kernel launch failed");
@@ -744,6 +754,12 @@ int adaflo_ns_vmult_phase(adaflo_ctx *ctx, double *dst_u, double *dst_p, const d
     {
       TRY(ctx, launch_ns_vmult_q2(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p, phase, interface_faces),
           "Q2 kernel launch failed");
+    }
+  else if (ctx->variant == 1 && ctx->hop && hop_supported(ctx, OP_VMULT))
+    {
+      TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
+      TRY(ctx, launch_ns_vmult_hop(ctx, OP_VMULT, dst_u, dst_p, src_u, src_p, phase, interface_faces),
+          "plane-per-lane kernel launch failed");
     }
   else if (ctx->variant == 1)
     {
@@ -850,6 +866,14 @@ int adaflo_ns_velocity_vmult(adaflo_ctx *ctx, double *dst_u, const double *src_u
     {
       TRY(ctx, launch_ns_vmult_q2(ctx, OP_VMULT_VELOCITY, dst_u, nullptr, src_u, nullptr),
           "Q2 kernel launch failed");
+      return 0;
+    }
+  if (ctx->variant == 1 && ctx->hop && hop_supported(ctx, OP_VMULT_VELOCITY))
+    {
+      TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
+      TRY(ctx, ensure_lin_prec_generic(ctx), "state re-layout failed");
+      TRY(ctx, launch_ns_vmult_hop(ctx, OP_VMULT_VELOCITY, dst_u, nullptr, src_u, nullptr),
+          "plane-per-lane kernel launch failed");
       return 0;
     }
   if (ctx->variant == 1 && hox_supported(ctx)) // (its frozen streaming copy carries the frozen coefficients)

@@ -133,6 +133,16 @@ struct adaflo_ctx
   int                     *hox_wg_list = nullptr;
   long                     hox_wg_key[4] = {0, 0, 0, 0};
   int                      hox_wg_counts[3] = {0, 0, 0};
+  // plane-per-lane Q4/Q3 kernel (ns_hop.hip): its streaming copies of the state (keyed on lin_gen / lin_prec_gen like the
+  // others), its table and tile list; `hop`: use it where it applies (kernel variant 3 = variant 1 + this)
+  adaflo_hip::DeviceBuffer hop_lin, hop_lin_prec, hop_tab;
+  unsigned long            hop_lin_gen = 0, hop_lin_prec_gen = 0;
+  int                      hop_lin_mode = -1, hop_lin_prec_mode = -1;
+  std::vector<double>      hop_tab_host;
+  int                     *hop_wg_list = nullptr;
+  long                     hop_wg_key[4] = {0, 0, 0, 0};
+  int                      hop_wg_counts[3] = {0, 0, 0};
+  bool                     hop = false;
   int                     *q2_wg_list = nullptr;     // [interface | interior A | interior B] workgroups
   long                     q2_wg_key[4] = {0, 0, 0, 0};
   int                      q2_wg_counts[3] = {0, 0, 0};

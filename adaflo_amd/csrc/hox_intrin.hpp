@@ -18,6 +18,29 @@ namespace adaflo_hip
   __device__ __forceinline__ void opaque(unsigned &v) { asm volatile("" : "+v"(v)); }
   __device__ __forceinline__ void opaque(double &v) { asm volatile("" : "+v"(v)); } // (also: "this load has arrived")
 
+  __device__ __forceinline__ void opaque_ptr(const double *&p) { asm volatile("" : "+v"(p)); }
+  __device__ __forceinline__ void opaque_s(int &v) { asm volatile("" : "+s"(v)); } // (a wave-uniform value: stays scalar)
+
+  // a cell = a DPP row of 16 lanes (ns_hop_kernel): the value the same lane position holds one row below (rows 1, 3
+  // receive rows 0, 2; the even rows get their own value back) and one half-wave below (lanes 32..63 receive 0..31) --
+  // gfx950's v_permlane16_swap / v_permlane32_swap, two per double, no LDS
+  __device__ __forceinline__ double from_row_below(const double v)
+  {
+    const unsigned long long b  = (unsigned long long)__double_as_longlong(v);
+    const unsigned           lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    const auto               r0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto               r1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __longlong_as_double((long long)(((unsigned long long)r1[0] << 32) | r0[0]));
+  }
+  __device__ __forceinline__ double from_half_below(const double v)
+  {
+    const unsigned long long b  = (unsigned long long)__double_as_longlong(v);
+    const unsigned           lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    const auto               r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto               r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __longlong_as_double((long long)(((unsigned long long)r1[0] << 32) | r0[0]));
+  }
+
   // the offset becomes known only after `v` has been computed: pins a prefetch behind the arithmetic that frees its
   // destination registers (otherwise all loads of an unrolled loop are hoisted to its top and stay live together).
   // (An offset, not the pointer: behind an opaque pointer the compiler no longer knows the address space.)
@@ -45,6 +68,19 @@ namespace adaflo_hip
     __builtin_amdgcn_sched_barrier(0); // phases stay phases: the scheduler otherwise interleaves them for ILP and the
                                        // kernel needs 440 instead of ~230 registers
   }
+
+  // the same without the scheduling barrier (ns_hop_kernel: the exchanges of consecutive quadrature points may overlap);
+  // between an LDS write and the reads of OTHER lanes of the wave that depend on it
+  __device__ __forceinline__ void wave_fence()
+  {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  // before an LDS write to a location other lanes of the wave may still have to READ: nothing on the hardware (the LDS
+  // executes one wave's instructions in order and the compiler keeps may-alias accesses in order); the host emulator,
+  // which runs the lanes one after the other, meets here
+  __device__ __forceinline__ void emu_sync() {}
 
   // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load and store of
   // the wave (vmcnt(0)) -- that would drain the prefetches in flight at every step of the marching loop

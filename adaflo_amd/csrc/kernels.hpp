@@ -26,6 +26,10 @@ namespace adaflo_hip
   int  hox_unconvert_state(adaflo_ctx *ctx, double *generic, bool frozen_copy = false);
   int  launch_ns_vmult_hox(adaflo_ctx *ctx, int op, double *dst_u, double *dst_p, const double *src_u,
                            const double *src_p, int phase = -1, uint32_t iface = 0);
+  // plane-per-lane Q4/Q3 kernel (ns_hop.hip), constant coefficients, vmult and velocity_vmult
+  bool hop_supported(const adaflo_ctx *ctx, int op);
+  int  launch_ns_vmult_hop(adaflo_ctx *ctx, int op, double *dst_u, double *dst_p, const double *src_u,
+                           const double *src_p, int phase = -1, uint32_t iface = 0);
 } // namespace adaflo_hip
 
 namespace adaflo_hip

@@ -1273,10 +1273,10 @@ namespace adaflo_hip
       return blocks;
     }
 
-    template <int K, int SPACE>
+    // (G: the tile geometry -- Geo<K> for this kernel, hop::PGeo for the plane-per-lane kernel of ns_hop_kernel.hpp)
+    template <int K, int SPACE, class G = Geo<K>>
     __device__ __forceinline__ void hox_fix_block(const HXArgs &A, long bb, bool &done)
     {
-      using G             = Geo<K>;
       constexpr int  DEG = SPACE == 0 ? K : K - 1, NC = SPACE == 0 ? 3 : 1;
       const int      nn_x = SPACE == 0 ? A.nnx : A.npx, nn_y = SPACE == 0 ? A.nny : A.npy, nn_z = SPACE == 0 ? A.nnz : A.npz;
       const long     n_y = (long)(A.tiles_y - 1) * nn_z, n_z = (long)(A.tiles_z - 1) * nn_y;
@@ -1323,7 +1323,7 @@ namespace adaflo_hip
       done = false;
     }
 
-    template <int K>
+    template <int K, class G = Geo<K>>
     __global__ __launch_bounds__(256) void ns_hox_fixup_kernel(const HXArgs A, const int with_p)
     {
       long total = 0, first_p = 0;
@@ -1337,9 +1337,9 @@ namespace adaflo_hip
         {
           bool done;
           if (bb < first_p)
-            hox_fix_block<K, 0>(A, bb, done);
+            hox_fix_block<K, 0, G>(A, bb, done);
           else
-            hox_fix_block<K, 1>(A, bb - first_p, done);
+            hox_fix_block<K, 1, G>(A, bb - first_p, done);
         }
     }
 

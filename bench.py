@@ -54,7 +54,8 @@ def parse():
     ap.add_argument("--cells", type=int, default=0,
                     help="beltrami: cells per direction per GPU (128); cavity: GLOBAL cells per direction (64)")
     ap.add_argument("--degree", type=int, default=0, help="velocity degree (beltrami 2, cavity 4)")
-    ap.add_argument("--variant", type=int, default=1, help="0 generic kernels, 1 specialised")
+    ap.add_argument("--variant", type=int, default=1, help="0 generic kernels, 1 specialised, 2 = 1 with the round-2 z-sweep kernel for Q3..Q5, "
+                    "3 = 1 with the plane-per-lane kernel for Q4/Q3")
     ap.add_argument("--chunk", type=int, default=0, help="Q2 kernel z-chunk (0 = heuristic)")
     ap.add_argument("--state-pad", type=int, default=-1, help="Q2 state skew padding in 16 B units")
     ap.add_argument("--linearization", default="coupled implicit Newton",
@@ -377,7 +378,8 @@ def main():
         raise SystemExit("non-finite result")
 
     kernel_name = "ns_q2_kernel" if (k == 2 and args.variant >= 1) else (
-        "ns_hox_kernel" if (3 <= k <= 5 and args.variant == 1) else (
+        "ns_hop_kernel" if (k == 4 and args.variant == 3) else
+        "ns_hox_kernel" if (3 <= k <= 5 and args.variant in (1, 3)) else (
             "ns_ho_kernel" if (3 <= k <= 5 and args.variant == 2) else "ns_cell_kernel"))
     traffic = None
     try:  # PMC-measured HBM bytes per launch of the dominant kernel (profiles/, collected with rocprofv3)

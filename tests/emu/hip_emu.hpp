@@ -183,10 +183,29 @@ namespace adaflo_hip
   inline void   opaque(int &) {}
   inline void   opaque(unsigned &) {}
   inline void   opaque(double &) {}
+  inline void   opaque_ptr(const double *&) {}
+  inline void   opaque_s(int &) {}
   inline void   pin_after(unsigned &, const double) {}
   inline void   sink(const double) {}
   inline unsigned long long clock_now() { return 0; }
   inline void   wave_sync() { emu::yield(1); }
+  inline void   wave_fence() { emu::yield(1); }
+  inline void   emu_sync() { emu::yield(1); }
+  // cross-lane moves of ns_hop_kernel (v_permlane16_swap / v_permlane32_swap on the device): every lane of the wave
+  // deposits its value, the wave meets, every lane picks up its partner's.  Lanes that have left the kernel hold no
+  // value anybody reads.
+  inline double g_xlane[1024];
+  inline double xlane_from(const double v, const int delta)
+  {
+    const int t = (int)emu::g_threadIdx.x, l = t & 63;
+    g_xlane[t]  = v;
+    emu::yield(1);
+    const double r = l >= delta && ((l / delta) & 1) ? g_xlane[t - delta] : v;
+    emu::yield(1);
+    return r;
+  }
+  inline double from_row_below(const double v) { return xlane_from(v, 16); }  // rows 1, 3 <- rows 0, 2
+  inline double from_half_below(const double v) { return xlane_from(v, 32); } // lanes 32..63 <- lanes 0..31
   inline void   lds_barrier() { emu::yield(2); }
   inline void   lds_flag_set(const unsigned a, const int v) { *reinterpret_cast<volatile int *>(emu::g_lds + a) = v; }
   inline void   lds_flag_wait(const unsigned a, const int target)

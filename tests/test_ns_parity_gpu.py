@@ -472,6 +472,73 @@ def test_velocity_vmult_high_order_sweep_kernel():
     assert rel_l2(dst.numpy(), ref) < TOL
 
 
+# ----------------------------------------------------------------------------- Q4/Q3 plane-per-lane kernel (round 5)
+@pytest.mark.parametrize("ncell", [(4, 2, 3), (5, 3, 4), (9, 6, 10), (33, 5, 9), (1, 1, 1), (2, 7, 2)])
+def test_vmult_plane_per_lane_kernel(ncell):
+    """csrc/ns_hop.hip (variant 3, k = 4): full and clipped 2 x 2 tiles, Newton with pressure"""
+    case = Case(ncell, k=4, upper=(1.0, 0.5, 2.0), tau_grad_div=0.2)
+    eu, ep = run_vmult(case, variant=3)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+@pytest.mark.parametrize("lx", [1, 2, 3, 7])
+def test_vmult_plane_per_lane_kernel_chunks(lx):
+    """x-chunks of every length: the seam planes between chunks go through the x-slabs"""
+    case = Case((7, 5, 9), k=4, tau_grad_div=0.1)
+    src_u, src_p, lin = case.random_u(), case.random_p(), case.random_lin()
+    w, modes = case.weights_modes()
+    ref_u, ref_p = orc.ns_vmult(case.mesh, case.k, case.prm, src_u, src_p, case.con_u, case.con_p, lin=lin,
+                                weights=w, modes=modes)
+    op = case.engine()
+    op.set_kernel_variant(3)
+    op.set_linearization(lin)
+    op.set_x_chunk(lx)
+    dst = op.block_vector(np.full(case.n_u, 7.0), np.full(case.n_p, 7.0))
+    op.vmult(dst, op.block_vector(src_u, src_p))
+    got_u, got_p = dst.numpy()
+    assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL
+
+
+@pytest.mark.parametrize("lin,phys", [(1, 0), (2, 0), (3, 0), (4, 0), (0, 1), (0, 2)])
+def test_vmult_plane_per_lane_kernel_modes(lin, phys):
+    case = Case((5, 4, 3), k=4, linearization=lin, physical_type=phys, beta=1.0, tau_grad_div=0.3, viscosity=0.2,
+                damping=0.3)
+    eu, ep = run_vmult(case, variant=3)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+def test_vmult_plane_per_lane_kernel_partial_constraints():
+    case = Case((5, 5, 3), k=4, faces_u=[0, 3, 4], faces_p=[1, 5], pressure_average_fix=False)
+    eu, ep = run_vmult(case, variant=3)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+def test_velocity_vmult_plane_per_lane_kernel():
+    """velocity_vmult on the state frozen by fix_linearization_point; the streaming copies of the state follow the
+    generic ones; variable coefficients fall back to the x-marching kernel under the same variant"""
+    case = Case((5, 3, 4), k=4)
+    src_u, src_p, lin, lin2 = case.random_u(), case.random_p(), case.random_lin(), case.random_lin()
+    ref = orc.ns_velocity_vmult(case.mesh, case.k, case.prm, src_u, case.con_u, lin=lin)
+    w, modes = case.weights_modes()
+    ref2_u, ref2_p = orc.ns_vmult(case.mesh, case.k, case.prm, src_u, src_p, case.con_u, case.con_p, lin=lin2,
+                                  weights=w, modes=modes)
+    op = case.engine()
+    op.set_kernel_variant(3)
+    op.set_linearization(lin)
+    dst2 = op.block_vector()
+    op.vmult(dst2, op.block_vector(src_u, src_p))              # (builds the streaming copy of `lin`)
+    op.fix_linearization_point()
+    op.set_linearization(lin2)
+    src, dst = op.initialize_u_vector(src_u), op.initialize_u_vector(np.full(case.n_u, 3.0))
+    op.velocity_vmult(dst, src)
+    assert rel_l2(dst.numpy(), ref) < TOL
+    op.vmult(dst2, op.block_vector(src_u, src_p))
+    got_u, got_p = dst2.numpy()
+    assert rel_l2(got_u, ref2_u) < TOL and rel_l2(got_p, ref2_p) < TOL
+    eu, ep = run_vmult(Case((3, 4, 3), k=4, density_diff=0.5), variant=3, coefficients=True)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
 # ----------------------------------------------------------------------------- Q3..Q5 x-marching kernel (round 4)
 @pytest.mark.parametrize("k,ncell", [(3, (4, 4, 3)), (3, (9, 5, 6)), (3, (8, 8, 20)), (4, (4, 2, 3)), (4, (5, 3, 4)),
                                      (4, (9, 6, 10)), (4, (33, 5, 9)), (5, (3, 2, 2)), (5, (4, 3, 3))])
