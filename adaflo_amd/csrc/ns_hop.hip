@@ -151,6 +151,14 @@ namespace adaflo_hip
       return e;
     if (int e = ensure(ctx->hox_xslab_p, n_t * PGeo::TPY * PGeo::TPZ))
       return e;
+#if HOP_STAMP
+    {
+      static unsigned long long *stamps = nullptr;
+      if (!stamps)
+        (void)hipMalloc(&stamps, (size_t)1 << 24);
+      A.stamps = stamps;
+    }
+#endif
     A.slab_u  = ctx->hox_slab_u.p;
     A.xslab_u = ctx->hox_xslab_u.p;
     A.slab_p  = ctx->hox_slab_p.p;
@@ -230,6 +238,32 @@ namespace adaflo_hip
       return ADAFLO_EHIP;
     if (stop)
       (void)hipEventRecord(stop, ctx->stream);
+#if HOP_STAMP
+    {
+      // development aid: medians over the waves of the per-phase cycle sums of the launch just made
+      static int calls = 0;
+      if (++calls == 20)
+        {
+          (void)hipDeviceSynchronize();
+          std::vector<unsigned long long> h(n_t * 10);
+          (void)hipMemcpy(h.data(), A.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+          const char *name[8] = {"top of step", "evaluate u", "evaluate p", "quadrature loop", "integrate u", "integrate p", "carry", "emit + node loads"};
+          double      total   = 0;
+          for (int j = 0; j < 8; ++j)
+            {
+              std::vector<double> v;
+              for (size_t w = 0; w < n_t; ++w)
+                if (h[w * 10 + 9])
+                  v.push_back((double)h[w * 10 + j] / (double)h[w * 10 + 9]);
+              std::sort(v.begin(), v.end());
+              std::fprintf(stderr, "hop stamp: %-18s median %8.0f  p10 %8.0f  p90 %8.0f cycles per step\n", name[j],
+                           v[v.size() / 2], v[v.size() / 10], v[v.size() * 9 / 10]);
+              total += v[v.size() / 2];
+            }
+          std::fprintf(stderr, "hop stamp: sum of medians %.0f cycles per step\n", total);
+        }
+    }
+#endif
     if (phase == -1 || phase == 1)
       ctx->kernel_timer.count++;
     if (phase == 0)

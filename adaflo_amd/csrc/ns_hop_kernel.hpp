@@ -45,6 +45,22 @@ namespace adaflo_hip
 #define HOP_EXP 0
 #endif
     // waves per SIMD the register allocation is made for (2: 256 registers per lane; 1: 512)
+    // HOP_STAMP: s_memtime stamps at the phase boundaries of a step, summed per wave into HXArgs::stamps ([tile][10]
+    // cycles: top of step, evaluate u, evaluate p, quadrature loop, integrate u, integrate p, carry, emit + node loads, -,
+    // steps) -- the launcher prints the medians (development aid)
+#ifndef HOP_STAMP
+#define HOP_STAMP 0
+#endif
+    // HOP_SCHED: 1 = scheduling barriers at the exchanges and after every quadrature point (phases stay phases: fewer
+    // registers), 0 = the compiler may interleave neighbouring lines / points
+#ifndef HOP_SCHED
+#define HOP_SCHED 1
+#endif
+#if HOP_SCHED
+#define HOP_XSYNC wave_sync
+#else
+#define HOP_XSYNC wave_fence
+#endif
 #ifndef HOP_PREFETCH_NODES
 #define HOP_PREFETCH_NODES 0
 #endif
@@ -493,6 +509,17 @@ namespace adaflo_hip
       };
 
       load_nodes(cx0);
+#if HOP_STAMP
+      unsigned long long acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock_now();
+#define HOP_MARK(j)                            \
+  {                                            \
+    const unsigned long long tn = clock_now(); \
+    acc[j] += tn - tlast;                      \
+    tlast = tn;                                \
+  }
+#else
+#define HOP_MARK(j)
+#endif
 
 #pragma unroll 1
       for (int step = 0; step < ns; ++step)
@@ -526,6 +553,7 @@ namespace adaflo_hip
                     }
                 }
             }
+          HOP_MARK(0)
           // velocity: y and z in registers (values at (x node, yq, zq))
           {
             EoMat<N, N, 1> mS;
@@ -573,7 +601,7 @@ namespace adaflo_hip
 #pragma unroll
                 for (int j = 0; j < N; ++j)
                   xb_own[64 * j] = U[j + N * k];
-                wave_sync();
+                HOP_XSYNC();
 #pragma unroll
                 for (int j = 0; j < N; ++j)
                   {
@@ -590,6 +618,7 @@ namespace adaflo_hip
                   }
               }
           }
+          HOP_MARK(1)
           // pressure: y, z in registers, x across the lanes of component 0; p at the quadrature points -> LDS
           if constexpr (WITH_P)
             {
@@ -638,7 +667,7 @@ namespace adaflo_hip
 #pragma unroll
                   for (int j = 0; j < N; ++j)
                     xb_own[64 * j] = PW[j + N * k];
-                  wave_sync();
+                  HOP_XSYNC();
                   double pl[N];
 #pragma unroll
                   for (int j = 0; j < N; ++j)
@@ -656,8 +685,9 @@ namespace adaflo_hip
                     pq_w[(j + N * k) * ws] = pl[j];
                 }
             }
-          wave_sync();
+          HOP_XSYNC();
 
+          HOP_MARK(2)
           // ================= quadrature points of my plane (:702-893) ================================================
           double R[NQ];
 #pragma unroll
@@ -764,11 +794,13 @@ namespace adaflo_hip
                 for (int k = 0; k < N; ++k)
                   R[yq + N * k] += dm(zq * N + k) * tg2;
                 ux[p] = tg0; // (d/dx of this point is consumed: its slot takes the tested x-gradient)
-                __builtin_amdgcn_sched_barrier(0); // one point at a time: interleaved, the points' temporaries add up
+                if (HOP_SCHED)
+                  __builtin_amdgcn_sched_barrier(0); // one point at a time: interleaved, the points' temporaries add up
               });
             });
           }
 
+          HOP_MARK(3)
           // ================= integrate (:897-907): x across the lanes, then z and y in registers =====================
           {
             double xsc[N], xdsc[N];
@@ -787,7 +819,7 @@ namespace adaflo_hip
 #pragma unroll
                 for (int j = 0; j < N; ++j)
                   xb_own[64 * j] = ux[j + N * k];
-                wave_sync();
+                HOP_XSYNC();
                 double acc[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j)
@@ -802,7 +834,7 @@ namespace adaflo_hip
 #pragma unroll
                 for (int j = 0; j < N; ++j)
                   xb_own[64 * j] = R[j + N * k];
-                wave_sync();
+                HOP_XSYNC();
 #pragma unroll
                 for (int j = 0; j < N; ++j)
                   {
@@ -840,6 +872,7 @@ namespace adaflo_hip
                   R[j + N * k] = out[j];
               }
           }
+          HOP_MARK(4)
           double Rp[NP * NP];
 #pragma unroll
           for (int n = 0; n < NP * NP; ++n)
@@ -854,7 +887,7 @@ namespace adaflo_hip
                 for (int m = 0; m < N; ++m)
                   xpc[m] = t[TB::X_PC + m];
               }
-              wave_sync();
+              HOP_XSYNC();
               double T[NQ];
 #pragma unroll
               for (int n = 0; n < NQ; ++n)
@@ -894,6 +927,7 @@ namespace adaflo_hip
                 }
             }
 
+          HOP_MARK(5)
           // ================= carry in x, faces inside the wave, emit the finished node planes =========================
           emu_sync();
           {
@@ -929,6 +963,7 @@ namespace adaflo_hip
                   crp_w[n * wsp] = Rp[n];
               }
           }
+          HOP_MARK(6)
 #if HOP_PREFETCH_NODES
           // the nodal planes of the next step travel while this one is emitted
           load_nodes(cx + 1);
@@ -937,13 +972,22 @@ namespace adaflo_hip
 #if !HOP_PREFETCH_NODES
           load_nodes(cx + 1);
 #endif
+          HOP_MARK(7)
+#if HOP_STAMP
+          acc[9] += 1;
+#endif
         }
+#if HOP_STAMP
+      if (A.stamps && lane == 0)
+        for (int j = 0; j < 10; ++j)
+          A.stamps[(size_t)tile * 10 + j] = acc[j];
+#endif
       if (NPC > 0)
         wait_vmcnt<0>(); // no copy may land in LDS after the wave has left
       // ---- the last node plane of the chunk ----------------------------------------------------------------------------
       {
         double R[NQ], Rp[NP * NP];
-        wave_sync();
+        HOP_XSYNC();
 #pragma unroll
         for (int n = 0; n < NQ; ++n)
           R[n] = cru[n];
