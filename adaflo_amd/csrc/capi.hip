@@ -744,8 +744,8 @@ int adaflo_ns_vmult_phase(adaflo_ctx *ctx, double *dst_u, double *dst_p, const d
   CHECK_CTX(ctx);
   if (!dst_u || !dst_p || !src_u || !src_p)
     return fail(ctx, ADAFLO_EINVAL, "null vector");
-  if (phase < 0 || phase > 2)
-    return fail(ctx, ADAFLO_EINVAL, "phase must be 0, 1 or 2");
+  if (phase < 0 || phase > 5)
+    return fail(ctx, ADAFLO_EINVAL, "phase must be 0 ... 5");
   if (!adaflo_ns_supports_phases(ctx))
     return fail(ctx, ADAFLO_EUNSUPPORTED, "phased vmult needs one of the sweep kernels (Q2/Q1, or Q3..Q5 with constant coefficients)");
   if (needs_lin(ctx) && !has_lin(ctx))

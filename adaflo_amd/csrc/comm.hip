@@ -116,6 +116,10 @@ struct adaflo_comm
   double     *sbuf = nullptr, *rbuf = nullptr;
   hipStream_t comm_stream = nullptr;
   hipEvent_t  ev_packed = nullptr, ev_arrived = nullptr;
+  // second compute stream of the overlapped schedule: packs, unpacks and the cells at the interface run here, beside
+  // the interior cells on the engine's stream
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t  ev_src = nullptr, ev_iface = nullptr, ev_done = nullptr;
   // transport
   void                *nccl = nullptr; // ncclComm_t
   adaflo_exchange_fn   exchange_cb = nullptr;
@@ -381,7 +385,11 @@ namespace
         // carry the device-scope release / acquire that the pack -> RCCL -> unpack chain needs, RCCL's own kernels fence
         // what they move between devices)
         hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_arrived, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess)
+        hipEventCreateWithFlags(&c->ev_arrived, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_src, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_iface, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess)
       return cfail(c, ADAFLO_ENOMEM, "communicator allocation failed");
     c->d_dot = c->d_inv + 1;
     return 0;
@@ -517,12 +525,15 @@ int adaflo_comm_destroy(adaflo_comm *c)
     if (p)
       (void)hipFree(p);
   c->matvec_timer.destroy();
-  if (c->ev_packed)
-    (void)hipEventDestroy(c->ev_packed);
-  if (c->ev_arrived)
-    (void)hipEventDestroy(c->ev_arrived);
+  if (c->aux_stream)
+    (void)hipStreamSynchronize(c->aux_stream);
+  for (hipEvent_t e : {c->ev_packed, c->ev_arrived, c->ev_src, c->ev_iface, c->ev_done})
+    if (e)
+      (void)hipEventDestroy(e);
   if (c->comm_stream)
     (void)hipStreamDestroy(c->comm_stream);
+  if (c->aux_stream)
+    (void)hipStreamDestroy(c->aux_stream);
   delete c;
   return 0;
 }
@@ -638,25 +649,60 @@ int adaflo_ns_vmult_distributed(adaflo_ctx *ctx, adaflo_comm *c, double *dst_u, 
     }
   else if (phased)
     {
-      //   ghost update of src   ||  interior cells, first half
-      //   cells at the interface, seam sums of the interface nodes
-      //   compress(add) of dst  ||  interior cells, second half
-      if (!src_ghosts_valid)
-        if (int e = exchange_start(c, c->copy, src_u, src_p))
+      // Two compute streams (round 5).  The engine's stream S runs ALL interior cells as one launch; beside it, on the
+      // auxiliary stream S2: ghost update of src (pack, messages on the communication stream, unpack), the cells at
+      // the interface + the seam sums of the interface nodes, compress(add) of dst (pack, messages, unpack-add).  S joins
+      // for the remaining seam sums and at the end.  The former schedule split the interior into two launches on ONE stream
+      // (A | interface | B): three partially filled rounds of workgroups where the plain operator has two, and every
+      // hand-over to the communication stream sat between two sweep kernels (32^3 Q4/Q3: +26 % with no message at all).
+      //   S : set-up . [src ready] . interior cells ........................ [wait iface] seam sums . [wait done] rows
+      //   S2:           [wait] pack > msgs > unpack . interface cells + seams . [iface] pack > msgs > unpack-add . [done]
+      struct OnStream // the launchers enqueue on ctx->stream
+      {
+        adaflo_ctx *ctx;
+        hipStream_t saved;
+        OnStream(adaflo_ctx *x, hipStream_t s)
+          : ctx(x)
+          , saved(x->stream)
+        {
+          x->stream = s;
+        }
+        ~OnStream() { ctx->stream = saved; }
+      };
+      hipStream_t S = ctx->stream, S2 = c->aux_stream;
+      // tables and streaming copies of the state are brought up to date on S before S2 may touch them
+      if (int e = adaflo_ns_vmult_phase(ctx, dst_u, dst_p, src_u, src_p, 5, c->iface))
+        return e;
+      if (hipEventRecord(c->ev_src, S) != hipSuccess || hipStreamWaitEvent(S2, c->ev_src, 0) != hipSuccess)
+        return cfail(c, ADAFLO_EHIP, "event failed");
+      if (int e = adaflo_ns_vmult_phase(ctx, dst_u, dst_p, src_u, src_p, 3, c->iface))
+        return e;
+      {
+        OnStream on(ctx, S2);
+        if (!src_ghosts_valid)
+          {
+            if (int e = exchange_start(c, c->copy, src_u, src_p))
+              return e;
+            if (int e = exchange_finish(c, c->copy, src_u, src_p, false))
+              return e;
+          }
+        if (int e = adaflo_ns_vmult_phase(ctx, dst_u, dst_p, src_u, src_p, 1, c->iface))
           return e;
-      if (int e = adaflo_ns_vmult_phase(ctx, dst_u, dst_p, src_u, src_p, 0, c->iface))
-        return e;
-      if (!src_ghosts_valid)
-        if (int e = exchange_finish(c, c->copy, src_u, src_p, false))
+        if (hipEventRecord(c->ev_iface, S2) != hipSuccess)
+          return cfail(c, ADAFLO_EHIP, "event failed");
+        if (int e = exchange_start(c, c->add, dst_u, dst_p))
           return e;
-      if (int e = adaflo_ns_vmult_phase(ctx, dst_u, dst_p, src_u, src_p, 1, c->iface))
+        if (int e = exchange_finish(c, c->add, dst_u, dst_p, true))
+          return e;
+        if (hipEventRecord(c->ev_done, S2) != hipSuccess)
+          return cfail(c, ADAFLO_EHIP, "event failed");
+      }
+      if (hipStreamWaitEvent(S, c->ev_iface, 0) != hipSuccess)
+        return cfail(c, ADAFLO_EHIP, "event failed");
+      if (int e = adaflo_ns_vmult_phase(ctx, dst_u, dst_p, src_u, src_p, 4, c->iface))
         return e;
-      if (int e = exchange_start(c, c->add, dst_u, dst_p))
-        return e;
-      if (int e = adaflo_ns_vmult_phase(ctx, dst_u, dst_p, src_u, src_p, 2, c->iface))
-        return e;
-      if (int e = exchange_finish(c, c->add, dst_u, dst_p, true))
-        return e;
+      if (hipStreamWaitEvent(S, c->ev_done, 0) != hipSuccess)
+        return cfail(c, ADAFLO_EHIP, "event failed");
     }
   else
     {

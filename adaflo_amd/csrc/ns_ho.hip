@@ -1233,7 +1233,7 @@ namespace adaflo_hip
       A.zslab_u = ctx->q2_zslab_u.p;
       A.slab_p  = ctx->q2_slab_p.p;
       A.zslab_p = ctx->q2_zslab_p.p;
-      if (with_p && !A.integrate_p && phase <= 0)
+      if (with_p && !A.integrate_p && (phase <= 0 || phase == 3))
         if (int e = launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, A.npx, A.npy, A.npz, A.con_p, -1., true))
           return e;
       long nwg = (long)n_wg;
@@ -1268,9 +1268,10 @@ namespace adaflo_hip
             }
           const int nb = ctx->q2_wg_counts[0], na = ctx->q2_wg_counts[1], nc = ctx->q2_wg_counts[2];
           A.wg_list   = ctx->q2_wg_list;
-          A.wg_offset = phase == 1 ? 0 : (phase == 0 ? nb : nb + na);
-          A.wg_count  = phase == 1 ? nb : (phase == 0 ? na : nc);
-          A.fix_mode  = phase; // 1: interface nodes, 2: the others (phase 0 runs no fix-up)
+          A.wg_offset = phase == 1 ? 0 : ((phase == 0 || phase == 3) ? nb : nb + na);
+          A.wg_count  = phase == 1 ? nb : (phase == 0 ? na : (phase == 3 ? na + nc : (phase >= 4 ? 0 : nc)));
+          A.fix_mode  = phase == 4 ? 2 : phase; // 1: interface nodes, 2: the others (phases 0 and 3 run no fix-up; 3 = 0 + 2
+                                               // without it, 4 = the fix-up of phase 2 alone, 5 = set-up only: the two-stream schedule of comm.hip)
           A.iface     = iface;
           nwg         = A.wg_count;
         }
@@ -1321,7 +1322,7 @@ namespace adaflo_hip
         (void)hipEventRecord(stop, ctx->stream);
       if (phase == -1 || phase == 1)
         ctx->kernel_timer.count++;
-      if (phase == 0)
+      if (phase == 0 || phase == 3 || phase == 5)
         return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
       const long tiles = (long)A.tiles_x * A.tiles_y;
       const bool fix_p = with_p && A.integrate_p;

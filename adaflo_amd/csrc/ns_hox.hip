@@ -194,7 +194,7 @@ namespace adaflo_hip
       A.xslab_u = ctx->hox_xslab_u.p;
       A.slab_p  = ctx->hox_slab_p.p;
       A.xslab_p = ctx->hox_xslab_p.p;
-      if (with_p && !A.integrate_p && phase <= 0)
+      if (with_p && !A.integrate_p && (phase <= 0 || phase == 3))
         if (int e = launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, A.npx, A.npy, A.npz, A.con_p, -1., true))
           return e;
       long nwg = (long)n_wg;
@@ -217,9 +217,10 @@ namespace adaflo_hip
             }
           const int nb = ctx->hox_wg_counts[0], na = ctx->hox_wg_counts[1], nc = ctx->hox_wg_counts[2];
           A.wg_list   = ctx->hox_wg_list;
-          A.wg_offset = phase == 1 ? 0 : (phase == 0 ? nb : nb + na);
-          A.wg_count  = phase == 1 ? nb : (phase == 0 ? na : nc);
-          A.fix_mode  = phase; // 1: interface nodes, 2: the others (phase 0 runs no fix-up)
+          A.wg_offset = phase == 1 ? 0 : ((phase == 0 || phase == 3) ? nb : nb + na);
+          A.wg_count  = phase == 1 ? nb : (phase == 0 ? na : (phase == 3 ? na + nc : (phase >= 4 ? 0 : nc)));
+          A.fix_mode  = phase == 4 ? 2 : phase; // 1: interface nodes, 2: the others (phases 0 and 3 run no fix-up; 3 = 0 + 2
+                                               // without it, 4 = the fix-up of phase 2 alone, 5 = set-up only: the two-stream schedule of comm.hip)
           A.iface     = iface;
           nwg         = A.wg_count;
         }
@@ -340,7 +341,7 @@ namespace adaflo_hip
         }
       if (phase == -1 || phase == 1)
         ctx->kernel_timer.count++;
-      if (phase == 0)
+      if (phase == 0 || phase == 3 || phase == 5)
         return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
       const bool fix_p = with_p && A.integrate_p;
       const long blocks = hox_fix_blocks(A, fix_p); // one per seam row, one per 256 entries of the x-seam planes

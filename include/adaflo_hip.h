@@ -154,6 +154,9 @@ int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx);       /* :1144-1152 */
  *   phase 1: cells that touch the interface; afterwards dst is final on the interface nodes
  *            (ready for compress(add)); requires the ghost values of src
  *   phase 2: the remaining interior cells and seam sums
+ *   phases 3, 4, 5 (the two-stream schedule of adaflo_ns_vmult_distributed): 3 = ALL interior cells (0 and 2 in one
+ *            launch) without the seam sums, 4 = the seam sums of phase 2 alone (after phases 1 and 3), 5 = set-up only
+ *            (tables and streaming copies of the state brought up to date, nothing launched on the cells)
  * After phase 2 dst equals the result of adaflo_ns_vmult without the mean-value projection.
  * Only with the sweep kernels -- Q2/Q1 (constant or variable coefficients) and Q3/Q2 .. Q5/Q4 (constant
  * coefficients) --, ADAFLO_EUNSUPPORTED otherwise; adaflo_ns_supports_phases tells (1 / 0) for the

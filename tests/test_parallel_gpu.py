@@ -84,6 +84,8 @@ def _worker(rank, world, port, grid, cells, k, gu, gp, glin, gcoef, ref_u, ref_p
         ndst = adaflo_amd.BlockVector([V(nctx, du), V(nctx, dp)])
         # (k > 2: variant 1 is the high-order sweep kernel; it has no phased schedule, `overlap` is then ignored)
         combos = ((1, True, False), (1, False, False), (0, False, False), (1, True, True), (0, False, True))
+        if k == 4 and gcoef is None:
+            combos += ((3, True, True),)                    # the plane-per-lane kernel under the two-stream schedule
         only = os.environ.get("ADAFLO_TEST_VARIANTS")       # (scripts/dev/stress_parallel.py: bisecting a fault)
         if only:
             combos = tuple(c for c in combos if str(c[0]) in only.split(","))
@@ -248,7 +250,8 @@ def _run_distributed_case(world, cells, k=2, two_phase=False, against_oracle=Fal
         else:
             os.environ["GPU_MAX_HW_QUEUES"] = saved_queues
     only = os.environ.get("ADAFLO_TEST_VARIANTS")
-    n_combos = 5 if not only else sum(1 for v in (1, 1, 0, 1, 0) if str(v) in only.split(","))
+    variants = (1, 1, 0, 1, 0) + ((3,) if (k == 4 and not two_phase) else ())
+    n_combos = len(variants) if not only else sum(1 for v in variants if str(v) in only.split(","))
     assert len(results) == n_combos * world, (len(results), n_combos, world)
     for key, (eu, ep) in results.items():
         assert eu < 1e-12 and ep < 1e-12, (key, eu, ep)
