@@ -6,13 +6,13 @@
 // (source/navier_stokes.cc:593-631: SolverFGMRES<BlockVector>::solve(navier_stokes_matrix, solution_update,
 // system_rhs, preconditioner)).  This file does the same with a small templated FGMRES of its own:
 //   * BlockVector: two device arrays (velocity | pressure) with the few vector operations a Krylov solver needs,
-//     forwarded to adaflo_vector_*;
-//   * NavierStokesMatrixHIP::vmult            -> adaflo_ns_vmult
-//   * NavierStokesPreconditionerHIP::vmult    -> adaflo_ns_preconditioner_vmult (with inner solves)
+//     forwarded to adaflo_vector_*; `block(i).get_values()` is what include/adaflo_hip.hpp asks of a vector type;
+//   * adaflo::hip::NavierStokesMatrix::vmult          -> adaflo_ns_vmult            (the shipped header, not a test class)
+//   * adaflo::hip::NavierStokesPreconditioner::vmult  -> adaflo_ns_preconditioner_vmult (with inner solves)
 //   * solve_fgmres<Matrix, Vector, Preconditioner>: right-preconditioned FGMRES(50), modified Gram-Schmidt.
 // It linearises a smooth field on a 6 x 5 x 4 Q2/Q1 brick (adaflo_ns_residual produces the state), solves
 // J du = J x_true, and checks the solution against adaflo_ns_solve_system -- the same algorithm inside the library.
-#include "adaflo_hip.h"
+#include "adaflo_hip.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -49,6 +49,8 @@ namespace
       check(ctx, adaflo_copy_d2h(ctx, h.data(), p, sizeof(double) * h.size()), "d2h");
       return h;
     }
+    double       *get_values() { return p; }
+    const double *get_values() const { return p; }
     adaflo_ctx *ctx;
     int64_t     n;
     double     *p = nullptr;
@@ -85,38 +87,13 @@ namespace
       return a + b;
     }
     double      l2_norm() const { return std::sqrt((*this) * (*this)); }
-    DeviceArray u, p;
+    DeviceArray       &block(const unsigned i) { return i == 0 ? u : p; }
+    const DeviceArray &block(const unsigned i) const { return i == 0 ? u : p; }
+    DeviceArray        u, p;
   };
 
-  class NavierStokesMatrixHIP
-  {
-  public:
-    explicit NavierStokesMatrixHIP(adaflo_ctx *ctx)
-      : ctx(ctx)
-    {}
-    void vmult(BlockVector &dst, const BlockVector &src) const
-    {
-      check(ctx, adaflo_ns_vmult(ctx, dst.u.p, dst.p.p, src.u.p, src.p.p), "adaflo_ns_vmult");
-    }
-
-  private:
-    adaflo_ctx *ctx;
-  };
-
-  class NavierStokesPreconditionerHIP
-  {
-  public:
-    explicit NavierStokesPreconditionerHIP(adaflo_ctx *ctx)
-      : ctx(ctx)
-    {}
-    void vmult(BlockVector &dst, const BlockVector &src) const
-    {
-      check(ctx, adaflo_ns_preconditioner_vmult(ctx, dst.u.p, dst.p.p, src.u.p, src.p.p), "adaflo_ns_preconditioner_vmult");
-    }
-
-  private:
-    adaflo_ctx *ctx;
-  };
+  using NavierStokesMatrixHIP         = adaflo::hip::NavierStokesMatrix<DeviceArray, BlockVector>;
+  using NavierStokesPreconditionerHIP = adaflo::hip::NavierStokesPreconditioner<BlockVector>;
 
   // right-preconditioned flexible GMRES(restart); x is the start value and the result; returns the iterations
   template <class Matrix, class Vector, class Preconditioner, class MakeVector>

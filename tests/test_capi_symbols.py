@@ -87,15 +87,18 @@ def test_time_stepping_bdf2_weights():
 
 
 def test_cpp_translation_unit_compiles_and_links():
-    """tests/capi_cpp/drop_in.cpp (the duck-typed vmult seam of source/navier_stokes.cc:593-631 over the C ABI) is plain
-    host C++17: it compiles with g++ against include/adaflo_hip.h alone and links against the shared library; it RUNS in
-    tests/test_boundary_gpu.py"""
+    """The shipped C++ host side include/adaflo_hip.hpp (NavierStokesMatrix, the block preconditioner and the four
+    level-set operator structs with the reference's method names, templated on the vector types) and its two users under
+    tests/capi_cpp/ -- drop_in.cpp (the duck-typed vmult seam of source/navier_stokes.cc:593-631 driven by a templated
+    FGMRES) and operators.cpp (every method, compared with the ctypes path) -- are plain host C++17: they compile with g++
+    -Wall -Werror against include/ alone and link against the shared library; they RUN in tests/test_boundary_gpu.py"""
     import os
     import subprocess
     import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     libdir = os.path.join(root, "adaflo_amd", "lib")
     with tempfile.TemporaryDirectory() as tmp:
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
-                               os.path.join(root, "tests", "capi_cpp", "drop_in.cpp"), "-o", os.path.join(tmp, "drop_in"),
-                               "-L", libdir, "-ladaflo_hip", "-Wl,-rpath," + libdir])
+        for unit in ("drop_in", "operators"):
+            subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                                   os.path.join(root, "tests", "capi_cpp", unit + ".cpp"), "-o", os.path.join(tmp, unit),
+                                   "-L", libdir, "-ladaflo_hip", "-Wl,-rpath," + libdir])
