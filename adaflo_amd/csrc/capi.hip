@@ -377,7 +377,7 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
                           &ctx->q1_poisson_coef, &ctx->ho_tab, &ctx->res_sum_u, &ctx->res_sum_p, &ctx->res_old,
                           &ctx->ls_art_visc, &ctx->ls_stab_vel_sum, &ctx->ls_stab_ls_sum, &ctx->hox_lin, &ctx->hox_lin_prec, &ctx->pc_tridiag,
                           &ctx->hox_slab_u, &ctx->hox_xslab_u, &ctx->hox_slab_p, &ctx->hox_xslab_p, &ctx->hox_tab,
-                          &ctx->hop_lin, &ctx->hop_lin_prec, &ctx->hop_tab})
+                          &ctx->hop_lin, &ctx->hop_lin_prec, &ctx->hop_tab, &ctx->lin_nodal})
     release(*b);
   for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch,
                     ctx->d_tab_ls, ctx->d_ls_diag, ctx->d_tab_force, ctx->d_tab_maxvel})
@@ -468,13 +468,15 @@ int adaflo_copy_d2h(adaflo_ctx *ctx, void *dst, const void *src, size_t bytes)
 int adaflo_set_kernel_variant(adaflo_ctx *ctx, int variant)
 {
   CHECK_CTX(ctx);
-  if (variant < 0 || variant > 3)
+  if (variant < 0 || variant > 4)
     return fail(ctx, ADAFLO_EINVAL, "unknown kernel variant");
   if (ctx->flat && variant != 0)
     return fail(ctx, ADAFLO_EUNSUPPORTED, "dim = 2 runs on the generic kernels (variant 0) only");
   // 3 = 1 with the plane-per-lane kernel for Q4/Q3 constant-coefficient vmult / velocity_vmult (ns_hop.hip)
-  ctx->hop     = variant == 3;
-  ctx->variant = variant == 3 ? 1 : variant;
+  // 4 = 1 WITHOUT the recompute-state mode of the Q2/Q1 Newton vmult (ns_q2.hip, RCP): the streaming kernel of rounds 1-4
+  ctx->hop          = variant == 3;
+  ctx->q2_recompute = variant != 4;
+  ctx->variant      = variant >= 3 ? 1 : variant;
   return 0;
 }
 

@@ -415,7 +415,10 @@ namespace adaflo_hip
     // more pieces per point in the state stream, (rho, mu) and (damping, -); register prefetch also for k = 4 (the
     // ring would not fit the LDS of two workgroups per CU)
     template <int K, int LIN_MODE, bool WITH_P, bool RES = false, bool VARCO = false>
-    __global__ __launch_bounds__(NTH, HOX_LB) void ns_hox_kernel(const HXArgs A)
+#ifndef HOX_RES_LB
+#define HOX_RES_LB HOX_LB
+#endif
+    __global__ __launch_bounds__(NTH, (RES ? HOX_RES_LB : HOX_LB)) void ns_hox_kernel(const HXArgs A)
     {
       using G           = Geo<K>;
       constexpr int N = G::N, NP = G::NP, KP = G::KP, NL = G::NL, N3 = G::N3, NN = N * N;

@@ -557,10 +557,32 @@ namespace adaflo_hip
     // quadrature-point state (:725-800) is WRITTEN in the streaming layout instead of being read
     // DIV: divergence block only (local_divergence, :920-961): the pressure lane integrates
     // (q, c_div div u), the velocity lanes evaluate but integrate and emit nothing
-    template <int LIN_MODE, bool WITH_P, bool ISO, bool VARCO, bool RES = false, bool DIV = false>
-    __global__ __launch_bounds__(NT, 2) void ns_q2_kernel(const Q2Args A)
+    // RCP: recompute-state mode (round 5, review item 3): the Newton vmult does NOT stream the 2 592 B per cell of
+    // (u_lin, grad u_lin); the nodal linearisation point (the solution vector of the last residual, kept by the host) is
+    // gathered, interpolated and differentiated next to the source field -- the state is a function of the nodal field,
+    // :778-816 -- and the other components' values and the trace come from quad broadcasts instead of ring reads
+    template <int LIN_MODE, bool WITH_P, bool ISO, bool VARCO, bool RES = false, bool DIV = false, bool RCP = false>
+    // waves per SIMD the registers are allocated for.  The residual mode holds three fields (solution, old-solution
+    // combination, sums) and spilled 160-184 B at 256 registers; with 512 (one workgroup per CU) it has no scratch and
+    // is faster: 128^3 2.29 -> 2.10 ms (round 5, profiles/r05_residual_lb.log).  The operator modes stream the state and
+    // want two workgroups per CU.
+#ifndef Q2_RES_LB
+#define Q2_RES_LB 1
+#endif
+#ifndef Q2_LB
+#define Q2_LB 2
+#endif
+    // The recompute mode holds three fields of 27 values as well.  Cubic cells: 256 registers + 32 B of scratch, two
+    // workgroups per CU -- 128^3 kernel 1.016 ms against 1.462 ms with 512 registers / one workgroup per CU (266 used) and
+    // 1.287 ms for the streaming kernel (round 5, profiles/r05_recompute.log): the mode is bound by FP64 issue and wants the
+    // second wave.  Other cells (three sets of derivative coefficients): 160 B of scratch at 256, none at 512.
+#ifndef Q2_RCP_LB
+#define Q2_RCP_LB (ISO ? 2 : 1)
+#endif
+    __global__ __launch_bounds__(NT, (RES ? Q2_RES_LB : (RCP ? Q2_RCP_LB : Q2_LB))) void ns_q2_kernel(const Q2Args A)
     {
-      constexpr bool RING_ON = LIN_MODE != 2 && !RES; // state stream through the LDS ring
+      constexpr bool RING_ON = LIN_MODE != 2 && !RES && !RCP; // state stream through the LDS ring
+      static_assert(!RCP || (LIN_MODE == 0 && !RES && !VARCO && !DIV), "recompute mode: constant-coefficient Newton vmult");
       static_assert(!DIV || (LIN_MODE == 2 && WITH_P && !RES && !VARCO), "divergence mode");
       static_assert(!(RES && VARCO), "residual mode: constant coefficients only");
       extern __shared__ double lds[];
@@ -714,8 +736,8 @@ namespace adaflo_hip
             dma_p_plane(A, lds, cz0, Ip0, Jp0, lane);
             dma_p_plane(A, lds, cz0 + 1, Ip0, Jp0, lane);
           }
-        if (RES) // node planes of the old-solution combination live in the (unused) ring area
-          {
+        if (RES || RCP) // node planes of the old-solution combination (RCP: of the linearisation point) live in the
+          {             // (unused) ring area
             dma_u_plane_single(A, lds, 2 * cz0, I0, J0, wave, lane, A.old_u, L_RING);
             dma_u_planes(A, lds, 2 * cz0 + 1, I0, J0, wave, lane, A.old_u, L_RING);
           }
@@ -788,11 +810,11 @@ namespace adaflo_hip
             issue_burst(cz);
 
           double R[27];
-          if (RES)
+          double V2[(RES || RCP) ? 27 : 1]; // second nodal field: old-solution combination (RES) / linearisation point (RCP)
+          if (RES || RCP)
             {
-              // (w, rho (weight_old u_old + weight_old_old u_old_old)) of the momentum row (:675-686,
+              // RES: (w, rho (weight_old u_old + weight_old_old u_old_old)) of the momentum row (:675-686,
               // :730-733): interpolate the nodal combination, it only enters through its values
-              double V2[27];
 #pragma unroll
               for (int c = 0; c < 3; ++c)
                 {
@@ -804,6 +826,9 @@ namespace adaflo_hip
                       V2[a + 3 * b + 9 * c] = pl[b * UROW + a * 3 + (a == 2 ? fix_last : 0)];
                 }
               interp_all(V2);
+            }
+          if (RES)
+            {
               const double co = is_p ? 0. : A.c_old;
 #pragma unroll
               for (int n = 0; n < 27; ++n)
@@ -888,7 +913,7 @@ namespace adaflo_hip
           dma_u_planes(A, lds, 2 * cz + 3, I0, J0, wave, lane);
           if (WITH_P)
             dma_p_plane(A, lds, cz + 2, Ip0, Jp0, lane);
-          if (RES)
+          if (RES || RCP)
             dma_u_planes(A, lds, 2 * cz + 3, I0, J0, wave, lane, A.old_u, L_RING);
 
           // ---- C: interpolate to the Gauss points (in place) ----------------------------
@@ -968,6 +993,23 @@ namespace adaflo_hip
               const double  g2 = dline(qz, V[qx + 3 * qy], V[qx + 3 * qy + 9], V[qx + 3 * qy + 18],
                                        A.ah[e2][0], A.ah[e2][1], A.ah[e2][2], A.ah[e2][3]);
 
+              if (RCP)
+                {
+                  // the state of this point from the interpolated nodal linearisation point: my component's value and
+                  // gradient row (what the ring delivers as st0, st1), the other components' values and the trace of
+                  // the gradient through the quad
+                  const double b0 = dline(qx, V2[0 + 3 * qy + 9 * qz], V2[1 + 3 * qy + 9 * qz], V2[2 + 3 * qy + 9 * qz],
+                                          A.ah[0][0], A.ah[0][1], A.ah[0][2], A.ah[0][3]);
+                  const double b1 = dline(qy, V2[qx + 9 * qz], V2[qx + 3 + 9 * qz], V2[qx + 6 + 9 * qz],
+                                          A.ah[e1][0], A.ah[e1][1], A.ah[e1][2], A.ah[e1][3]);
+                  const double b2 = dline(qz, V2[qx + 3 * qy], V2[qx + 3 * qy + 9], V2[qx + 3 * qy + 18],
+                                          A.ah[e2][0], A.ah[e2][1], A.ah[e2][2], A.ah[e2][3]);
+                  const double vb = V2[q];
+                  st0   = make_double2(vb, b0);
+                  st1   = make_double2(b1, b2);
+                  r_ub0 = quad_bcast<0>(vb), r_ub1 = quad_bcast<1>(vb), r_ub2 = quad_bcast<2>(vb);
+                  r_trl = quad_bcast<0>(b0) + quad_bcast<1>(b1) + quad_bcast<2>(b2);
+                }
 #if !defined(Q2_LDS_EXCHANGE)
               // gradient rows of the three velocity components, visible to all four lanes (DPP)
               const double G00 = quad_bcast<0>(g0), G01 = quad_bcast<0>(g1), G02 = quad_bcast<0>(g2);
@@ -1768,6 +1810,7 @@ namespace adaflo_hip
     if (hipGetLastError() != hipSuccess)
       return ADAFLO_EHIP;
     ctx->lin_q2_valid = true;
+    ctx->lin_nodal_valid = false; // (a state that did not come from a nodal field the engine knows)
     ctx->lin_q2_mode  = q2_lin_mode(ctx);
     ctx->lin_q2_varco = varco;
     return 0;
@@ -1801,9 +1844,14 @@ namespace adaflo_hip
         if (int e = q2_prepare_state(ctx))
           return e;
       }
+    // recompute-state mode (default of kernel variant 1 since round 5; variant 4 streams): constant-coefficient Newton
+    // vmult on the nodal linearisation point the last residual left (only then is the state a function of a nodal field
+    // the engine knows)
+    const bool recompute = ctx->q2_recompute && op == OP_VMULT && !residual && q2_lin_mode(ctx) == 0 && !q2_varco(ctx) &&
+                           ctx->lin_q2_valid && ctx->lin_nodal_valid && ctx->lin_nodal.p;
     Q2Args A{};
     const bool divergence = op == OP_DIVERGENCE;
-    A.old_u     = res_old;
+    A.old_u     = recompute ? ctx->lin_nodal.p : res_old;
     A.c_old     = res_c_old;
     A.state_out = residual ? ctx->lin_q2.p : nullptr;
     A.c_div     = res_c_old; // (divergence mode passes its weight here)
@@ -1984,6 +2032,18 @@ namespace adaflo_hip
       hipLaunchKernelGGL((ns_q2_kernel<LM, WP, IS, VC, RS, DV>), grid, block, lds_bytes, ctx->stream, A); \
   }                                                                                             \
   }
+#define Q2_LAUNCH_V7(LM, WP, IS, VC, RS, DV, RC)                                                      \
+  {                                                                                             \
+    static bool attr_set = false;                                                               \
+    if (!attr_set)                                                                              \
+      {                                                                                         \
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_q2_kernel<LM, WP, IS, VC, RS, DV, RC>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
+        attr_set = err == hipSuccess;                                                           \
+      }                                                                                         \
+    if (err == hipSuccess && nwg > 0)                                                           \
+      hipLaunchKernelGGL((ns_q2_kernel<LM, WP, IS, VC, RS, DV, RC>), grid, block, lds_bytes, ctx->stream, A); \
+  }
 #define Q2_LAUNCH_I(LM, WP, IS)              \
   {                                          \
     if (varco)                               \
@@ -2032,6 +2092,13 @@ namespace adaflo_hip
               default:
                 Q2_LAUNCH_V(2, true, false, false, true);
             }
+      }
+    else if (recompute)
+      {
+        if (iso)
+          Q2_LAUNCH_V7(0, true, true, false, false, false, true)
+        else
+          Q2_LAUNCH_V7(0, true, false, false, false, false, true)
       }
     else if (with_p)
       switch (lin_mode)
@@ -2139,6 +2206,25 @@ namespace adaflo_hip
         ctx->lin_q2_valid = true;
         ctx->lin_q2_mode  = lin_mode;
         ctx->lin_q2_varco = false;
+      }
+    // recompute-state mode: keep the nodal linearisation point (the solution this residual was evaluated at)
+    ctx->lin_nodal_valid = false;
+    if (ctx->q2_recompute && lin_mode == 0)
+      {
+        const size_t nu = 3 * (size_t)ctx->n_nodes_u;
+        if (ctx->lin_nodal.count != nu)
+          {
+            if (ctx->lin_nodal.p)
+              (void)hipFree(ctx->lin_nodal.p);
+            ctx->lin_nodal.p     = nullptr;
+            ctx->lin_nodal.count = 0;
+            if (hipMalloc(&ctx->lin_nodal.p, nu * sizeof(double)) != hipSuccess)
+              return ADAFLO_ENOMEM;
+            ctx->lin_nodal.count = nu;
+          }
+        if (hipMemcpyAsync(ctx->lin_nodal.p, src_u, nu * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+          return ADAFLO_EHIP;
+        ctx->lin_nodal_valid = true;
       }
     return 0;
   }

@@ -541,7 +541,12 @@ int adaflo_set_q2_state_pad(adaflo_ctx *ctx, int pad_16B);
 /* select the implementation of the operator applications: 0 = generic per-cell kernels (any
  * degree), 1 = auto (default: Q2/Q1 sweep kernel, Q3..Q5 x-marching kernel ns_hox.hip, structured Q1
  * sweep kernel for the level set and the Q1 pressure operators, generic elsewhere), 2 = as 1 but the
- * round-2 z-sweep kernel (ns_ho.hip) for Q3..Q5, kept for comparison.  All variants are bitwise
+ * round-2 z-sweep kernel (ns_ho.hip) for Q3..Q5, kept for comparison; 3 = as 1 with the plane-per-lane kernel
+ * (ns_hop.hip) for the constant-coefficient Q4/Q3 vmult / velocity_vmult (round 5, slower than 1: kept for comparison);
+ * 4 = as 1 but the Q2/Q1 Newton vmult always STREAMS the quadrature-point state (rounds 1-4).  Since round 5 variant 1
+ * recomputes (u_lin, grad u_lin) from the nodal solution the last adaflo_ns_residual of this context was computed at --
+ * the state is that interpolation, navier_stokes_matrix.cc:778-816 -- and streams only a state that was set through
+ * adaflo_ns_set_linearization or that carries variable coefficients.  All variants are bitwise
  * reproducible. */
 int adaflo_set_kernel_variant(adaflo_ctx *ctx, int variant);
 

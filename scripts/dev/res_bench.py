@@ -1,0 +1,5 @@
+import sys, json
+sys.path.insert(0, "scripts"); sys.path.insert(0, ".")
+import bench_ops as b
+b.ns_residual_case(2, 128, 1)
+b.ns_residual_case(4, 64, 1)

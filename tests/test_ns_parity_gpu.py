@@ -794,3 +794,40 @@ def test_residual_sweep_kernel(ncell, upper, lin, phys):
             op.set_kernel_variant(0)                      # generic kernel on the frozen streaming copy
             op.velocity_vmult(vdst, vsrc)
             assert rel_l2(vdst.numpy(), ref_vel) < TOL, variant
+
+
+@pytest.mark.parametrize("ncell,upper,faces_u", [((9, 8, 5), (1., 1., 1.), range(6)), ((17, 9, 6), (1., 1., 3.), [0, 3, 4]),
+                                                  ((5, 4, 9), (1., 2., 1.), range(6)), ((1, 1, 1), (1., 1., 1.), range(6))])
+def test_vmult_recomputes_the_state_from_the_nodal_linearisation_point(ncell, upper, faces_u):
+    """default since round 5 (kernel variant 1): the Q2/Q1 Newton vmult does not stream (u_lin, grad u_lin) but evaluates
+    it from the nodal solution the last residual was computed at (navier_stokes_matrix.cc:778-816: the state IS that
+    interpolation); against the oracle's vmult on the oracle's state, after a second residual at another point, with
+    the streaming kernel forced (variant 4), and with a state set through the canonical array (no nodal field known: the
+    streaming kernel takes over by itself)"""
+    case = Case(ncell, k=2, lower=(0., 0., 0.), upper=upper, faces_u=faces_u, steps=3, tau_grad_div=0.1)
+    old_u, oldold_u = case.smooth_u(0.05), case.smooth_u(0.0)
+    vm_u, vm_p = case.random_u(), case.random_p()
+    w, modes = case.weights_modes()
+    op = case.engine()
+    dst = op.block_vector()
+    for scale in (1.0, 0.6):
+        src_u, src_p = scale * (case.smooth_u(0.1) + 0.05 * case.random_u()), case.smooth_p(0.1)
+        lin_ref = np.zeros(case.n_cells * case.nq * 12)
+        orc.ns_residual(case.mesh, case.k, case.prm, src_u, src_p, old_u, oldold_u, con_u=case.con_u, con_p=case.con_p,
+                        lin=lin_ref)
+        ref_u, ref_p = orc.ns_vmult(case.mesh, 2, case.prm, vm_u, vm_p, case.con_u, case.con_p, lin=lin_ref,
+                                    weights=w, modes=modes)
+        rhs = op.block_vector()
+        op.residual(rhs, op.block_vector(src_u, src_p), None, op.block_vector(old_u), op.block_vector(oldold_u))
+        for variant in (1, 4):
+            op.set_kernel_variant(variant)
+            op.vmult(dst, op.block_vector(vm_u, vm_p))
+            gu, gp = dst.numpy()
+            assert rel_l2(gu, ref_u) < TOL and rel_l2(gp, ref_p) < TOL, (scale, variant, rel_l2(gu, ref_u), rel_l2(gp, ref_p))
+        op.set_kernel_variant(1)
+    lin = case.random_lin()
+    ref_u, ref_p = orc.ns_vmult(case.mesh, 2, case.prm, vm_u, vm_p, case.con_u, case.con_p, lin=lin, weights=w, modes=modes)
+    op.set_linearization(lin)
+    op.vmult(dst, op.block_vector(vm_u, vm_p))
+    gu, gp = dst.numpy()
+    assert rel_l2(gu, ref_u) < TOL and rel_l2(gp, ref_p) < TOL
