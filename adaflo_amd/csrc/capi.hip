@@ -377,7 +377,7 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
                           &ctx->q1_poisson_coef, &ctx->ho_tab, &ctx->res_sum_u, &ctx->res_sum_p, &ctx->res_old,
                           &ctx->ls_art_visc, &ctx->ls_stab_vel_sum, &ctx->ls_stab_ls_sum, &ctx->hox_lin, &ctx->hox_lin_prec, &ctx->pc_tridiag,
                           &ctx->hox_slab_u, &ctx->hox_xslab_u, &ctx->hox_slab_p, &ctx->hox_xslab_p, &ctx->hox_tab,
-                          &ctx->hop_lin, &ctx->hop_lin_prec, &ctx->hop_tab, &ctx->lin_nodal})
+                          &ctx->hop_lin, &ctx->hop_lin_prec, &ctx->hop_tab, &ctx->lin_nodal, &ctx->lin_nodal_prec})
     release(*b);
   for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch,
                     ctx->d_tab_ls, ctx->d_ls_diag, ctx->d_tab_force, ctx->d_tab_maxvel})
@@ -505,6 +505,7 @@ int adaflo_ns_set_params(adaflo_ctx *ctx, const adaflo_ns_params *p)
       ctx->hox_lin_primary      = false; // (the generic copies are current now; the x-marching kernel re-creates its own)
       ctx->hox_lin_prec_primary = false;
       release(ctx->lin_q2_prec);
+      ctx->lin_nodal_prec_valid = false;
     }
   ctx->ns = NSDev{p->physical_type, p->linearization, p->beta, p->tau_grad_div, p->density,
                   p->viscosity, p->damping, p->density_diff, p->weight, p->weight_old,
@@ -635,6 +636,7 @@ int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx)
       ctx->lin_prec_generic_valid = false;
       release(ctx->rho_prec), release(ctx->mu_prec), release(ctx->damp_prec); // (the residual mode runs with constant coefficients only)
       release(ctx->lin_q2_prec);
+      ctx->lin_nodal_prec_valid = false;
       ctx->q1_poisson_src = nullptr;
       return 0;
     }
@@ -662,9 +664,21 @@ int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx)
                                   hipMemcpyDeviceToDevice, ctx->stream));
       ctx->lin_q2_prec_varco = ctx->lin_q2_varco;
       ctx->lin_q2_prec_mode  = ctx->lin_q2_mode;
+      // ... and the nodal linearisation point of the recompute-state mode, if the state came from a residual
+      ctx->lin_nodal_prec_valid = false;
+      if (ctx->lin_nodal_valid && ctx->lin_q2_valid && ctx->lin_nodal.p)
+        {
+          TRY(ctx, alloc(ctx, ctx->lin_nodal_prec, ctx->lin_nodal.count), ctx->last_error);
+          HIP_TRY(ctx, hipMemcpyAsync(ctx->lin_nodal_prec.p, ctx->lin_nodal.p, ctx->lin_nodal.count * sizeof(double),
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+          ctx->lin_nodal_prec_valid = true;
+        }
     }
   else
-    release(ctx->lin_q2_prec);
+    {
+      release(ctx->lin_q2_prec);
+      ctx->lin_nodal_prec_valid = false;
+    }
   return 0;
 }
 

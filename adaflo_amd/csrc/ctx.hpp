@@ -156,8 +156,8 @@ struct adaflo_ctx
   int                      q2_lz        = 0; // z-chunk length override (0 = heuristic)
   // recompute-state mode of the Q2/Q1 kernel (on by default, kernel variant 4 switches it off): nodal copy of the
   // solution the last residual was evaluated at; valid only together with lin_q2_valid
-  bool                     q2_recompute = true, lin_nodal_valid = false;
-  adaflo_hip::DeviceBuffer lin_nodal;
+  bool                     q2_recompute = true, lin_nodal_valid = false, lin_nodal_prec_valid = false;
+  adaflo_hip::DeviceBuffer lin_nodal, lin_nodal_prec; // (..._prec: frozen by fix_linearization_point, velocity_vmult)
   int                      q2_state_pad = 0; // skew padding (double2) per (tile, layer) state block
 
   // level-set operators

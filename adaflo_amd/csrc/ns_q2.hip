@@ -1847,11 +1847,15 @@ namespace adaflo_hip
     // recompute-state mode (default of kernel variant 1 since round 5; variant 4 streams): constant-coefficient Newton
     // vmult on the nodal linearisation point the last residual left (only then is the state a function of a nodal field
     // the engine knows)
-    const bool recompute = ctx->q2_recompute && op == OP_VMULT && !residual && q2_lin_mode(ctx) == 0 && !q2_varco(ctx) &&
-                           ctx->lin_q2_valid && ctx->lin_nodal_valid && ctx->lin_nodal.p;
+    // (velocity_vmult: the frozen nodal copy if a frozen state exists, else the current one -- as the streamed state)
+    const bool frozen    = op == OP_VMULT_VELOCITY && ctx->lin_q2_prec.p;
+    const bool recompute = ctx->q2_recompute && !residual && (op == OP_VMULT || op == OP_VMULT_VELOCITY) && q2_lin_mode(ctx) == 0 &&
+                           (frozen ? (!ctx->lin_q2_prec_varco && ctx->lin_q2_prec_mode == 0 && ctx->lin_nodal_prec_valid &&
+                                      ctx->lin_nodal_prec.p) :
+                                     (!q2_varco(ctx) && ctx->lin_q2_valid && ctx->lin_nodal_valid && ctx->lin_nodal.p));
     Q2Args A{};
     const bool divergence = op == OP_DIVERGENCE;
-    A.old_u     = recompute ? ctx->lin_nodal.p : res_old;
+    A.old_u     = recompute ? (frozen ? ctx->lin_nodal_prec.p : ctx->lin_nodal.p) : res_old;
     A.c_old     = res_c_old;
     A.state_out = residual ? ctx->lin_q2.p : nullptr;
     A.c_div     = res_c_old; // (divergence mode passes its weight here)
@@ -2093,12 +2097,19 @@ namespace adaflo_hip
                 Q2_LAUNCH_V(2, true, false, false, true);
             }
       }
-    else if (recompute)
+    else if (recompute && with_p)
       {
         if (iso)
           Q2_LAUNCH_V7(0, true, true, false, false, false, true)
         else
           Q2_LAUNCH_V7(0, true, false, false, false, false, true)
+      }
+    else if (recompute)
+      {
+        if (iso)
+          Q2_LAUNCH_V7(0, false, true, false, false, false, true)
+        else
+          Q2_LAUNCH_V7(0, false, false, false, false, false, true)
       }
     else if (with_p)
       switch (lin_mode)

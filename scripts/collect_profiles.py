@@ -58,6 +58,11 @@ for name in sorted(os.listdir(src)):
 
 # HBM bytes per launch of the dominant kernels; gfx950: FETCH_SIZE counts 64 B per 128-B request of wide (16 B per
 # lane) coalesced reads, which is how the Q2/Q1 kernel issues all its loads (MI355X_MICROARCH.md, HBM section)
+try:   # (entries of kernels the run did not profile are kept)
+    with open(os.path.join(dst, "pmc_traffic.json")) as _f:
+        _old = json.load(_f)
+except (OSError, ValueError):
+    _old = {}
 traffic = {"_comment": "scripts/collect_profiles.py from scripts/measure_round.sh %s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in "
                        "separate passes of bench.py --steps 5 --warmup 2; KB per launch averaged.  ns_q2_kernel: hbm_bytes = "
                        "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 correction for 16-B-per-lane streaming reads), the same for "
@@ -71,11 +76,13 @@ def mean_kb(pass_name, kernel, counter):
     return sum(v) / len(v) if v else None
 
 
-VMULT_Q2 = "ns_q2_kernel<0, true, true, false, false, false>"   # (the residual mode <..., true, false> runs once as set-up)
-f, w = mean_kb("pmc_q2_fetch", VMULT_Q2, "FETCH_SIZE"), mean_kb("pmc_q2_write", VMULT_Q2, "WRITE_SIZE")
-if f and w:
-    traffic["128x128x128 k=2 variant=1"] = {"ns_q2_kernel": {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
-                                                                "hbm_bytes": int((2 * f + w) * 1024)}}
+# (the residual mode <..., true, false, false> runs once as set-up; round 5: variant 1 = the recompute-state mode
+# <..., false, false, true>, variant 4 = the streaming kernel <..., false, false, false>)
+for key, passes, kernel in (("128x128x128 k=2 variant=1", ("pmc_q2_fetch", "pmc_q2_write"), "ns_q2_kernel<0, true, true, false, false, false, true>"),
+                            ("128x128x128 k=2 variant=4", ("pmc_q2s_fetch", "pmc_q2s_write"), "ns_q2_kernel<0, true, true, false, false, false, false>")):
+    f, w = mean_kb(passes[0], kernel, "FETCH_SIZE"), mean_kb(passes[1], kernel, "WRITE_SIZE")
+    if f and w:
+        traffic[key] = {"ns_q2_kernel": {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes": int((2 * f + w) * 1024)}}
 # calibration of FETCH_SIZE for the access shape of ns_ho_kernel<4> (8 B per lane in runs of 25 lanes):
 # scripts/dev/fetch_probe.hip reads a known number of bytes in that shape (and 8 / 16 B per lane contiguously)
 PROBE_BYTES = {"read16_contiguous": 2147483648, "read8_contiguous": 2147483648, "read8_runs_of_25": 2147472000}
@@ -104,6 +111,8 @@ if f and w:
     else:
         entry["hbm_bytes"] = int((2 * f + w) * 1024)
     traffic["64x64x64 k=4 variant=1"] = {"ns_hox_kernel": entry}
+for _k, _v in _old.items():
+    traffic.setdefault(_k, _v)
 with open(os.path.join(dst, "pmc_traffic.json"), "w") as out:
     json.dump(traffic, out, indent=1)
 print(json.dumps(traffic, indent=1))
