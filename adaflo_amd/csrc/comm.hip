@@ -379,13 +379,16 @@ namespace
         hipMalloc(&c->rbuf, std::max(nr, 1L) * sizeof(double)) != hipSuccess ||
         hipMalloc(&c->d_inv, 2 * sizeof(double)) != hipSuccess ||
         hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) != hipSuccess ||
-        // (events that order the two streams of ONE device: no system-scope fence.  A default event makes every record
-        // a cache write-back + invalidate of the whole device -- behind a sweep kernel that is 25-30 us during which
-        // the next phase kernel cannot start, profiles/r05_trace_through_comm_before.log; the kernel boundaries already
-        // carry the device-scope release / acquire that the pack -> RCCL -> unpack chain needs, RCCL's own kernels fence
-        // what they move between devices)
-        hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_arrived, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
+        // Events that only order streams of ONE device (ev_src, ev_iface, ev_done below) carry no system-scope fence: a
+        // default event makes every record a cache write-back + invalidate of the whole device -- behind a sweep kernel
+        // that is 25-30 us during which the next kernel cannot start (profiles/r05_trace_through_comm_before.log); the
+        // kernel boundaries already carry the device-scope release / acquire such hand-overs need.  The two events next to
+        // the message transport keep the default semantics: what the pack kernel wrote must be visible to RCCL's send
+        // (possibly a peer's read over xGMI), and what a peer wrote into rbuf must be seen by the unpack kernel -- the
+        // configuration every stream-ordered RCCL program runs in; they are recorded on the auxiliary and the communication
+        // stream, off the engine stream's critical path
+        hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_arrived, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_src, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_iface, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
