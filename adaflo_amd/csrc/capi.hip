@@ -506,6 +506,7 @@ int adaflo_ns_set_params(adaflo_ctx *ctx, const adaflo_ns_params *p)
       ctx->hox_lin_prec_primary = false;
       release(ctx->lin_q2_prec);
       ctx->lin_nodal_prec_valid = false;
+      ctx->lin_serial++;
     }
   ctx->ns = NSDev{p->physical_type, p->linearization, p->beta, p->tau_grad_div, p->density,
                   p->viscosity, p->damping, p->density_diff, p->weight, p->weight_old,
@@ -532,6 +533,7 @@ int adaflo_ns_set_linearization(adaflo_ctx *ctx, const double *lin, int src_on_d
   ctx->lin_q2_valid      = false;
   ctx->lin_generic_valid = true;
   ctx->lin_gen++;
+  ctx->lin_serial++; // (a state that did not come from a nodal field the engine knows: nothing to recompute from)
   ctx->hox_lin_primary = false;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (staging)
@@ -666,7 +668,7 @@ int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx)
       ctx->lin_q2_prec_mode  = ctx->lin_q2_mode;
       // ... and the nodal linearisation point of the recompute-state mode, if the state came from a residual
       ctx->lin_nodal_prec_valid = false;
-      if (ctx->lin_nodal_valid && ctx->lin_q2_valid && ctx->lin_nodal.p)
+      if (lin_nodal_current(ctx))
         {
           TRY(ctx, alloc(ctx, ctx->lin_nodal_prec, ctx->lin_nodal.count), ctx->last_error);
           HIP_TRY(ctx, hipMemcpyAsync(ctx->lin_nodal_prec.p, ctx->lin_nodal.p, ctx->lin_nodal.count * sizeof(double),
@@ -802,6 +804,7 @@ int adaflo_ns_residual(adaflo_ctx *ctx, double *rhs_u, double *rhs_p, const doub
     return fail(ctx, ADAFLO_EINVAL, "null vector");
   if (ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE && (!old_u || !old_old_u))
     return fail(ctx, ADAFLO_EINVAL, "solution_old / solution_old_old required");
+  ctx->lin_serial++; // (whatever path: the state is that of src from here on)
   if (ctx->variant >= 1 && q2_residual_supported(ctx))
     {
       // sweep kernel in residual mode: cell-loop sums into work vectors, then
@@ -861,6 +864,8 @@ int adaflo_ns_residual(adaflo_ctx *ctx, double *rhs_u, double *rhs_p, const doub
   a.oldold_u = old_old_u;
   TRY(ctx, launch_ns_cell_generic(ctx, OP_RESIDUAL, a), "cell kernel launch failed");
   ctx->lin_q2_valid = false;
+  if (ctx->variant >= 1 && q2_supported(ctx)) // (two-phase flow: the Q2/Q1 vmult recomputes the state from this copy)
+    TRY(ctx, q2_capture_nodal(ctx, src_u), "nodal copy failed");
   // system_rhs.sadd(-1., 1., user_rhs)  :292
   TRY(ctx, launch_sadd(ctx, rhs_u, -1., user_u, 3 * ctx->n_nodes_u), "sadd failed");
   TRY(ctx, launch_sadd(ctx, rhs_p, -1., user_p, ctx->n_nodes_p), "sadd failed");

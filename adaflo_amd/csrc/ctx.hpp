@@ -156,7 +156,10 @@ struct adaflo_ctx
   int                      q2_lz        = 0; // z-chunk length override (0 = heuristic)
   // recompute-state mode of the Q2/Q1 kernel (on by default, kernel variant 4 switches it off): nodal copy of the
   // solution the last residual was evaluated at; valid only together with lin_q2_valid
-  bool                     q2_recompute = true, lin_nodal_valid = false, lin_nodal_prec_valid = false;
+  // lin_serial counts every change of the linearisation state (set_linearization, any residual, a change of scheme); the
+  // nodal copy is current while lin_nodal_serial equals it -- whatever layouts the state has been converted to since
+  bool                     q2_recompute = true, lin_nodal_prec_valid = false;
+  unsigned long            lin_serial = 1, lin_nodal_serial = 0;
   adaflo_hip::DeviceBuffer lin_nodal, lin_nodal_prec; // (..._prec: frozen by fix_linearization_point, velocity_vmult)
   int                      q2_state_pad = 0; // skew padding (double2) per (tile, layer) state block
 

@@ -180,6 +180,12 @@ namespace adaflo_hip
   int  q2_prepare_state(adaflo_ctx *ctx);
   int  launch_ns_vmult_q2(adaflo_ctx *ctx, int op, double *dst_u, double *dst_p,
                           const double *src_u, const double *src_p, int phase = -1, uint32_t iface = 0);
+  // recompute-state mode: nodal copy of the solution a residual has just been evaluated at (no-op unless the mode applies)
+  int  q2_capture_nodal(adaflo_ctx *ctx, const double *src_u);
+  inline bool lin_nodal_current(const adaflo_ctx *ctx)
+  {
+    return ctx->lin_nodal.p && ctx->lin_nodal_serial == ctx->lin_serial;
+  }
   // residual mode of the sweep kernel (writes the quadrature-point state in the streaming layout)
   bool q2_residual_supported(const adaflo_ctx *ctx);
   int  launch_ns_residual_q2(adaflo_ctx *ctx, double *sum_u, double *sum_p, const double *src_u,

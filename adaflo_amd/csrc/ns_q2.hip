@@ -56,6 +56,7 @@ namespace adaflo_hip
       const double *src_u, *src_p;
       double       *dst_u, *dst_p;
       const double *state;
+      const double *rho, *mu, *damp; // recompute mode with variable coefficients: generic arrays [cell][q]
       // residual mode (template RES): combination of the old solutions at the nodes
       // (weight_old u_old + weight_old_old u_old_old), its factor rho_old in the momentum row,
       // and the streaming state array the kernel WRITES (linearisation point = src)
@@ -581,8 +582,10 @@ namespace adaflo_hip
 #endif
     __global__ __launch_bounds__(NT, (RES ? Q2_RES_LB : (RCP ? Q2_RCP_LB : Q2_LB))) void ns_q2_kernel(const Q2Args A)
     {
-      constexpr bool RING_ON = LIN_MODE != 2 && !RES && !RCP; // state stream through the LDS ring
-      static_assert(!RCP || (LIN_MODE == 0 && !RES && !VARCO && !DIV), "recompute mode: constant-coefficient Newton vmult");
+      constexpr bool RING_ON = LIN_MODE != 2 && !RES && !RCP; // state stream through the LDS ring (RCP with variable
+                                                              // coefficients: rho, mu, damping by plain loads from the
+                                                              // generic arrays, 24 B per cell and point, L2-friendly)
+      static_assert(!RCP || (LIN_MODE == 0 && !RES && !DIV), "recompute mode: Newton vmult");
       static_assert(!DIV || (LIN_MODE == 2 && WITH_P && !RES && !VARCO), "divergence mode");
       static_assert(!(RES && VARCO), "residual mode: constant coefficients only");
       extern __shared__ double lds[];
@@ -809,6 +812,11 @@ namespace adaflo_hip
           if (NX_ > 0 && layer > 0)
             issue_burst(cz);
 
+          // recompute mode with variable coefficients: first entry of my cell in the generic arrays [cell][27] (cells
+          // beyond the mesh read the tile's first cell: legal address, unused values)
+          const unsigned coef_cell = (RCP && VARCO) ?
+                                       (unsigned)((((size_t)cz * A.ncy + (TY * by + (valid ? cyl : 0))) * A.ncx + (TX * bx + (valid ? cxl : 0))) * 27) :
+                                       0u;
           double R[27];
           double V2[(RES || RCP) ? 27 : 1]; // second nodal field: old-solution combination (RES) / linearisation point (RCP)
           if (RES || RCP)
@@ -993,6 +1001,11 @@ namespace adaflo_hip
               const double  g2 = dline(qz, V[qx + 3 * qy], V[qx + 3 * qy + 9], V[qx + 3 * qy + 18],
                                        A.ah[e2][0], A.ah[e2][1], A.ah[e2][2], A.ah[e2][3]);
 
+              if (RCP && VARCO)
+                {
+                  const unsigned cq_ = coef_cell + (unsigned)q;
+                  r_rho = A.rho[cq_], r_mu = A.mu[cq_], r_damp = A.damp[cq_];
+                }
               if (RCP)
                 {
                   // the state of this point from the interpolated nodal linearisation point: my component's value and
@@ -1810,7 +1823,6 @@ namespace adaflo_hip
     if (hipGetLastError() != hipSuccess)
       return ADAFLO_EHIP;
     ctx->lin_q2_valid = true;
-    ctx->lin_nodal_valid = false; // (a state that did not come from a nodal field the engine knows)
     ctx->lin_q2_mode  = q2_lin_mode(ctx);
     ctx->lin_q2_varco = varco;
     return 0;
@@ -1837,25 +1849,30 @@ namespace adaflo_hip
                        const double *src_p, const int phase, const uint32_t iface, const bool residual,
                        const double *res_old, const double res_c_old)
   {
-    if (!residual && op != OP_DIVERGENCE)
+    // recompute-state mode (default of kernel variant 1 since round 5; variant 4 streams): Newton vmult / velocity_vmult
+    // on the nodal linearisation point the last residual left (only then is the state a function of a nodal field the
+    // engine knows); variable coefficients are read from the generic arrays.  velocity_vmult: the frozen nodal copy and
+    // the frozen coefficients if fix_linearization_point has been called, else the current ones -- as the streamed state
+    const bool frozen    = op == OP_VMULT_VELOCITY && (ctx->lin_q2_prec.p || ctx->lin_prec.p);
+    const bool recompute = ctx->q2_recompute && !residual && (op == OP_VMULT || op == OP_VMULT_VELOCITY) && q2_lin_mode(ctx) == 0 &&
+                           (frozen ? (ctx->lin_nodal_prec_valid && ctx->lin_nodal_prec.p != nullptr) : lin_nodal_current(ctx));
+    const bool rc_varco  = recompute && (frozen ? ctx->rho_prec.p != nullptr : q2_varco(ctx));
+    if (!residual && op != OP_DIVERGENCE && !recompute)
       {
         if (ctx->lin_q2_valid && (ctx->lin_q2_mode != q2_lin_mode(ctx) || ctx->lin_q2_varco != q2_varco(ctx)))
           ctx->lin_q2_valid = false;
         if (int e = q2_prepare_state(ctx))
           return e;
       }
-    // recompute-state mode (default of kernel variant 1 since round 5; variant 4 streams): constant-coefficient Newton
-    // vmult on the nodal linearisation point the last residual left (only then is the state a function of a nodal field
-    // the engine knows)
-    // (velocity_vmult: the frozen nodal copy if a frozen state exists, else the current one -- as the streamed state)
-    const bool frozen    = op == OP_VMULT_VELOCITY && ctx->lin_q2_prec.p;
-    const bool recompute = ctx->q2_recompute && !residual && (op == OP_VMULT || op == OP_VMULT_VELOCITY) && q2_lin_mode(ctx) == 0 &&
-                           (frozen ? (!ctx->lin_q2_prec_varco && ctx->lin_q2_prec_mode == 0 && ctx->lin_nodal_prec_valid &&
-                                      ctx->lin_nodal_prec.p) :
-                                     (!q2_varco(ctx) && ctx->lin_q2_valid && ctx->lin_nodal_valid && ctx->lin_nodal.p));
     Q2Args A{};
     const bool divergence = op == OP_DIVERGENCE;
     A.old_u     = recompute ? (frozen ? ctx->lin_nodal_prec.p : ctx->lin_nodal.p) : res_old;
+    if (rc_varco)
+      {
+        A.rho  = frozen ? ctx->rho_prec.p : ctx->rho.p;
+        A.mu   = frozen ? ctx->mu_prec.p : ctx->mu.p;
+        A.damp = frozen ? ctx->damp_prec.p : ctx->damp.p;
+      }
     A.c_old     = res_c_old;
     A.state_out = residual ? ctx->lin_q2.p : nullptr;
     A.c_div     = res_c_old; // (divergence mode passes its weight here)
@@ -2097,19 +2114,24 @@ namespace adaflo_hip
                 Q2_LAUNCH_V(2, true, false, false, true);
             }
       }
-    else if (recompute && with_p)
-      {
-        if (iso)
-          Q2_LAUNCH_V7(0, true, true, false, false, false, true)
-        else
-          Q2_LAUNCH_V7(0, true, false, false, false, false, true)
-      }
     else if (recompute)
       {
-        if (iso)
-          Q2_LAUNCH_V7(0, false, true, false, false, false, true)
+#define Q2_LAUNCH_RC(WP, IS)                                 \
+  {                                                          \
+    if (rc_varco)                                            \
+      Q2_LAUNCH_V7(0, WP, IS, true, false, false, true)      \
+    else                                                     \
+      Q2_LAUNCH_V7(0, WP, IS, false, false, false, true)     \
+  }
+        if (with_p && iso)
+          Q2_LAUNCH_RC(true, true)
+        else if (with_p)
+          Q2_LAUNCH_RC(true, false)
+        else if (iso)
+          Q2_LAUNCH_RC(false, true)
         else
-          Q2_LAUNCH_V7(0, false, false, false, false, false, true)
+          Q2_LAUNCH_RC(false, false)
+#undef Q2_LAUNCH_RC
       }
     else if (with_p)
       switch (lin_mode)
@@ -2186,6 +2208,28 @@ namespace adaflo_hip
   // sum_u / sum_p = cell-loop result of NavierStokesOps::residual (zero on constrained rows);
   // old_comb = weight_old u_old + weight_old_old u_old_old at the nodes (or nullptr).  Leaves the
   // quadrature-point state of `src` in the streaming layout (ctx->lin_q2).
+  // (the caller has bumped ctx->lin_serial for the state it is about to produce)
+  int q2_capture_nodal(adaflo_ctx *ctx, const double *src_u)
+  {
+    if (!ctx->q2_recompute || q2_lin_mode(ctx) != 0)
+      return 0;
+    const size_t nu = 3 * (size_t)ctx->n_nodes_u;
+    if (ctx->lin_nodal.count != nu)
+      {
+        if (ctx->lin_nodal.p)
+          (void)hipFree(ctx->lin_nodal.p);
+        ctx->lin_nodal.p     = nullptr;
+        ctx->lin_nodal.count = 0;
+        if (hipMalloc(&ctx->lin_nodal.p, nu * sizeof(double)) != hipSuccess)
+          return ADAFLO_ENOMEM;
+        ctx->lin_nodal.count = nu;
+      }
+    if (hipMemcpyAsync(ctx->lin_nodal.p, src_u, nu * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+      return ADAFLO_EHIP;
+    ctx->lin_nodal_serial = ctx->lin_serial;
+    return 0;
+  }
+
   int launch_ns_residual_q2(adaflo_ctx *ctx, double *sum_u, double *sum_p, const double *src_u,
                             const double *src_p, const double *old_comb)
   {
@@ -2219,24 +2263,9 @@ namespace adaflo_hip
         ctx->lin_q2_varco = false;
       }
     // recompute-state mode: keep the nodal linearisation point (the solution this residual was evaluated at)
-    ctx->lin_nodal_valid = false;
-    if (ctx->q2_recompute && lin_mode == 0)
-      {
-        const size_t nu = 3 * (size_t)ctx->n_nodes_u;
-        if (ctx->lin_nodal.count != nu)
-          {
-            if (ctx->lin_nodal.p)
-              (void)hipFree(ctx->lin_nodal.p);
-            ctx->lin_nodal.p     = nullptr;
-            ctx->lin_nodal.count = 0;
-            if (hipMalloc(&ctx->lin_nodal.p, nu * sizeof(double)) != hipSuccess)
-              return ADAFLO_ENOMEM;
-            ctx->lin_nodal.count = nu;
-          }
-        if (hipMemcpyAsync(ctx->lin_nodal.p, src_u, nu * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
-          return ADAFLO_EHIP;
-        ctx->lin_nodal_valid = true;
-      }
+    if (lin_mode == 0)
+      if (int e = q2_capture_nodal(ctx, src_u))
+        return e;
     return 0;
   }
 } // namespace adaflo_hip

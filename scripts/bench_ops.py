@@ -27,7 +27,10 @@ def timeit(fn, sync, reps=20, warm=3):
     return (time.perf_counter() - t0) / reps
 
 
-def ns_case(k, n, variant, two_phase=False):
+def ns_case(k, n, variant, two_phase=False, state_from_residual=False):
+    """state_from_residual: the state comes from NavierStokesMatrix::residual of the same context, the way a Newton
+    step produces it -- for Q2/Q1 with Newton linearisation the vmult then recomputes it from the nodal linearisation
+    point (kernel variant 1; variant 4 streams it); otherwise a random canonical array is set and streamed"""
     fp = adaflo_amd.FlowParameters(velocity_degree=k, density_diff=0.5 if two_phase else 0.0)
     ts = adaflo_amd.TimeStepping(fp)
     for _ in range(3):
@@ -37,17 +40,21 @@ def ns_case(k, n, variant, two_phase=False):
     op.set_kernel_variant(variant)
     rng = np.random.default_rng(1)
     nq = (k + 1) ** 3
-    op.set_linearization(rng.uniform(-1, 1, op.n_cells() * nq * 12))
+    if not state_from_residual:
+        op.set_linearization(rng.uniform(-1, 1, op.n_cells() * nq * 12))
     if two_phase:  # variable rho, mu, damping at the quadrature points
         nc = op.n_cells() * nq
         op.set_coefficients(rng.uniform(.5, 2, nc), rng.uniform(.5, 2, nc), rng.uniform(-.5, .5, nc))
     src = op.block_vector(rng.uniform(-1, 1, op.n_dofs_u()), rng.uniform(-1, 1, op.n_dofs_p()))
     dst = op.block_vector()
+    if state_from_residual:
+        op.residual(dst, src, None, op.block_vector(rng.uniform(-1, 1, op.n_dofs_u())),
+                    op.block_vector(rng.uniform(-1, 1, op.n_dofs_u())))
     t = timeit(lambda: op.vmult(dst, src), op.synchronize)
     ndof = op.n_dofs_u() + op.n_dofs_p()
     b_alg = op.n_cells() * (16 * (3 * k ** 3 + (k - 1) ** 3) + 8 * (15 if two_phase else 12) * nq)
-    print(json.dumps({"op": "ns_vmult" + ("_two_phase" if two_phase else ""), "k": k, "cells": n,
-                      "variant": variant, "ms": round(t * 1e3, 4),
+    print(json.dumps({"op": "ns_vmult" + ("_two_phase" if two_phase else "") + ("_after_residual" if state_from_residual else ""),
+                      "k": k, "cells": n, "variant": variant, "ms": round(t * 1e3, 4),
                       "MDoF/s": round(ndof / t / 1e6, 1), "alg_GB/s": round(b_alg / t / 1e9, 1),
                       "frac_of_8TB/s": round(b_alg / t / 8e12, 4)}), flush=True)
 
@@ -259,6 +266,9 @@ if __name__ == "__main__":
     ns_host_vector_case(128)
     ns_case(2, 128, 1, two_phase=True)
     ns_case(2, 128, 0, two_phase=True)
+    for v in (1, 4):                                 # round 5: state recomputed from the nodal linearisation point (1) / streamed (4)
+        ns_case(2, 128, v, state_from_residual=True)
+        ns_case(2, 128, v, two_phase=True, state_from_residual=True)
     for k, n in ((3, 64), (4, 64), (5, 48)):        # 1: x-marching kernel (round 4), 2: z-sweep kernel (round 2), 0: generic
         for v in (1, 2, 0):
             ns_case(k, n, v)

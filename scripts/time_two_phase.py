@@ -30,6 +30,8 @@ def main():
         ctx = ns.navier_stokes_matrix._require()
         adaflo_amd._lib.check(ctx, adaflo_amd._lib.load().adaflo_ns_preconditioner_set_inner(ctx, int(sys.argv[3])))
 
+    if os.environ.get("ADAFLO_KERNEL_VARIANT"):   # e.g. 4: the Q2/Q1 vmult streams the state instead of recomputing it
+        ns.navier_stokes_matrix.set_kernel_variant(int(os.environ["ADAFLO_KERNEL_VARIANT"]))
     if len(sys.argv) > 6:      # cheap stage of the two-phase solver: BiCGStab iterations of the velocity block (0 = off)
         ns.cheap_velocity_iterations = int(sys.argv[6])
 

@@ -831,3 +831,42 @@ def test_vmult_recomputes_the_state_from_the_nodal_linearisation_point(ncell, up
     op.vmult(dst, op.block_vector(vm_u, vm_p))
     gu, gp = dst.numpy()
     assert rel_l2(gu, ref_u) < TOL and rel_l2(gp, ref_p) < TOL
+
+
+@pytest.mark.parametrize("ncell,upper", [((9, 8, 5), (1., 1., 1.)), ((17, 9, 6), (1., 1., 3.)), ((3, 2, 2), (1., 2., 1.))])
+def test_two_phase_vmult_recomputes_the_state_from_the_nodal_linearisation_point(ncell, upper):
+    """variable density / viscosity / damping (the two-phase Jacobian): the residual runs on the generic kernel, the
+    Q2/Q1 Newton vmult and velocity_vmult recompute (u_lin, grad u_lin) from the nodal copy it left and read rho, mu,
+    damping from the generic arrays -- no 64-lane streaming copy is built for them; against the oracle, against the
+    streaming kernel (variant 4), and the frozen operator after new coefficients and a new residual"""
+    case = Case(ncell, k=2, lower=(0., 0., 0.), upper=upper, steps=3, tau_grad_div=0.1, density_diff=0.5)
+    old_u, oldold_u = case.smooth_u(0.05), case.smooth_u(0.0)
+    vm_u, vm_p = case.random_u(), case.random_p()
+    w, modes = case.weights_modes()
+    rho, mu, damp = case.random_coefficients()
+    src_u, src_p = case.smooth_u(0.1) + 0.05 * case.random_u(), case.smooth_p(0.1)
+    lin_ref = np.zeros(case.n_cells * case.nq * 12)
+    orc.ns_residual(case.mesh, case.k, case.prm, src_u, src_p, old_u, oldold_u, con_u=case.con_u, con_p=case.con_p,
+                    lin=lin_ref, rho=rho, mu=mu, damp=damp)
+    ref_u, ref_p = orc.ns_vmult(case.mesh, 2, case.prm, vm_u, vm_p, case.con_u, case.con_p, lin=lin_ref, rho=rho, mu=mu,
+                                damp=damp, weights=w, modes=modes)
+    ref_vel = orc.ns_velocity_vmult(case.mesh, 2, case.prm, vm_u, case.con_u, lin=lin_ref, rho=rho, mu=mu, damp=damp)
+    op = case.engine()
+    op.set_coefficients(rho, mu, damp)
+    rhs, dst = op.block_vector(), op.block_vector()
+    op.residual(rhs, op.block_vector(src_u, src_p), None, op.block_vector(old_u), op.block_vector(oldold_u))
+    for variant in (1, 4):
+        op.set_kernel_variant(variant)
+        op.vmult(dst, op.block_vector(vm_u, vm_p))
+        gu, gp = dst.numpy()
+        assert rel_l2(gu, ref_u) < TOL and rel_l2(gp, ref_p) < TOL, (variant, rel_l2(gu, ref_u), rel_l2(gp, ref_p))
+    op.set_kernel_variant(1)
+    op.fix_linearization_point()
+    # the operator moves on: other coefficients, another linearisation point -- the frozen one must not follow
+    op.set_coefficients(*case.random_coefficients())
+    op.residual(rhs, op.block_vector(0.5 * src_u, src_p), None, op.block_vector(old_u), op.block_vector(oldold_u))
+    vsrc, vdst = op.initialize_u_vector(vm_u), op.initialize_u_vector()
+    for variant in (1, 4):
+        op.set_kernel_variant(variant)
+        op.velocity_vmult(vdst, vsrc)
+        assert rel_l2(vdst.numpy(), ref_vel) < TOL, variant
