@@ -15,6 +15,13 @@
 #include "hox_intrin.hpp"
 #include "ns_hox_kernel.hpp"
 
+// recompute-state mode of the x-marching kernels (template RCP of ns_hox_kernel): measured
+// SLOWER than the streamed state for k = 3, 4, 5 (Q4/Q3 64^3: 1.85 against 1.32 ms), so the product build does not
+// instantiate it; -DHOX_RCP_BUILD=1 reproduces the measurement (scripts/dev/ab_hox_rcp.sh), the emulator tests cover it
+#ifndef HOX_RCP_BUILD
+#define HOX_RCP_BUILD 0
+#endif
+
 namespace adaflo_hip
 {
   namespace
@@ -158,7 +165,7 @@ namespace adaflo_hip
       A.src_p       = src_p;
       A.dst_u       = dst_u;
       A.dst_p       = dst_p;
-      bool varco = false;
+      bool varco = false, recompute = false;
       if (residual)
         {
           A.old_u = old_comb;
@@ -170,8 +177,20 @@ namespace adaflo_hip
               A.lin_out = ctx->hox_lin.p;
             }
         }
-      else if (int e = prepare_state<K>(ctx, op == OP_VMULT_VELOCITY, lin_mode, &A.lin, &varco))
-        return e;
+      else
+        {
+          // recompute-state mode (default of kernel variant 1; variant 4 streams): the state is the interpolation of the
+          // nodal field the last residual was evaluated at -- constant coefficients; velocity_vmult takes the frozen
+          // nodal copy if fix_linearization_point has been called, as the streamed state
+          const bool frozen = op == OP_VMULT_VELOCITY && (ctx->lin_prec.p || ctx->hox_lin_prec_primary || ctx->rho_prec.p);
+          const bool co     = frozen ? ctx->rho_prec.p != nullptr : ctx->rho.p != nullptr;
+          recompute = HOX_FUSED && HOX_RCP_BUILD && ctx->q2_recompute && lin_mode != 2 && !co &&
+                      (frozen ? (ctx->lin_nodal_prec_valid && ctx->lin_nodal_prec.p != nullptr) : lin_nodal_current(ctx));
+          if (recompute)
+            A.lin_u = frozen ? ctx->lin_nodal_prec.p : ctx->lin_nodal.p;
+          else if (int e = prepare_state<K>(ctx, op == OP_VMULT_VELOCITY, lin_mode, &A.lin, &varco))
+            return e;
+        }
       const bool   with_p = op == OP_VMULT || residual;
       const size_t n_wg   = (size_t)A.tiles_y * A.tiles_z * A.n_chunks;
       if (int e = ensure(ctx->hox_slab_u, n_wg * G::RIMU * (K * A.LX + 1) * 3))
@@ -224,7 +243,8 @@ namespace adaflo_hip
           A.iface     = iface;
           nwg         = A.wg_count;
         }
-      const size_t lds_bytes = (size_t)G::LDS_BYTES;
+      const bool   deep      = HOX_DEEP && G::RING && !residual && !varco && !recompute && lin_mode != 2;
+      const size_t lds_bytes = (size_t)(deep ? G::LDS_BYTES_DEEP : G::LDS_BYTES);
       const dim3   grid((unsigned)(nwg > 0 ? nwg : 1)), block(NTH);
       hipError_t   err  = hipSuccess;
       hipEvent_t   stop = (ctx->timing && nwg > 0) ? ctx->kernel_timer.start(ctx->stream) : nullptr;
@@ -240,12 +260,29 @@ namespace adaflo_hip
     if (err == hipSuccess && nwg > 0)                                                                          \
       hipLaunchKernelGGL((ns_hox_kernel<K, LM, WP, false, VC>), grid, block, lds_bytes, ctx->stream, A);       \
   }
-#define HOX_LAUNCH(LM, WP)       \
-  {                              \
-    if (varco)                   \
-      HOX_LAUNCH_V(LM, WP, true) \
-    else                         \
-      HOX_LAUNCH_V(LM, WP, false) \
+#define HOX_LAUNCH_RC(LM, WP)                                                                                       \
+  {                                                                                                                \
+    static bool attr_set = false;                                                                                  \
+    if (!attr_set)                                                                                                 \
+      {                                                                                                            \
+        err      = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_hox_kernel<K, LM, WP, false, false, true>), \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);               \
+        attr_set = err == hipSuccess;                                                                              \
+      }                                                                                                            \
+    if (err == hipSuccess && nwg > 0)                                                                              \
+      hipLaunchKernelGGL((ns_hox_kernel<K, LM, WP, false, false, true>), grid, block, lds_bytes, ctx->stream, A);  \
+  }
+#define HOX_LAUNCH(LM, WP)                     \
+  {                                            \
+    if (varco)                                 \
+      HOX_LAUNCH_V(LM, WP, true)               \
+    else if (recompute)                        \
+      {                                        \
+        if constexpr (LM != 2 && HOX_FUSED && HOX_RCP_BUILD) \
+          HOX_LAUNCH_RC(LM, WP)                \
+      }                                        \
+    else                                       \
+      HOX_LAUNCH_V(LM, WP, false)              \
   }
 #define HOX_LAUNCH_RES(LM)                                                                                \
   {                                                                                                       \
@@ -296,6 +333,7 @@ namespace adaflo_hip
               HOX_LAUNCH(2, false);
           }
 #undef HOX_LAUNCH
+#undef HOX_LAUNCH_RC
 #undef HOX_LAUNCH_V
 #undef HOX_LAUNCH_RES
       if (err != hipSuccess)
@@ -330,6 +368,9 @@ namespace adaflo_hip
 #endif
       if (residual && lin_mode != 2)
         {
+          if (HOX_RCP_BUILD)
+            if (int e = q2_capture_nodal(ctx, src_u)) // (the recompute-state mode of the vmults of this Newton step)
+              return e;
           // the streaming copy is now THE state: the generic copy is stale until somebody asks for it
           ctx->lin_gen++;
           ctx->hox_lin_gen       = ctx->lin_gen;

@@ -50,6 +50,13 @@ namespace adaflo_hip
 #ifndef HOX_FLAGS
 #define HOX_FLAGS 0
 #endif
+    // HOX_FUSED (round 5, default): evaluate and integrate carry value AND derivative arrays through the transposes
+    // (x: S u, (D S) u -> y: 3 arrays -> z: value + gradient at the quadrature points of the lane's z-LINE), two exchange
+    // stages per component and phase instead of four to six; 9 instead of 6 one-dimensional contractions, the same LDS
+    // volume.  The quadrature loop then runs on z-lines.  0: the round-4 form (x-lines, derivative by derivative)
+#ifndef HOX_FUSED
+#define HOX_FUSED 1
+#endif
     constexpr int NTH  = 256;
     constexpr int NMAX = 6;
     constexpr int NLIN_ = 12;
@@ -96,6 +103,10 @@ namespace adaflo_hip
       static constexpr int  RING_BYTES = RING ? 2 * (NLIN_ / 2) * SLOT : 0; // per wave
       static constexpr int  FLAG_BYTES = 64; // pub[4], done[4] (HOX_FLAGS)
       static constexpr int  LDS_BYTES = 8 * (4 * WAVE + PUB_DOUBLES) + 4 * RING_BYTES + FLAG_BYTES;
+      // HOX_DEEP: a ring of ALL N points of a cell (the state of a step is issued one whole step ahead), one workgroup
+      // per CU
+      static constexpr int  RING_BYTES_DEEP = RING ? N * (NLIN_ / 2) * SLOT : 0;
+      static constexpr int  LDS_BYTES_DEEP  = 8 * (4 * WAVE + PUB_DOUBLES) + 4 * RING_BYTES_DEEP + FLAG_BYTES;
       static_assert(NL <= PL, "cell does not fit its lane slot");
       static_assert(WY * WZ == 4, "four waves per workgroup");
     };
@@ -112,6 +123,7 @@ namespace adaflo_hip
       int    integrate_p;
       uint32_t con_u, con_p;
       const double *src_u, *src_p, *lin; // lin: streaming layout of this kernel (hox_state_offset)
+      const double *lin_u;               // recompute-state mode (template RCP): the nodal linearisation point
       double       *dst_u, *dst_p;
       // residual mode (template RES): nodal combination weight_old u_old + weight_old_old u_old_old (or null), its
       // factor (the density), and the streaming state the kernel WRITES for the vmults of this Newton step
@@ -226,7 +238,8 @@ namespace adaflo_hip
     {
       static constexpr int N = K + 1, NP = K;
       static constexpr int S = 0, ST = S + eo_size(N, N), D = ST + eo_size(N, N), DT = D + eo_size(N, N),
-                           SP = DT + eo_size(N, N), SPT = SP + eo_size(N, NP), C = SPT + eo_size(NP, N);
+                           SP = DT + eo_size(N, N), SPT = SP + eo_size(N, NP), DS = SPT + eo_size(NP, N),
+                           DST = DS + eo_size(N, N), C = DST + eo_size(N, N); // DS = D S: nodes -> d/dx at the Gauss points
       static constexpr int C_W = 0, C_IH = N, C_DET = N + 3, C_CA = N + 4, C_CB = N + 5, C_BETA = N + 6, C_TGD = N + 7,
                            C_TMU = N + 8, C_GAMMA = N + 9, C_T1RHO = N + 10, C_DAMPF = N + 11, C_TAU1 = N + 12,
                            SIZE = C + N + 13;
@@ -246,6 +259,15 @@ namespace adaflo_hip
       eo_table(t, Dc, N, N, true);
       eo_table(t, Sp, N, NP, false);
       eo_table(t, Sp, N, NP, true);
+      {
+        std::vector<double> DS(N * N, 0.);
+        for (int q = 0; q < N; ++q)
+          for (int i = 0; i < N; ++i)
+            for (int r = 0; r < N; ++r)
+              DS[q * N + i] += Dc[q * N + r] * S[r * N + i];
+        eo_table(t, DS.data(), N, N, false);
+        eo_table(t, DS.data(), N, N, true);
+      }
       for (int q = 0; q < N; ++q)
         t.push_back(w[q]);
       for (int e = 0; e < 3; ++e)
@@ -405,6 +427,17 @@ namespace adaflo_hip
 #ifndef HOX_LB
 #define HOX_LB 2
 #endif
+    // HOX_DEEP = 1 (experiment, round 5): k = 4 with a streamed state at ONE workgroup per CU (512 registers, 147 KB of
+    // LDS) and a state ring that holds a whole cell: every point's pieces are issued one step (~15 k cycles) before they
+    // are read, where the two-point ring issues three of five points ~500 cycles ahead of an HBM round trip of ~2 700
+#ifndef HOX_DEEP
+#define HOX_DEEP 0
+#endif
+    template <int K, int LIN_MODE, bool RES, bool VARCO, bool RCP>
+    constexpr bool hox_deep()
+    {
+      return HOX_DEEP && Geo<K>::RING && !RES && !VARCO && !RCP && LIN_MODE != 2 && !(HOX_EXP & 4);
+    }
 
     // RES: residual mode (source/navier_stokes_matrix.cc:266-293, 663-686, 725-800 for the schemes without
     // extrapolated old velocities): plain reads of the current solution (boundary values included), the nonlinear
@@ -414,18 +447,26 @@ namespace adaflo_hip
     // VARCO: variable density / viscosity / damping at the quadrature points (two-phase flow, :636-642, :827-845): two
     // more pieces per point in the state stream, (rho, mu) and (damping, -); register prefetch also for k = 4 (the
     // ring would not fit the LDS of two workgroups per CU)
-    template <int K, int LIN_MODE, bool WITH_P, bool RES = false, bool VARCO = false>
+    // RCP: recompute-state mode (round 5, as ns_q2.hip): the linearisation state (u_lin, grad u_lin) at the quadrature
+    // points is the interpolation of the nodal field the last residual was evaluated at -- three more evaluate chains per
+    // cell on node lines that are read like the source vector (72 B per node) instead of 96 B of state per quadrature point
+    template <int K, int LIN_MODE, bool WITH_P, bool RES = false, bool VARCO = false, bool RCP = false>
 #ifndef HOX_RES_LB
 #define HOX_RES_LB HOX_LB
 #endif
-    __global__ __launch_bounds__(NTH, (RES ? HOX_RES_LB : HOX_LB)) void ns_hox_kernel(const HXArgs A)
+#ifndef HOX_RCP_LB
+#define HOX_RCP_LB HOX_LB
+#endif
+    __global__ __launch_bounds__(NTH, (RES ? HOX_RES_LB : (RCP ? HOX_RCP_LB : (hox_deep<K, LIN_MODE, RES, VARCO, RCP>() ? 1 : HOX_LB))))
+      void ns_hox_kernel(const HXArgs A)
     {
+      static_assert(!RCP || (!RES && !VARCO && LIN_MODE != 2 && HOX_FUSED), "recompute-state mode: Newton / Picard vmult, constant coefficients");
       using G           = Geo<K>;
       constexpr int N = G::N, NP = G::NP, KP = G::KP, NL = G::NL, N3 = G::N3, NN = N * N;
       constexpr int CPW = G::CPW, PL = G::PL, CY = G::CY, CZ = G::CZ, CWY = G::CWY, CWZ = G::CWZ, WY = G::WY;
       constexpr int TNY = G::TNY, TNZ = G::TNZ, TPY = G::TPY, TPZ = G::TPZ, RIMU = G::RIMU, RIMP = G::RIMP;
       constexpr int BUF = G::BUF, PUBD = G::PUBD, PUBV = G::PUBV;
-      constexpr int NSTL = RES ? 0 : nst_of(LIN_MODE);                // linearisation values READ per point
+      constexpr int NSTL = (RES || RCP) ? 0 : nst_of(LIN_MODE);       // linearisation values READ per point
       constexpr int NST = NSTL + (VARCO ? 4 : 0), NPC = NST / 2;       // ... with the coefficients (rho, mu | damping, -)
       static_assert(!(RES && VARCO), "residual mode: constant coefficients only");
       constexpr int NSO = RES ? nst_of(LIN_MODE) : 0, NPO = NSO / 2;  // ... WRITTEN per point (residual mode)
@@ -516,11 +557,13 @@ namespace adaflo_hip
       double *const  PUBY = lds + 4 * G::WAVE, *const PUBZ = PUBY + G::PUBY_BUFS * PUBD; // publish areas (Geo)
       // state ring of my wave
       constexpr bool RING = G::RING && NST > 0 && !VARCO && !(HOX_EXP & 4);
-      constexpr int  SLOT = G::SLOT, RS = 2 * (NST / 2 > 0 ? NST / 2 : 1);
-      char *const    ring = reinterpret_cast<char *>(lds + 4 * G::WAVE + G::PUB_DOUBLES) + wave * G::RING_BYTES;
+      constexpr bool DEEP = hox_deep<K, LIN_MODE, RES, VARCO, RCP>();
+      constexpr int  RPTS = DEEP ? N : 2, RING_BYTES = DEEP ? G::RING_BYTES_DEEP : G::RING_BYTES; // points in the ring
+      constexpr int  SLOT = G::SLOT, RS = RPTS * (NST / 2 > 0 ? NST / 2 : 1);
+      char *const    ring = reinterpret_cast<char *>(lds + 4 * G::WAVE + G::PUB_DOUBLES) + wave * RING_BYTES;
       const unsigned ring_m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_byte_addr(ring)), ring_lane = lds_byte_addr(ring) + 16 * lane;
       // hand-off flags (HOX_FLAGS): pub[w] = number of combines wave w has published, done[w] = ... has collected
-      const unsigned flag0 = lds_byte_addr(reinterpret_cast<char *>(lds + 4 * G::WAVE + G::PUB_DOUBLES) + 4 * G::RING_BYTES);
+      const unsigned flag0 = lds_byte_addr(reinterpret_cast<char *>(lds + 4 * G::WAVE + G::PUB_DOUBLES) + 4 * RING_BYTES);
       int            seq   = 0;
       if (HOX_FLAGS)
         {
@@ -532,7 +575,7 @@ namespace adaflo_hip
       const ctab_t tab = as_ctab(A.tab);
 
       // nodal x-lines of the step to come
-      double Un[3][N], Pn[NP];
+      double Un[3][N], Pn[NP], Ln[RCP ? 3 : 1][N];
       auto   load_nodes = [&](const int cxn) {
         if ((HOX_EXP & 32) && cxn > cx0)
           return;
@@ -543,6 +586,15 @@ namespace adaflo_hip
 #pragma unroll
           for (int d = 0; d < 3; ++d)
             Un[d][i] = pu[urow + i * 3 + d];
+        if constexpr (RCP)
+          {
+            const double *pl = A.lin_u + (size_t)(K * cxc) * 3;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+              for (int d = 0; d < 3; ++d)
+                Ln[d][i] = pl[urow + i * 3 + d];
+          }
         if (WITH_P)
           {
             const double *pp = A.src_p + (size_t)(KP * cxc);
@@ -551,7 +603,7 @@ namespace adaflo_hip
               Pn[i] = pp[prow + i];
           }
       };
-      double st[NST > 0 ? NST : 1];
+      double st[RCP ? nst_of(LIN_MODE) : (NST > 0 ? NST : 1)];
       auto   load_state = [&](const double *const base, const unsigned off) { // base wave-uniform, off per lane
 #pragma unroll
         for (int e = 0; e < NPC; ++e)
@@ -586,8 +638,7 @@ namespace adaflo_hip
       if (RING)
         {
           const double *const c0 = stg + (size_t)cx0 * ST_CELL;
-          ring_issue(c0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-          ring_issue(c0, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+          static_for<RPTS>([&](auto p_) { ring_issue(c0, p_, p_); });
         }
 
       // ---- combine the partial sums of the cross-section per owned line, emit NV nodes -------------------------
@@ -838,9 +889,58 @@ namespace adaflo_hip
             if (cx == A.ncx - 1 && (A.con_p >> 1 & 1))
               P[KP] = 0.;
           };
-          // one velocity component: x in registers, y, z (values at the Gauss points), d/dz, d/dy, d/dx
+          // nodal x-line -> value, d/dx, d/dy, d/dz at the Gauss points of my z-line (HOX_FUSED)
+          auto eval_fused = [&](double (&U)[N], double (&O)[4][N]) {
+            double           l0[N], l1[N], l2[N];
+            EoMat<N, N, 1>  mS;
+            EoMat<N, N, -1> mX;
+            mS.load(tb(TB::S));
+            mX.load(tb(TB::DS));
+            mS.template apply<false>(U, l0); // S_x u
+            mX.template apply<false>(U, l1); // (D S)_x u
+            wr_line<0, 1, N>(px, l0);
+            wr_line<BUF, 1, N>(px, l1);
+            wave_sync();
+            mS.load(tb(TB::S));
+            mX.load(tb(TB::DS));
+            rd_line<0, N, N>(ay, l0);
+            rd_line<BUF, N, N>(ay, l1);
+            ds_wait<0>(l0);
+            ds_wait<0>(l1);
+            mX.template apply<false>(l0, l2); // (D S)_y S_x u
+            mS.template apply<false>(l0, U);  // S_y S_x u
+            mS.template apply<false>(l1, l0); // S_y (D S)_x u
+            wave_sync();
+            wr_line<0, N, N>(py, U);
+            wr_line<BUF, N, N>(py, l0);
+            wr_line<2 * BUF, N, N>(py, l2);
+            wave_sync();
+            mS.load(tb(TB::S));
+            mX.load(tb(TB::DS));
+            rd_line<0, NN, N>(az, l0);
+            rd_line<BUF, NN, N>(az, l1);
+            rd_line<2 * BUF, NN, N>(az, l2);
+            ds_wait<2 * N>(l0);
+            mS.template apply<false>(l0, O[0]); // value
+            mX.template apply<false>(l0, O[3]); // d/dz
+            ds_wait<N>(l1);
+            mS.template apply<false>(l1, O[1]); // d/dx
+            ds_wait<0>(l2);
+            mS.template apply<false>(l2, O[2]); // d/dy
+            wave_sync();
+          };
+          // one velocity component.  HOX_FUSED: x in registers (S u and (D S) u), y (three arrays), z: value and gradient
+          // at the Gauss points of my z-line -- two exchanges; otherwise x, y, z (values), then d/dz, d/dy, d/dx by
+          // collocation, back on x-lines -- five exchanges
           auto eval_single = [&](auto d_) {
             constexpr int d = decltype(d_)::value;
+            if constexpr (HOX_FUSED)
+              {
+                double U[N];
+                nodal_u(d_, U);
+                eval_fused(U, G[d]);
+                return;
+              }
             double        U[N], T[N], ln[N];
             nodal_u(d_, U);
             EoMat<N, N, 1>  mS;
@@ -901,6 +1001,12 @@ namespace adaflo_hip
             mP.load(tb(TB::SP));
             rd_line<BUF, NN, NP>(az, ln); // z-line (a, b, .)
             ds_wait<0>(ln);
+            if constexpr (HOX_FUSED) // (the quadrature loop runs on z-lines)
+              {
+                mP.template apply<false>(ln, PQ);
+                wave_sync();
+                return;
+              }
             mP.template apply<false>(ln, T);
             wave_sync();
             wr_line<0, NN, N>(pz, T);
@@ -934,6 +1040,12 @@ namespace adaflo_hip
             mS.load(tb(TB::S));
             rd_line<BUF, NN, N>(az, ln);
             ds_wait<0>(ln);
+            if constexpr (HOX_FUSED)
+              {
+                mS.template apply<false>(ln, OQ[RES ? d : 0]);
+                wave_sync();
+                return;
+              }
             mS.template apply<false>(ln, T);
             wave_sync();
             wr_line<0, NN, N>(pz, T);
@@ -962,6 +1074,15 @@ namespace adaflo_hip
                       OQ[d][i] = 0.;
                 }
             }
+          // recompute-state mode: (u_lin, grad u_lin) at my quadrature points from the nodal linearisation point (plain
+          // read: the boundary values take part, as in the residual that produced the streamed state)
+          double GL[RCP ? 3 : 1][4][N];
+          if constexpr (RCP)
+            {
+              eval_fused(Ln[0], GL[0]);
+              eval_fused(Ln[1], GL[1]);
+              eval_fused(Ln[2], GL[2]);
+            }
           eval_single(I0_{});
           eval_single(I1_{});
           eval_single(I2_{});
@@ -976,7 +1097,7 @@ namespace adaflo_hip
             }
 
           HOX_MARK(2)
-          // ================= quadrature points of my x-line (:702-893) ==========================================
+          // ================= quadrature points of my line (:702-893) ============================================
           static_for<N>([&](auto i_) {
               constexpr int i_c = decltype(i_)::value, i = i_c;
               if constexpr (RING)
@@ -985,12 +1106,14 @@ namespace adaflo_hip
                   // NPC pieces issued one point ago
                   if (i == 0)
                     wait_vmcnt<0>();
-                  else if (i >= 2)
+                  else if (i >= 2 && !DEEP)
                     wait_vmcnt<NPC>();
-                  ring_read_impl<(i_c % 2) * NPC, NPC, RS, SLOT>(ring_lane, st);
+                  ring_read_impl<(i_c % RPTS) * NPC, NPC, RS, SLOT>(ring_lane, st);
                   // the slots are free again: the same half of the ring takes the next point of its parity (in the
                   // last step of the chunk that is the same cell once more, never read: no branch in this loop)
-                  if constexpr (i_c + 2 < N)
+                  if constexpr (DEEP) // (the whole cell arrived a step ago; the slots take the same point of the next cell)
+                    ring_issue(stn, i_, i_);
+                  else if constexpr (i_c + 2 < N)
                     ring_issue(stc, std::integral_constant<int, i_c + 2>{}, std::integral_constant<int, i_c % 2>{});
                   else
                     ring_issue(stn, std::integral_constant<int, i_c % 2>{}, std::integral_constant<int, i_c % 2>{});
@@ -1007,6 +1130,22 @@ namespace adaflo_hip
                     g[d][e] = G[d][1 + e][i] * cst[TB::C_IH + e];
                 }
               const double div = g[0][0] + g[1][1] + g[2][2];
+              if constexpr (RCP)
+                {
+#pragma unroll
+                  for (int d = 0; d < 3; ++d)
+                    st[d] = GL[d][0][i];
+                  if constexpr (LIN_MODE == 0)
+                    {
+#pragma unroll
+                      for (int d = 0; d < 3; ++d)
+#pragma unroll
+                        for (int e = 0; e < 3; ++e)
+                          st[3 + 3 * d + e] = GL[d][1 + e][i] * cst[TB::C_IH + e];
+                    }
+                  else
+                    st[3] = GL[0][1][i] * cst[TB::C_IH + 0] + GL[1][2][i] * cst[TB::C_IH + 1] + GL[2][3][i] * cst[TB::C_IH + 2];
+                }
               // :717, :827-835, :841-845 with the coefficients of this point (taken before the next point's state
               // overwrites the registers)
               double cA_q, cB_q, tmu_q;
@@ -1103,6 +1242,46 @@ namespace adaflo_hip
             double        W[N], ln[N], l2[N];
             EoMat<N, N, 1>  mS;
             EoMat<N, N, -1> mD;
+            if constexpr (HOX_FUSED)
+              {
+                // z in registers: S^T tv + (D S)^T tz, S^T tx, S^T ty; y: S^T . + (D S)^T ., S^T .; x: S^T . + (D S)^T .
+                mS.load(tb(TB::ST));
+                mD.load(tb(TB::DST));
+                mS.template apply<false>(G[d][0], W);
+                mD.template apply<true>(G[d][3], W);
+                mS.template apply<false>(G[d][1], ln);
+                mS.template apply<false>(G[d][2], l2);
+                wr_line<0, NN, N>(pz, W);
+                wr_line<BUF, NN, N>(pz, ln);
+                wr_line<2 * BUF, NN, N>(pz, l2);
+                wave_sync();
+                mS.load(tb(TB::ST));
+                mD.load(tb(TB::DST));
+                rd_line<0, N, N>(ay, W);
+                rd_line<2 * BUF, N, N>(ay, l2);
+                rd_line<BUF, N, N>(ay, ln);
+                ds_wait<N>(W);
+                ds_wait<N>(l2);
+                double B1[N], B2[N];
+                mS.template apply<false>(W, B1);
+                mD.template apply<true>(l2, B1);
+                ds_wait<0>(ln);
+                mS.template apply<false>(ln, B2);
+                wave_sync();
+                wr_line<0, N, N>(py, B1);
+                wr_line<BUF, N, N>(py, B2);
+                wave_sync();
+                mS.load(tb(TB::ST));
+                mD.load(tb(TB::DST));
+                rd_line<0, 1, N>(ax, W);
+                rd_line<BUF, 1, N>(ax, ln);
+                ds_wait<N>(W);
+                mS.template apply<false>(W, R[d]);
+                ds_wait<0>(ln);
+                mD.template apply<true>(ln, R[d]);
+                wave_sync();
+                return;
+              }
             mD.load(tb(TB::DT));
             mD.template apply<true>(G[d][1], G[d][0]); // W = tested value + D^T (x) in registers
             wr_line<0, 1, N>(px, G[d][0]);
@@ -1144,14 +1323,22 @@ namespace adaflo_hip
           };
           auto integ_p = [&]() {
             double ln[N], T[NP];
-            wr_line<0, 1, N>(px, PQ);
-            wave_sync();
             EoMat<NP, N, 1> mP;
-            mP.load(tb(TB::SPT));
-            rd_line<0, NN, N>(az, ln);
-            ds_wait<0>(ln);
-            mP.template apply<false>(ln, T); // z: [N][N][NP]
-            wave_sync();
+            if constexpr (HOX_FUSED) // (the tested values are on z-lines already)
+              {
+                mP.load(tb(TB::SPT));
+                mP.template apply<false>(PQ, T);
+              }
+            else
+              {
+                wr_line<0, 1, N>(px, PQ);
+                wave_sync();
+                mP.load(tb(TB::SPT));
+                rd_line<0, NN, N>(az, ln);
+                ds_wait<0>(ln);
+                mP.template apply<false>(ln, T); // z: [N][N][NP]
+                wave_sync();
+              }
             wr_line<BUF, NN, NP>(pz, T);
             wave_sync();
             mP.load(tb(TB::SPT));
@@ -1379,7 +1566,8 @@ namespace adaflo_hip
           if (cy < ncy && cz < ncz)
             {
               const size_t cellg = ((size_t)cz * ncy + cy) * ncx + cx;
-              const int    q     = ((l / N) * N + l % N) * N + i; // line l = (j, k) = (l % N, l / N)
+              // x-lines: line l = (j, k) = (l % N, l / N), point i along x; HOX_FUSED: z-lines, l = (x, y), i along z
+              const int    q     = HOX_FUSED ? (i * N + l / N) * N + l % N : ((l / N) * N + l % N) * N + i;
               if (npl < 0 || piece < npl)
                 {
                   v0 = generic[(cellg * NLIN_ + 2 * piece) * N3 + q];
@@ -1425,7 +1613,7 @@ namespace adaflo_hip
           if (cy < ncy && cz < ncz)
             {
               const size_t cellg = ((size_t)cz * ncy + cy) * ncx + cx;
-              const int    q     = ((l / N) * N + l % N) * N + i;
+              const int    q     = HOX_FUSED ? (i * N + l / N) * N + l % N : ((l / N) * N + l % N) * N + i;
               generic[(cellg * NLIN_ + 2 * piece) * N3 + q]     = in[2 * it];
               generic[(cellg * NLIN_ + 2 * piece + 1) * N3 + q] = in[2 * it + 1];
             }

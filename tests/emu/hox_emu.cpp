@@ -15,18 +15,18 @@ using namespace adaflo_hip::hox;
 
 namespace
 {
-  template <int K, int LM, bool WP, bool VARCO = false>
+  template <int K, int LM, bool WP, bool VARCO = false, bool RCP = false>
   void run_main(const HXArgs &A, const long nwg)
   {
     if (nwg > 0)
-      emu::launch((unsigned)nwg, NTH, [&] { ns_hox_kernel<K, LM, WP, false, VARCO>(A); });
+      emu::launch((unsigned)nwg, NTH, [&] { ns_hox_kernel<K, LM, WP, false, VARCO, RCP>(A); });
   }
 
   template <int K>
   int run(const int *ncell, const double *h, const int op, const int lin_mode, const int integrate_p, const double *coef,
           const unsigned con_u, const unsigned con_p, const double *lin_generic, const double *src_u, const double *src_p,
           double *dst_u, double *dst_p, const int lx, const unsigned iface, const int phased, const double *rho = nullptr,
-          const double *mu = nullptr, const double *damp = nullptr)
+          const double *mu = nullptr, const double *damp = nullptr, const double *lin_nodal = nullptr)
   {
     using G         = Geo<K>;
     constexpr int N = K + 1;
@@ -51,11 +51,12 @@ namespace
     const bool          varco = rho != nullptr;
     const int           npl = nst_of(lin_mode) / 2, npc = npl + (varco ? 2 : 0);
     std::vector<double> state((size_t)A.ngz * A.ngy * A.ncx * N * npc * G::CPW * G::NL * 2 + 2);
-    if (npc > 0)
+    if (npc > 0 && !lin_nodal)
       emu::launch(4, 256, [&] {
         hox_convert_state_kernel<K>(state.data(), lin_generic, A.ncx, A.ncy, A.ncz, A.ngy, A.ngz, npc, varco ? npl : -1, rho, mu, damp);
       });
-    A.lin = state.data();
+    A.lin   = lin_nodal ? nullptr : state.data();
+    A.lin_u = lin_nodal; // recompute-state mode: the kernel interpolates the nodal linearisation point itself
     const size_t        n_wg = (size_t)A.tiles_y * A.tiles_z * A.n_chunks;
     const double        nan  = std::nan("");
     std::vector<double> slab_u(n_wg * G::RIMU * (K * A.LX + 1) * 3, nan), xslab_u(n_wg * G::TNY * G::TNZ * 3, nan),
@@ -85,6 +86,24 @@ namespace
                 run_main<K, 1, false, true>(A, nwg);
               else
                 run_main<K, 2, false, true>(A, nwg);
+            }
+          return;
+        }
+      if (lin_nodal)
+        {
+          if (with_p)
+            {
+              if (lin_mode == 0)
+                run_main<K, 0, true, false, true>(A, nwg);
+              else
+                run_main<K, 1, true, false, true>(A, nwg);
+            }
+          else
+            {
+              if (lin_mode == 0)
+                run_main<K, 0, false, false, true>(A, nwg);
+              else
+                run_main<K, 1, false, false, true>(A, nwg);
             }
           return;
         }
@@ -224,6 +243,26 @@ extern "C" int hox_emu_vmult(const int K, const int *ncell, const double *h, con
         return run<4>(ncell, h, op, lin_mode, integrate_p, coef, con_u, con_p, lin_generic, src_u, src_p, dst_u, dst_p, lx, iface, phased, rho, mu, damp);
       case 5:
         return run<5>(ncell, h, op, lin_mode, integrate_p, coef, con_u, con_p, lin_generic, src_u, src_p, dst_u, dst_p, lx, iface, phased, rho, mu, damp);
+    }
+  return -1;
+}
+
+// recompute-state mode (template RCP): the state is the interpolation of the nodal field `lin_nodal` (lin_mode 0 or 1)
+extern "C" int hox_emu_vmult_recompute(const int K, const int *ncell, const double *h, const int op, const int lin_mode,
+                                       const int integrate_p, const double *coef, const unsigned con_u, const unsigned con_p,
+                                       const double *lin_nodal, const double *src_u, const double *src_p, double *dst_u,
+                                       double *dst_p, const int lx, const unsigned iface, const int phased)
+{
+  if (lin_mode != 0 && lin_mode != 1)
+    return -2;
+  switch (K)
+    {
+      case 3:
+        return run<3>(ncell, h, op, lin_mode, integrate_p, coef, con_u, con_p, nullptr, src_u, src_p, dst_u, dst_p, lx, iface, phased, nullptr, nullptr, nullptr, lin_nodal);
+      case 4:
+        return run<4>(ncell, h, op, lin_mode, integrate_p, coef, con_u, con_p, nullptr, src_u, src_p, dst_u, dst_p, lx, iface, phased, nullptr, nullptr, nullptr, lin_nodal);
+      case 5:
+        return run<5>(ncell, h, op, lin_mode, integrate_p, coef, con_u, con_p, nullptr, src_u, src_p, dst_u, dst_p, lx, iface, phased, nullptr, nullptr, nullptr, lin_nodal);
     }
   return -1;
 }

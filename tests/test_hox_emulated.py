@@ -39,11 +39,17 @@ def face_bits(faces, ncomp):
     return m
 
 
-def run_emulated(lib, case, op=0, lx=0, iface=0, phased=0, seed_src=True, varco=False):
+def run_emulated(lib, case, op=0, lx=0, iface=0, phased=0, seed_src=True, varco=False, recompute=False):
     k, prm = case.k, case.prm
     src_u, src_p = case.random_u(), case.random_p()
     lin = case.random_lin()                                  # canonical [cell][q][12]
     nq = case.nq
+    lin_nodal = None
+    if recompute:                                            # the state the oracle's residual leaves at a nodal field
+        lin_nodal = case.random_u()
+        lin = np.zeros(case.n_cells * nq * 12)
+        orc.ns_residual(case.mesh, k, prm, lin_nodal, case.random_p(), case.random_u(), case.random_u(), con_u=case.con_u,
+                        con_p=case.con_p, lin=lin)
     lin_generic = np.ascontiguousarray(lin.reshape(case.n_cells, nq, 12).transpose(0, 2, 1))
     stokes = prm.physical_type == 2
     lin_mode = 2 if (stokes or prm.linearization == 3) else (0 if prm.linearization == 0 else 1)
@@ -62,9 +68,15 @@ def run_emulated(lib, case, op=0, lx=0, iface=0, phased=0, seed_src=True, varco=
     ncell = (C.c_int * 3)(*case.ncell)
     h = (C.c_double * 3)(*[case.mesh.h[d] for d in range(3)])
     dp = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
-    rc = lib.hox_emu_vmult(k, ncell, h, op, lin_mode, integrate_p, dp(coef), face_bits(case.faces_u, 3),
-                           face_bits(case.faces_p, 1), dp(lin_generic), dp(src_u), dp(src_p), dp(dst_u), dp(dst_p),
-                           lx if lx else case.ncell[0], iface, phased, dp(co.get("rho")), dp(co.get("mu")), dp(co.get("damp")))
+    if recompute:
+        lib.hox_emu_vmult_recompute.restype = C.c_int
+        rc = lib.hox_emu_vmult_recompute(k, ncell, h, op, lin_mode, integrate_p, dp(coef), face_bits(case.faces_u, 3),
+                                         face_bits(case.faces_p, 1), dp(lin_nodal), dp(src_u), dp(src_p), dp(dst_u),
+                                         dp(dst_p), lx if lx else case.ncell[0], iface, phased)
+    else:
+        rc = lib.hox_emu_vmult(k, ncell, h, op, lin_mode, integrate_p, dp(coef), face_bits(case.faces_u, 3),
+                               face_bits(case.faces_p, 1), dp(lin_generic), dp(src_u), dp(src_p), dp(dst_u), dp(dst_p),
+                               lx if lx else case.ncell[0], iface, phased, dp(co.get("rho")), dp(co.get("mu")), dp(co.get("damp")))
     assert rc == 0
     if op == 0:
         ref_u, ref_p = orc.ns_vmult(case.mesh, k, prm, src_u, src_p, case.con_u, case.con_p, lin=lin, **co)
@@ -148,4 +160,15 @@ def test_emulated_variable_coefficients(emu, k, ncell, lin, phys, op):
     case = Case(ncell, k=k, faces_u=[0, 3, 4], faces_p=[1], linearization=lin, physical_type=phys, tau_grad_div=0.3,
                 density_diff=-0.5)
     eu, ep = run_emulated(emu, case, op=op, lx=2, varco=True)
+    assert eu < TOL and ep < TOL, (eu, ep)
+
+
+@pytest.mark.parametrize("k,ncell,lx,lin,op,phased", [(4, (3, 2, 5), 2, 0, 0, 0), (4, (2, 3, 4), 0, 1, 0, 0), (3, (3, 5, 5), 2, 0, 0, 0),
+                                                      (5, (2, 3, 2), 1, 0, 0, 0), (4, (3, 3, 3), 0, 0, 2, 0), (4, (4, 3, 5), 2, 0, 0, 1)])
+def test_emulated_recompute_state_mode(emu, k, ncell, lx, lin, op, phased):
+    """recompute-state mode (template RCP): the kernel interpolates (u_lin, grad u_lin) from the nodal field the
+    residual was evaluated at (boundary values included) instead of streaming them; reference: the oracle's vmult on
+    the state the oracle's residual stored at that field.  Newton, Picard-type, velocity block, phased schedule"""
+    case = Case(ncell, k=k, faces_u=[0, 3, 4, 5], faces_p=[1], linearization=lin, tau_grad_div=0.3, damping=0.2, steps=3)
+    eu, ep = run_emulated(emu, case, op=op, lx=lx, recompute=True, phased=phased, iface=0b010011 if phased else 0)
     assert eu < TOL and ep < TOL, (eu, ep)
