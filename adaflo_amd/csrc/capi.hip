@@ -621,7 +621,7 @@ int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx)
   // with the sweep kernels only the streaming copy is frozen; the generic frozen copy is rebuilt
   // from it on demand (ensure_lin_prec_generic)
   const bool streaming_only = ctx->variant >= 1 && q2_supported(ctx) && needs_lin(ctx) && ctx->lin_q2.p &&
-                              ctx->lin_q2_valid && !ctx->lin_q2_varco;
+                              ctx->lin_q2_valid && !ctx->lin_q2_varco && !ctx->rho.p;
   if (ctx->variant == 1 && hox_supported(ctx) && needs_lin(ctx) && ctx->hox_lin_primary && !ctx->lin_generic_valid)
     {
       // the state exists in the streaming layout of the x-marching kernel only (its residual mode wrote it): freeze
@@ -660,6 +660,8 @@ int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx)
   // keep a frozen copy in the streaming layout of the Q2/Q1 kernel as well
   if (q2_supported(ctx) && has_lin(ctx) && needs_lin(ctx))
     {
+      if (ctx->lin_q2_valid && ctx->lin_q2_varco != (ctx->rho.p != nullptr))
+        ctx->lin_q2_valid = false; // (written without coefficient pieces by the variable-coefficient residual; the generic copy is current by now)
       TRY(ctx, q2_prepare_state(ctx), "state conversion failed");
       TRY(ctx, alloc(ctx, ctx->lin_q2_prec, ctx->lin_q2.count), ctx->last_error);
       HIP_TRY(ctx, hipMemcpyAsync(ctx->lin_q2_prec.p, ctx->lin_q2.p, ctx->lin_q2.count * sizeof(double),

@@ -57,6 +57,14 @@ namespace adaflo_hip
 #ifndef HOX_FUSED
 #define HOX_FUSED 1
 #endif
+    // the residual mode on the fused chains as well (1, default).  With the values of u AND of the old-velocity combination
+    // live they need more registers: k = 4, 5 run the residual at one workgroup per CU (512 registers, no scratch;
+    // measured on one box, residual call in ms, round-4 chains / fused at two workgroups per CU / fused at one: Q3/Q2 64^3
+    // 1.13 / 1.12 / 1.22, Q4/Q3 64^3 2.33 / 3.08 / 2.62, Q5/Q4 48^3 2.85 / 3.87 / 2.62).  0: the round-4 chains (x-line
+    // quadrature loop) storing the state pieces at the z-line positions of the vmult: scattered 16-byte stores, Q4/Q3 2.73
+#ifndef HOX_RES_FUSED
+#define HOX_RES_FUSED 1
+#endif
     constexpr int NTH  = 256;
     constexpr int NMAX = 6;
     constexpr int NLIN_ = 12;
@@ -452,7 +460,7 @@ namespace adaflo_hip
     // cell on node lines that are read like the source vector (72 B per node) instead of 96 B of state per quadrature point
     template <int K, int LIN_MODE, bool WITH_P, bool RES = false, bool VARCO = false, bool RCP = false>
 #ifndef HOX_RES_LB
-#define HOX_RES_LB HOX_LB
+#define HOX_RES_LB (K == 3 ? HOX_LB : 1)
 #endif
 #ifndef HOX_RCP_LB
 #define HOX_RCP_LB HOX_LB
@@ -466,6 +474,7 @@ namespace adaflo_hip
       constexpr int CPW = G::CPW, PL = G::PL, CY = G::CY, CZ = G::CZ, CWY = G::CWY, CWZ = G::CWZ, WY = G::WY;
       constexpr int TNY = G::TNY, TNZ = G::TNZ, TPY = G::TPY, TPZ = G::TPZ, RIMU = G::RIMU, RIMP = G::RIMP;
       constexpr int BUF = G::BUF, PUBD = G::PUBD, PUBV = G::PUBV;
+      constexpr bool FUSED = HOX_FUSED && (!RES || HOX_RES_FUSED);     // value + gradient through two exchanges, z-line loop
       constexpr int NSTL = (RES || RCP) ? 0 : nst_of(LIN_MODE);       // linearisation values READ per point
       constexpr int NST = NSTL + (VARCO ? 4 : 0), NPC = NST / 2;       // ... with the coefficients (rho, mu | damping, -)
       static_assert(!(RES && VARCO), "residual mode: constant coefficients only");
@@ -934,7 +943,7 @@ namespace adaflo_hip
           // collocation, back on x-lines -- five exchanges
           auto eval_single = [&](auto d_) {
             constexpr int d = decltype(d_)::value;
-            if constexpr (HOX_FUSED)
+            if constexpr (FUSED)
               {
                 double U[N];
                 nodal_u(d_, U);
@@ -1001,7 +1010,7 @@ namespace adaflo_hip
             mP.load(tb(TB::SP));
             rd_line<BUF, NN, NP>(az, ln); // z-line (a, b, .)
             ds_wait<0>(ln);
-            if constexpr (HOX_FUSED) // (the quadrature loop runs on z-lines)
+            if constexpr (FUSED) // (the quadrature loop runs on z-lines)
               {
                 mP.template apply<false>(ln, PQ);
                 wave_sync();
@@ -1040,7 +1049,7 @@ namespace adaflo_hip
             mS.load(tb(TB::S));
             rd_line<BUF, NN, N>(az, ln);
             ds_wait<0>(ln);
-            if constexpr (HOX_FUSED)
+            if constexpr (FUSED)
               {
                 mS.template apply<false>(ln, OQ[RES ? d : 0]);
                 wave_sync();
@@ -1201,7 +1210,11 @@ namespace adaflo_hip
                   // (u, grad u) row-major (Newton) or (u, div u) (Picard-type); cells beyond the mesh store nothing
                   if (fl & F_CELL)
                     {
-                      double *const so = sog + ((size_t)cx * ST_CELL + (unsigned)(i * ST_POINT) + st_lane);
+                      // (x-line loop, lane (y, z) = (a, b), point i along x, next to a z-line vmult: the piece of point
+                      // (i, a, b) belongs to line (x, y) = (i, a), point b)
+                      double *const so = (HOX_FUSED && !FUSED) ?
+                                           sog + ((size_t)cx * ST_CELL + (unsigned)(b * ST_POINT) + (unsigned)(cw * NL + i + N * a) * 2) :
+                                           sog + ((size_t)cx * ST_CELL + (unsigned)(i * ST_POINT) + st_lane);
                       so[0] = u[0], so[1] = u[1];
                       if constexpr (LIN_MODE == 0)
                         {
@@ -1242,7 +1255,7 @@ namespace adaflo_hip
             double        W[N], ln[N], l2[N];
             EoMat<N, N, 1>  mS;
             EoMat<N, N, -1> mD;
-            if constexpr (HOX_FUSED)
+            if constexpr (FUSED)
               {
                 // z in registers: S^T tv + (D S)^T tz, S^T tx, S^T ty; y: S^T . + (D S)^T ., S^T .; x: S^T . + (D S)^T .
                 mS.load(tb(TB::ST));
@@ -1324,7 +1337,7 @@ namespace adaflo_hip
           auto integ_p = [&]() {
             double ln[N], T[NP];
             EoMat<NP, N, 1> mP;
-            if constexpr (HOX_FUSED) // (the tested values are on z-lines already)
+            if constexpr (FUSED) // (the tested values are on z-lines already)
               {
                 mP.load(tb(TB::SPT));
                 mP.template apply<false>(PQ, T);

@@ -587,7 +587,10 @@ namespace adaflo_hip
                                                               // generic arrays, 24 B per cell and point, L2-friendly)
       static_assert(!RCP || (LIN_MODE == 0 && !RES && !DIV), "recompute mode: Newton vmult");
       static_assert(!DIV || (LIN_MODE == 2 && WITH_P && !RES && !VARCO), "divergence mode");
-      static_assert(!(RES && VARCO), "residual mode: constant coefficients only");
+      // (RES && VARCO, round 5: the residual of two-phase flow -- the coefficients of the layer's 27 points are read from the
+      // generic arrays [cell][27], lane d of a quad its array (rho, mu, damping), and handed round by DPP; the state goes
+      // out in the constant-coefficient layout: the vmults of this Newton step recompute it or re-lay it out with the
+      // coefficient pieces)
       extern __shared__ double lds[];
       // state ring geometry.  Constant coefficients: pieces of 48 lanes x 16 B, 9 slots.
       // Variable rho/mu/damping (two-phase flow): lanes 48..63 of every piece carry the
@@ -814,7 +817,7 @@ namespace adaflo_hip
 
           // recompute mode with variable coefficients: first entry of my cell in the generic arrays [cell][27] (cells
           // beyond the mesh read the tile's first cell: legal address, unused values)
-          const unsigned coef_cell = (RCP && VARCO) ?
+          const unsigned coef_cell = ((RCP || RES) && VARCO) ?
                                        (unsigned)((((size_t)cz * A.ncy + (TY * by + (valid ? cyl : 0))) * A.ncx + (TX * bx + (valid ? cxl : 0))) * 27) :
                                        0u;
           double R[27];
@@ -835,7 +838,17 @@ namespace adaflo_hip
                 }
               interp_all(V2);
             }
-          if (RES)
+          // variable-coefficient residual: the layer's coefficients, one array per lane of the quad (issued before the
+          // plane copies of the next layer: the compiler's wait for them then leaves those copies in flight)
+          double CQ[(RES && VARCO) ? 27 : 1];
+          if (RES && VARCO)
+            {
+              const double *const arr = d == 1 ? A.mu : (d == 2 ? A.damp : A.rho);
+#pragma unroll
+              for (int n = 0; n < 27; ++n)
+                CQ[n] = arr[coef_cell + n];
+            }
+          if (RES && !VARCO)
             {
               const double co = is_p ? 0. : A.c_old;
 #pragma unroll
@@ -1006,6 +1019,8 @@ namespace adaflo_hip
                   const unsigned cq_ = coef_cell + (unsigned)q;
                   r_rho = A.rho[cq_], r_mu = A.mu[cq_], r_damp = A.damp[cq_];
                 }
+              if (RES && VARCO)
+                r_rho = quad_bcast<0>(CQ[q]), r_mu = quad_bcast<1>(CQ[q]), r_damp = quad_bcast<2>(CQ[q]);
               if (RCP)
                 {
                   // the state of this point from the interpolated nodal linearisation point: my component's value and
@@ -1055,6 +1070,8 @@ namespace adaflo_hip
               const double cB_q = VARCO ? A.tau1 * r_rho : A.cB;
               const double tmu_q = VARCO ? (is_p ? 0. : A.tau1 * r_mu) : tmu_l;
               double conv = cA_q * Vq;
+              if (RES && VARCO) // :727-732 times the density of the point (A.c_old: 1 with a time derivative, else 0)
+                conv += (A.c_old * r_rho) * V2[q];
               if (RES)
                 {
                   if (LIN_MODE != 2)
@@ -1860,19 +1877,46 @@ namespace adaflo_hip
     if (!residual && op != OP_DIVERGENCE && !recompute)
       {
         if (ctx->lin_q2_valid && (ctx->lin_q2_mode != q2_lin_mode(ctx) || ctx->lin_q2_varco != q2_varco(ctx)))
-          ctx->lin_q2_valid = false;
+          {
+            // (a streaming copy without coefficient pieces that is THE state -- the variable-coefficient residual wrote
+            // it, then the kernel variant was changed to the streaming one: the generic copy first)
+            if (!ctx->lin_generic_valid && !ctx->lin_q2_varco && ctx->lin_q2_mode == q2_lin_mode(ctx))
+              {
+                const size_t count = (size_t)ctx->n_cells * ctx->nq_u * 12;
+                if (ctx->lin.count != count)
+                  {
+                    if (ctx->lin.p)
+                      (void)hipFree(ctx->lin.p);
+                    ctx->lin.p     = nullptr;
+                    ctx->lin.count = 0;
+                    if (hipMalloc(&ctx->lin.p, count * sizeof(double)) != hipSuccess)
+                      return ADAFLO_ENOMEM;
+                    ctx->lin.count = count;
+                    if (hipMemsetAsync(ctx->lin.p, 0, count * sizeof(double), ctx->stream) != hipSuccess)
+                      return ADAFLO_EHIP;
+                  }
+                if (int e = q2_unconvert_state(ctx, ctx->lin.p, ctx->lin_q2.p, ctx->lin_q2_mode))
+                  return e;
+                ctx->lin_generic_valid = true;
+                ctx->lin_gen++;
+              }
+            ctx->lin_q2_valid = false;
+          }
         if (int e = q2_prepare_state(ctx))
           return e;
       }
     Q2Args A{};
     const bool divergence = op == OP_DIVERGENCE;
     A.old_u     = recompute ? (frozen ? ctx->lin_nodal_prec.p : ctx->lin_nodal.p) : res_old;
+    const bool res_varco = residual && q2_varco(ctx); // (two-phase residual: coefficients from the generic arrays)
     if (rc_varco)
       {
         A.rho  = frozen ? ctx->rho_prec.p : ctx->rho.p;
         A.mu   = frozen ? ctx->mu_prec.p : ctx->mu.p;
         A.damp = frozen ? ctx->damp_prec.p : ctx->damp.p;
       }
+    if (res_varco)
+      A.rho = ctx->rho.p, A.mu = ctx->mu.p, A.damp = ctx->damp.p;
     A.c_old     = res_c_old;
     A.state_out = residual ? ctx->lin_q2.p : nullptr;
     A.c_div     = res_c_old; // (divergence mode passes its weight here)
@@ -2086,6 +2130,18 @@ namespace adaflo_hip
         else
           Q2_LAUNCH_V6(2, true, false, false, false, true)
       }
+    else if (res_varco)
+      {
+        // (variable coefficients: Newton / Picard-type, q2_residual_supported)
+        if (iso && lin_mode == 0)
+          Q2_LAUNCH_V(0, true, true, true, true)
+        else if (iso)
+          Q2_LAUNCH_V(1, true, true, true, true)
+        else if (lin_mode == 0)
+          Q2_LAUNCH_V(0, true, false, true, true)
+        else
+          Q2_LAUNCH_V(1, true, false, true, true)
+      }
     else if (residual)
       {
         // (constant coefficients, src = the solution: launch_ns_residual_q2)
@@ -2198,8 +2254,14 @@ namespace adaflo_hip
   // that of the solution itself) and Stokes, constant coefficients
   bool q2_residual_supported(const adaflo_ctx *ctx)
   {
-    if (ctx->k != 2 || ctx->flat || ctx->rho.p || ctx->mu.p || ctx->damp.p)
+    if (ctx->k != 2 || ctx->flat)
       return false;
+    // variable coefficients (two-phase flow, round 5): with the Newton linearisation and the recompute-state mode of the
+    // vmults (kernel variant 1) -- the state then leaves the kernel in the constant-coefficient layout and nobody reads it
+    // unless asked (get_linearization, a change of variant: re-laid out then)
+    if (ctx->rho.p || ctx->mu.p || ctx->damp.p)
+      return q2_varco(ctx) && ctx->q2_recompute && ctx->ns.physical_type != ADAFLO_STOKES &&
+             ctx->ns.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON;
     const NSDev &P = ctx->ns;
     return P.physical_type == ADAFLO_STOKES || P.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON ||
            P.linearization == ADAFLO_COUPLED_IMPLICIT_PICARD;
@@ -2253,7 +2315,8 @@ namespace adaflo_hip
               return ADAFLO_EHIP;
           }
       }
-    const double c_old = (old_comb && ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE) ? ctx->ns.density : 0.;
+    // (variable coefficients: the kernel multiplies by the density of the point)
+    const double c_old = (old_comb && ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE) ? (q2_varco(ctx) ? 1. : ctx->ns.density) : 0.;
     if (int e = q2_launch(ctx, OP_VMULT, sum_u, sum_p, src_u, src_p, -1, 0u, true, old_comb ? old_comb : src_u, c_old))
       return e;
     if (lin_mode != 2)

@@ -59,10 +59,11 @@ def ns_case(k, n, variant, two_phase=False, state_from_residual=False):
                       "frac_of_8TB/s": round(b_alg / t / 8e12, 4)}), flush=True)
 
 
-def ns_residual_case(k, n, variant):
+def ns_residual_case(k, n, variant, two_phase=False):
     """NavierStokesMatrix::residual (a3: the producer of the q-point state, once per Newton step);
-    algorithmic bytes: 3 velocity vectors + p read, 2 vectors written, state written once"""
-    fp = adaflo_amd.FlowParameters(velocity_degree=k)
+    algorithmic bytes: 3 velocity vectors + p read, 2 vectors written, state written once (two_phase: + rho, mu, damping
+    read per quadrature point)"""
+    fp = adaflo_amd.FlowParameters(velocity_degree=k, density_diff=0.5 if two_phase else 0.0)
     ts = adaflo_amd.TimeStepping(fp)
     for _ in range(3):
         ts.next()
@@ -70,14 +71,17 @@ def ns_residual_case(k, n, variant):
     op.initialize(ts, True)
     op.set_kernel_variant(variant)
     rng = np.random.default_rng(1)
+    if two_phase:
+        nc = op.n_cells() * (k + 1) ** 3
+        op.set_coefficients(rng.uniform(.5, 2, nc), rng.uniform(.5, 2, nc), rng.uniform(-.5, .5, nc))
     sol = op.block_vector(rng.uniform(-1, 1, op.n_dofs_u()), rng.uniform(-1, 1, op.n_dofs_p()))
     old = adaflo_amd.BlockVector([op.initialize_u_vector(rng.uniform(-1, 1, op.n_dofs_u()))])
     oldold = adaflo_amd.BlockVector([op.initialize_u_vector(rng.uniform(-1, 1, op.n_dofs_u()))])
     rhs = op.block_vector()
     t = timeit(lambda: op.residual(rhs, sol, None, old, oldold), op.synchronize, reps=10, warm=2)
     nq = (k + 1) ** 3
-    b_alg = op.n_cells() * (8 * (5 * 3 * k ** 3 + 2 * (k - 1) ** 3) + 8 * 12 * nq)
-    print(json.dumps({"op": "ns_residual", "k": k, "cells": n, "variant": variant, "ms": round(t * 1e3, 4),
+    b_alg = op.n_cells() * (8 * (5 * 3 * k ** 3 + 2 * (k - 1) ** 3) + 8 * (15 if two_phase else 12) * nq)
+    print(json.dumps({"op": "ns_residual" + ("_two_phase" if two_phase else ""), "k": k, "cells": n, "variant": variant, "ms": round(t * 1e3, 4),
                       "alg_GB/s": round(b_alg / t / 1e9, 1), "frac_of_8TB/s": round(b_alg / t / 8e12, 4)}), flush=True)
 
 

@@ -833,6 +833,59 @@ def test_vmult_recomputes_the_state_from_the_nodal_linearisation_point(ncell, up
     assert rel_l2(gu, ref_u) < TOL and rel_l2(gp, ref_p) < TOL
 
 
+@pytest.mark.parametrize("ncell,upper,phys,faces_u", [((9, 8, 5), (1., 1., 1.), 0, range(6)), ((17, 9, 6), (1., 1., 3.), 0, [0, 3, 4]),
+                                                       ((5, 4, 9), (1., 2., 1.), 1, range(6)), ((1, 1, 1), (1., 1., 1.), 0, range(6))])
+def test_two_phase_residual_sweep_kernel(ncell, upper, phys, faces_u):
+    """the residual of two-phase flow (variable density / viscosity / damping, navier_stokes_matrix.cc:266-293, 636-642,
+    711-713, 831-845) on the Q2/Q1 sweep kernel (template RES with VARCO, round 5): right-hand side with the
+    read-modify-write semantics of the reference, the state it leaves (canonical array), the Jacobian on that state in
+    the recompute-state mode and -- after a change of kernel variant -- streamed with the coefficient pieces, the frozen
+    operator; against the oracle, and the generic kernels on the same inputs"""
+    case = Case(ncell, k=2, lower=(0., 0., 0.), upper=upper, faces_u=faces_u, physical_type=phys, steps=3,
+                tau_grad_div=0.1, density_diff=0.5)
+    src_u, src_p = case.smooth_u(0.1) + 0.05 * case.random_u(), case.smooth_p(0.1)
+    old_u, oldold_u = case.smooth_u(0.05), case.smooth_u(0.0)
+    rhs0_u, rhs0_p, usr_u, usr_p = case.random_u(), case.random_p(), case.random_u(), case.random_p()
+    rho, mu, damp = case.random_coefficients()
+    lin_ref = np.zeros(case.n_cells * case.nq * 12)
+    ref_u, ref_p = orc.ns_residual(case.mesh, case.k, case.prm, src_u, src_p, old_u, oldold_u, con_u=case.con_u,
+                                   con_p=case.con_p, lin=lin_ref, rhs_u=rhs0_u, rhs_p=rhs0_p, user_u=usr_u, user_p=usr_p,
+                                   rho=rho, mu=mu, damp=damp)
+    vm_u, vm_p = case.random_u(), case.random_p()
+    w, modes = case.weights_modes()
+    ref_vu, ref_vp = orc.ns_vmult(case.mesh, 2, case.prm, vm_u, vm_p, case.con_u, case.con_p, lin=lin_ref, rho=rho, mu=mu,
+                                  damp=damp, weights=w, modes=modes)
+    ref_vel = orc.ns_velocity_vmult(case.mesh, 2, case.prm, vm_u, case.con_u, lin=lin_ref, rho=rho, mu=mu, damp=damp)
+    for variant in (1, 0):
+        op = case.engine()
+        op.set_kernel_variant(variant)
+        op.set_coefficients(rho, mu, damp)
+        rhs = op.block_vector(rhs0_u, rhs0_p)
+        op.residual(rhs, op.block_vector(src_u, src_p), op.block_vector(usr_u, usr_p), op.block_vector(old_u),
+                    op.block_vector(oldold_u))
+        got_u, got_p = rhs.numpy()
+        assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL, (variant, rel_l2(got_u, ref_u), rel_l2(got_p, ref_p))
+        dst = op.block_vector()
+        op.vmult(dst, op.block_vector(vm_u, vm_p))
+        gu, gp = dst.numpy()
+        assert rel_l2(gu, ref_vu) < TOL and rel_l2(gp, ref_vp) < TOL, (variant, rel_l2(gu, ref_vu))
+        got_lin = op.get_linearization().reshape(-1, 12)
+        assert rel_l2(got_lin, lin_ref.reshape(-1, 12)) < TOL, variant
+        if variant == 1:
+            op.set_kernel_variant(4)                      # streamed: the state is re-laid out with the coefficient pieces
+            op.vmult(dst, op.block_vector(vm_u, vm_p))
+            gu, gp = dst.numpy()
+            assert rel_l2(gu, ref_vu) < TOL and rel_l2(gp, ref_vp) < TOL, ("streamed", rel_l2(gu, ref_vu))
+            op.set_kernel_variant(1)
+            op.residual(rhs, op.block_vector(src_u, src_p), None, op.block_vector(old_u), op.block_vector(oldold_u))
+        op.fix_linearization_point()
+        op.set_coefficients(*case.random_coefficients())
+        op.residual(rhs, op.block_vector(0.5 * src_u, src_p), None, op.block_vector(old_u), op.block_vector(oldold_u))
+        vsrc, vdst = op.initialize_u_vector(vm_u), op.initialize_u_vector()
+        op.velocity_vmult(vdst, vsrc)
+        assert rel_l2(vdst.numpy(), ref_vel) < TOL, variant
+
+
 @pytest.mark.parametrize("ncell,upper", [((9, 8, 5), (1., 1., 1.)), ((17, 9, 6), (1., 1., 3.)), ((3, 2, 2), (1., 2., 1.))])
 def test_two_phase_vmult_recomputes_the_state_from_the_nodal_linearisation_point(ncell, upper):
     """variable density / viscosity / damping (the two-phase Jacobian): the residual runs on the generic kernel, the
