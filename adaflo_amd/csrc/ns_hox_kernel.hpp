@@ -106,7 +106,10 @@ namespace adaflo_hip
       static constexpr int PUBY_BUFS = WY == 1 ? 1 : 2, PUB_DOUBLES = (PUBY_BUFS + 2) * PUBD;
       // state ring of a wave (LDS-DMA, k = 4 only): two quadrature points = 2 * 6 slots; a slot holds what ONE
       // global_load_lds_dwordx4 writes, 16 bytes per lane at M0 + 16 * lane, up to the last active lane
-      static constexpr bool RING = K == 4;
+#ifndef HOX_RING5
+#define HOX_RING5 1
+#endif
+      static constexpr bool RING = K == 4 || (K == 5 && HOX_RING5); // (k = 3: 94 KB with the ring, one workgroup per CU)
       static constexpr int  SLOT = 16 * ((CPW - 1) * PL + NL);          // bytes
       static constexpr int  RING_BYTES = RING ? 2 * (NLIN_ / 2) * SLOT : 0; // per wave
       static constexpr int  FLAG_BYTES = 64; // pub[4], done[4] (HOX_FLAGS)
