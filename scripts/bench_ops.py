@@ -264,6 +264,8 @@ if __name__ == "__main__":
     ns_case(2, 128, 0)
     ns_residual_case(2, 128, 1)
     ns_residual_case(2, 128, 0)
+    ns_residual_case(2, 128, 1, two_phase=True)      # round 5: variable coefficients on the sweep kernel
+    ns_residual_case(2, 128, 0, two_phase=True)
     for v in (1, 2, 0):
         ns_divergence_case((64, 64, 128), v)
         ns_divergence_case((128, 128, 128), v)
@@ -276,7 +278,9 @@ if __name__ == "__main__":
     for k, n in ((3, 64), (4, 64), (5, 48)):        # 1: x-marching kernel (round 4), 2: z-sweep kernel (round 2), 0: generic
         for v in (1, 2, 0):
             ns_case(k, n, v)
+    ns_residual_case(3, 64, 1)
     ns_residual_case(4, 64, 1)
+    ns_residual_case(5, 48, 1)
     for k in (3, 4):                                 # two-phase Jacobian on the x-marching kernel (round 4) / generic
         for v in (1, 0):
             ns_case(k, 64, v, two_phase=True)

@@ -101,6 +101,8 @@ if ratio:
 # runs in different rows) count in full
 f, w = mean_kb("pmc_q4_fetch", "ns_hox_kernel", "FETCH_SIZE"), mean_kb("pmc_q4_write", "ns_hox_kernel", "WRITE_SIZE")
 f0 = mean_kb("pmc_q4_fetch_nostate", "ns_hox_kernel", "FETCH_SIZE")
+if not f0:   # (the no-state build is a development build: keep the calibration of the run that had it)
+    f0 = _old.get("64x64x64 k=4 variant=1", {}).get("ns_hox_kernel", {}).get("FETCH_SIZE_KB_without_state_stream")
 if f and w:
     entry = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "raw_bytes": int((f + w) * 1024)}
     if f0:

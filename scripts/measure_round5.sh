@@ -22,6 +22,8 @@ pmc pmc_q2s_fetch FETCH_SIZE python3 $R/bench.py --variant 4 --steps 5 --warmup 
 pmc pmc_q2s_write WRITE_SIZE python3 $R/bench.py --variant 4 --steps 5 --warmup 2 --no-cpu-baseline
 pmc pmc_q2_sq1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline
 pmc pmc_q2_sq2 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline
+pmc pmc_q4_fetch FETCH_SIZE python3 $R/bench.py --config cavity --steps 5 --warmup 2 --no-cpu-baseline
+pmc pmc_q4_write WRITE_SIZE python3 $R/bench.py --config cavity --steps 5 --warmup 2 --no-cpu-baseline
 pmc pmc_hop_sq2 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" python3 $R/bench.py --config cavity --variant 3 --steps 5 --warmup 2 --no-cpu-baseline
 cd $R
 python3 bench.py > "$O/bench_n1_plain.log" 2>&1
