@@ -374,7 +374,7 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
                           &ctx->ls_convection, &ctx->ls_normal, &ctx->q1_convection, &ctx->q1_normal, &ctx->q1_normal_nodal, &ctx->q1_velocity_nodal,
                           &ctx->q1_slab, &ctx->q1_zslab, &ctx->pc_inv_u, &ctx->pc_inv_pm, &ctx->pc_inv_pl,
                           &ctx->pc_ones_p, &ctx->pc_tmp_u, &ctx->pc_tmp_p, &ctx->pc_tmp_p2, &ctx->pc_work, &ctx->kr_work, &ctx->kr_basis, &ctx->kr_scalars,
-                          &ctx->q1_poisson_coef, &ctx->ho_tab, &ctx->res_sum_u, &ctx->res_sum_p, &ctx->res_old,
+                          &ctx->q1_poisson_coef, &ctx->ho_tab, &ctx->res_sum_u, &ctx->res_sum_p, &ctx->res_old, &ctx->res_ext,
                           &ctx->ls_art_visc, &ctx->ls_stab_vel_sum, &ctx->ls_stab_ls_sum, &ctx->hox_lin, &ctx->hox_lin_prec, &ctx->pc_tridiag,
                           &ctx->hox_slab_u, &ctx->hox_xslab_u, &ctx->hox_slab_p, &ctx->hox_xslab_p, &ctx->hox_tab,
                           &ctx->hop_lin, &ctx->hop_lin_prec, &ctx->hop_tab, &ctx->lin_nodal, &ctx->lin_nodal_prec})
@@ -844,7 +844,16 @@ int adaflo_ns_residual(adaflo_ctx *ctx, double *rhs_u, double *rhs_p, const doub
               "old-solution combination failed");
           old_comb = ctx->res_old.p;
         }
-      TRY(ctx, launch_ns_residual_hox(ctx, ctx->res_sum_u.p, ctx->res_sum_p.p, src_u, src_p, old_comb),
+      const double *ext_comb = nullptr;
+      if (ctx->ns.linearization == ADAFLO_COUPLED_VELOCITY_SEMI_IMPLICIT || ctx->ns.linearization == ADAFLO_COUPLED_VELOCITY_EXPLICIT)
+        {
+          // :644-647, 740-782: the extrapolated velocity extrap_old u_old + extrap_old_old u_old_old, combined at the nodes
+          TRY(ctx, alloc(ctx, ctx->res_ext, nu), ctx->last_error);
+          TRY(ctx, launch_lincomb(ctx, ctx->res_ext.p, ctx->ns.extrap_old, old_u, ctx->ns.extrap_old_old, old_old_u, nu),
+              "extrapolation failed");
+          ext_comb = ctx->res_ext.p;
+        }
+      TRY(ctx, launch_ns_residual_hox(ctx, ctx->res_sum_u.p, ctx->res_sum_p.p, src_u, src_p, old_comb, ext_comb),
           "x-marching residual kernel launch failed");
       TRY(ctx, launch_residual_finish(ctx, rhs_u, ctx->res_sum_u.p, user_u, nu), "residual update failed");
       TRY(ctx, launch_residual_finish(ctx, rhs_p, ctx->res_sum_p.p, user_p, np), "residual update failed");

@@ -151,7 +151,7 @@ struct adaflo_ctx
   // (lin, lin_prec) are then stale until somebody asks for them (ensure_lin_generic, capi.hip)
   bool                     lin_generic_valid = true, lin_prec_generic_valid = true;
   int                      lin_q2_prec_mode = -1;
-  adaflo_hip::DeviceBuffer res_sum_u, res_sum_p, res_old; // work vectors of the sweep-kernel residual
+  adaflo_hip::DeviceBuffer res_sum_u, res_sum_p, res_old, res_ext; // work vectors of the sweep-kernel residual (res_ext: extrapolated velocity)
   int                      lin_q2_mode  = -1;
   int                      q2_lz        = 0; // z-chunk length override (0 = heuristic)
   // recompute-state mode of the Q2/Q1 kernel (on by default, kernel variant 4 switches it off): nodal copy of the

@@ -22,7 +22,7 @@ namespace adaflo_hip
   bool hox_supported(const adaflo_ctx *ctx);
   bool hox_residual_supported(const adaflo_ctx *ctx);
   int  launch_ns_residual_hox(adaflo_ctx *ctx, double *sum_u, double *sum_p, const double *src_u, const double *src_p,
-                              const double *old_comb);
+                              const double *old_comb, const double *ext_comb = nullptr);
   int  hox_unconvert_state(adaflo_ctx *ctx, double *generic, bool frozen_copy = false);
   int  launch_ns_vmult_hox(adaflo_ctx *ctx, int op, double *dst_u, double *dst_p, const double *src_u,
                            const double *src_p, int phase = -1, uint32_t iface = 0);

@@ -112,7 +112,8 @@ namespace adaflo_hip
     // (or null), the state is WRITTEN to ctx->hox_lin
     template <int K>
     int launch_hox(adaflo_ctx *ctx, const int op, double *dst_u, double *dst_p, const double *src_u, const double *src_p,
-                   const int phase, const uint32_t iface, const bool residual = false, const double *old_comb = nullptr)
+                   const int phase, const uint32_t iface, const bool residual = false, const double *old_comb = nullptr,
+                   const double *ext_comb = nullptr)
     {
       using G         = Geo<K>;
       constexpr int N = K + 1;
@@ -170,6 +171,7 @@ namespace adaflo_hip
         {
           A.old_u = old_comb;
           A.c_old = old_comb ? P.density : 0.;
+          A.lin_u = ext_comb; // (schemes that linearise about the extrapolated old velocity)
           if (lin_mode != 2)
             {
               if (int e = ensure(ctx->hox_lin, state_doubles<K>(ctx, lin_mode)))
@@ -296,7 +298,31 @@ namespace adaflo_hip
     if (err == hipSuccess && nwg > 0)                                                                     \
       hipLaunchKernelGGL((ns_hox_kernel<K, LM, true, true>), grid, block, lds_bytes, ctx->stream, A);     \
   }
-      if (residual)
+#define HOX_LAUNCH_RES_EXT(LM)                                                                                            \
+  {                                                                                                                       \
+    static bool attr_set = false;                                                                                         \
+    if (!attr_set)                                                                                                        \
+      {                                                                                                                   \
+        err      = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_hox_kernel<K, LM, true, true, false, false, true>), \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                      \
+        attr_set = err == hipSuccess;                                                                                     \
+      }                                                                                                                   \
+    if (err == hipSuccess && nwg > 0)                                                                                     \
+      hipLaunchKernelGGL((ns_hox_kernel<K, LM, true, true, false, false, true>), grid, block, lds_bytes, ctx->stream, A); \
+  }
+      if (residual && ext_comb)
+        {
+          if constexpr (K <= 4)
+            {
+              if (lin_mode == 1)
+                HOX_LAUNCH_RES_EXT(1)
+              else
+                HOX_LAUNCH_RES_EXT(2)
+            }
+          else
+            err = hipErrorNotSupported;
+        }
+      else if (residual)
         switch (lin_mode)
           {
             case 0:
@@ -336,6 +362,7 @@ namespace adaflo_hip
 #undef HOX_LAUNCH_RC
 #undef HOX_LAUNCH_V
 #undef HOX_LAUNCH_RES
+#undef HOX_LAUNCH_RES_EXT
       if (err != hipSuccess)
         return ADAFLO_EHIP;
       if (stop)
@@ -400,25 +427,32 @@ namespace adaflo_hip
     return ctx->k >= 3 && ctx->k <= 5 && !ctx->flat; // (constant and, since the two-phase mode, variable coefficients)
   }
 
-  // schemes whose residual needs no extrapolated old velocities (navier_stokes_matrix.cc:740-782 stay on the generic kernel)
+  // constant coefficients; Stokes, Newton, Picard-type, and (round 5, time-dependent equations: the old solutions exist)
+  // the schemes that linearise about the extrapolated old velocity (navier_stokes_matrix.cc:740-782).  The projection
+  // scheme stays on the generic kernel
   bool hox_residual_supported(const adaflo_ctx *ctx)
   {
     const int lin = ctx->ns.linearization;
-    return hox_supported(ctx) && !ctx->rho.p && lin != ADAFLO_PROJECTION &&
-           (ctx->ns.physical_type == ADAFLO_STOKES || lin == ADAFLO_COUPLED_IMPLICIT_NEWTON || lin == ADAFLO_COUPLED_IMPLICIT_PICARD);
+    if (!hox_supported(ctx) || ctx->rho.p || lin == ADAFLO_PROJECTION)
+      return false;
+    if (ctx->ns.physical_type == ADAFLO_STOKES || lin == ADAFLO_COUPLED_IMPLICIT_NEWTON || lin == ADAFLO_COUPLED_IMPLICIT_PICARD)
+      return true;
+    // (k = 5: the kernel needs one workgroup per CU, which ROCm 7.2 miscompiles -- ns_hox_kernel.hpp, HOX_EXT_LB --, and is
+    // slower than the generic kernel at two: 4.96 against 3.96 ms at 48^3)
+    return HOX_FUSED && HOX_RES_FUSED && ctx->k <= 4 && ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE;
   }
 
   int launch_ns_residual_hox(adaflo_ctx *ctx, double *sum_u, double *sum_p, const double *src_u, const double *src_p,
-                             const double *old_comb)
+                             const double *old_comb, const double *ext_comb)
   {
     switch (ctx->k)
       {
         case 3:
-          return launch_hox<3>(ctx, OP_VMULT, sum_u, sum_p, src_u, src_p, -1, 0u, true, old_comb);
+          return launch_hox<3>(ctx, OP_VMULT, sum_u, sum_p, src_u, src_p, -1, 0u, true, old_comb, ext_comb);
         case 4:
-          return launch_hox<4>(ctx, OP_VMULT, sum_u, sum_p, src_u, src_p, -1, 0u, true, old_comb);
+          return launch_hox<4>(ctx, OP_VMULT, sum_u, sum_p, src_u, src_p, -1, 0u, true, old_comb, ext_comb);
         case 5:
-          return launch_hox<5>(ctx, OP_VMULT, sum_u, sum_p, src_u, src_p, -1, 0u, true, old_comb);
+          return launch_hox<5>(ctx, OP_VMULT, sum_u, sum_p, src_u, src_p, -1, 0u, true, old_comb, ext_comb);
         default:
           return ADAFLO_EUNSUPPORTED;
       }

@@ -134,7 +134,8 @@ namespace adaflo_hip
       int    integrate_p;
       uint32_t con_u, con_p;
       const double *src_u, *src_p, *lin; // lin: streaming layout of this kernel (hox_state_offset)
-      const double *lin_u;               // recompute-state mode (template RCP): the nodal linearisation point
+      const double *lin_u;               // recompute-state mode (template RCP): the nodal linearisation point; residual of
+                                         // the extrapolating schemes (EXT): extrap_old u_old + extrap_old_old u_old_old
       double       *dst_u, *dst_p;
       // residual mode (template RES): nodal combination weight_old u_old + weight_old_old u_old_old (or null), its
       // factor (the density), and the streaming state the kernel WRITES for the vmults of this Newton step
@@ -461,16 +462,29 @@ namespace adaflo_hip
     // RCP: recompute-state mode (round 5, as ns_q2.hip): the linearisation state (u_lin, grad u_lin) at the quadrature
     // points is the interpolation of the nodal field the last residual was evaluated at -- three more evaluate chains per
     // cell on node lines that are read like the source vector (72 B per node) instead of 96 B of state per quadrature point
-    template <int K, int LIN_MODE, bool WITH_P, bool RES = false, bool VARCO = false, bool RCP = false>
+    // EXT (with RES): the residual of the schemes that linearise about the extrapolated old velocity
+    // (source/navier_stokes_matrix.cc:644-647, 740-782: semi-implicit, LIN_MODE 1, stores (u_ext, div u_ext) as the state;
+    // explicit, LIN_MODE 2, stores nothing): u_ext = extrap_old u_old + extrap_old_old u_old_old is linear in the nodal
+    // values, so the launcher combines the nodes once and the kernel evaluates value and gradient of ONE more field -- the
+    // chains of the recompute-state mode; one workgroup per CU (512 registers)
+    template <int K, int LIN_MODE, bool WITH_P, bool RES = false, bool VARCO = false, bool RCP = false, bool EXT = false>
 #ifndef HOX_RES_LB
 #define HOX_RES_LB (K == 3 ? HOX_LB : 1)
 #endif
 #ifndef HOX_RCP_LB
 #define HOX_RCP_LB HOX_LB
 #endif
-    __global__ __launch_bounds__(NTH, (RES ? HOX_RES_LB : (RCP ? HOX_RCP_LB : (hox_deep<K, LIN_MODE, RES, VARCO, RCP>() ? 1 : HOX_LB))))
+    // (k = 5 at one workgroup per CU -- 256 VGPRs + 230 AGPRs + 555 scalar-register spills into VGPR lanes -- produced a
+    // wrong code object with ROCm 7.2: the per-lane flag word of lane 0 changes in workgroups of partial tiles, the lane's
+    // pressure rows are then stored as "constrained"; found by the parity test on a 3 x 2 x 3 mesh, reproducible on
+    // 1 x 1 x 1, correct at two workgroups per CU with scratch: scripts/dev/res_k5_probe.py)
+#ifndef HOX_EXT_LB
+#define HOX_EXT_LB (K == 5 ? 2 : 1)
+#endif
+    __global__ __launch_bounds__(NTH, (EXT ? HOX_EXT_LB : (RES ? HOX_RES_LB : (RCP ? HOX_RCP_LB : (hox_deep<K, LIN_MODE, RES, VARCO, RCP>() ? 1 : HOX_LB)))))
       void ns_hox_kernel(const HXArgs A)
     {
+      static_assert(!EXT || (RES && LIN_MODE != 0 && !RCP && HOX_FUSED && HOX_RES_FUSED), "extrapolating residual: semi-implicit / explicit scheme");
       static_assert(!RCP || (!RES && !VARCO && LIN_MODE != 2 && HOX_FUSED), "recompute-state mode: Newton / Picard vmult, constant coefficients");
       using G           = Geo<K>;
       constexpr int N = G::N, NP = G::NP, KP = G::KP, NL = G::NL, N3 = G::N3, NN = N * N;
@@ -587,7 +601,7 @@ namespace adaflo_hip
       const ctab_t tab = as_ctab(A.tab);
 
       // nodal x-lines of the step to come
-      double Un[3][N], Pn[NP], Ln[RCP ? 3 : 1][N];
+      double Un[3][N], Pn[NP], Ln[(RCP || EXT) ? 3 : 1][N];
       auto   load_nodes = [&](const int cxn) {
         if ((HOX_EXP & 32) && cxn > cx0)
           return;
@@ -598,7 +612,7 @@ namespace adaflo_hip
 #pragma unroll
           for (int d = 0; d < 3; ++d)
             Un[d][i] = pu[urow + i * 3 + d];
-        if constexpr (RCP)
+        if constexpr (RCP || EXT)
           {
             const double *pl = A.lin_u + (size_t)(K * cxc) * 3;
 #pragma unroll
@@ -1088,8 +1102,8 @@ namespace adaflo_hip
             }
           // recompute-state mode: (u_lin, grad u_lin) at my quadrature points from the nodal linearisation point (plain
           // read: the boundary values take part, as in the residual that produced the streamed state)
-          double GL[RCP ? 3 : 1][4][N];
-          if constexpr (RCP)
+          double GL[(RCP || EXT) ? 3 : 1][4][N];
+          if constexpr (RCP || EXT)
             {
               eval_fused(Ln[0], GL[0]);
               eval_fused(Ln[1], GL[1]);
@@ -1178,7 +1192,25 @@ namespace adaflo_hip
               for (int d = 0; d < 3; ++d)
                 {
                   double res = 0.;
-                  if constexpr (RES) // :783-799 the nonlinear term of the solution itself (no extrapolation)
+                  if constexpr (RES && EXT) // :740-782 convection with the extrapolated velocity
+                    {
+                      const double ediv = GL[0][1][i] * cst[TB::C_IH + 0] + GL[1][2][i] * cst[TB::C_IH + 1] + GL[2][3][i] * cst[TB::C_IH + 2];
+                      if constexpr (LIN_MODE == 2) // explicit: the extrapolated field convects itself
+                        {
+                          res = cst[TB::C_BETA] * ediv * GL[d][0][i];
+#pragma unroll
+                          for (int e = 0; e < 3; ++e)
+                            res += GL[e][0][i] * (GL[d][1 + e][i] * cst[TB::C_IH + e]);
+                        }
+                      else // semi-implicit: it convects the solution
+                        {
+                          res = cst[TB::C_BETA] * ediv * u[d];
+#pragma unroll
+                          for (int e = 0; e < 3; ++e)
+                            res += GL[e][0][i] * g[d][e];
+                        }
+                    }
+                  else if constexpr (RES) // :783-799 the nonlinear term of the solution itself (no extrapolation)
                     {
                       if constexpr (LIN_MODE != 2)
                         {
@@ -1218,8 +1250,18 @@ namespace adaflo_hip
                       double *const so = (HOX_FUSED && !FUSED) ?
                                            sog + ((size_t)cx * ST_CELL + (unsigned)(b * ST_POINT) + (unsigned)(cw * NL + i + N * a) * 2) :
                                            sog + ((size_t)cx * ST_CELL + (unsigned)(i * ST_POINT) + st_lane);
-                      so[0] = u[0], so[1] = u[1];
-                      if constexpr (LIN_MODE == 0)
+                      if constexpr (EXT) // (u_ext, div u_ext): the state of the semi-implicit vmult
+                        {
+                          so[0] = GL[0][0][i], so[1] = GL[1][0][i];
+                          so[ST_PIECE]     = GL[2][0][i];
+                          so[ST_PIECE + 1] = GL[0][1][i] * cst[TB::C_IH + 0] + GL[1][2][i] * cst[TB::C_IH + 1] + GL[2][3][i] * cst[TB::C_IH + 2];
+                        }
+                      else
+                        so[0] = u[0], so[1] = u[1];
+                      if constexpr (EXT)
+                        {
+                        }
+                      else if constexpr (LIN_MODE == 0)
                         {
                           so[ST_PIECE] = u[2], so[ST_PIECE + 1] = g[0][0];
                           so[2 * ST_PIECE] = g[0][1], so[2 * ST_PIECE + 1] = g[0][2];

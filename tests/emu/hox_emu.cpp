@@ -164,7 +164,8 @@ namespace
   template <int K>
   int run_residual(const int *ncell, const double *h, const int lin_mode, const double *coef, const double c_old,
                    const unsigned con_u, const unsigned con_p, const double *src_u, const double *src_p,
-                   const double *old_comb, double *sum_u, double *sum_p, double *lin_generic, const int lx)
+                   const double *old_comb, double *sum_u, double *sum_p, double *lin_generic, const int lx,
+                   const double *ext_comb = nullptr)
   {
     using G         = Geo<K>;
     constexpr int N = K + 1;
@@ -187,6 +188,7 @@ namespace
     A.dst_p       = sum_p;
     A.old_u       = old_comb;
     A.c_old       = c_old;
+    A.lin_u       = ext_comb; // (extrapolating schemes, template EXT)
     const int           npc = nst_of(lin_mode) / 2;
     std::vector<double> state((size_t)A.ngz * A.ngy * A.ncx * N * npc * G::CPW * G::NL * 2 + 2, std::nan(""));
     A.lin_out = state.data();
@@ -198,7 +200,11 @@ namespace
     A.xslab_u = xslab_u.data();
     A.slab_p  = slab_p.data();
     A.xslab_p = xslab_p.data();
-    if (lin_mode == 0)
+    if (ext_comb && lin_mode == 1)
+      emu::launch((unsigned)n_wg, NTH, [&] { ns_hox_kernel<K, 1, true, true, false, false, true>(A); });
+    else if (ext_comb)
+      emu::launch((unsigned)n_wg, NTH, [&] { ns_hox_kernel<K, 2, true, true, false, false, true>(A); });
+    else if (lin_mode == 0)
       emu::launch((unsigned)n_wg, NTH, [&] { ns_hox_kernel<K, 0, true, true>(A); });
     else if (lin_mode == 1)
       emu::launch((unsigned)n_wg, NTH, [&] { ns_hox_kernel<K, 1, true, true>(A); });
@@ -263,6 +269,27 @@ extern "C" int hox_emu_vmult_recompute(const int K, const int *ncell, const doub
         return run<4>(ncell, h, op, lin_mode, integrate_p, coef, con_u, con_p, nullptr, src_u, src_p, dst_u, dst_p, lx, iface, phased, nullptr, nullptr, nullptr, lin_nodal);
       case 5:
         return run<5>(ncell, h, op, lin_mode, integrate_p, coef, con_u, con_p, nullptr, src_u, src_p, dst_u, dst_p, lx, iface, phased, nullptr, nullptr, nullptr, lin_nodal);
+    }
+  return -1;
+}
+
+// residual of the schemes that linearise about the extrapolated old velocity (template EXT): ext_comb = extrap_old u_old
+// + extrap_old_old u_old_old at the nodes; lin_mode 1 (semi-implicit: stores (u_ext, div u_ext)) or 2 (explicit)
+extern "C" int hox_emu_residual_extrapolated(const int K, const int *ncell, const double *h, const int lin_mode, const double *coef,
+                                             const double c_old, const unsigned con_u, const unsigned con_p, const double *src_u,
+                                             const double *src_p, const double *old_comb, const double *ext_comb, double *sum_u,
+                                             double *sum_p, double *lin_generic, const int lx)
+{
+  if (!ext_comb || (lin_mode != 1 && lin_mode != 2))
+    return -2;
+  switch (K)
+    {
+      case 3:
+        return run_residual<3>(ncell, h, lin_mode, coef, c_old, con_u, con_p, src_u, src_p, old_comb, sum_u, sum_p, lin_generic, lx, ext_comb);
+      case 4:
+        return run_residual<4>(ncell, h, lin_mode, coef, c_old, con_u, con_p, src_u, src_p, old_comb, sum_u, sum_p, lin_generic, lx, ext_comb);
+      case 5:
+        return run_residual<5>(ncell, h, lin_mode, coef, c_old, con_u, con_p, src_u, src_p, old_comb, sum_u, sum_p, lin_generic, lx, ext_comb);
     }
   return -1;
 }

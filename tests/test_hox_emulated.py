@@ -172,3 +172,36 @@ def test_emulated_recompute_state_mode(emu, k, ncell, lx, lin, op, phased):
     case = Case(ncell, k=k, faces_u=[0, 3, 4, 5], faces_p=[1], linearization=lin, tau_grad_div=0.3, damping=0.2, steps=3)
     eu, ep = run_emulated(emu, case, op=op, lx=lx, recompute=True, phased=phased, iface=0b010011 if phased else 0)
     assert eu < TOL and ep < TOL, (eu, ep)
+
+
+@pytest.mark.parametrize("k,ncell,lx,lin", [(4, (3, 2, 5), 2, 2), (4, (2, 3, 4), 0, 3), (3, (3, 5, 5), 2, 2), (5, (2, 3, 2), 1, 2),
+                                            (3, (4, 3, 3), 0, 3)])
+def test_emulated_residual_of_the_extrapolating_schemes(emu, k, ncell, lx, lin):
+    """residual mode with template EXT: the semi-implicit (2) and explicit (3) treatments of convection linearise about
+    extrap_old u_old + extrap_old_old u_old_old (navier_stokes_matrix.cc:644-647, 740-782); the kernel evaluates value and
+    gradient of that nodal combination as one more field; sums and the stored state (u_ext, div u_ext) against the oracle"""
+    case = Case(ncell, k=k, faces_u=[0, 3, 4, 5], faces_p=[1], linearization=lin, tau_grad_div=0.3, damping=0.2,
+                density=1.3, steps=3)
+    prm = case.prm
+    src_u, src_p, old_u, oo_u = case.random_u(), case.random_p(), case.random_u(), case.random_u()
+    lin_ref = np.zeros(case.n_cells * case.nq * 12)
+    ref_u, ref_p = orc.ns_residual(case.mesh, k, prm, src_u, src_p, old_u, oo_u, con_u=case.con_u, con_p=case.con_p,
+                                   lin=lin_ref)
+    lin_mode = 1 if lin == 2 else 2
+    coef = np.array([prm.weight * prm.density - prm.damping, prm.tau1 * prm.density, prm.beta, prm.tau_grad_div,
+                     prm.viscosity * prm.tau1])
+    old_comb = prm.weight_old * old_u + prm.weight_old_old * oo_u
+    ext_comb = prm.extrap_old * old_u + prm.extrap_old_old * oo_u
+    sum_u, sum_p = np.full(case.n_u, np.nan), np.full(case.n_p, np.nan)
+    lin_generic = np.zeros(case.n_cells * 12 * case.nq)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    emu.hox_emu_residual_extrapolated.restype = C.c_int
+    rc = emu.hox_emu_residual_extrapolated(k, (C.c_int * 3)(*case.ncell), (C.c_double * 3)(*[case.mesh.h[d] for d in range(3)]),
+                                           lin_mode, dp(coef), C.c_double(prm.density), face_bits(case.faces_u, 3),
+                                           face_bits(case.faces_p, 1), dp(src_u), dp(src_p), dp(old_comb), dp(ext_comb),
+                                           dp(sum_u), dp(sum_p), dp(lin_generic), lx if lx else case.ncell[0])
+    assert rc == 0
+    assert rel_l2(-sum_u, ref_u) < TOL and rel_l2(-sum_p, ref_p) < TOL, (rel_l2(-sum_u, ref_u), rel_l2(-sum_p, ref_p))
+    if lin_mode == 1:
+        got = lin_generic.reshape(case.n_cells, 12, case.nq).transpose(0, 2, 1)
+        assert rel_l2(got[:, :, :4], lin_ref.reshape(case.n_cells, case.nq, 12)[:, :, :4]) < TOL

@@ -653,13 +653,15 @@ def test_two_phase_vmult_x_marching_kernel(k, ncell, lin, phys, chunk):
 
 @pytest.mark.parametrize("k,ncell,lin,phys,chunk", [(4, (5, 4, 9), 0, 0, 0), (4, (9, 3, 2), 1, 0, 4), (3, (6, 5, 5), 0, 0, 2),
                                                     (5, (3, 2, 3), 0, 0, 0), (4, (4, 4, 4), 0, 1, 0), (4, (3, 5, 2), 0, 2, 1),
-                                                    (3, (4, 4, 3), 1, 0, 0)])
+                                                    (3, (4, 4, 3), 1, 0, 0), (4, (5, 4, 9), 2, 0, 0), (3, (6, 5, 5), 2, 0, 2),
+                                                    (5, (3, 2, 3), 2, 0, 0), (4, (4, 4, 4), 3, 0, 1), (3, (3, 4, 5), 3, 0, 0)])
 def test_residual_x_marching_kernel(k, ncell, lin, phys, chunk):
     """residual mode of the Q3..Q5 x-marching kernel (round 4; navier_stokes_matrix.cc:266-293, 663-686, 725-800): the
     right-hand side with the read-modify-write semantics of the reference, partial constraints whose boundary values are
     read plainly, the state it leaves in the STREAMING layout only -- read back through the generic one, used by the
     next vmult, frozen by fix_linearization_point while a later residual replaces it --, Picard-type state, stationary
-    and Stokes equations; the generic kernel on the same inputs"""
+    and Stokes equations; (round 5) the schemes that linearise about the extrapolated old velocity (:740-782; semi-implicit
+    = 2 stores (u_ext, div u_ext), explicit = 3 stores nothing); the generic kernel on the same inputs"""
     case = Case(ncell, k=k, lower=(0., 0., 0.), upper=(1., 1.5, 1.), faces_u=[0, 2, 3, 5], faces_p=[1],
                 linearization=lin, physical_type=phys, tau_grad_div=0.2, damping=0.1, density=1.2, steps=3)
     src_u, src_p = case.smooth_u(0.1) + 0.01 * case.random_u(), case.smooth_p(0.1)
@@ -685,7 +687,7 @@ def test_residual_x_marching_kernel(k, ncell, lin, phys, chunk):
         op.vmult(dst, op.block_vector(vm_u, vm_p))      # on the state the residual wrote
         gu, gp = dst.numpy()
         assert rel_l2(gu, ref_vu) < TOL and rel_l2(gp, ref_vp) < TOL, (variant, rel_l2(gu, ref_vu))
-        if phys != 2:
+        if phys != 2 and lin != 3:
             ncomp = 12 if lin == 0 else 4
             got_lin = op.get_linearization().reshape(-1, 12)
             assert rel_l2(got_lin[:, :ncomp], lin_ref.reshape(-1, 12)[:, :ncomp]) < TOL
@@ -713,6 +715,32 @@ def test_residual_x_marching_kernel(k, ncell, lin, phys, chunk):
             op.vmult(dst, op.block_vector(vm_u, vm_p))
             gu, gp = dst.numpy()
             assert rel_l2(gu, r2u) < TOL and rel_l2(gp, r2p) < TOL, variant
+
+
+@pytest.mark.parametrize("k", [3, 4, 5])
+@pytest.mark.parametrize("lin", [0, 1, 2, 3])
+def test_residual_x_marching_kernel_on_partial_tiles(k, lin):
+    """the residual modes of the x-marching kernel (incl. the extrapolating schemes, which run with 512 registers per
+    lane) on meshes whose workgroup cross-sections are cut in y, in z, in both, and on a single cell: waves without a
+    cell of their own compute on cell (0, 0) and must leave no trace"""
+    for ncell in ((1, 1, 1), (2, 2, 3), (3, 2, 5), (1, 3, 2), (2, 5, 1)):
+        case = Case(ncell, k=k, lower=(0., 0., 0.), upper=(1., 1.5, 1.), faces_u=[0, 2, 3, 5], faces_p=[1],
+                    linearization=lin, tau_grad_div=0.2, damping=0.1, density=1.2, steps=3)
+        src_u, src_p = case.smooth_u(0.1) + 0.01 * case.random_u(), case.smooth_p(0.1)
+        old_u, oldold_u = case.smooth_u(0.05), case.smooth_u(0.0)
+        lin_ref = np.zeros(case.n_cells * case.nq * 12)
+        ref_u, ref_p = orc.ns_residual(case.mesh, k, case.prm, src_u, src_p, old_u, oldold_u, con_u=case.con_u,
+                                       con_p=case.con_p, lin=lin_ref)
+        op = case.engine()
+        for rep in range(2):
+            rhs = op.block_vector()
+            op.residual(rhs, op.block_vector(src_u, src_p), None, op.block_vector(old_u), op.block_vector(oldold_u))
+            got_u, got_p = rhs.numpy()
+            assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL, (ncell, rep, rel_l2(got_u, ref_u), rel_l2(got_p, ref_p))
+        if lin != 3:
+            ncomp = 12 if lin == 0 else 4
+            got_lin = op.get_linearization().reshape(-1, 12)
+            assert rel_l2(got_lin[:, :ncomp], lin_ref.reshape(-1, 12)[:, :ncomp]) < TOL, ncell
 
 
 @pytest.mark.parametrize("k", [2, 4])
