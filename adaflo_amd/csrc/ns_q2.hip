@@ -806,6 +806,26 @@ namespace adaflo_hip
           interp3(X[n], X[n + 9], X[n + 18], s0, s1, s2);
       };
 
+      // recompute mode with variable coefficients (round 5, second form): lane d of a quad loads ITS coefficient array
+      // (rho, mu, damping) for the 27 points of the cell layer and the three values go round the quad by DPP -- 27 instead
+      // of 81 loads per lane and layer --, issued in thirds a third ahead (the first third of a layer during the last
+      // third of the layer before), so that no load is waited for right after it was issued
+#ifndef Q2_RCP_COEF_PIPE
+#define Q2_RCP_COEF_PIPE 1
+#endif
+      constexpr bool CPIPE = RCP && VARCO && Q2_RCP_COEF_PIPE;
+      const double *const coef_arr = CPIPE ? (d == 1 ? A.mu : (d == 2 ? A.damp : A.rho)) : nullptr;
+      // (first entry of my cell of layer 0 in the arrays [cell][27], and the step to the next layer)
+      const unsigned coef_first = CPIPE ? (unsigned)((((size_t)(TY * by + (valid ? cyl : 0))) * A.ncx + (TX * bx + (valid ? cxl : 0))) * 27) : 0u;
+      const unsigned coef_layer = (unsigned)(A.ncy * A.ncx * 27);
+      double CPN[9]; // (the first third of the layer to come)
+      if (CPIPE)
+        {
+          const unsigned c0 = coef_first + (unsigned)cz0 * coef_layer;
+#pragma unroll
+          for (int n = 0; n < 9; ++n)
+            CPN[n] = coef_arr[c0 + n];
+        }
       for (int layer = 0; layer < nl; ++layer)
         {
           const int cz      = cz0 + layer;
@@ -817,6 +837,13 @@ namespace adaflo_hip
 
           // recompute mode with variable coefficients: first entry of my cell in the generic arrays [cell][27] (cells
           // beyond the mesh read the tile's first cell: legal address, unused values)
+          double CP0[9], CP1[9], CP2[9];
+          if (CPIPE)
+            {
+#pragma unroll
+              for (int n = 0; n < 9; ++n)
+                CP0[n] = CPN[n];
+            }
           const unsigned coef_cell = ((RCP || RES) && VARCO) ?
                                        (unsigned)((((size_t)cz * A.ncy + (TY * by + (valid ? cyl : 0))) * A.ncx + (TX * bx + (valid ? cxl : 0))) * 27) :
                                        0u;
@@ -944,8 +971,29 @@ namespace adaflo_hip
           const double2 *sout_layer = reinterpret_cast<const double2 *>(A.state_out) +
                                       ((size_t)bt * A.ncz + cz) * A.state_stride;
 
+          // (three thirds of nine points: the coefficient loads of the recompute mode are issued between them)
 #pragma unroll
-          for (int q = 0; q < 27; ++q)
+          for (int third = 0; third < 3; ++third)
+          {
+          if (CPIPE)
+            {
+              // the third to come: 9..17 and 18..26 of this layer, 0..8 of the next (the last layer of the chunk fetches
+              // its own once more: legal addresses, unused values)
+              const unsigned cn = third == 2 ? coef_first + (unsigned)cz_next * coef_layer : coef_cell + 9u * (unsigned)(third + 1);
+#pragma unroll
+              for (int n = 0; n < 9; ++n)
+                {
+                  const double v = coef_arr[cn + n];
+                  if (third == 0)
+                    CP1[n] = v;
+                  else if (third == 1)
+                    CP2[n] = v;
+                  else
+                    CPN[n] = v;
+                }
+            }
+#pragma unroll
+          for (int q = 9 * third; q < 9 * third + 9; ++q)
             {
               const int qx = q % 3, qy = (q / 3) % 3, qz = q / 9;
               double2   st0 = make_double2(0., 0.), st1 = make_double2(0., 0.);
@@ -1014,13 +1062,18 @@ namespace adaflo_hip
               const double  g2 = dline(qz, V[qx + 3 * qy], V[qx + 3 * qy + 9], V[qx + 3 * qy + 18],
                                        A.ah[e2][0], A.ah[e2][1], A.ah[e2][2], A.ah[e2][3]);
 
-              if (RCP && VARCO)
+              if (RCP && VARCO && !CPIPE)
                 {
                   const unsigned cq_ = coef_cell + (unsigned)q;
                   r_rho = A.rho[cq_], r_mu = A.mu[cq_], r_damp = A.damp[cq_];
                 }
               if (RES && VARCO)
                 r_rho = quad_bcast<0>(CQ[q]), r_mu = quad_bcast<1>(CQ[q]), r_damp = quad_bcast<2>(CQ[q]);
+              if (CPIPE)
+                {
+                  const double cq_ = q < 9 ? CP0[q % 9] : (q < 18 ? CP1[q % 9] : CP2[q % 9]);
+                  r_rho = quad_bcast<0>(cq_), r_mu = quad_bcast<1>(cq_), r_damp = quad_bcast<2>(cq_);
+                }
               if (RCP)
                 {
                   // the state of this point from the interpolated nodal linearisation point: my component's value and
@@ -1133,6 +1186,7 @@ namespace adaflo_hip
               dline_t(qz, tg2, R[qx + 3 * qy], R[qx + 3 * qy + 9], R[qx + 3 * qy + 18],
                       A.ah[e2][0], A.ah[e2][1], A.ah[e2][2], A.ah[e2][3]);
             }
+          }
 
           // ---- transposed interpolation back to the nodes --------------------------------
 #pragma unroll
