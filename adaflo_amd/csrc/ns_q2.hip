@@ -83,13 +83,26 @@ namespace adaflo_hip
       return A.fix_mode == 1 ? !on : on;
     }
 
-    template <int SEL>
+    // Q2_SWIZZLE (experiment, round 5): bit mask of the broadcasts that go through the LDS crossbar (ds_swizzle_b32, quad
+    // mode: no LDS memory, the LDS pipeline instead of a VALU slot) instead of v_mov_b32_dpp; WHICH = group of the call site
+#ifndef Q2_SWIZZLE
+#define Q2_SWIZZLE 0
+#endif
+    template <int SEL, int WHICH = 0>
     __device__ __forceinline__ double quad_bcast(const double x)
     {
       constexpr int ctrl = SEL * 0x55; // quad_perm:[SEL,SEL,SEL,SEL]
       int lo = __double2loint(x), hi = __double2hiint(x);
-      lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xf, 0xf, true);
-      hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xf, 0xf, true);
+      if constexpr ((Q2_SWIZZLE >> WHICH) & 1)
+        {
+          lo = __builtin_amdgcn_ds_swizzle(lo, 0x8000 | ctrl);
+          hi = __builtin_amdgcn_ds_swizzle(hi, 0x8000 | ctrl);
+        }
+      else
+        {
+          lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xf, 0xf, true);
+          hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xf, 0xf, true);
+        }
       return __hiloint2double(hi, lo);
     }
 
@@ -1088,17 +1101,17 @@ namespace adaflo_hip
                   const double vb = V2[q];
                   st0   = make_double2(vb, b0);
                   st1   = make_double2(b1, b2);
-                  r_ub0 = quad_bcast<0>(vb), r_ub1 = quad_bcast<1>(vb), r_ub2 = quad_bcast<2>(vb);
-                  r_trl = quad_bcast<0>(b0) + quad_bcast<1>(b1) + quad_bcast<2>(b2);
+                  r_ub0 = quad_bcast<0, 2>(vb), r_ub1 = quad_bcast<1, 2>(vb), r_ub2 = quad_bcast<2, 2>(vb);
+                  r_trl = quad_bcast<0, 3>(b0) + quad_bcast<1, 3>(b1) + quad_bcast<2, 3>(b2);
                 }
 #if !defined(Q2_LDS_EXCHANGE)
               // gradient rows of the three velocity components, visible to all four lanes (DPP)
-              const double G00 = quad_bcast<0>(g0), G01 = quad_bcast<0>(g1), G02 = quad_bcast<0>(g2);
-              const double G10 = quad_bcast<1>(g0), G11 = quad_bcast<1>(g1), G12 = quad_bcast<1>(g2);
-              const double G20 = quad_bcast<2>(g0), G21 = quad_bcast<2>(g1), G22 = quad_bcast<2>(g2);
+              const double G00 = quad_bcast<0, 0>(g0), G01 = quad_bcast<0, 0>(g1), G02 = quad_bcast<0, 0>(g2);
+              const double G10 = quad_bcast<1, 0>(g0), G11 = quad_bcast<1, 0>(g1), G12 = quad_bcast<1, 0>(g2);
+              const double G20 = quad_bcast<2, 0>(g0), G21 = quad_bcast<2, 0>(g1), G22 = quad_bcast<2, 0>(g2);
               const double c0 = sel3(d, G00, G01, G02), c1 = sel3(d, G10, G11, G12), c2 = sel3(d, G20, G21, G22);
-              const double u0 = quad_bcast<0>(Vq), u1 = quad_bcast<1>(Vq), u2 = quad_bcast<2>(Vq);
-              const double pres = quad_bcast<3>(Vq);
+              const double u0 = quad_bcast<0, 1>(Vq), u1 = quad_bcast<1, 1>(Vq), u2 = quad_bcast<2, 1>(Vq);
+              const double pres = quad_bcast<3, 1>(Vq);
 #else
               // (measured alternative, 17 % slower: exposed LDS latency per point + one more barrier)
               // Exchange inside the quad through a wave-private LDS record [lane d][g0 g1 g2 v]:
