@@ -572,9 +572,17 @@ int adaflo_ns_set_coefficients(adaflo_ctx *ctx, const double *rho, const double 
 {
   CHECK_CTX(ctx);
   const size_t count = (size_t)ctx->n_cells * ctx->nq_u;
-  TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
-  ctx->lin_q2_valid    = false; // the streaming copies of the sweep kernels carry the coefficients
-  ctx->hox_lin_primary = false; // (ensure_lin_generic above brought the generic copy up to date)
+  // a state that exists only as the Q2/Q1 streaming copy WITHOUT coefficient pieces (left by the sweep-kernel residual, also
+  // the variable-coefficient one) is independent of the coefficients: it stays what it is (every time step of a two-phase
+  // run sets new coefficients before its first residual -- re-laying out the state of the step before would be 3 ms at
+  // 128^3 for nothing); whoever needs another layout later converts then (ensure_lin_generic, q2_launch)
+  const bool keep_q2 = ctx->lin_q2.p && ctx->lin_q2_valid && !ctx->lin_q2_varco && !ctx->lin_generic_valid && !ctx->hox_lin_primary;
+  if (!keep_q2)
+    {
+      TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
+      ctx->lin_q2_valid    = false; // the streaming copies of the sweep kernels carry the coefficients
+      ctx->hox_lin_primary = false; // (ensure_lin_generic above brought the generic copy up to date)
+    }
   ctx->lin_gen++;
   ctx->q1_poisson_src = nullptr;
   if (!rho && !mu && !damping)

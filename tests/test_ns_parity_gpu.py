@@ -914,6 +914,38 @@ def test_two_phase_residual_sweep_kernel(ncell, upper, phys, faces_u):
         assert rel_l2(vdst.numpy(), ref_vel) < TOL, variant
 
 
+@pytest.mark.parametrize("first_coefficients", [False, True])
+def test_new_coefficients_leave_the_state_of_the_sweep_residual_alone(first_coefficients):
+    """adaflo_ns_set_coefficients after a sweep-kernel residual (what every two-phase time step does): the state exists
+    only as the streaming copy without coefficient pieces and is NOT re-laid out; the Jacobian with the new coefficients
+    on that state -- recomputed (variant 1), streamed with coefficient pieces (variant 4: converted on demand), generic
+    (variant 0) -- and the canonical state against the oracle"""
+    case = Case((9, 8, 5), k=2, lower=(0., 0., 0.), upper=(1., 1., 1.), steps=3, tau_grad_div=0.1, density_diff=0.5)
+    src_u, src_p = case.smooth_u(0.1) + 0.05 * case.random_u(), case.smooth_p(0.1)
+    old_u, oldold_u = case.smooth_u(0.05), case.smooth_u(0.0)
+    vm_u, vm_p = case.random_u(), case.random_p()
+    w, modes = case.weights_modes()
+    co1, co2 = case.random_coefficients(), case.random_coefficients()
+    lin_ref = np.zeros(case.n_cells * case.nq * 12)
+    kw1 = dict(rho=co1[0], mu=co1[1], damp=co1[2]) if first_coefficients else {}
+    orc.ns_residual(case.mesh, case.k, case.prm, src_u, src_p, old_u, oldold_u, con_u=case.con_u, con_p=case.con_p,
+                    lin=lin_ref, **kw1)
+    ref_u, ref_p = orc.ns_vmult(case.mesh, 2, case.prm, vm_u, vm_p, case.con_u, case.con_p, lin=lin_ref, rho=co2[0],
+                                mu=co2[1], damp=co2[2], weights=w, modes=modes)
+    op = case.engine()
+    if first_coefficients:
+        op.set_coefficients(*co1)
+    rhs, dst = op.block_vector(), op.block_vector()
+    op.residual(rhs, op.block_vector(src_u, src_p), None, op.block_vector(old_u), op.block_vector(oldold_u))
+    op.set_coefficients(*co2)
+    for variant in (1, 4, 0, 1):
+        op.set_kernel_variant(variant)
+        op.vmult(dst, op.block_vector(vm_u, vm_p))
+        gu, gp = dst.numpy()
+        assert rel_l2(gu, ref_u) < TOL and rel_l2(gp, ref_p) < TOL, (variant, rel_l2(gu, ref_u), rel_l2(gp, ref_p))
+    assert rel_l2(op.get_linearization().reshape(-1, 12), lin_ref.reshape(-1, 12)) < TOL
+
+
 @pytest.mark.parametrize("ncell,upper", [((9, 8, 5), (1., 1., 1.)), ((17, 9, 6), (1., 1., 3.)), ((3, 2, 2), (1., 2., 1.))])
 def test_two_phase_vmult_recomputes_the_state_from_the_nodal_linearisation_point(ncell, upper):
     """variable density / viscosity / damping (the two-phase Jacobian): the residual runs on the generic kernel, the
