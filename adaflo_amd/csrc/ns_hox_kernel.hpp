@@ -439,6 +439,9 @@ namespace adaflo_hip
 #ifndef HOX_LB
 #define HOX_LB 2
 #endif
+#ifndef HOX_NODES_LATE
+#define HOX_NODES_LATE 0
+#endif
     // HOX_DEEP = 1 (experiment, round 5): k = 4 with a streamed state at ONE workgroup per CU (512 registers, 147 KB of
     // LDS) and a state ring that holds a whole cell: every point's pieces are issued one step (~15 k cycles) before they
     // are read, where the two-point ring issues three of five points ~500 cycles ahead of an HBM round trip of ~2 700
@@ -584,6 +587,13 @@ namespace adaflo_hip
       // state ring of my wave
       constexpr bool RING = G::RING && NST > 0 && !VARCO && !(HOX_EXP & 4);
       constexpr bool DEEP = hox_deep<K, LIN_MODE, RES, VARCO, RCP>();
+      // k = 5 spills a few registers in the integrate phase; a scratch reload is followed by vmcnt(0), which waits for every
+      // copy in flight -- so the two points of the NEXT cell are issued after the integrate phase, not at the end of the
+      // quadrature loop (they still have the combine, emit and evaluate phases, > 10 k cycles, to arrive)
+#ifndef HOX_LATE_RING
+#define HOX_LATE_RING 1
+#endif
+      constexpr bool LATE_RING = HOX_LATE_RING && RING && !DEEP && K == 5;
       constexpr int  RPTS = DEEP ? N : 2, RING_BYTES = DEEP ? G::RING_BYTES_DEEP : G::RING_BYTES; // points in the ring
       constexpr int  SLOT = G::SLOT, RS = RPTS * (NST / 2 > 0 ? NST / 2 : 1);
       char *const    ring = reinterpret_cast<char *>(lds + 4 * G::WAVE + G::PUB_DOUBLES) + wave * RING_BYTES;
@@ -611,7 +621,7 @@ namespace adaflo_hip
         for (int i = 0; i < N; ++i)
 #pragma unroll
           for (int d = 0; d < 3; ++d)
-            Un[d][i] = pu[urow + i * 3 + d];
+            Un[d][i] = (pu + urow)[i * 3 + d]; // (ONE per-lane address + immediate offsets: unsigned index sums are 18 addresses, hoisted and spilled)
         if constexpr (RCP || EXT)
           {
             const double *pl = A.lin_u + (size_t)(K * cxc) * 3;
@@ -619,14 +629,14 @@ namespace adaflo_hip
             for (int i = 0; i < N; ++i)
 #pragma unroll
               for (int d = 0; d < 3; ++d)
-                Ln[d][i] = pl[urow + i * 3 + d];
+                Ln[d][i] = (pl + urow)[i * 3 + d];
           }
         if (WITH_P)
           {
             const double *pp = A.src_p + (size_t)(KP * cxc);
 #pragma unroll
             for (int i = 0; i < NP; ++i)
-              Pn[i] = pp[prow + i];
+              Pn[i] = (pp + prow)[i];
           }
       };
       double st[RCP ? nst_of(LIN_MODE) : (NST > 0 ? NST : 1)];
@@ -634,8 +644,8 @@ namespace adaflo_hip
 #pragma unroll
         for (int e = 0; e < NPC; ++e)
           {
-            st[2 * e]     = base[off + e * ST_PIECE];
-            st[2 * e + 1] = base[off + e * ST_PIECE + 1];
+            st[2 * e]     = (base + off)[e * ST_PIECE]; // (one per-lane address + immediate offsets)
+            st[2 * e + 1] = (base + off)[e * ST_PIECE + 1];
           }
       };
 
@@ -1050,7 +1060,7 @@ namespace adaflo_hip
             const double *po = A.old_u + (size_t)(K * cx) * 3;
 #pragma unroll
             for (int i = 0; i < N; ++i)
-              U[i] = po[urow + i * 3 + d];
+              U[i] = (po + urow)[i * 3 + d];
             EoMat<N, N, 1> mS;
             mS.load(tb(TB::S));
             mS.template apply<false>(U, T);
@@ -1133,7 +1143,12 @@ namespace adaflo_hip
                   if (i == 0)
                     wait_vmcnt<0>();
                   else if (i >= 2 && !DEEP)
-                    wait_vmcnt<NPC>();
+                    {
+                      if (LATE_RING && i == N - 1) // (nothing was issued at point N - 2: my pieces are the youngest)
+                        wait_vmcnt<0>();
+                      else
+                        wait_vmcnt<NPC>();
+                    }
                   ring_read_impl<(i_c % RPTS) * NPC, NPC, RS, SLOT>(ring_lane, st);
                   // the slots are free again: the same half of the ring takes the next point of its parity (in the
                   // last step of the chunk that is the same cell once more, never read: no branch in this loop)
@@ -1141,7 +1156,7 @@ namespace adaflo_hip
                     ring_issue(stn, i_, i_);
                   else if constexpr (i_c + 2 < N)
                     ring_issue(stc, std::integral_constant<int, i_c + 2>{}, std::integral_constant<int, i_c % 2>{});
-                  else
+                  else if constexpr (!LATE_RING)
                     ring_issue(stn, std::integral_constant<int, i_c % 2>{}, std::integral_constant<int, i_c % 2>{});
                 }
               const ctab_t cst = tb(TB::C); // constants of the quadrature-point operation
@@ -1417,13 +1432,22 @@ namespace adaflo_hip
             Rp[i] = 0.;
           integ_single(I0_{});
           // the nodal lines of the next step arrive during the rest of the integration (issued here, not earlier: the
-          // quadrature loop and the first component need the registers)
-          load_nodes(cx + 1);
+          // quadrature loop and the first component need the registers; k = 5, HOX_NODES_LATE: one component later still)
+          if (!(HOX_NODES_LATE && K == 5))
+            load_nodes(cx + 1);
           integ_single(I1_{});
+          if (HOX_NODES_LATE && K == 5)
+            load_nodes(cx + 1);
           integ_single(I2_{});
           HOX_MARK(4)
           if constexpr (WITH_P)
             integ_p();
+          if constexpr (LATE_RING)
+            {
+              // the first two points of the next cell (both halves of the ring were free since the quadrature loop)
+              ring_issue(stn, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+              ring_issue(stn, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+            }
 
           HOX_MARK(5)
           // ================= carry in x, combine in y / z, emit the K finished nodes ============================

@@ -837,7 +837,7 @@ namespace adaflo_hip
           const unsigned c0 = coef_first + (unsigned)cz0 * coef_layer;
 #pragma unroll
           for (int n = 0; n < 9; ++n)
-            CPN[n] = coef_arr[c0 + n];
+            CPN[n] = (coef_arr + c0)[n]; // (one per-lane address + immediate offsets)
         }
       for (int layer = 0; layer < nl; ++layer)
         {
@@ -886,7 +886,7 @@ namespace adaflo_hip
               const double *const arr = d == 1 ? A.mu : (d == 2 ? A.damp : A.rho);
 #pragma unroll
               for (int n = 0; n < 27; ++n)
-                CQ[n] = arr[coef_cell + n];
+                CQ[n] = (arr + coef_cell)[n]; // (one per-lane address + immediate offsets, not 27 index sums)
             }
           if (RES && !VARCO)
             {
@@ -996,7 +996,7 @@ namespace adaflo_hip
 #pragma unroll
               for (int n = 0; n < 9; ++n)
                 {
-                  const double v = coef_arr[cn + n];
+                  const double v = (coef_arr + cn)[n];
                   if (third == 0)
                     CP1[n] = v;
                   else if (third == 1)
