@@ -830,7 +830,16 @@ int adaflo_ns_residual(adaflo_ctx *ctx, double *rhs_u, double *rhs_p, const doub
               "old-solution combination failed");
           old_comb = ctx->res_old.p;
         }
-      TRY(ctx, launch_ns_residual_q2(ctx, ctx->res_sum_u.p, ctx->res_sum_p.p, src_u, src_p, old_comb),
+      const double *ext_comb = nullptr;
+      if (ctx->ns.linearization == ADAFLO_COUPLED_VELOCITY_SEMI_IMPLICIT || ctx->ns.linearization == ADAFLO_COUPLED_VELOCITY_EXPLICIT)
+        {
+          // :644-647, 740-782: the extrapolated velocity extrap_old u_old + extrap_old_old u_old_old, combined at the nodes
+          TRY(ctx, alloc(ctx, ctx->res_ext, nu), ctx->last_error);
+          TRY(ctx, launch_lincomb(ctx, ctx->res_ext.p, ctx->ns.extrap_old, old_u, ctx->ns.extrap_old_old, old_old_u, nu),
+              "extrapolation failed");
+          ext_comb = ctx->res_ext.p;
+        }
+      TRY(ctx, launch_ns_residual_q2(ctx, ctx->res_sum_u.p, ctx->res_sum_p.p, src_u, src_p, old_comb, ext_comb),
           "Q2 residual kernel launch failed");
       if (needs_lin(ctx))
         ctx->lin_generic_valid = false;

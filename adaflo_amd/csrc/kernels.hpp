@@ -189,7 +189,7 @@ namespace adaflo_hip
   // residual mode of the sweep kernel (writes the quadrature-point state in the streaming layout)
   bool q2_residual_supported(const adaflo_ctx *ctx);
   int  launch_ns_residual_q2(adaflo_ctx *ctx, double *sum_u, double *sum_p, const double *src_u,
-                             const double *src_p, const double *old_comb);
+                             const double *src_p, const double *old_comb, const double *ext_comb = nullptr);
   int  q2_unconvert_state(adaflo_ctx *ctx, double *generic, const double *streaming, int lin_mode);
   int  launch_ns_divergence_q2(adaflo_ctx *ctx, double *sum_p, const double *src_u, const double *any_p, double weight);
   // dst[i] += src[i] for the entries that are not on a constrained face

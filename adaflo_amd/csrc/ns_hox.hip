@@ -437,7 +437,7 @@ namespace adaflo_hip
       return false;
     if (ctx->ns.physical_type == ADAFLO_STOKES || lin == ADAFLO_COUPLED_IMPLICIT_NEWTON || lin == ADAFLO_COUPLED_IMPLICIT_PICARD)
       return true;
-    // (k = 5: the kernel needs one workgroup per CU, which ROCm 7.2 miscompiles -- ns_hox_kernel.hpp, HOX_EXT_LB --, and is
+    // (k = 5: the kernel needs one workgroup per CU, whose build computes wrong pressure rows -- ns_hox_kernel.hpp, HOX_EXT_LB --, and is
     // slower than the generic kernel at two: 4.96 against 3.96 ms at 48^3)
     return HOX_FUSED && HOX_RES_FUSED && ctx->k <= 4 && ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE;
   }

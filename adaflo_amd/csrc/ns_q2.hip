@@ -52,6 +52,7 @@ namespace adaflo_hip
       int    integrate_p;
       long   state_stride; // double2 elements per (tile, layer) block (payload + skew padding)
       double *slab_u, *zslab_u, *slab_p, *zslab_p; // seam partial sums, see q2_seam_fixup_kernel
+      const double *ext_u; // residual of the extrapolating schemes (template EXT): extrap_old u_old + extrap_old_old u_old_old
       uint32_t con_u, con_p;
       const double *src_u, *src_p;
       double       *dst_u, *dst_p;
@@ -399,7 +400,9 @@ namespace adaflo_hip
       v.x = a;
       v.y = b;
       // nt: dst is written once and not re-read by this kernel (measured -2 %)
-      asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+      // (s_nop 1: a store of more than 64 bits must be two wait states ahead of a VALU write of its data registers, and
+      // the compiler does not look into the statement -- its next instruction may be a v_accvgpr_read into them)
+      asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
     }
 
     // 16-byte store to sbase + voff for the lanes in `mask` (no exec branch in the caller's code)
@@ -409,9 +412,13 @@ namespace adaflo_hip
       double2v v;
       v.x = a;
       v.y = b;
+      // (s_nop 0 behind the SALU instruction: two wait states between a store of more than 64 bits and a VALU write of its
+      // data registers -- the compiler does not look into the statement; found in round 5 when a 512-register build, whose
+      // next instruction often is a v_accvgpr_read into those registers, stored wrong values)
       asm volatile("s_mov_b64 exec, %3\n\t"
                    "global_store_dwordx4 %0, %1, %2 nt\n\t"
-                   "s_mov_b64 exec, -1" ::"v"(voff), "v"(v), "s"(sbase), "s"(mask)
+                   "s_mov_b64 exec, -1\n\t"
+                   "s_nop 0" ::"v"(voff), "v"(v), "s"(sbase), "s"(mask)
                    : "memory");
     }
 
@@ -456,7 +463,8 @@ namespace adaflo_hip
       unsigned long long saved;
       asm volatile("s_and_saveexec_b64 %0, %4\n\t"
                    "global_store_dwordx4 %1, %2, %3 " Q2_DST_POLICY "\n\t"
-                   "s_mov_b64 exec, %0"
+                   "s_mov_b64 exec, %0\n\t"
+                   "s_nop 0" // (two wait states behind a store of more than 64 bits, see store_b128_masked)
                    : "=&s"(saved)
                    : "v"(voff), "v"(v), "s"(sbase), "s"(mask)
                    : "memory", "scc");
@@ -575,7 +583,12 @@ namespace adaflo_hip
     // (u_lin, grad u_lin); the nodal linearisation point (the solution vector of the last residual, kept by the host) is
     // gathered, interpolated and differentiated next to the source field -- the state is a function of the nodal field,
     // :778-816 -- and the other components' values and the trace come from quad broadcasts instead of ring reads
-    template <int LIN_MODE, bool WITH_P, bool ISO, bool VARCO, bool RES = false, bool DIV = false, bool RCP = false>
+    // EXT (with RES; round 5): the residual of the schemes that linearise about the extrapolated old velocity
+    // (navier_stokes_matrix.cc:644-647, 740-782; LIN_MODE 1 = semi-implicit, stores (u_ext, div u_ext) as the state of the
+    // vmults; LIN_MODE 2 = explicit).  u_ext = extrap_old u_old + extrap_old_old u_old_old is combined at the nodes by the
+    // launcher; its node planes take three more plane buffers behind L_TOTAL (the kernel runs at one workgroup per CU), it
+    // is interpolated like the other fields and differentiated per point like the linearisation point of the RCP mode
+    template <int LIN_MODE, bool WITH_P, bool ISO, bool VARCO, bool RES = false, bool DIV = false, bool RCP = false, bool EXT = false>
     // waves per SIMD the registers are allocated for.  The residual mode holds three fields (solution, old-solution
     // combination, sums) and spilled 160-184 B at 256 registers; with 512 (one workgroup per CU) it has no scratch and
     // is faster: 128^3 2.29 -> 2.10 ms (round 5, profiles/r05_residual_lb.log).  The operator modes stream the state and
@@ -593,12 +606,23 @@ namespace adaflo_hip
 #ifndef Q2_RCP_LB
 #define Q2_RCP_LB (ISO ? 2 : 1)
 #endif
-    __global__ __launch_bounds__(NT, (RES ? Q2_RES_LB : (RCP ? Q2_RCP_LB : Q2_LB))) void ns_q2_kernel(const Q2Args A)
+    // (EXT: 256 registers with 184-516 B of scratch.  The 512-register build -- four fields of 27 values fit there without
+    // scratch, 128^3: 2.67 instead of 4.29 ms -- computes WRONG sums on the GPU, deterministically, on every mesh; it is not
+    // the placement of the third plane set above 64 KB of LDS (swapped: the same), not the wait states behind the wide asm
+    // stores (added: the same), there is a barrier between the gathers and the plane copies, and the 256-register build of
+    // the same source is exact.  Cause not found in the time there was; scripts/dev/res_k5_probe.py 2,8,8,4,2 reproduces it
+    // with -DQ2_EXT_LB=1.)
+#ifndef Q2_EXT_LB
+#define Q2_EXT_LB 2
+#endif
+    __global__ __launch_bounds__(NT, (EXT ? Q2_EXT_LB : (RES ? Q2_RES_LB : (RCP ? Q2_RCP_LB : Q2_LB)))) void ns_q2_kernel(const Q2Args A)
     {
       constexpr bool RING_ON = LIN_MODE != 2 && !RES && !RCP; // state stream through the LDS ring (RCP with variable
                                                               // coefficients: rho, mu, damping by plain loads from the
                                                               // generic arrays, 24 B per cell and point, L2-friendly)
       static_assert(!RCP || (LIN_MODE == 0 && !RES && !DIV), "recompute mode: Newton vmult");
+      static_assert(!EXT || (RES && LIN_MODE != 0 && !VARCO && WITH_P), "extrapolating residual: semi-implicit / explicit, constant coefficients");
+      constexpr int L_OLDP = L_RING, L_EXTP = L_TOTAL; // plane buffers of the second / third nodal field
       static_assert(!DIV || (LIN_MODE == 2 && WITH_P && !RES && !VARCO), "divergence mode");
       // (RES && VARCO, round 5: the residual of two-phase flow -- the coefficients of the layer's 27 points are read from the
       // generic arrays [cell][27], lane d of a quad its array (rho, mu, damping), and handed round by DPP; the state goes
@@ -757,8 +781,13 @@ namespace adaflo_hip
           }
         if (RES || RCP) // node planes of the old-solution combination (RCP: of the linearisation point) live in the
           {             // (unused) ring area
-            dma_u_plane_single(A, lds, 2 * cz0, I0, J0, wave, lane, A.old_u, L_RING);
-            dma_u_planes(A, lds, 2 * cz0 + 1, I0, J0, wave, lane, A.old_u, L_RING);
+            dma_u_plane_single(A, lds, 2 * cz0, I0, J0, wave, lane, A.old_u, L_OLDP);
+            dma_u_planes(A, lds, 2 * cz0 + 1, I0, J0, wave, lane, A.old_u, L_OLDP);
+          }
+        if (EXT)
+          {
+            dma_u_plane_single(A, lds, 2 * cz0, I0, J0, wave, lane, A.ext_u, L_EXTP);
+            dma_u_planes(A, lds, 2 * cz0 + 1, I0, J0, wave, lane, A.ext_u, L_EXTP);
           }
       }
       // wave-private exchange records (alias of the publish scratch, which is only live in D/E)
@@ -869,7 +898,7 @@ namespace adaflo_hip
 #pragma unroll
               for (int c = 0; c < 3; ++c)
                 {
-                  const double *pl = lds + L_RING + ((2 * cz + c) % 3) * UPLANE_L + 2 * cyl * UROW + 2 * cxl * 3 + (is_p ? 0 : d);
+                  const double *pl = lds + L_OLDP + ((2 * cz + c) % 3) * UPLANE_L + 2 * cyl * UROW + 2 * cxl * 3 + (is_p ? 0 : d);
 #pragma unroll
                   for (int b = 0; b < 3; ++b)
 #pragma unroll
@@ -887,6 +916,21 @@ namespace adaflo_hip
 #pragma unroll
               for (int n = 0; n < 27; ++n)
                 CQ[n] = (arr + coef_cell)[n]; // (one per-lane address + immediate offsets, not 27 index sums)
+            }
+          double V3[EXT ? 27 : 1]; // third nodal field: the extrapolated velocity
+          if (EXT)
+            {
+#pragma unroll
+              for (int c = 0; c < 3; ++c)
+                {
+                  const double *pl = lds + L_EXTP + ((2 * cz + c) % 3) * UPLANE_L + 2 * cyl * UROW + 2 * cxl * 3 + (is_p ? 0 : d);
+#pragma unroll
+                  for (int b = 0; b < 3; ++b)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+                      V3[a + 3 * b + 9 * c] = pl[b * UROW + a * 3 + (a == 2 ? fix_last : 0)];
+                }
+              interp_all(V3);
             }
           if (RES && !VARCO)
             {
@@ -975,7 +1019,9 @@ namespace adaflo_hip
           if (WITH_P)
             dma_p_plane(A, lds, cz + 2, Ip0, Jp0, lane);
           if (RES || RCP)
-            dma_u_planes(A, lds, 2 * cz + 3, I0, J0, wave, lane, A.old_u, L_RING);
+            dma_u_planes(A, lds, 2 * cz + 3, I0, J0, wave, lane, A.old_u, L_OLDP);
+          if (EXT)
+            dma_u_planes(A, lds, 2 * cz + 3, I0, J0, wave, lane, A.ext_u, L_EXTP);
 
           // ---- C: interpolate to the Gauss points (in place) ----------------------------
           interp_all(V);
@@ -1138,7 +1184,30 @@ namespace adaflo_hip
               double conv = cA_q * Vq;
               if (RES && VARCO) // :727-732 times the density of the point (A.c_old: 1 with a time derivative, else 0)
                 conv += (A.c_old * r_rho) * V2[q];
-              if (RES)
+              if (RES && EXT)
+                {
+                  // :740-782 value and gradient row of my component of the extrapolated velocity, the other components'
+                  // values and div u_ext through the quad
+                  const double b0 = dline(qx, V3[0 + 3 * qy + 9 * qz], V3[1 + 3 * qy + 9 * qz], V3[2 + 3 * qy + 9 * qz],
+                                          A.ah[0][0], A.ah[0][1], A.ah[0][2], A.ah[0][3]);
+                  const double b1 = dline(qy, V3[qx + 9 * qz], V3[qx + 3 + 9 * qz], V3[qx + 6 + 9 * qz],
+                                          A.ah[e1][0], A.ah[e1][1], A.ah[e1][2], A.ah[e1][3]);
+                  const double b2 = dline(qz, V3[qx + 3 * qy], V3[qx + 3 * qy + 9], V3[qx + 3 * qy + 18],
+                                          A.ah[e2][0], A.ah[e2][1], A.ah[e2][2], A.ah[e2][3]);
+                  const double vb = V3[q];
+                  const double ov0 = quad_bcast<0>(vb), ov1 = quad_bcast<1>(vb), ov2 = quad_bcast<2>(vb);
+                  const double ediv = quad_bcast<0>(b0) + quad_bcast<1>(b1) + quad_bcast<2>(b2);
+                  if (LIN_MODE == 2) // explicit: the extrapolated field convects itself
+                    conv += cB_q * (A.beta * ediv * vb + ov0 * b0 + ov1 * b1 + ov2 * b2);
+                  else // semi-implicit: it convects the solution; (u_ext, div u_ext) is the state of the vmults
+                    {
+                      conv += cB_q * (A.beta * ediv * Vq + ov0 * g0 + ov1 * g1 + ov2 * g2);
+                      const double2 *sp = sout_layer + (size_t)(2 * q) * (4 * 48);
+                      store_b128_masked(sp, sout_voff, vb, ediv, sout_mask);
+                      store_b128_masked(sp + 4 * 48, sout_voff, ediv, ediv, sout_mask);
+                    }
+                }
+              else if (RES)
                 {
                   if (LIN_MODE != 2)
                     {
@@ -1931,7 +2000,7 @@ namespace adaflo_hip
   // can be packed), 2 = the remaining interior workgroups + the rest of the fix-up.
   static int q2_launch(adaflo_ctx *ctx, const int op, double *dst_u, double *dst_p, const double *src_u,
                        const double *src_p, const int phase, const uint32_t iface, const bool residual,
-                       const double *res_old, const double res_c_old)
+                       const double *res_old, const double res_c_old, const double *res_ext = nullptr)
   {
     // recompute-state mode (default of kernel variant 1 since round 5; variant 4 streams): Newton vmult / velocity_vmult
     // on the nodal linearisation point the last residual left (only then is the state a function of a nodal field the
@@ -1985,6 +2054,7 @@ namespace adaflo_hip
     if (res_varco)
       A.rho = ctx->rho.p, A.mu = ctx->mu.p, A.damp = ctx->damp.p;
     A.c_old     = res_c_old;
+    A.ext_u     = res_ext; // (residual of the semi-implicit / explicit scheme: the extrapolated velocity at the nodes)
     A.state_out = residual ? ctx->lin_q2.p : nullptr;
     A.c_div     = res_c_old; // (divergence mode passes its weight here)
     A.ncx = ctx->desc.ncell[0];
@@ -2128,7 +2198,7 @@ namespace adaflo_hip
     hipEvent_t stop = (ctx->timing && nwg > 0) ? ctx->kernel_timer.start(ctx->stream) : nullptr;
     const bool   iso = ctx->desc.h[0] == ctx->desc.h[1] && ctx->desc.h[1] == ctx->desc.h[2];
     const dim3   grid((unsigned)(nwg > 0 ? nwg : 1)), block(NT);
-    const size_t lds_bytes = sizeof(double) * L_TOTAL;
+    const size_t lds_bytes = sizeof(double) * (L_TOTAL + (res_ext ? 3 * UPLANE_L : 0)); // (+ the node planes of the extrapolated velocity)
     hipError_t   err       = hipSuccess;
 #define Q2_LAUNCH_V(LM, WP, IS, VC, RS)                                                               \
   {                                                                                             \
@@ -2196,6 +2266,30 @@ namespace adaflo_hip
           Q2_LAUNCH_V6(2, true, true, false, false, true)
         else
           Q2_LAUNCH_V6(2, true, false, false, false, true)
+      }
+    else if (residual && res_ext)
+      {
+#define Q2_LAUNCH_EXT(LM, IS)                                                                                       \
+  {                                                                                                                 \
+    static bool attr_set = false;                                                                                   \
+    if (!attr_set)                                                                                                  \
+      {                                                                                                             \
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_q2_kernel<LM, true, IS, false, true, false, false, true>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                      \
+        attr_set = err == hipSuccess;                                                                               \
+      }                                                                                                             \
+    if (err == hipSuccess && nwg > 0)                                                                               \
+      hipLaunchKernelGGL((ns_q2_kernel<LM, true, IS, false, true, false, false, true>), grid, block, lds_bytes, ctx->stream, A); \
+  }
+        if (iso && lin_mode == 1)
+          Q2_LAUNCH_EXT(1, true)
+        else if (iso)
+          Q2_LAUNCH_EXT(2, true)
+        else if (lin_mode == 1)
+          Q2_LAUNCH_EXT(1, false)
+        else
+          Q2_LAUNCH_EXT(2, false)
+#undef Q2_LAUNCH_EXT
       }
     else if (res_varco)
       {
@@ -2330,8 +2424,13 @@ namespace adaflo_hip
       return q2_varco(ctx) && ctx->q2_recompute && ctx->ns.physical_type != ADAFLO_STOKES &&
              ctx->ns.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON;
     const NSDev &P = ctx->ns;
-    return P.physical_type == ADAFLO_STOKES || P.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON ||
-           P.linearization == ADAFLO_COUPLED_IMPLICIT_PICARD;
+    if (P.physical_type == ADAFLO_STOKES || P.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON ||
+        P.linearization == ADAFLO_COUPLED_IMPLICIT_PICARD)
+      return true;
+    // (round 5) the schemes that linearise about the extrapolated old velocity, time-dependent equations (the old
+    // solutions exist); the projection scheme stays on the generic kernel
+    return P.physical_type == ADAFLO_INCOMPRESSIBLE &&
+           (P.linearization == ADAFLO_COUPLED_VELOCITY_SEMI_IMPLICIT || P.linearization == ADAFLO_COUPLED_VELOCITY_EXPLICIT);
   }
 
   // sum_u / sum_p = cell-loop result of NavierStokesOps::residual (zero on constrained rows);
@@ -2360,7 +2459,7 @@ namespace adaflo_hip
   }
 
   int launch_ns_residual_q2(adaflo_ctx *ctx, double *sum_u, double *sum_p, const double *src_u,
-                            const double *src_p, const double *old_comb)
+                            const double *src_p, const double *old_comb, const double *ext_comb)
   {
     const int lin_mode = q2_lin_mode(ctx);
     if (lin_mode != 2)
@@ -2384,7 +2483,7 @@ namespace adaflo_hip
       }
     // (variable coefficients: the kernel multiplies by the density of the point)
     const double c_old = (old_comb && ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE) ? (q2_varco(ctx) ? 1. : ctx->ns.density) : 0.;
-    if (int e = q2_launch(ctx, OP_VMULT, sum_u, sum_p, src_u, src_p, -1, 0u, true, old_comb ? old_comb : src_u, c_old))
+    if (int e = q2_launch(ctx, OP_VMULT, sum_u, sum_p, src_u, src_p, -1, 0u, true, old_comb ? old_comb : src_u, c_old, ext_comb))
       return e;
     if (lin_mode != 2)
       {

@@ -22,6 +22,11 @@ def run(k, ncell, lin, reps=4):
         if len(bad) and r == 0:
             for b_ in bad[:8]:
                 print("   row", b_, "got", gp[b_], "ref", ref_p[b_], "diff", gp[b_] - ref_p[b_])
+        if r == 0:
+            nnx, nny, nnz = [k * n + 1 for n in ncell]
+            eu = np.abs(gu - ref_u).reshape(nnz, nny, nnx, 3)
+            print("   max |err_u| per z-plane:", " ".join("%.1e" % v for v in eu.max(axis=(1, 2, 3))))
+            print("   max |err_u| per component:", " ".join("%.1e" % v for v in eu.max(axis=(0, 1, 2))), " per x:", " ".join("%.0e" % v for v in eu.max(axis=(0, 1, 3))))
         print(k, ncell, "lin", lin, "rep", r, "err_u %.2e err_p %.2e" % (rel_l2(gu, ref_u), rel_l2(gp, ref_p)), "bad p rows", bad[:12], len(bad), flush=True)
 
 for a in sys.argv[1:]:

@@ -778,10 +778,13 @@ def test_change_of_scheme_after_the_state_was_frozen(k):
 
 @pytest.mark.parametrize("ncell,upper,lin,phys", [((9, 8, 5), (1., 1., 1.), 0, 0), ((17, 9, 6), (1., 1., 3.), 0, 0),
                                                   ((8, 16, 3), (1., 1., 1.), 1, 0), ((5, 4, 9), (1., 2., 1.), 0, 1),
-                                                  ((4, 5, 3), (1., 1., 1.), 0, 2), ((1, 1, 1), (1., 1., 1.), 0, 0)])
+                                                  ((4, 5, 3), (1., 1., 1.), 0, 2), ((1, 1, 1), (1., 1., 1.), 0, 0),
+                                                  ((9, 8, 5), (1., 1., 1.), 2, 0), ((17, 9, 6), (1., 1., 3.), 3, 0),
+                                                  ((5, 4, 9), (1., 2., 1.), 2, 0), ((1, 1, 1), (1., 1., 1.), 2, 0)])
 def test_residual_sweep_kernel(ncell, upper, lin, phys):
     """residual mode of the Q2/Q1 sweep kernel (partial and multiple tiles, several z-chunks, non-cubic
-    cells, Picard state, stationary and Stokes equations): right-hand side with the read-modify-write
+    cells, Picard state, stationary and Stokes equations; round 5: the semi-implicit (2) and explicit (3) schemes, which
+    linearise about the extrapolated old velocity, :740-782): right-hand side with the read-modify-write
     semantics of the reference (rhs = user - rhs - cell loop), the state it leaves (both layouts) and the
     operator applied on that state, against the oracle; generic kernel on the same inputs"""
     case = Case(ncell, k=2, lower=(0., 0., 0.), upper=upper, linearization=lin, physical_type=phys, steps=3)
@@ -808,7 +811,7 @@ def test_residual_sweep_kernel(ncell, upper, lin, phys):
         op.vmult(dst, op.block_vector(vm_u, vm_p))      # streaming state written by the residual
         gu, gp = dst.numpy()
         assert rel_l2(gu, ref_vu) < TOL and rel_l2(gp, ref_vp) < TOL, (variant, rel_l2(gu, ref_vu))
-        if phys != 2:
+        if phys != 2 and lin != 3:
             ncomp = 12 if lin == 0 else 4
             got_lin = op.get_linearization().reshape(-1, 12)
             assert rel_l2(got_lin[:, :ncomp], lin_ref.reshape(-1, 12)[:, :ncomp]) < TOL
