@@ -98,7 +98,12 @@ namespace adaflo_hip
   // means everything older than the N youngest has landed) before it reads the slot with ds_rd128
   __device__ __forceinline__ void dma_b128(const double *sbase, const unsigned voff, const unsigned lds_byte)
   {
-    asm volatile("s_mov_b32 m0, %0\n\t"
+    // wait states the compiler cannot insert into the statement: the scalar base may be fresh from v_readfirstlane
+    // (uniform_ptr; a VMEM instruction must be five wait states behind a VALU write of a scalar register it reads), and an
+    // LDS-DMA must be one wait state behind the SALU write of M0 (cdna_hip_programming.md, "What hipcc does not do" 2)
+    asm volatile("s_nop 3\n\t"
+                 "s_mov_b32 m0, %0\n\t"
+                 "s_nop 0\n\t"
                  "global_load_lds_dwordx4 %1, %2 nt" ::"s"(lds_byte),
                  "v"(voff), "s"(sbase)
                  : "memory"); // (m0 cannot be named as a clobber; on gfx950 the compiler itself loads M0 right before

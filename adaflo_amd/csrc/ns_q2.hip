@@ -367,7 +367,12 @@ namespace adaflo_hip
     __device__ __forceinline__ void dma_b128(const void *sbase, const unsigned voff,
                                              const unsigned lds_byte, const unsigned long long mask)
     {
-      asm volatile("s_mov_b32 m0, %0\n\t"
+      // (s_nop 4 first: the scalar base may be fresh from v_readfirstlane -- uniform64 -- and a VMEM instruction must be five
+      // wait states behind a VALU write of a scalar register it reads; the compiler pads its own instructions, not the
+      // inside of this statement.  Without it the copy can run with the base of the copy before: a valid plane of another
+      // field -- round 5, the 512-register build of the extrapolating residual)
+      asm volatile("s_nop 4\n\t"
+                   "s_mov_b32 m0, %0\n\t"
                    "s_mov_b64 exec, %3\n\t"
 #if defined(Q2_EXP) && Q2_EXP == 5
                    "global_load_lds_dwordx4 %1, %2\n\t"
@@ -381,7 +386,8 @@ namespace adaflo_hip
     __device__ __forceinline__ void dma_b32(const void *sbase, const unsigned voff,
                                             const unsigned lds_byte, const unsigned long long mask)
     {
-      asm volatile("s_mov_b32 m0, %0\n\t"
+      asm volatile("s_nop 4\n\t"
+                   "s_mov_b32 m0, %0\n\t"
                    "s_mov_b64 exec, %3\n\t"
                    "global_load_lds_dword %1, %2\n\t"
                    "s_mov_b64 exec, -1" ::"s"(lds_byte), "v"(voff), "s"(sbase), "s"(mask)
