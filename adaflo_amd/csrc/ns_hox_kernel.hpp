@@ -480,7 +480,7 @@ namespace adaflo_hip
     // (k = 5 at one workgroup per CU -- 256 VGPRs + 230 AGPRs + 555 scalar-register spills into VGPR lanes -- computes wrong
     // pressure rows: the per-lane flag word of lane 0 changes in workgroups of partial tiles, the lane's pressure rows are
     // then stored as "constrained"; found by the parity test on a 3 x 2 x 3 mesh, reproducible on 1 x 1 x 1, correct at two
-    // workgroups per CU with scratch: scripts/dev/res_k5_probe.py.  A wrong code object or a hazard only this allocation
+    // workgroups per CU with scratch: tests/probe_residual.py.  A wrong code object or a hazard only this allocation
     // exposes: not resolved)
 #ifndef HOX_EXT_LB
 #define HOX_EXT_LB (K == 5 ? 2 : 1)

@@ -616,7 +616,7 @@ namespace adaflo_hip
     // scratch, 128^3: 2.67 instead of 4.29 ms -- computes WRONG sums on the GPU, deterministically, on every mesh; it is not
     // the placement of the third plane set above 64 KB of LDS (swapped: the same), not the wait states behind the wide asm
     // stores (added: the same), there is a barrier between the gathers and the plane copies, and the 256-register build of
-    // the same source is exact.  Cause not found in the time there was; scripts/dev/res_k5_probe.py 2,8,8,4,2 reproduces it
+    // the same source is exact.  Cause not found in the time there was; tests/probe_residual.py 2,8,8,4,2 reproduces it
     // with -DQ2_EXT_LB=1.)
 #ifndef Q2_EXT_LB
 #define Q2_EXT_LB 2

@@ -1,6 +1,9 @@
-"""development: repeat the residual of one Q_k/Q_{k-1} case on the x-marching kernel and print the errors against the oracle"""
+"""TEST INFRASTRUCTURE (development probe, not collected by pytest): repeat NavierStokesMatrix::residual of one Q_k/Q_{k-1}
+case on the sweep / x-marching kernels and print the errors against the oracle, per z-plane and component.
+   usage (repo root, GPU box): python tests/probe_residual.py k,nx,ny,nz,linearization [...]"""
 import sys
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from common import Case, rel_l2
 from oracle import oracle as orc
