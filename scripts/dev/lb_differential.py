@@ -1,0 +1,42 @@
+"""development: outputs of the kernels that ship at one workgroup per CU (512 registers: residual modes of the Q2/Q1 and
+x-marching kernels, recompute mode on non-cubic cells) for a set of meshes, written to <out>.npz -- run once with the
+product library and once with a library built for 256 registers (-DQ2_RES_LB=2 -DQ2_RCP_LB=2 / -DHOX_RES_LB=2
+-DHOX_EXT_LB=2) and compare bitwise (scripts/dev/lb_differential.sh): the same source, the same floating-point operations.
+usage: lb_differential.py out.npz"""
+import sys
+sys.path.insert(0, ".")
+import numpy as np
+import adaflo_amd
+
+out = {}
+rng = np.random.default_rng(7)
+for k, cells, upper, lin in ((2, (24, 17, 12), (1., 1., 1.), "coupled implicit Newton"), (2, (33, 16, 9), (1., 2., 1.), "coupled implicit Newton"),
+                             (2, (16, 16, 16), (1., 1., 1.), "coupled implicit Picard"), (2, (24, 17, 12), (1., 1., 1.), "coupled velocity semi-implicit"),
+                             (4, (9, 7, 10), (1., 1., 1.), "coupled implicit Newton"), (5, (5, 3, 6), (1., 1., 1.), "coupled implicit Newton"),
+                             (5, (4, 4, 4), (1., 1., 1.), "coupled implicit Picard"), (4, (8, 8, 8), (1., 1., 1.), "coupled velocity semi-implicit"),
+                             (3, (9, 9, 9), (1., 1., 1.), "coupled velocity explicit")):
+    for two_phase in ((False, True) if k == 2 and "Newton" in lin else (False,)):
+        fp = adaflo_amd.FlowParameters(velocity_degree=k, linearization=lin, density_diff=0.5 if two_phase else 0.0)
+        ts = adaflo_amd.TimeStepping(fp)
+        for _ in range(3):
+            ts.next()
+        op = adaflo_amd.NavierStokesMatrix(fp, adaflo_amd.BrickMesh(list(cells), [0.] * 3, list(upper)))
+        op.initialize(ts, True)
+        if two_phase:
+            nc = op.n_cells() * (k + 1) ** 3
+            op.set_coefficients(rng.uniform(.5, 2, nc), rng.uniform(.5, 2, nc), rng.uniform(-.5, .5, nc))
+        sol = op.block_vector(rng.uniform(-1, 1, op.n_dofs_u()), rng.uniform(-1, 1, op.n_dofs_p()))
+        old = adaflo_amd.BlockVector([op.initialize_u_vector(rng.uniform(-1, 1, op.n_dofs_u()))])
+        oldold = adaflo_amd.BlockVector([op.initialize_u_vector(rng.uniform(-1, 1, op.n_dofs_u()))])
+        rhs, dst = op.block_vector(), op.block_vector()
+        op.residual(rhs, sol, None, old, oldold)
+        key = "k%d_%s_%s_%s" % (k, "x".join(map(str, cells)), lin.replace(" ", "_"), "tp" if two_phase else "cc")
+        ru, rp = rhs.numpy()
+        out[key + "_res_u"], out[key + "_res_p"] = ru, rp
+        if "explicit" not in lin:
+            out[key + "_lin"] = op.get_linearization()
+        op.vmult(dst, sol)
+        vu, vp = dst.numpy()
+        out[key + "_vm_u"], out[key + "_vm_p"] = vu, vp
+np.savez(sys.argv[1], **out)
+print("wrote", sys.argv[1], len(out), "arrays")
