@@ -77,9 +77,9 @@ def mean_kb(pass_name, kernel, counter):
 
 
 # (the residual mode <..., true, false, false> runs once as set-up; round 5: variant 1 = the recompute-state mode
-# <..., false, false, true>, variant 4 = the streaming kernel <..., false, false, false>)
-for key, passes, kernel in (("128x128x128 k=2 variant=1", ("pmc_q2_fetch", "pmc_q2_write"), "ns_q2_kernel<0, true, true, false, false, false, true>"),
-                            ("128x128x128 k=2 variant=4", ("pmc_q2s_fetch", "pmc_q2s_write"), "ns_q2_kernel<0, true, true, false, false, false, false>")):
+# <..., false, false, true, false>, variant 4 = the streaming kernel <..., false, false, false, false>; the last parameter: EXT)
+for key, passes, kernel in (("128x128x128 k=2 variant=1", ("pmc_q2_fetch", "pmc_q2_write"), "ns_q2_kernel<0, true, true, false, false, false, true, false>"),
+                            ("128x128x128 k=2 variant=4", ("pmc_q2s_fetch", "pmc_q2s_write"), "ns_q2_kernel<0, true, true, false, false, false, false, false>")):
     f, w = mean_kb(passes[0], kernel, "FETCH_SIZE"), mean_kb(passes[1], kernel, "WRITE_SIZE")
     if f and w:
         traffic[key] = {"ns_q2_kernel": {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes": int((2 * f + w) * 1024)}}
