@@ -123,11 +123,33 @@ namespace adaflo_hip
         int lx = ctx->hox_lx > 0 ? ctx->hox_lx : 0;
         if (lx == 0)
           {
-            // as long as possible (fewer x seams), but at least ~1024 workgroups for the 256 CUs
+            // x-chunks by a small cost model (round 5): the workgroups run in rounds of (workgroups per CU) x (CUs) slots;
+            // a workgroup of m chunks per row costs its chunk length + ~2.5 steps (prologue, the seam plane, the tail of the
+            // pipeline); take the m with the least rounds x cost, chunks of at least 4 cells.  (Before: "at least 1024
+            // workgroups" -- fine where the tiles fill the slots evenly, e.g. 512 tiles of Q4/Q3 64^3, but Q5/Q4 48^3 has 576
+            // tiles: two chunks are 2.25 rounds, four are 4.5: kernel 1.18 -> 1.08 ms.)
+            static const int n_cu = [] {
+              int dev = 0, n = 0;
+              if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+                n = 256;
+              return n;
+            }();
+            const bool one_per_cu = residual && K > 3; // (HOX_RES_LB / HOX_EXT_LB: 512 registers)
+            const long slots = (long)n_cu * (one_per_cu ? 1 : 2);
             const long tiles = (long)((ctx->desc.ncell[1] + G::CY - 1) / G::CY) * ((ctx->desc.ncell[2] + G::CZ - 1) / G::CZ);
-            lx               = ctx->desc.ncell[0];
-            while (lx > 4 && tiles * ((ctx->desc.ncell[0] + lx - 1) / lx) < 1024)
-              lx = (lx + 1) / 2;
+            const int  ncx   = ctx->desc.ncell[0];
+            double     best  = 1e300;
+            lx               = ncx;
+            for (int m = 1; m <= ncx; ++m)
+              {
+                const int l = (ncx + m - 1) / m;
+                if (l < 4 && m > 1)
+                  break;
+                const long   chunks = (ncx + l - 1) / l, rounds = (tiles * chunks + slots - 1) / slots;
+                const double cost   = (double)rounds * (l + 2.5);
+                if (cost < best * 0.999)
+                  best = cost, lx = l;
+              }
           }
         hox_geometry<K>(A, ctx->desc.ncell, lx);
       }
