@@ -89,11 +89,22 @@ namespace adaflo_hip
 #ifndef Q2_SWIZZLE
 #define Q2_SWIZZLE 0
 #endif
-    template <int SEL, int WHICH = 0>
+    // GUARD (kernels built for one workgroup per CU, round 5): the two halves go through an (empty) asm statement, i.e. through
+    // copies, before the DPP moves read them.  Without it the 512-register build of the extrapolating residual computed
+    // wrong sums -- deterministically, on every mesh; bisected with bitwise comparisons against the 256-register build of the
+    // same source (scripts/dev/lb_diff_ext.sh): gathers, plane copies and every part of the formula alone were equal, the
+    // full formula was not, and this pin (with or without wait states) makes it equal.  The DPP moves read halves of f64
+    // results three instructions after v_fmac_f64 / v_mul_f64 wrote them -- in both builds; with ONE wave per SIMD those
+    // issue back to back.  Whether it is a wait-state gap of the compiler for double-precision producers on gfx950 or
+    // something else was not established; kernels at two waves per SIMD have never shown it (444 parity tests, five rounds)
+    // and keep the direct form (two moves less per broadcast).
+    template <int SEL, int WHICH = 0, bool GUARD = false>
     __device__ __forceinline__ double quad_bcast(const double x)
     {
       constexpr int ctrl = SEL * 0x55; // quad_perm:[SEL,SEL,SEL,SEL]
       int lo = __double2loint(x), hi = __double2hiint(x);
+      if constexpr (GUARD)
+        asm volatile("" : "+v"(lo), "+v"(hi));
       if constexpr ((Q2_SWIZZLE >> WHICH) & 1)
         {
           lo = __builtin_amdgcn_ds_swizzle(lo, 0x8000 | ctrl);
@@ -612,14 +623,10 @@ namespace adaflo_hip
 #ifndef Q2_RCP_LB
 #define Q2_RCP_LB (ISO ? 2 : 1)
 #endif
-    // (EXT: 256 registers with 184-516 B of scratch.  The 512-register build -- four fields of 27 values fit there without
-    // scratch, 128^3: 2.67 instead of 4.29 ms -- computes WRONG sums on the GPU, deterministically, on every mesh; it is not
-    // the placement of the third plane set above 64 KB of LDS (swapped: the same), not the wait states behind the wide asm
-    // stores (added: the same), there is a barrier between the gathers and the plane copies, and the 256-register build of
-    // the same source is exact.  Cause not found in the time there was; tests/probe_residual.py 2,8,8,4,2 reproduces it
-    // with -DQ2_EXT_LB=1.)
+    // (EXT: four fields of 27 values -- 512 registers, no scratch; needs the guarded quad_bcast, see there.  256 registers:
+    // 184-516 B of scratch, 128^3 semi-implicit 4.36 instead of 2.7 ms)
 #ifndef Q2_EXT_LB
-#define Q2_EXT_LB 2
+#define Q2_EXT_LB 1
 #endif
     __global__ __launch_bounds__(NT, (EXT ? Q2_EXT_LB : (RES ? Q2_RES_LB : (RCP ? Q2_RCP_LB : Q2_LB)))) void ns_q2_kernel(const Q2Args A)
     {
@@ -629,6 +636,7 @@ namespace adaflo_hip
       static_assert(!RCP || (LIN_MODE == 0 && !RES && !DIV), "recompute mode: Newton vmult");
       static_assert(!EXT || (RES && LIN_MODE != 0 && !VARCO && WITH_P), "extrapolating residual: semi-implicit / explicit, constant coefficients");
       constexpr int L_OLDP = L_RING, L_EXTP = L_TOTAL; // plane buffers of the second / third nodal field
+      constexpr bool QG = (EXT ? Q2_EXT_LB : (RES ? Q2_RES_LB : (RCP ? Q2_RCP_LB : Q2_LB))) == 1; // quad_bcast guard
       static_assert(!DIV || (LIN_MODE == 2 && WITH_P && !RES && !VARCO), "divergence mode");
       // (RES && VARCO, round 5: the residual of two-phase flow -- the coefficients of the layer's 27 points are read from the
       // generic arrays [cell][27], lane d of a quad its array (rho, mu, damping), and handed round by DPP; the state goes
@@ -1133,11 +1141,11 @@ namespace adaflo_hip
                   r_rho = A.rho[cq_], r_mu = A.mu[cq_], r_damp = A.damp[cq_];
                 }
               if (RES && VARCO)
-                r_rho = quad_bcast<0>(CQ[q]), r_mu = quad_bcast<1>(CQ[q]), r_damp = quad_bcast<2>(CQ[q]);
+                r_rho = quad_bcast<0, 0, QG>(CQ[q]), r_mu = quad_bcast<1, 0, QG>(CQ[q]), r_damp = quad_bcast<2, 0, QG>(CQ[q]);
               if (CPIPE)
                 {
                   const double cq_ = q < 9 ? CP0[q % 9] : (q < 18 ? CP1[q % 9] : CP2[q % 9]);
-                  r_rho = quad_bcast<0>(cq_), r_mu = quad_bcast<1>(cq_), r_damp = quad_bcast<2>(cq_);
+                  r_rho = quad_bcast<0, 0, QG>(cq_), r_mu = quad_bcast<1, 0, QG>(cq_), r_damp = quad_bcast<2, 0, QG>(cq_);
                 }
               if (RCP)
                 {
@@ -1153,17 +1161,17 @@ namespace adaflo_hip
                   const double vb = V2[q];
                   st0   = make_double2(vb, b0);
                   st1   = make_double2(b1, b2);
-                  r_ub0 = quad_bcast<0, 2>(vb), r_ub1 = quad_bcast<1, 2>(vb), r_ub2 = quad_bcast<2, 2>(vb);
-                  r_trl = quad_bcast<0, 3>(b0) + quad_bcast<1, 3>(b1) + quad_bcast<2, 3>(b2);
+                  r_ub0 = quad_bcast<0, 2, QG>(vb), r_ub1 = quad_bcast<1, 2, QG>(vb), r_ub2 = quad_bcast<2, 2, QG>(vb);
+                  r_trl = quad_bcast<0, 3, QG>(b0) + quad_bcast<1, 3, QG>(b1) + quad_bcast<2, 3, QG>(b2);
                 }
 #if !defined(Q2_LDS_EXCHANGE)
               // gradient rows of the three velocity components, visible to all four lanes (DPP)
-              const double G00 = quad_bcast<0, 0>(g0), G01 = quad_bcast<0, 0>(g1), G02 = quad_bcast<0, 0>(g2);
-              const double G10 = quad_bcast<1, 0>(g0), G11 = quad_bcast<1, 0>(g1), G12 = quad_bcast<1, 0>(g2);
-              const double G20 = quad_bcast<2, 0>(g0), G21 = quad_bcast<2, 0>(g1), G22 = quad_bcast<2, 0>(g2);
+              const double G00 = quad_bcast<0, 0, QG>(g0), G01 = quad_bcast<0, 0, QG>(g1), G02 = quad_bcast<0, 0, QG>(g2);
+              const double G10 = quad_bcast<1, 0, QG>(g0), G11 = quad_bcast<1, 0, QG>(g1), G12 = quad_bcast<1, 0, QG>(g2);
+              const double G20 = quad_bcast<2, 0, QG>(g0), G21 = quad_bcast<2, 0, QG>(g1), G22 = quad_bcast<2, 0, QG>(g2);
               const double c0 = sel3(d, G00, G01, G02), c1 = sel3(d, G10, G11, G12), c2 = sel3(d, G20, G21, G22);
-              const double u0 = quad_bcast<0, 1>(Vq), u1 = quad_bcast<1, 1>(Vq), u2 = quad_bcast<2, 1>(Vq);
-              const double pres = quad_bcast<3, 1>(Vq);
+              const double u0 = quad_bcast<0, 1, QG>(Vq), u1 = quad_bcast<1, 1, QG>(Vq), u2 = quad_bcast<2, 1, QG>(Vq);
+              const double pres = quad_bcast<3, 1, QG>(Vq);
 #else
               // (measured alternative, 17 % slower: exposed LDS latency per point + one more barrier)
               // Exchange inside the quad through a wave-private LDS record [lane d][g0 g1 g2 v]:
@@ -1201,8 +1209,8 @@ namespace adaflo_hip
                   const double b2 = dline(qz, V3[qx + 3 * qy], V3[qx + 3 * qy + 9], V3[qx + 3 * qy + 18],
                                           A.ah[e2][0], A.ah[e2][1], A.ah[e2][2], A.ah[e2][3]);
                   const double vb = V3[q];
-                  const double ov0 = quad_bcast<0>(vb), ov1 = quad_bcast<1>(vb), ov2 = quad_bcast<2>(vb);
-                  const double ediv = quad_bcast<0>(b0) + quad_bcast<1>(b1) + quad_bcast<2>(b2);
+                  const double ov0 = quad_bcast<0, 0, QG>(vb), ov1 = quad_bcast<1, 0, QG>(vb), ov2 = quad_bcast<2, 0, QG>(vb);
+                  const double ediv = quad_bcast<0, 0, QG>(b0) + quad_bcast<1, 0, QG>(b1) + quad_bcast<2, 0, QG>(b2);
                   if (LIN_MODE == 2) // explicit: the extrapolated field convects itself
                     conv += cB_q * (A.beta * ediv * vb + ov0 * b0 + ov1 * b1 + ov2 * b2);
                   else // semi-implicit: it convects the solution; (u_ext, div u_ext) is the state of the vmults
@@ -1468,13 +1476,13 @@ namespace adaflo_hip
                       // the quad's 2 nodes x 3 components of a row are 48 contiguous bytes; regroup them
                       // inside the quad so that every lane stores 16 B (scalar row base + lane offset)
                       {
-                        const double b00 = quad_bcast<0>(a0), b01 = quad_bcast<1>(a0), b02 = quad_bcast<2>(a0);
-                        const double b10 = quad_bcast<0>(a1), b11 = quad_bcast<1>(a1), b12 = quad_bcast<2>(a1);
+                        const double b00 = quad_bcast<0, 0, QG>(a0), b01 = quad_bcast<1, 0, QG>(a0), b02 = quad_bcast<2, 0, QG>(a0);
+                        const double b10 = quad_bcast<0, 0, QG>(a1), b11 = quad_bcast<1, 0, QG>(a1), b12 = quad_bcast<2, 0, QG>(a1);
                         store_b128_dst(dp, voff, sel3(d, b00, b02, b11), sel3(d, b01, b10, b12), vmask_u);
                       }
                       {
-                        const double b00 = quad_bcast<0>(a3), b01 = quad_bcast<1>(a3), b02 = quad_bcast<2>(a3);
-                        const double b10 = quad_bcast<0>(a4), b11 = quad_bcast<1>(a4), b12 = quad_bcast<2>(a4);
+                        const double b00 = quad_bcast<0, 0, QG>(a3), b01 = quad_bcast<1, 0, QG>(a3), b02 = quad_bcast<2, 0, QG>(a3);
+                        const double b10 = quad_bcast<0, 0, QG>(a4), b11 = quad_bcast<1, 0, QG>(a4), b12 = quad_bcast<2, 0, QG>(a4);
                         store_b128_dst(dp + A.nnx * 3, voff, sel3(d, b00, b02, b11), sel3(d, b01, b10, b12), vmask_u);
                       }
                     }
