@@ -4,14 +4,14 @@
 #   scripts/dev/build_variant.sh hox_lb2 ns_hox -DHOX_RES_LB=2 -DHOX_EXT_LB=2      (two libraries: one unit each)
 cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
-python scripts/dev/lb_differential.py gpurun_out/lbd_product.npz
-ADAFLO_LIB_PATH=adaflo_amd/lib/variants/lib_q2_lb2.so python scripts/dev/lb_differential.py gpurun_out/lbd_q2_lb2.npz
-ADAFLO_LIB_PATH=adaflo_amd/lib/variants/lib_hox_lb2.so python scripts/dev/lb_differential.py gpurun_out/lbd_hox_lb2.npz
+python scripts/dev/lb_differential.py /tmp/lbd_product.npz
+ADAFLO_LIB_PATH=adaflo_amd/lib/variants/lib_q2_lb2.so python scripts/dev/lb_differential.py /tmp/lbd_q2_lb2.npz
+ADAFLO_LIB_PATH=adaflo_amd/lib/variants/lib_hox_lb2.so python scripts/dev/lb_differential.py /tmp/lbd_hox_lb2.npz
 python - <<'PY'
 import numpy as np
-a = np.load("gpurun_out/lbd_product.npz")
+a = np.load("/tmp/lbd_product.npz")
 for name in ("q2_lb2", "hox_lb2"):
-    b = np.load("gpurun_out/lbd_%s.npz" % name)
+    b = np.load("/tmp/lbd_%s.npz" % name)
     worst = 0.0
     for key in a.files:
         x, y = a[key], b[key]
