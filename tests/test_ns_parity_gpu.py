@@ -986,3 +986,38 @@ def test_two_phase_vmult_recomputes_the_state_from_the_nodal_linearisation_point
         op.set_kernel_variant(variant)
         op.velocity_vmult(vdst, vsrc)
         assert rel_l2(vdst.numpy(), ref_vel) < TOL, variant
+
+
+@pytest.mark.parametrize("k,lin,two_phase", [(2, 0, False), (2, 0, True), (2, 1, False), (2, 2, False), (2, 3, False),
+                                              (3, 2, False), (4, 0, False), (4, 2, False), (5, 0, False)])
+def test_residual_kernels_on_random_meshes_against_the_generic_kernels(k, lin, two_phase):
+    """the residual modes of the sweep kernels (most of them built for 512 registers) on a seeded sweep of small meshes --
+    cut tiles in every direction, non-cubic cells, one to a few cell layers -- against the generic kernels of the same
+    engine (which the other tests tie to the oracle): sums and the stored state; a broad net for allocation-dependent
+    faults like the one the extrapolating residual of round 5 had"""
+    rng = np.random.default_rng(100 * k + 10 * lin + int(two_phase))
+    nmax = {2: 20, 3: 9, 4: 7, 5: 5}[k]
+    for trial in range(6):
+        ncell = tuple(int(v) for v in rng.integers(1, nmax + 1, 3))
+        upper = tuple(float(v) for v in rng.choice([1.0, 1.5, 2.0], 3)) if trial % 2 else (1., 1., 1.)
+        case = Case(ncell, k=k, lower=(0., 0., 0.), upper=upper, faces_u=[0, 2, 3, 5], faces_p=[1], linearization=lin,
+                    tau_grad_div=0.2, damping=0.1, density=1.2, steps=3, density_diff=0.5 if two_phase else 0.0)
+        src_u, src_p = case.smooth_u(0.1) + 0.05 * case.random_u(), case.smooth_p(0.1)
+        old_u, oldold_u = case.smooth_u(0.05) + 0.02 * case.random_u(), case.smooth_u(0.0) + 0.02 * case.random_u()
+        coefficients = case.random_coefficients() if two_phase else None
+        results = []
+        for variant in (1, 0):
+            op = case.engine()
+            op.set_kernel_variant(variant)
+            if two_phase:
+                op.set_coefficients(*coefficients)
+            rhs = op.block_vector()
+            op.residual(rhs, op.block_vector(src_u, src_p), None, op.block_vector(old_u), op.block_vector(oldold_u))
+            ru, rp = rhs.numpy()
+            lin_state = op.get_linearization() if lin != 3 else np.zeros(1)
+            results.append((ru, rp, lin_state))
+        (au, ap, al), (bu, bp, bl) = results
+        assert rel_l2(au, bu) < TOL and rel_l2(ap, bp) < TOL, (ncell, upper, rel_l2(au, bu), rel_l2(ap, bp))
+        if lin != 3:
+            ncomp = 12 if lin == 0 else 4
+            assert rel_l2(al.reshape(-1, 12)[:, :ncomp], bl.reshape(-1, 12)[:, :ncomp]) < TOL, (ncell, upper)
