@@ -1021,3 +1021,39 @@ def test_residual_kernels_on_random_meshes_against_the_generic_kernels(k, lin, t
         if lin != 3:
             ncomp = 12 if lin == 0 else 4
             assert rel_l2(al.reshape(-1, 12)[:, :ncomp], bl.reshape(-1, 12)[:, :ncomp]) < TOL, (ncell, upper)
+
+
+@pytest.mark.parametrize("k,lin,two_phase", [(2, 0, False), (2, 0, True), (2, 1, False), (2, 2, False), (3, 0, False),
+                                              (4, 0, False), (4, 0, True), (5, 0, False), (5, 1, False)])
+def test_operator_kernels_on_random_meshes_against_the_generic_kernels(k, lin, two_phase):
+    """vmult and velocity_vmult of the sweep kernels on the state a residual of the same context left (Q2/Q1 Newton: the
+    recompute-state mode, on cubic and non-cubic cells; the streamed modes otherwise), on a seeded sweep of small meshes
+    with cut tiles, against the generic kernels"""
+    rng = np.random.default_rng(7 + 100 * k + 10 * lin + int(two_phase))
+    nmax = {2: 20, 3: 9, 4: 7, 5: 5}[k]
+    for trial in range(5):
+        ncell = tuple(int(v) for v in rng.integers(1, nmax + 1, 3))
+        upper = tuple(float(v) for v in rng.choice([1.0, 1.5, 2.0], 3)) if trial % 2 else (1., 1., 1.)
+        case = Case(ncell, k=k, lower=(0., 0., 0.), upper=upper, faces_u=[0, 2, 3, 5], faces_p=[1], linearization=lin,
+                    tau_grad_div=0.2, damping=0.1, density=1.2, steps=3, density_diff=0.5 if two_phase else 0.0)
+        src_u, src_p = case.smooth_u(0.1) + 0.05 * case.random_u(), case.smooth_p(0.1)
+        old_u, oldold_u = case.smooth_u(0.05), case.smooth_u(0.0)
+        vm_u, vm_p = case.random_u(), case.random_p()
+        coefficients = case.random_coefficients() if two_phase else None
+        results = []
+        for variant in (1, 0):
+            op = case.engine()
+            op.set_kernel_variant(variant)
+            if two_phase:
+                op.set_coefficients(*coefficients)
+            rhs, dst = op.block_vector(), op.block_vector()
+            op.residual(rhs, op.block_vector(src_u, src_p), None, op.block_vector(old_u), op.block_vector(oldold_u))
+            op.vmult(dst, op.block_vector(vm_u, vm_p))
+            du, dp = dst.numpy()
+            op.fix_linearization_point()
+            vsrc, vdst = op.initialize_u_vector(vm_u), op.initialize_u_vector()
+            op.velocity_vmult(vdst, vsrc)
+            results.append((du, dp, vdst.numpy()))
+        (au, ap, av), (bu, bp, bv) = results
+        assert rel_l2(au, bu) < TOL and rel_l2(ap, bp) < TOL and rel_l2(av, bv) < TOL, \
+            (ncell, upper, rel_l2(au, bu), rel_l2(ap, bp), rel_l2(av, bv))
