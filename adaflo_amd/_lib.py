@@ -145,6 +145,7 @@ SIGNATURES = {
     "adaflo_ls_compute_curvature_vmult": (C.c_int, [_CTX, _D, _D, C.c_int]),
     "adaflo_ls_compute_curvature_rhs": (C.c_int, [_CTX, _D, _D]),
     "adaflo_set_kernel_variant": (C.c_int, [_CTX, C.c_int]),
+    "adaflo_has_kernel_variant": (C.c_int, [C.c_int]),
     "adaflo_ls_compute_heaviside": (C.c_int, [_CTX, _D, _D, C.c_double]),
     "adaflo_ls_curvature_correction": (C.c_int, [_CTX, _D, _D]),
     "adaflo_ls_projection_vmult": (C.c_int, [_CTX, _D, _D]),

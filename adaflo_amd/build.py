@@ -14,6 +14,10 @@ LIB = os.path.join(LIBDIR, "libadaflo_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
+# the superseded Q3..Q5 kernels (ns_ho.hip: kernel variant 2, ns_hop.hip: variant 3) are compiled into the library only on
+# request; the stamp file makes a change of the setting rebuild the two units
+if os.environ.get("ADAFLO_BUILD_VARIANTS") == "1":
+    FLAGS.append("-DADAFLO_BUILD_VARIANTS")
 
 
 def _stale(target, deps):
@@ -30,10 +34,12 @@ def build(force=False, verbose=False):
         os.path.join(_HERE, "..", "include", "adaflo_hip.h")]
     objs = []
     procs = []
+    stamp, setting = os.path.join(LIBDIR, ".variants_setting"), os.environ.get("ADAFLO_BUILD_VARIANTS", "0")
+    changed = not os.path.exists(stamp) or open(stamp).read() != setting
     for s in srcs:
         o = os.path.join(LIBDIR, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
+        if force or _stale(o, [s] + hdrs) or (changed and os.path.basename(s) in ("ns_ho.hip", "ns_hop.hip", "capi.hip")):
             cmd = ["hipcc", "-c", s, "-o", o] + FLAGS
             if verbose:
                 print(" ".join(cmd))
@@ -41,6 +47,8 @@ def build(force=False, verbose=False):
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed for " + s)
+    with open(stamp, "w") as f:
+        f.write(setting)
     if force or procs or _stale(LIB, objs):
         cmd = ["hipcc", "-shared", "-o", LIB] + objs + ["--offload-arch=" + ARCH, "-fno-gpu-rdc"]
         if verbose:
@@ -49,5 +57,37 @@ def build(force=False, verbose=False):
     return LIB
 
 
+# Test infrastructure (tests/test_lb_differential_gpu.py): the kernels that ship at one workgroup per CU (512 registers) built
+# once more for two (256 registers) -- the same source, the same floating-point operations, another register allocation.  The
+# product never loads these libraries.
+VARIANTS = {"q2_lb2": ("ns_q2", ["-DQ2_RES_LB=2", "-DQ2_RCP_LB=2", "-DQ2_EXT_LB=2"]),
+            "hox_lb2": ("ns_hox", ["-DHOX_RES_LB=2", "-DHOX_EXT_LB=2"])}
+
+
+def build_variants(force=False, verbose=False):
+    build(verbose=verbose)
+    vdir = os.path.join(LIBDIR, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(_HERE, "..", "include", "adaflo_hip.h")]
+    jobs, libs = [], {}
+    for tag, (unit, flags) in VARIANTS.items():
+        lib, obj, src = os.path.join(vdir, "lib_%s.so" % tag), os.path.join(vdir, "%s_%s.o" % (unit, tag)), os.path.join(CSRC, unit + ".hip")
+        libs[tag] = lib
+        if force or _stale(lib, [src, LIB] + hdrs):
+            cmd = ["hipcc", "-c", src, "-o", obj] + FLAGS + flags
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((tag, unit, obj, lib, subprocess.Popen(cmd)))
+    for tag, unit, obj, lib, p in jobs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed for variant " + tag)
+        objs = [os.path.join(LIBDIR, f) for f in sorted(os.listdir(LIBDIR)) if f.endswith(".o") and f != unit + ".o"]
+        subprocess.check_call(["hipcc", "-shared", "-o", lib] + objs + [obj, "--offload-arch=" + ARCH, "-fno-gpu-rdc"])
+        os.remove(obj)
+    return libs
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--variants" in sys.argv:
+        print(build_variants(force="--force" in sys.argv, verbose=True))

@@ -465,6 +465,15 @@ int adaflo_copy_d2h(adaflo_ctx *ctx, void *dst, const void *src, size_t bytes)
   return 0;
 }
 
+int adaflo_has_kernel_variant(int variant)
+{
+#if defined(ADAFLO_BUILD_VARIANTS)
+  return variant >= 0 && variant <= 4;
+#else
+  return variant == 0 || variant == 1 || variant == 4;
+#endif
+}
+
 int adaflo_set_kernel_variant(adaflo_ctx *ctx, int variant)
 {
   CHECK_CTX(ctx);
@@ -472,6 +481,12 @@ int adaflo_set_kernel_variant(adaflo_ctx *ctx, int variant)
     return fail(ctx, ADAFLO_EINVAL, "unknown kernel variant");
   if (ctx->flat && variant != 0)
     return fail(ctx, ADAFLO_EUNSUPPORTED, "dim = 2 runs on the generic kernels (variant 0) only");
+  // (2 and 3 select a kernel of their own only for the degrees these kernels exist for; elsewhere they mean what 1 means --
+  // for Q2/Q1, 2 also selects the divergence mode of the sweep kernel in divergence_vmult_add)
+  if (!adaflo_has_kernel_variant(variant) && ((variant == 2 && ctx->k >= 3 && ctx->k <= 5) || (variant == 3 && ctx->k == 4)))
+    return fail(ctx, ADAFLO_EUNSUPPORTED,
+                "kernel variants 2 and 3 (the superseded Q3..Q5 kernels) are not in this build of the library: "
+                "ADAFLO_BUILD_VARIANTS=1 python adaflo_amd/build.py --force");
   // 3 = 1 with the plane-per-lane kernel for Q4/Q3 constant-coefficient vmult / velocity_vmult (ns_hop.hip)
   // 4 = 1 WITHOUT the recompute-state mode of the Q2/Q1 Newton vmult (ns_q2.hip, RCP): the streaming kernel of rounds 1-4
   ctx->hop          = variant == 3;

@@ -28,9 +28,14 @@
 // FP64 MFMA for the 1D contractions: measured (scripts/dev/mfma_f64_probe.hip) and
 // rejected -- v_mfma_f64_16x16x4_f64 issues at the f64 vector rate and a 5x5 matrix fills at most
 // 29 % of the tile even with three cells packed on the block diagonal.
+//
+// Superseded by the x-marching kernel (ns_hox.hip, default since round 4) and kept for comparison: compiled into the library only
+// with -DADAFLO_BUILD_VARIANTS (ADAFLO_BUILD_VARIANTS=1 python adaflo_amd/build.py); the product build has the stubs at the end of this
+// file and refuses kernel variant 2.
 #include "basis.hpp"
 #include "kernels.hpp"
 
+#if defined(ADAFLO_BUILD_VARIANTS)
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -1233,7 +1238,7 @@ namespace adaflo_hip
       A.zslab_u = ctx->q2_zslab_u.p;
       A.slab_p  = ctx->q2_slab_p.p;
       A.zslab_p = ctx->q2_zslab_p.p;
-      if (with_p && !A.integrate_p && (phase <= 0 || phase == 3))
+      if (with_p && !A.integrate_p && (phase <= 0 || phase == 5)) // (5: the set-up phase of the two-stream schedule runs on the engine stream BEFORE the auxiliary stream may pack or unpack-add dst_p; in phase 3 it raced with them -- ADVICE r05)
         if (int e = launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, A.npx, A.npy, A.npz, A.con_p, -1., true))
           return e;
       long nwg = (long)n_wg;
@@ -1358,3 +1363,13 @@ namespace adaflo_hip
       }
   }
 } // namespace adaflo_hip
+#else
+namespace adaflo_hip
+{
+  bool ho_supported(const adaflo_ctx *) { return false; }
+  int  launch_ns_vmult_ho(adaflo_ctx *, const int, double *, double *, const double *, const double *, const int, const uint32_t)
+  {
+    return ADAFLO_EUNSUPPORTED;
+  }
+} // namespace adaflo_hip
+#endif

@@ -2,9 +2,14 @@
 // description of the decomposition are in ns_hop_kernel.hpp.
 // NavierStokesMatrix::vmult / velocity_vmult with constant coefficients, velocity degree 4
 // (source/navier_stokes_matrix.cc:221-262, 337-382, 601-916).
+//
+// Measured slower than the x-marching kernel and kept for comparison: compiled into the library only with
+// -DADAFLO_BUILD_VARIANTS (ADAFLO_BUILD_VARIANTS=1 python adaflo_amd/build.py); the product build has the stubs at the end of this file and
+// refuses kernel variant 3.
 #include "basis.hpp"
 #include "kernels.hpp"
 
+#if defined(ADAFLO_BUILD_VARIANTS)
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -163,7 +168,7 @@ namespace adaflo_hip
     A.xslab_u = ctx->hox_xslab_u.p;
     A.slab_p  = ctx->hox_slab_p.p;
     A.xslab_p = ctx->hox_xslab_p.p;
-    if (with_p && !A.integrate_p && (phase <= 0 || phase == 3))
+    if (with_p && !A.integrate_p && (phase <= 0 || phase == 5)) // (5: the set-up phase of the two-stream schedule runs on the engine stream BEFORE the auxiliary stream may pack or unpack-add dst_p; in phase 3 it raced with them -- ADVICE r05)
       if (int e = launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, A.npx, A.npy, A.npz, A.con_p, -1., true))
         return e;
     long nt = (long)n_t;
@@ -279,3 +284,13 @@ namespace adaflo_hip
     return hipGetLastError() == hipSuccess ? 0 : ADAFLO_EHIP;
   }
 } // namespace adaflo_hip
+#else
+namespace adaflo_hip
+{
+  bool hop_supported(const adaflo_ctx *, const int) { return false; }
+  int  launch_ns_vmult_hop(adaflo_ctx *, const int, double *, double *, const double *, const double *, const int, const uint32_t)
+  {
+    return ADAFLO_EUNSUPPORTED;
+  }
+} // namespace adaflo_hip
+#endif

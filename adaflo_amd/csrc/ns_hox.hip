@@ -237,7 +237,7 @@ namespace adaflo_hip
       A.xslab_u = ctx->hox_xslab_u.p;
       A.slab_p  = ctx->hox_slab_p.p;
       A.xslab_p = ctx->hox_xslab_p.p;
-      if (with_p && !A.integrate_p && (phase <= 0 || phase == 3))
+      if (with_p && !A.integrate_p && (phase <= 0 || phase == 5)) // (5: the set-up phase of the two-stream schedule runs on the engine stream BEFORE the auxiliary stream may pack or unpack-add dst_p; in phase 3 it raced with them -- ADVICE r05)
         if (int e = launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, A.npx, A.npy, A.npz, A.con_p, -1., true))
           return e;
       long nwg = (long)n_wg;
@@ -320,6 +320,9 @@ namespace adaflo_hip
     if (err == hipSuccess && nwg > 0)                                                                     \
       hipLaunchKernelGGL((ns_hox_kernel<K, LM, true, true>), grid, block, lds_bytes, ctx->stream, A);     \
   }
+#ifndef HOX_EXT_KMAX
+#define HOX_EXT_KMAX 5 // (k = 5 since round 6, see HOX_EXT_LB in ns_hox_kernel.hpp; -DHOX_EXT_KMAX=4 sends it to the generic kernel)
+#endif
 #define HOX_LAUNCH_RES_EXT(LM)                                                                                            \
   {                                                                                                                       \
     static bool attr_set = false;                                                                                         \
@@ -334,7 +337,7 @@ namespace adaflo_hip
   }
       if (residual && ext_comb)
         {
-          if constexpr (K <= 4)
+          if constexpr (K <= HOX_EXT_KMAX)
             {
               if (lin_mode == 1)
                 HOX_LAUNCH_RES_EXT(1)
@@ -459,9 +462,8 @@ namespace adaflo_hip
       return false;
     if (ctx->ns.physical_type == ADAFLO_STOKES || lin == ADAFLO_COUPLED_IMPLICIT_NEWTON || lin == ADAFLO_COUPLED_IMPLICIT_PICARD)
       return true;
-    // (k = 5: the kernel needs one workgroup per CU, whose build computes wrong pressure rows -- ns_hox_kernel.hpp, HOX_EXT_LB --, and is
-    // slower than the generic kernel at two: 4.96 against 3.96 ms at 48^3)
-    return HOX_FUSED && HOX_RES_FUSED && ctx->k <= 4 && ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE;
+    // (k = 5 needs one workgroup per CU: 3.13 ms at 48^3 against 4.96 ms at two and 4.01 ms for the generic kernel)
+    return HOX_FUSED && HOX_RES_FUSED && ctx->k <= HOX_EXT_KMAX && ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE;
   }
 
   int launch_ns_residual_hox(adaflo_ctx *ctx, double *sum_u, double *sum_p, const double *src_u, const double *src_p,

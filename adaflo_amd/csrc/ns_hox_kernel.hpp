@@ -477,13 +477,17 @@ namespace adaflo_hip
 #ifndef HOX_RCP_LB
 #define HOX_RCP_LB HOX_LB
 #endif
-    // (k = 5 at one workgroup per CU -- 256 VGPRs + 230 AGPRs + 555 scalar-register spills into VGPR lanes -- computes wrong
-    // pressure rows: the per-lane flag word of lane 0 changes in workgroups of partial tiles, the lane's pressure rows are
-    // then stored as "constrained"; found by the parity test on a 3 x 2 x 3 mesh, reproducible on 1 x 1 x 1, correct at two
-    // workgroups per CU with scratch: tests/probe_residual.py.  A wrong code object or a hazard only this allocation
-    // exposes: not resolved)
+    // k = 5 at one workgroup per CU (256 VGPRs + 148 AGPRs + 550 scalar-register spills into VGPR lanes).  History: the build
+    // of commit b79a1e7 (round 5) stored wrong, run-to-run DIFFERENT pressure rows (and once faulted on an address) with this
+    // setting, and the instance was sent to the generic kernel.  Round 6: reproduced on that commit (profiles/r06_k5_old.log);
+    // on the tree since b0746b5 (node lines through one per-lane address + immediate offsets instead of 18 hoisted and
+    // spilled 32-bit index sums) the same setting is exact on every parity case, repeatedly, and bitwise equal to the
+    // 256-register build of the same source (tests/test_lb_differential_gpu.py holds that for every kernel built for one
+    // workgroup per CU).  A result that changes from run to run is a read of something not yet written, not a wrong
+    // instruction stream; which read it was in the old address code was not established ("register-allocation
+    // dependent results").  3.13 against 4.01 ms for the generic kernel at 48^3.
 #ifndef HOX_EXT_LB
-#define HOX_EXT_LB (K == 5 ? 2 : 1)
+#define HOX_EXT_LB 1
 #endif
     __global__ __launch_bounds__(NTH, (EXT ? HOX_EXT_LB : (RES ? HOX_RES_LB : (RCP ? HOX_RCP_LB : (hox_deep<K, LIN_MODE, RES, VARCO, RCP>() ? 1 : HOX_LB)))))
       void ns_hox_kernel(const HXArgs A)

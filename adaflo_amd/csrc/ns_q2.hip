@@ -89,15 +89,27 @@ namespace adaflo_hip
 #ifndef Q2_SWIZZLE
 #define Q2_SWIZZLE 0
 #endif
-    // GUARD (kernels built for one workgroup per CU, round 5): the two halves go through an (empty) asm statement, i.e. through
-    // copies, before the DPP moves read them.  Without it the 512-register build of the extrapolating residual computed
-    // wrong sums -- deterministically, on every mesh; bisected with bitwise comparisons against the 256-register build of the
-    // same source (scripts/dev/lb_diff_ext.sh): gathers, plane copies and every part of the formula alone were equal, the
-    // full formula was not, and this pin (with or without wait states) makes it equal.  The DPP moves read halves of f64
-    // results three instructions after v_fmac_f64 / v_mul_f64 wrote them -- in both builds; with ONE wave per SIMD those
-    // issue back to back.  Whether it is a wait-state gap of the compiler for double-precision producers on gfx950 or
-    // something else was not established; kernels at two waves per SIMD have never shown it (444 parity tests, five rounds)
-    // and keep the direct form (two moves less per broadcast).
+    // GUARD (kernels built for one workgroup per CU): the two halves go through an (empty) asm statement before the DPP moves
+    // read them.  Without it hipcc 7.2 (clang 22) MISCOMPILES the 512-register build of the extrapolating residual --
+    // deterministically wrong sums on every mesh.  What round 6 established (profiles/r06_q2_ext_*.log, DESIGN.md
+    // "register-allocation dependent results"):
+    //  * not a pipeline hazard: on the MI355X a DPP move needs ONE wait state behind an f64 / 32-bit VALU result, behind
+    //    v_accvgpr_read and none behind an SALU write of EXEC (scripts/dev/hazard_probe.hip; the compiler pads two), and the
+    //    wrong code object stays wrong, same values, with `s_nop 7` behind EVERY VALU instruction of the kernel (listing
+    //    edited and re-assembled, scripts/dev/isa_patch_build.py);
+    //  * not the hand-written asm: wait states behind every asm statement that restores EXEC change nothing;
+    //  * the instruction stream is what is wrong: the same source is bitwise right as soon as the register allocation
+    //    differs (-mllvm -enable-misched=0, -vgpr-regalloc=basic, -amdgpu-sdwa-peephole=0, this guard, or 256 registers),
+    //    while -amdgpu-dpp-combine=0, -enable-post-misched=0, -amdgpu-waitcnt-forcezero, -amdgpu-spill-vgpr-to-agpr=0,
+    //    -amdgpu-enable-rewrite-partial-reg-uses=0 leave it wrong; -verify-machineinstrs is silent;
+    //  * the symptom: the unscaled, lane-local gradient entries (d_e u_d, twice that for e = d) of the layer's last
+    //    quadrature point are ADDED to three finished node values of the layer (the first layer adds whatever the
+    //    registers held before): a stale register read in the combine phase, guarding any subset of the broadcast sites
+    //    moves the error elsewhere (scripts/dev/lb_diff_ext.sh, -DQ2_QG_SITES).
+    // The guard forces copies and pins the order of the moves against the other asm statements, which is enough to keep the
+    // allocator away from the bad assignment; tests/test_lb_differential_gpu.py compares every kernel built for 512 registers
+    // with the 256-register build of the same source bit by bit, so a compiler update that brings the problem back fails a
+    // test instead of a simulation.  Kernels at two waves per SIMD keep the direct form (two moves less per broadcast).
     template <int SEL, int WHICH = 0, bool GUARD = false>
     __device__ __forceinline__ double quad_bcast(const double x)
     {
@@ -346,6 +358,14 @@ namespace adaflo_hip
 #endif
 #endif
 
+    // development (round 6, scripts/dev/lb_diff_ext.sh): wait states behind every asm statement that restores EXEC
+#if defined(Q2_EXEC_PAD)
+#define Q2_PAD_STR2(x) #x
+#define Q2_PAD_STR(x) Q2_PAD_STR2(x)
+#define Q2_EXEC_PAD_ASM "\n\ts_nop " Q2_PAD_STR(Q2_EXEC_PAD)
+#else
+#define Q2_EXEC_PAD_ASM ""
+#endif
     __device__ __forceinline__ void lds_barrier()
     {
       // LDS-only workgroup barrier: unlike __syncthreads() it does not drain vmcnt, so the
@@ -390,7 +410,7 @@ namespace adaflo_hip
 #else
                    "global_load_lds_dwordx4 %1, %2 nt\n\t"
 #endif
-                   "s_mov_b64 exec, -1" ::"s"(lds_byte), "v"(voff), "s"(sbase), "s"(mask)
+                   "s_mov_b64 exec, -1" Q2_EXEC_PAD_ASM ::"s"(lds_byte), "v"(voff), "s"(sbase), "s"(mask)
                    : "memory");
     }
     //   lane l writes lds_byte + 4*l
@@ -401,7 +421,7 @@ namespace adaflo_hip
                    "s_mov_b32 m0, %0\n\t"
                    "s_mov_b64 exec, %3\n\t"
                    "global_load_lds_dword %1, %2\n\t"
-                   "s_mov_b64 exec, -1" ::"s"(lds_byte), "v"(voff), "s"(sbase), "s"(mask)
+                   "s_mov_b64 exec, -1" Q2_EXEC_PAD_ASM ::"s"(lds_byte), "v"(voff), "s"(sbase), "s"(mask)
                    : "memory");
     }
 
@@ -435,7 +455,7 @@ namespace adaflo_hip
       asm volatile("s_mov_b64 exec, %3\n\t"
                    "global_store_dwordx4 %0, %1, %2 nt\n\t"
                    "s_mov_b64 exec, -1\n\t"
-                   "s_nop 0" ::"v"(voff), "v"(v), "s"(sbase), "s"(mask)
+                   "s_nop 0" Q2_EXEC_PAD_ASM ::"v"(voff), "v"(v), "s"(sbase), "s"(mask)
                    : "memory");
     }
 
@@ -462,7 +482,7 @@ namespace adaflo_hip
       unsigned long long saved;
       asm volatile("s_and_saveexec_b64 %0, %4\n\t"
                    "global_store_dwordx2 %1, %2, %3 " Q2_DST_POLICY "\n\t"
-                   "s_mov_b64 exec, %0"
+                   "s_mov_b64 exec, %0" Q2_EXEC_PAD_ASM
                    : "=&s"(saved)
                    : "v"(voff), "v"(a), "s"(sbase), "s"(mask)
                    : "memory", "scc");
@@ -481,7 +501,7 @@ namespace adaflo_hip
       asm volatile("s_and_saveexec_b64 %0, %4\n\t"
                    "global_store_dwordx4 %1, %2, %3 " Q2_DST_POLICY "\n\t"
                    "s_mov_b64 exec, %0\n\t"
-                   "s_nop 0" // (two wait states behind a store of more than 64 bits, see store_b128_masked)
+                   "s_nop 0" Q2_EXEC_PAD_ASM // (two wait states behind a store of more than 64 bits, see store_b128_masked)
                    : "=&s"(saved)
                    : "v"(voff), "v"(v), "s"(sbase), "s"(mask)
                    : "memory", "scc");
@@ -636,7 +656,21 @@ namespace adaflo_hip
       static_assert(!RCP || (LIN_MODE == 0 && !RES && !DIV), "recompute mode: Newton vmult");
       static_assert(!EXT || (RES && LIN_MODE != 0 && !VARCO && WITH_P), "extrapolating residual: semi-implicit / explicit, constant coefficients");
       constexpr int L_OLDP = L_RING, L_EXTP = L_TOTAL; // plane buffers of the second / third nodal field
+#if defined(Q2_QG_OFF) // (development: the unguarded form in the one-workgroup-per-CU builds, scripts/dev/lb_diff_ext.sh;
+                       // Q2_QG_SITES: bit mask of the call-site groups that keep the guard -- 1 quadrature loop, 2 second / third
+                       // field (recompute and extrapolating modes), 4 phase E, 8 coefficients)
+#ifndef Q2_QG_SITES
+#define Q2_QG_SITES 0
+#endif
+      constexpr bool QG = false;
+      constexpr bool QG1 = Q2_QG_SITES & 1, QG2 = Q2_QG_SITES & 2, QG4 = Q2_QG_SITES & 4, QG8 = Q2_QG_SITES & 8;
+#else
+#define Q2_QG_ALL
+#endif
+#if defined(Q2_QG_ALL)
       constexpr bool QG = (EXT ? Q2_EXT_LB : (RES ? Q2_RES_LB : (RCP ? Q2_RCP_LB : Q2_LB))) == 1; // quad_bcast guard
+      constexpr bool QG1 = QG, QG2 = QG, QG4 = QG, QG8 = QG;
+#endif
       static_assert(!DIV || (LIN_MODE == 2 && WITH_P && !RES && !VARCO), "divergence mode");
       // (RES && VARCO, round 5: the residual of two-phase flow -- the coefficients of the layer's 27 points are read from the
       // generic arrays [cell][27], lane d of a quad its array (rho, mu, damping), and handed round by DPP; the state goes
@@ -1141,11 +1175,11 @@ namespace adaflo_hip
                   r_rho = A.rho[cq_], r_mu = A.mu[cq_], r_damp = A.damp[cq_];
                 }
               if (RES && VARCO)
-                r_rho = quad_bcast<0, 0, QG>(CQ[q]), r_mu = quad_bcast<1, 0, QG>(CQ[q]), r_damp = quad_bcast<2, 0, QG>(CQ[q]);
+                r_rho = quad_bcast<0, 0, QG8>(CQ[q]), r_mu = quad_bcast<1, 0, QG8>(CQ[q]), r_damp = quad_bcast<2, 0, QG8>(CQ[q]);
               if (CPIPE)
                 {
                   const double cq_ = q < 9 ? CP0[q % 9] : (q < 18 ? CP1[q % 9] : CP2[q % 9]);
-                  r_rho = quad_bcast<0, 0, QG>(cq_), r_mu = quad_bcast<1, 0, QG>(cq_), r_damp = quad_bcast<2, 0, QG>(cq_);
+                  r_rho = quad_bcast<0, 0, QG8>(cq_), r_mu = quad_bcast<1, 0, QG8>(cq_), r_damp = quad_bcast<2, 0, QG8>(cq_);
                 }
               if (RCP)
                 {
@@ -1161,17 +1195,17 @@ namespace adaflo_hip
                   const double vb = V2[q];
                   st0   = make_double2(vb, b0);
                   st1   = make_double2(b1, b2);
-                  r_ub0 = quad_bcast<0, 2, QG>(vb), r_ub1 = quad_bcast<1, 2, QG>(vb), r_ub2 = quad_bcast<2, 2, QG>(vb);
-                  r_trl = quad_bcast<0, 3, QG>(b0) + quad_bcast<1, 3, QG>(b1) + quad_bcast<2, 3, QG>(b2);
+                  r_ub0 = quad_bcast<0, 2, QG2>(vb), r_ub1 = quad_bcast<1, 2, QG2>(vb), r_ub2 = quad_bcast<2, 2, QG2>(vb);
+                  r_trl = quad_bcast<0, 3, QG2>(b0) + quad_bcast<1, 3, QG2>(b1) + quad_bcast<2, 3, QG2>(b2);
                 }
 #if !defined(Q2_LDS_EXCHANGE)
               // gradient rows of the three velocity components, visible to all four lanes (DPP)
-              const double G00 = quad_bcast<0, 0, QG>(g0), G01 = quad_bcast<0, 0, QG>(g1), G02 = quad_bcast<0, 0, QG>(g2);
-              const double G10 = quad_bcast<1, 0, QG>(g0), G11 = quad_bcast<1, 0, QG>(g1), G12 = quad_bcast<1, 0, QG>(g2);
-              const double G20 = quad_bcast<2, 0, QG>(g0), G21 = quad_bcast<2, 0, QG>(g1), G22 = quad_bcast<2, 0, QG>(g2);
+              const double G00 = quad_bcast<0, 0, QG1>(g0), G01 = quad_bcast<0, 0, QG1>(g1), G02 = quad_bcast<0, 0, QG1>(g2);
+              const double G10 = quad_bcast<1, 0, QG1>(g0), G11 = quad_bcast<1, 0, QG1>(g1), G12 = quad_bcast<1, 0, QG1>(g2);
+              const double G20 = quad_bcast<2, 0, QG1>(g0), G21 = quad_bcast<2, 0, QG1>(g1), G22 = quad_bcast<2, 0, QG1>(g2);
               const double c0 = sel3(d, G00, G01, G02), c1 = sel3(d, G10, G11, G12), c2 = sel3(d, G20, G21, G22);
-              const double u0 = quad_bcast<0, 1, QG>(Vq), u1 = quad_bcast<1, 1, QG>(Vq), u2 = quad_bcast<2, 1, QG>(Vq);
-              const double pres = quad_bcast<3, 1, QG>(Vq);
+              const double u0 = quad_bcast<0, 1, QG1>(Vq), u1 = quad_bcast<1, 1, QG1>(Vq), u2 = quad_bcast<2, 1, QG1>(Vq);
+              const double pres = quad_bcast<3, 1, QG1>(Vq);
 #else
               // (measured alternative, 17 % slower: exposed LDS latency per point + one more barrier)
               // Exchange inside the quad through a wave-private LDS record [lane d][g0 g1 g2 v]:
@@ -1209,8 +1243,8 @@ namespace adaflo_hip
                   const double b2 = dline(qz, V3[qx + 3 * qy], V3[qx + 3 * qy + 9], V3[qx + 3 * qy + 18],
                                           A.ah[e2][0], A.ah[e2][1], A.ah[e2][2], A.ah[e2][3]);
                   const double vb = V3[q];
-                  const double ov0 = quad_bcast<0, 0, QG>(vb), ov1 = quad_bcast<1, 0, QG>(vb), ov2 = quad_bcast<2, 0, QG>(vb);
-                  const double ediv = quad_bcast<0, 0, QG>(b0) + quad_bcast<1, 0, QG>(b1) + quad_bcast<2, 0, QG>(b2);
+                  const double ov0 = quad_bcast<0, 0, QG2>(vb), ov1 = quad_bcast<1, 0, QG2>(vb), ov2 = quad_bcast<2, 0, QG2>(vb);
+                  const double ediv = quad_bcast<0, 0, QG2>(b0) + quad_bcast<1, 0, QG2>(b1) + quad_bcast<2, 0, QG2>(b2);
                   if (LIN_MODE == 2) // explicit: the extrapolated field convects itself
                     conv += cB_q * (A.beta * ediv * vb + ov0 * b0 + ov1 * b1 + ov2 * b2);
                   else // semi-implicit: it convects the solution; (u_ext, div u_ext) is the state of the vmults
@@ -1476,13 +1510,13 @@ namespace adaflo_hip
                       // the quad's 2 nodes x 3 components of a row are 48 contiguous bytes; regroup them
                       // inside the quad so that every lane stores 16 B (scalar row base + lane offset)
                       {
-                        const double b00 = quad_bcast<0, 0, QG>(a0), b01 = quad_bcast<1, 0, QG>(a0), b02 = quad_bcast<2, 0, QG>(a0);
-                        const double b10 = quad_bcast<0, 0, QG>(a1), b11 = quad_bcast<1, 0, QG>(a1), b12 = quad_bcast<2, 0, QG>(a1);
+                        const double b00 = quad_bcast<0, 0, QG4>(a0), b01 = quad_bcast<1, 0, QG4>(a0), b02 = quad_bcast<2, 0, QG4>(a0);
+                        const double b10 = quad_bcast<0, 0, QG4>(a1), b11 = quad_bcast<1, 0, QG4>(a1), b12 = quad_bcast<2, 0, QG4>(a1);
                         store_b128_dst(dp, voff, sel3(d, b00, b02, b11), sel3(d, b01, b10, b12), vmask_u);
                       }
                       {
-                        const double b00 = quad_bcast<0, 0, QG>(a3), b01 = quad_bcast<1, 0, QG>(a3), b02 = quad_bcast<2, 0, QG>(a3);
-                        const double b10 = quad_bcast<0, 0, QG>(a4), b11 = quad_bcast<1, 0, QG>(a4), b12 = quad_bcast<2, 0, QG>(a4);
+                        const double b00 = quad_bcast<0, 0, QG4>(a3), b01 = quad_bcast<1, 0, QG4>(a3), b02 = quad_bcast<2, 0, QG4>(a3);
+                        const double b10 = quad_bcast<0, 0, QG4>(a4), b11 = quad_bcast<1, 0, QG4>(a4), b12 = quad_bcast<2, 0, QG4>(a4);
                         store_b128_dst(dp + A.nnx * 3, voff, sel3(d, b00, b02, b11), sel3(d, b01, b10, b12), vmask_u);
                       }
                     }
@@ -2163,7 +2197,7 @@ namespace adaflo_hip
       A.slab_p  = ctx->q2_slab_p.p;
       A.zslab_p = ctx->q2_zslab_p.p;
     }
-    if (with_p && !A.integrate_p && (phase <= 0 || phase == 3))
+    if (with_p && !A.integrate_p && (phase <= 0 || phase == 5)) // (5: the set-up phase of the two-stream schedule runs on the engine stream BEFORE the auxiliary stream may pack or unpack-add dst_p; in phase 3 it raced with them -- ADVICE r05)
       if (int e = launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, A.npx, A.npy, A.npz,
                                      A.con_p, -1., true))
         return e;

@@ -181,6 +181,12 @@ class NavierStokesMatrix:
     def synchronize(self):
         _lib.check(self._ctx, self._lib.adaflo_synchronize(self._require()))
 
+    @staticmethod
+    def has_kernel_variant(variant):
+        """are the kernels of `variant` in this build of the library (2, 3: the superseded Q3..Q5 kernels, built only with
+        ADAFLO_BUILD_VARIANTS=1)"""
+        return bool(_lib.load().adaflo_has_kernel_variant(int(variant)))
+
     def set_kernel_variant(self, variant):
         _lib.check(self._ctx, self._lib.adaflo_set_kernel_variant(self._require(), variant))
         self._variant = variant

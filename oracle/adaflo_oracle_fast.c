@@ -12,8 +12,12 @@
  * tuned AVX-512 kernel (no cross-cell SIMD batching, no even-odd trick);
  * bench.py labels it accordingly.
  *
- * 3D only, vmult only (Newton / Picard-type / Stokes branches), constant or
- * variable coefficients, canonical state layout [cell][q][12].
+ * 3D only; vmult (Newton / Picard-type / Stokes branches), constant or
+ * variable coefficients, canonical state layout [cell][q][12]; and (round 6)
+ * NavierStokesMatrix::residual of the two fully implicit schemes
+ * (source/navier_stokes_matrix.cc:266-293, :663-686, :725-732, :783-799), which WRITES that
+ * state -- so that the full-size tests can hold the path bench.py times
+ * (residual -> vmult on the state the residual left) against the oracle.
  */
 #include <math.h>
 #include <stdint.h>
@@ -88,14 +92,21 @@ int orc_fast_n_threads(void)
 #endif
 }
 
-/* y = J x, full vmult semantics incl. zeroing, constrained rows, mean projection */
-int orc_fast_ns_vmult(const orc_mesh *m, int k, const orc_ns_params *P, const double *src_u,
-                      const double *src_p, double *dst_u, double *dst_p, const uint8_t *con_u,
-                      const uint8_t *con_p, const double *lin, const double *rho_q,
-                      const double *mu_q, const double *damp_q, const double *weights,
-                      const double *modes)
+/* residual == 0: y = J x, full vmult semantics incl. zeroing, constrained rows, mean projection (lin is read);
+ * residual == 1: the cell loop of NavierStokesMatrix::residual (:266-293): plain reads of the solution (:663-671),
+ * values of the old solutions (:673-686, :727-732), the nonlinear term of the solution itself and the state
+ * (u, grad u) or (u, div u) WRITTEN to lin (:783-799), no contribution to constrained rows; the caller negates and
+ * adds the user vector */
+static int fast_ns_apply(const orc_mesh *m, int k, const orc_ns_params *P, const double *src_u,
+                         const double *src_p, double *dst_u, double *dst_p, const uint8_t *con_u,
+                         const uint8_t *con_p, double *lin, const double *rho_q,
+                         const double *mu_q, const double *damp_q, const double *weights,
+                         const double *modes, int residual, const double *old_u, const double *oldold_u)
 {
   if (m->dim != 3 || k + 1 > MAXN) return -1;
+  if (residual && (P->linearization > 1 || !lin)) return -2; /* (the extrapolating schemes: naive oracle only) */
+  const int with_old = residual && P->physical_type == 0;
+  const double w1 = P->weight_old, w2 = P->weight_old_old;
   const int p = k - 1, n = k + 1, ndu = k + 1, ndp = k;
   const int nq3 = n * n * n, ndu3 = ndu * ndu * ndu;
   double xq[MAXN], wq[MAXN], Su[MAXN * MAXN], Du[MAXN * MAXN], Sp[MAXN * MAXN], Dp[MAXN * MAXN];
@@ -141,6 +152,7 @@ int orc_fast_ns_vmult(const orc_mesh *m, int k, const orc_ns_params *P, const do
         double ul[3 * MAXN * MAXN * MAXN], pl[MAXN * MAXN * MAXN], t1[MAXN * MAXN * MAXN],
           t2[MAXN * MAXN * MAXN];
         double vu[3][MAXN * MAXN * MAXN], gu[3][3][MAXN * MAXN * MAXN], vp[MAXN * MAXN * MAXN];
+        double vo[3][MAXN * MAXN * MAXN]; /* residual: w1 u_old + w2 u_old_old at the q-points (interpolation is linear) */
 #pragma omp for schedule(static)
         for (long blk = 0; blk < nblk; ++blk)
           {
@@ -155,15 +167,35 @@ int orc_fast_ns_vmult(const orc_mesh *m, int k, const orc_ns_params *P, const do
                     const long node = (cx * k + i) + nnu[0] * ((cy * k + j) + nnu[1] * (long)(cz * k + kk));
                     const int l = i + ndu * (j + ndu * kk);
                     for (int d = 0; d < 3; ++d)
-                      ul[d * ndu3 + l] = (con_u && con_u[node * 3 + d]) ? 0. : src_u[node * 3 + d];
+                      ul[d * ndu3 + l] = (!residual && con_u && con_u[node * 3 + d]) ? 0. : src_u[node * 3 + d];
                   }
             for (int kk = 0; kk < ndp; ++kk)
               for (int j = 0; j < ndp; ++j)
                 for (int i = 0; i < ndp; ++i)
                   {
                     const long node = (cx * p + i) + nnp[0] * ((cy * p + j) + nnp[1] * (long)(cz * p + kk));
-                    pl[i + ndp * (j + ndp * kk)] = (con_p && con_p[node]) ? 0. : src_p[node];
+                    pl[i + ndp * (j + ndp * kk)] = (!residual && con_p && con_p[node]) ? 0. : src_p[node];
                   }
+            if (with_old) /* :673-686, :727-732 */
+              {
+                double ol[3 * MAXN * MAXN * MAXN];
+                for (int kk = 0; kk < ndu; ++kk)
+                  for (int j = 0; j < ndu; ++j)
+                    for (int i = 0; i < ndu; ++i)
+                      {
+                        const long node = (cx * k + i) + nnu[0] * ((cy * k + j) + nnu[1] * (long)(cz * k + kk));
+                        const int l = i + ndu * (j + ndu * kk);
+                        for (int d = 0; d < 3; ++d)
+                          ol[d * ndu3 + l] = w1 * old_u[node * 3 + d] + w2 * oldold_u[node * 3 + d];
+                      }
+                for (int d = 0; d < 3; ++d)
+                  {
+                    int s0[3] = {ndu, ndu, ndu}, s1[3] = {n, ndu, ndu}, s2[3] = {n, n, ndu};
+                    apply_dir(Su, n, ndu, 0, 0, s0, ol + d * ndu3, t1, 0);
+                    apply_dir(Su, n, ndu, 0, 1, s1, t1, t2, 0);
+                    apply_dir(Su, n, ndu, 0, 2, s2, t2, vo[d], 0);
+                  }
+              }
             /* evaluate: interpolate to q-points, then collocation derivatives */
             for (int d = 0; d < 3; ++d)
               {
@@ -191,12 +223,28 @@ int orc_fast_ns_vmult(const orc_mesh *m, int k, const orc_ns_params *P, const do
                     for (int e = 0; e < 3; ++e) g[d][e] = gu[d][e][q] * ih[e];
                   }
                 const double div = g[0][0] + g[1][1] + g[2][2];
-                const double *L = lin ? lin + ((size_t)c * nq3 + q) * 12 : NULL;
+                double *L = lin ? lin + ((size_t)c * nq3 + q) * 12 : NULL;
                 if (!stokes)
                   {
                     const double rho = rho_q ? rho_q[c * nq3 + q] : P->density;
                     for (int d = 0; d < 3; ++d) conv[d] = val[d] * w0;
-                    if (P->linearization == 0)
+                    if (residual) /* :727-732, :783-799 */
+                      {
+                        for (int d = 0; d < 3; ++d)
+                          {
+                            if (with_old) conv[d] += vo[d][q];
+                            double res = beta * div * val[d];
+                            for (int e = 0; e < 3; ++e) res += val[e] * g[d][e];
+                            conv[d] += tau1 * res;
+                            L[d] = val[d];
+                          }
+                        if (P->linearization == 0)
+                          for (int d = 0; d < 3; ++d)
+                            for (int e = 0; e < 3; ++e) L[3 + 3 * d + e] = g[d][e];
+                        else
+                          L[3] = div;
+                      }
+                    else if (P->linearization == 0)
                       {
                         const double f1 = beta * div, f2 = beta * (L[3] + L[7] + L[11]);
                         for (int d = 0; d < 3; ++d)
@@ -269,6 +317,8 @@ int orc_fast_ns_vmult(const orc_mesh *m, int k, const orc_ns_params *P, const do
           }
       }
     }
+  if (residual)
+    return 0;
   if (con_u)
     {
 #pragma omp parallel for
@@ -278,5 +328,37 @@ int orc_fast_ns_vmult(const orc_mesh *m, int k, const orc_ns_params *P, const do
     for (long i = 0; i < np; ++i) if (con_p[i]) dst_p[i] = -src_p[i];
   if (weights && P->linearization != 4 && P->physical_type != 1)
     orc_ns_pressure_projection(np, dst_p, weights, modes);
+  return 0;
+}
+
+int orc_fast_ns_vmult(const orc_mesh *m, int k, const orc_ns_params *P, const double *src_u,
+                      const double *src_p, double *dst_u, double *dst_p, const uint8_t *con_u,
+                      const uint8_t *con_p, const double *lin, const double *rho_q,
+                      const double *mu_q, const double *damp_q, const double *weights,
+                      const double *modes)
+{
+  return fast_ns_apply(m, k, P, src_u, src_p, dst_u, dst_p, con_u, con_p, (double *)lin, rho_q, mu_q, damp_q,
+                       weights, modes, 0, NULL, NULL);
+}
+
+/* NavierStokesMatrix::residual (source/navier_stokes_matrix.cc:266-293) for the fully implicit schemes
+ * (Newton: lin = (u, grad u); Picard-type: lin = (u, div u)): rhs = user - (cell loop), lin overwritten.
+ * Returns -2 for the schemes that extrapolate the old velocity (the naive oracle has them). */
+int orc_fast_ns_residual(const orc_mesh *m, int k, const orc_ns_params *P, const double *src_u,
+                         const double *src_p, double *rhs_u, double *rhs_p, const double *user_u,
+                         const double *user_p, const uint8_t *con_u, const uint8_t *con_p, double *lin,
+                         const double *rho_q, const double *mu_q, const double *damp_q,
+                         const double *old_u, const double *oldold_u)
+{
+  const int rc = fast_ns_apply(m, k, P, src_u, src_p, rhs_u, rhs_p, con_u, con_p, lin, rho_q, mu_q, damp_q,
+                               NULL, NULL, 1, old_u, oldold_u);
+  if (rc)
+    return rc;
+  const long nu = ((long)k * m->ncell[0] + 1) * ((long)k * m->ncell[1] + 1) * ((long)k * m->ncell[2] + 1) * 3;
+  const long np = ((long)(k - 1) * m->ncell[0] + 1) * ((long)(k - 1) * m->ncell[1] + 1) * ((long)(k - 1) * m->ncell[2] + 1);
+#pragma omp parallel for
+  for (long i = 0; i < nu; ++i) rhs_u[i] = -rhs_u[i] + (user_u ? user_u[i] : 0.);
+#pragma omp parallel for
+  for (long i = 0; i < np; ++i) rhs_p[i] = -rhs_p[i] + (user_p ? user_p[i] : 0.);
   return 0;
 }

@@ -395,6 +395,18 @@ def fast_ns_vmult(mesh, k, prm, src_u, src_p, con_u=None, con_p=None, lin=None, 
     return dst_u, dst_p
 
 
+def fast_ns_residual(mesh, k, prm, src_u, src_p, old_u, oldold_u, con_u=None, con_p=None, lin=None, rho=None, mu=None,
+                     damp=None, user_u=None, user_p=None):
+    """OpenMP restatement of NavierStokesMatrix::residual for the fully implicit schemes (adaflo_oracle_fast.c): returns
+    (rhs_u, rhs_p), `lin` is overwritten with the state the vmults of the Newton step read"""
+    rhs_u, rhs_p = np.empty_like(src_u), np.empty_like(src_p)
+    rc = lib().orc_fast_ns_residual(C.byref(mesh), k, C.byref(prm), _p(src_u), _p(src_p), _p(rhs_u), _p(rhs_p),
+                                    _p(user_u), _p(user_p), _u8(con_u), _u8(con_p), _p(lin), _p(rho), _p(mu), _p(damp),
+                                    _p(old_u), _p(oldold_u))
+    assert rc == 0, rc
+    return rhs_u, rhs_p
+
+
 class BatchedNSVmult:
     """cell-batched restatement (adaflo_oracle_batched.c): W cells per SIMD register, state in the batched layout,
     compile-time loop bounds, optional even-odd 1D kernels -- the data flow of deal.II's FEEvaluation path"""

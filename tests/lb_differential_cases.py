@@ -1,10 +1,12 @@
-"""development: outputs of the kernels that ship at one workgroup per CU (512 registers: residual modes of the Q2/Q1 and
-x-marching kernels, recompute mode on non-cubic cells) for a set of meshes, written to <out>.npz -- run once with the
-product library and once with a library built for 256 registers (-DQ2_RES_LB=2 -DQ2_RCP_LB=2 / -DHOX_RES_LB=2
--DHOX_EXT_LB=2) and compare bitwise (scripts/dev/lb_differential.sh): the same source, the same floating-point operations.
-usage: lb_differential.py out.npz"""
+"""TEST INFRASTRUCTURE (run by tests/test_lb_differential_gpu.py, not collected by pytest): outputs of the kernels that ship
+at one workgroup per CU (512 registers: residual modes of the Q2/Q1 and x-marching kernels, recompute mode on non-cubic
+cells, the extrapolating residuals) for a set of meshes, written to <out>.npz -- run once with the product library and
+once with a library built for 256 registers (adaflo_amd/build.py: VARIANTS) and compared bitwise: the same source, the same
+floating-point operations, another register allocation.
+usage: ADAFLO_LIB_PATH=... python tests/lb_differential_cases.py out.npz"""
+import os
 import sys
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import adaflo_amd
 
@@ -14,7 +16,9 @@ for k, cells, upper, lin in ((2, (24, 17, 12), (1., 1., 1.), "coupled implicit N
                              (2, (16, 16, 16), (1., 1., 1.), "coupled implicit Picard"), (2, (24, 17, 12), (1., 1., 1.), "coupled velocity semi-implicit"),
                              (4, (9, 7, 10), (1., 1., 1.), "coupled implicit Newton"), (5, (5, 3, 6), (1., 1., 1.), "coupled implicit Newton"),
                              (5, (4, 4, 4), (1., 1., 1.), "coupled implicit Picard"), (4, (8, 8, 8), (1., 1., 1.), "coupled velocity semi-implicit"),
-                             (3, (9, 9, 9), (1., 1., 1.), "coupled velocity explicit")):
+                             (3, (9, 9, 9), (1., 1., 1.), "coupled velocity explicit"), (2, (8, 8, 4), (1., 1., 1.), "coupled velocity explicit"),
+                             (2, (17, 9, 6), (1., 1.5, 1.), "coupled velocity explicit"), (5, (3, 2, 3), (1., 1.5, 1.), "coupled velocity semi-implicit"),
+                             (5, (4, 4, 4), (1., 1., 1.), "coupled velocity explicit"), (4, (5, 3, 4), (1., 1., 1.), "coupled velocity explicit")):
     for two_phase in ((False, True) if k == 2 and "Newton" in lin else (False,)):
         fp = adaflo_amd.FlowParameters(velocity_degree=k, linearization=lin, density_diff=0.5 if two_phase else 0.0)
         ts = adaflo_amd.TimeStepping(fp)

@@ -36,6 +36,65 @@ def test_config2_128cubed_against_openmp_oracle():
     assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL, (rel_l2(got_u, ref_u), rel_l2(got_p, ref_p))
 
 
+def _timed_path_against_openmp_oracle(case, k):
+    """The path bench.py times, held against the oracle entry by entry: NavierStokesMatrix::residual at the nodal interpolant
+    of the Beltrami field (navier_stokes_matrix.cc:266-293; it leaves the linearisation state, :778-799), then vmult on THAT
+    state -- kernel variant 1: Q2/Q1 recomputes the state from the nodal linearisation point (ns_q2_kernel, RCP mode), Q3..Q5
+    stream what the residual kernel stored (ns_hox_kernel) --, then velocity_vmult on the frozen copy.  The oracle side:
+    orc_fast_ns_residual (OpenMP; right-hand side AND state) and orc_fast_ns_vmult on the oracle's own state."""
+    orc.fast_set_threads(orc.usable_cores())
+    rng = np.random.default_rng(20260515)
+    u0, p0 = case.smooth_u(0.0), case.smooth_p(0.0)
+    old_u, oldold_u = case.smooth_u(-0.05), case.smooth_u(-0.1)
+    lin = np.zeros(case.n_cells * case.nq * 12)
+    ref_ru, ref_rp = orc.fast_ns_residual(case.mesh, k, case.prm, u0, p0, old_u, oldold_u, con_u=case.con_u, lin=lin)
+    src_u, src_p = rng.uniform(-1, 1, case.n_u), rng.uniform(-1, 1, case.n_p)
+    w, modes = case.weights_modes()
+    ref_u, ref_p = orc.fast_ns_vmult(case.mesh, k, case.prm, src_u, src_p, case.con_u, None, lin=lin, weights=w, modes=modes)
+    # velocity_vmult (navier_stokes_matrix.cc:337-382) = the velocity block of the same Jacobian: the naive oracle's own
+    # entry on small meshes; at full size vmult of (src_u, 0) restricted to the velocity rows (the same block by linearity)
+    if case.n_cells <= 32 ** 3:
+        ref_v = orc.ns_velocity_vmult(case.mesh, k, case.prm, src_u, case.con_u, lin=lin)
+    else:
+        ref_v, _ = orc.fast_ns_vmult(case.mesh, k, case.prm, src_u, np.zeros(case.n_p), case.con_u, None, lin=lin)
+    del lin
+    op = case.engine()
+    op.set_kernel_variant(1)
+    rhs = op.block_vector()
+    op.residual(rhs, op.block_vector(u0, p0), None, op.block_vector(old_u), op.block_vector(oldold_u))
+    got_ru, got_rp = rhs.numpy()
+    assert rel_l2(got_ru, ref_ru) < TOL and rel_l2(got_rp, ref_rp) < TOL, (rel_l2(got_ru, ref_ru), rel_l2(got_rp, ref_rp))
+    src, dst = op.block_vector(src_u, src_p), op.block_vector()
+    op.vmult(dst, src)
+    got_u, got_p = dst.numpy()
+    assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL, (rel_l2(got_u, ref_u), rel_l2(got_p, ref_p))
+    op.fix_linearization_point()                     # velocity_vmult on the frozen (nodal / streamed) copy
+    vdst = op.initialize_u_vector(np.zeros(case.n_u))
+    op.velocity_vmult(vdst, op.initialize_u_vector(src_u))
+    assert rel_l2(vdst.numpy(), ref_v) < TOL, rel_l2(vdst.numpy(), ref_v)
+    return op
+
+
+def test_timed_path_config2_128cubed_residual_then_recomputed_vmult_against_openmp_oracle():
+    """BASELINE configs[1] exactly as bench.py runs it: 128^3 Q2/Q1, Newton, BDF-2; the vmult kernel is the one whose time
+    is the headline -- ns_q2_kernel<0,true,true,false,false,false,true,false>, state recomputed from the nodal field"""
+    op = _timed_path_against_openmp_oracle(Case((128, 128, 128), k=2, steps=3), 2)
+    ksec, kcount = op.get_kernel_statistics()
+    assert kcount > 0
+
+
+def test_timed_path_config5_q4_cavity_64cubed_residual_then_vmult_against_openmp_oracle():
+    """BASELINE configs[4] as `bench.py --config cavity` runs it: the state the x-marching RESIDUAL kernel stored in the
+    streaming layout is what the x-marching vmult kernel streams"""
+    _timed_path_against_openmp_oracle(Case((64, 64, 64), k=4, lower=(0., 0., 0.), upper=(1., 1., 3.), physical_type=1,
+                                           viscosity=0.01), 4)
+
+
+@pytest.mark.parametrize("k,ncell", [(2, (17, 9, 6)), (3, (5, 4, 3)), (5, (3, 2, 3))])
+def test_timed_path_small_meshes_with_the_naive_oracle_velocity_block(k, ncell):
+    _timed_path_against_openmp_oracle(Case(ncell, k=k, steps=3, tau_grad_div=0.1, damping=0.2), k)
+
+
 def _sweep_vs_generic_and_linearity(case, nq):
     op = case.engine()
     rng = np.random.default_rng(11)

@@ -91,6 +91,25 @@ def test_fast_oracle_matches_naive_oracle(k, ncell, lin):
     assert rel_l2(b[0], a[0]) < 1e-13 and rel_l2(b[1], a[1]) < 1e-13
 
 
+@pytest.mark.parametrize("k,ncell", [(2, (5, 4, 3)), (4, (2, 2, 2))])
+@pytest.mark.parametrize("lin,phys", [(0, 0), (1, 0), (0, 1)])
+def test_fast_oracle_residual_matches_naive_oracle(k, ncell, lin, phys):
+    """orc_fast_ns_residual (OpenMP, sum-factorised; the full-size checker of the path bench.py times) against the naive
+    restatement of NavierStokesMatrix::residual (navier_stokes_matrix.cc:266-293): right-hand side with a user vector, the
+    quadrature-point state it writes, variable coefficients"""
+    case = Case(ncell, k=k, linearization=lin, physical_type=phys, faces_u=[0, 2, 3, 5], faces_p=[1], tau_grad_div=0.2,
+                damping=0.1, density=1.2, steps=3)
+    su, sp, ou, oou = case.random_u(), case.random_p(), case.random_u(), case.random_u()
+    uu, up = case.random_u(), case.random_p()
+    rho, mu, dmp = case.random_coefficients()
+    la, lb = np.zeros(case.n_cells * case.nq * 12), np.zeros(case.n_cells * case.nq * 12)
+    kw = dict(con_u=case.con_u, con_p=case.con_p, rho=rho, mu=mu, damp=dmp, user_u=uu, user_p=up)
+    a = orc.ns_residual(case.mesh, k, case.prm, su, sp, ou, oou, lin=la, **kw)
+    b = orc.fast_ns_residual(case.mesh, k, case.prm, su, sp, ou, oou, lin=lb, **kw)
+    assert rel_l2(b[0], a[0]) < 1e-13 and rel_l2(b[1], a[1]) < 1e-13
+    assert np.abs(la).max() > 0.1 and rel_l2(lb, la) < 1e-13
+
+
 def test_beltrami_residual_converges_with_mesh_refinement():
     """manufactured solution (tests/beltrami.cc:82-172): the discrete momentum residual of the
     exact fields (incl. time derivative via BDF weights of the exact history) decays under refinement"""
