@@ -123,6 +123,8 @@ SIGNATURES = {
     "adaflo_ns_vmult_distributed": (C.c_int, [_CTX, _COMM, _D, _D, _D, _D, C.c_int]),
     "adaflo_comm_force_phased_schedule": (C.c_int, [_COMM, C.c_int]),
     "adaflo_comm_matvec_statistics": (C.c_int, [_COMM, C.POINTER(C.c_uint), C.POINTER(MinMaxAvg)]),
+    "adaflo_comm_set_phase_timing": (C.c_int, [_COMM, C.c_int]),
+    "adaflo_comm_phase_statistics": (C.c_int, [_COMM, C.POINTER(C.c_uint), C.POINTER(C.c_double)]),
     "adaflo_ls_set_params": (C.c_int, [_CTX, C.POINTER(LSParams)]),
     "adaflo_ls_set_diagonal": (C.c_int, [_CTX, _D]),
     "adaflo_ls_set_evaluated_convection": (C.c_int, [_CTX, C.c_void_p, C.c_int]),

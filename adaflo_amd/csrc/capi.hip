@@ -104,9 +104,13 @@ namespace
     a.brick   = ctx->brick;
     a.ns      = ctx->ns;
     a.lin     = prec_state && ctx->lin_prec.p && ctx->lin_prec_generic_valid ? ctx->lin_prec.p : ctx->lin.p;
-    a.rho     = prec_state && ctx->rho_prec.p ? ctx->rho_prec.p : ctx->rho.p;
-    a.mu      = prec_state && ctx->mu_prec.p ? ctx->mu_prec.p : ctx->mu.p;
-    a.damp    = prec_state && ctx->damp_prec.p ? ctx->damp_prec.p : ctx->damp.p;
+    // velocity_vmult swaps ALL FOUR arrays as soon as a frozen linearisation exists (navier_stokes_matrix.cc:349-356): a state
+    // frozen without coefficients is applied with CONSTANT coefficients even if coefficient arrays were set afterwards
+    // (found by tests/test_state_machine_gpu.py, round 6: the current arrays were used); no frozen state: the current ones
+    const bool frozen = prec_state && (ctx->lin_prec.p || ctx->lin_q2_prec.p || ctx->hox_lin_prec_primary || ctx->rho_prec.p);
+    a.rho     = frozen ? ctx->rho_prec.p : ctx->rho.p;
+    a.mu      = frozen ? ctx->mu_prec.p : ctx->mu.p;
+    a.damp    = frozen ? ctx->damp_prec.p : ctx->damp.p;
     a.tab     = ctx->d_tab_u;
     a.n_cells = ctx->n_cells;
     return a;

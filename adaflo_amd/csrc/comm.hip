@@ -133,6 +133,11 @@ struct adaflo_comm
   // get_matvec_statistics (:1194-1206): device time of every adaflo_ns_vmult_distributed of this rank, events on the
   // engine stream around the whole sequence (the stream waits for both exchanges inside it)
   adaflo_hip::EventTimer matvec_timer;
+  // optional device times of the pieces of adaflo_ns_vmult_distributed (adaflo_comm_set_phase_timing): 0 ghost update of src
+  // (pack, messages, unpack), 1 cells at the interface + their seam sums, 2 compress(add) of dst, 3 interior cells, 4 tail
+  // (remaining seam sums, constrained rows, mean-value projection).  0-2 run on the auxiliary stream beside 3.
+  adaflo_hip::EventTimer phase_timer[5];
+  bool                   phase_timing = false;
   double                *d_stats = nullptr; // `world` doubles for the reduction of the per-rank times
   std::string last_error;
 };
@@ -528,6 +533,8 @@ int adaflo_comm_destroy(adaflo_comm *c)
     if (p)
       (void)hipFree(p);
   c->matvec_timer.destroy();
+  for (auto &t : c->phase_timer)
+    t.destroy();
   if (c->aux_stream)
     (void)hipStreamSynchronize(c->aux_stream);
   for (hipEvent_t e : {c->ev_packed, c->ev_arrived, c->ev_src, c->ev_iface, c->ev_done})
@@ -644,6 +651,7 @@ int adaflo_ns_vmult_distributed(adaflo_ctx *ctx, adaflo_comm *c, double *dst_u, 
       c->matvec_timer.count++;
     }
   } timed(c);
+  hipEvent_t tail_stop = nullptr;
   if (c->world == 1 && !phased)
     {
       // (the context was created without the local mean-value fix when a communicator takes care of it)
@@ -678,30 +686,61 @@ int adaflo_ns_vmult_distributed(adaflo_ctx *ctx, adaflo_comm *c, double *dst_u, 
         return e;
       if (hipEventRecord(c->ev_src, S) != hipSuccess || hipStreamWaitEvent(S2, c->ev_src, 0) != hipSuccess)
         return cfail(c, ADAFLO_EHIP, "event failed");
-      if (int e = adaflo_ns_vmult_phase(ctx, dst_u, dst_p, src_u, src_p, 3, c->iface))
-        return e;
+      struct Piece // (times one piece on one stream when adaflo_comm_set_phase_timing is on)
+      {
+        hipEvent_t  stop;
+        hipStream_t s;
+        Piece(adaflo_comm *cc, const int i, hipStream_t st)
+          : stop(cc->phase_timing ? cc->phase_timer[i].start(st) : nullptr)
+          , s(st)
+        {
+          if (cc->phase_timing)
+            cc->phase_timer[i].count++;
+        }
+        void done()
+        {
+          if (stop)
+            (void)hipEventRecord(stop, s);
+          stop = nullptr;
+        }
+      };
+      {
+        Piece t3(c, 3, S);
+        if (int e = adaflo_ns_vmult_phase(ctx, dst_u, dst_p, src_u, src_p, 3, c->iface))
+          return e;
+        t3.done();
+      }
       {
         OnStream on(ctx, S2);
         if (!src_ghosts_valid)
           {
+            Piece t0(c, 0, S2);
             if (int e = exchange_start(c, c->copy, src_u, src_p))
               return e;
             if (int e = exchange_finish(c, c->copy, src_u, src_p, false))
               return e;
+            t0.done();
           }
+        Piece t1(c, 1, S2);
         if (int e = adaflo_ns_vmult_phase(ctx, dst_u, dst_p, src_u, src_p, 1, c->iface))
           return e;
+        t1.done();
         if (hipEventRecord(c->ev_iface, S2) != hipSuccess)
           return cfail(c, ADAFLO_EHIP, "event failed");
+        Piece t2(c, 2, S2);
         if (int e = exchange_start(c, c->add, dst_u, dst_p))
           return e;
         if (int e = exchange_finish(c, c->add, dst_u, dst_p, true))
           return e;
+        t2.done();
         if (hipEventRecord(c->ev_done, S2) != hipSuccess)
           return cfail(c, ADAFLO_EHIP, "event failed");
       }
       if (hipStreamWaitEvent(S, c->ev_iface, 0) != hipSuccess)
         return cfail(c, ADAFLO_EHIP, "event failed");
+      tail_stop = c->phase_timing ? c->phase_timer[4].start(S) : nullptr;
+      if (c->phase_timing)
+        c->phase_timer[4].count++;
       if (int e = adaflo_ns_vmult_phase(ctx, dst_u, dst_p, src_u, src_p, 4, c->iface))
         return e;
       if (hipStreamWaitEvent(S, c->ev_done, 0) != hipSuccess)
@@ -731,6 +770,36 @@ int adaflo_ns_vmult_distributed(adaflo_ctx *ctx, adaflo_comm *c, double *dst_u, 
       if (int e = launch_subtract_scaled(ctx, dst_p, c->d_dot, c->d_inv, ctx->n_nodes_p))
         return cfail(c, e, "projection failed");
     }
+  if (tail_stop)
+    (void)hipEventRecord(tail_stop, ctx->stream);
+  return 0;
+}
+
+int adaflo_comm_set_phase_timing(adaflo_comm *c, int enabled)
+{
+  if (!c)
+    return ADAFLO_EINVAL;
+  c->phase_timing = enabled != 0;
+  return 0;
+}
+
+int adaflo_comm_phase_statistics(adaflo_comm *c, unsigned *count, double seconds[5])
+{
+  if (!c || !seconds)
+    return ADAFLO_EINVAL;
+  if (hipStreamSynchronize(c->ctx->stream) != hipSuccess || hipStreamSynchronize(c->aux_stream) != hipSuccess)
+    return cfail(c, ADAFLO_EHIP, "synchronisation failed");
+  unsigned n = 0;
+  for (int i = 0; i < 5; ++i)
+    {
+      c->phase_timer[i].fold();
+      seconds[i] = c->phase_timer[i].seconds;
+      n = c->phase_timer[i].count > n ? c->phase_timer[i].count : n;
+      c->phase_timer[i].seconds = 0.;
+      c->phase_timer[i].count   = 0;
+    }
+  if (count)
+    *count = n;
   return 0;
 }
 

@@ -63,7 +63,11 @@ namespace adaflo_hip
         {
           if (pool.size() >= 8192)
             {
-              (void)hipStreamSynchronize(stream);
+              // (the pairs may have been recorded on several streams -- the two-stream schedule of comm.hip shares this
+              // timer --: wait for the stop events themselves, a synchronisation of the calling stream alone left the
+              // other stream's pairs "not ready" and fold() dropped them)
+              for (size_t i = 1; i < used; i += 2)
+                (void)hipEventSynchronize(pool[i]);
               fold();
             }
           else

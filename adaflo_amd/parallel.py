@@ -414,6 +414,16 @@ class NativeCommunicator:
         self._check(self._lib.adaflo_comm_matvec_statistics(self.handle, C.byref(n), C.byref(st)))
         return n.value, st
 
+    def set_phase_timing(self, enabled=True):
+        self._check(self._lib.adaflo_comm_set_phase_timing(self.handle, int(enabled)))
+
+    def phase_statistics(self):
+        """(count, {piece: seconds}) of this rank since the last call: the pieces of adaflo_ns_vmult_distributed"""
+        import ctypes as C
+        n, sec = C.c_uint(0), (C.c_double * 5)()
+        self._check(self._lib.adaflo_comm_phase_statistics(self.handle, C.byref(n), sec))
+        return n.value, dict(zip(("src_exchange", "interface_cells", "dst_exchange", "interior_cells", "tail"), list(sec)))
+
     def close(self):
         if self.handle:
             self._lib.adaflo_comm_destroy(self.handle)

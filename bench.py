@@ -340,10 +340,18 @@ def measure(args, world, rank, local_rank):
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        kw = {"device_id": device} if backend == "nccl" else {}
+        attempt = int(os.environ.get("ADAFLO_BENCH_ATTEMPT", "1"))
+        if attempt > 1 and os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True":
+            # the repetition of a failed job (see supervise): the launcher's store still holds the rendezvous keys of the
+            # first attempt (addresses of processes that are gone) -- the same store under a prefix of its own
+            import datetime
+            base = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, False,
+                                 timeout=datetime.timedelta(seconds=300))
+            dist.init_process_group(backend, store=dist.PrefixStore("adaflo_bench_attempt%d" % attempt, base), rank=rank,
+                                    world_size=world, **kw)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     import adaflo_amd
     from adaflo_amd import build as _build
@@ -474,6 +482,18 @@ def measure(args, world, rank, local_rank):
     events[args.steps].record()
     barrier()
     step_ms = np.array([events[i].elapsed_time(events[i + 1]) for i in range(args.steps)])
+    # device times of the pieces of the distributed operator on rank 0 (a third, untimed pass: ten more event records per
+    # application): what overlaps with what, so that one driver run of an N > 1 job diagnoses itself
+    phase_ms = None
+    if op.comm is not None:
+        op.comm.set_phase_timing(True)
+        barrier()
+        for i in range(args.steps):
+            op.vmult(dst, src, src_consistent=args.src_consistent)
+        barrier()
+        n_ph, sec = op.comm.phase_statistics()
+        op.comm.set_phase_timing(False)
+        phase_ms = {name: round(1e3 * t / max(n_ph, 1), 4) for name, t in sec.items()}
     if args.print_steps and rank == 0:
         print("step ms:", " ".join("%.3f" % t for t in step_ms), file=sys.stderr)
     op.local.get_kernel_statistics()
@@ -570,6 +590,9 @@ def measure(args, world, rank, local_rank):
         out["ms_per_step_min_rank"] = round(1e3 * rank_min / max(mcount, 1), 4)
         out["ms_per_step_max_rank"] = round(1e3 * rank_max / max(mcount, 1), 4)
         out["min_rank"], out["max_rank"] = rank_imin, rank_imax
+    if phase_ms is not None:
+        # (rank 0; src_exchange, interface_cells and dst_exchange run on the auxiliary stream beside interior_cells)
+        out["phase_ms_rank0"] = phase_ms
     if dry_run:
         out["dry_run"] = True       # ranks share one GPU, gloo messages: functional check only
     if not args.no_cpu_baseline:

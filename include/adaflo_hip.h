@@ -286,6 +286,13 @@ typedef struct adaflo_min_max_avg
   int    min_index, max_index;
 } adaflo_min_max_avg;
 int         adaflo_comm_matvec_statistics(adaflo_comm *comm, unsigned *count, adaflo_min_max_avg *stats);
+/* Diagnostics of one rank (not collective): device seconds of the pieces of adaflo_ns_vmult_distributed accumulated since the
+ * last call -- [0] ghost update of src (pack, messages, unpack), [1] cells at the inter-GPU interface + their seam sums,
+ * [2] compress(add) of dst, all three on the auxiliary stream BESIDE [3] the interior cells, [4] the tail (remaining seam sums,
+ * constrained rows, mean-value projection) -- and the number of operator applications.  Off by default (ten more event
+ * records per application).  The reference times the operator as a whole only, navier_stokes_matrix.cc:1194-1206. */
+int         adaflo_comm_set_phase_timing(adaflo_comm *comm, int enabled);
+int         adaflo_comm_phase_statistics(adaflo_comm *comm, unsigned *count, double seconds[5]);
 /* measurement aid (bench.py --through-comm): take the three-phase schedule -- packs, events, second stream,
  * three kernel launches, unpacks, constrained rows -- also with world = 1, where adaflo_ns_vmult_distributed
  * otherwise forwards to adaflo_ns_vmult.  Shows the fixed cost of the distributed path on one GPU.          */

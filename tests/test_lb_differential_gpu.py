@@ -1,10 +1,12 @@
-"""Kernels built for one workgroup per CU (512 registers) against the 256-register build of the SAME source, bit by bit.
+"""Kernels built for one workgroup per CU (512 registers) against the 256-register build of the SAME source.
 
 Why: round 5 met a 512-register build that computed deterministically wrong sums and round 6 showed it to be a wrong
 instruction stream of the compiler, not a hardware hazard ("register-allocation dependent results"; the guarded
 `quad_bcast` of csrc/ns_q2.hip keeps the allocator away from it).  Both builds run the same floating-point operations in the
-same order, so ANY difference is a miscompilation of one of them -- the test that would have caught it, and that catches
-the next compiler that brings it back.  The 256-register libraries are test infrastructure (adaflo_amd/build.py: VARIANTS,
+same order up to the contraction of a multiply-add here and there (the launch bound and the guard change what the optimiser
+sees: observed differences are one or two units in the last place), while the miscompiled build was off by O(1) to O(100):
+agreement to 1e-13 of the largest entry tells the two apart -- the test that would have caught it, and that catches the
+next compiler that brings it back.  Most arrays are in fact bitwise equal; their number is reported.  The 256-register libraries are test infrastructure (adaflo_amd/build.py: VARIANTS,
 built by __graft_entry__.build(), or here when missing)."""
 import os
 import subprocess
@@ -38,9 +40,12 @@ def outputs(tmp_path_factory):
 
 
 @pytest.mark.parametrize("variant", ["q2_lb2", "hox_lb2"])
-def test_512_register_kernels_equal_their_256_register_builds_bitwise(outputs, variant):
+def test_512_register_kernels_equal_their_256_register_builds(outputs, variant):
     a, b = outputs["product"], outputs[variant]
     assert sorted(a.files) == sorted(b.files) and len(a.files) > 50
-    bad = [(key, float(np.abs(a[key] - b[key]).max())) for key in a.files if not np.array_equal(a[key], b[key])]
-    assert not bad, bad[:5]
     assert all(np.isfinite(a[key]).all() for key in a.files)
+    rel = {key: float(np.abs(a[key] - b[key]).max() / max(np.abs(b[key]).max(), 1e-300)) for key in a.files}
+    bad = sorted(((v, key) for key, v in rel.items() if v > 1e-13), reverse=True)
+    assert not bad, bad[:5]
+    print("%s: %d of %d arrays bitwise equal, largest relative difference %.1e" % (
+        variant, sum(1 for v in rel.values() if v == 0.0), len(rel), max(rel.values())))
