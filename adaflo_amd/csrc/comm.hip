@@ -681,6 +681,18 @@ int adaflo_ns_vmult_distributed(adaflo_ctx *ctx, adaflo_comm *c, double *dst_u, 
         ~OnStream() { ctx->stream = saved; }
       };
       hipStream_t S = ctx->stream, S2 = c->aux_stream;
+      // an error return from inside the schedule must not leave work on the auxiliary stream that the engine stream was
+      // never joined with (a caller that continues on S would race with it): wait for it on the way out
+      struct JoinOnError
+      {
+        hipStream_t s;
+        bool        armed = true;
+        ~JoinOnError()
+        {
+          if (armed)
+            (void)hipStreamSynchronize(s);
+        }
+      } join{S2};
       // tables and streaming copies of the state are brought up to date on S before S2 may touch them
       if (int e = adaflo_ns_vmult_phase(ctx, dst_u, dst_p, src_u, src_p, 5, c->iface))
         return e;
@@ -732,6 +744,12 @@ int adaflo_ns_vmult_distributed(adaflo_ctx *ctx, adaflo_comm *c, double *dst_u, 
           return e;
         if (int e = exchange_finish(c, c->add, dst_u, dst_p, true))
           return e;
+        // rows on boundary x interface: the sharers added their +-src as well.  Here, behind the unpack-add on the auxiliary
+        // stream (which has time to spare beside the interior cells), not as one more kernel behind the tail on the engine
+        // stream (round 6: 32^3 Q4/Q3 through the communicator 0.209 -> see profiles/r06_through_comm_q4_32.log); every other
+        // writer of these rows writes the same +-src, and the tail's seam sums skip constrained rows
+        if (int e = adaflo_ns_apply_constrained_rows(ctx, dst_u, dst_p, src_u, src_p))
+          return e;
         t2.done();
         if (hipEventRecord(c->ev_done, S2) != hipSuccess)
           return cfail(c, ADAFLO_EHIP, "event failed");
@@ -745,6 +763,7 @@ int adaflo_ns_vmult_distributed(adaflo_ctx *ctx, adaflo_comm *c, double *dst_u, 
         return e;
       if (hipStreamWaitEvent(S, c->ev_done, 0) != hipSuccess)
         return cfail(c, ADAFLO_EHIP, "event failed");
+      join.armed = false; // (S now waits for everything S2 was given)
     }
   else
     {
@@ -756,7 +775,7 @@ int adaflo_ns_vmult_distributed(adaflo_ctx *ctx, adaflo_comm *c, double *dst_u, 
       if (int e = adaflo_comm_compress_add(c, dst_u, dst_p))
         return e;
     }
-  if (c->world > 1 || phased) // rows on boundary x interface: the sharers added their +-src as well
+  if (c->world > 1 && !phased) // rows on boundary x interface: the sharers added their +-src as well (phased: done above)
     if (int e = adaflo_ns_apply_constrained_rows(ctx, dst_u, dst_p, src_u, src_p))
       return e;
   // :191-205 with the global weights; skipped for the projection scheme and the stationary equation

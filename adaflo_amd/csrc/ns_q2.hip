@@ -2121,8 +2121,12 @@ namespace adaflo_hip
       const long tiles = (long)A.tiles_x * A.tiles_y;
       // z-chunks of 32 cell layers while that leaves >= 1024 workgroups (128^3: 36.1 against 35.5 GDoF/s with 16:
       // fewer chunk prologues and chunk-boundary planes in the fix-up pass)
+      // (recompute mode, round 6: four rounds of workgroups instead of two -- 128^3: 16 layers 1.139 ms against 1.156 with 32,
+      // 160^3 2.150 against 2.169; 256^3 has 16 rounds with 32 already and loses 1.4 % with 16: profiles/r06_chunk_sweep.log.
+      // The streaming kernel pays more per chunk prologue and keeps the 1024 of round 3.)
+      const long want  = recompute ? 2048 : 1024;
       int        lz    = ctx->q2_lz > 0 ? ctx->q2_lz : 32;
-      while (lz > 4 && tiles * ((A.ncz + lz - 1) / lz) < 1024)
+      while (lz > 4 && tiles * ((A.ncz + lz - 1) / lz) < want)
         lz /= 2;
       if (lz > A.ncz)
         lz = A.ncz;

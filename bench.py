@@ -134,10 +134,25 @@ def supervise(args, script=None, argv=None):
         except OSError:
             return []
 
+    current = []                                           # the running child: stopped with the supervisor
+
+    def stop(signum, frame):
+        for ch in current:
+            if ch.poll() is None:
+                ch.kill()
+        sys.exit(128 + signum)
+    import signal
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        try:
+            signal.signal(sig, stop)
+        except ValueError:                                 # (not the main thread: tests that call supervise() directly)
+            pass
+
     def attempt(no, extra):
         env = dict(os.environ, ADAFLO_BENCH_WORKER="1", ADAFLO_BENCH_ATTEMPT=str(no), ADAFLO_BENCH_BOX=box)
         cmd = [sys.executable, script or os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else argv) + extra
         child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else None, text=True)
+        current[:] = [child]
         lines, t0, rc = [], time.perf_counter(), None
         if rank == 0:                                      # (reader thread: the pipe must not fill up)
             import threading
