@@ -18,6 +18,15 @@ class BrickDesc(C.Structure):
                 ("device", C.c_int), ("stream", C.c_void_p)]
 
 
+class IndexedDesc(C.Structure):
+    _fields_ = [("device", C.c_int), ("stream", C.c_void_p), ("velocity_degree", C.c_int), ("pressure_average_fix", C.c_int),
+                ("n_cells", C.c_int64), ("n_nodes_u", C.c_int64), ("n_nodes_p", C.c_int64),
+                ("cell_nodes_u", C.POINTER(C.c_int)), ("cell_nodes_p", C.POINTER(C.c_int)),
+                ("constrained_u", C.POINTER(C.c_ubyte)), ("constrained_p", C.POINTER(C.c_ubyte)),
+                ("cell_extents", C.POINTER(C.c_double)), ("h", C.c_double * 3),
+                ("n_colours", C.c_int), ("colour_offsets", C.POINTER(C.c_int64))]
+
+
 class LSParams(C.Structure):
     _fields_ = [("epsilon_used", C.c_double), ("minimal_edge_length", C.c_double),
                 ("time_step", C.c_double), ("weight", C.c_double), ("weight_old", C.c_double),
@@ -71,6 +80,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _D, C.c_int, C.c_void_p)
 # name -> (restype, argtypes); mirrors include/adaflo_hip.h one to one
 SIGNATURES = {
     "adaflo_ctx_create": (C.c_int, [C.POINTER(BrickDesc), C.POINTER(_CTX)]),
+    "adaflo_ctx_create_indexed": (C.c_int, [C.POINTER(IndexedDesc), C.POINTER(_CTX)]),
     "adaflo_ctx_destroy": (C.c_int, [_CTX]),
     "adaflo_last_error": (C.c_char_p, [_CTX]),
     "adaflo_synchronize": (C.c_int, [_CTX]),

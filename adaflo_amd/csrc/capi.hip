@@ -203,6 +203,11 @@ namespace
   }
 } // namespace
 
+// entry points that need the structured brick (level set, sweep kernels, halo plans, fast diagonalisation)
+#define BRICK_ONLY(ctx)                                                                                                   \
+  if ((ctx)->indexed)                                                                                                     \
+    return fail(ctx, ADAFLO_EUNSUPPORTED, "not available on an indexed context (adaflo_ctx_create_indexed): needs the structured brick")
+
 extern "C" {
 
 const char *adaflo_last_error(const adaflo_ctx *ctx)
@@ -347,6 +352,150 @@ static int ctx_create_impl(const adaflo_brick_desc *desc, adaflo_ctx *ctx)
 
 int adaflo_ctx_destroy(adaflo_ctx *ctx);
 
+// Indexed context (first alternative; include/adaflo_hip.h): the adapter's tables instead of the brick.
+// Built on the brick set-up of a one-cell brick (stream, 1D tables, default parameters), then the sizes and tables replaced.
+static int ctx_create_indexed_impl(const adaflo_indexed_desc *d, adaflo_ctx *ctx)
+{
+  const int k = d->velocity_degree;
+  if (k < 2 || k > 6)
+    return fail(nullptr, ADAFLO_EUNSUPPORTED, "velocity degree must be in [2,6] (reference: ExcNotImplemented)");
+  if (d->n_cells < 1 || d->n_nodes_u < 1 || d->n_nodes_p < 1 || !d->cell_nodes_u || !d->cell_nodes_p || !d->constrained_u ||
+      !d->constrained_p || d->n_colours < 1 || !d->colour_offsets)
+    return fail(nullptr, ADAFLO_EINVAL, "indexed context: missing table");
+  if (d->colour_offsets[0] != 0 || d->colour_offsets[d->n_colours] != d->n_cells)
+    return fail(nullptr, ADAFLO_EINVAL, "indexed context: the colour ranges must cover the cells [0, n_cells)");
+  if (d->n_nodes_u > 0x7fffffffLL / 3 || d->n_cells > 0x7fffffffLL)
+    return fail(nullptr, ADAFLO_EUNSUPPORTED, "indexed context: 32-bit node tables");
+  const long nu3 = (long)(k + 1) * (k + 1) * (k + 1), np3 = (long)k * k * k;
+  // the tables must be usable: indices in range, and no node twice inside one colour (the scatter has no atomics)
+  {
+    std::vector<int> seen_u((size_t)d->n_nodes_u, -1), seen_p((size_t)d->n_nodes_p, -1);
+    for (int c = 0; c < d->n_colours; ++c)
+      {
+        if (d->colour_offsets[c + 1] < d->colour_offsets[c])
+          return fail(nullptr, ADAFLO_EINVAL, "indexed context: colour offsets must not decrease");
+        for (int64_t cell = d->colour_offsets[c]; cell < d->colour_offsets[c + 1]; ++cell)
+          {
+            for (long l = 0; l < nu3; ++l)
+              {
+                const int n = d->cell_nodes_u[cell * nu3 + l];
+                if (n < 0 || n >= d->n_nodes_u)
+                  return fail(nullptr, ADAFLO_EINVAL, "indexed context: velocity node index out of range");
+              }
+            for (long l = 0; l < np3; ++l)
+              {
+                const int n = d->cell_nodes_p[cell * np3 + l];
+                if (n < 0 || n >= d->n_nodes_p)
+                  return fail(nullptr, ADAFLO_EINVAL, "indexed context: pressure node index out of range");
+              }
+          }
+        // two cells of colour c sharing a node: mark the nodes of every cell with (colour, cell) and look for a second owner
+        for (int64_t cell = d->colour_offsets[c]; cell < d->colour_offsets[c + 1]; ++cell)
+          {
+            for (long l = 0; l < nu3; ++l)
+              {
+                int &s = seen_u[d->cell_nodes_u[cell * nu3 + l]];
+                if (s >= 0 && s != (int)(cell - d->colour_offsets[c]))
+                  return fail(nullptr, ADAFLO_EINVAL, "indexed context: two cells of one colour share a velocity node");
+                s = (int)(cell - d->colour_offsets[c]);
+              }
+            for (long l = 0; l < np3; ++l)
+              {
+                int &s = seen_p[d->cell_nodes_p[cell * np3 + l]];
+                if (s >= 0 && s != (int)(cell - d->colour_offsets[c]))
+                  return fail(nullptr, ADAFLO_EINVAL, "indexed context: two cells of one colour share a pressure node");
+                s = (int)(cell - d->colour_offsets[c]);
+              }
+          }
+        std::fill(seen_u.begin(), seen_u.end(), -1);
+        std::fill(seen_p.begin(), seen_p.end(), -1);
+      }
+  }
+  adaflo_brick_desc b{};
+  b.dim = 3;
+  for (int i = 0; i < 3; ++i)
+    {
+      b.ncell[i] = 1;
+      b.h[i]     = d->cell_extents ? 1. : d->h[i];
+    }
+  b.velocity_degree      = k;
+  b.device               = d->device;
+  b.stream               = d->stream;
+  b.pressure_average_fix = 0; // (computed below, through the tables)
+  if (int e = ctx_create_impl(&b, ctx))
+    return e;
+  ctx->indexed   = true;
+  ctx->variant   = 0; // generic kernels only
+  ctx->pc_inner  = 0;
+  ctx->n_cells   = d->n_cells;
+  ctx->n_nodes_u = d->n_nodes_u;
+  ctx->n_nodes_p = d->n_nodes_p;
+  ctx->idx_colour_off.assign(d->colour_offsets, d->colour_offsets + d->n_colours + 1);
+  auto up = [&](auto **dst, const auto *src, const size_t count) -> int {
+    if (hipMalloc((void **)dst, count * sizeof(**dst)) != hipSuccess)
+      return ADAFLO_ENOMEM;
+    return copy_to_device_now(*dst, src, count * sizeof(**dst)) == hipSuccess ? 0 : ADAFLO_EHIP;
+  };
+  TRY(nullptr, up(&ctx->d_idx_u, d->cell_nodes_u, (size_t)d->n_cells * nu3), "indexed context: table upload failed");
+  TRY(nullptr, up(&ctx->d_idx_p, d->cell_nodes_p, (size_t)d->n_cells * np3), "indexed context: table upload failed");
+  TRY(nullptr, up(&ctx->d_flag_u, d->constrained_u, (size_t)d->n_nodes_u * 3), "indexed context: table upload failed");
+  TRY(nullptr, up(&ctx->d_flag_p, d->constrained_p, (size_t)d->n_nodes_p), "indexed context: table upload failed");
+  if (d->cell_extents)
+    {
+      for (int64_t i = 0; i < 3 * d->n_cells; ++i)
+        if (!(d->cell_extents[i] > 0.))
+          return fail(nullptr, ADAFLO_EINVAL, "indexed context: cell extents must be positive");
+      TRY(nullptr, up(&ctx->d_cell_h, d->cell_extents, (size_t)d->n_cells * 3), "indexed context: table upload failed");
+    }
+  ctx->brick.idx_u  = ctx->d_idx_u;
+  ctx->brick.idx_p  = ctx->d_idx_p;
+  ctx->brick.flag_u = ctx->d_flag_u;
+  ctx->brick.flag_p = ctx->d_flag_p;
+  ctx->brick.cell_h = ctx->d_cell_h;
+  // pressure constant mode 0, source/navier_stokes_matrix.cc:117-168 (as in ctx_create_impl, through the tables)
+  if (d->pressure_average_fix)
+    {
+      const long np = ctx->n_nodes_p;
+      HIP_TRY(nullptr, hipMalloc(&ctx->d_p_weights, np * sizeof(double)));
+      HIP_TRY(nullptr, hipMalloc(&ctx->d_p_modes, np * sizeof(double)));
+      TRY(nullptr, launch_fill(ctx, ctx->d_p_weights, 0., np), "fill failed");
+      ScalarArgs sa{};
+      sa.brick   = ctx->brick;
+      sa.ns      = ctx->ns;
+      sa.dst     = ctx->d_p_weights;
+      sa.tab     = ctx->d_tab_pp;
+      sa.n_cells = ctx->n_cells;
+      sa.mode    = SC_MASS_WEIGHT;
+      sa.nq_u3   = ctx->nq_u;
+      TRY(nullptr, launch_ns_scalar_generic(ctx, sa), "mass-weight kernel launch failed");
+      TRY(nullptr, launch_fill(ctx, ctx->d_p_modes, 1., np), "fill failed");
+      TRY(nullptr, launch_prepare_dst(ctx, ctx->d_p_modes, ctx->d_p_modes, np, 1, 1, 1, 1, 0u, 0., false), "mask failed");
+      const double mw   = host_dot(ctx, ctx->d_p_modes, ctx->d_p_weights, np);
+      ctx->inv_p_weight = 1. / mw;
+    }
+  HIP_TRY(nullptr, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int adaflo_ctx_create_indexed(const adaflo_indexed_desc *desc, adaflo_ctx **out)
+{
+  if (!desc || !out)
+    return fail(nullptr, ADAFLO_EINVAL, "null argument");
+  *out = nullptr;
+  adaflo_ctx *ctx = new adaflo_ctx;
+  const int   rc  = ctx_create_indexed_impl(desc, ctx);
+  if (rc != 0)
+    {
+      const std::string msg = g_create_error;
+      (void)hipGetLastError();
+      adaflo_ctx_destroy(ctx);
+      g_create_error = msg;
+      return rc;
+    }
+  *out = ctx;
+  return 0;
+}
+
 int adaflo_ctx_create(const adaflo_brick_desc *desc, adaflo_ctx **out)
 {
   if (!desc || !out)
@@ -385,6 +534,9 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
     release(*b);
   for (double *p : {ctx->d_tab_u, ctx->d_tab_pp, ctx->d_p_weights, ctx->d_p_modes, ctx->d_scratch,
                     ctx->d_tab_ls, ctx->d_ls_diag, ctx->d_tab_force, ctx->d_tab_maxvel})
+    if (p)
+      (void)hipFree(p);
+  for (void *p : {(void *)ctx->d_idx_u, (void *)ctx->d_idx_p, (void *)ctx->d_flag_u, (void *)ctx->d_flag_p, (void *)ctx->d_cell_h})
     if (p)
       (void)hipFree(p);
   fdm_destroy(ctx);
@@ -485,6 +637,8 @@ int adaflo_set_kernel_variant(adaflo_ctx *ctx, int variant)
     return fail(ctx, ADAFLO_EINVAL, "unknown kernel variant");
   if (ctx->flat && variant != 0)
     return fail(ctx, ADAFLO_EUNSUPPORTED, "dim = 2 runs on the generic kernels (variant 0) only");
+  if (ctx->indexed && variant != 0)
+    return fail(ctx, ADAFLO_EUNSUPPORTED, "an indexed context runs on the generic kernels (variant 0) only");
   // (2 and 3 select a kernel of their own only for the degrees these kernels exist for; elsewhere they mean what 1 means --
   // for Q2/Q1, 2 also selects the divergence mode of the sweep kernel in divergence_vmult_add)
   if (!adaflo_has_kernel_variant(variant) && ((variant == 2 && ctx->k >= 3 && ctx->k <= 5) || (variant == 3 && ctx->k == 4)))
@@ -789,6 +943,7 @@ int adaflo_ns_vmult_phase(adaflo_ctx *ctx, double *dst_u, double *dst_p, const d
                           const double *src_p, int phase, unsigned interface_faces)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (!dst_u || !dst_p || !src_u || !src_p)
     return fail(ctx, ADAFLO_EINVAL, "null vector");
   if (phase < 0 || phase > 5)
@@ -973,6 +1128,7 @@ int adaflo_ns_velocity_vmult(adaflo_ctx *ctx, double *dst_u, const double *src_u
 int adaflo_ns_velocity_block_diagonal(adaflo_ctx *ctx, double *diagonal_u)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (!diagonal_u)
     return fail(ctx, ADAFLO_EINVAL, "null vector");
   if (needs_lin(ctx) && !has_lin(ctx))
@@ -1191,6 +1347,7 @@ int adaflo_set_timing(adaflo_ctx *ctx, int enabled)
 int adaflo_fdm_apply(adaflo_ctx *ctx, int field, double *dst, const double *src, double c_mass, double c_lap)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (ctx->flat)
     return fail(ctx, ADAFLO_EUNSUPPORTED, "the fast-diagonalisation inverses are dim = 3 only");
   if (!dst || !src || field < 0 || field > 2)
@@ -1205,6 +1362,7 @@ int adaflo_fdm_apply_sum(adaflo_ctx *ctx, int field, double *dst, const double *
                          double c_mass2, double c_lap2)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (ctx->flat)
     return fail(ctx, ADAFLO_EUNSUPPORTED, "the fast-diagonalisation inverses are dim = 3 only");
   if (!dst || !src || field < 0 || field > 2 || (c_mass2 == 0. && c_lap2 == 0.))
@@ -1239,6 +1397,7 @@ int adaflo_ns_preconditioner_set_cheap_velocity_iterations(adaflo_ctx *ctx, int 
 int adaflo_ns_preconditioner_set_inner(adaflo_ctx *ctx, int mode)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (mode < 0 || mode > 1)
     return fail(ctx, ADAFLO_EINVAL, "unknown inner-solve mode");
   if (ctx->flat && mode == 1)
@@ -1316,12 +1475,16 @@ static int halo_transfer_impl(adaflo_ctx *ctx, double *vec, double *buf, const i
 int adaflo_halo_transfer(adaflo_ctx *ctx, double *vec, double *buf, const int *nn, int ncomp, int n_regions,
                          const int *regions, int mode)
 {
+  if (ctx && ctx->indexed)
+    return ADAFLO_EUNSUPPORTED; // (indexed context: needs the structured brick)
   return halo_transfer_impl(ctx, vec, buf, nn, ncomp, n_regions, regions, mode, 0);
 }
 
 int adaflo_halo_transfer_ordered(adaflo_ctx *ctx, double *vec, double *buf, const int *nn, int ncomp, int n_regions,
                                  const int *regions, int mode, int self_pos)
 {
+  if (ctx && ctx->indexed)
+    return ADAFLO_EUNSUPPORTED; // (indexed context: needs the structured brick)
   return halo_transfer_impl(ctx, vec, buf, nn, ncomp, n_regions, regions, mode, self_pos);
 }
 
@@ -1412,6 +1575,7 @@ static int ls_generic_state(adaflo_ctx *ctx, const int which)
 int adaflo_ls_set_params(adaflo_ctx *ctx, const adaflo_ls_params *p)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (!p)
     return fail(ctx, ADAFLO_EINVAL, "null params");
   ctx->ls = LSDev{p->epsilon_used, p->minimal_edge_length, p->time_step, p->weight, p->weight_old,
@@ -1422,6 +1586,7 @@ int adaflo_ls_set_params(adaflo_ctx *ctx, const adaflo_ls_params *p)
 int adaflo_ls_set_diagonal(adaflo_ctx *ctx, const double *diag)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (int e = ls_ready(ctx))
     return e;
   if (!ctx->d_ls_diag)
@@ -1434,6 +1599,7 @@ int adaflo_ls_set_diagonal(adaflo_ctx *ctx, const double *diag)
 int adaflo_ls_set_evaluated_convection(adaflo_ctx *ctx, const double *u_q, int src_on_device)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (int e = ls_ready(ctx))
     return e;
   ctx->q1_convection_valid         = false;
@@ -1445,6 +1611,7 @@ int adaflo_ls_set_evaluated_convection(adaflo_ctx *ctx, const double *u_q, int s
 int adaflo_ls_get_evaluated_convection(adaflo_ctx *ctx, double *u_q, int dst_on_device)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (int e = ls_generic_state(ctx, 0))
     return e;
   return get_q_array(ctx, ctx->ls_convection, u_q, dst_on_device);
@@ -1453,6 +1620,7 @@ int adaflo_ls_get_evaluated_convection(adaflo_ctx *ctx, double *u_q, int dst_on_
 int adaflo_ls_set_evaluated_normal(adaflo_ctx *ctx, const double *n_q, int src_on_device)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (int e = ls_ready(ctx))
     return e;
   ctx->q1_normal_valid         = false;
@@ -1464,6 +1632,7 @@ int adaflo_ls_set_evaluated_normal(adaflo_ctx *ctx, const double *n_q, int src_o
 int adaflo_ls_get_evaluated_normal(adaflo_ctx *ctx, double *n_q, int dst_on_device)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (int e = ls_generic_state(ctx, 1))
     return e;
   return get_q_array(ctx, ctx->ls_normal, n_q, dst_on_device);
@@ -1569,6 +1738,7 @@ static int ls_vmult(adaflo_ctx *ctx, double *dst, const double *src, const int m
 int adaflo_ls_advance_concentration_vmult(adaflo_ctx *ctx, double *dst, const double *src)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (!ctx->ls_convection.p && !ctx->q1_convection_valid && !ctx->q1_convection_nodal_valid)
     return fail(ctx, ADAFLO_ENOTINIT, "evaluated_convection not set (run the rhs kernel first)");
   return ls_vmult(ctx, dst, src, 0 /*LS_ADVECT*/, 0, ctx->ls_convection.p, 1);
@@ -1579,6 +1749,7 @@ int adaflo_ls_advance_concentration_rhs(adaflo_ctx *ctx, double *dst, const doub
                                         const double *vel_solution, int use_old_old)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (int e = ls_ready(ctx))
     return e;
   if (!dst || !solution || !solution_old || !solution_old_old || !vel_solution)
@@ -1627,6 +1798,7 @@ int adaflo_ls_set_convection_stabilization(adaflo_ctx *ctx, int enabled, double 
                                            unsigned symmetry_faces)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (int e = ls_ready(ctx))
     return e;
   if (enabled && !(global_omega_diameter > 0.))
@@ -1645,6 +1817,7 @@ int adaflo_ls_set_convection_stabilization(adaflo_ctx *ctx, int enabled, double 
 int adaflo_ls_set_artificial_viscosities(adaflo_ctx *ctx, const double *nu, int src_on_device)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (!nu)
     return fail(ctx, ADAFLO_EINVAL, "null array");
   TRY(ctx, alloc(ctx, ctx->ls_art_visc, (size_t)ctx->n_cells), ctx->last_error);
@@ -1657,6 +1830,7 @@ int adaflo_ls_set_artificial_viscosities(adaflo_ctx *ctx, const double *nu, int 
 int adaflo_ls_get_artificial_viscosities(adaflo_ctx *ctx, double *nu, int dst_on_device)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (!nu || !ctx->ls_art_visc.p)
     return fail(ctx, ADAFLO_ENOTINIT, "artificial viscosities not set");
   HIP_TRY(ctx, hipMemcpyAsync(nu, ctx->ls_art_visc.p, ctx->n_cells * sizeof(double),
@@ -1668,6 +1842,7 @@ int adaflo_ls_get_artificial_viscosities(adaflo_ctx *ctx, double *nu, int dst_on
 int adaflo_ls_max_velocity(adaflo_ctx *ctx, const double *vel_solution, double *max_velocity)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (!vel_solution || !max_velocity)
     return fail(ctx, ADAFLO_EINVAL, "null argument");
   const int k = ctx->k;
@@ -1699,6 +1874,7 @@ int adaflo_ls_max_velocity(adaflo_ctx *ctx, const double *vel_solution, double *
 int adaflo_ls_stabilization_boundary_term(adaflo_ctx *ctx, double *dst, const double *vec, double sign)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (int e = ls_ready(ctx))
     return e;
   if (!dst || !vec || !ctx->ls_art_visc.p)
@@ -1719,6 +1895,7 @@ int adaflo_ls_advance_concentration_rhs_stabilized(adaflo_ctx *ctx, double *dst,
                                                    double old_step_size, double global_max_velocity)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (int e = ls_ready(ctx))
     return e;
   if (!ctx->ls_stab)
@@ -1759,6 +1936,7 @@ int adaflo_ls_advance_concentration_rhs_stabilized(adaflo_ctx *ctx, double *dst,
 int adaflo_ls_reinitialization_vmult(adaflo_ctx *ctx, double *dst, const double *src, int diffuse_only)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (!diffuse_only && !ctx->ls_normal.p && !ctx->q1_normal_valid)
     return fail(ctx, ADAFLO_ENOTINIT, "evaluated_normal not set (run the rhs kernel with first_reinit_step)");
   return ls_vmult(ctx, dst, src, diffuse_only ? 2 : 1, 0, ctx->ls_normal.p, 1);
@@ -1769,6 +1947,7 @@ int adaflo_ls_reinitialization_rhs(adaflo_ctx *ctx, double *dst, const double *s
                                    int first_reinit_step)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (int e = ls_ready(ctx))
     return e;
   if (!dst || !solution || (!diffuse_only && first_reinit_step && !normal_vector_field))
@@ -1832,18 +2011,21 @@ int adaflo_ls_reinitialization_rhs(adaflo_ctx *ctx, double *dst, const double *s
 int adaflo_ls_compute_normal_vmult(adaflo_ctx *ctx, double *dst, const double *src)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   return ls_vmult(ctx, dst, src, 3 /*LS_NORMAL*/, 1, nullptr, 3);
 }
 
 int adaflo_ls_projection_vmult(adaflo_ctx *ctx, double *dst, const double *src)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   return ls_vmult(ctx, dst, src, 3 /*LS_NORMAL*/, 1, nullptr, 1); // one scalar block of the normal operator
 }
 
 int adaflo_ls_projection_solve(adaflo_ctx *ctx, double *dst, const double *rhs, int n_blocks)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (int e = ls_ready(ctx))
     return e;
   if (!dst || !rhs || n_blocks < 1)
@@ -1866,6 +2048,7 @@ int adaflo_ls_projection_solve(adaflo_ctx *ctx, double *dst, const double *rhs, 
 int adaflo_ls_compute_normal_rhs(adaflo_ctx *ctx, double *dst, const double *level_set_solution)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (int e = ls_ready(ctx))
     return e;
   if (!dst || !level_set_solution)
@@ -1883,12 +2066,14 @@ int adaflo_ls_compute_normal_rhs(adaflo_ctx *ctx, double *dst, const double *lev
 int adaflo_ls_compute_curvature_vmult(adaflo_ctx *ctx, double *dst, const double *src, int apply_diffusion)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   return ls_vmult(ctx, dst, src, 4 /*LS_CURVATURE*/, apply_diffusion, nullptr, 1);
 }
 
 int adaflo_ls_mass_matrix_diagonal(adaflo_ctx *ctx, double *diagonal)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (int e = ls_ready(ctx))
     return e;
   if (!diagonal)
@@ -1900,6 +2085,7 @@ int adaflo_ls_mass_matrix_diagonal(adaflo_ctx *ctx, double *diagonal)
 int adaflo_ls_compute_heaviside(adaflo_ctx *ctx, double *heaviside, const double *level_set, double epsilon)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (int e = ls_ready(ctx))
     return e;
   if (!heaviside || !level_set)
@@ -1911,6 +2097,7 @@ int adaflo_ls_compute_heaviside(adaflo_ctx *ctx, double *heaviside, const double
 int adaflo_ls_curvature_correction(adaflo_ctx *ctx, double *curvature, const double *level_set)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (int e = ls_ready(ctx))
     return e;
   if (!curvature || !level_set)
@@ -1923,6 +2110,7 @@ int adaflo_ls_compute_force(adaflo_ctx *ctx, double *user_rhs_u, const double *h
                             const double *curvature, const adaflo_force_params *p)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (int e = ls_ready(ctx))
     return e;
   if (!user_rhs_u || !heaviside || !curvature || !p)
@@ -1961,6 +2149,7 @@ int adaflo_ls_compute_force(adaflo_ctx *ctx, double *user_rhs_u, const double *h
 int adaflo_ls_compute_curvature_rhs(adaflo_ctx *ctx, double *dst, const double *normal_vector_field)
 {
   CHECK_CTX(ctx);
+  BRICK_ONLY(ctx);
   if (int e = ls_ready(ctx))
     return e;
   if (!dst || !normal_vector_field)

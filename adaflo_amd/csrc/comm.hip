@@ -469,6 +469,8 @@ int adaflo_comm_get_unique_id(adaflo_comm_unique_id *id)
 int adaflo_comm_create(adaflo_ctx *ctx, const adaflo_comm_unique_id *id, int rank, int world, const int *grid,
                        int pressure_average_fix, adaflo_comm **out)
 {
+  if (ctx && ctx->indexed)
+    return ADAFLO_EUNSUPPORTED; // (indexed context: needs the structured brick)
   if (!out || !id)
     return ADAFLO_EINVAL;
   *out = nullptr;
@@ -498,6 +500,8 @@ int adaflo_comm_create(adaflo_ctx *ctx, const adaflo_comm_unique_id *id, int ran
 int adaflo_comm_create_custom(adaflo_ctx *ctx, int rank, int world, const int *grid, adaflo_exchange_fn exchange,
                               adaflo_allreduce_fn allreduce, void *user, int pressure_average_fix, adaflo_comm **out)
 {
+  if (ctx && ctx->indexed)
+    return ADAFLO_EUNSUPPORTED; // (indexed context: needs the structured brick)
   if (!out || (world > 1 && (!exchange || !allreduce)))
     return ADAFLO_EINVAL;
   *out = nullptr;

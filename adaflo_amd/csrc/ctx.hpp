@@ -108,6 +108,13 @@ struct adaflo_ctx
   int     nq_u = 0; // (k+1)^3
 
   adaflo_hip::BrickDev brick{};
+  // indexed context (adaflo_ctx_create_indexed): device copies of the adapter's tables (brick.idx_* / flag_* / cell_h point
+  // into them) and the colour ranges; only the generic kernels of the Navier-Stokes block run on it
+  bool              indexed = false;
+  std::vector<long> idx_colour_off;
+  int              *d_idx_u = nullptr, *d_idx_p = nullptr;
+  unsigned char    *d_flag_u = nullptr, *d_flag_p = nullptr;
+  double           *d_cell_h = nullptr;
   adaflo_hip::NSDev    ns{};
   bool                 ns_params_set = false;
 

@@ -25,6 +25,14 @@ namespace adaflo_hip
     // two cells of one colour share no node, so the scatter needs no atomics and the result is bitwise
     // reproducible.  -1: all cells in one launch (kernels that do not scatter).
     int      colour = -1;
+    // INDEXED context (round 6; SURVEY 8(b).1, first alternative: what an adapter copies out of a MatrixFree on any conforming
+    // Cartesian mesh): per-cell node tables in the cell's lexicographic order, constraint flags per degree of freedom, the
+    // cells sorted by colour (no two cells of a colour share a node) -- a launch covers cells [cell_first, cell_first + grid) --
+    // and, optionally, the extents of every cell (the diagonal of its Jacobian).  Null tables = the structured brick.
+    const int           *idx_u = nullptr, *idx_p = nullptr; // [n_cells][(k+1)^3], [n_cells][k^3]
+    const unsigned char *flag_u = nullptr, *flag_p = nullptr; // [n_nodes_u * 3], [n_nodes_p]
+    const double        *cell_h = nullptr;                    // [n_cells][3] or null (h above)
+    long                 cell_first = 0;
   };
   // number of cells of a colour
   inline long n_cells_of_colour(const int ncell[3], const int colour)
@@ -50,6 +58,8 @@ namespace adaflo_hip
   // (or of the one launch over all n_cells cells)
   __device__ __forceinline__ long brick_cell(const BrickDev &b, const long blk, const long n_cells)
   {
+    if (b.idx_u)
+      return b.cell_first + blk; // (indexed context: the table order is the launch order)
     if (b.colour < 0)
       return xcd_remap(blk, n_cells);
     const int  px = b.colour & 1, py = b.colour >> 1 & 1, pz = b.colour >> 2 & 1;
@@ -480,5 +490,68 @@ namespace adaflo_hip
         if (!on_constrained_face(I, J, K, nnx, nny, nnz, mask, NC == 1 ? 1 : 3, c))
           vec[node * NC + c] += loc[c * ND3 + l];
       }
+  }
+
+  // ---- indexed context: the same two operations through the node table of the cell ---------------------------------
+  // (NC = 3: velocity space, node table / flags of degree DEG = k; NC = 1: pressure space)
+  template <int DEG, int NC, int NT, bool RESOLVE>
+  __device__ void gather_cell_indexed(const double *__restrict__ vec, double *loc, const int *__restrict__ nodes,
+                                      const unsigned char *__restrict__ flags)
+  {
+    constexpr int ND3 = (DEG + 1) * (DEG + 1) * (DEG + 1);
+    for (int o = threadIdx.x; o < ND3 * NC; o += NT)
+      {
+        const int  c = o % NC, l = o / NC;
+        const long dof = (long)nodes[l] * NC + c;
+        double     v   = vec[dof];
+        if (RESOLVE && flags[dof])
+          v = 0.;
+        loc[c * ND3 + l] = v;
+      }
+  }
+  template <int DEG, int NC, int NT>
+  __device__ void scatter_cell_indexed(double *__restrict__ vec, const double *loc, const int *__restrict__ nodes,
+                                       const unsigned char *__restrict__ flags)
+  {
+    constexpr int ND3 = (DEG + 1) * (DEG + 1) * (DEG + 1);
+    for (int o = threadIdx.x; o < ND3 * NC; o += NT)
+      {
+        const int  c = o % NC, l = o / NC;
+        const long dof = (long)nodes[l] * NC + c;
+        if (!flags[dof])
+          vec[dof] += loc[c * ND3 + l];
+      }
+  }
+  // brick or table, by what the context carries (`c`: the cell; `resolve`: the caller's mask != "none")
+  template <int DEG, int NC, int NT, bool RESOLVE, int ZF>
+  __device__ __forceinline__ void gather_any(const BrickDev &b, const double *__restrict__ vec, double *loc, const long c,
+                                             const int cx, const int cy, const int cz, const int nnx, const int nny,
+                                             const int nnz, const uint32_t mask)
+  {
+    if (ZF == 0 && b.idx_u)
+      {
+        constexpr int ND3 = (DEG + 1) * (DEG + 1) * (DEG + 1);
+        gather_cell_indexed<DEG, NC, NT, RESOLVE>(vec, loc, (NC == 3 ? b.idx_u : b.idx_p) + c * ND3, NC == 3 ? b.flag_u : b.flag_p);
+      }
+    else
+      gather_cell<DEG, NC, NT, RESOLVE, ZF>(vec, loc, cx, cy, cz, nnx, nny, nnz, mask);
+  }
+  template <int DEG, int NC, int NT, int ZF>
+  __device__ __forceinline__ void scatter_any(const BrickDev &b, double *__restrict__ vec, const double *loc, const long c,
+                                              const int cx, const int cy, const int cz, const int nnx, const int nny,
+                                              const int nnz, const uint32_t mask)
+  {
+    if (ZF == 0 && b.idx_u)
+      {
+        constexpr int ND3 = (DEG + 1) * (DEG + 1) * (DEG + 1);
+        scatter_cell_indexed<DEG, NC, NT>(vec, loc, (NC == 3 ? b.idx_u : b.idx_p) + c * ND3, NC == 3 ? b.flag_u : b.flag_p);
+      }
+    else
+      scatter_cell<DEG, NC, NT, ZF>(vec, loc, cx, cy, cz, nnx, nny, nnz, mask, b.colour);
+  }
+  // extents of cell c
+  __device__ __forceinline__ const double *cell_extents(const BrickDev &b, const long c)
+  {
+    return b.cell_h ? b.cell_h + 3 * c : b.h;
   }
 } // namespace adaflo_hip

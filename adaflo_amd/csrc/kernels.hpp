@@ -18,6 +18,18 @@ namespace adaflo_hip
     const hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
     return e != hipSuccess ? e : hipDeviceSynchronize();
   }
+  // the colours a coloured cell loop runs through: the eight parities of the brick, or the colour ranges of an indexed context
+  inline int n_colours(const adaflo_ctx *ctx) { return ctx->indexed ? (int)ctx->idx_colour_off.size() - 1 : 8; }
+  inline long cells_of_colour(const adaflo_ctx *ctx, const BrickDev &b, const int colour)
+  {
+    return ctx->indexed ? ctx->idx_colour_off[colour + 1] - ctx->idx_colour_off[colour] : n_cells_of_colour(b.ncell, colour);
+  }
+  inline void set_colour(const adaflo_ctx *ctx, BrickDev &b, const int colour)
+  {
+    b.colour = colour;
+    if (ctx->indexed)
+      b.cell_first = ctx->idx_colour_off[colour];
+  }
   // x-marching Q_k/Q_{k-1} kernel for k = 3, 4, 5 (ns_hox.hip), constant coefficients: the default since round 4
   bool hox_supported(const adaflo_ctx *ctx);
   bool hox_residual_supported(const adaflo_ctx *ctx);

@@ -807,6 +807,8 @@ int adaflo_invert_diagonal(adaflo_ctx *ctx, double *inverse_diagonal, const doub
 int adaflo_solve(adaflo_ctx *ctx, int op, int method, double *x, const double *b, const double *inverse_diagonal,
                  const adaflo_solver_control *control, adaflo_solver_result *result)
 {
+  if (ctx && ctx->indexed)
+    return ADAFLO_EUNSUPPORTED; // (indexed context: needs the structured brick)
   if (!ctx)
     return ADAFLO_ENOTINIT;
   if (!x || !b || !control || !result)
@@ -960,6 +962,8 @@ static int pc_check_built(adaflo_ctx *ctx)
 
 int adaflo_ns_preconditioner_setup(adaflo_ctx *ctx)
 {
+  if (ctx && ctx->indexed)
+    return ADAFLO_EUNSUPPORTED; // (indexed context: needs the structured brick)
   if (!ctx)
     return ADAFLO_ENOTINIT;
   const long nu = 3 * ctx->n_nodes_u, np = ctx->n_nodes_p;
@@ -1041,6 +1045,8 @@ int adaflo_ns_preconditioner_statistics(adaflo_ctx *ctx, int64_t *velocity_solve
 int adaflo_ns_preconditioner_vmult(adaflo_ctx *ctx, double *dst_u, double *dst_p, const double *src_u,
                                    const double *src_p)
 {
+  if (ctx && ctx->indexed)
+    return ADAFLO_EUNSUPPORTED; // (indexed context: needs the structured brick)
   if (!ctx)
     return ADAFLO_ENOTINIT;
   if (int rc = pc_check_built(ctx))
@@ -1208,6 +1214,8 @@ int adaflo_ns_solve_system(adaflo_ctx *ctx, double *update_u, double *update_p, 
                            const double *rhs_p, const adaflo_solver_control *control, int restart,
                            adaflo_solver_result *result)
 {
+  if (ctx && ctx->indexed)
+    return ADAFLO_EUNSUPPORTED; // (indexed context: needs the structured brick)
   if (!ctx)
     return ADAFLO_ENOTINIT;
   if (!update_u || !update_p || !rhs_u || !rhs_p || !control || !result || restart < 1)

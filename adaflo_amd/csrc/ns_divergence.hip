@@ -249,7 +249,7 @@ namespace adaflo_hip
 
   bool divergence_stencil_supported(const adaflo_ctx *ctx)
   {
-    return ctx->k == 2 && !ctx->flat;
+    return ctx->k == 2 && !ctx->flat && !ctx->indexed;
   }
 
   // dst_p += weight (q, div u) on the free pressure rows; `plain`: velocity read without resolving constraints

@@ -97,9 +97,9 @@ namespace adaflo_hip
     const NSDev &P = a.ns;
 
     // :662-667 velocity: plain read for the residual, constraints resolved otherwise
-    gather_cell<K, 3, NT, !RES, ZF>(a.src_u, ul, cx, cy, cz, nux, nuy, nuz, a.brick.con_u);
+    gather_any<K, 3, NT, !RES, ZF>(a.brick, a.src_u, ul, c, cx, cy, cz, nux, nuy, nuz, a.brick.con_u);
     if (OP != OP_VMULT_VELOCITY)
-      gather_cell<K - 1, 1, NT, !RES, ZF>(a.src_p, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
+      gather_any<K - 1, 1, NT, !RES, ZF>(a.brick, a.src_p, pl, c, cx, cy, cz, npx, npy, npz, a.brick.con_p);
     __syncthreads();
 
     // :668-671
@@ -122,13 +122,13 @@ namespace adaflo_hip
     // :673-686 old solutions for the residual
     if (RES && P.physical_type == ADAFLO_INCOMPRESSIBLE)
       {
-        gather_cell<K, 3, NT, false, ZF>(a.old_u, ul, cx, cy, cz, nux, nuy, nuz, 0u);
+        gather_any<K, 3, NT, false, ZF>(a.brick, a.old_u, ul, c, cx, cy, cz, nux, nuy, nuz, 0u);
         __syncthreads();
         if constexpr (REGQ)
           evaluate_u_reg(ul, rvo, rgo);
         else
           evaluate_u(ul, vo, go);
-        gather_cell<K, 3, NT, false, ZF>(a.oldold_u, ul, cx, cy, cz, nux, nuy, nuz, 0u);
+        gather_any<K, 3, NT, false, ZF>(a.brick, a.oldold_u, ul, c, cx, cy, cz, nux, nuy, nuz, 0u);
         __syncthreads();
         if constexpr (REGQ)
           evaluate_u_reg(ul, rvoo, rgoo);
@@ -143,8 +143,9 @@ namespace adaflo_hip
     const bool   need_extrap = P.linearization == ADAFLO_PROJECTION ||
                              P.linearization == ADAFLO_COUPLED_VELOCITY_SEMI_IMPLICIT ||
                              P.linearization == ADAFLO_COUPLED_VELOCITY_EXPLICIT;
-    const double ih[3] = {1. / a.brick.h[0], 1. / a.brick.h[1], 1. / a.brick.h[2]};
-    const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
+    const double *const hc = cell_extents(a.brick, c);
+    const double ih[3] = {1. / hc[0], 1. / hc[1], 1. / hc[2]};
+    const double det   = hc[0] * hc[1] * hc[2];
     double      *lin   = a.lin ? a.lin + (size_t)c * NLIN * NQ3 : nullptr;
 
     // :702-893 quadrature-point loop
@@ -317,7 +318,7 @@ namespace adaflo_hip
       for (int d = 0; d < 3; ++d)
         SFU::template integrate<true, true>(S_u, D_u, vu + d * NQ3, gu + (3 * d + 0) * NQ3, gu + (3 * d + 1) * NQ3,
                                             gu + (3 * d + 2) * NQ3, ul + d * NDU3, tmp);
-    scatter_cell<K, 3, NT, ZF>(a.dst_u, ul, cx, cy, cz, nux, nuy, nuz, a.brick.con_u, a.brick.colour);
+    scatter_any<K, 3, NT, ZF>(a.brick, a.dst_u, ul, c, cx, cy, cz, nux, nuy, nuz, a.brick.con_u);
     if (OP != OP_VMULT_VELOCITY && P.linearization != ADAFLO_PROJECTION)
       {
         if constexpr (REGQ)
@@ -329,7 +330,7 @@ namespace adaflo_hip
           }
         else
           SFP::template integrate<true, false>(S_p, D_p, vp, nullptr, nullptr, nullptr, pl, tmp);
-        scatter_cell<K - 1, 1, NT, ZF>(a.dst_p, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p, a.brick.colour);
+        scatter_any<K - 1, 1, NT, ZF>(a.brick, a.dst_p, pl, c, cx, cy, cz, npx, npy, npz, a.brick.con_p);
       }
   }
 
@@ -346,10 +347,10 @@ namespace adaflo_hip
     if (lds > 64 * 1024)                                                                         \
       err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_cell_kernel<K, OPV, NT, ZF>),     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-    for (int colour = 0; colour < 8 && err == hipSuccess; ++colour)                              \
-      if (const long nc = n_cells_of_colour(a.brick.ncell, colour))                              \
+    for (int colour = 0; colour < n_colours(ctx) && err == hipSuccess; ++colour)                 \
+      if (const long nc = cells_of_colour(ctx, a.brick, colour))                                 \
         {                                                                                        \
-          a.brick.colour = colour;                                                               \
+          set_colour(ctx, a.brick, colour);                                                      \
           hipLaunchKernelGGL((ns_cell_kernel<K, OPV, NT, ZF>), dim3((unsigned)nc), block, lds, ctx->stream, a); \
         }                                                                                        \
   }
@@ -478,8 +479,9 @@ namespace adaflo_hip
       }
     __syncthreads();
     const double w0 = P.physical_type == ADAFLO_INCOMPRESSIBLE ? P.weight : 0.;
-    const double ih[3] = {1. / a.brick.h[0], 1. / a.brick.h[1], 1. / a.brick.h[2]};
-    const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
+    const double *const hc = cell_extents(a.brick, c);
+    const double ih[3] = {1. / hc[0], 1. / hc[1], 1. / hc[2]};
+    const double det   = hc[0] * hc[1] * hc[2];
     for (int l = tid; l < ND3; l += NT)
       {
         constexpr int NDY = ZF == 2 ? 1 : ND, NQY = ZF == 2 ? 1 : NQ;
@@ -624,17 +626,18 @@ namespace adaflo_hip
     const int  nux = K * ncx + 1, nuy = ZF == 2 ? 1 : K * ncy + 1, nuz = ZF ? 1 : K * ncz + 1;
     const int  npx = (K - 1) * ncx + 1, npy = ZF == 2 ? 1 : (K - 1) * ncy + 1, npz = ZF ? 1 : (K - 1) * ncz + 1;
     const NSDev &P = a.ns;
-    const double ih[3] = {1. / a.brick.h[0], 1. / a.brick.h[1], 1. / a.brick.h[2]};
-    const double det   = a.brick.h[0] * a.brick.h[1] * a.brick.h[2];
+    const double *const hc = cell_extents(a.brick, c);
+    const double ih[3] = {1. / hc[0], 1. / hc[1], 1. / hc[2]};
+    const double det   = hc[0] * hc[1] * hc[2];
     const int    mode  = a.mode;
 
     if (mode == SC_DIVERGENCE || mode == SC_DIVERGENCE_VISC)
       {
         // :935-939: plain read for the projection scheme
         if (P.linearization == ADAFLO_PROJECTION)
-          gather_cell<K, 3, NT, false, ZF>(a.src, ul, cx, cy, cz, nux, nuy, nuz, 0u);
+          gather_any<K, 3, NT, false, ZF>(a.brick, a.src, ul, c, cx, cy, cz, nux, nuy, nuz, 0u);
         else
-          gather_cell<K, 3, NT, true, ZF>(a.src, ul, cx, cy, cz, nux, nuy, nuz, a.brick.con_u);
+          gather_any<K, 3, NT, true, ZF>(a.brick, a.src, ul, c, cx, cy, cz, nux, nuy, nuz, a.brick.con_u);
         __syncthreads();
         if (QU)
           for (int d = 0; d < 3; ++d)
@@ -653,7 +656,7 @@ namespace adaflo_hip
           }
         __syncthreads();
         SFP::template integrate<true, false>(S_p, D_p, vp, nullptr, nullptr, nullptr, pl, tmp);
-        scatter_cell<K - 1, 1, NT, ZF>(a.dst, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p, a.brick.colour);
+        scatter_any<K - 1, 1, NT, ZF>(a.brick, a.dst, pl, c, cx, cy, cz, npx, npy, npz, a.brick.con_p);
         return;
       }
 
@@ -664,7 +667,7 @@ namespace adaflo_hip
       __syncthreads(); // the 1D tables staged above are read across waves below (k = 5: 125 points, 4 waves)
     else
       {
-        gather_cell<K - 1, 1, NT, true, ZF>(a.src, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p);
+        gather_any<K - 1, 1, NT, true, ZF>(a.brick, a.src, pl, c, cx, cy, cz, npx, npy, npz, a.brick.con_p);
         __syncthreads();
         if (need_grad)
           SFP::template evaluate<false, true>(S_p, D_p, pl, nullptr, gp, gp + NQ3, gp + 2 * NQ3, tmp);
@@ -713,7 +716,7 @@ namespace adaflo_hip
       SFP::template integrate<false, true>(S_p, D_p, nullptr, gp, gp + NQ3, gp + 2 * NQ3, pl, tmp);
     else
       SFP::template integrate<true, false>(S_p, D_p, vp, nullptr, nullptr, nullptr, pl, tmp);
-    scatter_cell<K - 1, 1, NT, ZF>(a.dst, pl, cx, cy, cz, npx, npy, npz, a.brick.con_p, a.brick.colour);
+    scatter_any<K - 1, 1, NT, ZF>(a.brick, a.dst, pl, c, cx, cy, cz, npx, npy, npz, a.brick.con_p);
   }
 
   template <int K, int NT, int ZF = 0>
@@ -730,20 +733,20 @@ namespace adaflo_hip
         if (lds > 64 * 1024)
           err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_scalar_kernel<K, true, NT, ZF>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        for (int colour = 0; colour < 8 && err == hipSuccess; ++colour) // (no atomics in the scatter, fe_kernels.hpp)
-          if (const long nc = n_cells_of_colour(a.brick.ncell, colour))
+        for (int colour = 0; colour < n_colours(ctx) && err == hipSuccess; ++colour) // (no atomics in the scatter, fe_kernels.hpp)
+          if (const long nc = cells_of_colour(ctx, a.brick, colour))
             {
-              a.brick.colour = colour;
+              set_colour(ctx, a.brick, colour);
               hipLaunchKernelGGL((ns_scalar_kernel<K, true, NT, ZF>), dim3((unsigned)nc), block, lds, ctx->stream, a);
             }
       }
     else
       {
         const size_t lds = sizeof(double) * sc_lds_doubles<K, false, NT, ZF>();
-        for (int colour = 0; colour < 8; ++colour)
-          if (const long nc = n_cells_of_colour(a.brick.ncell, colour))
+        for (int colour = 0; colour < n_colours(ctx); ++colour)
+          if (const long nc = cells_of_colour(ctx, a.brick, colour))
             {
-              a.brick.colour = colour;
+              set_colour(ctx, a.brick, colour);
               hipLaunchKernelGGL((ns_scalar_kernel<K, false, NT, ZF>), dim3((unsigned)nc), block, lds, ctx->stream, a);
             }
       }

@@ -449,7 +449,7 @@ namespace adaflo_hip
 
   bool hox_supported(const adaflo_ctx *ctx)
   {
-    return ctx->k >= 3 && ctx->k <= 5 && !ctx->flat; // (constant and, since the two-phase mode, variable coefficients)
+    return ctx->k >= 3 && ctx->k <= 5 && !ctx->flat && !ctx->indexed; // (constant and, since the two-phase mode, variable coefficients)
   }
 
   // constant coefficients; Stokes, Newton, Picard-type, and (round 5, time-dependent equations: the old solutions exist)

@@ -1974,7 +1974,7 @@ namespace adaflo_hip
 
   bool q2_supported(const adaflo_ctx *ctx)
   {
-    if (ctx->k != 2 || ctx->flat)
+    if (ctx->k != 2 || ctx->flat || ctx->indexed) // (an indexed context has no brick to sweep)
       return false;
     if (!ctx->rho.p && !ctx->mu.p && !ctx->damp.p)
       return true;

@@ -42,6 +42,20 @@ namespace adaflo_hip
         }
     }
 
+    // the same with the constraint flags of an indexed context
+    __global__ __launch_bounds__(VT) void prepare_dst_flags_kernel(double *__restrict__ dst, const double *__restrict__ src,
+                                                                   const long n, const unsigned char *__restrict__ flags,
+                                                                   const double sign, const bool zero_rest)
+    {
+      for (long i = blockIdx.x * (long)VT + threadIdx.x; i < n; i += (long)gridDim.x * VT)
+        {
+          if (flags[i])
+            dst[i] = sign * src[i];
+          else if (zero_rest)
+            dst[i] = 0.;
+        }
+    }
+
     // dst = sign * src on the constrained faces only (:247-256): one work item per (face, node of the face,
     // component) -- 6 n^2 instead of n^3 entries; a node on several constrained faces is written more than once,
     // with the same value
@@ -350,6 +364,12 @@ namespace adaflo_hip
                          const int ncomp, const int nnx, const int nny, const int nnz,
                          const uint32_t mask, const double sign, const bool zero_rest)
   {
+    if (ctx->indexed) // (the flags of the space: three components = velocity, one = pressure)
+      {
+        hipLaunchKernelGGL(prepare_dst_flags_kernel, dim3(grid_for(n_nodes * ncomp)), dim3(VT), 0, ctx->stream, dst, src,
+                           n_nodes * ncomp, ncomp == 3 ? ctx->d_flag_u : ctx->d_flag_p, sign, zero_rest);
+        return check();
+      }
     hipLaunchKernelGGL(prepare_dst_kernel, dim3(grid_for(n_nodes * ncomp)), dim3(VT), 0, ctx->stream,
                        dst, src, n_nodes, ncomp, nnx, nny, nnz, mask, sign, zero_rest);
     return check();
@@ -358,6 +378,13 @@ namespace adaflo_hip
   int launch_constrained_faces(adaflo_ctx *ctx, double *dst, const double *src, const int ncomp, const int nnx, const int nny,
                                const int nnz, const uint32_t mask, const double sign)
   {
+    if (ctx->indexed)
+      {
+        const long n = (ncomp == 3 ? 3 * ctx->n_nodes_u : ctx->n_nodes_p);
+        hipLaunchKernelGGL(prepare_dst_flags_kernel, dim3(grid_for(n)), dim3(VT), 0, ctx->stream, dst, src, n,
+                           ncomp == 3 ? ctx->d_flag_u : ctx->d_flag_p, sign, false);
+        return check();
+      }
     if (mask == 0u)
       return 0;
     const long total = 2 * ((long)nny * nnz + (long)nnx * nnz + (long)nnx * nny) * ncomp;

@@ -69,6 +69,14 @@ class NavierStokesMatrix:
         self.mesh = mesh
         self._lib = _lib.load()
         self._ctx = None
+        self._indexed = hasattr(mesh, "cell_nodes")     # IndexedMesh: the adapter's tables instead of a brick
+        if self._indexed:
+            assert mesh.k == parameters.velocity_degree
+            self._device, self._stream = device, stream
+            self.time_stepping = None
+            self._variant = 0
+            self._has_variable_coefficients = False
+            return
         self._desc = _lib.BrickDesc()
         d = self._desc
         d.dim = mesh.dim
@@ -99,9 +107,27 @@ class NavierStokesMatrix:
     def initialize(self, time_stepping, pressure_average_fix):
         """NavierStokesMatrix::initialize, source/navier_stokes_matrix.cc:85-168"""
         self.clear()
-        self._desc.pressure_average_fix = int(bool(pressure_average_fix))
         ctx = _lib.CtxHandle()
-        code = self._lib.adaflo_ctx_create(C.byref(self._desc), C.byref(ctx))
+        if self._indexed:
+            m, k = self.mesh, self.mesh.k
+            keep = [np.ascontiguousarray(m.cell_nodes[k], dtype=np.int32), np.ascontiguousarray(m.cell_nodes[k - 1], dtype=np.int32),
+                    np.ascontiguousarray(m.constrained_u, dtype=np.uint8), np.ascontiguousarray(m.constrained_p, dtype=np.uint8),
+                    np.ascontiguousarray(m.cell_extents, dtype=np.float64), np.ascontiguousarray(m.colour_offsets, dtype=np.int64)]
+            d = _lib.IndexedDesc()
+            d.device, d.stream, d.velocity_degree = self._device, None, k
+            d.pressure_average_fix = int(bool(pressure_average_fix))
+            d.n_cells, d.n_nodes_u, d.n_nodes_p = m.n_cells, m.n_nodes(k), m.n_nodes(k - 1)
+            d.cell_nodes_u = keep[0].ctypes.data_as(C.POINTER(C.c_int))
+            d.cell_nodes_p = keep[1].ctypes.data_as(C.POINTER(C.c_int))
+            d.constrained_u = keep[2].ctypes.data_as(C.POINTER(C.c_ubyte))
+            d.constrained_p = keep[3].ctypes.data_as(C.POINTER(C.c_ubyte))
+            d.cell_extents = keep[4].ctypes.data_as(C.POINTER(C.c_double))
+            d.n_colours = len(keep[5]) - 1
+            d.colour_offsets = keep[5].ctypes.data_as(C.POINTER(C.c_int64))
+            code = self._lib.adaflo_ctx_create_indexed(C.byref(d), C.byref(ctx))
+        else:
+            self._desc.pressure_average_fix = int(bool(pressure_average_fix))
+            code = self._lib.adaflo_ctx_create(C.byref(self._desc), C.byref(ctx))
         if code != 0:
             raise _lib.AdafloError("adaflo_ctx_create failed (%d): %s" % (
                 code, self._lib.adaflo_last_error(None).decode()))

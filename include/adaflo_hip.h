@@ -108,6 +108,36 @@ typedef struct
   double extrap_old, extrap_old_old;
 } adaflo_ns_params;
 
+/* ---- indexed context (first alternative) -------------------
+ * What an adapter copies out of deal.II's MatrixFree / DoFHandler for ANY conforming Cartesian hexahedral mesh (no
+ * hanging nodes): per-cell DoF tables, constrained-DoF flags, the diagonal of every cell's Jacobian and a colouring of the
+ * cells -- replaces MatrixFree<dim>::reinit for meshes that are not one brick (an L-shaped channel, a box with an
+ * obstacle; source/navier_stokes.cc:396-502 builds its MatrixFree from whatever the triangulation is).  All arrays are
+ * HOST memory and are copied.  Numbering: velocity dof = node * 3 + component with the adapter's own node numbers
+ * (0 .. n_nodes_u - 1), pressure dof = node; inside a cell the nodes are listed lexicographically (x fastest) in the
+ * cell's local Gauss-Lobatto lattice, as FE_Q's hierarchical-to-lexicographic numbering delivers them.
+ * The context runs the GENERIC kernels of the Navier-Stokes block: adaflo_ns_vmult, _residual, _velocity_vmult,
+ * _divergence_vmult_add, _pressure_{poisson,mass,convdiff}_vmult, the pressure-mean projection, the quadrature-point stores
+ * ([cell] = the order of the tables).  The sweep kernels, the level-set operators, the device Krylov drivers and the
+ * communicator need the brick and return ADAFLO_EUNSUPPORTED. */
+typedef struct
+{
+  int     device;
+  void   *stream;              /* hipStream_t or NULL: engine-owned stream */
+  int     velocity_degree;     /* k of Q_k / Q_{k-1}, 2 ... 6 */
+  int     pressure_average_fix;
+  int64_t n_cells, n_nodes_u, n_nodes_p;
+  const int           *cell_nodes_u;  /* [n_cells][(k+1)^3] */
+  const int           *cell_nodes_p;  /* [n_cells][k^3] */
+  const unsigned char *constrained_u; /* [n_nodes_u * 3]: 1 = constrained row (Dirichlet, symmetry, ...) */
+  const unsigned char *constrained_p; /* [n_nodes_p] */
+  const double        *cell_extents;  /* [n_cells][3] edge lengths hx, hy, hz of every cell, or NULL: all cells `h` */
+  double               h[3];
+  int                  n_colours;     /* the cells are sorted by colour: colour c = cells [colour_offsets[c], colour_offsets[c+1]) */
+  const int64_t       *colour_offsets; /* [n_colours + 1]; no two cells of one colour share a node */
+} adaflo_indexed_desc;
+int         adaflo_ctx_create_indexed(const adaflo_indexed_desc *desc, adaflo_ctx **out);
+
 /* ---- context ------------------------------------------------------------ */
 int         adaflo_ctx_create(const adaflo_brick_desc *desc, adaflo_ctx **out);
 int         adaflo_ctx_destroy(adaflo_ctx *ctx);              /* NavierStokesMatrix::clear */
