@@ -2127,14 +2127,22 @@ int adaflo_ls_compute_force(adaflo_ctx *ctx, double *user_rhs_u, const double *h
     {
       const size_t count = (size_t)ctx->n_cells * ctx->nq_u;
       const bool   had_damping = ctx->damp.p != nullptr;
-      TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
+      // (as adaflo_ns_set_coefficients: a state that exists only as the Q2/Q1 streaming copy WITHOUT coefficient pieces does
+      // not depend on the coefficients and stays what it is -- this runs once per time step of a two-phase run, and the
+      // re-layout it used to force was ~3 ms at 128^3 for nothing)
+      const bool keep_q2 = ctx->lin_q2.p && ctx->lin_q2_valid && !ctx->lin_q2_varco && !ctx->lin_generic_valid && !ctx->hox_lin_primary;
+      if (!keep_q2)
+        TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
       TRY(ctx, alloc(ctx, ctx->rho, count), ctx->last_error);
       TRY(ctx, alloc(ctx, ctx->mu, count), ctx->last_error);
       TRY(ctx, alloc(ctx, ctx->damp, count), ctx->last_error);
       if (!had_damping) // variable_damping_coefficients default to parameters.damping
         TRY(ctx, launch_fill(ctx, ctx->damp.p, ctx->ns.damping, (long)count), "fill failed");
-      ctx->lin_q2_valid    = false; // the streaming copies of the sweep kernels carry the coefficients
-      ctx->hox_lin_primary = false;
+      if (!keep_q2)
+        {
+          ctx->lin_q2_valid    = false; // the streaming copies of the sweep kernels carry the coefficients
+          ctx->hox_lin_primary = false;
+        }
       ctx->lin_gen++;
       ctx->q1_poisson_src = nullptr;
     }
