@@ -9,4 +9,4 @@ from .parameters import FlowParameters, flow_parameters_from_prm  # noqa: F401
 from .time_stepping import TimeStepping  # noqa: F401
 from .vectors import BlockVector, DeviceVector  # noqa: F401
 from .navier_stokes_matrix import BrickMesh, NavierStokesMatrix  # noqa: F401
-from .indexed_mesh import IndexedMesh  # noqa: F401
+from .indexed_mesh import IndexedMesh, RefinedMesh  # noqa: F401

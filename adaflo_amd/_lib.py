@@ -24,7 +24,11 @@ class IndexedDesc(C.Structure):
                 ("cell_nodes_u", C.POINTER(C.c_int)), ("cell_nodes_p", C.POINTER(C.c_int)),
                 ("constrained_u", C.POINTER(C.c_ubyte)), ("constrained_p", C.POINTER(C.c_ubyte)),
                 ("cell_extents", C.POINTER(C.c_double)), ("h", C.c_double * 3),
-                ("n_colours", C.c_int), ("colour_offsets", C.POINTER(C.c_int64))]
+                ("n_colours", C.c_int), ("colour_offsets", C.POINTER(C.c_int64)),
+                ("n_hanging_u", C.c_int64), ("n_hanging_p", C.c_int64),
+                ("hanging_ptr_u", C.POINTER(C.c_int64)), ("hanging_ptr_p", C.POINTER(C.c_int64)),
+                ("hanging_master_u", C.POINTER(C.c_int)), ("hanging_master_p", C.POINTER(C.c_int)),
+                ("hanging_weight_u", C.POINTER(C.c_double)), ("hanging_weight_p", C.POINTER(C.c_double))]
 
 
 class LSParams(C.Structure):

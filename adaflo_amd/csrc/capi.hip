@@ -367,9 +367,41 @@ static int ctx_create_indexed_impl(const adaflo_indexed_desc *d, adaflo_ctx *ctx
   if (d->n_nodes_u > 0x7fffffffLL / 3 || d->n_cells > 0x7fffffffLL)
     return fail(nullptr, ADAFLO_EUNSUPPORTED, "indexed context: 32-bit node tables");
   const long nu3 = (long)(k + 1) * (k + 1) * (k + 1), np3 = (long)k * k * k;
-  // the tables must be usable: indices in range, and no node twice inside one colour (the scatter has no atomics)
+  // hanging-node constraints (optional): CSR rows of (master, weight); masters are regular nodes
+  const int64_t nh_u = d->n_hanging_u, nh_p = d->n_hanging_p;
+  if (nh_u < 0 || nh_p < 0 || nh_u > 0x7fffffffLL || nh_p > 0x7fffffffLL ||
+      (nh_u > 0 && (!d->hanging_ptr_u || !d->hanging_master_u || !d->hanging_weight_u)) ||
+      (nh_p > 0 && (!d->hanging_ptr_p || !d->hanging_master_p || !d->hanging_weight_p)))
+    return fail(nullptr, ADAFLO_EINVAL, "indexed context: missing hanging-node table");
+  auto check_hanging = [](const int64_t nh, const int64_t *ptr, const int *master, const int64_t n_nodes) -> bool {
+    if (nh == 0)
+      return true;
+    if (ptr[0] != 0)
+      return false;
+    for (int64_t h = 0; h < nh; ++h)
+      {
+        if (ptr[h + 1] <= ptr[h])
+          return false;
+        for (int64_t j = ptr[h]; j < ptr[h + 1]; ++j)
+          if (master[j] < 0 || master[j] >= n_nodes)
+            return false;
+      }
+    return true;
+  };
+  if (!check_hanging(nh_u, d->hanging_ptr_u, d->hanging_master_u, d->n_nodes_u) ||
+      !check_hanging(nh_p, d->hanging_ptr_p, d->hanging_master_p, d->n_nodes_p))
+    return fail(nullptr, ADAFLO_EINVAL, "indexed context: hanging-node rows must be non-empty, ascending and name regular nodes");
+  // the tables must be usable: indices in range, and no node twice inside one colour (the scatter has no atomics; a
+  // hanging entry writes to its masters)
   {
     std::vector<int> seen_u((size_t)d->n_nodes_u, -1), seen_p((size_t)d->n_nodes_p, -1);
+    auto visit = [](std::vector<int> &seen, const int node, const int cell_in_colour) -> bool {
+      int &s = seen[node];
+      if (s >= 0 && s != cell_in_colour)
+        return false;
+      s = cell_in_colour;
+      return true;
+    };
     for (int c = 0; c < d->n_colours; ++c)
       {
         if (d->colour_offsets[c + 1] < d->colour_offsets[c])
@@ -379,32 +411,44 @@ static int ctx_create_indexed_impl(const adaflo_indexed_desc *d, adaflo_ctx *ctx
             for (long l = 0; l < nu3; ++l)
               {
                 const int n = d->cell_nodes_u[cell * nu3 + l];
-                if (n < 0 || n >= d->n_nodes_u)
+                if (n < -nh_u || n >= d->n_nodes_u)
                   return fail(nullptr, ADAFLO_EINVAL, "indexed context: velocity node index out of range");
               }
             for (long l = 0; l < np3; ++l)
               {
                 const int n = d->cell_nodes_p[cell * np3 + l];
-                if (n < 0 || n >= d->n_nodes_p)
+                if (n < -nh_p || n >= d->n_nodes_p)
                   return fail(nullptr, ADAFLO_EINVAL, "indexed context: pressure node index out of range");
               }
           }
-        // two cells of colour c sharing a node: mark the nodes of every cell with (colour, cell) and look for a second owner
+        // two cells of colour c sharing a node: mark the nodes of every cell with its number inside the colour and look
+        // for a second owner
         for (int64_t cell = d->colour_offsets[c]; cell < d->colour_offsets[c + 1]; ++cell)
           {
+            const int me = (int)(cell - d->colour_offsets[c]);
             for (long l = 0; l < nu3; ++l)
               {
-                int &s = seen_u[d->cell_nodes_u[cell * nu3 + l]];
-                if (s >= 0 && s != (int)(cell - d->colour_offsets[c]))
+                const int n  = d->cell_nodes_u[cell * nu3 + l];
+                bool      ok = true;
+                if (n >= 0)
+                  ok = visit(seen_u, n, me);
+                else
+                  for (int64_t j = d->hanging_ptr_u[-1 - n]; j < d->hanging_ptr_u[-n] && ok; ++j)
+                    ok = visit(seen_u, d->hanging_master_u[j], me);
+                if (!ok)
                   return fail(nullptr, ADAFLO_EINVAL, "indexed context: two cells of one colour share a velocity node");
-                s = (int)(cell - d->colour_offsets[c]);
               }
             for (long l = 0; l < np3; ++l)
               {
-                int &s = seen_p[d->cell_nodes_p[cell * np3 + l]];
-                if (s >= 0 && s != (int)(cell - d->colour_offsets[c]))
+                const int n  = d->cell_nodes_p[cell * np3 + l];
+                bool      ok = true;
+                if (n >= 0)
+                  ok = visit(seen_p, n, me);
+                else
+                  for (int64_t j = d->hanging_ptr_p[-1 - n]; j < d->hanging_ptr_p[-n] && ok; ++j)
+                    ok = visit(seen_p, d->hanging_master_p[j], me);
+                if (!ok)
                   return fail(nullptr, ADAFLO_EINVAL, "indexed context: two cells of one colour share a pressure node");
-                s = (int)(cell - d->colour_offsets[c]);
               }
           }
         std::fill(seen_u.begin(), seen_u.end(), -1);
@@ -452,6 +496,20 @@ static int ctx_create_indexed_impl(const adaflo_indexed_desc *d, adaflo_ctx *ctx
   ctx->brick.flag_u = ctx->d_flag_u;
   ctx->brick.flag_p = ctx->d_flag_p;
   ctx->brick.cell_h = ctx->d_cell_h;
+  if (nh_u > 0)
+    {
+      TRY(nullptr, up(&ctx->d_hang_ptr_u, (const long *)d->hanging_ptr_u, (size_t)nh_u + 1), "indexed context: table upload failed");
+      TRY(nullptr, up(&ctx->d_hang_master_u, d->hanging_master_u, (size_t)d->hanging_ptr_u[nh_u]), "indexed context: table upload failed");
+      TRY(nullptr, up(&ctx->d_hang_weight_u, d->hanging_weight_u, (size_t)d->hanging_ptr_u[nh_u]), "indexed context: table upload failed");
+      ctx->brick.hang_ptr_u = ctx->d_hang_ptr_u, ctx->brick.hang_master_u = ctx->d_hang_master_u, ctx->brick.hang_weight_u = ctx->d_hang_weight_u;
+    }
+  if (nh_p > 0)
+    {
+      TRY(nullptr, up(&ctx->d_hang_ptr_p, (const long *)d->hanging_ptr_p, (size_t)nh_p + 1), "indexed context: table upload failed");
+      TRY(nullptr, up(&ctx->d_hang_master_p, d->hanging_master_p, (size_t)d->hanging_ptr_p[nh_p]), "indexed context: table upload failed");
+      TRY(nullptr, up(&ctx->d_hang_weight_p, d->hanging_weight_p, (size_t)d->hanging_ptr_p[nh_p]), "indexed context: table upload failed");
+      ctx->brick.hang_ptr_p = ctx->d_hang_ptr_p, ctx->brick.hang_master_p = ctx->d_hang_master_p, ctx->brick.hang_weight_p = ctx->d_hang_weight_p;
+    }
   // pressure constant mode 0, source/navier_stokes_matrix.cc:117-168 (as in ctx_create_impl, through the tables)
   if (d->pressure_average_fix)
     {
@@ -536,7 +594,9 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
                     ctx->d_tab_ls, ctx->d_ls_diag, ctx->d_tab_force, ctx->d_tab_maxvel})
     if (p)
       (void)hipFree(p);
-  for (void *p : {(void *)ctx->d_idx_u, (void *)ctx->d_idx_p, (void *)ctx->d_flag_u, (void *)ctx->d_flag_p, (void *)ctx->d_cell_h})
+  for (void *p : {(void *)ctx->d_idx_u, (void *)ctx->d_idx_p, (void *)ctx->d_flag_u, (void *)ctx->d_flag_p, (void *)ctx->d_cell_h,
+                  (void *)ctx->d_hang_ptr_u, (void *)ctx->d_hang_ptr_p, (void *)ctx->d_hang_master_u, (void *)ctx->d_hang_master_p,
+                  (void *)ctx->d_hang_weight_u, (void *)ctx->d_hang_weight_p})
     if (p)
       (void)hipFree(p);
   fdm_destroy(ctx);

@@ -115,6 +115,9 @@ struct adaflo_ctx
   int              *d_idx_u = nullptr, *d_idx_p = nullptr;
   unsigned char    *d_flag_u = nullptr, *d_flag_p = nullptr;
   double           *d_cell_h = nullptr;
+  long             *d_hang_ptr_u = nullptr, *d_hang_ptr_p = nullptr; // hanging-node constraints (CSR), optional
+  int              *d_hang_master_u = nullptr, *d_hang_master_p = nullptr;
+  double           *d_hang_weight_u = nullptr, *d_hang_weight_p = nullptr;
   adaflo_hip::NSDev    ns{};
   bool                 ns_params_set = false;
 

@@ -33,6 +33,11 @@ namespace adaflo_hip
     const unsigned char *flag_u = nullptr, *flag_p = nullptr; // [n_nodes_u * 3], [n_nodes_p]
     const double        *cell_h = nullptr;                    // [n_cells][3] or null (h above)
     long                 cell_first = 0;
+    // hanging nodes (one level of local refinement): a table entry < 0 is hanging node h = -1 - entry; its value is
+    // sum_j w_j value(master_j), j in [ptr[h], ptr[h+1]) -- what MatrixFree applies to the cells at a refined face / edge
+    const long   *hang_ptr_u = nullptr, *hang_ptr_p = nullptr;
+    const int    *hang_master_u = nullptr, *hang_master_p = nullptr;
+    const double *hang_weight_u = nullptr, *hang_weight_p = nullptr;
   };
   // number of cells of a colour
   inline long n_cells_of_colour(const int ncell[3], const int colour)
@@ -496,30 +501,68 @@ namespace adaflo_hip
   // (NC = 3: velocity space, node table / flags of degree DEG = k; NC = 1: pressure space)
   template <int DEG, int NC, int NT, bool RESOLVE>
   __device__ void gather_cell_indexed(const double *__restrict__ vec, double *loc, const int *__restrict__ nodes,
-                                      const unsigned char *__restrict__ flags)
+                                      const unsigned char *__restrict__ flags, const long *__restrict__ hptr,
+                                      const int *__restrict__ hmaster, const double *__restrict__ hweight)
   {
     constexpr int ND3 = (DEG + 1) * (DEG + 1) * (DEG + 1);
     for (int o = threadIdx.x; o < ND3 * NC; o += NT)
       {
-        const int  c = o % NC, l = o / NC;
-        const long dof = (long)nodes[l] * NC + c;
-        double     v   = vec[dof];
-        if (RESOLVE && flags[dof])
-          v = 0.;
+        const int c = o % NC, l = o / NC, node = nodes[l];
+        double    v = 0.;
+        if (node >= 0)
+          {
+            const long dof = (long)node * NC + c;
+            v              = vec[dof];
+            if (RESOLVE && flags[dof])
+              v = 0.;
+          }
+        else // hanging node: interpolate its masters (read_dof_values resolves the constraint)
+          for (long j = hptr[-1 - node]; j < hptr[-node]; ++j)
+            {
+              const long dof = (long)hmaster[j] * NC + c;
+              if (!(RESOLVE && flags[dof]))
+                v += hweight[j] * vec[dof];
+            }
         loc[c * ND3 + l] = v;
       }
   }
   template <int DEG, int NC, int NT>
   __device__ void scatter_cell_indexed(double *__restrict__ vec, const double *loc, const int *__restrict__ nodes,
-                                       const unsigned char *__restrict__ flags)
+                                       const unsigned char *__restrict__ flags, const long *__restrict__ hptr,
+                                       const int *__restrict__ hmaster, const double *__restrict__ hweight)
   {
     constexpr int ND3 = (DEG + 1) * (DEG + 1) * (DEG + 1);
+    bool          any_hanging = false;
     for (int o = threadIdx.x; o < ND3 * NC; o += NT)
       {
-        const int  c = o % NC, l = o / NC;
-        const long dof = (long)nodes[l] * NC + c;
+        const int c = o % NC, l = o / NC, node = nodes[l];
+        if (node < 0)
+          {
+            any_hanging = true;
+            continue;
+          }
+        const long dof = (long)node * NC + c;
         if (!flags[dof])
           vec[dof] += loc[c * ND3 + l];
+      }
+    // hanging entries: their sums go to the masters with the weights (distribute_local_to_global).  A master may be a
+    // regular node of this very cell, and two hanging nodes share masters: one thread per component walks them in table
+    // order, behind the plain adds of the whole workgroup -- no atomics, the order of the additions is fixed
+    if (hptr && __syncthreads_or(any_hanging))
+      {
+        __threadfence_block();
+        if (threadIdx.x < NC)
+          {
+            const int c = threadIdx.x;
+            for (int l = 0; l < ND3; ++l)
+              if (nodes[l] < 0)
+                for (long j = hptr[-1 - nodes[l]]; j < hptr[-nodes[l]]; ++j)
+                  {
+                    const long dof = (long)hmaster[j] * NC + c;
+                    if (!flags[dof])
+                      vec[dof] += hweight[j] * loc[c * ND3 + l];
+                  }
+          }
       }
   }
   // brick or table, by what the context carries (`c`: the cell; `resolve`: the caller's mask != "none")
@@ -531,7 +574,9 @@ namespace adaflo_hip
     if (ZF == 0 && b.idx_u)
       {
         constexpr int ND3 = (DEG + 1) * (DEG + 1) * (DEG + 1);
-        gather_cell_indexed<DEG, NC, NT, RESOLVE>(vec, loc, (NC == 3 ? b.idx_u : b.idx_p) + c * ND3, NC == 3 ? b.flag_u : b.flag_p);
+        gather_cell_indexed<DEG, NC, NT, RESOLVE>(vec, loc, (NC == 3 ? b.idx_u : b.idx_p) + c * ND3, NC == 3 ? b.flag_u : b.flag_p,
+                                                  NC == 3 ? b.hang_ptr_u : b.hang_ptr_p, NC == 3 ? b.hang_master_u : b.hang_master_p,
+                                                  NC == 3 ? b.hang_weight_u : b.hang_weight_p);
       }
     else
       gather_cell<DEG, NC, NT, RESOLVE, ZF>(vec, loc, cx, cy, cz, nnx, nny, nnz, mask);
@@ -544,7 +589,9 @@ namespace adaflo_hip
     if (ZF == 0 && b.idx_u)
       {
         constexpr int ND3 = (DEG + 1) * (DEG + 1) * (DEG + 1);
-        scatter_cell_indexed<DEG, NC, NT>(vec, loc, (NC == 3 ? b.idx_u : b.idx_p) + c * ND3, NC == 3 ? b.flag_u : b.flag_p);
+        scatter_cell_indexed<DEG, NC, NT>(vec, loc, (NC == 3 ? b.idx_u : b.idx_p) + c * ND3, NC == 3 ? b.flag_u : b.flag_p,
+                                          NC == 3 ? b.hang_ptr_u : b.hang_ptr_p, NC == 3 ? b.hang_master_u : b.hang_master_p,
+                                          NC == 3 ? b.hang_weight_u : b.hang_weight_p);
       }
     else
       scatter_cell<DEG, NC, NT, ZF>(vec, loc, cx, cy, cz, nnx, nny, nnz, mask, b.colour);

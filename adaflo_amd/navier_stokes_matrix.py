@@ -124,6 +124,15 @@ class NavierStokesMatrix:
             d.cell_extents = keep[4].ctypes.data_as(C.POINTER(C.c_double))
             d.n_colours = len(keep[5]) - 1
             d.colour_offsets = keep[5].ctypes.data_as(C.POINTER(C.c_int64))
+            for name, degree in (("u", k), ("p", k - 1)):        # hanging-node constraints (RefinedMesh), optional
+                ptr, master, weight = getattr(m, "hanging", {}).get(degree, (np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0)))
+                if len(ptr) > 1:
+                    keep += [np.ascontiguousarray(ptr, dtype=np.int64), np.ascontiguousarray(master, dtype=np.int32),
+                             np.ascontiguousarray(weight, dtype=np.float64)]
+                    setattr(d, "n_hanging_" + name, len(ptr) - 1)
+                    setattr(d, "hanging_ptr_" + name, keep[-3].ctypes.data_as(C.POINTER(C.c_int64)))
+                    setattr(d, "hanging_master_" + name, keep[-2].ctypes.data_as(C.POINTER(C.c_int)))
+                    setattr(d, "hanging_weight_" + name, keep[-1].ctypes.data_as(C.POINTER(C.c_double)))
             code = self._lib.adaflo_ctx_create_indexed(C.byref(d), C.byref(ctx))
         else:
             self._desc.pressure_average_fix = int(bool(pressure_average_fix))

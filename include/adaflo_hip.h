@@ -109,10 +109,11 @@ typedef struct
 } adaflo_ns_params;
 
 /* ---- indexed context (first alternative) -------------------
- * What an adapter copies out of deal.II's MatrixFree / DoFHandler for ANY conforming Cartesian hexahedral mesh (no
- * hanging nodes): per-cell DoF tables, constrained-DoF flags, the diagonal of every cell's Jacobian and a colouring of the
- * cells -- replaces MatrixFree<dim>::reinit for meshes that are not one brick (an L-shaped channel, a box with an
- * obstacle; source/navier_stokes.cc:396-502 builds its MatrixFree from whatever the triangulation is).  All arrays are
+ * What an adapter copies out of deal.II's MatrixFree / DoFHandler for ANY Cartesian hexahedral mesh, locally refined ones
+ * included: per-cell DoF tables, constrained-DoF flags, hanging-node constraints, the diagonal of every cell's Jacobian and
+ * a colouring of the cells -- replaces MatrixFree<dim>::reinit for meshes that are not one brick (an L-shaped channel, a
+ * box with an obstacle, the two refined cells of tests/beltrami.cc:403-412; source/navier_stokes.cc:396-502 builds its
+ * MatrixFree from whatever the triangulation is).  All arrays are
  * HOST memory and are copied.  Numbering: velocity dof = node * 3 + component with the adapter's own node numbers
  * (0 .. n_nodes_u - 1), pressure dof = node; inside a cell the nodes are listed lexicographically (x fastest) in the
  * cell's local Gauss-Lobatto lattice, as FE_Q's hierarchical-to-lexicographic numbering delivers them.
@@ -134,7 +135,17 @@ typedef struct
   const double        *cell_extents;  /* [n_cells][3] edge lengths hx, hy, hz of every cell, or NULL: all cells `h` */
   double               h[3];
   int                  n_colours;     /* the cells are sorted by colour: colour c = cells [colour_offsets[c], colour_offsets[c+1]) */
-  const int64_t       *colour_offsets; /* [n_colours + 1]; no two cells of one colour share a node */
+  const int64_t       *colour_offsets; /* [n_colours + 1]; no two cells of one colour share a node (masters of hanging nodes count) */
+  /* Hanging nodes (AffineConstraints lines with entries, DoFTools::make_hanging_node_constraints, source/navier_stokes.cc:241-242): a cell
+   * table entry e < 0 names hanging node h = -1 - e, whose value is sum_j weight[j] * value(master[j]), j in
+   * [ptr[h], ptr[h+1]) -- FEEvaluation::read_dof_values interpolates, distribute_local_to_global sends the cell's sums to
+   * the masters with the same weights.  Masters are regular nodes (chains resolved by the adapter, as AffineConstraints::
+   * close() does).  In the vectors a hanging node keeps its own number and is flagged in constrained_u / _p, so its row
+   * is the identity like every constrained row (navier_stokes_matrix.cc:247-256).  All zero / NULL: no hanging nodes. */
+  int64_t              n_hanging_u, n_hanging_p;
+  const int64_t       *hanging_ptr_u, *hanging_ptr_p;       /* [n_hanging + 1] */
+  const int           *hanging_master_u, *hanging_master_p; /* [ptr[n_hanging]] node numbers */
+  const double        *hanging_weight_u, *hanging_weight_p; /* [ptr[n_hanging]] */
 } adaflo_indexed_desc;
 int         adaflo_ctx_create_indexed(const adaflo_indexed_desc *desc, adaflo_ctx **out);
 
