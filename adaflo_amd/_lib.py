@@ -188,6 +188,7 @@ SIGNATURES = {
     "adaflo_get_kernel_statistics": (C.c_int, [_CTX, C.POINTER(C.c_uint), C.POINTER(C.c_double)]),
     "adaflo_set_timing": (C.c_int, [_CTX, C.c_int]),
     "adaflo_set_q2_chunk": (C.c_int, [_CTX, C.c_int]),
+    "adaflo_set_q2_lazy_state": (C.c_int, [_CTX, C.c_int]),
     "adaflo_set_hox_chunk": (C.c_int, [_CTX, C.c_int]),
     "adaflo_set_q2_state_pad": (C.c_int, [_CTX, C.c_int]),
 }

@@ -125,13 +125,16 @@ namespace
   // is a linearisation point stored (in either layout)?
   bool has_lin(const adaflo_ctx *ctx)
   {
-    return (ctx->lin.p && ctx->lin_generic_valid) || (ctx->lin_q2.p && ctx->lin_q2_valid) || ctx->hox_lin_primary;
+    return (ctx->lin.p && ctx->lin_generic_valid) || (ctx->lin_q2.p && ctx->lin_q2_valid) || ctx->hox_lin_primary || ctx->lin_q2_deferred;
   }
 
   // the generic copy [cell][12][q] of the state, rebuilt from the streaming copy the sweep-kernel
   // residual wrote if it is stale
   int ensure_lin_generic(adaflo_ctx *ctx)
   {
+    if (!ctx->lin_generic_valid && ctx->lin_q2_deferred) // (lazy state of the Q2/Q1 residual: lay it out first)
+      if (int e = q2_materialize_state(ctx))
+        return e;
     if (!ctx->lin_generic_valid && ctx->hox_lin_primary)
       {
         // the residual mode of the x-marching kernel left the state in its streaming layout only
@@ -581,7 +584,7 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
   for (DeviceBuffer *b : {&ctx->lin, &ctx->rho, &ctx->mu, &ctx->damp, &ctx->lin_prec, &ctx->rho_prec,
                           &ctx->mu_prec, &ctx->damp_prec, &ctx->lin_q2, &ctx->lin_q2_prec,
-                          &ctx->q2_slab_u, &ctx->q2_zslab_u, &ctx->q2_slab_p, &ctx->q2_zslab_p,
+                          &ctx->q2_slab_u, &ctx->q2_zslab_u, &ctx->q2_slab_p, &ctx->q2_zslab_p, &ctx->q2_state_sink,
                           &ctx->ls_convection, &ctx->ls_normal, &ctx->q1_convection, &ctx->q1_normal, &ctx->q1_normal_nodal, &ctx->q1_velocity_nodal,
                           &ctx->q1_slab, &ctx->q1_zslab, &ctx->pc_inv_u, &ctx->pc_inv_pm, &ctx->pc_inv_pl,
                           &ctx->pc_ones_p, &ctx->pc_tmp_u, &ctx->pc_tmp_p, &ctx->pc_tmp_p2, &ctx->pc_work, &ctx->kr_work, &ctx->kr_basis, &ctx->kr_scalars,
@@ -735,6 +738,7 @@ int adaflo_ns_set_params(adaflo_ctx *ctx, const adaflo_ns_params *p)
       // adaflo_ns_fix_linearization_point (its kernel would be instantiated for the NEW scheme)
       TRY(ctx, ensure_lin_prec_generic(ctx), "state re-layout failed");
       ctx->lin_q2_valid    = false;
+      ctx->lin_q2_deferred = false;      // (laid out by ensure_lin_generic above, if it was deferred)
       ctx->hox_lin_primary      = false; // (the generic copies are current now; the x-marching kernel re-creates its own)
       ctx->hox_lin_prec_primary = false;
       release(ctx->lin_q2_prec);
@@ -764,6 +768,7 @@ int adaflo_ns_set_linearization(adaflo_ctx *ctx, const double *lin, int src_on_d
   TRY(ctx, launch_transpose_state(ctx, ctx->lin.p, src, ctx->n_cells, ctx->nq_u, NLIN, true),
       "state re-layout failed");
   ctx->lin_q2_valid      = false;
+  ctx->lin_q2_deferred   = false;
   ctx->lin_generic_valid = true;
   ctx->lin_gen++;
   ctx->lin_serial++; // (a state that did not come from a nodal field the engine knows: nothing to recompute from)
@@ -809,7 +814,8 @@ int adaflo_ns_set_coefficients(adaflo_ctx *ctx, const double *rho, const double 
   // the variable-coefficient one) is independent of the coefficients: it stays what it is (every time step of a two-phase
   // run sets new coefficients before its first residual -- re-laying out the state of the step before would be 3 ms at
   // 128^3 for nothing); whoever needs another layout later converts then (ensure_lin_generic, q2_launch)
-  const bool keep_q2 = ctx->lin_q2.p && ctx->lin_q2_valid && !ctx->lin_q2_varco && !ctx->lin_generic_valid && !ctx->hox_lin_primary;
+  const bool keep_q2 = (ctx->lin_q2.p && ctx->lin_q2_valid && !ctx->lin_q2_varco && !ctx->lin_generic_valid && !ctx->hox_lin_primary) ||
+                       ctx->lin_q2_deferred; // (a deferred state is a function of the nodal field alone)
   if (!keep_q2)
     {
       TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
@@ -859,6 +865,7 @@ int adaflo_ns_get_coefficients(adaflo_ctx *ctx, double *rho, double *mu, double 
 int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx)
 {
   CHECK_CTX(ctx);
+  TRY(ctx, q2_materialize_state(ctx), "state layout failed"); // (lazy state of the Q2/Q1 residual: the frozen copies are made from the laid-out one)
   // with the sweep kernels only the streaming copy is frozen; the generic frozen copy is rebuilt
   // from it on demand (ensure_lin_prec_generic)
   const bool streaming_only = ctx->variant >= 1 && q2_supported(ctx) && needs_lin(ctx) && ctx->lin_q2.p &&
@@ -1049,6 +1056,7 @@ int adaflo_ns_residual(adaflo_ctx *ctx, double *rhs_u, double *rhs_p, const doub
   if (ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE && (!old_u || !old_old_u))
     return fail(ctx, ADAFLO_EINVAL, "solution_old / solution_old_old required");
   ctx->lin_serial++; // (whatever path: the state is that of src from here on)
+  ctx->lin_q2_deferred = false;
   if (ctx->variant >= 1 && q2_residual_supported(ctx))
     {
       // sweep kernel in residual mode: cell-loop sums into work vectors, then
@@ -1476,6 +1484,13 @@ int adaflo_set_q2_state_pad(adaflo_ctx *ctx, int pad_16B)
   TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
   ctx->q2_state_pad = pad_16B;
   ctx->lin_q2_valid = false;
+  return 0;
+}
+
+int adaflo_set_q2_lazy_state(adaflo_ctx *ctx, int lazy)
+{
+  CHECK_CTX(ctx);
+  ctx->q2_lazy_state = lazy != 0; // (a state that is deferred right now stays deferred until somebody asks for it)
   return 0;
 }
 
@@ -2190,7 +2205,8 @@ int adaflo_ls_compute_force(adaflo_ctx *ctx, double *user_rhs_u, const double *h
       // (as adaflo_ns_set_coefficients: a state that exists only as the Q2/Q1 streaming copy WITHOUT coefficient pieces does
       // not depend on the coefficients and stays what it is -- this runs once per time step of a two-phase run, and the
       // re-layout it used to force was ~3 ms at 128^3 for nothing)
-      const bool keep_q2 = ctx->lin_q2.p && ctx->lin_q2_valid && !ctx->lin_q2_varco && !ctx->lin_generic_valid && !ctx->hox_lin_primary;
+      const bool keep_q2 = (ctx->lin_q2.p && ctx->lin_q2_valid && !ctx->lin_q2_varco && !ctx->lin_generic_valid && !ctx->hox_lin_primary) ||
+                       ctx->lin_q2_deferred; // (a deferred state is a function of the nodal field alone)
       if (!keep_q2)
         TRY(ctx, ensure_lin_generic(ctx), "state re-layout failed");
       TRY(ctx, alloc(ctx, ctx->rho, count), ctx->last_error);

@@ -203,6 +203,8 @@ namespace adaflo_hip
   int  launch_ns_residual_q2(adaflo_ctx *ctx, double *sum_u, double *sum_p, const double *src_u,
                              const double *src_p, const double *old_comb, const double *ext_comb = nullptr);
   int  q2_unconvert_state(adaflo_ctx *ctx, double *generic, const double *streaming, int lin_mode);
+  // lazy state: lays out the state a residual deferred (ctx->lin_q2_deferred), no-op otherwise
+  int  q2_materialize_state(adaflo_ctx *ctx);
   int  launch_ns_divergence_q2(adaflo_ctx *ctx, double *sum_p, const double *src_u, const double *any_p, double weight);
   // dst[i] += src[i] for the entries that are not on a constrained face
   int launch_add_unconstrained(adaflo_ctx *ctx, double *dst, const double *src, long n_nodes, int ncomp, int nnx,

@@ -1997,6 +1997,8 @@ namespace adaflo_hip
 
   int q2_prepare_state(adaflo_ctx *ctx)
   {
+    if (int e = q2_materialize_state(ctx))
+      return e;
     if (ctx->lin_q2_valid || q2_lin_mode(ctx) == 2)
       return 0;
     // (the streaming copy is rebuilt from the generic one, which must exist and be current:
@@ -2062,7 +2064,8 @@ namespace adaflo_hip
   // can be packed), 2 = the remaining interior workgroups + the rest of the fix-up.
   static int q2_launch(adaflo_ctx *ctx, const int op, double *dst_u, double *dst_p, const double *src_u,
                        const double *src_p, const int phase, const uint32_t iface, const bool residual,
-                       const double *res_old, const double res_c_old, const double *res_ext = nullptr)
+                       const double *res_old, const double res_c_old, const double *res_ext = nullptr,
+                       const bool discard_state = false)
   {
     // recompute-state mode (default of kernel variant 1 since round 5; variant 4 streams): Newton vmult / velocity_vmult
     // on the nodal linearisation point the last residual left (only then is the state a function of a nodal field the
@@ -2074,6 +2077,8 @@ namespace adaflo_hip
     const bool rc_varco  = recompute && (frozen ? ctx->rho_prec.p != nullptr : q2_varco(ctx));
     if (!residual && op != OP_DIVERGENCE && !recompute)
       {
+        if (int e = q2_materialize_state(ctx)) // (a residual deferred the layout of the state this kernel streams)
+          return e;
         if (ctx->lin_q2_valid && (ctx->lin_q2_mode != q2_lin_mode(ctx) || ctx->lin_q2_varco != q2_varco(ctx)))
           {
             // (a streaming copy without coefficient pieces that is THE state -- the variable-coefficient residual wrote
@@ -2117,7 +2122,7 @@ namespace adaflo_hip
       A.rho = ctx->rho.p, A.mu = ctx->mu.p, A.damp = ctx->damp.p;
     A.c_old     = res_c_old;
     A.ext_u     = res_ext; // (residual of the semi-implicit / explicit scheme: the extrapolated velocity at the nodes)
-    A.state_out = residual ? ctx->lin_q2.p : nullptr;
+    A.state_out = residual ? (discard_state ? ctx->q2_state_sink.p : ctx->lin_q2.p) : nullptr;
     A.c_div     = res_c_old; // (divergence mode passes its weight here)
     A.ncx = ctx->desc.ncell[0];
     A.ncy = ctx->desc.ncell[1];
@@ -2182,6 +2187,8 @@ namespace adaflo_hip
     const bool use_prec = op == OP_VMULT_VELOCITY && ctx->lin_q2_prec.p;
     const bool varco    = residual ? false : (use_prec ? ctx->lin_q2_prec_varco : q2_varco(ctx));
     A.state_stride = 27L * 2 * 4 * (varco ? 64 : 48) + ctx->q2_state_pad;
+    if (residual && discard_state)
+      A.state_stride = 0; // every (tile, layer) block of the state lands on the one block of the sink
     A.con_u       = ctx->brick.con_u;
     A.con_p       = ctx->brick.con_p;
     A.src_u       = src_u;
@@ -2524,34 +2531,97 @@ namespace adaflo_hip
     return 0;
   }
 
+  // the streaming copy of the state as the residual mode writes it (constant-coefficient layout)
+  static int q2_alloc_state(adaflo_ctx *ctx)
+  {
+    const int    tiles_x = (ctx->desc.ncell[0] + TX - 1) / TX, tiles_y = (ctx->desc.ncell[1] + TY - 1) / TY;
+    const long   stride2 = 27L * 2 * 4 * 48 + ctx->q2_state_pad;
+    const size_t count   = (size_t)tiles_x * tiles_y * ctx->desc.ncell[2] * 2 * stride2;
+    if (ctx->lin_q2.count != count)
+      {
+        if (ctx->lin_q2.p)
+          (void)hipFree(ctx->lin_q2.p);
+        ctx->lin_q2.p     = nullptr;
+        ctx->lin_q2.count = 0;
+        if (hipMalloc(&ctx->lin_q2.p, count * sizeof(double)) != hipSuccess)
+          return ADAFLO_ENOMEM;
+        ctx->lin_q2.count = count;
+        // cells beyond the mesh in partial tiles are never written: define them once
+        if (hipMemsetAsync(ctx->lin_q2.p, 0, count * sizeof(double), ctx->stream) != hipSuccess)
+          return ADAFLO_EHIP;
+      }
+    return 0;
+  }
+  static int q2_ensure_buffer(DeviceBuffer &b, const size_t count)
+  {
+    if (b.count >= count && b.p)
+      return 0;
+    if (b.p)
+      (void)hipFree(b.p);
+    b.p     = nullptr;
+    b.count = 0;
+    if (hipMalloc(&b.p, count * sizeof(double)) != hipSuccess)
+      return ADAFLO_ENOMEM;
+    b.count = count;
+    return 0;
+  }
+
+  // Lazy state: the Newton residual below skips the layout of the quadrature-point state when the recompute-state vmult is
+  // its consumer; whoever needs the state after all (adaflo_ns_get_linearization, the generic and the streaming kernels,
+  // adaflo_ns_fix_linearization_point, a change of scheme) gets it here: the residual kernel once more on the nodal
+  // linearisation point, for the state alone -- the sums go to the work vectors of the residual and are dropped.
+  // Invariant: lin_q2_deferred implies lin_nodal_current (every ctx->lin_serial++ site clears the flag).
+  int q2_materialize_state(adaflo_ctx *ctx)
+  {
+    if (!ctx->lin_q2_deferred)
+      return 0;
+    if (!lin_nodal_current(ctx) || q2_lin_mode(ctx) != 0)
+      return ADAFLO_ENOTINIT;
+    const size_t nu = 3 * (size_t)ctx->n_nodes_u, np = (size_t)ctx->n_nodes_p;
+    if (int e = q2_alloc_state(ctx))
+      return e;
+    if (int e = q2_ensure_buffer(ctx->res_sum_u, nu))
+      return e;
+    if (int e = q2_ensure_buffer(ctx->res_sum_p, np))
+      return e;
+    if (int e = q2_ensure_buffer(ctx->res_ext, nu)) // (a pressure to read: the state does not depend on it)
+      return e;
+    if (hipMemsetAsync(ctx->res_ext.p, 0, np * sizeof(double), ctx->stream) != hipSuccess)
+      return ADAFLO_EHIP;
+    if (int e = q2_launch(ctx, OP_VMULT, ctx->res_sum_u.p, ctx->res_sum_p.p, ctx->lin_nodal.p, ctx->res_ext.p, -1, 0u, true,
+                          ctx->lin_nodal.p, 0., nullptr, false))
+      return e;
+    ctx->lin_q2_deferred = false;
+    ctx->lin_q2_valid    = true;
+    ctx->lin_q2_mode     = 0;
+    ctx->lin_q2_varco    = false;
+    return 0;
+  }
+
   int launch_ns_residual_q2(adaflo_ctx *ctx, double *sum_u, double *sum_p, const double *src_u,
                             const double *src_p, const double *old_comb, const double *ext_comb)
   {
     const int lin_mode = q2_lin_mode(ctx);
-    if (lin_mode != 2)
+    // Newton + recompute-state vmult (kernel variant 1): nobody reads the laid-out state unless asked (q2_materialize_state)
+    const bool defer = lin_mode == 0 && ctx->q2_recompute && ctx->q2_lazy_state && !ext_comb;
+    ctx->lin_q2_deferred = false; // (the caller has bumped lin_serial: whatever was deferred belongs to the state before)
+    if (defer)
       {
-        const int    tiles_x = (ctx->desc.ncell[0] + TX - 1) / TX, tiles_y = (ctx->desc.ncell[1] + TY - 1) / TY;
-        const long   stride2 = 27L * 2 * 4 * 48 + ctx->q2_state_pad;
-        const size_t count   = (size_t)tiles_x * tiles_y * ctx->desc.ncell[2] * 2 * stride2;
-        if (ctx->lin_q2.count != count)
-          {
-            if (ctx->lin_q2.p)
-              (void)hipFree(ctx->lin_q2.p);
-            ctx->lin_q2.p     = nullptr;
-            ctx->lin_q2.count = 0;
-            if (hipMalloc(&ctx->lin_q2.p, count * sizeof(double)) != hipSuccess)
-              return ADAFLO_ENOMEM;
-            ctx->lin_q2.count = count;
-            // cells beyond the mesh in partial tiles are never written: define them once
-            if (hipMemsetAsync(ctx->lin_q2.p, 0, count * sizeof(double), ctx->stream) != hipSuccess)
-              return ADAFLO_EHIP;
-          }
+        if (int e = q2_ensure_buffer(ctx->q2_state_sink, (size_t)(27L * 2 * 4 * 48 + 64) * 2))
+          return e;
+      }
+    else if (lin_mode != 2)
+      {
+        if (int e = q2_alloc_state(ctx))
+          return e;
       }
     // (variable coefficients: the kernel multiplies by the density of the point)
     const double c_old = (old_comb && ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE) ? (q2_varco(ctx) ? 1. : ctx->ns.density) : 0.;
-    if (int e = q2_launch(ctx, OP_VMULT, sum_u, sum_p, src_u, src_p, -1, 0u, true, old_comb ? old_comb : src_u, c_old, ext_comb))
+    if (int e = q2_launch(ctx, OP_VMULT, sum_u, sum_p, src_u, src_p, -1, 0u, true, old_comb ? old_comb : src_u, c_old, ext_comb, defer))
       return e;
-    if (lin_mode != 2)
+    if (defer)
+      ctx->lin_q2_valid = false;
+    else if (lin_mode != 2)
       {
         ctx->lin_q2_valid = true;
         ctx->lin_q2_mode  = lin_mode;
@@ -2561,6 +2631,7 @@ namespace adaflo_hip
     if (lin_mode == 0)
       if (int e = q2_capture_nodal(ctx, src_u))
         return e;
+    ctx->lin_q2_deferred = defer; // (with the nodal copy in place: the invariant of q2_materialize_state)
     return 0;
   }
 } // namespace adaflo_hip

@@ -347,6 +347,11 @@ class NavierStokesMatrix:
     def set_q2_chunk(self, layers):
         _lib.check(self._ctx, self._lib.adaflo_set_q2_chunk(self._require(), int(layers)))
 
+    def set_lazy_state(self, lazy):
+        """Q2/Q1 Newton residual: lay out the quadrature-point state only when somebody asks for it (default) or with
+        every residual (rounds 1-5); include/adaflo_hip.h: adaflo_set_q2_lazy_state"""
+        _lib.check(self._ctx, self._lib.adaflo_set_q2_lazy_state(self._require(), int(bool(lazy))))
+
     def pressure_mass_weight(self, dst):
         """dst += integral of the pressure shape functions (local_pressure_mass_weight)"""
         ctx = self._require()

@@ -59,7 +59,7 @@ def ns_case(k, n, variant, two_phase=False, state_from_residual=False):
                       "frac_of_8TB/s": round(b_alg / t / 8e12, 4)}), flush=True)
 
 
-def ns_residual_case(k, n, variant, two_phase=False):
+def ns_residual_case(k, n, variant, two_phase=False, lazy=True):
     """NavierStokesMatrix::residual (a3: the producer of the q-point state, once per Newton step);
     algorithmic bytes: 3 velocity vectors + p read, 2 vectors written, state written once (two_phase: + rho, mu, damping
     read per quadrature point)"""
@@ -70,6 +70,8 @@ def ns_residual_case(k, n, variant, two_phase=False):
     op = adaflo_amd.NavierStokesMatrix(fp, adaflo_amd.BrickMesh([n] * 3, [-1] * 3, [1] * 3))
     op.initialize(ts, True)
     op.set_kernel_variant(variant)
+    if k == 2 and variant:
+        op.set_lazy_state(lazy)      # (lazy: the state is laid out only when somebody asks; the bytes below still count it)
     rng = np.random.default_rng(1)
     if two_phase:
         nc = op.n_cells() * (k + 1) ** 3
@@ -81,7 +83,8 @@ def ns_residual_case(k, n, variant, two_phase=False):
     t = timeit(lambda: op.residual(rhs, sol, None, old, oldold), op.synchronize, reps=10, warm=2)
     nq = (k + 1) ** 3
     b_alg = op.n_cells() * (8 * (5 * 3 * k ** 3 + 2 * (k - 1) ** 3) + 8 * (15 if two_phase else 12) * nq)
-    print(json.dumps({"op": "ns_residual" + ("_two_phase" if two_phase else ""), "k": k, "cells": n, "variant": variant, "ms": round(t * 1e3, 4),
+    print(json.dumps({"op": "ns_residual" + ("_two_phase" if two_phase else ""), "k": k, "cells": n, "variant": variant,
+                      "state": "lazy" if (lazy and k == 2 and variant) else "written", "ms": round(t * 1e3, 4),
                       "alg_GB/s": round(b_alg / t / 1e9, 1), "frac_of_8TB/s": round(b_alg / t / 8e12, 4)}), flush=True)
 
 
