@@ -1073,7 +1073,8 @@ int adaflo_ns_residual(adaflo_ctx *ctx, double *rhs_u, double *rhs_p, const doub
           old_comb = ctx->res_old.p;
         }
       const double *ext_comb = nullptr;
-      if (ctx->ns.linearization == ADAFLO_COUPLED_VELOCITY_SEMI_IMPLICIT || ctx->ns.linearization == ADAFLO_COUPLED_VELOCITY_EXPLICIT)
+      if (ctx->ns.linearization == ADAFLO_COUPLED_VELOCITY_SEMI_IMPLICIT || ctx->ns.linearization == ADAFLO_COUPLED_VELOCITY_EXPLICIT ||
+          ctx->ns.linearization == ADAFLO_PROJECTION)
         {
           // :644-647, 740-782: the extrapolated velocity extrap_old u_old + extrap_old_old u_old_old, combined at the nodes
           TRY(ctx, alloc(ctx, ctx->res_ext, nu), ctx->last_error);
@@ -1104,7 +1105,8 @@ int adaflo_ns_residual(adaflo_ctx *ctx, double *rhs_u, double *rhs_p, const doub
           old_comb = ctx->res_old.p;
         }
       const double *ext_comb = nullptr;
-      if (ctx->ns.linearization == ADAFLO_COUPLED_VELOCITY_SEMI_IMPLICIT || ctx->ns.linearization == ADAFLO_COUPLED_VELOCITY_EXPLICIT)
+      if (ctx->ns.linearization == ADAFLO_COUPLED_VELOCITY_SEMI_IMPLICIT || ctx->ns.linearization == ADAFLO_COUPLED_VELOCITY_EXPLICIT ||
+          ctx->ns.linearization == ADAFLO_PROJECTION)
         {
           // :644-647, 740-782: the extrapolated velocity extrap_old u_old + extrap_old_old u_old_old, combined at the nodes
           TRY(ctx, alloc(ctx, ctx->res_ext, nu), ctx->last_error);

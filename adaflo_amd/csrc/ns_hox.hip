@@ -238,7 +238,8 @@ namespace adaflo_hip
       A.slab_p  = ctx->hox_slab_p.p;
       A.xslab_p = ctx->hox_xslab_p.p;
       if (with_p && !A.integrate_p && (phase <= 0 || phase == 5)) // (5: the set-up phase of the two-stream schedule runs on the engine stream BEFORE the auxiliary stream may pack or unpack-add dst_p; in phase 3 it raced with them -- ADVICE r05)
-        if (int e = launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, A.npx, A.npy, A.npz, A.con_p, -1., true))
+        if (int e = residual ? launch_fill(ctx, dst_p, 0., ctx->n_nodes_p) : // (the residual's sums of rows that are not integrated: 0)
+                               launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, A.npx, A.npy, A.npz, A.con_p, -1., true))
           return e;
       long nwg = (long)n_wg;
       if (phase >= 0)
@@ -453,12 +454,12 @@ namespace adaflo_hip
   }
 
   // constant coefficients; Stokes, Newton, Picard-type, and (round 5, time-dependent equations: the old solutions exist)
-  // the schemes that linearise about the extrapolated old velocity (navier_stokes_matrix.cc:740-782).  The projection
-  // scheme stays on the generic kernel
+  // the schemes that linearise about the extrapolated old velocity (navier_stokes_matrix.cc:740-782); (round 6) the
+  // projection scheme: the semi-implicit residual without the pressure rows (:644-647, :902-907)
   bool hox_residual_supported(const adaflo_ctx *ctx)
   {
     const int lin = ctx->ns.linearization;
-    if (!hox_supported(ctx) || ctx->rho.p || lin == ADAFLO_PROJECTION)
+    if (!hox_supported(ctx) || ctx->rho.p)
       return false;
     if (ctx->ns.physical_type == ADAFLO_STOKES || lin == ADAFLO_COUPLED_IMPLICIT_NEWTON || lin == ADAFLO_COUPLED_IMPLICIT_PICARD)
       return true;

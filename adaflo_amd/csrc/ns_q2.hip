@@ -2223,9 +2223,13 @@ namespace adaflo_hip
       A.zslab_p = ctx->q2_zslab_p.p;
     }
     if (with_p && !A.integrate_p && (phase <= 0 || phase == 5)) // (5: the set-up phase of the two-stream schedule runs on the engine stream BEFORE the auxiliary stream may pack or unpack-add dst_p; in phase 3 it raced with them -- ADVICE r05)
-      if (int e = launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, A.npx, A.npy, A.npz,
-                                     A.con_p, -1., true))
-        return e;
+      {
+        // projection scheme: the pressure rows are not integrated (:902-907) -- vmult: 0 and -src on constrained rows; the
+        // residual's cell-loop sums: 0
+        if (int e = residual ? launch_fill(ctx, dst_p, 0., ctx->n_nodes_p) :
+                               launch_prepare_dst(ctx, dst_p, src_p, ctx->n_nodes_p, 1, A.npx, A.npy, A.npz, A.con_p, -1., true))
+          return e;
+      }
     long nwg = (long)A.tiles_x * A.tiles_y * A.n_chunks;
     if (phase >= 0)
       {
@@ -2501,9 +2505,11 @@ namespace adaflo_hip
         P.linearization == ADAFLO_COUPLED_IMPLICIT_PICARD)
       return true;
     // (round 5) the schemes that linearise about the extrapolated old velocity, time-dependent equations (the old
-    // solutions exist); the projection scheme stays on the generic kernel
+    // solutions exist); (round 6) the projection scheme: the semi-implicit residual without the pressure rows (:644-647,
+    // :902-907)
     return P.physical_type == ADAFLO_INCOMPRESSIBLE &&
-           (P.linearization == ADAFLO_COUPLED_VELOCITY_SEMI_IMPLICIT || P.linearization == ADAFLO_COUPLED_VELOCITY_EXPLICIT);
+           (P.linearization == ADAFLO_COUPLED_VELOCITY_SEMI_IMPLICIT || P.linearization == ADAFLO_COUPLED_VELOCITY_EXPLICIT ||
+            P.linearization == ADAFLO_PROJECTION);
   }
 
   // sum_u / sum_p = cell-loop result of NavierStokesOps::residual (zero on constrained rows);

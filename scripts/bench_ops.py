@@ -59,11 +59,13 @@ def ns_case(k, n, variant, two_phase=False, state_from_residual=False):
                       "frac_of_8TB/s": round(b_alg / t / 8e12, 4)}), flush=True)
 
 
-def ns_residual_case(k, n, variant, two_phase=False, lazy=True):
+def ns_residual_case(k, n, variant, two_phase=False, lazy=True, linearization=None):
     """NavierStokesMatrix::residual (a3: the producer of the q-point state, once per Newton step);
     algorithmic bytes: 3 velocity vectors + p read, 2 vectors written, state written once (two_phase: + rho, mu, damping
     read per quadrature point)"""
     fp = adaflo_amd.FlowParameters(velocity_degree=k, density_diff=0.5 if two_phase else 0.0)
+    if linearization is not None:
+        fp.linearization = linearization
     ts = adaflo_amd.TimeStepping(fp)
     for _ in range(3):
         ts.next()
@@ -83,7 +85,8 @@ def ns_residual_case(k, n, variant, two_phase=False, lazy=True):
     t = timeit(lambda: op.residual(rhs, sol, None, old, oldold), op.synchronize, reps=10, warm=2)
     nq = (k + 1) ** 3
     b_alg = op.n_cells() * (8 * (5 * 3 * k ** 3 + 2 * (k - 1) ** 3) + 8 * (15 if two_phase else 12) * nq)
-    print(json.dumps({"op": "ns_residual" + ("_two_phase" if two_phase else ""), "k": k, "cells": n, "variant": variant,
+    print(json.dumps({"op": "ns_residual" + ("_two_phase" if two_phase else "") + ("" if linearization is None else "_lin%d" % linearization),
+                      "k": k, "cells": n, "variant": variant,
                       "state": "lazy" if (lazy and k == 2 and variant) else "written", "ms": round(t * 1e3, 4),
                       "alg_GB/s": round(b_alg / t / 1e9, 1), "frac_of_8TB/s": round(b_alg / t / 8e12, 4)}), flush=True)
 
@@ -278,12 +281,16 @@ if __name__ == "__main__":
     for v in (1, 4):                                 # round 5: state recomputed from the nodal linearisation point (1) / streamed (4)
         ns_case(2, 128, v, state_from_residual=True)
         ns_case(2, 128, v, two_phase=True, state_from_residual=True)
+    has_v2 = bool(adaflo_amd._lib.load().adaflo_has_kernel_variant(2))   # (the superseded kernels: ADAFLO_BUILD_VARIANTS=1 only)
     for k, n in ((3, 64), (4, 64), (5, 48)):        # 1: x-marching kernel (round 4), 2: z-sweep kernel (round 2), 0: generic
-        for v in (1, 2, 0):
+        for v in ((1, 2, 0) if has_v2 else (1, 0)):
             ns_case(k, n, v)
     ns_residual_case(3, 64, 1)
     ns_residual_case(4, 64, 1)
     ns_residual_case(5, 48, 1)
+    for k, n in ((2, 128), (4, 64)):                 # round 6: the projection scheme's residual on the sweep kernels / generic
+        for v in (1, 0):
+            ns_residual_case(k, n, v, linearization=4)
     for k in (3, 4):                                 # two-phase Jacobian on the x-marching kernel (round 4) / generic
         for v in (1, 0):
             ns_case(k, 64, v, two_phase=True)

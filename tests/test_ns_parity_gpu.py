@@ -654,14 +654,16 @@ def test_two_phase_vmult_x_marching_kernel(k, ncell, lin, phys, chunk):
 @pytest.mark.parametrize("k,ncell,lin,phys,chunk", [(4, (5, 4, 9), 0, 0, 0), (4, (9, 3, 2), 1, 0, 4), (3, (6, 5, 5), 0, 0, 2),
                                                     (5, (3, 2, 3), 0, 0, 0), (4, (4, 4, 4), 0, 1, 0), (4, (3, 5, 2), 0, 2, 1),
                                                     (3, (4, 4, 3), 1, 0, 0), (4, (5, 4, 9), 2, 0, 0), (3, (6, 5, 5), 2, 0, 2),
-                                                    (5, (3, 2, 3), 2, 0, 0), (4, (4, 4, 4), 3, 0, 1), (3, (3, 4, 5), 3, 0, 0)])
+                                                    (5, (3, 2, 3), 2, 0, 0), (4, (4, 4, 4), 3, 0, 1), (3, (3, 4, 5), 3, 0, 0),
+                                                    (4, (5, 4, 9), 4, 0, 0), (3, (6, 5, 5), 4, 0, 2), (5, (3, 2, 3), 4, 0, 0)])
 def test_residual_x_marching_kernel(k, ncell, lin, phys, chunk):
     """residual mode of the Q3..Q5 x-marching kernel (round 4; navier_stokes_matrix.cc:266-293, 663-686, 725-800): the
     right-hand side with the read-modify-write semantics of the reference, partial constraints whose boundary values are
     read plainly, the state it leaves in the STREAMING layout only -- read back through the generic one, used by the
     next vmult, frozen by fix_linearization_point while a later residual replaces it --, Picard-type state, stationary
     and Stokes equations; (round 5) the schemes that linearise about the extrapolated old velocity (:740-782; semi-implicit
-    = 2 stores (u_ext, div u_ext), explicit = 3 stores nothing); the generic kernel on the same inputs"""
+    = 2 stores (u_ext, div u_ext), explicit = 3 stores nothing); (round 6) the projection scheme = 4: the semi-implicit
+    residual without the pressure rows (:902-907); the generic kernel on the same inputs"""
     case = Case(ncell, k=k, lower=(0., 0., 0.), upper=(1., 1.5, 1.), faces_u=[0, 2, 3, 5], faces_p=[1],
                 linearization=lin, physical_type=phys, tau_grad_div=0.2, damping=0.1, density=1.2, steps=3)
     src_u, src_p = case.smooth_u(0.1) + 0.01 * case.random_u(), case.smooth_p(0.1)
@@ -780,11 +782,12 @@ def test_change_of_scheme_after_the_state_was_frozen(k):
                                                   ((8, 16, 3), (1., 1., 1.), 1, 0), ((5, 4, 9), (1., 2., 1.), 0, 1),
                                                   ((4, 5, 3), (1., 1., 1.), 0, 2), ((1, 1, 1), (1., 1., 1.), 0, 0),
                                                   ((9, 8, 5), (1., 1., 1.), 2, 0), ((17, 9, 6), (1., 1., 3.), 3, 0),
-                                                  ((5, 4, 9), (1., 2., 1.), 2, 0), ((1, 1, 1), (1., 1., 1.), 2, 0)])
+                                                  ((5, 4, 9), (1., 2., 1.), 2, 0), ((1, 1, 1), (1., 1., 1.), 2, 0),
+                                                  ((9, 8, 5), (1., 1., 1.), 4, 0), ((17, 9, 6), (1., 1., 3.), 4, 0)])
 def test_residual_sweep_kernel(ncell, upper, lin, phys):
     """residual mode of the Q2/Q1 sweep kernel (partial and multiple tiles, several z-chunks, non-cubic
     cells, Picard state, stationary and Stokes equations; round 5: the semi-implicit (2) and explicit (3) schemes, which
-    linearise about the extrapolated old velocity, :740-782): right-hand side with the read-modify-write
+    linearise about the extrapolated old velocity, :740-782; round 6: the projection scheme (4), :902-907): right-hand side with the read-modify-write
     semantics of the reference (rhs = user - rhs - cell loop), the state it leaves (both layouts) and the
     operator applied on that state, against the oracle; generic kernel on the same inputs"""
     case = Case(ncell, k=2, lower=(0., 0., 0.), upper=upper, linearization=lin, physical_type=phys, steps=3)
@@ -989,7 +992,7 @@ def test_two_phase_vmult_recomputes_the_state_from_the_nodal_linearisation_point
 
 
 @pytest.mark.parametrize("k,lin,two_phase", [(2, 0, False), (2, 0, True), (2, 1, False), (2, 2, False), (2, 3, False),
-                                              (3, 2, False), (4, 0, False), (4, 2, False), (5, 0, False)])
+                                              (3, 2, False), (4, 0, False), (4, 2, False), (5, 0, False), (2, 4, False), (4, 4, False)])
 def test_residual_kernels_on_random_meshes_against_the_generic_kernels(k, lin, two_phase):
     """the residual modes of the sweep kernels (most of them built for 512 registers) on a seeded sweep of small meshes --
     cut tiles in every direction, non-cubic cells, one to a few cell layers -- against the generic kernels of the same
