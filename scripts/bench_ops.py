@@ -64,8 +64,9 @@ def ns_residual_case(k, n, variant, two_phase=False, lazy=True, linearization=No
     algorithmic bytes: 3 velocity vectors + p read, 2 vectors written, state written once (two_phase: + rho, mu, damping
     read per quadrature point)"""
     fp = adaflo_amd.FlowParameters(velocity_degree=k, density_diff=0.5 if two_phase else 0.0)
-    if linearization is not None:
-        fp.linearization = linearization
+    if linearization is not None:                    # (index into parameters.LINEARIZATIONS: 4 = projection)
+        from adaflo_amd.parameters import LINEARIZATIONS
+        fp.linearization = {v: n for n, v in LINEARIZATIONS.items()}[linearization]
     ts = adaflo_amd.TimeStepping(fp)
     for _ in range(3):
         ts.next()
