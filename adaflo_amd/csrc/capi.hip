@@ -589,7 +589,7 @@ int adaflo_ctx_destroy(adaflo_ctx *ctx)
                           &ctx->q1_slab, &ctx->q1_zslab, &ctx->pc_inv_u, &ctx->pc_inv_pm, &ctx->pc_inv_pl,
                           &ctx->pc_ones_p, &ctx->pc_tmp_u, &ctx->pc_tmp_p, &ctx->pc_tmp_p2, &ctx->pc_work, &ctx->kr_work, &ctx->kr_basis, &ctx->kr_scalars,
                           &ctx->q1_poisson_coef, &ctx->ho_tab, &ctx->res_sum_u, &ctx->res_sum_p, &ctx->res_old, &ctx->res_ext,
-                          &ctx->ls_art_visc, &ctx->ls_stab_vel_sum, &ctx->ls_stab_ls_sum, &ctx->hox_lin, &ctx->hox_lin_prec, &ctx->pc_tridiag,
+                          &ctx->ls_art_visc, &ctx->ls_stab_vel_sum, &ctx->ls_stab_ls_sum, &ctx->hox_lin, &ctx->hox_lin_prec, &ctx->hox_coef, &ctx->pc_tridiag,
                           &ctx->hox_slab_u, &ctx->hox_xslab_u, &ctx->hox_slab_p, &ctx->hox_xslab_p, &ctx->hox_tab,
                           &ctx->hop_lin, &ctx->hop_lin_prec, &ctx->hop_tab, &ctx->lin_nodal, &ctx->lin_nodal_prec})
     release(*b);
@@ -823,6 +823,7 @@ int adaflo_ns_set_coefficients(adaflo_ctx *ctx, const double *rho, const double 
       ctx->hox_lin_primary = false; // (ensure_lin_generic above brought the generic copy up to date)
     }
   ctx->lin_gen++;
+  ctx->coef_gen++;
   ctx->q1_poisson_src = nullptr;
   if (!rho && !mu && !damping)
     {
@@ -880,11 +881,24 @@ int adaflo_ns_fix_linearization_point(adaflo_ctx *ctx)
       ctx->lin_prec_gen++;
       ctx->hox_lin_prec_gen       = ctx->lin_prec_gen;
       ctx->hox_lin_prec_mode      = ctx->hox_lin_mode;
-      ctx->hox_lin_prec_varco     = false; // the copy carries no coefficient pieces (a flag left by an earlier
-                                           // variable-coefficient vmult would send prepare_state to the stale generic copy)
+      ctx->hox_lin_prec_varco     = ctx->hox_lin_varco; // coefficient pieces only if the variable-coefficient residual wrote
+                                                        // the copy (a flag left by an earlier variable-coefficient vmult
+                                                        // would send prepare_state to the stale generic copy)
       ctx->hox_lin_prec_primary   = true;
       ctx->lin_prec_generic_valid = false;
-      release(ctx->rho_prec), release(ctx->mu_prec), release(ctx->damp_prec); // (the residual mode runs with constant coefficients only)
+      if (ctx->hox_lin_varco && ctx->rho.p)
+        {
+          // the frozen coefficients (generic arrays: what the generic kernels and the Q1 pressure operators read)
+          const DeviceBuffer *csrc[3] = {&ctx->rho, &ctx->mu, &ctx->damp};
+          DeviceBuffer       *cdst[3] = {&ctx->rho_prec, &ctx->mu_prec, &ctx->damp_prec};
+          for (int i = 0; i < 3; ++i)
+            {
+              TRY(ctx, alloc(ctx, *cdst[i], csrc[i]->count), ctx->last_error);
+              HIP_TRY(ctx, hipMemcpyAsync(cdst[i]->p, csrc[i]->p, csrc[i]->count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        }
+      else
+        release(ctx->rho_prec), release(ctx->mu_prec), release(ctx->damp_prec);
       release(ctx->lin_q2_prec);
       ctx->lin_nodal_prec_valid = false;
       ctx->q1_poisson_src = nullptr;
@@ -2222,6 +2236,7 @@ int adaflo_ls_compute_force(adaflo_ctx *ctx, double *user_rhs_u, const double *h
           ctx->hox_lin_primary = false;
         }
       ctx->lin_gen++;
+      ctx->coef_gen++;
       ctx->q1_poisson_src = nullptr;
     }
   TRY(ctx,

@@ -137,6 +137,10 @@ struct adaflo_ctx
   // x-marching Q3..Q5 kernel (ns_hox.hip): streaming copies of the (frozen) linearisation state and the generation
   // of the generic copy they were converted from, seam slabs, 1D tables, workgroup list of the phased schedule
   adaflo_hip::DeviceBuffer hox_lin, hox_lin_prec, hox_slab_u, hox_xslab_u, hox_slab_p, hox_xslab_p, hox_tab;
+  // coefficient stream of the variable-coefficient residual of the x-marching kernel (round 6) and the counter of changes of
+  // rho / mu / damping it is current for
+  adaflo_hip::DeviceBuffer hox_coef;
+  unsigned long            coef_gen = 1, hox_coef_gen = 0;
   unsigned long            lin_gen = 1, lin_prec_gen = 1, hox_lin_gen = 0, hox_lin_prec_gen = 0;
   int                      hox_lin_mode = -1, hox_lin_prec_mode = -1;
   bool                     hox_lin_varco = false, hox_lin_prec_varco = false; // the streaming copy carries rho / mu / damping

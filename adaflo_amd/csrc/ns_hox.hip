@@ -108,6 +108,34 @@ namespace adaflo_hip
       return 0;
     }
 
+    // coefficient stream of the variable-coefficient residual: (rho, mu), (damping, -) per quadrature point in the layout of
+    // a state without linearisation pieces, rebuilt when the arrays changed (ctx->coef_gen)
+    template <int K>
+    int prepare_coefficients(adaflo_ctx *ctx, const double **out)
+    {
+      using G           = Geo<K>;
+      const size_t need = state_doubles<K>(ctx, 2, true);
+      if (ctx->hox_coef.p && ctx->hox_coef.count >= need && ctx->hox_coef_gen == ctx->coef_gen)
+        {
+          *out = ctx->hox_coef.p;
+          return 0;
+        }
+      if (int e = ensure(ctx->hox_coef, need))
+        return e;
+      const int  ncx = ctx->desc.ncell[0], ncy = ctx->desc.ncell[1], ncz = ctx->desc.ncell[2];
+      const int  ngy = (ncy + G::CWY - 1) / G::CWY, ngz = (ncz + G::CWZ - 1) / G::CWZ;
+      long       nb  = ((long)(need / 2) + 255) / 256;
+      if (nb > 256 * 64)
+        nb = 256 * 64;
+      hipLaunchKernelGGL((hox_convert_state_kernel<K>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, ctx->hox_coef.p,
+                         (const double *)nullptr, ncx, ncy, ncz, ngy, ngz, 2, 0, ctx->rho.p, ctx->mu.p, ctx->damp.p);
+      if (hipGetLastError() != hipSuccess)
+        return ADAFLO_EHIP;
+      ctx->hox_coef_gen = ctx->coef_gen;
+      *out              = ctx->hox_coef.p;
+      return 0;
+    }
+
     // residual = true: dst_u / dst_p receive the cell-loop sums, old_comb is the nodal combination of the old solutions
     // (or null), the state is WRITTEN to ctx->hox_lin
     template <int K>
@@ -191,12 +219,16 @@ namespace adaflo_hip
       bool varco = false, recompute = false;
       if (residual)
         {
+          varco   = ctx->rho.p != nullptr; // (two-phase residual, round 6: hox_residual_supported admits Newton / Picard-type)
           A.old_u = old_comb;
-          A.c_old = old_comb ? P.density : 0.;
+          A.c_old = old_comb ? (varco ? 1. : P.density) : 0.; // (variable density: the kernel multiplies by the point's)
           A.lin_u = ext_comb; // (schemes that linearise about the extrapolated old velocity)
+          if (varco)
+            if (int e = prepare_coefficients<K>(ctx, &A.lin))
+              return e;
           if (lin_mode != 2)
             {
-              if (int e = ensure(ctx->hox_lin, state_doubles<K>(ctx, lin_mode)))
+              if (int e = ensure(ctx->hox_lin, state_doubles<K>(ctx, lin_mode, varco)))
                 return e;
               A.lin_out = ctx->hox_lin.p;
             }
@@ -309,17 +341,29 @@ namespace adaflo_hip
     else                                       \
       HOX_LAUNCH_V(LM, WP, false)              \
   }
-#define HOX_LAUNCH_RES(LM)                                                                                \
-  {                                                                                                       \
-    static bool attr_set = false;                                                                         \
-    if (!attr_set)                                                                                        \
-      {                                                                                                   \
-        err      = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_hox_kernel<K, LM, true, true>), \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);      \
-        attr_set = err == hipSuccess;                                                                     \
-      }                                                                                                   \
-    if (err == hipSuccess && nwg > 0)                                                                     \
-      hipLaunchKernelGGL((ns_hox_kernel<K, LM, true, true>), grid, block, lds_bytes, ctx->stream, A);     \
+#define HOX_LAUNCH_RES_V(LM, VC)                                                                              \
+  {                                                                                                           \
+    static bool attr_set = false;                                                                             \
+    if (!attr_set)                                                                                            \
+      {                                                                                                       \
+        err      = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_hox_kernel<K, LM, true, true, VC>), \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);          \
+        attr_set = err == hipSuccess;                                                                         \
+      }                                                                                                       \
+    if (err == hipSuccess && nwg > 0)                                                                         \
+      hipLaunchKernelGGL((ns_hox_kernel<K, LM, true, true, VC>), grid, block, lds_bytes, ctx->stream, A);     \
+  }
+#define HOX_LAUNCH_RES(LM)             \
+  {                                    \
+    if (varco)                         \
+      {                                \
+        if constexpr (LM != 2)         \
+          HOX_LAUNCH_RES_V(LM, true)   \
+        else                           \
+          err = hipErrorNotSupported;  \
+      }                                \
+    else                               \
+      HOX_LAUNCH_RES_V(LM, false)      \
   }
 #ifndef HOX_EXT_KMAX
 #define HOX_EXT_KMAX 5 // (k = 5 since round 6, see HOX_EXT_LB in ns_hox_kernel.hpp; -DHOX_EXT_KMAX=4 sends it to the generic kernel)
@@ -388,6 +432,7 @@ namespace adaflo_hip
 #undef HOX_LAUNCH_RC
 #undef HOX_LAUNCH_V
 #undef HOX_LAUNCH_RES
+#undef HOX_LAUNCH_RES_V
 #undef HOX_LAUNCH_RES_EXT
       if (err != hipSuccess)
         return ADAFLO_EHIP;
@@ -428,7 +473,7 @@ namespace adaflo_hip
           ctx->lin_gen++;
           ctx->hox_lin_gen       = ctx->lin_gen;
           ctx->hox_lin_mode      = lin_mode;
-          ctx->hox_lin_varco     = false; // (the residual mode runs with constant coefficients: no rho / mu pieces)
+          ctx->hox_lin_varco     = varco; // (the variable-coefficient residual lets the coefficient pieces ride along)
           ctx->hox_lin_primary   = true;
           ctx->lin_generic_valid = false;
           ctx->lin_q2_valid      = false;
@@ -459,8 +504,12 @@ namespace adaflo_hip
   bool hox_residual_supported(const adaflo_ctx *ctx)
   {
     const int lin = ctx->ns.linearization;
-    if (!hox_supported(ctx) || ctx->rho.p)
+    if (!hox_supported(ctx))
       return false;
+    // variable coefficients (two-phase flow, round 6): Newton / Picard-type, all three arrays
+    if (ctx->rho.p || ctx->mu.p || ctx->damp.p)
+      return ctx->rho.p && ctx->mu.p && ctx->damp.p && ctx->ns.physical_type != ADAFLO_STOKES &&
+             (lin == ADAFLO_COUPLED_IMPLICIT_NEWTON || lin == ADAFLO_COUPLED_IMPLICIT_PICARD);
     if (ctx->ns.physical_type == ADAFLO_STOKES || lin == ADAFLO_COUPLED_IMPLICIT_NEWTON || lin == ADAFLO_COUPLED_IMPLICIT_PICARD)
       return true;
     // (k = 5 needs one workgroup per CU: 3.13 ms at 48^3 against 4.96 ms at two and 4.01 ms for the generic kernel)
@@ -490,7 +539,9 @@ namespace adaflo_hip
     const int           mode = frozen_copy ? ctx->hox_lin_prec_mode : ctx->hox_lin_mode;
     if (!src || mode < 0 || mode > 1)
       return ADAFLO_ENOTINIT;
-    const int ncx = ctx->desc.ncell[0], ncy = ctx->desc.ncell[1], ncz = ctx->desc.ncell[2], npc = nst_of(mode) / 2;
+    const bool varco = frozen_copy ? ctx->hox_lin_prec_varco : ctx->hox_lin_varco; // (two more pieces per point: skipped)
+    const int  ncx = ctx->desc.ncell[0], ncy = ctx->desc.ncell[1], ncz = ctx->desc.ncell[2], npl = nst_of(mode) / 2,
+               npc = npl + (varco ? 2 : 0);
 #define HOX_UNCONVERT(K)                                                                                                     \
   {                                                                                                                          \
     using G          = Geo<K>;                                                                                               \
@@ -500,7 +551,7 @@ namespace adaflo_hip
     if (nb > 256 * 64)                                                                                                       \
       nb = 256 * 64;                                                                                                         \
     hipLaunchKernelGGL((hox_unconvert_state_kernel<K>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, generic, src,            \
-                       ncx, ncy, ncz, ngy, ngz, npc);                                                                        \
+                       ncx, ncy, ncz, ngy, ngz, npc, npl);                                                                   \
   }
     switch (ctx->k)
       {

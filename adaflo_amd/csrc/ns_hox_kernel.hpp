@@ -502,8 +502,13 @@ namespace adaflo_hip
       constexpr bool FUSED = HOX_FUSED && (!RES || HOX_RES_FUSED);     // value + gradient through two exchanges, z-line loop
       constexpr int NSTL = (RES || RCP) ? 0 : nst_of(LIN_MODE);       // linearisation values READ per point
       constexpr int NST = NSTL + (VARCO ? 4 : 0), NPC = NST / 2;       // ... with the coefficients (rho, mu | damping, -)
-      static_assert(!(RES && VARCO), "residual mode: constant coefficients only");
+      static_assert(!(RES && VARCO) || (!EXT && LIN_MODE != 2), "variable-coefficient residual: Newton / Picard-type");
       constexpr int NSO = RES ? nst_of(LIN_MODE) : 0, NPO = NSO / 2;  // ... WRITTEN per point (residual mode)
+      // RES + VARCO (round 6; two-phase flow with k >= 3, :636-642, :717-732, :827-845): the coefficients arrive as a stream
+      // of their own, two pieces per point ((rho, mu), (damping, -): the layout of a Stokes-type state with coefficients),
+      // and leave behind the state pieces, so that what the residual writes IS the streaming state of the
+      // variable-coefficient vmults (NPO + 2 pieces per point)
+      constexpr int NPOV = NPO + ((RES && VARCO) ? 2 : 0);
       static_assert(!RES || WITH_P, "the residual has both blocks");
       using TB = Tab<K>;
       double *const lds = dyn_lds();
@@ -576,10 +581,11 @@ namespace adaflo_hip
       // state: per-lane pointer to the first piece of the first cell of my row of cell groups
       // state: wave-uniform base of my wave's row of cell groups + 32-bit lane offset.  (A cell beyond the mesh reads
       // its own slot of the zero-padded group, a group beyond the mesh the last one: legal addresses, unused values.)
-      constexpr unsigned ST_PIECE = CPW * NL * 2, ST_POINT = (RES ? NPO : NPC) * ST_PIECE, ST_CELL = N * ST_POINT; // doubles
+      constexpr unsigned ST_PIECE = CPW * NL * 2, ST_POINT = NPC * ST_PIECE, ST_CELL = N * ST_POINT; // doubles (read)
+      constexpr unsigned SO_POINT = NPOV * ST_PIECE, SO_CELL = N * SO_POINT;                          // ... (written)
       const int          gyw = min((by * CY + (wave % WY) * CWY) / CWY, A.ngy - 1), gzw = min((bz * CZ + (wave / WY) * CWZ) / CWZ, A.ngz - 1);
       const double *const stg = A.lin + (NST > 0 ? ((size_t)gzw * A.ngy + gyw) * A.ncx * ST_CELL : 0);
-      double *const       sog = RES && NSO > 0 ? A.lin_out + ((size_t)gzw * A.ngy + gyw) * A.ncx * ST_CELL : nullptr;
+      double *const       sog = RES && NSO > 0 ? A.lin_out + ((size_t)gzw * A.ngy + gyw) * A.ncx * SO_CELL : nullptr;
       const unsigned      st_lane = (unsigned)(cw * NL + lc) * 2;
 
       // wave-private transposition buffers T0, T1, T2 and the lane's line bases in the three layouts
@@ -1254,7 +1260,9 @@ namespace adaflo_hip
                       for (int e = 0; e < 3; ++e)
                         res += st[e] * g[d][e];
                     }
-                  if constexpr (RES) // :717-732 with the time derivative of BDF: weight u + (weight_old u_old + ...)
+                  if constexpr (RES && VARCO) // (... times the density of the point, :827: A.c_old is 1 or 0 then)
+                    conv[d] = (cA_q * u[d] + (A.c_old * st[NSTL]) * OQ[d][i] + cB_q * res) * jxw;
+                  else if constexpr (RES) // :717-732 with the time derivative of BDF: weight u + (weight_old u_old + ...)
                     conv[d] = (cA_q * u[d] + A.c_old * OQ[d][i] + cB_q * res) * jxw;
                   else
                     conv[d] = (cA_q * u[d] + cB_q * res) * jxw; // :717,:827-835
@@ -1268,8 +1276,8 @@ namespace adaflo_hip
                       // (x-line loop, lane (y, z) = (a, b), point i along x, next to a z-line vmult: the piece of point
                       // (i, a, b) belongs to line (x, y) = (i, a), point b)
                       double *const so = (HOX_FUSED && !FUSED) ?
-                                           sog + ((size_t)cx * ST_CELL + (unsigned)(b * ST_POINT) + (unsigned)(cw * NL + i + N * a) * 2) :
-                                           sog + ((size_t)cx * ST_CELL + (unsigned)(i * ST_POINT) + st_lane);
+                                           sog + ((size_t)cx * SO_CELL + (unsigned)(b * SO_POINT) + (unsigned)(cw * NL + i + N * a) * 2) :
+                                           sog + ((size_t)cx * SO_CELL + (unsigned)(i * SO_POINT) + st_lane);
                       if constexpr (EXT) // (u_ext, div u_ext): the state of the semi-implicit vmult
                         {
                           so[0] = GL[0][0][i], so[1] = GL[1][0][i];
@@ -1291,6 +1299,11 @@ namespace adaflo_hip
                         }
                       else
                         so[ST_PIECE] = u[2], so[ST_PIECE + 1] = div;
+                      if constexpr (VARCO) // the coefficients of the point ride along (before the next point's overwrite st)
+                        {
+                          so[NPO * ST_PIECE] = st[NSTL], so[NPO * ST_PIECE + 1] = st[NSTL + 1];
+                          so[(NPO + 1) * ST_PIECE] = st[NSTL + 2], so[(NPO + 1) * ST_PIECE + 1] = st[NSTL + 3];
+                        }
                     }
                 }
               if (NST > 0 && i + 1 < N && !(HOX_EXP & 4) && !RING)
@@ -1677,7 +1690,7 @@ namespace adaflo_hip
     template <int K>
     __global__ __launch_bounds__(256) void hox_unconvert_state_kernel(double *generic, const double *in, const int ncx,
                                                                       const int ncy, const int ncz, const int ngy,
-                                                                      const int ngz, const int npc)
+                                                                      const int ngz, const int npc, const int npl)
     {
       using G          = Geo<K>;
       constexpr int N = G::N, NL = G::NL, N3 = G::N3, CPW = G::CPW;
@@ -1697,7 +1710,7 @@ namespace adaflo_hip
           r /= ncx;
           const int gy = (int)(r % ngy), gz = (int)(r / ngy);
           const int cy = gy * G::CWY + scw % G::CWY, cz = gz * G::CWZ + scw / G::CWY;
-          if (cy < ncy && cz < ncz)
+          if (cy < ncy && cz < ncz && piece < npl) // (pieces npl, npl + 1 of a variable-coefficient state: rho, mu, damping)
             {
               const size_t cellg = ((size_t)cz * ncy + cy) * ncx + cx;
               const int    q     = HOX_FUSED ? (i * N + l / N) * N + l % N : ((l / N) * N + l % N) * N + i;

@@ -920,6 +920,79 @@ def test_two_phase_residual_sweep_kernel(ncell, upper, phys, faces_u):
         assert rel_l2(vdst.numpy(), ref_vel) < TOL, variant
 
 
+@pytest.mark.parametrize("k,ncell,lin,phys,chunk", [(4, (5, 4, 9), 0, 0, 0), (3, (6, 5, 5), 0, 0, 2), (5, (3, 2, 3), 0, 0, 0),
+                                                    (4, (9, 3, 2), 1, 0, 4), (3, (4, 4, 3), 1, 0, 0), (4, (4, 4, 4), 0, 1, 0)])
+def test_two_phase_residual_x_marching_kernel(k, ncell, lin, phys, chunk):
+    """the residual of two-phase flow (variable density / viscosity / damping, navier_stokes_matrix.cc:266-293, 636-642,
+    711-713, 717-732, 827-845) on the Q3..Q5 x-marching kernel (template RES with VARCO, round 6): the coefficients arrive as
+    a stream of their own and ride along into the state the residual writes, which IS the streaming state of the
+    variable-coefficient Jacobian -- right-hand side with the read-modify-write semantics of the reference, the Jacobian on
+    that state, the canonical state, the frozen operator (coefficients and state) while a new residual with new
+    coefficients replaces the current one, new coefficients on the old state; Newton and Picard-type, stationary; against
+    the oracle, and the generic kernels on the same inputs"""
+    case = Case(ncell, k=k, lower=(0., 0., 0.), upper=(1., 1.5, 1.), faces_u=[0, 2, 3, 5], faces_p=[1], linearization=lin,
+                physical_type=phys, steps=3, tau_grad_div=0.1, damping=0.1, density_diff=0.5)
+    src_u, src_p = case.smooth_u(0.1) + 0.05 * case.random_u(), case.smooth_p(0.1)
+    old_u, oldold_u = case.smooth_u(0.05), case.smooth_u(0.0)
+    rhs0_u, rhs0_p, usr_u, usr_p = case.random_u(), case.random_p(), case.random_u(), case.random_p()
+    rho, mu, damp = case.random_coefficients()
+    co2 = case.random_coefficients()
+    lin_ref = np.zeros(case.n_cells * case.nq * 12)
+    ref_u, ref_p = orc.ns_residual(case.mesh, k, case.prm, src_u, src_p, old_u, oldold_u, con_u=case.con_u,
+                                   con_p=case.con_p, lin=lin_ref, rhs_u=rhs0_u, rhs_p=rhs0_p, user_u=usr_u, user_p=usr_p,
+                                   rho=rho, mu=mu, damp=damp)
+    vm_u, vm_p = case.random_u(), case.random_p()
+    w, modes = case.weights_modes()
+    ref_vu, ref_vp = orc.ns_vmult(case.mesh, k, case.prm, vm_u, vm_p, case.con_u, case.con_p, lin=lin_ref, rho=rho, mu=mu,
+                                  damp=damp, weights=w, modes=modes)
+    ref_vel = orc.ns_velocity_vmult(case.mesh, k, case.prm, vm_u, case.con_u, lin=lin_ref, rho=rho, mu=mu, damp=damp)
+    ref2_u, ref2_p = orc.ns_vmult(case.mesh, k, case.prm, vm_u, vm_p, case.con_u, case.con_p, lin=lin_ref, rho=co2[0], mu=co2[1],
+                                  damp=co2[2], weights=w, modes=modes)
+    lin3 = np.zeros_like(lin_ref)
+    orc.ns_residual(case.mesh, k, case.prm, 0.5 * src_u, src_p, old_u, oldold_u, con_u=case.con_u, con_p=case.con_p, lin=lin3,
+                    rho=co2[0], mu=co2[1], damp=co2[2])
+    ref3_u, ref3_p = orc.ns_vmult(case.mesh, k, case.prm, vm_u, vm_p, case.con_u, case.con_p, lin=lin3, rho=co2[0], mu=co2[1],
+                                  damp=co2[2], weights=w, modes=modes)
+    ncomp = 12 if lin == 0 else 4
+    for variant in (1, 0):
+        op = case.engine()
+        op.set_kernel_variant(variant)
+        op.set_x_chunk(chunk)
+        op.set_coefficients(rho, mu, damp)
+        rhs = op.block_vector(rhs0_u, rhs0_p)
+        op.residual(rhs, op.block_vector(src_u, src_p), op.block_vector(usr_u, usr_p), op.block_vector(old_u),
+                    op.block_vector(oldold_u))
+        got_u, got_p = rhs.numpy()
+        assert rel_l2(got_u, ref_u) < TOL and rel_l2(got_p, ref_p) < TOL, (variant, rel_l2(got_u, ref_u), rel_l2(got_p, ref_p))
+        dst = op.block_vector()
+        op.vmult(dst, op.block_vector(vm_u, vm_p))              # streams what the residual wrote, coefficient pieces included
+        gu, gp = dst.numpy()
+        assert rel_l2(gu, ref_vu) < TOL and rel_l2(gp, ref_vp) < TOL, (variant, rel_l2(gu, ref_vu))
+        got_lin = op.get_linearization().reshape(-1, 12)
+        assert rel_l2(got_lin[:, :ncomp], lin_ref.reshape(-1, 12)[:, :ncomp]) < TOL, variant
+        op.vmult(dst, op.block_vector(vm_u, vm_p))              # (the streaming copy is still the current one)
+        gu, gp = dst.numpy()
+        assert rel_l2(gu, ref_vu) < TOL and rel_l2(gp, ref_vp) < TOL, variant
+        op.fix_linearization_point()                            # freezes state AND coefficients
+        op.set_coefficients(*co2)                               # new coefficients on the old state
+        op.vmult(dst, op.block_vector(vm_u, vm_p))
+        gu, gp = dst.numpy()
+        assert rel_l2(gu, ref2_u) < TOL and rel_l2(gp, ref2_p) < TOL, (variant, rel_l2(gu, ref2_u))
+        op.residual(rhs, op.block_vector(0.5 * src_u, src_p), None, op.block_vector(old_u), op.block_vector(oldold_u))
+        vsrc, vdst = op.initialize_u_vector(vm_u), op.initialize_u_vector()
+        op.velocity_vmult(vdst, vsrc)                           # the frozen operator
+        assert rel_l2(vdst.numpy(), ref_vel) < TOL, (variant, rel_l2(vdst.numpy(), ref_vel))
+        op.vmult(dst, op.block_vector(vm_u, vm_p))              # the new one
+        gu, gp = dst.numpy()
+        assert rel_l2(gu, ref3_u) < TOL and rel_l2(gp, ref3_p) < TOL, (variant, rel_l2(gu, ref3_u))
+        op.set_kernel_variant(0)                                # generic kernels on the copies the sweep kernel left
+        op.velocity_vmult(vdst, vsrc)
+        assert rel_l2(vdst.numpy(), ref_vel) < TOL, variant
+        op.vmult(dst, op.block_vector(vm_u, vm_p))
+        gu, gp = dst.numpy()
+        assert rel_l2(gu, ref3_u) < TOL and rel_l2(gp, ref3_p) < TOL, variant
+
+
 @pytest.mark.parametrize("first_coefficients", [False, True])
 def test_new_coefficients_leave_the_state_of_the_sweep_residual_alone(first_coefficients):
     """adaflo_ns_set_coefficients after a sweep-kernel residual (what every two-phase time step does): the state exists
@@ -992,7 +1065,8 @@ def test_two_phase_vmult_recomputes_the_state_from_the_nodal_linearisation_point
 
 
 @pytest.mark.parametrize("k,lin,two_phase", [(2, 0, False), (2, 0, True), (2, 1, False), (2, 2, False), (2, 3, False),
-                                              (3, 2, False), (4, 0, False), (4, 2, False), (5, 0, False), (2, 4, False), (4, 4, False)])
+                                              (3, 2, False), (4, 0, False), (4, 2, False), (5, 0, False), (2, 4, False), (4, 4, False),
+                                              (3, 0, True), (4, 0, True), (4, 1, True)])
 def test_residual_kernels_on_random_meshes_against_the_generic_kernels(k, lin, two_phase):
     """the residual modes of the sweep kernels (most of them built for 512 registers) on a seeded sweep of small meshes --
     cut tiles in every direction, non-cubic cells, one to a few cell layers -- against the generic kernels of the same
