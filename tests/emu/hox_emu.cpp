@@ -213,7 +213,7 @@ namespace
     if (hox_fix_blocks(A, true) > 0)
       emu::launch(3, 256, [&] { ns_hox_fixup_kernel<K>(A, 1); });
     if (npc > 0)
-      emu::launch(4, 256, [&] { hox_unconvert_state_kernel<K>(lin_generic, state.data(), A.ncx, A.ncy, A.ncz, A.ngy, A.ngz, npc); });
+      emu::launch(4, 256, [&] { hox_unconvert_state_kernel<K>(lin_generic, state.data(), A.ncx, A.ncy, A.ncz, A.ngy, A.ngz, npc, npc); });
     return 0;
   }
 } // namespace
