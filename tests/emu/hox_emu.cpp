@@ -165,7 +165,8 @@ namespace
   int run_residual(const int *ncell, const double *h, const int lin_mode, const double *coef, const double c_old,
                    const unsigned con_u, const unsigned con_p, const double *src_u, const double *src_p,
                    const double *old_comb, double *sum_u, double *sum_p, double *lin_generic, const int lx,
-                   const double *ext_comb = nullptr)
+                   const double *ext_comb = nullptr, const double *rho = nullptr, const double *mu = nullptr,
+                   const double *damp = nullptr)
   {
     using G         = Geo<K>;
     constexpr int N = K + 1;
@@ -176,7 +177,11 @@ namespace
       const Quadrature1D        qu = gauss(N);
       const Shape1D             su = shape_fe_q(K, qu), sp = shape_fe_q(K - 1, qu);
       const std::vector<double> dc = collocation_derivative(qu);
-      tab = hox_table<K>(su.S.data(), dc.data(), sp.S.data(), qu.w.data(), h, coef[0], coef[1], coef[2], coef[3], coef[4]);
+      if (rho) // (variable coefficients: the table carries gamma, tau1, 1, tau1 as for the two-phase vmult: coef[5..8])
+        tab = hox_table<K>(su.S.data(), dc.data(), sp.S.data(), qu.w.data(), h, coef[0], coef[1], coef[2], coef[3], coef[4],
+                           coef[5], coef[6], coef[7], coef[8]);
+      else
+        tab = hox_table<K>(su.S.data(), dc.data(), sp.S.data(), qu.w.data(), h, coef[0], coef[1], coef[2], coef[3], coef[4]);
     }
     A.tab         = tab.data();
     A.integrate_p = 1;
@@ -189,9 +194,19 @@ namespace
     A.old_u       = old_comb;
     A.c_old       = c_old;
     A.lin_u       = ext_comb; // (extrapolating schemes, template EXT)
-    const int           npc = nst_of(lin_mode) / 2;
+    const int           npl = nst_of(lin_mode) / 2, npc = npl + (rho ? 2 : 0);
     std::vector<double> state((size_t)A.ngz * A.ngy * A.ncx * N * npc * G::CPW * G::NL * 2 + 2, std::nan(""));
     A.lin_out = state.data();
+    // variable-coefficient residual (RES + VARCO): the coefficient stream, two pieces per point
+    std::vector<double> coef_stream;
+    if (rho)
+      {
+        coef_stream.assign((size_t)A.ngz * A.ngy * A.ncx * N * 2 * G::CPW * G::NL * 2 + 2, std::nan(""));
+        emu::launch(4, 256, [&] {
+          hox_convert_state_kernel<K>(coef_stream.data(), nullptr, A.ncx, A.ncy, A.ncz, A.ngy, A.ngz, 2, 0, rho, mu, damp);
+        });
+        A.lin = coef_stream.data();
+      }
     const size_t        n_wg = (size_t)A.tiles_y * A.tiles_z * A.n_chunks;
     const double        nan  = std::nan("");
     std::vector<double> slab_u(n_wg * G::RIMU * (K * A.LX + 1) * 3, nan), xslab_u(n_wg * G::TNY * G::TNZ * 3, nan),
@@ -200,7 +215,13 @@ namespace
     A.xslab_u = xslab_u.data();
     A.slab_p  = slab_p.data();
     A.xslab_p = xslab_p.data();
-    if (ext_comb && lin_mode == 1)
+    if (rho && lin_mode == 0)
+      emu::launch((unsigned)n_wg, NTH, [&] { ns_hox_kernel<K, 0, true, true, true>(A); });
+    else if (rho && lin_mode == 1)
+      emu::launch((unsigned)n_wg, NTH, [&] { ns_hox_kernel<K, 1, true, true, true>(A); });
+    else if (rho)
+      return -3;
+    else if (ext_comb && lin_mode == 1)
       emu::launch((unsigned)n_wg, NTH, [&] { ns_hox_kernel<K, 1, true, true, false, false, true>(A); });
     else if (ext_comb)
       emu::launch((unsigned)n_wg, NTH, [&] { ns_hox_kernel<K, 2, true, true, false, false, true>(A); });
@@ -213,7 +234,28 @@ namespace
     if (hox_fix_blocks(A, true) > 0)
       emu::launch(3, 256, [&] { ns_hox_fixup_kernel<K>(A, 1); });
     if (npc > 0)
-      emu::launch(4, 256, [&] { hox_unconvert_state_kernel<K>(lin_generic, state.data(), A.ncx, A.ncy, A.ncz, A.ngy, A.ngz, npc, npc); });
+      emu::launch(4, 256, [&] { hox_unconvert_state_kernel<K>(lin_generic, state.data(), A.ncx, A.ncy, A.ncz, A.ngy, A.ngz, npc, npl); });
+    if (rho) // the coefficient pieces behind the state pieces: what the two-phase vmult will stream
+      {
+        const long total = (long)A.ngz * A.ngy * A.ncx * N * npc * G::CPW * G::NL;
+        for (long it = 0; it < total; ++it)
+          {
+            const int piece = (int)((it / (G::NL * G::CPW)) % npc);
+            if (piece < npl)
+              continue;
+            const long pt = it / ((long)G::NL * G::CPW * npc), in_piece = it % ((long)G::NL * G::CPW);
+            // (cells of a partial group beyond the mesh store nothing: the decode of hox_convert_state_kernel)
+            const int  scw = (int)((it / G::NL) % G::CPW);
+            const long grp = pt / ((long)N * A.ncx);
+            const int  gy = (int)(grp % A.ngy), gz = (int)(grp / A.ngy);
+            if (gy * G::CWY + scw % G::CWY >= A.ncy || gz * G::CWZ + scw / G::CWY >= A.ncz)
+              continue;
+            const long src = (pt * 2 + (piece - npl)) * (long)G::NL * G::CPW + in_piece;
+            const double a0 = state[2 * it], a1 = state[2 * it + 1], b0 = coef_stream[2 * src], b1 = coef_stream[2 * src + 1];
+            if (!(a0 == b0 && a1 == b1))
+              return -4;
+          }
+      }
     return 0;
   }
 } // namespace
@@ -231,6 +273,26 @@ extern "C" int hox_emu_residual(const int K, const int *ncell, const double *h, 
         return run_residual<4>(ncell, h, lin_mode, coef, c_old, con_u, con_p, src_u, src_p, old_comb, sum_u, sum_p, lin_generic, lx);
       case 5:
         return run_residual<5>(ncell, h, lin_mode, coef, c_old, con_u, con_p, src_u, src_p, old_comb, sum_u, sum_p, lin_generic, lx);
+    }
+  return -1;
+}
+
+// variable-coefficient residual (templates RES + VARCO, round 6): coef[0..8] as for the two-phase vmult, c_old = 1 or 0
+extern "C" int hox_emu_residual_varco(const int K, const int *ncell, const double *h, const int lin_mode, const double *coef,
+                                      const double c_old, const unsigned con_u, const unsigned con_p, const double *src_u,
+                                      const double *src_p, const double *old_comb, const double *rho, const double *mu,
+                                      const double *damp, double *sum_u, double *sum_p, double *lin_generic, const int lx)
+{
+  if (!rho || !mu || !damp)
+    return -2;
+  switch (K)
+    {
+      case 3:
+        return run_residual<3>(ncell, h, lin_mode, coef, c_old, con_u, con_p, src_u, src_p, old_comb, sum_u, sum_p, lin_generic, lx, nullptr, rho, mu, damp);
+      case 4:
+        return run_residual<4>(ncell, h, lin_mode, coef, c_old, con_u, con_p, src_u, src_p, old_comb, sum_u, sum_p, lin_generic, lx, nullptr, rho, mu, damp);
+      case 5:
+        return run_residual<5>(ncell, h, lin_mode, coef, c_old, con_u, con_p, src_u, src_p, old_comb, sum_u, sum_p, lin_generic, lx, nullptr, rho, mu, damp);
     }
   return -1;
 }

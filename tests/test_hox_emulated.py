@@ -205,3 +205,38 @@ def test_emulated_residual_of_the_extrapolating_schemes(emu, k, ncell, lx, lin):
     if lin_mode == 1:
         got = lin_generic.reshape(case.n_cells, 12, case.nq).transpose(0, 2, 1)
         assert rel_l2(got[:, :, :4], lin_ref.reshape(case.n_cells, case.nq, 12)[:, :, :4]) < TOL
+
+
+@pytest.mark.parametrize("k,ncell,lx,lin,phys", [(4, (3, 2, 5), 2, 0, 0), (3, (3, 5, 5), 0, 1, 0), (5, (2, 3, 2), 1, 0, 0),
+                                                  (4, (3, 3, 2), 0, 0, 1)])
+def test_emulated_variable_coefficient_residual(emu, k, ncell, lx, lin, phys):
+    """residual mode with variable coefficients (templates RES + VARCO, round 6; navier_stokes_matrix.cc:636-642, 717-732,
+    827-845): density / viscosity / damping arrive as a two-piece stream of their own; sums and the stored state against
+    the oracle's two-phase residual; the coefficient pieces ride along behind the state pieces (checked bitwise inside the
+    emulator: what the two-phase vmult will stream)"""
+    case = Case(ncell, k=k, faces_u=[0, 3, 4, 5], faces_p=[1], linearization=lin, physical_type=phys, tau_grad_div=0.3,
+                damping=0.2, density=1.3, density_diff=-0.5, steps=3)
+    prm = case.prm
+    src_u, src_p, old_u, oo_u = case.random_u(), case.random_p(), case.random_u(), case.random_u()
+    rho, mu, damp = case.random_coefficients()
+    lin_ref = np.zeros(case.n_cells * case.nq * 12)
+    ref_u, ref_p = orc.ns_residual(case.mesh, k, prm, src_u, src_p, old_u, oo_u, con_u=case.con_u, con_p=case.con_p,
+                                   lin=lin_ref, rho=rho, mu=mu, damp=damp)
+    lin_mode = 0 if prm.linearization == 0 else 1
+    gamma = prm.weight if prm.physical_type == 0 else 0.0
+    coef = np.array([gamma * prm.density - prm.damping, prm.tau1 * prm.density, prm.beta, prm.tau_grad_div,
+                     prm.viscosity * prm.tau1, gamma, prm.tau1, 1.0, prm.tau1])
+    old_comb = prm.weight_old * old_u + prm.weight_old_old * oo_u if prm.physical_type == 0 else None
+    sum_u, sum_p = np.full(case.n_u, np.nan), np.full(case.n_p, np.nan)
+    lin_generic = np.zeros(case.n_cells * 12 * case.nq)
+    dp = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+    emu.hox_emu_residual_varco.restype = C.c_int
+    rc = emu.hox_emu_residual_varco(k, (C.c_int * 3)(*case.ncell), (C.c_double * 3)(*[case.mesh.h[d] for d in range(3)]), lin_mode,
+                                    dp(coef), C.c_double(1.0 if prm.physical_type == 0 else 0.0), face_bits(case.faces_u, 3),
+                                    face_bits(case.faces_p, 1), dp(src_u), dp(src_p), dp(old_comb), dp(rho), dp(mu), dp(damp),
+                                    dp(sum_u), dp(sum_p), dp(lin_generic), lx if lx else case.ncell[0])
+    assert rc == 0, rc
+    assert rel_l2(-sum_u, ref_u) < TOL and rel_l2(-sum_p, ref_p) < TOL, (rel_l2(-sum_u, ref_u), rel_l2(-sum_p, ref_p))
+    got = lin_generic.reshape(case.n_cells, 12, case.nq).transpose(0, 2, 1)
+    ncomp = 12 if lin_mode == 0 else 4
+    assert rel_l2(got[:, :, :ncomp], lin_ref.reshape(case.n_cells, case.nq, 12)[:, :, :ncomp]) < TOL
