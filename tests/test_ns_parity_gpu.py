@@ -993,6 +993,62 @@ def test_two_phase_residual_x_marching_kernel(k, ncell, lin, phys, chunk):
         assert rel_l2(gu, ref3_u) < TOL and rel_l2(gp, ref3_p) < TOL, variant
 
 
+def test_lazy_state_of_the_newton_residual():
+    """adaflo_set_q2_lazy_state (round 6): with the recompute-state vmult as consumer the Q2/Q1 Newton residual does not lay
+    out the quadrature-point state (NavierStokesMatrix::residual fills linearized_velocities in its cell loop,
+    navier_stokes_matrix.cc:778-799: deferred here, not dropped).  Everything a caller can observe is bitwise what the eager
+    residual gives: right-hand side, vmult, velocity_vmult, the canonical state (laid out on demand), the streaming kernel
+    after a change of variant, the frozen operator; and the device memory the state would take stays free until somebody asks"""
+    import torch
+    ncell = (24, 24, 24)
+    case = Case(ncell, k=2, lower=(0., 0., 0.), upper=(1., 1., 1.), steps=3, tau_grad_div=0.1)
+    src_u, src_p = case.smooth_u(0.1) + 0.05 * case.random_u(), case.smooth_p(0.1)
+    old_u, oldold_u = case.smooth_u(0.05), case.smooth_u(0.0)
+    vm_u, vm_p = case.random_u(), case.random_p()
+    state_bytes = case.n_cells * 27 * 12 * 8
+    out, taken = {}, {}
+    for lazy in (True, False):
+        op = case.engine()
+        op.set_lazy_state(lazy)
+        rhs, dst = op.block_vector(), op.block_vector()
+        vsrc, vdst = op.initialize_u_vector(vm_u), op.initialize_u_vector()
+        old, oldold = op.block_vector(old_u), op.block_vector(oldold_u)
+        sol, vm = op.block_vector(src_u, src_p), op.block_vector(vm_u, vm_p)
+        op.residual(rhs, sol, None, old, oldold)
+        op.vmult(dst, vm)
+        op.velocity_vmult(vdst, vsrc)
+        op.synchronize()
+        res = [a.copy() for a in rhs.numpy()] + [a.copy() for a in dst.numpy()] + [vdst.numpy().copy()]
+        torch.cuda.synchronize()
+        free = torch.cuda.mem_get_info()[0]
+        res.append(op.get_linearization().copy())               # laid out now: streaming copy (lazy only) + canonical copy
+        taken[lazy] = free - torch.cuda.mem_get_info()[0]
+        op.vmult(dst, vm)                                       # (recomputed again: the nodal copy is still current)
+        res += [a.copy() for a in dst.numpy()]
+        op.residual(rhs, sol, None, old, oldold)                # deferred again
+        op.set_kernel_variant(4)                                # the streaming kernel needs the laid-out state
+        op.vmult(dst, vm)
+        res += [a.copy() for a in dst.numpy()]
+        op.set_kernel_variant(1)
+        op.residual(rhs, sol, None, old, oldold)
+        op.fix_linearization_point()                            # frozen copies are made from the laid-out state
+        op.residual(rhs, op.block_vector(0.5 * src_u, src_p), None, old, oldold)
+        op.velocity_vmult(vdst, vsrc)
+        res.append(vdst.numpy().copy())
+        out[lazy] = res
+        del rhs, dst, vsrc, vdst, old, oldold, sol, vm
+        op.clear()
+    for a, b in zip(out[True], out[False]):
+        assert np.array_equal(a, b)
+    # the lazy residual had not allocated the streaming copy: asking for the state takes that much more device memory
+    assert taken[True] - taken[False] >= 0.9 * state_bytes, (taken, state_bytes)
+    lin_ref = np.zeros(case.n_cells * case.nq * 12)
+    orc.ns_residual(case.mesh, 2, case.prm, src_u, src_p, old_u, oldold_u, con_u=case.con_u, con_p=case.con_p, lin=lin_ref)
+    assert rel_l2(out[True][5], lin_ref) < TOL
+    ref_vel = orc.ns_velocity_vmult(case.mesh, 2, case.prm, vm_u, case.con_u, lin=lin_ref)
+    assert rel_l2(out[True][-1], ref_vel) < TOL
+
+
 @pytest.mark.parametrize("first_coefficients", [False, True])
 def test_new_coefficients_leave_the_state_of_the_sweep_residual_alone(first_coefficients):
     """adaflo_ns_set_coefficients after a sweep-kernel residual (what every two-phase time step does): the state exists
