@@ -1150,7 +1150,9 @@ int adaflo_ns_residual(adaflo_ctx *ctx, double *rhs_u, double *rhs_p, const doub
   a.oldold_u = old_old_u;
   TRY(ctx, launch_ns_cell_generic(ctx, OP_RESIDUAL, a), "cell kernel launch failed");
   ctx->lin_q2_valid = false;
-  if (ctx->variant >= 1 && q2_supported(ctx)) // (two-phase flow: the Q2/Q1 vmult recomputes the state from this copy)
+  // (two-phase flow: the Q2/Q1 vmult recomputes the state from this copy -- where the state is that of the solution itself)
+  if (ctx->variant >= 1 && q2_supported(ctx) &&
+      (ctx->ns.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON || ctx->ns.linearization == ADAFLO_COUPLED_IMPLICIT_PICARD))
     TRY(ctx, q2_capture_nodal(ctx, src_u), "nodal copy failed");
   // system_rhs.sadd(-1., 1., user_rhs)  :292
   TRY(ctx, launch_sadd(ctx, rhs_u, -1., user_u, 3 * ctx->n_nodes_u), "sadd failed");

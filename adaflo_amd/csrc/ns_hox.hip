@@ -366,7 +366,10 @@ namespace adaflo_hip
       HOX_LAUNCH_RES_V(LM, false)      \
   }
 #ifndef HOX_EXT_KMAX
-#define HOX_EXT_KMAX 5 // (k = 5 since round 6, see HOX_EXT_LB in ns_hox_kernel.hpp; -DHOX_EXT_KMAX=4 sends it to the generic kernel)
+#define HOX_EXT_KMAX 4 // (k = 5: generic kernel.  Its build for one workgroup per CU stores the pressure rows of the valid cells of
+                       // PARTIAL z-tiles to wild addresses (or faults), run-to-run differently, whenever the instruction stream moves:
+                       // round 5, "gone" after an address rewrite, back in round 6 after an unrelated edit of the header -- see
+                       // HOX_EXT_LB in ns_hox_kernel.hpp and DESIGN.md section 8; -DHOX_EXT_KMAX=5 builds it for the probes)
 #endif
 #define HOX_LAUNCH_RES_EXT(LM)                                                                                            \
   {                                                                                                                       \
@@ -467,7 +470,7 @@ namespace adaflo_hip
       if (residual && lin_mode != 2)
         {
           if (HOX_RCP_BUILD)
-            if (int e = q2_capture_nodal(ctx, src_u)) // (the recompute-state mode of the vmults of this Newton step)
+            if (int e = q2_capture_nodal(ctx, ext_comb ? ext_comb : src_u)) // (the recompute-state mode of the vmults of this Newton step)
               return e;
           // the streaming copy is now THE state: the generic copy is stale until somebody asks for it
           ctx->lin_gen++;

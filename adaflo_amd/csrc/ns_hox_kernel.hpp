@@ -477,15 +477,19 @@ namespace adaflo_hip
 #ifndef HOX_RCP_LB
 #define HOX_RCP_LB HOX_LB
 #endif
-    // k = 5 at one workgroup per CU (256 VGPRs + 148 AGPRs + 550 scalar-register spills into VGPR lanes).  History: the build
-    // of commit b79a1e7 (round 5) stored wrong, run-to-run DIFFERENT pressure rows (and once faulted on an address) with this
-    // setting, and the instance was sent to the generic kernel.  Round 6: reproduced on that commit (profiles/r06_k5_old.log);
-    // on the tree since b0746b5 (node lines through one per-lane address + immediate offsets instead of 18 hoisted and
-    // spilled 32-bit index sums) the same setting is exact on every parity case, repeatedly, and bitwise equal to the
-    // 256-register build of the same source (tests/test_lb_differential_gpu.py holds that for every kernel built for one
-    // workgroup per CU).  A result that changes from run to run is a read of something not yet written, not a wrong
-    // instruction stream; which read it was in the old address code was not established ("register-allocation
-    // dependent results").  3.13 against 4.01 ms for the generic kernel at 48^3.
+    // k = 5 at one workgroup per CU (256 VGPRs + 146 AGPRs + 568 scalar-register spills into VGPR lanes) is NOT shipped
+    // (HOX_EXT_KMAX = 4 in ns_hox.hip: the generic kernel serves the instance).  History: the build of commit b79a1e7 (round 5)
+    // stored wrong, run-to-run DIFFERENT pressure rows (and once faulted on an address); after the address rewrite of b0746b5
+    // it was exact on every parity case and bitwise equal to its 256-register build, and round 6 shipped it -- until an
+    // unrelated edit of this header (the variable-coefficient residual: other template instances) moved its instruction
+    // stream and the fault was back, caught by the parity test and by tests/test_lb_differential_gpu.py.  What is known
+    // (profiles/r06_k5_ext_round6.log): the rows lost are the pressure rows of the VALID cells of a
+    // partial z-tile (the store goes to a wild address: rows stay zero, or the process dies of a memory fault); wait states
+    // around every VALU / AGPR / lane instruction do not cure it (re-assembled listings); a full EXEC mask does not (HOX_MIRROR);
+    // -amdgpu-prealloc-sgpr-spill-vgprs does not; the VGPRs that carry the scalar spills are touched by nothing but
+    // v_readlane / v_writelane; with the scalar spills in scratch memory (-mllvm -amdgpu-spill-sgpr-to-vgpr=0) the instance is
+    // exact five runs out of five -- and 3.4x slower (10.8 against 3.2 ms at 48^3), which also moves every timing.  Neither a
+    // compiler fault nor a race in this source is established; k = 3, 4 (223 / 349 scalar spills) pass all of the above.
 #ifndef HOX_EXT_LB
 #define HOX_EXT_LB 1
 #endif
@@ -513,13 +517,21 @@ namespace adaflo_hip
       using TB = Tab<K>;
       double *const lds = dyn_lds();
 
-      const int tid = threadIdx.x, lane = tid & 63;
+      const int tid = threadIdx.x, hw_lane = tid & 63;
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-      const int cw = lane / PL, l = lane % PL;
+      const int cw = hw_lane / PL, l0 = hw_lane % PL;
       // lanes beyond the (k+1)^2 lines of a cell leave at once (k = 4: 7 of 32, k = 5: 28 of 64): the rest of the
-      // kernel runs under ONE exec mask, no LDS store needs a branch (s_barrier counts waves, not lanes)
-      if (l >= NL)
+      // kernel runs under ONE exec mask, no LDS store needs a branch (s_barrier counts waves, not lanes).
+      // HOX_MIRROR = 1 (diagnostic, round 6): in the residual modes the spare lanes stay and MIRROR a line of their cell -- the
+      // same loads, the same stores of the same values to the same addresses --, so that the kernel runs with a full EXEC
+      // mask.  Built to test whether the k = 5 fault (HOX_EXT_LB above) comes from retired lanes: it does not.
+#ifndef HOX_MIRROR
+#define HOX_MIRROR 0
+#endif
+      constexpr bool MIRROR = HOX_MIRROR && RES && 2 * NL >= PL;
+      if (!MIRROR && l0 >= NL)
         return;
+      const int l = (MIRROR && l0 >= NL) ? l0 - NL : l0, lane = cw * PL + l; // (lane: the logical lane all roles derive from)
       constexpr bool active = true;
       const int      lc = l;
       const int      a = lc % N, b = lc / N;
@@ -608,7 +620,7 @@ namespace adaflo_hip
       constexpr int  RPTS = DEEP ? N : 2, RING_BYTES = DEEP ? G::RING_BYTES_DEEP : G::RING_BYTES; // points in the ring
       constexpr int  SLOT = G::SLOT, RS = RPTS * (NST / 2 > 0 ? NST / 2 : 1);
       char *const    ring = reinterpret_cast<char *>(lds + 4 * G::WAVE + G::PUB_DOUBLES) + wave * RING_BYTES;
-      const unsigned ring_m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_byte_addr(ring)), ring_lane = lds_byte_addr(ring) + 16 * lane;
+      const unsigned ring_m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_byte_addr(ring)), ring_lane = lds_byte_addr(ring) + 16 * hw_lane;
       // hand-off flags (HOX_FLAGS): pub[w] = number of combines wave w has published, done[w] = ... has collected
       const unsigned flag0 = lds_byte_addr(reinterpret_cast<char *>(lds + 4 * G::WAVE + G::PUB_DOUBLES) + 4 * RING_BYTES);
       int            seq   = 0;

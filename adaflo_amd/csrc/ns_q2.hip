@@ -665,7 +665,7 @@ namespace adaflo_hip
       constexpr bool RING_ON = LIN_MODE != 2 && !RES && !RCP; // state stream through the LDS ring (RCP with variable
                                                               // coefficients: rho, mu, damping by plain loads from the
                                                               // generic arrays, 24 B per cell and point, L2-friendly)
-      static_assert(!RCP || (LIN_MODE == 0 && !RES && !DIV), "recompute mode: Newton vmult");
+      static_assert(!RCP || (LIN_MODE != 2 && !RES && !DIV), "recompute mode: Newton / Picard-type vmult");
       static_assert(!EXT || (RES && LIN_MODE != 0 && !VARCO && WITH_P), "extrapolating residual: semi-implicit / explicit, constant coefficients");
       constexpr int L_OLDP = L_RING, L_EXTP = L_TOTAL; // plane buffers of the second / third nodal field
 #if defined(Q2_QG_OFF) // (development: the unguarded form in the one-workgroup-per-CU builds, scripts/dev/lb_diff_ext.sh;
@@ -1292,8 +1292,10 @@ namespace adaflo_hip
                 }
               else if (LIN_MODE == 1) // Picard-type :817-826, state = (u_lin, div_lin)
                 {
+                  // (recompute mode, round 6: div u_lin is the trace formed through the quad -- for the schemes that linearise
+                  // about the extrapolated velocity the nodal field is that extrapolation)
                   const double ub0 = r_ub0, ub1 = r_ub1, ub2 = r_ub2;
-                  double       res = (A.beta * st0.y) * Vq;
+                  double       res = (A.beta * (RCP ? r_trl : st0.y)) * Vq;
                   res += ub0 * g0;
                   res += ub1 * g1;
                   res += ub2 * g2;
@@ -2072,7 +2074,7 @@ namespace adaflo_hip
     // engine knows); variable coefficients are read from the generic arrays.  velocity_vmult: the frozen nodal copy and
     // the frozen coefficients if fix_linearization_point has been called, else the current ones -- as the streamed state
     const bool frozen    = op == OP_VMULT_VELOCITY && (ctx->lin_q2_prec.p || ctx->lin_prec.p);
-    const bool recompute = ctx->q2_recompute && !residual && (op == OP_VMULT || op == OP_VMULT_VELOCITY) && q2_lin_mode(ctx) == 0 &&
+    const bool recompute = ctx->q2_recompute && !residual && (op == OP_VMULT || op == OP_VMULT_VELOCITY) && q2_lin_mode(ctx) != 2 &&
                            (frozen ? (ctx->lin_nodal_prec_valid && ctx->lin_nodal_prec.p != nullptr) : lin_nodal_current(ctx));
     const bool rc_varco  = recompute && (frozen ? ctx->rho_prec.p != nullptr : q2_varco(ctx));
     if (!residual && op != OP_DIVERGENCE && !recompute)
@@ -2412,10 +2414,14 @@ namespace adaflo_hip
       {
 #define Q2_LAUNCH_RC(WP, IS)                                 \
   {                                                          \
-    if (rc_varco)                                            \
+    if (rc_varco && lin_mode == 0)                           \
       Q2_LAUNCH_V7(0, WP, IS, true, false, false, true)      \
-    else                                                     \
+    else if (rc_varco)                                       \
+      Q2_LAUNCH_V7(1, WP, IS, true, false, false, true)      \
+    else if (lin_mode == 0)                                  \
       Q2_LAUNCH_V7(0, WP, IS, false, false, false, true)     \
+    else                                                     \
+      Q2_LAUNCH_V7(1, WP, IS, false, false, false, true)     \
   }
         if (with_p && iso)
           Q2_LAUNCH_RC(true, true)
@@ -2494,12 +2500,13 @@ namespace adaflo_hip
   {
     if (ctx->k != 2 || ctx->flat)
       return false;
-    // variable coefficients (two-phase flow, round 5): with the Newton linearisation and the recompute-state mode of the
-    // vmults (kernel variant 1) -- the state then leaves the kernel in the constant-coefficient layout and nobody reads it
-    // unless asked (get_linearization, a change of variant: re-laid out then)
+    // variable coefficients (two-phase flow, round 5): with the Newton -- round 6: or the Picard-type -- linearisation and the
+    // recompute-state mode of the vmults (kernel variant 1) -- the state then leaves the kernel in the constant-coefficient
+    // layout (or not at all: lazy state) and nobody reads it unless asked (get_linearization, a change of variant: re-laid
+    // out then)
     if (ctx->rho.p || ctx->mu.p || ctx->damp.p)
       return q2_varco(ctx) && ctx->q2_recompute && ctx->ns.physical_type != ADAFLO_STOKES &&
-             ctx->ns.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON;
+             (ctx->ns.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON || ctx->ns.linearization == ADAFLO_COUPLED_IMPLICIT_PICARD);
     const NSDev &P = ctx->ns;
     if (P.physical_type == ADAFLO_STOKES || P.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON ||
         P.linearization == ADAFLO_COUPLED_IMPLICIT_PICARD)
@@ -2516,9 +2523,11 @@ namespace adaflo_hip
   // old_comb = weight_old u_old + weight_old_old u_old_old at the nodes (or nullptr).  Leaves the
   // quadrature-point state of `src` in the streaming layout (ctx->lin_q2).
   // (the caller has bumped ctx->lin_serial for the state it is about to produce)
+  // (src_u: the nodal field whose interpolation IS the state -- the solution for Newton / Picard-type, the extrapolated old
+  // velocity for the semi-implicit and the projection scheme)
   int q2_capture_nodal(adaflo_ctx *ctx, const double *src_u)
   {
-    if (!ctx->q2_recompute || q2_lin_mode(ctx) != 0)
+    if (!ctx->q2_recompute || q2_lin_mode(ctx) == 2)
       return 0;
     const size_t nu = 3 * (size_t)ctx->n_nodes_u;
     if (ctx->lin_nodal.count != nu)
@@ -2581,8 +2590,10 @@ namespace adaflo_hip
   {
     if (!ctx->lin_q2_deferred)
       return 0;
-    if (!lin_nodal_current(ctx) || q2_lin_mode(ctx) != 0)
+    if (!lin_nodal_current(ctx) || q2_lin_mode(ctx) == 2)
       return ADAFLO_ENOTINIT;
+    // (semi-implicit / projection scheme: the state is that of the extrapolated velocity, which is what the nodal copy holds)
+    const bool ext = ctx->ns.linearization == ADAFLO_COUPLED_VELOCITY_SEMI_IMPLICIT || ctx->ns.linearization == ADAFLO_PROJECTION;
     const size_t nu = 3 * (size_t)ctx->n_nodes_u, np = (size_t)ctx->n_nodes_p;
     if (int e = q2_alloc_state(ctx))
       return e;
@@ -2595,11 +2606,11 @@ namespace adaflo_hip
     if (hipMemsetAsync(ctx->res_ext.p, 0, np * sizeof(double), ctx->stream) != hipSuccess)
       return ADAFLO_EHIP;
     if (int e = q2_launch(ctx, OP_VMULT, ctx->res_sum_u.p, ctx->res_sum_p.p, ctx->lin_nodal.p, ctx->res_ext.p, -1, 0u, true,
-                          ctx->lin_nodal.p, 0., nullptr, false))
+                          ctx->lin_nodal.p, 0., ext ? ctx->lin_nodal.p : nullptr, false))
       return e;
     ctx->lin_q2_deferred = false;
     ctx->lin_q2_valid    = true;
-    ctx->lin_q2_mode     = 0;
+    ctx->lin_q2_mode     = q2_lin_mode(ctx);
     ctx->lin_q2_varco    = false;
     return 0;
   }
@@ -2609,7 +2620,7 @@ namespace adaflo_hip
   {
     const int lin_mode = q2_lin_mode(ctx);
     // Newton + recompute-state vmult (kernel variant 1): nobody reads the laid-out state unless asked (q2_materialize_state)
-    const bool defer = lin_mode == 0 && ctx->q2_recompute && ctx->q2_lazy_state && !ext_comb;
+    const bool defer = lin_mode != 2 && ctx->q2_recompute && ctx->q2_lazy_state;
     ctx->lin_q2_deferred = false; // (the caller has bumped lin_serial: whatever was deferred belongs to the state before)
     if (defer)
       {
@@ -2633,9 +2644,10 @@ namespace adaflo_hip
         ctx->lin_q2_mode  = lin_mode;
         ctx->lin_q2_varco = false;
       }
-    // recompute-state mode: keep the nodal linearisation point (the solution this residual was evaluated at)
-    if (lin_mode == 0)
-      if (int e = q2_capture_nodal(ctx, src_u))
+    // recompute-state mode: keep the nodal linearisation point (the solution this residual was evaluated at; the
+    // extrapolated old velocity for the schemes that linearise about it)
+    if (lin_mode != 2)
+      if (int e = q2_capture_nodal(ctx, ext_comb ? ext_comb : src_u))
         return e;
     ctx->lin_q2_deferred = defer; // (with the nodal copy in place: the invariant of q2_materialize_state)
     return 0;

@@ -27,11 +27,14 @@ def timeit(fn, sync, reps=20, warm=3):
     return (time.perf_counter() - t0) / reps
 
 
-def ns_case(k, n, variant, two_phase=False, state_from_residual=False):
+def ns_case(k, n, variant, two_phase=False, state_from_residual=False, linearization=None):
     """state_from_residual: the state comes from NavierStokesMatrix::residual of the same context, the way a Newton
     step produces it -- for Q2/Q1 with Newton linearisation the vmult then recomputes it from the nodal linearisation
     point (kernel variant 1; variant 4 streams it); otherwise a random canonical array is set and streamed"""
     fp = adaflo_amd.FlowParameters(velocity_degree=k, density_diff=0.5 if two_phase else 0.0)
+    if linearization is not None:                    # (index into parameters.LINEARIZATIONS)
+        from adaflo_amd.parameters import LINEARIZATIONS
+        fp.linearization = {v: n for n, v in LINEARIZATIONS.items()}[linearization]
     ts = adaflo_amd.TimeStepping(fp)
     for _ in range(3):
         ts.next()
@@ -53,7 +56,8 @@ def ns_case(k, n, variant, two_phase=False, state_from_residual=False):
     t = timeit(lambda: op.vmult(dst, src), op.synchronize)
     ndof = op.n_dofs_u() + op.n_dofs_p()
     b_alg = op.n_cells() * (16 * (3 * k ** 3 + (k - 1) ** 3) + 8 * (15 if two_phase else 12) * nq)
-    print(json.dumps({"op": "ns_vmult" + ("_two_phase" if two_phase else "") + ("_after_residual" if state_from_residual else ""),
+    print(json.dumps({"op": "ns_vmult" + ("_two_phase" if two_phase else "") + ("_after_residual" if state_from_residual else "")
+                      + ("" if linearization is None else "_lin%d" % linearization),
                       "k": k, "cells": n, "variant": variant, "ms": round(t * 1e3, 4),
                       "MDoF/s": round(ndof / t / 1e6, 1), "alg_GB/s": round(b_alg / t / 1e9, 1),
                       "frac_of_8TB/s": round(b_alg / t / 8e12, 4)}), flush=True)

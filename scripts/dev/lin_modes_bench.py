@@ -1,0 +1,8 @@
+import os, sys
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, os.path.join(ROOT, "scripts")); sys.path.insert(0, ROOT)
+import bench_ops as b
+for lin in (0, 1, 2, 4, 3):
+    b.ns_case(2, 128, 1, state_from_residual=True, linearization=lin)
+for lin in (0, 1, 2):
+    b.ns_case(4, 64, 1, state_from_residual=True, linearization=lin)

@@ -1,0 +1,3 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/../..}"
+timeout 2400 python -m pytest -q -m gpu -x tests/test_ns_parity_gpu.py tests/test_state_machine_gpu.py tests/test_lb_differential_gpu.py tests/test_full_size_gpu.py 2>&1 | tail -8
