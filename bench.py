@@ -557,10 +557,12 @@ def measure(args, world, rank, local_rank):
     # point the residual left (kernel variant 1; variant 4 streams).  `achieved` / `frac` stay what the contract defines --
     # SURVEY 8(d)'s algorithmic bytes per cell over the kernel time --; the bytes this kernel has to move are listed next
     # to them (vectors + 24 k^3 B per cell of nodal linearisation point), and `traffic` is what the PMC counters saw
-    recomputed = k == 2 and args.variant in (1, 2, 3) and args.linearization == "coupled implicit Newton"
+    # (round 6: the Picard-type state as well -- Picard, semi-implicit and projection schemes; the explicit scheme has no state)
+    newton = args.linearization == "coupled implicit Newton"
+    recomputed = k == 2 and args.variant in (1, 2, 3) and args.linearization != "coupled velocity explicit"
     # FP64 work of the recompute mode, counted in the ISA of ns_q2_kernel<0,true,true,false,false,false,true,false>:
     # per cell layer and lane 770 v_fmac_f64 + 328 v_fma_f64 (2 flop) + 458 v_mul_f64 + 342 v_add_f64, four lanes per cell
-    flop_per_cell = 4 * (2 * (770 + 328) + 458 + 342) if recomputed else None
+    flop_per_cell = 4 * (2 * (770 + 328) + 458 + 342) if (recomputed and newton) else None
     b_moved_launch = (16 * (3 * k ** 3 + (k - 1) ** 3) + 24 * k ** 3) * n_cells_local if recomputed else b_alg_launch
     out = {
         "metric": "MDoF/s for NavierStokesMatrix::vmult (3D Q%d/Q%d)" % (k, k - 1),
@@ -593,7 +595,7 @@ def measure(args, world, rank, local_rank):
                      "frac_bytes_to_move": round(b_moved_launch / kernel_avg / 1e9 / HBM_PEAK_GBS, 4) if kernel_avg > 0 else None,
                      "vmult_ms_device": round(1e3 * msec / max(mcount, 1), 4)},
     }
-    if recomputed and kernel_avg > 0:
+    if recomputed and newton and kernel_avg > 0:
         # the kernel that recomputes the state is bound by FP64 issue, not by HBM: `achieved` / `frac` above stay
         # the contract's algorithmic bytes over the kernel time; this object prices the same launch against the FP64 vector peak
         tf = flop_per_cell * n_cells_local / kernel_avg / 1e12
