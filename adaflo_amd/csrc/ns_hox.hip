@@ -228,9 +228,12 @@ namespace adaflo_hip
               return e;
           if (lin_mode != 2)
             {
-              if (int e = ensure(ctx->hox_lin, state_doubles<K>(ctx, lin_mode, varco)))
+              // (+ one cell: the sink of the cells beyond the mesh, HXArgs::lin_sink)
+              const size_t n_state = state_doubles<K>(ctx, lin_mode, varco);
+              if (int e = ensure(ctx->hox_lin, n_state + (size_t)N * (nst_of(lin_mode) / 2 + (varco ? 2 : 0)) * G::CPW * G::NL * 2))
                 return e;
-              A.lin_out = ctx->hox_lin.p;
+              A.lin_out  = ctx->hox_lin.p;
+              A.lin_sink = ctx->hox_lin.p + n_state;
             }
         }
       else
@@ -366,10 +369,9 @@ namespace adaflo_hip
       HOX_LAUNCH_RES_V(LM, false)      \
   }
 #ifndef HOX_EXT_KMAX
-#define HOX_EXT_KMAX 4 // (k = 5: generic kernel.  Its build for one workgroup per CU stores the pressure rows of the valid cells of
-                       // PARTIAL z-tiles to wild addresses (or faults), run-to-run differently, whenever the instruction stream moves:
-                       // round 5, "gone" after an address rewrite, back in round 6 after an unrelated edit of the header -- see
-                       // HOX_EXT_LB in ns_hox_kernel.hpp and DESIGN.md section 8; -DHOX_EXT_KMAX=5 builds it for the probes)
+#define HOX_EXT_KMAX 5 // (k = 5 at one workgroup per CU: HOX_EXT_LB in ns_hox_kernel.hpp; its fault of rounds 5 / 6 -- spill copies that
+                       // hipcc placed under the THEN mask of `if (fl & F_CELL)` -- went with that branch; -DHOX_EXT_KMAX=4 sends the
+                       // instance to the generic kernel)
 #endif
 #define HOX_LAUNCH_RES_EXT(LM)                                                                                            \
   {                                                                                                                       \

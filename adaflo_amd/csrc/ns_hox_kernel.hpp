@@ -142,6 +142,7 @@ namespace adaflo_hip
       const double *old_u;
       double        c_old;
       double       *lin_out;
+      double       *lin_sink; // (residual modes: one cell's worth of state behind lin_out, where cells beyond the mesh "store")
       double       *slab_u, *xslab_u, *slab_p, *xslab_p;
       const double *tab; // Tab<K>: the 1D matrices in even / odd form and the constants of the quadrature-point operation
       // phased execution for the multi-GPU overlap (as in ns_q2.hip / ns_ho.hip)
@@ -477,19 +478,20 @@ namespace adaflo_hip
 #ifndef HOX_RCP_LB
 #define HOX_RCP_LB HOX_LB
 #endif
-    // k = 5 at one workgroup per CU (256 VGPRs + 146 AGPRs + 568 scalar-register spills into VGPR lanes) is NOT shipped
-    // (HOX_EXT_KMAX = 4 in ns_hox.hip: the generic kernel serves the instance).  History: the build of commit b79a1e7 (round 5)
-    // stored wrong, run-to-run DIFFERENT pressure rows (and once faulted on an address); after the address rewrite of b0746b5
-    // it was exact on every parity case and bitwise equal to its 256-register build, and round 6 shipped it -- until an
-    // unrelated edit of this header (the variable-coefficient residual: other template instances) moved its instruction
-    // stream and the fault was back, caught by the parity test and by tests/test_lb_differential_gpu.py.  What is known
-    // (profiles/r06_k5_ext_round6.log): the rows lost are the pressure rows of the VALID cells of a
-    // partial z-tile (the store goes to a wild address: rows stay zero, or the process dies of a memory fault); wait states
-    // around every VALU / AGPR / lane instruction do not cure it (re-assembled listings); a full EXEC mask does not (HOX_MIRROR);
-    // -amdgpu-prealloc-sgpr-spill-vgprs does not; the VGPRs that carry the scalar spills are touched by nothing but
-    // v_readlane / v_writelane; with the scalar spills in scratch memory (-mllvm -amdgpu-spill-sgpr-to-vgpr=0) the instance is
-    // exact five runs out of five -- and 3.4x slower (10.8 against 3.2 ms at 48^3), which also moves every timing.  Neither a
-    // compiler fault nor a race in this source is established; k = 3, 4 (223 / 349 scalar spills) pass all of the above.
+    // k = 5 at one workgroup per CU (256 VGPRs + 146 AGPRs + 568 scalar-register spills into VGPR lanes).  History: the build
+    // of commit b79a1e7 (round 5) stored wrong, run-to-run DIFFERENT pressure rows (and sometimes died of a memory fault) on
+    // meshes with a partial z-tile; after an address rewrite (b0746b5) it was exact, round 6 shipped it -- and an unrelated
+    // edit of this header brought the fault back.  Root cause (round 6, profiles/r06_k5_ext_round6.log):
+    // the residual mode stored the state under `if (fl & F_CELL)` at the point of the highest register pressure, and hipcc 7.2
+    // placed eight AGPR spill copies of values that are live for ALL lanes (the flag word, the lane number, ...) into the FLOW
+    // block of that if / else, ahead of the s_andn2_saveexec that flips EXEC -- where they execute under the THEN mask.  The
+    // lanes of cells beyond the mesh (whole waves for k = 5: one cell per wave) came back from the join with whatever the
+    // AGPRs held before, i.e. with random flags and lane numbers, and stored their sums over the rows of cell (0, 0) of the
+    // cross-section -- the valid cell of a partial tile -- or to wild addresses.  Proof: the SAME listing with those eight
+    // copies moved behind the s_or_b64 exec that closes the region (scripts/dev/isa_patch_build.py flow-spills) is exact,
+    // twelve runs of twelve; the unpatched one fails every run.  Fix at the source: no branch there -- cells beyond the
+    // mesh store into a sink (HXArgs::lin_sink); scripts/dev/isa_flow_audit.py lists such copies per kernel (now: none in
+    // any unit of the library).
 #ifndef HOX_EXT_LB
 #define HOX_EXT_LB 1
 #endif
@@ -1282,14 +1284,19 @@ namespace adaflo_hip
               if constexpr (RES && NSO > 0)
                 {
                   // the state of the vmults to come, in their streaming layout: piece e = values (2 e, 2 e + 1) of
-                  // (u, grad u) row-major (Newton) or (u, div u) (Picard-type); cells beyond the mesh store nothing
-                  if (fl & F_CELL)
+                  // (u, grad u) row-major (Newton) or (u, div u) (Picard-type).  Cells beyond the mesh store into a sink
+                  // behind the state -- NOT "nothing" under `if (fl & F_CELL)`: this is the point of the highest register
+                  // pressure of the kernel, and hipcc 7.2 put the AGPR spills of values that are live for ALL lanes (the
+                  // flag word, the lane number) into the Flow block of that if / else, where they execute under the THEN
+                  // mask: lanes of cells beyond the mesh -- whole waves for k = 5 -- came back from the join with stale
+                  // flags and stored to wild addresses (the k = 5 extrapolating residual of rounds 5, 6)
                     {
                       // (x-line loop, lane (y, z) = (a, b), point i along x, next to a z-line vmult: the piece of point
                       // (i, a, b) belongs to line (x, y) = (i, a), point b)
+                      double *const so_cell = (fl & F_CELL) ? sog + (size_t)cx * SO_CELL : A.lin_sink;
                       double *const so = (HOX_FUSED && !FUSED) ?
-                                           sog + ((size_t)cx * SO_CELL + (unsigned)(b * SO_POINT) + (unsigned)(cw * NL + i + N * a) * 2) :
-                                           sog + ((size_t)cx * SO_CELL + (unsigned)(i * SO_POINT) + st_lane);
+                                           so_cell + ((unsigned)(b * SO_POINT) + (unsigned)(cw * NL + i + N * a) * 2) :
+                                           so_cell + ((unsigned)(i * SO_POINT) + st_lane);
                       if constexpr (EXT) // (u_ext, div u_ext): the state of the semi-implicit vmult
                         {
                           so[0] = GL[0][0][i], so[1] = GL[1][0][i];

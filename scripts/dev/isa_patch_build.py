@@ -6,7 +6,8 @@ clang-offload-bundler -> host .s with .incbin of the new fat binary -> object ->
    edits: poison (every vector register that is dead at the header of the kernel's largest loop -- first access in the loop body
           is a write -- gets a value that names it, 2 (1 + N / 256) as the high word of a double, at the top of every iteration:
           neutral for a correct instruction stream; in a wrong one a stale read shows WHICH register it read) | none | nop-valu (s_nop 7 behind every VALU instruction of the kernel, asm statements untouched) |
-          nop-dpp (s_nop 7 ahead of and behind every DPP move) | nop-agpr (s_nop 7 around v_accvgpr_* and v_readlane / v_writelane)"""
+          nop-dpp (s_nop 7 ahead of and behind every DPP move) | nop-agpr (s_nop 7 around v_accvgpr_* and v_readlane / v_writelane) |
+          flow-spills (register-allocator copies in the Flow block of a divergent if / else moved behind the join)"""
 import os
 import re
 import subprocess
@@ -109,6 +110,73 @@ if edit == "poison":
     ins = ["\tv_mov_b32_e32 v%d, 0x%x" % (r, 0x40000000 | (r << 12)) for r in dead]
     out = out[:start + 1] + body[:lo + 1] + ins + body[lo + 1:]
     print("poison: loop of %d lines, %d registers dead at its header" % (hi - lo, len(dead)))
+if edit == "flow-spills":
+    # Round 6, second half: register-allocator copies (v_accvgpr_write / v_mov) that sit in the FLOW block of a divergent
+    # if / else -- between the block's label and the s_andn2_saveexec that flips EXEC to the else side -- execute under the
+    # THEN mask only; a value that is live for all lanes and re-loaded after the join is lost for the else lanes.  Move such
+    # copies behind the s_or_b64 exec, exec that closes the region (checked: sources not written, destinations not touched
+    # in between).
+    REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
+
+    def regs(tok):
+        r = set()
+        for m in REG.finditer(tok):
+            if m.group(1):
+                r.add(m.group(1) + m.group(2))
+            else:
+                r.update(m.group(3) + str(x) for x in range(int(m.group(4)), int(m.group(5)) + 1))
+        return r
+    body = out[start + 1:]
+    moved, i = 0, 0
+    while i < len(body):
+        m = re.match(r"\s+s_andn2_saveexec_b64 (s\[\d+:\d+\]), (s\[\d+:\d+\])", body[i])
+        if not m or m.group(1) != m.group(2):
+            i += 1
+            continue
+        lab = i - 1
+        while lab >= 0 and not re.match(r"^\.LBB\d+_\d+:", body[lab]):
+            lab -= 1
+        close = None
+        for j in range(i + 1, min(i + 400, len(body))):
+            if re.match(r"\s+s_or_b64 exec, exec, " + re.escape(m.group(1)), body[j]):
+                close = j
+                break
+        if lab < 0 or close is None:
+            i += 1
+            continue
+        cand = [q for q in range(lab + 1, i) if re.match(r"\s+(v_accvgpr_write_b32|v_mov_b32_e32|v_mov_b64_e32) ", body[q])]
+        take = []
+        for q in cand:
+            ops = body[q].split(";")[0].split(None, 1)[1].split(",")
+            dst, src = regs(ops[0]), regs(",".join(ops[1:]))
+            ok = True
+            for r in range(lab + 1, close + 1):
+                if r == q:
+                    continue
+                t = body[r].split(";")[0].strip()
+                if not t or t.startswith("."):
+                    continue
+                parts = t.split(None, 1)
+                if len(parts) < 2:
+                    continue
+                allr = regs(parts[1])
+                d2 = set() if parts[0].startswith(("global_store", "ds_write", "s_", "v_cmp", "v_readlane", "v_writelane")) else regs(parts[1].split(",")[0])
+                if (r > q and (d2 & src)) or (allr & dst and r not in cand):
+                    ok = False
+                    break
+            if ok:
+                take.append(q)
+        if take:
+            lines = [body[q] for q in take]
+            for q in sorted(take, reverse=True):
+                del body[q]
+            pos = close - len(take) + 1
+            body[pos:pos] = lines
+            moved += len(take)
+            print("flow-spills: block at line %d: moved %d of %d copies behind the join" % (lab, len(take), len(cand)))
+        i = close + 1
+    out = out[:start + 1] + body
+    print("flow-spills: %d instructions moved" % moved)
 open(os.path.join(work, "dev_mod.s"), "w").write("\n".join(out))
 print("edit %s: %d s_nop inserted" % (edit, n_ins))
 run = lambda cmd: subprocess.check_call(cmd, cwd=work)

@@ -195,8 +195,10 @@ namespace
     A.c_old       = c_old;
     A.lin_u       = ext_comb; // (extrapolating schemes, template EXT)
     const int           npl = nst_of(lin_mode) / 2, npc = npl + (rho ? 2 : 0);
-    std::vector<double> state((size_t)A.ngz * A.ngy * A.ncx * N * npc * G::CPW * G::NL * 2 + 2, std::nan(""));
-    A.lin_out = state.data();
+    const size_t        n_state = (size_t)A.ngz * A.ngy * A.ncx * N * npc * G::CPW * G::NL * 2;
+    std::vector<double> state(n_state + (size_t)N * npc * G::CPW * G::NL * 2 + 2, std::nan("")); // (+ the sink of cells beyond the mesh)
+    A.lin_out  = state.data();
+    A.lin_sink = state.data() + n_state;
     // variable-coefficient residual (RES + VARCO): the coefficient stream, two pieces per point
     std::vector<double> coef_stream;
     if (rho)
