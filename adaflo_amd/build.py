@@ -27,6 +27,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+AUDIT = os.path.join(LIBDIR, ".isa_audit.json")
+
+
+def _audit_listing(path):
+    from . import isa_audit
+    with open(path, errors="replace") as f:
+        return isa_audit.summarize(isa_audit.flow_block_copies(f.read()))
+
+
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
@@ -34,19 +43,47 @@ def build(force=False, verbose=False):
         os.path.join(_HERE, "..", "include", "adaflo_hip.h")]
     objs = []
     procs = []
+    audits = []
     stamp, setting = os.path.join(LIBDIR, ".variants_setting"), os.environ.get("ADAFLO_BUILD_VARIANTS", "0")
     changed = not os.path.exists(stamp) or open(stamp).read() != setting
+    import json
+    report = {}
+    if os.path.exists(AUDIT):
+        try:
+            report = json.load(open(AUDIT))
+        except ValueError:
+            report = {}
     for s in srcs:
         o = os.path.join(LIBDIR, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + hdrs) or (changed and os.path.basename(s) in ("ns_ho.hip", "ns_hop.hip", "capi.hip")):
+        if force or _stale(o, [s] + hdrs) or (changed and os.path.basename(s) in ("ns_ho.hip", "ns_hop.hip", "capi.hip")) or \
+                os.path.basename(s)[:-4] not in report:   # (no audit record of the unit: compile it again)
             cmd = ["hipcc", "-c", s, "-o", o] + FLAGS
             if verbose:
                 print(" ".join(cmd))
             procs.append((s, subprocess.Popen(cmd)))
+            # the device listing of the same unit, for the audit below (a compile of its own: the product object is built
+            # exactly as before)
+            listing = o[:-2] + ".gfx950.s"
+            audits.append((s, listing, subprocess.Popen(["hipcc", "-S", "--cuda-device-only", s, "-o", listing] + FLAGS,
+                                                        stderr=subprocess.DEVNULL)))
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed for " + s)
+    # ISA audit (adaflo_amd/isa_audit.py): register-allocator copies under a partial EXEC mask in Flow blocks
+    for s, listing, p in audits:
+        unit = os.path.basename(s)[:-4]
+        if p.wait() != 0 or not os.path.exists(listing):
+            raise RuntimeError("hipcc -S failed for " + s)
+        report[unit] = _audit_listing(listing)
+        os.remove(listing)
+    if audits:
+        with open(AUDIT, "w") as f:
+            json.dump(report, f, indent=1, sort_keys=True)
+    bad = {u: r for u, r in report.items() if r.get("copies", 0) and os.path.exists(os.path.join(CSRC, u + ".hip"))}
+    if bad and os.environ.get("ADAFLO_ALLOW_FLOW_COPIES") != "1":
+        raise RuntimeError("ISA audit: register-allocator copies in Flow blocks ahead of the EXEC flip (they execute under the "
+                           "THEN mask; DESIGN.md section 8): %s -- restructure the branch, or ADAFLO_ALLOW_FLOW_COPIES=1" % bad)
     with open(stamp, "w") as f:
         f.write(setting)
     if force or procs or _stale(LIB, objs):

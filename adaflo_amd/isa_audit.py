@@ -1,0 +1,42 @@
+"""Build-time audit of the device listings (round 6).  hipcc 7.2 can place register-allocator copies -- AGPR spills
+(v_accvgpr_write / _read), v_mov copies, scratch spills -- of values that are live for ALL lanes into the FLOW block of a
+divergent if / else: between the block's label (the target of the s_cbranch_execz that skips the THEN part) and the
+s_andn2_saveexec that flips EXEC to the ELSE side.  There they execute under the THEN mask; lanes of the else side re-load
+stale registers behind the join.  This is what made the Q5/Q4 extrapolating residual store to wild addresses in rounds 5 and
+6 (the same listing with the copies moved behind the join is exact).  `flow_block_copies` finds the
+pattern in a gfx950 assembly listing; adaflo_amd/build.py runs it over every unit it compiles and refuses to link a library
+with a hit (scripts/dev/isa_flow_audit.py: the same for one unit with extra flags)."""
+import re
+
+COPY = re.compile(r"\s+(v_accvgpr_write_b32|v_accvgpr_read_b32|v_mov_b32_e32|v_mov_b64_e32|scratch_store_dword\w*|scratch_load_dword\w*) ")
+LABEL = re.compile(r"^\.LBB\d+_\d+:")
+FLIP = re.compile(r"\s+s_andn2_saveexec_b64 (s\[\d+:\d+\]), \1")
+IF = re.compile(r"\s+s_and_saveexec_b64 ")
+
+
+def flow_block_copies(listing):
+    """{kernel symbol: [(line of the Flow block's label, [copy instructions])]} of an assembly listing (text)"""
+    found, kernel, label = {}, None, None
+    lines = listing.split("\n")
+    for i, l in enumerate(lines):
+        if l.startswith("_Z") and ":" in l.split(";")[0]:
+            kernel, label = l.split(":")[0], None
+        elif l.startswith(".Lfunc_end"):
+            kernel = None
+        elif kernel is None:
+            continue
+        elif LABEL.match(l):
+            label = i
+        elif IF.match(l):
+            label = None      # an `if` starts in this block: what follows is ordinary THEN code, not a Flow block
+        elif label is not None and FLIP.match(l):
+            copies = [lines[q].split(";")[0].strip() for q in range(label + 1, i) if COPY.match(lines[q])]
+            if copies:
+                found.setdefault(kernel, []).append((label, copies))
+            label = None
+    return found
+
+
+def summarize(found):
+    return {"kernels": len(found), "copies": sum(len(c) for blocks in found.values() for _, c in blocks),
+            "symbols": sorted(found)}
