@@ -74,8 +74,8 @@ def parse():
     ap.add_argument("--comm", default="native", choices=["torch", "native"],
                     help="N > 1: ghost exchange inside the engine (default; adaflo_ns_vmult_distributed of the C ABI: "
                          "RCCL group send/recv on a second stream) or driven through torch.distributed point-to-point "
-                         "operations.  A failing RCCL set-up ends the run with the RCCL error string and a non-zero "
-                         "exit code (no fallback).")
+                         "operations.  If the job with the engine's communicator fails, the supervising parent processes run it once "
+                         "more with --comm torch and the line carries the RCCL error string (native_error).")
     ap.add_argument("--src-consistent", action="store_true",
                     help="N > 1: skip the owner->ghost update of src in the timed vmult (valid inside a Krylov loop, "
                          "where the replicas of an interface DoF are bitwise identical after the rank-ordered "
