@@ -1171,7 +1171,9 @@ int adaflo_ns_velocity_vmult(adaflo_ctx *ctx, double *dst_u, const double *src_u
   // (frozen coefficient copies without a frozen streaming copy: generic kernel; likewise a frozen state that exists in
   // the generic layout only -- after a change of scheme, adaflo_ns_set_params)
   const bool frozen_generic_only = ctx->lin_prec.p && ctx->lin_prec_generic_valid && !ctx->lin_q2_prec.p;
-  if (ctx->variant >= 1 && q2_supported(ctx) && !frozen_generic_only && (!ctx->rho_prec.p || ctx->lin_q2_prec.p))
+  // (explicit scheme: no state -- the sweep kernel reads the frozen coefficients from the generic arrays)
+  const bool explicit_no_state = !needs_lin(ctx) && ctx->ns.physical_type != ADAFLO_STOKES;
+  if (ctx->variant >= 1 && q2_supported(ctx) && !frozen_generic_only && (!ctx->rho_prec.p || ctx->lin_q2_prec.p || explicit_no_state))
     {
       TRY(ctx, launch_ns_vmult_q2(ctx, OP_VMULT_VELOCITY, dst_u, nullptr, src_u, nullptr),
           "Q2 kernel launch failed");

@@ -915,7 +915,10 @@ namespace adaflo_hip
 #ifndef Q2_RCP_COEF_PIPE
 #define Q2_RCP_COEF_PIPE 1
 #endif
-      constexpr bool CPIPE = RCP && VARCO && Q2_RCP_COEF_PIPE;
+      // (round 6: also the operator WITHOUT a linearisation state -- explicit convection of two-phase flow -- reads its
+      // coefficients this way: there is no state stream for them to ride on)
+      constexpr bool CGEN  = VARCO && !RES && !DIV && (RCP || LIN_MODE == 2); // coefficients from the generic arrays
+      constexpr bool CPIPE = CGEN && Q2_RCP_COEF_PIPE;
       const double *const coef_arr = CPIPE ? (d == 1 ? A.mu : (d == 2 ? A.damp : A.rho)) : nullptr;
       // (first entry of my cell of layer 0 in the arrays [cell][27], and the step to the next layer)
       const unsigned coef_first = CPIPE ? (unsigned)((((size_t)(TY * by + (valid ? cyl : 0))) * A.ncx + (TX * bx + (valid ? cxl : 0))) * 27) : 0u;
@@ -946,7 +949,7 @@ namespace adaflo_hip
               for (int n = 0; n < 9; ++n)
                 CP0[n] = CPN[n];
             }
-          const unsigned coef_cell = ((RCP || RES) && VARCO) ?
+          const unsigned coef_cell = (CGEN || (RES && VARCO)) ?
                                        (unsigned)((((size_t)cz * A.ncy + (TY * by + (valid ? cyl : 0))) * A.ncx + (TX * bx + (valid ? cxl : 0))) * 27) :
                                        0u;
           double R[27];
@@ -1181,7 +1184,7 @@ namespace adaflo_hip
               const double  g2 = dline(qz, V[qx + 3 * qy], V[qx + 3 * qy + 9], V[qx + 3 * qy + 18],
                                        A.ah[e2][0], A.ah[e2][1], A.ah[e2][2], A.ah[e2][3]);
 
-              if (RCP && VARCO && !CPIPE)
+              if (CGEN && !CPIPE)
                 {
                   const unsigned cq_ = coef_cell + (unsigned)q;
                   r_rho = A.rho[cq_], r_mu = A.mu[cq_], r_damp = A.damp[cq_];
@@ -1994,7 +1997,10 @@ namespace adaflo_hip
       return false;
     if (!ctx->rho.p && !ctx->mu.p && !ctx->damp.p)
       return true;
-    return q2_varco(ctx) && q2_lin_mode(ctx) != 2;
+    // (no linearisation state to carry the coefficients: round 6 reads them from the generic arrays for the explicit scheme;
+    // Stokes with variable coefficients -- no value terms at all, :708 -- stays on the generic kernel)
+    return q2_varco(ctx) && (q2_lin_mode(ctx) != 2 || (ctx->ns.linearization == ADAFLO_COUPLED_VELOCITY_EXPLICIT &&
+                                                       ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE));
   }
 
   int q2_prepare_state(adaflo_ctx *ctx)
@@ -2077,6 +2083,10 @@ namespace adaflo_hip
     const bool recompute = ctx->q2_recompute && !residual && (op == OP_VMULT || op == OP_VMULT_VELOCITY) && q2_lin_mode(ctx) != 2 &&
                            (frozen ? (ctx->lin_nodal_prec_valid && ctx->lin_nodal_prec.p != nullptr) : lin_nodal_current(ctx));
     const bool rc_varco  = recompute && (frozen ? ctx->rho_prec.p != nullptr : q2_varco(ctx));
+    // explicit scheme (no state): velocity_vmult takes the coefficients fix_linearization_point froze, if any (as the
+    // generic kernel, make_ns_args)
+    const bool ex_frozen = !residual && q2_lin_mode(ctx) == 2 && op == OP_VMULT_VELOCITY && ctx->rho_prec.p != nullptr;
+    const bool ex_varco  = !residual && q2_lin_mode(ctx) == 2 && op != OP_DIVERGENCE && (ex_frozen || q2_varco(ctx));
     if (!residual && op != OP_DIVERGENCE && !recompute)
       {
         if (int e = q2_materialize_state(ctx)) // (a residual deferred the layout of the state this kernel streams)
@@ -2122,6 +2132,12 @@ namespace adaflo_hip
       }
     if (res_varco)
       A.rho = ctx->rho.p, A.mu = ctx->mu.p, A.damp = ctx->damp.p;
+    if (ex_varco)
+      {
+        A.rho  = ex_frozen ? ctx->rho_prec.p : ctx->rho.p;
+        A.mu   = ex_frozen ? ctx->mu_prec.p : ctx->mu.p;
+        A.damp = ex_frozen ? ctx->damp_prec.p : ctx->damp.p;
+      }
     A.c_old     = res_c_old;
     A.ext_u     = res_ext; // (residual of the semi-implicit / explicit scheme: the extrapolated velocity at the nodes)
     A.state_out = residual ? (discard_state ? ctx->q2_state_sink.p : ctx->lin_q2.p) : nullptr;
@@ -2187,7 +2203,7 @@ namespace adaflo_hip
     A.tau1        = P.tau1;
     // the frozen copy of velocity_vmult carries the coefficients it was built with
     const bool use_prec = op == OP_VMULT_VELOCITY && ctx->lin_q2_prec.p;
-    const bool varco    = residual ? false : (use_prec ? ctx->lin_q2_prec_varco : q2_varco(ctx));
+    const bool varco    = residual ? false : (q2_lin_mode(ctx) == 2 ? ex_varco : (use_prec ? ctx->lin_q2_prec_varco : q2_varco(ctx)));
     A.state_stride = 27L * 2 * 4 * (varco ? 64 : 48) + ctx->q2_state_pad;
     if (residual && discard_state)
       A.state_stride = 0; // every (tile, layer) block of the state lands on the one block of the sink

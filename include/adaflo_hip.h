@@ -593,9 +593,10 @@ int adaflo_set_q2_state_pad(adaflo_ctx *ctx, int pad_16B);
  * (ns_hop.hip) for the constant-coefficient Q4/Q3 vmult / velocity_vmult (round 5, slower than 1: kept for comparison);
  * 4 = as 1 but the Q2/Q1 Newton vmult always STREAMS the quadrature-point state (rounds 1-4).  Since round 5 variant 1
  * recomputes (u_lin, grad u_lin) from the nodal solution the last adaflo_ns_residual of this context was computed at --
- * the state is that interpolation, navier_stokes_matrix.cc:778-816; variable density / viscosity / damping are read from
- * the arrays of adaflo_ns_set_coefficients next to it -- and streams only a state that was set through
- * adaflo_ns_set_linearization (no nodal field behind it) or that belongs to a Picard-type scheme.
+ * the state is that interpolation, navier_stokes_matrix.cc:778-816 (round 6: also the (u, div u) state of the Picard-type,
+ * semi-implicit and projection schemes, the nodal field being the extrapolated old velocity where the scheme linearises about
+ * it); variable density / viscosity / damping are read from the arrays of adaflo_ns_set_coefficients next to it -- and streams
+ * only a state that was set through adaflo_ns_set_linearization (no nodal field behind it).
  * All variants are bitwise reproducible. */
 int adaflo_set_kernel_variant(adaflo_ctx *ctx, int variant);
 /* Lazy quadrature-point state of the Q2/Q1 Newton residual (default 1, round 6).  The recompute-state vmult of variant 1

@@ -4,5 +4,5 @@ sys.path.insert(0, os.path.join(ROOT, "scripts")); sys.path.insert(0, ROOT)
 import bench_ops as b
 for lin in (0, 1, 2, 4, 3):
     b.ns_case(2, 128, 1, state_from_residual=True, linearization=lin)
-for lin in (0, 1, 2):
-    b.ns_case(4, 64, 1, state_from_residual=True, linearization=lin)
+for v in (1, 0):                                 # round 6: explicit scheme with variable coefficients on the sweep kernel / generic
+    b.ns_case(2, 128, v, two_phase=True, linearization=3)

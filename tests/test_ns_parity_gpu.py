@@ -375,10 +375,11 @@ def test_full_size_properties_128cubed():
 
 
 # ----------------------------------------------------------------------------- two-phase flow
-@pytest.mark.parametrize("lin,ncell", [(0, (4, 4, 3)), (0, (17, 9, 20)), (1, (9, 16, 5)), (2, (10, 8, 6))])
+@pytest.mark.parametrize("lin,ncell", [(0, (4, 4, 3)), (0, (17, 9, 20)), (1, (9, 16, 5)), (2, (10, 8, 6)), (3, (9, 8, 5)), (3, (17, 9, 20))])
 def test_vmult_variable_coefficients_q2_kernel(lin, ncell):
     """variable rho / mu / damping at the quadrature points ride in the spare lanes of the state
-    pieces of the Q2/Q1 sweep kernel (navier_stokes_matrix.cc:636-642,:827-845)"""
+    pieces of the Q2/Q1 sweep kernel (navier_stokes_matrix.cc:636-642,:827-845); round 6: the explicit scheme (3) has no
+    state for them to ride on -- the kernel reads them from the generic arrays, one array per lane of a quad"""
     case = Case(ncell, k=2, linearization=lin, density_diff=0.5, damping=0.2, tau_grad_div=0.1,
                 upper=(1.0, 0.5, 2.0))
     eu, ep = run_vmult(case, variant=1, coefficients=True)
@@ -404,6 +405,39 @@ def test_velocity_vmult_variable_coefficients_uses_the_frozen_state():
         assert rel_l2(dst.numpy(), ref) < TOL
         # ... while vmult sees the new ones: switching back to constant coefficients works too
         op.set_coefficients(None, None, None)
+
+
+def test_explicit_scheme_with_variable_coefficients_on_the_sweep_kernel():
+    """two-phase flow with explicit convection (rising_bubble_ls_expl.prm of the reference): vmult and velocity_vmult have no
+    linearisation state; velocity_vmult takes the coefficients fix_linearization_point froze while vmult sees the new ones,
+    constant coefficients again after they are cleared; sweep kernel (1) and generic kernel (0) against the oracle"""
+    case = Case((9, 8, 5), k=2, linearization=3, density_diff=0.5, damping=0.2, tau_grad_div=0.1, upper=(1.0, 0.5, 2.0), steps=3)
+    src_u, src_p = case.random_u(), case.random_p()
+    co1, co2 = case.random_coefficients(), case.random_coefficients()
+    w, modes = case.weights_modes()
+    ref_vel1 = orc.ns_velocity_vmult(case.mesh, 2, case.prm, src_u, case.con_u, rho=co1[0], mu=co1[1], damp=co1[2])
+    ref2 = orc.ns_vmult(case.mesh, 2, case.prm, src_u, src_p, case.con_u, case.con_p, rho=co2[0], mu=co2[1], damp=co2[2],
+                        weights=w, modes=modes)
+    ref3 = orc.ns_vmult(case.mesh, 2, case.prm, src_u, src_p, case.con_u, case.con_p, weights=w, modes=modes)
+    for variant in (1, 0):
+        op = case.engine()
+        op.set_kernel_variant(variant)
+        op.set_coefficients(*co1)
+        op.fix_linearization_point()
+        op.set_coefficients(*co2)
+        vsrc, vdst = op.initialize_u_vector(src_u), op.initialize_u_vector(np.full(case.n_u, 3.0))
+        op.velocity_vmult(vdst, vsrc)
+        assert rel_l2(vdst.numpy(), ref_vel1) < TOL, variant
+        dst = op.block_vector()
+        op.vmult(dst, op.block_vector(src_u, src_p))
+        gu, gp = dst.numpy()
+        assert rel_l2(gu, ref2[0]) < TOL and rel_l2(gp, ref2[1]) < TOL, variant
+        op.set_coefficients(None, None, None)
+        op.vmult(dst, op.block_vector(src_u, src_p))
+        gu, gp = dst.numpy()
+        assert rel_l2(gu, ref3[0]) < TOL and rel_l2(gp, ref3[1]) < TOL, variant
+        op.velocity_vmult(vdst, vsrc)                          # (still the frozen two-phase operator)
+        assert rel_l2(vdst.numpy(), ref_vel1) < TOL, variant
 
 
 @pytest.mark.parametrize("k,ncell,lin,phys,coefficients,faces_u",
