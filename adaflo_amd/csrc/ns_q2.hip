@@ -666,7 +666,7 @@ namespace adaflo_hip
                                                               // coefficients: rho, mu, damping by plain loads from the
                                                               // generic arrays, 24 B per cell and point, L2-friendly)
       static_assert(!RCP || (LIN_MODE != 2 && !RES && !DIV), "recompute mode: Newton / Picard-type vmult");
-      static_assert(!EXT || (RES && LIN_MODE != 0 && !VARCO && WITH_P), "extrapolating residual: semi-implicit / explicit, constant coefficients");
+      static_assert(!EXT || (RES && LIN_MODE != 0 && WITH_P), "extrapolating residual: semi-implicit / explicit (round 6: also with variable coefficients)");
       constexpr int L_OLDP = L_RING, L_EXTP = L_TOTAL; // plane buffers of the second / third nodal field
 #if defined(Q2_QG_OFF) // (development: the unguarded form in the one-workgroup-per-CU builds, scripts/dev/lb_diff_ext.sh;
                        // Q2_QG_SITES: bit mask of the call-site groups that keep the guard -- 1 quadrature loop, 2 second / third
@@ -2364,17 +2364,24 @@ namespace adaflo_hip
       }
     else if (residual && res_ext)
       {
-#define Q2_LAUNCH_EXT(LM, IS)                                                                                       \
+#define Q2_LAUNCH_EXT_V(LM, IS, VC)                                                                                 \
   {                                                                                                                 \
     static bool attr_set = false;                                                                                   \
     if (!attr_set)                                                                                                  \
       {                                                                                                             \
-        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_q2_kernel<LM, true, IS, false, true, false, false, true>), \
+        err = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_q2_kernel<LM, true, IS, VC, true, false, false, true>), \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                      \
         attr_set = err == hipSuccess;                                                                               \
       }                                                                                                             \
     if (err == hipSuccess && nwg > 0)                                                                               \
-      hipLaunchKernelGGL((ns_q2_kernel<LM, true, IS, false, true, false, false, true>), grid, block, lds_bytes, ctx->stream, A); \
+      hipLaunchKernelGGL((ns_q2_kernel<LM, true, IS, VC, true, false, false, true>), grid, block, lds_bytes, ctx->stream, A); \
+  }
+#define Q2_LAUNCH_EXT(LM, IS)           \
+  {                                     \
+    if (res_varco)                      \
+      Q2_LAUNCH_EXT_V(LM, IS, true)     \
+    else                                \
+      Q2_LAUNCH_EXT_V(LM, IS, false)    \
   }
         if (iso && lin_mode == 1)
           Q2_LAUNCH_EXT(1, true)
@@ -2385,6 +2392,7 @@ namespace adaflo_hip
         else
           Q2_LAUNCH_EXT(2, false)
 #undef Q2_LAUNCH_EXT
+#undef Q2_LAUNCH_EXT_V
       }
     else if (res_varco)
       {
@@ -2520,9 +2528,11 @@ namespace adaflo_hip
     // recompute-state mode of the vmults (kernel variant 1) -- the state then leaves the kernel in the constant-coefficient
     // layout (or not at all: lazy state) and nobody reads it unless asked (get_linearization, a change of variant: re-laid
     // out then)
+    // (round 6, second half: the schemes that linearise about the extrapolated velocity as well -- time-dependent equations)
     if (ctx->rho.p || ctx->mu.p || ctx->damp.p)
       return q2_varco(ctx) && ctx->q2_recompute && ctx->ns.physical_type != ADAFLO_STOKES &&
-             (ctx->ns.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON || ctx->ns.linearization == ADAFLO_COUPLED_IMPLICIT_PICARD);
+             (ctx->ns.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON || ctx->ns.linearization == ADAFLO_COUPLED_IMPLICIT_PICARD ||
+              ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE);
     const NSDev &P = ctx->ns;
     if (P.physical_type == ADAFLO_STOKES || P.linearization == ADAFLO_COUPLED_IMPLICIT_NEWTON ||
         P.linearization == ADAFLO_COUPLED_IMPLICIT_PICARD)

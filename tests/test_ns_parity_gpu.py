@@ -903,14 +903,18 @@ def test_vmult_recomputes_the_state_from_the_nodal_linearisation_point(ncell, up
 
 @pytest.mark.parametrize("ncell,upper,phys,faces_u,lin", [((9, 8, 5), (1., 1., 1.), 0, range(6), 0), ((17, 9, 6), (1., 1., 3.), 0, [0, 3, 4], 0),
                                                            ((5, 4, 9), (1., 2., 1.), 1, range(6), 0), ((1, 1, 1), (1., 1., 1.), 0, range(6), 0),
-                                                           ((9, 8, 5), (1., 1., 1.), 0, range(6), 1), ((17, 9, 6), (1., 1., 3.), 0, [0, 3, 4], 1)])
+                                                           ((9, 8, 5), (1., 1., 1.), 0, range(6), 1), ((17, 9, 6), (1., 1., 3.), 0, [0, 3, 4], 1),
+                                                           ((9, 8, 5), (1., 1., 1.), 0, range(6), 2), ((17, 9, 6), (1., 1., 3.), 0, [0, 3, 4], 2),
+                                                           ((9, 8, 5), (1., 1., 1.), 0, range(6), 3), ((5, 4, 9), (1., 2., 1.), 0, [0, 3, 4], 4)])
 def test_two_phase_residual_sweep_kernel(ncell, upper, phys, faces_u, lin):
     """the residual of two-phase flow (variable density / viscosity / damping, navier_stokes_matrix.cc:266-293, 636-642,
     711-713, 831-845) on the Q2/Q1 sweep kernel (template RES with VARCO, round 5): right-hand side with the
     read-modify-write semantics of the reference, the state it leaves (canonical array), the Jacobian on that state in
     the recompute-state mode and -- after a change of kernel variant -- streamed with the coefficient pieces, the frozen
     operator; against the oracle, and the generic kernels on the same inputs.  Round 6: the Picard-type scheme as well (lin = 1:
-    its Jacobian recomputes (u_lin, div u_lin) from the nodal field like the Newton one)"""
+    its Jacobian recomputes (u_lin, div u_lin) from the nodal field like the Newton one) and, second half, the schemes that
+    linearise about the extrapolated old velocity (2 semi-implicit, 3 explicit: no state, 4 projection; rising_bubble_ls_imex /
+    _expl of the reference)"""
     case = Case(ncell, k=2, lower=(0., 0., 0.), upper=upper, faces_u=faces_u, physical_type=phys, steps=3,
                 tau_grad_div=0.1, density_diff=0.5, linearization=lin)
     src_u, src_p = case.smooth_u(0.1) + 0.05 * case.random_u(), case.smooth_p(0.1)
@@ -940,8 +944,9 @@ def test_two_phase_residual_sweep_kernel(ncell, upper, phys, faces_u, lin):
         gu, gp = dst.numpy()
         assert rel_l2(gu, ref_vu) < TOL and rel_l2(gp, ref_vp) < TOL, (variant, rel_l2(gu, ref_vu))
         ncomp = 12 if lin == 0 else 4
-        got_lin = op.get_linearization().reshape(-1, 12)
-        assert rel_l2(got_lin[:, :ncomp], lin_ref.reshape(-1, 12)[:, :ncomp]) < TOL, variant
+        if lin != 3:
+            got_lin = op.get_linearization().reshape(-1, 12)
+            assert rel_l2(got_lin[:, :ncomp], lin_ref.reshape(-1, 12)[:, :ncomp]) < TOL, variant
         if variant == 1:
             op.set_kernel_variant(4)                      # streamed: the state is re-laid out with the coefficient pieces
             op.vmult(dst, op.block_vector(vm_u, vm_p))
