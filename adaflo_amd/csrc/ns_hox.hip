@@ -373,17 +373,24 @@ namespace adaflo_hip
                        // hipcc placed under the THEN mask of `if (fl & F_CELL)` -- went with that branch; -DHOX_EXT_KMAX=4 sends the
                        // instance to the generic kernel)
 #endif
-#define HOX_LAUNCH_RES_EXT(LM)                                                                                            \
-  {                                                                                                                       \
-    static bool attr_set = false;                                                                                         \
-    if (!attr_set)                                                                                                        \
-      {                                                                                                                   \
-        err      = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_hox_kernel<K, LM, true, true, false, false, true>), \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                      \
-        attr_set = err == hipSuccess;                                                                                     \
-      }                                                                                                                   \
-    if (err == hipSuccess && nwg > 0)                                                                                     \
-      hipLaunchKernelGGL((ns_hox_kernel<K, LM, true, true, false, false, true>), grid, block, lds_bytes, ctx->stream, A); \
+#define HOX_LAUNCH_RES_EXT_V(LM, VC)                                                                                   \
+  {                                                                                                                    \
+    static bool attr_set = false;                                                                                      \
+    if (!attr_set)                                                                                                     \
+      {                                                                                                                \
+        err      = hipFuncSetAttribute(reinterpret_cast<const void *>(&ns_hox_kernel<K, LM, true, true, VC, false, true>), \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                   \
+        attr_set = err == hipSuccess;                                                                                  \
+      }                                                                                                                \
+    if (err == hipSuccess && nwg > 0)                                                                                  \
+      hipLaunchKernelGGL((ns_hox_kernel<K, LM, true, true, VC, false, true>), grid, block, lds_bytes, ctx->stream, A); \
+  }
+#define HOX_LAUNCH_RES_EXT(LM)           \
+  {                                      \
+    if (varco)                           \
+      HOX_LAUNCH_RES_EXT_V(LM, true)     \
+    else                                 \
+      HOX_LAUNCH_RES_EXT_V(LM, false)    \
   }
       if (residual && ext_comb)
         {
@@ -439,6 +446,7 @@ namespace adaflo_hip
 #undef HOX_LAUNCH_RES
 #undef HOX_LAUNCH_RES_V
 #undef HOX_LAUNCH_RES_EXT
+#undef HOX_LAUNCH_RES_EXT_V
       if (err != hipSuccess)
         return ADAFLO_EHIP;
       if (stop)
@@ -511,10 +519,12 @@ namespace adaflo_hip
     const int lin = ctx->ns.linearization;
     if (!hox_supported(ctx))
       return false;
-    // variable coefficients (two-phase flow, round 6): Newton / Picard-type, all three arrays
+    // variable coefficients (two-phase flow, round 6): all three arrays; Newton / Picard-type, and the schemes that linearise
+    // about the extrapolated old velocity where their residual mode is built (time-dependent equations)
     if (ctx->rho.p || ctx->mu.p || ctx->damp.p)
       return ctx->rho.p && ctx->mu.p && ctx->damp.p && ctx->ns.physical_type != ADAFLO_STOKES &&
-             (lin == ADAFLO_COUPLED_IMPLICIT_NEWTON || lin == ADAFLO_COUPLED_IMPLICIT_PICARD);
+             (lin == ADAFLO_COUPLED_IMPLICIT_NEWTON || lin == ADAFLO_COUPLED_IMPLICIT_PICARD ||
+              (HOX_FUSED && HOX_RES_FUSED && ctx->k <= HOX_EXT_KMAX && ctx->ns.physical_type == ADAFLO_INCOMPRESSIBLE));
     if (ctx->ns.physical_type == ADAFLO_STOKES || lin == ADAFLO_COUPLED_IMPLICIT_NEWTON || lin == ADAFLO_COUPLED_IMPLICIT_PICARD)
       return true;
     // (k = 5 needs one workgroup per CU: 3.13 ms at 48^3 against 4.96 ms at two and 4.01 ms for the generic kernel)

@@ -508,7 +508,7 @@ namespace adaflo_hip
       constexpr bool FUSED = HOX_FUSED && (!RES || HOX_RES_FUSED);     // value + gradient through two exchanges, z-line loop
       constexpr int NSTL = (RES || RCP) ? 0 : nst_of(LIN_MODE);       // linearisation values READ per point
       constexpr int NST = NSTL + (VARCO ? 4 : 0), NPC = NST / 2;       // ... with the coefficients (rho, mu | damping, -)
-      static_assert(!(RES && VARCO) || (!EXT && LIN_MODE != 2), "variable-coefficient residual: Newton / Picard-type");
+      static_assert(!(RES && VARCO) || EXT || LIN_MODE != 2, "variable-coefficient residual: not for Stokes");
       constexpr int NSO = RES ? nst_of(LIN_MODE) : 0, NPO = NSO / 2;  // ... WRITTEN per point (residual mode)
       // RES + VARCO (round 6; two-phase flow with k >= 3, :636-642, :717-732, :827-845): the coefficients arrive as a stream
       // of their own, two pieces per point ((rho, mu), (damping, -): the layout of a Stokes-type state with coefficients),

@@ -19,9 +19,8 @@ for k, cells, upper, lin in ((2, (24, 17, 12), (1., 1., 1.), "coupled implicit N
                              (3, (9, 9, 9), (1., 1., 1.), "coupled velocity explicit"), (2, (8, 8, 4), (1., 1., 1.), "coupled velocity explicit"),
                              (2, (17, 9, 6), (1., 1.5, 1.), "coupled velocity explicit"), (5, (3, 2, 3), (1., 1.5, 1.), "coupled velocity semi-implicit"),
                              (5, (4, 4, 4), (1., 1., 1.), "coupled velocity explicit"), (4, (5, 3, 4), (1., 1., 1.), "coupled velocity explicit")):
-    # (two-phase variants: Q2/Q1 every scheme since round 6 -- the extrapolating residuals with variable coefficients are new
-    # 512-register builds --; k = 4, 5 Newton / Picard-type: the variable-coefficient residual of the x-marching kernel)
-    for two_phase in ((False, True) if (k == 2 or (k in (4, 5) and "implicit" in lin)) else (False,)):
+    # (two-phase variants since round 6 -- the variable-coefficient residuals of every scheme are new 512-register builds)
+    for two_phase in ((False, True) if k in (2, 4, 5) else (False,)):
         fp = adaflo_amd.FlowParameters(velocity_degree=k, linearization=lin, density_diff=0.5 if two_phase else 0.0)
         ts = adaflo_amd.TimeStepping(fp)
         for _ in range(3):

@@ -963,7 +963,9 @@ def test_two_phase_residual_sweep_kernel(ncell, upper, phys, faces_u, lin):
 
 
 @pytest.mark.parametrize("k,ncell,lin,phys,chunk", [(4, (5, 4, 9), 0, 0, 0), (3, (6, 5, 5), 0, 0, 2), (5, (3, 2, 3), 0, 0, 0),
-                                                    (4, (9, 3, 2), 1, 0, 4), (3, (4, 4, 3), 1, 0, 0), (4, (4, 4, 4), 0, 1, 0)])
+                                                    (4, (9, 3, 2), 1, 0, 4), (3, (4, 4, 3), 1, 0, 0), (4, (4, 4, 4), 0, 1, 0),
+                                                    (4, (5, 4, 9), 2, 0, 0), (3, (6, 5, 5), 2, 0, 2), (5, (3, 2, 3), 2, 0, 0),
+                                                    (4, (4, 4, 5), 3, 0, 1), (5, (3, 2, 3), 3, 0, 0), (4, (3, 5, 2), 4, 0, 0)])
 def test_two_phase_residual_x_marching_kernel(k, ncell, lin, phys, chunk):
     """the residual of two-phase flow (variable density / viscosity / damping, navier_stokes_matrix.cc:266-293, 636-642,
     711-713, 717-732, 827-845) on the Q3..Q5 x-marching kernel (template RES with VARCO, round 6): the coefficients arrive as
@@ -996,6 +998,8 @@ def test_two_phase_residual_x_marching_kernel(k, ncell, lin, phys, chunk):
     ref3_u, ref3_p = orc.ns_vmult(case.mesh, k, case.prm, vm_u, vm_p, case.con_u, case.con_p, lin=lin3, rho=co2[0], mu=co2[1],
                                   damp=co2[2], weights=w, modes=modes)
     ncomp = 12 if lin == 0 else 4
+    # (second half of round 6: the schemes that linearise about the extrapolated old velocity -- 2 semi-implicit, 3 explicit:
+    # no state, 4 projection -- with variable coefficients: templates RES + EXT + VARCO)
     for variant in (1, 0):
         op = case.engine()
         op.set_kernel_variant(variant)
@@ -1010,8 +1014,9 @@ def test_two_phase_residual_x_marching_kernel(k, ncell, lin, phys, chunk):
         op.vmult(dst, op.block_vector(vm_u, vm_p))              # streams what the residual wrote, coefficient pieces included
         gu, gp = dst.numpy()
         assert rel_l2(gu, ref_vu) < TOL and rel_l2(gp, ref_vp) < TOL, (variant, rel_l2(gu, ref_vu))
-        got_lin = op.get_linearization().reshape(-1, 12)
-        assert rel_l2(got_lin[:, :ncomp], lin_ref.reshape(-1, 12)[:, :ncomp]) < TOL, variant
+        if lin != 3:
+            got_lin = op.get_linearization().reshape(-1, 12)
+            assert rel_l2(got_lin[:, :ncomp], lin_ref.reshape(-1, 12)[:, :ncomp]) < TOL, variant
         op.vmult(dst, op.block_vector(vm_u, vm_p))              # (the streaming copy is still the current one)
         gu, gp = dst.numpy()
         assert rel_l2(gu, ref_vu) < TOL and rel_l2(gp, ref_vp) < TOL, variant
