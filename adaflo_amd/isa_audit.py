@@ -10,7 +10,9 @@ import re
 
 COPY = re.compile(r"\s+(v_accvgpr_write_b32|v_accvgpr_read_b32|v_mov_b32_e32|v_mov_b64_e32|scratch_store_dword\w*|scratch_load_dword\w*) ")
 LABEL = re.compile(r"^\.LBB\d+_\d+:")
-FLIP = re.compile(r"\s+s_andn2_saveexec_b64 (s\[\d+:\d+\]), \1")
+# the two forms of the flip to the ELSE side hipcc emits: s_andn2_saveexec sX, sX  |  s_or_saveexec sX, sX ... s_xor exec, exec, sX
+# (what stands between the block's label and the first of these runs under the THEN mask)
+FLIP = re.compile(r"\s+s_(andn2|or)_saveexec_b64 (s\[\d+:\d+\]), \2")
 IF = re.compile(r"\s+s_and_saveexec_b64 ")
 
 

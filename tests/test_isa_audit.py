@@ -42,7 +42,12 @@ _ZN6kernelE:
 """
 
 
+# the other form of the flip hipcc emits: s_or_saveexec sX, sX ... s_xor_b64 exec, exec, sX
+BAD2 = BAD.replace("\ts_andn2_saveexec_b64 s[4:5], s[4:5]\n", "\ts_or_saveexec_b64 s[4:5], s[4:5]\n\ts_xor_b64 exec, exec, s[4:5]\n")
+
+
 def test_detector_on_synthetic_listings():
+    assert isa_audit.summarize(isa_audit.flow_block_copies(BAD2))["copies"] == 2
     hit = isa_audit.flow_block_copies(BAD)
     assert list(hit) == ["_ZN6kernelE"] and len(hit["_ZN6kernelE"]) == 1
     assert hit["_ZN6kernelE"][0][1] == ["v_accvgpr_write_b32 a12, v237", "v_accvgpr_write_b32 a3, v236"]
