@@ -177,13 +177,12 @@ struct adaflo_ctx
   // lin_serial counts every change of the linearisation state (set_linearization, any residual, a change of scheme); the
   // nodal copy is current while lin_nodal_serial equals it -- whatever layouts the state has been converted to since
   bool                     q2_recompute = true, lin_nodal_prec_valid = false;
-  // lazy state (round 6): a Newton residual whose consumer is the recompute-state vmult does not WRITE the quadrature-point
+  // lazy state (round 6): a residual whose consumer is the recompute-state vmult does not WRITE the quadrature-point
   // state (5.4 GB at 128^3): lin_q2_deferred = "the state is the interpolation of lin_nodal (current by invariant) and has
   // not been laid out"; q2_materialize_state runs the residual kernel once more for the state alone when somebody needs it
-  // (get_linearization, generic / streaming kernels, fix_linearization_point, a change of scheme).  q2_state_sink: where the
-  // kernel's state stores go meanwhile (one (tile, layer) block, every workgroup the same: they stay in L2)
+  // (get_linearization, generic / streaming kernels, fix_linearization_point, a change of scheme).  Meanwhile the kernel
+  // issues its state stores with an empty EXEC mask (Q2Args::state_out == nullptr)
   bool                     q2_lazy_state = true, lin_q2_deferred = false;
-  adaflo_hip::DeviceBuffer q2_state_sink;
   unsigned long            lin_serial = 1, lin_nodal_serial = 0;
   adaflo_hip::DeviceBuffer lin_nodal, lin_nodal_prec; // (..._prec: frozen by fix_linearization_point, velocity_vmult)
   int                      q2_state_pad = 0; // skew padding (double2) per (tile, layer) state block

@@ -891,7 +891,15 @@ namespace adaflo_hip
       lds_barrier();
       // residual mode: the state of a point leaves as two 16-byte stores per velocity lane
       const unsigned           sout_voff = 16u * (unsigned)(wave * 48 + cq * 3 + (is_p ? 0 : d));
-      const unsigned long long sout_mask = 0x7777777777777777ull; // lanes d < 3
+      // (lanes d < 3; lazy state, round 6: no buffer -- the stores are issued with an EMPTY mask and move nothing.  A sink
+      // buffer "that stays in L2" was the first form: its non-temporal stores still wrote 3.7 of the 5.4 GB through to
+      // memory, profiles/r06_pmc_res_lazy.txt)
+      // (the wait behind the quadrature loop then may not count on them: Q2_RES_WAIT_ALL -- a run-time choice between two
+      // counted waits there split the layer body into blocks and the 512-register builds went to 3-5 KB of scratch, 28 ms)
+#ifndef Q2_RES_WAIT_ALL
+#define Q2_RES_WAIT_ALL 1
+#endif
+      const unsigned long long sout_mask = A.state_out ? 0x7777777777777777ull : 0ull;
       auto interp_all = [&](double *X) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -1363,8 +1371,8 @@ namespace adaflo_hip
               if (NX_ > 0)
                 lds_barrier();
             }
-          else if (RES && LIN_MODE != 2)
-            wait_vmcnt<54>();
+          else if (RES && LIN_MODE != 2 && !Q2_RES_WAIT_ALL)
+            wait_vmcnt<54>(); // (rounds 4-5: the plane copies are older than the 54 state stores of this layer)
           else
             wait_vmcnt<0>();
 
@@ -2140,7 +2148,7 @@ namespace adaflo_hip
       }
     A.c_old     = res_c_old;
     A.ext_u     = res_ext; // (residual of the semi-implicit / explicit scheme: the extrapolated velocity at the nodes)
-    A.state_out = residual ? (discard_state ? ctx->q2_state_sink.p : ctx->lin_q2.p) : nullptr;
+    A.state_out = residual ? (discard_state ? nullptr : ctx->lin_q2.p) : nullptr; // (null: the kernel masks its state stores off)
     A.c_div     = res_c_old; // (divergence mode passes its weight here)
     A.ncx = ctx->desc.ncell[0];
     A.ncy = ctx->desc.ncell[1];
@@ -2205,8 +2213,6 @@ namespace adaflo_hip
     const bool use_prec = op == OP_VMULT_VELOCITY && ctx->lin_q2_prec.p;
     const bool varco    = residual ? false : (q2_lin_mode(ctx) == 2 ? ex_varco : (use_prec ? ctx->lin_q2_prec_varco : q2_varco(ctx)));
     A.state_stride = 27L * 2 * 4 * (varco ? 64 : 48) + ctx->q2_state_pad;
-    if (residual && discard_state)
-      A.state_stride = 0; // every (tile, layer) block of the state lands on the one block of the sink
     A.con_u       = ctx->brick.con_u;
     A.con_p       = ctx->brick.con_p;
     A.src_u       = src_u;
@@ -2648,12 +2654,7 @@ namespace adaflo_hip
     // Newton + recompute-state vmult (kernel variant 1): nobody reads the laid-out state unless asked (q2_materialize_state)
     const bool defer = lin_mode != 2 && ctx->q2_recompute && ctx->q2_lazy_state;
     ctx->lin_q2_deferred = false; // (the caller has bumped lin_serial: whatever was deferred belongs to the state before)
-    if (defer)
-      {
-        if (int e = q2_ensure_buffer(ctx->q2_state_sink, (size_t)(27L * 2 * 4 * 48 + 64) * 2))
-          return e;
-      }
-    else if (lin_mode != 2)
+    if (!defer && lin_mode != 2)
       {
         if (int e = q2_alloc_state(ctx))
           return e;

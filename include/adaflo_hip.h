@@ -601,7 +601,7 @@ int adaflo_set_q2_state_pad(adaflo_ctx *ctx, int pad_16B);
 int adaflo_set_kernel_variant(adaflo_ctx *ctx, int variant);
 /* Lazy quadrature-point state of the Q2/Q1 Newton residual (default 1, round 6).  The recompute-state vmult of variant 1
  * never reads the state adaflo_ns_residual lays out at the quadrature points (96 B per point: 5.4 GB at 128^3, 43.5 GB at
- * 256^3), so the residual does not write it; the engine lays it out on demand -- adaflo_ns_get_linearization, the generic
+ * 256^3), so the residual does not write it (its state stores are issued with an empty mask); the engine lays it out on demand -- adaflo_ns_get_linearization, the generic
  * and the streaming kernels, adaflo_ns_fix_linearization_point, a change of scheme -- by one more pass of the residual kernel
  * over the nodal field it kept.  Results are bitwise the same either way (NavierStokesMatrix::residual fills
  * linearized_velocities in the cell loop, navier_stokes_matrix.cc:778-799: here that is deferred, not dropped).  0 = write
