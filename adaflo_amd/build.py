@@ -30,10 +30,12 @@ def _stale(target, deps):
 AUDIT = os.path.join(LIBDIR, ".isa_audit.json")
 
 
-def _audit_listing(path):
+def _audit_listing(path, remarks=""):
     from . import isa_audit
     with open(path, errors="replace") as f:
-        return isa_audit.summarize(isa_audit.flow_block_copies(f.read()))
+        rec = isa_audit.summarize(isa_audit.flow_block_copies(f.read()))
+    rec.update(isa_audit.scratch_use(remarks))
+    return rec
 
 
 def build(force=False, verbose=False):
@@ -65,8 +67,10 @@ def build(force=False, verbose=False):
             # the device listing of the same unit, for the audit below (a compile of its own: the product object is built
             # exactly as before)
             listing = o[:-2] + ".gfx950.s"
-            audits.append((s, listing, subprocess.Popen(["hipcc", "-S", "--cuda-device-only", s, "-o", listing] + FLAGS,
-                                                        stderr=subprocess.DEVNULL)))
+            # (-Rpass-analysis=kernel-resource-usage: scratch bytes per lane of every kernel, recorded beside the audit)
+            audits.append((s, listing, subprocess.Popen(["hipcc", "-S", "--cuda-device-only", s, "-o", listing,
+                                                         "-Rpass-analysis=kernel-resource-usage"] + FLAGS,
+                                                        stdout=subprocess.DEVNULL, stderr=open(listing + ".remarks", "w"))))
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed for " + s)
@@ -75,8 +79,11 @@ def build(force=False, verbose=False):
         unit = os.path.basename(s)[:-4]
         if p.wait() != 0 or not os.path.exists(listing):
             raise RuntimeError("hipcc -S failed for " + s)
-        report[unit] = _audit_listing(listing)
+        with open(listing + ".remarks", errors="replace") as f:
+            remarks = f.read()
+        report[unit] = _audit_listing(listing, remarks)
         os.remove(listing)
+        os.remove(listing + ".remarks")
     if audits:
         with open(AUDIT, "w") as f:
             json.dump(report, f, indent=1, sort_keys=True)

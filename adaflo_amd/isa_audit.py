@@ -42,3 +42,23 @@ def flow_block_copies(listing):
 def summarize(found):
     return {"kernels": len(found), "copies": sum(len(c) for blocks in found.values() for _, c in blocks),
             "symbols": sorted(found)}
+
+
+def scratch_use(remarks):
+    """{"max_scratch": bytes per lane, "max_scratch_kernel": symbol, "kernels_with_scratch": n} from the text hipcc prints with
+    -Rpass-analysis=kernel-resource-usage.  A parity-green change can send a 512-register kernel to kilobytes of scratch (round
+    6: a run-time choice between two counted waits in the Q2/Q1 residual -- 3-5 KB, 12x slower, every test green): the build
+    records the figure and tests/test_isa_audit.py bounds it."""
+    worst, name, n, cur = 0, None, 0, None
+    for line in remarks.split("\n"):
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            continue
+        m = re.search(r"remark:\s+ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and cur:
+            v = int(m.group(1))
+            n += v > 0
+            if v > worst:
+                worst, name = v, cur
+    return {"max_scratch": worst, "max_scratch_kernel": name, "kernels_with_scratch": n}
