@@ -85,6 +85,12 @@ def test_timed_path_config2_128cubed_residual_then_recomputed_vmult_against_open
     assert kcount > 0
 
 
+def test_timed_path_128cubed_picard_type_state_recomputed_against_openmp_oracle():
+    """the same path with the Picard-type linearisation (round 6: its state (u, div u) is recomputed from the nodal field as
+    well -- ns_q2_kernel<1, ..., RCP> -- and the residual defers the layout of the state)"""
+    _timed_path_against_openmp_oracle(Case((128, 128, 128), k=2, steps=3, linearization=1), 2)
+
+
 def test_timed_path_config5_q4_cavity_64cubed_residual_then_vmult_against_openmp_oracle():
     """BASELINE configs[4] as `bench.py --config cavity` runs it: the state the x-marching RESIDUAL kernel stored in the
     streaming layout is what the x-marching vmult kernel streams"""
